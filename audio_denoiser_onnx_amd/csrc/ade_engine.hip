@@ -1,0 +1,934 @@
+// ade_engine.hip — host side of libade: the C ABI of include/ade.h, manifest/weight loading, HBM workspace,
+// launch sequence (optionally replayed from a captured hipGraph) and parity/timing taps.
+//
+// One engine = one HIP device, one stream, one resident copy of the weights (191 KB) and a workspace sized for
+// `capacity` independent chunks (~2.6 MB of fp32 activations per 1 s chunk; 288 GB of HBM3E holds >100k chunks).
+// There is no CPU execution mode: without a HIP device ade_create fails with ADE_ERR_DEVICE.
+#include "ade_internal.h"
+
+#include "../../include/ade.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ade;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+    std::vector<int> dims;
+    const float* data = nullptr;
+    size_t count = 0;
+};
+
+struct KernelStat {
+    std::string name;
+    float ms = 0.f;
+    int launches = 0;
+};
+
+struct GraphEntry {
+    const void* in;
+    void* out_pcm;
+    void* out_f32;
+    int batch;
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+};
+
+}  // namespace
+
+struct ade_engine {
+    int device = 0;
+    int in_len = 0, T = 0, out_len = 0;
+    int sample_rate = 16000;
+    std::string last_error;
+    std::map<std::string, std::string> meta;
+    std::vector<float> blob_storage;
+    std::map<std::string, Tensor> tensors;
+
+    hipStream_t stream = nullptr;
+    float* d_weights = nullptr;
+    int* d_ints = nullptr;
+    FftTabs tabs{};
+    BandTab erb_bm{}, erb_bs{};
+    ConvW en0{}, en1{}, de3{}, de4{};
+    GtConvW en_gt[3]{}, de_gt[3]{};
+    DpW dp[2]{};
+
+    // workspace
+    int capacity = 0;
+    int last_batch = 0;
+    int16_t* d_pcm_in = nullptr;
+    int16_t* d_pcm_out = nullptr;
+    float* d_f32_out = nullptr;
+    float* ws = nullptr;   // one slab, carved below
+    float *mean = nullptr, *spec = nullptr, *feat = nullptr, *e0 = nullptr, *e1 = nullptr, *h = nullptr, *zt = nullptr;
+    float *xe[3] = {}, *ate[3] = {}, *xd[3] = {}, *atd[3] = {};
+    float *rnn = nullptr, *dpm[2] = {}, *dpo[2] = {};
+    float *d3 = nullptr, *mask = nullptr, *frames = nullptr;
+    int16_t* h_pcm_in = nullptr;    // pinned staging for ade_process
+    int16_t* h_pcm_out = nullptr;
+    float* h_f32_out = nullptr;
+
+    bool use_graph = true;
+    bool graph_supported = true;
+    std::vector<GraphEntry> graphs;
+
+    bool profile = false;
+    std::vector<KernelStat> stats;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<int> event_stat;
+};
+
+namespace {
+
+ade_status fail(ade_engine* e, ade_status st, const std::string& msg) {
+    if (e) e->last_error = msg;
+    else g_create_error = msg;
+    return st;
+}
+
+#define HIP_TRY(e, expr)                                                                                        \
+    do {                                                                                                        \
+        hipError_t _err = (expr);                                                                               \
+        if (_err != hipSuccess)                                                                                 \
+            return fail((e), ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_err));              \
+    } while (0)
+
+// ---- flat JSON object of string / number / bool values -> string map ------------------------------------
+bool parse_manifest(const char* s, std::map<std::string, std::string>& out, std::string& err) {
+    size_t i = 0, n = strlen(s);
+    auto ws = [&]() { while (i < n && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i; };
+    auto str = [&](std::string& v) -> bool {
+        if (s[i] != '"') return false;
+        ++i;
+        v.clear();
+        while (i < n && s[i] != '"') {
+            if (s[i] == '\\' && i + 1 < n) {
+                ++i;
+                switch (s[i]) {
+                    case 'n': v += '\n'; break;
+                    case 't': v += '\t'; break;
+                    case 'u': v += '?'; i += 4; break;
+                    default: v += s[i];
+                }
+                ++i;
+            } else v += s[i++];
+        }
+        if (i >= n) return false;
+        ++i;
+        return true;
+    };
+    ws();
+    if (i >= n || s[i] != '{') { err = "manifest is not a JSON object"; return false; }
+    ++i;
+    ws();
+    if (i < n && s[i] == '}') return true;
+    while (i < n) {
+        ws();
+        std::string key, val;
+        if (!str(key)) { err = "manifest: expected a string key"; return false; }
+        ws();
+        if (i >= n || s[i] != ':') { err = "manifest: expected ':' after key " + key; return false; }
+        ++i;
+        ws();
+        if (i < n && s[i] == '"') {
+            if (!str(val)) { err = "manifest: bad string value for " + key; return false; }
+        } else {
+            size_t j = i;
+            while (j < n && s[j] != ',' && s[j] != '}' && s[j] != ' ' && s[j] != '\n') ++j;
+            val.assign(s + i, j - i);
+            i = j;
+            if (val == "true") val = "1";
+            else if (val == "false") val = "0";
+            else if (val == "null") val.clear();
+        }
+        out[key] = val;
+        ws();
+        if (i < n && s[i] == ',') { ++i; continue; }
+        if (i < n && s[i] == '}') return true;
+        err = "manifest: expected ',' or '}' after " + key;
+        return false;
+    }
+    err = "manifest: unterminated object";
+    return false;
+}
+
+// the reference's REQUIRED_AUDIO_METADATA_KEYS (audio_onnx_metadata.py:8-26)
+const char* kRequiredKeys[] = {"audio_metadata_version", "producer", "model_name", "task", "model_family", "dynamic_axes", "opset",
+                               "input_audio_dtype", "output_audio_dtype", "in_sample_rate", "out_sample_rate", "model_sample_rate",
+                               "input_audio_length", "input_to_output_scale", "max_dynamic_audio_seconds",
+                               "normalize_audio_default", "normalize_target_rms"};
+
+// _parse_bool (audio_onnx_metadata.py:281-287)
+bool parse_bool(const std::string& v, bool* out) {
+    std::string s;
+    for (char c : v) s += (char)tolower(c);
+    if (s == "1" || s == "true" || s == "yes" || s == "on") { *out = true; return true; }
+    if (s == "0" || s == "false" || s == "no" || s == "off") { *out = false; return true; }
+    return false;
+}
+
+bool parse_int(const std::string& v, long* out) {
+    char* end = nullptr;
+    long x = strtol(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end) return false;
+    *out = x;
+    return true;
+}
+
+ade_status parse_blob(ade_engine* e, const void* blob, size_t nbytes) {
+    const unsigned char* p = (const unsigned char*)blob;
+    if (!blob || nbytes < 12 || memcmp(p, "ADEWGT01", 8) != 0) return fail(e, ADE_ERR_BAD_VALUE, "weights: not an ADEWGT01 blob");
+    uint32_t n;
+    memcpy(&n, p + 8, 4);
+    size_t pos = 12;
+    struct Ent { std::string name; std::vector<int> dims; uint64_t off, nb; size_t count; };
+    std::vector<Ent> ents;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint16_t ln;
+        if (pos + 2 > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: truncated header");
+        memcpy(&ln, p + pos, 2);
+        pos += 2;
+        if (pos + ln + 2 > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: truncated header");
+        Ent en;
+        en.name.assign((const char*)p + pos, ln);
+        pos += ln;
+        const int dtype = p[pos], ndim = p[pos + 1];
+        pos += 2;
+        if (dtype != 0 || ndim > 8 || pos + 4u * ndim + 16 > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: bad tensor header " + en.name);
+        en.count = 1;
+        for (int d = 0; d < ndim; ++d) {
+            uint32_t v;
+            memcpy(&v, p + pos, 4);
+            pos += 4;
+            en.dims.push_back((int)v);
+            en.count *= v;
+        }
+        memcpy(&en.off, p + pos, 8);
+        memcpy(&en.nb, p + pos + 8, 8);
+        pos += 16;
+        if (en.nb != en.count * 4) return fail(e, ADE_ERR_BAD_VALUE, "weights: bad extent " + en.name);
+        ents.push_back(en);
+    }
+    const size_t data0 = (pos + 63) & ~(size_t)63;
+    size_t total = 0;
+    for (auto& en : ents) total += en.count;
+    e->blob_storage.resize(total + 1);
+    size_t w = 0;
+    for (auto& en : ents) {
+        if (data0 + en.off + en.nb > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: data out of range " + en.name);
+        memcpy(e->blob_storage.data() + w, p + data0 + en.off, en.nb);
+        Tensor t;
+        t.dims = en.dims;
+        t.data = e->blob_storage.data() + w;
+        t.count = en.count;
+        e->tensors[en.name] = t;
+        w += en.count;
+    }
+    return ADE_OK;
+}
+
+// ---- weight arena builder: canonical kernel layouts, every tensor 64-byte aligned ------------------------
+struct Arena {
+    std::vector<float> f;
+    size_t alloc(size_t n) {
+        size_t off = (f.size() + 15) & ~(size_t)15;
+        f.resize(off + n, 0.0f);
+        return off;
+    }
+};
+
+struct Loader {
+    ade_engine* e;
+    ade_status st = ADE_OK;
+    const float* get(const std::string& name, std::initializer_list<int> dims) {
+        auto it = e->tensors.find(name);
+        if (it == e->tensors.end()) {
+            if (st == ADE_OK) st = fail(e, ADE_ERR_MISSING_KEY, "weights: tensor missing: " + name);
+            return nullptr;
+        }
+        std::vector<int> want(dims);
+        if (it->second.dims != want) {
+            if (st == ADE_OK) st = fail(e, ADE_ERR_SHAPE_MISMATCH, "weights: tensor has the wrong shape: " + name);
+            return nullptr;
+        }
+        return it->second.data;
+    }
+};
+
+// PyTorch GRU rows of hidden unit j -> [3x8 ih | 3xH hh | 3 b_ih | 3 b_hh]
+void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* bih, const float* bhh, int H, int j) {
+    for (int g = 0; g < 3; ++g)
+        for (int k = 0; k < 8; ++k) dst[g * 8 + k] = wih[(g * H + j) * 8 + k];
+    for (int g = 0; g < 3; ++g)
+        for (int k = 0; k < H; ++k) dst[24 + g * H + k] = whh[(g * H + j) * H + k];
+    for (int g = 0; g < 3; ++g) {
+        dst[24 + 3 * H + g] = bih[g * H + j];
+        dst[24 + 3 * H + 3 + g] = bhh[g * H + j];
+    }
+}
+
+struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc; float s1, s2; };
+struct DpOff { size_t intra_gru, inter_gru, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
+
+bool load_gt(Loader& L, Arena& A, const std::string& p, bool deconv, GtOff& o) {
+    const float* pw1 = deconv ? L.get(p + "point_conv1.weight", {24, 16, 1, 1}) : L.get(p + "point_conv1.weight", {16, 24, 1, 1});
+    const float* pw1b = L.get(p + "point_conv1.bias", {16});
+    const float* a1 = L.get(p + "point_act.weight", {1});
+    const float* dw = L.get(p + "depth_conv.weight", {16, 1, 3, 3});
+    const float* dwb = L.get(p + "depth_conv.bias", {16});
+    const float* a2 = L.get(p + "depth_act.weight", {1});
+    const float* pw2 = deconv ? L.get(p + "point_conv2.weight", {16, 8, 1, 1}) : L.get(p + "point_conv2.weight", {8, 16, 1, 1});
+    const float* pw2b = L.get(p + "point_conv2.bias", {8});
+    const float* wih = L.get(p + "tra.att_gru.weight_ih_l0", {48, 8});
+    const float* whh = L.get(p + "tra.att_gru.weight_hh_l0", {48, 16});
+    const float* bih = L.get(p + "tra.att_gru.bias_ih_l0", {48});
+    const float* bhh = L.get(p + "tra.att_gru.bias_hh_l0", {48});
+    const float* fcw = L.get(p + "tra.att_fc.weight", {8, 16});
+    const float* fcb = L.get(p + "tra.att_fc.bias", {8});
+    if (L.st != ADE_OK) return false;
+    o.pw1 = A.alloc(24 * 16);
+    for (int ci = 0; ci < 24; ++ci)
+        for (int co = 0; co < 16; ++co) A.f[o.pw1 + ci * 16 + co] = deconv ? pw1[ci * 16 + co] : pw1[co * 24 + ci];
+    o.pw1_b = A.alloc(16);
+    memcpy(&A.f[o.pw1_b], pw1b, 64);
+    o.dw = A.alloc(9 * 16);
+    for (int c = 0; c < 16; ++c)
+        for (int kt = 0; kt < 3; ++kt)
+            for (int kf = 0; kf < 3; ++kf) {
+                // decoder ConvTranspose2d taps y[t,f] += W[kt][kf] h[t-kt*d, f+1-kf] == encoder-form taps flipped in kt and kf
+                const int ekt = deconv ? 2 - kt : kt, ekf = deconv ? 2 - kf : kf;
+                A.f[o.dw + (ekt * 3 + ekf) * 16 + c] = dw[c * 9 + kt * 3 + kf];
+            }
+    o.dw_b = A.alloc(16);
+    memcpy(&A.f[o.dw_b], dwb, 64);
+    o.pw2 = A.alloc(16 * 8);
+    for (int ci = 0; ci < 16; ++ci)
+        for (int co = 0; co < 8; ++co) A.f[o.pw2 + ci * 8 + co] = deconv ? pw2[ci * 8 + co] : pw2[co * 16 + ci];
+    o.pw2_b = A.alloc(8);
+    memcpy(&A.f[o.pw2_b], pw2b, 32);
+    o.gru = A.alloc(16 * 78);
+    for (int j = 0; j < 16; ++j) pack_gru_lane(&A.f[o.gru + j * 78], wih, whh, bih, bhh, 16, j);
+    o.fc = A.alloc(8 * 17);
+    for (int c = 0; c < 8; ++c) {
+        for (int k = 0; k < 16; ++k) A.f[o.fc + c * 17 + k] = fcw[c * 16 + k];
+        A.f[o.fc + c * 17 + 16] = fcb[c];
+    }
+    o.s1 = a1[0];
+    o.s2 = a2[0];
+    return true;
+}
+
+bool load_dp(Loader& L, Arena& A, const std::string& p, DpOff& o) {
+    o.intra_gru = A.alloc(16 * 42);
+    o.inter_gru = A.alloc(16 * 54);
+    for (int grp = 0; grp < 2; ++grp) {
+        const std::string r = p + "intra_rnn.rnn" + std::to_string(grp + 1) + ".";
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float* wih = L.get(r + "weight_ih_l0" + sfx, {12, 8});
+            const float* whh = L.get(r + "weight_hh_l0" + sfx, {12, 4});
+            const float* bih = L.get(r + "bias_ih_l0" + sfx, {12});
+            const float* bhh = L.get(r + "bias_hh_l0" + sfx, {12});
+            if (L.st != ADE_OK) return false;
+            for (int j = 0; j < 4; ++j) pack_gru_lane(&A.f[o.intra_gru + (grp * 8 + dir * 4 + j) * 42], wih, whh, bih, bhh, 4, j);
+        }
+        const std::string q = p + "inter_rnn.rnn" + std::to_string(grp + 1) + ".";
+        const float* wih = L.get(q + "weight_ih_l0", {24, 8});
+        const float* whh = L.get(q + "weight_hh_l0", {24, 8});
+        const float* bih = L.get(q + "bias_ih_l0", {24});
+        const float* bhh = L.get(q + "bias_hh_l0", {24});
+        if (L.st != ADE_OK) return false;
+        for (int j = 0; j < 8; ++j) pack_gru_lane(&A.f[o.inter_gru + (grp * 8 + j) * 54], wih, whh, bih, bhh, 8, j);
+    }
+    const char* part[2] = {"intra", "inter"};
+    for (int i = 0; i < 2; ++i) {
+        const float* fw = L.get(p + part[i] + "_fc.weight", {16, 16});
+        const float* fb = L.get(p + part[i] + "_fc.bias", {16});
+        const float* lw = L.get(p + part[i] + "_ln.weight", {kFw, 16});
+        const float* lb = L.get(p + part[i] + "_ln.bias", {kFw, 16});
+        if (L.st != ADE_OK) return false;
+        o.fc[i] = A.alloc(256);
+        for (int k = 0; k < 16; ++k)
+            for (int co = 0; co < 16; ++co) A.f[o.fc[i] + k * 16 + co] = fw[co * 16 + k];
+        o.fc_b[i] = A.alloc(16);
+        memcpy(&A.f[o.fc_b[i]], fb, 64);
+        o.ln_w[i] = A.alloc(kFw * 16);
+        memcpy(&A.f[o.ln_w[i]], lw, kFw * 64);
+        o.ln_b[i] = A.alloc(kFw * 16);
+        memcpy(&A.f[o.ln_b[i]], lb, kFw * 64);
+    }
+    return true;
+}
+
+// banded form of a dense (n_in x n_out) row-major matrix: per output column the run [first nz, last nz]
+void band_table(const float* m, int n_in, int n_out, std::vector<int>& start, std::vector<float>& w, int& count) {
+    start.assign(n_out, 0);
+    std::vector<int> len(n_out, 0);
+    count = 0;
+    for (int o = 0; o < n_out; ++o) {
+        int lo = -1, hi = -1;
+        for (int i = 0; i < n_in; ++i)
+            if (m[(size_t)i * n_out + o] != 0.0f) { if (lo < 0) lo = i; hi = i; }
+        if (lo >= 0) { start[o] = lo; len[o] = hi - lo + 1; }
+        if (len[o] > count) count = len[o];
+    }
+    if (count == 0) count = 1;
+    w.assign((size_t)count * n_out, 0.0f);
+    for (int o = 0; o < n_out; ++o)
+        for (int n = 0; n < len[o]; ++n) w[(size_t)n * n_out + o] = m[(size_t)(start[o] + n) * n_out + o];
+}
+
+ade_status build_device_constants(ade_engine* e) {
+    Loader L{e};
+    Arena A;
+    // --- FFT tables.  Window exactly as the reference builds it in fp32 (STFT_Process.py:93 'hann_sqrt' periodic).
+    const size_t o_win = A.alloc(kNfft), o_tw256 = A.alloc(512), o_tw512 = A.alloc(2 * 257 + 2), o_ws = A.alloc(kHop);
+    {
+        const float step = (float)(2.0 * M_PI / (double)kNfft);
+        for (int n = 0; n < kNfft; ++n) A.f[o_win + n] = sqrtf(cosf((float)n * step) * -0.5f + 0.5f);
+        for (int k = 0; k < 256; ++k) {
+            A.f[o_tw256 + 2 * k] = (float)cos(2.0 * M_PI * k / 256.0);
+            A.f[o_tw256 + 2 * k + 1] = (float)-sin(2.0 * M_PI * k / 256.0);
+        }
+        for (int k = 0; k <= 256; ++k) {
+            A.f[o_tw512 + 2 * k] = (float)cos(2.0 * M_PI * k / 512.0);
+            A.f[o_tw512 + 2 * k + 1] = (float)-sin(2.0 * M_PI * k / 512.0);
+        }
+        A.f[o_tw512 + 2 * 256] = -1.0f;
+        A.f[o_tw512 + 2 * 256 + 1] = 0.0f;
+        A.f[o_tw512 + 2 * 128] = 0.0f;   // e^{-i pi/2} = -i exactly
+        A.f[o_tw256 + 2 * 64] = 0.0f;
+        A.f[o_tw256 + 2 * 128 + 1] = 0.0f;
+        A.f[o_tw256 + 2 * 192] = 0.0f;
+        // COLA denominator over one hop period: conv_transpose1d(ones, w^2) in fp32 (STFT_Process.py:254-273)
+        for (int r = 0; r < kHop; ++r) {
+            const float a = A.f[o_win + r] * A.f[o_win + r], b = A.f[o_win + kHop + r] * A.f[o_win + kHop + r];
+            A.f[o_ws + r] = a + b;
+        }
+    }
+    // --- ERB matrices -> banded tables
+    const float* erb_t = L.get("erb.erb_weight_t", {kErbHigh, kErbBands});
+    const float* ierb_t = L.get("erb.ierb_weight_t", {kErbBands, kErbHigh});
+    if (L.st != ADE_OK) return L.st;
+    std::vector<int> bm_start, bs_start;
+    std::vector<float> bm_w, bs_w;
+    int bm_count = 0, bs_count = 0;
+    band_table(erb_t, kErbHigh, kErbBands, bm_start, bm_w, bm_count);
+    band_table(ierb_t, kErbBands, kErbHigh, bs_start, bs_w, bs_count);
+    const size_t o_bm = A.alloc(bm_w.size()), o_bs = A.alloc(bs_w.size());
+    memcpy(&A.f[o_bm], bm_w.data(), bm_w.size() * 4);
+    memcpy(&A.f[o_bs], bs_w.data(), bs_w.size() * 4);
+    // --- conv blocks
+    const float* w0 = L.get("encoder.en_convs.0.conv.weight", {16, 9, 1, 5});
+    const float* b0 = L.get("encoder.en_convs.0.conv.bias", {16});
+    const float* a0 = L.get("encoder.en_convs.0.act.weight", {1});
+    const float* w1 = L.get("encoder.en_convs.1.conv.weight", {16, 8, 1, 5});
+    const float* b1 = L.get("encoder.en_convs.1.conv.bias", {16});
+    const float* a1 = L.get("encoder.en_convs.1.act.weight", {1});
+    const float* w3 = L.get("decoder.de_convs.3.conv.weight", {16, 8, 1, 5});
+    const float* b3 = L.get("decoder.de_convs.3.conv.bias", {16});
+    const float* a3 = L.get("decoder.de_convs.3.act.weight", {1});
+    const float* w4 = L.get("decoder.de_convs.4.conv.weight", {16, 2, 1, 5});
+    const float* b4 = L.get("decoder.de_convs.4.conv.bias", {2});
+    if (L.st != ADE_OK) return L.st;
+    const size_t o_w0 = A.alloc(5 * 9 * 16), o_b0 = A.alloc(16), o_w1 = A.alloc(5 * 2 * 8 * 8), o_b1 = A.alloc(16);
+    const size_t o_w3 = A.alloc(5 * 2 * 8 * 8), o_b3 = A.alloc(16), o_w4 = A.alloc(5 * 16 * 2), o_b4 = A.alloc(2);
+    for (int co = 0; co < 16; ++co)
+        for (int ci = 0; ci < 9; ++ci)
+            for (int k = 0; k < 5; ++k) A.f[o_w0 + (k * 9 + ci) * 16 + co] = w0[(co * 9 + ci) * 5 + k];
+    for (int g = 0; g < 2; ++g)
+        for (int co = 0; co < 8; ++co)
+            for (int ci = 0; ci < 8; ++ci)
+                for (int k = 0; k < 5; ++k) {
+                    A.f[o_w1 + ((k * 2 + g) * 8 + ci) * 8 + co] = w1[((g * 8 + co) * 8 + ci) * 5 + k];   // Conv2d (Cout, Cin/g,1,5)
+                    A.f[o_w3 + ((k * 2 + g) * 8 + ci) * 8 + co] = w3[((g * 8 + ci) * 8 + co) * 5 + k];   // ConvT  (Cin, Cout/g,1,5)
+                }
+    for (int ci = 0; ci < 16; ++ci)
+        for (int co = 0; co < 2; ++co)
+            for (int k = 0; k < 5; ++k) A.f[o_w4 + (k * 16 + ci) * 2 + co] = w4[(ci * 2 + co) * 5 + k];
+    memcpy(&A.f[o_b0], b0, 64);
+    memcpy(&A.f[o_b1], b1, 64);
+    memcpy(&A.f[o_b3], b3, 64);
+    memcpy(&A.f[o_b4], b4, 8);
+    GtOff gte[3], gtd[3];
+    DpOff dpo[2];
+    static const int en_dil[3] = {1, 2, 5}, de_dil[3] = {5, 2, 1};   // Export_GTCRN.py:490-492,512-514
+    for (int i = 0; i < 3; ++i) {
+        if (!load_gt(L, A, "encoder.en_convs." + std::to_string(i + 2) + ".", false, gte[i])) return L.st;
+        if (!load_gt(L, A, "decoder.de_convs." + std::to_string(i) + ".", true, gtd[i])) return L.st;
+    }
+    if (!load_dp(L, A, "dpgrnn1.", dpo[0]) || !load_dp(L, A, "dpgrnn2.", dpo[1])) return L.st;
+
+    // --- upload
+    HIP_TRY(e, hipMalloc((void**)&e->d_weights, A.f.size() * sizeof(float)));
+    HIP_TRY(e, hipMemcpy(e->d_weights, A.f.data(), A.f.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<int> ints(bm_start);
+    ints.insert(ints.end(), bs_start.begin(), bs_start.end());
+    HIP_TRY(e, hipMalloc((void**)&e->d_ints, ints.size() * sizeof(int)));
+    HIP_TRY(e, hipMemcpy(e->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+    const float* W = e->d_weights;
+    e->tabs.win = W + o_win;
+    e->tabs.tw256 = reinterpret_cast<const float2*>(W + o_tw256);
+    e->tabs.tw512 = reinterpret_cast<const float2*>(W + o_tw512);
+    e->tabs.win_sum = W + o_ws;
+    e->erb_bm = BandTab{e->d_ints, W + o_bm, bm_count, kErbBands};
+    e->erb_bs = BandTab{e->d_ints + kErbBands, W + o_bs, bs_count, kErbHigh};
+    e->en0 = ConvW{W + o_w0, W + o_b0, a0[0]};
+    e->en1 = ConvW{W + o_w1, W + o_b1, a1[0]};
+    e->de3 = ConvW{W + o_w3, W + o_b3, a3[0]};
+    e->de4 = ConvW{W + o_w4, W + o_b4, 0.0f};
+    for (int i = 0; i < 3; ++i) {
+        const GtOff* src[2] = {&gte[i], &gtd[i]};
+        GtConvW* dst[2] = {&e->en_gt[i], &e->de_gt[i]};
+        for (int k = 0; k < 2; ++k) {
+            const GtOff& o = *src[k];
+            *dst[k] = GtConvW{W + o.pw1, W + o.pw1_b, W + o.dw, W + o.dw_b, W + o.pw2, W + o.pw2_b, W + o.gru, W + o.fc,
+                              o.s1, o.s2, k == 0 ? en_dil[i] : de_dil[i]};
+        }
+    }
+    for (int i = 0; i < 2; ++i) {
+        const DpOff& o = dpo[i];
+        e->dp[i] = DpW{W + o.intra_gru, W + o.inter_gru, W + o.fc[0], W + o.fc_b[0], W + o.ln_w[0], W + o.ln_b[0],
+                       W + o.fc[1], W + o.fc_b[1], W + o.ln_w[1], W + o.ln_b[1]};
+    }
+    return ADE_OK;
+}
+
+void free_graphs(ade_engine* e) {
+    for (auto& g : e->graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    e->graphs.clear();
+}
+
+void free_workspace(ade_engine* e) {
+    free_graphs(e);
+    if (e->ws) hipFree(e->ws);
+    if (e->d_pcm_in) hipFree(e->d_pcm_in);
+    if (e->d_pcm_out) hipFree(e->d_pcm_out);
+    if (e->d_f32_out) hipFree(e->d_f32_out);
+    if (e->h_pcm_in) hipHostFree(e->h_pcm_in);
+    if (e->h_pcm_out) hipHostFree(e->h_pcm_out);
+    if (e->h_f32_out) hipHostFree(e->h_f32_out);
+    e->ws = nullptr;
+    e->d_pcm_in = e->d_pcm_out = nullptr;
+    e->d_f32_out = nullptr;
+    e->h_pcm_in = e->h_pcm_out = nullptr;
+    e->h_f32_out = nullptr;
+    e->capacity = 0;
+}
+
+ade_status reserve(ade_engine* e, int batch) {
+    if (batch <= e->capacity) return ADE_OK;
+    HIP_TRY(e, hipSetDevice(e->device));
+    if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
+    free_workspace(e);
+    const size_t B = (size_t)batch, T = (size_t)e->T;
+    const size_t nfr = B * T;
+    struct Carve { float** p; size_t n; };
+    std::vector<Carve> cs = {
+        {&e->mean, B}, {&e->spec, nfr * 2 * kBinsPad}, {&e->feat, nfr * 3 * kErbPad}, {&e->e0, nfr * kF1 * kCh},
+        {&e->e1, nfr * kFw * kCh}, {&e->h, nfr * kFw * kCh}, {&e->zt, nfr * 8}, {&e->rnn, nfr * kFw * kCh},
+        {&e->d3, nfr * kF1 * kCh}, {&e->mask, nfr * 2 * kErbPad}, {&e->frames, nfr * kNfft}};
+    for (int i = 0; i < 3; ++i) {
+        cs.push_back({&e->xe[i], nfr * kFw * kCh});
+        cs.push_back({&e->ate[i], nfr * 8});
+        cs.push_back({&e->xd[i], nfr * kFw * kCh});
+        cs.push_back({&e->atd[i], nfr * 8});
+    }
+    for (int i = 0; i < 2; ++i) {
+        cs.push_back({&e->dpm[i], nfr * kFw * kCh});
+        cs.push_back({&e->dpo[i], nfr * kFw * kCh});
+    }
+    size_t total = 0;
+    for (auto& c : cs) total += (c.n + 63) & ~(size_t)63;
+    HIP_TRY(e, hipMalloc((void**)&e->ws, total * sizeof(float)));
+    size_t off = 0;
+    for (auto& c : cs) {
+        *c.p = e->ws + off;
+        off += (c.n + 63) & ~(size_t)63;
+    }
+    HIP_TRY(e, hipMalloc((void**)&e->d_pcm_in, B * e->in_len * sizeof(int16_t)));
+    HIP_TRY(e, hipMalloc((void**)&e->d_pcm_out, B * e->out_len * sizeof(int16_t)));
+    HIP_TRY(e, hipMalloc((void**)&e->d_f32_out, B * e->out_len * sizeof(float)));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
+    e->capacity = batch;
+    return ADE_OK;
+}
+
+// ---- the launch sequence -------------------------------------------------------------------------------
+struct Seq {
+    ade_engine* e;
+    hipStream_t s;
+    bool prof;
+    int cursor = 0;
+    void begin(const char* name) {
+        if (!prof) return;
+        int si = -1;
+        for (size_t i = 0; i < e->stats.size(); ++i)
+            if (e->stats[i].name == name) si = (int)i;
+        if (si < 0) { e->stats.push_back(KernelStat{name, 0.f, 0}); si = (int)e->stats.size() - 1; }
+        if ((int)e->events.size() <= cursor) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            e->events.push_back({a, b});
+            e->event_stat.push_back(si);
+        }
+        e->event_stat[cursor] = si;
+        hipEventRecord(e->events[cursor].first, s);
+    }
+    void end() {
+        if (!prof) return;
+        hipEventRecord(e->events[cursor].second, s);
+        ++cursor;
+    }
+};
+
+void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32, bool prof) {
+    const int T = e->T, nfr = B * T;
+    Seq q{e, s, prof};
+    const View none{nullptr, nullptr};
+    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean); q.end();
+    q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
+    q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
+    q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
+    View x{e->e1, nullptr};
+    for (int i = 0; i < 3; ++i) {   // Encoder GTConvBlocks (Export_GTCRN.py:502-504)
+        q.begin("gt_pw1"); launch_gt_pw1(s, x, none, e->en_gt[i], e->h, nfr); q.end();
+        q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, none, e->en_gt[i], e->xe[i], e->zt, B, T); q.end();
+        q.begin("tra_gru"); launch_tra(s, e->zt, e->en_gt[i], e->ate[i], B, T); q.end();
+        x = View{e->xe[i], e->ate[i]};
+    }
+    for (int i = 0; i < 2; ++i) {   // DPGRNN x2 (Export_GTCRN.py:577-578)
+        q.begin("intra_gru"); launch_intra_gru(s, x, e->dp[i].intra_gru, e->rnn, nfr); q.end();
+        q.begin("fc_ln_res"); launch_fc_ln_res(s, e->rnn, x, e->dp[i].intra_fc, e->dp[i].intra_fc_b, e->dp[i].intra_ln_w,
+                                               e->dp[i].intra_ln_b, e->dpm[i], B, T); q.end();
+        q.begin("inter_gru"); launch_inter_gru(s, e->dpm[i], e->dp[i].inter_gru, e->rnn, B, T); q.end();
+        q.begin("fc_ln_res"); launch_fc_ln_res(s, e->rnn, View{e->dpm[i], nullptr}, e->dp[i].inter_fc, e->dp[i].inter_fc_b,
+                                               e->dp[i].inter_ln_w, e->dp[i].inter_ln_b, e->dpo[i], B, T); q.end();
+        x = View{e->dpo[i], nullptr};
+    }
+    for (int i = 0; i < 3; ++i) {   // Decoder GTConvBlocks on x + en_outs[4-i] (Export_GTCRN.py:524-526)
+        const View skip{e->xe[2 - i], e->ate[2 - i]};
+        q.begin("gt_pw1"); launch_gt_pw1(s, x, skip, e->de_gt[i], e->h, nfr); q.end();
+        q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, skip, e->de_gt[i], e->xd[i], e->zt, B, T); q.end();
+        q.begin("tra_gru"); launch_tra(s, e->zt, e->de_gt[i], e->atd[i], B, T); q.end();
+        x = View{e->xd[i], e->atd[i]};
+    }
+    q.begin("deconv3"); launch_deconv3(s, x, View{e->e1, nullptr}, e->de3, e->d3, nfr); q.end();
+    q.begin("deconv4"); launch_deconv4(s, e->d3, e->e0, e->de4, e->mask, nfr); q.end();
+    q.begin("istft_mask"); launch_istft_masked(s, e->spec, e->mask, e->erb_bs, e->tabs, e->frames, nfr); q.end();
+    q.begin("ola_pcm"); launch_ola_pcm(s, e->frames, e->tabs, B, T, d_out, d_f32); q.end();
+}
+
+ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32) {
+    if (B == 0) return ADE_OK;
+    e->last_batch = B;
+    if (e->profile) {
+        for (auto& st : e->stats) { st.ms = 0.f; st.launches = 0; }
+        enqueue(e, s, d_in, B, d_out, d_f32, true);
+        HIP_TRY(e, hipStreamSynchronize(s));
+        for (size_t i = 0; i < e->events.size(); ++i) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second);
+            e->stats[e->event_stat[i]].ms += ms;
+            e->stats[e->event_stat[i]].launches += 1;
+        }
+        return ADE_OK;
+    }
+    if (e->use_graph && e->graph_supported) {
+        GraphEntry* hit = nullptr;
+        for (auto& g : e->graphs)
+            if (g.in == d_in && g.out_pcm == d_out && g.out_f32 == d_f32 && g.batch == B) hit = &g;
+        if (!hit) {
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                enqueue(e, s, d_in, B, d_out, d_f32, false);
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                if (hipStreamEndCapture(s, &graph) == hipSuccess && graph &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    if (e->graphs.size() >= 8) {
+                        hipGraphExecDestroy(e->graphs.front().exec);
+                        hipGraphDestroy(e->graphs.front().graph);
+                        e->graphs.erase(e->graphs.begin());
+                    }
+                    e->graphs.push_back(GraphEntry{d_in, d_out, d_f32, B, exec, graph});
+                    hit = &e->graphs.back();
+                } else {
+                    if (graph) hipGraphDestroy(graph);
+                    e->graph_supported = false;
+                }
+            } else {
+                (void)hipGetLastError();
+                e->graph_supported = false;
+            }
+        }
+        if (hit) {
+            HIP_TRY(e, hipGraphLaunch(hit->exec, s));
+            return ADE_OK;
+        }
+    }
+    enqueue(e, s, d_in, B, d_out, d_f32, false);
+    HIP_TRY(e, hipGetLastError());
+    return ADE_OK;
+}
+
+}  // namespace
+
+// ======================================= C ABI ================================================================
+extern "C" {
+
+ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device, ade_handle* out) {
+    if (!out) return fail(nullptr, ADE_ERR_BAD_VALUE, "ade_create: out is NULL");
+    *out = nullptr;
+    if (!manifest_json) return fail(nullptr, ADE_ERR_NOT_FOUND, "ade_create: manifest is NULL (metadata carrier missing)");
+    if (!weights) return fail(nullptr, ADE_ERR_NOT_FOUND, "ade_create: weights are NULL");
+    ade_engine* e = new ade_engine();
+    auto bail = [&](ade_status st) {
+        g_create_error = e->last_error;
+        ade_destroy(e);
+        return st;
+    };
+    std::string err;
+    if (!parse_manifest(manifest_json, e->meta, err)) return bail(fail(e, ADE_ERR_BAD_VALUE, err));
+    // load_runtime_metadata: every required key present and non-empty (audio_onnx_metadata.py:251-256,300-302)
+    for (const char* k : kRequiredKeys) {
+        auto it = e->meta.find(k);
+        if (it == e->meta.end() || it->second.empty())
+            return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
+    }
+    if (e->meta["model_family"] != "gtcrn")
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn only)"));
+    bool dyn = false;
+    if (!parse_bool(e->meta["dynamic_axes"], &dyn))
+        return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
+    if (dyn) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
+    long sr_in = 0, sr_out = 0, sr_model = 0, L = 0;
+    if (!parse_int(e->meta["in_sample_rate"], &sr_in) || !parse_int(e->meta["out_sample_rate"], &sr_out) ||
+        !parse_int(e->meta["model_sample_rate"], &sr_model) || !parse_int(e->meta["input_audio_length"], &L))
+        return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
+    if (sr_in != sr_model || sr_out != sr_model)
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "in/out sample rate != model sample rate (resampling path not implemented)"));
+    if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
+    auto opt = [&](const char* k, const char* want) {
+        auto it = e->meta.find(k);
+        return it == e->meta.end() || it->second.empty() || it->second == want;
+    };
+    if (!opt("nfft", "512") || !opt("hop_length", "256") || !opt("window_length", "512") || !opt("window_type", "hann_sqrt") ||
+        !opt("pad_mode", "reflect") || !opt("center_pad", "1"))
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "STFT configuration other than 512/512/256 hann_sqrt reflect centre-pad"));
+    bool fold = false;
+    if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty()) {
+        if (!parse_bool(e->meta["use_batch_fold"], &fold))
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
+        if (fold) return bail(fail(e, ADE_ERR_UNSUPPORTED, "use_batch_fold=1: pass the folded windows as batch rows instead"));
+    }
+    // validate_audio_metadata (audio_onnx_metadata.py:322-351): export length / channels must agree with the "graph"
+    long v = 0;
+    if (e->meta.count("export_audio_length") && !e->meta["export_audio_length"].empty()) {
+        if (!parse_int(e->meta["export_audio_length"], &v) || v != L)
+            return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input length does not match metadata export_audio_length"));
+    }
+    for (const char* k : {"input_channels", "output_channels", "num_audio_inputs"})
+        if (e->meta.count(k) && !e->meta[k].empty() && e->meta[k] != "1")
+            return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, std::string("metadata ") + k + " must be 1 for GTCRN"));
+    if (L < kNfft / 2 + 2 || L > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
+    e->in_len = (int)L;
+    e->T = e->in_len / kHop + 1;                 // STATIC_SIGNAL_LENGTH, Export_GTCRN.py:45
+    e->out_len = kHop * (e->T - 1);              // STFT_Process.py:169-176 with max_frames = T
+    e->sample_rate = (int)sr_model;
+    if (e->meta.count("max_signal_length") && !e->meta["max_signal_length"].empty()) {
+        if (!parse_int(e->meta["max_signal_length"], &v) || v != e->T)
+            return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "max_signal_length does not equal input_audio_length // hop + 1"));
+    }
+    ade_status st = parse_blob(e, weights, weights_nbytes);
+    if (st != ADE_OK) return bail(st);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return bail(fail(e, ADE_ERR_DEVICE, "no HIP device visible: libade has no CPU execution mode"));
+    }
+    if (device < 0 || device >= ndev) return bail(fail(e, ADE_ERR_DEVICE, "device ordinal out of range"));
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(e, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
+    st = build_device_constants(e);
+    if (st != ADE_OK) return bail(st);
+    e->blob_storage.clear();
+    e->blob_storage.shrink_to_fit();
+    e->tensors.clear();
+    const char* env = getenv("ADE_GRAPH");
+    if (env && env[0] == '0') e->use_graph = false;
+    *out = e;
+    return ADE_OK;
+}
+
+ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
+    if (!h || !d) return ADE_ERR_BAD_VALUE;
+    d->abi_version = ADE_ABI_VERSION;
+    d->in_channels = 1;
+    d->out_channels = 1;
+    d->n_outputs = 1;
+    d->in_len = h->in_len;
+    d->out_len = h->out_len;
+    d->in_sample_rate = d->out_sample_rate = d->model_sample_rate = h->sample_rate;
+    d->frames = h->T;
+    d->max_batch = h->capacity;
+    d->device = h->device;
+    return ADE_OK;
+}
+
+ade_status ade_reserve(ade_handle h, int batch) {
+    if (!h || batch < 0) return ADE_ERR_BAD_VALUE;
+    return reserve(h, batch);
+}
+
+ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
+    if (!h || !key || !value) return ADE_ERR_BAD_VALUE;
+    if (strcmp(key, "graph") == 0) {
+        bool b;
+        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, "option graph must be 0/1");
+        h->use_graph = b;
+        return ADE_OK;
+    }
+    return fail(h, ADE_ERR_MISSING_KEY, std::string("unknown option: ") + key);
+}
+
+ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, void* hip_stream) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device: bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ade_status st = reserve(h, batch);
+    if (st != ADE_OK) return st;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    st = run(h, s, d_in, batch, d_out, d_f32);
+    if (st != ADE_OK) return st;
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process: bad arguments");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    ade_status st = reserve(h, batch);
+    if (st != ADE_OK) return st;
+    const size_t nin = (size_t)batch * h->in_len, nout = (size_t)batch * h->out_len;
+    memcpy(h->h_pcm_in, in, nin * sizeof(int16_t));
+    HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in, h->h_pcm_in, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    st = run(h, h->stream, h->d_pcm_in, batch, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
+    if (st != ADE_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_pcm) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
+    if (out_f32) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
+    return ADE_OK;
+}
+
+ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t count, size_t* written) {
+    if (!h || !name || !out || !written) return ADE_ERR_BAD_VALUE;
+    const size_t nfr = (size_t)h->last_batch * h->T;
+    struct Tap { const char* name; const float* p; size_t n; };
+    const Tap taps[] = {
+        {"mean", h->mean, (size_t)h->last_batch}, {"spec", h->spec, nfr * 2 * kBinsPad}, {"feat", h->feat, nfr * 3 * kErbPad},
+        {"e0", h->e0, nfr * kF1 * kCh}, {"e1", h->e1, nfr * kFw * kCh}, {"h", h->h, nfr * kFw * kCh}, {"zt", h->zt, nfr * 8},
+        {"x_e2", h->xe[0], nfr * kFw * kCh}, {"x_e3", h->xe[1], nfr * kFw * kCh}, {"x_e4", h->xe[2], nfr * kFw * kCh},
+        {"at_e2", h->ate[0], nfr * 8}, {"at_e3", h->ate[1], nfr * 8}, {"at_e4", h->ate[2], nfr * 8},
+        {"x_d0", h->xd[0], nfr * kFw * kCh}, {"x_d1", h->xd[1], nfr * kFw * kCh}, {"x_d2", h->xd[2], nfr * kFw * kCh},
+        {"at_d0", h->atd[0], nfr * 8}, {"at_d1", h->atd[1], nfr * 8}, {"at_d2", h->atd[2], nfr * 8},
+        {"rnn", h->rnn, nfr * kFw * kCh}, {"dp1_mid", h->dpm[0], nfr * kFw * kCh}, {"dp1", h->dpo[0], nfr * kFw * kCh},
+        {"dp2_mid", h->dpm[1], nfr * kFw * kCh}, {"dp2", h->dpo[1], nfr * kFw * kCh}, {"d3", h->d3, nfr * kF1 * kCh},
+        {"mask", h->mask, nfr * 2 * kErbPad}, {"frames", h->frames, nfr * kNfft}};
+    for (const Tap& t : taps)
+        if (strcmp(t.name, name) == 0) {
+            if (!t.p || t.n == 0) return fail(h, ADE_ERR_NOT_FOUND, "tap has no data yet");
+            if (count < t.n) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+            HIP_TRY(h, hipSetDevice(h->device));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(out, t.p, t.n * sizeof(float), hipMemcpyDeviceToHost));
+            *written = t.n;
+            return ADE_OK;
+        }
+    return fail(h, ADE_ERR_MISSING_KEY, std::string("unknown tap: ") + name);
+}
+
+int ade_kernel_count(ade_handle h) { return h ? (int)h->stats.size() : 0; }
+const char* ade_kernel_name(ade_handle h, int i) { return (h && i >= 0 && i < (int)h->stats.size()) ? h->stats[i].name.c_str() : ""; }
+ade_status ade_profile_last(ade_handle h, int enable) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    h->profile = enable != 0;
+    return ADE_OK;
+}
+ade_status ade_kernel_ms(ade_handle h, int i, float* total_ms, int* launches) {
+    if (!h || i < 0 || i >= (int)h->stats.size()) return ADE_ERR_BAD_VALUE;
+    if (total_ms) *total_ms = h->stats[i].ms;
+    if (launches) *launches = h->stats[i].launches;
+    return ADE_OK;
+}
+
+const char* ade_last_error(ade_handle h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
+
+void ade_destroy(ade_handle h) {
+    if (!h) return;
+    if (h->stream) {
+        hipSetDevice(h->device);
+        hipStreamSynchronize(h->stream);
+    }
+    free_workspace(h);
+    for (auto& ev : h->events) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    if (h->d_weights) hipFree(h->d_weights);
+    if (h->d_ints) hipFree(h->d_ints);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream) {
+    if (!h || batch < 0 || (batch > 0 && (!d_x || !d_spec))) return ADE_ERR_BAD_VALUE;
+    if (length < kNfft / 2 + 2) return fail(h, ADE_ERR_SHAPE_MISMATCH, "ade_stft_forward: length too short for reflect padding");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    launch_stft_ref(s, d_x, batch, length, length / kHop + 1, h->tabs, d_spec);
+    HIP_TRY(h, hipGetLastError());
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
+    if (!h || batch < 0 || frames < 2 || (batch > 0 && (!d_spec || !d_y))) return ADE_ERR_BAD_VALUE;
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    float* tmp = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&tmp, (size_t)batch * frames * kNfft * sizeof(float)));
+    launch_istft_ref(s, d_spec, batch, frames, h->tabs, tmp);
+    launch_ola_pcm(s, tmp, h->tabs, batch, frames, nullptr, d_y);
+    hipError_t err = hipGetLastError();
+    hipStreamSynchronize(s);
+    hipFree(tmp);
+    if (err != hipSuccess) return fail(h, ADE_ERR_DEVICE, hipGetErrorString(err));
+    return ADE_OK;
+}
+
+}  // extern "C"

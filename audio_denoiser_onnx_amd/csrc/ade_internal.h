@@ -1,0 +1,104 @@
+// ade_internal.h — shapes, device-side parameter blocks and launcher prototypes shared by the engine
+// (ade_engine.hip) and the gfx950 kernels (ade_kernels.hip).  Not part of the public ABI (include/ade.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ade {
+
+// ---- static shapes of the GTCRN path (GTCRN/Export_GTCRN.py:37-39,535,540) ---------------------------------
+constexpr int kNfft = 512;
+constexpr int kHop = 256;
+constexpr int kBins = 257;       // n_fft/2 + 1
+constexpr int kBinsPad = 260;    // row pitch of a spectrum row in HBM (16-byte multiple)
+constexpr int kErb = 129;        // 65 pass-through + 64 ERB bands
+constexpr int kErbPad = 132;
+constexpr int kErbLow = 65;
+constexpr int kErbBands = 64;
+constexpr int kErbHigh = 192;
+constexpr int kF1 = 65;          // width after en_convs[0]
+constexpr int kFw = 33;          // width after en_convs[1] (DPGRNN "width")
+constexpr int kCh = 16;
+constexpr int kTileFrames = 7;   // 7 frames x 33 bins = 231 threads of a 256-thread workgroup
+constexpr int kTileThreads = kTileFrames * kFw;
+
+// Activation tensor in HBM, channels-last (B, T, F, 16), optionally carrying a deferred TRA gate:
+// the logical value of even channel 2i at (b,t,*) is x[...,2i] * at[(b*T+t)*8 + i]   (Export_GTCRN.py:156,324).
+struct View {
+    const float* x;
+    const float* at;   // nullptr: no deferred gate
+};
+
+// Banded (sparse) form of the ERB matrices (Export_GTCRN.py:79-107): output o sums `count` consecutive inputs
+// starting at start[o]; w is [count][n_out], zero-padded, so the sum equals the dense matmul term for term.
+struct BandTab {
+    const int* start;
+    const float* w;
+    int count;
+    int n_out;
+};
+
+struct FftTabs {
+    const float* win;      // [512] analysis == synthesis window (sqrt-hann, periodic)
+    const float2* tw256;   // e^{-2 pi i k/256}, k < 256
+    const float2* tw512;   // e^{-2 pi i k/512}, k <= 256
+    const float* win_sum;  // [256] COLA denominator, one hop period (STFT_Process.py:265-273)
+};
+
+struct ConvW {             // ConvBlock after BN fold, weights re-laid out output-channel-fastest
+    const float* w;
+    const float* b;
+    float slope;           // PReLU slope (unused for the Tanh block)
+};
+
+struct GtConvW {           // GTConvBlock after BN fold, canonical ("encoder") tap order for both conv flavours
+    const float* pw1;      // [24][16]
+    const float* pw1_b;    // [16]
+    const float* dw;       // [3][3][16]   (kt, kf, c):  y[t,f] += dw[kt][kf][c] * h[t-(2-kt)d, f-1+kf]
+    const float* dw_b;     // [16]
+    const float* pw2;      // [16][8]
+    const float* pw2_b;    // [8]
+    const float* gru;      // [16 lanes][78]  TRA GRU rows per lane (3x8 ih | 3x16 hh | 3 b_ih | 3 b_hh)
+    const float* fc;       // [8][17]         TRA Linear rows (16 w | bias)
+    float pw1_slope, dw_slope;
+    int dilation;
+};
+
+struct DpW {               // one DPGRNN block
+    const float* intra_gru;   // [16 lanes][42]   lane = (group, dir, unit)
+    const float* inter_gru;   // [16 lanes][54]   lane = (group, unit)
+    const float* intra_fc;    // [16][16] (k, co) + [16] bias
+    const float* intra_fc_b;
+    const float* intra_ln_w;  // [33][16]
+    const float* intra_ln_b;
+    const float* inter_fc;
+    const float* inter_fc_b;
+    const float* inter_ln_w;
+    const float* inter_ln_b;
+};
+
+// ---- launchers (ade_kernels.hip) ---------------------------------------------------------------------------
+void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean);
+void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs,
+                     BandTab erb_bm, float* spec, float* feat);
+void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec);
+void launch_conv0(hipStream_t s, const float* feat, ConvW w, float* e0, int nframes);
+void launch_conv1(hipStream_t s, const float* e0, ConvW w, float* e1, int nframes);
+void launch_gt_pw1(hipStream_t s, View a, View skip, GtConvW w, float* h, int nframes);
+void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T);
+void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T);
+void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes);
+void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T);
+void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,
+                      const float* ln_b, float* out, int B, int T);
+void launch_deconv3(hipStream_t s, View a, View skip, ConvW w, float* d3, int nframes);
+void launch_deconv4(hipStream_t s, const float* d3, const float* e0, ConvW w, float* mask, int nframes);
+void launch_istft_masked(hipStream_t s, const float* spec, const float* mask, BandTab erb_bs, FftTabs tabs, float* frames,
+                         int nframes);
+void launch_istft_ref(hipStream_t s, const float* ref_spec, int B, int T, FftTabs tabs, float* frames);
+void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int T, int16_t* pcm, float* f32);
+
+}  // namespace ade

@@ -1,0 +1,197 @@
+"""``InferenceSession`` — host-side mirror of the object the reference drives per slice.
+
+The reference's inference scripts talk to ``onnxruntime.InferenceSession`` (GTCRN/Inference_GTCRN_ONNX.py:237,
+262-267, 307-317): ``get_inputs()/get_outputs()`` metadata, pre-bound buffers, one ``run_with_iobinding`` per
+slice.  This class exposes the same surface over libade's C ABI (include/ade.h); the compute is the hand-written
+gfx950 path and nothing else — construction fails loudly without the built library or a GPU.
+
+Differences from ORT that are the point of this engine: ``run`` accepts ``(B, 1, L)`` and treats the B rows as
+B independent reference calls executed as one batch, and :meth:`run_device` takes device tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .metadata import MetadataReader, load_runtime_metadata, validate_audio_metadata
+
+INPUT_NAME = "noisy_audio"       # GTCRN/Export_GTCRN.py:768
+OUTPUT_NAME = "denoised_audio"   # GTCRN/Export_GTCRN.py:769
+
+
+class NodeArg:
+    """What ``session.get_inputs()[i]`` looks like to the reference driver (name / shape / type)."""
+
+    def __init__(self, name: str, shape: Sequence[int], type_: str = "tensor(int16)"):
+        self.name, self.shape, self.type = name, list(shape), type_
+
+    def __repr__(self):
+        return f"NodeArg(name={self.name!r}, type={self.type!r}, shape={self.shape})"
+
+
+class ModelMeta:
+    def __init__(self, custom_metadata_map: Dict[str, str]):
+        self.custom_metadata_map = dict(custom_metadata_map)
+
+
+def resolve_model_path(path) -> Path:
+    """A model directory resolves to its single ``*.adew`` blob (the reference resolves a dir to ``GTCRN.onnx``,
+    Inference_GTCRN_ONNX.py:26-32)."""
+    p = Path(path).expanduser()
+    if p.is_dir():
+        blobs = sorted(p.glob("*.adew"))
+        if len(blobs) != 1:
+            raise FileNotFoundError(f"expected exactly one .adew weight blob in {p}, found {len(blobs)}")
+        return blobs[0]
+    if not p.exists():
+        raise FileNotFoundError(f"model file not found: {p}")
+    return p
+
+
+class InferenceSession:
+    def __init__(self, model_path=None, *, weights: Optional[bytes] = None, metadata: Optional[Dict[str, str]] = None,
+                 device_id: int = 0, library: Optional[_lib.AdeLibrary] = None):
+        """``model_path``: ``<name>.adew`` (or its directory) with ``<name>_Metadata.json`` beside it; or pass
+        ``weights`` + ``metadata`` directly.  ``library`` defaults to the in-tree gfx950 build."""
+        self._lib = library or _lib.get_library()
+        self._h = C.c_void_p()
+        if model_path is not None:
+            model_path = resolve_model_path(model_path)
+            reader = load_runtime_metadata(model_path)          # FileNotFoundError / KeyError like the reference
+            with open(model_path, "rb") as f:
+                weights = f.read()
+        else:
+            if weights is None or metadata is None:
+                raise ValueError("pass either model_path or both weights and metadata")
+            reader = MetadataReader(metadata)
+        self.metadata = reader
+        self._weights = bytes(weights)
+        st = self._lib.c.ade_create(reader.to_json().encode(), self._weights, len(self._weights), int(device_id),
+                                    C.byref(self._h))
+        self._lib.check(st, None)
+        io = _lib.IoDesc()
+        self._lib.check(self._lib.c.ade_get_io(self._h, C.byref(io)), self._h)
+        self.in_len, self.out_len, self.frames = io.in_len, io.out_len, io.frames
+        self.sample_rate = io.model_sample_rate
+        self.device_id = io.device
+        self._inputs = [NodeArg(INPUT_NAME, [1, io.in_channels, io.in_len])]
+        self._outputs = [NodeArg(OUTPUT_NAME, [1, io.out_channels, io.out_len])]
+        self._inputs_meta, self._outputs_meta = self._inputs, self._outputs   # names the reference script touches
+        validate_audio_metadata(reader, self)
+
+    # -- ORT-shaped surface --------------------------------------------------------------------------------
+    def get_inputs(self) -> List[NodeArg]:
+        return self._inputs
+
+    def get_outputs(self) -> List[NodeArg]:
+        return self._outputs
+
+    def get_modelmeta(self) -> ModelMeta:
+        return ModelMeta(self.metadata.metadata)
+
+    def get_providers(self) -> List[str]:
+        return ["AdeMI355XExecutionProvider"]
+
+    def run(self, output_names, input_feed: Dict[str, np.ndarray], return_f32: bool = False):
+        """``session.run(None, {"noisy_audio": int16 (B,1,L)})`` -> ``[int16 (B,1,L_out)]`` (+ fp32 pre-PCM tap)."""
+        if INPUT_NAME not in input_feed:
+            raise KeyError(f"missing input {INPUT_NAME!r}")
+        x = np.asarray(input_feed[INPUT_NAME])
+        if x.dtype != np.int16:
+            raise ValueError(f"{INPUT_NAME} must be int16, got {x.dtype}")
+        if x.ndim != 3 or x.shape[1] != 1 or x.shape[2] != self.in_len:
+            raise ValueError(f"{INPUT_NAME} must have shape (B, 1, {self.in_len}), got {x.shape}")
+        pcm, f32 = self.process(x[:, 0, :], want_f32=return_f32)
+        out = [pcm[:, None, :]]
+        if return_f32:
+            out.append(f32[:, None, :])
+        return out
+
+    # -- batch call on host buffers ---------------------------------------------------------------------------
+    def process(self, pcm: np.ndarray, want_f32: bool = False):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if pcm.ndim != 2 or pcm.shape[1] != self.in_len:
+            raise ValueError(f"expected int16 (B, {self.in_len}), got {pcm.shape}")
+        B = pcm.shape[0]
+        out = np.empty((B, self.out_len), np.int16)
+        f32 = np.empty((B, self.out_len), np.float32) if want_f32 else None
+        st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if want_f32 else None)
+        self._lib.check(st, self._h)
+        return out, f32
+
+    # -- batch call on device buffers (torch tensors on this session's GPU) ------------------------------------
+    def run_device(self, d_in, d_out, d_f32=None, stream: Optional[int] = None) -> None:
+        """``d_in`` int16 (B, L) / ``d_out`` int16 (B, L_out) CUDA(HIP) tensors; enqueues on ``stream`` (a raw
+        hipStream_t handle, e.g. ``torch.cuda.current_stream().cuda_stream``) or runs synchronously when None."""
+        B = int(d_in.shape[0])
+        if tuple(d_in.shape) != (B, self.in_len) or tuple(d_out.shape) != (B, self.out_len):
+            raise ValueError("device tensors must be (B, in_len) int16 -> (B, out_len) int16")
+        if not d_in.is_contiguous() or not d_out.is_contiguous():
+            raise ValueError("device tensors must be contiguous")
+        f32_ptr = None
+        if d_f32 is not None:
+            if tuple(d_f32.shape) != (B, self.out_len) or not d_f32.is_contiguous():
+                raise ValueError("d_f32 must be a contiguous (B, out_len) float32 tensor")
+            f32_ptr = C.c_void_p(d_f32.data_ptr())
+        st = self._lib.c.ade_process_device(self._h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr()), f32_ptr,
+                                            C.c_void_p(stream) if stream else None)
+        self._lib.check(st, self._h)
+
+    def reserve(self, batch: int) -> None:
+        self._lib.check(self._lib.c.ade_reserve(self._h, int(batch)), self._h)
+
+    def set_option(self, key: str, value: str) -> None:
+        self._lib.check(self._lib.c.ade_set_option(self._h, key.encode(), str(value).encode()), self._h)
+
+    # -- parity / timing taps ---------------------------------------------------------------------------------
+    def tap(self, name: str, count: int) -> np.ndarray:
+        buf = np.empty(int(count), np.float32)
+        n = C.c_size_t()
+        self._lib.check(self._lib.c.ade_debug_tap(self._h, name.encode(), buf.ctypes.data, buf.size, C.byref(n)), self._h)
+        return buf[: n.value]
+
+    def profile(self, enable: bool) -> None:
+        self._lib.check(self._lib.c.ade_profile_last(self._h, int(bool(enable))), self._h)
+
+    def kernel_times(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for i in range(self._lib.c.ade_kernel_count(self._h)):
+            ms, n = C.c_float(), C.c_int()
+            self._lib.check(self._lib.c.ade_kernel_ms(self._h, i, C.byref(ms), C.byref(n)), self._h)
+            out[self._lib.c.ade_kernel_name(self._h, i).decode()] = {"ms": float(ms.value), "launches": int(n.value)}
+        return out
+
+    # -- STFT_Process operator on device tensors ---------------------------------------------------------------
+    def stft_device(self, d_x, d_spec, stream: Optional[int] = None) -> None:
+        B, L = int(d_x.shape[0]), int(d_x.shape[1])
+        st = self._lib.c.ade_stft_forward(self._h, C.c_void_p(d_x.data_ptr()), B, L, C.c_void_p(d_spec.data_ptr()),
+                                          C.c_void_p(stream) if stream else None)
+        self._lib.check(st, self._h)
+
+    def istft_device(self, d_spec, d_y, stream: Optional[int] = None) -> None:
+        B, T = int(d_spec.shape[0]), int(d_spec.shape[2])
+        st = self._lib.c.ade_istft_forward(self._h, C.c_void_p(d_spec.data_ptr()), B, T, C.c_void_p(d_y.data_ptr()),
+                                           C.c_void_p(stream) if stream else None)
+        self._lib.check(st, self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h:
+            self._lib.c.ade_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — RTF / audio-seconds-per-second of the GTCRN chunk path at batch = 256 x 1 s chunks (BASELINE.json).
+
+A "step" is one pass of the hot path (int16 PCM in HBM -> STFT -> GTCRN -> mask -> ISTFT/OLA -> int16 PCM in HBM)
+over one batch of 256 synthetic 1 s chunks per GPU (`configs[1]`), through libade's C ABI on device buffers.
+Weights: seeded reference-architecture weights (tests/golden/gtcrn_seed0.adew; the reference ships no checkpoint).
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: chunks are independent reference calls, so each rank runs its own 256 chunks (weak scaling) with NO
+collective in the data path; `--stitch` additionally all-gathers the int16 outputs over RCCL inside the timed region
+(what a file-level job needs to write one wav).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CHUNK = 16000
+SR = 16000
+
+# Algorithmic work per 1 s chunk (T = 63 frames) of each kernel family, per LAUNCH-SET in one forward:
+# MACs counted from the layer shapes (DESIGN.md "Kernels"); bytes = activation tensors the op must read + write once.
+_T = 63
+KERNEL_MODEL = {
+    # name: (MACs per chunk per forward, algorithmic bytes per chunk per forward)
+    "pcm_mean": (0, 32000),
+    "stft_feat": (int(_T * (2.5 * 512 * 9 / 2 + 3 * 382)), 32000 + _T * (2 * 257 + 3 * 129) * 4),
+    "conv0": (_T * 65 * 16 * 45, _T * (3 * 129 + 65 * 16) * 4),
+    "conv1": (_T * 33 * 16 * 40, _T * (65 * 16 + 33 * 16) * 4),
+    "gt_pw1": (6 * _T * 33 * 384, 6 * _T * 33 * (8 + 16) * 4),
+    "gt_dw_pw2": (6 * _T * 33 * 272, 6 * _T * 33 * (16 + 8 + 16) * 4),
+    "tra_gru": (6 * _T * 1280, 6 * _T * 16 * 4),
+    "intra_gru": (2 * _T * 33 * 4 * 144, 2 * _T * 33 * 32 * 4),
+    "inter_gru": (2 * _T * 33 * 2 * 384, 2 * _T * 33 * 32 * 4),
+    "fc_ln_res": (4 * _T * 33 * 256, 4 * _T * 33 * 48 * 4),
+    "deconv3": (_T * 33 * 16 * 8 * 5, _T * (2 * 33 * 16 + 65 * 16) * 4),
+    "deconv4": (_T * 65 * 16 * 2 * 5, _T * (2 * 65 * 16 + 2 * 129) * 4),
+    "istft_mask": (int(_T * (2.5 * 512 * 9 / 2 + 2 * 382 + 4 * 257)), _T * (2 * 257 + 2 * 129 + 512) * 4),
+    "ola_pcm": (0, _T * 512 * 4 + 31744),
+}
+PIPELINE_BYTES_PER_CHUNK = 32000 + 31744          # int16 in + int16 out
+PIPELINE_FLOP_PER_CHUNK = 54.5e6                   # 2 x 26.52 MMAC network + FFT-form STFT/ISTFT
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3                           # fp32 dense: f32-MFMA rate == fp32 VALU rate on gfx950
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
+    ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
+    """Oracle (C restatement of the reference, OpenMP over chunks) timed on this host: the reported CPU baseline."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle_lib import GtcrnOracle   # test infrastructure used as the *baseline*, never as the product
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    o = GtcrnOracle(blob, CHUNK)
+    t0 = time.perf_counter()
+    o.process(x[:cores], threads=cores)                     # probe: one chunk per core
+    probe = time.perf_counter() - t0
+    n = int(max(cores, min(x.shape[0], (budget_s / max(probe, 1e-3)) * cores)))
+    n = max(cores, (n // cores) * cores)
+    t0 = time.perf_counter()
+    o.process(x[:n], threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * (15872 / SR) / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the same synthetic 1 s chunks, oracle/ade_oracle.c (dense-DFT reference arithmetic), "
+                      f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch
+
+    with open(os.path.join(REPO, "tests", "golden", "gtcrn_seed0.adew"), "rb") as f:
+        blob = f.read()
+    meta = build_audio_metadata(producer="bench.py", model_name="GTCRN", task="denoise", model_family="gtcrn",
+                                input_audio_length=CHUNK)
+    sess = InferenceSession(weights=blob, metadata=meta, device_id=local_rank)
+    if args.no_graph:
+        sess.set_option("graph", "0")
+    B = args.batch
+    sess.reserve(B)
+    x_host = synth_batch(B, CHUNK, first_index=rank * B)
+    d_in = torch.from_numpy(x_host).cuda()
+    d_out = torch.empty((B, sess.out_len), dtype=torch.int16, device="cuda")
+    gathered = torch.empty((world * B, sess.out_len), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        sess.run_device(d_in, d_out, stream=stream)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    audio_s_per_step = world * B * (sess.out_len / SR)
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+    value = audio_s_per_step * args.steps / elapsed
+
+    roofline = cpu = kernels = None
+    if rank == 0:
+        # per-kernel device time, HIP events on the launch stream (ade_profile_last), averaged over a few forwards
+        sess.profile(True)
+        acc = {}
+        reps = 5
+        for _ in range(reps):
+            sess.run_device(d_in, d_out, stream=stream)
+            for k, v in sess.kernel_times().items():
+                a = acc.setdefault(k, {"ms": 0.0, "launches": v["launches"]})
+                a["ms"] += v["ms"] / reps
+        sess.profile(False)
+        kernels = {k: {"ms_per_forward": round(v["ms"], 4), "launches": v["launches"]} for k, v in acc.items()}
+        dom = max(acc, key=lambda k: acc[k]["ms"])
+        macs, nbytes = KERNEL_MODEL[dom]
+        t_launch = acc[dom]["ms"] * 1e-3 / acc[dom]["launches"]
+        flops_launch = 2.0 * macs * B / acc[dom]["launches"]
+        bytes_launch = float(nbytes) * B / acc[dom]["launches"]
+        tf = flops_launch / t_launch / 1e12
+        gbs = bytes_launch / t_launch / 1e9
+        if tf / FP32_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "peak_note": "fp32 dense peak (f32-MFMA rate == fp32 VALU rate, 157.3 TF); this kernel is fp32 VALU work",
+                        "avg_launch_us": round(t_launch * 1e6, 2), "alt_hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        else:
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(t_launch * 1e6, 2),
+                        "alt_fp32_frac": round(tf / FP32_PEAK_TFLOPS, 4)}
+        per_gpu_step_s = elapsed / max(1, args.steps)
+        roofline["pipeline"] = {
+            "hbm_frac": round(PIPELINE_BYTES_PER_CHUNK * B / per_gpu_step_s / 1e9 / HBM_PEAK_GBS, 6),
+            "fp32_frac": round(PIPELINE_FLOP_PER_CHUNK * B / per_gpu_step_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+            "sum_kernel_ms": round(sum(v["ms"] for v in acc.values()), 4),
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(blob, x_host, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "audio_seconds_per_second (GTCRN 16 kHz, batch=256 x 1 s chunks; RTF = 1/value)",
+            "value": round(value, 1),
+            "unit": "audio-s/s",
+            "rtf": float(f"{1.0 / value:.3e}"),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
+                                   "(BASELINE.json configs[1])",
+                       "chunks_per_gpu": B, "chunk_samples": CHUNK, "out_samples": sess.out_len,
+                       "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)",
+                       "hipgraph": not args.no_graph, "stitch_all_gather": bool(gathered is not None)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/*
+ * ade.h — C ABI of libade, the MI355X (gfx950) engine for the reference's per-chunk denoise call.
+ *
+ * The reference (DakeQQ/Audio-Denoiser-ONNX) has no plugin / FFI layer: its hot-path boundary is the tensor
+ * contract of the exported ONNX graph as driven by GTCRN/Inference_GTCRN_ONNX.py:307-317
+ *     input  "noisy_audio"    int16 (1, 1, L)         (GTCRN/Export_GTCRN.py:768)
+ *     output "denoised_audio" int16 (1, 1, L_out)     (GTCRN/Export_GTCRN.py:769)
+ * with static shapes (DYNAMIC_AXES=False, Export_GTCRN.py:28), caller-owned pre-bound buffers re-used for every
+ * slice (Inference_GTCRN_ONNX.py:307-311), synchronous single-threaded execution (:156), no state carried between
+ * calls (zero GRU state, Export_GTCRN.py:339-352), plus the string metadata map of audio_onnx_metadata.py:8-26.
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * A batch of B rows is B INDEPENDENT reference calls (per-row DC mean, Export_GTCRN.py:647): row b of the output
+ * equals what the reference's session.run returns for row b alone.
+ */
+#ifndef ADE_H
+#define ADE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADE_ABI_VERSION 1
+
+/* Status codes map 1:1 onto the exception classes the reference raises at this boundary
+ * (audio_onnx_metadata.py:251-256 KeyError, :281-287 / :325-351 ValueError, :293-297 FileNotFoundError). */
+typedef enum ade_status {
+    ADE_OK = 0,
+    ADE_ERR_NOT_FOUND = 1,      /* FileNotFoundError: weights / manifest carrier missing            */
+    ADE_ERR_MISSING_KEY = 2,    /* KeyError: required metadata key or weight tensor absent          */
+    ADE_ERR_SHAPE_MISMATCH = 3, /* ValueError: length / channel / tensor-shape disagreement         */
+    ADE_ERR_BAD_VALUE = 4,      /* ValueError: malformed value (bad bool, bad blob, bad argument)   */
+    ADE_ERR_DEVICE = 5,         /* no usable gfx950 device / HIP runtime failure (no CPU fallback)  */
+    ADE_ERR_UNSUPPORTED = 6     /* model family or configuration this build does not implement      */
+} ade_status;
+
+typedef struct ade_engine* ade_handle;
+
+/* What session.get_inputs()/get_outputs() report for the bound tensors (Inference_GTCRN_ONNX.py:262-267,276-277). */
+typedef struct ade_io_desc {
+    int32_t abi_version;
+    int32_t in_channels;       /* 1 */
+    int32_t out_channels;      /* 1 */
+    int32_t n_outputs;         /* 1 ("denoised_audio") */
+    int32_t in_len;            /* L: static input length in samples                      */
+    int32_t out_len;           /* L_out = 256 * (L / 256): 15872 for L = 16000           */
+    int32_t in_sample_rate;
+    int32_t out_sample_rate;
+    int32_t model_sample_rate;
+    int32_t frames;            /* T = L / hop + 1 (Export_GTCRN.py:45)                    */
+    int32_t max_batch;         /* rows the current workspace holds without re-allocation */
+    int32_t device;            /* HIP device ordinal                                      */
+} ade_io_desc;
+
+/* Replaces onnxruntime.InferenceSession(model) + load_runtime_metadata/validate_audio_metadata
+ * (Inference_GTCRN_ONNX.py:237-239).  `manifest_json`: flat JSON object of string values carrying the reference's
+ * metadata key set (audio_onnx_metadata.py:161-203); `weights`: ADEWGT01 blob of the BN-folded tensors under the
+ * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode). */
+ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device,
+                      ade_handle* out);
+
+/* Replaces session.get_inputs()/get_outputs() shape queries. */
+ade_status ade_get_io(ade_handle h, ade_io_desc* desc);
+
+/* Replaces one (or B) `_update_ortvalue + run_with_iobinding + output copy` rounds
+ * (Inference_GTCRN_ONNX.py:314-317) on caller-owned HOST buffers.  Synchronous.
+ *   in        [B][in_len] int16 ;  out_pcm [B][out_len] int16 ;
+ *   out_f32   optional [B][out_len] float: the waveform before the x32767/clamp/truncate tail (parity tap). */
+ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32);
+
+/* Same call on DEVICE buffers (what a GPU execution provider's io-binding does, Inference_GTCRN_ONNX.py:69-92,
+ * 193-198): enqueues on `hip_stream` (a hipStream_t, NULL = the engine's own stream) and returns without
+ * synchronising when a stream is given. */
+ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int16_t* d_out_pcm, float* d_out_f32,
+                              void* hip_stream);
+
+/* Grow the workspace so `batch` rows run without allocation inside the timed path. */
+ade_status ade_reserve(ade_handle h, int batch);
+
+/* Options: "graph" = "0"/"1" replay the launch sequence from a captured hipGraph (default 1). */
+ade_status ade_set_option(ade_handle h, const char* key, const char* value);
+
+/* Parity taps: copy a named intermediate of the LAST processed batch to host (engine-native layout, see
+ * DESIGN.md "Data layout").  `count` = capacity of `out` in floats; `*written` = floats copied. */
+ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t count, size_t* written);
+
+/* Timing tap: average device time (ms) of the kernels launched by the last ade_process_device/ade_process call,
+ * measured with hipEvents on the stream the kernels ran on.  Index by ade_kernel_name(i); returns count. */
+int ade_kernel_count(ade_handle h);
+const char* ade_kernel_name(ade_handle h, int index);
+ade_status ade_profile_last(ade_handle h, int enable);
+ade_status ade_kernel_ms(ade_handle h, int index, float* total_ms, int* launches);
+
+/* Message of the last failing call on this handle (or of ade_create when h == NULL). */
+const char* ade_last_error(ade_handle h);
+
+void ade_destroy(ade_handle h);
+
+/* ---- STFT_Process operator (GTCRN/STFT_Process.py:129-341), FFT-based, on device buffers -----------------
+ * stft_B packed:  x [B][L] float -> spec [B][2*(n_fft/2+1)][T]   (reference layout, re rows then im rows)
+ * istft_B packed: spec [B][2F][T] -> y [B][hop*(T-1)] (center_pad=True, static_norm=True).
+ * This build implements n_fft = 512, hop = 256, window "hann_sqrt", center pad, reflect. */
+ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
+ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADE_H */

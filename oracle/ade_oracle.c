@@ -152,22 +152,28 @@ static int build_window(float* w, int win_length, int n_fft, const char* type) {
 
 /* _build_stft_kernels (GTCRN/STFT_Process.py:213-227): kernel[(c), n] with c in [0,F) = cos(omega)*w,
  * c in [F,2F) = -sin(omega)*w; omega = fp32(2*pi/N) * f * t evaluated in fp32 BEFORE cos/sin. */
-static void build_stft_kernel(float* k, const float* w, int n_fft) {
+static void build_stft_kernel(float* k, const float* w, int n_fft, int exact) {
     const int F = n_fft / 2 + 1;
     const float omega_factor = (float)(2.0 * M_PI / (double)n_fft);
     for (int f = 0; f < F; ++f) {
         const float wf = omega_factor * (float)f;
         for (int t = 0; t < n_fft; ++t) {
             const float omega = wf * (float)t;
-            k[(size_t)f * n_fft + t] = cosf(omega) * w[t];
-            k[(size_t)(F + f) * n_fft + t] = -sinf(omega) * w[t];
+            float c = cosf(omega), s = sinf(omega);
+            if (exact) { /* test knob: exactly-reduced double angles instead of the reference's fp32 ones */
+                const double a = 2.0 * M_PI * (double)(((long)f * t) % n_fft) / (double)n_fft;
+                c = (float)cos(a);
+                s = (float)sin(a);
+            }
+            k[(size_t)f * n_fft + t] = c * w[t];
+            k[(size_t)(F + f) * n_fft + t] = -s * w[t];
         }
     }
 }
 
 /* _build_istft_kernels (GTCRN/STFT_Process.py:229-251): ((scale*cos)*inv_n)*w and ((scale*-sin)*inv_n)*w,
  * scale = 1 for DC and (even N) Nyquist, 2 otherwise. */
-static void build_istft_kernel(float* k, const float* w, int n_fft) {
+static void build_istft_kernel(float* k, const float* w, int n_fft, int exact) {
     const int F = n_fft / 2 + 1;
     const float omega_factor = (float)(2.0 * M_PI / (double)n_fft);
     const float inv_n = (float)(1.0 / (double)n_fft);
@@ -177,8 +183,14 @@ static void build_istft_kernel(float* k, const float* w, int n_fft) {
         const float wf = omega_factor * (float)f;
         for (int n = 0; n < n_fft; ++n) {
             const float omega = wf * (float)n;
-            k[(size_t)f * n_fft + n] = ((scale * cosf(omega)) * inv_n) * w[n];
-            k[(size_t)(F + f) * n_fft + n] = ((scale * -sinf(omega)) * inv_n) * w[n];
+            float c = cosf(omega), s = sinf(omega);
+            if (exact) {
+                const double a = 2.0 * M_PI * (double)(((long)f * n) % n_fft) / (double)n_fft;
+                c = (float)cos(a);
+                s = (float)sin(a);
+            }
+            k[(size_t)f * n_fft + n] = ((scale * c) * inv_n) * w[n];
+            k[(size_t)(F + f) * n_fft + n] = ((scale * -s) * inv_n) * w[n];
         }
     }
 }
@@ -249,7 +261,7 @@ int ade_oracle_stft(const float* x, int B, int L, int n_fft, int win_length, int
     float* w = (float*)malloc(sizeof(float) * (size_t)n_fft);
     if (build_window(w, win_length, n_fft, window)) { free(w); return -1; }
     float* k = (float*)malloc(sizeof(float) * (size_t)2 * F * n_fft);
-    build_stft_kernel(k, w, n_fft);
+    build_stft_kernel(k, w, n_fft, 0);
     const int Lp = center_pad ? L + n_fft : L;
     const int T = (Lp - n_fft) / hop + 1;
     float* xp = (float*)malloc(sizeof(float) * (size_t)(L + n_fft));
@@ -267,7 +279,7 @@ int ade_oracle_istft(const float* spec, int B, int T, int n_fft, int win_length,
     float* w = (float*)malloc(sizeof(float) * (size_t)n_fft);
     if (build_window(w, win_length, n_fft, window)) { free(w); return -1; }
     float* k = (float*)malloc(sizeof(float) * (size_t)2 * F * n_fft);
-    build_istft_kernel(k, w, n_fft);
+    build_istft_kernel(k, w, n_fft, 0);
     const int raw_len = n_fft + hop * (T - 1);
     const int out_start = center_pad ? n_fft / 2 : 0;
     const int out_len = center_pad ? raw_len - n_fft : raw_len;
@@ -659,8 +671,8 @@ int ade_oracle_create(const void* blob, size_t nbytes, int in_len, ade_oracle** 
     build_window(o->window, NFFT, NFFT, "hann_sqrt"); /* Export_GTCRN.py:34 */
     o->stft_kernel = (float*)malloc(sizeof(float) * 2 * FBINS * NFFT);
     o->istft_kernel = (float*)malloc(sizeof(float) * 2 * FBINS * NFFT);
-    build_stft_kernel(o->stft_kernel, o->window, NFFT);
-    build_istft_kernel(o->istft_kernel, o->window, NFFT);
+    build_stft_kernel(o->stft_kernel, o->window, NFFT, 0);
+    build_istft_kernel(o->istft_kernel, o->window, NFFT, 0);
     o->win_sum = (float*)malloc(sizeof(float) * (size_t)o->out_len);
     build_win_sum(o->win_sum, o->window, NFFT, HOP, o->T, NFFT / 2, o->out_len);
     int bad = 0;
@@ -736,6 +748,15 @@ void ade_oracle_destroy(ade_oracle* o) {
     free(o->blob.t);
     free(o->blob.storage);
     free(o);
+}
+
+/* TEST KNOB (not reference behaviour): rebuild the DFT tables from exactly-reduced double-precision angles.  The
+ * reference evaluates cos/sin of fp32 angles up to ~1600 rad (STFT_Process.py:215-222), which makes its own STFT
+ * ~4e-5 relative-inexact; the HIP path uses an exact FFT.  With this knob on, oracle and HIP path agree to fp32
+ * round-off at EVERY tap, which separates kernel bugs from that known table error. */
+void ade_oracle_set_exact_dft(ade_oracle* o, int exact) {
+    build_stft_kernel(o->stft_kernel, o->window, NFFT, exact);
+    build_istft_kernel(o->istft_kernel, o->window, NFFT, exact);
 }
 
 int ade_oracle_in_len(const ade_oracle* o) { return o->in_len; }

@@ -29,6 +29,8 @@ typedef struct ade_oracle ade_oracle;
  * 512/512/256 sqrt-hann STFT tables for a static chunk length `in_len` (T = in_len/256+1). */
 int ade_oracle_create(const void* blob, size_t nbytes, int in_len, ade_oracle** out);
 void ade_oracle_destroy(ade_oracle* o);
+/* test knob: exact (double-angle) DFT tables instead of the reference's fp32-angle tables; see ade_oracle.c */
+void ade_oracle_set_exact_dft(ade_oracle* o, int exact);
 int ade_oracle_in_len(const ade_oracle* o);
 int ade_oracle_out_len(const ade_oracle* o);
 const char* ade_oracle_last_error(void);

@@ -34,6 +34,8 @@ def lib():
         L.ade_oracle_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.ade_oracle_destroy.argtypes = [C.c_void_p]
         L.ade_oracle_destroy.restype = None
+        L.ade_oracle_set_exact_dft.argtypes = [C.c_void_p, C.c_int]
+        L.ade_oracle_set_exact_dft.restype = None
         L.ade_oracle_in_len.argtypes = [C.c_void_p]
         L.ade_oracle_out_len.argtypes = [C.c_void_p]
         L.ade_oracle_last_error.restype = C.c_char_p
@@ -62,6 +64,10 @@ class GtcrnOracle:
         self.in_len = lib().ade_oracle_in_len(self._h)
         self.out_len = lib().ade_oracle_out_len(self._h)
         self.T = self.in_len // 256 + 1
+
+    def set_exact_dft(self, exact: bool):
+        """Test knob: exact DFT tables (NOT the reference's arithmetic) to isolate kernel error from table error."""
+        lib().ade_oracle_set_exact_dft(self._h, int(bool(exact)))
 
     def close(self):
         if self._h:

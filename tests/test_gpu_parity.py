@@ -1,0 +1,133 @@
+"""GPU parity tests proper: the HIP path through the C ABI (libade.so on a real MI355X) vs the CPU oracle and the
+committed reference-generated golden vectors.
+
+Tolerances (north_star: 1e-4 max-abs fp32 vs the reference CPU path):
+  * waveform before the PCM tail: <= 1e-4 vs golden (reference) and vs oracle; observed ~6e-6, which is the reference's
+    own fp32-angle DFT-table error — the HIP path uses an exact FFT;
+  * int16: <= 1 LSB (truncating cast, Export_GTCRN.py:690);
+  * with the oracle's exact-DFT test knob every intermediate tap agrees to fp32 round-off (2e-6 relative).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ade_testlib import GOLD, compare_taps, golden_blob, golden_inputs, make_session
+from audio_denoiser_onnx_amd.synth import synth_batch
+from oracle_lib import GtcrnOracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess0():
+    return make_session(None, seed=0)     # None -> the in-tree gfx950 libade.so; raises if it is missing
+
+
+def test_library_is_the_hip_build(sess0):
+    assert sess0._lib.path.endswith(os.path.join("audio_denoiser_onnx_amd", "libade.so"))
+    assert sess0.get_providers() == ["AdeMI355XExecutionProvider"]
+
+
+def test_taps_vs_oracle_exact_dft(sess0):
+    ins = golden_inputs()
+    pcm_in = np.stack([ins["randn"], ins["wav0"], ins["square_fs"]])
+    pcm, f32 = sess0.process(pcm_in, want_f32=True)
+    o = GtcrnOracle(golden_blob(0), 16000)
+    o.set_exact_dft(True)
+    for row in (1, 2):
+        opcm, of32 = o.process(pcm_in[row:row + 1])
+        res = compare_taps(sess0, o, batch=3, row=row)
+        for name, (err, scale) in res.items():
+            assert err <= 4e-6 * max(1.0, scale) + 4e-6, f"row {row} tap {name}: {err:.3e} (scale {scale:.3g})"
+        assert np.abs(f32[row] - of32[0]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_golden_reference_outputs(seed):
+    outs = np.load(os.path.join(GOLD, f"gtcrn_seed{seed}_outputs.npz"))
+    names = sorted({k.split(".")[0] for k in outs.files})
+    ins = golden_inputs()
+    sess = make_session(None, seed=seed)
+    pcm, f32 = sess.process(np.stack([ins[n] for n in names]), want_f32=True)
+    for i, n in enumerate(names):
+        assert np.abs(f32[i] - outs[f"{n}.wave_f32"]).max() <= 1e-4, n
+        assert np.abs(pcm[i].astype(np.int32) - outs[f"{n}.pcm_out"].astype(np.int32)).max() <= 1, n
+    if seed == 0:
+        z = names.index("zeros")
+        assert not pcm[z].any()
+
+
+def test_length_32000_golden():
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_len32000.npz"))
+    sess = make_session(None, seed=0, length=32000)
+    assert (sess.in_len, sess.out_len, sess.frames) == (32000, 32000, 126)
+    pcm, f32 = sess.process(g["pcm_in"][None], want_f32=True)
+    assert np.abs(f32[0] - g["wave_f32"]).max() <= 1e-4
+    assert np.abs(pcm[0].astype(np.int32) - g["pcm_out"].astype(np.int32)).max() <= 1
+
+
+def test_full_batch_256_properties_and_oracle_sample(sess0):
+    x = synth_batch(256)
+    pcm, f32 = sess0.process(x, want_f32=True)
+    assert pcm.shape == (256, 15872)
+    # rows are independent reference calls: any sub-batch reproduces its rows bit-for-bit (deterministic kernels)
+    sub, sub32 = sess0.process(x[37:41], want_f32=True)
+    assert np.array_equal(sub, pcm[37:41]) and np.array_equal(sub32, f32[37:41])
+    # permutation equivariance over the batch axis
+    perm = np.random.default_rng(0).permutation(256)
+    pp, _ = sess0.process(x[perm])
+    assert np.array_equal(pp, pcm[perm])
+    # oracle on a sample of rows (the oracle is too slow for all 256 in a unit test)
+    rows = [0, 1, 63, 64, 128, 200, 255]
+    opcm, of32 = GtcrnOracle(golden_blob(0), 16000).process(x[rows], threads=4)
+    assert np.abs(f32[rows] - of32).max() <= 1e-4
+    assert np.abs(pcm[rows].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+    assert np.isfinite(f32).all()
+
+
+def test_device_buffers_graph_and_plain_launch_agree(sess0):
+    import torch
+    x = torch.from_numpy(synth_batch(8)).cuda()
+    out_a = torch.empty((8, 15872), dtype=torch.int16, device="cuda")
+    out_b = torch.empty_like(out_a)
+    sess0.set_option("graph", "1")
+    sess0.run_device(x, out_a)
+    sess0.run_device(x, out_a)            # second call replays the captured graph
+    sess0.set_option("graph", "0")
+    sess0.run_device(x, out_b)
+    sess0.set_option("graph", "1")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    ref, _ = sess0.process(x.cpu().numpy())
+    assert np.array_equal(out_a.cpu().numpy(), ref)
+
+
+def test_stft_process_operator():
+    import torch
+    from oracle_lib import oracle_istft, oracle_stft
+    sess = make_session(None, seed=0)
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal((3, 16000)).astype(np.float32)
+    dx = torch.from_numpy(x).cuda()
+    dspec = torch.empty((3, 514, 63), dtype=torch.float32, device="cuda")
+    sess.stft_device(dx, dspec)
+    ref = oracle_stft(x, 512, 512, 256, "hann_sqrt")
+    assert np.abs(dspec.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()     # reference table error (H1)
+    dy = torch.empty((3, 15872), dtype=torch.float32, device="cuda")
+    sess.istft_device(dspec, dy)
+    y = dy.cpu().numpy()
+    assert np.abs(y - x[:, :15872]).max() <= 2e-5                                   # STFT -> ISTFT round trip
+    yref = oracle_istft(ref, 512, 512, 256, "hann_sqrt")
+    assert np.abs(y - yref).max() <= 1e-4
+
+
+def test_kernel_profile_tap(sess0):
+    sess0.profile(True)
+    sess0.process(synth_batch(4))
+    sess0.profile(False)
+    kt = sess0.kernel_times()
+    assert set(kt) >= {"stft_feat", "conv0", "gt_pw1", "gt_dw_pw2", "tra_gru", "intra_gru", "inter_gru", "fc_ln_res",
+                       "deconv3", "deconv4", "istft_mask", "ola_pcm"}
+    assert kt["gt_pw1"]["launches"] == 6 and kt["fc_ln_res"]["launches"] == 4
+    assert all(v["ms"] > 0 for v in kt.values())

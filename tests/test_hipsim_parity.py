@@ -1,0 +1,52 @@
+"""Kernel logic under the host-side HIP simulator vs the oracle (CPU, test-only build of csrc/*.hip).
+
+This does NOT exercise the product library: it compiles the same kernel and engine sources with g++ against
+tests/hipsim (fibers per HIP thread) so that indexing / barrier / shuffle data-flow bugs are caught before GPU time
+is spent.  The GPU parity tests proper are in test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from ade_testlib import compare_taps, golden_blob, golden_inputs, hipsim_library, make_session
+from oracle_lib import GtcrnOracle
+
+pytestmark = pytest.mark.hipsim
+
+
+@pytest.fixture(scope="module")
+def simlib():
+    return hipsim_library()
+
+
+def test_hipsim_taps_and_waveform(simlib):
+    ins = golden_inputs()
+    sess = make_session(simlib, seed=0)
+    pcm_in = np.stack([ins["randn"], ins["wav0"]])
+    pcm, f32 = sess.process(pcm_in, want_f32=True)
+    o = GtcrnOracle(golden_blob(0), 16000)
+    # (1) against the oracle with the reference's own (fp32-angle) DFT table: the documented 1e-4 contract
+    opcm, of32 = o.process(pcm_in)
+    assert np.abs(f32 - of32).max() <= 1e-4
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+    # (2) against the oracle with exact DFT tables: every tap to fp32 round-off (isolates kernel error)
+    o.set_exact_dft(True)
+    opcm, of32 = o.process(pcm_in[1:2])
+    res = compare_taps(sess, o, batch=2, row=1)
+    for name, (err, scale) in res.items():
+        assert err <= 2e-6 * max(1.0, scale) + 4e-6, f"{name}: {err:.3e} (scale {scale:.3g})"
+    assert np.abs(f32[1] - of32[0]).max() <= 5e-6
+
+
+def test_hipsim_edge_inputs_and_batch_tail(simlib):
+    ins = golden_inputs()
+    sess = make_session(simlib, seed=1)
+    names = ["zeros", "impulse15999", "dc_min"]          # B=3: frame count not a multiple of the 4-frame workgroup
+    pcm_in = np.stack([ins[n] for n in names])
+    pcm, f32 = sess.process(pcm_in, want_f32=True)
+    o = GtcrnOracle(golden_blob(1), 16000)
+    opcm, of32 = o.process(pcm_in)
+    assert np.abs(f32 - of32).max() <= 1e-4
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+    assert not pcm[0].any() and not pcm[2].any()        # silence and pure DC come out exactly silent
+    empty, _ = sess.process(np.zeros((0, 16000), np.int16))
+    assert empty.shape == (0, 15872)
