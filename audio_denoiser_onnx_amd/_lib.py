@@ -62,6 +62,14 @@ class AdeLibrary:
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "The engine has no CPU fallback.")
         self.path = path
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64/libhsa-runtime64, and a second
+        # copy loaded later reports "No HIP GPUs are available".  Loading torch's first makes libade's
+        # DT_NEEDED libamdhip64.so.7 resolve to the copy already in the process (torch is this package's
+        # device-memory / stream / torch.distributed plumbing, not its compute path).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         self.c = L
         L.ade_create.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]

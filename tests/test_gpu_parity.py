@@ -50,9 +50,18 @@ def test_golden_reference_outputs(seed):
     ins = golden_inputs()
     sess = make_session(None, seed=seed)
     pcm, f32 = sess.process(np.stack([ins[n] for n in names]), want_f32=True)
+    o = GtcrnOracle(golden_blob(seed), 16000)
+    o.set_exact_dft(True)
     for i, n in enumerate(names):
         assert np.abs(f32[i] - outs[f"{n}.wave_f32"]).max() <= 1e-4, n
-        assert np.abs(pcm[i].astype(np.int32) - outs[f"{n}.pcm_out"].astype(np.int32)).max() <= 1, n
+        # int16 vs the reference: 1 LSB at realistic levels; the full-scale square (|X| up to ~300) carries the
+        # reference's own DFT-table error of up to 1e-4 in the waveform = 3.3 LSB, so allow ceil(1e-4 * 32767) = 4 there
+        lim = 4 if n == "square_fs" else 1
+        assert np.abs(pcm[i].astype(np.int32) - outs[f"{n}.pcm_out"].astype(np.int32)).max() <= lim, n
+        # ... and with exact DFT tables in the oracle the same input is within 1 LSB / 1e-5: the gap is the table, not the kernels
+        opcm, of32 = o.process(ins[n])
+        assert np.abs(f32[i] - of32[0]).max() <= 1e-5, n
+        assert np.abs(pcm[i].astype(np.int32) - opcm[0].astype(np.int32)).max() <= 1, n
     if seed == 0:
         z = names.index("zeros")
         assert not pcm[z].any()
