@@ -1,0 +1,67 @@
+// ade_device.h — small device-side helpers shared by the gfx950 kernel translation units.
+#pragma once
+
+#include "ade_internal.h"
+
+namespace ade {
+namespace dev {
+
+// sigmoid / tanh on the hardware exp and reciprocal units (v_exp_f32, v_rcp_f32: ~1 ulp each); the network's
+// gates only need ~1e-6 absolute accuracy (parity tolerance 1e-4 on the waveform, observed ~1e-6).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) {
+    // 1 - 2/(e^{2x}+1): saturates cleanly to +-1 for large |x|
+    return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
+
+__device__ __forceinline__ void ld4(const float* p, float* v) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+__device__ __forceinline__ void ld8(const float* p, float* v) { ld4(p, v); ld4(p + 4, v + 4); }
+__device__ __forceinline__ void ld16(const float* p, float* v) { ld8(p, v); ld8(p + 8, v + 8); }
+__device__ __forceinline__ void st4(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st16(float* p, const float* v) { st4(p, v); st4(p + 4, v + 4); st4(p + 8, v + 8); st4(p + 12, v + 12); }
+
+// channels [0,8) of a (possibly gated) activation at position `pos` of frame `frame`
+__device__ __forceinline__ void view_ld8_lo(const View& a, size_t pos, size_t frame, float* v) {
+    ld8(a.x + pos * kCh, v);
+    if (a.at) {
+        float g[4];
+        ld4(a.at + frame * 8, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[2 * i] *= g[i];
+    }
+}
+// channels [8,16)
+__device__ __forceinline__ void view_ld8_hi(const View& a, size_t pos, size_t frame, float* v) {
+    ld8(a.x + pos * kCh + 8, v);
+    if (a.at) {
+        float g[4];
+        ld4(a.at + frame * 8 + 4, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[2 * i] *= g[i];
+    }
+}
+__device__ __forceinline__ void view_ld16(const View& a, size_t pos, size_t frame, float* v) {
+    view_ld8_lo(a, pos, frame, v);
+    view_ld8_hi(a, pos, frame, v + 8);
+}
+
+// DPP cross-lane moves (one VALU op, no LDS round trip).  CTRL: quad_perm = p0|p1<<2|p2<<4|p3<<6 ; row_newbcast:n = 0x150+n
+// (gfx90a+: lane n of each 16-lane row to the whole row).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int K> __device__ __forceinline__ float row_bcast(float v) { return dpp_mov<0x150 + K>(v); }    // K < 16
+template <int K> __device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(v); }   // K < 4
+
+inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
+
+}  // namespace dev
+}  // namespace ade

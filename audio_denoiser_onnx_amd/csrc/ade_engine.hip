@@ -80,6 +80,8 @@ struct ade_engine {
 
     bool use_graph = true;
     bool graph_supported = true;
+    bool use_fused = true;      // per-chunk LDS-resident stage kernels when T <= 64 (ade_fused.hip)
+    bool last_fused = false;
     std::vector<GraphEntry> graphs;
 
     bool profile = false;
@@ -607,6 +609,23 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
     q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
     View x{e->e1, nullptr};
+    const bool fused = e->use_fused && fused_supported(T);
+    e->last_fused = fused;
+    if (fused) {
+        // one workgroup per chunk per stage, activations LDS-resident; gates applied inside, so every tensor is plain
+        for (int i = 0; i < 3; ++i) {
+            q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T); q.end();
+            x = View{e->xe[i], nullptr};
+        }
+        for (int i = 0; i < 2; ++i) {
+            q.begin("dpgrnn"); launch_dpgrnn(s, x.x, e->dp[i], e->dpo[i], B, T); q.end();
+            x = View{e->dpo[i], nullptr};
+        }
+        for (int i = 0; i < 3; ++i) {
+            q.begin("gtblock"); launch_gtblock(s, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T); q.end();
+            x = View{e->xd[i], nullptr};
+        }
+    } else {
     for (int i = 0; i < 3; ++i) {   // Encoder GTConvBlocks (Export_GTCRN.py:502-504)
         q.begin("gt_pw1"); launch_gt_pw1(s, x, none, e->en_gt[i], e->h, nfr); q.end();
         q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, none, e->en_gt[i], e->xe[i], e->zt, B, T); q.end();
@@ -628,6 +647,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, skip, e->de_gt[i], e->xd[i], e->zt, B, T); q.end();
         q.begin("tra_gru"); launch_tra(s, e->zt, e->de_gt[i], e->atd[i], B, T); q.end();
         x = View{e->xd[i], e->atd[i]};
+    }
     }
     q.begin("deconv3"); launch_deconv3(s, x, View{e->e1, nullptr}, e->de3, e->d3, nfr); q.end();
     q.begin("deconv4"); launch_deconv4(s, e->d3, e->e0, e->de4, e->mask, nfr); q.end();
@@ -770,6 +790,10 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
     st = build_device_constants(e);
     if (st != ADE_OK) return bail(st);
+    if (fused_init() != hipSuccess) {
+        (void)hipGetLastError();
+        e->use_fused = false;   // keep the multi-kernel path if the 140 KB dynamic-LDS request is refused
+    }
     e->blob_storage.clear();
     e->blob_storage.shrink_to_fit();
     e->tensors.clear();
@@ -801,10 +825,12 @@ ade_status ade_reserve(ade_handle h, int batch) {
 
 ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
     if (!h || !key || !value) return ADE_ERR_BAD_VALUE;
-    if (strcmp(key, "graph") == 0) {
+    if (strcmp(key, "graph") == 0 || strcmp(key, "fused") == 0) {
         bool b;
-        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, "option graph must be 0/1");
-        h->use_graph = b;
+        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, std::string("option ") + key + " must be 0/1");
+        if (key[0] == 'g') h->use_graph = b;
+        else h->use_fused = b;
+        free_graphs(h);
         return ADE_OK;
     }
     return fail(h, ADE_ERR_MISSING_KEY, std::string("unknown option: ") + key);
@@ -863,7 +889,10 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
             if (count < t.n) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
             HIP_TRY(h, hipSetDevice(h->device));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
-            HIP_TRY(h, hipMemcpy(out, t.p, t.n * sizeof(float), hipMemcpyDeviceToHost));
+            if (h->last_fused && strncmp(name, "at_", 3) == 0)
+                for (size_t i = 0; i < t.n; ++i) out[i] = 1.0f;   // fused stages apply the TRA gate in-kernel: x_* is already gated
+            else
+                HIP_TRY(h, hipMemcpy(out, t.p, t.n * sizeof(float), hipMemcpyDeviceToHost));
             *written = t.n;
             return ADE_OK;
         }

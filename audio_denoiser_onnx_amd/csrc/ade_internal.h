@@ -101,4 +101,10 @@ void launch_istft_masked(hipStream_t s, const float* spec, const float* mask, Ba
 void launch_istft_ref(hipStream_t s, const float* ref_spec, int B, int T, FftTabs tabs, float* frames);
 void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int T, int16_t* pcm, float* f32);
 
+// ---- per-chunk LDS-resident stage kernels (ade_fused.hip); valid for T <= 64 frames -------------------------
+bool fused_supported(int T);
+hipError_t fused_init();   // raises the dynamic-LDS limit of the stage kernels (once per process/device)
+void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T);
+void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T);
+
 }  // namespace ade

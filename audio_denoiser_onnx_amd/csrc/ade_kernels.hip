@@ -11,55 +11,13 @@
 //  * STFT/ISTFT are 512-point real FFTs done as a packed 256-point radix-4 Stockham FFT, one wavefront per
 //    frame, twiddles/window from small L2-resident tables, butterflies exchanged through LDS.
 // Reference arithmetic being reproduced is cited per kernel (paths relative to the reference repo).
-#include "ade_internal.h"
+#include "ade_device.h"
 
 namespace ade {
 
+using namespace dev;
+
 namespace {
-
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_f(float x) {
-    // 1 - 2/(e^{2x}+1): saturates cleanly to +-1, abs error ~1e-7
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
-}
-__device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
-
-__device__ __forceinline__ void ld4(const float* p, float* v) {
-    const float4 q = *reinterpret_cast<const float4*>(p);
-    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-}
-__device__ __forceinline__ void ld8(const float* p, float* v) { ld4(p, v); ld4(p + 4, v + 4); }
-__device__ __forceinline__ void ld16(const float* p, float* v) { ld8(p, v); ld8(p + 8, v + 8); }
-__device__ __forceinline__ void st4(float* p, const float* v) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void st16(float* p, const float* v) { st4(p, v); st4(p + 4, v + 4); st4(p + 8, v + 8); st4(p + 12, v + 12); }
-
-// channels [0,8) of a (possibly gated) activation at position `pos` of frame `frame`
-__device__ __forceinline__ void view_ld8_lo(const View& a, size_t pos, size_t frame, float* v) {
-    ld8(a.x + pos * kCh, v);
-    if (a.at) {
-        float g[4];
-        ld4(a.at + frame * 8, g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[2 * i] *= g[i];
-    }
-}
-// channels [8,16)
-__device__ __forceinline__ void view_ld8_hi(const View& a, size_t pos, size_t frame, float* v) {
-    ld8(a.x + pos * kCh + 8, v);
-    if (a.at) {
-        float g[4];
-        ld4(a.at + frame * 8 + 4, g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[2 * i] *= g[i];
-    }
-}
-__device__ __forceinline__ void view_ld16(const View& a, size_t pos, size_t frame, float* v) {
-    view_ld8_lo(a, pos, frame, v);
-    view_ld8_hi(a, pos, frame, v + 8);
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // F1 (part): per-chunk DC mean.  Export_GTCRN.py:645-647 — mean over THIS call's samples after the 2^-15 scale.
@@ -746,8 +704,6 @@ __global__ __launch_bounds__(256) void k_ola_pcm(const float* __restrict__ frame
         *reinterpret_cast<short4*>(pcm + o) = make_short4(q[0], q[1], q[2], q[3]);
     }
 }
-
-inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace
 

@@ -105,6 +105,22 @@ static inline T __shfl_up(T v, unsigned d, int width = 64) {
 
 #define __expf(x) expf(x)   /* glibc declares extern __expf/__logf itself */
 #define __logf(x) logf(x)
+// DPP (data-parallel primitives) emulation: quad_perm (ctrl 0x00-0xFF) and row_newbcast:n (0x150+n, gfx90a+).
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const int lane = ::hipsim::lane_id();
+    int from;
+    if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl >= 0x150 && ctrl <= 0x15F) from = (lane & ~15) | (ctrl & 15);
+    else { fprintf(stderr, "hipsim: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
+    return (int)::hipsim::wave_exchange((uint32_t)src, from);
+}
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
+static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }
+namespace hipsim { extern unsigned char dyn_smem[]; }
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hipsim::dyn_smem);
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float __fsqrt_rn(float a) { return sqrtf(a); }
@@ -175,6 +191,8 @@ hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphExecDestroy(hipGraphExec_t e);
 }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 
 template <typename... KArgs, typename... Args>
 static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/,

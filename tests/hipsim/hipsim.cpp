@@ -11,6 +11,7 @@
 namespace hipsim {
 
 ThreadState* cur = nullptr;
+alignas(64) unsigned char dyn_smem[160 * 1024];
 dim3 cur_block, cur_bdim, cur_gdim;
 
 namespace {
