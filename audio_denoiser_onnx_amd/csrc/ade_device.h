@@ -61,6 +61,30 @@ __device__ __forceinline__ float dpp_mov(float v) {
 template <int K> __device__ __forceinline__ float row_bcast(float v) { return dpp_mov<0x150 + K>(v); }    // K < 16
 template <int K> __device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(v); }   // K < 4
 
+// Wave-uniform, read-only tables (conv / Linear weights): viewing them through the CONSTANT address space lets the
+// compiler fetch them with scalar loads (s_load through the scalar cache -> SGPR operands of v_fma) even when the
+// pointer arrived inside a by-value struct, where no __restrict__/noalias information survives and the loads would
+// otherwise become per-lane global_loads (and, hoisted out of loops, spill to scratch).  The engine never writes the
+// weight arena while a kernel runs, which is what the constant address space asserts.
+#if defined(__has_attribute)
+#if __has_attribute(address_space)
+#define ADE_CONSTANT_AS __attribute__((address_space(4)))
+#endif
+#endif
+#ifndef ADE_CONSTANT_AS
+#define ADE_CONSTANT_AS
+#endif
+// Optimisation barrier on a (wave-uniform) pointer: the compiler must treat it as changed, so loads through it stay
+// inside the loop iteration that uses them instead of being hoisted out as 300+ live SGPRs (which then spill to
+// VGPR lanes, one v_readlane per use).  Emits no instruction.
+#if defined(__AMDGCN__)
+#define ADE_KEEP_IN_LOOP(p) asm volatile("" : "+s"(p))
+#else
+#define ADE_KEEP_IN_LOOP(p) ((void)0)
+#endif
+typedef const float ADE_CONSTANT_AS* cfptr;
+__device__ __forceinline__ cfptr cptr(const float* p) { return (cfptr)p; }
+
 inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace dev

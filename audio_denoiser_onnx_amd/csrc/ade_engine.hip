@@ -82,6 +82,7 @@ struct ade_engine {
     bool graph_supported = true;
     bool use_fused = true;      // per-chunk LDS-resident stage kernels when T <= 64 (ade_fused.hip)
     bool last_fused = false;
+    long long* d_clk = nullptr;   // 64 phase-clock slots (profile mode only)
     std::vector<GraphEntry> graphs;
 
     bool profile = false;
@@ -477,6 +478,8 @@ ade_status build_device_constants(ade_engine* e) {
     std::vector<int> ints(bm_start);
     ints.insert(ints.end(), bs_start.begin(), bs_start.end());
     HIP_TRY(e, hipMalloc((void**)&e->d_ints, ints.size() * sizeof(int)));
+    HIP_TRY(e, hipMalloc((void**)&e->d_clk, 64 * sizeof(long long)));
+    HIP_TRY(e, hipMemset(e->d_clk, 0, 64 * sizeof(long long)));
     HIP_TRY(e, hipMemcpy(e->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const float* W = e->d_weights;
     e->tabs.win = W + o_win;
@@ -614,15 +617,15 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     if (fused) {
         // one workgroup per chunk per stage, activations LDS-resident; gates applied inside, so every tensor is plain
         for (int i = 0; i < 3; ++i) {
-            q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T); q.end();
+            q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->xe[i], nullptr};
         }
         for (int i = 0; i < 2; ++i) {
-            q.begin("dpgrnn"); launch_dpgrnn(s, x.x, e->dp[i], e->dpo[i], B, T); q.end();
+            q.begin("dpgrnn"); launch_dpgrnn(s, x.x, e->dp[i], e->dpo[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->dpo[i], nullptr};
         }
         for (int i = 0; i < 3; ++i) {
-            q.begin("gtblock"); launch_gtblock(s, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T); q.end();
+            q.begin("gtblock"); launch_gtblock(s, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T, nullptr); q.end();
             x = View{e->xd[i], nullptr};
         }
     } else {
@@ -883,6 +886,14 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         {"rnn", h->rnn, nfr * kFw * kCh}, {"dp1_mid", h->dpm[0], nfr * kFw * kCh}, {"dp1", h->dpo[0], nfr * kFw * kCh},
         {"dp2_mid", h->dpm[1], nfr * kFw * kCh}, {"dp2", h->dpo[1], nfr * kFw * kCh}, {"d3", h->d3, nfr * kF1 * kCh},
         {"mask", h->mask, nfr * 2 * kErbPad}, {"frames", h->frames, nfr * kNfft}};
+    if (strcmp(name, "phase_clock") == 0) {   // wall_clock64() stamps of workgroup 0's phases (profile mode), as tick deltas
+        if (count < 64) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+        long long raw[64];
+        HIP_TRY(h, hipMemcpy(raw, h->d_clk, sizeof raw, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 64; ++i) out[i] = (float)(raw[i] - raw[(i / 16) * 16]);
+        *written = 64;
+        return ADE_OK;
+    }
     for (const Tap& t : taps)
         if (strcmp(t.name, name) == 0) {
             if (!t.p || t.n == 0) return fail(h, ADE_ERR_NOT_FOUND, "tap has no data yet");
@@ -928,6 +939,7 @@ void ade_destroy(ade_handle h) {
     }
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_ints) hipFree(h->d_ints);
+    if (h->d_clk) hipFree(h->d_clk);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }

@@ -36,8 +36,11 @@ constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
 
 #define ADE_REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
+// Optional phase clocks: when `clk` is non-null, thread 0 of workgroup 0 stamps wall_clock64() at each phase boundary.
+#define ADE_CLK(i) do { if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restrict__ a, const float* __restrict__ skip, GtConvW w,
-                                                           float* __restrict__ out, int T) {
+                                                           float* __restrict__ out, int T, long long* __restrict__ clk) {
     HIP_DYNAMIC_SHARED(float4, smem)
     float4* H = smem;
     float* zt = reinterpret_cast<float*>(smem + 4 * kPmax);
@@ -47,13 +50,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
     const int P = T * kFw;
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * P;
+    const cfptr c_pw1_b = cptr(w.pw1_b), c_dw_b = cptr(w.dw_b), c_pw2_b = cptr(w.pw2_b);
+    ADE_CLK(0);
 
     // ---- phase 1: (a + skip)[:, :8] -> SFE(3) -> 1x1 (24->16) + BN + PReLU -> H (LDS)         (:305-310)
     for (int p = tid; p < P; p += kFusedThreads) {
         const int t = p / kFw, f = p - t * kFw;
+        cfptr c_pw1 = cptr(w.pw1);
+        ADE_KEEP_IN_LOOP(c_pw1);
         float acc[16];
 #pragma unroll
-        for (int co = 0; co < 16; ++co) acc[co] = w.pw1_b[co];
+        for (int co = 0; co < 16; ++co) acc[co] = c_pw1_b[co];
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             const int ff = f - 1 + o;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
 #pragma unroll
             for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int co = 0; co < 16; ++co) acc[co] += w.pw1[(c * 3 + o) * 16 + co] * x[c];
+                for (int co = 0; co < 16; ++co) acc[co] += c_pw1[(c * 3 + o) * 16 + co] * x[c];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -81,6 +88,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
                                            prelu_f(acc[4 * q + 2], w.pw1_slope), prelu_f(acc[4 * q + 3], w.pw1_slope));
     }
     __syncthreads();
+    ADE_CLK(1);
 
     // ---- phase 2: causal dilated depthwise 3x3 + BN + PReLU -> 1x1 (16->8) + BN -> h1 (registers)   (:311-320)
     float h1r[kPosPerThread][8];
@@ -89,9 +97,12 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         const int p = tid + i * kFusedThreads;
         if (p < P) {
             const int t = p / kFw, f = p - t * kFw;
+            cfptr c_dw = cptr(w.dw), c_pw2 = cptr(w.pw2);   // per-copy opaque pointers: no cross-copy SGPR hoarding
+            ADE_KEEP_IN_LOOP(c_dw);
+            ADE_KEEP_IN_LOOP(c_pw2);
             float acc[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = w.dw_b[c];
+            for (int c = 0; c < 16; ++c) acc[c] = c_dw_b[c];
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 const int tt = t - (2 - kt) * w.dilation;
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 x = H[q * kPmax + pp];
-                        const float* wq = w.dw + (kt * 3 + kf) * 16 + 4 * q;
+                        const cfptr wq = c_dw + (kt * 3 + kf) * 16 + 4 * q;
                         acc[4 * q] += wq[0] * x.x; acc[4 * q + 1] += wq[1] * x.y;
                         acc[4 * q + 2] += wq[2] * x.z; acc[4 * q + 3] += wq[3] * x.w;
                     }
@@ -113,14 +124,15 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[c] = prelu_f(acc[c], w.dw_slope);
 #pragma unroll
-            for (int co = 0; co < 8; ++co) h1r[i][co] = w.pw2_b[co];
+            for (int co = 0; co < 8; ++co) h1r[i][co] = c_pw2_b[co];
 #pragma unroll
             for (int ci = 0; ci < 16; ++ci)
 #pragma unroll
-                for (int co = 0; co < 8; ++co) h1r[i][co] += w.pw2[ci * 8 + co] * acc[ci];
+                for (int co = 0; co < 8; ++co) h1r[i][co] += c_pw2[ci * 8 + co] * acc[ci];
         }
     }
     __syncthreads();   // every tap read of H is done: planes may be reused
+    ADE_CLK(2);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
@@ -130,6 +142,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         }
     }
     __syncthreads();
+    ADE_CLK(3);
 
     // ---- phase 3: TRA energy zt[t][c] = mean_f h1^2                                           (:154)
     for (int idx = tid; idx < T * 8; idx += kFusedThreads) {
@@ -143,6 +156,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         zt[idx] = s / (float)kFw;
     }
     __syncthreads();
+    ADE_CLK(4);
     // ---- phase 4a: GRU input projections for every t at once: GI[t][g*16+j] = b_ih + W_ih zt[t]
     for (int idx = tid; idx < T * 48; idx += kFusedThreads) {
         const int t = idx / 48, r = idx - t * 48;
@@ -154,6 +168,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         GI[idx] = s;
     }
     __syncthreads();
+    ADE_CLK(5);
     // ---- phase 4b: the serial part, GRU(8->16) over T on one 16-lane row (all four rows of wave 0 run it redundantly;
     //      h exchanged with row_newbcast DPP)                                                    (:149,155)
     if (tid < 64) {
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         }
     }
     __syncthreads();
+    ADE_CLK(6);
     // ---- phase 4c: at[t][c] = sigmoid(Linear(16->8)(h_t))                                      (:155)
     for (int idx = tid; idx < T * 8; idx += kFusedThreads) {
         const int t = idx >> 3, c = idx & 7;
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         at[idx] = sigmoid_f(s);
     }
     __syncthreads();
+    ADE_CLK(7);
     // ---- phase 5: gate, interleave with the bypass half, store                                 (:156,324)
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
@@ -210,6 +227,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
             st16(out + (base + p) * kCh, o);
         }
     }
+    ADE_CLK(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -226,6 +244,7 @@ constexpr size_t kDpSmemBytes = (size_t)4 * kPmax * 16 + (size_t)kPmax * 4 + 2 *
 __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* stat, const float* __restrict__ fc,
                                             const float* __restrict__ fc_b, const float* __restrict__ ln_w,
                                             const float* __restrict__ ln_b, int T, int P, int tid, float (*v)[16]) {
+    const cfptr c_fc_b = cptr(fc_b);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
@@ -236,12 +255,14 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
                 const float4 x = R[q * kPmax + p];
                 r[4 * q] = x.x; r[4 * q + 1] = x.y; r[4 * q + 2] = x.z; r[4 * q + 3] = x.w;
             }
+            cfptr c_fc = cptr(fc);
+            ADE_KEEP_IN_LOOP(c_fc);
 #pragma unroll
-            for (int co = 0; co < 16; ++co) v[i][co] = fc_b[co];
+            for (int co = 0; co < 16; ++co) v[i][co] = c_fc_b[co];
 #pragma unroll
             for (int k = 0; k < 16; ++k)
 #pragma unroll
-                for (int co = 0; co < 16; ++co) v[i][co] += fc[k * 16 + co] * r[k];
+                for (int co = 0; co < 16; ++co) v[i][co] += c_fc[k * 16 + co] * r[k];
             float s = 0.0f;
 #pragma unroll
             for (int co = 0; co < 16; ++co) s += v[i][co];
@@ -288,7 +309,8 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
     }
 }
 
-__global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restrict__ x, DpW w, float* __restrict__ out, int T) {
+__global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restrict__ x, DpW w, float* __restrict__ out, int T,
+                                                          long long* __restrict__ clk) {
     HIP_DYNAMIC_SHARED(float4, smem)
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * P;
 
+    ADE_CLK(16);
     // ---- phase A: intra GRNN.  16 lanes per frame: lane = group*8 + dir*4 + unit (== output channel); GRU(8->4)
     //      along F, hidden exchanged inside the quad with quad_perm DPP.                          (:441-446,472-473)
     {
@@ -346,6 +369,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
         }
     }
     __syncthreads();
+    ADE_CLK(17);
     // ---- phase B: intra Linear + LayerNorm + residual -> mid (registers, and back into R for the inter GRU)
     //      (mid is parked in `out` -- L2-resident, re-read by the same thread in phase D -- instead of 48 live VGPRs)
     {
@@ -367,6 +391,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
         }
     }
     __syncthreads();
+    ADE_CLK(18);
     // ---- phase C: inter GRNN.  16 lanes per F column: lane = group*8 + unit; GRU(8->8) along T, in place in R
     //      (a column position is read, then overwritten, by its own 16 lanes only).              (:450-455,478-479)
     if (tid < ((kFw * 16 + 63) / 64) * 64) {
@@ -407,6 +432,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
         }
     }
     __syncthreads();
+    ADE_CLK(19);
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
     float y[kPosPerThread][16];
     fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, w.inter_ln_w, w.inter_ln_b, T, P, tid, y);
@@ -421,6 +447,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
             st16(out + (base + p) * kCh, y[i]);
         }
     }
+    ADE_CLK(20);
 }
 
 }  // namespace
@@ -434,11 +461,11 @@ hipError_t fused_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dpgrnn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDpSmemBytes);
 }
 
-void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T) {
-    hipLaunchKernelGGL(k_gtblock, dim3(B), dim3(kFusedThreads), kGtSmemBytes, s, a, skip, w, out, T);
+void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk) {
+    hipLaunchKernelGGL(k_gtblock, dim3(B), dim3(kFusedThreads), kGtSmemBytes, s, a, skip, w, out, T, clk);
 }
-void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T) {
-    hipLaunchKernelGGL(k_dpgrnn, dim3(B), dim3(kFusedThreads), kDpSmemBytes, s, x, w, out, T);
+void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T, long long* clk) {
+    hipLaunchKernelGGL(k_dpgrnn, dim3(B), dim3(kFusedThreads), kDpSmemBytes, s, x, w, out, T, clk);
 }
 
 }  // namespace ade

@@ -104,7 +104,7 @@ void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int
 // ---- per-chunk LDS-resident stage kernels (ade_fused.hip); valid for T <= 64 frames -------------------------
 bool fused_supported(int T);
 hipError_t fused_init();   // raises the dynamic-LDS limit of the stage kernels (once per process/device)
-void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T);
-void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T);
+void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk);
+void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T, long long* clk);
 
 }  // namespace ade

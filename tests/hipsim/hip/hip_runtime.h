@@ -118,6 +118,8 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
+static inline long long wall_clock64() { return 0; }
+static inline long long clock64() { return 0; }
 static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }
 namespace hipsim { extern unsigned char dyn_smem[]; }
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hipsim::dyn_smem);

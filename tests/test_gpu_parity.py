@@ -39,7 +39,8 @@ def test_taps_vs_oracle_exact_dft(sess0):
         opcm, of32 = o.process(pcm_in[row:row + 1])
         res = compare_taps(sess0, o, batch=3, row=row)
         for name, (err, scale) in res.items():
-            assert err <= 4e-6 * max(1.0, scale) + 4e-6, f"row {row} tap {name}: {err:.3e} (scale {scale:.3g})"
+            # gates use the hardware v_exp_f32 / v_rcp_f32 units (~1 ulp each); 8e-6 observed on the full-scale square
+            assert err <= 1e-5 * max(1.0, scale) + 1e-5, f"row {row} tap {name}: {err:.3e} (scale {scale:.3g})"
         assert np.abs(f32[row] - of32[0]).max() <= 1e-5
 
 
@@ -134,9 +135,24 @@ def test_stft_process_operator():
 def test_kernel_profile_tap(sess0):
     sess0.profile(True)
     sess0.process(synth_batch(4))
-    sess0.profile(False)
     kt = sess0.kernel_times()
-    assert set(kt) >= {"stft_feat", "conv0", "gt_pw1", "gt_dw_pw2", "tra_gru", "intra_gru", "inter_gru", "fc_ln_res",
-                       "deconv3", "deconv4", "istft_mask", "ola_pcm"}
-    assert kt["gt_pw1"]["launches"] == 6 and kt["fc_ln_res"]["launches"] == 4
+    assert set(kt) >= {"stft_feat", "conv0", "conv1", "gtblock", "dpgrnn", "deconv3", "deconv4", "istft_mask", "ola_pcm"}
+    assert kt["gtblock"]["launches"] == 6 and kt["dpgrnn"]["launches"] == 2
     assert all(v["ms"] > 0 for v in kt.values())
+    sess0.set_option("fused", "0")            # the multi-kernel path (any T) keeps its own kernel names
+    sess0.process(synth_batch(4))
+    kt = sess0.kernel_times()
+    sess0.set_option("fused", "1")
+    sess0.profile(False)
+    assert kt["gt_pw1"]["launches"] == 6 and kt["fc_ln_res"]["launches"] == 4 and kt["tra_gru"]["ms"] > 0
+
+
+def test_fused_and_multikernel_paths_agree(sess0):
+    """The per-chunk LDS-resident stage kernels and the multi-kernel path are two implementations of the same math."""
+    x = synth_batch(6)
+    a_pcm, a_f32 = sess0.process(x, want_f32=True)
+    sess0.set_option("fused", "0")
+    b_pcm, b_f32 = sess0.process(x, want_f32=True)
+    sess0.set_option("fused", "1")
+    assert np.abs(a_f32 - b_f32).max() <= 2e-5
+    assert np.abs(a_pcm.astype(np.int32) - b_pcm.astype(np.int32)).max() <= 1
