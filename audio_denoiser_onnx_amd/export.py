@@ -1,0 +1,110 @@
+"""Checkpoint -> engine model files (``<name>.adew`` + ``<name>_Metadata.json``).
+
+Plays the role of the reference's ``GTCRN/Export_GTCRN.py:742-789`` minus the ONNX step: take the
+checkpoint-format ``state_dict`` (``torch.load(..)['model']``), fold every BatchNorm into its conv exactly as
+``ConvBlock.fuse_bn_`` / ``GTConvBlock.fuse_bn_`` do (Export_GTCRN.py:171-194, 244-267), pre-transpose the ERB
+matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the reference's own names.
+
+    python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000]
+"""
+from __future__ import annotations
+
+import sys
+from collections import OrderedDict
+from pathlib import Path
+from typing import Dict, Mapping
+
+import numpy as np
+
+from .metadata import build_audio_metadata, write_metadata
+from .weights import save_blob
+
+BN_EPS = 1e-5   # nn.BatchNorm2d default, as constructed at Export_GTCRN.py:167,214,221,225
+
+# (conv, bn) pairs of the two block flavours; transposed = nn.ConvTranspose2d (decoder)
+_CONVBLOCKS = [("encoder.en_convs.0.", False, 1), ("encoder.en_convs.1.", False, 2),
+               ("decoder.de_convs.3.", True, 2), ("decoder.de_convs.4.", True, 1)]
+_GTBLOCKS = [(f"encoder.en_convs.{i}.", False) for i in (2, 3, 4)] + [(f"decoder.de_convs.{i}.", True) for i in (0, 1, 2)]
+
+
+def _fold(w: np.ndarray, b, gamma, beta, mean, var, transposed: bool, groups: int):
+    """BN(conv(x)) == conv'(x): scale per OUTPUT channel; ConvTranspose2d weights are (Cin, Cout/groups, kh, kw)."""
+    scale = (gamma / np.sqrt(var + BN_EPS)).astype(np.float32)
+    if transposed:
+        cin, og = w.shape[0], w.shape[1]
+        wv = w.reshape(groups, cin // groups, og, w.shape[2], w.shape[3])
+        w2 = (wv * scale.reshape(groups, 1, og, 1, 1)).reshape(w.shape)
+    else:
+        w2 = w * scale.reshape(-1, 1, 1, 1)
+    b2 = beta - mean * scale if b is None else (b - mean) * scale + beta
+    return w2.astype(np.float32), b2.astype(np.float32)
+
+
+def fold_gtcrn_state_dict(sd: Mapping[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """Checkpoint-format GTCRN state_dict (numpy arrays) -> the BN-folded tensor set libade loads."""
+    sd = {k: np.asarray(v, dtype=np.float32) for k, v in sd.items() if "num_batches_tracked" not in k}
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def bn(prefix):
+        return sd[prefix + "weight"], sd[prefix + "bias"], sd[prefix + "running_mean"], sd[prefix + "running_var"]
+
+    for p, transposed, groups in _CONVBLOCKS:
+        w, b = _fold(sd[p + "conv.weight"], sd.get(p + "conv.bias"), *bn(p + "bn."), transposed, groups)
+        out[p + "conv.weight"], out[p + "conv.bias"] = w, b
+        if p + "act.weight" in sd:
+            out[p + "act.weight"] = sd[p + "act.weight"]
+    for p, transposed in _GTBLOCKS:
+        for conv, bnn, groups in (("point_conv1", "point_bn1", 1), ("depth_conv", "depth_bn", 16), ("point_conv2", "point_bn2", 1)):
+            w, b = _fold(sd[p + conv + ".weight"], sd.get(p + conv + ".bias"), *bn(p + bnn + "."), transposed, groups)
+            out[p + conv + ".weight"], out[p + conv + ".bias"] = w, b
+        out[p + "point_act.weight"] = sd[p + "point_act.weight"]
+        out[p + "depth_act.weight"] = sd[p + "depth_act.weight"]
+        for leaf in ("tra.att_gru.weight_ih_l0", "tra.att_gru.weight_hh_l0", "tra.att_gru.bias_ih_l0", "tra.att_gru.bias_hh_l0",
+                     "tra.att_fc.weight", "tra.att_fc.bias"):
+            out[p + leaf] = sd[p + leaf]
+    for k, v in sd.items():
+        if k.startswith("dpgrnn"):
+            out[k] = v
+    out["erb.erb_weight_t"] = np.ascontiguousarray(sd["erb.erb_fc.weight"].T)     # (192, 64)
+    out["erb.ierb_weight_t"] = np.ascontiguousarray(sd["erb.ierb_fc.weight"].T)   # (64, 192)
+    return out
+
+
+def load_state_dict(path) -> Dict[str, np.ndarray]:
+    path = Path(path)
+    if path.suffix == ".npz":
+        return dict(np.load(path))
+    import torch
+    ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def export_gtcrn(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "GTCRN") -> Path:
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    save_blob(model_path, fold_gtcrn_state_dict(load_state_dict(checkpoint)))
+    meta = build_audio_metadata(producer=Path(__file__).name, model_name=name, task="denoise", model_family="gtcrn",
+                                input_audio_length=input_audio_length, extra={"n_mels": 100})
+    write_metadata(model_path, meta)
+    return model_path
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    length = 16000
+    if "--length" in argv:
+        i = argv.index("--length")
+        length = int(argv[i + 1])
+        del argv[i:i + 2]
+    if len(argv) != 2:
+        print(__doc__)
+        return 2
+    path = export_gtcrn(argv[0], argv[1], length)
+    print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""The reference's ``GTCRN/Inference_GTCRN_ONNX.py`` call surface on the MI355X engine.
+
+    python -m audio_denoiser_onnx_amd.inference_gtcrn <model_dir_or_.adew> [noisy.wav] [denoised.wav] [--sequential]
+
+Same life-cycle as the reference script (Inference_GTCRN_ONNX.py:237-344): open the session, load + validate the
+metadata, read the wav as mono int16 at IN_SAMPLE_RATE, optional RMS normalisation, cut fixed-length slices (stride =
+the model's OUTPUT length when it differs from the input length, :287-290), zero-pad the tail (:291-298), run, concat,
+trim to the original length, write PCM_16, print the RTF.
+
+What differs is only the hot loop: the reference runs one ``run_with_iobinding`` per slice (:326-330); slices carry
+no state from one to the next, so here ALL slices of the file go through the engine as ONE batch (``--sequential``
+reproduces the one-slice-per-call loop for comparison).  With ``torch.distributed`` initialised, slices are sharded
+across ranks and the outputs stitched with an all-gather (distributed.py).
+"""
+from __future__ import annotations
+
+import sys
+import time
+import wave
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .distributed import shard_bounds, stitch_rows
+from .metadata import runtime_config_from_metadata
+from .session import InferenceSession
+
+NORMALIZE_TARGET_RMS = 4096.0
+
+
+def read_wav_int16(path, sample_rate: int) -> np.ndarray:
+    """Mono int16 at ``sample_rate`` — what ``AudioSegment.from_file(..).set_channels(1).set_frame_rate(sr)`` yields
+    (Inference_GTCRN_ONNX.py:272).  Multi-channel files are averaged; other rates are not resampled here."""
+    with wave.open(str(path), "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError(f"{path}: only 16-bit PCM wav is supported, got {8 * w.getsampwidth()}-bit")
+        sr, ch = w.getframerate(), w.getnchannels()
+        data = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    if ch > 1:
+        data = (data.reshape(-1, ch).astype(np.int32).sum(axis=1) // ch).astype(np.int16)
+    if sr != sample_rate:
+        raise NotImplementedError(f"{path}: sample rate {sr} != model input rate {sample_rate} (resampling is not implemented)")
+    return np.ascontiguousarray(data, dtype=np.int16)
+
+
+def write_wav_int16(path, pcm: np.ndarray, sample_rate: int) -> None:
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sample_rate)
+        w.writeframes(np.ascontiguousarray(pcm, dtype="<i2").tobytes())
+
+
+def normalise_audio(audio: np.ndarray, enable: bool, target_rms: float = NORMALIZE_TARGET_RMS) -> np.ndarray:
+    """Optional RMS normalisation to ``target_rms`` with int16 clipping (Inference_GTCRN_ONNX.py:115-135)."""
+    if not enable:
+        return audio
+    x = audio.astype(np.float32)
+    rms = np.sqrt(np.mean(x * x, dtype=np.float32), dtype=np.float32)
+    if rms > 0.0:
+        x *= target_rms / (rms + 1e-7)
+    np.clip(x, -32768.0, 32767.0, out=x)
+    return x.astype(np.int16)
+
+
+def plan_slices(audio_len: int, in_len: int, out_len: int) -> Tuple[int, int, int]:
+    """(stride, number of slices, zero-padded length) exactly as Inference_GTCRN_ONNX.py:287-299 computes them."""
+    stride = in_len
+    if audio_len > in_len:
+        if in_len != out_len:
+            stride = out_len
+        n = int(np.ceil((audio_len - in_len) / stride)) + 1
+        return stride, n, (n - 1) * stride + in_len
+    return stride, 1, in_len
+
+
+def cut_slices(audio: np.ndarray, in_len: int, out_len: int) -> Tuple[np.ndarray, int]:
+    stride, n, total = plan_slices(len(audio), in_len, out_len)
+    padded = np.zeros(total, np.int16)
+    padded[: len(audio)] = audio
+    idx = np.arange(n)[:, None] * stride + np.arange(in_len)[None, :]
+    return padded[idx], stride
+
+
+def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = False, rank: int = 0, world: int = 1,
+            group=None) -> np.ndarray:
+    """int16 mono waveform in -> int16 denoised waveform out (length preserved)."""
+    audio_len = len(audio)
+    slices, _ = cut_slices(audio, session.in_len, session.out_len)
+    lo, hi = shard_bounds(len(slices), world, rank)
+    mine = slices[lo:hi]
+    if sequential:
+        outs = [session.run(None, {"noisy_audio": s.reshape(1, 1, -1)})[0].reshape(1, -1) for s in mine]
+        local = np.concatenate(outs, axis=0) if outs else np.zeros((0, session.out_len), np.int16)
+    else:
+        local, _ = session.process(mine)
+    full = stitch_rows(local, len(slices), world, rank, group) if world > 1 else local
+    return full.reshape(-1)[:audio_len]            # np.concatenate(saved).reshape(-1)[:audio_len]  (:332)
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    sequential = "--sequential" in argv
+    argv = [a for a in argv if not a.startswith("--")]
+    if not argv:
+        print(__doc__)
+        return 2
+    model = argv[0]
+    here = Path(__file__).resolve().parent
+    default_in = Path("/root/reference/Test_Examples/denoise/gtcrn_mix.wav")   # Example_Audio.py registry entry "gtcrn"
+    noisy = Path(argv[1]) if len(argv) > 1 else default_in
+    out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised.wav"
+
+    session = InferenceSession(model)
+    cfg = runtime_config_from_metadata(session.metadata)
+    print(f"\nUsable Providers: {session.get_providers()}")
+    print(f"\nTest Input Audio: {noisy}")
+    audio = read_wav_int16(noisy, cfg["IN_SAMPLE_RATE"])
+    audio = normalise_audio(audio, cfg["NORMALIZE_AUDIO"], cfg["NORMALIZE_TARGET_RMS"])
+    print("\nRunning the GTCRN on the MI355X engine.")
+    session.reserve(plan_slices(len(audio), session.in_len, session.out_len)[1])
+    t0 = time.time()
+    denoised = denoise(session, audio, sequential=sequential)
+    elapsed = time.time() - t0
+    print("Complete: 100.00%")
+    write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])
+    duration = len(denoised) / cfg["OUT_SAMPLE_RATE"] if cfg["OUT_SAMPLE_RATE"] > 0 else 0.0
+    rtf = elapsed / duration if duration > 0 else float("inf")
+    print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {rtf:.6f}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -108,6 +108,7 @@ def main():
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
+    from audio_denoiser_onnx_amd.distributed import stitch_device
     from audio_denoiser_onnx_amd.metadata import build_audio_metadata
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_batch
@@ -130,7 +131,7 @@ def main():
     def step():
         sess.run_device(d_in, d_out, stream=stream)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, d_out)
+            stitch_device(d_out, gathered)
 
     for _ in range(args.warmup):
         step()

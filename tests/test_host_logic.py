@@ -1,0 +1,100 @@
+"""Host-side logic (no GPU): BN fold vs the reference's own fold, metadata contract, slice plan of the driver,
+model-file resolution, wav I/O."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ade_testlib import GOLD, golden_blob
+from audio_denoiser_onnx_amd import metadata as md
+from audio_denoiser_onnx_amd.export import export_gtcrn, fold_gtcrn_state_dict
+from audio_denoiser_onnx_amd.inference_gtcrn import cut_slices, normalise_audio, plan_slices, read_wav_int16, write_wav_int16
+from audio_denoiser_onnx_amd.weights import load_blob, pack_blob, unpack_blob
+
+
+def test_bn_fold_matches_reference_fold():
+    """fold_gtcrn_state_dict(pre-fold state_dict) == what the reference's prepare_for_export_() produced (fixture)."""
+    unfused = dict(np.load(os.path.join(GOLD, "gtcrn_seed0_unfused_state_dict.npz")))
+    mine = fold_gtcrn_state_dict(unfused)
+    ref = unpack_blob(golden_blob(0))
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert mine[k].shape == ref[k].shape, k
+        np.testing.assert_allclose(mine[k], ref[k], rtol=2e-6, atol=1e-7, err_msg=k)
+
+
+def test_blob_roundtrip_and_rejects_garbage():
+    t = unpack_blob(golden_blob(1))
+    again = unpack_blob(pack_blob(t))
+    assert list(again) == list(t) and all(np.array_equal(again[k], t[k]) for k in t)
+    with pytest.raises(ValueError):
+        unpack_blob(b"ADEWGT01" + b"\0" * 3)
+    with pytest.raises(ValueError):
+        unpack_blob(b"not a blob")
+
+
+def test_export_writes_model_and_manifest(tmp_path):
+    path = export_gtcrn(os.path.join(GOLD, "gtcrn_seed0_unfused_state_dict.npz"), tmp_path, 16000)
+    assert path.name == "GTCRN.adew" and md.metadata_path_for_model(path).exists()
+    reader = md.load_runtime_metadata(path)
+    cfg = md.runtime_config_from_metadata(reader)
+    assert cfg["IN_SAMPLE_RATE"] == cfg["OUT_SAMPLE_RATE"] == cfg["MODEL_SAMPLE_RATE"] == 16000
+    assert cfg["HOP_LENGTH"] == 256 and cfg["FOLD_WINDOW_LENGTH"] == 24064 and cfg["NORMALIZE_AUDIO"] is False
+    assert reader.required_int("max_signal_length") == 63
+    assert load_blob(path)["erb.erb_weight_t"].shape == (192, 64)
+
+
+def test_metadata_contract_errors(tmp_path):
+    meta = md.build_audio_metadata(producer="t", model_name="GTCRN", task="denoise", model_family="gtcrn", input_audio_length=16000)
+    assert set(md.REQUIRED_AUDIO_METADATA_KEYS) <= set(meta)
+    assert meta["dynamic_axes"] == "0" and meta["center_pad"] == "1"          # bools are stamped as 1/0
+    model = tmp_path / "GTCRN.adew"
+    model.write_bytes(b"x")
+    with pytest.raises(FileNotFoundError):                                    # no carrier next to the model
+        md.load_runtime_metadata(model)
+    broken = {k: v for k, v in meta.items() if k != "normalize_target_rms"}
+    md.metadata_path_for_model(model).write_text(json.dumps(broken))
+    with pytest.raises(KeyError):
+        md.load_runtime_metadata(model)
+    r = md.MetadataReader(dict(meta, normalize_audio_default="maybe"))
+    with pytest.raises(ValueError):
+        md.runtime_config_from_metadata(r)
+
+    class FakeArg:
+        def __init__(self, shape): self.shape = shape
+
+    class FakeSession:
+        def __init__(self, n): self.n = n
+        def get_inputs(self): return [FakeArg([1, 1, self.n])]
+        def get_outputs(self): return [FakeArg([1, 1, 15872])]
+
+    md.validate_audio_metadata(md.MetadataReader(meta), FakeSession(16000))
+    with pytest.raises(ValueError):
+        md.validate_audio_metadata(md.MetadataReader(meta), FakeSession(32000))
+
+
+def test_slice_plan_matches_reference_loop():
+    # the reference's own example: gtcrn_mix.wav, 156302 samples -> 10 slices of 16000 at stride 15872
+    stride, n, total = plan_slices(156302, 16000, 15872)
+    assert (stride, n, total) == (15872, 10, 9 * 15872 + 16000)
+    assert plan_slices(16000, 16000, 15872) == (16000, 1, 16000)
+    assert plan_slices(100, 16000, 15872) == (16000, 1, 16000)               # short file: zero-padded to one slice
+    assert plan_slices(64000, 32000, 32000) == (32000, 2, 64000)             # in == out: stride = in
+    audio = (np.arange(40000) % 3000).astype(np.int16)
+    slices, stride = cut_slices(audio, 16000, 15872)
+    assert slices.shape == (3, 16000) and stride == 15872
+    assert np.array_equal(slices[1][:100], audio[15872:15972])
+    assert not slices[2][40000 - 2 * 15872:].any()                           # tail is zero padding
+
+
+def test_wav_io_and_normalise(tmp_path):
+    pcm = (np.sin(np.arange(8000) / 10.0) * 8000).astype(np.int16)
+    p = tmp_path / "a.wav"
+    write_wav_int16(p, pcm, 16000)
+    assert np.array_equal(read_wav_int16(p, 16000), pcm)
+    with pytest.raises(NotImplementedError):
+        read_wav_int16(p, 48000)
+    assert normalise_audio(pcm, False) is pcm
+    n = normalise_audio(pcm, True, 4096.0)
+    assert abs(np.sqrt(np.mean(n.astype(np.float64) ** 2)) - 4096.0) < 2.0
