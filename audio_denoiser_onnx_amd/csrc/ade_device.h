@@ -85,6 +85,50 @@ template <int K> __device__ __forceinline__ float quad_bcast(float v) { return d
 typedef const float ADE_CONSTANT_AS* cfptr;
 __device__ __forceinline__ cfptr cptr(const float* p) { return (cfptr)p; }
 
+// ---- 256-point complex FFT of one wavefront, ONE 256-entry LDS buffer (in place) ---------------------------------
+// Radix-4 Stockham: lane holds z[lane + 64 r] on entry, Z[lane + 64 r] (natural order) on exit.  Every pass reads its
+// four inputs into registers, then (after a barrier) scatters its outputs into the same buffer, so half the LDS of the
+// ping-pong form is needed.  The buffer is private to the wavefront, and a wavefront's LDS operations execute in
+// program order, so the only ordering needed between a pass's scatter and the next pass's gather is "do not let the
+// compiler move them": wave_sync() (no instruction on the GPU; a real wave barrier under the host simulator).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ float2 fcmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ void fradix4(float2* v) {
+    const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
+    const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+    const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
+    const float2 d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+    const float2 a3 = make_float2(d.y, -d.x);   // -i * d
+    v[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+    v[1] = make_float2(a1.x + a3.x, a1.y + a3.y);
+    v[2] = make_float2(a0.x - a2.x, a0.y - a2.y);
+    v[3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+}
+__device__ __forceinline__ void fft256_inplace(float2* v, float2* buf, int lane, const float2* __restrict__ tw256) {
+    fradix4(v);                                   // pass 0: Ns = 1, no twiddle
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[4 * lane + r] = v[r];
+    wave_sync();
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+        const int Ns = 1 << (2 * pass);           // 4, 16, 64
+        const int k = lane & (Ns - 1);
+        const int tstride = 64 / Ns;              // angle -2 pi r k / (4 Ns) -> tw256[r k 64 / Ns]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = buf[lane + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) v[r] = fcmul(v[r], tw256[r * k * tstride]);
+        fradix4(v);
+        if (pass < 3) {
+            wave_sync();                          // every lane has read this pass's inputs
+            const int j0 = ((lane - k) << 2) + k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[j0 + r * Ns] = v[r];
+            wave_sync();
+        }
+    }
+}
+
 inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace dev

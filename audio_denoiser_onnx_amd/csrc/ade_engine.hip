@@ -607,15 +607,14 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     const int T = e->T, nfr = B * T;
     Seq q{e, s, prof};
     const View none{nullptr, nullptr};
-    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean); q.end();
-    q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
-    q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
-    q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
-    View x{e->e1, nullptr};
     const bool fused = e->use_fused && fused_supported(T);
     e->last_fused = fused;
+    View x{e->e1, nullptr};
     if (fused) {
-        // one workgroup per chunk per stage, activations LDS-resident; gates applied inside, so every tensor is plain
+        // ---- fused path: one 1024-thread workgroup per chunk per stage, activations LDS-resident, inter-stage tensors
+        //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
+        long long* clk = prof ? e->d_clk : nullptr;
+        q.begin("front"); launch_front(s, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk); q.end();
         for (int i = 0; i < 3; ++i) {
             q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->xe[i], nullptr};
@@ -628,7 +627,15 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             q.begin("gtblock"); launch_gtblock(s, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T, nullptr); q.end();
             x = View{e->xd[i], nullptr};
         }
-    } else {
+        q.begin("back"); launch_back(s, x.x, e->e1, e->e0, e->spec, e->de3, e->de4, e->erb_bs, e->tabs, e->d3, e->mask, d_out, d_f32, B, T,
+                                     clk); q.end();
+        return;
+    }
+    // ---- multi-kernel path (any T): channels-last tensors, deferred TRA gates (View)
+    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean); q.end();
+    q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
+    q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
+    q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
     for (int i = 0; i < 3; ++i) {   // Encoder GTConvBlocks (Export_GTCRN.py:502-504)
         q.begin("gt_pw1"); launch_gt_pw1(s, x, none, e->en_gt[i], e->h, nfr); q.end();
         q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, none, e->en_gt[i], e->xe[i], e->zt, B, T); q.end();
@@ -650,7 +657,6 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         q.begin("gt_dw_pw2"); launch_gt_dw_pw2(s, e->h, x, skip, e->de_gt[i], e->xd[i], e->zt, B, T); q.end();
         q.begin("tra_gru"); launch_tra(s, e->zt, e->de_gt[i], e->atd[i], B, T); q.end();
         x = View{e->xd[i], e->atd[i]};
-    }
     }
     q.begin("deconv3"); launch_deconv3(s, x, View{e->e1, nullptr}, e->de3, e->d3, nfr); q.end();
     q.begin("deconv4"); launch_deconv4(s, e->d3, e->e0, e->de4, e->mask, nfr); q.end();
@@ -793,7 +799,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
     st = build_device_constants(e);
     if (st != ADE_OK) return bail(st);
-    if (fused_init() != hipSuccess) {
+    if (fused_init() != hipSuccess || frontback_init() != hipSuccess) {
         (void)hipGetLastError();
         e->use_fused = false;   // keep the multi-kernel path if the 140 KB dynamic-LDS request is refused
     }
@@ -897,13 +903,32 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
     for (const Tap& t : taps)
         if (strcmp(t.name, name) == 0) {
             if (!t.p || t.n == 0) return fail(h, ADE_ERR_NOT_FOUND, "tap has no data yet");
+            if (h->last_fused)
+                for (const char* lds_only : {"mean", "feat", "h", "zt", "rnn", "dp1_mid", "dp2_mid", "frames"})
+                    if (strcmp(name, lds_only) == 0)
+                        return fail(h, ADE_ERR_NOT_FOUND, std::string("tap lives in LDS on the fused path (set option fused=0): ") + name);
             if (count < t.n) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
             HIP_TRY(h, hipSetDevice(h->device));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
-            if (h->last_fused && strncmp(name, "at_", 3) == 0)
+            if (h->last_fused && strncmp(name, "at_", 3) == 0) {
                 for (size_t i = 0; i < t.n; ++i) out[i] = 1.0f;   // fused stages apply the TRA gate in-kernel: x_* is already gated
-            else
+            } else {
                 HIP_TRY(h, hipMemcpy(out, t.p, t.n * sizeof(float), hipMemcpyDeviceToHost));
+                const bool is16 = !strcmp(name, "e0") || !strcmp(name, "e1") || !strcmp(name, "d3") || !strncmp(name, "x_", 2) ||
+                                  !strcmp(name, "dp1") || !strcmp(name, "dp2");
+                if (h->last_fused && is16) {
+                    // fused path keeps (B,.,.,16) tensors channel-quad planar [b][q][p][4]: hand back channels-last [b][p][16]
+                    const size_t per = t.n / (size_t)h->last_batch, P = per / 16;
+                    std::vector<float> tmp(per);
+                    for (int b = 0; b < h->last_batch; ++b) {
+                        float* o = out + (size_t)b * per;
+                        memcpy(tmp.data(), o, per * sizeof(float));
+                        for (size_t q4 = 0; q4 < 4; ++q4)
+                            for (size_t p = 0; p < P; ++p)
+                                for (int c = 0; c < 4; ++c) o[p * 16 + q4 * 4 + c] = tmp[(q4 * P + p) * 4 + c];
+                    }
+                }
+            }
             *written = t.n;
             return ADE_OK;
         }

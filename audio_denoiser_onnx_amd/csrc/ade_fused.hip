@@ -27,9 +27,26 @@ constexpr int kPosPerThread = 3;          // ceil(2112 / 1024)
 
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
+// Inter-stage tensors of the fused path live in HBM in the same channel-quad planar form as in LDS:
+//   X[b][q][p] = float4(channels 4q..4q+3 of position p), p < P positions of the chunk
+// so a wavefront whose lanes own consecutive positions moves 1 KB contiguous per instruction (16 B per lane,
+// fully coalesced) instead of 64 lanes x 16 B at a 64-byte stride.  Xc = chunk base (X + b * 16 * P).
+__device__ __forceinline__ void pl_ld8(const float* Xc, int P, int p, int q0, float* v) {
+    ld4(Xc + ((size_t)q0 * P + p) * 4, v);
+    ld4(Xc + ((size_t)(q0 + 1) * P + p) * 4, v + 4);
+}
+__device__ __forceinline__ void pl_ld16(const float* Xc, int P, int p, float* v) {
+    pl_ld8(Xc, P, p, 0, v);
+    pl_ld8(Xc, P, p, 2, v + 8);
+}
+__device__ __forceinline__ void pl_st16(float* Xc, int P, int p, const float* v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st4(Xc + ((size_t)q * P + p) * 4, v + 4 * q);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // GTConvBlock, whole block for one chunk (Export_GTCRN.py:303-324 + TRA :144-156).
-//   in : a (+ skip) (B,T,33,16) plain tensors ;  out: (B,T,33,16) = interleave(h1 * at, bypass)
+//   in : a (+ skip), quad-planar (B,4,P,4) ;  out: same layout = interleave(h1 * at, bypass)
 // LDS: H[4][kPmax] float4 | zt[64][8] | at[64][8] ; GI[64][48] and HS[64][16] alias H planes 2-3 after phase 2.
 // ---------------------------------------------------------------------------------------------------------
 constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
@@ -49,7 +66,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
     float* HS = GI + kTmaxFused * 48;
     const int P = T * kFw;
     const int tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * P;
+    const float* ac = a + (size_t)blockIdx.x * kCh * P;
+    const float* sc = skip ? skip + (size_t)blockIdx.x * kCh * P : nullptr;
+    float* oc = out + (size_t)blockIdx.x * kCh * P;
     const cfptr c_pw1_b = cptr(w.pw1_b), c_dw_b = cptr(w.dw_b), c_pw2_b = cptr(w.pw2_b);
     ADE_CLK(0);
 
@@ -66,10 +85,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
             const int ff = f - 1 + o;
             float x[8];
             if (ff >= 0 && ff < kFw) {
-                ld8(a + (base + p - f + ff) * kCh, x);
-                if (skip) {
+                pl_ld8(ac, P, p - f + ff, 0, x);
+                if (sc) {
                     float y[8];
-                    ld8(skip + (base + p - f + ff) * kCh, y);
+                    pl_ld8(sc, P, p - f + ff, 0, y);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[i] += y[i];
                 }
@@ -182,16 +201,26 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
             bh[g] = pk[75 + g];
         }
         float h = 0.0f;
+        // The step latency IS the kernel's critical path: the three 16-term dot products run as 4 independent
+        // partial sums each (12 chains of 4 FMAs instead of 3 chains of 16) and the step's three input-projection
+        // values are fetched from LDS one step ahead, so nothing but the h -> gates -> h chain is serial.
+        float gi_r = GI[j], gi_z = GI[16 + j], gi_n = GI[32 + j];
         for (int t = 0; t < T; ++t) {
-            float gr = bh[0], gz = bh[1], gn = bh[2];
-#define ADE_TRA_K(K) { const float hk = row_bcast<K>(h); gr += wh[0][K] * hk; gz += wh[1][K] * hk; gn += wh[2][K] * hk; }
+            const int tn = t + 1 < T ? t + 1 : t;
+            const float nx_r = GI[tn * 48 + j], nx_z = GI[tn * 48 + 16 + j], nx_n = GI[tn * 48 + 32 + j];
+            float ar[4] = {bh[0], 0.0f, 0.0f, 0.0f}, az[4] = {bh[1], 0.0f, 0.0f, 0.0f}, an[4] = {bh[2], 0.0f, 0.0f, 0.0f};
+#define ADE_TRA_K(K) { const float hk = row_bcast<K>(h); ar[K & 3] += wh[0][K] * hk; az[K & 3] += wh[1][K] * hk; an[K & 3] += wh[2][K] * hk; }
             ADE_REP16(ADE_TRA_K)
 #undef ADE_TRA_K
-            const float r = sigmoid_f(GI[t * 48 + j] + gr);
-            const float z = sigmoid_f(GI[t * 48 + 16 + j] + gz);
-            const float n = tanh_f(GI[t * 48 + 32 + j] + r * gn);
+            const float gr = (ar[0] + ar[1]) + (ar[2] + ar[3]);
+            const float gz = (az[0] + az[1]) + (az[2] + az[3]);
+            const float gn = (an[0] + an[1]) + (an[2] + an[3]);
+            const float r = sigmoid_f(gi_r + gr);
+            const float z = sigmoid_f(gi_z + gz);
+            const float n = tanh_f(gi_n + r * gn);
             h = (1.0f - z) * n + z * h;
             if (tid < 16) HS[t * 16 + j] = h;
+            gi_r = nx_r; gi_z = nx_z; gi_n = nx_n;
         }
     }
     __syncthreads();
@@ -214,17 +243,17 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restri
         if (p < P) {
             const int t = p / kFw;
             float by[8];
-            ld8(a + (base + p) * kCh + 8, by);
-            if (skip) {
+            pl_ld8(ac, P, p, 2, by);
+            if (sc) {
                 float y[8];
-                ld8(skip + (base + p) * kCh + 8, y);
+                pl_ld8(sc, P, p, 2, y);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) by[k] += y[k];
             }
             float o[16];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { o[2 * k] = h1r[i][k] * at[t * 8 + k]; o[2 * k + 1] = by[k]; }
-            st16(out + (base + p) * kCh, o);
+            pl_st16(oc, P, p, o);
         }
     }
     ADE_CLK(8);
@@ -318,7 +347,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
     float* stat = red + kPmax;
     const int P = T * kFw;
     const int tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * P;
+    const float* xc = x + (size_t)blockIdx.x * kCh * P;
+    float* oc = out + (size_t)blockIdx.x * kCh * P;
 
     ADE_CLK(16);
     // ---- phase A: intra GRNN.  16 lanes per frame: lane = group*8 + dir*4 + unit (== output channel); GRU(8->4)
@@ -339,16 +369,18 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
             bi[g] = pk[36 + g];
             bh[g] = pk[39 + g];
         }
-        const float* xrow = x + (base + (size_t)tc * kFw) * kCh + grp * 8;
+        const int prow = tc * kFw;
         float h = 0.0f;
-        float xn[8];
-        ld8(xrow + (dir ? kFw - 1 : 0) * kCh, xn);
+        // inputs come from HBM/L2 (~1 us away): a 4-slot register ring keeps three steps of loads in flight, and the
+        // fully unrolled loop lets the scheduler start the (h-independent) input projections early.
+        float xq[4][8];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pl_ld8(xc, P, prow + (dir ? kFw - 1 - d : d), grp * 2, xq[d]);
+#pragma unroll
         for (int s = 0; s < kFw; ++s) {
             const int f = dir ? kFw - 1 - s : s;
-            float xv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = xn[k];
-            if (s + 1 < kFw) ld8(xrow + (dir ? f - 1 : f + 1) * kCh, xn);   // prefetch the next step's input
+            if (s + 3 < kFw) pl_ld8(xc, P, prow + (dir ? f - 3 : f + 3), grp * 2, xq[(s + 3) & 3]);
+            const float* xv = xq[s & 3];
             float gi[3], gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) { gi[g] = bi[g]; gh[g] = bh[g]; }
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
             {
                 const float h0 = quad_bcast<0>(h), h1 = quad_bcast<1>(h), h2 = quad_bcast<2>(h), h3 = quad_bcast<3>(h);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gh[g] += wh[g][0] * h0 + wh[g][1] * h1 + wh[g][2] * h2 + wh[g][3] * h3;
+                for (int g = 0; g < 3; ++g) gh[g] += (wh[g][0] * h0 + wh[g][1] * h1) + (wh[g][2] * h2 + wh[g][3] * h3);
             }
             const float r = sigmoid_f(gi[0] + gh[0]);
             const float z = sigmoid_f(gi[1] + gh[1]);
@@ -380,13 +412,13 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
             const int p = tid + i * kFusedThreads;
             if (p < P) {
                 float xr[16];
-                ld16(x + (base + p) * kCh, xr);
+                pl_ld16(xc, P, p, xr);
 #pragma unroll
                 for (int co = 0; co < 16; ++co) mid[i][co] += xr[co];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     R[q * kPmax + p] = make_float4(mid[i][4 * q], mid[i][4 * q + 1], mid[i][4 * q + 2], mid[i][4 * q + 3]);
-                st16(out + (base + p) * kCh, mid[i]);
+                pl_st16(oc, P, p, mid[i]);
             }
         }
     }
@@ -409,24 +441,28 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
             bh[g] = pk[51 + g];
         }
         float h = 0.0f;
+        float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
         for (int t = 0; t < T; ++t) {
             const int p = t * kFw + fc_;
-            const float4 xa = R[(grp * 2) * kPmax + p], xb = R[(grp * 2 + 1) * kPmax + p];
+            const int pn = (t + 1 < T ? t + 1 : t) * kFw + fc_;
             const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            float gi[3], gh[3];
+            xa = R[(grp * 2) * kPmax + pn];          // next step's input: issued now, needed after this step's write
+            xb = R[(grp * 2 + 1) * kPmax + pn];
+            float gi[3], ga[3], gb[3];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) { gi[g] = bi[g]; gh[g] = bh[g]; }
+            for (int g = 0; g < 3; ++g) { gi[g] = bi[g]; ga[g] = bh[g]; gb[g] = 0.0f; }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) gi[g] += wi[g][k] * xv[k];
-#define ADE_INTER_K(K) { const float lo = row_bcast<K>(h), hi = row_bcast<K + 8>(h); const float hk = grp ? hi : lo; \
-                         gh[0] += wh[0][K] * hk; gh[1] += wh[1][K] * hk; gh[2] += wh[2][K] * hk; }
-            ADE_INTER_K(0) ADE_INTER_K(1) ADE_INTER_K(2) ADE_INTER_K(3) ADE_INTER_K(4) ADE_INTER_K(5) ADE_INTER_K(6) ADE_INTER_K(7)
+#define ADE_INTER_K(K, ACC) { const float lo = row_bcast<K>(h), hi = row_bcast<K + 8>(h); const float hk = grp ? hi : lo; \
+                              ACC[0] += wh[0][K] * hk; ACC[1] += wh[1][K] * hk; ACC[2] += wh[2][K] * hk; }
+            ADE_INTER_K(0, ga) ADE_INTER_K(1, gb) ADE_INTER_K(2, ga) ADE_INTER_K(3, gb)
+            ADE_INTER_K(4, ga) ADE_INTER_K(5, gb) ADE_INTER_K(6, ga) ADE_INTER_K(7, gb)
 #undef ADE_INTER_K
-            const float r = sigmoid_f(gi[0] + gh[0]);
-            const float z = sigmoid_f(gi[1] + gh[1]);
-            const float n = tanh_f(gi[2] + r * gh[2]);
+            const float r = sigmoid_f(gi[0] + (ga[0] + gb[0]));
+            const float z = sigmoid_f(gi[1] + (ga[1] + gb[1]));
+            const float n = tanh_f(gi[2] + r * (ga[2] + gb[2]));
             h = (1.0f - z) * n + z * h;
             if (live) Rf[((size_t)(q >> 2) * kPmax + p) * 4 + (q & 3)] = h;
         }
@@ -441,10 +477,10 @@ __global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restric
         const int p = tid + i * kFusedThreads;
         if (p < P) {
             float m[16];
-            ld16(out + (base + p) * kCh, m);     // mid, written by this same thread in phase B
+            pl_ld16(oc, P, p, m);     // mid, written by this same thread in phase B
 #pragma unroll
             for (int co = 0; co < 16; ++co) y[i][co] += m[co];
-            st16(out + (base + p) * kCh, y[i]);
+            pl_st16(oc, P, p, y[i]);
         }
     }
     ADE_CLK(20);

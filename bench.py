@@ -50,6 +50,11 @@ KERNEL_MODEL = {
     # fused per-chunk stage kernels (ade_fused.hip): a GTConvBlock = pw1 + dw/pw2 + TRA ; a DPGRNN = 2 GRNN + 2 (FC+LN)
     "gtblock": (6 * _T * (33 * (384 + 272) + 1280), (3 * 2 + 3 * 3) * _T * 33 * 16 * 4),
     "dpgrnn": (2 * _T * 33 * (4 * 144 + 2 * 384 + 2 * 256), 2 * 2 * _T * 33 * 16 * 4),
+    # front = mean + STFT/feat + conv0 + conv1 ; back = deconv3 + deconv4 + mask/irFFT/OLA/PCM   (ade_frontback.hip)
+    "front": (int(_T * (2.5 * 512 * 9 / 2 + 3 * 382)) + _T * 65 * 16 * 45 + _T * 33 * 16 * 40,
+              32000 + _T * (2 * 257 + 65 * 16 + 33 * 16) * 4),
+    "back": (_T * 33 * 16 * 8 * 5 + _T * 65 * 16 * 2 * 5 + int(_T * (2.5 * 512 * 9 / 2 + 2 * 382 + 4 * 257)),
+             _T * (2 * 33 * 16 + 65 * 16 + 2 * 257) * 4 + 31744),
 }
 PIPELINE_BYTES_PER_CHUNK = 32000 + 31744          # int16 in + int16 out
 PIPELINE_FLOP_PER_CHUNK = 54.5e6                   # 2 x 26.52 MMAC network + FFT-form STFT/ISTFT

@@ -136,7 +136,8 @@ def test_kernel_profile_tap(sess0):
     sess0.profile(True)
     sess0.process(synth_batch(4))
     kt = sess0.kernel_times()
-    assert set(kt) >= {"stft_feat", "conv0", "conv1", "gtblock", "dpgrnn", "deconv3", "deconv4", "istft_mask", "ola_pcm"}
+    assert set(kt) >= {"front", "gtblock", "dpgrnn", "back"}
+    assert kt["front"]["launches"] == 1 and kt["back"]["launches"] == 1
     assert kt["gtblock"]["launches"] == 6 and kt["dpgrnn"]["launches"] == 2
     assert all(v["ms"] > 0 for v in kt.values())
     sess0.set_option("fused", "0")            # the multi-kernel path (any T) keeps its own kernel names

@@ -1,12 +1,16 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+#!/usr/bin/env python3
+"""Print the in-kernel phase clocks (wall_clock64 ticks, 10 ns) of workgroup 0 of each fused stage kernel."""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from ade_testlib import make_session
 from audio_denoiser_onnx_amd.synth import synth_batch
 s = make_session(None)
 for B in (1, 256):
     x = synth_batch(B)
     s.process(x); s.profile(True); s.process(x); s.process(x)
-    c = s.tap('phase_clock', 64)
-    print('B', B, 'gtblock phase ticks (10ns):', c[:9].astype(int).tolist())
-    print('B', B, 'dpgrnn  phase ticks (10ns):', c[16:21].astype(int).tolist())
+    c = s.tap('phase_clock', 64).astype(int)
+    print('B', B, 'gtblock[pw1,dw,h1,energy,GI,GRU,at,out]:', (c[1:9] - c[0:8]).tolist(), 'total', c[8])
+    print('B', B, 'dpgrnn [intra,fcln,inter,fcln]       :', (c[17:21] - c[16:20]).tolist(), 'total', c[20])
+    print('B', B, 'front  [mean,stft,conv0,conv1]       :', (c[33:37] - c[32:36]).tolist(), 'total', c[36])
+    print('B', B, 'back   [deconv3,deconv4,istft,pcm]   :', (c[49:53] - c[48:52]).tolist(), 'total', c[52])
     s.profile(False)
