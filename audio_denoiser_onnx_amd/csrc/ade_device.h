@@ -82,6 +82,13 @@ template <int K> __device__ __forceinline__ float quad_bcast(float v) { return d
 #else
 #define ADE_KEEP_IN_LOOP(p) ((void)0)
 #endif
+// Opaque per-lane value: everything derived from it is private to the code that follows, so the optimiser cannot
+// share (and keep live) index arithmetic across the stages inlined into one kernel.  Emits no instruction.
+#if defined(__AMDGCN__)
+#define ADE_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define ADE_OPAQUE_V(x) ((void)0)
+#endif
 typedef const float ADE_CONSTANT_AS* cfptr;
 __device__ __forceinline__ cfptr cptr(const float* p) { return (cfptr)p; }
 

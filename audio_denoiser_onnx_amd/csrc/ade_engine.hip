@@ -81,11 +81,13 @@ struct ade_engine {
     bool use_graph = true;
     bool graph_supported = true;
     bool use_fused = true;      // per-chunk LDS-resident stage kernels when T <= 64 (ade_fused.hip)
+    bool use_single = true;     // ... as ONE launch (k_gtcrn_chunk); profile mode always uses the per-stage kernels
     bool last_fused = false;
     long long* d_clk = nullptr;   // 64 phase-clock slots (profile mode only)
     std::vector<GraphEntry> graphs;
 
     bool profile = false;
+    int profile_mode = 1;       // 1: one kernel per stage (+ phase clocks); 2: the shipped launch sequence, timed as launched
     std::vector<KernelStat> stats;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<int> event_stat;
@@ -614,6 +616,17 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         // ---- fused path: one 1024-thread workgroup per chunk per stage, activations LDS-resident, inter-stage tensors
         //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
         long long* clk = prof ? e->d_clk : nullptr;
+        if (e->use_single && (!prof || e->profile_mode == 2)) {
+            ChunkArgs A{};
+            A.pcm_in = d_in; A.pcm_out = d_out; A.f32_out = d_f32; A.L = e->in_len; A.T = T;
+            A.tabs = e->tabs; A.erb_bm = e->erb_bm; A.erb_bs = e->erb_bs;
+            A.en0 = e->en0; A.en1 = e->en1; A.de3 = e->de3; A.de4 = e->de4;
+            for (int i = 0; i < 3; ++i) { A.en_gt[i] = e->en_gt[i]; A.de_gt[i] = e->de_gt[i]; A.xe[i] = e->xe[i]; A.xd[i] = e->xd[i]; }
+            for (int i = 0; i < 2; ++i) { A.dp[i] = e->dp[i]; A.dpo[i] = e->dpo[i]; }
+            A.spec = e->spec; A.e0 = e->e0; A.e1 = e->e1; A.d3 = e->d3; A.mask = e->mask; A.clk = nullptr;
+            q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, A, B); q.end();
+            return;
+        }
         q.begin("front"); launch_front(s, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk); q.end();
         for (int i = 0; i < 3; ++i) {
             q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
@@ -799,7 +812,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
     st = build_device_constants(e);
     if (st != ADE_OK) return bail(st);
-    if (fused_init() != hipSuccess || frontback_init() != hipSuccess) {
+    if (fused_init() != hipSuccess) {
         (void)hipGetLastError();
         e->use_fused = false;   // keep the multi-kernel path if the 140 KB dynamic-LDS request is refused
     }
@@ -834,11 +847,12 @@ ade_status ade_reserve(ade_handle h, int batch) {
 
 ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
     if (!h || !key || !value) return ADE_ERR_BAD_VALUE;
-    if (strcmp(key, "graph") == 0 || strcmp(key, "fused") == 0) {
+    if (strcmp(key, "graph") == 0 || strcmp(key, "fused") == 0 || strcmp(key, "single_launch") == 0) {
         bool b;
         if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, std::string("option ") + key + " must be 0/1");
         if (key[0] == 'g') h->use_graph = b;
-        else h->use_fused = b;
+        else if (key[0] == 'f') h->use_fused = b;
+        else h->use_single = b;
         free_graphs(h);
         return ADE_OK;
     }
@@ -940,6 +954,7 @@ const char* ade_kernel_name(ade_handle h, int i) { return (h && i >= 0 && i < (i
 ade_status ade_profile_last(ade_handle h, int enable) {
     if (!h) return ADE_ERR_BAD_VALUE;
     h->profile = enable != 0;
+    if (enable) h->profile_mode = enable == 2 ? 2 : 1;
     return ADE_OK;
 }
 ade_status ade_kernel_ms(ade_handle h, int i, float* total_ms, int* launches) {

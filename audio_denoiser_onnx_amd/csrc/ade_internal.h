@@ -106,12 +106,27 @@ bool fused_supported(int T);
 hipError_t fused_init();   // raises the dynamic-LDS limit of the stage kernels (once per process/device)
 void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk);
 void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T, long long* clk);
-// front / back stages (ade_frontback.hip).  All (B,.,.,16) tensors of the fused path are channel-quad planar:
+// front / back stages (ade_stage_frontback.h).  All (B,.,.,16) tensors of the fused path are channel-quad planar:
 // X[b][q][p] = float4(channels 4q..4q+3 of position p).
-hipError_t frontback_init();
 void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
                   float* e0, float* e1, long long* clk);
 void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
                  FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk);
+
+// Everything the single-launch chunk kernel needs (passed by value as the kernel argument block, ~1 KB).
+struct ChunkArgs {
+    const int16_t* pcm_in;
+    int16_t* pcm_out;
+    float* f32_out;          // optional pre-PCM waveform
+    int L, T;
+    FftTabs tabs;
+    BandTab erb_bm, erb_bs;
+    ConvW en0, en1, de3, de4;
+    GtConvW en_gt[3], de_gt[3];
+    DpW dp[2];
+    float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3], *d3, *mask;
+    long long* clk;          // optional phase clocks
+};
+void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B);
 
 }  // namespace ade

@@ -1,4 +1,4 @@
-// ade_frontback.hip — per-chunk fused FRONT (PCM -> spectrum, e0, e1) and BACK (d2 -> PCM) stage kernels.
+// ade_stage_frontback.h — per-chunk fused FRONT (PCM -> spectrum, e0, e1) and BACK (d2 -> PCM) stage kernels.
 //
 // Same design as ade_fused.hip: one 1024-thread workgroup owns one audio chunk; everything that is per-frame local
 // (STFT, feature build, ERB merge; mask, irFFT, overlap-add, PCM tail) stays in LDS, the inter-stage tensors go to
@@ -9,28 +9,16 @@
 //                 -> complex ratio mask -> irFFT-512 -> window -> overlap-add (LDS) -> /sum(w^2) -> *32767, clamp, trunc
 // Reference lines: Export_GTCRN.py:637-647, 594-595, 99-102, 117-141, 159-197, 488-489, 515-516, 104-107, 583-590, 681-690 ;
 // STFT_Process.py:303-316, 239-251, 326-336.
-#include "ade_device.h"
+#pragma once
+#include "ade_stage_net.h"
 
 namespace ade {
+namespace stage {
 
-using namespace dev;
 
-namespace {
-
-constexpr int kTmaxFused = 64;
-constexpr int kFusedThreads = 1024;
 constexpr int kWbuf = 264;   // float2 slots of one wave's FFT / spectrum buffer (257 used)
 
-#define ADE_CLK(i) do { if (clk && blockIdx.x == 0 && threadIdx.x == 0) clk[i] = wall_clock64(); } while (0)
 
-__device__ __forceinline__ void pl_ld16(const float* Xc, int P, int p, float* v) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ld4(Xc + ((size_t)q * P + p) * 4, v + 4 * q);
-}
-__device__ __forceinline__ void pl_st16(float* Xc, int P, int p, const float* v) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st4(Xc + ((size_t)q * P + p) * 4, v + 4 * q);
-}
 
 // X[k] and X[256-k] of the 512-point real FFT from the packed 256-point FFT Z, in place in buf[0..256]
 // (Z[256] == Z[0]).  E = (Z[k] + conj Z[256-k])/2, O = -i (Z[k] - conj Z[256-k])/2, X[k] = E + e^{-2 pi i k/512} O.
@@ -56,20 +44,21 @@ __device__ __forceinline__ LdsTabs stage_tables(float* dst, const FftTabs& t, in
     return LdsTabs{win, reinterpret_cast<const float2*>(tw256), reinterpret_cast<const float2*>(tw512)};
 }
 
-__global__ __launch_bounds__(kFusedThreads) void k_front(const int16_t* __restrict__ pcm, int L, int T, FftTabs tabs, BandTab erb,
-                                                         ConvW c0, ConvW c1, float* __restrict__ spec, float* __restrict__ e0,
-                                                         float* __restrict__ e1, long long* __restrict__ clk) {
-    HIP_DYNAMIC_SHARED(float, smem)
+__device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_t* __restrict__ pcm, int L, int T, const FftTabs& tabs,
+                                            const BandTab& erb, const ConvW& c0, const ConvW& c1, float* __restrict__ spec,
+                                            float* __restrict__ e0, float* __restrict__ e1, long long* __restrict__ clk) {
     float* feat = smem;
     float2* wbuf_all = reinterpret_cast<float2*>(smem + kFrontFeatFloats);
     int* red = reinterpret_cast<int*>(wbuf_all + 16 * kWbuf);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    ADE_OPAQUE_V(tid_);
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
     float2* buf = wbuf_all + wave * kWbuf;
-    const int16_t* row = pcm + (size_t)blockIdx.x * L;
+    const int16_t* row = pcm + (size_t)chunk * L;
     const int P0 = T * kF1, P = T * kFw;
-    float* e0c = e0 + (size_t)blockIdx.x * kCh * P0;
-    float* e1c = e1 + (size_t)blockIdx.x * kCh * P;
-    float* specc = spec + (size_t)blockIdx.x * T * 2 * kBinsPad;
+    float* e0c = e0 + (size_t)chunk * kCh * P0;
+    float* e1c = e1 + (size_t)chunk * kCh * P;
+    float* specc = spec + (size_t)chunk * T * 2 * kBinsPad;
     ADE_CLK(32);
     const LdsTabs lt = stage_tables(reinterpret_cast<float*>(red + 16), tabs, tid);
 
@@ -255,23 +244,23 @@ __global__ __launch_bounds__(kFusedThreads) void k_front(const int16_t* __restri
 constexpr size_t kBackAccFloats = (size_t)kNfft + (size_t)kHop * (kTmaxFused - 1);
 constexpr size_t kBackSmemBytes = (size_t)16 * kWbuf * 8 + kBackAccFloats * 4 + kTabFloats * 4;
 
-__global__ __launch_bounds__(kFusedThreads) void k_back(const float* __restrict__ x, const float* __restrict__ e1,
-                                                        const float* __restrict__ e0, const float* __restrict__ spec, ConvW c3, ConvW c4,
-                                                        BandTab bs, FftTabs tabs, float* __restrict__ d3, float* __restrict__ mask,
-                                                        int16_t* __restrict__ pcm, float* __restrict__ f32, int T,
-                                                        long long* __restrict__ clk) {
-    HIP_DYNAMIC_SHARED(float, smem)
+__device__ __forceinline__ void back_stage(float* smem, int chunk, const float* __restrict__ x, const float* __restrict__ e1,
+                                           const float* __restrict__ e0, const float* __restrict__ spec, const ConvW& c3, const ConvW& c4,
+                                           const BandTab& bs, const FftTabs& tabs, float* __restrict__ d3, float* __restrict__ mask,
+                                           int16_t* __restrict__ pcm, float* __restrict__ f32, int T, long long* __restrict__ clk) {
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
     float* acc = smem + 16 * kWbuf * 2;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    ADE_OPAQUE_V(tid_);
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
     float2* buf = wbuf_all + wave * kWbuf;
     const int P0 = T * kF1, P = T * kFw;
-    const float* xc = x + (size_t)blockIdx.x * kCh * P;
-    const float* e1c = e1 + (size_t)blockIdx.x * kCh * P;
-    const float* e0c = e0 + (size_t)blockIdx.x * kCh * P0;
-    float* d3c = d3 + (size_t)blockIdx.x * kCh * P0;
-    float* maskc = mask + (size_t)blockIdx.x * T * 2 * kErbPad;
-    const float* specc = spec + (size_t)blockIdx.x * T * 2 * kBinsPad;
+    const float* xc = x + (size_t)chunk * kCh * P;
+    const float* e1c = e1 + (size_t)chunk * kCh * P;
+    const float* e0c = e0 + (size_t)chunk * kCh * P0;
+    float* d3c = d3 + (size_t)chunk * kCh * P0;
+    float* maskc = mask + (size_t)chunk * T * 2 * kErbPad;
+    const float* specc = spec + (size_t)chunk * T * 2 * kBinsPad;
     ADE_CLK(48);
     const LdsTabs lt = stage_tables(acc + kBackAccFloats, tabs, tid);   // made visible by the barriers below
 
@@ -412,8 +401,8 @@ __global__ __launch_bounds__(kFusedThreads) void k_back(const float* __restrict_
     // ---- trim N/2, / sum(w^2), * 32767, clamp, truncating cast                          (STFT_Process.py:330-333, Export:681,690)
     {
         const int out_len = kHop * (T - 1);
-        int16_t* po = pcm ? pcm + (size_t)blockIdx.x * out_len : nullptr;
-        float* fo = f32 ? f32 + (size_t)blockIdx.x * out_len : nullptr;
+        int16_t* po = pcm ? pcm + (size_t)chunk * out_len : nullptr;
+        float* fo = f32 ? f32 + (size_t)chunk * out_len : nullptr;
         for (int i4 = tid; i4 < out_len / 4; i4 += kFusedThreads) {
             const int n = i4 * 4;
             float v[4], ws[4];
@@ -433,23 +422,6 @@ __global__ __launch_bounds__(kFusedThreads) void k_back(const float* __restrict_
     ADE_CLK(52);
 }
 
-}  // namespace
 
-hipError_t frontback_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_front), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kFrontSmemBytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_back), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBackSmemBytes);
-}
-
-void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
-                  float* e0, float* e1, long long* clk) {
-    hipLaunchKernelGGL(k_front, dim3(B), dim3(kFusedThreads), kFrontSmemBytes, s, pcm, L, T, tabs, erb_bm, c0, c1, spec, e0, e1, clk);
-}
-void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
-                 FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk) {
-    hipLaunchKernelGGL(k_back, dim3(B), dim3(kFusedThreads), kBackSmemBytes, s, x, e1, e0, spec, c3, c4, erb_bs, tabs, d3, mask, pcm, f32, T,
-                       clk);
-}
-
+}  // namespace stage
 }  // namespace ade

@@ -155,8 +155,9 @@ class InferenceSession:
         self._lib.check(self._lib.c.ade_debug_tap(self._h, name.encode(), buf.ctypes.data, buf.size, C.byref(n)), self._h)
         return buf[: n.value]
 
-    def profile(self, enable: bool) -> None:
-        self._lib.check(self._lib.c.ade_profile_last(self._h, int(bool(enable))), self._h)
+    def profile(self, enable) -> None:
+        """0/False: off; 1/True: one kernel per stage (+ phase clocks); 2: the shipped launch sequence timed as launched."""
+        self._lib.check(self._lib.c.ade_profile_last(self._h, int(enable)), self._h)
 
     def kernel_times(self) -> Dict[str, Dict[str, float]]:
         out = {}

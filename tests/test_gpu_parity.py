@@ -157,3 +157,19 @@ def test_fused_and_multikernel_paths_agree(sess0):
     sess0.set_option("fused", "1")
     assert np.abs(a_f32 - b_f32).max() <= 2e-5
     assert np.abs(a_pcm.astype(np.int32) - b_pcm.astype(np.int32)).max() <= 1
+
+
+def test_single_launch_equals_stage_kernels(sess0):
+    """k_gtcrn_chunk (one launch for the whole network) runs the same stage bodies as the per-stage kernels."""
+    x = synth_batch(5)
+    a_pcm, a_f32 = sess0.process(x, want_f32=True)
+    sess0.set_option("single_launch", "0")
+    b_pcm, b_f32 = sess0.process(x, want_f32=True)
+    sess0.set_option("single_launch", "1")
+    assert np.array_equal(a_pcm, b_pcm) and np.array_equal(a_f32, b_f32)
+    sess0.profile(2)
+    sess0.process(x)
+    kt = sess0.kernel_times()
+    sess0.profile(0)
+    assert kt["gtcrn_chunk"]["launches"] == 1 and kt["gtcrn_chunk"]["ms"] > 0
+    assert all(v["launches"] == 0 for k, v in kt.items() if k != "gtcrn_chunk")     # nothing else was launched
