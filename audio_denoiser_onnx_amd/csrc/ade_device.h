@@ -60,6 +60,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 }
 template <int K> __device__ __forceinline__ float row_bcast(float v) { return dpp_mov<0x150 + K>(v); }    // K < 16
 template <int K> __device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(v); }   // K < 4
+template <int N> __device__ __forceinline__ float row_ror(float v) { return dpp_mov<0x120 + N>(v); }     // rotate within the 16-lane row, 1 <= N <= 15
 
 // Wave-uniform, read-only tables (conv / Linear weights): viewing them through the CONSTANT address space lets the
 // compiler fetch them with scalar loads (s_load through the scalar cache -> SGPR operands of v_fma) even when the

@@ -91,6 +91,7 @@ struct ade_engine {
     std::vector<KernelStat> stats;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<int> event_stat;
+    int events_used = 0;
 };
 
 namespace {
@@ -602,6 +603,7 @@ struct Seq {
         if (!prof) return;
         hipEventRecord(e->events[cursor].second, s);
         ++cursor;
+        e->events_used = cursor;
     }
 };
 
@@ -682,9 +684,10 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     e->last_batch = B;
     if (e->profile) {
         for (auto& st : e->stats) { st.ms = 0.f; st.launches = 0; }
+        e->events_used = 0;
         enqueue(e, s, d_in, B, d_out, d_f32, true);
         HIP_TRY(e, hipStreamSynchronize(s));
-        for (size_t i = 0; i < e->events.size(); ++i) {
+        for (size_t i = 0; i < (size_t)e->events_used; ++i) {   // only the events recorded by THIS run
             float ms = 0.f;
             hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second);
             e->stats[e->event_stat[i]].ms += ms;

@@ -165,30 +165,43 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     __syncthreads();
     ADE_CLK(3);
 
-    // ---- phase 3: TRA energy zt[t][c] = mean_f h1^2                                           (:154)
-    for (int idx = tid; idx < T * 8; idx += kFusedThreads) {
-        const int t = idx >> 3, c = idx & 7;
-        const float4* row = H + (c >> 2) * kPmax + t * kFw;
-        float s = 0.0f;
-        for (int f = 0; f < kFw; ++f) {
-            const float v = comp(row[f], c & 3);
-            s += v * v;
+    // ---- phase 3+4a: TRA energy zt[t][c] = mean_f h1^2 (:154) and the GRU input projections GI[t][g*16+j] = b_ih + W_ih zt[t],
+    //      one 16-lane DPP row per frame: lane j sums f in {j, j+16, j+32}, a 4-step row rotation all-reduce (fixed order,
+    //      deterministic) gives every lane the 8 channel energies, then lane j produces its three gate rows.
+    {
+        const int tr = tid >> 4, j = tid & 15;
+        const int t = tr < T ? tr : T - 1;       // rows beyond T recompute the last frame (cross-lane ops need the whole wave)
+        {
+            float e[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int f = j + 16 * u;
+                if (f < kFw) {
+                    const float4 a0 = H[t * kFw + f], a1 = H[kPmax + t * kFw + f];
+                    e[0] += a0.x * a0.x; e[1] += a0.y * a0.y; e[2] += a0.z * a0.z; e[3] += a0.w * a0.w;
+                    e[4] += a1.x * a1.x; e[5] += a1.y * a1.y; e[6] += a1.z * a1.z; e[7] += a1.w * a1.w;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                e[c] += row_ror<8>(e[c]);
+                e[c] += row_ror<4>(e[c]);
+                e[c] += row_ror<2>(e[c]);
+                e[c] += row_ror<1>(e[c]);
+                e[c] = e[c] / (float)kFw;
+            }
+            const float* pk = w.gru + j * 78;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                float sacc = pk[72 + g];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sacc += pk[g * 8 + k] * e[k];
+                if (tr < T) GI[t * 48 + g * 16 + j] = sacc;
+            }
         }
-        zt[idx] = s / (float)kFw;
     }
     __syncthreads();
     ADE_CLK(4);
-    // ---- phase 4a: GRU input projections for every t at once: GI[t][g*16+j] = b_ih + W_ih zt[t]
-    for (int idx = tid; idx < T * 48; idx += kFusedThreads) {
-        const int t = idx / 48, r = idx - t * 48;
-        const int g = r >> 4, j = r & 15;
-        const float* pk = w.gru + j * 78;
-        float s = pk[72 + g];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += pk[g * 8 + k] * zt[t * 8 + k];
-        GI[idx] = s;
-    }
-    __syncthreads();
     ADE_CLK(5);
     // ---- phase 4b: the serial part, GRU(8->16) over T on one 16-lane row (all four rows of wave 0 run it redundantly;
     //      h exchanged with row_newbcast DPP)                                                    (:149,155)
@@ -301,10 +314,11 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
         }
     }
     __syncthreads();
-    if (tid < T) {
-        float s = 0.0f;
-        for (int f = 0; f < kFw; ++f) s += red[tid * kFw + f];
-        stat[tid] = s / (float)(kFw * kCh);
+    {   // per-frame total: one 16-lane row per frame, 3 partials per lane, row rotation all-reduce (fixed order)
+        const int tr = tid >> 4, j = tid & 15, t = tr < T ? tr : T - 1;
+        float s = red[t * kFw + j] + red[t * kFw + j + 16] + (j == 0 ? red[t * kFw + 32] : 0.0f);
+        s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s);
+        if (j == 0 && tr < T) stat[t] = s / (float)(kFw * kCh);
     }
     __syncthreads();
 #pragma unroll
@@ -319,10 +333,11 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
         }
     }
     __syncthreads();
-    if (tid < T) {
-        float s = 0.0f;
-        for (int f = 0; f < kFw; ++f) s += red[tid * kFw + f];
-        stat[kTmaxFused + tid] = 1.0f / sqrtf(s / (float)(kFw * kCh) + 1e-8f);
+    {
+        const int tr = tid >> 4, j = tid & 15, t = tr < T ? tr : T - 1;
+        float s = red[t * kFw + j] + red[t * kFw + j + 16] + (j == 0 ? red[t * kFw + 32] : 0.0f);
+        s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s);
+        if (j == 0 && tr < T) stat[kTmaxFused + t] = 1.0f / sqrtf(s / (float)(kFw * kCh) + 1e-8f);
     }
     __syncthreads();
 #pragma unroll

@@ -198,6 +198,19 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(t_launch * 1e6, 2),
                         "alt_fp32_frac": round(tf / FP32_PEAK_TFLOPS, 4)}
+        # HBM-side traffic of the dominant kernel: bench.py cannot run PMC passes itself, so it reports the committed
+        # rocprofv3 FETCH_SIZE / WRITE_SIZE measurement of this kernel (profiles/traffic_pmc.json, tools/pmc_traffic.sh)
+        try:
+            with open(os.path.join(REPO, "profiles", "traffic_pmc.json")) as f:
+                tp = json.load(f)
+            ent = tp["kernels"].get(dom)
+            if ent:
+                roofline["traffic"] = int((2.0 * ent["fetch_kib"] + ent["write_kib"]) * 1024 * B / tp["batch"])
+                roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
+                                            f"({tp['build']}); fabric-side incl. Infinity-Cache hits; algorithmic bytes per launch = "
+                                            f"{int(bytes_launch)}")
+        except (OSError, KeyError, ValueError):
+            pass
         per_gpu_step_s = elapsed / max(1, args.steps)
         roofline["pipeline"] = {
             "hbm_frac": round(PIPELINE_BYTES_PER_CHUNK * B / per_gpu_step_s / 1e9 / HBM_PEAK_GBS, 6),

@@ -113,6 +113,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     int from;
     if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
     else if (ctrl >= 0x150 && ctrl <= 0x15F) from = (lane & ~15) | (ctrl & 15);
+    else if (ctrl >= 0x121 && ctrl <= 0x12F) from = (lane & ~15) | ((lane - (ctrl & 15)) & 15);   // row_ror:n
     else { fprintf(stderr, "hipsim: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
     return (int)::hipsim::wave_exchange((uint32_t)src, from);
 }
