@@ -921,7 +921,7 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         if (strcmp(t.name, name) == 0) {
             if (!t.p || t.n == 0) return fail(h, ADE_ERR_NOT_FOUND, "tap has no data yet");
             if (h->last_fused)
-                for (const char* lds_only : {"mean", "feat", "h", "zt", "rnn", "dp1_mid", "dp2_mid", "frames"})
+                for (const char* lds_only : {"mean", "feat", "h", "zt", "rnn", "dp1_mid", "dp2_mid", "frames", "d3", "mask"})
                     if (strcmp(name, lds_only) == 0)
                         return fail(h, ADE_ERR_NOT_FOUND, std::string("tap lives in LDS on the fused path (set option fused=0): ") + name);
             if (count < t.n) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");

@@ -54,19 +54,21 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
     const float* x = A.e1;
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // encoder GTConvBlocks
-        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, i == 0 ? A.clk : nullptr);
+        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, i == 0 ? A.clk : nullptr, /*x1_in_lds=*/i > 0,
+                      /*next_x1=*/i < 2, nullptr);
         __syncthreads();
         x = A.xe[i];
     }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
-        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, i == 0 ? A.clk : nullptr);
+        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, i == 0 ? A.clk : nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
         __syncthreads();
         x = A.dpo[i];
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // decoder GTConvBlocks on x + en_outs[4 - i]
-        gtblock_stage(smem, chunk, x, A.xe[2 - i], A.de_gt[i], A.xd[i], A.T, nullptr);
+        gtblock_stage(smem, chunk, x, A.xe[2 - i], A.de_gt[i], A.xd[i], A.T, nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
+                      /*next_skip=*/i < 2 ? A.xe[1 - i] : nullptr);
         __syncthreads();
         x = A.xd[i];
     }

@@ -57,8 +57,11 @@ constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
 // Optional phase clocks: when `clk` is non-null, thread 0 of workgroup 0 stamps wall_clock64() at each phase boundary.
 #define ADE_CLK(i) do { if (clk && chunk == 0 && threadIdx.x == 0) clk[i] = wall_clock64(); } while (0)
 
+// x1_in_lds : the previous stage of the same launch already left this block's pointwise input (a+skip)[:, :8] in LDS planes 2-3.
+// next_x1   : leave the NEXT GTConvBlock's pointwise input there (out[:, :8] + next_skip[:, :8]); next_skip may be null.
 __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const float* __restrict__ a, const float* __restrict__ skip,
-                                              const GtConvW& w, float* __restrict__ out, int T, long long* __restrict__ clk) {
+                                              const GtConvW& w, float* __restrict__ out, int T, long long* __restrict__ clk,
+                                              bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr) {
     float4* H = smem;
     float* zt = reinterpret_cast<float*>(smem + 4 * kPmax);
     float* at = zt + kTmaxFused * 8;
@@ -74,39 +77,63 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     const cfptr c_pw1_b = cptr(w.pw1_b), c_dw_b = cptr(w.dw_b), c_pw2_b = cptr(w.pw2_b);
     ADE_CLK(0);
 
-    // ---- phase 1: (a + skip)[:, :8] -> SFE(3) -> 1x1 (24->16) + BN + PReLU -> H (LDS)         (:305-310)
-    for (int p = tid; p < P; p += kFusedThreads) {
-        const int t = p / kFw, f = p - t * kFw;
-        cfptr c_pw1 = cptr(w.pw1);
-        ADE_KEEP_IN_LOOP(c_pw1);
-        float acc[16];
-#pragma unroll
-        for (int co = 0; co < 16; ++co) acc[co] = c_pw1_b[co];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int ff = f - 1 + o;
+    // ---- phase 0: stage the pointwise input x1 = (a + skip)[:, :8] in LDS planes 2-3 (own position, fully coalesced);
+    //      skipped when the previous stage of this launch left it there.
+    if (!x1_in_lds) {
+        for (int p = tid; p < P; p += kFusedThreads) {
             float x[8];
-            if (ff >= 0 && ff < kFw) {
-                pl_ld8(ac, P, p - f + ff, 0, x);
-                if (sc) {
-                    float y[8];
-                    pl_ld8(sc, P, p - f + ff, 0, y);
+            pl_ld8(ac, P, p, 0, x);
+            if (sc) {
+                float y[8];
+                pl_ld8(sc, P, p, 0, y);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] += y[i];
-                }
-            } else {
+                for (int k = 0; k < 8; ++k) x[k] += y[k];
+            }
+            H[2 * kPmax + p] = make_float4(x[0], x[1], x[2], x[3]);
+            H[3 * kPmax + p] = make_float4(x[4], x[5], x[6], x[7]);
+        }
+        __syncthreads();
+    }
+    // ---- phase 1: SFE(3) -> 1x1 (24->16) + BN + PReLU, neighbours from LDS.  Output channels 0-7 go straight to planes 0-1;
+    //      channels 8-15 wait in registers until every lane has read its x1 neighbours out of planes 2-3.   (:305-310)
+    float hi[kPosPerThread][8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = 0.0f;
+    for (int i = 0; i < kPosPerThread; ++i) {
+        const int p = tid + i * kFusedThreads;
+        if (p < P) {
+            const int t = p / kFw, f = p - t * kFw;
+            cfptr c_pw1 = cptr(w.pw1);
+            ADE_KEEP_IN_LOOP(c_pw1);
+            float acc[16];
+#pragma unroll
+            for (int co = 0; co < 16; ++co) acc[co] = c_pw1_b[co];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const int ff = f - 1 + o;
+                if (ff < 0 || ff >= kFw) continue;
+                const float4 xa = H[2 * kPmax + p - 1 + o], xb = H[3 * kPmax + p - 1 + o];
+                const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int co = 0; co < 16; ++co) acc[co] += c_pw1[(c * 3 + o) * 16 + co] * x[c];
             }
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], w.pw1_slope);
+            H[p] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            H[kPmax + p] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 #pragma unroll
-                for (int co = 0; co < 16; ++co) acc[co] += c_pw1[(c * 3 + o) * 16 + co] * x[c];
+            for (int k = 0; k < 8; ++k) hi[i][k] = acc[8 + k];
         }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            H[q * kPmax + p] = make_float4(prelu_f(acc[4 * q], w.pw1_slope), prelu_f(acc[4 * q + 1], w.pw1_slope),
-                                           prelu_f(acc[4 * q + 2], w.pw1_slope), prelu_f(acc[4 * q + 3], w.pw1_slope));
+    for (int i = 0; i < kPosPerThread; ++i) {
+        const int p = tid + i * kFusedThreads;
+        if (p < P) {
+            H[2 * kPmax + p] = make_float4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+            H[3 * kPmax + p] = make_float4(hi[i][4], hi[i][5], hi[i][6], hi[i][7]);
+        }
     }
     __syncthreads();
     ADE_CLK(1);
@@ -205,7 +232,21 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     ADE_CLK(5);
     // ---- phase 4b: the serial part, GRU(8->16) over T on one 16-lane row (all four rows of wave 0 run it redundantly;
     //      h exchanged with row_newbcast DPP)                                                    (:149,155)
-    if (tid < 64) {
+    if (tid >= 64) {
+        // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
+        for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
+            float by[8];
+            pl_ld8(ac, P, p, 2, by);
+            if (sc) {
+                float y[8];
+                pl_ld8(sc, P, p, 2, y);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) by[k] += y[k];
+            }
+            H[p] = make_float4(by[0], by[1], by[2], by[3]);
+            H[kPmax + p] = make_float4(by[4], by[5], by[6], by[7]);
+        }
+    } else {
         const int j = tid & 15;
         const float* pk = w.gru + j * 78;
         float wh[3][16], bh[3];
@@ -251,24 +292,33 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     }
     __syncthreads();
     ADE_CLK(7);
-    // ---- phase 5: gate, interleave with the bypass half, store                                 (:156,324)
+    // ---- phase 5: gate, interleave with the bypass half (LDS), store; optionally leave the next block's pointwise input
+    //      (out[:, :8] + next_skip[:, :8]) in planes 2-3                                            (:156,324)
+    const float* nsc = next_skip ? next_skip + (size_t)chunk * kCh * P : nullptr;
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
         if (p < P) {
             const int t = p / kFw;
-            float by[8];
-            pl_ld8(ac, P, p, 2, by);
-            if (sc) {
-                float y[8];
-                pl_ld8(sc, P, p, 2, y);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) by[k] += y[k];
-            }
+            const float4 b0 = H[p], b1 = H[kPmax + p];
+            const float by[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             float o[16];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { o[2 * k] = h1r[i][k] * at[t * 8 + k]; o[2 * k + 1] = by[k]; }
             pl_st16(oc, P, p, o);
+            if (next_x1) {
+                float n8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) n8[k] = o[k];
+                if (nsc) {
+                    float y[8];
+                    pl_ld8(nsc, P, p, 0, y);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) n8[k] += y[k];
+                }
+                H[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
+                H[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
+            }
         }
     }
     ADE_CLK(8);
@@ -356,7 +406,8 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
 }
 
 __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const float* __restrict__ x, const DpW& w, float* __restrict__ out,
-                                             int T, long long* __restrict__ clk) {
+                                             int T, long long* __restrict__ clk, bool next_x1 = false,
+                                             const float* __restrict__ next_skip = nullptr) {
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
     float* red = reinterpret_cast<float*>(smem + 4 * kPmax);
@@ -499,6 +550,19 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
 #pragma unroll
             for (int co = 0; co < 16; ++co) y[i][co] += m[co];
             pl_st16(oc, P, p, y[i]);
+            if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (R is dead)
+                float n8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) n8[k] = y[i][k];
+                if (next_skip) {
+                    float sk[8];
+                    pl_ld8(next_skip + (size_t)chunk * kCh * P, P, p, 0, sk);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) n8[k] += sk[k];
+                }
+                R[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
+                R[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
+            }
         }
     }
     ADE_CLK(20);

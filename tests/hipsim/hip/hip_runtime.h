@@ -121,6 +121,7 @@ static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); retur
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline long long wall_clock64() { return 0; }
+static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }   // fibers never preempt
 static inline void __builtin_amdgcn_wave_barrier() { (void)::hipsim::wave_exchange(0u, ::hipsim::lane_id()); }
 static inline long long clock64() { return 0; }
 static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }

@@ -7,10 +7,10 @@ from audio_denoiser_onnx_amd.synth import synth_batch
 s = make_session(None)
 for B in (1, 256):
     x = synth_batch(B)
-    s.process(x); s.profile(True); s.process(x); s.process(x)
+    s.process(x); s.profile(1); s.process(x); s.process(x)
     c = s.tap('phase_clock', 64).astype(int)
-    print('B', B, 'gtblock[pw1,dw,h1,energy,GI,GRU,at,out]:', (c[1:9] - c[0:8]).tolist(), 'total', c[8])
+    print('B', B, 'gtblock[pw1,dw,h1,energy+GI,-,GRU,at,out]:', (c[1:9] - c[0:8]).tolist(), 'total', c[8])
     print('B', B, 'dpgrnn [intra,fcln,inter,fcln]       :', (c[17:21] - c[16:20]).tolist(), 'total', c[20])
-    print('B', B, 'front  [mean,stft,conv0,conv1]       :', (c[33:37] - c[32:36]).tolist(), 'total', c[36])
-    print('B', B, 'back   [deconv3,deconv4,istft,pcm]   :', (c[49:53] - c[48:52]).tolist(), 'total', c[52])
-    s.profile(False)
+    print('B', B, 'front  [mean | last tile: stft..conv0, conv0..conv1, conv1]:', c[33] - c[32], (c[35:37] - c[34:36]).tolist(), 'total', c[36])
+    print('B', B, 'back   [last tile: stage+deconv3, +e0, deconv4, istft] :', (c[50:53] - c[49:52]).tolist(), 'total', c[53])
+    s.profile(0)
