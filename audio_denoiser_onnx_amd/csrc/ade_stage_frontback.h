@@ -284,6 +284,17 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
 
     for (int t0 = 0; t0 < T; t0 += kTileF) {
         const int nf = T - t0 < kTileF ? T - t0 : kTileF;
+        // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase four barriers later (hides L2/HBM)
+        float sre[5], sim[5];
+        {
+            const int tcp = wave < nf ? t0 + wave : t0;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int k = r < 4 ? lane + 64 * r : 256;
+                sre[r] = (r < 4 || lane == 0) ? specc[((size_t)tcp * 2 + 0) * kBinsPad + k] : 0.0f;
+                sim[r] = (r < 4 || lane == 0) ? specc[((size_t)tcp * 2 + 1) * kBinsPad + k] : 0.0f;
+            }
+        }
         // ---- stage S = (x + e1) of the tile: own-position, fully coalesced loads                    (:527)
         for (int idx = tid; idx < nf * kFw; idx += kFusedThreads) {
             float a[16], b[16];
@@ -380,15 +391,13 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         // ---- ERB split + complex ratio mask + irFFT-512 + synthesis window + overlap-add, one wavefront per frame.
         //      Neighbouring frames run concurrently and overlap by 256 samples: see the two-parity add below.
         {
-            const int t = t0 + wave;
             const bool live = wave < nf;
-            const int tc = live ? t : t0;
             const float* mr = M + (size_t)(live ? wave : 0) * 2 * kErbPad;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 if (r == 4 && lane != 0) break;
                 const int k = r < 4 ? lane + 64 * r : 256;
-                const float xr = specc[((size_t)tc * 2 + 0) * kBinsPad + k], xi = specc[((size_t)tc * 2 + 1) * kBinsPad + k];
+                const float xr = sre[r], xi = sim[r];
                 float m0, m1;
                 if (k < kErbLow) {
                     m0 = mr[k];

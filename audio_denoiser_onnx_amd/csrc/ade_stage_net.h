@@ -331,7 +331,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
 // LDS: R[4][kPmax] float4 (rnn outputs, then mid, then rnn outputs again) | red[kPmax] | stat[2][64].
 // `mid` is parked in the output buffer between the two halves (same thread writes and re-reads it).
 // ---------------------------------------------------------------------------------------------------------
-constexpr size_t kDpSmemBytes = (size_t)4 * kPmax * 16 + (size_t)kPmax * 4 + 2 * kTmaxFused * 4;
+constexpr size_t kDpSmemBytes = (size_t)4 * kPmax * 16 + (size_t)kPmax * 4 + 2 * kTmaxFused * 4 + (size_t)4 * kFw * kCh * 4;   // + 4 LayerNorm tables
 
 // Linear(16,16) on the rnn output of each of this thread's positions, two-pass LayerNorm statistics per frame
 // through LDS, then  y = res + (v - mean) * rstd * gamma + beta.   v/res/y: [kPosPerThread][16] registers.
@@ -412,10 +412,17 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     float* Rf = reinterpret_cast<float*>(smem);
     float* red = reinterpret_cast<float*>(smem + 4 * kPmax);
     float* stat = red + kPmax;
+    float* lnt = stat + 2 * kTmaxFused;   // LDS copies of the 4 LayerNorm tables [intra gamma | intra beta | inter gamma | inter beta]
     const int P = T * kFw;
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
+    for (int i = tid; i < kFw * kCh; i += kFusedThreads) {   // (made visible by the barrier after phase A)
+        lnt[i] = w.intra_ln_w[i];
+        lnt[kFw * kCh + i] = w.intra_ln_b[i];
+        lnt[2 * kFw * kCh + i] = w.inter_ln_w[i];
+        lnt[3 * kFw * kCh + i] = w.inter_ln_b[i];
+    }
     const float* xc = x + (size_t)chunk * kCh * P;
     float* oc = out + (size_t)chunk * kCh * P;
 
@@ -475,7 +482,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     //      (mid is parked in `out` -- L2-resident, re-read by the same thread in phase D -- instead of 48 live VGPRs)
     {
         float mid[kPosPerThread][16];
-        fc_ln_phase(R, red, stat, w.intra_fc, w.intra_fc_b, w.intra_ln_w, w.intra_ln_b, T, P, tid, mid);
+        fc_ln_phase(R, red, stat, w.intra_fc, w.intra_fc_b, lnt, lnt + kFw * kCh, T, P, tid, mid);
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
             const int p = tid + i * kFusedThreads;
@@ -540,7 +547,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     ADE_CLK(19);
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
     float y[kPosPerThread][16];
-    fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, w.inter_ln_w, w.inter_ln_b, T, P, tid, y);
+    fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, tid, y);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
