@@ -61,6 +61,32 @@ __device__ __forceinline__ float dpp_mov(float v) {
 template <int K> __device__ __forceinline__ float row_bcast(float v) { return dpp_mov<0x150 + K>(v); }    // K < 16
 template <int K> __device__ __forceinline__ float quad_bcast(float v) { return dpp_mov<K * 0x55>(v); }   // K < 4
 template <int N> __device__ __forceinline__ float row_ror(float v) { return dpp_mov<0x120 + N>(v); }     // rotate within the 16-lane row, 1 <= N <= 15
+template <int N> __device__ __forceinline__ float quad_rot(float v) {                                      // lane u of a quad reads lane (u+N)&3
+    return dpp_mov<((N) & 3) | (((N + 1) & 3) << 2) | (((N + 2) & 3) << 4) | (((N + 3) & 3) << 6)>(v);
+}
+
+// Cross-row moves inside a wavefront (gfx950 v_permlane16_swap_b32 / v_permlane32_swap_b32).  With 16-lane rows r0..r3:
+//   swap16(v, s): .a = [v.r0, s.r0, v.r2, s.r2]   .b = [v.r1, s.r1, v.r3, s.r3]
+//   swap32(v, s): .a = [v.r0, v.r1, s.r0, s.r1]   .b = [v.r2, v.r3, s.r2, s.r3]
+struct Swapped { float a, b; };
+__device__ __forceinline__ Swapped swap16(float v, float s) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(s), false, false);
+    return Swapped{__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+}
+__device__ __forceinline__ Swapped swap32(float v, float s) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(v), (unsigned)__float_as_int(s), false, false);
+    return Swapped{__int_as_float((int)r[0]), __int_as_float((int)r[1])};
+}
+
+// Two-wide fp32 vector: arithmetic on it is what becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (the packed fp32 ops
+// the 157 TFLOP/s fp32 peak is quoted on).  The recurrent loops are VALU-issue-bound, so halving the FMA instruction
+// count is a direct win.  (g++ spelling for the host-side simulator build under tests/hipsim.)
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float v2f __attribute__((vector_size(8)));
+#endif
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r[0] = a; r[1] = b; return r; }
 
 // Wave-uniform, read-only tables (conv / Linear weights): viewing them through the CONSTANT address space lets the
 // compiler fetch them with scalar loads (s_load through the scalar cache -> SGPR operands of v_fma) even when the

@@ -230,8 +230,11 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     __syncthreads();
     ADE_CLK(4);
     ADE_CLK(5);
-    // ---- phase 4b: the serial part, GRU(8->16) over T on one 16-lane row (all four rows of wave 0 run it redundantly;
-    //      h exchanged with row_newbcast DPP)                                                    (:149,155)
+    // ---- phase 4b: the serial part, GRU(8->16) over T, on wave 0.  Its step latency IS this stage's critical path
+    //      (the other 15 wavefronts wait), so it is written for instruction count: the three gate mat-vecs run in
+    //      PARALLEL on the wavefront's 16-lane rows (row 0: r, row 2: z, rows 1/3: W_hn h), every row holds a copy of
+    //      h and gathers it with 15 row rotations against pre-rotated packed weights, and the gates meet through four
+    //      cross-row swaps per step: ~46 instructions instead of ~100.                              (:149,155)
     if (tid >= 64) {
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
         for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
@@ -247,36 +250,47 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             H[kPmax + p] = make_float4(by[4], by[5], by[6], by[7]);
         }
     } else {
-        const int j = tid & 15;
-        const float* pk = w.gru + j * 78;
-        float wh[3][16], bh[3];
+        const int j = tid & 15, row = tid >> 4;
+        const int gsel = (row & 1) ? 2 : (row >> 1);                 // gate of this row: r, n, z, n
+        const float* pk = w.gru + j * 78 + 24 + gsel * 16;           // W_h{gate}[j][:]
+        int ks[16];                                                  // ks[s] = hidden index delivered by rotation s (measured)
+        ks[0] = j;
+#define ADE_KS(S) ks[S] = (int)row_ror<S>((float)j);
+        ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7) ADE_KS(8)
+        ADE_KS(9) ADE_KS(10) ADE_KS(11) ADE_KS(12) ADE_KS(13) ADE_KS(14) ADE_KS(15)
+#undef ADE_KS
+        v2f wr[8];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) wh[g][k] = pk[24 + g * 16 + k];
-            bh[g] = pk[75 + g];
-        }
-        float h = 0.0f;
-        // The step latency IS the kernel's critical path: the three 16-term dot products run as 4 independent
-        // partial sums each (12 chains of 4 FMAs instead of 3 chains of 16) and the step's three input-projection
-        // values are fetched from LDS one step ahead, so nothing but the h -> gates -> h chain is serial.
-        float gi_r = GI[j], gi_z = GI[16 + j], gi_n = GI[32 + j];
+        for (int m = 0; m < 8; ++m) wr[m] = mk2(pk[ks[2 * m]], pk[ks[2 * m + 1]]);
+        const float bh = w.gru[j * 78 + 75 + gsel];
+        float h = 0.0f;                                              // the same h_{t-1}[j] in all four rows
+        float gi = GI[gsel * 16 + j];                                // this row's input projection, fetched one step ahead
         for (int t = 0; t < T; ++t) {
             const int tn = t + 1 < T ? t + 1 : t;
-            const float nx_r = GI[tn * 48 + j], nx_z = GI[tn * 48 + 16 + j], nx_n = GI[tn * 48 + 32 + j];
-            float ar[4] = {bh[0], 0.0f, 0.0f, 0.0f}, az[4] = {bh[1], 0.0f, 0.0f, 0.0f}, an[4] = {bh[2], 0.0f, 0.0f, 0.0f};
-#define ADE_TRA_K(K) { const float hk = row_bcast<K>(h); ar[K & 3] += wh[0][K] * hk; az[K & 3] += wh[1][K] * hk; an[K & 3] += wh[2][K] * hk; }
-            ADE_REP16(ADE_TRA_K)
-#undef ADE_TRA_K
-            const float gr = (ar[0] + ar[1]) + (ar[2] + ar[3]);
-            const float gz = (az[0] + az[1]) + (az[2] + az[3]);
-            const float gn = (an[0] + an[1]) + (an[2] + an[3]);
-            const float r = sigmoid_f(gi_r + gr);
-            const float z = sigmoid_f(gi_z + gz);
-            const float n = tanh_f(gi_n + r * gn);
-            h = (1.0f - z) * n + z * h;
+            const float gnx = GI[tn * 48 + gsel * 16 + j];
+            float hs[16];
+            hs[0] = h;
+#define ADE_HS(S) hs[S] = row_ror<S>(h);
+            ADE_HS(1) ADE_HS(2) ADE_HS(3) ADE_HS(4) ADE_HS(5) ADE_HS(6) ADE_HS(7) ADE_HS(8)
+            ADE_HS(9) ADE_HS(10) ADE_HS(11) ADE_HS(12) ADE_HS(13) ADE_HS(14) ADE_HS(15)
+#undef ADE_HS
+            v2f a0 = mk2(bh, 0.0f), a1 = mk2(0.0f, 0.0f);
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) {
+                a0 += wr[m] * mk2(hs[2 * m], hs[2 * m + 1]);
+                a1 += wr[m + 1] * mk2(hs[2 * m + 2], hs[2 * m + 3]);
+            }
+            const v2f a2 = a0 + a1;
+            const float a = a2[0] + a2[1];                           // b_h + W_h{gate} h      (every row its own gate)
+            const float sg = sigmoid_f(gi + a);                      // rows 0 / 2: r / z
+            const float X = swap16(sg, sg).a;                        // rows 1 / 3 <- r / z
+            const float n = tanh_f(gi + X * a);                      // row 1: n = tanh(gi_n + r * (b_hn + W_hn h))
+            const float n3 = swap32(n, n).a;                         // row 3 <- n (row 1); row 3 already holds z in X
+            const float hc = n3 + X * (h - n3);                      // row 3: h_t = (1 - z) n + z h_{t-1}
+            const float hb = swap32(hc, hc).b;                       // rows 1, 3 <- h_t
+            h = swap16(hb, hb).b;                                    // all rows <- h_t
             if (tid < 16) HS[t * 16 + j] = h;
-            gi_r = nx_r; gi_z = nx_z; gi_n = nx_n;
+            gi = gnx;
         }
     }
     __syncthreads();
@@ -434,17 +448,23 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
         const int grp = q >> 3, dir = (q >> 2) & 1;
         const bool live = t < T;
         const int tc = live ? t : T - 1;
-        const float* pk = w.intra_gru + q * 42;
-        float wi[3][8], wh[3][4], bi[3], bh[3];
+        const float* pk = w.intra_gru + q * 42;                      // [W_ih 3x8 | W_hh 3x4 | b_ih 3 | b_hh 3] of this output row
+        const int unit = q & 3;
+        int ks[4];                                                   // ks[s] = hidden index delivered by quad rotation s
+        ks[0] = unit;
+        ks[1] = (int)quad_rot<1>((float)unit); ks[2] = (int)quad_rot<2>((float)unit); ks[3] = (int)quad_rot<3>((float)unit);
+        // packed-fp32 formulation (see the inter GRU below): r|z share one accumulator, n is packed over input pairs
+        v2f wi_rz[8], wh_rz[4], wi_n[4], wh_n[2];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
+        for (int k = 0; k < 8; ++k) wi_rz[k] = mk2(pk[k], pk[8 + k]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wi[g][k] = pk[g * 8 + k];
+        for (int k = 0; k < 4; ++k) wh_rz[k] = mk2(pk[24 + ks[k]], pk[28 + ks[k]]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wh[g][k] = pk[24 + g * 4 + k];
-            bi[g] = pk[36 + g];
-            bh[g] = pk[39 + g];
-        }
+        for (int m = 0; m < 4; ++m) wi_n[m] = mk2(pk[16 + 2 * m], pk[16 + 2 * m + 1]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wh_n[m] = mk2(pk[32 + ks[2 * m]], pk[32 + ks[2 * m + 1]]);
+        const v2f b_rz = mk2(pk[36] + pk[39], pk[37] + pk[40]);
+        const float bi_n = pk[38], bh_n = pk[41];
         const int prow = tc * kFw;
         float h = 0.0f;
         // inputs come from HBM/L2 (~1 us away): a 4-slot register ring keeps three steps of loads in flight, and the
@@ -457,22 +477,21 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
             const int f = dir ? kFw - 1 - s : s;
             if (s + 3 < kFw) pl_ld8(xc, P, prow + (dir ? f - 3 : f + 3), grp * 2, xq[(s + 3) & 3]);
             const float* xv = xq[s & 3];
-            float gi[3], gh[3];
+            v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) { gi[g] = bi[g]; gh[g] = bh[g]; }
+            for (int k = 0; k < 8; ++k) a_rz += wi_rz[k] * xv[k];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gi[g] += wi[g][k] * xv[k];
-            {
-                const float h0 = quad_bcast<0>(h), h1 = quad_bcast<1>(h), h2 = quad_bcast<2>(h), h3 = quad_bcast<3>(h);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gh[g] += (wh[g][0] * h0 + wh[g][1] * h1) + (wh[g][2] * h2 + wh[g][3] * h3);
-            }
-            const float r = sigmoid_f(gi[0] + gh[0]);
-            const float z = sigmoid_f(gi[1] + gh[1]);
-            const float n = tanh_f(gi[2] + r * gh[2]);
-            h = (1.0f - z) * n + z * h;
+            for (int m = 0; m < 4; ++m) a_n += wi_n[m] * mk2(xv[2 * m], xv[2 * m + 1]);
+            const float h1 = quad_rot<1>(h), h2 = quad_rot<2>(h), h3 = quad_rot<3>(h);
+            v2f c0 = a_rz, c1 = mk2(0.0f, 0.0f), c_n = mk2(bh_n, 0.0f);
+            c0 += wh_rz[0] * h; c1 += wh_rz[1] * h1; c0 += wh_rz[2] * h2; c1 += wh_rz[3] * h3;
+            c_n += wh_n[0] * mk2(h, h1);
+            c_n += wh_n[1] * mk2(h2, h3);
+            const v2f rz = c0 + c1;
+            const float r = sigmoid_f(rz[0]);
+            const float z = sigmoid_f(rz[1]);
+            const float n = tanh_f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1]));
+            h = n + z * (h - n);
             if (live) Rf[((size_t)(q >> 2) * kPmax + tc * kFw + f) * 4 + (q & 3)] = h;
         }
     }
@@ -500,22 +519,36 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     }
     __syncthreads();
     ADE_CLK(18);
-    // ---- phase C: inter GRNN.  16 lanes per F column: lane = group*8 + unit; GRU(8->8) along T, in place in R
+    // ---- phase C: inter GRNN.  16 lanes per F column: lane = 2*unit + group; GRU(8->8) along T, in place in R
     //      (a column position is read, then overwritten, by its own 16 lanes only).              (:450-455,478-479)
+    //      The loop is VALU-issue-bound (9 wavefronts on 4 SIMDs), so it is written for instruction count: r|z gates as
+    //      one packed accumulator, the n gate packed over input pairs, and the 8 hidden values of a lane's own group
+    //      fetched with 7 row rotations by 2s (group in the lane's low bit => a rotation by 2s stays inside the group);
+    //      each lane keeps its recurrent weights pre-rotated to match.
     if (tid < ((kFw * 16 + 63) / 64) * 64) {
         const int f = tid >> 4, q = tid & 15;
-        const int grp = q >> 3;
+        const int grp = q & 1, unit = q >> 1;
         const bool live = f < kFw;
         const int fc_ = live ? f : kFw - 1;
-        const float* pk = w.inter_gru + q * 54;
-        float wi[3][8], wh[3][8], bi[3], bh[3];
+        const float* pk = w.inter_gru + (grp * 8 + unit) * 54;      // [W_ih 3x8 | W_hh 3x8 | b_ih 3 | b_hh 3] of this output row
+        int ks[8];                                                   // ks[s] = hidden index delivered by rotation s (measured, so the
+        ks[0] = unit;                                                // rotation direction convention cannot matter)
+#define ADE_KS(S) ks[S] = ((int)row_ror<2 * S>((float)q)) >> 1;
+        ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7)
+#undef ADE_KS
+        v2f wi_rz[8], wh_rz[8], wi_n[4], wh_n[4];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { wi[g][k] = pk[g * 8 + k]; wh[g][k] = pk[24 + g * 8 + k]; }
-            bi[g] = pk[48 + g];
-            bh[g] = pk[51 + g];
+        for (int k = 0; k < 8; ++k) {
+            wi_rz[k] = mk2(pk[k], pk[8 + k]);
+            wh_rz[k] = mk2(pk[24 + ks[k]], pk[32 + ks[k]]);
         }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            wi_n[m] = mk2(pk[16 + 2 * m], pk[16 + 2 * m + 1]);
+            wh_n[m] = mk2(pk[40 + ks[2 * m]], pk[40 + ks[2 * m + 1]]);
+        }
+        const v2f b_rz = mk2(pk[48] + pk[51], pk[49] + pk[52]);
+        const float bi_n = pk[50], bh_n = pk[53];
         float h = 0.0f;
         float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
         for (int t = 0; t < T; ++t) {
@@ -524,23 +557,27 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
             const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
             xa = R[(grp * 2) * kPmax + pn];          // next step's input: issued now, needed after this step's write
             xb = R[(grp * 2 + 1) * kPmax + pn];
-            float gi[3], ga[3], gb[3];
+            v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) { gi[g] = bi[g]; ga[g] = bh[g]; gb[g] = 0.0f; }
+            for (int k = 0; k < 8; ++k) a_rz += wi_rz[k] * xv[k];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int m = 0; m < 4; ++m) a_n += wi_n[m] * mk2(xv[2 * m], xv[2 * m + 1]);
+            float hs[8];
+            hs[0] = h;
+#define ADE_HS(S) hs[S] = row_ror<2 * S>(h);
+            ADE_HS(1) ADE_HS(2) ADE_HS(3) ADE_HS(4) ADE_HS(5) ADE_HS(6) ADE_HS(7)
+#undef ADE_HS
+            v2f c0 = a_rz, c1 = mk2(0.0f, 0.0f), c_n = mk2(bh_n, 0.0f);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gi[g] += wi[g][k] * xv[k];
-#define ADE_INTER_K(K, ACC) { const float lo = row_bcast<K>(h), hi = row_bcast<K + 8>(h); const float hk = grp ? hi : lo; \
-                              ACC[0] += wh[0][K] * hk; ACC[1] += wh[1][K] * hk; ACC[2] += wh[2][K] * hk; }
-            ADE_INTER_K(0, ga) ADE_INTER_K(1, gb) ADE_INTER_K(2, ga) ADE_INTER_K(3, gb)
-            ADE_INTER_K(4, ga) ADE_INTER_K(5, gb) ADE_INTER_K(6, ga) ADE_INTER_K(7, gb)
-#undef ADE_INTER_K
-            const float r = sigmoid_f(gi[0] + (ga[0] + gb[0]));
-            const float z = sigmoid_f(gi[1] + (ga[1] + gb[1]));
-            const float n = tanh_f(gi[2] + r * (ga[2] + gb[2]));
-            h = (1.0f - z) * n + z * h;
-            if (live) Rf[((size_t)(q >> 2) * kPmax + p) * 4 + (q & 3)] = h;
+            for (int k = 0; k < 8; k += 2) { c0 += wh_rz[k] * hs[k]; c1 += wh_rz[k + 1] * hs[k + 1]; }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) c_n += wh_n[m] * mk2(hs[2 * m], hs[2 * m + 1]);
+            const v2f rz = c0 + c1;
+            const float r = sigmoid_f(rz[0]);
+            const float z = sigmoid_f(rz[1]);
+            const float n = tanh_f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1]));
+            h = n + z * (h - n);
+            if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
         }
     }
     __syncthreads();

@@ -117,6 +117,22 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     else { fprintf(stderr, "hipsim: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
     return (int)::hipsim::wave_exchange((uint32_t)src, from);
 }
+// gfx950 v_permlane16_swap_b32 / v_permlane32_swap_b32 (semantics probed on hardware, tools/ubench/permlane_probe.hip):
+//   p16: vdst' = [vdst.r0, src0.r0, vdst.r2, src0.r2], src0' = [vdst.r1, src0.r1, vdst.r3, src0.r3]  (16-lane rows)
+//   p32: vdst' = [vdst.lo, src0.lo],                   src0' = [vdst.hi, src0.hi]                      (32-lane halves)
+struct hipsim_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline hipsim_u2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src0, bool, bool) {
+    const int lane = ::hipsim::lane_id();
+    const unsigned s_prev = ::hipsim::wave_exchange(src0, (lane - 16) & 63), v_next = ::hipsim::wave_exchange(vdst, (lane + 16) & 63);
+    const bool odd = (lane >> 4) & 1;
+    return hipsim_u2{{odd ? s_prev : vdst, odd ? src0 : v_next}};
+}
+static inline hipsim_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src0, bool, bool) {
+    const int lane = ::hipsim::lane_id();
+    const unsigned s_lo = ::hipsim::wave_exchange(src0, (lane - 32) & 63), v_hi = ::hipsim::wave_exchange(vdst, (lane + 32) & 63);
+    const bool hi = lane >= 32;
+    return hipsim_u2{{hi ? s_lo : vdst, hi ? src0 : v_hi}};
+}
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
