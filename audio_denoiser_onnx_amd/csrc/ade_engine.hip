@@ -618,6 +618,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         // ---- fused path: one 1024-thread workgroup per chunk per stage, activations LDS-resident, inter-stage tensors
         //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
         long long* clk = prof ? e->d_clk : nullptr;
+        if (clk) (void)hipMemsetAsync(e->d_clk, 0, 64 * sizeof(long long), s);   // phase accumulators start from zero
         if (e->use_single && (!prof || e->profile_mode == 2)) {
             ChunkArgs A{};
             A.pcm_in = d_in; A.pcm_out = d_out; A.f32_out = d_f32; A.L = e->in_len; A.T = T;
@@ -913,7 +914,8 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         if (count < 64) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
         long long raw[64];
         HIP_TRY(h, hipMemcpy(raw, h->d_clk, sizeof raw, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 64; ++i) out[i] = (float)(raw[i] - raw[(i / 16) * 16]);
+        for (int i = 0; i < 64; ++i)   // slots 40-47 / 56-63 are per-phase accumulators over the tile loops (raw tick sums)
+            out[i] = (i & 15) >= 8 && i >= 32 ? (float)raw[i] : (float)(raw[i] - raw[(i / 16) * 16]);
         *written = 64;
         return ADE_OK;
     }

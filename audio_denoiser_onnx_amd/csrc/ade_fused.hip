@@ -49,19 +49,19 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
     HIP_DYNAMIC_SHARED(float4, smem)
     const int chunk = blockIdx.x;
     float* fsm = reinterpret_cast<float*>(smem);
-    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, A.clk);
+    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, /*clk=*/nullptr);
     __syncthreads();
     const float* x = A.e1;
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // encoder GTConvBlocks
-        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, i == 0 ? A.clk : nullptr, /*x1_in_lds=*/i > 0,
+        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, /*clk=*/nullptr, /*x1_in_lds=*/i > 0,
                       /*next_x1=*/i < 2, nullptr);
         __syncthreads();
         x = A.xe[i];
     }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
-        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, i == 0 ? A.clk : nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
+        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, /*clk=*/nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
         __syncthreads();
         x = A.dpo[i];
     }
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
         __syncthreads();
         x = A.xd[i];
     }
-    back_stage(fsm, chunk, x, A.e1, A.e0, A.spec, A.de3, A.de4, A.erb_bs, A.tabs, A.d3, A.mask, A.pcm_out, A.f32_out, A.T, A.clk);
+    back_stage(fsm, chunk, x, A.e1, A.e0, A.spec, A.de3, A.de4, A.erb_bs, A.tabs, A.d3, A.mask, A.pcm_out, A.f32_out, A.T, /*clk=*/nullptr);   // phase clocks exist in the per-stage kernels only
 }
 
 }  // namespace

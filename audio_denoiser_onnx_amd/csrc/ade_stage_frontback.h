@@ -9,6 +9,14 @@
 //                 only) -> ERB split -> complex ratio mask -> irFFT-512 -> window -> overlap-add (LDS, 256-sample carry
 //                 between tiles) -> /sum(w^2) -> *32767, clamp, truncate -> int16
 // so a neighbour tap never costs a second trip to L2/HBM and d3 / mask / windowed frames never leave the CU.
+//
+// Work decomposition.  16 frames x 65 columns = 1040 and 16 x 33 x 2 groups = 1056 are both just over the 1024 lanes of
+// the workgroup, so every conv phase is ONE full round over 16 frames x 64 (or 32 columns x 2 channel groups) = exactly
+// 1024 lane-tasks -- no idle wavefronts, no integer division, group index wave-uniform so the weights stay scalar
+// operands -- plus a small TAIL for the last column of each frame, spread one output channel per lane over 256 (32)
+// lanes.  The 256 workgroups of a batch run in lock-step, so HBM would see bursts at every staging phase; instead
+// the loads a tile needs (next tile's PCM pairs, this tile's spectrum and e0, next tile's d2/e1) are issued one or
+// more compute phases ahead of their use and land in registers while the FMAs run.
 // Inter-stage tensors in HBM are channel-quad planar (ade_stage_net.h).
 // Reference lines: Export_GTCRN.py:637-647, 594-595, 99-102, 117-141, 159-197, 488-489, 515-516, 104-107, 583-590, 681-690 ;
 // STFT_Process.py:303-316, 239-251, 326-336.
@@ -23,6 +31,8 @@ constexpr int kTileF = 16;            // frames per tile = wavefronts per workgr
 constexpr int kTileP1 = kTileF * kF1; // 1040 positions of width 65
 constexpr int kTileP = kTileF * kFw;  // 528 positions of width 33
 constexpr size_t kTabFloats = 512 + 2 * 256 + 2 * 264;   // window | tw256 | tw512 staged in LDS
+constexpr int kBmCap = 16;            // ERB-merge band rows kept in LDS (wider band tables are read from L2)
+constexpr int kBsCap = 4;             // ERB-split band rows kept in LDS
 
 // X[k] of the 512-point real FFT from the packed 256-point FFT Z:  E = (Z[k] + conj Z[256-k])/2,
 // O = -i (Z[k] - conj Z[256-k])/2,  X[k] = E + e^{-2 pi i k/512} O.   zp = Z[256-k] (un-conjugated).
@@ -44,11 +54,49 @@ __device__ __forceinline__ LdsTabs stage_tables(float* dst, const FftTabs& t, in
     return LdsTabs{win, reinterpret_cast<const float2*>(tw256), reinterpret_cast<const float2*>(tw512)};
 }
 
+// The 4 sample pairs (2n, 2n+1), n = lane + 64 r, of frame t that this lane windows: packed int16 pairs, reflect-padded
+// at the chunk edges (STFT_Process.py:306-309).  Plain loads, no dependence on the DC mean: issued a whole tile ahead.
+__device__ __forceinline__ void load_frame_pairs(const int16_t* __restrict__ row, int L, int t, int lane, bool live, bool pair_ok, int* raw) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = lane + 64 * r;
+        const int j0 = kHop * t + 2 * n - kNfft / 2;             // even index of the pair
+        if (!live) {
+            raw[r] = 0;
+        } else if (pair_ok && j0 >= 0 && j0 + 1 < L) {            // interior: one aligned 32-bit load
+            raw[r] = *reinterpret_cast<const int*>(row + j0);
+        } else {
+            int ja = j0, jb = j0 + 1;
+            ja = ja < 0 ? -ja : (ja >= L ? 2 * (L - 1) - ja : ja);
+            jb = jb < 0 ? -jb : (jb >= L ? 2 * (L - 1) - jb : jb);
+            raw[r] = ((int)row[ja] & 0xffff) | ((int)row[jb] << 16);
+        }
+    }
+}
+
+// ERB merge of one frame, one band per lane: banded sum == the dense 192x64 matmul term for term    (Export_GTCRN.py:99-102)
+__device__ __forceinline__ void erb_merge(const float* wtab, int count, int s0, const float2* buf, int lane, float* fr) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int n = 0; n < count; ++n) {
+        const float wv = wtab[n * kErbBands + lane];
+        const float2 x = buf[kErbLow + min(s0 + n, kErbHigh - 1)];
+        a0 += sqrtf((x.x * x.x + x.y * x.y) + 1e-12f) * wv;
+        a1 += x.x * wv;
+        a2 += x.y * wv;
+    }
+    fr[kErbLow + lane] = a0;
+    fr[kErb + kErbLow + lane] = a1;
+    fr[2 * kErb + kErbLow + lane] = a2;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// FRONT.  LDS (floats): wbuf[16][264]x2 | feat[16][3][129] | E0[4][1040]x4 | tabs | red[16]
+// FRONT.  LDS (floats): wbuf[16][264]x2 | feat[16][3][129] | E0[4][1040]x4 | tabs | ERB band rows | red[16]
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kFrontFeatFloats = (size_t)kTileF * 3 * kErb;
-constexpr size_t kFrontSmemBytes = ((size_t)16 * kWbuf * 2 + kFrontFeatFloats + (size_t)4 * kTileP1 * 4 + kTabFloats + 16) * 4;
+constexpr int kC0TailW = 27 * 16;       // conv0 taps k = 0..2 (all 16 output channels): the weights the fo = 64 tail uses
+constexpr int kC1TailW = 3 * 2 * 64;    // conv1 taps k = 0..2
+constexpr size_t kFrontSmemBytes = ((size_t)16 * kWbuf * 2 + kFrontFeatFloats + (size_t)4 * kTileP1 * 4 + kTabFloats +
+                                    (size_t)kBmCap * kErbBands + kC0TailW + kC1TailW + 16) * 4;
 
 __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_t* __restrict__ pcm, int L, int T, const FftTabs& tabs,
                                             const BandTab& erb, const ConvW& c0, const ConvW& c1, float* __restrict__ spec,
@@ -56,24 +104,47 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
     float* feat = smem + 16 * kWbuf * 2;
     float4* E0 = reinterpret_cast<float4*>(feat + kFrontFeatFloats);
+    float* E0f = reinterpret_cast<float*>(E0);
     float* tabmem = reinterpret_cast<float*>(E0 + 4 * kTileP1);
-    int* red = reinterpret_cast<int*>(tabmem + kTabFloats);
+    float* erbw = tabmem + kTabFloats;
+    float* w0t = erbw + kBmCap * kErbBands;      // tail weights live in LDS: a tail lane owns ONE output channel, so they
+    float* w1t = w0t + kC0TailW;                 // cannot be scalar operands, and a VMEM load here would have to wait for
+    int* red = reinterpret_cast<int*>(w1t + kC1TailW);   // the (in-order) prefetches in flight
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_, wave = tid >> 6, lane = tid & 63;
-    float2* buf = wbuf_all + wave * kWbuf;
     const int16_t* row = pcm + (size_t)chunk * L;
     const int P0 = T * kF1, P = T * kFw;
     float* e0c = e0 + (size_t)chunk * kCh * P0;
     float* e1c = e1 + (size_t)chunk * kCh * P;
     float* specc = spec + (size_t)chunk * T * 2 * kBinsPad;
     ADE_CLK(32);
+    const bool pair_ok = ((L & 1) == 0) && ((reinterpret_cast<size_t>(row) & 3) == 0);
+    int raw[4];                                            // tile 0's samples: in flight while the mean is computed
+    load_frame_pairs(row, L, wave, lane, wave < T, pair_ok, raw);
     const LdsTabs lt = stage_tables(tabmem, tabs, tid);
+    const bool erb_lds = erb.count <= kBmCap;
+    if (erb_lds)
+        for (int i = tid; i < erb.count * kErbBands; i += kFusedThreads) erbw[i] = erb.w[i];
+    const int erb_s0 = erb.start[lane];
+    for (int i = tid; i < kC0TailW; i += kFusedThreads) w0t[i] = c0.w[i];          // taps k < 3 are the first 27 rows
+    for (int i = tid; i < kC1TailW; i += kFusedThreads) w1t[i] = c1.w[i];          // taps k < 3 are the first 6 (k,g) blocks
+    const float b0t = c0.b[tid & 15], b1t = c1.b[tid & 15];                        // tail biases (lane -> channel, see below)
 
     // ---- F1: DC mean of THIS chunk (exact integer sum, one rounding)                     (Export_GTCRN.py:645-647)
     {
         int s = 0;
-        for (int i = tid; i < L; i += kFusedThreads) s += (int)row[i];
+        if (((L & 7) == 0) && ((reinterpret_cast<size_t>(row) & 15) == 0)) {      // 8 samples per 16-byte load
+            const int4* r4 = reinterpret_cast<const int4*>(row);
+#pragma unroll 2
+            for (int i = tid; i < (L >> 3); i += kFusedThreads) {
+                const int4 q = r4[i];
+                s += (int)(short)(q.x & 0xffff) + (q.x >> 16) + (int)(short)(q.y & 0xffff) + (q.y >> 16)
+                   + (int)(short)(q.z & 0xffff) + (q.z >> 16) + (int)(short)(q.w & 0xffff) + (q.w >> 16);
+            }
+        } else {
+            for (int i = tid; i < L; i += kFusedThreads) s += (int)row[i];
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
         if (lane == 0) red[wave] = s;
@@ -87,34 +158,30 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
         dc = (float)((double)tot / ((double)L * 32768.0));
     }
     ADE_CLK(33);
-    const bool pair_ok = ((L & 1) == 0) && ((reinterpret_cast<size_t>(row) & 3) == 0);
+    long long clk_prev = ADE_CLK_START();
     const cfptr c0b = cptr(c0.b), c1b = cptr(c1.b);
 
     for (int t0 = 0; t0 < T; t0 += kTileF) {
         const int nf = T - t0 < kTileF ? T - t0 : kTileF;
         // ---- F2-F5: one wavefront per frame of the tile
         {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);     // per-iteration copy: keeps the FFT's ~40 loop-invariant LDS addresses from being hoisted
+            const int wave = tq >> 6, lane = tq & 63;      // out of the tile loop (where they would be spilled to scratch)
+            float2* buf = wbuf_all + wave * kWbuf;
             const int t = t0 + wave;
             const bool live = wave < nf;
             float2 v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = lane + 64 * r;
-                float s[2];
-                const int j0 = kHop * t + 2 * n - kNfft / 2;             // even index of the sample pair (2n, 2n+1) of this frame
-                if (live && pair_ok && j0 >= 0 && j0 + 1 < L) {          // interior: one aligned 32-bit load for the pair
-                    const int w2 = *reinterpret_cast<const int*>(row + j0);
-                    s[0] = (float)(short)(w2 & 0xffff) * (1.0f / 32768.0f) - dc;
-                    s[1] = (float)(short)(w2 >> 16) * (1.0f / 32768.0f) - dc;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        int j = j0 + q;
-                        j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);     // reflect (STFT_Process.py:306-309)
-                        s[q] = live ? (float)row[j] * (1.0f / 32768.0f) - dc : 0.0f;
-                    }
-                }
-                v[r] = make_float2(s[0] * lt.win[2 * n], s[1] * lt.win[2 * n + 1]);
+                const float sa = (float)(short)(raw[r] & 0xffff) * (1.0f / 32768.0f) - dc;
+                const float sb = (float)(raw[r] >> 16) * (1.0f / 32768.0f) - dc;
+                v[r] = make_float2(sa * lt.win[2 * n], sb * lt.win[2 * n + 1]);
+            }
+            {   // the next tile's samples: issued now, consumed after this tile's two conv phases
+                const int tn = t + kTileF;
+                load_frame_pairs(row, L, tn, lane, tn < T, pair_ok, raw);
             }
             fft256_inplace(v, buf, lane, lt.tw256);
             wave_sync();                                       // last pass's reads are done (buffer is wave-private)
@@ -132,6 +199,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
                 }
                 float2 xm = make_float2(0.0f, 0.0f);
                 if (lane == 0) { const float2 z = buf[128]; xm = rfft_bin(z, z, lt.tw512[128]); }
+                wave_sync();
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int k = lane + 64 * r;
@@ -156,101 +224,154 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
                         fr[2 * kErb + k] = x.y;
                     }
                 }
-                // ERB merge, one band per lane: banded sum == the dense 192x64 matmul term for term    (:99-102)
-                const int s0 = erb.start[lane];
-                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-                for (int n = 0; n < erb.count; ++n) {
-                    const float wv = erb.w[n * kErbBands + lane];
-                    const float2 x = buf[kErbLow + min(s0 + n, kErbHigh - 1)];
-                    a0 += sqrtf((x.x * x.x + x.y * x.y) + 1e-12f) * wv;
-                    a1 += x.x * wv;
-                    a2 += x.y * wv;
-                }
-                fr[kErbLow + lane] = a0;
-                fr[kErb + kErbLow + lane] = a1;
-                fr[2 * kErb + kErbLow + lane] = a2;
+                if (erb_lds) erb_merge(erbw, erb.count, erb_s0, buf, lane, fr);
+                else erb_merge(erb.w, erb.count, erb_s0, buf, lane, fr);
             }
         }
         __syncthreads();    // feat of the tile complete (and the previous tile's conv1 is done with E0)
         ADE_CLK(34);
-        // ---- F6-F7a: SFE(3) + Conv2d(9->16,(1,5),s(1,2),p(0,2)) + BN + PReLU, one lane per (t,fo) -> E0 (LDS) + e0 (HBM)
-        for (int idx = tid; idx < nf * kF1; idx += kFusedThreads) {
-            const int tl = idx / kF1, fo = idx - tl * kF1;
-            const float* fr = feat + (size_t)tl * 3 * kErb;
-            cfptr cw = cptr(c0.w);
-            ADE_KEEP_IN_LOOP(cw);
-            float v[3][7];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const int q = 2 * fo - 3 + j;
-                    v[c][j] = (q >= 0 && q < kErb) ? fr[c * kErb + q] : 0.0f;
-                }
-            float acc[16];
-#pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = c0b[co];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int p = 2 * fo - 2 + k;           // position in the SFE output; the conv zero-pads outside [0,129)
-                const bool pv = p >= 0 && p < kErb;
+        ADE_CLK_ACC(40);
+        // ---- F6-F7a: SFE(3) + Conv2d(9->16,(1,5),s(1,2),p(0,2)) + BN + PReLU -> E0 (LDS) + e0 (HBM).
+        //      Main round: one lane per (frame, fo < 64), 16 output channels each.
+        {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);                               // keep this phase's index arithmetic out of the other phases' live ranges
+            const int tl = tq >> 6, fo = tq & 63;
+            if (tl < nf) {
+                const float* fr = feat + (size_t)tl * 3 * kErb;
+                cfptr cw = cptr(c0.w);
+                ADE_KEEP_IN_LOOP(cw);
+                float v[3][7];
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        const float x = pv ? v[c][k + o] : 0.0f;          // SFE channel c*3+o at p = feat[c][p-1+o]
-#pragma unroll
-                        for (int co = 0; co < 16; ++co) acc[co] += cw[(k * 9 + c * 3 + o) * 16 + co] * x;
+                    for (int j = 0; j < 7; ++j) {
+                        const int q = 2 * fo - 3 + j;
+                        v[c][j] = (q >= 0 && q < kErb) ? fr[c * kErb + q] : 0.0f;
                     }
+                float acc[16];
+#pragma unroll
+                for (int co = 0; co < 16; ++co) acc[co] = c0b[co];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const bool pv = 2 * fo - 2 + k >= 0;               // position in the SFE output; the conv zero-pads outside [0,129)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            const float x = pv ? v[c][k + o] : 0.0f;   // SFE channel c*3+o at p = feat[c][p-1+o]
+#pragma unroll
+                            for (int co = 0; co < 16; ++co) acc[co] += cw[(k * 9 + c * 3 + o) * 16 + co] * x;
+                        }
+                }
+#pragma unroll
+                for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], c0.slope);
+                const int idx = tl * kF1 + fo;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) E0[q * kTileP1 + idx] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                pl_st16(e0c, P0, t0 * kF1 + idx, acc);
             }
+        }
+        //      Tail: column fo = 64 of every frame, one lane per (frame, output channel); taps k = 0..2 reach p = 126..128.
+        if (tid < kTileF * 16) {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int tl = tq >> 4, co = tq & 15;
+            if (tl < nf) {
+                const float* fr = feat + (size_t)tl * 3 * kErb;
+                float acc = b0t;
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], c0.slope);
+                for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) E0[q * kTileP1 + idx] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            pl_st16(e0c, P0, t0 * kF1 + idx, acc);
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int o = 0; o < 3; ++o) {
+                            const int q = 2 * (kF1 - 1) - 3 + k + o;   // 125 .. 129
+                            const float x = q < kErb ? fr[c * kErb + q] : 0.0f;
+                            acc += w0t[(k * 9 + c * 3 + o) * 16 + co] * x;
+                        }
+                acc = prelu_f(acc, c0.slope);
+                const int idx = tl * kF1 + (kF1 - 1);
+                E0f[((size_t)(co >> 2) * kTileP1 + idx) * 4 + (co & 3)] = acc;
+                e0c[((size_t)(co >> 2) * P0 + t0 * kF1 + idx) * 4 + (co & 3)] = acc;
+            }
         }
         __syncthreads();
         ADE_CLK(35);
+        ADE_CLK_ACC(41);
         // ---- F7b: Conv2d(16->16,(1,5),s2,groups 2) + BN + PReLU from E0 (LDS) -> e1 (HBM)                 (:489)
-        for (int idx = tid; idx < nf * kFw; idx += kFusedThreads) {
-            const int tl = idx / kFw, fo = idx - tl * kFw;
-            cfptr cw = cptr(c1.w);
-            ADE_KEEP_IN_LOOP(cw);
-            float acc[16];
+        //      Main round: one lane per (group, frame, fo < 32), the group's 8 output channels each.
+        {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int g = __builtin_amdgcn_readfirstlane(tq >> 9);     // wavefronts 0-7: group 0, 8-15: group 1
+            const int tl = (tq >> 5) & 15, fo = tq & 31;
+            if (tl < nf) {
+                cfptr cw = cptr(c1.w);
+                ADE_KEEP_IN_LOOP(cw);
+                float acc[8];
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = c1b[co];
+                for (int co = 0; co < 8; ++co) acc[co] = c1b[g * 8 + co];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int fi = 2 * fo - 2 + k;
-                if (fi < 0 || fi >= kF1) continue;
-                const int pp = tl * kF1 + fi;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int k = 0; k < 5; ++k) {
+                    // (zero padding by select, not by branch: a divergent branch here would turn the wave-uniform weight
+                    //  addresses after the join into per-lane values, i.e. the scalar weight loads into VMEM loads)
+                    const int fi = 2 * fo - 2 + k;                     // <= 64 for fo < 32
+                    const bool ok = fi >= 0;
+                    const int pp = tl * kF1 + (ok ? fi : 0);
                     const float4 xa = E0[(2 * g) * kTileP1 + pp], xb = E0[(2 * g + 1) * kTileP1 + pp];
-                    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                    const float x[8] = {ok ? xa.x : 0.0f, ok ? xa.y : 0.0f, ok ? xa.z : 0.0f, ok ? xa.w : 0.0f,
+                                        ok ? xb.x : 0.0f, ok ? xb.y : 0.0f, ok ? xb.z : 0.0f, ok ? xb.w : 0.0f};
 #pragma unroll
                     for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
-                        for (int co = 0; co < 8; ++co) acc[g * 8 + co] += cw[((k * 2 + g) * 8 + ci) * 8 + co] * x[ci];
+                        for (int co = 0; co < 8; ++co) acc[co] += cw[((k * 2 + g) * 8 + ci) * 8 + co] * x[ci];
                 }
-            }
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], c1.slope);
-            pl_st16(e1c, P, t0 * kFw + idx, acc);
+                for (int co = 0; co < 8; ++co) acc[co] = prelu_f(acc[co], c1.slope);
+                const int p = t0 * kFw + tl * kFw + fo;
+                st4(e1c + ((size_t)(2 * g) * P + p) * 4, acc);
+                st4(e1c + ((size_t)(2 * g + 1) * P + p) * 4, acc + 4);
+            }
+        }
+        //      Tail: column fo = 32, one lane per (frame, group, output channel); taps k = 0..2 reach fi = 62..64.
+        if (tid < kTileF * 16) {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int tl = tq >> 4, g = (tq >> 3) & 1, co = tq & 7;     // (tq & 15 == g*8 + co: the channel b1t was loaded for)
+            if (tl < nf) {
+                float acc = b1t;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int pp = tl * kF1 + (kF1 - 3) + k;
+#pragma unroll
+                    for (int ci = 0; ci < 8; ++ci)
+                        acc += w1t[((k * 2 + g) * 8 + ci) * 8 + co] * E0f[((size_t)(2 * g + (ci >> 2)) * kTileP1 + pp) * 4 + (ci & 3)];
+                }
+                acc = prelu_f(acc, c1.slope);
+                const int p = t0 * kFw + tl * kFw + (kFw - 1);
+                e1c[((size_t)(2 * g + (co >> 2)) * P + p) * 4 + (co & 3)] = acc;
+            }
         }
         ADE_CLK(36);
+        ADE_CLK_ACC(42);
         // no barrier here: the next tile's FFT phase touches neither E0 nor (before its own barrier) anything conv1 reads
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // BACK.  LDS (floats): S[4][528]x4 (reused as the FFT buffers wbuf[16][264]x2) | D[4][1040]x4 | M[16][2][132] |
-//                      acc[512 + 256*15] | tabs
+//                      acc[512 + 256*15] | tabs | win_sum[256] | ERB-split rows [4][192] | ERB-split starts [192]
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t kBackAccFloats = (size_t)kNfft + (size_t)kHop * (kTileF - 1);
-constexpr size_t kBackSmemBytes =
-    ((size_t)4 * kTileP * 4 + (size_t)4 * kTileP1 * 4 + (size_t)kTileF * 2 * kErbPad + kBackAccFloats + kTabFloats) * 4;
+constexpr int kC3TailW = 2 * 2 * 64;    // deconv3 taps 2 and 4, both groups
+constexpr int kC4TailW = 2 * 16 * 2;    // deconv4 taps 2 and 4
+constexpr size_t kBackSmemBytes = ((size_t)4 * kTileP * 4 + (size_t)4 * kTileP1 * 4 + (size_t)kTileF * 2 * kErbPad + kBackAccFloats +
+                                   kTabFloats + kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW) * 4;
 static_assert((size_t)4 * kTileP * 4 >= (size_t)16 * kWbuf * 2, "the S tile must be able to hold the 16 FFT buffers");
+constexpr int kSUnits = 4 * kTileP;        // float4 slots of one S tile
+constexpr int kSThreads = kSUnits / 3;     // 704 lanes x 3 slots stage a tile
+static_assert(kSThreads * 3 == kSUnits && kSThreads % 64 == 0, "S staging split");
 
 __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* __restrict__ x, const float* __restrict__ e1,
                                            const float* __restrict__ e0, const float* __restrict__ spec, const ConvW& c3, const ConvW& c4,
@@ -260,15 +381,21 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     (void)d3;
     (void)mask;
     float4* S = reinterpret_cast<float4*>(smem);
+    float* Sf = smem;
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
     float4* D = S + 4 * kTileP;
+    float* Df = reinterpret_cast<float*>(D);
     float* M = reinterpret_cast<float*>(D + 4 * kTileP1);
     float* acc = M + kTileF * 2 * kErbPad;
     float* tabmem = acc + kBackAccFloats;
+    float* wsum = tabmem + kTabFloats;
+    float* bsw = wsum + kHop;
+    int* bss = reinterpret_cast<int*>(bsw + kBsCap * kErbHigh);
+    float* w3t = reinterpret_cast<float*>(bss + kErbHigh);     // tail weights (see front_stage): [tap 2 | tap 4] x [g][ci][co]
+    float* w4t = w3t + kC3TailW;                               // [tap 2 | tap 4] x [ci][co]
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
-    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
-    float2* buf = wbuf_all + wave * kWbuf;
+    const int tid = tid_;
     const int P0 = T * kF1, P = T * kFw;
     const float* xc = x + (size_t)chunk * kCh * P;
     const float* e1c = e1 + (size_t)chunk * kCh * P;
@@ -278,15 +405,58 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     int16_t* po = pcm ? pcm + (size_t)chunk * out_len : nullptr;
     float* fo32 = f32 ? f32 + (size_t)chunk * out_len : nullptr;
     ADE_CLK(48);
+
+    // S = (d2 + e1) of a tile: 3 float4 slots per lane on 704 lanes, slot u = plane * 528 + tile position (== the LDS index).
+    // issue_s() only starts the loads; commit_s() adds and writes the tile (called one or more compute phases later).
+    // Every lane's sa/sb are (re)defined by each issue_s(), so nothing is live across the tile loop's back edge.
+    auto issue_s = [&](int t0n, bool go, float4* sa, float4* sb) {
+        const int nfn = T - t0n < kTileF ? T - t0n : kTileF;
+        int tq = tid;
+        ADE_OPAQUE_V(tq);
+        const bool on = go && tq < kSThreads;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = tq + kSThreads * i, q = u / kTileP, idx = u - q * kTileP;
+            const int idc = idx < nfn * kFw ? idx : 0;                                   // (clamped: the value is unused)
+            const size_t off = ((size_t)q * P + (size_t)t0n * kFw + idc) * 4;
+            sa[i] = on ? *reinterpret_cast<const float4*>(xc + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sb[i] = on ? *reinterpret_cast<const float4*>(e1c + off) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto commit_s = [&](const float4* sa, const float4* sb) {
+        int tq = tid;
+        ADE_OPAQUE_V(tq);
+        if (tq < kSThreads) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                S[tq + kSThreads * i] = make_float4(sa[i].x + sb[i].x, sa[i].y + sb[i].y, sa[i].z + sb[i].z, sa[i].w + sb[i].w);
+        }
+    };
+    float4 sa0[3], sb0[3];
+    issue_s(0, true, sa0, sb0);
     const LdsTabs lt = stage_tables(tabmem, tabs, tid);
+    for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
+    const bool bs_lds = bs.count <= kBsCap;
+    if (bs_lds) {
+        for (int i = tid; i < bs.count * kErbHigh; i += kFusedThreads) bsw[i] = bs.w[i];
+        for (int i = tid; i < kErbHigh; i += kFusedThreads) bss[i] = bs.start[i];
+    }
+    for (int i = tid; i < kC3TailW; i += kFusedThreads) w3t[i] = c3.w[(i < 128 ? 2 : 4) * 128 + (i & 127)];
+    for (int i = tid; i < kC4TailW; i += kFusedThreads) w4t[i] = c4.w[(i < 32 ? 2 : 4) * 32 + (i & 31)];
+    const float b3t = c3.b[tid & 15], b4t = c4.b[tid & 1];
     for (int i = tid; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = 0.0f;
     const cfptr c3b = cptr(c3.b), c4b = cptr(c4.b), c4w = cptr(c4.w);
+    commit_s(sa0, sb0);
+    long long clk_prev = ADE_CLK_START();
 
     for (int t0 = 0; t0 < T; t0 += kTileF) {
         const int nf = T - t0 < kTileF ? T - t0 : kTileF;
-        // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase four barriers later (hides L2/HBM)
+        // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase three barriers later
         float sre[5], sim[5];
         {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int wave = tq >> 6, lane = tq & 63;
             const int tcp = wave < nf ? t0 + wave : t0;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -295,102 +465,142 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                 sim[r] = (r < 4 || lane == 0) ? specc[((size_t)tcp * 2 + 1) * kBinsPad + k] : 0.0f;
             }
         }
-        // ---- stage S = (x + e1) of the tile: own-position, fully coalesced loads                    (:527)
-        for (int idx = tid; idx < nf * kFw; idx += kFusedThreads) {
-            float a[16], b[16];
-            pl_ld16(xc, P, t0 * kFw + idx, a);
-            pl_ld16(e1c, P, t0 * kFw + idx, b);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                S[q * kTileP + idx] = make_float4(a[4 * q] + b[4 * q], a[4 * q + 1] + b[4 * q + 1], a[4 * q + 2] + b[4 * q + 2], a[4 * q + 3] + b[4 * q + 3]);
-        }
-        __syncthreads();    // also: the previous tile's finalize is done with acc, and its FFT buffers (= S) are free
+        __syncthreads();    // S of this tile (committed in the prologue / at the end of the previous tile) is visible
         ADE_CLK(49);
-        // ---- ConvTranspose2d(16->16,(1,5),s(1,2),p(0,2),groups 2) + BN + PReLU: one lane per input column m ->
-        //      outputs fo = 2m (taps 0,2,4 <- m+1,m,m-1) and 2m+1 (taps 1,3 <- m+1,m) -> D (LDS)      (:515)
-        for (int idx = tid; idx < nf * kFw; idx += kFusedThreads) {
-            const int tl = idx / kFw, m = idx - tl * kFw;
-            cfptr cw = cptr(c3.w);
-            ADE_KEEP_IN_LOOP(cw);
-            float ev[16], od[16];
+        ADE_CLK_ACC(56);
+        // ---- ConvTranspose2d(16->16,(1,5),s(1,2),p(0,2),groups 2) + BN + PReLU, + e0 -> D (LDS)       (:515, :528)
+        //      Main round: one lane per (group, frame, input column m < 32): outputs fo = 2m (taps 0,2,4 <- m+1,m,m-1)
+        //      and 2m+1 (taps 1,3 <- m+1,m) of the group's 8 channels; the e0 addends are fetched while the FMAs run.
+        {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int g = __builtin_amdgcn_readfirstlane(tq >> 9);
+            const int tl = (tq >> 5) & 15, m = tq & 31;
+            if (tl < nf) {
+                const int idx = tl * kFw + m, pe = tl * kF1 + 2 * m;
+                float4 ea[2], eb[2];
 #pragma unroll
-            for (int co = 0; co < 16; ++co) { ev[co] = c3b[co]; od[co] = c3b[co]; }
+                for (int h = 0; h < 2; ++h) {
+                    const float* src = e0c + ((size_t)(2 * g + h) * P0 + (size_t)t0 * kF1 + pe) * 4;
+                    ea[h] = *reinterpret_cast<const float4*>(src);
+                    eb[h] = *reinterpret_cast<const float4*>(src + 4);
+                }
+                cfptr cw = cptr(c3.w);
+                ADE_KEEP_IN_LOOP(cw);
+                float ev[8], od[8];
 #pragma unroll
-            for (int dlt = -1; dlt <= 1; ++dlt) {
-                const int fi = m + dlt;
-                if (fi < 0 || fi >= kFw) continue;
-                const int ke = 2 - 2 * dlt, ko = 3 - 2 * dlt;
+                for (int co = 0; co < 8; ++co) { ev[co] = c3b[g * 8 + co]; od[co] = c3b[g * 8 + co]; }
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float4 xa = S[(2 * g) * kTileP + idx + dlt], xb = S[(2 * g + 1) * kTileP + idx + dlt];
-                    const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                for (int dlt = -1; dlt <= 1; ++dlt) {
+                    const bool ok = m + dlt >= 0;                       // m + dlt <= 32 is always a valid column; padding by select
+                    const int ke = 2 - 2 * dlt, ko = 3 - 2 * dlt;
+                    const int ps = idx + (ok ? dlt : 0);
+                    const float4 xa = S[(2 * g) * kTileP + ps], xb = S[(2 * g + 1) * kTileP + ps];
+                    const float xv[8] = {ok ? xa.x : 0.0f, ok ? xa.y : 0.0f, ok ? xa.z : 0.0f, ok ? xa.w : 0.0f,
+                                         ok ? xb.x : 0.0f, ok ? xb.y : 0.0f, ok ? xb.z : 0.0f, ok ? xb.w : 0.0f};
 #pragma unroll
                     for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
                         for (int co = 0; co < 8; ++co) {
-                            ev[g * 8 + co] += cw[((ke * 2 + g) * 8 + ci) * 8 + co] * xv[ci];
-                            if (dlt >= 0) od[g * 8 + co] += cw[((ko * 2 + g) * 8 + ci) * 8 + co] * xv[ci];
+                            ev[co] += cw[((ke * 2 + g) * 8 + ci) * 8 + co] * xv[ci];
+                            if (dlt >= 0) od[co] += cw[((ko * 2 + g) * 8 + ci) * 8 + co] * xv[ci];
                         }
                 }
-            }
-            const int pe = tl * kF1 + 2 * m;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                D[q * kTileP1 + pe] = make_float4(prelu_f(ev[4 * q], c3.slope), prelu_f(ev[4 * q + 1], c3.slope),
-                                                  prelu_f(ev[4 * q + 2], c3.slope), prelu_f(ev[4 * q + 3], c3.slope));
-                if (2 * m + 1 < kF1)
-                    D[q * kTileP1 + pe + 1] = make_float4(prelu_f(od[4 * q], c3.slope), prelu_f(od[4 * q + 1], c3.slope),
-                                                          prelu_f(od[4 * q + 2], c3.slope), prelu_f(od[4 * q + 3], c3.slope));
+                for (int h = 0; h < 2; ++h) {
+                    D[(2 * g + h) * kTileP1 + pe] =
+                        make_float4(prelu_f(ev[4 * h], c3.slope) + ea[h].x, prelu_f(ev[4 * h + 1], c3.slope) + ea[h].y,
+                                    prelu_f(ev[4 * h + 2], c3.slope) + ea[h].z, prelu_f(ev[4 * h + 3], c3.slope) + ea[h].w);
+                    D[(2 * g + h) * kTileP1 + pe + 1] =
+                        make_float4(prelu_f(od[4 * h], c3.slope) + eb[h].x, prelu_f(od[4 * h + 1], c3.slope) + eb[h].y,
+                                    prelu_f(od[4 * h + 2], c3.slope) + eb[h].z, prelu_f(od[4 * h + 3], c3.slope) + eb[h].w);
+                }
             }
         }
-        __syncthreads();
-        // ---- D += e0 tile (own-position coalesced loads)                                               (:528)
-        for (int idx = tid; idx < nf * kF1; idx += kFusedThreads) {
-            float b[16];
-            pl_ld16(e0c, P0, t0 * kF1 + idx, b);
+        //      Tail: input column m = 32 -> output fo = 64 only (taps 2,4 <- m, m-1); one lane per (frame, group, channel).
+        if (tid < kTileF * 16) {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int tl = tq >> 4, g = (tq >> 3) & 1, co = tq & 7;
+            if (tl < nf) {
+                const int pe = tl * kF1 + (kF1 - 1);
+                const float eadd = e0c[((size_t)(2 * g + (co >> 2)) * P0 + (size_t)t0 * kF1 + pe) * 4 + (co & 3)];
+                float ev = b3t;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 d = D[q * kTileP1 + idx];
-                d.x += b[4 * q]; d.y += b[4 * q + 1]; d.z += b[4 * q + 2]; d.w += b[4 * q + 3];
-                D[q * kTileP1 + idx] = d;
+                for (int dlt = -1; dlt <= 0; ++dlt) {
+                    const int ps = tl * kFw + (kFw - 1) + dlt;
+#pragma unroll
+                    for (int ci = 0; ci < 8; ++ci)      // tap ke = 2 - 2 dlt -> w3t block (dlt + 1 ? 0 : 1)
+                        ev += w3t[(dlt < 0 ? 128 : 0) + (g * 8 + ci) * 8 + co] * Sf[((size_t)(2 * g + (ci >> 2)) * kTileP + ps) * 4 + (ci & 3)];
+                }
+                Df[((size_t)(2 * g + (co >> 2)) * kTileP1 + pe) * 4 + (co & 3)] = prelu_f(ev, c3.slope) + eadd;
             }
         }
-        __syncthreads();
+        __syncthreads();    // D complete; S is dead until commit_s() at the end of the tile
         ADE_CLK(50);
+        ADE_CLK_ACC(57);
+        float4 sa[3], sb[3];
+        const bool has_next = t0 + kTileF < T;
+        issue_s(has_next ? t0 + kTileF : t0, has_next, sa, sb);      // next tile's d2/e1: in flight during deconv4 + irFFT + overlap-add
         // ---- ConvTranspose2d(16->2) + BN + Tanh -> mask tile M (LDS)                                   (:516)
-        for (int idx = tid; idx < nf * kF1; idx += kFusedThreads) {
-            const int tl = idx / kF1, m = idx - tl * kF1;
-            float ev[2] = {c4b[0], c4b[1]}, od[2] = {c4b[0], c4b[1]};
+        //      Main round: one lane per (frame, input column m < 64) -> mask bins 2m, 2m+1.
+        {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int tl = tq >> 6, m = tq & 63;
+            if (tl < nf) {
+                const int idx = tl * kF1 + m;
+                float ev[2] = {c4b[0], c4b[1]}, od[2] = {c4b[0], c4b[1]};
 #pragma unroll
-            for (int dlt = -1; dlt <= 1; ++dlt) {
-                const int fi = m + dlt;
-                if (fi < 0 || fi >= kF1) continue;
-                const int ke = 2 - 2 * dlt, ko = 3 - 2 * dlt;
+                for (int dlt = -1; dlt <= 1; ++dlt) {
+                    const bool ok = m + dlt >= 0;                       // m + dlt <= 64 is always a valid column; padding by select
+                    const int ke = 2 - 2 * dlt, ko = 3 - 2 * dlt;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 xq = D[q * kTileP1 + idx + dlt];
-                    const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 xq = D[q * kTileP1 + idx + (ok ? dlt : 0)];
+                        const float xv[4] = {ok ? xq.x : 0.0f, ok ? xq.y : 0.0f, ok ? xq.z : 0.0f, ok ? xq.w : 0.0f};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                        for (int co = 0; co < 2; ++co) {
-                            ev[co] += c4w[(ke * 16 + 4 * q + c) * 2 + co] * xv[c];
-                            if (dlt >= 0) od[co] += c4w[(ko * 16 + 4 * q + c) * 2 + co] * xv[c];
-                        }
+                            for (int co = 0; co < 2; ++co) {
+                                ev[co] += c4w[(ke * 16 + 4 * q + c) * 2 + co] * xv[c];
+                                if (dlt >= 0) od[co] += c4w[(ko * 16 + 4 * q + c) * 2 + co] * xv[c];
+                            }
+                    }
+                }
+                float* mr = M + (size_t)tl * 2 * kErbPad;
+#pragma unroll
+                for (int co = 0; co < 2; ++co) {
+                    mr[co * kErbPad + 2 * m] = tanhf(ev[co]);
+                    mr[co * kErbPad + 2 * m + 1] = tanhf(od[co]);
                 }
             }
-            float* mr = M + (size_t)tl * 2 * kErbPad;
+        }
+        //      Tail: input column m = 64 -> mask bin 128 only (taps 2,4 <- m, m-1); one lane per (frame, mask channel).
+        if (tid < kTileF * 2) {
+            const int tl = tid >> 1, co = tid & 1;
+            if (tl < nf) {
+                float ev = b4t;
 #pragma unroll
-            for (int co = 0; co < 2; ++co) {
-                mr[co * kErbPad + 2 * m] = tanhf(ev[co]);
-                if (2 * m + 1 < kErb) mr[co * kErbPad + 2 * m + 1] = tanhf(od[co]);
+                for (int dlt = -1; dlt <= 0; ++dlt) {
+                    const int ps = tl * kF1 + (kF1 - 1) + dlt;
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci)
+                        ev += w4t[(dlt < 0 ? 32 : 0) + ci * 2 + co] * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
+                }
+                M[(size_t)tl * 2 * kErbPad + co * kErbPad + (kErb - 1)] = tanhf(ev);
             }
         }
-        __syncthreads();    // mask complete; S is dead from here on: its memory becomes the 16 FFT buffers
+        __syncthreads();    // mask complete; the S region becomes the 16 FFT buffers
         ADE_CLK(51);
+        ADE_CLK_ACC(58);
         // ---- ERB split + complex ratio mask + irFFT-512 + synthesis window + overlap-add, one wavefront per frame.
         //      Neighbouring frames run concurrently and overlap by 256 samples: see the two-parity add below.
         {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int wave = tq >> 6, lane = tq & 63;
+            float2* buf = wbuf_all + wave * kWbuf;
             const bool live = wave < nf;
             const float* mr = M + (size_t)(live ? wave : 0) * 2 * kErbPad;
 #pragma unroll
@@ -403,13 +613,24 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                     m0 = mr[k];
                     m1 = mr[kErbPad + k];
                 } else {   // ERB.bs: banded == dense 64x192 matmul                                 (:104-107)
-                    const int o = k - kErbLow, s0 = bs.start[o];
+                    const int o = k - kErbLow;
                     m0 = 0.0f; m1 = 0.0f;
-                    for (int n = 0; n < bs.count; ++n) {
-                        const float wv = bs.w[n * kErbHigh + o];
-                        const int jj = min(s0 + n, kErbBands - 1);
-                        m0 += mr[kErbLow + jj] * wv;
-                        m1 += mr[kErbPad + kErbLow + jj] * wv;
+                    if (bs_lds) {
+                        const int s0 = bss[o];
+                        for (int n = 0; n < bs.count; ++n) {
+                            const float wv = bsw[n * kErbHigh + o];
+                            const int jj = min(s0 + n, kErbBands - 1);
+                            m0 += mr[kErbLow + jj] * wv;
+                            m1 += mr[kErbPad + kErbLow + jj] * wv;
+                        }
+                    } else {
+                        const int s0 = bs.start[o];
+                        for (int n = 0; n < bs.count; ++n) {
+                            const float wv = bs.w[n * kErbHigh + o];
+                            const int jj = min(s0 + n, kErbBands - 1);
+                            m0 += mr[kErbLow + jj] * wv;
+                            m1 += mr[kErbPad + kErbLow + jj] * wv;
+                        }
                     }
                 }
                 float2 y = make_float2(xr * m0 - xi * m1, xi * m0 + xr * m1);                        // (:585-590)
@@ -448,15 +669,20 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
             }
         }
         ADE_CLK(52);
+        ADE_CLK_ACC(59);
+        // the FFT buffers are dead: S of the next tile (loads issued before deconv4) goes in
+        if (has_next) commit_s(sa, sb);
         // ---- finalize the 256*nf samples this tile completed: raw index m = 256*t0 + i, output n = m - 256 (trim N/2),
         //      / sum(w^2), * 32767, clamp, truncating cast          (STFT_Process.py:330-333, Export_GTCRN.py:681,690)
-        for (int i4 = tid; i4 < nf * (kHop / 4); i4 += kFusedThreads) {
+        int tf = tid;
+        ADE_OPAQUE_V(tf);
+        for (int i4 = tf; i4 < nf * (kHop / 4); i4 += kFusedThreads) {
             const int i = i4 * 4;
             const int n = kHop * t0 + i - kHop;
             if (n < 0 || n >= out_len) continue;
             float v[4], ws[4];
             ld4(acc + i, v);
-            ld4(tabs.win_sum + (i & (kHop - 1)), ws);
+            ld4(wsum + (i & (kHop - 1)), ws);
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = v[u] / ws[u];
             if (fo32) st4(fo32 + n, v);
@@ -467,15 +693,17 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                 *reinterpret_cast<short4*>(po + n) = make_short4(q[0], q[1], q[2], q[3]);
             }
         }
+        ADE_CLK_ACC(60);
         __syncthreads();
         // carry the half-finished last 256 samples to the front of acc, clear the rest
         {
             float carry = 0.0f;
-            if (tid < kHop) carry = acc[kHop * nf + tid];
+            if (tf < kHop) carry = acc[kHop * nf + tf];
             __syncthreads();
-            for (int i = tid; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = i < kHop ? carry : 0.0f;
+            for (int i = tf; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = i < kHop ? carry : 0.0f;
         }
-        // (the S-staging barrier of the next tile orders these writes before the next tile's atomics)
+        // (the barrier at the top of the next tile orders these writes, and commit_s(), before their readers)
+        ADE_CLK_ACC(61);
     }
     ADE_CLK(53);
 }

@@ -56,6 +56,10 @@ constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
 
 // Optional phase clocks: when `clk` is non-null, thread 0 of workgroup 0 stamps wall_clock64() at each phase boundary.
 #define ADE_CLK(i) do { if (clk && chunk == 0 && threadIdx.x == 0) clk[i] = wall_clock64(); } while (0)
+// Accumulating variant for phases inside a tile loop: slot i += time since the previous ADE_CLK_ACC (needs a local
+// `long long clk_prev` initialised with ADE_CLK_START()).
+#define ADE_CLK_START() ((clk && chunk == 0 && threadIdx.x == 0) ? wall_clock64() : 0)
+#define ADE_CLK_ACC(i) do { if (clk && chunk == 0 && threadIdx.x == 0) { const long long n_ = wall_clock64(); clk[i] += n_ - clk_prev; clk_prev = n_; } } while (0)
 
 // x1_in_lds : the previous stage of the same launch already left this block's pointwise input (a+skip)[:, :8] in LDS planes 2-3.
 // next_x1   : leave the NEXT GTConvBlock's pointwise input there (out[:, :8] + next_skip[:, :8]); next_skip may be null.
