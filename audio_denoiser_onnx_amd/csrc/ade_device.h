@@ -78,6 +78,12 @@ __device__ __forceinline__ Swapped swap32(float v, float s) {
     return Swapped{__int_as_float((int)r[0]), __int_as_float((int)r[1])};
 }
 
+// Value of lane LANE for the whole wavefront (v_readlane_b32: lands in an SGPR, i.e. a scalar operand of later VALU ops).
+template <int LANE> __device__ __forceinline__ float read_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE));
+}
+constexpr float kLog2e = 1.4426950408889634f;
+
 // Two-wide fp32 vector: arithmetic on it is what becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (the packed fp32 ops
 // the 157 TFLOP/s fp32 peak is quoted on).  The recurrent loops are VALU-issue-bound, so halving the FMA instruction
 // count is a direct win.  (g++ spelling for the host-side simulator build under tests/hipsim.)

@@ -432,8 +432,25 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                 S[tq + kSThreads * i] = make_float4(sa[i].x + sb[i].x, sa[i].y + sb[i].y, sa[i].z + sb[i].z, sa[i].w + sb[i].w);
         }
     };
+    // e0 addends of a tile's deconv3 main round (lane = (group, frame, column m): outputs 2m, 2m+1 of the group's 2 planes)
+    auto issue_e0 = [&](int t0n, bool go, float4* ea, float4* eb) {
+        const int nfn = T - t0n < kTileF ? T - t0n : kTileF;
+        int tq = tid;
+        ADE_OPAQUE_V(tq);
+        const int g = tq >> 9, tl = (tq >> 5) & 15, m = tq & 31;
+        const bool on = go && tl < nfn;
+        const int pe = on ? tl * kF1 + 2 * m : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* src = e0c + ((size_t)(2 * g + h) * P0 + (size_t)t0n * kF1 + pe) * 4;
+            ea[h] = on ? *reinterpret_cast<const float4*>(src) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            eb[h] = on ? *reinterpret_cast<const float4*>(src + 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
     float4 sa0[3], sb0[3];
     issue_s(0, true, sa0, sb0);
+    float4 ea[2], eb[2];                    // loop-carried: tile k issues tile k+1's (every lane redefines them each time)
+    issue_e0(0, true, ea, eb);
     const LdsTabs lt = stage_tables(tabmem, tabs, tid);
     for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
     const bool bs_lds = bs.count <= kBsCap;
@@ -470,7 +487,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         ADE_CLK_ACC(56);
         // ---- ConvTranspose2d(16->16,(1,5),s(1,2),p(0,2),groups 2) + BN + PReLU, + e0 -> D (LDS)       (:515, :528)
         //      Main round: one lane per (group, frame, input column m < 32): outputs fo = 2m (taps 0,2,4 <- m+1,m,m-1)
-        //      and 2m+1 (taps 1,3 <- m+1,m) of the group's 8 channels; the e0 addends are fetched while the FMAs run.
+        //      and 2m+1 (taps 1,3 <- m+1,m) of the group's 8 channels; the e0 addends were requested a tile ago (issue_e0).
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);
@@ -478,13 +495,6 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
             const int tl = (tq >> 5) & 15, m = tq & 31;
             if (tl < nf) {
                 const int idx = tl * kFw + m, pe = tl * kF1 + 2 * m;
-                float4 ea[2], eb[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float* src = e0c + ((size_t)(2 * g + h) * P0 + (size_t)t0 * kF1 + pe) * 4;
-                    ea[h] = *reinterpret_cast<const float4*>(src);
-                    eb[h] = *reinterpret_cast<const float4*>(src + 4);
-                }
                 cfptr cw = cptr(c3.w);
                 ADE_KEEP_IN_LOOP(cw);
                 float ev[8], od[8];
@@ -542,6 +552,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         float4 sa[3], sb[3];
         const bool has_next = t0 + kTileF < T;
         issue_s(has_next ? t0 + kTileF : t0, has_next, sa, sb);      // next tile's d2/e1: in flight during deconv4 + irFFT + overlap-add
+        issue_e0(has_next ? t0 + kTileF : t0, has_next, ea, eb);     // ... and its e0 addends (consumed at the end of its deconv3)
         // ---- ConvTranspose2d(16->2) + BN + Tanh -> mask tile M (LDS)                                   (:516)
         //      Main round: one lane per (frame, input column m < 64) -> mask bins 2m, 2m+1.
         {
@@ -571,8 +582,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                 float* mr = M + (size_t)tl * 2 * kErbPad;
 #pragma unroll
                 for (int co = 0; co < 2; ++co) {
-                    mr[co * kErbPad + 2 * m] = tanhf(ev[co]);
-                    mr[co * kErbPad + 2 * m + 1] = tanhf(od[co]);
+                    mr[co * kErbPad + 2 * m] = tanh_f(ev[co]);
+                    mr[co * kErbPad + 2 * m + 1] = tanh_f(od[co]);
                 }
             }
         }
@@ -588,7 +599,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
                     for (int ci = 0; ci < 16; ++ci)
                         ev += w4t[(dlt < 0 ? 32 : 0) + ci * 2 + co] * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
                 }
-                M[(size_t)tl * 2 * kErbPad + co * kErbPad + (kErb - 1)] = tanhf(ev);
+                M[(size_t)tl * 2 * kErbPad + co * kErbPad + (kErb - 1)] = tanh_f(ev);
             }
         }
         __syncthreads();    // mask complete; the S region becomes the 16 FFT buffers

@@ -227,7 +227,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
                 float sacc = pk[72 + g];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sacc += pk[g * 8 + k] * e[k];
-                if (tr < T) GI[t * 48 + g * 16 + j] = sacc;
+                if (tr < T) GI[t * 48 + g * 16 + j] = sacc * (g == 2 ? 2.0f * kLog2e : -kLog2e);   // pre-scaled for exp2 (phase 4b)
             }
         }
     }
@@ -235,10 +235,13 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     ADE_CLK(4);
     ADE_CLK(5);
     // ---- phase 4b: the serial part, GRU(8->16) over T, on wave 0.  Its step latency IS this stage's critical path
-    //      (the other 15 wavefronts wait), so it is written for instruction count: the three gate mat-vecs run in
-    //      PARALLEL on the wavefront's 16-lane rows (row 0: r, row 2: z, rows 1/3: W_hn h), every row holds a copy of
-    //      h and gathers it with 15 row rotations against pre-rotated packed weights, and the gates meet through four
-    //      cross-row swaps per step: ~46 instructions instead of ~100.                              (:149,155)
+    //      (the other 15 wavefronts wait), so it is written for the length of the dependent chain:
+    //      * the three gate mat-vecs run in PARALLEL on the wavefront's 16-lane rows (row 0: r, row 2: z, rows 1/3: W_hn h);
+    //      * h_{t-1} lives in 16 SGPRs (v_readlane from the row that produced it), so the mat-vec is 8 packed FMAs with
+    //        scalar operands -- no per-step broadcast / rotation traffic;
+    //      * gates meet through two cross-row swaps (r -> row 1 for n, n -> row 3 where z already is);
+    //      * weights, biases and input projections are pre-scaled by -log2(e) (r, z) and 2 log2(e) (n), so every
+    //        activation is exp2 -> add -> rcp with no multiply in front.                              (:149,155)
     if (tid >= 64) {
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
         for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
@@ -256,44 +259,50 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     } else {
         const int j = tid & 15, row = tid >> 4;
         const int gsel = (row & 1) ? 2 : (row >> 1);                 // gate of this row: r, n, z, n
+        const float sc = gsel == 2 ? 2.0f * kLog2e : -kLog2e;
         const float* pk = w.gru + j * 78 + 24 + gsel * 16;           // W_h{gate}[j][:]
-        int ks[16];                                                  // ks[s] = hidden index delivered by rotation s (measured)
-        ks[0] = j;
-#define ADE_KS(S) ks[S] = (int)row_ror<S>((float)j);
-        ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7) ADE_KS(8)
-        ADE_KS(9) ADE_KS(10) ADE_KS(11) ADE_KS(12) ADE_KS(13) ADE_KS(14) ADE_KS(15)
-#undef ADE_KS
         v2f wr[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) wr[m] = mk2(pk[ks[2 * m]], pk[ks[2 * m + 1]]);
-        const float bh = w.gru[j * 78 + 75 + gsel];
-        float h = 0.0f;                                              // the same h_{t-1}[j] in all four rows
+        for (int m = 0; m < 8; ++m) wr[m] = mk2(pk[2 * m] * sc, pk[2 * m + 1] * sc);
+        const float bh = w.gru[j * 78 + 75 + gsel] * sc;
+        int shb[16];                                                 // h_{t-1} (fp32 bit patterns), wave-uniform
+#pragma unroll
+        for (int k = 0; k < 16; ++k) shb[k] = 0;
+        float hv = 0.0f;                                             // h_{t-1}[j] (meaningful in row 3, which computes h_t)
         float gi = GI[gsel * 16 + j];                                // this row's input projection, fetched one step ahead
+        // row 3 stores h_t; the other rows' (meaningless) values go to GI row 0, which is dead once `gi` is loaded --
+        // an address select instead of an exec-mask branch in the serial loop
+        float* hsp = row == 3 ? HS + j : GI + (tid & 63);
+        const int hs_step = row == 3 ? 16 : 0;
         for (int t = 0; t < T; ++t) {
             const int tn = t + 1 < T ? t + 1 : t;
             const float gnx = GI[tn * 48 + gsel * 16 + j];
-            float hs[16];
-            hs[0] = h;
-#define ADE_HS(S) hs[S] = row_ror<S>(h);
-            ADE_HS(1) ADE_HS(2) ADE_HS(3) ADE_HS(4) ADE_HS(5) ADE_HS(6) ADE_HS(7) ADE_HS(8)
-            ADE_HS(9) ADE_HS(10) ADE_HS(11) ADE_HS(12) ADE_HS(13) ADE_HS(14) ADE_HS(15)
-#undef ADE_HS
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ADE_KEEP_IN_LOOP(shb[k]);   // pin h_{t-1} to scalar registers (no copy back to VGPRs)
+            float sh[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sh[k] = __int_as_float(shb[k]);
             v2f a0 = mk2(bh, 0.0f), a1 = mk2(0.0f, 0.0f);
 #pragma unroll
             for (int m = 0; m < 8; m += 2) {
-                a0 += wr[m] * mk2(hs[2 * m], hs[2 * m + 1]);
-                a1 += wr[m + 1] * mk2(hs[2 * m + 2], hs[2 * m + 3]);
+                a0 += wr[m] * mk2(sh[2 * m], sh[2 * m + 1]);
+                a1 += wr[m + 1] * mk2(sh[2 * m + 2], sh[2 * m + 3]);
             }
             const v2f a2 = a0 + a1;
-            const float a = a2[0] + a2[1];                           // b_h + W_h{gate} h      (every row its own gate)
-            const float sg = sigmoid_f(gi + a);                      // rows 0 / 2: r / z
-            const float X = swap16(sg, sg).a;                        // rows 1 / 3 <- r / z
-            const float n = tanh_f(gi + X * a);                      // row 1: n = tanh(gi_n + r * (b_hn + W_hn h))
-            const float n3 = swap32(n, n).a;                         // row 3 <- n (row 1); row 3 already holds z in X
-            const float hc = n3 + X * (h - n3);                      // row 3: h_t = (1 - z) n + z h_{t-1}
-            const float hb = swap32(hc, hc).b;                       // rows 1, 3 <- h_t
-            h = swap16(hb, hb).b;                                    // all rows <- h_t
-            if (tid < 16) HS[t * 16 + j] = h;
+            const float a = a2[0] + a2[1];                           // scaled (b_h + W_h{gate} h), every row its own gate
+            const float e = __builtin_amdgcn_exp2f(gi + a);
+            const float sg = fast_rcp(1.0f + e);                     // rows 0 / 2: r / z
+            const float X = swap16(e, sg).a;                         // rows 1 / 3 <- r / z
+            const float en = __builtin_amdgcn_exp2f(gi + X * a);     // row 1: e^{2 (gi_n + r (b_hn + W_hn h))}
+            const float n = 1.0f - 2.0f * fast_rcp(en + 1.0f);       // row 1: n
+            const float n3 = swap32(en, n).a;                        // row 3 <- n (row 3 already holds z in X); `en` is a dead value
+            const float hc = n3 + X * (hv - n3);                     // row 3: h_t = (1 - z) n + z h_{t-1}
+            hv = hc;
+#define ADE_RL(K) shb[K] = __builtin_amdgcn_readlane(__float_as_int(hc), 48 + K);
+            ADE_REP16(ADE_RL)
+#undef ADE_RL
+            *hsp = hc;
+            hsp += hs_step;
             gi = gnx;
         }
     }
@@ -458,17 +467,19 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
         ks[0] = unit;
         ks[1] = (int)quad_rot<1>((float)unit); ks[2] = (int)quad_rot<2>((float)unit); ks[3] = (int)quad_rot<3>((float)unit);
         // packed-fp32 formulation (see the inter GRU below): r|z share one accumulator, n is packed over input pairs
+        // weights and biases pre-scaled by -log2(e) (r, z) / 2 log2(e) (n): the activations are exp2 -> add -> rcp
+        constexpr float kS = -kLog2e, kN = 2.0f * kLog2e;
         v2f wi_rz[8], wh_rz[4], wi_n[4], wh_n[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wi_rz[k] = mk2(pk[k], pk[8 + k]);
+        for (int k = 0; k < 8; ++k) wi_rz[k] = mk2(pk[k] * kS, pk[8 + k] * kS);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wh_rz[k] = mk2(pk[24 + ks[k]], pk[28 + ks[k]]);
+        for (int k = 0; k < 4; ++k) wh_rz[k] = mk2(pk[24 + ks[k]] * kS, pk[28 + ks[k]] * kS);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wi_n[m] = mk2(pk[16 + 2 * m], pk[16 + 2 * m + 1]);
+        for (int m = 0; m < 4; ++m) wi_n[m] = mk2(pk[16 + 2 * m] * kN, pk[16 + 2 * m + 1] * kN);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) wh_n[m] = mk2(pk[32 + ks[2 * m]], pk[32 + ks[2 * m + 1]]);
-        const v2f b_rz = mk2(pk[36] + pk[39], pk[37] + pk[40]);
-        const float bi_n = pk[38], bh_n = pk[41];
+        for (int m = 0; m < 2; ++m) wh_n[m] = mk2(pk[32 + ks[2 * m]] * kN, pk[32 + ks[2 * m + 1]] * kN);
+        const v2f b_rz = mk2((pk[36] + pk[39]) * kS, (pk[37] + pk[40]) * kS);
+        const float bi_n = pk[38] * kN, bh_n = pk[41] * kN;
         const int prow = tc * kFw;
         float h = 0.0f;
         // inputs come from HBM/L2 (~1 us away): a 4-slot register ring keeps three steps of loads in flight, and the
@@ -492,9 +503,9 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
             c_n += wh_n[0] * mk2(h, h1);
             c_n += wh_n[1] * mk2(h2, h3);
             const v2f rz = c0 + c1;
-            const float r = sigmoid_f(rz[0]);
-            const float z = sigmoid_f(rz[1]);
-            const float n = tanh_f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1]));
+            const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[0]));
+            const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[1]));
+            const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1])) + 1.0f);
             h = n + z * (h - n);
             if (live) Rf[((size_t)(q >> 2) * kPmax + tc * kFw + f) * 4 + (q & 3)] = h;
         }
@@ -540,19 +551,20 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
 #define ADE_KS(S) ks[S] = ((int)row_ror<2 * S>((float)q)) >> 1;
         ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7)
 #undef ADE_KS
+        constexpr float kS = -kLog2e, kN = 2.0f * kLog2e;        // pre-scaling for exp2-based activations (see the intra GRU)
         v2f wi_rz[8], wh_rz[8], wi_n[4], wh_n[4];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            wi_rz[k] = mk2(pk[k], pk[8 + k]);
-            wh_rz[k] = mk2(pk[24 + ks[k]], pk[32 + ks[k]]);
+            wi_rz[k] = mk2(pk[k] * kS, pk[8 + k] * kS);
+            wh_rz[k] = mk2(pk[24 + ks[k]] * kS, pk[32 + ks[k]] * kS);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            wi_n[m] = mk2(pk[16 + 2 * m], pk[16 + 2 * m + 1]);
-            wh_n[m] = mk2(pk[40 + ks[2 * m]], pk[40 + ks[2 * m + 1]]);
+            wi_n[m] = mk2(pk[16 + 2 * m] * kN, pk[16 + 2 * m + 1] * kN);
+            wh_n[m] = mk2(pk[40 + ks[2 * m]] * kN, pk[40 + ks[2 * m + 1]] * kN);
         }
-        const v2f b_rz = mk2(pk[48] + pk[51], pk[49] + pk[52]);
-        const float bi_n = pk[50], bh_n = pk[53];
+        const v2f b_rz = mk2((pk[48] + pk[51]) * kS, (pk[49] + pk[52]) * kS);
+        const float bi_n = pk[50] * kN, bh_n = pk[53] * kN;
         float h = 0.0f;
         float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
         for (int t = 0; t < T; ++t) {
@@ -577,9 +589,9 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
 #pragma unroll
             for (int m = 0; m < 4; ++m) c_n += wh_n[m] * mk2(hs[2 * m], hs[2 * m + 1]);
             const v2f rz = c0 + c1;
-            const float r = sigmoid_f(rz[0]);
-            const float z = sigmoid_f(rz[1]);
-            const float n = tanh_f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1]));
+            const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[0]));
+            const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[1]));
+            const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1])) + 1.0f);
             h = n + z * (h - n);
             if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
         }
