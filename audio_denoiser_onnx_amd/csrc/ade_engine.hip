@@ -83,7 +83,7 @@ struct ade_engine {
     bool use_fused = true;      // per-chunk LDS-resident stage kernels when T <= 64 (ade_fused.hip)
     bool use_single = true;     // ... as ONE launch (k_gtcrn_chunk); profile mode always uses the per-stage kernels
     bool last_fused = false;
-    long long* d_clk = nullptr;   // 64 phase-clock slots (profile mode only)
+    long long* d_clk = nullptr;   // phase-clock slots (profile modes 1 and 3 only)
     std::vector<GraphEntry> graphs;
 
     bool profile = false;
@@ -283,6 +283,8 @@ void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* 
     }
 }
 
+constexpr int kClkSlots = 64 * 10;
+
 struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc; float s1, s2; };
 struct DpOff { size_t intra_gru, inter_gru, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
 
@@ -481,8 +483,8 @@ ade_status build_device_constants(ade_engine* e) {
     std::vector<int> ints(bm_start);
     ints.insert(ints.end(), bs_start.begin(), bs_start.end());
     HIP_TRY(e, hipMalloc((void**)&e->d_ints, ints.size() * sizeof(int)));
-    HIP_TRY(e, hipMalloc((void**)&e->d_clk, 64 * sizeof(long long)));
-    HIP_TRY(e, hipMemset(e->d_clk, 0, 64 * sizeof(long long)));
+    HIP_TRY(e, hipMalloc((void**)&e->d_clk, kClkSlots * sizeof(long long)));
+    HIP_TRY(e, hipMemset(e->d_clk, 0, kClkSlots * sizeof(long long)));
     HIP_TRY(e, hipMemcpy(e->d_ints, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
     const float* W = e->d_weights;
     e->tabs.win = W + o_win;
@@ -618,15 +620,16 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         // ---- fused path: one 1024-thread workgroup per chunk per stage, activations LDS-resident, inter-stage tensors
         //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
         long long* clk = prof ? e->d_clk : nullptr;
-        if (clk) (void)hipMemsetAsync(e->d_clk, 0, 64 * sizeof(long long), s);   // phase accumulators start from zero
-        if (e->use_single && (!prof || e->profile_mode == 2)) {
+        if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
+        if (e->use_single && (!prof || e->profile_mode >= 2)) {
             ChunkArgs A{};
             A.pcm_in = d_in; A.pcm_out = d_out; A.f32_out = d_f32; A.L = e->in_len; A.T = T;
             A.tabs = e->tabs; A.erb_bm = e->erb_bm; A.erb_bs = e->erb_bs;
             A.en0 = e->en0; A.en1 = e->en1; A.de3 = e->de3; A.de4 = e->de4;
             for (int i = 0; i < 3; ++i) { A.en_gt[i] = e->en_gt[i]; A.de_gt[i] = e->de_gt[i]; A.xe[i] = e->xe[i]; A.xd[i] = e->xd[i]; }
             for (int i = 0; i < 2; ++i) { A.dp[i] = e->dp[i]; A.dpo[i] = e->dpo[i]; }
-            A.spec = e->spec; A.e0 = e->e0; A.e1 = e->e1; A.d3 = e->d3; A.mask = e->mask; A.clk = nullptr;
+            A.spec = e->spec; A.e0 = e->e0; A.e1 = e->e1; A.d3 = e->d3; A.mask = e->mask;
+            A.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
             q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, A, B); q.end();
             return;
         }
@@ -696,7 +699,10 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
         }
         return ADE_OK;
     }
-    if (e->use_graph && e->graph_supported) {
+    // A captured graph pays off for the multi-kernel launch sequences (10 or 34 launches).  The single-launch path is one
+    // kernel: a plain launch has less per-step overhead than a one-node graph (measured: 0.462 vs 0.475 ms per step).
+    const bool one_kernel = e->use_fused && e->use_single && fused_supported(e->T);
+    if (e->use_graph && e->graph_supported && !one_kernel) {
         GraphEntry* hit = nullptr;
         for (auto& g : e->graphs)
             if (g.in == d_in && g.out_pcm == d_out && g.out_f32 == d_f32 && g.batch == B) hit = &g;
@@ -912,11 +918,16 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         {"mask", h->mask, nfr * 2 * kErbPad}, {"frames", h->frames, nfr * kNfft}};
     if (strcmp(name, "phase_clock") == 0) {   // wall_clock64() stamps of workgroup 0's phases (profile mode), as tick deltas
         if (count < 64) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
-        long long raw[64];
-        HIP_TRY(h, hipMemcpy(raw, h->d_clk, sizeof raw, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 64; ++i)   // slots 40-47 / 56-63 are per-phase accumulators over the tile loops (raw tick sums)
-            out[i] = (i & 15) >= 8 && i >= 32 ? (float)raw[i] : (float)(raw[i] - raw[(i / 16) * 16]);
-        *written = 64;
+        // Per-stage kernels (profile mode 1) use the first 64 slots: gtblock 0-15, dpgrnn 16-31, front 32-47, back 48-63.
+        // The single-launch clock build (mode 3) uses one such 64-slot page per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back].
+        // Stamps are returned relative to their group of 16; slots 8-15 of the front / back groups are per-phase
+        // accumulators over the tile loops (raw tick sums).
+        const size_t n = count >= (size_t)kClkSlots ? (size_t)kClkSlots : 64;
+        long long raw[kClkSlots];
+        HIP_TRY(h, hipMemcpy(raw, h->d_clk, n * sizeof(long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i)
+            out[i] = (i & 15) >= 8 && (i & 63) >= 32 ? (float)raw[i] : (float)(raw[i] - raw[(i / 16) * 16]);
+        *written = n;
         return ADE_OK;
     }
     for (const Tap& t : taps)
@@ -959,7 +970,7 @@ const char* ade_kernel_name(ade_handle h, int i) { return (h && i >= 0 && i < (i
 ade_status ade_profile_last(ade_handle h, int enable) {
     if (!h) return ADE_ERR_BAD_VALUE;
     h->profile = enable != 0;
-    if (enable) h->profile_mode = enable == 2 ? 2 : 1;
+    if (enable) h->profile_mode = (enable == 2 || enable == 3) ? enable : 1;
     return ADE_OK;
 }
 ade_status ade_kernel_ms(ade_handle h, int i, float* total_ms, int* launches) {

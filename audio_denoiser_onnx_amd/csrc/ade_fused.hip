@@ -45,34 +45,39 @@ __global__ __launch_bounds__(kFusedThreads) void k_back(const float* __restrict_
     back_stage(reinterpret_cast<float*>(smem), blockIdx.x, x, e1, e0, spec, c3, c4, bs, tabs, d3, mask, pcm, f32, T, clk);
 }
 
+// kClk = false is the shipped kernel (no phase-clock code at all); kClk = true is the same kernel with thread 0 of
+// workgroup 0 stamping phase clocks into A.clk, 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back].
+template <bool kClk>
 __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
     HIP_DYNAMIC_SHARED(float4, smem)
+    long long* const clk0 = kClk ? A.clk : nullptr;
     const int chunk = blockIdx.x;
     float* fsm = reinterpret_cast<float*>(smem);
-    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, /*clk=*/nullptr);
+    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, clk0);
     __syncthreads();
     const float* x = A.e1;
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // encoder GTConvBlocks
-        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, /*clk=*/nullptr, /*x1_in_lds=*/i > 0,
+        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0,
                       /*next_x1=*/i < 2, nullptr);
         __syncthreads();
         x = A.xe[i];
     }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
-        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, /*clk=*/nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
+        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
         __syncthreads();
         x = A.dpo[i];
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // decoder GTConvBlocks on x + en_outs[4 - i]
-        gtblock_stage(smem, chunk, x, A.xe[2 - i], A.de_gt[i], A.xd[i], A.T, nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
+        gtblock_stage(smem, chunk, x, A.xe[2 - i], A.de_gt[i], A.xd[i], A.T, kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
                       /*next_skip=*/i < 2 ? A.xe[1 - i] : nullptr);
         __syncthreads();
         x = A.xd[i];
     }
-    back_stage(fsm, chunk, x, A.e1, A.e0, A.spec, A.de3, A.de4, A.erb_bs, A.tabs, A.d3, A.mask, A.pcm_out, A.f32_out, A.T, /*clk=*/nullptr);   // phase clocks exist in the per-stage kernels only
+    back_stage(fsm, chunk, x, A.e1, A.e0, A.spec, A.de3, A.de4, A.erb_bs, A.tabs, A.d3, A.mask, A.pcm_out, A.f32_out, A.T,
+               kClk ? clk0 + 64 * 9 : nullptr);
 }
 
 }  // namespace
@@ -80,11 +85,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
 bool fused_supported(int T) { return T >= 2 && T <= kTmaxFused; }
 
 hipError_t fused_init() {
-    const void* fns[5] = {reinterpret_cast<const void*>(&k_front), reinterpret_cast<const void*>(&k_gtblock),
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_front), reinterpret_cast<const void*>(&k_gtblock),
                           reinterpret_cast<const void*>(&k_dpgrnn), reinterpret_cast<const void*>(&k_back),
-                          reinterpret_cast<const void*>(&k_gtcrn_chunk)};
-    const size_t bytes[5] = {kFrontSmemBytes, kGtSmemBytes, kDpSmemBytes, kBackSmemBytes, kChunkSmemBytes};
-    for (int i = 0; i < 5; ++i) {
+                          reinterpret_cast<const void*>(&k_gtcrn_chunk<false>), reinterpret_cast<const void*>(&k_gtcrn_chunk<true>)};
+    const size_t bytes[6] = {kFrontSmemBytes, kGtSmemBytes, kDpSmemBytes, kBackSmemBytes, kChunkSmemBytes, kChunkSmemBytes};
+    for (int i = 0; i < 6; ++i) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes[i]);
         if (e != hipSuccess) return e;
     }
@@ -107,7 +112,8 @@ void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0
                        clk);
 }
 void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B) {
-    hipLaunchKernelGGL(k_gtcrn_chunk, dim3(B), dim3(kFusedThreads), kChunkSmemBytes, s, args);
+    if (args.clk) hipLaunchKernelGGL(k_gtcrn_chunk<true>, dim3(B), dim3(kFusedThreads), kChunkSmemBytes, s, args);
+    else hipLaunchKernelGGL(k_gtcrn_chunk<false>, dim3(B), dim3(kFusedThreads), kChunkSmemBytes, s, args);
 }
 
 }  // namespace ade

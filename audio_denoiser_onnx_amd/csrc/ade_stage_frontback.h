@@ -549,10 +549,14 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         __syncthreads();    // D complete; S is dead until commit_s() at the end of the tile
         ADE_CLK(50);
         ADE_CLK_ACC(57);
+        // Next tile's d2/e1 and e0 addends: requested here, consumed at the end of this tile / at the end of the next deconv3.
+        // (These two tensors are the back stage's HBM stream -- ~130 KB per tile per workgroup, all 256 workgroups in
+        // lock-step -- and the request queue back-pressures the issuing wavefronts for about as long as HBM needs to
+        // deliver them, wherever in the tile the requests are placed: measured, not assumed.)
         float4 sa[3], sb[3];
         const bool has_next = t0 + kTileF < T;
-        issue_s(has_next ? t0 + kTileF : t0, has_next, sa, sb);      // next tile's d2/e1: in flight during deconv4 + irFFT + overlap-add
-        issue_e0(has_next ? t0 + kTileF : t0, has_next, ea, eb);     // ... and its e0 addends (consumed at the end of its deconv3)
+        issue_s(has_next ? t0 + kTileF : t0, has_next, sa, sb);
+        issue_e0(has_next ? t0 + kTileF : t0, has_next, ea, eb);
         // ---- ConvTranspose2d(16->2) + BN + Tanh -> mask tile M (LDS)                                   (:516)
         //      Main round: one lane per (frame, input column m < 64) -> mask bins 2m, 2m+1.
         {

@@ -196,6 +196,19 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     __syncthreads();
     ADE_CLK(3);
 
+    // wave 0's recurrent weights for phase 4b: requested NOW -- at the start of 4b the other 15 wavefronts flood the CU's
+    // memory queue with their staging loads, and these few loads would wait behind all of them before the recurrence
+    // (the critical path) could start
+    v2f wr_raw[8];
+    float bh_raw = 0.0f;
+    {
+        const int j = tid & 15, row = (tid >> 4) & 3;
+        const int gsel = (row & 1) ? 2 : (row >> 1);
+        const float* pk = w.gru + j * 78 + 24 + gsel * 16;           // W_h{gate}[j][:]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) wr_raw[m] = tid < 64 ? mk2(pk[2 * m], pk[2 * m + 1]) : mk2(0.0f, 0.0f);
+        if (tid < 64) bh_raw = w.gru[j * 78 + 75 + gsel];
+    }
     // ---- phase 3+4a: TRA energy zt[t][c] = mean_f h1^2 (:154) and the GRU input projections GI[t][g*16+j] = b_ih + W_ih zt[t],
     //      one 16-lane DPP row per frame: lane j sums f in {j, j+16, j+32}, a 4-step row rotation all-reduce (fixed order,
     //      deterministic) gives every lane the 8 channel energies, then lane j produces its three gate rows.
@@ -242,7 +255,24 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     //      * gates meet through two cross-row swaps (r -> row 1 for n, n -> row 3 where z already is);
     //      * weights, biases and input projections are pre-scaled by -log2(e) (r, z) and 2 log2(e) (n), so every
     //        activation is exp2 -> add -> rcp with no multiply in front.                              (:149,155)
+    // the next block's skip addend (8 channels per position) is requested during this phase and lands while the
+    // recurrence runs (wave 0 asks AFTER its weight loads: VMEM returns in order, and the recurrence must not wait for HBM)
+    const float* nsc = (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr;
+    float nsk[kPosPerThread][8];
+    auto request_next_skip = [&]() {
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const int p = tid + i * kFusedThreads;
+            if (nsc && p < P) {
+                pl_ld8(nsc, P, p, 0, nsk[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) nsk[i][k] = 0.0f;
+            }
+        }
+    };
     if (tid >= 64) {
+        request_next_skip();
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
         for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
             float by[8];
@@ -260,15 +290,15 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         const int j = tid & 15, row = tid >> 4;
         const int gsel = (row & 1) ? 2 : (row >> 1);                 // gate of this row: r, n, z, n
         const float sc = gsel == 2 ? 2.0f * kLog2e : -kLog2e;
-        const float* pk = w.gru + j * 78 + 24 + gsel * 16;           // W_h{gate}[j][:]
         v2f wr[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) wr[m] = mk2(pk[2 * m] * sc, pk[2 * m + 1] * sc);
-        const float bh = w.gru[j * 78 + 75 + gsel] * sc;
+        for (int m = 0; m < 8; ++m) wr[m] = wr_raw[m] * sc;
+        const float bh = bh_raw * sc;
         int shb[16];                                                 // h_{t-1} (fp32 bit patterns), wave-uniform
 #pragma unroll
         for (int k = 0; k < 16; ++k) shb[k] = 0;
         float hv = 0.0f;                                             // h_{t-1}[j] (meaningful in row 3, which computes h_t)
+        request_next_skip();
         float gi = GI[gsel * 16 + j];                                // this row's input projection, fetched one step ahead
         // row 3 stores h_t; the other rows' (meaningless) values go to GI row 0, which is dead once `gi` is loaded --
         // an address select instead of an exec-mask branch in the serial loop
@@ -321,7 +351,6 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     ADE_CLK(7);
     // ---- phase 5: gate, interleave with the bypass half (LDS), store; optionally leave the next block's pointwise input
     //      (out[:, :8] + next_skip[:, :8]) in planes 2-3                                            (:156,324)
-    const float* nsc = next_skip ? next_skip + (size_t)chunk * kCh * P : nullptr;
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
@@ -336,13 +365,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             if (next_x1) {
                 float n8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) n8[k] = o[k];
-                if (nsc) {
-                    float y[8];
-                    pl_ld8(nsc, P, p, 0, y);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) n8[k] += y[k];
-                }
+                for (int k = 0; k < 8; ++k) n8[k] = o[k] + nsk[i][k];
                 H[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
                 H[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
             }
@@ -364,7 +387,8 @@ constexpr size_t kDpSmemBytes = (size_t)4 * kPmax * 16 + (size_t)kPmax * 4 + 2 *
 // through LDS, then  y = res + (v - mean) * rstd * gamma + beta.   v/res/y: [kPosPerThread][16] registers.
 __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* stat, const float* __restrict__ fc,
                                             const float* __restrict__ fc_b, const float* __restrict__ ln_w,
-                                            const float* __restrict__ ln_b, int T, int P, int tid, float (*v)[16]) {
+                                            const float* __restrict__ ln_b, int T, int P, int tid, float (*v)[16],
+                                            const float* __restrict__ pre_src = nullptr, float (*pre)[8] = nullptr) {
     const cfptr c_fc_b = cptr(fc_b);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
@@ -388,6 +412,18 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
 #pragma unroll
             for (int co = 0; co < 16; ++co) s += v[i][co];
             red[p] = s;
+        }
+    }
+    if (pre) {   // optional prefetch (8 channels per own position, planes 0-1 of pre_src): in flight across the statistics passes
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const int p = tid + i * kFusedThreads;
+            if (pre_src && p < P) {
+                pl_ld8(pre_src, P, p, 0, pre[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre[i][k] = 0.0f;
+            }
         }
     }
     __syncthreads();
@@ -600,7 +636,9 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     ADE_CLK(19);
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
     float y[kPosPerThread][16];
-    fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, tid, y);
+    float nsk[kPosPerThread][8];       // the following GTConvBlock's skip addend (zero when there is none)
+    fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, tid, y,
+                (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr, nsk);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
@@ -613,13 +651,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
             if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (R is dead)
                 float n8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) n8[k] = y[i][k];
-                if (next_skip) {
-                    float sk[8];
-                    pl_ld8(next_skip + (size_t)chunk * kCh * P, P, p, 0, sk);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) n8[k] += sk[k];
-                }
+                for (int k = 0; k < 8; ++k) n8[k] = y[i][k] + nsk[i][k];
                 R[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
                 R[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
             }

@@ -156,7 +156,8 @@ class InferenceSession:
         return buf[: n.value]
 
     def profile(self, enable) -> None:
-        """0/False: off; 1/True: one kernel per stage (+ phase clocks); 2: the shipped launch sequence timed as launched."""
+        """0/False: off; 1/True: one kernel per stage (+ phase clocks); 2: the shipped launch sequence timed as launched;
+        3: the single-launch kernel's phase-clock build (tap ``phase_clock`` with 640 slots)."""
         self._lib.check(self._lib.c.ade_profile_last(self._h, int(enable)), self._h)
 
     def kernel_times(self) -> Dict[str, Dict[str, float]]:

@@ -90,7 +90,8 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
 /* Timing tap: device time (ms) of the kernels launched by the last ade_process_device/ade_process call, measured with
  * hipEvents on the stream the kernels ran on.  ade_profile_last(h, 2): time the shipped launch sequence as launched
  * (one "gtcrn_chunk" kernel on the fused path); (h, 1): one kernel per network stage + in-kernel phase clocks;
- * (h, 0): off.  Index results by ade_kernel_name(i). */
+ * (h, 3): the single-launch kernel's phase-clock build (debug tap "phase_clock", 640 slots); (h, 0): off.
+ * Index results by ade_kernel_name(i). */
 int ade_kernel_count(ade_handle h);
 const char* ade_kernel_name(ade_handle h, int index);
 ade_status ade_profile_last(ade_handle h, int enable);

@@ -136,6 +136,7 @@ static inline hipsim_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __builtin_amdgcn_readlane(int x, int lane) { return (int)::hipsim::wave_exchange((uint32_t)x, lane); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values here
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline long long wall_clock64() { return 0; }

@@ -101,12 +101,14 @@ def test_device_buffers_graph_and_plain_launch_agree(sess0):
     x = torch.from_numpy(synth_batch(8)).cuda()
     out_a = torch.empty((8, 15872), dtype=torch.int16, device="cuda")
     out_b = torch.empty_like(out_a)
+    sess0.set_option("single_launch", "0")   # the one-kernel path is always a plain launch; graphs serve the 10-launch sequence
     sess0.set_option("graph", "1")
     sess0.run_device(x, out_a)
     sess0.run_device(x, out_a)            # second call replays the captured graph
     sess0.set_option("graph", "0")
     sess0.run_device(x, out_b)
     sess0.set_option("graph", "1")
+    sess0.set_option("single_launch", "1")
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
     ref, _ = sess0.process(x.cpu().numpy())
