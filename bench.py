@@ -50,7 +50,7 @@ KERNEL_MODEL = {
     # fused per-chunk stage kernels (ade_fused.hip): a GTConvBlock = pw1 + dw/pw2 + TRA ; a DPGRNN = 2 GRNN + 2 (FC+LN)
     "gtblock": (6 * _T * (33 * (384 + 272) + 1280), (3 * 2 + 3 * 3) * _T * 33 * 16 * 4),
     "dpgrnn": (2 * _T * 33 * (4 * 144 + 2 * 384 + 2 * 256), 2 * 2 * _T * 33 * 16 * 4),
-    # front = mean + STFT/feat + conv0 + conv1 ; back = deconv3 + deconv4 + mask/irFFT/OLA/PCM   (ade_frontback.hip)
+    # front = mean + STFT/feat + conv0 + conv1 ; back = deconv3 + deconv4 + mask/irFFT/OLA/PCM   (ade_stage_frontback.h)
     "front": (int(_T * (2.5 * 512 * 9 / 2 + 3 * 382)) + _T * 65 * 16 * 45 + _T * 33 * 16 * 40,
               32000 + _T * (2 * 257 + 65 * 16 + 33 * 16) * 4),
     "back": (_T * 33 * 16 * 8 * 5 + _T * 65 * 16 * 2 * 5 + int(_T * (2.5 * 512 * 9 / 2 + 2 * 382 + 4 * 257)),
@@ -239,7 +239,8 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "chunks_per_gpu": B, "chunk_samples": CHUNK, "out_samples": sess.out_len,
                        "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)",
-                       "hipgraph": not args.no_graph, "stitch_all_gather": bool(gathered is not None)},
+                       "launch": "one kernel per step (k_gtcrn_chunk), plain launch" if not args.no_graph else "one kernel per step, hipGraph disabled",
+                       "stitch_all_gather": bool(gathered is not None)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
