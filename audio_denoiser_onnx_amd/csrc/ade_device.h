@@ -115,6 +115,22 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r[0] = a; r[1] = b
 #else
 #define ADE_KEEP_IN_LOOP(p) ((void)0)
 #endif
+// Same, additionally ordered after the instruction that produced `tok` (a VGPR value): used to pace a fully unrolled
+// sequence of scalar weight-row fetches one row ahead of the FMAs instead of all up front (where the rows would not fit
+// the SGPR file and would be parked in VGPR lanes, one v_readlane per use).  Emits no instruction.
+#if defined(__AMDGCN__)
+#define ADE_KEEP_AFTER(p, tok) asm volatile("" : "+s"(p), "+v"(tok))
+#else
+#define ADE_KEEP_AFTER(p, tok) ((void)0)
+#endif
+// Fresh scalar copy of a 64-bit pointer that arrived inside a wide kernel-argument tuple (one s_load_dwordx16 for a whole
+// by-value struct): the register allocator tracks such a tuple as ONE live range, so keeping a member alive keeps --
+// and spills / restores -- all sixteen registers.  One s_mov_b64.
+#if defined(__AMDGCN__)
+#define ADE_SCALAR_COPY(dst, src) asm volatile("s_mov_b64 %0, %1" : "=s"(dst) : "s"(src))
+#else
+#define ADE_SCALAR_COPY(dst, src) ((dst) = (src))
+#endif
 // Opaque per-lane value: everything derived from it is private to the code that follows, so the optimiser cannot
 // share (and keep live) index arithmetic across the stages inlined into one kernel.  Emits no instruction.
 #if defined(__AMDGCN__)

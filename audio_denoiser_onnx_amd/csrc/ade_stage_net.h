@@ -79,6 +79,14 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     const float* sc = skip ? skip + (size_t)chunk * kCh * P : nullptr;
     float* oc = out + (size_t)chunk * kCh * P;
     const cfptr c_pw1_b = cptr(w.pw1_b), c_dw_b = cptr(w.dw_b), c_pw2_b = cptr(w.pw2_b);
+    // Private copies of the weight base pointers: `w` arrives as one 16-dword SGPR tuple, and every use of a member
+    // would otherwise restore the whole tuple from its spill lanes (16 v_readlane per weight row).
+    cfptr c_pw1, c_dw, c_pw2;
+    ADE_SCALAR_COPY(c_pw1, cptr(w.pw1));
+    ADE_SCALAR_COPY(c_dw, cptr(w.dw));
+    ADE_SCALAR_COPY(c_pw2, cptr(w.pw2));
+    const float pw1_slope = w.pw1_slope, dw_slope = w.dw_slope;
+    const int dilation = w.dilation;
     ADE_CLK(0);
 
     // ---- phase 0: stage the pointwise input x1 = (a + skip)[:, :8] in LDS planes 2-3 (own position, fully coalesced);
@@ -98,45 +106,91 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         }
         __syncthreads();
     }
-    // ---- phase 1: SFE(3) -> 1x1 (24->16) + BN + PReLU, neighbours from LDS.  Output channels 0-7 go straight to planes 0-1;
-    //      channels 8-15 wait in registers until every lane has read its x1 neighbours out of planes 2-3.   (:305-310)
+    // ---- conv phases: each lane owns THREE ADJACENT columns (t, 3c..3c+2) of the (T,33) grid -- 33 = 3 x 11, so the lane's
+    //      positions are simply 3u, 3u+1, 3u+2 (u = tid < 11 T <= 704).  One weight row fetched into scalar registers
+    //      serves three positions (a third of the scalar-load / SGPR-recycling overhead per position), the 3-tap
+    //      neighbourhoods of the three positions share 5 columns (10 / 60 tap reads instead of 18 / 108), and a lane
+    //      stride of 3 float4 = 48 B is conflict-free for ds_read/write_b128.
+    const int U = T * (kFw / 3);
+    const bool own = tid < U;
+    const int p0 = own ? 3 * tid : 0;
+    const int cfirst = own ? tid % (kFw / 3) : 0;          // column triple index c: f0 = 3c
+    const bool left_ok = cfirst != 0, right_ok = cfirst != kFw / 3 - 1;     // columns f0-1 / f0+3 exist
+    // ---- phase 1: SFE(3) -> 1x1 (24->16) + BN + PReLU.  Output channels 0-7 go straight to planes 0-1; channels 8-15 wait
+    //      in registers until every lane has read its x1 neighbours out of planes 2-3.                     (:305-310)
     float hi[kPosPerThread][8];
+    if (own) {
+        float xc[5][8];                                    // x1 columns f0-1 .. f0+3 (zero outside the grid: select, not branch)
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            const int t = p / kFw, f = p - t * kFw;
-            cfptr c_pw1 = cptr(w.pw1);
-            ADE_KEEP_IN_LOOP(c_pw1);
-            float acc[16];
+        for (int k = 0; k < 5; ++k) {
+            const bool ok = (k != 0 || left_ok) && (k != 4 || right_ok);
+            const int pp = p0 - 1 + (ok ? k : 1);
+            const float4 xa = H[2 * kPmax + pp], xb = H[3 * kPmax + pp];
+            xc[k][0] = ok ? xa.x : 0.0f; xc[k][1] = ok ? xa.y : 0.0f; xc[k][2] = ok ? xa.z : 0.0f; xc[k][3] = ok ? xa.w : 0.0f;
+            xc[k][4] = ok ? xb.x : 0.0f; xc[k][5] = ok ? xb.y : 0.0f; xc[k][6] = ok ? xb.z : 0.0f; xc[k][7] = ok ? xb.w : 0.0f;
+        }
+        v2f acc[kPosPerThread][8];
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = c_pw1_b[co];
+        for (int i = 0; i < kPosPerThread; ++i)
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const int ff = f - 1 + o;
-                if (ff < 0 || ff >= kFw) continue;
-                const float4 xa = H[2 * kPmax + p - 1 + o], xb = H[3 * kPmax + p - 1 + o];
-                const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_pw1_b[2 * m], c_pw1_b[2 * m + 1]);
+        // 24 weight rows (input channel c, SFE tap o), each 16 scalars serving 3 positions = 24 packed FMAs.  Scalar loads
+        // return out of order, so a wavefront can only wait for ALL of them: the rows are fetched in double-buffered groups
+        // of two, the next group requested right after the first FMA of the current one (its wait has just drained the
+        // queue) and landing under the remaining 47 FMAs.
+        v2f wc[2][8], wn[2][8];
+        {
+            cfptr g0 = c_pw1;
+            ADE_KEEP_IN_LOOP(g0);
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int co = 0; co < 16; ++co) acc[co] += c_pw1[(c * 3 + o) * 16 + co] * x[c];
+                for (int m = 0; m < 8; ++m) wc[j][m] = mk2(g0[j * 16 + 2 * m], g0[j * 16 + 2 * m + 1]);
+        }
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = 2 * g + j, c = r / 3, o = r % 3;        // row index = c * 3 + o (the weight layout)
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int i = 0; i < kPosPerThread; ++i) {
+                        acc[i][m] += wc[j][m] * xc[i + o][c];
+                        if (j == 0 && m == 0 && i == 0 && g < 11) {
+                            float tok = acc[0][0][0];
+                            cfptr gn = c_pw1 + (2 * g + 2) * 16;
+                            ADE_KEEP_AFTER(gn, tok);
+                            acc[0][0][0] = tok;
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                                for (int mm = 0; mm < 8; ++mm) wn[jj][mm] = mk2(gn[jj * 16 + 2 * mm], gn[jj * 16 + 2 * mm + 1]);
+                        }
+                    }
             }
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], w.pw1_slope);
-            H[p] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            H[kPmax + p] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) hi[i][k] = acc[8 + k];
+                for (int m = 0; m < 8; ++m) wc[j][m] = wn[j][m];
+        }
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            float r[16];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { r[2 * m] = prelu_f(acc[i][m][0], pw1_slope); r[2 * m + 1] = prelu_f(acc[i][m][1], pw1_slope); }
+            H[p0 + i] = make_float4(r[0], r[1], r[2], r[3]);
+            H[kPmax + p0 + i] = make_float4(r[4], r[5], r[6], r[7]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hi[i][k] = r[8 + k];
         }
     }
     __syncthreads();
+    if (own) {
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            H[2 * kPmax + p] = make_float4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
-            H[3 * kPmax + p] = make_float4(hi[i][4], hi[i][5], hi[i][6], hi[i][7]);
+        for (int i = 0; i < kPosPerThread; ++i) {
+            H[2 * kPmax + p0 + i] = make_float4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
+            H[3 * kPmax + p0 + i] = make_float4(hi[i][4], hi[i][5], hi[i][6], hi[i][7]);
         }
     }
     __syncthreads();
@@ -144,53 +198,113 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
 
     // ---- phase 2: causal dilated depthwise 3x3 + BN + PReLU -> 1x1 (16->8) + BN -> h1 (registers)   (:311-320)
     float h1r[kPosPerThread][8];
+    if (own) {
+        const int t = tid / (kFw / 3);
+        v2f acc[kPosPerThread][8];
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            const int t = p / kFw, f = p - t * kFw;
-            cfptr c_dw = cptr(w.dw), c_pw2 = cptr(w.pw2);   // per-copy opaque pointers: no cross-copy SGPR hoarding
-            ADE_KEEP_IN_LOOP(c_dw);
-            ADE_KEEP_IN_LOOP(c_pw2);
-            float acc[16];
+        for (int i = 0; i < kPosPerThread; ++i)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = c_dw_b[c];
+            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) {
-                const int tt = t - (2 - kt) * w.dilation;
-                if (tt < 0) continue;
+        for (int kt = 0; kt < 3; ++kt) {
+            const int tt = t - (2 - kt) * dilation;
+            if (tt < 0) continue;                          // (per-lane: early frames only; the weights below are indexed by constants)
+            const int pr = p0 - (2 - kt) * dilation * kFw;
+            // weights of (kt, channel quad q): 3 taps x 4 channels; the next quad's are requested after this quad's first FMA
+            v2f wc[3][2], wn[3][2];
+            {
+                cfptr g0 = c_dw + kt * 48;
+                ADE_KEEP_IN_LOOP(g0);
 #pragma unroll
-                for (int kf = 0; kf < 3; ++kf) {
-                    const int ff = f - 1 + kf;
-                    if (ff < 0 || ff >= kFw) continue;
-                    const int pp = tt * kFw + ff;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 x = H[q * kPmax + pp];
-                        const cfptr wq = c_dw + (kt * 3 + kf) * 16 + 4 * q;
-                        acc[4 * q] += wq[0] * x.x; acc[4 * q + 1] += wq[1] * x.y;
-                        acc[4 * q + 2] += wq[2] * x.z; acc[4 * q + 3] += wq[3] * x.w;
-                    }
-                }
+                for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = mk2(g0[kf * 16], g0[kf * 16 + 1]); wc[kf][1] = mk2(g0[kf * 16 + 2], g0[kf * 16 + 3]); }
             }
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = prelu_f(acc[c], w.dw_slope);
+            for (int q = 0; q < 4; ++q) {
+                v2f col[5][2];                             // channels 4q..4q+3 of columns f0-1 .. f0+3 at frame tt
 #pragma unroll
-            for (int co = 0; co < 8; ++co) h1r[i][co] = c_pw2_b[co];
+                for (int k = 0; k < 5; ++k) {
+                    const bool ok = (k != 0 || left_ok) && (k != 4 || right_ok);
+                    const float4 x = H[q * kPmax + pr - 1 + (ok ? k : 1)];
+                    col[k][0] = mk2(ok ? x.x : 0.0f, ok ? x.y : 0.0f);
+                    col[k][1] = mk2(ok ? x.z : 0.0f, ok ? x.w : 0.0f);
+                }
 #pragma unroll
-            for (int ci = 0; ci < 16; ++ci)
+                for (int kf = 0; kf < 3; ++kf)
 #pragma unroll
-                for (int co = 0; co < 8; ++co) h1r[i][co] += c_pw2[ci * 8 + co] * acc[ci];
+                    for (int i = 0; i < kPosPerThread; ++i) {
+                        acc[i][2 * q] += wc[kf][0] * col[i + kf][0];
+                        if (kf == 0 && i == 0 && q < 3) {
+                            float tok = acc[0][2 * q][0];
+                            cfptr gn = c_dw + kt * 48 + 4 * (q + 1);
+                            ADE_KEEP_AFTER(gn, tok);
+                            acc[0][2 * q][0] = tok;
+#pragma unroll
+                            for (int kk = 0; kk < 3; ++kk) { wn[kk][0] = mk2(gn[kk * 16], gn[kk * 16 + 1]); wn[kk][1] = mk2(gn[kk * 16 + 2], gn[kk * 16 + 3]); }
+                        }
+                        acc[i][2 * q + 1] += wc[kf][1] * col[i + kf][1];
+                    }
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = wn[kf][0]; wc[kf][1] = wn[kf][1]; }
+            }
         }
+        v2f h2[kPosPerThread][4];
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(prelu_f(acc[i][m][0], dw_slope), prelu_f(acc[i][m][1], dw_slope));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) h2[i][m] = mk2(c_pw2_b[2 * m], c_pw2_b[2 * m + 1]);
+        }
+        {   // 1x1 (16->8): 16 rows of 8 scalars, fetched in double-buffered groups of four rows (see phase 1)
+            v2f wc[4][4], wn[4][4];
+            {
+                cfptr g0 = c_pw2;
+                ADE_KEEP_IN_LOOP(g0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) wc[j][m] = mk2(g0[j * 8 + 2 * m], g0[j * 8 + 2 * m + 1]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ci = 4 * g + j;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int i = 0; i < kPosPerThread; ++i) {
+                            h2[i][m] += wc[j][m] * acc[i][ci >> 1][ci & 1];
+                            if (j == 0 && m == 0 && i == 0 && g < 3) {
+                                float tok = h2[0][0][0];
+                                cfptr gn = c_pw2 + (4 * g + 4) * 8;
+                                ADE_KEEP_AFTER(gn, tok);
+                                h2[0][0][0] = tok;
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                    for (int mm = 0; mm < 4; ++mm) wn[jj][mm] = mk2(gn[jj * 8 + 2 * mm], gn[jj * 8 + 2 * mm + 1]);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) wc[j][m] = wn[j][m];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { h1r[i][2 * m] = h2[i][m][0]; h1r[i][2 * m + 1] = h2[i][m][1]; }
     }
     __syncthreads();   // every tap read of H is done: planes may be reused
     ADE_CLK(2);
+    if (own) {
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            H[p] = make_float4(h1r[i][0], h1r[i][1], h1r[i][2], h1r[i][3]);
-            H[kPmax + p] = make_float4(h1r[i][4], h1r[i][5], h1r[i][6], h1r[i][7]);
+        for (int i = 0; i < kPosPerThread; ++i) {
+            H[p0 + i] = make_float4(h1r[i][0], h1r[i][1], h1r[i][2], h1r[i][3]);
+            H[kPmax + p0 + i] = make_float4(h1r[i][4], h1r[i][5], h1r[i][6], h1r[i][7]);
         }
     }
     __syncthreads();
@@ -262,7 +376,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     auto request_next_skip = [&]() {
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
-            const int p = tid + i * kFusedThreads;
+            const int p = tid + i * kFusedThreads;          // global memory is always walked position-linear (coalesced)
             if (nsc && p < P) {
                 pl_ld8(nsc, P, p, 0, nsk[i]);
             } else {
@@ -349,25 +463,42 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     }
     __syncthreads();
     ADE_CLK(7);
-    // ---- phase 5: gate, interleave with the bypass half (LDS), store; optionally leave the next block's pointwise input
-    //      (out[:, :8] + next_skip[:, :8]) in planes 2-3                                            (:156,324)
+    // ---- phase 5: gate, interleave with the bypass half, store; optionally leave the next block's pointwise input
+    //      (out[:, :8] + next_skip[:, :8]) in planes 2-3.  The column-triple owners hold h1 in registers, but HBM wants
+    //      position-linear lanes (16 B per lane, 1 KB contiguous per instruction): the gated half goes through LDS planes
+    //      2-3 (GI / HS are dead), and every lane then assembles the positions tid, tid+1024, tid+2048.     (:156,324)
+    if (own) {
+        const int t = tid / (kFw / 3);
+        float g8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g8[k] = at[t * 8 + k];
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            H[2 * kPmax + p0 + i] = make_float4(h1r[i][0] * g8[0], h1r[i][1] * g8[1], h1r[i][2] * g8[2], h1r[i][3] * g8[3]);
+            H[3 * kPmax + p0 + i] = make_float4(h1r[i][4] * g8[4], h1r[i][5] * g8[5], h1r[i][6] * g8[6], h1r[i][7] * g8[7]);
+        }
+    }
+    __syncthreads();
+    float n8[kPosPerThread][8];
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
         if (p < P) {
-            const int t = p / kFw;
-            const float4 b0 = H[p], b1 = H[kPmax + p];
-            const float by[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            float o[16];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { o[2 * k] = h1r[i][k] * at[t * 8 + k]; o[2 * k + 1] = by[k]; }
+            const float4 b0 = H[p], b1 = H[kPmax + p], g0 = H[2 * kPmax + p], g1 = H[3 * kPmax + p];
+            const float o[16] = {g0.x, b0.x, g0.y, b0.y, g0.z, b0.z, g0.w, b0.w, g1.x, b1.x, g1.y, b1.y, g1.z, b1.z, g1.w, b1.w};
             pl_st16(oc, P, p, o);
-            if (next_x1) {
-                float n8[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) n8[k] = o[k] + nsk[i][k];
-                H[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
-                H[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
+            for (int k = 0; k < 8; ++k) n8[i][k] = o[k] + nsk[i][k];
+        }
+    }
+    if (next_x1) {
+        __syncthreads();    // every lane has read the gated half out of planes 2-3
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const int p = tid + i * kFusedThreads;
+            if (p < P) {
+                H[2 * kPmax + p] = make_float4(n8[i][0], n8[i][1], n8[i][2], n8[i][3]);
+                H[3 * kPmax + p] = make_float4(n8[i][4], n8[i][5], n8[i][6], n8[i][7]);
             }
         }
     }

@@ -10,8 +10,10 @@ from ade_testlib import make_session
 from audio_denoiser_onnx_amd.synth import synth_batch
 
 GT = '[pw1,dw,h1,energy+GI,-,GRU,at,out]'
-s = make_session(None)
+import os
+from audio_denoiser_onnx_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+s = make_session(_lib.AdeLibrary(os.path.abspath(sys.argv[2])) if len(sys.argv) > 2 else None)   # optional: another build to look at
 x = synth_batch(B)
 s.process(x); s.profile(1); s.process(x); s.process(x)
 c = s.tap('phase_clock', 64).astype(int)
