@@ -323,6 +323,24 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         for (int m = 0; m < 8; ++m) wr_raw[m] = tid < 64 ? mk2(pk[2 * m], pk[2 * m + 1]) : mk2(0.0f, 0.0f);
         if (tid < 64) bh_raw = w.gru[j * 78 + 75 + gsel];
     }
+    // The next block's skip addend (8 channels per position) is requested HERE, two phases before its use: the compiler
+    // drains the vector-memory counter before wave 0 enters the serial recurrence (first use of the weights above), and
+    // by then -- after the energy phase -- these HBM loads have landed, so the recurrence does not wait for them.
+    const float* nsc = (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr;
+    float nsk[kPosPerThread][8];
+    auto request_next_skip = [&]() {
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const int p = tid + i * kFusedThreads;          // global memory is always walked position-linear (coalesced)
+            if (nsc && p < P) {
+                pl_ld8(nsc, P, p, 0, nsk[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) nsk[i][k] = 0.0f;
+            }
+        }
+    };
+    request_next_skip();
     // ---- phase 3+4a: TRA energy zt[t][c] = mean_f h1^2 (:154) and the GRU input projections GI[t][g*16+j] = b_ih + W_ih zt[t],
     //      one 16-lane DPP row per frame: lane j sums f in {j, j+16, j+32}, a 4-step row rotation all-reduce (fixed order,
     //      deterministic) gives every lane the 8 channel energies, then lane j produces its three gate rows.
@@ -369,24 +387,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     //      * gates meet through two cross-row swaps (r -> row 1 for n, n -> row 3 where z already is);
     //      * weights, biases and input projections are pre-scaled by -log2(e) (r, z) and 2 log2(e) (n), so every
     //        activation is exp2 -> add -> rcp with no multiply in front.                              (:149,155)
-    // the next block's skip addend (8 channels per position) is requested during this phase and lands while the
-    // recurrence runs (wave 0 asks AFTER its weight loads: VMEM returns in order, and the recurrence must not wait for HBM)
-    const float* nsc = (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr;
-    float nsk[kPosPerThread][8];
-    auto request_next_skip = [&]() {
-#pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            const int p = tid + i * kFusedThreads;          // global memory is always walked position-linear (coalesced)
-            if (nsc && p < P) {
-                pl_ld8(nsc, P, p, 0, nsk[i]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) nsk[i][k] = 0.0f;
-            }
-        }
-    };
     if (tid >= 64) {
-        request_next_skip();
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
         for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
             float by[8];
@@ -412,7 +413,6 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
 #pragma unroll
         for (int k = 0; k < 16; ++k) shb[k] = 0;
         float hv = 0.0f;                                             // h_{t-1}[j] (meaningful in row 3, which computes h_t)
-        request_next_skip();
         float gi = GI[gsel * 16 + j];                                // this row's input projection, fetched one step ahead
         // row 3 stores h_t; the other rows' (meaningless) values go to GI row 0, which is dead once `gi` is loaded --
         // an address select instead of an exec-mask branch in the serial loop
