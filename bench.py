@@ -134,7 +134,12 @@ def main():
     d_in = torch.from_numpy(x_host).cuda()
     d_out = torch.empty((B, sess.out_len), dtype=torch.int16, device="cuda")
     gathered = torch.empty((world * B, sess.out_len), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # A real (non-null) stream: ade_process_device treats a NULL stream handle as "run synchronously", which would put a
+    # host round trip between consecutive steps.  Steps are enqueued back to back; the timed region is still bracketed
+    # by barrier + torch.cuda.synchronize() on both sides.
+    launch_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(launch_stream)
+    stream = launch_stream.cuda_stream
 
     def step():
         sess.run_device(d_in, d_out, stream=stream)
