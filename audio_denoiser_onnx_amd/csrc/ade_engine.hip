@@ -47,7 +47,8 @@ struct GraphEntry {
 
 struct ade_engine {
     int device = 0;
-    int in_len = 0, T = 0, out_len = 0;
+    int in_len = 0, T = 0, out_len = 0;   // per WINDOW (== per call unless batch-fold)
+    int n_win = 1;                        // windows per call: USE_BATCH_FOLD folds (1,1,n_win*W) into (n_win,1,W), Export_GTCRN.py:656-660
     int sample_rate = 16000;
     std::string last_error;
     std::map<std::string, std::string> meta;
@@ -621,8 +622,14 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
+        const float* dc = nullptr;
+        if (e->n_win > 1) {   // batch-fold: one DC mean per call, shared by its windows
+            q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean, e->n_win); q.end();
+            dc = e->mean;
+        }
         if (e->use_single && (!prof || e->profile_mode >= 2)) {
             ChunkArgs A{};
+            A.dc = dc;
             A.pcm_in = d_in; A.pcm_out = d_out; A.f32_out = d_f32; A.L = e->in_len; A.T = T;
             A.tabs = e->tabs; A.erb_bm = e->erb_bm; A.erb_bs = e->erb_bs;
             A.en0 = e->en0; A.en1 = e->en1; A.de3 = e->de3; A.de4 = e->de4;
@@ -633,7 +640,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, A, B); q.end();
             return;
         }
-        q.begin("front"); launch_front(s, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk); q.end();
+        q.begin("front"); launch_front(s, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk, dc); q.end();
         for (int i = 0; i < 3; ++i) {
             q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->xe[i], nullptr};
@@ -651,7 +658,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         return;
     }
     // ---- multi-kernel path (any T): channels-last tensors, deferred TRA gates (View)
-    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean); q.end();
+    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean, e->n_win); q.end();
     q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
     q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
     q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
@@ -788,11 +795,23 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
     if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty()) {
         if (!parse_bool(e->meta["use_batch_fold"], &fold))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
-        if (fold) return bail(fail(e, ADE_ERR_UNSUPPORTED, "use_batch_fold=1: pass the folded windows as batch rows instead"));
+    }
+    long fold_w = 0;
+    if (fold) {   // the call's input is n_win windows of fold_window_length model-rate samples (a multiple of the hop)
+        if (!e->meta.count("fold_window_length") || !parse_int(e->meta["fold_window_length"], &fold_w) || fold_w <= 0 || fold_w % kHop != 0)
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "use_batch_fold=1 needs fold_window_length: a positive multiple of the hop length"));
     }
     // validate_audio_metadata (audio_onnx_metadata.py:322-351): export length / channels must agree with the "graph"
     long v = 0;
-    if (e->meta.count("export_audio_length") && !e->meta["export_audio_length"].empty()) {
+    if (fold) {   // the graph input is EXPORT_AUDIO_LENGTH = ceil(INPUT_AUDIO_LENGTH / W) * W            (Export_GTCRN.py:43)
+        const long want = (L + fold_w - 1) / fold_w * fold_w;
+        if (e->meta.count("export_audio_length") && !e->meta["export_audio_length"].empty()) {
+            if (!parse_int(e->meta["export_audio_length"], &v) || v != want)
+                return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "export_audio_length is not input_audio_length rounded up to whole fold windows"));
+        }
+        e->n_win = (int)(want / fold_w);
+        L = fold_w;
+    } else if (e->meta.count("export_audio_length") && !e->meta["export_audio_length"].empty()) {
         if (!parse_int(e->meta["export_audio_length"], &v) || v != L)
             return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input length does not match metadata export_audio_length"));
     }
@@ -841,18 +860,18 @@ ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
     d->in_channels = 1;
     d->out_channels = 1;
     d->n_outputs = 1;
-    d->in_len = h->in_len;
-    d->out_len = h->out_len;
+    d->in_len = h->in_len * h->n_win;       // what one call sees (the fold is internal)
+    d->out_len = h->out_len * h->n_win;
     d->in_sample_rate = d->out_sample_rate = d->model_sample_rate = h->sample_rate;
     d->frames = h->T;
-    d->max_batch = h->capacity;
+    d->max_batch = h->capacity / h->n_win;
     d->device = h->device;
     return ADE_OK;
 }
 
 ade_status ade_reserve(ade_handle h, int batch) {
     if (!h || batch < 0) return ADE_ERR_BAD_VALUE;
-    return reserve(h, batch);
+    return reserve(h, batch * h->n_win);
 }
 
 ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
@@ -873,10 +892,11 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device: bad arguments");
     HIP_TRY(h, hipSetDevice(h->device));
-    ade_status st = reserve(h, batch);
+    const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
+    ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
-    st = run(h, s, d_in, batch, d_out, d_f32);
+    st = run(h, s, d_in, rows, d_out, d_f32);
     if (st != ADE_OK) return st;
     if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
     return ADE_OK;
@@ -887,12 +907,13 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process: bad arguments");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    ade_status st = reserve(h, batch);
+    const int rows = batch * h->n_win;
+    ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
-    const size_t nin = (size_t)batch * h->in_len, nout = (size_t)batch * h->out_len;
+    const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
     memcpy(h->h_pcm_in, in, nin * sizeof(int16_t));
     HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in, h->h_pcm_in, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
-    st = run(h, h->stream, h->d_pcm_in, batch, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
+    st = run(h, h->stream, h->d_pcm_in, rows, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
     if (st != ADE_OK) return st;
     HIP_TRY(h, hipMemcpyAsync(h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));

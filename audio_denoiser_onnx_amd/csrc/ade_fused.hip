@@ -22,9 +22,10 @@ constexpr size_t kChunkSmemBytes = cmax(cmax(kGtSmemBytes, kDpSmemBytes), cmax(k
 
 __global__ __launch_bounds__(kFusedThreads) void k_front(const int16_t* __restrict__ pcm, int L, int T, FftTabs tabs, BandTab erb,
                                                          ConvW c0, ConvW c1, float* __restrict__ spec, float* __restrict__ e0,
-                                                         float* __restrict__ e1, long long* __restrict__ clk) {
+                                                         float* __restrict__ e1, long long* __restrict__ clk,
+                                                         const float* __restrict__ dc) {
     HIP_DYNAMIC_SHARED(float4, smem)
-    front_stage(reinterpret_cast<float*>(smem), blockIdx.x, pcm, L, T, tabs, erb, c0, c1, spec, e0, e1, clk);
+    front_stage(reinterpret_cast<float*>(smem), blockIdx.x, pcm, L, T, tabs, erb, c0, c1, spec, e0, e1, clk, dc);
 }
 __global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restrict__ a, const float* __restrict__ skip, GtConvW w,
                                                            float* __restrict__ out, int T, long long* __restrict__ clk) {
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
     long long* const clk0 = kClk ? A.clk : nullptr;
     const int chunk = blockIdx.x;
     float* fsm = reinterpret_cast<float*>(smem);
-    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, clk0);
+    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, clk0, A.dc);
     __syncthreads();
     const float* x = A.e1;
 #pragma unroll 1
@@ -103,8 +104,8 @@ void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int 
     hipLaunchKernelGGL(k_dpgrnn, dim3(B), dim3(kFusedThreads), kDpSmemBytes, s, x, w, out, T, clk);
 }
 void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
-                  float* e0, float* e1, long long* clk) {
-    hipLaunchKernelGGL(k_front, dim3(B), dim3(kFusedThreads), kFrontSmemBytes, s, pcm, L, T, tabs, erb_bm, c0, c1, spec, e0, e1, clk);
+                  float* e0, float* e1, long long* clk, const float* dc) {
+    hipLaunchKernelGGL(k_front, dim3(B), dim3(kFusedThreads), kFrontSmemBytes, s, pcm, L, T, tabs, erb_bm, c0, c1, spec, e0, e1, clk, dc);
 }
 void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
                  FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk) {

@@ -81,7 +81,7 @@ struct DpW {               // one DPGRNN block
 };
 
 // ---- launchers (ade_kernels.hip) ---------------------------------------------------------------------------
-void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean);
+void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call = 1);
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs,
                      BandTab erb_bm, float* spec, float* feat);
 void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec);
@@ -109,7 +109,7 @@ void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int 
 // front / back stages (ade_stage_frontback.h).  All (B,.,.,16) tensors of the fused path are channel-quad planar:
 // X[b][q][p] = float4(channels 4q..4q+3 of position p).
 void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
-                  float* e0, float* e1, long long* clk);
+                  float* e0, float* e1, long long* clk, const float* dc = nullptr);
 void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
                  FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk);
 
@@ -126,6 +126,7 @@ struct ChunkArgs {
     DpW dp[2];
     float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3], *d3, *mask;
     long long* clk;          // optional phase clocks
+    const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
 };
 void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B);
 

@@ -23,17 +23,22 @@ namespace {
 // F1 (part): per-chunk DC mean.  Export_GTCRN.py:645-647 — mean over THIS call's samples after the 2^-15 scale.
 // Integer sum is exact; one rounding at the end.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pcm_mean(const int16_t* __restrict__ pcm, int L, float* __restrict__ mean) {
-    __shared__ int part[256];
-    const int16_t* row = pcm + (size_t)blockIdx.x * L;
-    int s = 0;
-    for (int i = threadIdx.x; i < L; i += 256) s += (int)row[i];
+__global__ __launch_bounds__(256) void k_pcm_mean(const int16_t* __restrict__ pcm, int L, int rows, float* __restrict__ mean) {
+    // One workgroup per reference CALL: `rows` consecutive windows of L samples share one DC mean (rows = 1 unless the
+    // model was exported with USE_BATCH_FOLD, where torch.mean runs over the whole input before the fold,
+    // Export_GTCRN.py:647-660).  The mean is written once per window so that downstream kernels index it by row.
+    __shared__ long long part[256];
+    const int16_t* base = pcm + (size_t)blockIdx.x * rows * L;
+    const long long n = (long long)rows * L;
+    long long s = 0;
+    for (long long i = threadIdx.x; i < n; i += 256) s += (long long)base[i];
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
         long long tot = 0;
         for (int i = 0; i < 256; ++i) tot += part[i];
-        mean[blockIdx.x] = (float)((double)tot / ((double)L * 32768.0));
+        const float m = (float)((double)tot / ((double)n * 32768.0));
+        for (int r = 0; r < rows; ++r) mean[(size_t)blockIdx.x * rows + r] = m;
     }
 }
 
@@ -708,8 +713,8 @@ __global__ __launch_bounds__(256) void k_ola_pcm(const float* __restrict__ frame
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------------
-void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean) {
-    hipLaunchKernelGGL(k_pcm_mean, dim3(B), dim3(256), 0, s, pcm, L, mean);
+void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call) {
+    hipLaunchKernelGGL(k_pcm_mean, dim3(B / rows_per_call), dim3(256), 0, s, pcm, L, rows_per_call, mean);
 }
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs, BandTab erb_bm,
                      float* spec, float* feat) {

@@ -100,7 +100,8 @@ constexpr size_t kFrontSmemBytes = ((size_t)16 * kWbuf * 2 + kFrontFeatFloats + 
 
 __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_t* __restrict__ pcm, int L, int T, const FftTabs& tabs,
                                             const BandTab& erb, const ConvW& c0, const ConvW& c1, float* __restrict__ spec,
-                                            float* __restrict__ e0, float* __restrict__ e1, long long* __restrict__ clk) {
+                                            float* __restrict__ e0, float* __restrict__ e1, long long* __restrict__ clk,
+                                            const float* __restrict__ dc_rows = nullptr) {
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
     float* feat = smem + 16 * kWbuf * 2;
     float4* E0 = reinterpret_cast<float4*>(feat + kFrontFeatFloats);
@@ -132,7 +133,8 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
     const float b0t = c0.b[tid & 15], b1t = c1.b[tid & 15];                        // tail biases (lane -> channel, see below)
 
     // ---- F1: DC mean of THIS chunk (exact integer sum, one rounding)                     (Export_GTCRN.py:645-647)
-    {
+    //      (batch-fold models: the mean is per CALL, over all of its windows, and arrives precomputed in dc_rows)
+    if (!dc_rows) {
         int s = 0;
         if (((L & 7) == 0) && ((reinterpret_cast<size_t>(row) & 15) == 0)) {      // 8 samples per 16-byte load
             const int4* r4 = reinterpret_cast<const int4*>(row);
@@ -151,7 +153,9 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
     }
     __syncthreads();
     float dc;
-    {
+    if (dc_rows) {
+        dc = dc_rows[chunk];
+    } else {
         long long tot = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) tot += red[i];

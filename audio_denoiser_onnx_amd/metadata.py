@@ -66,7 +66,10 @@ def build_audio_metadata(*, producer: str, model_name: str, task: str, model_fam
     out_sample_rate = in_sample_rate if out_sample_rate is None else out_sample_rate
     model_sample_rate = out_sample_rate if model_sample_rate is None else model_sample_rate
     fold_window = ((int(batch_window_seconds * model_sample_rate) + hop_length - 1) // hop_length) * hop_length
-    frames = input_audio_length // hop_length + 1
+    # USE_BATCH_FOLD (Export_GTCRN.py:41-45): the graph input is rounded UP to whole fold windows and the static frame
+    # count is that of ONE window
+    export_length = ((input_audio_length + fold_window - 1) // fold_window) * fold_window if use_batch_fold else input_audio_length
+    frames = (fold_window if use_batch_fold else export_length) // hop_length + 1
     return build_model_metadata({
         "audio_metadata_version": AUDIO_METADATA_VERSION,
         "producer": producer,
@@ -81,7 +84,7 @@ def build_audio_metadata(*, producer: str, model_name: str, task: str, model_fam
         "out_sample_rate": out_sample_rate,
         "model_sample_rate": model_sample_rate,
         "input_audio_length": input_audio_length,
-        "export_audio_length": input_audio_length,
+        "export_audio_length": export_length,
         "model_audio_length": int(round(input_audio_length * model_sample_rate / in_sample_rate)),
         "output_audio_length": int(round(input_audio_length * out_sample_rate / in_sample_rate)),
         "input_to_output_scale": float(out_sample_rate / in_sample_rate),

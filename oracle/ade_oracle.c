@@ -765,7 +765,7 @@ int ade_oracle_out_len(const ade_oracle* o) { return o->out_len; }
 #define TAP(o, on, name) ((on) ? tap_get((o), (name)) : NULL)
 
 /* One reference call: GTCRN_CUSTOM.forward (Export_GTCRN.py:636-693) with B = 1. */
-static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, float* out_f32, int taps_on) {
+static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, float* out_f32, int taps_on, const float* call_mean) {
     const int L = o->in_len, T = o->T;
     const size_t TT = (size_t)T;
     float* audio = (float*)malloc(sizeof(float) * (size_t)L);
@@ -792,7 +792,8 @@ static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, floa
         const float inv = (float)(1.0 / 32768.0);
         double s = 0.0;
         for (int i = 0; i < L; ++i) { audio[i] = (float)in[i] * inv; s += audio[i]; }
-        const float mean = (float)(s / L);
+        /* batch-fold (Export_GTCRN.py:647,656-660): the mean was taken over the whole call BEFORE the fold into windows */
+        const float mean = call_mean ? *call_mean : (float)(s / L);
         for (int i = 0; i < L; ++i) audio[i] -= mean;
     }
     if (taps_on) memcpy(tap_get(o, "audio_f32"), audio, sizeof(float) * (size_t)L);
@@ -917,13 +918,38 @@ int ade_oracle_process(ade_oracle* o, const int16_t* in, int B, int16_t* out_pcm
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
         for (int b = 0; b < B; ++b)
             process_one(o, in + (size_t)b * o->in_len, out_pcm ? out_pcm + (size_t)b * o->out_len : NULL,
-                        out_f32 ? out_f32 + (size_t)b * o->out_len : NULL, b == 0);
+                        out_f32 ? out_f32 + (size_t)b * o->out_len : NULL, b == 0, NULL);
         return 0;
     }
 #endif
     (void)n_threads;
     for (int b = 0; b < B; ++b)
         process_one(o, in + (size_t)b * o->in_len, out_pcm ? out_pcm + (size_t)b * o->out_len : NULL,
-                    out_f32 ? out_f32 + (size_t)b * o->out_len : NULL, b == 0);
+                    out_f32 ? out_f32 + (size_t)b * o->out_len : NULL, b == 0, NULL);
+    return 0;
+}
+
+/* USE_BATCH_FOLD=True exports (Export_GTCRN.py:41-45,656-660,671-672): one call = n_win windows of in_len samples,
+ * DC mean over the WHOLE call, windows processed as a batch and stitched back (in_len must be a multiple of the hop,
+ * so out_len == in_len per window). */
+int ade_oracle_process_fold(ade_oracle* o, const int16_t* in, int n_calls, int n_win, int16_t* out_pcm, float* out_f32, int n_threads) {
+    if (!o || !in || n_calls < 0 || n_win < 1) return fail("bad arguments", NULL);
+    if (o->out_len != o->in_len) return fail("fold needs a window length that is a multiple of the hop", NULL);
+    (void)n_threads;
+    for (int c = 0; c < n_calls; ++c) {
+        const int16_t* base = in + (size_t)c * n_win * o->in_len;
+        const float inv = (float)(1.0 / 32768.0);
+        double s = 0.0;
+        for (size_t i = 0; i < (size_t)n_win * o->in_len; ++i) s += (float)base[i] * inv;
+        const float mean = (float)(s / ((double)n_win * o->in_len));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 1 ? n_threads : 1)
+#endif
+        for (int w = 0; w < n_win; ++w) {
+            const size_t off = ((size_t)c * n_win + w);
+            process_one(o, in + off * o->in_len, out_pcm ? out_pcm + off * o->out_len : NULL,
+                        out_f32 ? out_f32 + off * o->out_len : NULL, c == 0 && w == 0, &mean);
+        }
+    }
     return 0;
 }

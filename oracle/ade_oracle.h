@@ -40,6 +40,10 @@ const char* ade_oracle_last_error(void);
  * n_threads <= 1 runs serially; > 1 uses OpenMP over chunks. */
 int ade_oracle_process(ade_oracle* o, const int16_t* in, int B, int16_t* out_pcm, float* out_f32, int n_threads);
 
+/* USE_BATCH_FOLD=True exports: n_calls calls of n_win windows each ([n_calls][n_win][in_len] -> [n_calls][n_win][out_len]);
+ * the DC mean is taken over the whole call before the fold (Export_GTCRN.py:647,656-660). */
+int ade_oracle_process_fold(ade_oracle* o, const int16_t* in, int n_calls, int n_win, int16_t* out_pcm, float* out_f32, int n_threads);
+
 /* Taps (reference layouts) of chunk 0 of the most recent ade_oracle_process call. */
 int ade_oracle_tap(const ade_oracle* o, const char* name, const float** data, size_t* count);
 

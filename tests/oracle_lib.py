@@ -40,6 +40,7 @@ def lib():
         L.ade_oracle_out_len.argtypes = [C.c_void_p]
         L.ade_oracle_last_error.restype = C.c_char_p
         L.ade_oracle_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ade_oracle_process_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ade_oracle_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
         L.ade_oracle_stft.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
                                       C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -86,6 +87,17 @@ class GtcrnOracle:
         out_pcm = np.empty((B, self.out_len), np.int16)
         out_f32 = np.empty((B, self.out_len), np.float32)
         rc = lib().ade_oracle_process(self._h, pcm.ctypes.data, B, out_pcm.ctypes.data, out_f32.ctypes.data, threads)
+        if rc != 0:
+            raise OracleError(lib().ade_oracle_last_error().decode())
+        return out_pcm, out_f32
+
+    def process_fold(self, pcm: np.ndarray, n_win: int, threads: int = 1):
+        """USE_BATCH_FOLD calls: pcm (n_calls, n_win * in_len) -> (n_calls, n_win * out_len); mean over the whole call."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(-1, n_win * self.in_len)
+        n_calls = pcm.shape[0]
+        out_pcm = np.empty((n_calls, n_win * self.out_len), np.int16)
+        out_f32 = np.empty((n_calls, n_win * self.out_len), np.float32)
+        rc = lib().ade_oracle_process_fold(self._h, pcm.ctypes.data, n_calls, n_win, out_pcm.ctypes.data, out_f32.ctypes.data, threads)
         if rc != 0:
             raise OracleError(lib().ade_oracle_last_error().decode())
         return out_pcm, out_f32

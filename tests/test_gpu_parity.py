@@ -175,3 +175,47 @@ def test_single_launch_equals_stage_kernels(sess0):
     sess0.profile(0)
     assert kt["gtcrn_chunk"]["launches"] == 1 and kt["gtcrn_chunk"]["ms"] > 0
     assert all(v["launches"] == 0 for k, v in kt.items() if k != "gtcrn_chunk")     # nothing else was launched
+
+
+def test_batch_fold_reference_golden():
+    """USE_BATCH_FOLD export mode: the fixture is the reference run with USE_BATCH_FOLD=True (one DC mean per call,
+    2 windows of 24064 samples = 95 frames each -> the any-T multi-kernel path)."""
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_fold.npz"))
+    meta = build_audio_metadata(producer="tests", model_name="GTCRN", task="denoise", model_family="gtcrn",
+                                input_audio_length=int(g["input_audio_length"]), use_batch_fold=True)
+    sess = InferenceSession(weights=golden_blob(0), metadata=meta)
+    assert (sess.in_len, sess.out_len, sess.frames) == (48128, 48128, 95)
+    pcm, f32 = sess.process(np.stack([g["pcm_in"], g["pcm_in"][::-1]]), want_f32=True)     # two calls in one batch
+    assert np.abs(pcm[0].astype(np.int32) - g["pcm_out"].astype(np.int32)).max() <= 1
+    o = GtcrnOracle(golden_blob(0), 24064)
+    o.set_exact_dft(True)
+    opcm, of32 = o.process_fold(np.stack([g["pcm_in"], g["pcm_in"][::-1]]), 2, threads=4)
+    assert np.abs(f32 - of32).max() <= 1e-5
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
+def test_batch_fold_single_launch_window():
+    """A 1.0 s fold window (T = 64) runs on the single-launch kernel with the per-call mean passed in."""
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_fold.npz"))
+    W = 16128
+    meta = build_audio_metadata(producer="tests", model_name="GTCRN", task="denoise", model_family="gtcrn",
+                                input_audio_length=2 * W + 100, use_batch_fold=True, batch_window_seconds=1.0)
+    sess = InferenceSession(weights=golden_blob(0), metadata=meta)
+    assert (sess.in_len, sess.frames) == (3 * W, 64)                       # rounded up to whole windows
+    x = np.stack([np.resize(g["pcm_in"], 3 * W)] * 3)               # three calls of three windows each
+    x[1] = x[1] // 2 + 300
+    pcm, f32 = sess.process(x, want_f32=True)
+    sess.profile(2)
+    sess.process(x)
+    kt = sess.kernel_times()
+    sess.profile(0)
+    assert kt["gtcrn_chunk"]["launches"] == 1 and kt["pcm_mean"]["launches"] == 1
+    o = GtcrnOracle(golden_blob(0), W)
+    o.set_exact_dft(True)
+    opcm, of32 = o.process_fold(x, 3, threads=4)
+    assert np.abs(f32 - of32).max() <= 1e-5
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1

@@ -50,3 +50,24 @@ def test_hipsim_edge_inputs_and_batch_tail(simlib):
     assert not pcm[0].any() and not pcm[2].any()        # silence and pure DC come out exactly silent
     empty, _ = sess.process(np.zeros((0, 16000), np.int16))
     assert empty.shape == (0, 15872)
+
+
+def test_hipsim_batch_fold_fused_window(simlib):
+    """USE_BATCH_FOLD with a 1.0 s window (W = 16128 -> T = 64): the single-launch path with a per-CALL DC mean."""
+    import os
+    from ade_testlib import GOLD, default_meta
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_fold.npz"))
+    W = 16128
+    meta = build_audio_metadata(producer="tests", model_name="GTCRN", task="denoise", model_family="gtcrn",
+                                input_audio_length=2 * W, use_batch_fold=True, batch_window_seconds=1.0)
+    assert int(meta["fold_window_length"]) == W and int(meta["export_audio_length"]) == 2 * W
+    sess = InferenceSession(weights=golden_blob(0), metadata=meta, library=simlib)
+    assert (sess.in_len, sess.out_len, sess.frames) == (2 * W, 2 * W, 64)
+    pcm_in = g["pcm_in"][:2 * W]
+    pcm, f32 = sess.process(pcm_in[None], want_f32=True)
+    o = GtcrnOracle(golden_blob(0), W)
+    opcm, of32 = o.process_fold(pcm_in, 2)
+    assert np.abs(f32 - of32).max() <= 1e-4
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1

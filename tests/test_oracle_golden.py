@@ -101,3 +101,19 @@ def test_oracle_stft_istft_roundtrip_and_dft_truth():
             y = oracle_istft(spec, n_fft, win, hop, wt)
             n = y.shape[1]
             assert np.abs(y - x[:, :n]).max() < 2e-3
+
+
+def test_oracle_batch_fold_matches_reference():
+    """USE_BATCH_FOLD export mode (Export_GTCRN.py:41-45,647-660): one call = whole fold windows, ONE DC mean for the
+    call, windows run as a batch and stitched.  Fixture: the reference itself with USE_BATCH_FOLD=True on 48128 samples
+    (tools/make_golden_gtcrn_fold.py); the input carries a DC step so that per-window means would be visibly wrong."""
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_fold.npz"))
+    W, n_win = int(g["fold_window_length"]), int(g["n_windows"])
+    assert (W, n_win, g["pcm_in"].size) == (24064, 2, 48128)
+    o = GtcrnOracle(_blob(0), W)
+    assert o.out_len == W                                   # W is a multiple of the hop: every window reconstructs to W samples
+    pcm, _ = o.process_fold(g["pcm_in"], n_win, threads=2)
+    assert np.abs(pcm[0].astype(np.int32) - g["pcm_out"].astype(np.int32)).max() <= 1
+    # the same windows as independent calls (per-window means) do NOT reproduce the fold output
+    pcm_rows, _ = o.process(g["pcm_in"].reshape(n_win, W), threads=2)
+    assert np.abs(pcm_rows.reshape(-1).astype(np.int32) - g["pcm_out"].astype(np.int32)).max() > 1

@@ -42,7 +42,7 @@ def import_stft_process(model_dir: str = "GTCRN"):
     return mod
 
 
-def import_gtcrn_namespace(input_audio_length: int = 16000) -> dict:
+def import_gtcrn_namespace(input_audio_length: int = 16000, overrides: dict = None) -> dict:
     """Exec the class defs + constants of GTCRN/Export_GTCRN.py; return the namespace."""
     import numpy as np
     import torch
@@ -62,6 +62,8 @@ def import_gtcrn_namespace(input_audio_length: int = 16000) -> dict:
             if names and all(n.isupper() or "_" in n and n.upper() == n for n in names):
                 if names == ["INPUT_AUDIO_LENGTH"]:
                     node = ast.parse(f"INPUT_AUDIO_LENGTH = {int(input_audio_length)}").body[0]
+                elif overrides and len(names) == 1 and names[0] in overrides:      # e.g. {"USE_BATCH_FOLD": True}
+                    node = ast.parse(f"{names[0]} = {overrides[names[0]]!r}").body[0]
                 keep.append(node)
     module = ast.Module(body=keep, type_ignores=[])
     ast.fix_missing_locations(module)
