@@ -84,6 +84,19 @@ template <int LANE> __device__ __forceinline__ float read_lane(float v) {
 }
 constexpr float kLog2e = 1.4426950408889634f;
 
+// fp32 matrix-core tile (v_mfma_f32_16x16x4_f32, exact f32 = a k-ordered fmaf chain, 32 cycles):  D(16x16) += A(16x4) B(4x16)
+//   A operand: one float per lane, lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: one float per lane, lane l holds B[k = l >> 4][j = l & 15]
+//   C / D    : four floats per lane, lane l holds D[i = 4 (l >> 4) + r][j = l & 15], r = 0..3
+// With i = output channel and j = position, a lane's four results are the channel quad (l >> 4) of position (l & 15):
+// exactly one float4 of the channel-quad planar LDS layout.
+#if defined(__clang__)
+typedef float v4f __attribute__((ext_vector_type(4)));
+#else
+typedef float v4f __attribute__((vector_size(16)));
+#endif
+__device__ __forceinline__ v4f mfma16x16x4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
 // Two-wide fp32 vector: arithmetic on it is what becomes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (the packed fp32 ops
 // the 157 TFLOP/s fp32 peak is quoted on).  The recurrent loops are VALU-issue-bound, so halving the FMA instruction
 // count is a direct win.  (g++ spelling for the host-side simulator build under tests/hipsim.)

@@ -137,6 +137,25 @@ static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); retur
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __builtin_amdgcn_readlane(int x, int lane) { return (int)::hipsim::wave_exchange((uint32_t)x, lane); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+// v_mfma_f32_16x16x4_f32: D = A(16x4) B(4x16) + C, operand layout as documented in csrc/ade_device.h; k-ordered fmaf chain.
+typedef float hipsim_v4f __attribute__((vector_size(16)));
+static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim_v4f c, int, int, int) {
+    const int lane = ::hipsim::lane_id();
+    const int j = lane & 15, g = lane >> 4;
+    uint32_t ab, bb;
+    std::memcpy(&ab, &a, 4);
+    std::memcpy(&bb, &b, 4);
+    hipsim_v4f d = c;
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t av = ::hipsim::wave_exchange(ab, (4 * g + r) + 16 * k), bv = ::hipsim::wave_exchange(bb, j + 16 * k);
+            float af, bf;
+            std::memcpy(&af, &av, 4);
+            std::memcpy(&bf, &bv, 4);
+            d[r] = fmaf(af, bf, d[r]);
+        }
+    return d;
+}
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values here
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline long long wall_clock64() { return 0; }
