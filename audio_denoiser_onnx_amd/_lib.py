@@ -46,10 +46,18 @@ class IoDesc(C.Structure):
         "out_sample_rate", "model_sample_rate", "frames", "max_batch", "device")]
 
 
+class StftConfig(C.Structure):
+    """``ade_stft_config`` (include/ade.h)."""
+    _fields_ = [("n_fft", C.c_int), ("win_length", C.c_int), ("hop", C.c_int), ("window", C.c_char_p),
+                ("synthesis_window", C.c_char_p), ("center_pad", C.c_int), ("pad_mode", C.c_char_p)]
+
+
 EXPORTED_SYMBOLS = (
     "ade_create", "ade_get_io", "ade_process", "ade_process_device", "ade_reserve", "ade_set_option", "ade_debug_tap",
     "ade_kernel_count", "ade_kernel_name", "ade_profile_last", "ade_kernel_ms", "ade_last_error", "ade_destroy",
     "ade_stft_forward", "ade_istft_forward",
+    "ade_stft_create", "ade_stft_frames", "ade_stft_output_length", "ade_stft_analyze", "ade_stft_synthesize",
+    "ade_stft_last_error", "ade_stft_destroy",
 )
 
 
@@ -90,6 +98,15 @@ class AdeLibrary:
         L.ade_destroy.restype = None
         L.ade_stft_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ade_istft_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ade_stft_create.argtypes = [C.POINTER(StftConfig), C.c_int, C.POINTER(C.c_void_p)]
+        L.ade_stft_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ade_stft_output_length.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ade_stft_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ade_stft_synthesize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ade_stft_last_error.argtypes = [C.c_void_p]
+        L.ade_stft_last_error.restype = C.c_char_p
+        L.ade_stft_destroy.argtypes = [C.c_void_p]
+        L.ade_stft_destroy.restype = None
 
     def check(self, status: int, handle: Optional[C.c_void_p]) -> None:
         if status == ADE_OK:
@@ -97,6 +114,11 @@ class AdeLibrary:
         msg = self.c.ade_last_error(handle if handle else None)
         text = msg.decode("utf-8", "replace") if msg else f"libade status {status}"
         raise _EXC.get(status, RuntimeError)(text)
+
+
+def raise_for_status(status: int, text: str) -> None:
+    """Raise the reference-equivalent exception class for a libade status (same mapping as ``AdeLibrary.check``)."""
+    raise _EXC.get(status, RuntimeError)(text)
 
 
 _default: Optional[AdeLibrary] = None

@@ -109,6 +109,31 @@ void ade_destroy(ade_handle h);
 ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
 ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
 
+/* ---- generic STFT_Process operator: any n_fft / win_length / hop / window, for the other model families -------
+ * Replaces the reference's STFT_Process module in its 'stft_B' (packed) and 'istft_B' (packed, static_norm=True) forms
+ * as instantiated by GTCRN (512/512/256 hann_sqrt, GTCRN/Export_GTCRN.py:719-741), ZipEnhancer (400/400/100 hann,
+ * ZipEnhancer/Export_ZipEnhancer.py:947-948), Mel-Band-Roformer (2048/2048/441 hann,
+ * Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:695-696) and DFSMN (1920/1920/960 symmetric hamming analysis,
+ * periodic hamming synthesis, no centre pad, DFSMN/Export_DFSMN.py:273-274); class at GTCRN/STFT_Process.py:129-341.
+ * Window names: "hann", "hann_sqrt", "hamming" (torch periodic=True), with a "_sym" suffix for periodic=False;
+ * "hamming_periodic" is accepted as an alias of "hamming".  Layouts are the reference's: x [B][L] float ->
+ * spec [B][2*(n_fft/2+1)][T] (re rows, then im rows) -> y [B][out_len].  Dense windowed DFT as fp32 MFMA GEMMs. */
+typedef struct ade_stft_plan* ade_stft_handle;
+typedef struct ade_stft_config {
+    int n_fft, win_length, hop;
+    const char* window;             /* analysis window */
+    const char* synthesis_window;   /* NULL: same as the analysis window */
+    int center_pad;                 /* 1: pad n_fft/2 on both sides (pad_mode), ISTFT trims them again */
+    const char* pad_mode;           /* "reflect" | "constant" (NULL = "reflect") */
+} ade_stft_config;
+ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_handle* out);
+ade_status ade_stft_frames(ade_stft_handle h, int length, int* frames);             /* T for an input of `length` samples */
+ade_status ade_stft_output_length(ade_stft_handle h, int frames, int* out_len);     /* ISTFT output length for T frames */
+ade_status ade_stft_analyze(ade_stft_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
+ade_status ade_stft_synthesize(ade_stft_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
+const char* ade_stft_last_error(ade_stft_handle h);   /* h == NULL: the last failing ade_stft_create of this thread */
+void ade_stft_destroy(ade_stft_handle h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,14 +124,23 @@ static const wt_t* blob_find(const blob_t* b, const char* name) {
 /* torch.{hann,hamming}_window(L, periodic=True): arange(L+1) * (2*pi/L) -> cos -> * (-beta) + alpha, all fp32
  * (GTCRN/STFT_Process.py:88-97 registry; 'hann_sqrt' = hann.pow(0.5) :93), then centre pad/crop to n_fft (:100-113). */
 static int build_window(float* w, int win_length, int n_fft, const char* type) {
+    /* Names follow the GTCRN registry (periodic=True); a "_sym" suffix selects torch's periodic=False form, which is what
+     * other folders' registries bind to the same names ('hamming' in DFSMN/STFT_Process.py:92, 'hann_sqrt' in
+     * ZipEnhancer/STFT_Process.py:94); "hamming_periodic" (DFSMN/STFT_Process.py:93) is an alias of "hamming". */
     float alpha, beta;
-    int do_sqrt = 0;
-    if (strcmp(type, "hann") == 0) { alpha = 0.5f; beta = 0.5f; }
-    else if (strcmp(type, "hann_sqrt") == 0) { alpha = 0.5f; beta = 0.5f; do_sqrt = 1; }
-    else if (strcmp(type, "hamming") == 0) { alpha = 0.54f; beta = 0.46f; }
+    int do_sqrt = 0, sym = 0;
+    char base[32];
+    size_t tl = strlen(type);
+    if (tl >= sizeof base) return fail("unsupported window type: ", type);
+    strcpy(base, type);
+    if (tl > 4 && strcmp(base + tl - 4, "_sym") == 0) { base[tl - 4] = 0; sym = 1; }
+    if (strcmp(base, "hamming_periodic") == 0) strcpy(base, "hamming");
+    if (strcmp(base, "hann") == 0) { alpha = 0.5f; beta = 0.5f; }
+    else if (strcmp(base, "hann_sqrt") == 0) { alpha = 0.5f; beta = 0.5f; do_sqrt = 1; }
+    else if (strcmp(base, "hamming") == 0) { alpha = 0.54f; beta = 0.46f; }
     else return fail("unsupported window type: ", type);
     float* raw = (float*)malloc(sizeof(float) * (size_t)win_length);
-    const float step = (float)(2.0 * M_PI / (double)win_length);
+    const float step = (float)(2.0 * M_PI / (double)(sym ? win_length - 1 : win_length));
     for (int n = 0; n < win_length; ++n) {
         float v = cosf((float)n * step) * (-beta) + alpha;
         raw[n] = do_sqrt ? sqrtf(v) : v;
@@ -255,13 +264,17 @@ static void istft_packed_one(const float* spec, int T, const float* kernel, int 
     for (int i = 0; i < out_len; ++i) out[i] = raw[out_start + i] / win_sum[i];
 }
 
+/* test knob for the two generic entry points below: exact (double-angle) DFT tables instead of the reference's fp32 angles */
+static int g_generic_exact = 0;
+void ade_oracle_set_generic_exact_dft(int exact) { g_generic_exact = exact != 0; }
+
 int ade_oracle_stft(const float* x, int B, int L, int n_fft, int win_length, int hop, const char* window, int center_pad,
                     const char* pad_mode, float* out, int* T_out) {
     const int F = n_fft / 2 + 1;
     float* w = (float*)malloc(sizeof(float) * (size_t)n_fft);
     if (build_window(w, win_length, n_fft, window)) { free(w); return -1; }
     float* k = (float*)malloc(sizeof(float) * (size_t)2 * F * n_fft);
-    build_stft_kernel(k, w, n_fft, 0);
+    build_stft_kernel(k, w, n_fft, g_generic_exact);
     const int Lp = center_pad ? L + n_fft : L;
     const int T = (Lp - n_fft) / hop + 1;
     float* xp = (float*)malloc(sizeof(float) * (size_t)(L + n_fft));
@@ -279,7 +292,7 @@ int ade_oracle_istft(const float* spec, int B, int T, int n_fft, int win_length,
     float* w = (float*)malloc(sizeof(float) * (size_t)n_fft);
     if (build_window(w, win_length, n_fft, window)) { free(w); return -1; }
     float* k = (float*)malloc(sizeof(float) * (size_t)2 * F * n_fft);
-    build_istft_kernel(k, w, n_fft, 0);
+    build_istft_kernel(k, w, n_fft, g_generic_exact);
     const int raw_len = n_fft + hop * (T - 1);
     const int out_start = center_pad ? n_fft / 2 : 0;
     const int out_len = center_pad ? raw_len - n_fft : raw_len;

@@ -49,6 +49,7 @@ int ade_oracle_tap(const ade_oracle* o, const char* name, const float** data, si
 
 /* Generic STFT_Process restatement ('stft_B' packed / 'istft_B' packed, static_norm=True).
  * window: "hann","hann_sqrt","hamming" (periodic) ; pad_mode: "reflect" or "constant". */
+void ade_oracle_set_generic_exact_dft(int exact);   /* test knob: exact DFT tables in ade_oracle_stft / ade_oracle_istft */
 int ade_oracle_stft(const float* x, int B, int L, int n_fft, int win_length, int hop, const char* window,
                     int center_pad, const char* pad_mode, float* out /* [B][2*(n_fft/2+1)][T] */, int* T_out);
 int ade_oracle_istft(const float* spec /* [B][2F][T] */, int B, int T, int n_fft, int win_length, int hop,

@@ -57,6 +57,7 @@ extern dim3 cur_block, cur_bdim, cur_gdim;
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
 void block_barrier();
 uint32_t wave_exchange(uint32_t v, int src_lane);   // every live lane of the wave must call
+void wave_allgather2(uint32_t a, uint32_t b, uint32_t* out_a, uint32_t* out_b);   // every lane of the wave must call
 int lane_id();
 }  // namespace hipsim
 
@@ -142,16 +143,16 @@ typedef float hipsim_v4f __attribute__((vector_size(16)));
 static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim_v4f c, int, int, int) {
     const int lane = ::hipsim::lane_id();
     const int j = lane & 15, g = lane >> 4;
-    uint32_t ab, bb;
+    uint32_t ab, bb, all_a[64], all_b[64];
     std::memcpy(&ab, &a, 4);
     std::memcpy(&bb, &b, 4);
+    ::hipsim::wave_allgather2(ab, bb, all_a, all_b);
     hipsim_v4f d = c;
     for (int r = 0; r < 4; ++r)
         for (int k = 0; k < 4; ++k) {
-            const uint32_t av = ::hipsim::wave_exchange(ab, (4 * g + r) + 16 * k), bv = ::hipsim::wave_exchange(bb, j + 16 * k);
             float af, bf;
-            std::memcpy(&af, &av, 4);
-            std::memcpy(&bf, &bv, 4);
+            std::memcpy(&af, &all_a[(4 * g + r) + 16 * k], 4);     // A[i = 4g + r][k]
+            std::memcpy(&bf, &all_b[j + 16 * k], 4);               // B[k][j]
             d[r] = fmaf(af, bf, d[r]);
         }
     return d;

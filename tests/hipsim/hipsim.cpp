@@ -26,6 +26,7 @@ struct Fiber {
 
 struct Wave {
     uint32_t slot[64];
+    uint32_t slot2[64];
     int alive = 0, arrived = 0;
     unsigned gen = 0;
 };
@@ -105,6 +106,19 @@ uint32_t wave_exchange(uint32_t v, int src_lane) {
     const uint32_t out = w->slot[src_lane & 63];
     wave_barrier(w);
     return out;
+}
+
+// every lane deposits two words; after one rendezvous every lane sees all 64 pairs (used by the MFMA emulation, which
+// would otherwise need 32 separate exchanges per instruction)
+void wave_allgather2(uint32_t a, uint32_t b, uint32_t* out_a, uint32_t* out_b) {
+    BlockRun* r = g_run;
+    Fiber* f = r->running;
+    Wave* w = &r->waves[f->linear / 64];
+    w->slot[f->linear & 63] = a;
+    w->slot2[f->linear & 63] = b;
+    wave_barrier(w);
+    for (int i = 0; i < 64; ++i) { out_a[i] = w->slot[i]; out_b[i] = w->slot2[i]; }
+    wave_barrier(w);
 }
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {

@@ -41,6 +41,8 @@ def lib():
         L.ade_oracle_last_error.restype = C.c_char_p
         L.ade_oracle_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ade_oracle_process_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ade_oracle_set_generic_exact_dft.argtypes = [C.c_int]
+        L.ade_oracle_set_generic_exact_dft.restype = None
         L.ade_oracle_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
         L.ade_oracle_stft.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
                                       C.c_char_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -108,6 +110,11 @@ class GtcrnOracle:
         if lib().ade_oracle_tap(self._h, name.encode(), C.byref(p), C.byref(n)) != 0:
             raise OracleError(lib().ade_oracle_last_error().decode())
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def oracle_set_generic_exact_dft(exact: bool) -> None:
+    """Exact (double-angle) DFT tables in oracle_stft / oracle_istft instead of the reference's fp32-angle tables."""
+    lib().ade_oracle_set_generic_exact_dft(int(bool(exact)))
 
 
 def oracle_stft(x: np.ndarray, n_fft, win_length, hop, window, center=True, pad_mode="reflect"):

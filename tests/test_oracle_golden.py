@@ -117,3 +117,28 @@ def test_oracle_batch_fold_matches_reference():
     # the same windows as independent calls (per-window means) do NOT reproduce the fold output
     pcm_rows, _ = o.process(g["pcm_in"].reshape(n_win, W), threads=2)
     assert np.abs(pcm_rows.reshape(-1).astype(np.int32) - g["pcm_out"].astype(np.int32)).max() > 1
+
+
+# analysis / synthesis window names in the oracle's vocabulary for each fixture of tools/make_golden_stft.py
+STFT_CASES = {
+    "gtcrn": ("hann_sqrt", "hann_sqrt"),
+    "zipenhancer": ("hann", "hann"),
+    "melband": ("hann", "hann"),
+    "dfsmn": ("hamming_sym", "hamming_periodic"),     # DFSMN's registry binds 'hamming' to periodic=False
+}
+
+
+@pytest.mark.parametrize("name", sorted(STFT_CASES))
+def test_oracle_stft_process_configs(name):
+    """STFT_Process restatement vs each starred model folder's own STFT_Process copy (rows a1-a4): 512/256 sqrt-hann,
+    400/100 hann, 2048/441 hann (centre, reflect) and 1920/960 hamming without centre padding."""
+    g = np.load(os.path.join(GOLD, f"stft_{name}.npz"))
+    n_fft, win, hop, center = int(g["n_fft"]), int(g["win_length"]), int(g["hop"]), bool(g["center"])
+    wa, ws = STFT_CASES[name]
+    spec = oracle_stft(g["x"], n_fft, win, hop, wa, center, str(g["pad_mode"]))
+    assert spec.shape == g["spec"].shape
+    # fp32 sums over n_fft terms in a different order than torch's conv1d: a few 1e-6 relative at n_fft = 2048
+    assert np.abs(spec - g["spec"]).max() <= 1e-5 * np.abs(g["spec"]).max()
+    y = oracle_istft(g["spec"], n_fft, win, hop, ws, center)
+    assert y.shape == g["y"].shape
+    assert np.abs(y - g["y"]).max() <= 1e-5

@@ -1,0 +1,109 @@
+"""Generic STFT_Process operator (csrc/ade_stft.hip): the dense windowed DFT as fp32 MFMA
+GEMMs for the analysis / synthesis configurations of the starred model folders.
+
+Fixtures: tests/golden/stft_<name>.npz, produced by each folder's own STFT_Process copy (tools/make_golden_stft.py).
+The operator uses exact-angle DFT tables; the reference evaluates cos/sin of fp32 angles (up to 1e-4 relative table
+error), so two comparisons are made: tight against the oracle with exact tables (kernel error only) and
+loose against the reference fixture (kernel + the reference's table error).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ade_testlib import GOLD, hipsim_library
+from audio_denoiser_onnx_amd import _lib
+from oracle_lib import oracle_istft, oracle_set_generic_exact_dft, oracle_stft
+
+CASES = {   # name -> (analysis window, synthesis window) in the canonical vocabulary
+    "gtcrn": ("hann_sqrt", "hann_sqrt"),
+    "zipenhancer": ("hann", "hann"),
+    "melband": ("hann", "hann"),
+    "dfsmn": ("hamming_sym", "hamming_periodic"),
+}
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLD, f"stft_{name}.npz"))
+    return g, int(g["n_fft"]), int(g["win_length"]), int(g["hop"]), bool(g["center"]), str(g["pad_mode"])
+
+
+@pytest.mark.hipsim
+def test_hipsim_generic_stft_small():
+    """Kernel logic under the host simulator (MFMA emulated): ZipEnhancer's 400/100 hann on a short input."""
+    lib = hipsim_library()
+    g, n_fft, win, hop, center, pad = _load("zipenhancer")
+    x = np.ascontiguousarray(g["x"][:, :1300])
+    cfg = _lib.StftConfig(n_fft, win, hop, b"hann", None, int(center), pad.encode())
+    h = C.c_void_p()
+    assert lib.c.ade_stft_create(C.byref(cfg), 0, C.byref(h)) == 0
+    t = C.c_int()
+    assert lib.c.ade_stft_frames(h, x.shape[1], C.byref(t)) == 0 and t.value == 14
+    spec = np.empty((2, n_fft + 2, t.value), np.float32)
+    assert lib.c.ade_stft_analyze(h, x.ctypes.data, 2, x.shape[1], spec.ctypes.data, None) == 0     # (simulated device memory = host memory)
+    oracle_set_generic_exact_dft(True)
+    try:
+        ref = oracle_stft(x, n_fft, win, hop, "hann", center, pad)
+        assert np.abs(spec - ref).max() <= 2e-6 * np.abs(ref).max()
+        n = C.c_int()
+        assert lib.c.ade_stft_output_length(h, t.value, C.byref(n)) == 0 and n.value == 1300
+        y = np.empty((2, n.value), np.float32)
+        assert lib.c.ade_stft_synthesize(h, spec.ctypes.data, 2, t.value, y.ctypes.data, None) == 0
+        assert np.abs(y - oracle_istft(ref, n_fft, win, hop, "hann", center)).max() <= 2e-6
+        assert np.abs(y - x).max() <= 2e-6                                                         # perfect reconstruction
+    finally:
+        oracle_set_generic_exact_dft(False)
+        lib.c.ade_stft_destroy(h)
+    bad = _lib.StftConfig(400, 400, 100, b"kaiser", None, 1, b"reflect")
+    assert lib.c.ade_stft_create(C.byref(bad), 0, C.byref(h)) == _lib.ADE_ERR_UNSUPPORTED
+    assert b"kaiser" in lib.c.ade_stft_last_error(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_stft_process_configs(name):
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    g, n_fft, win, hop, center, pad = _load(name)
+    wa, ws = CASES[name]
+    stft = STFT_Process("stft_B", n_fft, win, hop, 0, wa, center, pad)
+    x = torch.from_numpy(g["x"]).cuda()
+    spec = stft(x[:, None, :])
+    assert tuple(spec.shape) == g["spec"].shape
+    spec_h = spec.cpu().numpy()
+    smax = float(np.abs(g["spec"]).max())
+    # loose: the reference fixture (its fp32-angle table error included: up to ~1e-4 relative at n_fft = 2048)
+    assert np.abs(spec_h - g["spec"]).max() <= 2e-4 * smax
+    oracle_set_generic_exact_dft(True)
+    try:
+        ref = oracle_stft(g["x"], n_fft, win, hop, wa, center, pad)
+        assert np.abs(spec_h - ref).max() <= 1e-5 * smax                       # tight: kernel error only
+        istft = STFT_Process("istft_B", n_fft, win, hop, spec.shape[2], ws, center, pad, static_norm=True)
+        y = istft(torch.from_numpy(g["spec"]).cuda()).cpu().numpy().reshape(2, -1)
+        assert y.shape == g["y"].shape
+        # vs the reference fixture.  Without centre padding the first / last hop is divided by a tiny sum(w^2)
+        # (hamming ends at 0.08), which amplifies the reference's own table error there (7e-4 observed)
+        assert np.abs(y - g["y"]).max() <= (1e-4 if center else 2e-3)
+        assert np.abs(y - oracle_istft(g["spec"], n_fft, win, hop, ws, center)).max() <= 1e-5
+    finally:
+        oracle_set_generic_exact_dft(False)
+    if center:    # analysis -> synthesis of the operator's own spectrum reconstructs the input
+        y2 = STFT_Process("istft_B", n_fft, win, hop, spec.shape[2], ws, center, pad)(spec).cpu().numpy().reshape(2, -1)
+        assert np.abs(y2 - g["x"][:, :y2.shape[1]]).max() <= 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_stft_process_large_batch_properties():
+    """Mel-Band geometry at a realistic size (stereo 1.5 s windows): linearity and batch independence."""
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    stft = STFT_Process("stft_B", 2048, 2048, 441, 0, "hann", True, "reflect")
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.randn(16, 66150, generator=gen) * 0.1).cuda()
+    a = stft(x)
+    assert a.shape == (16, 2050, 151)
+    b = stft(x[3:5])
+    assert torch.equal(a[3:5], b)                                              # rows are independent, kernels deterministic
+    c = stft(2.0 * x[:2] + x[2:4])
+    assert float((c - (2.0 * a[:2] + a[2:4])).abs().max()) <= 1e-4 * float(a.abs().max())

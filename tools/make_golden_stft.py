@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""STFT_Process golden vectors for the analysis/synthesis configurations of the starred models, produced by RUNNING each
+model folder's own STFT_Process copy here (build container only).
+
+    GTCRN       512 / 512 / 256   hann_sqrt (periodic)   centre, reflect      GTCRN/STFT_Process.py
+    ZipEnhancer 400 / 400 / 100   hann (periodic)        centre, reflect      ZipEnhancer/STFT_Process.py
+    Mel-Band    2048 / 2048 / 441 hann (periodic)        centre, reflect      Mel_Band_Roformer/Stereo/STFT_Process.py
+    DFSMN       1920 / 1920 / 960 hamming (symmetric) analysis, hamming_periodic synthesis, no centre pad   DFSMN/STFT_Process.py
+
+Each fixture holds x (B, L), the packed spectrum stft_B(x) (B, 2F, T) and istft_B(spectrum) (B, L_out).
+
+    python tools/make_golden_stft.py      # writes tests/golden/stft_<name>.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from ref_import import import_stft_process  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+CASES = [
+    # name, model dir, n_fft, win, hop, analysis window, synthesis window, center, pad_mode, L, static kwarg
+    ("gtcrn", "GTCRN", 512, 512, 256, "hann_sqrt", "hann_sqrt", True, "reflect", 6000, "static_norm"),
+    ("zipenhancer", "ZipEnhancer", 400, 400, 100, "hann", "hann", True, "reflect", 4000, "static_norm"),
+    ("melband", "Mel_Band_Roformer/Stereo", 2048, 2048, 441, "hann", "hann", True, "reflect", 13230, "static_frames"),
+    ("dfsmn", "DFSMN", 1920, 1920, 960, "hamming", "hamming_periodic", False, "constant", 12480, "static_norm"),
+]
+
+
+def main():
+    for name, mdir, n_fft, win, hop, wa, ws, center, pad, L, static_kw in CASES:
+        mod = import_stft_process(mdir)
+        torch.manual_seed(1234)
+        x = torch.randn(2, 1, L) * 0.25
+        stft = mod.STFT_Process("stft_B", n_fft, win, hop, 0, wa, center, pad).eval()
+        with torch.inference_mode():
+            spec = stft._stft_B_packed_forward(x) if hasattr(stft, "_stft_B_packed_forward") else torch.cat(stft(x), dim=1)
+            T = spec.shape[2]
+            istft = mod.STFT_Process("istft_B", n_fft, win, hop, T, ws, center, pad, **{static_kw: True}).eval()
+            F = n_fft // 2 + 1
+            if hasattr(istft, "_istft_B_packed_forward"):
+                y = istft._istft_B_packed_forward(spec)
+            else:
+                y = istft(spec[:, :F], spec[:, F:])
+        y = y.reshape(2, -1)
+        np.savez_compressed(os.path.join(GOLD, f"stft_{name}.npz"), x=x.numpy().reshape(2, L), spec=spec.numpy(), y=y.numpy(),
+                            n_fft=np.int64(n_fft), win_length=np.int64(win), hop=np.int64(hop), center=np.int64(center),
+                            analysis_window=np.array(wa), synthesis_window=np.array(ws), pad_mode=np.array(pad))
+        err = float((y - x.reshape(2, L)[:, :y.shape[1]]).abs().max()) if center else float("nan")
+        print(f"{name}: spec {tuple(spec.shape)} y {tuple(y.shape)} roundtrip err {err:.2e}")
+
+
+if __name__ == "__main__":
+    main()

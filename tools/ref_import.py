@@ -27,6 +27,8 @@ def _stub_absent_modules():
                 __import__(name)
             except Exception:
                 sys.modules[name] = types.ModuleType(name)
+                if name == "onnxslim":      # `from onnxslim import slim` at the top of some STFT_Process copies
+                    sys.modules[name].slim = lambda *a, **k: None
 
 
 def import_stft_process(model_dir: str = "GTCRN"):
