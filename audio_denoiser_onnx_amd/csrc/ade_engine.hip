@@ -22,12 +22,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct Tensor {
-    std::vector<int> dims;
-    const float* data = nullptr;
-    size_t count = 0;
-};
-
 struct KernelStat {
     std::string name;
     float ms = 0.f;
@@ -54,6 +48,8 @@ struct ade_engine {
     std::map<std::string, std::string> meta;
     std::vector<float> blob_storage;
     std::map<std::string, Tensor> tensors;
+
+    ade::DfsmnEngine* dfsmn = nullptr;    // model_family "dfsmn": the sub-engine of csrc/ade_dfsmn.hip (everything below is GTCRN's)
 
     hipStream_t stream = nullptr;
     float* d_weights = nullptr;
@@ -546,6 +542,19 @@ ade_status reserve(ade_engine* e, int batch) {
     if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     free_workspace(e);
     const size_t B = (size_t)batch, T = (size_t)e->T;
+    if (e->dfsmn) {   // the sub-engine owns its activations; only the I/O staging of ade_process lives here
+        std::string derr;
+        const int rc = ade::dfsmn_reserve(e->dfsmn, batch, derr);
+        if (rc != ADE_OK) return fail(e, (ade_status)rc, derr);
+        HIP_TRY(e, hipMalloc((void**)&e->d_pcm_in, B * e->in_len * sizeof(int16_t)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_pcm_out, B * e->out_len * sizeof(int16_t)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_f32_out, B * e->out_len * sizeof(float)));
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
+        HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
+        e->capacity = batch;
+        return ADE_OK;
+    }
     const size_t nfr = B * T;
     struct Carve { float** p; size_t n; };
     std::vector<Carve> cs = {
@@ -693,6 +702,11 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
 ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32) {
     if (B == 0) return ADE_OK;
     e->last_batch = B;
+    if (e->dfsmn) {
+        std::string derr;
+        const int rc = ade::dfsmn_run(e->dfsmn, s, d_in, B, d_out, d_f32, derr);
+        return rc == ADE_OK ? ADE_OK : fail(e, (ade_status)rc, derr);
+    }
     if (e->profile) {
         for (auto& st : e->stats) { st.ms = 0.f; st.launches = 0; }
         e->events_used = 0;
@@ -770,8 +784,48 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (it == e->meta.end() || it->second.empty())
             return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
     }
+    if (e->meta["model_family"] == "dfsmn") {   // DFSMN/Export_DFSMN.py: 48 kHz, int16 I/O, static shapes, no centre pad
+        bool dyn_d = false, fold_d = false;
+        if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
+        if (dyn_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
+        if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && (!parse_bool(e->meta["use_batch_fold"], &fold_d) || fold_d))
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn: use_batch_fold is not implemented"));
+        long sri = 0, sro = 0, srm = 0, Ld = 0;
+        if (!parse_int(e->meta["in_sample_rate"], &sri) || !parse_int(e->meta["out_sample_rate"], &sro) ||
+            !parse_int(e->meta["model_sample_rate"], &srm) || !parse_int(e->meta["input_audio_length"], &Ld))
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
+        if (srm != 48000 || sri != srm || sro != srm)
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn runs at 48 kHz in, model and out (resampling path not implemented)"));
+        if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
+        if (Ld < 1920 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
+        ade_status std_ = parse_blob(e, weights, weights_nbytes);
+        if (std_ != ADE_OK) return bail(std_);
+        int ndev_d = 0;
+        if (hipGetDeviceCount(&ndev_d) != hipSuccess || ndev_d <= 0) {
+            (void)hipGetLastError();
+            return bail(fail(e, ADE_ERR_DEVICE, "no HIP device visible: libade has no CPU execution mode"));
+        }
+        if (device < 0 || device >= ndev_d) return bail(fail(e, ADE_ERR_DEVICE, "device ordinal out of range"));
+        e->device = device;
+        if (hipSetDevice(device) != hipSuccess) return bail(fail(e, ADE_ERR_DEVICE, "hipSetDevice failed"));
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
+        std::string derr;
+        const int rc = ade::dfsmn_create(e->tensors, (int)Ld, device, &e->dfsmn, derr);
+        if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
+        e->in_len = (int)Ld;
+        e->T = ade::dfsmn_frames(e->dfsmn);
+        e->out_len = ade::dfsmn_out_len(e->dfsmn);
+        e->sample_rate = 48000;
+        e->blob_storage.clear();
+        e->blob_storage.shrink_to_fit();
+        e->tensors.clear();
+        *out = e;
+        return ADE_OK;
+    }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn only)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
@@ -925,6 +979,12 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
 
 ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t count, size_t* written) {
     if (!h || !name || !out || !written) return ADE_ERR_BAD_VALUE;
+    if (h->dfsmn) {
+        std::string derr;
+        HIP_TRY(h, hipSetDevice(h->device));
+        const int rc = ade::dfsmn_tap(h->dfsmn, h->stream, name, h->last_batch, out, count, written, derr);
+        return rc == ADE_OK ? ADE_OK : fail(h, (ade_status)rc, derr);
+    }
     const size_t nfr = (size_t)h->last_batch * h->T;
     struct Tap { const char* name; const float* p; size_t n; };
     const Tap taps[] = {
@@ -1010,6 +1070,7 @@ void ade_destroy(ade_handle h) {
         hipStreamSynchronize(h->stream);
     }
     free_workspace(h);
+    if (h->dfsmn) ade::dfsmn_destroy(h->dfsmn);
     for (auto& ev : h->events) {
         hipEventDestroy(ev.first);
         hipEventDestroy(ev.second);
@@ -1022,6 +1083,7 @@ void ade_destroy(ade_handle h) {
 }
 
 ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream) {
+    if (h && h->dfsmn) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stft_forward: this handle is a DFSMN model (use ade_stft_create for a generic STFT)");
     if (!h || batch < 0 || (batch > 0 && (!d_x || !d_spec))) return ADE_ERR_BAD_VALUE;
     if (length < kNfft / 2 + 2) return fail(h, ADE_ERR_SHAPE_MISMATCH, "ade_stft_forward: length too short for reflect padding");
     if (batch == 0) return ADE_OK;
@@ -1034,6 +1096,7 @@ ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int lengt
 }
 
 ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
+    if (h && h->dfsmn) return fail(h, ADE_ERR_UNSUPPORTED, "ade_istft_forward: this handle is a DFSMN model (use ade_stft_create for a generic STFT)");
     if (!h || batch < 0 || frames < 2 || (batch > 0 && (!d_spec || !d_y))) return ADE_ERR_BAD_VALUE;
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -1,0 +1,132 @@
+// ade_gemm.h — fp32 GEMM on the MI355X matrix cores with functor operands (shared by the STFT operator and DFSMN).
+//
+//   C(m, n) = sum_k A(m, k) * B(k, n)        exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain)
+//
+// Operands and the result are FUNCTORS, so framing a waveform, reflecting its ends, masking a spectrum, squaring a
+// spectrum into a power spectrum, adding a bias or applying an activation all happen in the loaders / the store instead of
+// in separate passes over HBM:
+//   struct ALoad { static constexpr bool kAlongK = ...; __device__ float operator()(int m, int k) const; };
+//        kAlongK = true : consecutive k are contiguous in memory (row-major weight matrices)
+//        kAlongK = false: consecutive m are contiguous (an activation read "transposed")
+//   struct BLoad { static constexpr bool kAlongN = ...; __device__ float operator()(int k, int n) const; };
+//        kAlongN = true : consecutive n contiguous (row-major activations / tables);  false: consecutive k contiguous
+//   struct Store { __device__ void operator()(int m, int n, float v) const; };
+// The flags only choose which lanes fetch which elements of a slab (so that the fetches coalesce); out-of-range
+// elements are never requested.
+// One 256-thread workgroup computes a 128 x 128 tile; each of its 4 wavefronts owns a 64 x 64 quadrant as 4 x 4 MFMA tiles
+// (64 accumulator VGPRs).  Slabs of 16 k are staged k-major in LDS with a row stride of 144 floats (144 mod 64 = 16):
+// the per-lane operand reads -- 16 consecutive rows x 4 consecutive k -- then cover all 64 banks exactly once.
+#pragma once
+#include "ade_device.h"
+
+namespace ade {
+namespace gemm {
+
+using namespace dev;
+
+constexpr int kTM = 128, kTN = 128, kTK = 16;
+constexpr int kLds = 144;
+
+template <class AL, class BL, class ST>
+__global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
+    __shared__ float As[kTK * kLds];
+    __shared__ float Bs[kTK * kLds];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_blk = blockIdx.y * kTM, n_blk = blockIdx.x * kTN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int j16 = lane & 15, g = lane >> 4;
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+        if (AL::kAlongK) {          // thread = (row, half slab): 8 consecutive k of one row
+            const int r = tid >> 1, kh = (tid & 1) * 8, m = m_blk + r;
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = v[u];
+        } else {                    // thread = (row, half slab): consecutive lanes = consecutive rows for each k
+            const int r = tid & 127, kh = (tid >> 7) * 8, m = m_blk + r;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+        }
+        if (BL::kAlongN) {          // thread = (column, half slab)
+            const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Bs[(kh + u) * kLds + c] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
+        } else {                    // thread = (k, 16 column groups): consecutive lanes = consecutive k of one column
+            const int kk = tid & 15, cg = tid >> 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = cg + 16 * u, n = n_blk + c;
+                Bs[kk * kLds + c] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < kTK; ks += 4) {       // lane (g, j16) supplies A[row 16 i + j16][k + g] and B[k + g][col 16 j + j16]
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(ks + g) * kLds + wm + 16 * i + j16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[(ks + g) * kLds + wn + 16 * j + j16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x4(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_blk + wm + 16 * i + 4 * g + r, n = n_blk + wn + 16 * j + j16;
+                if (m < M && n < N) store(m, n, acc[i][j][r]);
+            }
+}
+
+template <class AL, class BL, class ST>
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
+    const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+}
+
+// ---- common functors ------------------------------------------------------------------------------------------
+struct RowMajorA {      // A(m, k) = p[m * ld + k]
+    static constexpr bool kAlongK = true;
+    const float* p;
+    int ld;
+    __device__ float operator()(int m, int k) const { return p[(size_t)m * ld + k]; }
+};
+struct RowMajorB {      // B(k, n) = p[k * ld + n]
+    static constexpr bool kAlongN = true;
+    const float* p;
+    int ld;
+    __device__ float operator()(int k, int n) const { return p[(size_t)k * ld + n]; }
+};
+enum { kActNone = 0, kActRelu = 1, kActSigmoid = 2, kActLogFloor = 3 };
+template <int ACT>
+struct BiasActStore {   // C(m, n) -> p[m * ld + n] = act(v + bias[m])   (bias may be null)
+    float* p;
+    int ld;
+    const float* bias;
+    float floor_;       // kActLogFloor: log(max(v, floor_))
+    __device__ void operator()(int m, int n, float v) const {
+        if (bias) v += bias[m];
+        if (ACT == kActRelu) v = v > 0.0f ? v : 0.0f;
+        if (ACT == kActSigmoid) v = 1.0f / (1.0f + expf(-v));
+        if (ACT == kActLogFloor) v = logf(v > floor_ ? v : floor_);
+        p[(size_t)m * ld + n] = v;
+    }
+};
+
+}  // namespace gemm
+}  // namespace ade

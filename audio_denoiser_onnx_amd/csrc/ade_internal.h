@@ -1,6 +1,9 @@
 // ade_internal.h — shapes, device-side parameter blocks and launcher prototypes shared by the engine
 // (ade_engine.hip) and the gfx950 kernels (ade_kernels.hip).  Not part of the public ABI (include/ade.h).
 #pragma once
+#include <map>
+#include <string>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -129,5 +132,23 @@ struct ChunkArgs {
     const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
 };
 void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B);
+
+// ---- a tensor of the parsed ADEWGT01 weight blob (host memory, owned by the engine while it is being built)
+struct Tensor {
+    std::vector<int> dims;
+    const float* data = nullptr;
+    size_t count = 0;
+};
+
+// ---- model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip.  Built by ade_create from the same
+//      manifest + blob format; every GEMM-shaped step runs on the matrix cores (csrc/ade_gemm.h).
+struct DfsmnEngine;
+int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, DfsmnEngine** out, std::string& err);   // ade_status
+int dfsmn_reserve(DfsmnEngine* d, int batch, std::string& err);
+int dfsmn_run(DfsmnEngine* d, hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err);
+int dfsmn_frames(const DfsmnEngine* d);
+int dfsmn_out_len(const DfsmnEngine* d);
+int dfsmn_tap(DfsmnEngine* d, hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err);
+void dfsmn_destroy(DfsmnEngine* d);
 
 }  // namespace ade

@@ -10,12 +10,10 @@
 //              (framing, centre padding and reflection are index arithmetic in the B-operand loader: no im2col buffer)
 //   synthesis  frame[b,t][n]  = sum_c spec[b][c][t] * Kinv[c][n]            M = B*T, N = n_fft, K = 2F
 //              y[b][m]        = sum_t frame[b,t][m + start - t*hop] / sum_t w^2[m + start - t*hop]   (gather: deterministic)
-// One 256-thread workgroup computes a 128 x 128 tile; each of its 4 wavefronts owns a 64 x 64 quadrant as 4 x 4 MFMA
-// tiles (64 accumulator VGPRs); operands are staged k-major in LDS with a row stride of 144 floats, which makes the
-// per-lane operand reads (16 consecutive rows x 4 consecutive k) conflict-free.
+// The GEMM itself is csrc/ade_gemm.h (128 x 128 workgroup tiles, functor operands).
 // Tables use exact angles (reduced f*n mod N, evaluated in double); the reference evaluates cos/sin of fp32 angles up
 // to 2*pi*N/2, which costs it up to 1e-4 relative -- the parity tests price that difference explicitly.
-#include "ade_device.h"
+#include "ade_gemm.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
 
@@ -29,116 +27,43 @@ namespace {
 
 using namespace dev;
 
-constexpr int kTM = 128, kTN = 128, kTK = 16;      // workgroup tile
-constexpr int kLds = 144;                          // k-major LDS row stride (floats): 144 mod 64 = 16
-
 struct StftDims {
     int n_fft, hop, F2;        // F2 = 2 * (n_fft/2 + 1)
     int pad;                   // n_fft/2 when centre-padded, else 0
     int reflect;               // 1: reflect, 0: zeros (only meaningful with pad > 0)
 };
 
-// MODE 0: analysis.  A = K table [F2][n_fft] ; B(k, j) = padded sample ; C(m, j) -> spec[b][m][t]
-// MODE 1: synthesis frames.  A(j, k) = spec[b][k][t] ; B = Kinv [F2][n_fft] ; C(j, n) -> frames[j][n]
-template <int MODE>
-__global__ __launch_bounds__(256) void k_stft_gemm(const float* __restrict__ tab, const float* __restrict__ src, float* __restrict__ dst,
-                                                   StftDims d, int Bn, int L, int T) {
-    __shared__ float As[kTK * kLds];
-    __shared__ float Bs[kTK * kLds];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = MODE == 0 ? d.F2 : Bn * T;
-    const int N = MODE == 0 ? Bn * T : d.n_fft;
-    const int K = MODE == 0 ? d.n_fft : d.F2;
-    const int m_blk = blockIdx.y * kTM, n_blk = blockIdx.x * kTN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;       // this wavefront's quadrant
-    const int j16 = lane & 15, g = lane >> 4;
-    v4f acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-
-    for (int k0 = 0; k0 < K; k0 += kTK) {
-        // ---- stage the two operand slabs, k-major
-        if (MODE == 0) {
-            {   // A: table rows m, 8 consecutive k per thread (two 16-byte loads)
-                const int r = tid >> 1, kh = (tid & 1) * 8, m = m_blk + r;
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (m < M && k0 + kh + u < K) ? tab[(size_t)m * d.n_fft + k0 + kh + u] : 0.0f;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = v[u];
-            }
-            {   // B: frames.  thread = (k, 16 column groups): consecutive lanes read consecutive samples of one frame
-                const int kk = tid & 15, jg = tid >> 4;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int jl = jg + 16 * u, j = n_blk + jl;
-                    float v = 0.0f;
-                    if (j < N && k0 + kk < K) {
-                        const int b = j / T, t = j - b * T;
-                        int idx = t * d.hop + k0 + kk - d.pad;
-                        bool ok = true;
-                        if (idx < 0) { ok = d.reflect != 0; idx = -idx; }
-                        else if (idx >= L) { ok = d.reflect != 0; idx = 2 * (L - 1) - idx; }
-                        if (ok) v = src[(size_t)b * L + idx];
-                    }
-                    Bs[kk * kLds + jl] = v;
-                }
-            }
-        } else {
-            {   // A: spectrum, A(j, k) = spec[b][k][t]: for one k consecutive j are consecutive t
-                const int jl = tid & 127, kh = (tid >> 7) * 8, j = m_blk + jl;
-                const int b = j < M ? j / T : 0, t = j < M ? j - b * T : 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + kh + u;
-                    As[(kh + u) * kLds + jl] = (j < M && k < K) ? src[((size_t)b * d.F2 + k) * T + t] : 0.0f;
-                }
-            }
-            {   // B: inverse table rows k, columns n
-                const int nl = tid & 127, kh = (tid >> 7) * 8, n = n_blk + nl;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + kh + u;
-                    Bs[(kh + u) * kLds + nl] = (n < N && k < K) ? tab[(size_t)k * d.n_fft + n] : 0.0f;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 4 k-steps of 4: lane (g, j16) supplies A[row 16 i + j16][k + g] and B[k + g][col 16 j + j16]
-#pragma unroll
-        for (int ks = 0; ks < kTK; ks += 4) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[(ks + g) * kLds + wm + 16 * i + j16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[(ks + g) * kLds + wn + 16 * j + j16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x4(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
+// analysis B operand: B(k, j) = padded sample k of frame j = (b, t); consecutive k are consecutive samples
+struct FrameB {
+    static constexpr bool kAlongN = false;
+    const float* x;
+    StftDims d;
+    int L, T;
+    __device__ float operator()(int k, int j) const {
+        const int b = j / T, t = j - b * T;
+        int idx = t * d.hop + k - d.pad;
+        if (idx < 0) { if (!d.reflect) return 0.0f; idx = -idx; }
+        else if (idx >= L) { if (!d.reflect) return 0.0f; idx = 2 * (L - 1) - idx; }
+        return x[(size_t)b * L + idx];
     }
-    // ---- store: lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_blk + wm + 16 * i + 4 * g + r, n = n_blk + wn + 16 * j + j16;
-                if (m < M && n < N) {
-                    if (MODE == 0) {
-                        const int b = n / T, t = n - b * T;
-                        dst[((size_t)b * d.F2 + m) * T + t] = acc[i][j][r];
-                    } else {
-                        dst[(size_t)m * d.n_fft + n] = acc[i][j][r];
-                    }
-                }
-            }
-}
+};
+struct SpecStore {             // C(c, j) -> spec[b][c][t]
+    float* spec;
+    int F2, T;
+    __device__ void operator()(int c, int j, float v) const {
+        const int b = j / T, t = j - b * T;
+        spec[((size_t)b * F2 + c) * T + t] = v;
+    }
+};
+struct SpecA {                 // synthesis A operand: A(j, c) = spec[b][c][t]; consecutive j are consecutive t
+    static constexpr bool kAlongK = false;
+    const float* spec;
+    int F2, T;
+    __device__ float operator()(int j, int c) const {
+        const int b = j / T, t = j - b * T;
+        return spec[((size_t)b * F2 + c) * T + t];
+    }
+};
 
 // overlap-add as a gather (every output sample sums its <= ceil(n_fft/hop) contributing frames in a fixed order), trim,
 // divide by the matching sum of squared window samples (static_norm, STFT_Process.py:253-273,326-336)
@@ -293,8 +218,8 @@ ade_status ade_stft_analyze(ade_stft_handle p, const float* d_x, int batch, int 
     if (st != ADE_OK) return st;
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
-    const dim3 grid((unsigned)((batch * T + ade::kTN - 1) / ade::kTN), (unsigned)((p->d.F2 + ade::kTM - 1) / ade::kTM));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ade::k_stft_gemm<0>), grid, dim3(256), 0, s, (const float*)p->d_fwd, d_x, d_spec, p->d, batch, length, T);
+    ade::gemm::launch(s, ade::gemm::RowMajorA{p->d_fwd, p->d.n_fft}, ade::FrameB{d_x, p->d, length, T}, ade::SpecStore{d_spec, p->d.F2, T},
+                      p->d.F2, batch * T, p->d.n_fft);
     STFT_HIP(p, hipGetLastError());
     if (!hip_stream) STFT_HIP(p, hipStreamSynchronize(s));
     return ADE_OK;
@@ -314,9 +239,8 @@ ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch
         STFT_HIP(p, hipMalloc((void**)&p->d_frames, need * sizeof(float)));
         p->frames_cap = need;
     }
-    const dim3 grid((unsigned)((p->d.n_fft + ade::kTN - 1) / ade::kTN), (unsigned)((batch * frames + ade::kTM - 1) / ade::kTM));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ade::k_stft_gemm<1>), grid, dim3(256), 0, s, (const float*)p->d_inv, d_spec, p->d_frames, p->d, batch, 0,
-                       frames);
+    ade::gemm::launch(s, ade::SpecA{d_spec, p->d.F2, frames}, ade::gemm::RowMajorB{p->d_inv, p->d.n_fft},
+                      ade::gemm::BiasActStore<ade::gemm::kActNone>{p->d_frames, p->d.n_fft, nullptr, 0.0f}, batch * frames, p->d.n_fft, p->d.F2);
     int out_len = 0;
     (void)ade_stft_output_length(p, frames, &out_len);
     const long long total = (long long)batch * out_len;

@@ -41,3 +41,80 @@ def test_dfsmn_oracle_matches_reference(gold, tensors):
     assert not pcm[3].any()
     m = gold["speech0.mask"]
     assert float(m.std()) > 0.05 and float(m.min()) < 0.2 and float(m.max()) > 0.8      # a non-degenerate mask
+
+
+def _dfsmn_meta(length):
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    return build_audio_metadata(producer="tests", model_name="DFSMN", task="denoise", model_family="dfsmn", input_audio_length=length,
+                                in_sample_rate=48000, nfft=1920, window_length=1920, hop_length=960, window_type="hamming",
+                                center_pad=False, pad_mode="constant", feature_kind="kaldi_fbank_stft")
+
+
+def _blob_bytes():
+    with open(os.path.join(GOLD, "dfsmn_seed0.adew"), "rb") as f:
+        return f.read()
+
+
+@pytest.mark.hipsim
+@pytest.mark.skipif(not os.environ.get("ADE_SLOW_TESTS"), reason="~2 min under the host simulator (3972 x 1920 MFMA GEMM emulated); set ADE_SLOW_TESTS=1")
+def test_hipsim_dfsmn_tiny(tensors):
+    """The whole DFSMN launch sequence under the host simulator on a 3-frame input (MFMA emulated)."""
+    import time
+    from ade_testlib import hipsim_library
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    L = 1920 + 2 * 960
+    sess = InferenceSession(weights=_blob_bytes(), metadata=_dfsmn_meta(L), library=hipsim_library())
+    assert (sess.in_len, sess.out_len, sess.frames, sess.sample_rate) == (L, L, 3, 48000)
+    g = np.load(os.path.join(GOLD, "dfsmn_seed0_io.npz"))
+    x = g["speech0.pcm_in"][5000:5000 + L][None]
+    t0 = time.time()
+    pcm, f32 = sess.process(x, want_f32=True)
+    o = DfsmnOracle(tensors, L, exact_dft=True)
+    opcm, of32 = o.process(x)
+    assert np.abs(sess.tap("logmel", 120 * 3).reshape(120, 3) - o.taps["logmel"]).max() <= 2e-4
+    assert np.abs(sess.tap("mask", 961 * 3).reshape(961, 3) - o.taps["mask"]).max() <= 1e-4
+    assert np.abs(f32 - of32).max() <= 2e-5
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+    print("sim seconds", time.time() - t0)
+
+
+@pytest.mark.gpu
+def test_gpu_dfsmn_reference_golden(gold, tensors):
+    """HIP path through the C ABI vs the reference-generated fixture and vs the oracle with exact DFT tables."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    L = int(gold["input_audio_length"])
+    sess = InferenceSession(weights=_blob_bytes(), metadata=_dfsmn_meta(L))
+    assert (sess.in_len, sess.out_len, sess.frames, sess.sample_rate) == (L, L, 24, 48000)
+    names = ["speech0", "speech1", "randn", "zeros"]
+    x = np.stack([gold[f"{n}.pcm_in"] for n in names])
+    pcm, f32 = sess.process(x, want_f32=True)
+    for i, n in enumerate(names):
+        # vs the reference fixture: 1 LSB + the reference's own fp32-angle DFT-table error (amplified where sum(w^2) is
+        # small: no centre padding, hamming ends at 0.08) -> a few LSB at the chunk edges for loud inputs
+        d = np.abs(pcm[i].astype(np.int32) - gold[f"{n}.pcm_out"].astype(np.int32))
+        assert d[1920:-1920].max() <= 2 and d.max() <= 24, (n, int(d.max()))
+    assert not pcm[3].any()
+    o = DfsmnOracle(tensors, L, exact_dft=True)
+    opcm, of32 = o.process(x)
+    assert np.abs(sess.tap("logmel", 4 * 120 * 24).reshape(120, 4, 24)[:, 0] - o.taps["logmel"]).max() <= 2e-4
+    assert np.abs(sess.tap("mask", 4 * 961 * 24).reshape(961, 4, 24)[:, 0] - o.taps["mask"]).max() <= 1e-4
+    assert np.abs(f32 - of32).max() <= 2e-5
+    assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_dfsmn_batch_properties():
+    """The reference's default 2 s export (96000 samples, 99 frames) at batch 32: rows are independent calls."""
+    import torch
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    sess = InferenceSession(weights=_blob_bytes(), metadata=_dfsmn_meta(96000))
+    assert (sess.in_len, sess.out_len, sess.frames) == (96000, 96000, 99)
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((32, 96000)) * 1500).astype(np.int16)
+    pcm, _ = sess.process(x)
+    sub, _ = sess.process(x[5:9])
+    assert np.array_equal(sub, pcm[5:9])
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty((32, 96000), dtype=torch.int16, device="cuda")
+    sess.run_device(d_in, d_out)
+    assert np.array_equal(d_out.cpu().numpy(), pcm)
