@@ -76,19 +76,31 @@ def plan_slices(audio_len: int, in_len: int, out_len: int) -> Tuple[int, int, in
     return stride, 1, in_len
 
 
-def cut_slices(audio: np.ndarray, in_len: int, out_len: int) -> Tuple[np.ndarray, int]:
+def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "zeros", rng=None) -> Tuple[np.ndarray, int]:
+    """Slices exactly as the reference drivers cut them.  ``tail_pad``: ``"zeros"`` (GTCRN / ZipEnhancer,
+    Inference_GTCRN_ONNX.py:291-299) or ``"noise"`` -- Gaussian noise scaled to the RMS of the last ``pad`` samples (of
+    the whole file when it is shorter than one slice), the reference's policy for DFSMN / Mel-Band / MossFormer2 when
+    batch-fold is inactive (DFSMN/Inference_DFSMN_ONNX.py:292-305).  The reference draws that noise unseeded; pass a
+    ``numpy.random.Generator`` as ``rng`` for a reproducible run (it only affects the last, partial slice)."""
     stride, n, total = plan_slices(len(audio), in_len, out_len)
     padded = np.zeros(total, np.int16)
     padded[: len(audio)] = audio
+    pad = total - len(audio)
+    if tail_pad == "noise" and pad > 0 and len(audio) > 0:
+        ref = (audio[-pad:] if len(audio) > in_len else audio).astype(np.float32)
+        rng = rng or np.random.default_rng()
+        padded[len(audio):] = (np.sqrt(np.mean(ref * ref)) * rng.normal(0.0, 1.0, pad)).astype(np.int16)
+    elif tail_pad not in ("zeros", "noise"):
+        raise ValueError(f"tail_pad must be 'zeros' or 'noise', got {tail_pad!r}")
     idx = np.arange(n)[:, None] * stride + np.arange(in_len)[None, :]
     return padded[idx], stride
 
 
 def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = False, rank: int = 0, world: int = 1,
-            group=None) -> np.ndarray:
+            group=None, tail_pad: str = "zeros", rng=None) -> np.ndarray:
     """int16 mono waveform in -> int16 denoised waveform out (length preserved)."""
     audio_len = len(audio)
-    slices, _ = cut_slices(audio, session.in_len, session.out_len)
+    slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng)
     lo, hi = shard_bounds(len(slices), world, rank)
     mine = slices[lo:hi]
     if sequential:

@@ -118,3 +118,28 @@ def test_gpu_dfsmn_batch_properties():
     d_out = torch.empty((32, 96000), dtype=torch.int16, device="cuda")
     sess.run_device(d_in, d_out)
     assert np.array_equal(d_out.cpu().numpy(), pcm)
+
+
+@pytest.mark.gpu
+def test_gpu_dfsmn_file_driver(tensors, tmp_path):
+    """inference_dfsmn: model dir + manifest on disk, ragged 48 kHz file, seeded noise tail; vs the oracle per slice."""
+    import wave
+    from audio_denoiser_onnx_amd import inference_dfsmn
+    from audio_denoiser_onnx_amd.inference_gtcrn import cut_slices, read_wav_int16
+    from audio_denoiser_onnx_amd.metadata import write_metadata
+    L = 24000
+    model = tmp_path / "DFSMN.adew"
+    model.write_bytes(_blob_bytes())
+    write_metadata(model, _dfsmn_meta(L))
+    g = np.load(os.path.join(GOLD, "dfsmn_seed0_io.npz"))
+    audio = np.concatenate([g["speech0.pcm_in"], g["speech1.pcm_in"], g["randn.pcm_in"]])[:61000]    # 2.54 slices
+    noisy = tmp_path / "in.wav"
+    with wave.open(str(noisy), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(48000); w.writeframes(audio.astype("<i2").tobytes())
+    out_path = tmp_path / "out.wav"
+    assert inference_dfsmn.main([str(model), str(noisy), str(out_path), "--seed", "11"]) == 0
+    got = read_wav_int16(out_path, 48000)
+    assert got.shape == audio.shape
+    slices, _ = cut_slices(audio, L, L, "noise", np.random.default_rng(11))
+    ref, _ = DfsmnOracle(tensors, L, exact_dft=True).process(slices)
+    assert np.abs(got.astype(np.int32) - ref.reshape(-1)[:len(audio)].astype(np.int32)).max() <= 1

@@ -98,3 +98,21 @@ def test_wav_io_and_normalise(tmp_path):
     assert normalise_audio(pcm, False) is pcm
     n = normalise_audio(pcm, True, 4096.0)
     assert abs(np.sqrt(np.mean(n.astype(np.float64) ** 2)) - 4096.0) < 2.0
+
+
+def test_tail_padding_policies():
+    """Zeros for GTCRN / ZipEnhancer; RMS-scaled Gaussian noise for DFSMN-style drivers when fold is inactive
+    (DFSMN/Inference_DFSMN_ONNX.py:292-305) -- seeded here, unseeded in the reference."""
+    from audio_denoiser_onnx_amd.inference_gtcrn import cut_slices
+    a = (np.random.default_rng(0).standard_normal(2500) * 1000).astype(np.int16)
+    z, stride = cut_slices(a, 1000, 1000)
+    assert z.shape == (3, 1000) and stride == 1000 and not z[2, 500:].any() and np.array_equal(z.reshape(-1)[:2500], a)
+    n1, _ = cut_slices(a, 1000, 1000, "noise", np.random.default_rng(5))
+    n2, _ = cut_slices(a, 1000, 1000, "noise", np.random.default_rng(5))
+    assert np.array_equal(n1, n2) and np.array_equal(n1.reshape(-1)[:2500], a)
+    tail_rms = float(np.sqrt(np.mean(a[-500:].astype(np.float32) ** 2)))
+    assert 0.8 * tail_rms < float(n1[2, 500:].astype(np.float32).std()) < 1.2 * tail_rms
+    short, _ = cut_slices(a[:300], 1000, 1000, "noise", np.random.default_rng(1))      # shorter than one slice: RMS of the whole file
+    assert short.shape == (1, 1000) and short[0, 300:].any()
+    with pytest.raises(ValueError):
+        cut_slices(a, 1000, 1000, "mirror")
