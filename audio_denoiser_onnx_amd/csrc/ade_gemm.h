@@ -41,32 +41,58 @@ __global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int k0 = 0; k0 < K; k0 += kTK) {
+    // Software pipeline: the operand elements of slab k+1 are requested (into registers) before the 64 MFMAs of slab k
+    // run and are written to LDS after them, so the HBM / L2 latency of a slab hides under the matrix work of the
+    // previous one.  Which lane fetches which element depends on the operand's contiguous direction (see the header).
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
         if (AL::kAlongK) {          // thread = (row, half slab): 8 consecutive k of one row
             const int r = tid >> 1, kh = (tid & 1) * 8, m = m_blk + r;
-            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = v[u];
+            for (int u = 0; u < 8; ++u) ra[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
         } else {                    // thread = (row, half slab): consecutive lanes = consecutive rows for each k
             const int r = tid & 127, kh = (tid >> 7) * 8, m = m_blk + r;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+            for (int u = 0; u < 8; ++u) ra[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
         }
         if (BL::kAlongN) {          // thread = (column, half slab)
             const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) Bs[(kh + u) * kLds + c] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
+            for (int u = 0; u < 8; ++u) rb[u] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
         } else {                    // thread = (k, 16 column groups): consecutive lanes = consecutive k of one column
             const int kk = tid & 15, cg = tid >> 4;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int c = cg + 16 * u, n = n_blk + c;
-                Bs[kk * kLds + c] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
+                const int n = n_blk + cg + 16 * u;
+                rb[u] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
             }
         }
+    };
+    auto stash = [&]() {            // registers -> k-major LDS slabs (same lane maps as fetch)
+        if (AL::kAlongK) {
+            const int r = tid >> 1, kh = (tid & 1) * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = ra[u];
+        } else {
+            const int r = tid & 127, kh = (tid >> 7) * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = ra[u];
+        }
+        if (BL::kAlongN) {
+            const int c = tid & 127, kh = (tid >> 7) * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Bs[(kh + u) * kLds + c] = rb[u];
+        } else {
+            const int kk = tid & 15, cg = tid >> 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Bs[kk * kLds + cg + 16 * u] = rb[u];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+        stash();
         __syncthreads();
+        if (k0 + kTK < K) fetch(k0 + kTK);
 #pragma unroll
         for (int ks = 0; ks < kTK; ks += 4) {       // lane (g, j16) supplies A[row 16 i + j16][k + g] and B[k + g][col 16 j + j16]
             float a[4], b[4];

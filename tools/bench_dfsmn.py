@@ -2,7 +2,9 @@
 """DFSMN throughput on one MI355X (informational; BASELINE.json has no DFSMN configuration): batch x 2 s chunks @ 48 kHz,
 int16 PCM resident in HBM, steps enqueued back to back on one stream."""
 import os, sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.chdir(REPO)
 import numpy as np
 import torch
 from audio_denoiser_onnx_amd.metadata import build_audio_metadata
