@@ -105,15 +105,27 @@ void hamming_f32(int n, bool periodic, std::vector<float>& w) {   // the fp32 ev
 
 }  // namespace
 
-struct DfsmnEngine {
-    int device = 0, in_len = 0, T = 0, out_len = 0, depth = 0, lorder = 0;
+struct DfsmnEngine : SubEngine {
+    int device = 0, in_len_ = 0, T = 0, out_len_ = 0, depth = 0, lorder = 0;
     float* d_w = nullptr;      // one arena: tables + weights
     const float *k_an = nullptr, *k_inv = nullptr, *wsum = nullptr, *mel = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *lin2_w = nullptr,
                 *lin2_b = nullptr;
     std::vector<const float*> uf_lin_w, uf_lin_b, uf_proj_w, uf_conv_w;
     int capacity = 0;
     float* ws = nullptr;
-    float *an = nullptr, *feat = nullptr, *x = nullptr, *f1 = nullptr, *p1 = nullptr, *mask = nullptr, *frames = nullptr;
+    float *an = nullptr, *feat = nullptr, *x = nullptr, *f1 = nullptr, *p1 = nullptr, *mask = nullptr, *frames_buf = nullptr;
+
+    ~DfsmnEngine() override {
+        (void)hipSetDevice(device);
+        if (d_w) (void)hipFree(d_w);
+        if (ws) (void)hipFree(ws);
+    }
+    int frames() const override { return T; }
+    int in_len() const override { return in_len_; }
+    int out_len() const override { return out_len_; }
+    int reserve(int batch, std::string& err) override;
+    int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
+    int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
 };
 
 namespace {
@@ -125,7 +137,7 @@ int dfail(std::string& err, int st, const std::string& msg) { err = msg; return 
     } while (0)
 }  // namespace
 
-int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, DfsmnEngine** out, std::string& err) {
+int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (in_len < kFrame) return dfail(err, ADE_ERR_SHAPE_MISMATCH, "dfsmn: input_audio_length shorter than one 1920-sample frame");
     auto get = [&](const std::string& name, std::vector<int> dims, const float** p) -> bool {
@@ -155,9 +167,9 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
     }
     DfsmnEngine* d = new DfsmnEngine();
     d->device = device;
-    d->in_len = in_len;
+    d->in_len_ = in_len;
     d->T = (in_len - kFrame) / kHopD + 1;                       // STFT_SIGNAL_LENGTH (Export_DFSMN.py:66)
-    d->out_len = kNfftD + kHopD * (d->T - 1);                   // raw conv_transpose length, no centre trim
+    d->out_len_ = kNfftD + kHopD * (d->T - 1);                   // raw conv_transpose length, no centre trim
     d->depth = depth;
     d->lorder = lo;
 
@@ -200,7 +212,7 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
             arena[o_inv + (size_t)(kStBins + f) * kNfftD + n] = ((scale * -s) * (float)(1.0 / kNfftD)) * wsyn[n];
         }
     }
-    const size_t o_ws = push(nullptr, (size_t)d->out_len);
+    const size_t o_ws = push(nullptr, (size_t)d->out_len_);
     for (int t = 0; t < d->T; ++t)
         for (int n = 0; n < kNfftD; ++n) arena[o_ws + (size_t)t * kHopD + n] += wsyn[n] * wsyn[n];
     const size_t o_mel = push(mel, (size_t)kMel * kFbBins), o_l1w = push(l1w, (size_t)kHid * kMel), o_l1b = push(l1b, kHid),
@@ -212,7 +224,7 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
         o_h[4 * i + 2] = push(hw[4 * i + 2], (size_t)kHid * kHid);
         o_h[4 * i + 3] = push(hw[4 * i + 3], (size_t)kHid * lo);
     }
-    auto bail = [&](int st) { dfsmn_destroy(d); return st; };
+    auto bail = [&](int st) { delete d; return st; };
     if (hipSetDevice(device) != hipSuccess) return bail(dfail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
     if (hipMalloc((void**)&d->d_w, arena.size() * sizeof(float)) != hipSuccess) return bail(dfail(err, ADE_ERR_DEVICE, "hipMalloc of the DFSMN weights failed"));
     if (hipMemcpy(d->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
@@ -229,7 +241,8 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
     return ADE_OK;
 }
 
-int dfsmn_reserve(DfsmnEngine* d, int batch, std::string& err) {
+int DfsmnEngine::reserve(int batch, std::string& err) {
+    DfsmnEngine* d = this;
     if (batch <= d->capacity) return ADE_OK;
     DF_HIP(hipSetDevice(d->device));
     DF_HIP(hipDeviceSynchronize());
@@ -242,21 +255,22 @@ int dfsmn_reserve(DfsmnEngine* d, int batch, std::string& err) {
     size_t total = 0;
     for (size_t s : sizes) total += (s + 63) & ~(size_t)63;
     DF_HIP(hipMalloc((void**)&d->ws, total * sizeof(float)));
-    float** ptrs[7] = {&d->an, &d->feat, &d->x, &d->f1, &d->p1, &d->mask, &d->frames};
+    float** ptrs[7] = {&d->an, &d->feat, &d->x, &d->f1, &d->p1, &d->mask, &d->frames_buf};
     size_t off = 0;
     for (int i = 0; i < 7; ++i) { *ptrs[i] = d->ws + off; off += (sizes[i] + 63) & ~(size_t)63; }
     d->capacity = batch;
     return ADE_OK;
 }
 
-int dfsmn_run(DfsmnEngine* d, hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+    DfsmnEngine* d = this;
     if (batch == 0) return ADE_OK;
-    int st = dfsmn_reserve(d, batch, err);
+    int st = reserve(batch, err);
     if (st != ADE_OK) return st;
     using namespace gemm;
     const int N = batch * d->T;
     // fused analysis convolution: [fbank re | fbank im | stft re | stft im] x frames                       (Export_DFSMN.py:205-209)
-    launch(s, RowMajorA{d->k_an, kFrame}, PcmFrameB{d_in, d->in_len, d->T}, BiasActStore<kActNone>{d->an, N, nullptr, 0.0f}, kAnRows, N, kFrame);
+    launch(s, RowMajorA{d->k_an, kFrame}, PcmFrameB{d_in, d->in_len_, d->T}, BiasActStore<kActNone>{d->an, N, nullptr, 0.0f}, kAnRows, N, kFrame);
     // Kaldi log-mel: mel_banks x power, clamp(eps), log                                                  (:216-217)
     launch(s, RowMajorA{d->mel, kFbBins}, PowerB{d->an, N}, BiasActStore<kActLogFloor>{d->feat, N, nullptr, 1.1920928955078125e-07f}, kMel, N, kFbBins);
     // mask network                                                                                          (:224-230)
@@ -270,19 +284,17 @@ int dfsmn_run(DfsmnEngine* d, hipStream_t s, const int16_t* d_in, int batch, int
     }
     launch(s, RowMajorA{d->lin2_w, kHid}, RowMajorB{d->x, N}, BiasActStore<kActSigmoid>{d->mask, N, d->lin2_b, 0.0f}, kStBins, N, kHid);
     // masked spectrum -> ISTFT frames, then overlap-add + PCM tail                                        (:236-244)
-    launch(s, MaskedSpecA{d->an + (size_t)2 * kFbBins * N, d->mask, N}, RowMajorB{d->k_inv, kNfftD}, BiasActStore<kActNone>{d->frames, kNfftD, nullptr, 0.0f},
+    launch(s, MaskedSpecA{d->an + (size_t)2 * kFbBins * N, d->mask, N}, RowMajorB{d->k_inv, kNfftD}, BiasActStore<kActNone>{d->frames_buf, kNfftD, nullptr, 0.0f},
            N, kNfftD, 2 * kStBins);
-    const long long total = (long long)batch * d->out_len;
-    hipLaunchKernelGGL(k_dfsmn_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->frames, d->wsum, d_out, d_f32, d->T,
-                       d->out_len, total);
+    const long long total = (long long)batch * d->out_len_;
+    hipLaunchKernelGGL(k_dfsmn_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->frames_buf, d->wsum, d_out, d_f32, d->T,
+                       d->out_len_, total);
     DF_HIP(hipGetLastError());
     return ADE_OK;
 }
 
-int dfsmn_frames(const DfsmnEngine* d) { return d->T; }
-int dfsmn_out_len(const DfsmnEngine* d) { return d->out_len; }
-
-int dfsmn_tap(DfsmnEngine* d, hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+int DfsmnEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+    DfsmnEngine* d = this;
     const size_t N = (size_t)batch * d->T;
     const float* src = nullptr;
     size_t n = 0;
@@ -295,14 +307,6 @@ int dfsmn_tap(DfsmnEngine* d, hipStream_t s, const char* name, int batch, float*
     DF_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
     *written = n;
     return ADE_OK;
-}
-
-void dfsmn_destroy(DfsmnEngine* d) {
-    if (!d) return;
-    (void)hipSetDevice(d->device);
-    if (d->d_w) (void)hipFree(d->d_w);
-    if (d->ws) (void)hipFree(d->ws);
-    delete d;
 }
 
 }  // namespace ade

@@ -49,7 +49,8 @@ struct ade_engine {
     std::vector<float> blob_storage;
     std::map<std::string, Tensor> tensors;
 
-    ade::DfsmnEngine* dfsmn = nullptr;    // model_family "dfsmn": the sub-engine of csrc/ade_dfsmn.hip (everything below is GTCRN's)
+    ade::SubEngine* sub = nullptr;        // model_family "dfsmn" / "mel_band_roformer": a sub-engine (everything below is GTCRN's)
+    int channels = 1;                     // PCM rows per batch item; in_len / out_len below count one batch item (channels * samples)
 
     hipStream_t stream = nullptr;
     float* d_weights = nullptr;
@@ -542,9 +543,9 @@ ade_status reserve(ade_engine* e, int batch) {
     if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     free_workspace(e);
     const size_t B = (size_t)batch, T = (size_t)e->T;
-    if (e->dfsmn) {   // the sub-engine owns its activations; only the I/O staging of ade_process lives here
+    if (e->sub) {   // the sub-engine owns its activations; only the I/O staging of ade_process lives here
         std::string derr;
-        const int rc = ade::dfsmn_reserve(e->dfsmn, batch, derr);
+        const int rc = e->sub->reserve(batch, derr);
         if (rc != ADE_OK) return fail(e, (ade_status)rc, derr);
         HIP_TRY(e, hipMalloc((void**)&e->d_pcm_in, B * e->in_len * sizeof(int16_t)));
         HIP_TRY(e, hipMalloc((void**)&e->d_pcm_out, B * e->out_len * sizeof(int16_t)));
@@ -702,9 +703,9 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
 ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32) {
     if (B == 0) return ADE_OK;
     e->last_batch = B;
-    if (e->dfsmn) {
+    if (e->sub) {
         std::string derr;
-        const int rc = ade::dfsmn_run(e->dfsmn, s, d_in, B, d_out, d_f32, derr);
+        const int rc = e->sub->run(s, d_in, B, d_out, d_f32, derr);
         return rc == ADE_OK ? ADE_OK : fail(e, (ade_status)rc, derr);
     }
     if (e->profile) {
@@ -784,19 +785,22 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (it == e->meta.end() || it->second.empty())
             return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
     }
-    if (e->meta["model_family"] == "dfsmn") {   // DFSMN/Export_DFSMN.py: 48 kHz, int16 I/O, static shapes, no centre pad
+    const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer";
+    if (fam_dfsmn || fam_melband) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
+        const std::string fam = e->meta["model_family"];
+        const long rate = fam_dfsmn ? 48000 : 44100;
         bool dyn_d = false, fold_d = false;
         if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
         if (dyn_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && (!parse_bool(e->meta["use_batch_fold"], &fold_d) || fold_d))
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn: use_batch_fold is not implemented"));
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + ": use_batch_fold is not implemented (pass the windows as batch rows)"));
         long sri = 0, sro = 0, srm = 0, Ld = 0;
         if (!parse_int(e->meta["in_sample_rate"], &sri) || !parse_int(e->meta["out_sample_rate"], &sro) ||
             !parse_int(e->meta["model_sample_rate"], &srm) || !parse_int(e->meta["input_audio_length"], &Ld))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
-        if (srm != 48000 || sri != srm || sro != srm)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn runs at 48 kHz in, model and out (resampling path not implemented)"));
+        if (srm != rate || sri != srm || sro != srm)
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (resampling path not implemented)"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
             return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
         if (Ld < 1920 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
@@ -812,12 +816,19 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (hipSetDevice(device) != hipSuccess) return bail(fail(e, ADE_ERR_DEVICE, "hipSetDevice failed"));
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(e, ADE_ERR_DEVICE, "hipStreamCreate failed"));
         std::string derr;
-        const int rc = ade::dfsmn_create(e->tensors, (int)Ld, device, &e->dfsmn, derr);
+        bool exact_dft = false;
+        if (e->meta.count("ade_dft_tables")) {
+            if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
+            else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
+        }
+        const int rc = fam_dfsmn ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
+                                 : ade::melband_create(e->tensors, (int)Ld, exact_dft, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
-        e->in_len = (int)Ld;
-        e->T = ade::dfsmn_frames(e->dfsmn);
-        e->out_len = ade::dfsmn_out_len(e->dfsmn);
-        e->sample_rate = 48000;
+        e->channels = e->sub->channels();
+        e->in_len = e->sub->in_len() * e->channels;
+        e->T = e->sub->frames();
+        e->out_len = e->sub->out_len() * e->channels;
+        e->sample_rate = (int)rate;
         e->blob_storage.clear();
         e->blob_storage.shrink_to_fit();
         e->tensors.clear();
@@ -825,7 +836,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return ADE_OK;
     }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
@@ -911,11 +922,11 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
 ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
     if (!h || !d) return ADE_ERR_BAD_VALUE;
     d->abi_version = ADE_ABI_VERSION;
-    d->in_channels = 1;
-    d->out_channels = 1;
+    d->in_channels = h->channels;
+    d->out_channels = h->channels;
     d->n_outputs = 1;
-    d->in_len = h->in_len * h->n_win;       // what one call sees (the fold is internal)
-    d->out_len = h->out_len * h->n_win;
+    d->in_len = h->in_len / h->channels * h->n_win;       // per channel; what one call sees (the fold is internal)
+    d->out_len = h->out_len / h->channels * h->n_win;
     d->in_sample_rate = d->out_sample_rate = d->model_sample_rate = h->sample_rate;
     d->frames = h->T;
     d->max_batch = h->capacity / h->n_win;
@@ -979,10 +990,10 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
 
 ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t count, size_t* written) {
     if (!h || !name || !out || !written) return ADE_ERR_BAD_VALUE;
-    if (h->dfsmn) {
+    if (h->sub) {
         std::string derr;
         HIP_TRY(h, hipSetDevice(h->device));
-        const int rc = ade::dfsmn_tap(h->dfsmn, h->stream, name, h->last_batch, out, count, written, derr);
+        const int rc = h->sub->tap(h->stream, name, h->last_batch, out, count, written, derr);
         return rc == ADE_OK ? ADE_OK : fail(h, (ade_status)rc, derr);
     }
     const size_t nfr = (size_t)h->last_batch * h->T;
@@ -1070,7 +1081,7 @@ void ade_destroy(ade_handle h) {
         hipStreamSynchronize(h->stream);
     }
     free_workspace(h);
-    if (h->dfsmn) ade::dfsmn_destroy(h->dfsmn);
+    delete h->sub;
     for (auto& ev : h->events) {
         hipEventDestroy(ev.first);
         hipEventDestroy(ev.second);
@@ -1083,7 +1094,7 @@ void ade_destroy(ade_handle h) {
 }
 
 ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream) {
-    if (h && h->dfsmn) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stft_forward: this handle is a DFSMN model (use ade_stft_create for a generic STFT)");
+    if (h && h->sub) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stft_forward: GTCRN handles only (use ade_stft_create for a generic STFT)");
     if (!h || batch < 0 || (batch > 0 && (!d_x || !d_spec))) return ADE_ERR_BAD_VALUE;
     if (length < kNfft / 2 + 2) return fail(h, ADE_ERR_SHAPE_MISMATCH, "ade_stft_forward: length too short for reflect padding");
     if (batch == 0) return ADE_OK;
@@ -1096,7 +1107,7 @@ ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int lengt
 }
 
 ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
-    if (h && h->dfsmn) return fail(h, ADE_ERR_UNSUPPORTED, "ade_istft_forward: this handle is a DFSMN model (use ade_stft_create for a generic STFT)");
+    if (h && h->sub) return fail(h, ADE_ERR_UNSUPPORTED, "ade_istft_forward: GTCRN handles only (use ade_stft_create for a generic STFT)");
     if (!h || batch < 0 || frames < 2 || (batch > 0 && (!d_spec || !d_y))) return ADE_ERR_BAD_VALUE;
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));

@@ -27,12 +27,11 @@ using namespace dev;
 constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kLds = 144;
 
+// one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kTK x kLds LDS slabs
 template <class AL, class BL, class ST>
-__global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
-    __shared__ float As[kTK * kLds];
-    __shared__ float Bs[kTK * kLds];
+__device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const ST& store, int M, int N, int K, int m_blk, int n_blk,
+                                          float* As, float* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m_blk = blockIdx.y * kTM, n_blk = blockIdx.x * kTN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int j16 = lane & 15, g = lane >> 4;
     v4f acc[4][4];
@@ -120,9 +119,35 @@ __global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int
 }
 
 template <class AL, class BL, class ST>
+__global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
+    __shared__ float As[kTK * kLds];
+    __shared__ float Bs[kTK * kLds];
+    gemm_tile(a_of, b_of, store, M, N, K, (int)blockIdx.y * kTM, (int)blockIdx.x * kTN, As, Bs);
+}
+
+template <class AL, class BL, class ST>
 inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+}
+
+// Batched form: blockIdx.z selects a problem.  `prob(z)` (evaluated once per workgroup, so its table reads are scalar loads)
+// returns a struct with members a, b, st (functors as above) and M, N, K; problems may differ in every one of them -- tiles
+// outside a problem's own M x N exit at once, the grid is sized for the largest.
+template <class P>
+__global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
+    __shared__ float As[kTK * kLds];
+    __shared__ float Bs[kTK * kLds];
+    const auto q = prob((int)blockIdx.z);
+    const int m_blk = (int)blockIdx.y * kTM, n_blk = (int)blockIdx.x * kTN;
+    if (m_blk >= q.M || n_blk >= q.N) return;
+    gemm_tile(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
+}
+
+template <class P>
+inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N) {
+    const dim3 grid((unsigned)((max_N + kTN - 1) / kTN), (unsigned)((max_M + kTM - 1) / kTM), (unsigned)batch);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P>), grid, dim3(256), 0, s, prob);
 }
 
 // ---- common functors ------------------------------------------------------------------------------------------
@@ -131,6 +156,12 @@ struct RowMajorA {      // A(m, k) = p[m * ld + k]
     const float* p;
     int ld;
     __device__ float operator()(int m, int k) const { return p[(size_t)m * ld + k]; }
+};
+struct WeightNK {       // B(k, n) = p[n * ld + k]: a torch Linear weight (out_features, in_features) used as x @ W^T
+    static constexpr bool kAlongN = false;
+    const float* p;
+    int ld;
+    __device__ float operator()(int k, int n) const { return p[(size_t)n * ld + k]; }
 };
 struct RowMajorB {      // B(k, n) = p[k * ld + n]
     static constexpr bool kAlongN = true;

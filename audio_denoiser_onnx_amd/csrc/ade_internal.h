@@ -140,15 +140,22 @@ struct Tensor {
     size_t count = 0;
 };
 
-// ---- model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip.  Built by ade_create from the same
-//      manifest + blob format; every GEMM-shaped step runs on the matrix cores (csrc/ade_gemm.h).
-struct DfsmnEngine;
-int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, DfsmnEngine** out, std::string& err);   // ade_status
-int dfsmn_reserve(DfsmnEngine* d, int batch, std::string& err);
-int dfsmn_run(DfsmnEngine* d, hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err);
-int dfsmn_frames(const DfsmnEngine* d);
-int dfsmn_out_len(const DfsmnEngine* d);
-int dfsmn_tap(DfsmnEngine* d, hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err);
-void dfsmn_destroy(DfsmnEngine* d);
+// ---- model families other than GTCRN are sub-engines behind one interface; ade_create builds them from the same manifest +
+//      blob format and ade_process / ade_run_device / ade_debug_tap forward to them.  Every GEMM-shaped step of these models
+//      runs on the matrix cores (csrc/ade_gemm.h).  PCM rows are [batch][channels()][in_len()] int16.
+struct SubEngine {
+    virtual ~SubEngine() {}
+    virtual int frames() const = 0;
+    virtual int in_len() const = 0;      // samples per channel row
+    virtual int out_len() const = 0;
+    virtual int channels() const { return 1; }
+    virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status
+    virtual int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) = 0;
+    virtual int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) = 0;
+};
+// model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip
+int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err);
+// model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
+int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, bool exact_dft, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

@@ -1,0 +1,623 @@
+// ade_melband.hip — Mel-Band-Roformer (44.1 kHz stereo source separation / denoising) on the MI355X: SURVEY.md section 8 row a17.
+//
+// Reference: MelBandRoformer.forward / _core over the FUSED buffers its constructor registers
+// (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:540-680; buffers :330-538):
+//   int16 (B, 2, L) -> * 2^-15 -> STFT(2048, hop 441, periodic hann, reflect) -> channel-interleaved bins (f*2+ch) ->
+//   gather the 60 overlapping mel bands -> per band L2-normalise + Linear(d_i, 384) -> depth x [time transformer over the
+//   frames of each band, frequency transformer over the bands of each frame] -> per band tanh MLP 384-1536-1536-2 d_i + GLU
+//   -> scatter-add back to bins (the averaging is folded into the GLU value rows) -> complex mask x spectrum -> ISTFT
+//   -> * 32767, clamp, truncate -> int16.
+//   transformer(x) = { x += W_o [softmax(rot(q) rot(k)^T) v * sigmoid(gates)];  x += W_2 gelu(W_1 n(x) + b_1) + b_2;  n(x) * g }
+//   with n(x) = x / max(|x|_2, 1e-12) and (q | k | v | gates) = W_in n(x) + b_in   (q pre-scaled by dim_head^-1/2).
+// Everything but the attention core and three row-wise kernels is a matrix product, so the model runs on the generic
+// matrix-core GEMM of csrc/ade_gemm.h (exact fp32, v_mfma_f32_16x16x4_f32) with functor operands and stores:
+//   * the token matrix X is (row, 384) row-major with row = (band * B + b) * T + t.  BOTH attention axes read it in place:
+//     a time sequence is T consecutive rows, a frequency sequence is 60 rows a stride of B*T apart -- the reference's two
+//     permutes per layer pair (:611-614) never materialise.
+//   * every n(x) feeding a Linear is folded into that GEMM's store (v * inv_norm[row] + bias): X is read once by the GEMM
+//     and once by a one-wave-per-row norm kernel, never rewritten.
+//   * residual adds, biases, GELU, tanh are GEMM stores; the band gather is the A-operand loader of the band-split GEMM and
+//     the complex mask the A-operand of the synthesis GEMM.
+//   * the per-band problems (band split, mask estimator; K or N differ per band) run as ONE batched launch each
+//     (blockIdx.z = band, gemm::launch_batched).
+// DFT tables: by default the REFERENCE's (cos / sin of fp32 angles up to 2 pi * 1024, i.e. up to ~1e-4 off).  Unlike
+// the other models this one is sensitive to them: each band is L2-normalised before its Linear (:576), so in a band that is
+// nearly silent the leakage those table errors cause IS the normalised input.  Matching the reference there means matching its
+// tables; manifest key ade_dft_tables = "exact" selects exactly reduced angles instead (closer to torch.stft, which the
+// checkpoints were trained with).
+#include "ade_gemm.h"
+#include "ade_internal.h"
+#include "../../include/ade.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ade {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kNfftM = 2048, kHopM = 441, kBinsM = kNfftM / 2 + 1;   // Export_MelBandRoformer.py:42-45
+constexpr int kChan = 2, kFc = kBinsM * kChan;                        // channel-interleaved bins
+constexpr int kDh = 64;                                               // dim_head
+constexpr int kMaxSeq = 256;                                          // attention keeps K and V of one (sequence, head) in LDS
+
+// ---- operand / store functors ----------------------------------------------------------------------------------------
+struct StereoFrameB {          // B(k, j) = reflect-padded sample k of frame j = (clip-channel row r, t), * 2^-15 (:326-327, :649)
+    static constexpr bool kAlongN = false;
+    const int16_t* pcm;
+    int L, T;
+    __device__ float operator()(int k, int j) const {
+        const int r = j / T, t = j - r * T;
+        int idx = t * kHopM + k - kNfftM / 2;
+        if (idx < 0) idx = -idx;
+        else if (idx >= L) idx = 2 * (L - 1) - idx;
+        return (float)pcm[(size_t)r * L + idx] * (1.0f / 32768.0f);
+    }
+};
+struct BinStore {              // C(c*1025 + f, (b, ch, t)) -> S[(f*2 + ch)*2 + c][b*T + t]   (:596)
+    float* S;
+    int T, BT;
+    __device__ void operator()(int m, int n, float v) const {
+        const int c = m >= kBinsM ? 1 : 0, f = m - c * kBinsM;
+        const int r = n / T, t = n - r * T, b = r >> 1, ch = r & 1;
+        S[(size_t)((f * 2 + ch) * 2 + c) * BT + b * T + t] = v;
+    }
+};
+struct BandGatherA {           // A(bt, k) = S[gcol[off + k]][bt]: column k of band's slice of the gathered (t, 2S) matrix (:597-598)
+    static constexpr bool kAlongK = false;
+    const float* S;
+    const int* gcol;           // (fi[col >> 1] * 2 + (col & 1)) per gathered column
+    int BT;
+    __device__ float operator()(int m, int k) const { return S[(size_t)gcol[k] * BT + m]; }
+};
+struct ScaleBiasStore {        // out[(row0 + m) * ld + n] = v * scale[m] + bias[n]
+    float* out;
+    const float* scale;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = v * scale[m] + bias[n]; }
+};
+struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
+    float* out;
+    const float* scale;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const {
+        const float x = v * scale[m] + bias[n];
+        out[(size_t)m * ld + n] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    }
+};
+struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)
+    float* x;
+    const float* bias;         // may be null
+    int ld;
+    __device__ void operator()(int m, int n, float v) const {
+        float* p = x + (size_t)m * ld + n;
+        *p = *p + (bias ? v + bias[n] : v);
+    }
+};
+struct BiasTanhStore {         // tanh(v + bias[n])   (:581-582)
+    float* out;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = tanhf(v + bias[n]); }
+};
+struct BiasTransposedStore {   // YT[(col0 + n) * BT + m] = v + bias[n]: the raw last Linear of the mask estimator, column-major
+    float* yt;
+    const float* bias;
+    int BT;
+    __device__ void operator()(int m, int n, float v) const { yt[(size_t)n * BT + m] = v + bias[n]; }
+};
+struct PlanarSpecA {           // A(j, k) = MS[k][j]: masked spectrum, k = c*1025 + f, j = (b, ch, t)
+    static constexpr bool kAlongK = false;
+    const float* ms;
+    int J;
+    __device__ float operator()(int j, int k) const { return ms[(size_t)k * J + j]; }
+};
+
+struct BandTable {             // per band: first gathered column, width d_i, weight offsets into the arena (floats)
+    const int* off;            // [nb + 1] prefix sums of dim_inputs
+    const long long* bs_w;     // [nb]
+    const long long* bs_b;
+    const long long* w3;
+    const long long* b3;
+};
+template <class A, class B, class S>
+struct Prob { A a; B b; S st; int M, N, K; };
+
+struct BandSplitProb {         // z = band: X[band rows] = (gathered slice) x bs_w_z^T * inv_norm + bs_b_z      (:574-577)
+    const float* S;
+    const int* gcol;
+    const float* arena;
+    BandTable bt;
+    const float* invn;         // [nb][BT]
+    float* X;
+    int BT, dim;
+    __device__ Prob<BandGatherA, gemm::WeightNK, ScaleBiasStore> operator()(int z) const {
+        const int off = bt.off[z], d = bt.off[z + 1] - off;
+        return {BandGatherA{S, gcol + off, BT}, gemm::WeightNK{arena + bt.bs_w[z], d},
+                ScaleBiasStore{X + (size_t)z * BT * dim, invn + (size_t)z * BT, arena + bt.bs_b[z], dim}, BT, dim, d};
+    }
+};
+struct MeHiddenProb {          // z = band: out_z = tanh(in_z x Wt_z + b_z), Wt (K, N) row-major (:581-582)
+    const float* in;
+    const float* wt;
+    const float* bias;
+    float* out;
+    int BT, K, N;
+    __device__ Prob<gemm::RowMajorA, gemm::RowMajorB, BiasTanhStore> operator()(int z) const {
+        return {gemm::RowMajorA{in + (size_t)z * BT * K, K}, gemm::RowMajorB{wt + (size_t)z * K * N, N},
+                BiasTanhStore{out + (size_t)z * BT * N, bias + (size_t)z * N, N}, BT, N, K};
+    }
+};
+struct MeOutProb {             // z = band: YT[2 off_z ..][bt] = h_z x me_w3_z^T + me_b3_z     (:583)
+    const float* in;
+    const float* arena;
+    BandTable bt;
+    float* yt;
+    int BT, K;
+    __device__ Prob<gemm::RowMajorA, gemm::WeightNK, BiasTransposedStore> operator()(int z) const {
+        const int off = bt.off[z], d = bt.off[z + 1] - off;
+        return {gemm::RowMajorA{in + (size_t)z * BT * K, K}, gemm::WeightNK{arena + bt.w3[z], K},
+                BiasTransposedStore{yt + (size_t)2 * off * BT, arena + bt.b3[z], BT}, BT, 2 * d, K};
+    }
+};
+
+// ---- row-wise kernels (one wavefront per row) ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inv[row] = 1 / max(|x_row|_2, 1e-12)   (:533-538)
+__global__ __launch_bounds__(256) void k_row_invnorm(const float* __restrict__ x, float* __restrict__ inv, int rows, int dim) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int k = lane; k < dim; k += 64) { const float v = x[(size_t)row * dim + k]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// x_row = x_row / max(|x_row|, eps) * g (:571), and inv[row] = 1 / max(|new x_row|, eps) for the next consumer
+__global__ __launch_bounds__(256) void k_row_normalize_gain(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ inv, int rows,
+                                                            int dim) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int k = lane; k < dim; k += 64) { const float v = x[(size_t)row * dim + k]; s += v * v; }
+    const float r = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    float s2 = 0.0f;
+    for (int k = lane; k < dim; k += 64) {
+        const float v = x[(size_t)row * dim + k] * r * g[k];
+        x[(size_t)row * dim + k] = v;
+        s2 += v * v;
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(s2), 1e-12f);
+}
+
+// band-input norms: inv[band][bt] = 1 / max(|gathered slice|, eps); thread = bt (coalesced over bt), loop over the band's columns
+__global__ __launch_bounds__(256) void k_band_invnorm(const float* __restrict__ S, const int* __restrict__ gcol, const int* __restrict__ off,
+                                                      float* __restrict__ inv, int BT) {
+    const int band = blockIdx.y, bt = (int)blockIdx.x * 256 + threadIdx.x;
+    if (bt >= BT) return;
+    const int lo = off[band], hi = off[band + 1];
+    float s = 0.0f;
+    for (int c = lo; c < hi; ++c) { const float v = S[(size_t)gcol[c] * BT + bt]; s += v * v; }
+    inv[(size_t)band * BT + bt] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// ---- attention core (:546-561): one workgroup per (sequence, head); K and V (rotary applied to K) live in LDS, one query per thread.
+// row(seq, p) = seq * seq_stride + p * pos_stride.  Two passes over the keys (max, then exp / accumulate) = the reference's softmax.
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, const float* __restrict__ rcos,
+                                                   const float* __restrict__ rsin, int n, long long seq_stride, long long pos_stride, int ldq, int di,
+                                                   int heads) {
+    extern __shared__ float lds[];
+    float* Ks = lds;
+    float* Vs = lds + (size_t)n * kDh;
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+    const long long row0 = (long long)seq * seq_stride;
+    for (int i = tid; i < n * kDh; i += 256) {
+        const int p = i >> 6, d = i & 63;
+        const float* src = qkvg + (size_t)(row0 + p * pos_stride) * ldq + head * kDh;
+        const float kv = src[di + d], kp = src[di + (d ^ 1)];
+        Ks[i] = kv * rcos[p * kDh + d] + kp * rsin[p * kDh + d];        // rotate_half = pair swap, sign folded into rsin (:438-453)
+        Vs[i] = src[2 * di + d];
+    }
+    __syncthreads();
+    if (tid >= n) return;
+    const size_t row = (size_t)(row0 + tid * pos_stride);
+    float q[kDh];
+    {
+        const float* src = qkvg + row * ldq + head * kDh;
+#pragma unroll
+        for (int d = 0; d < kDh; d += 2) {
+            const float a = src[d], b = src[d + 1];
+            q[d] = a * rcos[tid * kDh + d] + b * rsin[tid * kDh + d];
+            q[d + 1] = b * rcos[tid * kDh + d + 1] + a * rsin[tid * kDh + d + 1];
+        }
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * kDh);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < kDh / 4; ++d) {
+            const float4 k4 = kr[d];
+            s0 = fmaf(q[4 * d], k4.x, s0); s1 = fmaf(q[4 * d + 1], k4.y, s1); s2 = fmaf(q[4 * d + 2], k4.z, s2); s3 = fmaf(q[4 * d + 3], k4.w, s3);
+        }
+        mx = fmaxf(mx, (s0 + s1) + (s2 + s3));
+    }
+    float acc[kDh];
+#pragma unroll
+    for (int d = 0; d < kDh; ++d) acc[d] = 0.0f;
+    float l = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * kDh);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < kDh / 4; ++d) {
+            const float4 k4 = kr[d];
+            s0 = fmaf(q[4 * d], k4.x, s0); s1 = fmaf(q[4 * d + 1], k4.y, s1); s2 = fmaf(q[4 * d + 2], k4.z, s2); s3 = fmaf(q[4 * d + 3], k4.w, s3);
+        }
+        const float e = expf(((s0 + s1) + (s2 + s3)) - mx);
+        l += e;
+        const float4* vr = reinterpret_cast<const float4*>(Vs + j * kDh);
+#pragma unroll
+        for (int d = 0; d < kDh / 4; ++d) {
+            const float4 v4 = vr[d];
+            acc[4 * d] = fmaf(e, v4.x, acc[4 * d]); acc[4 * d + 1] = fmaf(e, v4.y, acc[4 * d + 1]);
+            acc[4 * d + 2] = fmaf(e, v4.z, acc[4 * d + 2]); acc[4 * d + 3] = fmaf(e, v4.w, acc[4 * d + 3]);
+        }
+    }
+    const float gate = 1.0f / (1.0f + expf(-qkvg[row * ldq + 3 * di + head]));      // sigmoid(gates) (:559)
+    const float sc = gate / l;
+    float4* dst = reinterpret_cast<float4*>(ao + row * di + head * kDh);
+#pragma unroll
+    for (int d = 0; d < kDh / 4; ++d) dst[d] = make_float4(acc[4 * d] * sc, acc[4 * d + 1] * sc, acc[4 * d + 2] * sc, acc[4 * d + 3] * sc);
+}
+
+// GLU + scatter-add + complex mask (:583, :616-624).  thread = (bt, fc); the bands that own bin fc are listed in CSR order (ascending
+// gathered index = the reference's scatter order).  Writes the masked spectrum planar for the synthesis GEMM: MS[c*1025 + f][(b, ch, t)].
+__global__ __launch_bounds__(256) void k_mask_apply(const float* __restrict__ S, const float* __restrict__ yt, const int* __restrict__ csr_start,
+                                                    const int* __restrict__ csr_col, const int* __restrict__ csr_d, float* __restrict__ ms,
+                                                    float* __restrict__ mask_tap, int B, int T) {
+    const int BT = B * T, bt = (int)blockIdx.x * 256 + threadIdx.x, fc = blockIdx.y;
+    if (bt >= BT) return;
+    float mr = 0.0f, mi = 0.0f;
+    for (int e = csr_start[fc]; e < csr_start[fc + 1]; ++e) {
+        const int col = csr_col[e], d = csr_d[e];
+        const float ar = yt[(size_t)col * BT + bt], gr = yt[(size_t)(col + d) * BT + bt];
+        const float ai = yt[(size_t)(col + 1) * BT + bt], gi = yt[(size_t)(col + 1 + d) * BT + bt];
+        mr += ar * (1.0f / (1.0f + expf(-gr)));
+        mi += ai * (1.0f / (1.0f + expf(-gi)));
+    }
+    const float re = S[(size_t)(fc * 2) * BT + bt], im = S[(size_t)(fc * 2 + 1) * BT + bt];
+    const int f = fc >> 1, ch = fc & 1, b = bt / T, t = bt - b * T;
+    const size_t J = (size_t)BT * kChan, j = (size_t)(b * kChan + ch) * T + t;
+    ms[(size_t)f * J + j] = re * mr - im * mi;
+    ms[(size_t)(kBinsM + f) * J + j] = re * mi + im * mr;
+    if (mask_tap) { mask_tap[(size_t)(fc * 2) * BT + bt] = mr; mask_tap[(size_t)(fc * 2 + 1) * BT + bt] = mi; }
+}
+
+// overlap-add gather, / static COLA sum, then the PCM tail: * 32767, clamp, truncate (:667, :676)
+__global__ __launch_bounds__(256) void k_melband_ola_pcm(const float* __restrict__ frames, const float* __restrict__ wsum, int16_t* __restrict__ pcm,
+                                                         float* __restrict__ f32, int T, int L, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / L), m = (int)(i - (long long)r * L) + kNfftM / 2;
+    int t_hi = m / kHopM;
+    if (t_hi > T - 1) t_hi = T - 1;
+    const int t_lo = m - kNfftM + 1 <= 0 ? 0 : (m - kNfftM + kHopM) / kHopM;
+    float s = 0.0f;
+    for (int t = t_lo; t <= t_hi; ++t) s += frames[((size_t)r * T + t) * kNfftM + (m - t * kHopM)];
+    const float y = s / wsum[m - kNfftM / 2];
+    if (f32) f32[i] = y;
+    if (pcm) pcm[i] = (short)(int)fminf(fmaxf(y * 32767.0f, -32768.0f), 32767.0f);
+}
+
+int mfail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
+#define MB_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return mfail(err, ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct TfW { const float *in_w, *in_b, *out_w, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *out_g; };
+
+}  // namespace
+
+struct MelbandEngine : SubEngine {
+    int device = 0, L = 0, T = 0, depth = 0, nb = 0, dim = 0, di = 0, heads = 0, ffd = 0, med = 0, S2 = 0 /* gathered columns */, max_d = 0 /* widest band */;
+    float* d_w = nullptr;          // arena: DFT tables, rotary tables, COLA sum, every fused buffer
+    int* d_i = nullptr;            // arena of int tables
+    long long* d_ll = nullptr;     // per-band weight offsets
+    const float *k_fwd = nullptr, *k_inv = nullptr, *wsum = nullptr, *tcos = nullptr, *tsin = nullptr, *fcos = nullptr, *fsin = nullptr;
+    const float *me_w1t = nullptr, *me_b1 = nullptr, *me_w2t = nullptr, *me_b2 = nullptr;
+    std::vector<TfW> time_tf, freq_tf;
+    const int *gcol = nullptr, *off = nullptr, *csr_start = nullptr, *csr_col = nullptr, *csr_d = nullptr;
+    BandTable bt{};
+    int capacity = 0;
+    float* ws = nullptr;
+    float *Sp = nullptr, *X = nullptr, *invn = nullptr, *bufA = nullptr, *bufB = nullptr, *AO = nullptr, *YT = nullptr, *MS = nullptr,
+          *frames_buf = nullptr, *mask_tap = nullptr;
+
+    ~MelbandEngine() override {
+        (void)hipSetDevice(device);
+        if (d_w) (void)hipFree(d_w);
+        if (d_i) (void)hipFree(d_i);
+        if (d_ll) (void)hipFree(d_ll);
+        if (ws) (void)hipFree(ws);
+    }
+    int frames() const override { return T; }
+    int in_len() const override { return L; }
+    int out_len() const override { return L; }
+    int channels() const override { return kChan; }
+    int reserve(int batch, std::string& err) override;
+    int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
+    int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
+    void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
+};
+
+int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, bool exact_dft, int device, SubEngine** out, std::string& err) {
+    *out = nullptr;
+    if (in_len < kNfftM || in_len % kHopM != 0)
+        return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: input_audio_length must be a multiple of the 441-sample hop and at least 2048");
+    const int T = in_len / kHopM + 1;
+    auto find = [&](const std::string& name) -> const Tensor* {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) { err = "weights: tensor missing: " + name; return nullptr; }
+        return &it->second;
+    };
+    auto shaped = [&](const std::string& name, std::vector<int> dims) -> const Tensor* {
+        const Tensor* t = find(name);
+        if (t && t->dims != dims) { err = "weights: tensor has the wrong shape: " + name; return nullptr; }
+        return t;
+    };
+    auto status = [&]() { return err.find("missing") != std::string::npos ? ADE_ERR_MISSING_KEY : ADE_ERR_SHAPE_MISMATCH; };
+    const Tensor *t_fi = find("freq_indices"), *t_di = find("dim_inputs");
+    if (!t_fi || !t_di) return status();
+    const int nb = (int)t_di->count, nsel = (int)t_fi->count;
+    std::vector<int> off((size_t)nb + 1, 0);
+    for (int i = 0; i < nb; ++i) {
+        const int d = (int)t_di->data[i];
+        if (d < 2 || (d & 1)) return mfail(err, ADE_ERR_BAD_VALUE, "melband: dim_inputs entries must be positive and even");
+        off[i + 1] = off[i] + d;
+    }
+    if (off[nb] != 2 * nsel) return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: sum(dim_inputs) must equal 2 * len(freq_indices)");
+    if (nb < 1 || nb > kMaxSeq) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: 1..256 bands supported");
+    if (T > kMaxSeq) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: at most 256 frames per clip (input_audio_length <= 112455); fold longer audio into windows");
+    const Tensor* t_bs0 = find("bs_w_0");
+    if (!t_bs0 || t_bs0->dims.size() != 2) return status();
+    const int dim = t_bs0->dims[0];
+    int depth = 0;
+    while (tensors.count("time" + std::to_string(depth) + "_in_w")) ++depth;
+    if (depth < 1) return mfail(err, ADE_ERR_MISSING_KEY, "weights: tensor missing: time0_in_w");
+    const Tensor* t_ow = find("time0_out_w");
+    const Tensor* t_f1 = find("time0_ff1_w");
+    const Tensor* t_m1 = find("me_w1t");
+    if (!t_ow || !t_f1 || !t_m1 || t_ow->dims.size() != 2 || t_f1->dims.size() != 2 || t_m1->dims.size() != 3) return status();
+    const int di = t_ow->dims[1], ffd = t_f1->dims[0], med = t_m1->dims[2];
+    if (di % kDh) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: dim_inner must be a multiple of dim_head = 64");
+    const int heads = di / kDh, ldq = 3 * di + heads;
+
+    MelbandEngine* e = new MelbandEngine();
+    e->device = device; e->L = in_len; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
+    e->S2 = off[nb];
+    for (int i = 0; i < nb; ++i) e->max_d = std::max(e->max_d, off[i + 1] - off[i]);
+    auto bail = [&](int st) { delete e; return st; };
+
+    // ---- collect every tensor with its place in the arena
+    struct Item { const float* src; size_t n; size_t at; };
+    std::vector<Item> items;
+    size_t arena = 0;
+    auto place = [&](const float* src, size_t n) { const size_t at = arena; arena += (n + 63) & ~(size_t)63; items.push_back({src, n, at}); return at; };
+    std::vector<long long> ll((size_t)4 * nb);
+    for (int i = 0; i < nb; ++i) {
+        const int d = off[i + 1] - off[i];
+        const std::string s = std::to_string(i);
+        const Tensor *w = shaped("bs_w_" + s, {dim, d}), *b = shaped("bs_b_" + s, {dim}), *w3 = shaped("me_w3_" + s, {2 * d, med}), *b3 = shaped("me_b3_" + s, {2 * d});
+        if (!w || !b || !w3 || !b3) return bail(status());
+        ll[i] = (long long)place(w->data, w->count); ll[nb + i] = (long long)place(b->data, b->count);
+        ll[2 * nb + i] = (long long)place(w3->data, w3->count); ll[3 * nb + i] = (long long)place(b3->data, b3->count);
+    }
+    struct TfAt { size_t v[8]; };
+    std::vector<TfAt> tf_at;
+    for (int i = 0; i < depth; ++i)
+        for (const char* axis : {"time", "freq"}) {
+            const std::string p = std::string(axis) + std::to_string(i) + "_";
+            const Tensor* ts[8] = {shaped(p + "in_w", {ldq, dim}), shaped(p + "in_b", {ldq}), shaped(p + "out_w", {dim, di}), shaped(p + "ff1_w", {ffd, dim}),
+                                   shaped(p + "ff1_b", {ffd}), shaped(p + "ff2_w", {dim, ffd}), shaped(p + "ff2_b", {dim}), shaped(p + "out_g", {dim})};
+            TfAt at{};
+            for (int k = 0; k < 8; ++k) {
+                if (!ts[k]) return bail(status());
+                at.v[k] = place(ts[k]->data, ts[k]->count);
+            }
+            tf_at.push_back(at);
+        }
+    const Tensor *m1 = shaped("me_w1t", {nb, dim, med}), *mb1 = shaped("me_b1", {nb, 1, med}), *m2 = shaped("me_w2t", {nb, med, med}), *mb2 = shaped("me_b2", {nb, 1, med});
+    if (!m1 || !mb1 || !m2 || !mb2) return bail(status());
+    const size_t a_m1 = place(m1->data, m1->count), a_mb1 = place(mb1->data, mb1->count), a_m2 = place(m2->data, m2->count), a_mb2 = place(mb2->data, mb2->count);
+
+    // ---- host-built tables: DFT matrices (exact angles), COLA sum, rotary tables (:395-401, :438-449)
+    std::vector<float> fwd((size_t)2 * kBinsM * kNfftM), inv((size_t)2 * kBinsM * kNfftM), win((size_t)kNfftM), wsum((size_t)in_len, 0.0f);
+    {
+        const float step = (float)(2.0 * M_PI / (double)kNfftM);
+        for (int n = 0; n < kNfftM; ++n) win[n] = cosf((float)n * step) * (-0.5f) + 0.5f;       // torch.hann_window(periodic=True) in fp32
+        for (int f = 0; f < kBinsM; ++f) {
+            const float scale = (f == 0 || f == kBinsM - 1) ? 1.0f : 2.0f;
+            for (int n = 0; n < kNfftM; ++n) {
+                float c, s;
+                if (exact_dft) {
+                    const double a = 2.0 * M_PI * (double)(((long long)f * n) % kNfftM) / kNfftM;
+                    c = (float)cos(a); s = (float)sin(a);
+                } else {        // the reference's tables: cos / sin of the fp32 product (2 pi / N) * f * n (Stereo/STFT_Process.py:205-243)
+                    const float omega = (step * (float)f) * (float)n;
+                    c = cosf(omega); s = sinf(omega);
+                }
+                fwd[(size_t)f * kNfftM + n] = c * win[n];
+                fwd[(size_t)(kBinsM + f) * kNfftM + n] = -s * win[n];
+                inv[(size_t)f * kNfftM + n] = ((scale * c) * (float)(1.0 / kNfftM)) * win[n];
+                inv[(size_t)(kBinsM + f) * kNfftM + n] = ((scale * -s) * (float)(1.0 / kNfftM)) * win[n];
+            }
+        }
+        std::vector<float> raw((size_t)kNfftM + (size_t)kHopM * (T - 1), 0.0f);
+        for (int t = 0; t < T; ++t)
+            for (int n = 0; n < kNfftM; ++n) raw[(size_t)t * kHopM + n] += win[n] * win[n];
+        for (int m = 0; m < in_len; ++m) wsum[m] = raw[(size_t)m + kNfftM / 2];
+    }
+    auto half_round = [](float v) { return (float)(_Float16)v; };
+    std::vector<float> tcos((size_t)T * kDh), tsin((size_t)T * kDh), fcos((size_t)nb * kDh), fsin((size_t)nb * kDh);
+    {
+        float inv_freq[kDh / 2];
+        for (int i = 0; i < kDh / 2; ++i) inv_freq[i] = (float)pow(10000.0, -(double)((float)(2 * i) / (float)kDh));
+        const int npos = T > nb ? T : nb;
+        for (int p = 0; p < npos; ++p)
+            for (int d = 0; d < kDh; ++d) {
+                const float ang = (float)p * inv_freq[d >> 1];
+                const float c = cosf(ang), s = sinf(ang), sign = (d & 1) ? 1.0f : -1.0f;
+                if (p < T) { tcos[(size_t)p * kDh + d] = half_round(c); tsin[(size_t)p * kDh + d] = half_round(s) * sign; }   // time tables pass through fp16 (:413-414)
+                if (p < nb) { fcos[(size_t)p * kDh + d] = c; fsin[(size_t)p * kDh + d] = s * sign; }
+            }
+    }
+    const size_t a_fwd = place(fwd.data(), fwd.size()), a_inv = place(inv.data(), inv.size()), a_ws = place(wsum.data(), wsum.size()),
+                 a_tc = place(tcos.data(), tcos.size()), a_ts = place(tsin.data(), tsin.size()), a_fc = place(fcos.data(), fcos.size()),
+                 a_fs = place(fsin.data(), fsin.size());
+
+    // ---- int tables: gather columns, band offsets, bin -> owning gathered entries (CSR, ascending gathered index)
+    std::vector<int> gcol((size_t)off[nb]);
+    std::vector<int> band_of((size_t)nsel);
+    for (int i = 0; i < nb; ++i)
+        for (int c = off[i]; c < off[i + 1]; c += 2) band_of[c >> 1] = i;
+    std::vector<int> count((size_t)kFc + 1, 0);
+    for (int sidx = 0; sidx < nsel; ++sidx) {
+        const int fc = (int)t_fi->data[sidx];
+        if (fc < 0 || fc >= kFc || (float)fc != t_fi->data[sidx]) return bail(mfail(err, ADE_ERR_BAD_VALUE, "melband: freq_indices entries must be integers in [0, 2050)"));
+        gcol[2 * sidx] = fc * 2; gcol[2 * sidx + 1] = fc * 2 + 1;
+        ++count[fc + 1];
+    }
+    for (int fc = 0; fc < kFc; ++fc) count[fc + 1] += count[fc];
+    std::vector<int> csr_col((size_t)nsel), csr_d((size_t)nsel), fill(count.begin(), count.end() - 1);
+    for (int sidx = 0; sidx < nsel; ++sidx) {
+        const int fc = (int)t_fi->data[sidx], band = band_of[sidx], at = fill[fc]++;
+        csr_col[at] = off[band] + 2 * sidx;        // raw column of the GLU value (re) in YT: 2*off_band + (2*sidx - off_band)
+        csr_d[at] = off[band + 1] - off[band];     // + d: the matching gate column
+    }
+    std::vector<int> ints;
+    auto place_i = [&](const std::vector<int>& v) { const size_t at = ints.size(); ints.insert(ints.end(), v.begin(), v.end()); ints.resize((ints.size() + 15) & ~(size_t)15); return at; };
+    const size_t i_gcol = place_i(gcol), i_off = place_i(off), i_cs = place_i(count), i_cc = place_i(csr_col), i_cd = place_i(csr_d);
+
+    if (hipSetDevice(device) != hipSuccess) return bail(mfail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipMalloc((void**)&e->d_w, arena * sizeof(float)) != hipSuccess) return bail(mfail(err, ADE_ERR_DEVICE, "hipMalloc of the Mel-Band-Roformer weights failed"));
+    for (const Item& it : items)
+        if (hipMemcpy(e->d_w + it.at, it.src, it.n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(mfail(err, ADE_ERR_DEVICE, "upload of the Mel-Band-Roformer weights failed"));
+    if (hipMalloc((void**)&e->d_i, ints.size() * sizeof(int)) != hipSuccess || hipMalloc((void**)&e->d_ll, ll.size() * sizeof(long long)) != hipSuccess ||
+        hipMemcpy(e->d_i, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_ll, ll.data(), ll.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(mfail(err, ADE_ERR_DEVICE, "upload of the band tables failed"));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxSeq * kDh * (int)sizeof(float));
+    e->k_fwd = e->d_w + a_fwd; e->k_inv = e->d_w + a_inv; e->wsum = e->d_w + a_ws;
+    e->tcos = e->d_w + a_tc; e->tsin = e->d_w + a_ts; e->fcos = e->d_w + a_fc; e->fsin = e->d_w + a_fs;
+    e->me_w1t = e->d_w + a_m1; e->me_b1 = e->d_w + a_mb1; e->me_w2t = e->d_w + a_m2; e->me_b2 = e->d_w + a_mb2;
+    for (size_t k = 0; k < tf_at.size(); ++k) {
+        const TfAt& a = tf_at[k];
+        TfW w{e->d_w + a.v[0], e->d_w + a.v[1], e->d_w + a.v[2], e->d_w + a.v[3], e->d_w + a.v[4], e->d_w + a.v[5], e->d_w + a.v[6], e->d_w + a.v[7]};
+        (k & 1 ? e->freq_tf : e->time_tf).push_back(w);
+    }
+    e->gcol = e->d_i + i_gcol; e->off = e->d_i + i_off; e->csr_start = e->d_i + i_cs; e->csr_col = e->d_i + i_cc; e->csr_d = e->d_i + i_cd;
+    e->bt = BandTable{e->off, e->d_ll, e->d_ll + nb, e->d_ll + 2 * nb, e->d_ll + 3 * nb};
+    *out = e;
+    return ADE_OK;
+}
+
+int MelbandEngine::reserve(int batch, std::string& err) {
+    if (batch <= capacity) return ADE_OK;
+    MB_HIP(hipSetDevice(device));
+    MB_HIP(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    ws = nullptr;
+    capacity = 0;
+    const size_t BT = (size_t)batch * T, R = (size_t)nb * BT;
+    const size_t wide = (size_t)(3 * di + heads) > (size_t)med ? (size_t)(3 * di + heads) : (size_t)med;
+    const size_t hid = (size_t)ffd > (size_t)med ? (size_t)ffd : (size_t)med;
+    const size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
+                              (size_t)kChan * BT * kNfftM, (size_t)kFc * 2 * BT};
+    size_t total = 0;
+    for (size_t s : sizes) total += (s + 63) & ~(size_t)63;
+    MB_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
+    float** ptrs[10] = {&Sp, &X, &invn, &bufA, &bufB, &AO, &YT, &MS, &frames_buf, &mask_tap};
+    size_t at = 0;
+    for (int i = 0; i < 10; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
+    capacity = batch;
+    return ADE_OK;
+}
+
+void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc,
+                                const float* rs) {
+    using namespace gemm;
+    const int ldq = 3 * di + heads;
+    // invn holds 1 / |x_row| on entry (written by whoever produced X)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, ScaleBiasStore{bufA, invn, w.in_b, ldq}, R, ldq, dim);                     // (:547-548)
+    hipLaunchKernelGGL(k_attention, dim3((unsigned)nseq, (unsigned)heads), dim3(256), (size_t)2 * n * kDh * sizeof(float), s, (const float*)bufA, AO, rc, rs, n,
+                       seq_stride, pos_stride, ldq, di, heads);                                                                     // (:549-560)
+    launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di);                               // (:561, :569)
+    hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
+    launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim);               // (:564)
+    launch(s, RowMajorA{bufB, ffd}, WeightNK{w.ff2_w, ffd}, ResidualStore{X, w.ff2_b, dim}, R, dim, ffd);                          // (:565, :570)
+    hipLaunchKernelGGL(k_row_normalize_gain, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, X, w.out_g, invn, R, dim);            // (:571)
+}
+
+int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+    if (batch == 0) return ADE_OK;
+    int st = reserve(batch, err);
+    if (st != ADE_OK) return st;
+    using namespace gemm;
+    const int B = batch, BT = B * T, R = nb * BT, J = BT * kChan;
+    // STFT of every (clip, channel) row into channel-interleaved bins                                                              (:648-651, :596)
+    launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB{d_in, L, T}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
+    // band split                                                                                                                   (:597-599)
+    hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
+    launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim);
+    hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
+    // axial transformers: time = T consecutive rows per (band, clip); frequency = nb rows B*T apart per (clip, frame)              (:609-614)
+    for (int i = 0; i < depth; ++i) {
+        transformer(s, time_tf[i], R, T, nb * B, (long long)T, 1LL, tcos, tsin);
+        transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin);
+    }
+    // mask estimator: per band 384 -> 1536 -> 1536 (tanh) -> 2 d_i, kept raw and column-major for the GLU / scatter kernel         (:579-585)
+    launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med);
+    launch_batched(s, MeHiddenProb{bufB, me_w2t, me_b2, bufA, BT, med, med}, nb, BT, med);
+    launch_batched(s, MeOutProb{bufA, d_w, bt, YT, BT, med}, nb, BT, 2 * max_d);
+    hipLaunchKernelGGL(k_mask_apply, dim3((unsigned)((BT + 255) / 256), (unsigned)kFc), dim3(256), 0, s, (const float*)Sp, (const float*)YT, csr_start, csr_col,
+                       csr_d, MS, mask_tap, B, T);                                                                                  // (:616-624)
+    // synthesis GEMM + overlap-add + PCM tail                                                                                      (:661, :667-676)
+    launch(s, PlanarSpecA{MS, J}, RowMajorB{k_inv, kNfftM}, BiasActStore<kActNone>{frames_buf, kNfftM, nullptr, 0.0f}, J, kNfftM, 2 * kBinsM);
+    const long long total = (long long)B * kChan * L;
+    hipLaunchKernelGGL(k_melband_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)frames_buf, wsum, d_out, d_f32, T, L, total);
+    MB_HIP(hipGetLastError());
+    return ADE_OK;
+}
+
+int MelbandEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+    const size_t BT = (size_t)batch * T;
+    const float* src = nullptr;
+    size_t n = 0;
+    if (strcmp(name, "tokens") == 0) { src = X; n = (size_t)nb * BT * dim; }              // transformer output (band, clip, frame, dim)
+    else if (strcmp(name, "mask") == 0) { src = mask_tap; n = (size_t)kFc * 2 * BT; }     // averaged complex mask [fc][re|im][clip*T + t]
+    else if (strcmp(name, "spec") == 0) { src = Sp; n = (size_t)kFc * 2 * BT; }
+    else return mfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    if (!src || batch <= 0) return mfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet");
+    if (count < n) return mfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+    MB_HIP(hipStreamSynchronize(s));
+    MB_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    *written = n;
+    return ADE_OK;
+}
+
+}  // namespace ade

@@ -77,6 +77,8 @@ class InferenceSession:
         io = _lib.IoDesc()
         self._lib.check(self._lib.c.ade_get_io(self._h, C.byref(io)), self._h)
         self.in_len, self.out_len, self.frames = io.in_len, io.out_len, io.frames
+        self.channels = io.in_channels                    # 1 (GTCRN, DFSMN) or 2 (Mel-Band-Roformer stereo)
+        self.row_in, self.row_out = io.in_channels * io.in_len, io.out_channels * io.out_len   # one batch item, channel-planar
         self.sample_rate = io.model_sample_rate
         self.device_id = io.device
         self._inputs = [NodeArg(INPUT_NAME, [1, io.in_channels, io.in_len])]
@@ -104,22 +106,22 @@ class InferenceSession:
         x = np.asarray(input_feed[INPUT_NAME])
         if x.dtype != np.int16:
             raise ValueError(f"{INPUT_NAME} must be int16, got {x.dtype}")
-        if x.ndim != 3 or x.shape[1] != 1 or x.shape[2] != self.in_len:
-            raise ValueError(f"{INPUT_NAME} must have shape (B, 1, {self.in_len}), got {x.shape}")
-        pcm, f32 = self.process(x[:, 0, :], want_f32=return_f32)
-        out = [pcm[:, None, :]]
+        if x.ndim != 3 or x.shape[1] != self.channels or x.shape[2] != self.in_len:
+            raise ValueError(f"{INPUT_NAME} must have shape (B, {self.channels}, {self.in_len}), got {x.shape}")
+        pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32)
+        out = [pcm.reshape(-1, self.channels, self.out_len)]
         if return_f32:
-            out.append(f32[:, None, :])
+            out.append(f32.reshape(-1, self.channels, self.out_len))
         return out
 
     # -- batch call on host buffers ---------------------------------------------------------------------------
     def process(self, pcm: np.ndarray, want_f32: bool = False):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)
-        if pcm.ndim != 2 or pcm.shape[1] != self.in_len:
-            raise ValueError(f"expected int16 (B, {self.in_len}), got {pcm.shape}")
+        if pcm.ndim != 2 or pcm.shape[1] != self.row_in:
+            raise ValueError(f"expected int16 (B, {self.row_in}), got {pcm.shape}")
         B = pcm.shape[0]
-        out = np.empty((B, self.out_len), np.int16)
-        f32 = np.empty((B, self.out_len), np.float32) if want_f32 else None
+        out = np.empty((B, self.row_out), np.int16)
+        f32 = np.empty((B, self.row_out), np.float32) if want_f32 else None
         st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if want_f32 else None)
         self._lib.check(st, self._h)
         return out, f32
@@ -129,14 +131,14 @@ class InferenceSession:
         """``d_in`` int16 (B, L) / ``d_out`` int16 (B, L_out) CUDA(HIP) tensors; enqueues on ``stream`` (a raw
         hipStream_t handle, e.g. ``torch.cuda.current_stream().cuda_stream``) or runs synchronously when None."""
         B = int(d_in.shape[0])
-        if tuple(d_in.shape) != (B, self.in_len) or tuple(d_out.shape) != (B, self.out_len):
-            raise ValueError("device tensors must be (B, in_len) int16 -> (B, out_len) int16")
+        if tuple(d_in.shape) != (B, self.row_in) or tuple(d_out.shape) != (B, self.row_out):
+            raise ValueError("device tensors must be (B, channels * in_len) int16 -> (B, channels * out_len) int16")
         if not d_in.is_contiguous() or not d_out.is_contiguous():
             raise ValueError("device tensors must be contiguous")
         f32_ptr = None
         if d_f32 is not None:
-            if tuple(d_f32.shape) != (B, self.out_len) or not d_f32.is_contiguous():
-                raise ValueError("d_f32 must be a contiguous (B, out_len) float32 tensor")
+            if tuple(d_f32.shape) != (B, self.row_out) or not d_f32.is_contiguous():
+                raise ValueError("d_f32 must be a contiguous (B, channels * out_len) float32 tensor")
             f32_ptr = C.c_void_p(d_f32.data_ptr())
         st = self._lib.c.ade_process_device(self._h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr()), f32_ptr,
                                             C.c_void_p(stream) if stream else None)

@@ -130,6 +130,7 @@ class MelBandOracle:
         re, im = spec[..., :FBINS], spec[..., FBINS:]
         # (chan, F, T, 2) -> (F*chan, T, 2), channel-minor (:596)
         rep = np.stack((re, im), axis=-1).transpose(2, 0, 1, 3).reshape(FBINS * 2, T, 2)
+        self.taps["spec"] = rep.copy()
         sel = rep[self.fi]                                                                 # (S, T, 2) (:597)
         xb = sel.transpose(1, 0, 2).reshape(T, -1)                                         # (T, 2S) (:598)
         outs, off = [], 0
@@ -155,6 +156,7 @@ class MelBandOracle:
         masks = masks.reshape(T, -1, 2).transpose(1, 0, 2)                                 # (S, T, 2) (:616)
         avg = np.zeros_like(rep)
         np.add.at(avg, self.fi, masks)                                                     # scatter_add (:617-619)
+        self.taps["mask_avg"] = avg.copy()
         mr, mi = avg[..., 0], avg[..., 1]
         out_re = (rep[..., 0] * mr - rep[..., 1] * mi).astype(F32)                         # (:621-624)
         out_im = (rep[..., 0] * mi + rep[..., 1] * mr).astype(F32)

@@ -49,3 +49,72 @@ def test_oracle_matches_reference_forward(fixture):
     d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.05
     assert np.abs(z["pcm_out"]).max() > 2000                                              # a non-trivial signal came out
+
+
+def test_band_tables_match_the_reference():
+    from audio_denoiser_onnx_amd.mel_bands import band_tables
+    z = np.load(GOLD)
+    fi, di = band_tables()
+    assert np.array_equal(fi, z["freq_indices"]) and np.array_equal(di, z["dim_inputs"])
+
+
+# ---- GPU: the HIP engine through the C ABI ------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def session(fixture):
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    z, _, w = fixture
+    sess = InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(z["pcm_in"].shape[1]))
+    yield sess
+    sess.close()
+
+
+@pytest.mark.gpu
+def test_gpu_matches_reference_fixture(fixture, session):
+    """int16 (1, 2, L) through libade vs the reference's own forward: within 2 LSB, almost all samples equal."""
+    z = fixture[0]
+    assert session.channels == 2 and session.frames == int(z["frames"])
+    out = session.run(None, {"noisy_audio": z["pcm_in"][None]})[0]
+    assert out.shape == (1, 2, z["pcm_in"].shape[1]) and out.dtype == np.int16
+    d = out[0].astype(np.int32) - z["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_exact_tables_match_exact_oracle(fixture):
+    """ade_dft_tables = "exact" against the oracle with exactly reduced angles, stage by stage."""
+    from melband_oracle import MelBandOracle
+    z, _, w = fixture
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    T, L = int(z["frames"]), z["pcm_in"].shape[1]
+    o = MelBandOracle(w, z["freq_indices"], z["dim_inputs"], T, int(z["depth"]), exact_dft=True)
+    want = o.process(z["pcm_in"])
+    with InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(L, dft_tables="exact")) as session:
+        got = session.run(None, {"noisy_audio": z["pcm_in"][None]})[0][0]
+        tokens = session.tap("tokens", 60 * T * 384).reshape(60, T, 384)
+        sp = session.tap("spec", 2050 * 2 * T).reshape(2050, 2, T).transpose(0, 2, 1)
+        mk = session.tap("mask", 2050 * 2 * T).reshape(2050, 2, T).transpose(0, 2, 1)
+    assert np.abs(sp - o.taps["spec"]).max() < 2e-3          # |spec| reaches ~225
+    e = np.abs(mk - o.taps["mask_avg"])
+    assert np.median(e) < 5e-5 and e.max() < 2e-2, (np.median(e), e.max())
+    err = np.abs(tokens - o.taps["tf_out"])
+    assert np.median(err) < 2e-5 and err.max() < 3e-2, (np.median(err), err.max())   # max: the near-silent top bands (values reach 19.6)
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10
+
+
+@pytest.mark.gpu
+def test_gpu_batch_rows_are_independent_clips(fixture, session):
+    """B stereo clips in one call = B separate calls (the reference's fold windows are independent clips, :588-594)."""
+    z = fixture[0]
+    a = z["pcm_in"]
+    b = np.ascontiguousarray(a[::-1, ::-1] // 2)
+    one_a = session.run(None, {"noisy_audio": a[None]})[0][0]
+    one_b = session.run(None, {"noisy_audio": b[None]})[0][0]
+    both = session.run(None, {"noisy_audio": np.stack((a, b, a))})[0]
+    for got, want in ((both[0], one_a), (both[1], one_b), (both[2], one_a)):
+        d = got.astype(np.int32) - want.astype(np.int32)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
