@@ -793,8 +793,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
         if (dyn_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
-        if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && (!parse_bool(e->meta["use_batch_fold"], &fold_d) || fold_d))
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + ": use_batch_fold is not implemented (pass the windows as batch rows)"));
+        if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
+        if (fold_d && fam_dfsmn) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn: use_batch_fold is not implemented"));
         long sri = 0, sro = 0, srm = 0, Ld = 0;
         if (!parse_int(e->meta["in_sample_rate"], &sri) || !parse_int(e->meta["out_sample_rate"], &sro) ||
             !parse_int(e->meta["model_sample_rate"], &srm) || !parse_int(e->meta["input_audio_length"], &Ld))
@@ -804,6 +805,19 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
             return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
         if (Ld < 1920 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
+        long sub_win = 1;
+        if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
+            long fw = 0;    //                                                            (Export_MelBandRoformer.py:47-51, 644-647)
+            if (!e->meta.count("fold_window_length") || !parse_int(e->meta["fold_window_length"], &fw) || fw <= 0)
+                return bail(fail(e, ADE_ERR_BAD_VALUE, "use_batch_fold=1 needs fold_window_length"));
+            const long want = (Ld + fw - 1) / fw * fw;
+            long exp_len = 0;
+            if (e->meta.count("export_audio_length") && !e->meta["export_audio_length"].empty() &&
+                (!parse_int(e->meta["export_audio_length"], &exp_len) || exp_len != want))
+                return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "export_audio_length is not input_audio_length rounded up to whole fold windows"));
+            sub_win = want / fw;
+            Ld = fw;
+        }
         ade_status std_ = parse_blob(e, weights, weights_nbytes);
         if (std_ != ADE_OK) return bail(std_);
         int ndev_d = 0;
@@ -822,7 +836,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
         const int rc = fam_dfsmn ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
-                                 : ade::melband_create(e->tensors, (int)Ld, exact_dft, device, &e->sub, derr);
+                                 : ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
         e->in_len = e->sub->in_len() * e->channels;

@@ -156,6 +156,6 @@ struct SubEngine {
 // model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip
 int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err);
 // model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
-int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, bool exact_dft, int device, SubEngine** out, std::string& err);
+int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

@@ -45,16 +45,22 @@ constexpr int kDh = 64;                                               // dim_hea
 constexpr int kMaxSeq = 256;                                          // attention keeps K and V of one (sequence, head) in LDS
 
 // ---- operand / store functors ----------------------------------------------------------------------------------------
-struct StereoFrameB {          // B(k, j) = reflect-padded sample k of frame j = (clip-channel row r, t), * 2^-15 (:326-327, :649)
+// PCM of one call is [channel][window][L] (batch-fold, :644-647; n_win = 1 without it), calls follow each other; the model's
+// rows are window-major / channel-minor: row r = (call * n_win + window) * 2 + channel.
+__device__ __forceinline__ size_t pcm_row_offset(int r, int n_win, int L) {
+    const int b = r >> 1, ch = r & 1, call = b / n_win, w = b - call * n_win;
+    return ((size_t)(call * kChan + ch) * n_win + w) * L;
+}
+struct StereoFrameB {          // B(k, j) = reflect-padded sample k of frame j = (row r, t), * 2^-15 (:326-327, :649)
     static constexpr bool kAlongN = false;
     const int16_t* pcm;
-    int L, T;
+    int L, T, n_win;
     __device__ float operator()(int k, int j) const {
         const int r = j / T, t = j - r * T;
         int idx = t * kHopM + k - kNfftM / 2;
         if (idx < 0) idx = -idx;
         else if (idx >= L) idx = 2 * (L - 1) - idx;
-        return (float)pcm[(size_t)r * L + idx] * (1.0f / 32768.0f);
+        return (float)pcm[pcm_row_offset(r, n_win, L) + idx] * (1.0f / 32768.0f);
     }
 };
 struct BinStore {              // C(c*1025 + f, (b, ch, t)) -> S[(f*2 + ch)*2 + c][b*T + t]   (:596)
@@ -307,18 +313,19 @@ __global__ __launch_bounds__(256) void k_mask_apply(const float* __restrict__ S,
 
 // overlap-add gather, / static COLA sum, then the PCM tail: * 32767, clamp, truncate (:667, :676)
 __global__ __launch_bounds__(256) void k_melband_ola_pcm(const float* __restrict__ frames, const float* __restrict__ wsum, int16_t* __restrict__ pcm,
-                                                         float* __restrict__ f32, int T, int L, long long total) {
+                                                         float* __restrict__ f32, int T, int L, int n_win, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int r = (int)(i / L), m = (int)(i - (long long)r * L) + kNfftM / 2;
+    const size_t o = pcm_row_offset(r, n_win, L) + (size_t)(m - kNfftM / 2);      // stitch each channel's windows back (:663-664)
     int t_hi = m / kHopM;
     if (t_hi > T - 1) t_hi = T - 1;
     const int t_lo = m - kNfftM + 1 <= 0 ? 0 : (m - kNfftM + kHopM) / kHopM;
     float s = 0.0f;
     for (int t = t_lo; t <= t_hi; ++t) s += frames[((size_t)r * T + t) * kNfftM + (m - t * kHopM)];
     const float y = s / wsum[m - kNfftM / 2];
-    if (f32) f32[i] = y;
-    if (pcm) pcm[i] = (short)(int)fminf(fmaxf(y * 32767.0f, -32768.0f), 32767.0f);
+    if (f32) f32[o] = y;
+    if (pcm) pcm[o] = (short)(int)fminf(fmaxf(y * 32767.0f, -32768.0f), 32767.0f);
 }
 
 int mfail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
@@ -333,7 +340,7 @@ struct TfW { const float *in_w, *in_b, *out_w, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *
 }  // namespace
 
 struct MelbandEngine : SubEngine {
-    int device = 0, L = 0, T = 0, depth = 0, nb = 0, dim = 0, di = 0, heads = 0, ffd = 0, med = 0, S2 = 0 /* gathered columns */, max_d = 0 /* widest band */;
+    int device = 0, L = 0 /* one window */, n_win = 1, T = 0, depth = 0, nb = 0, dim = 0, di = 0, heads = 0, ffd = 0, med = 0, S2 = 0 /* gathered columns */, max_d = 0 /* widest band */;
     float* d_w = nullptr;          // arena: DFT tables, rotary tables, COLA sum, every fused buffer
     int* d_i = nullptr;            // arena of int tables
     long long* d_ll = nullptr;     // per-band weight offsets
@@ -355,8 +362,8 @@ struct MelbandEngine : SubEngine {
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
-    int in_len() const override { return L; }
-    int out_len() const override { return L; }
+    int in_len() const override { return L * n_win; }
+    int out_len() const override { return L * n_win; }
     int channels() const override { return kChan; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
@@ -364,8 +371,9 @@ struct MelbandEngine : SubEngine {
     void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
 };
 
-int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, bool exact_dft, int device, SubEngine** out, std::string& err) {
+int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
+    if (n_win < 1) return mfail(err, ADE_ERR_BAD_VALUE, "melband: n_win must be >= 1");
     if (in_len < kNfftM || in_len % kHopM != 0)
         return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: input_audio_length must be a multiple of the 441-sample hop and at least 2048");
     const int T = in_len / kHopM + 1;
@@ -407,7 +415,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, boo
     const int heads = di / kDh, ldq = 3 * di + heads;
 
     MelbandEngine* e = new MelbandEngine();
-    e->device = device; e->L = in_len; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
+    e->device = device; e->L = in_len; e->n_win = n_win; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
     e->S2 = off[nb];
     for (int i = 0; i < nb; ++i) e->max_d = std::max(e->max_d, off[i + 1] - off[i]);
     auto bail = [&](int st) { delete e; return st; };
@@ -543,7 +551,7 @@ int MelbandEngine::reserve(int batch, std::string& err) {
     if (ws) (void)hipFree(ws);
     ws = nullptr;
     capacity = 0;
-    const size_t BT = (size_t)batch * T, R = (size_t)nb * BT;
+    const size_t BT = (size_t)batch * n_win * T, R = (size_t)nb * BT;
     const size_t wide = (size_t)(3 * di + heads) > (size_t)med ? (size_t)(3 * di + heads) : (size_t)med;
     const size_t hid = (size_t)ffd > (size_t)med ? (size_t)ffd : (size_t)med;
     const size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
@@ -578,9 +586,9 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     int st = reserve(batch, err);
     if (st != ADE_OK) return st;
     using namespace gemm;
-    const int B = batch, BT = B * T, R = nb * BT, J = BT * kChan;
+    const int B = batch * n_win, BT = B * T, R = nb * BT, J = BT * kChan;      // every fold window is an independent stereo clip (:588-594)
     // STFT of every (clip, channel) row into channel-interleaved bins                                                              (:648-651, :596)
-    launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB{d_in, L, T}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
+    launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB{d_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
     // band split                                                                                                                   (:597-599)
     hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
     launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim);
@@ -599,13 +607,13 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     // synthesis GEMM + overlap-add + PCM tail                                                                                      (:661, :667-676)
     launch(s, PlanarSpecA{MS, J}, RowMajorB{k_inv, kNfftM}, BiasActStore<kActNone>{frames_buf, kNfftM, nullptr, 0.0f}, J, kNfftM, 2 * kBinsM);
     const long long total = (long long)B * kChan * L;
-    hipLaunchKernelGGL(k_melband_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)frames_buf, wsum, d_out, d_f32, T, L, total);
+    hipLaunchKernelGGL(k_melband_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)frames_buf, wsum, d_out, d_f32, T, L, n_win, total);
     MB_HIP(hipGetLastError());
     return ADE_OK;
 }
 
 int MelbandEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
-    const size_t BT = (size_t)batch * T;
+    const size_t BT = (size_t)batch * n_win * T;
     const float* src = nullptr;
     size_t n = 0;
     if (strcmp(name, "tokens") == 0) { src = X; n = (size_t)nb * BT * dim; }              // transformer output (band, clip, frame, dim)

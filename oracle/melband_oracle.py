@@ -168,3 +168,11 @@ class MelBandOracle:
             raw[:, t * HOP:t * HOP + NFFT] += fr[:, t]
         wav = (raw[:, half:half + self.L] / self.win_sum).astype(F32)
         return np.clip(wav * F32(32767.0), -32768.0, 32767.0).astype(np.int16)             # (:667, :676) trunc toward zero
+
+    def process_fold(self, pcm: np.ndarray, n_win: int) -> np.ndarray:
+        """USE_BATCH_FOLD (:644-647, :663-664): (2, n_win * W) -> n_win independent stereo clips of W -> stitched back per channel."""
+        assert pcm.shape == (2, n_win * self.L)
+        out = np.empty_like(pcm)
+        for w in range(n_win):
+            out[:, w * self.L:(w + 1) * self.L] = self.process(np.ascontiguousarray(pcm[:, w * self.L:(w + 1) * self.L]))
+        return out

@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 from audio_denoiser_onnx_amd import weightgen  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden", "melband_seed0_io.npz")
+GOLD_FOLD = os.path.join(HERE, "golden", "melband_seed0_fold_io.npz")
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +50,18 @@ def test_oracle_matches_reference_forward(fixture):
     d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.05
     assert np.abs(z["pcm_out"]).max() > 2000                                              # a non-trivial signal came out
+
+
+def test_oracle_batch_fold_matches_reference_forward(fixture):
+    """USE_BATCH_FOLD = True in the reference (3 windows of 13230 samples folded into the batch) against the oracle."""
+    from melband_oracle import MelBandOracle
+    z, _, w = fixture
+    zf = np.load(GOLD_FOLD)
+    W = int(zf["fold_window_length"])
+    o = MelBandOracle(w, z["freq_indices"], z["dim_inputs"], W // 441 + 1, int(z["depth"]))
+    out = o.process_fold(zf["pcm_in"], zf["pcm_in"].shape[1] // W)
+    d = out.astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.05
 
 
 def test_band_tables_match_the_reference():
@@ -118,3 +131,21 @@ def test_gpu_batch_rows_are_independent_clips(fixture, session):
     for got, want in ((both[0], one_a), (both[1], one_b), (both[2], one_a)):
         d = got.astype(np.int32) - want.astype(np.int32)
         assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+
+
+@pytest.mark.gpu
+def test_gpu_batch_fold_matches_reference_fixture(fixture):
+    """A use_batch_fold = 1 manifest: one call = (1, 2, 3 * 13230), windows folded inside the engine like the reference's graph."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    w = fixture[2]
+    zf = np.load(GOLD_FOLD)
+    meta = melband.metadata(int(zf["input_audio_length"]), use_batch_fold=True, batch_window_seconds=float(zf["batch_window_seconds"]))
+    assert int(meta["fold_window_length"]) == int(zf["fold_window_length"]) and int(meta["export_audio_length"]) == zf["pcm_in"].shape[1]
+    with InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=meta) as sess:
+        assert sess.in_len == zf["pcm_in"].shape[1] and sess.frames == 31
+        out = sess.run(None, {"noisy_audio": np.stack((zf["pcm_in"], zf["pcm_in"]))})[0]
+    d = out[0].astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
+    assert np.array_equal(out[0], out[1])                                    # second call of the batch: same clip, same result

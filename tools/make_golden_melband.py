@@ -35,12 +35,12 @@ from audio_denoiser_onnx_amd import weightgen  # noqa: E402
 L, DEPTH = 13230, 1          # 0.3 s of stereo @ 44.1 kHz -> 31 frames; one (time, freq) transformer pair
 
 
-def import_namespace(length: int) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "Mel_Band_Roformer", "Stereo", "Export_MelBandRoformer.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
-    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": False}
+    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -84,9 +84,9 @@ def weight_spec(model) -> list:
     return spec
 
 
-def main():
-    ns = import_namespace(L)
+def build_model(ns, length):
     T = ns["MAX_SIGNAL_LENGTH"]
+    fold = bool(ns["USE_BATCH_FOLD"])
     STFT_Process = import_stft_process("Mel_Band_Roformer/Stereo").STFT_Process
     stft = STFT_Process("stft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], 0, ns["WINDOW_TYPE"], True, "reflect").eval()
     istft = STFT_Process("istft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], T, ns["WINDOW_TYPE"], True, "reflect",
@@ -96,9 +96,9 @@ def main():
     nn.Module.load_state_dict = lambda self, sd, strict=True: types.SimpleNamespace(missing_keys=[], unexpected_keys=[])
     try:
         torch.manual_seed(0)
-        model = ns["MelBandRoformer"](stft, istft, T, False, 0, L, dim=384, depth=DEPTH, stereo=True, num_stems=1,
-                                      time_transformer_depth=1, freq_transformer_depth=1, num_bands=60, dim_head=64, heads=8,
-                                      mask_estimator_depth=2).eval()
+        model = ns["MelBandRoformer"](stft, istft, T, fold, ns["FOLD_WINDOW_LENGTH"] if fold else 0, ns["EXPORT_AUDIO_LENGTH"], dim=384, depth=DEPTH,
+                                      stereo=True, num_stems=1, time_transformer_depth=1, freq_transformer_depth=1, num_bands=60, dim_head=64,
+                                      heads=8, mask_estimator_depth=2).eval()
     finally:
         torch.load, nn.Module.load_state_dict = real_load, real_lsd
     spec = weight_spec(model)
@@ -107,15 +107,24 @@ def main():
         for name, shape, scale in spec:
             bufs[name].copy_(torch.from_numpy(weightgen.tensor(name, shape, scale)))
     print("buffers overwritten:", len(spec), "tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats")
-    wav_path = os.path.join(REF_ROOT, "Test_Examples", "denoise", "mel_band_roformer.wav")
+    return model, spec, T
+
+
+def read_clip(start: int, length: int) -> np.ndarray:
     from scipy.io import wavfile
-    _, data = wavfile.read(wav_path)          # WAVE_FORMAT_EXTENSIBLE: the stdlib wave module refuses it
+    _, data = wavfile.read(os.path.join(REF_ROOT, "Test_Examples", "denoise", "mel_band_roformer.wav"))   # WAVE_FORMAT_EXTENSIBLE
     if data.dtype != np.int16:
         data = (np.clip(data.astype(np.float64) / (np.iinfo(data.dtype).max if data.dtype.kind == "i" else 1.0), -1, 1) * 32767).astype(np.int16)
     pcm_all = data.reshape(len(data), -1).T
     if pcm_all.shape[0] == 1:
         pcm_all = np.repeat(pcm_all, 2, axis=0)
-    pcm = np.ascontiguousarray(pcm_all[:2, 44100:44100 + L])
+    return np.ascontiguousarray(pcm_all[:2, start:start + length])
+
+
+def main():
+    ns = import_namespace(L)
+    model, spec, T = build_model(ns, L)
+    pcm = read_clip(44100, L)
     taps = {}
     orig = model._band_split
     model._band_split = lambda x: taps.setdefault("band_split", orig(x))
@@ -132,6 +141,20 @@ def main():
     print("out", out.shape, int(np.abs(out).max()), "in max", int(np.abs(pcm).max()), "T", T,
           "band_split rms", float(taps["band_split"].pow(2).mean().sqrt()), "tf_out rms", float(taps["tf_out"].pow(2).mean().sqrt()),
           "masks rms", float(taps["masks"].pow(2).mean().sqrt()))
+
+    # USE_BATCH_FOLD = True (:47-51, 644-647, 663-664): BATCH_WINDOW_SECONDS = 0.3 -> W = 13230 (31 frames); INPUT_AUDIO_LENGTH
+    # = 30000 -> the graph input is 3 whole windows = 39690 samples per channel, folded into a batch of 3 stereo clips
+    ns = import_namespace(30000, fold=True, window_seconds=0.3)
+    assert ns["FOLD_WINDOW_LENGTH"] == 13230 and ns["EXPORT_AUDIO_LENGTH"] == 39690, (ns["FOLD_WINDOW_LENGTH"], ns["EXPORT_AUDIO_LENGTH"])
+    model, spec2, T2 = build_model(ns, 30000)
+    assert spec2 == spec and T2 == 31
+    E = ns["EXPORT_AUDIO_LENGTH"]
+    pcm = read_clip(22050, E)
+    with torch.inference_mode():
+        out = model(torch.from_numpy(pcm.reshape(1, 2, E).copy())).numpy().reshape(2, E)
+    np.savez_compressed(os.path.join(mg.GOLD, "melband_seed0_fold_io.npz"), pcm_in=pcm, pcm_out=out, input_audio_length=np.int64(30000),
+                        fold_window_length=np.int64(13230), batch_window_seconds=np.float64(0.3))
+    print("fold out", out.shape, int(np.abs(out).max()))
 
 
 if __name__ == "__main__":
