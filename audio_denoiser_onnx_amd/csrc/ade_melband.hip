@@ -42,7 +42,7 @@ using namespace dev;
 constexpr int kNfftM = 2048, kHopM = 441, kBinsM = kNfftM / 2 + 1;   // Export_MelBandRoformer.py:42-45
 constexpr int kChan = 2, kFc = kBinsM * kChan;                        // channel-interleaved bins
 constexpr int kDh = 64;                                               // dim_head
-constexpr int kMaxSeq = 256;                                          // attention keeps K and V of one (sequence, head) in LDS
+constexpr int kMaxBands = 1024, kMaxFrames = 8192;                    // sanity bounds only: attention streams K / V, any length works
 
 // ---- operand / store functors ----------------------------------------------------------------------------------------
 // PCM of one call is [channel][window][L] (batch-fold, :644-647; n_win = 1 without it), calls follow each other; the model's
@@ -218,74 +218,102 @@ __global__ __launch_bounds__(256) void k_band_invnorm(const float* __restrict__ 
     inv[(size_t)band * BT + bt] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
 }
 
-// ---- attention core (:546-561): one workgroup per (sequence, head); K and V (rotary applied to K) live in LDS, one query per thread.
-// row(seq, p) = seq * seq_stride + p * pos_stride.  Two passes over the keys (max, then exp / accumulate) = the reference's softmax.
+// ---- attention core (:546-561) on the matrix cores, flash style ------------------------------------------------------------
+// grid = (sequence, head, block of 64 queries); wave w of the workgroup owns queries 16 w .. 16 w + 15 of the block and keeps
+// their rotated Q, running max / sum and the 16 x 64 output tile in registers, while the workgroup streams K (rotated) and V
+// through LDS 64 keys at a time -- any sequence length, 35 KB of LDS, 4 workgroups per CU.
+// Both products are computed TRANSPOSED so that no operand ever changes lanes (v_mfma_f32_16x16x4_f32: lane l supplies
+// A[l & 15][l >> 4] and B[l >> 4][l & 15], and holds D[4 (l >> 4) + r][l & 15]):
+//   S^T tile  = K_tile (16 keys x 64) . Q^T (64 x 16 queries): lane (g, j) holds S[key 4 g + r][query j]   -> softmax statistics are per LANE COLUMN j
+//   O^T tile += V^T (16 dims x keys) . P^T (keys x 16 queries), contraction step s taking keys {4 k + s}: the B operand of lane (k, j) is its own
+//               register p[s], the A operand V[key 4 k + s][dim]; the accumulator again has the query in the lane column, so the online-softmax
+//               rescale is lane-local.
+// row(seq, p) = seq * seq_stride + p * pos_stride.
+constexpr int kKc = 64;            // keys per LDS chunk
+constexpr int kKvStride = 68;      // floats per K / V row in LDS: 16 rows x 4 consecutive floats (K) and 4 rows x 16 floats (V) both cover all 64 banks once
+
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, const float* __restrict__ rcos,
-                                                   const float* __restrict__ rsin, int n, long long seq_stride, long long pos_stride, int ldq, int di,
-                                                   int heads) {
-    extern __shared__ float lds[];
-    float* Ks = lds;
-    float* Vs = lds + (size_t)n * kDh;
-    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+                                                   const float* __restrict__ rsin, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
+    __shared__ float Ks[kKc * kKvStride];
+    __shared__ float Vs[kKc * kKvStride];
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, g = lane >> 4;
     const long long row0 = (long long)seq * seq_stride;
-    for (int i = tid; i < n * kDh; i += 256) {
-        const int p = i >> 6, d = i & 63;
-        const float* src = qkvg + (size_t)(row0 + p * pos_stride) * ldq + head * kDh;
-        const float kv = src[di + d], kp = src[di + (d ^ 1)];
-        Ks[i] = kv * rcos[p * kDh + d] + kp * rsin[p * kDh + d];        // rotate_half = pair swap, sign folded into rsin (:438-453)
-        Vs[i] = src[2 * di + d];
-    }
-    __syncthreads();
-    if (tid >= n) return;
-    const size_t row = (size_t)(row0 + tid * pos_stride);
-    float q[kDh];
+    const int qi = (int)blockIdx.z * 64 + wave * 16 + j16;                      // this lane's query
+    const bool q_ok = qi < n;
+    const size_t qrow = (size_t)(row0 + (long long)(q_ok ? qi : 0) * pos_stride);
+    float qreg[16];                                                             // Q[query j16][d = 4 ks + g], rotary applied (:552)
     {
-        const float* src = qkvg + row * ldq + head * kDh;
+        const float* src = qkvg + qrow * ldq + head * kDh;
+        const float* rc = rcos + (size_t)(q_ok ? qi : 0) * kDh;
+        const float* rs = rsin + (size_t)(q_ok ? qi : 0) * kDh;
 #pragma unroll
-        for (int d = 0; d < kDh; d += 2) {
-            const float a = src[d], b = src[d + 1];
-            q[d] = a * rcos[tid * kDh + d] + b * rsin[tid * kDh + d];
-            q[d + 1] = b * rcos[tid * kDh + d + 1] + a * rsin[tid * kDh + d + 1];
+        for (int ks = 0; ks < 16; ++ks) {
+            const int d = 4 * ks + g;
+            qreg[ks] = q_ok ? src[d] * rc[d] + src[d ^ 1] * rs[d] : 0.0f;      // rotate_half = pair swap, sign folded into rsin (:438-453)
         }
     }
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) {
-        const float4* kr = reinterpret_cast<const float4*>(Ks + j * kDh);
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+    v4f acc[4];
 #pragma unroll
-        for (int d = 0; d < kDh / 4; ++d) {
-            const float4 k4 = kr[d];
-            s0 = fmaf(q[4 * d], k4.x, s0); s1 = fmaf(q[4 * d + 1], k4.y, s1); s2 = fmaf(q[4 * d + 2], k4.z, s2); s3 = fmaf(q[4 * d + 3], k4.w, s3);
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const bool wave_live = (int)blockIdx.z * 64 + wave * 16 < n;               // a wave whose 16 queries are all padding only helps loading
+
+    for (int c0 = 0; c0 < n; c0 += kKc) {
+        __syncthreads();
+        for (int i = tid; i < kKc * kDh; i += 256) {
+            const int p = i >> 6, d = i & 63, key = c0 + p;
+            float kv = 0.0f, vv = 0.0f;
+            if (key < n) {
+                const float* src = qkvg + (size_t)(row0 + (long long)key * pos_stride) * ldq + head * kDh;
+                kv = src[di + d] * rcos[(size_t)key * kDh + d] + src[di + (d ^ 1)] * rsin[(size_t)key * kDh + d];
+                vv = src[2 * di + d];
+            }
+            Ks[p * kKvStride + d] = kv;                                         // padded keys are zero rows: their p is 0 and 0 * 0 stays 0
+            Vs[p * kKvStride + d] = vv;
         }
-        mx = fmaxf(mx, (s0 + s1) + (s2 + s3));
+        __syncthreads();
+        if (!wave_live) continue;
+        const int tiles = (n - c0 + 15) / 16 < kKc / 16 ? (n - c0 + 15) / 16 : kKc / 16;
+        for (int kt = 0; kt < tiles; ++kt) {
+            v4f st = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            const float* kr = Ks + (16 * kt + j16) * kKvStride + g;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) st = mfma16x16x4(kr[4 * ks], qreg[ks], st);
+            const int key0 = c0 + 16 * kt + 4 * g;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (key0 + r >= n) st[r] = -INFINITY;
+                mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);                                   // finite: every visited tile has at least one real key
+            const float alpha = expf(m - m_new);
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - m_new);
+            l = l * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));               // this lane's share of the row sum; the four g-lanes are added at the end
+            m = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = acc[dt] * alpha;
+            const float* vr = Vs + (16 * kt + 4 * g) * kKvStride + j16;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16x16x4(vr[sidx * kKvStride + 16 * dt], pr[sidx], acc[dt]);
+        }
     }
-    float acc[kDh];
-#pragma unroll
-    for (int d = 0; d < kDh; ++d) acc[d] = 0.0f;
-    float l = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float4* kr = reinterpret_cast<const float4*>(Ks + j * kDh);
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma unroll
-        for (int d = 0; d < kDh / 4; ++d) {
-            const float4 k4 = kr[d];
-            s0 = fmaf(q[4 * d], k4.x, s0); s1 = fmaf(q[4 * d + 1], k4.y, s1); s2 = fmaf(q[4 * d + 2], k4.z, s2); s3 = fmaf(q[4 * d + 3], k4.w, s3);
-        }
-        const float e = expf(((s0 + s1) + (s2 + s3)) - mx);
-        l += e;
-        const float4* vr = reinterpret_cast<const float4*>(Vs + j * kDh);
-#pragma unroll
-        for (int d = 0; d < kDh / 4; ++d) {
-            const float4 v4 = vr[d];
-            acc[4 * d] = fmaf(e, v4.x, acc[4 * d]); acc[4 * d + 1] = fmaf(e, v4.y, acc[4 * d + 1]);
-            acc[4 * d + 2] = fmaf(e, v4.z, acc[4 * d + 2]); acc[4 * d + 3] = fmaf(e, v4.w, acc[4 * d + 3]);
-        }
-    }
-    const float gate = 1.0f / (1.0f + expf(-qkvg[row * ldq + 3 * di + head]));      // sigmoid(gates) (:559)
+    if (!q_ok) return;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float gate = 1.0f / (1.0f + expf(-qkvg[qrow * ldq + 3 * di + head]));      // sigmoid(gates) (:559)
     const float sc = gate / l;
-    float4* dst = reinterpret_cast<float4*>(ao + row * di + head * kDh);
+    float* dst = ao + qrow * di + head * kDh + 4 * g;                                 // lane (g, j): dims 16 dt + 4 g + r of query j
 #pragma unroll
-    for (int d = 0; d < kDh / 4; ++d) dst[d] = make_float4(acc[4 * d] * sc, acc[4 * d + 1] * sc, acc[4 * d + 2] * sc, acc[4 * d + 3] * sc);
+    for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(acc[dt][0] * sc, acc[dt][1] * sc, acc[dt][2] * sc, acc[dt][3] * sc);
 }
 
 // GLU + scatter-add + complex mask (:583, :616-624).  thread = (bt, fc); the bands that own bin fc are listed in CSR order (ascending
@@ -398,8 +426,8 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
         off[i + 1] = off[i] + d;
     }
     if (off[nb] != 2 * nsel) return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: sum(dim_inputs) must equal 2 * len(freq_indices)");
-    if (nb < 1 || nb > kMaxSeq) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: 1..256 bands supported");
-    if (T > kMaxSeq) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: at most 256 frames per clip (input_audio_length <= 112455); fold longer audio into windows");
+    if (nb < 1 || nb > kMaxBands) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: 1..1024 bands supported");
+    if (T > kMaxFrames) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: at most 8192 frames per clip; fold longer audio into windows");
     const Tensor* t_bs0 = find("bs_w_0");
     if (!t_bs0 || t_bs0->dims.size() != 2) return status();
     const int dim = t_bs0->dims[0];
@@ -529,7 +557,6 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
         hipMemcpy(e->d_i, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(e->d_ll, ll.data(), ll.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess)
         return bail(mfail(err, ADE_ERR_DEVICE, "upload of the band tables failed"));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxSeq * kDh * (int)sizeof(float));
     e->k_fwd = e->d_w + a_fwd; e->k_inv = e->d_w + a_inv; e->wsum = e->d_w + a_ws;
     e->tcos = e->d_w + a_tc; e->tsin = e->d_w + a_ts; e->fcos = e->d_w + a_fc; e->fsin = e->d_w + a_fs;
     e->me_w1t = e->d_w + a_m1; e->me_b1 = e->d_w + a_mb1; e->me_w2t = e->d_w + a_m2; e->me_b2 = e->d_w + a_mb2;
@@ -572,8 +599,8 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     const int ldq = 3 * di + heads;
     // invn holds 1 / |x_row| on entry (written by whoever produced X)
     launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, ScaleBiasStore{bufA, invn, w.in_b, ldq}, R, ldq, dim);                     // (:547-548)
-    hipLaunchKernelGGL(k_attention, dim3((unsigned)nseq, (unsigned)heads), dim3(256), (size_t)2 * n * kDh * sizeof(float), s, (const float*)bufA, AO, rc, rs, n,
-                       seq_stride, pos_stride, ldq, di, heads);                                                                     // (:549-560)
+    hipLaunchKernelGGL(k_attention, dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)bufA, AO, rc, rs, n,
+                       seq_stride, pos_stride, ldq, di);                                                                     // (:549-560)
     launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di);                               // (:561, :569)
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim);               // (:564)

@@ -116,3 +116,34 @@ def test_tail_padding_policies():
     assert short.shape == (1, 1000) and short[0, 300:].any()
     with pytest.raises(ValueError):
         cut_slices(a, 1000, 1000, "mirror")
+
+
+def test_wavio_roundtrip_plain_and_extensible(tmp_path):
+    import wave
+    from audio_denoiser_onnx_amd.wavio import read_pcm16, write_pcm16
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((2, 1001)) * 5000).astype(np.int16)
+    for ext in (False, True):
+        write_pcm16(tmp_path / "a.wav", x, 44100, extensible=ext)
+        y, sr = read_pcm16(tmp_path / "a.wav")
+        assert sr == 44100 and np.array_equal(x, y)
+    write_pcm16(tmp_path / "m.wav", x[0], 16000)
+    with wave.open(str(tmp_path / "m.wav"), "rb") as w:                       # the plain header is what the stdlib reads
+        assert (w.getnchannels(), w.getframerate(), w.getnframes()) == (1, 16000, 1001)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.wav").write_bytes(b"RIFF\0\0\0\0WAVX")
+        read_pcm16(tmp_path / "bad.wav")
+
+
+def test_melband_driver_slicing_and_tail_policy():
+    from audio_denoiser_onnx_amd.inference_melband import cut_slices
+    a = (np.arange(2 * 25, dtype=np.int16).reshape(2, 25) + 100)
+    s = cut_slices(a, 10, fold_active=True)
+    assert s.shape == (3, 2, 10) and np.array_equal(s[1, 1], a[1, 10:20]) and np.all(s[2, :, 5:] == 0)
+    n1 = cut_slices(a, 10, fold_active=False, rng=np.random.default_rng(5))
+    n2 = cut_slices(a, 10, fold_active=False, rng=np.random.default_rng(5))
+    assert np.array_equal(n1, n2) and np.array_equal(n1[:, :, :5][2], a[:, 20:]) and np.any(n1[2, :, 5:] != 0)
+    rms = np.sqrt(np.mean(a[:, -5:].astype(np.float32) ** 2))
+    assert abs(float(np.std(n1[2, :, 5:].astype(np.float32))) / rms - 1.0) < 0.6            # noise scaled to the tail's RMS
+    short = cut_slices(a[:, :4], 10, fold_active=True)
+    assert short.shape == (1, 2, 10) and np.all(short[0, :, 4:] == 0)

@@ -149,3 +149,54 @@ def test_gpu_batch_fold_matches_reference_fixture(fixture):
     d = out[0].astype(np.int32) - zf["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
     assert np.array_equal(out[0], out[1])                                    # second call of the batch: same clip, same result
+
+
+@pytest.mark.gpu
+def test_gpu_file_driver_slices_batches_and_trims(fixture, session, tmp_path):
+    """The reference driver's life-cycle on a stereo WAVEX file that is not a whole number of slices (seeded noise tail)."""
+    from audio_denoiser_onnx_amd import inference_melband as drv
+    from audio_denoiser_onnx_amd.wavio import read_pcm16, write_pcm16
+    z = fixture[0]
+    L = z["pcm_in"].shape[1]
+    rng = np.random.default_rng(7)
+    audio = np.concatenate((z["pcm_in"], (rng.standard_normal((2, L // 2)) * 2000).astype(np.int16)), axis=1)
+    write_pcm16(tmp_path / "in.wav", audio, 44100, extensible=True)
+    loaded = drv.load_stereo(tmp_path / "in.wav", 44100)
+    assert np.array_equal(loaded, audio)
+    out = drv.denoise(session, loaded, fold_active=False, rng=np.random.default_rng(3))
+    assert out.shape == audio.shape and out.dtype == np.int16
+    d = out[:, :L].astype(np.int32) - z["pcm_out"].astype(np.int32)              # first slice = the fixture clip
+    assert np.abs(d).max() <= 2
+    slices = drv.cut_slices(loaded, L, False, np.random.default_rng(3))           # second slice: tail + seeded RMS noise
+    want = session.run(None, {"noisy_audio": slices[1:2]})[0][0]
+    assert np.array_equal(out[:, L:], want[:, :L // 2])
+    write_pcm16(tmp_path / "out.wav", out, 44100, extensible=True)
+    back, sr = read_pcm16(tmp_path / "out.wav")
+    assert sr == 44100 and np.array_equal(back, out)
+
+
+@pytest.mark.gpu
+def test_gpu_long_clip_streams_keys_through_lds(fixture):
+    """One 1.5 s fold window (66150 samples, 151 frames): the time attention runs 3 query blocks x 3 key chunks (the last
+    partial), the frequency attention 60 keys.  HIP ("exact" tables) against the oracle with exactly reduced angles."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    from melband_oracle import MelBandOracle
+    z, _, w = fixture
+    L, T = 66150, 151
+    rng = np.random.default_rng(11)
+    t = np.arange(L) / 44100.0
+    tone = sum(np.sin(2 * np.pi * f * t + ph) / (k + 1) for k, (f, ph) in enumerate(zip((180, 440, 1250, 3900, 9000, 15500), rng.uniform(0, 6.28, 6))))
+    pcm = np.stack([(4000 * tone + 900 * rng.standard_normal(L)), (3000 * np.roll(tone, 7) + 900 * rng.standard_normal(L))]).astype(np.int16)
+    o = MelBandOracle(w, z["freq_indices"], z["dim_inputs"], T, int(z["depth"]), exact_dft=True)
+    want = o.process(pcm)
+    with InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(L, dft_tables="exact")) as sess:
+        assert sess.frames == T
+        got = sess.run(None, {"noisy_audio": pcm[None]})[0][0]
+        tokens = sess.tap("tokens", 60 * T * 384).reshape(60, T, 384)
+    err = np.abs(tokens - o.taps["tf_out"])
+    assert np.median(err) < 2e-5 and err.max() < 3e-2, (np.median(err), err.max())
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
+    assert np.abs(want).max() > 1000
