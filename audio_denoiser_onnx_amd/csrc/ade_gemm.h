@@ -1,6 +1,7 @@
-// ade_gemm.h — fp32 GEMM on the MI355X matrix cores with functor operands (shared by the STFT operator and DFSMN).
+// ade_gemm.h — fp32 GEMM on the MI355X matrix cores with functor operands (shared by the STFT operator, DFSMN and
+// Mel-Band-Roformer).
 //
-//   C(m, n) = sum_k A(m, k) * B(k, n)        exact fp32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain)
+//   C(m, n) = sum_k A(m, k) * B(k, n)        exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain over k)
 //
 // Operands and the result are FUNCTORS, so framing a waveform, reflecting its ends, masking a spectrum, squaring a
 // spectrum into a power spectrum, adding a bias or applying an activation all happen in the loaders / the store instead of
@@ -12,12 +13,20 @@
 //        kAlongN = true : consecutive n contiguous (row-major activations / tables);  false: consecutive k contiguous
 //   struct Store { __device__ void operator()(int m, int n, float v) const; };
 // The flags only choose which lanes fetch which elements of a slab (so that the fetches coalesce); out-of-range
-// elements are never requested.
+// elements are never requested.  A k-contiguous operand may also offer
+//        __device__ bool can_vec4(int K) const;  __device__ float4 vec4(int row, int k) const;     (k % 4 == 0, k + 3 < K)
+// and is then fetched as whole 64-byte lines (4 lanes x float4 per row and slab) instead of 16 scalar loads per lane --
+// the difference between being bound by the texture-cache line rate and by the matrix cores.
 // One 256-thread workgroup computes a 128 x 128 tile; each of its 4 wavefronts owns a 64 x 64 quadrant as 4 x 4 MFMA tiles
-// (64 accumulator VGPRs).  Slabs of 16 k are staged k-major in LDS with a row stride of 144 floats (144 mod 64 = 16):
-// the per-lane operand reads -- 16 consecutive rows x 4 consecutive k -- then cover all 64 banks exactly once.
+// (64 accumulator VGPRs).  Slabs of 16 k are staged ROW-major in LDS, 20 floats per row (16 + 4 padding):
+//   * the contraction index of MFMA step s is mapped to k = 4 g + s for lane group g = lane >> 4 (any bijection is legal
+//     as long as A and B agree), so the four steps' operands of a lane are ONE ds_read_b128 at row * 20 + 4 g;
+//   * 20 * j mod 64 takes 16 distinct multiples of 4 for j = 0..15, so the 16 lanes of a group cover all 64 banks once.
 #pragma once
 #include "ade_device.h"
+
+#include <cstdint>
+#include <type_traits>
 
 namespace ade {
 namespace gemm {
@@ -25,9 +34,15 @@ namespace gemm {
 using namespace dev;
 
 constexpr int kTM = 128, kTN = 128, kTK = 16;
-constexpr int kLds = 144;
+constexpr int kRow = 20;               // LDS floats per staged row
+constexpr int kSlab = kTM * kRow;      // floats per operand slab
 
-// one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kTK x kLds LDS slabs
+template <class T, class = void>
+struct HasVec4 : std::false_type {};
+template <class T>
+struct HasVec4<T, std::void_t<decltype(&T::vec4)>> : std::true_type {};
+
+// one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kSlab LDS slabs
 template <class AL, class BL, class ST>
 __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const ST& store, int M, int N, int K, int m_blk, int n_blk,
                                           float* As, float* Bs) {
@@ -40,51 +55,84 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
+    bool a_v4 = false, b_v4 = false;
+    if constexpr (AL::kAlongK && HasVec4<AL>::value) a_v4 = a_of.can_vec4(K);
+    if constexpr (!BL::kAlongN && HasVec4<BL>::value) b_v4 = b_of.can_vec4(K);
+
     // Software pipeline: the operand elements of slab k+1 are requested (into registers) before the 64 MFMAs of slab k
     // run and are written to LDS after them, so the HBM / L2 latency of a slab hides under the matrix work of the
-    // previous one.  Which lane fetches which element depends on the operand's contiguous direction (see the header).
-    float ra[8], rb[8];
+    // previous one.  Which lane fetches which element depends on the operand's contiguous direction (see the header);
+    // every variant leaves each lane with two runs of 4 consecutive k of one row, stored as two ds_write_b128.
+    float4 ra[2], rb[2];
     auto fetch = [&](int k0) {
-        if (AL::kAlongK) {          // thread = (row, half slab): 8 consecutive k of one row
-            const int r = tid >> 1, kh = (tid & 1) * 8, m = m_blk + r;
+        if (a_v4) {                         // lane = (row, quarter): 4 lanes read one row's 64-byte line; rows r and r + 64
+            if constexpr (AL::kAlongK && HasVec4<AL>::value) {
+                const int r = tid >> 2, k = k0 + 4 * (tid & 3);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ra[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
-        } else {                    // thread = (row, half slab): consecutive lanes = consecutive rows for each k
-            const int r = tid & 127, kh = (tid >> 7) * 8, m = m_blk + r;
+                for (int h = 0; h < 2; ++h) {
+                    const int m = m_blk + r + 64 * h;
+                    ra[h] = (m < M && k < K) ? a_of.vec4(m, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+        } else {                            // lane = (row, half slab): 8 k of one row; consecutive lanes = consecutive k-halves / rows
+            const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8, m = m_blk + r;
+            float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ra[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+            for (int u = 0; u < 8; ++u) t[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+            ra[0] = make_float4(t[0], t[1], t[2], t[3]);
+            ra[1] = make_float4(t[4], t[5], t[6], t[7]);
         }
-        if (BL::kAlongN) {          // thread = (column, half slab)
-            const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
+        if (b_v4) {
+            if constexpr (!BL::kAlongN && HasVec4<BL>::value) {
+                const int c = tid >> 2, k = k0 + 4 * (tid & 3);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rb[u] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
-        } else {                    // thread = (k, 16 column groups): consecutive lanes = consecutive k of one column
+                for (int h = 0; h < 2; ++h) {
+                    const int n = n_blk + c + 64 * h;
+                    rb[h] = (n < N && k < K) ? b_of.vec4(n, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+        } else if (BL::kAlongN) {           // lane = (column, half slab): consecutive lanes = consecutive columns
+            const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
+            rb[0] = make_float4(t[0], t[1], t[2], t[3]);
+            rb[1] = make_float4(t[4], t[5], t[6], t[7]);
+        } else {                            // lane = (k, column group): consecutive lanes = consecutive k of one column; columns cg + 16 u
             const int kk = tid & 15, cg = tid >> 4;
+            float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int n = n_blk + cg + 16 * u;
-                rb[u] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
+                t[u] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
             }
+            rb[0] = make_float4(t[0], t[1], t[2], t[3]);
+            rb[1] = make_float4(t[4], t[5], t[6], t[7]);
         }
     };
-    auto stash = [&]() {            // registers -> k-major LDS slabs (same lane maps as fetch)
-        if (AL::kAlongK) {
-            const int r = tid >> 1, kh = (tid & 1) * 8;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = ra[u];
+    auto stash = [&]() {                    // registers -> row-major LDS slabs (same lane maps as fetch)
+        if (a_v4) {
+            const int r = tid >> 2, kq = 4 * (tid & 3);
+            *reinterpret_cast<float4*>(As + r * kRow + kq) = ra[0];
+            *reinterpret_cast<float4*>(As + (r + 64) * kRow + kq) = ra[1];
         } else {
-            const int r = tid & 127, kh = (tid >> 7) * 8;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) As[(kh + u) * kLds + r] = ra[u];
+            const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8;
+            *reinterpret_cast<float4*>(As + r * kRow + kh) = ra[0];
+            *reinterpret_cast<float4*>(As + r * kRow + kh + 4) = ra[1];
         }
-        if (BL::kAlongN) {
+        if (b_v4) {
+            const int c = tid >> 2, kq = 4 * (tid & 3);
+            *reinterpret_cast<float4*>(Bs + c * kRow + kq) = rb[0];
+            *reinterpret_cast<float4*>(Bs + (c + 64) * kRow + kq) = rb[1];
+        } else if (BL::kAlongN) {
             const int c = tid & 127, kh = (tid >> 7) * 8;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) Bs[(kh + u) * kLds + c] = rb[u];
+            *reinterpret_cast<float4*>(Bs + c * kRow + kh) = rb[0];
+            *reinterpret_cast<float4*>(Bs + c * kRow + kh + 4) = rb[1];
         } else {
             const int kk = tid & 15, cg = tid >> 4;
+            const float t[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) Bs[kk * kLds + cg + 16 * u] = rb[u];
+            for (int u = 0; u < 8; ++u) Bs[(cg + 16 * u) * kRow + kk] = t[u];
         }
     };
     fetch(0);
@@ -92,18 +140,20 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
         stash();
         __syncthreads();
         if (k0 + kTK < K) fetch(k0 + kTK);
+        float4 a4[4], b4[4];                // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
 #pragma unroll
-        for (int ks = 0; ks < kTK; ks += 4) {       // lane (g, j16) supplies A[row 16 i + j16][k + g] and B[k + g][col 16 j + j16]
-            float a[4], b[4];
+        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[(ks + g) * kLds + wm + 16 * i + j16];
+        for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[(ks + g) * kLds + wn + 16 * j + j16];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x4(a[i], b[j], acc[i][j]);
-        }
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+            }
         __syncthreads();
     }
     // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
@@ -120,8 +170,8 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 
 template <class AL, class BL, class ST>
 __global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
-    __shared__ float As[kTK * kLds];
-    __shared__ float Bs[kTK * kLds];
+    __shared__ __attribute__((aligned(16))) float As[kSlab];
+    __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     gemm_tile(a_of, b_of, store, M, N, K, (int)blockIdx.y * kTM, (int)blockIdx.x * kTN, As, Bs);
 }
 
@@ -136,8 +186,8 @@ inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M,
 // outside a problem's own M x N exit at once, the grid is sized for the largest.
 template <class P>
 __global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
-    __shared__ float As[kTK * kLds];
-    __shared__ float Bs[kTK * kLds];
+    __shared__ __attribute__((aligned(16))) float As[kSlab];
+    __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     const auto q = prob((int)blockIdx.z);
     const int m_blk = (int)blockIdx.y * kTM, n_blk = (int)blockIdx.x * kTN;
     if (m_blk >= q.M || n_blk >= q.N) return;
@@ -151,17 +201,24 @@ inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, i
 }
 
 // ---- common functors ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool vec4_ok(const float* p, int ld, int K) {
+    return ((K | ld) & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
 struct RowMajorA {      // A(m, k) = p[m * ld + k]
     static constexpr bool kAlongK = true;
     const float* p;
     int ld;
     __device__ float operator()(int m, int k) const { return p[(size_t)m * ld + k]; }
+    __device__ bool can_vec4(int K) const { return vec4_ok(p, ld, K); }
+    __device__ float4 vec4(int m, int k) const { return *reinterpret_cast<const float4*>(p + (size_t)m * ld + k); }
 };
 struct WeightNK {       // B(k, n) = p[n * ld + k]: a torch Linear weight (out_features, in_features) used as x @ W^T
     static constexpr bool kAlongN = false;
     const float* p;
     int ld;
     __device__ float operator()(int k, int n) const { return p[(size_t)n * ld + k]; }
+    __device__ bool can_vec4(int K) const { return vec4_ok(p, ld, K); }
+    __device__ float4 vec4(int n, int k) const { return *reinterpret_cast<const float4*>(p + (size_t)n * ld + k); }
 };
 struct RowMajorB {      // B(k, n) = p[k * ld + n]
     static constexpr bool kAlongN = true;

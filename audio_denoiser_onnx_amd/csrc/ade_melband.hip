@@ -507,7 +507,24 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
             for (int n = 0; n < kNfftM; ++n) raw[(size_t)t * kHopM + n] += win[n] * win[n];
         for (int m = 0; m < in_len; ++m) wsum[m] = raw[(size_t)m + kNfftM / 2];
     }
-    auto half_round = [](float v) { return (float)(_Float16)v; };
+    auto half_round = [](float v) {      // float -> IEEE binary16 -> float, round to nearest even (|v| <= 1 here: cos / sin)
+        uint32_t u;
+        memcpy(&u, &v, 4);
+        const uint32_t sign = u & 0x80000000u;
+        uint32_t a = u & 0x7fffffffu;
+        if (a >= 0x38800000u) {          // a normal half: keep 10 mantissa bits
+            a += 0xfffu + ((a >> 13) & 1u);
+            a &= ~0x1fffu;
+        } else {                         // a subnormal half: multiples of 2^-24
+            float f;
+            memcpy(&f, &a, 4);
+            f = rintf(f * 16777216.0f) * (1.0f / 16777216.0f);
+            memcpy(&a, &f, 4);
+        }
+        u = sign | a;
+        memcpy(&v, &u, 4);
+        return v;
+    };
     std::vector<float> tcos((size_t)T * kDh), tsin((size_t)T * kDh), fcos((size_t)nb * kDh), fsin((size_t)nb * kDh);
     {
         float inv_freq[kDh / 2];
