@@ -168,11 +168,21 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs (id mod 8), each with its own 4 MB L2.  Renumbering them so that
+// CONSECUTIVE logical ids share an XCD keeps the tiles that re-read one strip of A (all n-tiles of an m-tile) and the whole
+// B operand of a batch entry inside one L2 instead of fetching them over the fabric from eight.  (Measured neutral on the
+// Mel-Band-Roformer shapes -- the 256 MB Infinity Cache already absorbs those re-reads -- kept because it is never worse.)
+__device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
+    const int per = total >> 3, rem = total & 7, xcd = w & 7, idx = w >> 3;
+    return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+}
+
 template <class AL, class BL, class ST>
 __global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
-    gemm_tile(a_of, b_of, store, M, N, K, (int)blockIdx.y * kTM, (int)blockIdx.x * kTN, As, Bs);
+    const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
+    gemm_tile(a_of, b_of, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, As, Bs);
 }
 
 template <class AL, class BL, class ST>
@@ -188,8 +198,11 @@ template <class P>
 __global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
-    const auto q = prob((int)blockIdx.z);
-    const int m_blk = (int)blockIdx.y * kTM, n_blk = (int)blockIdx.x * kTN;
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const int id = xcd_contiguous_id((int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z), gx * gy * (int)gridDim.z);
+    const int z = id / (gx * gy), in_z = id - z * gx * gy;
+    const auto q = prob(z);
+    const int m_blk = (in_z / gx) * kTM, n_blk = (in_z % gx) * kTN;
     if (m_blk >= q.M || n_blk >= q.N) return;
     gemm_tile(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
 }
