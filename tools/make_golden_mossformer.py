@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""MossFormer2-SS-16K golden vectors, produced by RUNNING THE REFERENCE's ``MOSSFORMER_SS`` (constructor AND forward,
+MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662) here.
+
+The reference builds its network from the ``clearvoice`` package (absent here) and a checkpoint (absent).  Its wrapper only
+READS attributes of that network (:130-395), so this tool hands it a stand-in module tree with the same attribute paths and
+the parameter shapes the export's own comments and index arithmetic imply (model 512, FLASH group 256 / qk 128 / v,u 1024 /
+depthwise k 17 / rotary 32, gated-FSMN inner 256 with a depth-2 dilated dense memory of order 20) -- the published
+MossFormer2 geometry -- and LAYERS layers instead of 24 (the wrapper takes the count from the tree).  The wrapper's
+constructor then fuses / folds them exactly as for the real model; afterwards every registered weight buffer is overwritten by
+this package's counter-based generator (audio_denoiser_onnx_amd/weightgen.py; 5 M floats per layer cannot be committed) and
+the reference's own forward runs on a slice of its own test mixture.
+Pinned: everything the forward computes from the fused buffers and the scalar attributes (eps, slopes, scales: stored in the
+fixture).  Not pinned: the fold algebra of the constructor on real checkpoints, and the stand-in geometry itself.
+
+    python tools/make_golden_mossformer.py     # writes tests/golden/mossformer_seed0_io.npz
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import make_golden_gtcrn as mg  # noqa: E402
+from ref_import import REF_ROOT, _stub_absent_modules  # noqa: E402
+from audio_denoiser_onnx_amd import mossformer  # noqa: E402
+
+LAYERS = 2
+WINDOW = 2408          # (2408 - 16) // 8 + 1 = 300 frames: two FLASH groups of 256, the second padded with 212 zero rows
+
+
+def import_namespace(length: int, fold: bool, window_seconds: float) -> dict:
+    _stub_absent_modules()
+    path = os.path.join(REF_ROOT, "MossFormer2_SS_16K", "Export_MossFormer2_SS_16K.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef):
+            keep.append(node)
+        elif isinstance(node, ast.Assign):
+            names = [t.id for t in node.targets if isinstance(t, ast.Name)]
+            if names and all(n.upper() == n for n in names):
+                if len(names) == 1 and names[0] in over:
+                    node = ast.parse(f"{names[0]} = {over[names[0]]!r}").body[0]
+                keep.append(node)
+    module = ast.Module(body=keep, type_ignores=[])
+    ast.fix_missing_locations(module)
+    ns = {"torch": torch, "F": torch.nn.functional, "__name__": "ref_export_mossformer"}
+    exec(compile(module, path, "exec"), ns)
+    return ns
+
+
+# ---- stand-in module tree (attribute paths read by MOSSFORMER_SS.__init__) -----------------------------------------------
+class ScaleNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.scale, self.eps = dim ** -0.5, eps
+        self.g = nn.Parameter(torch.ones(1))
+
+
+class DepthwiseConv(nn.Module):
+    def __init__(self, ch, k=17):
+        super().__init__()
+        self.conv = nn.Conv1d(ch, ch, k, padding=(k - 1) // 2, groups=ch, bias=False)
+
+
+class ConvModule(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.sequential = nn.Sequential(nn.Identity(), DepthwiseConv(ch))
+
+
+class FFConvM(nn.Module):
+    def __init__(self, d_in, d_out, norm):
+        super().__init__()
+        self.mdl = nn.Sequential(norm, nn.Linear(d_in, d_out), nn.SiLU(), ConvModule(d_out), nn.Dropout(0.1))
+
+
+class OffsetScale(nn.Module):
+    def __init__(self, dim, heads=4):
+        super().__init__()
+        self.gamma, self.beta = nn.Parameter(torch.ones(heads, dim)), nn.Parameter(torch.zeros(heads, dim))
+
+
+class Rotary(nn.Module):
+    def __init__(self, dim=32):
+        super().__init__()
+        self.freqs = nn.Parameter(1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+class Flash(nn.Module):
+    def __init__(self, dim=512, group_size=256, qk=128, expansion=4):
+        super().__init__()
+        hidden = dim * expansion
+        self.group_size = group_size
+        self.rotary_pos_emb = Rotary(min(32, qk))
+        self.to_hidden = FFConvM(dim, hidden, ScaleNorm(dim))
+        self.to_qk = FFConvM(dim, qk, ScaleNorm(dim))
+        self.qk_offset_scale = OffsetScale(qk, 4)
+        self.to_out = FFConvM(dim * 2, dim, ScaleNorm(dim * 2))
+
+
+class DilatedDense(nn.Module):
+    def __init__(self, depth, lorder, ch):
+        super().__init__()
+        for i in range(depth):
+            setattr(self, f"conv{i + 1}", nn.Conv2d(ch * (i + 1), ch, (2 * lorder - 1, 1), dilation=(2 ** i, 1), groups=ch, bias=False))
+            setattr(self, f"norm{i + 1}", nn.InstanceNorm2d(ch, affine=True))
+            setattr(self, f"prelu{i + 1}", nn.PReLU(ch))
+
+
+class UniDeepFsmnDilated(nn.Module):
+    def __init__(self, dim, hidden, lorder=20, depth=2):
+        super().__init__()
+        self.depth, self.lorder = depth, lorder
+        self.linear, self.project = nn.Linear(dim, hidden), nn.Linear(hidden, dim, bias=False)
+        self.conv = DilatedDense(depth, lorder, dim)
+
+
+class GatedFsmn(nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.to_u = FFConvM(inner, inner, nn.LayerNorm(inner))
+        self.to_v = FFConvM(inner, inner, nn.LayerNorm(inner))
+        self.fsmn = UniDeepFsmnDilated(inner, inner)
+
+
+class FsmnBlock(nn.Module):
+    def __init__(self, dim=512, inner=256):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv1d(dim, inner, 1), nn.PReLU())
+        self.norm1, self.norm2 = nn.LayerNorm(inner, eps=1e-8), nn.LayerNorm(inner, eps=1e-8)
+        self.gated_fsmn = GatedFsmn(inner)
+        self.conv2 = nn.Conv1d(inner, dim, 1)
+
+
+class PosEnc(nn.Module):
+    def __init__(self, dim=512):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(1))
+        self.register_buffer("inv_freq", 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+def stand_in_network(layers: int, dim: int = 512):
+    def bag(**kw):
+        m = nn.Module()
+        for k, v in kw.items():
+            setattr(m, k, v)
+        return m
+    gfsmn = bag(layers=nn.ModuleList([Flash(dim) for _ in range(layers)]), fsmn=nn.ModuleList([FsmnBlock(dim) for _ in range(layers)]))
+    intra = bag(mossformerM=gfsmn, norm=nn.LayerNorm(dim, eps=1e-8))
+    mdl = bag(intra_mdl=intra, intra_norm=nn.GroupNorm(1, dim, eps=1e-8))
+    mask_net = bag(norm=nn.GroupNorm(1, dim, eps=1e-8), conv1d_encoder=nn.Conv1d(dim, dim, 1, bias=False), pos_enc=PosEnc(dim), mdl=mdl,
+                   conv1d_out=nn.Conv1d(dim, dim * 2, 1), conv1_decoder=nn.Conv1d(dim, dim, 1, bias=False),
+                   output=nn.Sequential(nn.Conv1d(dim, dim, 1), nn.Tanh()), output_gate=nn.Sequential(nn.Conv1d(dim, dim, 1), nn.Sigmoid()),
+                   prelu=nn.PReLU())
+    net = bag(enc=bag(conv1d=nn.Conv1d(1, dim, 16, stride=8, bias=False)), dec=nn.ConvTranspose1d(dim, 1, 16, stride=8, bias=False), mask_net=mask_net)
+    net.num_spks = 2
+    with torch.no_grad():       # distinct scalar slopes so that a swapped one shows
+        mask_net.prelu.weight.fill_(0.2)
+        for i, fb in enumerate(gfsmn.fsmn):
+            fb.conv1[1].weight.fill_(0.15 + 0.02 * i)
+    return net.eval()
+
+
+def weight_scale(name: str, shape) -> float:
+    """Scales that keep every activation O(1) through the stack."""
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    if name in ("encoder_w",): return 0.8
+    if name in ("decoder_w",): return 0.3
+    if name.startswith(("fl_in_c_", "fl_out_c_", "fs_uv_c_")): return 0.15
+    if name.startswith("fs_mem_w_"): return 0.15
+    if name.startswith("qkos_gamma_"): return 0.6
+    if name.startswith(("qkos_beta_",)) or name.endswith("_b") or "_b_" in name: return 0.05
+    if name.startswith(("fs_mem_norm_w_", "fs_n1_w_", "fs_n2_w_")) or name in ("mm_norm_w", "intra_norm_w"): return 1.2
+    if name.startswith("fs_mem_prelu_"): return 0.3
+    if name.startswith("fl_in_w_"): return 2.0 * 1.7 * 22.6 / fan_in ** 0.5          # acts on a unit-norm row: x sqrt(dim) restores O(1)
+    if name.startswith("fl_out_w_"): return 1.7 * 32.0 / fan_in ** 0.5
+    return 1.7 / fan_in ** 0.5
+
+
+SCALAR_ATTRS = ("norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fl_norm_eps", "fl_out_norm_eps", "front_norm_eps", "mm_norm_eps",
+                "intra_norm_eps", "fs_ln_eps", "fs_n1_eps", "fs_n2_eps", "fs_mem_depth", "tail_prelu_alpha", "static_frames", "static_padding",
+                "static_window_batch", "static_window_output", "fl_inv_g", "static_inv_n")
+
+
+def build(ns, length, fold, window):
+    torch.manual_seed(0)
+    net = stand_in_network(LAYERS)
+    model = ns["MOSSFORMER_SS"](net, length, 16000, 16000, fold, window if fold else 0).eval()
+    spec = []
+    skip = ("inv_int16", "emb_pos", "rot_cos", "rot_sin", "rot_signed_sin", "rot_pair_index", "shift_pad", "pad_A4", "pad_VU", "gn_one", "gn_zero")
+    with torch.no_grad():
+        for name, buf in model.named_buffers():
+            if name in skip:
+                continue
+            scale = weight_scale(name, list(buf.shape))
+            v = mossformer.synthetic_tensor(name, list(buf.shape), scale, model.static_frames, model.flash_group_size)
+            buf.copy_(torch.from_numpy(v))
+            spec.append((name, list(buf.shape), scale))
+    scalars = {k: float(getattr(model, k)) for k in SCALAR_ATTRS}
+    scalars["fs_front_alpha"] = [float(a) for a in model.fs_front_alpha]
+    scalars["fs_mem_paddings"] = [int(p) for p in model.fs_mem_paddings]
+    scalars["fs_mem_dilations"] = [int(p) for p in model.fs_mem_dilations]
+    scalars["fs_mem_norm_eps"] = [float(p) for p in model.fs_mem_norm_eps]
+    return model, spec, scalars
+
+
+def read_mix(start, length):
+    from scipy.io import wavfile
+    sr, data = wavfile.read(os.path.join(REF_ROOT, "Test_Examples", "separation", "mixed_speech.wav"))
+    data = data.reshape(len(data), -1)[:, 0]
+    assert data.dtype == np.int16, data.dtype
+    if sr != 16000:
+        data = data[::sr // 16000]
+    return np.ascontiguousarray(data[start:start + length])
+
+
+def main():
+    ns = import_namespace(WINDOW, False, 1.5)
+    model, spec, scalars = build(ns, WINDOW, False, 0)
+    print("buffers overwritten:", len(spec), "tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats; frames", model.static_frames,
+          "padding", model.static_padding)
+    pcm = read_mix(24000, WINDOW)
+    taps = {}
+    orig = model._run_mdl
+    def tapped(mdl_input, n):
+        taps["mdl_in"] = mdl_input.clone()
+        out = orig(mdl_input, n)
+        taps["mdl_out"] = out.clone()
+        return out
+    model._run_mdl = tapped
+    with torch.inference_mode():
+        outs = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy()))
+    out = np.stack([o.numpy().reshape(-1) for o in outs])
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_seed0_io.npz"), pcm_in=pcm, pcm_out=out, layers=np.int64(LAYERS), spec=np.array(json.dumps(spec)),
+                        scalars=np.array(json.dumps(scalars)), mdl_in=taps["mdl_in"][0].numpy()[:, ::7], mdl_out=taps["mdl_out"][0].numpy()[:, ::7])
+    print("out", out.shape, np.abs(out).max(axis=1), "in max", np.abs(pcm).max(), "mdl_in rms", float(taps["mdl_in"].pow(2).mean().sqrt()),
+          "mdl_out rms", float(taps["mdl_out"].pow(2).mean().sqrt()))
+
+    # USE_BATCH_FOLD = True: 3 windows of 2408 samples folded into the batch (per-window normalisation, :403-423, :572-576)
+    ns = import_namespace(3 * WINDOW - 500, True, WINDOW / 16000.0)
+    assert ns["FOLD_WINDOW_LENGTH"] == WINDOW and ns["EXPORT_AUDIO_LENGTH"] == 3 * WINDOW, (ns["FOLD_WINDOW_LENGTH"], ns["EXPORT_AUDIO_LENGTH"])
+    model, spec2, scalars2 = build(ns, 3 * WINDOW - 500, True, WINDOW)
+    assert spec2 == spec
+    pcm = read_mix(40000, 3 * WINDOW)
+    pcm[2 * WINDOW + 1200:] = 0                                                # a partly silent last window (the zero-padded tail of a file)
+    with torch.inference_mode():
+        outs = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy()))
+    out = np.stack([o.numpy().reshape(-1) for o in outs])
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_seed0_fold_io.npz"), pcm_in=pcm, pcm_out=out, input_audio_length=np.int64(3 * WINDOW - 500),
+                        fold_window_length=np.int64(WINDOW))
+    print("fold out", out.shape, np.abs(out).max(axis=1))
+
+
+if __name__ == "__main__":
+    main()
