@@ -50,7 +50,7 @@ struct ade_engine {
     std::map<std::string, Tensor> tensors;
 
     ade::SubEngine* sub = nullptr;        // model_family "dfsmn" / "mel_band_roformer": a sub-engine (everything below is GTCRN's)
-    int channels = 1;                     // PCM rows per batch item; in_len / out_len below count one batch item (channels * samples)
+    int channels = 1, n_outputs = 1;      // in_len / out_len below count one batch item: channels * samples in, n_outputs * channels * samples out
 
     hipStream_t stream = nullptr;
     float* d_weights = nullptr;
@@ -785,10 +785,11 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (it == e->meta.end() || it->second.empty())
             return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
     }
-    const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer";
-    if (fam_dfsmn || fam_melband) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
+    const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer",
+               fam_moss = e->meta["model_family"] == "mossformer2_ss";
+    if (fam_dfsmn || fam_melband || fam_moss) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
         const std::string fam = e->meta["model_family"];
-        const long rate = fam_dfsmn ? 48000 : 44100;
+        const long rate = fam_dfsmn ? 48000 : fam_melband ? 44100 : 16000;
         bool dyn_d = false, fold_d = false;
         if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
@@ -804,7 +805,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (resampling path not implemented)"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
             return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
-        if (Ld < 1920 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
+        if (Ld < 16 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
         long sub_win = 1;
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
             long fw = 0;    //                                                            (Export_MelBandRoformer.py:47-51, 644-647)
@@ -835,13 +836,15 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
-        const int rc = fam_dfsmn ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
-                                 : ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr);
+        const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
+                       : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
+                                     : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
+        e->n_outputs = e->sub->n_outputs();
         e->in_len = e->sub->in_len() * e->channels;
         e->T = e->sub->frames();
-        e->out_len = e->sub->out_len() * e->channels;
+        e->out_len = e->sub->out_len() * e->channels * e->n_outputs;
         e->sample_rate = (int)rate;
         e->blob_storage.clear();
         e->blob_storage.shrink_to_fit();
@@ -850,7 +853,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return ADE_OK;
     }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer, mossformer2_ss)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
@@ -938,9 +941,9 @@ ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
     d->abi_version = ADE_ABI_VERSION;
     d->in_channels = h->channels;
     d->out_channels = h->channels;
-    d->n_outputs = 1;
+    d->n_outputs = h->n_outputs;
     d->in_len = h->in_len / h->channels * h->n_win;       // per channel; what one call sees (the fold is internal)
-    d->out_len = h->out_len / h->channels * h->n_win;
+    d->out_len = h->out_len / (h->channels * h->n_outputs) * h->n_win;
     d->in_sample_rate = d->out_sample_rate = d->model_sample_rate = h->sample_rate;
     d->frames = h->T;
     d->max_batch = h->capacity / h->n_win;

@@ -149,6 +149,7 @@ struct SubEngine {
     virtual int in_len() const = 0;      // samples per channel row
     virtual int out_len() const = 0;
     virtual int channels() const { return 1; }
+    virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][channels()][out_len()]
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status
     virtual int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) = 0;
     virtual int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) = 0;
@@ -156,6 +157,8 @@ struct SubEngine {
 // model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip
 int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err);
 // model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
+// model_family "mossformer2_ss" (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662), csrc/ade_mossformer.hip
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

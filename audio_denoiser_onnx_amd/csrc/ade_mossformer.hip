@@ -1,0 +1,762 @@
+// ade_mossformer.hip — MossFormer2-SS-16K (two-speaker separation, 16 kHz) on the MI355X: SURVEY.md section 8 row a18.
+//
+// Reference: MOSSFORMER_SS.forward / _run_mdl / norm_audio / group_norm_static over the FUSED buffers its constructor registers
+// (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:398-662; buffers :130-395):
+//   int16 window -> two-stage RMS normalisation -> Conv1d(1, 512, k 16, s 8) + ReLU -> window norm + 1x1 conv + sinusoid positions
+//   -> L x [ FLASH block: token shift, ScaleNorm, fused Linear(512 -> 2048 | 128) + SiLU + depthwise k 17, OffsetScale x 4 + rotary,
+//            quadratic ReLU^2 attention inside groups of 256 tokens + global linear attention, u/v gating, ScaleNorm, Linear + SiLU +
+//            depthwise, residual ;
+//            gated FSMN block: 1x1 + PReLU, LayerNorm, fused u|v Linear + SiLU + depthwise, Linear-ReLU-Linear, two dilated dense
+//            memory convolutions (39 taps, dilation 1 / 2) each with InstanceNorm + PReLU, gate, LayerNorm, 1x1, residual ]
+//   -> LayerNorm, window norm + affine, skip -> PReLU -> per speaker tanh x sigmoid gate, 1x1 + ReLU, x encoder output
+//   -> ConvTranspose1d(512, 1, k 16, s 8) -> per (window, speaker) RMS restore -> int32 truncate, clamp -> int16.
+// Tokens are rows: every activation is (row, channels) row-major with row = window * frames + t, so all 1x1 convolutions, Linears
+// and both attention products are the functor GEMM of csrc/ade_gemm.h (exact fp32 on the matrix cores), with
+//   * ScaleNorm / window-norm folded into GEMM stores (v * inv_norm[row] + bias; v * rstd - rstd * mean * rowsum(W) + bias),
+//   * the token shift, PCM framing + normalisation, zero padding of attention groups, PReLU and the speaker gate as operand loaders,
+//   * SiLU / ReLU / ReLU^2 / residual adds / the encoder-mask product as stores,
+//   * the per-group attention products and the per-window linear attention as batched launches (blockIdx.z).
+// What is not a matrix product -- depthwise convolutions over time, row norms, per-channel instance norms, the RMS stages --
+// are small bandwidth-bound kernels below.
+#include "ade_gemm.h"
+#include "ade_internal.h"
+#include "../../include/ade.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ade {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kDim = 512, kHalf = 256, kVu = 1024, kVu2 = 2048, kQk = 128, kIn = kVu2 + kQk /* 2176 */, kInner = 256;
+constexpr int kEncK = 16, kEncS = 8, kDw = 17, kMemK = 39, kSpk = 2;
+enum Hyper { hNormFactor, hGroup, hRotDim, hDwPad, hFlNormEps, hFlOutNormEps, hFrontEps, hMmEps, hIntraEps, hFsLnEps, hFsN1Eps, hFsN2Eps,
+             hMemDepth, hTailAlpha, hMemNormEps, hLorder, hCount };
+
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide sum of one float per thread (blockDim.x <= 1024); every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// ---- RMS stages --------------------------------------------------------------------------------------------------------------
+// norm_audio (:403-423): one workgroup per window.  gains[b] = {scalar, scalarx}; rms_in[b] = rms * g * 1 / (g + eps) * 32767.
+__global__ __launch_bounds__(1024) void k_norm_audio(const int16_t* __restrict__ pcm, int W, float norm_factor, float2* __restrict__ gains,
+                                                     float* __restrict__ rms_in) {
+    __shared__ float red[16];
+    const int16_t* x = pcm + (size_t)blockIdx.x * W;
+    const float eps = 1e-6f;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) { const float v = (float)x[i] * (1.0f / 32768.0f); s += v * v; }
+    const float avg = block_sum(s, red) / (float)W;
+    float hs = 0.0f, hc = 0.0f;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const float v = (float)x[i] * (1.0f / 32768.0f), p = v * v;
+        if (p > avg) { hs += p; hc += 1.0f; }
+    }
+    hs = block_sum(hs, red);
+    hc = block_sum(hc, red);
+    if (threadIdx.x == 0) {
+        const float rms = sqrtf(avg), scalar = norm_factor / (rms + eps);
+        const float high = sqrtf(hs / fmaxf(hc, 1.0f)), scalarx = norm_factor / (high * scalar + eps);
+        const float gp = scalar * scalarx, undo = 1.0f / (gp + eps);
+        gains[blockIdx.x] = make_float2(scalar, scalarx);
+        rms_in[blockIdx.x] = rms * gp * undo * 32767.0f;
+    }
+}
+
+// mean / rstd of one window's (frames x 512) block, two passes (group_norm_static :398-401); one workgroup per window
+__global__ __launch_bounds__(1024) void k_window_stats(const float* __restrict__ x, long long count, float eps, float2* __restrict__ stats) {
+    __shared__ float red[16];
+    const float* p = x + (size_t)blockIdx.x * count;
+    float s = 0.0f;
+    for (long long i = threadIdx.x; i < count; i += blockDim.x) s += p[i];
+    const float mean = block_sum(s, red) / (float)count;
+    float q = 0.0f;
+    for (long long i = threadIdx.x; i < count; i += blockDim.x) { const float d = p[i] - mean; q += d * d; }
+    const float var = block_sum(q, red) / (float)count;
+    if (threadIdx.x == 0) stats[blockIdx.x] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+// ---- operand / store functors ------------------------------------------------------------------------------------------------
+struct EncFrameA {             // A((b, t), k) = normalised sample 8 t + k of window b (:579-582); the two gains apply in the reference's order
+    static constexpr bool kAlongK = true;
+    const int16_t* pcm;
+    const float2* gains;
+    int W, n;
+    __device__ float operator()(int m, int k) const {
+        const int b = m / n, t = m - b * n;
+        const float2 g = gains[b];
+        return (((float)pcm[(size_t)b * W + kEncS * t + k] * (1.0f / 32768.0f)) * g.x) * g.y;
+    }
+};
+template <int ACT>             // 0 none, 1 relu, 2 silu, 3 leaky(alpha)
+struct BiasActRowStore {       // out[m * ld + n] = act(v + bias[n])
+    float* out;
+    const float* bias;         // may be null
+    int ld;
+    float alpha;
+    __device__ void operator()(int m, int n, float v) const {
+        if (bias) v += bias[n];
+        if (ACT == 1) v = fmaxf(v, 0.0f);
+        if (ACT == 2) v = silu(v);
+        if (ACT == 3) v = v >= 0.0f ? v : v * alpha;
+        out[(size_t)m * ld + n] = v;
+    }
+};
+struct FrontStore {            // window norm folded: H = MI = v * rstd - rstd * mean * rowsum(W)[n] + b[n] + emb_pos[n][t]   (:586-591)
+    float *h, *mi;
+    const float2* stats;
+    const float *wsum, *bias, *emb;     // emb: (512, n_frames)
+    int n;
+    __device__ void operator()(int m, int c, float v) const {
+        const int b = m / n, t = m - b * n;
+        const float2 st = stats[b];
+        const float y = (v * st.y - st.y * st.x * wsum[c] + bias[c]) + emb[(size_t)c * n + t];
+        h[(size_t)m * kDim + c] = y;
+        mi[(size_t)m * kDim + c] = y;
+    }
+};
+struct ShiftA {                // token shift (:454-456): first half of the channels comes from the previous frame of the same window
+    static constexpr bool kAlongK = true;
+    const float* h;
+    int n;
+    __device__ float operator()(int m, int k) const {
+        if (k >= kHalf) return h[(size_t)m * kDim + k];
+        return (m % n) ? h[(size_t)(m - 1) * kDim + k] : 0.0f;
+    }
+    __device__ bool can_vec4(int) const { return true; }
+    __device__ float4 vec4(int m, int k) const {
+        if (k >= kHalf) return *reinterpret_cast<const float4*>(h + (size_t)m * kDim + k);
+        return (m % n) ? *reinterpret_cast<const float4*>(h + (size_t)(m - 1) * kDim + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+};
+struct ScaleSiluStore {        // silu(v * inv[m] + bias[n])   (ScaleNorm folded, :458-459, :502-503)
+    float* out;
+    const float* inv;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = silu(v * inv[m] + bias[n]); }
+};
+struct Relu2Store {            // attn = relu(q k^T)^2   (:487-488)
+    float* out;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const { const float r = fmaxf(v, 0.0f); out[(size_t)m * ld + n] = r * r; }
+};
+struct PaddedRowsB {           // B(k, n) = rows[(row0 + k) * ld + n] for k < valid, else 0: the zero-padded tail of the last attention group (:480-484)
+    static constexpr bool kAlongN = true;
+    const float* rows;
+    int ld, valid;
+    __device__ float operator()(int k, int n) const { return k < valid ? rows[(size_t)k * ld + n] : 0.0f; }
+};
+struct ColMajorA {             // A(m, k) = p[k * ld + m]: lin_k^T (:490), consecutive m contiguous
+    static constexpr bool kAlongK = false;
+    const float* p;
+    int ld;
+    __device__ float operator()(int m, int k) const { return p[(size_t)k * ld + m]; }
+};
+struct GuardedStore {          // out[m * ld + n] (=|+=) v for m < valid
+    float* out;
+    int ld, valid, accumulate;
+    __device__ void operator()(int m, int n, float v) const {
+        if (m >= valid) return;
+        float* p = out + (size_t)m * ld + n;
+        *p = accumulate ? *p + v : v;
+    }
+};
+struct ResidualBiasStore {     // x[m][n] += v + bias[n]   (:541)
+    float* x;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const {
+        float* p = x + (size_t)m * ld + n;
+        *p = *p + (v + bias[n]);
+    }
+};
+struct LeakyA {                // A(m, k) = leaky_relu(x[m][k], alpha)   (:599)
+    static constexpr bool kAlongK = true;
+    const float* x;
+    int ld;
+    float alpha;
+    __device__ float operator()(int m, int k) const { const float v = x[(size_t)m * ld + k]; return v >= 0.0f ? v : v * alpha; }
+    __device__ bool can_vec4(int) const { return true; }
+    __device__ float4 vec4(int m, int k) const {
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * ld + k);
+        v.x = v.x >= 0.0f ? v.x : v.x * alpha; v.y = v.y >= 0.0f ? v.y : v.y * alpha;
+        v.z = v.z >= 0.0f ? v.z : v.z * alpha; v.w = v.w >= 0.0f ? v.w : v.w * alpha;
+        return v;
+    }
+};
+struct SpeakerGateA {          // A((spk, row), k) = tanh(gp[row][spk*1024 + k]) * sigmoid(gp[row][spk*1024 + 512 + k])   (:601-605)
+    static constexpr bool kAlongK = true;
+    const float* gp;
+    int R;
+    __device__ float operator()(int m, int k) const {
+        const int spk = m / R, row = m - spk * R;
+        const float* p = gp + (size_t)row * (kSpk * 2 * kDim) + spk * 2 * kDim;
+        return tanhf(p[k]) * sigm(p[kDim + k]);
+    }
+};
+struct MaskEncStore {          // sep[(spk, row)][c] = relu(v) * x_enc[row][c]   (:606-611)
+    float* sep;
+    const float* xe;
+    int R;
+    __device__ void operator()(int m, int c, float v) const {
+        const int row = m % R;
+        sep[(size_t)m * kDim + c] = fmaxf(v, 0.0f) * xe[(size_t)row * kDim + c];
+    }
+};
+
+template <class A, class B, class S>
+struct Prob { A a; B b; S st; int M, N, K; };
+struct QuadScoreProb {         // z = (window, group): ATT_z = relu(quad_q quad_k^T)^2, 256 x 256 x 128
+    const float *qq, *qk;
+    float* att;
+    int g;
+    __device__ Prob<gemm::RowMajorA, gemm::WeightNK, Relu2Store> operator()(int z) const {
+        const size_t o = (size_t)z * g * kQk;
+        return {gemm::RowMajorA{qq + o, kQk}, gemm::WeightNK{qk + o, kQk}, Relu2Store{att + (size_t)z * g * g, g}, g, g, kQk};
+    }
+};
+struct QuadOutProb {           // z = (window, group): AO rows of the group = ATT_z x value rows (zero beyond the window's frames)
+    const float *att, *vu;
+    float* ao;
+    int g, groups, n;
+    __device__ Prob<gemm::RowMajorA, PaddedRowsB, GuardedStore> operator()(int z) const {
+        const int b = z / groups, gi = z - b * groups, valid = min(g, n - gi * g);
+        const size_t row0 = (size_t)b * n + (size_t)gi * g;
+        return {gemm::RowMajorA{att + (size_t)z * g * g, g}, PaddedRowsB{vu + row0 * kIn, kIn, valid}, GuardedStore{ao + row0 * kVu2, kVu2, valid, 0}, g, kVu2, g};
+    }
+};
+struct LinKvProb {             // z = window: LKV_z (128 x 2048) = lin_k^T x value rows   (:490-492; padded keys are zero rows, so K = frames)
+    const float *lk, *vu;
+    float* lkv;
+    int n, padded;
+    __device__ Prob<ColMajorA, gemm::RowMajorB, GuardedStore> operator()(int z) const {
+        return {ColMajorA{lk + (size_t)z * padded * kQk, kQk}, gemm::RowMajorB{vu + (size_t)z * n * kIn, kIn},
+                GuardedStore{lkv + (size_t)z * kQk * kVu2, kVu2, kQk, 0}, kQk, kVu2, n};
+    }
+};
+struct LinOutProb {            // z = window: AO rows += lin_q x LKV_z   (:495-497)
+    const float *lq, *lkv;
+    float* ao;
+    int n, padded;
+    __device__ Prob<gemm::RowMajorA, gemm::RowMajorB, GuardedStore> operator()(int z) const {
+        return {gemm::RowMajorA{lq + (size_t)z * padded * kQk, kQk}, gemm::RowMajorB{lkv + (size_t)z * kQk * kVu2, kVu2},
+                GuardedStore{ao + (size_t)z * n * kVu2, kVu2, n, 1}, n, kVu2, kQk};
+    }
+};
+
+// ---- row-wise and time-wise kernels ------------------------------------------------------------------------------------------
+// inv[m] = 1 / max(|token-shifted row m|, eps)   (:457)
+__global__ __launch_bounds__(256) void k_shift_invnorm(const float* __restrict__ h, float* __restrict__ inv, int rows, int n, float eps) {
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= rows) return;
+    const bool first = (m % n) == 0;
+    float s = 0.0f;
+    for (int k = lane; k < kDim; k += 64) {
+        const float v = k >= kHalf ? h[(size_t)m * kDim + k] : (first ? 0.0f : h[(size_t)(m - 1) * kDim + k]);
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) inv[m] = 1.0f / fmaxf(sqrtf(s), eps);
+}
+
+// y[m][c] = (res ? res[m][c] : 0) + x[m][c] + sum_k w[c][k] * x[m + k - pad][c], frames outside the window read as zero (:460, :504-505, :516)
+__global__ __launch_bounds__(256) void k_dwconv_res(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ res,
+                                                    float* __restrict__ y, int C, int n, int pad, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long long m = i / C;
+    const int t = (int)(m % n);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kDw; ++k) {
+        const int tt = t + k - pad;
+        if (tt >= 0 && tt < n) s += w[c * kDw + k] * x[(size_t)(m + k - pad) * C + c];
+    }
+    const float v = x[i] + s;
+    y[i] = res ? res[i] + v : v;
+}
+
+// OffsetScale x 4 + rotary on the first rot_dim channels (:466-474): heads[h][(b * padded + t)][128]; rows t >= n are zero
+__global__ __launch_bounds__(128) void k_offset_rotary(const float* __restrict__ proj, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ rcos, const float* __restrict__ rsin, float* __restrict__ heads, int n,
+                                                       int padded, int rot_dim, long long head_stride) {
+    const int d = threadIdx.x, tp = blockIdx.x, b = blockIdx.y;
+    const size_t o = ((size_t)b * padded + tp) * kQk + d;
+    if (tp >= n) {
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) heads[hd * head_stride + o] = 0.0f;
+        return;
+    }
+    const float* q = proj + ((size_t)b * n + tp) * kIn + kVu2;
+    const float v = q[d], vp = q[d ^ 1];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        float s = v * gamma[hd * kQk + d] + beta[hd * kQk + d];
+        if (d < rot_dim) {
+            const float sp = vp * gamma[hd * kQk + (d ^ 1)] + beta[hd * kQk + (d ^ 1)];
+            s = s * rcos[tp * rot_dim + d] + sp * rsin[tp * rot_dim + d];          // pair swap, sign folded into rsin (:196-205)
+        }
+        heads[hd * head_stride + o] = s;
+    }
+}
+
+// gate (:498-499) + ScaleNorm statistics (:502): g[m][j] = (att_u * v) * sigmoid(att_v * u); inv[m] = 1 / max(|g_m|, eps); one wave per row
+__global__ __launch_bounds__(256) void k_gate_invnorm(const float* __restrict__ ao, const float* __restrict__ proj, float* __restrict__ g,
+                                                      float* __restrict__ inv, int rows, float eps) {
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= rows) return;
+    const float* a = ao + (size_t)m * kVu2;
+    const float* p = proj + (size_t)m * kIn;
+    float s = 0.0f;
+    for (int j = lane; j < kVu; j += 64) {
+        const float o = (a[kVu + j] * p[j]) * sigm(a[j] * p[kVu + j]);
+        g[(size_t)m * kVu + j] = o;
+        s += o * o;
+    }
+    s = wave_sum(s);
+    if (lane == 0) inv[m] = 1.0f / fmaxf(sqrtf(s), eps);
+}
+
+// gf = LayerNorm(c1; w, b, eps1) and xn = LayerNorm(gf; no affine, eps2) over 256 channels (:510-512); one wave per row
+__global__ __launch_bounds__(256) void k_ln_pair(const float* __restrict__ c1, const float* __restrict__ w, const float* __restrict__ b,
+                                                 float* __restrict__ gf, float* __restrict__ xn, int rows, float eps1, float eps2) {
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= rows) return;
+    float v[4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = c1[(size_t)m * kInner + lane + 64 * i]; s += v[i]; }
+    const float mu = wave_sum(s) * (1.0f / kInner);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] -= mu; q += v[i] * v[i]; }
+    const float r = 1.0f / sqrtf(wave_sum(q) * (1.0f / kInner) + eps1);
+    s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = v[i] * r * w[lane + 64 * i] + b[lane + 64 * i];
+        gf[(size_t)m * kInner + lane + 64 * i] = v[i];
+        s += v[i];
+    }
+    const float mu2 = wave_sum(s) * (1.0f / kInner);
+    q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] -= mu2; q += v[i] * v[i]; }
+    const float r2 = 1.0f / sqrtf(wave_sum(q) * (1.0f / kInner) + eps2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[(size_t)m * kInner + lane + 64 * i] = v[i] * r2;
+}
+
+// dilated dense memory convolution j (:521-527): out[m][g] = sum_{c < cin} sum_k w[g][c][k] * dense[g * cin + c][t + k * dil - pad];
+// dense = [newer memory outputs ..., xp] concatenated on channels (:534-535): channel ch < 256 * (cin - 1) lives in `mem`, else in `xp`
+__global__ __launch_bounds__(256) void k_mem_conv(const float* __restrict__ xp, const float* __restrict__ mem, const float* __restrict__ w,
+                                                  float* __restrict__ out, int n, int cin, int dil, int pad, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % kInner);
+    const long long m = i / kInner;
+    const int t = (int)(m % n);
+    float s = 0.0f;
+    for (int c = 0; c < cin; ++c) {
+        const int ch = g * cin + c;
+        const float* src = ch < kInner * (cin - 1) ? mem + ch : xp + (ch - kInner * (cin - 1));
+        const float* wr = w + ((size_t)g * cin + c) * kMemK;
+        for (int k = 0; k < kMemK; ++k) {
+            const int tt = t + k * dil - pad;
+            if (tt >= 0 && tt < n) s += wr[k] * src[(size_t)(m + k * dil - pad) * kInner];
+        }
+    }
+    out[i] = s;
+}
+
+// per (window, channel) mean / rstd over time (F.instance_norm :528-531); grid (windows, 256 / 64), block (64 channels x 4 time slices)
+__global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int n, float eps, float2* __restrict__ stats) {
+    __shared__ float red[4][64];
+    const int c = (int)blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, b = blockIdx.x;
+    const float* p = x + (size_t)b * n * kInner + c;
+    float s = 0.0f;
+    for (int t = sl; t < n; t += 4) s += p[(size_t)t * kInner];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)n;
+    __syncthreads();
+    float q = 0.0f;
+    for (int t = sl; t < n; t += 4) { const float d = p[(size_t)t * kInner] - mean; q += d * d; }
+    red[sl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (sl == 0) {
+        const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)n;
+        stats[(size_t)b * kInner + c] = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
+// instance-norm affine + per-channel PReLU (:528-533), in place
+__global__ __launch_bounds__(256) void k_mem_norm_prelu(float* __restrict__ x, const float2* __restrict__ stats, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ slope, int n, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % kInner);
+    const long long win = i / kInner / n;
+    const float2 st = stats[(size_t)win * kInner + c];
+    const float v = (x[i] - st.x) * st.y * w[c] + b[c];
+    x[i] = v >= 0.0f ? v : v * slope[c];
+}
+
+// xu += memory; y = xv * xu + gf; n2 = LayerNorm(y; w, b, eps)   (:536-540); one wave per row
+__global__ __launch_bounds__(256) void k_fsmn_combine(const float* __restrict__ uv, const float* __restrict__ mem, const float* __restrict__ gf,
+                                                      const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ n2, int rows, float eps) {
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= rows) return;
+    float v[4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const float xu = uv[(size_t)m * kDim + c] + mem[(size_t)m * kInner + c];
+        v[i] = uv[(size_t)m * kDim + kInner + c] * xu + gf[(size_t)m * kInner + c];
+        s += v[i];
+    }
+    const float mu = wave_sum(s) * (1.0f / kInner);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] -= mu; q += v[i] * v[i]; }
+    const float r = 1.0f / sqrtf(wave_sum(q) * (1.0f / kInner) + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n2[(size_t)m * kInner + lane + 64 * i] = v[i] * r * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+// LayerNorm over 512 channels with affine (:544), out of place; one wave per row
+__global__ __launch_bounds__(256) void k_ln512(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                               int rows, float eps) {
+    const int m = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= rows) return;
+    float v[8];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = x[(size_t)m * kDim + lane + 64 * i]; s += v[i]; }
+    const float mu = wave_sum(s) * (1.0f / kDim);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] -= mu; q += v[i] * v[i]; }
+    const float r = 1.0f / sqrtf(wave_sum(q) * (1.0f / kDim) + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[(size_t)m * kDim + lane + 64 * i] = v[i] * r * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+// window norm + per-channel affine + skip (:549-551): out = (x - mean_b) * rstd_b * w[c] + b[c] + mi
+__global__ __launch_bounds__(256) void k_window_affine_skip(const float* __restrict__ x, const float2* __restrict__ stats, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ mi, float* __restrict__ out, int n,
+                                                            long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % kDim);
+    const float2 st = stats[i / kDim / n];
+    out[i] = ((x[i] - st.x) * st.y * w[c] + b[c]) + mi[i];
+}
+
+// ConvTranspose1d overlap-add (every sample has <= 2 frames), per (window, speaker) RMS restore, int32 truncate + clamp (:612-645).
+// grid = windows * 2 (window-major, speaker-minor); PCM out is [call][speaker][n_win * W] (:655-656).
+__global__ __launch_bounds__(1024) void k_decode_restore(const float* __restrict__ fr, const float* __restrict__ rms_in, int16_t* __restrict__ pcm,
+                                                         float* __restrict__ f32, float* __restrict__ wav_ws, int W, int n, int R, int n_win) {
+    __shared__ float red[16];
+    const int b = blockIdx.x / kSpk, spk = blockIdx.x % kSpk;
+    const float* rows = fr + ((size_t)spk * R + (size_t)b * n) * kEncK;
+    float* wav = wav_ws + (size_t)blockIdx.x * W;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int t1 = min(i / kEncS, n - 1), t0 = t1 - 1;
+        float v = 0.0f;
+        if (t0 >= 0 && i - kEncS * t0 < kEncK) v += rows[(size_t)t0 * kEncK + (i - kEncS * t0)];
+        if (i - kEncS * t1 < kEncK) v += rows[(size_t)t1 * kEncK + (i - kEncS * t1)];
+        wav[i] = v;
+        s += v * v;
+    }
+    const float rms_out = sqrtf(block_sum(s, red) / (float)W);
+    const float gain = rms_out > 0.0f ? rms_in[b] / rms_out : 0.0f;
+    const int call = b / n_win, win = b - call * n_win;
+    const size_t o = ((size_t)(call * kSpk + spk) * n_win + win) * W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const float y = wav[i] * gain;
+        if (f32) f32[o + i] = y;
+        if (pcm) pcm[o + i] = (int16_t)(int)fminf(fmaxf(truncf(y), -32768.0f), 32767.0f);
+    }
+}
+
+int xfail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
+#define MF_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return xfail(err, ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct LayerW {
+    const float *in_w, *in_b, *in_c, *gamma, *beta, *out_w, *out_b, *out_c;
+    const float *front_w, *front_b, *n1_w, *n1_b, *uv_w, *uv_b, *uv_c, *ml_w, *ml_b, *mp_w, *mem_w[4], *mn_w[4], *mn_b[4], *mprelu[4], *n2_w, *n2_b, *back_w,
+        *back_b;
+    float front_alpha;
+};
+
+}  // namespace
+
+struct MossformerEngine : SubEngine {
+    int device = 0, W = 0, n_win = 1, n = 0, padded = 0, groups = 0, layers = 0;
+    float hyper[hCount] = {};
+    float* d_w = nullptr;
+    const float *encoder_w = nullptr, *front_w = nullptr, *front_b = nullptr, *front_wsum = nullptr, *emb_pos = nullptr, *rot_cos = nullptr, *rot_sin = nullptr,
+                *mm_w = nullptr, *mm_b = nullptr, *intra_w = nullptr, *intra_b = nullptr, *tail_w = nullptr, *tail_b = nullptr, *maskdec_w = nullptr,
+                *decoder_w = nullptr;
+    std::vector<LayerW> L;
+    int capacity = 0;
+    float* ws = nullptr;
+    float2 *gains = nullptr, *wstats = nullptr, *cstats = nullptr;
+    float *rms_in = nullptr, *XE = nullptr, *MI = nullptr, *H = nullptr, *inv = nullptr, *P = nullptr, *P2 = nullptr, *heads = nullptr, *ATT = nullptr, *AO = nullptr,
+          *LKV = nullptr, *G = nullptr, *Y = nullptr, *C1 = nullptr, *GF = nullptr, *XN = nullptr, *UV = nullptr, *UV2 = nullptr, *F1 = nullptr, *XP = nullptr,
+          *M0 = nullptr, *M1 = nullptr, *N2 = nullptr, *HL = nullptr, *MO = nullptr, *GP = nullptr, *SEP = nullptr, *FR = nullptr, *WAV = nullptr;
+
+    ~MossformerEngine() override {
+        (void)hipSetDevice(device);
+        if (d_w) (void)hipFree(d_w);
+        if (ws) (void)hipFree(ws);
+    }
+    int frames() const override { return n; }
+    int in_len() const override { return W * n_win; }
+    int out_len() const override { return W * n_win; }
+    int n_outputs() const override { return kSpk; }          // separated_0 / separated_1 (:689-690)
+    int reserve(int batch, std::string& err) override;
+    int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
+    int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
+};
+
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err) {
+    *out = nullptr;
+    if (n_win < 1) return xfail(err, ADE_ERR_BAD_VALUE, "mossformer: n_win must be >= 1");
+    if (window_len < kEncK || (window_len - kEncK) % kEncS != 0)
+        return xfail(err, ADE_ERR_SHAPE_MISMATCH, "mossformer: the window length must be 16 + a multiple of the encoder stride 8 (ConvTranspose reconstructs exactly)");
+    const int n = (window_len - kEncK) / kEncS + 1;
+    auto find = [&](const std::string& name) -> const Tensor* {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) { err = "weights: tensor missing: " + name; return nullptr; }
+        return &it->second;
+    };
+    auto shaped = [&](const std::string& name, std::vector<int> dims) -> const Tensor* {
+        const Tensor* t = find(name);
+        if (t && t->dims != dims) { err = "weights: tensor has the wrong shape: " + name; return nullptr; }
+        return t;
+    };
+    auto status = [&]() { return err.find("missing") != std::string::npos ? ADE_ERR_MISSING_KEY : ADE_ERR_SHAPE_MISMATCH; };
+    const Tensor* hy = shaped("hyper", {hCount});
+    if (!hy) return status();
+    int layers = 0;
+    while (tensors.count("fl_in_w_" + std::to_string(layers))) ++layers;
+    if (layers < 1) return xfail(err, ADE_ERR_MISSING_KEY, "weights: tensor missing: fl_in_w_0");
+    const Tensor* alpha = shaped("fs_front_alpha", {layers});
+    if (!alpha) return status();
+    MossformerEngine* e = new MossformerEngine();
+    auto bail = [&](int st) { delete e; return st; };
+    memcpy(e->hyper, hy->data, sizeof(e->hyper));
+    const int group = (int)e->hyper[hGroup], rot = (int)e->hyper[hRotDim], depth = (int)e->hyper[hMemDepth], lorder = (int)e->hyper[hLorder];
+    if (group < 16 || group > 4096 || rot < 2 || rot > kQk || (rot & 1) || (int)e->hyper[hDwPad] != (kDw - 1) / 2 || depth < 1 || depth > 2 || 2 * lorder - 1 != kMemK)
+        return bail(xfail(err, ADE_ERR_UNSUPPORTED, "mossformer: unsupported geometry (group 16..4096, even rotary <= 128, depthwise k 17, memory order 20, depth 1..2)"));
+    e->device = device; e->W = window_len; e->n_win = n_win; e->n = n; e->layers = layers;
+    e->padded = (n + group - 1) / group * group;
+    e->groups = e->padded / group;
+
+    struct Item { const float* src; size_t count; size_t at; };
+    std::vector<Item> items;
+    size_t arena = 0;
+    auto place = [&](const Tensor* t) { const size_t at = arena; arena += (t->count + 63) & ~(size_t)63; items.push_back({t->data, t->count, at}); return at; };
+    std::vector<std::pair<const float**, size_t>> fix;
+    auto want = [&](const float** dst, const std::string& name, std::vector<int> dims) -> bool {
+        const Tensor* t = shaped(name, dims);
+        if (!t) return false;
+        fix.push_back({dst, place(t)});
+        return true;
+    };
+    bool ok = want(&e->encoder_w, "encoder_w", {kDim, 1, kEncK}) && want(&e->front_w, "front_w", {kDim, kDim, 1}) && want(&e->front_b, "front_b", {kDim}) &&
+              want(&e->emb_pos, "emb_pos", {1, kDim, n}) && want(&e->rot_cos, "rot_cos", {1, n, 1, rot}) && want(&e->rot_sin, "rot_signed_sin", {1, n, 1, rot}) &&
+              want(&e->mm_w, "mm_norm_w", {kDim}) && want(&e->mm_b, "mm_norm_b", {kDim}) && want(&e->intra_w, "intra_norm_w", {kDim}) &&
+              want(&e->intra_b, "intra_norm_b", {kDim}) && want(&e->tail_w, "tail_gate_w", {kSpk * 2 * kDim, kDim, 1}) &&
+              want(&e->tail_b, "tail_gate_b", {kSpk * 2 * kDim}) && want(&e->maskdec_w, "mask_decoder_w", {kDim, kDim, 1}) &&
+              want(&e->decoder_w, "decoder_w", {kDim, 1, kEncK});
+    e->L.resize((size_t)layers);
+    for (int i = 0; ok && i < layers; ++i) {
+        const std::string s = "_" + std::to_string(i);
+        LayerW& l = e->L[i];
+        l.front_alpha = alpha->data[i];
+        ok = want(&l.in_w, "fl_in_w" + s, {kIn, kDim}) && want(&l.in_b, "fl_in_b" + s, {kIn}) && want(&l.in_c, "fl_in_c" + s, {kIn, 1, kDw}) &&
+             want(&l.gamma, "qkos_gamma" + s, {4, kQk}) && want(&l.beta, "qkos_beta" + s, {4, kQk}) && want(&l.out_w, "fl_out_w" + s, {kDim, kVu}) &&
+             want(&l.out_b, "fl_out_b" + s, {kDim}) && want(&l.out_c, "fl_out_c" + s, {kDim, 1, kDw}) && want(&l.front_w, "fs_front_w" + s, {kInner, kDim}) &&
+             want(&l.front_b, "fs_front_b" + s, {kInner}) && want(&l.n1_w, "fs_n1_w" + s, {kInner}) && want(&l.n1_b, "fs_n1_b" + s, {kInner}) &&
+             want(&l.uv_w, "fs_uv_w" + s, {2 * kInner, kInner}) && want(&l.uv_b, "fs_uv_b" + s, {2 * kInner}) && want(&l.uv_c, "fs_uv_c" + s, {2 * kInner, 1, kDw}) &&
+             want(&l.ml_w, "fs_mem_linear_w" + s, {kInner, kInner}) && want(&l.ml_b, "fs_mem_linear_b" + s, {kInner}) &&
+             want(&l.mp_w, "fs_mem_project_w" + s, {kInner, kInner}) && want(&l.n2_w, "fs_n2_w" + s, {kInner}) && want(&l.n2_b, "fs_n2_b" + s, {kInner}) &&
+             want(&l.back_w, "fs_back_w" + s, {kDim, kInner}) && want(&l.back_b, "fs_back_b" + s, {kDim});
+        for (int j = 0; ok && j < depth; ++j) {
+            const std::string sj = s + "_" + std::to_string(j);
+            ok = want(&l.mem_w[j], "fs_mem_w" + sj, {kInner, j + 1, kMemK}) && want(&l.mn_w[j], "fs_mem_norm_w" + sj, {kInner}) &&
+                 want(&l.mn_b[j], "fs_mem_norm_b" + sj, {kInner}) && want(&l.mprelu[j], "fs_mem_prelu" + sj, {kInner});
+        }
+    }
+    if (!ok) return bail(status());
+    // row sums of the front 1x1 weight: the window mean folds into the GEMM store
+    std::vector<float> wsum((size_t)kDim);
+    {
+        const Tensor* fw = find("front_w");
+        for (int o = 0; o < kDim; ++o) {
+            double a = 0.0;
+            for (int c = 0; c < kDim; ++c) a += fw->data[(size_t)o * kDim + c];
+            wsum[o] = (float)a;
+        }
+    }
+    const size_t a_wsum = arena;
+    arena += kDim;
+    if (hipSetDevice(device) != hipSuccess) return bail(xfail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipMalloc((void**)&e->d_w, arena * sizeof(float)) != hipSuccess) return bail(xfail(err, ADE_ERR_DEVICE, "hipMalloc of the MossFormer2 weights failed"));
+    for (const Item& it : items)
+        if (hipMemcpy(e->d_w + it.at, it.src, it.count * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(xfail(err, ADE_ERR_DEVICE, "upload of the MossFormer2 weights failed"));
+    if (hipMemcpy(e->d_w + a_wsum, wsum.data(), kDim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(xfail(err, ADE_ERR_DEVICE, "upload of the MossFormer2 weights failed"));
+    for (auto& f : fix) *f.first = e->d_w + f.second;
+    e->front_wsum = e->d_w + a_wsum;
+    *out = e;
+    return ADE_OK;
+}
+
+int MossformerEngine::reserve(int batch, std::string& err) {
+    if (batch <= capacity) return ADE_OK;
+    MF_HIP(hipSetDevice(device));
+    MF_HIP(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    ws = nullptr;
+    capacity = 0;
+    const size_t B = (size_t)batch * n_win, R = B * n, RP = B * padded, g = (size_t)hyper[hGroup];
+    struct Carve { float** p; size_t count; };
+    float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr;
+    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
+                             {&inv, R}, {&P, R * kIn}, {&P2, R * kIn}, {&heads, 4 * RP * kQk}, {&ATT, B * groups * g * g}, {&AO, R * kVu2},
+                             {&LKV, B * kQk * kVu2}, {&G, R * kVu}, {&Y, R * kDim}, {&C1, R * kInner}, {&GF, R * kInner}, {&XN, R * kInner}, {&UV, R * kDim},
+                             {&UV2, R * kDim}, {&F1, R * kInner}, {&XP, R * kInner}, {&M0, R * kInner}, {&M1, R * kInner}, {&N2, R * kInner}, {&HL, R * kDim},
+                             {&MO, R * kDim}, {&GP, R * kSpk * 2 * kDim}, {&SEP, kSpk * R * kDim}, {&FR, kSpk * R * kEncK}, {&WAV, kSpk * B * (size_t)W}};
+    size_t total = 0;
+    for (auto& c : cs) total += (c.count + 63) & ~(size_t)63;
+    MF_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
+    size_t at = 0;
+    for (auto& c : cs) { *c.p = ws + at; at += (c.count + 63) & ~(size_t)63; }
+    gains = reinterpret_cast<float2*>(f_gains);
+    wstats = reinterpret_cast<float2*>(f_wstats);
+    cstats = reinterpret_cast<float2*>(f_cstats);
+    capacity = batch;
+    return ADE_OK;
+}
+
+int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+    if (batch == 0) return ADE_OK;
+    int st = reserve(batch, err);
+    if (st != ADE_OK) return st;
+    using namespace gemm;
+    const int B = batch * n_win, R = B * n, g = (int)hyper[hGroup], rot = (int)hyper[hRotDim], depth = (int)hyper[hMemDepth], lorder = (int)hyper[hLorder];
+    const long long head_stride = (long long)B * padded * kQk;
+    auto rows4 = [&](int rows) { return dim3((unsigned)((rows + 3) / 4)); };
+    auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+
+    // front end: RMS stages, encoder, window norm folded into the 1x1 conv, positions                         (:571-591)
+    hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, W, hyper[hNormFactor], gains, rms_in);
+    launch(s, EncFrameA{d_in, gains, W, n}, WeightNK{encoder_w, kEncK}, BiasActRowStore<1>{XE, nullptr, kDim, 0.0f}, R, kDim, kEncK);
+    hipLaunchKernelGGL(k_window_stats, dim3((unsigned)B), dim3(1024), 0, s, (const float*)XE, (long long)n * kDim, hyper[hFrontEps], wstats);
+    launch(s, RowMajorA{XE, kDim}, WeightNK{front_w, kDim}, FrontStore{H, MI, wstats, front_wsum, front_b, emb_pos, n}, R, kDim, kDim);
+
+    for (int i = 0; i < layers; ++i) {
+        const LayerW& l = L[i];
+        // ---- FLASH block (:451-505)
+        hipLaunchKernelGGL(k_shift_invnorm, rows4(R), dim3(256), 0, s, (const float*)H, inv, R, n, hyper[hFlNormEps]);
+        launch(s, ShiftA{H, n}, WeightNK{l.in_w, kDim}, ScaleSiluStore{P, inv, l.in_b, kIn}, R, kIn, kDim);
+        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kIn), dim3(256), 0, s, (const float*)P, l.in_c, (const float*)nullptr, P2, kIn, n, (kDw - 1) / 2,
+                           (long long)R * kIn);
+        hipLaunchKernelGGL(k_offset_rotary, dim3((unsigned)padded, (unsigned)B), dim3(kQk), 0, s, (const float*)P2, l.gamma, l.beta, rot_cos, rot_sin, heads, n,
+                           padded, rot, head_stride);
+        const float *quad_q = heads, *lin_q = heads + head_stride, *quad_k = heads + 2 * head_stride, *lin_k = heads + 3 * head_stride;
+        launch_batched(s, QuadScoreProb{quad_q, quad_k, ATT, g}, B * groups, g, g);
+        launch_batched(s, QuadOutProb{ATT, P2, AO, g, groups, n}, B * groups, g, kVu2);
+        launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded}, B, kQk, kVu2);
+        launch_batched(s, LinOutProb{lin_q, LKV, AO, n, padded}, B, n, kVu2);
+        hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
+        launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu);
+        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kDim), dim3(256), 0, s, (const float*)Y, l.out_c, (const float*)H, H, kDim, n, (kDw - 1) / 2,
+                           (long long)R * kDim);
+        // ---- gated FSMN block (:507-541)
+        launch(s, RowMajorA{H, kDim}, WeightNK{l.front_w, kDim}, BiasActRowStore<3>{C1, l.front_b, kInner, l.front_alpha}, R, kInner, kDim);
+        hipLaunchKernelGGL(k_ln_pair, rows4(R), dim3(256), 0, s, (const float*)C1, l.n1_w, l.n1_b, GF, XN, R, hyper[hFsN1Eps], hyper[hFsLnEps]);
+        launch(s, RowMajorA{XN, kInner}, WeightNK{l.uv_w, kInner}, BiasActRowStore<2>{UV, l.uv_b, kDim, 0.0f}, R, kDim, kInner);
+        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kDim), dim3(256), 0, s, (const float*)UV, l.uv_c, (const float*)nullptr, UV2, kDim, n, (kDw - 1) / 2,
+                           (long long)R * kDim);
+        launch(s, RowMajorA{UV2, kDim}, WeightNK{l.ml_w, kInner}, BiasActRowStore<1>{F1, l.ml_b, kInner, 0.0f}, R, kInner, kInner);
+        launch(s, RowMajorA{F1, kInner}, WeightNK{l.mp_w, kInner}, BiasActRowStore<0>{XP, nullptr, kInner, 0.0f}, R, kInner, kInner);
+        float* mem_prev = nullptr;
+        for (int j = 0; j < depth; ++j) {
+            float* dst = (j & 1) ? M1 : M0;
+            const int dil = 1 << j, pad = lorder + (dil - 1) * (lorder - 1) - 1;
+            // dense input of conv j = [out_{j-1}, ..., out_0, xp]; only depth <= 2 keeps a single previous output, deeper stacks are rejected at create
+            hipLaunchKernelGGL(k_mem_conv, flat((long long)R * kInner), dim3(256), 0, s, (const float*)XP, (const float*)mem_prev, l.mem_w[j], dst, n, j + 1, dil,
+                               pad, (long long)R * kInner);
+            hipLaunchKernelGGL(k_chan_stats, dim3((unsigned)B, kInner / 64), dim3(256), 0, s, (const float*)dst, n, hyper[hMemNormEps], cstats);
+            hipLaunchKernelGGL(k_mem_norm_prelu, flat((long long)R * kInner), dim3(256), 0, s, dst, (const float2*)cstats, l.mn_w[j], l.mn_b[j], l.mprelu[j], n,
+                               (long long)R * kInner);
+            mem_prev = dst;
+        }
+        hipLaunchKernelGGL(k_fsmn_combine, rows4(R), dim3(256), 0, s, (const float*)UV2, (const float*)mem_prev, (const float*)GF, l.n2_w, l.n2_b, N2, R,
+                           hyper[hFsN2Eps]);
+        launch(s, RowMajorA{N2, kInner}, WeightNK{l.back_w, kInner}, ResidualBiasStore{H, l.back_b, kDim}, R, kDim, kInner);
+    }
+    // final norms + skip (:544-551)
+    hipLaunchKernelGGL(k_ln512, rows4(R), dim3(256), 0, s, (const float*)H, mm_w, mm_b, HL, R, hyper[hMmEps]);
+    hipLaunchKernelGGL(k_window_stats, dim3((unsigned)B), dim3(1024), 0, s, (const float*)HL, (long long)n * kDim, hyper[hIntraEps], wstats);
+    hipLaunchKernelGGL(k_window_affine_skip, flat((long long)R * kDim), dim3(256), 0, s, (const float*)HL, (const float2*)wstats, intra_w, intra_b,
+                       (const float*)MI, MO, n, (long long)R * kDim);
+    // speaker tail, decoder, RMS restore (:599-645)
+    launch(s, LeakyA{MO, kDim, hyper[hTailAlpha]}, WeightNK{tail_w, kDim}, BiasActRowStore<0>{GP, tail_b, kSpk * 2 * kDim, 0.0f}, R, kSpk * 2 * kDim, kDim);
+    launch(s, SpeakerGateA{GP, R}, WeightNK{maskdec_w, kDim}, MaskEncStore{SEP, XE, R}, kSpk * R, kDim, kDim);
+    launch(s, RowMajorA{SEP, kDim}, RowMajorB{decoder_w, kEncK}, BiasActRowStore<0>{FR, nullptr, kEncK, 0.0f}, kSpk * R, kEncK, kDim);
+    hipLaunchKernelGGL(k_decode_restore, dim3((unsigned)(B * kSpk)), dim3(1024), 0, s, (const float*)FR, (const float*)rms_in, d_out, d_f32, WAV, W, n, R, n_win);
+    MF_HIP(hipGetLastError());
+    return ADE_OK;
+}
+
+int MossformerEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+    const size_t R = (size_t)batch * n_win * n;
+    const float* src = nullptr;
+    size_t cnt = 0;
+    if (strcmp(name, "mdl_in") == 0) { src = MI; cnt = R * kDim; }            // (window, frame, 512)
+    else if (strcmp(name, "mdl_out") == 0) { src = MO; cnt = R * kDim; }
+    else if (strcmp(name, "x_enc") == 0) { src = XE; cnt = R * kDim; }
+    else return xfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    if (!src || batch <= 0) return xfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet");
+    if (count < cnt) return xfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+    MF_HIP(hipStreamSynchronize(s));
+    MF_HIP(hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    *written = cnt;
+    return ADE_OK;
+}
+
+}  // namespace ade

@@ -78,11 +78,14 @@ class InferenceSession:
         self._lib.check(self._lib.c.ade_get_io(self._h, C.byref(io)), self._h)
         self.in_len, self.out_len, self.frames = io.in_len, io.out_len, io.frames
         self.channels = io.in_channels                    # 1 (GTCRN, DFSMN) or 2 (Mel-Band-Roformer stereo)
-        self.row_in, self.row_out = io.in_channels * io.in_len, io.out_channels * io.out_len   # one batch item, channel-planar
+        self.n_outputs = io.n_outputs                     # 1, or 2 for MossFormer2-SS ("separated_0", "separated_1")
+        self.row_in, self.row_out = io.in_channels * io.in_len, io.n_outputs * io.out_channels * io.out_len   # one batch item, planar
         self.sample_rate = io.model_sample_rate
         self.device_id = io.device
-        self._inputs = [NodeArg(INPUT_NAME, [1, io.in_channels, io.in_len])]
-        self._outputs = [NodeArg(OUTPUT_NAME, [1, io.out_channels, io.out_len])]
+        in_name = "mix_audio" if reader.string("model_family", "") == "mossformer2_ss" else INPUT_NAME        # :688
+        self._inputs = [NodeArg(in_name, [1, io.in_channels, io.in_len])]
+        out_names = [OUTPUT_NAME] if io.n_outputs == 1 else [f"separated_{i}" for i in range(io.n_outputs)]   # Export_MossFormer2_SS_16K.py:689-690
+        self._outputs = [NodeArg(name, [1, io.out_channels, io.out_len]) for name in out_names]
         self._inputs_meta, self._outputs_meta = self._inputs, self._outputs   # names the reference script touches
         validate_audio_metadata(reader, self)
 
@@ -101,17 +104,19 @@ class InferenceSession:
 
     def run(self, output_names, input_feed: Dict[str, np.ndarray], return_f32: bool = False):
         """``session.run(None, {"noisy_audio": int16 (B,1,L)})`` -> ``[int16 (B,1,L_out)]`` (+ fp32 pre-PCM tap)."""
-        if INPUT_NAME not in input_feed:
-            raise KeyError(f"missing input {INPUT_NAME!r}")
-        x = np.asarray(input_feed[INPUT_NAME])
+        if self._inputs[0].name not in input_feed:
+            raise KeyError(f"missing input {self._inputs[0].name!r}")
+        x = np.asarray(input_feed[self._inputs[0].name])
         if x.dtype != np.int16:
             raise ValueError(f"{INPUT_NAME} must be int16, got {x.dtype}")
         if x.ndim != 3 or x.shape[1] != self.channels or x.shape[2] != self.in_len:
             raise ValueError(f"{INPUT_NAME} must have shape (B, {self.channels}, {self.in_len}), got {x.shape}")
         pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32)
-        out = [pcm.reshape(-1, self.channels, self.out_len)]
+        pcm = pcm.reshape(-1, self.n_outputs, self.channels, self.out_len)
+        out = [np.ascontiguousarray(pcm[:, i]) for i in range(self.n_outputs)]               # one array per graph output
         if return_f32:
-            out.append(f32.reshape(-1, self.channels, self.out_len))
+            f32 = f32.reshape(-1, self.n_outputs, self.channels, self.out_len)
+            out += [np.ascontiguousarray(f32[:, i]) for i in range(self.n_outputs)]
         return out
 
     # -- batch call on host buffers ---------------------------------------------------------------------------

@@ -69,3 +69,61 @@ def test_position_tables_and_hyper_layout(fixture):
     h = dict(zip(mossformer.HYPER_KEYS, t["hyper"]))
     assert h["flash_group_size"] == 256 and h["fs_mem_lorder"] == 20 and h["fs_mem_depth"] == 2 and h["dw_pad"] == 8
     assert t["fs_front_alpha"].shape == (2,)
+
+
+# ---- GPU: the HIP engine through the C ABI ------------------------------------------------------------------------------
+def _session(fixture, length, **meta_kw):
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    _, fused, scalars, W = fixture
+    return InferenceSession(weights=pack_blob(mossformer.model_tensors(fused, scalars, W)), metadata=mossformer.metadata(length, **meta_kw))
+
+
+@pytest.mark.gpu
+def test_gpu_matches_reference_fixture(fixture):
+    """int16 (1, 1, W) through libade vs the reference's own forward: two outputs, within 2 LSB."""
+    z, _, _, W = fixture
+    with _session(fixture, W) as sess:
+        assert sess.n_outputs == 2 and [o.name for o in sess.get_outputs()] == ["separated_0", "separated_1"] and sess.get_inputs()[0].name == "mix_audio"
+        outs = sess.run(None, {"mix_audio": z["pcm_in"][None, None]})
+        mdl_in = sess.tap("mdl_in", sess.frames * 512).reshape(sess.frames, 512).T
+        mdl_out = sess.tap("mdl_out", sess.frames * 512).reshape(sess.frames, 512).T
+    assert len(outs) == 2 and outs[0].shape == (1, 1, W) and outs[0].dtype == np.int16
+    assert np.abs(mdl_in[:, ::7] - z["mdl_in"]).max() < 1e-3
+    assert np.abs(mdl_out[:, ::7] - z["mdl_out"]).max() < 5e-3
+    for spk in range(2):
+        d = outs[spk][0, 0].astype(np.int32) - z["pcm_out"][spk].astype(np.int32)
+        assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (spk, np.abs(d).max(), (d != 0).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_batch_fold_matches_reference_fixture(fixture):
+    """use_batch_fold = 1: one call = (1, 1, 3 * W), per-window RMS normalisation / restore, a partly silent last window."""
+    W = fixture[3]
+    zf = np.load(GOLD_FOLD)
+    meta_len = int(zf["input_audio_length"])
+    with _session(fixture, meta_len, use_batch_fold=True, batch_window_seconds=W / 16000.0) as sess:
+        assert sess.in_len == zf["pcm_in"].shape[0] and sess.frames == mossformer.frames_of(W)
+        outs = sess.run(None, {"mix_audio": np.stack((zf["pcm_in"], zf["pcm_in"]))[:, None]})
+    for spk in range(2):
+        d = outs[spk][0, 0].astype(np.int32) - zf["pcm_out"][spk].astype(np.int32)
+        assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (spk, np.abs(d).max(), (d != 0).mean())
+        assert np.array_equal(outs[spk][0], outs[spk][1])
+
+
+@pytest.mark.gpu
+def test_gpu_batch_rows_and_oracle_on_other_inputs(fixture):
+    """Batch rows are independent calls; seeded-noise, silent and full-scale windows against the oracle."""
+    z, _, _, W = fixture
+    rng = np.random.default_rng(5)
+    rows = np.stack([z["pcm_in"], (rng.standard_normal(W) * 4000).astype(np.int16), np.zeros(W, np.int16),
+                     (np.sign(np.sin(np.arange(W) * 0.05)) * 32767).astype(np.int16)])
+    want = _oracle(fixture).process(rows)                                   # (4, 2, W)
+    with _session(fixture, W) as sess:
+        outs = sess.run(None, {"mix_audio": rows[:, None]})
+        one = sess.run(None, {"mix_audio": rows[1:2, None]})
+    got = np.stack((outs[0][:, 0], outs[1][:, 0]), axis=1)
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 3 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
+    assert np.all(got[2] == 0)                                               # a silent window stays silent (gain 0 / 0 -> 0, :618-622)
+    assert np.array_equal(one[0][0], outs[0][1]) and np.array_equal(one[1][0], outs[1][1])
