@@ -80,3 +80,42 @@ def synthetic_tensor(name: str, shape, scale: float, frames: int, group_size: in
         v[0] *= np.float32(1.0 / group_size)
         v[3] *= np.float32(1.0 / frames)
     return v
+
+
+# stand-in scalar attributes of the published MossFormer2_SS_16K geometry (what MOSSFORMER_SS.__init__ derives from the clearvoice network)
+DEFAULT_SCALARS = {
+    "norm_factor": 10.0 ** (-25.0 / 20.0), "flash_group_size": 256, "rot_dim": 32, "dw_pad": 8, "fl_norm_eps": 1e-5 / 512 ** -0.5,
+    "fl_out_norm_eps": 1e-5 / 1024 ** -0.5, "front_norm_eps": 1e-8, "mm_norm_eps": 1e-8, "intra_norm_eps": 1e-8, "fs_ln_eps": 1e-5, "fs_n1_eps": 1e-8,
+    "fs_n2_eps": 1e-8, "fs_mem_depth": 2, "tail_prelu_alpha": 0.25, "fs_mem_paddings": [19, 38], "fs_mem_dilations": [1, 2],
+    "fs_mem_norm_eps": [1e-5, 1e-5],
+}
+
+
+def synthetic_spec(layers: int):
+    """(name, shape, scale) of every fused buffer for random-init weights of the architecture (tools/bench_mossformer.py)."""
+    def lin(fan_in):
+        return 1.7 / fan_in ** 0.5
+    spec = [("encoder_w", [512, 1, 16], 0.8), ("decoder_w", [512, 1, 16], 0.3), ("mask_decoder_w", [512, 512, 1], lin(512)),
+            ("mm_norm_w", [512], 1.2), ("mm_norm_b", [512], 0.05), ("intra_norm_w", [512], 1.2), ("intra_norm_b", [512], 0.05),
+            ("front_w", [512, 512, 1], lin(512)), ("front_b", [512], 0.05), ("tail_gate_w", [2048, 512, 1], lin(512)), ("tail_gate_b", [2048], 0.05)]
+    for i in range(layers):
+        spec += [(f"fl_in_w_{i}", [2176, 512], 2.0 * 1.7 * 22.6 / 512 ** 0.5), (f"fl_in_b_{i}", [2176], 0.05), (f"fl_in_c_{i}", [2176, 1, 17], 0.15),
+                 (f"fl_out_w_{i}", [512, 1024], 1.7 * 32.0 / 1024 ** 0.5), (f"fl_out_b_{i}", [512], 0.05), (f"fl_out_c_{i}", [512, 1, 17], 0.15),
+                 (f"qkos_gamma_{i}", [4, 128], 0.6), (f"qkos_beta_{i}", [4, 128], 0.05),
+                 (f"fs_uv_w_{i}", [512, 256], lin(256)), (f"fs_uv_b_{i}", [512], 0.05), (f"fs_uv_c_{i}", [512, 1, 17], 0.15),
+                 (f"fs_mem_w_{i}_0", [256, 1, 39], 0.15), (f"fs_mem_norm_w_{i}_0", [256], 1.2), (f"fs_mem_norm_b_{i}_0", [256], 0.05), (f"fs_mem_prelu_{i}_0", [256], 0.3),
+                 (f"fs_mem_w_{i}_1", [256, 2, 39], 0.15), (f"fs_mem_norm_w_{i}_1", [256], 1.2), (f"fs_mem_norm_b_{i}_1", [256], 0.05), (f"fs_mem_prelu_{i}_1", [256], 0.3),
+                 (f"fs_mem_linear_w_{i}", [256, 256], lin(256)), (f"fs_mem_linear_b_{i}", [256], 0.05), (f"fs_mem_project_w_{i}", [256, 256], lin(256)),
+                 (f"fs_front_w_{i}", [256, 512], lin(512)), (f"fs_front_b_{i}", [256], 0.05), (f"fs_back_w_{i}", [512, 256], lin(256)), (f"fs_back_b_{i}", [512], 0.05),
+                 (f"fs_n1_w_{i}", [256], 1.2), (f"fs_n1_b_{i}", [256], 0.05), (f"fs_n2_w_{i}", [256], 1.2), (f"fs_n2_b_{i}", [256], 0.05)]
+    return spec
+
+
+def flops_per_window(frames: int, layers: int, group: int = 256) -> float:
+    """Multiply-add flops (2 per MAC) of the matrix products of one window: encoder / decoder, per layer the FLASH projections, the
+    quadratic attention inside groups, the linear attention, the FSMN Linears; the speaker tail."""
+    padded = -(-frames // group) * group
+    per_layer = 2 * frames * (512 * 2176 + 1024 * 512 + 512 * 256 + 256 * 512 + 2 * 256 * 256 + 256 * 512)
+    per_layer += 2 * (padded // group) * (group * group * 128 + group * group * 2048) + 2 * 128 * 2048 * frames * 2
+    tail = 2 * frames * (16 * 512 + 512 * 512 + 512 * 2048 + 2 * 512 * 512 + 2 * 512 * 16)
+    return float(layers * per_layer + tail)

@@ -147,3 +147,23 @@ def test_melband_driver_slicing_and_tail_policy():
     assert abs(float(np.std(n1[2, :, 5:].astype(np.float32))) / rms - 1.0) < 0.6            # noise scaled to the tail's RMS
     short = cut_slices(a[:, :4], 10, fold_active=True)
     assert short.shape == (1, 2, 10) and np.all(short[0, :, 4:] == 0)
+
+
+def test_mossformer_driver_head_padding_and_slicing():
+    from audio_denoiser_onnx_amd import inference_mossformer as drv
+
+    class FakeSession:                      # echoes its input as speaker 0 and the negated input as speaker 1
+        in_len = 10
+
+        def get_inputs(self):
+            return [type("A", (), {"name": "mix_audio"})()]
+
+        def run(self, _, feed):
+            x = feed["mix_audio"]
+            assert x.shape[1:] == (1, 10)
+            return [x.copy(), -x]
+    audio = np.arange(1, 24, dtype=np.int16)
+    s0, s1 = drv.separate(FakeSession(), audio, pad_head=4, fold_active=True)
+    assert np.array_equal(s0, audio) and np.array_equal(s1, -audio)          # head zeros dropped, tail padding trimmed
+    sl = drv.cut_slices(np.concatenate((np.zeros(4, np.int16), audio)), 10, True)
+    assert sl.shape == (3, 10) and np.all(sl[0, :4] == 0) and np.all(sl[2, 7:] == 0)
