@@ -279,22 +279,91 @@ __global__ __launch_bounds__(256) void k_shift_invnorm(const float* __restrict__
     if (lane == 0) inv[m] = 1.0f / fmaxf(sqrtf(s), eps);
 }
 
-// y[m][c] = (res ? res[m][c] : 0) + x[m][c] + sum_k w[c][k] * x[m + k - pad][c], frames outside the window read as zero (:460, :504-505, :516)
-__global__ __launch_bounds__(256) void k_dwconv_res(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ res,
-                                                    float* __restrict__ y, int C, int n, int pad, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const long long m = i / C;
-    const int t = (int)(m % n);
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kDw; ++k) {
-        const int tt = t + k - pad;
-        if (tt >= 0 && tt < n) s += w[c * kDw + k] * x[(size_t)(m + k - pad) * C + c];
+// Depthwise convolution over time through an LDS tile (:460, :504-505, :516 with TAPS = 17; the dilated dense memory
+// convolutions :521-527 with TAPS = 39, CIN = j + 1 input channels per group).  grid = (time tiles of TT frames, channels / 64,
+// windows); the block stages rows t0 - pad .. t0 + TT - 1 + (TAPS - 1) dil - pad of its 64 * CIN input channels once (frames
+// outside the window read as zero) and every thread produces TT / 4 consecutive frames of one channel from LDS: HBM / L2 sees each
+// input about (1 + (TAPS - 1) dil / TT) times instead of TAPS times.
+//   out = (res ? res : 0) + (CENTER ? x : 0) + sum_{c < CIN} sum_k w[g][c][k] * in[g * CIN + c][t + k dil - pad]
+// The input channels of group g are g * CIN + c of the concatenation [src0 (split channels) | src1] (:534-535).
+// With `partial` set, the block also writes (count, mean, M2) of its outputs per channel for the instance norm that follows
+// (:528-531); k_chan_finalize merges the tiles in a fixed order (Chan's update), so the statistics are deterministic.
+template <int TAPS, int CIN, int TT, bool CENTER>
+__global__ __launch_bounds__(256) void k_tconv(const float* __restrict__ src0, const float* __restrict__ src1, int ld0, int ld1, int split,
+                                               const float* __restrict__ w, const float* __restrict__ res, float* __restrict__ y, int ldy, int n, int dil,
+                                               int pad, float4* __restrict__ partial) {
+    extern __shared__ float tile[];
+    __shared__ float red[2][4][64];
+    constexpr int kCols = 64 * CIN, kPer = TT / 4;
+    const int t0 = (int)blockIdx.x * TT, g0 = (int)blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
+    const int rows = TT + (TAPS - 1) * dil;
+    const size_t base = (size_t)b * n;
+    for (int idx = tid; idx < rows * kCols; idx += 256) {
+        const int r = idx / kCols, cc = idx - r * kCols, t = t0 - pad + r, ch = g0 * CIN + cc;
+        float v = 0.0f;
+        if (t >= 0 && t < n) v = ch < split ? src0[(base + t) * ld0 + ch] : src1[(base + t) * ld1 + (ch - split)];
+        tile[idx] = v;
     }
-    const float v = x[i] + s;
-    y[i] = res ? res[i] + v : v;
+    const int cl = tid & 63, tl = tid >> 6;
+    float wreg[TAPS * CIN];
+#pragma unroll
+    for (int i = 0; i < TAPS * CIN; ++i) wreg[i] = w[(size_t)(g0 + cl) * CIN * TAPS + i];
+    __syncthreads();
+    float outv[kPer];
+    float sum = 0.0f;
+    int cnt = 0;
+#pragma unroll
+    for (int o = 0; o < kPer; ++o) {
+        const int tt = tl * kPer + o, t = t0 + tt;
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) acc += wreg[c * TAPS + k] * tile[(tt + k * dil) * kCols + cl * CIN + c];
+        if (CENTER) acc += tile[(tt + pad) * kCols + cl];
+        outv[o] = acc;
+        if (t < n) {
+            const size_t at = (base + t) * ldy + g0 + cl;
+            y[at] = res ? res[at] + acc : acc;
+            sum += acc;
+            ++cnt;
+        }
+    }
+    if (!partial) return;
+    red[0][tl][cl] = sum;
+    red[1][tl][cl] = (float)cnt;
+    __syncthreads();
+    const float total = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    const float count = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    const float mean = total / fmaxf(count, 1.0f);
+    float m2 = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kPer; ++o)
+        if (t0 + tl * kPer + o < n) { const float d = outv[o] - mean; m2 += d * d; }
+    __syncthreads();
+    red[0][tl][cl] = m2;
+    __syncthreads();
+    if (tl == 0) {
+        const float M2 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        partial[((size_t)b * gridDim.x + blockIdx.x) * (gridDim.y * 64) + g0 + cl] = make_float4(count, mean, M2, 0.0f);
+    }
+}
+
+// merge the per-tile (count, mean, M2) of one (window, channel) in tile order -> (mean, rstd) with the biased variance
+__global__ __launch_bounds__(256) void k_chan_finalize(const float4* __restrict__ partial, int tiles, int C, float eps, float2* __restrict__ stats, int total) {
+    const int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float na = 0.0f, mean = 0.0f, M2 = 0.0f;
+    for (int t = 0; t < tiles; ++t) {
+        const float4 p = partial[((size_t)b * tiles + t) * C + c];
+        if (p.x <= 0.0f) continue;
+        const float nb = p.x, delta = p.y - mean, nn = na + nb;
+        mean += delta * (nb / nn);
+        M2 += p.z + delta * delta * (na * nb / nn);
+        na = nn;
+    }
+    stats[i] = make_float2(mean, 1.0f / sqrtf(M2 / fmaxf(na, 1.0f) + eps));
 }
 
 // OffsetScale x 4 + rotary on the first rot_dim channels (:466-474): heads[h][(b * padded + t)][128]; rows t >= n are zero
@@ -366,49 +435,6 @@ __global__ __launch_bounds__(256) void k_ln_pair(const float* __restrict__ c1, c
     const float r2 = 1.0f / sqrtf(wave_sum(q) * (1.0f / kInner) + eps2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) xn[(size_t)m * kInner + lane + 64 * i] = v[i] * r2;
-}
-
-// dilated dense memory convolution j (:521-527): out[m][g] = sum_{c < cin} sum_k w[g][c][k] * dense[g * cin + c][t + k * dil - pad];
-// dense = [newer memory outputs ..., xp] concatenated on channels (:534-535): channel ch < 256 * (cin - 1) lives in `mem`, else in `xp`
-__global__ __launch_bounds__(256) void k_mem_conv(const float* __restrict__ xp, const float* __restrict__ mem, const float* __restrict__ w,
-                                                  float* __restrict__ out, int n, int cin, int dil, int pad, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int g = (int)(i % kInner);
-    const long long m = i / kInner;
-    const int t = (int)(m % n);
-    float s = 0.0f;
-    for (int c = 0; c < cin; ++c) {
-        const int ch = g * cin + c;
-        const float* src = ch < kInner * (cin - 1) ? mem + ch : xp + (ch - kInner * (cin - 1));
-        const float* wr = w + ((size_t)g * cin + c) * kMemK;
-        for (int k = 0; k < kMemK; ++k) {
-            const int tt = t + k * dil - pad;
-            if (tt >= 0 && tt < n) s += wr[k] * src[(size_t)(m + k * dil - pad) * kInner];
-        }
-    }
-    out[i] = s;
-}
-
-// per (window, channel) mean / rstd over time (F.instance_norm :528-531); grid (windows, 256 / 64), block (64 channels x 4 time slices)
-__global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int n, float eps, float2* __restrict__ stats) {
-    __shared__ float red[4][64];
-    const int c = (int)blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, b = blockIdx.x;
-    const float* p = x + (size_t)b * n * kInner + c;
-    float s = 0.0f;
-    for (int t = sl; t < n; t += 4) s += p[(size_t)t * kInner];
-    red[sl][threadIdx.x & 63] = s;
-    __syncthreads();
-    const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)n;
-    __syncthreads();
-    float q = 0.0f;
-    for (int t = sl; t < n; t += 4) { const float d = p[(size_t)t * kInner] - mean; q += d * d; }
-    red[sl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (sl == 0) {
-        const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)n;
-        stats[(size_t)b * kInner + c] = make_float2(mean, 1.0f / sqrtf(var + eps));
-    }
 }
 
 // instance-norm affine + per-channel PReLU (:528-533), in place
@@ -530,6 +556,7 @@ struct MossformerEngine : SubEngine {
     int capacity = 0;
     float* ws = nullptr;
     float2 *gains = nullptr, *wstats = nullptr, *cstats = nullptr;
+    float4* partial = nullptr;     // per (window, time tile, channel) partial statistics of the memory convolutions
     float *rms_in = nullptr, *XE = nullptr, *MI = nullptr, *H = nullptr, *inv = nullptr, *P = nullptr, *P2 = nullptr, *heads = nullptr, *ATT = nullptr, *AO = nullptr,
           *LKV = nullptr, *G = nullptr, *Y = nullptr, *C1 = nullptr, *GF = nullptr, *XN = nullptr, *UV = nullptr, *UV2 = nullptr, *F1 = nullptr, *XP = nullptr,
           *M0 = nullptr, *M1 = nullptr, *N2 = nullptr, *HL = nullptr, *MO = nullptr, *GP = nullptr, *SEP = nullptr, *FR = nullptr, *WAV = nullptr;
@@ -653,8 +680,8 @@ int MossformerEngine::reserve(int batch, std::string& err) {
     capacity = 0;
     const size_t B = (size_t)batch * n_win, R = B * n, RP = B * padded, g = (size_t)hyper[hGroup];
     struct Carve { float** p; size_t count; };
-    float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr;
-    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
+    float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr, *f_partial = nullptr;
+    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&f_partial, 4 * B * (size_t)((n + 31) / 32) * kInner}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
                              {&inv, R}, {&P, R * kIn}, {&P2, R * kIn}, {&heads, 4 * RP * kQk}, {&ATT, B * groups * g * g}, {&AO, R * kVu2},
                              {&LKV, B * kQk * kVu2}, {&G, R * kVu}, {&Y, R * kDim}, {&C1, R * kInner}, {&GF, R * kInner}, {&XN, R * kInner}, {&UV, R * kDim},
                              {&UV2, R * kDim}, {&F1, R * kInner}, {&XP, R * kInner}, {&M0, R * kInner}, {&M1, R * kInner}, {&N2, R * kInner}, {&HL, R * kDim},
@@ -667,6 +694,7 @@ int MossformerEngine::reserve(int batch, std::string& err) {
     gains = reinterpret_cast<float2*>(f_gains);
     wstats = reinterpret_cast<float2*>(f_wstats);
     cstats = reinterpret_cast<float2*>(f_cstats);
+    partial = reinterpret_cast<float4*>(f_partial);
     capacity = batch;
     return ADE_OK;
 }
@@ -680,6 +708,11 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     const long long head_stride = (long long)B * padded * kQk;
     auto rows4 = [&](int rows) { return dim3((unsigned)((rows + 3) / 4)); };
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+    auto dwconv = [&](hipStream_t st_, const float* x, const float* w, const float* res, float* y, int C, int nb) {   // y = res + x + depthwise_17(x)
+        constexpr int kTT = 64;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kDw, 1, kTT, true>), dim3((unsigned)((n + kTT - 1) / kTT), (unsigned)(C / 64), (unsigned)nb), dim3(256),
+                           (size_t)(kTT + kDw - 1) * 64 * sizeof(float), st_, x, x, C, C, C, w, res, y, C, n, 1, (kDw - 1) / 2, (float4*)nullptr);
+    };
 
     // front end: RMS stages, encoder, window norm folded into the 1x1 conv, positions                         (:571-591)
     hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, W, hyper[hNormFactor], gains, rms_in);
@@ -692,8 +725,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
         // ---- FLASH block (:451-505)
         hipLaunchKernelGGL(k_shift_invnorm, rows4(R), dim3(256), 0, s, (const float*)H, inv, R, n, hyper[hFlNormEps]);
         launch(s, ShiftA{H, n}, WeightNK{l.in_w, kDim}, ScaleSiluStore{P, inv, l.in_b, kIn}, R, kIn, kDim);
-        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kIn), dim3(256), 0, s, (const float*)P, l.in_c, (const float*)nullptr, P2, kIn, n, (kDw - 1) / 2,
-                           (long long)R * kIn);
+        dwconv(s, P, l.in_c, nullptr, P2, kIn, B);
         hipLaunchKernelGGL(k_offset_rotary, dim3((unsigned)padded, (unsigned)B), dim3(kQk), 0, s, (const float*)P2, l.gamma, l.beta, rot_cos, rot_sin, heads, n,
                            padded, rot, head_stride);
         const float *quad_q = heads, *lin_q = heads + head_stride, *quad_k = heads + 2 * head_stride, *lin_k = heads + 3 * head_stride;
@@ -703,24 +735,31 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
         launch_batched(s, LinOutProb{lin_q, LKV, AO, n, padded}, B, n, kVu2);
         hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
         launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu);
-        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kDim), dim3(256), 0, s, (const float*)Y, l.out_c, (const float*)H, H, kDim, n, (kDw - 1) / 2,
-                           (long long)R * kDim);
+        dwconv(s, Y, l.out_c, H, H, kDim, B);
         // ---- gated FSMN block (:507-541)
         launch(s, RowMajorA{H, kDim}, WeightNK{l.front_w, kDim}, BiasActRowStore<3>{C1, l.front_b, kInner, l.front_alpha}, R, kInner, kDim);
         hipLaunchKernelGGL(k_ln_pair, rows4(R), dim3(256), 0, s, (const float*)C1, l.n1_w, l.n1_b, GF, XN, R, hyper[hFsN1Eps], hyper[hFsLnEps]);
         launch(s, RowMajorA{XN, kInner}, WeightNK{l.uv_w, kInner}, BiasActRowStore<2>{UV, l.uv_b, kDim, 0.0f}, R, kDim, kInner);
-        hipLaunchKernelGGL(k_dwconv_res, flat((long long)R * kDim), dim3(256), 0, s, (const float*)UV, l.uv_c, (const float*)nullptr, UV2, kDim, n, (kDw - 1) / 2,
-                           (long long)R * kDim);
+        dwconv(s, UV, l.uv_c, nullptr, UV2, kDim, B);
         launch(s, RowMajorA{UV2, kDim}, WeightNK{l.ml_w, kInner}, BiasActRowStore<1>{F1, l.ml_b, kInner, 0.0f}, R, kInner, kInner);
         launch(s, RowMajorA{F1, kInner}, WeightNK{l.mp_w, kInner}, BiasActRowStore<0>{XP, nullptr, kInner, 0.0f}, R, kInner, kInner);
         float* mem_prev = nullptr;
         for (int j = 0; j < depth; ++j) {
             float* dst = (j & 1) ? M1 : M0;
             const int dil = 1 << j, pad = lorder + (dil - 1) * (lorder - 1) - 1;
-            // dense input of conv j = [out_{j-1}, ..., out_0, xp]; only depth <= 2 keeps a single previous output, deeper stacks are rejected at create
-            hipLaunchKernelGGL(k_mem_conv, flat((long long)R * kInner), dim3(256), 0, s, (const float*)XP, (const float*)mem_prev, l.mem_w[j], dst, n, j + 1, dil,
-                               pad, (long long)R * kInner);
-            hipLaunchKernelGGL(k_chan_stats, dim3((unsigned)B, kInner / 64), dim3(256), 0, s, (const float*)dst, n, hyper[hMemNormEps], cstats);
+            // dense input of conv j = [out_{j-1}, xp] (depth <= 2): group g reads concatenated channels g (j + 1) .. g (j + 1) + j
+            constexpr int kTT = 32;
+            const int tiles = (n + kTT - 1) / kTT;
+            const dim3 grid((unsigned)tiles, kInner / 64, (unsigned)B);
+            const size_t lds = (size_t)(kTT + (kMemK - 1) * dil) * 64 * (j + 1) * sizeof(float);
+            if (j == 0)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 1, kTT, false>), grid, dim3(256), lds, s, (const float*)XP, (const float*)XP, kInner, kInner, kInner,
+                                   l.mem_w[0], (const float*)nullptr, dst, kInner, n, dil, pad, partial);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 2, kTT, false>), grid, dim3(256), lds, s, (const float*)mem_prev, (const float*)XP, kInner, kInner,
+                                   kInner, l.mem_w[1], (const float*)nullptr, dst, kInner, n, dil, pad, partial);
+            hipLaunchKernelGGL(k_chan_finalize, flat((long long)B * kInner), dim3(256), 0, s, (const float4*)partial, tiles, kInner, hyper[hMemNormEps], cstats,
+                               B * kInner);
             hipLaunchKernelGGL(k_mem_norm_prelu, flat((long long)R * kInner), dim3(256), 0, s, dst, (const float2*)cstats, l.mn_w[j], l.mn_b[j], l.mprelu[j], n,
                                (long long)R * kInner);
             mem_prev = dst;
