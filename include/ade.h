@@ -42,9 +42,9 @@ typedef struct ade_engine* ade_handle;
 /* What session.get_inputs()/get_outputs() report for the bound tensors (Inference_GTCRN_ONNX.py:262-267,276-277). */
 typedef struct ade_io_desc {
     int32_t abi_version;
-    int32_t in_channels;       /* 1 */
-    int32_t out_channels;      /* 1 */
-    int32_t n_outputs;         /* 1 ("denoised_audio") */
+    int32_t in_channels;       /* 1; 2 for Mel-Band-Roformer stereo (Export_MelBandRoformer.py:714)                  */
+    int32_t out_channels;      /* = in_channels                                                                       */
+    int32_t n_outputs;         /* 1 ("denoised_audio"); 2 for MossFormer2-SS ("separated_0/1", Export_MossFormer2_SS_16K.py:689) */
     int32_t in_len;            /* L: static input length in samples                      */
     int32_t out_len;           /* L_out = 256 * (L / 256): 15872 for L = 16000           */
     int32_t in_sample_rate;
@@ -58,7 +58,10 @@ typedef struct ade_io_desc {
 /* Replaces onnxruntime.InferenceSession(model) + load_runtime_metadata/validate_audio_metadata
  * (Inference_GTCRN_ONNX.py:237-239).  `manifest_json`: flat JSON object of string values carrying the reference's
  * metadata key set (audio_onnx_metadata.py:161-203); `weights`: ADEWGT01 blob of the BN-folded tensors under the
- * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode). */
+ * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode).
+ * The manifest key `model_family` selects the engine: "gtcrn" (GTCRN/Export_GTCRN.py), "dfsmn" (DFSMN/Export_DFSMN.py),
+ * "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py) or "mossformer2_ss"
+ * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py); the blob then carries that export's fused buffers. */
 ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device,
                       ade_handle* out);
 
@@ -67,8 +70,8 @@ ade_status ade_get_io(ade_handle h, ade_io_desc* desc);
 
 /* Replaces one (or B) `_update_ortvalue + run_with_iobinding + output copy` rounds
  * (Inference_GTCRN_ONNX.py:314-317) on caller-owned HOST buffers.  Synchronous.
- *   in        [B][in_len] int16 ;  out_pcm [B][out_len] int16 ;
- *   out_f32   optional [B][out_len] float: the waveform before the x32767/clamp/truncate tail (parity tap). */
+ *   in        [B][in_channels][in_len] int16 ;  out_pcm [B][n_outputs][out_channels][out_len] int16 (channel-planar) ;
+ *   out_f32   optional, same layout as out_pcm, float: the waveform before the PCM tail (scale / clamp / truncate; parity tap). */
 ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32);
 
 /* Same call on DEVICE buffers (what a GPU execution provider's io-binding does, Inference_GTCRN_ONNX.py:69-92,
