@@ -6,6 +6,12 @@ checkpoint-format ``state_dict`` (``torch.load(..)['model']``), fold every Batch
 matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the reference's own names.
 
     python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000]
+    python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold]
+    python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
+
+The other two families fold their checkpoints the way their export constructors do (``melband.fuse_checkpoint`` =
+Export_MelBandRoformer.py:455-538; ``mossformer.fuse_checkpoint`` = Export_MossFormer2_SS_16K.py:130-395); both folds are
+pinned against the reference's own constructors (tests/test_melband.py, tests/test_mossformer.py).
 """
 from __future__ import annotations
 
@@ -91,17 +97,57 @@ def export_gtcrn(checkpoint, out_dir, input_audio_length: int = 16000, name: str
     return model_path
 
 
+def export_melband(checkpoint, out_dir, input_audio_length: int = 66150, use_batch_fold: bool = False, heads: int = 8, dim_head: int = 64,
+                   name: str = "MelBandRoformer") -> Path:
+    """Upstream Mel-Band-Roformer ``.ckpt`` -> ``<name>.adew`` + manifest (the role of Export_MelBandRoformer.py:684-737 minus ONNX)."""
+    from . import melband
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    sd = {k: v for k, v in load_state_dict(checkpoint).items() if not k.endswith("rotary_embed.freqs")}
+    save_blob(model_path, melband.model_tensors(melband.fuse_checkpoint(sd, heads=heads, dim_head=dim_head)))
+    write_metadata(model_path, melband.metadata(input_audio_length, use_batch_fold=use_batch_fold))
+    return model_path
+
+
+def export_mossformer(checkpoint, out_dir, input_audio_length: int = 24000, use_batch_fold: bool = False, name: str = "MossFormer2_SS_16K") -> Path:
+    """clearvoice ``MossFormer2_SS_16K`` checkpoint -> ``<name>.adew`` + manifest (Export_MossFormer2_SS_16K.py:672-720 minus ONNX)."""
+    from . import mossformer
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    meta = mossformer.metadata(input_audio_length, use_batch_fold=use_batch_fold)
+    window = int(meta["fold_window_length"]) if use_batch_fold else input_audio_length
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in load_state_dict(checkpoint).items()}
+    fused, scalars = mossformer.fuse_checkpoint(sd, mossformer.frames_of(window))
+    save_blob(model_path, mossformer.model_tensors(fused, scalars, window))
+    write_metadata(model_path, meta)
+    return model_path
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
-    length = 16000
+    length, family, fold = None, "gtcrn", False
     if "--length" in argv:
         i = argv.index("--length")
         length = int(argv[i + 1])
         del argv[i:i + 2]
-    if len(argv) != 2:
+    if "--family" in argv:
+        i = argv.index("--family")
+        family = argv[i + 1]
+        del argv[i:i + 2]
+    if "--fold" in argv:
+        argv.remove("--fold")
+        fold = True
+    if len(argv) != 2 or family not in ("gtcrn", "mel_band_roformer", "mossformer2_ss"):
         print(__doc__)
         return 2
-    path = export_gtcrn(argv[0], argv[1], length)
+    if family == "mel_band_roformer":
+        path = export_melband(argv[0], argv[1], length or 66150, fold)
+    elif family == "mossformer2_ss":
+        path = export_mossformer(argv[0], argv[1], length or 24000, fold)
+    else:
+        path = export_gtcrn(argv[0], argv[1], length or 16000)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")
     return 0
 

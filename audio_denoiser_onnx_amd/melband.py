@@ -80,3 +80,62 @@ def flops_per_clip(frames: int, depth: int, dim: int = 384, heads: int = 8, dim_
     attn = 2 * 2 * heads * dim_head * (num_bands * frames * frames + frames * num_bands * num_bands)
     me = 2 * rows * (dim * me_hidden + me_hidden * me_hidden) + 2 * frames * 2 * s2 * me_hidden
     return float(stft + split + depth * (2 * proj + attn) + me)
+
+
+def fuse_checkpoint(state: Mapping[str, np.ndarray], heads: int = 8, dim_head: int = 64, num_bands: int = NUM_BANDS) -> Dict[str, np.ndarray]:
+    """Checkpoint ``state_dict`` (upstream Mel-Band-Roformer key names, e.g. ``layers.0.0.layers.0.0.to_qkv.weight``) -> the fused
+    buffers the engine consumes.  Restates the fold algebra of the reference's export constructor
+    (Export_MelBandRoformer.py:455-538) in float64 with one rounding to fp32 at the end, as the reference does:
+      * every RMSNorm gain (scale * gamma, scale = sqrt(dim)) folds into the Linear that consumes it (band split :456-461,
+        attention input :505-511, feed-forward :514-516, transformer output norm :519);
+      * q | k | v | gates stack into one projection, the attention scale dim_head^-1/2 folds into the q rows (:507-511);
+      * the mask-estimator MLP's two uniform Linears stack across bands, transposed for bmm (:498-501); the scatter-average
+        1 / (bands owning a bin) folds into the GLU value rows of the last Linear (:471-492).
+    Pinned against the reference's own constructor by tests/test_melband.py::test_checkpoint_fusion_matches_reference."""
+    g = {k: np.asarray(v, np.float64) for k, v in state.items()}
+    di = heads * dim_head
+    fi, dims = band_tables(SAMPLE_RATE, NFFT, num_bands, 2)
+    out: Dict[str, np.ndarray] = {}
+
+    def rms_gain(gamma):
+        return gamma * float(gamma.shape[0]) ** 0.5
+
+    for i in range(num_bands):
+        p = f"band_split.to_features.{i}."
+        out[f"bs_w_{i}"] = g[p + "1.weight"] * rms_gain(g[p + "0.gamma"])[None, :]
+        out[f"bs_b_{i}"] = g[p + "1.bias"]
+    depth = 0
+    while f"layers.{depth}.0.layers.0.0.to_qkv.weight" in g:
+        depth += 1
+    for i in range(depth):
+        for axis, name in ((0, "time"), (1, "freq")):
+            p = f"layers.{i}.{axis}."
+            a, f = p + "layers.0.0.", p + "layers.0.1."
+            wqkv = g[a + "to_qkv.weight"]
+            stacked = np.concatenate((wqkv[:di] * dim_head ** -0.5, wqkv[di:2 * di], wqkv[2 * di:], g[a + "to_gates.weight"]), axis=0)
+            out[f"{name}{i}_in_w"] = stacked * rms_gain(g[a + "norm.gamma"])[None, :]
+            out[f"{name}{i}_in_b"] = np.concatenate((np.zeros(3 * di), g[a + "to_gates.bias"]))
+            out[f"{name}{i}_out_w"] = g[a + "to_out.0.weight"]
+            out[f"{name}{i}_ff1_w"] = g[f + "net.1.weight"] * rms_gain(g[f + "net.0.gamma"])[None, :]
+            out[f"{name}{i}_ff1_b"] = g[f + "net.1.bias"]
+            out[f"{name}{i}_ff2_w"] = g[f + "net.4.weight"]
+            out[f"{name}{i}_ff2_b"] = g[f + "net.4.bias"]
+            out[f"{name}{i}_out_g"] = rms_gain(g[p + "norm.gamma"])
+    # bands owning each channel-interleaved bin -> per gathered entry, repeated for (re, im)
+    owners = np.bincount(fi, minlength=2 * (NFFT // 2 + 1)).astype(np.float64)
+    denom = np.repeat(1.0 / np.maximum(owners, 1e-8)[fi], 2)
+    w1, b1, w2, b2, off = [], [], [], [], 0
+    for i in range(num_bands):
+        p = f"mask_estimators.0.to_freqs.{i}.0."
+        d = int(dims[i])
+        w1.append(g[p + "0.weight"]); b1.append(g[p + "0.bias"]); w2.append(g[p + "2.weight"]); b2.append(g[p + "2.bias"])
+        w3, b3 = g[p + "4.weight"].copy(), g[p + "4.bias"].copy()
+        w3[:d] *= denom[off:off + d, None]
+        b3[:d] *= denom[off:off + d]
+        off += d
+        out[f"me_w3_{i}"], out[f"me_b3_{i}"] = w3, b3
+    out["me_w1t"] = np.stack(w1).transpose(0, 2, 1)
+    out["me_b1"] = np.stack(b1)[:, None, :]
+    out["me_w2t"] = np.stack(w2).transpose(0, 2, 1)
+    out["me_b2"] = np.stack(b2)[:, None, :]
+    return {k: np.ascontiguousarray(v, np.float32) for k, v in out.items()}

@@ -42,7 +42,7 @@ def position_tables(frames: int, rot_dim: int = 32, pos_scale: float = 1.0) -> D
 def model_tensors(fused: Mapping[str, np.ndarray], scalars: Mapping, window: int) -> Dict[str, np.ndarray]:
     """``fused`` (registered buffer name -> array) + position tables for ``window`` samples + the scalar attributes."""
     out = {k: np.ascontiguousarray(v, np.float32) for k, v in fused.items()}
-    out.update(position_tables(frames_of(window), int(scalars["rot_dim"])))
+    out.update(position_tables(frames_of(window), int(scalars["rot_dim"]), float(scalars.get("pos_scale", 1.0))))
     pads, dils = list(scalars["fs_mem_paddings"]), list(scalars["fs_mem_dilations"])
     lorder = pads[0] + 1                                           # padding_j = lorder + (dil_j - 1)(lorder - 1) - 1, dil_0 = 1 (:283-287)
     for j, (p, d) in enumerate(zip(pads, dils)):
@@ -119,3 +119,80 @@ def flops_per_window(frames: int, layers: int, group: int = 256) -> float:
     per_layer += 2 * (padded // group) * (group * group * 128 + group * group * 2048) + 2 * 128 * 2048 * frames * 2
     tail = 2 * frames * (16 * 512 + 512 * 512 + 512 * 2048 + 2 * 512 * 512 + 2 * 512 * 16)
     return float(layers * per_layer + tail)
+
+
+def fuse_checkpoint(state: Mapping[str, np.ndarray], frames: int, scalars: Mapping = None):
+    """clearvoice ``MossFormer2_SS_16K`` ``state_dict`` -> (fused buffers, scalar attributes) for ``frames`` encoder frames per window.
+    Restates the fold algebra of the reference's export wrapper (Export_MossFormer2_SS_16K.py:130-395) in float64 with one rounding
+    to fp32, as the reference does:
+      * the front GroupNorm affine folds into the 1x1 conv that consumes it (:222-228);
+      * to_hidden | to_qk share one ScaleNorm: their Linears stack, the scalar gains g / scale fold into the weights, their
+        depthwise kernels stack (:236-262); the to_out ScaleNorm gain folds into its Linear (:250);
+      * 1 / group_size folds into the quadratic-query OffsetScale row and 1 / frames into the linear-key row (:251-256);
+      * to_u | to_v share one affine-free LayerNorm: each branch's LayerNorm affine folds into its Linear, then they stack (:300-310);
+      * conv1d_out folds into output | output_gate per speaker (:367-389).
+    ``scalars``: the attributes that are not parameters (eps values, group size, memory order); default = the published geometry
+    (DEFAULT_SCALARS).  Pinned against the reference's own constructor by tests/test_mossformer.py::test_checkpoint_fusion_matches_reference."""
+    g = {k: np.asarray(v, np.float64) for k, v in state.items()}
+    sc = dict(DEFAULT_SCALARS if scalars is None else scalars)
+    group = int(sc["flash_group_size"])
+    out: Dict[str, np.ndarray] = {}
+    mn = "mask_net."
+    out["encoder_w"], out["decoder_w"], out["mask_decoder_w"] = g["enc.conv1d.weight"], g["dec.weight"], g[mn + "conv1_decoder.weight"]
+    out["mm_norm_w"], out["mm_norm_b"] = g[mn + "mdl.intra_mdl.norm.weight"], g[mn + "mdl.intra_mdl.norm.bias"]
+    out["intra_norm_w"], out["intra_norm_b"] = g[mn + "mdl.intra_norm.weight"], g[mn + "mdl.intra_norm.bias"]
+    fw = g[mn + "conv1d_encoder.weight"]
+    out["front_w"] = fw * g[mn + "norm.weight"][None, :, None]
+    out["front_b"] = fw[:, :, 0] @ g[mn + "norm.bias"] + (g[mn + "conv1d_encoder.bias"] if mn + "conv1d_encoder.bias" in g else 0.0)
+    lp = mn + "mdl.intra_mdl.mossformerM."
+    layers = 0
+    while f"{lp}layers.{layers}.to_hidden.mdl.1.weight" in g:
+        layers += 1
+    alphas = []
+    for i in range(layers):
+        fl = f"{lp}layers.{i}."
+        dim = g[fl + "to_hidden.mdl.1.weight"].shape[1]
+        in_fold, out_fold = float(dim) ** 0.5, float(g[fl + "to_out.mdl.1.weight"].shape[1]) ** 0.5          # 1 / ScaleNorm.scale, scale = dim^-1/2
+        out[f"fl_in_w_{i}"] = np.concatenate((g[fl + "to_hidden.mdl.1.weight"] * g[fl + "to_hidden.mdl.0.g"] * in_fold,
+                                              g[fl + "to_qk.mdl.1.weight"] * g[fl + "to_qk.mdl.0.g"] * in_fold), axis=0)
+        out[f"fl_in_b_{i}"] = np.concatenate((g[fl + "to_hidden.mdl.1.bias"], g[fl + "to_qk.mdl.1.bias"]))
+        out[f"fl_in_c_{i}"] = np.concatenate((g[fl + "to_hidden.mdl.3.sequential.1.conv.weight"], g[fl + "to_qk.mdl.3.sequential.1.conv.weight"]), axis=0)
+        out[f"fl_out_w_{i}"] = g[fl + "to_out.mdl.1.weight"] * g[fl + "to_out.mdl.0.g"] * out_fold
+        out[f"fl_out_b_{i}"] = g[fl + "to_out.mdl.1.bias"]
+        out[f"fl_out_c_{i}"] = g[fl + "to_out.mdl.3.sequential.1.conv.weight"]
+        row = np.array([1.0 / group, 1.0, 1.0, 1.0 / frames])[:, None]
+        out[f"qkos_gamma_{i}"] = g[fl + "qk_offset_scale.gamma"] * row
+        out[f"qkos_beta_{i}"] = g[fl + "qk_offset_scale.beta"] * row
+        fb = f"{lp}fsmn.{i}."
+        gf = fb + "gated_fsmn."
+        ws, bs, cs = [], [], []
+        for br in ("to_u", "to_v"):
+            lw, lb = g[f"{gf}{br}.mdl.1.weight"], g[f"{gf}{br}.mdl.1.bias"]
+            ws.append(lw * g[f"{gf}{br}.mdl.0.weight"][None, :])
+            bs.append(lw @ g[f"{gf}{br}.mdl.0.bias"] + lb)
+            cs.append(g[f"{gf}{br}.mdl.3.sequential.1.conv.weight"])
+        out[f"fs_uv_w_{i}"], out[f"fs_uv_b_{i}"], out[f"fs_uv_c_{i}"] = np.concatenate(ws), np.concatenate(bs), np.concatenate(cs)
+        for j in range(int(sc["fs_mem_depth"])):
+            out[f"fs_mem_w_{i}_{j}"] = g[f"{gf}fsmn.conv.conv{j + 1}.weight"][..., 0]
+            out[f"fs_mem_norm_w_{i}_{j}"], out[f"fs_mem_norm_b_{i}_{j}"] = g[f"{gf}fsmn.conv.norm{j + 1}.weight"], g[f"{gf}fsmn.conv.norm{j + 1}.bias"]
+            out[f"fs_mem_prelu_{i}_{j}"] = g[f"{gf}fsmn.conv.prelu{j + 1}.weight"]
+        out[f"fs_mem_linear_w_{i}"], out[f"fs_mem_linear_b_{i}"] = g[gf + "fsmn.linear.weight"], g[gf + "fsmn.linear.bias"]
+        out[f"fs_mem_project_w_{i}"] = g[gf + "fsmn.project.weight"]
+        out[f"fs_front_w_{i}"], out[f"fs_front_b_{i}"] = g[fb + "conv1.0.weight"][..., 0], g[fb + "conv1.0.bias"]
+        out[f"fs_back_w_{i}"], out[f"fs_back_b_{i}"] = g[fb + "conv2.weight"][..., 0], g[fb + "conv2.bias"]
+        out[f"fs_n1_w_{i}"], out[f"fs_n1_b_{i}"] = g[fb + "norm1.weight"], g[fb + "norm1.bias"]
+        out[f"fs_n2_w_{i}"], out[f"fs_n2_b_{i}"] = g[fb + "norm2.weight"], g[fb + "norm2.bias"]
+        alphas.append(float(g[fb + "conv1.1.weight"].reshape(-1)[0]))
+    gate_w = np.concatenate((g[mn + "output.0.weight"], g[mn + "output_gate.0.weight"]), axis=0)[..., 0]
+    gate_b = np.concatenate((g[mn + "output.0.bias"], g[mn + "output_gate.0.bias"]))
+    cw, cb = g[mn + "conv1d_out.weight"][..., 0], g[mn + "conv1d_out.bias"]
+    ch = gate_w.shape[1]
+    tw, tb = [], []
+    for spk in range(cw.shape[0] // ch):
+        tw.append(gate_w @ cw[spk * ch:(spk + 1) * ch])
+        tb.append(gate_w @ cb[spk * ch:(spk + 1) * ch] + gate_b)
+    out["tail_gate_w"], out["tail_gate_b"] = np.concatenate(tw)[..., None], np.concatenate(tb)
+    sc["tail_prelu_alpha"] = float(g[mn + "prelu.weight"].reshape(-1)[0])
+    sc["fs_front_alpha"] = alphas
+    sc["pos_scale"] = float(g[mn + "pos_enc.scale"].reshape(-1)[0]) if mn + "pos_enc.scale" in g else 1.0
+    return {k: np.ascontiguousarray(v, np.float32) for k, v in out.items()}, sc

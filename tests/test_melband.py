@@ -200,3 +200,23 @@ def test_gpu_long_clip_streams_keys_through_lds(fixture):
     d = got.astype(np.int32) - want.astype(np.int32)
     assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
     assert np.abs(want).max() > 1000
+
+
+def test_checkpoint_fusion_matches_reference():
+    """melband.fuse_checkpoint (upstream state_dict -> fused buffers) against the reference's own export constructor, run at
+    reduced width over generator-filled checkpoint tensors (tools/make_golden_melband.py::fusion_fixture)."""
+    from audio_denoiser_onnx_amd import melband
+    z = np.load(os.path.join(HERE, "golden", "melband_fusion.npz"))
+    state = {}
+    for key, shape, scale in json.loads(str(z["spec"])):
+        v = weightgen.tensor(key, shape, scale)
+        state[key] = np.abs(v) + np.float32(0.5) if key.endswith("gamma") else v
+    fused = melband.fuse_checkpoint(state, heads=int(z["heads"]), dim_head=int(z["dim_head"]))
+    names = json.loads(str(z["names"]))
+    assert set(names) == set(fused)
+    for name in names:
+        v = fused[name].reshape(-1).astype(np.float64)
+        got = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+        want = z[f"s_{name}"]
+        assert np.allclose(got[:-1], want[:-1], rtol=2e-6, atol=1e-7), name
+        assert abs(got[-1] - want[-1]) <= 1e-5 * max(1.0, np.abs(v).sum()), name

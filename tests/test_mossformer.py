@@ -127,3 +127,30 @@ def test_gpu_batch_rows_and_oracle_on_other_inputs(fixture):
     assert np.abs(d).max() <= 3 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
     assert np.all(got[2] == 0)                                               # a silent window stays silent (gain 0 / 0 -> 0, :618-622)
     assert np.array_equal(one[0][0], outs[0][1]) and np.array_equal(one[1][0], outs[1][1])
+
+
+def test_checkpoint_fusion_matches_reference():
+    """mossformer.fuse_checkpoint (clearvoice state_dict -> fused buffers + scalars) against the reference's own export constructor
+    run over a one-layer stand-in tree with generator-filled parameters (tools/make_golden_mossformer.py::fusion_fixture)."""
+    from audio_denoiser_onnx_amd import weightgen
+    z = np.load(os.path.join(HERE, "golden", "mossformer_fusion.npz"))
+    state = {}
+    for key, shape, scale in json.loads(str(z["spec"])):
+        v = weightgen.tensor(key, shape, scale)
+        state[key] = np.abs(v) + np.float32(0.4) if scale == 0.6 else v
+    want_sc = json.loads(str(z["scalars"]))
+    fused, sc = mossformer.fuse_checkpoint(state, int(want_sc["static_frames"]))
+    fused.update({k: v for k, v in mossformer.position_tables(int(want_sc["static_frames"]), 32, sc["pos_scale"]).items() if k == "emb_pos"})
+    names = json.loads(str(z["names"]))
+    assert set(names) == set(fused), set(names) ^ set(fused)
+    for name in names:
+        v = fused[name].reshape(-1).astype(np.float64)
+        got = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+        want = z[f"s_{name}"]
+        tol = 2e-4 if name == "emb_pos" else 2e-6                  # emb_pos: sin / cos of fp32 angles up to 300 rad, libm vs torch
+        assert np.allclose(got[:-1], want[:-1], rtol=tol, atol=tol), name
+        assert abs(got[-1] - want[-1]) <= 1e-5 * max(1.0, np.abs(v).sum()), name
+    for k in ("tail_prelu_alpha", "fl_norm_eps", "fl_out_norm_eps", "front_norm_eps", "mm_norm_eps", "intra_norm_eps", "fs_ln_eps", "fs_n1_eps", "fs_n2_eps",
+              "norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fs_mem_depth"):
+        assert abs(float(sc[k]) - float(want_sc[k])) <= 1e-6 * abs(float(want_sc[k])), k
+    assert np.allclose(sc["fs_front_alpha"], want_sc["fs_front_alpha"])

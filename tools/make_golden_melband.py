@@ -157,5 +157,46 @@ def main():
     print("fold out", out.shape, int(np.abs(out).max()))
 
 
+def fusion_fixture():
+    """Pins audio_denoiser_onnx_amd.melband.fuse_checkpoint: the reference's constructor at REDUCED width (dim 32, 2 heads of 16;
+    the fold algebra :455-538 is width-generic) over a checkpoint-shaped tree whose parameters come from the generator, keyed by
+    their state_dict names.  The fixture keeps the (key, shape, scale) spec and, per fused buffer, 64 strided samples + its sum."""
+    ns = import_namespace(L)
+    T = ns["MAX_SIGNAL_LENGTH"]
+    STFT_Process = import_stft_process("Mel_Band_Roformer/Stereo").STFT_Process
+    stft = STFT_Process("stft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], 0, ns["WINDOW_TYPE"], True, "reflect").eval()
+    istft = STFT_Process("istft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], T, ns["WINDOW_TYPE"], True, "reflect", static_frames=True).eval()
+    spec = []
+
+    def fill(self, sd, strict=True):
+        with torch.no_grad():
+            for key, p in self.state_dict().items():
+                if key.endswith(("rotary_pos_emb", "rotary_cos_freq", "rotary_sin_freq")) or not p.dtype.is_floating_point:
+                    continue
+                scale = 0.5 if key.endswith("gamma") else 0.3
+                v = weightgen.tensor(key, list(p.shape), scale)
+                if key.endswith("gamma"):
+                    v = np.abs(v) + np.float32(0.5)
+                p.copy_(torch.from_numpy(v))
+                spec.append((key, list(p.shape), scale))
+        return types.SimpleNamespace(missing_keys=[], unexpected_keys=[])
+    real_load, real_lsd = torch.load, nn.Module.load_state_dict
+    torch.load = lambda *a, **k: {}
+    nn.Module.load_state_dict = fill
+    try:
+        model = ns["MelBandRoformer"](stft, istft, T, False, 0, L, dim=32, depth=2, stereo=True, num_stems=1, time_transformer_depth=1,
+                                      freq_transformer_depth=1, num_bands=60, dim_head=16, heads=2, mask_estimator_depth=2).eval()
+    finally:
+        torch.load, nn.Module.load_state_dict = real_load, real_lsd
+    samples = {}
+    for name, shape, _ in weight_spec(model):
+        v = dict(model.named_buffers())[name].numpy().reshape(-1).astype(np.float64)
+        samples[name] = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+    np.savez_compressed(os.path.join(mg.GOLD, "melband_fusion.npz"), spec=np.array(json.dumps(spec)), heads=np.int64(2), dim_head=np.int64(16),
+                        names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
+    print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
+
+
 if __name__ == "__main__":
     main()
+    fusion_fixture()

@@ -263,5 +263,40 @@ def main():
     print("fold out", out.shape, np.abs(out).max(axis=1))
 
 
+def fusion_fixture():
+    """Pins audio_denoiser_onnx_amd.mossformer.fuse_checkpoint: the reference's constructor over a ONE-layer stand-in tree whose
+    parameters come from the generator keyed by their state_dict names; the fixture keeps the (key, shape, scale) spec and, per
+    fused buffer, 64 strided samples + its sum, plus the scalar attributes the constructor derived."""
+    from audio_denoiser_onnx_amd import weightgen
+    ns = import_namespace(WINDOW, False, 1.5)
+    torch.manual_seed(0)
+    net = stand_in_network(1)
+    spec = []
+    with torch.no_grad():
+        for key, p in net.state_dict().items():
+            if key.endswith(("inv_freq", "freqs", "running_mean", "running_var", "num_batches_tracked")):
+                continue
+            scale = 0.6 if key.endswith((".g", "scale", "gamma")) or "norm" in key and key.endswith("weight") else 0.3
+            v = weightgen.tensor(key, list(p.shape), scale)
+            if scale == 0.6:
+                v = np.abs(v) + np.float32(0.4)
+            p.copy_(torch.from_numpy(v))
+            spec.append((key, list(p.shape), scale))
+    model = ns["MOSSFORMER_SS"](net, WINDOW, 16000, 16000, False, 0).eval()
+    skip = ("inv_int16", "rot_cos", "rot_sin", "rot_signed_sin", "rot_pair_index", "shift_pad", "pad_A4", "pad_VU", "gn_one", "gn_zero")
+    samples = {}
+    for name, buf in model.named_buffers():
+        if name in skip:
+            continue
+        v = buf.detach().numpy().reshape(-1).astype(np.float64)
+        samples[name] = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+    scalars = {k: float(getattr(model, k)) for k in SCALAR_ATTRS}
+    scalars["fs_front_alpha"] = [float(a) for a in model.fs_front_alpha]
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_fusion.npz"), spec=np.array(json.dumps(spec)), scalars=np.array(json.dumps(scalars)),
+                        names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
+    print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
+
+
 if __name__ == "__main__":
     main()
+    fusion_fixture()
