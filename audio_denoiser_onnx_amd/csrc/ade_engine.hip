@@ -703,10 +703,16 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
 ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32) {
     if (B == 0) return ADE_OK;
     e->last_batch = B;
-    if (e->sub) {
-        std::string derr;
-        const int rc = e->sub->run(s, d_in, B, d_out, d_f32, derr);
-        return rc == ADE_OK ? ADE_OK : fail(e, (ade_status)rc, derr);
+    std::string sub_err;
+    int sub_rc = ADE_OK;
+    // the launch sequence of one call: a sub-engine's (hundreds of GEMM / row kernels) or GTCRN's
+    auto launch_all = [&](bool timed) {
+        if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
+        else enqueue(e, s, d_in, B, d_out, d_f32, timed);
+    };
+    if (e->sub && (e->profile || !e->use_graph || !e->graph_supported)) {
+        launch_all(false);
+        return sub_rc == ADE_OK ? ADE_OK : fail(e, (ade_status)sub_rc, sub_err);
     }
     if (e->profile) {
         for (auto& st : e->stats) { st.ms = 0.f; st.launches = 0; }
@@ -723,17 +729,19 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     }
     // A captured graph pays off for the multi-kernel launch sequences (10 or 34 launches).  The single-launch path is one
     // kernel: a plain launch has less per-step overhead than a one-node graph (measured: 0.462 vs 0.475 ms per step).
-    const bool one_kernel = e->use_fused && e->use_single && fused_supported(e->T);
+    // Sub-engines (300 - 800 launches per call) are launch-bound at small batches: replaying the captured sequence removes the
+    // per-launch host cost (their workspace is reserved before capture; reserve() drops the graphs when it reallocates).
+    const bool one_kernel = !e->sub && e->use_fused && e->use_single && fused_supported(e->T);
     if (e->use_graph && e->graph_supported && !one_kernel) {
         GraphEntry* hit = nullptr;
         for (auto& g : e->graphs)
             if (g.in == d_in && g.out_pcm == d_out && g.out_f32 == d_f32 && g.batch == B) hit = &g;
         if (!hit) {
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                enqueue(e, s, d_in, B, d_out, d_f32, false);
+                launch_all(false);
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
-                if (hipStreamEndCapture(s, &graph) == hipSuccess && graph &&
+                if (hipStreamEndCapture(s, &graph) == hipSuccess && graph && sub_rc == ADE_OK &&
                     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     if (e->graphs.size() >= 8) {
                         hipGraphExecDestroy(e->graphs.front().exec);
@@ -756,7 +764,8 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
             return ADE_OK;
         }
     }
-    enqueue(e, s, d_in, B, d_out, d_f32, false);
+    launch_all(false);
+    if (sub_rc != ADE_OK) return fail(e, (ade_status)sub_rc, sub_err);
     HIP_TRY(e, hipGetLastError());
     return ADE_OK;
 }
