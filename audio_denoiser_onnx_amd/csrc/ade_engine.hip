@@ -770,6 +770,72 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     return ADE_OK;
 }
 
+// ---- streaming: the multi-kernel launch sequence over pushes of N frames with carried state -------
+}  // namespace
+
+struct ade_stream {
+    ade_engine* e = nullptr;
+    int S = 0, N = 0;
+    bool first = true;
+    int16_t *pcm_hist = nullptr, *concat = nullptr, *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    float *d_f32 = nullptr, *h_f32 = nullptr;
+    float* state = nullptr;      // one allocation: dc | conv histories (ping-pong) | TRA hidden | inter-GRU hidden | OLA carry
+    size_t state_floats = 0;
+    float* dc = nullptr;
+    float* hist[6][2] = {};
+    int hist_cur[6] = {};
+    float* tra_h[6] = {};
+    float* inter_h[2] = {};
+    float* carry = nullptr;
+    float* ws = nullptr;         // activations of one push, same tensor set as the engine's multi-kernel workspace
+    float *spec = nullptr, *feat = nullptr, *e0 = nullptr, *e1 = nullptr, *h = nullptr, *zt = nullptr, *rnn = nullptr, *d3 = nullptr, *mask = nullptr,
+          *frames = nullptr, *xe[3] = {}, *ate[3] = {}, *xd[3] = {}, *atd[3] = {}, *dpm[2] = {}, *dpo[2] = {};
+};
+
+namespace {
+
+void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t* d_out, float* d_f32) {
+    ade_engine* e = st->e;
+    const int B = st->S, T = st->N, nfr = B * T, P = T * kHop;
+    launch_stream_concat(s, st->pcm_hist, d_in, st->concat, B, P, st->first);
+    launch_stream_keep(s, st->concat, st->pcm_hist, B, P);
+    launch_stft_pcm(s, st->concat, st->dc, B, P + kHop, T, e->tabs, e->erb_bm, st->spec, st->feat, /*center=*/false);
+    launch_conv0(s, st->feat, e->en0, st->e0, nfr);
+    launch_conv1(s, st->e0, e->en1, st->e1, nfr);
+    const View none{nullptr, nullptr};
+    View x{st->e1, nullptr};
+    auto gt_block = [&](int gi, const GtConvW& w, View in, View skip, float* xn, float* at) {
+        launch_gt_pw1(s, in, skip, w, st->h, nfr);
+        const int cur = st->hist_cur[gi];
+        launch_gt_dw_pw2(s, st->h, in, skip, w, xn, st->zt, B, T, st->hist[gi][cur]);
+        launch_hist_shift(s, st->hist[gi][cur], st->h, st->hist[gi][cur ^ 1], B, T, 2 * w.dilation);
+        st->hist_cur[gi] = cur ^ 1;
+        launch_tra(s, st->zt, w, at, B, T, st->tra_h[gi]);
+    };
+    for (int i = 0; i < 3; ++i) {
+        gt_block(i, e->en_gt[i], x, none, st->xe[i], st->ate[i]);
+        x = View{st->xe[i], st->ate[i]};
+    }
+    for (int i = 0; i < 2; ++i) {
+        launch_intra_gru(s, x, e->dp[i].intra_gru, st->rnn, nfr);
+        launch_fc_ln_res(s, st->rnn, x, e->dp[i].intra_fc, e->dp[i].intra_fc_b, e->dp[i].intra_ln_w, e->dp[i].intra_ln_b, st->dpm[i], B, T);
+        launch_inter_gru(s, st->dpm[i], e->dp[i].inter_gru, st->rnn, B, T, st->inter_h[i]);
+        launch_fc_ln_res(s, st->rnn, View{st->dpm[i], nullptr}, e->dp[i].inter_fc, e->dp[i].inter_fc_b, e->dp[i].inter_ln_w, e->dp[i].inter_ln_b,
+                         st->dpo[i], B, T);
+        x = View{st->dpo[i], nullptr};
+    }
+    for (int i = 0; i < 3; ++i) {
+        const View skip{st->xe[2 - i], st->ate[2 - i]};
+        gt_block(3 + i, e->de_gt[i], x, skip, st->xd[i], st->atd[i]);
+        x = View{st->xd[i], st->atd[i]};
+    }
+    launch_deconv3(s, x, View{st->e1, nullptr}, e->de3, st->d3, nfr);
+    launch_deconv4(s, st->d3, st->e0, e->de4, st->mask, nfr);
+    launch_istft_masked(s, st->spec, st->mask, e->erb_bs, e->tabs, st->frames, nfr);
+    launch_ola_pcm_stream(s, st->frames, st->carry, e->tabs, B, T, st->first, d_out, d_f32);
+    st->first = false;
+}
+
 }  // namespace
 
 // ======================================= C ABI ================================================================
@@ -1147,6 +1213,121 @@ ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int f
     hipFree(tmp);
     if (err != hipSuccess) return fail(h, ADE_ERR_DEVICE, hipGetErrorString(err));
     return ADE_OK;
+}
+
+
+// ---- streaming entry points ---------------------------------------------------------------------------------------------
+ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, ade_stream_handle* out) {
+    if (!out) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_create: out is NULL");
+    *out = nullptr;
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (h->sub || h->n_win != 1) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stream_create: streaming is implemented for plain GTCRN handles");
+    if (n_streams < 1 || frames_per_push < 2 || frames_per_push > 4096)
+        return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_create: need n_streams >= 1 and 2 <= frames_per_push <= 4096 (the first push reflects 257 samples)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ade_stream* st = new ade_stream();
+    st->e = h; st->S = n_streams; st->N = frames_per_push;
+    const size_t S = (size_t)n_streams, nfr = S * frames_per_push, P = (size_t)frames_per_push * kHop;
+    auto bail = [&](const char* what) { h->last_error = what; ade_stream_destroy(st); return ADE_ERR_DEVICE; };
+    // state
+    const GtConvW* gts[6] = {&h->en_gt[0], &h->en_gt[1], &h->en_gt[2], &h->de_gt[0], &h->de_gt[1], &h->de_gt[2]};
+    size_t total = (S + 63) & ~(size_t)63;
+    size_t o_hist[6][2], o_tra[6], o_inter[2], o_carry;
+    auto take = [&](size_t n) { const size_t at = total; total += (n + 63) & ~(size_t)63; return at; };
+    for (int i = 0; i < 6; ++i) {
+        const size_t n = S * 2 * gts[i]->dilation * kFw * kCh;
+        o_hist[i][0] = take(n); o_hist[i][1] = take(n);
+        o_tra[i] = take(S * 16);
+    }
+    for (int i = 0; i < 2; ++i) o_inter[i] = take(S * kFw * kCh);
+    o_carry = take(S * kHop);
+    st->state_floats = total;
+    if (hipMalloc((void**)&st->state, total * sizeof(float)) != hipSuccess) return bail("ade_stream_create: hipMalloc of the stream state failed");
+    st->dc = st->state;
+    for (int i = 0; i < 6; ++i) { st->hist[i][0] = st->state + o_hist[i][0]; st->hist[i][1] = st->state + o_hist[i][1]; st->tra_h[i] = st->state + o_tra[i]; }
+    for (int i = 0; i < 2; ++i) st->inter_h[i] = st->state + o_inter[i];
+    st->carry = st->state + o_carry;
+    // activations of one push
+    struct Carve { float** p; size_t n; };
+    std::vector<Carve> cs = {{&st->spec, nfr * 2 * kBinsPad}, {&st->feat, nfr * 3 * kErbPad}, {&st->e0, nfr * kF1 * kCh}, {&st->e1, nfr * kFw * kCh},
+                             {&st->h, nfr * kFw * kCh}, {&st->zt, nfr * 8}, {&st->rnn, nfr * kFw * kCh}, {&st->d3, nfr * kF1 * kCh},
+                             {&st->mask, nfr * 2 * kErbPad}, {&st->frames, nfr * kNfft}};
+    for (int i = 0; i < 3; ++i) {
+        cs.push_back({&st->xe[i], nfr * kFw * kCh}); cs.push_back({&st->ate[i], nfr * 8});
+        cs.push_back({&st->xd[i], nfr * kFw * kCh}); cs.push_back({&st->atd[i], nfr * 8});
+    }
+    for (int i = 0; i < 2; ++i) { cs.push_back({&st->dpm[i], nfr * kFw * kCh}); cs.push_back({&st->dpo[i], nfr * kFw * kCh}); }
+    size_t wtotal = 0;
+    for (auto& c : cs) wtotal += (c.n + 63) & ~(size_t)63;
+    if (hipMalloc((void**)&st->ws, wtotal * sizeof(float)) != hipSuccess) return bail("ade_stream_create: hipMalloc of the push workspace failed");
+    size_t at = 0;
+    for (auto& c : cs) { *c.p = st->ws + at; at += (c.n + 63) & ~(size_t)63; }
+    if (hipMalloc((void**)&st->pcm_hist, S * kHop * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->concat, S * (P + kHop) * sizeof(int16_t)) != hipSuccess ||
+        hipMalloc((void**)&st->d_in, S * P * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->d_out, S * P * sizeof(int16_t)) != hipSuccess ||
+        hipMalloc((void**)&st->d_f32, S * P * sizeof(float)) != hipSuccess ||
+        hipHostMalloc((void**)&st->h_in, S * P * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&st->h_out, S * P * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&st->h_f32, S * P * sizeof(float), hipHostMallocDefault) != hipSuccess)
+        return bail("ade_stream_create: allocation of the PCM staging buffers failed");
+    *out = st;
+    return ade_stream_reset(st);
+}
+
+ade_status ade_stream_reset(ade_stream_handle st) {
+    if (!st) return ADE_ERR_BAD_VALUE;
+    ade_engine* h = st->e;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemset(st->state, 0, st->state_floats * sizeof(float)));
+    HIP_TRY(h, hipMemset(st->pcm_hist, 0, (size_t)st->S * kHop * sizeof(int16_t)));
+    for (int i = 0; i < 6; ++i) st->hist_cur[i] = 0;
+    st->first = true;
+    return ADE_OK;
+}
+
+ade_status ade_stream_push_device(ade_stream_handle st, const int16_t* d_in, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream) {
+    if (!st || !d_in || (!d_out_pcm && !d_out_f32)) return ADE_ERR_BAD_VALUE;
+    ade_engine* h = st->e;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    enqueue_stream(st, s, d_in, d_out_pcm, d_out_f32);
+    HIP_TRY(h, hipGetLastError());
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+ade_status ade_stream_push(ade_stream_handle st, const int16_t* in, int16_t* out_pcm, float* out_f32) {
+    if (!st || !in || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
+    ade_engine* h = st->e;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)st->S * st->N * kHop;
+    memcpy(st->h_in, in, n * sizeof(int16_t));
+    HIP_TRY(h, hipMemcpyAsync(st->d_in, st->h_in, n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    enqueue_stream(st, h->stream, st->d_in, st->d_out, out_f32 ? st->d_f32 : nullptr);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(st->h_f32, st->d_f32, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_pcm) memcpy(out_pcm, st->h_out, n * sizeof(int16_t));
+    if (out_f32) memcpy(out_f32, st->h_f32, n * sizeof(float));
+    return ADE_OK;
+}
+
+void ade_stream_destroy(ade_stream_handle st) {
+    if (!st) return;
+    (void)hipSetDevice(st->e->device);
+    (void)hipDeviceSynchronize();
+    if (st->state) (void)hipFree(st->state);
+    if (st->ws) (void)hipFree(st->ws);
+    if (st->pcm_hist) (void)hipFree(st->pcm_hist);
+    if (st->concat) (void)hipFree(st->concat);
+    if (st->d_in) (void)hipFree(st->d_in);
+    if (st->d_out) (void)hipFree(st->d_out);
+    if (st->d_f32) (void)hipFree(st->d_f32);
+    if (st->h_in) (void)hipHostFree(st->h_in);
+    if (st->h_out) (void)hipHostFree(st->h_out);
+    if (st->h_f32) (void)hipHostFree(st->h_f32);
+    delete st;
 }
 
 }  // extern "C"

@@ -86,15 +86,15 @@ struct DpW {               // one DPGRNN block
 // ---- launchers (ade_kernels.hip) ---------------------------------------------------------------------------
 void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call = 1);
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs,
-                     BandTab erb_bm, float* spec, float* feat);
+                     BandTab erb_bm, float* spec, float* feat, bool center = true);
 void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec);
 void launch_conv0(hipStream_t s, const float* feat, ConvW w, float* e0, int nframes);
 void launch_conv1(hipStream_t s, const float* e0, ConvW w, float* e1, int nframes);
 void launch_gt_pw1(hipStream_t s, View a, View skip, GtConvW w, float* h, int nframes);
-void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T);
-void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T);
+void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T, const float* hist = nullptr);
+void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T, float* state = nullptr);
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes);
-void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T);
+void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state = nullptr);
 void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,
                       const float* ln_b, float* out, int B, int T);
 void launch_deconv3(hipStream_t s, View a, View skip, ConvW w, float* d3, int nframes);
@@ -103,6 +103,11 @@ void launch_istft_masked(hipStream_t s, const float* spec, const float* mask, Ba
                          int nframes);
 void launch_istft_ref(hipStream_t s, const float* ref_spec, int B, int T, FftTabs tabs, float* frames);
 void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int T, int16_t* pcm, float* f32);
+// streaming pieces (state carried across pushes; see ade_stream_* in include/ade.h)
+void launch_hist_shift(hipStream_t s, const float* hist_in, const float* h, float* hist_out, int B, int T, int depth);
+void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in, int16_t* concat, int B, int P, bool first);
+void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P);
+void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32);
 
 // ---- per-chunk LDS-resident stage kernels (ade_fused.hip); valid for T <= 64 frames -------------------------
 bool fused_supported(int T);

@@ -100,7 +100,7 @@ __device__ __forceinline__ void fft256_wave(float2* v, float2 (*buf)[256], int l
 template <bool PCM_IN>
 __global__ __launch_bounds__(256) void k_stft(const void* __restrict__ in, const float* __restrict__ mean, int L, int T,
                                               int nframes, FftTabs tabs, BandTab erb, float* __restrict__ spec,
-                                              float* __restrict__ feat, float* __restrict__ ref_spec) {
+                                              float* __restrict__ feat, float* __restrict__ ref_spec, int center) {
     __shared__ float2 zbuf[4][2][256];
     __shared__ float hi[4][3][kErbHigh];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -117,8 +117,11 @@ __global__ __launch_bounds__(256) void k_stft(const void* __restrict__ in, const
             float s[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                int j = kHop * t + 2 * n + q - kNfft / 2;          // index into the un-padded chunk
-                j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);   // reflect (STFT_Process.py:306-309)
+                int j = kHop * t + 2 * n + q;                      // streaming rows carry their own 256 samples of history: plain framing
+                if (center) {
+                    j -= kNfft / 2;                                // index into the un-padded chunk
+                    j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);   // reflect (STFT_Process.py:306-309)
+                }
                 float x = 0.0f;
                 if (live) {
                     if (PCM_IN) x = (float)(reinterpret_cast<const int16_t*>(in)[(size_t)b * L + j]) * (1.0f / 32768.0f) - dc;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256) void k_gt_pw1(View a, View skip, const float* 
 // energy zt[b,t,c] = mean_f h1^2 (:154).  Workgroup = 7 frames x 33 bins of one chunk.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gt_dw_pw2(const float* __restrict__ h, View a, View skip, GtConvW w,
-                                                   float* __restrict__ xn, float* __restrict__ zt, int T, int tiles) {
+                                                   float* __restrict__ xn, float* __restrict__ zt, int T, int tiles,
+                                                   const float* __restrict__ hist) {
     __shared__ float esq[kTileThreads][9];
     const int b = blockIdx.x / tiles, tile = blockIdx.x - b * tiles;
     const int tl = threadIdx.x / kFw, f = threadIdx.x - tl * kFw;
@@ -310,13 +314,14 @@ __global__ __launch_bounds__(256) void k_gt_dw_pw2(const float* __restrict__ h, 
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             const int tt = t - (2 - kt) * w.dilation;
-            if (tt < 0) continue;                                     // causal zero pad (:234-241,314-318)
+            if (tt < 0 && !hist) continue;                            // causal zero pad (:234-241,314-318)
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) {
                 const int ff = f - 1 + kf;
                 if (ff < 0 || ff >= kFw) continue;
                 float x[16];
-                ld16(h + (((size_t)b * T + tt) * kFw + ff) * kCh, x);
+                if (tt >= 0) ld16(h + (((size_t)b * T + tt) * kFw + ff) * kCh, x);
+                else ld16(hist + (((size_t)b * 2 * w.dilation + (2 * w.dilation + tt)) * kFw + ff) * kCh, x);   // streaming: the previous pushes' last 2 d frames
 #pragma unroll
                 for (int c = 0; c < 16; ++c) acc[c] += w.dw[(kt * 3 + kf) * 16 + c] * x[c];
             }
@@ -402,7 +407,7 @@ struct GruLane {
 // TRA (Export_GTCRN.py:144-156): zt (B,T,8) -> GRU(8->16) over T -> Linear(16->8) -> sigmoid -> at (B,T,8).
 // 16 lanes per chunk (one per hidden unit), 16 chunks per workgroup.
 __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const float* __restrict__ gru,
-                                             const float* __restrict__ fc, float* __restrict__ at, int B, int T) {
+                                             const float* __restrict__ fc, float* __restrict__ at, int B, int T, float* __restrict__ state) {
     const int site = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int j = threadIdx.x & 15;
     const bool live = site < B;
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
 #pragma unroll
     for (int k = 0; k < 16; ++k) fw[k] = fc[(j & 7) * 17 + k];
     const float fb = fc[(j & 7) * 17 + 16];
-    float h = 0.0f;
+    float h = state ? state[(size_t)b * 16 + j] : 0.0f;              // streaming: the hidden state carried from the previous push
     for (int t = 0; t < T; ++t) {
         float x[8];
         ld8(zt + ((size_t)b * T + t) * 8, x);
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
         for (int k = 0; k < 16; ++k) a += fw[k] * __shfl(h, k, 16);
         if (live && j < 8) at[((size_t)b * T + t) * 8 + j] = sigmoid_f(a);
     }
+    if (state && live) state[(size_t)b * 16 + j] = h;
 }
 
 // DPGRNN intra GRNN (Export_GTCRN.py:409-428,441-446,472-473): for every (b,t) frame, 2 groups x 2 directions of
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void k_intra_gru(View x, const float* __restri
 // DPGRNN inter GRNN (Export_GTCRN.py:450-455,478-479): for every (b,f) column, 2 groups of GRU(8->8) along T.
 // 16 lanes per column: lane = group*8 + unit.
 __global__ __launch_bounds__(256) void k_inter_gru(const float* __restrict__ x, const float* __restrict__ gru,
-                                                   float* __restrict__ rnn, int B, int T) {
+                                                   float* __restrict__ rnn, int B, int T, float* __restrict__ state) {
     const int site = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int q = threadIdx.x & 15;
     const int grp = q >> 3;
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void k_inter_gru(const float* __restrict__ x, 
     const int b = sc / kFw, f = sc - b * kFw;
     GruLane<8> g;
     g.load(gru + q * 54);
-    float h = 0.0f;
+    float h = state ? state[(size_t)sc * kCh + q] : 0.0f;             // streaming: carried per (stream, bin) column
     for (int t = 0; t < T; ++t) {
         const size_t pos = ((size_t)b * T + t) * kFw + f;
         float xv[8];
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(256) void k_inter_gru(const float* __restrict__ x, 
         h = g.step(xv, h);
         if (live) rnn[pos * kCh + q] = h;
     }
+    if (state && live) state[(size_t)sc * kCh + q] = h;
 }
 
 // Linear(16,16) + LayerNorm((33,16), eps 1e-8, affine) + residual (Export_GTCRN.py:447-448,473-475,479-481).
@@ -710,6 +717,67 @@ __global__ __launch_bounds__(256) void k_ola_pcm(const float* __restrict__ frame
     }
 }
 
+// ---- streaming: state carried across pushes of T frames per stream ---------------------------------
+// history of a GTConvBlock's depthwise input: out = last `depth` frames of [hist_in | h]  (depth = 2 * dilation)
+__global__ __launch_bounds__(256) void k_hist_shift(const float* __restrict__ hist_in, const float* __restrict__ h, float* __restrict__ hist_out,
+                                                    int T, int depth, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int per = kFw * kCh, e = (int)(i % per);
+    const long long fr = i / per;
+    const int b = (int)(fr / depth), k = (int)(fr - (long long)b * depth);
+    const int src = k + T;                                   // index into the concatenation [hist (depth) | h (T)]
+    hist_out[i] = src < depth ? hist_in[((size_t)b * depth + src) * per + e] : h[((size_t)b * T + (src - depth)) * per + e];
+}
+// concat[b] = [256 samples of history | the push]; a fresh stream's history is the reflection x[256], ..., x[1] (STFT_Process.py:306-309)
+__global__ __launch_bounds__(256) void k_stream_concat(const int16_t* __restrict__ hist, const int16_t* __restrict__ in, int16_t* __restrict__ concat,
+                                                       int P, int first, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int row = P + kHop, b = (int)(i / row), j = (int)(i - (long long)b * row);
+    concat[i] = j >= kHop ? in[(size_t)b * P + (j - kHop)] : (first ? in[(size_t)b * P + (kHop - j)] : hist[(size_t)b * kHop + j]);
+}
+__global__ __launch_bounds__(256) void k_stream_keep(const int16_t* __restrict__ concat, int16_t* __restrict__ hist, int P, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / kHop), j = (int)(i - (long long)b * kHop);
+    hist[i] = concat[(size_t)b * (P + kHop) + P + j];
+}
+// overlap-add with a carried half frame: output hop k of the push = second half of frame k - 1 (the carry for k = 0) + first half of
+// frame k, / sum(w^2); one hop behind the input (a frame is complete one hop after its centre).  The very first hop of a stream has no
+// predecessor and is written as zeros.  PCM tail as k_ola_pcm.
+__global__ __launch_bounds__(256) void k_ola_pcm_stream(const float* __restrict__ frames, const float* __restrict__ carry, const float* __restrict__ win_sum,
+                                                        int T, int B, int first, int16_t* __restrict__ pcm, float* __restrict__ f32) {
+    const int per = T * (kHop / 4);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * per) return;
+    const int b = (int)(idx / per);
+    const int n = (int)(idx - (long long)b * per) * 4;
+    const int j = n >> 8, r = n & 255;
+    float a[4], c[4], ws[4], v[4];
+    if (j > 0) ld4(frames + ((size_t)b * T + j - 1) * kNfft + kHop + r, a);
+    else ld4(carry + (size_t)b * kHop + r, a);
+    ld4(frames + ((size_t)b * T + j) * kNfft + r, c);
+    ld4(win_sum + r, ws);
+    const bool blank = first && j == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = blank ? 0.0f : (a[i] + c[i]) / ws[i];
+    const size_t o = (size_t)b * (size_t)T * kHop + n;
+    if (f32) st4(f32 + o, v);
+    if (pcm) {
+        short q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (short)(int)fminf(fmaxf(v[i] * 32767.0f, -32768.0f), 32767.0f);
+        *reinterpret_cast<short4*>(pcm + o) = make_short4(q[0], q[1], q[2], q[3]);
+    }
+}
+__global__ __launch_bounds__(256) void k_carry_keep(const float* __restrict__ frames, float* __restrict__ carry, int T, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / kHop), r = (int)(i - (long long)b * kHop);
+    carry[i] = frames[((size_t)b * T + T - 1) * kNfft + kHop + r];
+}
+
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------------
@@ -717,16 +785,16 @@ void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mea
     hipLaunchKernelGGL(k_pcm_mean, dim3(B / rows_per_call), dim3(256), 0, s, pcm, L, rows_per_call, mean);
 }
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs, BandTab erb_bm,
-                     float* spec, float* feat) {
+                     float* spec, float* feat, bool center) {
     const int nframes = B * T;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<true>), grid1(nframes, 4), dim3(256), 0, s, (const void*)pcm, mean, L, T, nframes,
-                       tabs, erb_bm, spec, feat, (float*)nullptr);
+                       tabs, erb_bm, spec, feat, (float*)nullptr, center ? 1 : 0);
 }
 void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec) {
     const int nframes = B * T;
     BandTab none = {nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<false>), grid1(nframes, 4), dim3(256), 0, s, (const void*)x, (const float*)nullptr, L,
-                       T, nframes, tabs, none, (float*)nullptr, (float*)nullptr, ref_spec);
+                       T, nframes, tabs, none, (float*)nullptr, (float*)nullptr, ref_spec, 1);
 }
 void launch_conv0(hipStream_t s, const float* feat, ConvW w, float* e0, int nframes) {
     hipLaunchKernelGGL(k_conv0, grid1((long long)nframes * kF1, 256), dim3(256), 0, s, feat, w.w, w.b, w.slope, e0, nframes);
@@ -738,18 +806,33 @@ void launch_gt_pw1(hipStream_t s, View a, View skip, GtConvW w, float* h, int nf
     hipLaunchKernelGGL(k_gt_pw1, grid1((long long)nframes * kFw, 256), dim3(256), 0, s, a, skip, w.pw1, w.pw1_b, w.pw1_slope, h,
                        nframes);
 }
-void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T) {
+void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T, const float* hist) {
     const int tiles = (T + kTileFrames - 1) / kTileFrames;
-    hipLaunchKernelGGL(k_gt_dw_pw2, dim3(B * tiles), dim3(256), 0, s, h, a, skip, w, xn, zt, T, tiles);
+    hipLaunchKernelGGL(k_gt_dw_pw2, dim3(B * tiles), dim3(256), 0, s, h, a, skip, w, xn, zt, T, tiles, hist);
 }
-void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T) {
-    hipLaunchKernelGGL(k_tra, grid1(B, 16), dim3(256), 0, s, zt, w.gru, w.fc, at, B, T);
+void launch_hist_shift(hipStream_t s, const float* hist_in, const float* h, float* hist_out, int B, int T, int depth) {
+    const long long n = (long long)B * depth * kFw * kCh;
+    hipLaunchKernelGGL(k_hist_shift, grid1(n, 256), dim3(256), 0, s, hist_in, h, hist_out, T, depth, n);
+}
+void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in, int16_t* concat, int B, int P, bool first) {
+    hipLaunchKernelGGL(k_stream_concat, grid1((long long)B * (P + kHop), 256), dim3(256), 0, s, hist, in, concat, P, first ? 1 : 0, (long long)B * (P + kHop));
+}
+void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P) {
+    hipLaunchKernelGGL(k_stream_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, concat, hist, P, (long long)B * kHop);
+}
+void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32) {
+    const long long n = (long long)B * T * (kHop / 4);
+    hipLaunchKernelGGL(k_ola_pcm_stream, grid1(n, 256), dim3(256), 0, s, frames, (const float*)carry, tabs.win_sum, T, B, first ? 1 : 0, pcm, f32);
+    hipLaunchKernelGGL(k_carry_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, frames, carry, T, (long long)B * kHop);
+}
+void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T, float* state) {
+    hipLaunchKernelGGL(k_tra, grid1(B, 16), dim3(256), 0, s, zt, w.gru, w.fc, at, B, T, state);
 }
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes) {
     hipLaunchKernelGGL(k_intra_gru, grid1(nframes, 16), dim3(256), 0, s, x, gru, rnn, nframes);
 }
-void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T) {
-    hipLaunchKernelGGL(k_inter_gru, grid1((long long)B * kFw, 16), dim3(256), 0, s, x, gru, rnn, B, T);
+void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state) {
+    hipLaunchKernelGGL(k_inter_gru, grid1((long long)B * kFw, 16), dim3(256), 0, s, x, gru, rnn, B, T, state);
 }
 void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,
                       const float* ln_b, float* out, int B, int T) {

@@ -292,7 +292,7 @@ template <int TAPS, int CIN, int TT, bool CENTER>
 __global__ __launch_bounds__(256) void k_tconv(const float* __restrict__ src0, const float* __restrict__ src1, int ld0, int ld1, int split,
                                                const float* __restrict__ w, const float* __restrict__ res, float* __restrict__ y, int ldy, int n, int dil,
                                                int pad, float4* __restrict__ partial) {
-    extern __shared__ float tile[];
+    HIP_DYNAMIC_SHARED(float, tile)
     __shared__ float red[2][4][64];
     constexpr int kCols = 64 * CIN, kPer = TT / 4;
     const int t0 = (int)blockIdx.x * TT, g0 = (int)blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;

@@ -204,3 +204,57 @@ class InferenceSession:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class StreamingSession:
+    """Stateful streaming over a GTCRN session (``ade_stream_*``, include/ade.h).
+
+    ``n_streams`` independent audio streams advance together, ``frames_per_push`` hops (x 256 samples) at a time.  The STFT overlap,
+    the causal-convolution histories and every GRU hidden state are carried on the device between pushes, so the concatenated outputs
+    equal what the reference's graph computes on the whole signal in ONE call -- one hop (256 samples) later, the stream's first hop
+    zero, and without the reference's whole-call DC removal (not causal).  The reference itself has no such mode: its driver calls a
+    stateless graph per slice (Inference_GTCRN_ONNX.py:307-317)."""
+
+    def __init__(self, session: InferenceSession, n_streams: int, frames_per_push: int):
+        self._lib, self._session = session._lib, session
+        self.n_streams, self.frames_per_push, self.samples_per_push = int(n_streams), int(frames_per_push), int(frames_per_push) * 256
+        self._h = C.c_void_p()
+        self._lib.check(self._lib.c.ade_stream_create(session._h, self.n_streams, self.frames_per_push, C.byref(self._h)), session._h)
+
+    def push(self, pcm: np.ndarray, want_f32: bool = False):
+        """int16 (n_streams, samples_per_push) -> int16 of the same shape (+ fp32 pre-PCM waveform)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        if pcm.shape != (self.n_streams, self.samples_per_push):
+            raise ValueError(f"expected int16 ({self.n_streams}, {self.samples_per_push}), got {pcm.shape}")
+        out = np.empty_like(pcm)
+        f32 = np.empty(pcm.shape, np.float32) if want_f32 else None
+        st = self._lib.c.ade_stream_push(self._h, pcm.ctypes.data, out.ctypes.data, f32.ctypes.data if want_f32 else None)
+        self._lib.check(st, self._session._h)
+        return (out, f32) if want_f32 else out
+
+    def push_device(self, d_in, d_out, d_f32=None, stream: Optional[int] = None) -> None:
+        if tuple(d_in.shape) != (self.n_streams, self.samples_per_push) or tuple(d_out.shape) != tuple(d_in.shape):
+            raise ValueError("device tensors must be (n_streams, samples_per_push) int16")
+        st = self._lib.c.ade_stream_push_device(self._h, C.c_void_p(d_in.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                                C.c_void_p(d_f32.data_ptr()) if d_f32 is not None else None, C.c_void_p(stream) if stream else None)
+        self._lib.check(st, self._session._h)
+
+    def reset(self) -> None:
+        self._lib.check(self._lib.c.ade_stream_reset(self._h), self._session._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.c.ade_stream_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -112,6 +112,25 @@ void ade_destroy(ade_handle h);
 ade_status ade_stft_forward(ade_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
 ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
 
+/* ---- stateful streaming over the GTCRN path -----------------------------------------------------
+ * The reference resets every state at each slice (zero GRU state, zero causal padding, reflected STFT edges:
+ * Inference_GTCRN_ONNX.py:307-317 calls a stateless graph), so slice edges are audible and a slice cannot be shorter than the
+ * network's memory.  A stream carries, per independent audio stream: the last 256 input samples (STFT overlap), each GTConvBlock's
+ * last 2 * dilation frames of depthwise input, the six TRA GRU and two inter-frame GRU hidden states, and the ISTFT overlap.
+ * Pushing a long signal in pieces of frames_per_push * 256 samples then produces EXACTLY what the reference's graph would produce
+ * on the whole signal in one call (every op of the network is causal in time), with two stated differences: the output is one
+ * hop (256 samples, 16 ms) behind the input -- a frame is complete one hop after its centre -- with the stream's first hop zero;
+ * and the per-call DC removal of GTCRN_CUSTOM.forward (Export_GTCRN.py:647, a mean over the WHOLE call, not computable causally)
+ * is not applied.  GTCRN handles only (not batch-fold, not the other model families).  All streams of a handle advance together. */
+typedef struct ade_stream* ade_stream_handle;
+ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, ade_stream_handle* out);
+/* in / out: [n_streams][frames_per_push * 256] int16 (out_f32 optional float, pre-PCM-tail), caller-owned HOST buffers; synchronous. */
+ade_status ade_stream_push(ade_stream_handle s, const int16_t* in, int16_t* out_pcm, float* out_f32);
+/* the same on DEVICE buffers; enqueues on `hip_stream` (NULL = the engine's stream, then synchronous). */
+ade_status ade_stream_push_device(ade_stream_handle s, const int16_t* d_in, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream);
+ade_status ade_stream_reset(ade_stream_handle s);      /* back to a fresh stream (zero state, next push reflects its head) */
+void ade_stream_destroy(ade_stream_handle s);           /* before ade_destroy of its engine */
+
 /* ---- generic STFT_Process operator: any n_fft / win_length / hop / window, for the other model families -------
  * Replaces the reference's STFT_Process module in its 'stft_B' (packed) and 'istft_B' (packed, static_norm=True) forms
  * as instantiated by GTCRN (512/512/256 hann_sqrt, GTCRN/Export_GTCRN.py:719-741), ZipEnhancer (400/400/100 hann,
