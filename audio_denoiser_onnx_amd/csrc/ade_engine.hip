@@ -43,7 +43,7 @@ struct ade_engine {
     int device = 0;
     int in_len = 0, T = 0, out_len = 0;   // per WINDOW (== per call unless batch-fold)
     int n_win = 1;                        // windows per call: USE_BATCH_FOLD folds (1,1,n_win*W) into (n_win,1,W), Export_GTCRN.py:656-660
-    int sample_rate = 16000;
+    int sample_rate = 16000, in_rate = 0, out_rate = 0;   // model rate; caller-side rates when they differ (0 = same)
     std::string last_error;
     std::map<std::string, std::string> meta;
     std::vector<float> blob_storage;
@@ -51,6 +51,12 @@ struct ade_engine {
 
     ade::SubEngine* sub = nullptr;        // model_family "dfsmn" / "mel_band_roformer": a sub-engine (everything below is GTCRN's)
     int channels = 1, n_outputs = 1;      // in_len / out_len below count one batch item: channels * samples in, n_outputs * channels * samples out
+    // driver-edge resampling around a sub-engine (in / out sample rate != model rate): caller-side lengths above, model-side below
+    bool resample = false;
+    int rs_model_in = 0, rs_model_out = 0;     // per channel row, at the model rate
+    float rs_scale_in = 1.0f, rs_scale_out = 1.0f, rs_pcm_scale = 1.0f;
+    bool rs_truncate_i32 = false;
+    float *rs_in = nullptr, *rs_out = nullptr;
 
     hipStream_t stream = nullptr;
     float* d_weights = nullptr;
@@ -529,6 +535,9 @@ void free_workspace(ade_engine* e) {
     if (e->h_pcm_in) hipHostFree(e->h_pcm_in);
     if (e->h_pcm_out) hipHostFree(e->h_pcm_out);
     if (e->h_f32_out) hipHostFree(e->h_f32_out);
+    if (e->rs_in) hipFree(e->rs_in);
+    if (e->rs_out) hipFree(e->rs_out);
+    e->rs_in = e->rs_out = nullptr;
     e->ws = nullptr;
     e->d_pcm_in = e->d_pcm_out = nullptr;
     e->d_f32_out = nullptr;
@@ -553,6 +562,10 @@ ade_status reserve(ade_engine* e, int batch) {
         HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
         HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
         HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
+        if (e->resample) {
+            HIP_TRY(e, hipMalloc((void**)&e->rs_in, B * e->channels * e->rs_model_in * sizeof(float)));
+            HIP_TRY(e, hipMalloc((void**)&e->rs_out, B * e->channels * e->n_outputs * e->rs_model_out * sizeof(float)));
+        }
         e->capacity = batch;
         return ADE_OK;
     }
@@ -707,7 +720,15 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     int sub_rc = ADE_OK;
     // the launch sequence of one call: a sub-engine's (hundreds of GEMM / row kernels) or GTCRN's
     auto launch_all = [&](bool timed) {
-        if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
+        if (e->sub && e->resample) {   // interpolate to the model rate, run on floats, interpolate the float waveform back and apply the PCM tail
+            const long long rows_in = (long long)B * e->channels, rows_out = (long long)B * e->channels * e->n_outputs;
+            launch_resample_in(s, d_in, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in);
+            e->sub->float_in = e->rs_in;
+            sub_rc = e->sub->run(s, d_in, B, nullptr, e->rs_out, sub_err);
+            e->sub->float_in = nullptr;
+            launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->channels * e->n_outputs), e->rs_scale_out,
+                                e->rs_pcm_scale, e->rs_truncate_i32);
+        } else if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
         else enqueue(e, s, d_in, B, d_out, d_f32, timed);
     };
     if (e->sub && (e->profile || !e->use_graph || !e->graph_supported)) {
@@ -876,12 +897,23 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (!parse_int(e->meta["in_sample_rate"], &sri) || !parse_int(e->meta["out_sample_rate"], &sro) ||
             !parse_int(e->meta["model_sample_rate"], &srm) || !parse_int(e->meta["input_audio_length"], &Ld))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
-        if (srm != rate || sri != srm || sro != srm)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (resampling path not implemented)"));
+        const bool rates_differ = sri != srm || sro != srm;
+        if (srm != rate) return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at a model rate of " + std::to_string(rate) + " Hz"));
+        // Resampling edges exist where the reference's STATIC export is self-consistent: MossFormer2 sizes its frames from the model-rate
+        // length (Export_MossFormer2_SS_16K.py:36-37,99-104).  DFSMN has no such path; Mel-Band-Roformer (like GTCRN) sizes its static frame
+        // count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with its STFT when the rates are equal.
+        if (rates_differ && !fam_moss)
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
+        if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
             return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
         if (Ld < 16 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
         long sub_win = 1;
+        const long caller_len = Ld;
+        if (rates_differ) {   // MODEL_AUDIO_LENGTH = round(L * model / in) (:36); batch-fold needs equal rates (:92-93)
+            if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
+            Ld = (long)llround((double)caller_len * (double)srm / (double)sri);
+        }
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
             long fw = 0;    //                                                            (Export_MelBandRoformer.py:47-51, 644-647)
             if (!e->meta.count("fold_window_length") || !parse_int(e->meta["fold_window_length"], &fw) || fw <= 0)
@@ -920,7 +952,21 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         e->in_len = e->sub->in_len() * e->channels;
         e->T = e->sub->frames();
         e->out_len = e->sub->out_len() * e->channels * e->n_outputs;
+        if (rates_differ) {   // F.interpolate(size = ...) on both edges (:562-571, :625-640): source scale = source length / target length
+            const long out_caller = (long)llround((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
+            e->resample = true;
+            e->rs_model_in = e->sub->in_len();
+            e->rs_model_out = e->sub->out_len();
+            e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);
+            e->rs_scale_out = (float)((double)e->rs_model_out / (double)out_caller);
+            e->rs_pcm_scale = 1.0f;            // MossFormer2's waveform is already in PCM units (rms restore, :622-623)
+            e->rs_truncate_i32 = true;         // .to(int32).clamp().to(int16) (:645)
+            e->in_len = (int)caller_len * e->channels;
+            e->out_len = (int)out_caller * e->channels * e->n_outputs;
+        }
         e->sample_rate = (int)rate;
+        e->in_rate = (int)sri;
+        e->out_rate = (int)sro;
         e->blob_storage.clear();
         e->blob_storage.shrink_to_fit();
         e->tensors.clear();
@@ -1019,7 +1065,9 @@ ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
     d->n_outputs = h->n_outputs;
     d->in_len = h->in_len / h->channels * h->n_win;       // per channel; what one call sees (the fold is internal)
     d->out_len = h->out_len / (h->channels * h->n_outputs) * h->n_win;
-    d->in_sample_rate = d->out_sample_rate = d->model_sample_rate = h->sample_rate;
+    d->model_sample_rate = h->sample_rate;
+    d->in_sample_rate = h->in_rate ? h->in_rate : h->sample_rate;
+    d->out_sample_rate = h->out_rate ? h->out_rate : h->sample_rate;
     d->frames = h->T;
     d->max_batch = h->capacity / h->n_win;
     d->device = h->device;

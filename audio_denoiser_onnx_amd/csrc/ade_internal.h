@@ -107,6 +107,9 @@ void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int
 void launch_hist_shift(hipStream_t s, const float* hist_in, const float* h, float* hist_out, int B, int T, int depth);
 void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in, int16_t* concat, int B, int P, bool first);
 void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P);
+// linear resampling of the driver edges (F.interpolate(mode='linear', align_corners=False)); src = scale * (dst + 0.5) - 0.5
+void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale);
+void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32);
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32);
 
 // ---- per-chunk LDS-resident stage kernels (ade_fused.hip); valid for T <= 64 frames -------------------------
@@ -154,6 +157,10 @@ struct SubEngine {
     virtual int in_len() const = 0;      // samples per channel row
     virtual int out_len() const = 0;
     virtual int channels() const { return 1; }
+    // Resampled input (in_sample_rate != model_sample_rate): when set, run() reads its PCM from here -- floats in int16 units, same
+    // [batch][channels()][in_len()] layout -- instead of d_in (the reference interpolates `audio.float()` before anything else).
+    const float* float_in = nullptr;
+    virtual bool accepts_float_input() const { return false; }
     virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][channels()][out_len()]
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status
     virtual int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) = 0;

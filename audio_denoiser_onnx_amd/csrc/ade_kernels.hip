@@ -778,6 +778,46 @@ __global__ __launch_bounds__(256) void k_carry_keep(const float* __restrict__ fr
     carry[i] = frames[((size_t)b * T + T - 1) * kNfft + kHop + r];
 }
 
+// ---- driver-edge resampling: torch.nn.functional.interpolate(mode='linear', align_corners=False) over the last axis (fp32) -----
+__device__ __forceinline__ void lerp_coords(int i, int Lin, float scale, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)i + 0.5f) - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    if (i0 > Lin - 1) i0 = Lin - 1;
+    i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void k_resample_in(const int16_t* __restrict__ in, float* __restrict__ out, int Lin, int Lout, float scale, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / Lout;
+    const int i = (int)(idx - r * Lout);
+    int i0, i1;
+    float l1;
+    lerp_coords(i, Lin, scale, i0, i1, l1);
+    const int16_t* row = in + r * Lin;
+    out[idx] = (1.0f - l1) * (float)row[i0] + l1 * (float)row[i1];
+}
+// output edge: interpolate the model-rate float waveform, scale to PCM, clamp, cast (truncate_i32: the int32 cast of MossFormer2, which
+// truncates before clamping; otherwise the float clamp then truncating cast of the STFT models)
+__global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ in, int16_t* __restrict__ pcm, float* __restrict__ f32, int Lin, int Lout,
+                                                      float scale, float pcm_scale, int truncate_i32, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / Lout;
+    const int i = (int)(idx - r * Lout);
+    int i0, i1;
+    float l1;
+    lerp_coords(i, Lin, scale, i0, i1, l1);
+    const float* row = in + r * Lin;
+    const float y = (1.0f - l1) * row[i0] + l1 * row[i1];
+    if (f32) f32[idx] = y;
+    if (pcm) {
+        const float v = y * pcm_scale;
+        pcm[idx] = (int16_t)(int)fminf(fmaxf(truncate_i32 ? truncf(v) : v, -32768.0f), 32767.0f);
+    }
+}
+
 }  // namespace
 
 // ---- launchers -------------------------------------------------------------------------------------------
@@ -819,6 +859,12 @@ void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in,
 }
 void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P) {
     hipLaunchKernelGGL(k_stream_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, concat, hist, P, (long long)B * kHop);
+}
+void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale) {
+    hipLaunchKernelGGL(k_resample_in, grid1(rows * Lout, 256), dim3(256), 0, s, in, out, Lin, Lout, scale, rows * Lout);
+}
+void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32) {
+    hipLaunchKernelGGL(k_resample_out, grid1(rows * Lout, 256), dim3(256), 0, s, in, pcm, f32, Lin, Lout, scale, pcm_scale, truncate_i32 ? 1 : 0, rows * Lout);
 }
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32) {
     const long long n = (long long)B * T * (kHop / 4);

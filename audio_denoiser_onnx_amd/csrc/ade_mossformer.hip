@@ -58,17 +58,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // ---- RMS stages --------------------------------------------------------------------------------------------------------------
 // norm_audio (:403-423): one workgroup per window.  gains[b] = {scalar, scalarx}; rms_in[b] = rms * g * 1 / (g + eps) * 32767.
-__global__ __launch_bounds__(1024) void k_norm_audio(const int16_t* __restrict__ pcm, int W, float norm_factor, float2* __restrict__ gains,
-                                                     float* __restrict__ rms_in) {
+__global__ __launch_bounds__(1024) void k_norm_audio(const int16_t* __restrict__ pcm, const float* __restrict__ fpcm, int W, float norm_factor,
+                                                     float2* __restrict__ gains, float* __restrict__ rms_in) {
     __shared__ float red[16];
     const int16_t* x = pcm + (size_t)blockIdx.x * W;
+    const float* xf = fpcm ? fpcm + (size_t)blockIdx.x * W : nullptr;       // resampled input (floats in int16 units) replaces pcm when set
     const float eps = 1e-6f;
     float s = 0.0f;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) { const float v = (float)x[i] * (1.0f / 32768.0f); s += v * v; }
+    for (int i = threadIdx.x; i < W; i += blockDim.x) { const float v = (xf ? xf[i] : (float)x[i]) * (1.0f / 32768.0f); s += v * v; }
     const float avg = block_sum(s, red) / (float)W;
     float hs = 0.0f, hc = 0.0f;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
-        const float v = (float)x[i] * (1.0f / 32768.0f), p = v * v;
+        const float v = (xf ? xf[i] : (float)x[i]) * (1.0f / 32768.0f), p = v * v;
         if (p > avg) { hs += p; hc += 1.0f; }
     }
     hs = block_sum(hs, red);
@@ -99,12 +100,14 @@ __global__ __launch_bounds__(1024) void k_window_stats(const float* __restrict__
 struct EncFrameA {             // A((b, t), k) = normalised sample 8 t + k of window b (:579-582); the two gains apply in the reference's order
     static constexpr bool kAlongK = true;
     const int16_t* pcm;
+    const float* fpcm;
     const float2* gains;
     int W, n;
     __device__ float operator()(int m, int k) const {
         const int b = m / n, t = m - b * n;
         const float2 g = gains[b];
-        return (((float)pcm[(size_t)b * W + kEncS * t + k] * (1.0f / 32768.0f)) * g.x) * g.y;
+        const size_t at = (size_t)b * W + kEncS * t + k;
+        return (((fpcm ? fpcm[at] : (float)pcm[at]) * (1.0f / 32768.0f)) * g.x) * g.y;
     }
 };
 template <int ACT>             // 0 none, 1 relu, 2 silu, 3 leaky(alpha)
@@ -569,6 +572,7 @@ struct MossformerEngine : SubEngine {
     int frames() const override { return n; }
     int in_len() const override { return W * n_win; }
     int out_len() const override { return W * n_win; }
+    bool accepts_float_input() const override { return true; }
     int n_outputs() const override { return kSpk; }          // separated_0 / separated_1 (:689-690)
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
@@ -715,8 +719,8 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     };
 
     // front end: RMS stages, encoder, window norm folded into the 1x1 conv, positions                         (:571-591)
-    hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, W, hyper[hNormFactor], gains, rms_in);
-    launch(s, EncFrameA{d_in, gains, W, n}, WeightNK{encoder_w, kEncK}, BiasActRowStore<1>{XE, nullptr, kDim, 0.0f}, R, kDim, kEncK);
+    hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, float_in, W, hyper[hNormFactor], gains, rms_in);
+    launch(s, EncFrameA{d_in, float_in, gains, W, n}, WeightNK{encoder_w, kEncK}, BiasActRowStore<1>{XE, nullptr, kDim, 0.0f}, R, kDim, kEncK);
     hipLaunchKernelGGL(k_window_stats, dim3((unsigned)B), dim3(1024), 0, s, (const float*)XE, (long long)n * kDim, hyper[hFrontEps], wstats);
     launch(s, RowMajorA{XE, kDim}, WeightNK{front_w, kDim}, FrontStore{H, MI, wstats, front_wsum, front_b, emb_pos, n}, R, kDim, kDim);
 

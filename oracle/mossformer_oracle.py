@@ -46,6 +46,18 @@ def _dwconv(x, c, pad):
     return out.astype(F32)
 
 
+def interpolate_linear(x, out_len):
+    """F.interpolate(x, size=out_len, mode='linear', align_corners=False) over the last axis, fp32 (the export's resampling edges :562-571,
+    :625-640): src = (in / out) * (dst + 0.5) - 0.5 clamped at 0, y = (1 - l) x[i0] + l x[min(i0 + 1, in - 1)]."""
+    n = x.shape[-1]
+    scale = F32(n / out_len)
+    src = np.maximum(scale * (np.arange(out_len, dtype=F32) + F32(0.5)) - F32(0.5), F32(0.0)).astype(F32)
+    i0 = np.minimum(src.astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    l1 = (src - i0.astype(F32)).astype(F32)
+    return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
 class MossFormerOracle:
     """tensors: the fused buffers by registered name (encoder_w, front_w, fl_in_w_i, ..., tail_gate_w, decoder_w) plus emb_pos
     (1, 512, n) and rot_cos / rot_signed_sin (1, n, 1, rot_dim); scalars: the dict the golden tool stores."""
@@ -72,7 +84,7 @@ class MossFormerOracle:
     def _norm_audio(self, pcm):
         """(B, W) int16 -> normalised (B, W), rms_in (B,)   (:403-423)."""
         eps, nf = F32(1e-6), F32(self.s["norm_factor"])
-        x = pcm.astype(F32) * F32(1.0 / 32768.0)
+        x = pcm.astype(F32) * F32(1.0 / 32768.0)            # pcm: int16, or floats in int16 units after the input interpolation
         p = (x * x).astype(F32)
         avg = p.mean(axis=1, keepdims=True, dtype=F32)
         rms = np.sqrt(avg).astype(F32)
@@ -160,12 +172,16 @@ class MossFormerOracle:
         n2 = _layer_norm(y, w[f"fs_n2_w_{i}"], w[f"fs_n2_b_{i}"], s["fs_n2_eps"])
         return (n2 @ w[f"fs_back_w_{i}"].T + w[f"fs_back_b_{i}"] + h).astype(F32)                          # (:541)
 
-    def process(self, pcm: np.ndarray) -> np.ndarray:
-        """pcm int16 (B, W): B independent windows -> int16 (B, 2, W)."""
-        assert pcm.ndim == 2 and pcm.shape[1] == self.W and pcm.dtype == np.int16
+    def process(self, pcm: np.ndarray, out_len: int = 0) -> np.ndarray:
+        """pcm int16 (B, L): B independent windows -> int16 (B, 2, L_out).  L != W or out_len: the resampling edges (in / out rate != 16 kHz):
+        the int16 samples are interpolated to W model-rate samples as floats, the restored waveform to out_len before the int cast."""
+        assert pcm.ndim == 2 and pcm.dtype == np.int16
         w, s, n = self.w, self.s, self.n
         B = pcm.shape[0]
-        x, rms_in = self._norm_audio(pcm)
+        xin = pcm.astype(F32)
+        if pcm.shape[1] != self.W:
+            xin = interpolate_linear(xin, self.W)
+        x, rms_in = self._norm_audio(xin)
         fr = np.stack([x[:, ENC_S * t:ENC_S * t + ENC_K] for t in range(n)], axis=1)                        # (B, n, 16)
         x_enc = np.maximum(fr @ w["encoder_w"][:, 0, :].T, F32(0.0)).astype(F32).transpose(0, 2, 1)        # (B, 512, n) (:579-582)
         normed = self._window_norm(x_enc, s["front_norm_eps"])
@@ -195,6 +211,8 @@ class MossFormerOracle:
         with np.errstate(divide="ignore", invalid="ignore"):
             gain = np.where(rms_out > 0, rms_in[:, None, None] / rms_out, F32(0.0)).astype(F32)             # (:622)
         out = (wav * gain).astype(F32)
+        if out_len and out_len != self.W:
+            out = interpolate_linear(out, out_len)
         self.taps["wav"] = out.copy()
         return np.clip(np.trunc(out.astype(np.float64)), -32768, 32767).astype(np.int16)                    # (:645) int32 cast truncates
 

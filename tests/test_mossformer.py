@@ -19,6 +19,7 @@ from audio_denoiser_onnx_amd import mossformer  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden", "mossformer_seed0_io.npz")
 GOLD_FOLD = os.path.join(HERE, "golden", "mossformer_seed0_fold_io.npz")
+GOLD_RESAMPLE = os.path.join(HERE, "golden", "mossformer_seed0_resample_io.npz")
 
 
 @pytest.fixture(scope="module")
@@ -56,6 +57,14 @@ def test_oracle_batch_fold_matches_reference_forward(fixture):
     zf = np.load(GOLD_FOLD)
     out = _oracle(fixture).process_fold(zf["pcm_in"])
     d = out.astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+
+
+def test_oracle_resampling_edges_match_reference_forward(fixture):
+    """IN 8 kHz -> model 16 kHz -> OUT 48 kHz in the reference (F.interpolate on both edges) against the oracle."""
+    zr = np.load(GOLD_RESAMPLE)
+    out = _oracle(fixture).process(zr["pcm_in"][None], out_len=zr["pcm_out"].shape[1])[0]
+    d = out.astype(np.int32) - zr["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
 
 
@@ -154,3 +163,17 @@ def test_checkpoint_fusion_matches_reference():
               "norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fs_mem_depth"):
         assert abs(float(sc[k]) - float(want_sc[k])) <= 1e-6 * abs(float(want_sc[k])), k
     assert np.allclose(sc["fs_front_alpha"], want_sc["fs_front_alpha"])
+
+
+@pytest.mark.gpu
+def test_gpu_resampling_edges_match_reference_fixture(fixture):
+    """in_sample_rate 8000 / out_sample_rate 48000 manifest: linear interpolation on both edges around the 16 kHz model, like the export."""
+    zr = np.load(GOLD_RESAMPLE)
+    L_in, L_out = zr["pcm_in"].shape[0], zr["pcm_out"].shape[1]
+    with _session(fixture, L_in, in_sample_rate=int(zr["in_rate"]), out_sample_rate=int(zr["out_rate"])) as sess:
+        assert sess.in_len == L_in and sess.out_len == L_out and sess.frames == mossformer.frames_of(fixture[3])
+        outs = sess.run(None, {"mix_audio": np.stack((zr["pcm_in"], zr["pcm_in"]))[:, None]})
+    for spk in range(2):
+        d = outs[spk][0, 0].astype(np.int32) - zr["pcm_out"][spk].astype(np.int32)
+        assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (spk, np.abs(d).max(), (d != 0).mean())
+        assert np.array_equal(outs[spk][0], outs[spk][1])

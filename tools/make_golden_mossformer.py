@@ -37,12 +37,13 @@ LAYERS = 2
 WINDOW = 2408          # (2408 - 16) // 8 + 1 = 300 frames: two FLASH groups of 256, the second padded with 212 zero rows
 
 
-def import_namespace(length: int, fold: bool, window_seconds: float) -> dict:
+def import_namespace(length: int, fold: bool, window_seconds: float, in_rate: int = 16000, out_rate: int = 16000) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "MossFormer2_SS_16K", "Export_MossFormer2_SS_16K.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
-    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds, "IN_SAMPLE_RATE": in_rate,
+            "OUT_SAMPLE_RATE": out_rate}
     keep = []
     for node in tree.body:
         if isinstance(node, ast.ClassDef):
@@ -194,10 +195,10 @@ SCALAR_ATTRS = ("norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fl_norm
                 "static_window_batch", "static_window_output", "fl_inv_g", "static_inv_n")
 
 
-def build(ns, length, fold, window):
+def build(ns, length, fold, window, in_rate=16000, out_rate=16000):
     torch.manual_seed(0)
     net = stand_in_network(LAYERS)
-    model = ns["MOSSFORMER_SS"](net, length, 16000, 16000, fold, window if fold else 0).eval()
+    model = ns["MOSSFORMER_SS"](net, length, in_rate, out_rate, fold, window if fold else 0).eval()
     spec = []
     skip = ("inv_int16", "emb_pos", "rot_cos", "rot_sin", "rot_signed_sin", "rot_pair_index", "shift_pad", "pad_A4", "pad_VU", "gn_one", "gn_zero")
     with torch.no_grad():
@@ -261,6 +262,18 @@ def main():
     np.savez_compressed(os.path.join(mg.GOLD, "mossformer_seed0_fold_io.npz"), pcm_in=pcm, pcm_out=out, input_audio_length=np.int64(3 * WINDOW - 500),
                         fold_window_length=np.int64(WINDOW))
     print("fold out", out.shape, np.abs(out).max(axis=1))
+
+    # resampling edges (:562-571, :625-640): 8 kHz in -> 16 kHz model (1204 -> 2408 samples, the same 300 frames) -> 48 kHz out (7224)
+    ns = import_namespace(WINDOW // 2, False, 1.5, in_rate=8000, out_rate=48000)
+    assert ns["MODEL_AUDIO_LENGTH"] == WINDOW and ns["OUTPUT_AUDIO_LENGTH"] == 3 * WINDOW
+    model, spec3, _ = build(ns, WINDOW // 2, False, 0, 8000, 48000)
+    assert spec3 == spec
+    pcm = np.ascontiguousarray(read_mix(24000, WINDOW)[::2])
+    with torch.inference_mode():
+        outs = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy()))
+    out = np.stack([o.numpy().reshape(-1) for o in outs])
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_seed0_resample_io.npz"), pcm_in=pcm, pcm_out=out, in_rate=np.int64(8000), out_rate=np.int64(48000))
+    print("resample out", out.shape, np.abs(out).max(axis=1))
 
 
 def fusion_fixture():
