@@ -750,8 +750,10 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     }
     // A captured graph pays off for the multi-kernel launch sequences (10 or 34 launches).  The single-launch path is one
     // kernel: a plain launch has less per-step overhead than a one-node graph (measured: 0.462 vs 0.475 ms per step).
-    // Sub-engines (300 - 800 launches per call) are launch-bound at small batches: replaying the captured sequence removes the
-    // per-launch host cost (their workspace is reserved before capture; reserve() drops the graphs when it reallocates).
+    // Sub-engines enqueue 300 - 800 launches per call; the captured sequence is replayed so that the host cost of issuing them does not
+    // depend on the caller's CPU (their workspace is reserved before capture; reserve() drops the graphs when it reallocates).  On the
+    // bench host the replay measured the same as plain launches (MossFormer2, 1 window: 26.9 ms both ways): small batches are bound by
+    // GPU-side kernel latency and by the few single-workgroup reductions, not by the host.
     const bool one_kernel = !e->sub && e->use_fused && e->use_single && fused_supported(e->T);
     if (e->use_graph && e->graph_supported && !one_kernel) {
         GraphEntry* hit = nullptr;
