@@ -15,7 +15,8 @@
 //   * ScaleNorm / window-norm folded into GEMM stores (v * inv_norm[row] + bias; v * rstd - rstd * mean * rowsum(W) + bias),
 //   * the token shift, PCM framing + normalisation, zero padding of attention groups, PReLU and the speaker gate as operand loaders,
 //   * SiLU / ReLU / ReLU^2 / residual adds / the encoder-mask product as stores,
-//   * the per-group attention products and the per-window linear attention as batched launches (blockIdx.z).
+//   * the per-group attention products and the per-window linear attention as batched launches (blockIdx.z); the quadratic and the
+//     linear attention outputs come out of ONE contraction over [256 keys of the group | 128 linear-attention channels].
 // What is not a matrix product -- depthwise convolutions over time, row norms, per-channel instance norms, the RMS stages --
 // are small bandwidth-bound kernels below.
 #include "ade_gemm.h"
@@ -238,14 +239,23 @@ struct QuadScoreProb {         // z = (window, group): ATT_z = relu(quad_q quad_
         return {gemm::RowMajorA{qq + o, kQk}, gemm::WeightNK{qk + o, kQk}, Relu2Store{att + (size_t)z * g * g, g}, g, g, kQk};
     }
 };
-struct QuadOutProb {           // z = (window, group): AO rows of the group = ATT_z x value rows (zero beyond the window's frames)
-    const float *att, *vu;
-    float* ao;
-    int g, groups, n;
-    __device__ Prob<gemm::RowMajorA, PaddedRowsB, GuardedStore> operator()(int z) const {
-        const int b = z / groups, gi = z - b * groups, valid = min(g, n - gi * g);
-        const size_t row0 = (size_t)b * n + (size_t)gi * g;
-        return {gemm::RowMajorA{att + (size_t)z * g * g, g}, PaddedRowsB{vu + row0 * kIn, kIn, valid}, GuardedStore{ao + row0 * kVu2, kVu2, valid, 0}, g, kVu2, g};
+struct AttLinA {               // A(m, k) = k < g ? ATT_z[m][k] : lin_q[row m][k - g]: the quadratic and the linear attention share one contraction
+    static constexpr bool kAlongK = true;
+    const float *att, *lq;
+    int g;
+    __device__ float operator()(int m, int k) const { return k < g ? att[(size_t)m * g + k] : lq[(size_t)m * kQk + (k - g)]; }
+    __device__ bool can_vec4(int) const { return (g & 3) == 0; }
+    __device__ float4 vec4(int m, int k) const {
+        return k < g ? *reinterpret_cast<const float4*>(att + (size_t)m * g + k) : *reinterpret_cast<const float4*>(lq + (size_t)m * kQk + (k - g));
+    }
+};
+struct VuLkvB {                // B(k, n) = k < g ? value row k of the group (zero beyond the window's frames, :480-484) : LKV[k - g][n]
+    static constexpr bool kAlongN = true;
+    const float *rows, *lkv;
+    int ld, valid, g;
+    __device__ float operator()(int k, int n) const {
+        if (k >= g) return lkv[(size_t)(k - g) * kVu2 + n];
+        return k < valid ? rows[(size_t)k * ld + n] : 0.0f;
     }
 };
 struct LinKvProb {             // z = window: LKV_z (128 x 2048) = lin_k^T x value rows   (:490-492; padded keys are zero rows, so K = frames)
@@ -257,13 +267,15 @@ struct LinKvProb {             // z = window: LKV_z (128 x 2048) = lin_k^T x val
                 GuardedStore{lkv + (size_t)z * kQk * kVu2, kVu2, kQk, 0}, kQk, kVu2, n};
     }
 };
-struct LinOutProb {            // z = window: AO rows += lin_q x LKV_z   (:495-497)
-    const float *lq, *lkv;
+struct AttOutProb {            // z = (window, group): AO rows of the group = ATT_z x value rows + lin_q x LKV_window   (:488, :495-497), K = g + 128
+    const float *att, *vu, *lq, *lkv;
     float* ao;
-    int n, padded;
-    __device__ Prob<gemm::RowMajorA, gemm::RowMajorB, GuardedStore> operator()(int z) const {
-        return {gemm::RowMajorA{lq + (size_t)z * padded * kQk, kQk}, gemm::RowMajorB{lkv + (size_t)z * kQk * kVu2, kVu2},
-                GuardedStore{ao + (size_t)z * n * kVu2, kVu2, n, 1}, n, kVu2, kQk};
+    int g, groups, n, padded;
+    __device__ Prob<AttLinA, VuLkvB, GuardedStore> operator()(int z) const {
+        const int b = z / groups, gi = z - b * groups, valid = min(g, n - gi * g);
+        const size_t row0 = (size_t)b * n + (size_t)gi * g;
+        return {AttLinA{att + (size_t)z * g * g, lq + ((size_t)b * padded + (size_t)gi * g) * kQk, g},
+                VuLkvB{vu + row0 * kIn, lkv + (size_t)b * kQk * kVu2, kIn, valid, g}, GuardedStore{ao + row0 * kVu2, kVu2, valid, 0}, g, kVu2, g + kQk};
     }
 };
 
@@ -734,9 +746,8 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
                            padded, rot, head_stride);
         const float *quad_q = heads, *lin_q = heads + head_stride, *quad_k = heads + 2 * head_stride, *lin_k = heads + 3 * head_stride;
         launch_batched(s, QuadScoreProb{quad_q, quad_k, ATT, g}, B * groups, g, g);
-        launch_batched(s, QuadOutProb{ATT, P2, AO, g, groups, n}, B * groups, g, kVu2);
         launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded}, B, kQk, kVu2);
-        launch_batched(s, LinOutProb{lin_q, LKV, AO, n, padded}, B, n, kVu2);
+        launch_batched(s, AttOutProb{ATT, P2, lin_q, LKV, AO, g, groups, n, padded}, B * groups, g, kVu2);
         hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
         launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu);
         dwconv(s, Y, l.out_c, H, H, kDim, B);
