@@ -86,3 +86,19 @@ def test_missing_weight_tensor_is_a_key_error(lib):
         assert st == _lib.ADE_ERR_DEVICE           # device probe comes before the arena build
     else:
         assert st == _lib.ADE_ERR_MISSING_KEY and "inter_fc.bias" in msg
+
+
+def test_model_family_manifest_checks_precede_the_device(lib):
+    """Family selection and its rate / fold rules are decided from the manifest alone (no GPU needed to be told 'unsupported')."""
+    from audio_denoiser_onnx_amd import melband, mossformer
+    blob = b"ADEWGT01"                                             # never parsed: the manifest is rejected first
+    st, msg = _create(lib, melband.metadata(13230) | {"in_sample_rate": "48000"}, blob)
+    assert st == _lib.ADE_ERR_UNSUPPORTED and "no consistent resampling" in msg
+    st, msg = _create(lib, mossformer.metadata(4816, use_batch_fold=True, batch_window_seconds=2408 / 16000.0, in_sample_rate=8000), blob)
+    assert st == _lib.ADE_ERR_BAD_VALUE and "equal input/model/output sample rates" in msg
+    st, msg = _create(lib, mossformer.metadata(2408) | {"model_sample_rate": "8000"}, blob)
+    assert st == _lib.ADE_ERR_UNSUPPORTED and "16000" in msg
+    st, msg = _create(lib, mossformer.metadata(2408) | {"model_family": "zipenhancer"}, blob)
+    assert st == _lib.ADE_ERR_UNSUPPORTED and "zipenhancer" in msg
+    st, msg = _create(lib, melband.metadata(13230) | {"ade_dft_tables": "fast"}, golden_blob(0))
+    assert st in (_lib.ADE_ERR_BAD_VALUE, _lib.ADE_ERR_DEVICE)     # the table option is validated after the blob parse; without a GPU the device check comes first
