@@ -884,8 +884,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
     }
     const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer",
-               fam_moss = e->meta["model_family"] == "mossformer2_ss";
-    if (fam_dfsmn || fam_melband || fam_moss) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
+               fam_moss = e->meta["model_family"] == "mossformer2_ss", fam_ulu = e->meta["model_family"] == "ul_unas";
+    if (fam_dfsmn || fam_melband || fam_moss || fam_ulu) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
         const std::string fam = e->meta["model_family"];
         const long rate = fam_dfsmn ? 48000 : fam_melband ? 44100 : 16000;
         bool dyn_d = false, fold_d = false;
@@ -945,8 +945,10 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
+        if (fold_d && fam_ulu) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ul_unas: use_batch_fold is not implemented (pass the windows as batch rows)"));
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
+                       : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
@@ -976,7 +978,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return ADE_OK;
     }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer, mossformer2_ss)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer, mossformer2_ss, ul_unas)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));

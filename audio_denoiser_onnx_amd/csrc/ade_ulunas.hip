@@ -1,0 +1,546 @@
+// ade_ulunas.hip — UL-UNAS (ultra-lightweight 16 kHz speech enhancement) on the MI355X: SURVEY.md section 8 row f2.
+//
+// Reference: ULUNAS_CUSTOM.forward (UL-UNAS/Export_UL_UNAS.py:848-913) around ULUNAS.forward and its blocks (:111-739), over the
+// tensors audio_denoiser_onnx_amd/ulunas.py::fold_state_dict produces (BatchNorm folded into the convolutions, AffinePReLU as
+// positive / negative slope tables per (channel, bin), the two half-width GRUs of every grouped GRU):
+//   int16 -> * 2^-15 -> STFT(512, hop 256, periodic hann, reflect) -> log(max(|X|^2, 1e-24)) -> ERB merge (65 + 64 bands) ->
+//   5 encoder blocks (XConvBlock / XMBBlocks / XDWSBlock: grouped, depthwise and pointwise convolutions causal in time, stride on
+//   frequency, AffinePReLU, channel shuffle, each ending in a causal time-frequency attention cTFA = time GRU gate x frequency
+//   bi-GRU gate) -> 2 x DPGRNN (the same grouped dual-path GRU as GTCRN's) -> 5 decoder blocks on x + skip (transposed
+//   convolutions) -> sigmoid -> ERB split -> real mask x spectrum -> ISTFT -> * 32767, clamp, truncate -> int16.
+// A first, correctness-first implementation: activations are channels-last (batch, frame, bin, channel) tensors in HBM and every
+// operator is its own bandwidth-bound kernel (one generic convolution kernel covers all 23 convolutions through a descriptor).
+// The DPGRNN blocks ARE GTCRN's (same widths: 33 bins x 16 channels) and reuse its multi-kernel path (ade_kernels.hip); the STFT
+// pair is the generic operator of ade_stft.hip (dense windowed DFT on the matrix cores, exact-angle tables).
+#include "ade_internal.h"
+#include "../../include/ade.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ade {
+
+namespace {
+
+constexpr int kUNfft = 512, kUHop = 256, kUBins = 257, kULow = 65, kUBands = 64, kUHigh = 192, kUErb = kULow + kUBands;   // 129
+
+__device__ __forceinline__ float usig(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct ConvDesc {              // one (de)convolution + bias [+ AffinePReLU] [+ channel shuffle] over (B, T, F, C) tensors
+    const float *w, *b, *pos, *neg, *abias;     // w in torch layout: Conv2d (Cout, Cin/g, kt, kf); ConvTranspose2d (Cin, Cout/g, kt, kf)
+    int Cin, Cout, Fi, Fo, kt, kf, stride, groups, deconv, shuffle;
+};
+
+__device__ __forceinline__ int shuffled(int j, int C) { return (j & 1) ? (j >> 1) + (C >> 1) : (j >> 1); }   // Shuffle.indices (:200-203)
+
+// out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648)
+__global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T,
+                                                  long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % d.Cout);
+    long long r = i / d.Cout;
+    const int fo = (int)(r % d.Fo);
+    r /= d.Fo;
+    const int t = (int)(r % T);
+    const long long b = r / T;
+    const int cc = d.shuffle ? shuffled(co, d.Cout) : co;           // output position co holds convolution channel cc
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups, g = cc / cog, pf = d.kf / 2;
+    float acc = d.b[cc];
+    for (int a = 0; a < d.kt; ++a) {
+        const int tt = d.deconv ? t - a : t - (d.kt - 1) + a;
+        if (tt < 0) continue;
+        for (int bb = 0; bb < d.kf; ++bb) {
+            int fi;
+            if (d.deconv) {
+                const int num = fo + pf - bb;
+                if (num < 0 || num % d.stride) continue;
+                fi = num / d.stride;
+            } else {
+                fi = fo * d.stride - pf + bb;
+            }
+            if (fi < 0 || fi >= d.Fi) continue;
+            const size_t at = (((size_t)b * T + tt) * d.Fi + fi) * d.Cin + (size_t)g * cig;
+            for (int ci = 0; ci < cig; ++ci) {
+                const float xv = x2 ? x[at + ci] + x2[at + ci] : x[at + ci];
+                const float wv = d.deconv ? d.w[(((size_t)(g * cig + ci) * cog + (cc - g * cog)) * d.kt + a) * d.kf + bb]
+                                          : d.w[(((size_t)cc * cig + ci) * d.kt + a) * d.kf + bb];
+                acc += xv * wv;
+            }
+        }
+    }
+    if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
+    out[i] = acc;
+}
+
+// cTFA statistics (:181-182, :150): zt[frame][c] = mean_f x^2 ; pf[frame][f] = mean_c x^2.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_ulu_stats(const float* __restrict__ x, float* __restrict__ zt, float* __restrict__ pfreq, int F, int C) {
+    const size_t frame = blockIdx.x;
+    const float* p = x + frame * F * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.0f;
+        for (int f = 0; f < F; ++f) { const float v = p[f * C + c]; s += v * v; }
+        zt[frame * C + c] = s / (float)F;
+    }
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) { const float v = p[f * C + c]; s += v * v; }
+        pfreq[frame * F + f] = s / (float)C;
+    }
+}
+
+// time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  One wavefront per clip, lane = hidden unit.
+// wih_t [C][3][2C], whh_t [2C][3][2C] (transposed so that lanes read consecutive floats), fc_t [2C][C].
+__global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
+                                               const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
+                                               const float* __restrict__ fc_b, float* __restrict__ at, int T, int C) {
+    __shared__ float hs[64];
+    const int b = blockIdx.x, j = threadIdx.x, H = 2 * C;
+    const bool unit = j < H;
+    float h = 0.0f;
+    hs[j] = 0.0f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float* z = zt + ((size_t)b * T + t) * C;
+        float gi[3] = {0.0f, 0.0f, 0.0f}, gh[3] = {0.0f, 0.0f, 0.0f};
+        if (unit) {
+            for (int g = 0; g < 3; ++g) { gi[g] = bih[g * H + j]; gh[g] = bhh[g * H + j]; }
+            for (int k = 0; k < C; ++k) {
+                const float zk = z[k];
+                for (int g = 0; g < 3; ++g) gi[g] += wih_t[(k * 3 + g) * H + j] * zk;
+            }
+            for (int k = 0; k < H; ++k) {
+                const float hk = hs[k];
+                for (int g = 0; g < 3; ++g) gh[g] += whh_t[(k * 3 + g) * H + j] * hk;
+            }
+            const float r = usig(gi[0] + gh[0]), zg = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
+            h = (1.0f - zg) * n + zg * h;
+        }
+        __syncthreads();
+        if (unit) hs[j] = h;
+        __syncthreads();
+        if (j < C) {
+            float a = fc_b[j];
+            for (int k = 0; k < H; ++k) a += fc_t[k * C + j] * hs[k];
+            at[((size_t)b * T + t) * C + j] = usig(a);
+        }
+    }
+}
+
+// frequency attention GRUs (:151-153): per frame, the zero-padded bin powers in groups of 4 are a sequence of H steps through a
+// bidirectional GRU(4 -> 4).  One thread per (frame, direction); weights [12][4] | [12][4] | [12] | [12] per direction.
+__global__ __launch_bounds__(256) void k_ulu_fa_gru(const float* __restrict__ pfreq, const float* __restrict__ wf, const float* __restrict__ wb,
+                                                    float* __restrict__ fah, int F, int H, long long frames) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= frames * 2) return;
+    const long long frame = i >> 1;
+    const int dir = (int)(i & 1);
+    const float* w = dir ? wb : wf;
+    float wih[12][4], whh[12][4], bi[12], bh[12];
+    for (int r = 0; r < 12; ++r) {
+        for (int k = 0; k < 4; ++k) { wih[r][k] = w[r * 4 + k]; whh[r][k] = w[48 + r * 4 + k]; }
+        bi[r] = w[96 + r];
+        bh[r] = w[108 + r];
+    }
+    float h[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < H; ++s) {
+        const int step = dir ? H - 1 - s : s;
+        float x[4];
+        for (int k = 0; k < 4; ++k) { const int f = 4 * step + k; x[k] = f < F ? pfreq[frame * F + f] : 0.0f; }
+        float hn[4];
+        for (int u = 0; u < 4; ++u) {
+            float gi[3], gh[3];
+            for (int g = 0; g < 3; ++g) {
+                gi[g] = bi[g * 4 + u];
+                gh[g] = bh[g * 4 + u];
+                for (int k = 0; k < 4; ++k) { gi[g] += wih[g * 4 + u][k] * x[k]; gh[g] += whh[g * 4 + u][k] * h[k]; }
+            }
+            const float r = usig(gi[0] + gh[0]), z = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
+            hn[u] = (1.0f - z) * n + z * h[u];
+        }
+        for (int u = 0; u < 4; ++u) { h[u] = hn[u]; fah[((size_t)frame * H + step) * 8 + dir * 4 + u] = hn[u]; }
+    }
+}
+
+// cTFA output (:154, :188-194) with the block's tail: out[.., co] = at[c] * x[c] * sigmoid(fc(fa)[f]) (+ residual[c]) with c = shuffle(co)
+__global__ __launch_bounds__(256) void k_ulu_apply(const float* __restrict__ x, const float* __restrict__ at, const float* __restrict__ fah,
+                                                   const float* __restrict__ fa_fc_w, const float* __restrict__ fa_fc_b, const float* __restrict__ res,
+                                                   float* __restrict__ out, int F, int C, int H, int shuffle, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = (int)(i % C);
+    const long long r = i / C;
+    const int f = (int)(r % F);
+    const long long frame = r / F;
+    const int c = shuffle ? shuffled(co, C) : co, u = f & 3;
+    const float* hrow = fah + ((size_t)frame * H + (f >> 2)) * 8;
+    float a = fa_fc_b[u];
+    for (int k = 0; k < 8; ++k) a += fa_fc_w[u * 8 + k] * hrow[k];
+    const size_t src = ((size_t)frame * F + f) * C + c;
+    float v = (at[(size_t)frame * C + c] * x[src]) * usig(a);
+    if (res) v += res[src];
+    out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_ulu_pcm2f(const int16_t* __restrict__ pcm, float* __restrict__ x, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) x[i] = (float)pcm[i] * (1.0f / 32768.0f);
+}
+// log-power + ERB merge (:725-727, :97-100): feat[frame][j], j < 129; spec is [b][re 257 | im 257][T]
+__global__ __launch_bounds__(256) void k_ulu_feat(const float* __restrict__ spec, const float* __restrict__ erb, float* __restrict__ feat, int T, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % kUErb);
+    const long long frame = i / kUErb;
+    const long long b = frame / T;
+    const int t = (int)(frame - b * T);
+    const float* s = spec + (size_t)b * 2 * kUBins * T + t;
+    auto logp = [&](int f) { const float re = s[(size_t)f * T], im = s[(size_t)(kUBins + f) * T]; return logf(fmaxf(re * re + im * im, 1e-24f)); };
+    float v;
+    if (j < kULow) v = logp(j);
+    else {
+        v = 0.0f;
+        const float* row = erb + (size_t)(j - kULow) * kUHigh;
+        for (int k = 0; k < kUHigh; ++k) { const float wv = row[k]; if (wv != 0.0f) v += wv * logp(kULow + k); }
+    }
+    feat[i] = v;
+}
+// sigmoid + ERB split (:649, :102-105) + real mask on both spectrum halves (:880), in place on spec
+__global__ __launch_bounds__(256) void k_ulu_mask(const float* __restrict__ m129, const float* __restrict__ erb, float* __restrict__ spec, float* __restrict__ mask_tap,
+                                                  int T, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int f = (int)(i % kUBins);
+    const long long frame = i / kUBins;
+    const long long b = frame / T;
+    const int t = (int)(frame - b * T);
+    const float* m = m129 + (size_t)frame * kUErb;
+    float v;
+    if (f < kULow) v = usig(m[f]);
+    else {
+        v = 0.0f;
+        for (int e = 0; e < kUBands; ++e) { const float wv = erb[(size_t)e * kUHigh + (f - kULow)]; if (wv != 0.0f) v += usig(m[kULow + e]) * wv; }
+    }
+    float* s = spec + (size_t)b * 2 * kUBins * T + t;
+    s[(size_t)f * T] *= v;
+    s[(size_t)(kUBins + f) * T] *= v;
+    if (mask_tap) mask_tap[i] = v;
+}
+__global__ __launch_bounds__(256) void k_ulu_f2pcm(const float* __restrict__ y, int16_t* __restrict__ pcm, float* __restrict__ f32, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    if (f32) f32[i] = y[i];
+    if (pcm) pcm[i] = (int16_t)(int)fminf(fmaxf(y[i] * 32767.0f, -32768.0f), 32767.0f);
+}
+
+int ufail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
+#define UL_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return ufail(err, ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct CtfaW { const float *ta_wih_t, *ta_whh_t, *ta_bih, *ta_bhh, *ta_fc_t, *ta_fc_b, *fa_f, *fa_b, *fa_fc_w, *fa_fc_b; };
+struct Block {
+    int type, cin, cout, width, in_width, kt, kf, stride, groups, deconv, last;
+    ConvDesc conv[3];          // type 0: conv ; type 1: pconv, dconv ; type 2: pconv1, dconv, pconv2
+    CtfaW ctfa;
+};
+struct DpPacked { const float *intra_gru, *inter_gru, *fc[2], *fc_b[2], *ln_w[2], *ln_b[2]; };
+
+// PyTorch GRU rows of hidden unit j -> [3x8 ih | 3xH hh | 3 b_ih | 3 b_hh]: the lane format of k_intra_gru / k_inter_gru (ade_kernels.hip)
+void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* bih, const float* bhh, int H, int j) {
+    for (int g = 0; g < 3; ++g)
+        for (int k = 0; k < 8; ++k) dst[g * 8 + k] = wih[(g * H + j) * 8 + k];
+    for (int g = 0; g < 3; ++g)
+        for (int k = 0; k < H; ++k) dst[24 + g * H + k] = whh[(g * H + j) * H + k];
+    for (int g = 0; g < 3; ++g) { dst[24 + 3 * H + g] = bih[g * H + j]; dst[24 + 3 * H + 3 + g] = bhh[g * H + j]; }
+}
+
+}  // namespace
+
+struct UlunasEngine : SubEngine {
+    int device = 0, L = 0, T = 0, out_len_ = 0;
+    ade_stft_handle plan = nullptr;
+    float* d_w = nullptr;
+    const float* erb = nullptr;
+    Block blocks[10];
+    DpPacked dp[2];
+    int capacity = 0;
+    float* ws = nullptr;
+    float *xf = nullptr, *spec = nullptr, *yf = nullptr, *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *dpa = nullptr, *dpb = nullptr, *skip[5] = {}, *zt = nullptr, *pfreq = nullptr, *at = nullptr,
+          *fah = nullptr, *rnn = nullptr, *dpm = nullptr, *mask_tap = nullptr;
+
+    ~UlunasEngine() override {
+        (void)hipSetDevice(device);
+        if (plan) ade_stft_destroy(plan);
+        if (d_w) (void)hipFree(d_w);
+        if (ws) (void)hipFree(ws);
+    }
+    int frames() const override { return T; }
+    int in_len() const override { return L; }
+    int out_len() const override { return out_len_; }
+    int reserve(int batch, std::string& err) override;
+    int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
+    int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
+    void ctfa(hipStream_t s, const Block& bk, const float* x, const float* res, float* out, int B, int shuffle);
+    float* run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B);
+};
+
+int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err) {
+    *out = nullptr;
+    if (in_len < kUNfft) return ufail(err, ADE_ERR_SHAPE_MISMATCH, "ul_unas: input_audio_length shorter than one 512-sample frame");
+    // ULUNAS() defaults (:655-668)
+    static const int types[5] = {0, 2, 1, 2, 1}, strides[5] = {2, 2, 1, 1, 1}, groups[5] = {1, 2, 2, 2, 2}, channels[5] = {12, 24, 24, 32, 16},
+                     kts[5] = {3, 2, 2, 1, 1}, kfs[5] = {3, 3, 3, 5, 5}, widths[5] = {65, 33, 33, 33, 33};
+    std::vector<float> arena;
+    auto put = [&](const float* src, size_t n) { const size_t at = arena.size(); arena.resize(at + ((n + 63) & ~(size_t)63), 0.0f); if (src) memcpy(&arena[at], src, n * sizeof(float)); return at; };
+    bool ok = true;
+    auto get = [&](const std::string& name, std::vector<int> dims) -> const float* {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) { if (ok) err = "weights: tensor missing: " + name; ok = false; return nullptr; }
+        if (it->second.dims != dims) { if (ok) err = "weights: tensor has the wrong shape: " + name; ok = false; return nullptr; }
+        return it->second.data;
+    };
+    struct Fix { const float** dst; size_t at; };
+    std::vector<Fix> fix;
+    auto want = [&](const float** dst, const std::string& name, std::vector<int> dims) {
+        const float* p = get(name, dims);
+        size_t n = 1;
+        for (int d : dims) n *= (size_t)d;
+        fix.push_back({dst, put(p, p ? n : 0)});
+    };
+    UlunasEngine* e = new UlunasEngine();
+    auto bail = [&](int st) { delete e; return st; };
+    e->device = device; e->L = in_len; e->T = in_len / kUHop + 1; e->out_len_ = kUHop * (e->T - 1);
+    auto conv = [&](ConvDesc& d, const std::string& wname, const std::string& aname, int cin, int cout, int fi, int fo, int kt, int kf, int stride, int g, int deconv,
+                    bool act, int shuffle) {
+        d = ConvDesc{nullptr, nullptr, nullptr, nullptr, nullptr, cin, cout, fi, fo, kt, kf, stride, g, deconv, shuffle};
+        if (deconv) want(&d.w, wname + "_w", {cin, cout / g, kt, kf});
+        else want(&d.w, wname + "_w", {cout, cin / g, kt, kf});
+        want(&d.b, wname + "_b", {cout});
+        if (act) {
+            want(&d.pos, aname + "pos", {cout, fo});
+            want(&d.neg, aname + "neg", {cout, fo});
+            want(&d.abias, aname + "bias", {cout, fo});
+        }
+    };
+    // transposed copies for the time-attention GRU (lanes read consecutive floats)
+    std::vector<std::vector<float>> keep;
+    auto ctfa = [&](CtfaW& c, const std::string& p, int C) {
+        const int H = 2 * C;
+        const float* wih = get(p + "ta_weight_ih_l0", {3 * H, C});
+        const float* whh = get(p + "ta_weight_hh_l0", {3 * H, H});
+        const float* fcw = get(p + "ta_fc_w", {C, H});
+        if (!ok) return;
+        std::vector<float> a((size_t)C * 3 * H), b((size_t)H * 3 * H), f((size_t)H * C);
+        for (int g = 0; g < 3; ++g)
+            for (int j = 0; j < H; ++j) {
+                for (int k = 0; k < C; ++k) a[((size_t)k * 3 + g) * H + j] = wih[((size_t)g * H + j) * C + k];
+                for (int k = 0; k < H; ++k) b[((size_t)k * 3 + g) * H + j] = whh[((size_t)g * H + j) * H + k];
+            }
+        for (int cc = 0; cc < C; ++cc)
+            for (int k = 0; k < H; ++k) f[(size_t)k * C + cc] = fcw[(size_t)cc * H + k];
+        fix.push_back({&c.ta_wih_t, put(a.data(), a.size())});
+        fix.push_back({&c.ta_whh_t, put(b.data(), b.size())});
+        fix.push_back({&c.ta_fc_t, put(f.data(), f.size())});
+        want(&c.ta_bih, p + "ta_bias_ih_l0", {3 * H});
+        want(&c.ta_bhh, p + "ta_bias_hh_l0", {3 * H});
+        want(&c.ta_fc_b, p + "ta_fc_b", {C});
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string sfx = dir ? "_reverse" : "";
+            const float *wi = get(p + "fa_weight_ih_l0" + sfx, {12, 4}), *wh = get(p + "fa_weight_hh_l0" + sfx, {12, 4}), *bi = get(p + "fa_bias_ih_l0" + sfx, {12}),
+                        *bh = get(p + "fa_bias_hh_l0" + sfx, {12});
+            if (!ok) return;
+            std::vector<float> pk(120);
+            memcpy(&pk[0], wi, 48 * 4); memcpy(&pk[48], wh, 48 * 4); memcpy(&pk[96], bi, 12 * 4); memcpy(&pk[108], bh, 12 * 4);
+            fix.push_back({dir ? &c.fa_b : &c.fa_f, put(pk.data(), pk.size())});
+        }
+        want(&c.fa_fc_w, p + "fa_fc_w", {4, 8});
+        want(&c.fa_fc_b, p + "fa_fc_b", {4});
+    };
+    auto make_block = [&](Block& bk, const std::string& p, int type, int cin, int cout, int width, int kt, int kf, int stride, int g, int deconv, int last) {
+        const int in_width = stride == 2 ? (deconv ? width / 2 + 1 : width * 2 - 1) : width;
+        bk = Block{};
+        bk.type = type; bk.cin = cin; bk.cout = cout; bk.width = width; bk.in_width = in_width; bk.kt = kt; bk.kf = kf; bk.stride = stride; bk.groups = g; bk.deconv = deconv;
+        bk.last = last;
+        if (type == 0) conv(bk.conv[0], p + "conv", p + "act_", cin, cout, in_width, width, kt, kf, stride, g, deconv, !last, 0);
+        else if (type == 1) {
+            conv(bk.conv[0], p + "pconv", p + "pconv_act_", cin, cout, in_width, in_width, 1, 1, 1, g, 0, true, g == 2);
+            conv(bk.conv[1], p + "dconv", p + "dconv_act_", cout, cout, in_width, width, kt, kf, stride, cout, deconv, !last, 0);
+        } else {
+            conv(bk.conv[0], p + "pconv1", p + "pconv1_act_", cin, cout, in_width, in_width, 1, 1, 1, g, 0, true, g == 2);
+            conv(bk.conv[1], p + "dconv", p + "dconv_act_", cout, cout, in_width, width, kt, kf, stride, cout, deconv, true, 0);
+            conv(bk.conv[2], p + "pconv2", "", cout, cout, width, width, 1, 1, 1, g, 0, false, 0);
+        }
+        ctfa(bk.ctfa, p + "ctfa_", cout);
+    };
+    int cin = 1;
+    for (int i = 0; i < 5; ++i) {
+        make_block(e->blocks[i], "encoder.en_convs." + std::to_string(i) + ".", types[i], cin, channels[i], widths[i], kts[i], kfs[i], strides[i], groups[i], 0, 0);
+        cin = channels[i];
+    }
+    int j = 0;
+    for (int i = 4; i >= 1; --i, ++j) {
+        make_block(e->blocks[5 + j], "decoder.de_convs." + std::to_string(j) + ".", types[i], cin, channels[i - 1], widths[i - 1], kts[i], kfs[i], strides[i], groups[i], 1, 0);
+        cin = channels[i - 1];
+    }
+    for (int i = 5; i < 9; ++i)
+        if (e->blocks[i].type == 2 && e->blocks[i].cin == e->blocks[i].cout && e->blocks[i].stride == 1) ok = false;   // residual on a skip-summed input: not in this architecture
+    make_block(e->blocks[9], "decoder.de_convs.4.", types[0], cin, 1, kUErb, kts[0], kfs[0], strides[0], groups[0], 1, 1);
+    want(&e->erb, "erb_filters", {kUBands, kUHigh});
+    // DPGRNN x 2 in GTCRN's lane formats
+    for (int i = 0; i < 2 && ok; ++i) {
+        const std::string p = "dpgrnn." + std::to_string(i) + ".";
+        std::vector<float> ig(16 * 42), og(16 * 54);
+        for (int grp = 0; grp < 2 && ok; ++grp) {
+            const std::string r = p + "intra_rnn.rnn" + std::to_string(grp + 1) + ".";
+            for (int dir = 0; dir < 2; ++dir) {
+                const std::string sfx = dir ? "_reverse" : "";
+                const float *wih = get(r + "weight_ih_l0" + sfx, {12, 8}), *whh = get(r + "weight_hh_l0" + sfx, {12, 4}), *bih = get(r + "bias_ih_l0" + sfx, {12}),
+                            *bhh = get(r + "bias_hh_l0" + sfx, {12});
+                if (!ok) break;
+                for (int u = 0; u < 4; ++u) pack_gru_lane(&ig[(grp * 8 + dir * 4 + u) * 42], wih, whh, bih, bhh, 4, u);
+            }
+            const std::string q = p + "inter_rnn.rnn" + std::to_string(grp + 1) + ".";
+            const float *wih = get(q + "weight_ih_l0", {24, 8}), *whh = get(q + "weight_hh_l0", {24, 8}), *bih = get(q + "bias_ih_l0", {24}), *bhh = get(q + "bias_hh_l0", {24});
+            if (!ok) break;
+            for (int u = 0; u < 8; ++u) pack_gru_lane(&og[(grp * 8 + u) * 54], wih, whh, bih, bhh, 8, u);
+        }
+        if (!ok) break;
+        fix.push_back({&e->dp[i].intra_gru, put(ig.data(), ig.size())});
+        fix.push_back({&e->dp[i].inter_gru, put(og.data(), og.size())});
+        const char* part[2] = {"intra", "inter"};
+        for (int k = 0; k < 2; ++k) {
+            const float* fw = get(p + part[k] + "_fc.weight", {16, 16});
+            if (!ok) break;
+            std::vector<float> ft(256);
+            for (int a = 0; a < 16; ++a)
+                for (int co = 0; co < 16; ++co) ft[a * 16 + co] = fw[co * 16 + a];
+            fix.push_back({&e->dp[i].fc[k], put(ft.data(), 256)});
+            want(&e->dp[i].fc_b[k], p + part[k] + "_fc.bias", {16});
+            want(&e->dp[i].ln_w[k], p + part[k] + "_ln.weight", {kFw, 16});
+            want(&e->dp[i].ln_b[k], p + part[k] + "_ln.bias", {kFw, 16});
+        }
+    }
+    if (!ok) return bail(err.find("missing") != std::string::npos ? ADE_ERR_MISSING_KEY : ADE_ERR_SHAPE_MISMATCH);
+    if (hipSetDevice(device) != hipSuccess) return bail(ufail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipMalloc((void**)&e->d_w, arena.size() * sizeof(float)) != hipSuccess || hipMemcpy(e->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(ufail(err, ADE_ERR_DEVICE, "upload of the UL-UNAS weights failed"));
+    for (auto& f : fix) *f.dst = e->d_w + f.at;
+    ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
+    if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
+    *out = e;
+    return ADE_OK;
+}
+
+int UlunasEngine::reserve(int batch, std::string& err) {
+    if (batch <= capacity) return ADE_OK;
+    UL_HIP(hipSetDevice(device));
+    UL_HIP(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    ws = nullptr;
+    capacity = 0;
+    const size_t B = batch, nfr = B * T, act = nfr * 1600;             // widest activation: 65 bins x 24 channels per frame
+    struct Carve { float** p; size_t n; };
+    std::vector<Carve> cs = {{&xf, B * L}, {&spec, B * 2 * kUBins * T}, {&yf, B * out_len_}, {&bufA, act}, {&bufB, act}, {&bufC, act}, {&bufD, act}, {&dpa, nfr * kFw * kCh}, {&dpb, nfr * kFw * kCh}, {&zt, nfr * 32},
+                             {&pfreq, nfr * 132}, {&at, nfr * 32}, {&fah, nfr * 33 * 8}, {&rnn, nfr * kFw * kCh}, {&dpm, nfr * kFw * kCh}, {&mask_tap, nfr * kUBins}};
+    for (int i = 0; i < 5; ++i) cs.push_back({&skip[i], nfr * (size_t)blocks[i].width * blocks[i].cout});
+    size_t total = 0;
+    for (auto& c : cs) total += (c.n + 63) & ~(size_t)63;
+    UL_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
+    size_t at_ = 0;
+    for (auto& c : cs) { *c.p = ws + at_; at_ += (c.n + 63) & ~(size_t)63; }
+    // let the STFT plan size its frame buffer now (it allocates lazily), so that run() never allocates
+    UL_HIP(hipMemset(spec, 0, B * 2 * kUBins * T * sizeof(float)));
+    if (ade_stft_synthesize(plan, spec, batch, T, yf, nullptr) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
+    capacity = batch;
+    return ADE_OK;
+}
+
+void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const float* res, float* out, int B, int shuffle) {
+    const int F = bk.width, C = bk.cout, H = (F + 3) / 4;
+    const long long nfr = (long long)B * T;
+    hipLaunchKernelGGL(k_ulu_stats, dim3((unsigned)nfr), dim3(256), 0, s, x, zt, pfreq, F, C);
+    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), 0, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
+                       bk.ctfa.ta_fc_b, at, T, C);
+    hipLaunchKernelGGL(k_ulu_fa_gru, dim3((unsigned)((nfr * 2 + 255) / 256)), dim3(256), 0, s, (const float*)pfreq, bk.ctfa.fa_f, bk.ctfa.fa_b, fah, F, H, nfr);
+    const long long total = nfr * F * C;
+    hipLaunchKernelGGL(k_ulu_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (const float*)at, (const float*)fah, bk.ctfa.fa_fc_w, bk.ctfa.fa_fc_b, res,
+                       out, F, C, H, shuffle, total);
+}
+
+// one encoder / decoder block (:264-273, :342-357, :433-453); x2 (decoder skip) is added to the input; result in dst
+float* UlunasEngine::run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B) {
+    auto conv = [&](const ConvDesc& d, const float* in, const float* in2, float* o) {
+        const long long total = (long long)B * T * d.Fo * d.Cout;
+        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in2, d, o, T, total);
+    };
+    const int tail_shuffle = (!bk.last && bk.groups == 2) ? 1 : 0;
+    if (bk.type == 0) {
+        conv(bk.conv[0], x, x2, t0);
+        ctfa(s, bk, t0, nullptr, dst, B, tail_shuffle);
+    } else if (bk.type == 1) {
+        conv(bk.conv[0], x, x2, t0);
+        conv(bk.conv[1], t0, nullptr, t1);
+        ctfa(s, bk, t1, nullptr, dst, B, 0);
+    } else {
+        conv(bk.conv[0], x, x2, t0);
+        conv(bk.conv[1], t0, nullptr, t1);
+        conv(bk.conv[2], t1, nullptr, t0);
+        const float* res = (bk.cin == bk.cout && bk.stride == 1) ? x : nullptr;      // use_residual (:397, :448-449); never together with a skip input (checked at create)
+        ctfa(s, bk, t0, res, dst, B, tail_shuffle);
+    }
+    return dst;
+}
+
+int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+    if (batch == 0) return ADE_OK;
+    int st = reserve(batch, err);
+    if (st != ADE_OK) return st;
+    const int B = batch;
+    const long long nfr = (long long)B * T;
+    auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+    hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
+    if (ade_stft_analyze(plan, xf, B, L, spec, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
+    hipLaunchKernelGGL(k_ulu_feat, flat(nfr * kUErb), dim3(256), 0, s, (const float*)spec, erb, bufC, T, nfr * kUErb);
+    const float* x = bufC;
+    for (int i = 0; i < 5; ++i) x = run_block(s, blocks[i], x, nullptr, bufA, bufB, skip[i], B);
+    // DPGRNN x 2 on (B, T, 33, 16): GTCRN's kernels (Export_UL_UNAS.py:561-574 == GTCRN's DPGRNN)
+    const float* in = x;
+    for (int i = 0; i < 2; ++i) {
+        float* o = i == 0 ? dpa : dpb;
+        launch_intra_gru(s, View{in, nullptr}, dp[i].intra_gru, rnn, (int)nfr);
+        launch_fc_ln_res(s, rnn, View{in, nullptr}, dp[i].fc[0], dp[i].fc_b[0], dp[i].ln_w[0], dp[i].ln_b[0], dpm, B, T);
+        launch_inter_gru(s, dpm, dp[i].inter_gru, rnn, B, T);
+        launch_fc_ln_res(s, rnn, View{dpm, nullptr}, dp[i].fc[1], dp[i].fc_b[1], dp[i].ln_w[1], dp[i].ln_b[1], o, B, T);
+        in = o;
+    }
+    // decoder: block i runs on x + en_outs[4 - i] (:647-648)
+    const float* dx = in;
+    for (int i = 0; i < 5; ++i) {
+        float* dst = (i & 1) ? bufD : bufC;
+        run_block(s, blocks[5 + i], dx, skip[4 - i], bufA, bufB, dst, B);
+        dx = dst;
+    }
+    // sigmoid, ERB split, real mask on the spectrum (:649, :734-736, :880); ISTFT; PCM tail (:955, :908)
+    hipLaunchKernelGGL(k_ulu_mask, flat(nfr * kUBins), dim3(256), 0, s, dx, erb, spec, mask_tap, T, nfr * kUBins);
+    if (ade_stft_synthesize(plan, spec, B, T, yf, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
+    hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, (long long)B * out_len_);
+    UL_HIP(hipGetLastError());
+    return ADE_OK;
+}
+
+int UlunasEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+    const size_t n = (size_t)batch * T * kUBins;
+    if (strcmp(name, "mask") != 0) return ufail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    if (!mask_tap || batch <= 0) return ufail(err, ADE_ERR_NOT_FOUND, "tap has no data yet");
+    if (count < n) return ufail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+    UL_HIP(hipStreamSynchronize(s));
+    UL_HIP(hipMemcpy(out, mask_tap, n * sizeof(float), hipMemcpyDeviceToHost));
+    *written = n;
+    return ADE_OK;
+}
+
+}  // namespace ade

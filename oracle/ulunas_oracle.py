@@ -37,12 +37,18 @@ def _gru(x, wih, whh, bih, bhh, reverse=False):
     return out
 
 
-def stft_tables():
-    """512 / 256 periodic-hann forward and inverse matrices with the reference's fp32 angles (UL-UNAS/STFT_Process.py, 'hann' :93)."""
+def stft_tables(exact: bool = False):
+    """512 / 256 periodic-hann forward and inverse matrices with the reference's fp32 angles (UL-UNAS/STFT_Process.py, 'hann' :93);
+    exact=True: exactly reduced angles (test knob: the HIP path's tables, isolates kernel error from the reference's table error)."""
     n = NFFT
     w = (np.cos(np.arange(n, dtype=F32) * F32(2.0 * np.pi / n)) * F32(-0.5) + F32(0.5)).astype(F32)
-    omega = (F32(2.0 * np.pi / n) * np.arange(FB, dtype=F32)[:, None]) * np.arange(n, dtype=F32)[None, :]
-    c, s = np.cos(omega).astype(F32), np.sin(omega).astype(F32)
+    if exact:
+        k = (np.arange(FB, dtype=np.int64)[:, None] * np.arange(n, dtype=np.int64)[None, :]) % n
+        ang = 2.0 * np.pi * k.astype(np.float64) / n
+        c, s = np.cos(ang).astype(F32), np.sin(ang).astype(F32)
+    else:
+        omega = (F32(2.0 * np.pi / n) * np.arange(FB, dtype=F32)[:, None]) * np.arange(n, dtype=F32)[None, :]
+        c, s = np.cos(omega).astype(F32), np.sin(omega).astype(F32)
     fwd = np.concatenate((c * w, -s * w), axis=0).astype(F32)
     scale = np.full((FB, 1), 2.0, F32)
     scale[0] = 1.0
@@ -52,11 +58,11 @@ def stft_tables():
 
 
 class UlunasOracle:
-    def __init__(self, tensors: dict, plan: list, in_len: int):
+    def __init__(self, tensors: dict, plan: list, in_len: int, exact_dft: bool = False):
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         self.plan, self.L = plan, int(in_len)
         self.T = self.L // HOP + 1
-        self.fwd, self.inv, win = stft_tables()
+        self.fwd, self.inv, win = stft_tables(exact_dft)
         raw = np.zeros(NFFT + HOP * (self.T - 1), F32)
         for t in range(self.T):
             raw[t * HOP:t * HOP + NFFT] += (win * win).astype(F32)

@@ -26,9 +26,9 @@ def fixture():
     return z, ulunas.fold_state_dict(state)
 
 
-def _oracle(fused, length=16000):
+def _oracle(fused, length=16000, exact_dft=False):
     from ulunas_oracle import UlunasOracle
-    return UlunasOracle(fused, ulunas.block_plan(), length)
+    return UlunasOracle(fused, ulunas.block_plan(), length, exact_dft)
 
 
 def test_fold_and_oracle_match_reference_export_path(fixture):
@@ -46,3 +46,53 @@ def test_erb_matrix_and_plan():
     assert e.shape == (64, 192) and e.min() >= 0 and np.all((e > 0).sum(axis=0) >= 1)
     plan = ulunas.block_plan()
     assert [p[1] for p in plan] == [0, 2, 1, 2, 1, 1, 2, 1, 2, 0] and plan[-1][3] == 1 and plan[-1][4] == 129 and plan[-1][-1]
+
+
+def _session(fused, length=16000, library=None):
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    return InferenceSession(weights=pack_blob(fused), metadata=ulunas.metadata(length), library=library)
+
+
+@pytest.mark.hipsim
+def test_hipsim_short_clip_matches_oracle(fixture):
+    """The same csrc/ade_ulunas.hip compiled for the host simulator: a 9-frame clip, mask and PCM against the oracle."""
+    from ade_testlib import hipsim_library
+    z, fused = fixture
+    L = 2048
+    pcm = np.ascontiguousarray(z["pcm_in"][:2, 3000:3000 + L])
+    o = _oracle(fused, L, exact_dft=True)                  # the engine's DFT tables use exactly reduced angles
+    want = o.process(pcm)
+    with _session(fused, L, hipsim_library()) as sess:
+        got = sess.run(None, {"noisy_audio": pcm[:, None]})[0][:, 0]
+        mask = sess.tap("mask", 2 * sess.frames * 257).reshape(2, sess.frames, 257)
+    assert np.abs(mask - o.taps["mask"]).max() < 2e-4
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_matches_reference_fixture(fixture):
+    z, fused = fixture
+    with _session(fused) as sess:
+        assert sess.frames == 63 and sess.out_len == 15872 and sess.channels == 1
+        out = sess.run(None, {"noisy_audio": z["pcm_in"][:, None]})[0][:, 0]
+        mask = sess.tap("mask", 3 * 63 * 257).reshape(3, 63, 257)
+        one = sess.run(None, {"noisy_audio": z["pcm_in"][1:2, None]})[0][0, 0]
+    assert np.abs(mask[0].T - z["mask0"]).max() < 5e-3          # log-power features of near-empty bins amplify the reference's DFT-table error (SURVEY H1)
+    d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02, (np.abs(d).max(), (d != 0).mean())
+    assert not out[2].any() and np.array_equal(one, out[1])
+
+
+@pytest.mark.gpu
+def test_gpu_two_second_clips_match_oracle(fixture):
+    """A length the fixture does not cover (T = 126): HIP vs oracle on seeded inputs."""
+    _, fused = fixture
+    rng = np.random.default_rng(3)
+    L = 32000
+    pcm = (rng.standard_normal((3, L)) * np.array([[300.0], [3000.0], [12000.0]])).astype(np.int16)
+    want = _oracle(fused, L, exact_dft=True).process(pcm)
+    with _session(fused, L) as sess:
+        got = sess.run(None, {"noisy_audio": pcm[:, None]})[0][:, 0]
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.02, (np.abs(d).max(), (d != 0).mean())
