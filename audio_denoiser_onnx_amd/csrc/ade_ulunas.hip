@@ -90,29 +90,40 @@ __global__ __launch_bounds__(256) void k_ulu_stats(const float* __restrict__ x, 
     }
 }
 
-// time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  One wavefront per clip, lane = hidden unit.
+// time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  One wavefront per clip, lane = hidden unit; the
+// recurrence is a chain of T dependent steps, so the weights live in LDS (one copy per workgroup) instead of being re-fetched per step.
 // wih_t [C][3][2C], whh_t [2C][3][2C] (transposed so that lanes read consecutive floats), fc_t [2C][C].
 __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
                                                const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
                                                const float* __restrict__ fc_b, float* __restrict__ at, int T, int C) {
+    HIP_DYNAMIC_SHARED(float, lds)
     __shared__ float hs[64];
     const int b = blockIdx.x, j = threadIdx.x, H = 2 * C;
+    float* s_wih = lds;                       // C * 3 * H
+    float* s_whh = s_wih + C * 3 * H;         // H * 3 * H
+    float* s_fc = s_whh + H * 3 * H;          // H * C
+    for (int i = j; i < C * 3 * H; i += 64) s_wih[i] = wih_t[i];
+    for (int i = j; i < H * 3 * H; i += 64) s_whh[i] = whh_t[i];
+    for (int i = j; i < H * C; i += 64) s_fc[i] = fc_t[i];
     const bool unit = j < H;
+    float bi[3] = {0.0f, 0.0f, 0.0f}, bh[3] = {0.0f, 0.0f, 0.0f};
+    if (unit)
+        for (int g = 0; g < 3; ++g) { bi[g] = bih[g * H + j]; bh[g] = bhh[g * H + j]; }
+    const float fb = j < C ? fc_b[j] : 0.0f;
     float h = 0.0f;
     hs[j] = 0.0f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const float* z = zt + ((size_t)b * T + t) * C;
-        float gi[3] = {0.0f, 0.0f, 0.0f}, gh[3] = {0.0f, 0.0f, 0.0f};
         if (unit) {
-            for (int g = 0; g < 3; ++g) { gi[g] = bih[g * H + j]; gh[g] = bhh[g * H + j]; }
+            float gi[3] = {bi[0], bi[1], bi[2]}, gh[3] = {bh[0], bh[1], bh[2]};
             for (int k = 0; k < C; ++k) {
                 const float zk = z[k];
-                for (int g = 0; g < 3; ++g) gi[g] += wih_t[(k * 3 + g) * H + j] * zk;
+                for (int g = 0; g < 3; ++g) gi[g] += s_wih[(k * 3 + g) * H + j] * zk;
             }
             for (int k = 0; k < H; ++k) {
                 const float hk = hs[k];
-                for (int g = 0; g < 3; ++g) gh[g] += whh_t[(k * 3 + g) * H + j] * hk;
+                for (int g = 0; g < 3; ++g) gh[g] += s_whh[(k * 3 + g) * H + j] * hk;
             }
             const float r = usig(gi[0] + gh[0]), zg = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
             h = (1.0f - zg) * n + zg * h;
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, con
         if (unit) hs[j] = h;
         __syncthreads();
         if (j < C) {
-            float a = fc_b[j];
-            for (int k = 0; k < H; ++k) a += fc_t[k * C + j] * hs[k];
+            float a = fb;
+            for (int k = 0; k < H; ++k) a += s_fc[k * C + j] * hs[k];
             at[((size_t)b * T + t) * C + j] = usig(a);
         }
     }
@@ -187,8 +198,10 @@ __global__ __launch_bounds__(256) void k_ulu_pcm2f(const int16_t* __restrict__ p
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < total) x[i] = (float)pcm[i] * (1.0f / 32768.0f);
 }
-// log-power + ERB merge (:725-727, :97-100): feat[frame][j], j < 129; spec is [b][re 257 | im 257][T]
-__global__ __launch_bounds__(256) void k_ulu_feat(const float* __restrict__ spec, const float* __restrict__ erb, float* __restrict__ feat, int T, long long total) {
+// log-power + ERB merge (:725-727, :97-100): feat[frame][j], j < 129; spec is [b][re 257 | im 257][T].  band_lo / band_hi: the non-zero
+// run of every ERB filter row (the filters are triangles: contiguous support).
+__global__ __launch_bounds__(256) void k_ulu_feat(const float* __restrict__ spec, const float* __restrict__ erb, const int* __restrict__ band_lo,
+                                                  const int* __restrict__ band_hi, float* __restrict__ feat, int T, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i % kUErb);
@@ -202,13 +215,14 @@ __global__ __launch_bounds__(256) void k_ulu_feat(const float* __restrict__ spec
     else {
         v = 0.0f;
         const float* row = erb + (size_t)(j - kULow) * kUHigh;
-        for (int k = 0; k < kUHigh; ++k) { const float wv = row[k]; if (wv != 0.0f) v += wv * logp(kULow + k); }
+        for (int k = band_lo[j - kULow]; k < band_hi[j - kULow]; ++k) v += row[k] * logp(kULow + k);     // ascending k: the dense matmul's order, zeros dropped
     }
     feat[i] = v;
 }
-// sigmoid + ERB split (:649, :102-105) + real mask on both spectrum halves (:880), in place on spec
-__global__ __launch_bounds__(256) void k_ulu_mask(const float* __restrict__ m129, const float* __restrict__ erb, float* __restrict__ spec, float* __restrict__ mask_tap,
-                                                  int T, long long total) {
+// sigmoid + ERB split (:649, :102-105) + real mask on both spectrum halves (:880), in place on spec.  bin_lo / bin_hi: the bands whose
+// filter covers high bin k (contiguous, at most a few).
+__global__ __launch_bounds__(256) void k_ulu_mask(const float* __restrict__ m129, const float* __restrict__ erb, const int* __restrict__ bin_lo,
+                                                  const int* __restrict__ bin_hi, float* __restrict__ spec, float* __restrict__ mask_tap, int T, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int f = (int)(i % kUBins);
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) void k_ulu_mask(const float* __restrict__ m129
     if (f < kULow) v = usig(m[f]);
     else {
         v = 0.0f;
-        for (int e = 0; e < kUBands; ++e) { const float wv = erb[(size_t)e * kUHigh + (f - kULow)]; if (wv != 0.0f) v += usig(m[kULow + e]) * wv; }
+        for (int e = bin_lo[f - kULow]; e < bin_hi[f - kULow]; ++e) v += usig(m[kULow + e]) * erb[(size_t)e * kUHigh + (f - kULow)];
     }
     float* s = spec + (size_t)b * 2 * kUBins * T + t;
     s[(size_t)f * T] *= v;
@@ -265,6 +279,7 @@ struct UlunasEngine : SubEngine {
     ade_stft_handle plan = nullptr;
     float* d_w = nullptr;
     const float* erb = nullptr;
+    int* d_tab = nullptr;              // band_lo[64] | band_hi[64] | bin_lo[192] | bin_hi[192]
     Block blocks[10];
     DpPacked dp[2];
     int capacity = 0;
@@ -276,6 +291,7 @@ struct UlunasEngine : SubEngine {
         (void)hipSetDevice(device);
         if (plan) ade_stft_destroy(plan);
         if (d_w) (void)hipFree(d_w);
+        if (d_tab) (void)hipFree(d_tab);
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
@@ -429,6 +445,27 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     if (hipMalloc((void**)&e->d_w, arena.size() * sizeof(float)) != hipSuccess || hipMemcpy(e->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(ufail(err, ADE_ERR_DEVICE, "upload of the UL-UNAS weights failed"));
     for (auto& f : fix) *f.dst = e->d_w + f.at;
+    {   // supports of the ERB triangles, both ways
+        const float* ef = tensors.find("erb_filters")->second.data;
+        std::vector<int> tab(2 * kUBands + 2 * kUHigh, 0);
+        for (int b2 = 0; b2 < kUBands; ++b2) {
+            int lo = kUHigh, hi = 0;
+            for (int k = 0; k < kUHigh; ++k)
+                if (ef[(size_t)b2 * kUHigh + k] != 0.0f) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+            tab[b2] = lo < hi ? lo : 0;
+            tab[kUBands + b2] = lo < hi ? hi : 0;
+        }
+        for (int k = 0; k < kUHigh; ++k) {
+            int lo = kUBands, hi = 0;
+            for (int b2 = 0; b2 < kUBands; ++b2)
+                if (ef[(size_t)b2 * kUHigh + k] != 0.0f) { lo = std::min(lo, b2); hi = std::max(hi, b2 + 1); }
+            tab[2 * kUBands + k] = lo < hi ? lo : 0;
+            tab[2 * kUBands + kUHigh + k] = lo < hi ? hi : 0;
+        }
+        if (hipMalloc((void**)&e->d_tab, tab.size() * sizeof(int)) != hipSuccess || hipMemcpy(e->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(ufail(err, ADE_ERR_DEVICE, "upload of the ERB tables failed"));
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 80 KB at 32 channels
     ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
     *out = e;
@@ -463,7 +500,7 @@ void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const fl
     const int F = bk.width, C = bk.cout, H = (F + 3) / 4;
     const long long nfr = (long long)B * T;
     hipLaunchKernelGGL(k_ulu_stats, dim3((unsigned)nfr), dim3(256), 0, s, x, zt, pfreq, F, C);
-    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), 0, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
+    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C) * sizeof(float), s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
                        bk.ctfa.ta_fc_b, at, T, C);
     hipLaunchKernelGGL(k_ulu_fa_gru, dim3((unsigned)((nfr * 2 + 255) / 256)), dim3(256), 0, s, (const float*)pfreq, bk.ctfa.fa_f, bk.ctfa.fa_b, fah, F, H, nfr);
     const long long total = nfr * F * C;
@@ -504,7 +541,7 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
     if (ade_stft_analyze(plan, xf, B, L, spec, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
-    hipLaunchKernelGGL(k_ulu_feat, flat(nfr * kUErb), dim3(256), 0, s, (const float*)spec, erb, bufC, T, nfr * kUErb);
+    hipLaunchKernelGGL(k_ulu_feat, flat(nfr * kUErb), dim3(256), 0, s, (const float*)spec, erb, (const int*)d_tab, (const int*)(d_tab + kUBands), bufC, T, nfr * kUErb);
     const float* x = bufC;
     for (int i = 0; i < 5; ++i) x = run_block(s, blocks[i], x, nullptr, bufA, bufB, skip[i], B);
     // DPGRNN x 2 on (B, T, 33, 16): GTCRN's kernels (Export_UL_UNAS.py:561-574 == GTCRN's DPGRNN)
@@ -525,7 +562,8 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
         dx = dst;
     }
     // sigmoid, ERB split, real mask on the spectrum (:649, :734-736, :880); ISTFT; PCM tail (:955, :908)
-    hipLaunchKernelGGL(k_ulu_mask, flat(nfr * kUBins), dim3(256), 0, s, dx, erb, spec, mask_tap, T, nfr * kUBins);
+    hipLaunchKernelGGL(k_ulu_mask, flat(nfr * kUBins), dim3(256), 0, s, dx, erb, (const int*)(d_tab + 2 * kUBands), (const int*)(d_tab + 2 * kUBands + kUHigh), spec, mask_tap, T,
+                       nfr * kUBins);
     if (ade_stft_synthesize(plan, spec, B, T, yf, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
     hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, (long long)B * out_len_);
     UL_HIP(hipGetLastError());
