@@ -8,6 +8,7 @@ matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the
     python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000]
     python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold]
     python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
+    python -m audio_denoiser_onnx_amd.export --family ul_unas <model_trained_on_dns3.tar> <out_dir> [--length 16000]
 
 The other two families fold their checkpoints the way their export constructors do (``melband.fuse_checkpoint`` =
 Export_MelBandRoformer.py:455-538; ``mossformer.fuse_checkpoint`` = Export_MossFormer2_SS_16K.py:130-395); both folds are
@@ -125,6 +126,17 @@ def export_mossformer(checkpoint, out_dir, input_audio_length: int = 24000, use_
     return model_path
 
 
+def export_ulunas(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "UL_UNAS") -> Path:
+    """UL-UNAS checkpoint (``ckpt['model']``, upstream or optimised key names) -> ``<name>.adew`` + manifest (Export_UL_UNAS.py:959-962 minus ONNX)."""
+    from . import ulunas
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    save_blob(model_path, ulunas.fold_state_dict(ulunas.convert_state_dict(load_state_dict(checkpoint))))
+    write_metadata(model_path, ulunas.metadata(input_audio_length))
+    return model_path
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     length, family, fold = None, "gtcrn", False
@@ -139,13 +151,15 @@ def main(argv=None) -> int:
     if "--fold" in argv:
         argv.remove("--fold")
         fold = True
-    if len(argv) != 2 or family not in ("gtcrn", "mel_band_roformer", "mossformer2_ss"):
+    if len(argv) != 2 or family not in ("gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas"):
         print(__doc__)
         return 2
     if family == "mel_band_roformer":
         path = export_melband(argv[0], argv[1], length or 66150, fold)
     elif family == "mossformer2_ss":
         path = export_mossformer(argv[0], argv[1], length or 24000, fold)
+    elif family == "ul_unas":
+        path = export_ulunas(argv[0], argv[1], length or 16000)
     else:
         path = export_gtcrn(argv[0], argv[1], length or 16000)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")

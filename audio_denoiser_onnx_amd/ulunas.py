@@ -54,6 +54,34 @@ def erb_matrix() -> np.ndarray:
     return np.abs(f[:, low:]).astype(np.float32)
 
 
+def convert_state_dict(original: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Upstream UL-UNAS checkpoint keys (blocks as ``nn.Sequential``: ``ops.N`` / ``pconv.N`` / ``dconv.N`` / ``pconv1.N`` / ``pconv2.N``) ->
+    the optimised model's flat names, with the AffinePReLU tables reshaped to (1, C, 1, W) and the slopes to (1, C, 1, 1): the mapping of
+    the reference's ``convert_state_dict`` (:742-822)."""
+    maps = {0: [("ops.1.", "conv."), ("ops.2.", "bn."), ("ops.3.", "act."), ("ops.4.", "ctfa.")],
+            1: [("pconv.0.", "pconv_conv."), ("pconv.1.", "pconv_bn."), ("pconv.2.", "pconv_act."), ("dconv.1.", "dconv_conv."), ("dconv.2.", "dconv_bn."),
+                ("dconv.3.", "dconv_act."), ("dconv.4.", "dconv_ctfa.")],
+            2: [("pconv1.0.", "pconv1_conv."), ("pconv1.1.", "pconv1_bn."), ("pconv1.2.", "pconv1_act."), ("dconv.1.", "dconv_conv."), ("dconv.2.", "dconv_bn."),
+                ("dconv.3.", "dconv_act."), ("pconv2.0.", "pconv2_conv."), ("pconv2.1.", "pconv2_bn."), ("pconv2.2.", "pconv2_ctfa.")]}
+    dec_types = [TYPES[i] for i in range(4, 0, -1)] + [TYPES[0]]
+    out: Dict[str, np.ndarray] = {}
+    for key, value in original.items():
+        new_key, value = key, np.asarray(value)
+        for head, types in (("encoder.en_convs.", TYPES), ("decoder.de_convs.", dec_types)):
+            if key.startswith(head):
+                idx, rest = key[len(head):].split(".", 1)
+                for old, new in maps[types[int(idx)]]:
+                    if rest.startswith(old):
+                        new_key = f"{head}{idx}.{new}{rest[len(old):]}"
+                        break
+        if new_key.endswith(("affine_weight", "affine_bias")) and value.ndim == 2:
+            value = value.reshape(1, value.shape[0], 1, value.shape[1])
+        elif new_key.endswith("slope_weight") and value.ndim <= 2:
+            value = value.reshape(1, value.shape[0], 1, 1)
+        out[new_key] = value
+    return out
+
+
 def _fold_conv(sd, conv, bn, transposed, groups):
     w = np.asarray(sd[conv + "weight"], np.float64)
     b = np.asarray(sd[conv + "bias"], np.float64) if conv + "bias" in sd else None

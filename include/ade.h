@@ -60,8 +60,8 @@ typedef struct ade_io_desc {
  * metadata key set (audio_onnx_metadata.py:161-203); `weights`: ADEWGT01 blob of the BN-folded tensors under the
  * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode).
  * The manifest key `model_family` selects the engine: "gtcrn" (GTCRN/Export_GTCRN.py), "dfsmn" (DFSMN/Export_DFSMN.py),
- * "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py) or "mossformer2_ss"
- * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py); the blob then carries that export's fused buffers. */
+ * "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py), "mossformer2_ss"
+ * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py) or "ul_unas" (UL-UNAS/Export_UL_UNAS.py); the blob then carries that export's fused buffers. */
 ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device,
                       ade_handle* out);
 

@@ -96,3 +96,32 @@ def test_gpu_two_second_clips_match_oracle(fixture):
         got = sess.run(None, {"noisy_audio": pcm[:, None]})[0][:, 0]
     d = got.astype(np.int32) - want.astype(np.int32)
     assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.02, (np.abs(d).max(), (d != 0).mean())
+
+
+def test_upstream_checkpoint_keys_convert_and_export(fixture, tmp_path):
+    """Upstream (nn.Sequential) key names -> optimised names -> the same folded tensors; export writes blob + manifest."""
+    from audio_denoiser_onnx_amd import export
+    from audio_denoiser_onnx_amd.weights import load_blob
+    z, fused = fixture
+    state = {str(k): z["w:" + str(k)] for k in z["keys"]}
+    back = {"conv.": "ops.1.", "bn.": "ops.2.", "act.": "ops.3.", "ctfa.": "ops.4."}
+    upstream = {}
+    for k, v in state.items():
+        if k.startswith("encoder.en_convs.0.") or k.startswith("decoder.de_convs.4."):           # the two XConvBlocks
+            head, rest = k[:19], k[19:]
+            for new, old in back.items():
+                if rest.startswith(new):
+                    k = head + old + rest[len(new):]
+                    break
+            if k.endswith(("affine_weight", "affine_bias")):
+                v = v[0, :, 0, :]
+            elif k.endswith("slope_weight"):
+                v = v[0, :, 0, :]
+        upstream[k] = v
+    assert any(".ops.1." in k for k in upstream)
+    again = ulunas.fold_state_dict(ulunas.convert_state_dict(upstream))
+    assert set(again) == set(fused) and all(np.array_equal(again[k], fused[k]) for k in fused)
+    np.savez(tmp_path / "ckpt.npz", **upstream)
+    path = export.export_ulunas(tmp_path / "ckpt.npz", tmp_path / "out", 16000)
+    blob = load_blob(path)
+    assert set(blob) == set(fused) and (tmp_path / "out" / "UL_UNAS_Metadata.json").exists()
