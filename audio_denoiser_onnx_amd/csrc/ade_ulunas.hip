@@ -34,44 +34,50 @@ struct ConvDesc {              // one (de)convolution + bias [+ AffinePReLU] [+ 
 
 __device__ __forceinline__ int shuffled(int j, int C) { return (j & 1) ? (j >> 1) + (C >> 1) : (j >> 1); }   // Shuffle.indices (:200-203)
 
-// out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648)
-__global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T,
-                                                  long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int co = (int)(i % d.Cout);
-    long long r = i / d.Cout;
-    const int fo = (int)(r % d.Fo);
-    r /= d.Fo;
-    const int t = (int)(r % T);
-    const long long b = r / T;
-    const int cc = d.shuffle ? shuffled(co, d.Cout) : co;           // output position co holds convolution channel cc
-    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups, g = cc / cog, pf = d.kf / 2;
-    float acc = d.b[cc];
+// out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648).
+// One workgroup per frame: the kt input frames it needs (already summed with the skip tensor) and the whole weight tensor are staged in LDS
+// once, so HBM / L2 sees every input element kt times instead of once per tap, channel and output.
+__global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T, int wsize) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const long long frame = blockIdx.x;
+    const long long b = frame / T;
+    const int t = (int)(frame - b * T), row = d.Fi * d.Cin;
+    float* xin = lds;                      // [kt][Fi * Cin]
+    float* wl = lds + d.kt * row;          // the weights in their torch layout
     for (int a = 0; a < d.kt; ++a) {
         const int tt = d.deconv ? t - a : t - (d.kt - 1) + a;
-        if (tt < 0) continue;
-        for (int bb = 0; bb < d.kf; ++bb) {
-            int fi;
-            if (d.deconv) {
-                const int num = fo + pf - bb;
-                if (num < 0 || num % d.stride) continue;
-                fi = num / d.stride;
-            } else {
-                fi = fo * d.stride - pf + bb;
-            }
-            if (fi < 0 || fi >= d.Fi) continue;
-            const size_t at = (((size_t)b * T + tt) * d.Fi + fi) * d.Cin + (size_t)g * cig;
-            for (int ci = 0; ci < cig; ++ci) {
-                const float xv = x2 ? x[at + ci] + x2[at + ci] : x[at + ci];
-                const float wv = d.deconv ? d.w[(((size_t)(g * cig + ci) * cog + (cc - g * cog)) * d.kt + a) * d.kf + bb]
-                                          : d.w[(((size_t)cc * cig + ci) * d.kt + a) * d.kf + bb];
-                acc += xv * wv;
-            }
-        }
+        const size_t at = ((size_t)b * T + (tt < 0 ? 0 : tt)) * row;
+        for (int i = threadIdx.x; i < row; i += 256) xin[a * row + i] = tt < 0 ? 0.0f : (x2 ? x[at + i] + x2[at + i] : x[at + i]);
     }
-    if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
-    out[i] = acc;
+    for (int i = threadIdx.x; i < wsize; i += 256) wl[i] = d.w[i];
+    __syncthreads();
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups, pf = d.kf / 2;
+    float* orow = out + (size_t)frame * d.Fo * d.Cout;
+    for (int o = threadIdx.x; o < d.Fo * d.Cout; o += 256) {
+        const int fo = o / d.Cout, co = o - fo * d.Cout;
+        const int cc = d.shuffle ? shuffled(co, d.Cout) : co;       // output position co holds convolution channel cc
+        const int g = cc / cog;
+        float acc = d.b[cc];
+        for (int a = 0; a < d.kt; ++a)
+            for (int bb = 0; bb < d.kf; ++bb) {
+                int fi;
+                if (d.deconv) {
+                    const int num = fo + pf - bb;
+                    if (num < 0 || num % d.stride) continue;
+                    fi = num / d.stride;
+                } else {
+                    fi = fo * d.stride - pf + bb;
+                }
+                if (fi < 0 || fi >= d.Fi) continue;
+                const float* xr = xin + a * row + fi * d.Cin + g * cig;
+                for (int ci = 0; ci < cig; ++ci) {
+                    const float wv = d.deconv ? wl[(((g * cig + ci) * cog + (cc - g * cog)) * d.kt + a) * d.kf + bb] : wl[((cc * cig + ci) * d.kt + a) * d.kf + bb];
+                    acc += xr[ci] * wv;
+                }
+            }
+        if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
+        orow[o] = acc;
+    }
 }
 
 // cTFA statistics (:181-182, :150): zt[frame][c] = mean_f x^2 ; pf[frame][f] = mean_c x^2.  One workgroup per frame.
@@ -511,8 +517,9 @@ void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const fl
 // one encoder / decoder block (:264-273, :342-357, :433-453); x2 (decoder skip) is added to the input; result in dst
 float* UlunasEngine::run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B) {
     auto conv = [&](const ConvDesc& d, const float* in, const float* in2, float* o) {
-        const long long total = (long long)B * T * d.Fo * d.Cout;
-        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in2, d, o, T, total);
+        const int wsize = d.Cout * (d.Cin / d.groups) * d.kt * d.kf;      // same element count for Conv2d and ConvTranspose2d layouts
+        const size_t lds = ((size_t)d.kt * d.Fi * d.Cin + wsize) * sizeof(float);
+        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((long long)B * T)), dim3(256), lds, s, in, in2, d, o, T, wsize);
     };
     const int tail_shuffle = (!bk.last && bk.groups == 2) ? 1 : 0;
     if (bk.type == 0) {
