@@ -37,7 +37,8 @@ __device__ __forceinline__ int shuffled(int j, int C) { return (j & 1) ? (j >> 1
 // out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648).
 // One workgroup per frame: the kt input frames it needs (already summed with the skip tensor) and the whole weight tensor are staged in LDS
 // once, so HBM / L2 sees every input element kt times instead of once per tap, channel and output.
-__global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T, int wsize) {
+__global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T, int wsize,
+                                                  float* __restrict__ zt, float* __restrict__ pfreq) {
     HIP_DYNAMIC_SHARED(float, lds)
     const long long frame = blockIdx.x;
     const long long b = frame / T;
@@ -78,21 +79,21 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
         if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
         orow[o] = acc;
     }
-}
-
-// cTFA statistics (:181-182, :150): zt[frame][c] = mean_f x^2 ; pf[frame][f] = mean_c x^2.  One workgroup per frame.
-__global__ __launch_bounds__(256) void k_ulu_stats(const float* __restrict__ x, float* __restrict__ zt, float* __restrict__ pfreq, int F, int C) {
-    const size_t frame = blockIdx.x;
-    const float* p = x + frame * F * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.0f;
-        for (int f = 0; f < F; ++f) { const float v = p[f * C + c]; s += v * v; }
-        zt[frame * C + c] = s / (float)F;
+    if (!zt) return;
+    // the block's last convolution also leaves the cTFA statistics of its frame (:181-182, :150): zt[c] = mean_f y^2, pfreq[f] = mean_c y^2
+    __syncthreads();                       // every thread is done with the staged inputs: the region is reused for the squares
+    float* sq = lds;                       // Fo * Cout <= the staged size is NOT guaranteed -> sized by the launcher
+    for (int o = threadIdx.x; o < d.Fo * d.Cout; o += 256) { const float v = orow[o]; sq[o] = v * v; }   // own writes: visible to this thread
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.Cout; c += 256) {
+        float a = 0.0f;
+        for (int f = 0; f < d.Fo; ++f) a += sq[f * d.Cout + c];
+        zt[frame * d.Cout + c] = a / (float)d.Fo;
     }
-    for (int f = threadIdx.x; f < F; f += 256) {
-        float s = 0.0f;
-        for (int c = 0; c < C; ++c) { const float v = p[f * C + c]; s += v * v; }
-        pfreq[frame * F + f] = s / (float)C;
+    for (int f = threadIdx.x; f < d.Fo; f += 256) {
+        float a = 0.0f;
+        for (int c = 0; c < d.Cout; ++c) a += sq[f * d.Cout + c];
+        pfreq[frame * d.Fo + f] = a / (float)d.Cout;
     }
 }
 
@@ -116,11 +117,18 @@ __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, con
     if (unit)
         for (int g = 0; g < 3; ++g) { bi[g] = bih[g * H + j]; bh[g] = bhh[g * H + j]; }
     const float fb = j < C ? fc_b[j] : 0.0f;
+    float* s_z = s_fc + H * C;                // 64 frames of the clip's zt rows: the recurrence must not wait on HBM every step
     float h = 0.0f;
     hs[j] = 0.0f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
-        const float* z = zt + ((size_t)b * T + t) * C;
+        if ((t & 63) == 0) {
+            __syncthreads();
+            const int n = min(64, T - t) * C;
+            for (int i = j; i < n; i += 64) s_z[i] = zt[((size_t)b * T + t) * C + i];
+            __syncthreads();
+        }
+        const float* z = s_z + (t & 63) * C;
         if (unit) {
             float gi[3] = {bi[0], bi[1], bi[2]}, gh[3] = {bh[0], bh[1], bh[2]};
             for (int k = 0; k < C; ++k) {
@@ -471,7 +479,7 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
         if (hipMalloc((void**)&e->d_tab, tab.size() * sizeof(int)) != hipSuccess || hipMemcpy(e->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             return bail(ufail(err, ADE_ERR_DEVICE, "upload of the ERB tables failed"));
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 80 KB at 32 channels
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 88 KB at 32 channels
     ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
     *out = e;
@@ -505,8 +513,7 @@ int UlunasEngine::reserve(int batch, std::string& err) {
 void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const float* res, float* out, int B, int shuffle) {
     const int F = bk.width, C = bk.cout, H = (F + 3) / 4;
     const long long nfr = (long long)B * T;
-    hipLaunchKernelGGL(k_ulu_stats, dim3((unsigned)nfr), dim3(256), 0, s, x, zt, pfreq, F, C);
-    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C) * sizeof(float), s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
+    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float), s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
                        bk.ctfa.ta_fc_b, at, T, C);
     hipLaunchKernelGGL(k_ulu_fa_gru, dim3((unsigned)((nfr * 2 + 255) / 256)), dim3(256), 0, s, (const float*)pfreq, bk.ctfa.fa_f, bk.ctfa.fa_b, fah, F, H, nfr);
     const long long total = nfr * F * C;
@@ -516,23 +523,24 @@ void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const fl
 
 // one encoder / decoder block (:264-273, :342-357, :433-453); x2 (decoder skip) is added to the input; result in dst
 float* UlunasEngine::run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B) {
-    auto conv = [&](const ConvDesc& d, const float* in, const float* in2, float* o) {
+    auto conv = [&](const ConvDesc& d, const float* in, const float* in2, float* o, bool stats) {
         const int wsize = d.Cout * (d.Cin / d.groups) * d.kt * d.kf;      // same element count for Conv2d and ConvTranspose2d layouts
-        const size_t lds = ((size_t)d.kt * d.Fi * d.Cin + wsize) * sizeof(float);
-        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((long long)B * T)), dim3(256), lds, s, in, in2, d, o, T, wsize);
+        const size_t stage = (size_t)d.kt * d.Fi * d.Cin + wsize, sq = stats ? (size_t)d.Fo * d.Cout : 0;
+        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((long long)B * T)), dim3(256), std::max(stage, sq) * sizeof(float), s, in, in2, d, o, T, wsize,
+                           stats ? zt : (float*)nullptr, stats ? pfreq : (float*)nullptr);
     };
     const int tail_shuffle = (!bk.last && bk.groups == 2) ? 1 : 0;
     if (bk.type == 0) {
-        conv(bk.conv[0], x, x2, t0);
+        conv(bk.conv[0], x, x2, t0, true);
         ctfa(s, bk, t0, nullptr, dst, B, tail_shuffle);
     } else if (bk.type == 1) {
-        conv(bk.conv[0], x, x2, t0);
-        conv(bk.conv[1], t0, nullptr, t1);
+        conv(bk.conv[0], x, x2, t0, false);
+        conv(bk.conv[1], t0, nullptr, t1, true);
         ctfa(s, bk, t1, nullptr, dst, B, 0);
     } else {
-        conv(bk.conv[0], x, x2, t0);
-        conv(bk.conv[1], t0, nullptr, t1);
-        conv(bk.conv[2], t1, nullptr, t0);
+        conv(bk.conv[0], x, x2, t0, false);
+        conv(bk.conv[1], t0, nullptr, t1, false);
+        conv(bk.conv[2], t1, nullptr, t0, true);
         const float* res = (bk.cin == bk.cout && bk.stride == 1) ? x : nullptr;      // use_residual (:397, :448-449); never together with a skip input (checked at create)
         ctfa(s, bk, t0, res, dst, B, tail_shuffle);
     }
