@@ -100,12 +100,14 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
 // time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  One wavefront per clip, lane = hidden unit; the
 // recurrence is a chain of T dependent steps, so the weights live in LDS (one copy per workgroup) instead of being re-fetched per step.
 // wih_t [C][3][2C], whh_t [2C][3][2C] (transposed so that lanes read consecutive floats), fc_t [2C][C].
+template <int C>               // compile-time channel count: the k loops unroll and their LDS reads pipeline
 __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
                                                const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
-                                               const float* __restrict__ fc_b, float* __restrict__ at, int T, int C) {
+                                               const float* __restrict__ fc_b, float* __restrict__ at, int T) {
     HIP_DYNAMIC_SHARED(float, lds)
     __shared__ float hs[64];
-    const int b = blockIdx.x, j = threadIdx.x, H = 2 * C;
+    constexpr int H = 2 * C;
+    const int b = blockIdx.x, j = threadIdx.x;
     float* s_wih = lds;                       // C * 3 * H
     float* s_whh = s_wih + C * 3 * H;         // H * 3 * H
     float* s_fc = s_whh + H * 3 * H;          // H * C
@@ -131,12 +133,16 @@ __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, con
         const float* z = s_z + (t & 63) * C;
         if (unit) {
             float gi[3] = {bi[0], bi[1], bi[2]}, gh[3] = {bh[0], bh[1], bh[2]};
+#pragma unroll
             for (int k = 0; k < C; ++k) {
                 const float zk = z[k];
+#pragma unroll
                 for (int g = 0; g < 3; ++g) gi[g] += s_wih[(k * 3 + g) * H + j] * zk;
             }
+#pragma unroll
             for (int k = 0; k < H; ++k) {
                 const float hk = hs[k];
+#pragma unroll
                 for (int g = 0; g < 3; ++g) gh[g] += s_whh[(k * 3 + g) * H + j] * hk;
             }
             const float r = usig(gi[0] + gh[0]), zg = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, con
         __syncthreads();
         if (j < C) {
             float a = fb;
+#pragma unroll
             for (int k = 0; k < H; ++k) a += s_fc[k * C + j] * hs[k];
             at[((size_t)b * T + t) * C + j] = usig(a);
         }
@@ -479,7 +486,8 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
         if (hipMalloc((void**)&e->d_tab, tab.size() * sizeof(int)) != hipSuccess || hipMemcpy(e->d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             return bail(ufail(err, ADE_ERR_DEVICE, "upload of the ERB tables failed"));
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 88 KB at 32 channels
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 88 KB at 32 channels
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
     *out = e;
@@ -513,8 +521,18 @@ int UlunasEngine::reserve(int batch, std::string& err) {
 void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const float* res, float* out, int B, int shuffle) {
     const int F = bk.width, C = bk.cout, H = (F + 3) / 4;
     const long long nfr = (long long)B * T;
-    hipLaunchKernelGGL(k_ulu_ta, dim3((unsigned)B), dim3(64), (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float), s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t,
-                       bk.ctfa.ta_fc_b, at, T, C);
+    const size_t ta_lds = (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float);
+#define ADE_ULU_TA(CC)                                                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta<CC>), dim3((unsigned)B), dim3(64), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
+                       bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t, bk.ctfa.ta_fc_b, at, T)
+    switch (C) {               // the channel counts of ULUNAS() (:665); create() rejects anything else
+        case 1: ADE_ULU_TA(1); break;
+        case 12: ADE_ULU_TA(12); break;
+        case 16: ADE_ULU_TA(16); break;
+        case 24: ADE_ULU_TA(24); break;
+        default: ADE_ULU_TA(32); break;
+    }
+#undef ADE_ULU_TA
     hipLaunchKernelGGL(k_ulu_fa_gru, dim3((unsigned)((nfr * 2 + 255) / 256)), dim3(256), 0, s, (const float*)pfreq, bk.ctfa.fa_f, bk.ctfa.fa_b, fah, F, H, nfr);
     const long long total = nfr * F * C;
     hipLaunchKernelGGL(k_ulu_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (const float*)at, (const float*)fah, bk.ctfa.fa_fc_w, bk.ctfa.fa_fc_b, res,
