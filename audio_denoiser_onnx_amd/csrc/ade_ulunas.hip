@@ -37,6 +37,7 @@ __device__ __forceinline__ int shuffled(int j, int C) { return (j & 1) ? (j >> 1
 // out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648).
 // One workgroup per frame: the kt input frames it needs (already summed with the skip tensor) and the whole weight tensor are staged in LDS
 // once, so HBM / L2 sees every input element kt times instead of once per tap, channel and output.
+template <int KT, int KF, int STRIDE, bool DECONV>      // the five kernel shapes of ULUNAS() (:667) as compile-time constants: the tap loops unroll
 __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T, int wsize,
                                                   float* __restrict__ zt, float* __restrict__ pfreq) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -44,35 +45,38 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
     const long long b = frame / T;
     const int t = (int)(frame - b * T), row = d.Fi * d.Cin;
     float* xin = lds;                      // [kt][Fi * Cin]
-    float* wl = lds + d.kt * row;          // the weights in their torch layout
-    for (int a = 0; a < d.kt; ++a) {
-        const int tt = d.deconv ? t - a : t - (d.kt - 1) + a;
+    float* wl = lds + KT * row;          // the weights in their torch layout
+    for (int a = 0; a < KT; ++a) {
+        const int tt = DECONV ? t - a : t - (KT - 1) + a;
         const size_t at = ((size_t)b * T + (tt < 0 ? 0 : tt)) * row;
         for (int i = threadIdx.x; i < row; i += 256) xin[a * row + i] = tt < 0 ? 0.0f : (x2 ? x[at + i] + x2[at + i] : x[at + i]);
     }
     for (int i = threadIdx.x; i < wsize; i += 256) wl[i] = d.w[i];
     __syncthreads();
-    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups, pf = d.kf / 2;
+    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
+    constexpr int pf = KF / 2;
     float* orow = out + (size_t)frame * d.Fo * d.Cout;
     for (int o = threadIdx.x; o < d.Fo * d.Cout; o += 256) {
         const int fo = o / d.Cout, co = o - fo * d.Cout;
         const int cc = d.shuffle ? shuffled(co, d.Cout) : co;       // output position co holds convolution channel cc
         const int g = cc / cog;
         float acc = d.b[cc];
-        for (int a = 0; a < d.kt; ++a)
-            for (int bb = 0; bb < d.kf; ++bb) {
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int bb = 0; bb < KF; ++bb) {
                 int fi;
-                if (d.deconv) {
+                if (DECONV) {
                     const int num = fo + pf - bb;
-                    if (num < 0 || num % d.stride) continue;
-                    fi = num / d.stride;
+                    if (num < 0 || num % STRIDE) continue;
+                    fi = num / STRIDE;
                 } else {
-                    fi = fo * d.stride - pf + bb;
+                    fi = fo * STRIDE - pf + bb;
                 }
                 if (fi < 0 || fi >= d.Fi) continue;
                 const float* xr = xin + a * row + fi * d.Cin + g * cig;
                 for (int ci = 0; ci < cig; ++ci) {
-                    const float wv = d.deconv ? wl[(((g * cig + ci) * cog + (cc - g * cog)) * d.kt + a) * d.kf + bb] : wl[((cc * cig + ci) * d.kt + a) * d.kf + bb];
+                    const float wv = DECONV ? wl[(((g * cig + ci) * cog + (cc - g * cog)) * KT + a) * KF + bb] : wl[((cc * cig + ci) * KT + a) * KF + bb];
                     acc += xr[ci] * wv;
                 }
             }
@@ -544,8 +548,23 @@ float* UlunasEngine::run_block(hipStream_t s, const Block& bk, const float* x, c
     auto conv = [&](const ConvDesc& d, const float* in, const float* in2, float* o, bool stats) {
         const int wsize = d.Cout * (d.Cin / d.groups) * d.kt * d.kf;      // same element count for Conv2d and ConvTranspose2d layouts
         const size_t stage = (size_t)d.kt * d.Fi * d.Cin + wsize, sq = stats ? (size_t)d.Fo * d.Cout : 0;
-        hipLaunchKernelGGL(k_ulu_conv, dim3((unsigned)((long long)B * T)), dim3(256), std::max(stage, sq) * sizeof(float), s, in, in2, d, o, T, wsize,
-                           stats ? zt : (float*)nullptr, stats ? pfreq : (float*)nullptr);
+        const dim3 grid((unsigned)((long long)B * T));
+        const size_t lds = std::max(stage, sq) * sizeof(float);
+        float *z = stats ? zt : nullptr, *pq = stats ? pfreq : nullptr;
+#define ADE_ULU_CONV(KT, KF, S, DC) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_conv<KT, KF, S, DC>), grid, dim3(256), lds, s, in, in2, d, o, T, wsize, z, pq)
+        const int key = d.kt * 1000 + d.kf * 100 + d.stride * 10 + d.deconv;       // create() admits exactly these shapes
+        switch (key) {
+            case 1110: ADE_ULU_CONV(1, 1, 1, false); break;
+            case 3320: ADE_ULU_CONV(3, 3, 2, false); break;
+            case 3321: ADE_ULU_CONV(3, 3, 2, true); break;
+            case 2320: ADE_ULU_CONV(2, 3, 2, false); break;
+            case 2321: ADE_ULU_CONV(2, 3, 2, true); break;
+            case 2310: ADE_ULU_CONV(2, 3, 1, false); break;
+            case 2311: ADE_ULU_CONV(2, 3, 1, true); break;
+            case 1510: ADE_ULU_CONV(1, 5, 1, false); break;
+            default: ADE_ULU_CONV(1, 5, 1, true); break;     // 1511
+        }
+#undef ADE_ULU_CONV
     };
     const int tail_shuffle = (!bk.last && bk.groups == 2) ? 1 : 0;
     if (bk.type == 0) {
