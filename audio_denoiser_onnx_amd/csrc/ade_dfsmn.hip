@@ -40,6 +40,13 @@ struct PcmFrameB {             // B(k, j) = sample k of frame j = (b, t), * 2^-1
         const int b = j / T, t = j - b * T;
         return (float)pcm[(size_t)b * L + t * kHopD + k] * (1.0f / 32768.0f);
     }
+    // four consecutive samples as one 8-byte load (frames start at multiples of 960 samples, so row starts are 8-byte aligned when L % 4 == 0)
+    __device__ bool can_vec4(int K) const { return (K & 3) == 0 && (L & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0; }
+    __device__ float4 vec4(int j, int k) const {
+        const int b = j / T, t = j - b * T;
+        const short4 v = *reinterpret_cast<const short4*>(pcm + (size_t)b * L + t * kHopD + k);
+        return make_float4((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f), (float)v.z * (1.0f / 32768.0f), (float)v.w * (1.0f / 32768.0f));
+    }
 };
 struct PowerB {                // B(f, j) = (re^2 + im^2) * 32768^2 of the fbank half of AN (:216)
     static constexpr bool kAlongN = true;
