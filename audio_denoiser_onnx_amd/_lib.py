@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = (
     "ade_kernel_count", "ade_kernel_name", "ade_profile_last", "ade_kernel_ms", "ade_last_error", "ade_destroy",
     "ade_stft_forward", "ade_istft_forward",
     "ade_stft_create", "ade_stft_frames", "ade_stft_output_length", "ade_stft_analyze", "ade_stft_synthesize",
-    "ade_stream_create", "ade_stream_push", "ade_stream_push_device", "ade_stream_reset", "ade_stream_destroy",
+    "ade_stream_create", "ade_stream_push", "ade_stream_push_device", "ade_stream_flush", "ade_stream_reset", "ade_stream_destroy",
     "ade_stft_last_error", "ade_stft_destroy",
 )
 
@@ -86,6 +86,7 @@ class AdeLibrary:
         L.ade_stream_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.ade_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ade_stream_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ade_stream_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ade_stream_reset.argtypes = [C.c_void_p]
         L.ade_stream_destroy.argtypes = [C.c_void_p]
         L.ade_stream_destroy.restype = None

@@ -799,8 +799,8 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
 struct ade_stream {
     ade_engine* e = nullptr;
     int S = 0, N = 0;
-    bool first = true;
-    int16_t *pcm_hist = nullptr, *concat = nullptr, *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    bool first = true, flushed = false;
+    int16_t *pcm_prev = nullptr, *pcm_hist = nullptr, *concat = nullptr, *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
     float *d_f32 = nullptr, *h_f32 = nullptr;
     float* state = nullptr;      // one allocation: dc | conv histories (ping-pong) | TRA hidden | inter-GRU hidden | OLA carry
     size_t state_floats = 0;
@@ -817,11 +817,15 @@ struct ade_stream {
 
 namespace {
 
-void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t* d_out, float* d_f32) {
+// flush = true: the single frame past the end of the signal (its second half is the end reflection); produces the stream's last hop
+void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t* d_out, float* d_f32, bool flush = false) {
     ade_engine* e = st->e;
-    const int B = st->S, T = st->N, nfr = B * T, P = T * kHop;
-    launch_stream_concat(s, st->pcm_hist, d_in, st->concat, B, P, st->first);
-    launch_stream_keep(s, st->concat, st->pcm_hist, B, P);
+    const int B = st->S, T = flush ? 1 : st->N, nfr = B * T, P = T * kHop;
+    if (flush) launch_stream_concat_flush(s, st->pcm_hist, st->pcm_prev, st->concat, B);
+    else {
+        launch_stream_concat(s, st->pcm_hist, d_in, st->concat, B, P, st->first);
+        launch_stream_keep(s, st->concat, st->pcm_hist, st->pcm_prev, B, P);
+    }
     launch_stft_pcm(s, st->concat, st->dc, B, P + kHop, T, e->tabs, e->erb_bm, st->spec, st->feat, /*center=*/false);
     launch_conv0(s, st->feat, e->en0, st->e0, nfr);
     launch_conv1(s, st->e0, e->en1, st->e1, nfr);
@@ -1314,7 +1318,7 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
     if (hipMalloc((void**)&st->ws, wtotal * sizeof(float)) != hipSuccess) return bail("ade_stream_create: hipMalloc of the push workspace failed");
     size_t at = 0;
     for (auto& c : cs) { *c.p = st->ws + at; at += (c.n + 63) & ~(size_t)63; }
-    if (hipMalloc((void**)&st->pcm_hist, S * kHop * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->concat, S * (P + kHop) * sizeof(int16_t)) != hipSuccess ||
+    if (hipMalloc((void**)&st->pcm_prev, S * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->pcm_hist, S * kHop * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->concat, S * (P + kHop) * sizeof(int16_t)) != hipSuccess ||
         hipMalloc((void**)&st->d_in, S * P * sizeof(int16_t)) != hipSuccess || hipMalloc((void**)&st->d_out, S * P * sizeof(int16_t)) != hipSuccess ||
         hipMalloc((void**)&st->d_f32, S * P * sizeof(float)) != hipSuccess ||
         hipHostMalloc((void**)&st->h_in, S * P * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
@@ -1332,14 +1336,17 @@ ade_status ade_stream_reset(ade_stream_handle st) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemset(st->state, 0, st->state_floats * sizeof(float)));
     HIP_TRY(h, hipMemset(st->pcm_hist, 0, (size_t)st->S * kHop * sizeof(int16_t)));
+    HIP_TRY(h, hipMemset(st->pcm_prev, 0, (size_t)st->S * sizeof(int16_t)));
     for (int i = 0; i < 6; ++i) st->hist_cur[i] = 0;
     st->first = true;
+    st->flushed = false;
     return ADE_OK;
 }
 
 ade_status ade_stream_push_device(ade_stream_handle st, const int16_t* d_in, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream) {
     if (!st || !d_in || (!d_out_pcm && !d_out_f32)) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
+    if (st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_push: the stream was flushed; reset it first");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     enqueue_stream(st, s, d_in, d_out_pcm, d_out_f32);
@@ -1351,11 +1358,29 @@ ade_status ade_stream_push_device(ade_stream_handle st, const int16_t* d_in, int
 ade_status ade_stream_push(ade_stream_handle st, const int16_t* in, int16_t* out_pcm, float* out_f32) {
     if (!st || !in || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
+    if (st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_push: the stream was flushed; reset it first");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = (size_t)st->S * st->N * kHop;
     memcpy(st->h_in, in, n * sizeof(int16_t));
     HIP_TRY(h, hipMemcpyAsync(st->d_in, st->h_in, n * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
     enqueue_stream(st, h->stream, st->d_in, st->d_out, out_f32 ? st->d_f32 : nullptr);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(st->h_f32, st->d_f32, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_pcm) memcpy(out_pcm, st->h_out, n * sizeof(int16_t));
+    if (out_f32) memcpy(out_f32, st->h_f32, n * sizeof(float));
+    return ADE_OK;
+}
+
+ade_status ade_stream_flush(ade_stream_handle st, int16_t* out_pcm, float* out_f32) {
+    if (!st || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
+    ade_engine* h = st->e;
+    if (st->first || st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_flush: nothing to flush (no push since the last reset, or already flushed)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)st->S * kHop;
+    enqueue_stream(st, h->stream, nullptr, st->d_out, out_f32 ? st->d_f32 : nullptr, /*flush=*/true);
+    st->flushed = true;
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(st->h_f32, st->d_f32, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1372,6 +1397,7 @@ void ade_stream_destroy(ade_stream_handle st) {
     if (st->state) (void)hipFree(st->state);
     if (st->ws) (void)hipFree(st->ws);
     if (st->pcm_hist) (void)hipFree(st->pcm_hist);
+    if (st->pcm_prev) (void)hipFree(st->pcm_prev);
     if (st->concat) (void)hipFree(st->concat);
     if (st->d_in) (void)hipFree(st->d_in);
     if (st->d_out) (void)hipFree(st->d_out);

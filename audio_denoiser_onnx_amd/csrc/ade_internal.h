@@ -106,7 +106,8 @@ void launch_ola_pcm(hipStream_t s, const float* frames, FftTabs tabs, int B, int
 // streaming pieces (state carried across pushes; see ade_stream_* in include/ade.h)
 void launch_hist_shift(hipStream_t s, const float* hist_in, const float* h, float* hist_out, int B, int T, int depth);
 void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in, int16_t* concat, int B, int P, bool first);
-void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P);
+void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int16_t* prev, int B, int P);
+void launch_stream_concat_flush(hipStream_t s, const int16_t* hist, const int16_t* prev, int16_t* concat, int B);
 // linear resampling of the driver edges (F.interpolate(mode='linear', align_corners=False)); src = scale * (dst + 0.5) - 0.5
 void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale);
 void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32);

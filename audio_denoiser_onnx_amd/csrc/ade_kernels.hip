@@ -737,11 +737,22 @@ __global__ __launch_bounds__(256) void k_stream_concat(const int16_t* __restrict
     const int row = P + kHop, b = (int)(i / row), j = (int)(i - (long long)b * row);
     concat[i] = j >= kHop ? in[(size_t)b * P + (j - kHop)] : (first ? in[(size_t)b * P + (kHop - j)] : hist[(size_t)b * kHop + j]);
 }
-__global__ __launch_bounds__(256) void k_stream_keep(const int16_t* __restrict__ concat, int16_t* __restrict__ hist, int P, long long total) {
+__global__ __launch_bounds__(256) void k_stream_keep(const int16_t* __restrict__ concat, int16_t* __restrict__ hist, int16_t* __restrict__ prev, int P,
+                                                     long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int b = (int)(i / kHop), j = (int)(i - (long long)b * kHop);
     hist[i] = concat[(size_t)b * (P + kHop) + P + j];
+    if (j == 0) prev[b] = concat[(size_t)b * (P + kHop) + P - 1];      // the sample before the history: the end reflection needs 257 samples
+}
+// end of stream: the one frame the one-shot graph computes past the signal, [last 256 samples | reflection x[L-2], ..., x[L-257]] (STFT_Process.py:306-309)
+__global__ __launch_bounds__(256) void k_stream_concat_flush(const int16_t* __restrict__ hist, const int16_t* __restrict__ prev, int16_t* __restrict__ concat,
+                                                             long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / (2 * kHop)), j = (int)(i - (long long)b * 2 * kHop);
+    if (j < kHop) concat[i] = hist[(size_t)b * kHop + j];
+    else { const int r = j - kHop; concat[i] = r < kHop - 1 ? hist[(size_t)b * kHop + (kHop - 2 - r)] : prev[b]; }
 }
 // overlap-add with a carried half frame: output hop k of the push = second half of frame k - 1 (the carry for k = 0) + first half of
 // frame k, / sum(w^2); one hop behind the input (a frame is complete one hop after its centre).  The very first hop of a stream has no
@@ -857,8 +868,11 @@ void launch_hist_shift(hipStream_t s, const float* hist_in, const float* h, floa
 void launch_stream_concat(hipStream_t s, const int16_t* hist, const int16_t* in, int16_t* concat, int B, int P, bool first) {
     hipLaunchKernelGGL(k_stream_concat, grid1((long long)B * (P + kHop), 256), dim3(256), 0, s, hist, in, concat, P, first ? 1 : 0, (long long)B * (P + kHop));
 }
-void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int B, int P) {
-    hipLaunchKernelGGL(k_stream_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, concat, hist, P, (long long)B * kHop);
+void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int16_t* prev, int B, int P) {
+    hipLaunchKernelGGL(k_stream_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, concat, hist, prev, P, (long long)B * kHop);
+}
+void launch_stream_concat_flush(hipStream_t s, const int16_t* hist, const int16_t* prev, int16_t* concat, int B) {
+    hipLaunchKernelGGL(k_stream_concat_flush, grid1((long long)B * 2 * kHop, 256), dim3(256), 0, s, hist, prev, concat, (long long)B * 2 * kHop);
 }
 void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale) {
     hipLaunchKernelGGL(k_resample_in, grid1(rows * Lout, 256), dim3(256), 0, s, in, out, Lin, Lout, scale, rows * Lout);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's ``GTCRN/Inference_GTCRN_ONNX.py`` call surface on the MI355X engine.
 
-    python -m audio_denoiser_onnx_amd.inference_gtcrn <model_dir_or_.adew> [noisy.wav] [denoised.wav] [--sequential]
+    python -m audio_denoiser_onnx_amd.inference_gtcrn <model_dir_or_.adew> [noisy.wav] [denoised.wav] [--sequential | --stream FRAMES]
 
 Same life-cycle as the reference script (Inference_GTCRN_ONNX.py:237-344): open the session, load + validate the
 metadata, read the wav as mono int16 at IN_SAMPLE_RATE, optional RMS normalisation, cut fixed-length slices (stride =
@@ -11,7 +11,8 @@ trim to the original length, write PCM_16, print the RTF.
 What differs is only the hot loop: the reference runs one ``run_with_iobinding`` per slice (:326-330); slices carry
 no state from one to the next, so here ALL slices of the file go through the engine as ONE batch (``--sequential``
 reproduces the one-slice-per-call loop for comparison).  With ``torch.distributed`` initialised, slices are sharded
-across ranks and the outputs stitched with an all-gather (distributed.py).
+across ranks and the outputs stitched with an all-gather (distributed.py).  ``--stream FRAMES`` instead runs the whole file through one
+stateful stream (``ade_stream_*``) in pushes of FRAMES hops: no slice edges at all.
 """
 from __future__ import annotations
 
@@ -112,9 +113,30 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
     return full.reshape(-1)[:audio_len]            # np.concatenate(saved).reshape(-1)[:audio_len]  (:332)
 
 
+def denoise_streaming(session: InferenceSession, audio: np.ndarray, frames_per_push: int = 62) -> np.ndarray:
+    """int16 mono waveform -> int16 denoised waveform of the same length through ONE stateful stream (``--stream N``): no slice edges --
+    the result is what the reference's graph would give on the whole file in one call (without its whole-call DC removal), which its
+    static export cannot do for files longer than the graph input.  The file is zero-padded to whole pushes; the stream's one-hop latency
+    is removed again (pushes + flush, first hop dropped)."""
+    from .session import StreamingSession
+    P = frames_per_push * 256
+    n = max(1, -(-len(audio) // P))
+    padded = np.zeros(n * P, np.int16)
+    padded[:len(audio)] = audio
+    with StreamingSession(session, 1, frames_per_push) as st:
+        parts = [st.push(padded[None, i * P:(i + 1) * P]) for i in range(n)]
+        parts.append(st.flush())
+    return np.ascontiguousarray(np.concatenate(parts, axis=1)[0, 256:256 + len(audio)])
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     sequential = "--sequential" in argv
+    stream_frames = 0
+    if "--stream" in argv:
+        i = argv.index("--stream")
+        stream_frames = int(argv[i + 1])
+        del argv[i:i + 2]
     argv = [a for a in argv if not a.startswith("--")]
     if not argv:
         print(__doc__)
@@ -134,7 +156,7 @@ def main(argv=None) -> int:
     print("\nRunning the GTCRN on the MI355X engine.")
     session.reserve(plan_slices(len(audio), session.in_len, session.out_len)[1])
     t0 = time.time()
-    denoised = denoise(session, audio, sequential=sequential)
+    denoised = denoise_streaming(session, audio, stream_frames) if stream_frames else denoise(session, audio, sequential=sequential)
     elapsed = time.time() - t0
     print("Complete: 100.00%")
     write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])

@@ -239,6 +239,14 @@ class StreamingSession:
                                                 C.c_void_p(d_f32.data_ptr()) if d_f32 is not None else None, C.c_void_p(stream) if stream else None)
         self._lib.check(st, self._session._h)
 
+    def flush(self, want_f32: bool = False):
+        """End of the signal: the last hop, int16 (n_streams, 256).  ``concatenate(pushes + [flush])[:, 256:]`` is then exactly the one-shot
+        output of the whole signal.  ``reset()`` before pushing again."""
+        out = np.empty((self.n_streams, 256), np.int16)
+        f32 = np.empty((self.n_streams, 256), np.float32) if want_f32 else None
+        self._lib.check(self._lib.c.ade_stream_flush(self._h, out.ctypes.data, f32.ctypes.data if want_f32 else None), self._session._h)
+        return (out, f32) if want_f32 else out
+
     def reset(self) -> None:
         self._lib.check(self._lib.c.ade_stream_reset(self._h), self._session._h)
 

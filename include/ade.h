@@ -128,6 +128,10 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
 ade_status ade_stream_push(ade_stream_handle s, const int16_t* in, int16_t* out_pcm, float* out_f32);
 /* the same on DEVICE buffers; enqueues on `hip_stream` (NULL = the engine's stream, then synchronous). */
 ade_status ade_stream_push_device(ade_stream_handle s, const int16_t* d_in, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream);
+/* End of the signal: the last hop (out: [n_streams][256]), computed from the one frame the reference's graph evaluates past the end
+ * (its second half is the reflection of the last 257 samples).  Pushes + flush then reproduce the one-shot output sample for sample,
+ * shifted by one hop.  The stream must be reset before it is pushed again. */
+ade_status ade_stream_flush(ade_stream_handle s, int16_t* out_pcm, float* out_f32);
 ade_status ade_stream_reset(ade_stream_handle s);      /* back to a fresh stream (zero state, next push reflects its head) */
 void ade_stream_destroy(ade_stream_handle s);           /* before ade_destroy of its engine */
 

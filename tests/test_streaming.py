@@ -30,6 +30,9 @@ def run_stream(sess, signals, frames_per_push):
     n_push = signals.shape[1] // P
     with StreamingSession(sess, signals.shape[0], frames_per_push) as st:
         parts = [st.push(signals[:, i * P:(i + 1) * P], want_f32=True) for i in range(n_push)]
+        parts.append(st.flush(want_f32=True))              # the last hop: the frame past the end, reflected
+        with pytest.raises(ValueError):
+            st.push(signals[:, :P])                        # a flushed stream must be reset first
         pcm = np.concatenate([p[0] for p in parts], axis=1)
         f32 = np.concatenate([p[1] for p in parts], axis=1)
         # a reset stream starts over: same first push again
@@ -48,10 +51,10 @@ def check_equivalence(library, frames_per_push, n_frames=40, seed=0):
     o = GtcrnOracle(golden_blob(seed), L)
     o.set_exact_dft(True)
     opcm, of32 = o.process(signals)
-    n_ok = L - HOP                                       # streamed hops 1 .. n_frames - 1 = one-shot hops 0 .. n_frames - 2
+    assert pcm.shape[1] == L + HOP                                                   # pushes + flush = the whole one-shot output, one hop later
     assert not pcm[:, :HOP].any() and not f32[:, :HOP].any()                         # the stream's first hop is blank
-    assert np.abs(f32[:, HOP:] - of32[:, :n_ok]).max() <= 1e-5
-    assert np.abs(pcm[:, HOP:].astype(np.int32) - opcm[:, :n_ok].astype(np.int32)).max() <= 1
+    assert np.abs(f32[:, HOP:] - of32).max() <= 1e-5
+    assert np.abs(pcm[:, HOP:].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
     return sess, signals, pcm
 
 
@@ -81,3 +84,21 @@ def test_gpu_streaming_rejects_other_families_and_bad_sizes():
     with pytest.raises(ValueError):
         with StreamingSession(sess, 2, 4) as st:
             st.push(np.zeros((2, 100), np.int16))
+
+
+@pytest.mark.gpu
+def test_gpu_file_driver_streaming_mode_has_no_slice_edges():
+    """``inference_gtcrn --stream``: a 2.3 s file through one stream equals the one-shot oracle on the (zero-padded) whole file."""
+    from audio_denoiser_onnx_amd import inference_gtcrn as drv
+    rng = np.random.default_rng(4)
+    n = 36000                                            # not a whole number of pushes: the driver zero-pads to 5 pushes of 32 frames = 40960
+    audio = zero_sum_signal(rng, n)                      # integer sum 0 -> the oracle's whole-call DC term on the padded file is exactly 0
+    padded = np.zeros(40960, np.int16)
+    padded[:n] = audio
+    sess = make_session(None, seed=0)                    # the session's own static length does not matter for streaming
+    out = drv.denoise_streaming(sess, audio, frames_per_push=32)
+    assert out.shape == audio.shape and out.dtype == np.int16
+    o = GtcrnOracle(golden_blob(0), 40960)
+    o.set_exact_dft(True)
+    opcm, _ = o.process(padded[None])
+    assert np.abs(out.astype(np.int32) - opcm[0, :len(audio)].astype(np.int32)).max() <= 1
