@@ -12,7 +12,7 @@ from __future__ import annotations
 import sys
 
 from . import inference_gtcrn
-from .session import InferenceSession, resolve_model_path
+from .session import resolve_model_path
 from .metadata import load_runtime_metadata
 
 

@@ -93,8 +93,6 @@ def main(seed=0):
     net.prepare_for_export_()
     model = ns["ULUNAS_CUSTOM"](net.float(), stft, istft, 16000, 16000, remove_dc_offset=False, use_batch_fold=False, fold_window=0,
                                 input_scale_folded=True, output_scale_folded=True).eval()
-    ins = mg.inputs_16k() if hasattr(mg, "inputs_16k") else None
-    z = np.load(os.path.join(mg.GOLD, "gtcrn_inputs.npz")) if os.path.exists(os.path.join(mg.GOLD, "gtcrn_inputs.npz")) else None
     rng = np.random.default_rng(1234)
     wav = None
     try:
