@@ -949,10 +949,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
-        if (fold_d && fam_ulu) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ul_unas: use_batch_fold is not implemented (pass the windows as batch rows)"));
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
-                       : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, device, &e->sub, derr)
+                       : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();

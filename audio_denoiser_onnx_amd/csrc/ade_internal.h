@@ -173,7 +173,7 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
 // model_family "mossformer2_ss" (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662), csrc/ade_mossformer.hip
 int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "ul_unas" (UL-UNAS/Export_UL_UNAS.py:51-913), csrc/ade_ulunas.hip
-int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err);
+int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

@@ -300,7 +300,7 @@ void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* 
 }  // namespace
 
 struct UlunasEngine : SubEngine {
-    int device = 0, L = 0, T = 0, out_len_ = 0;
+    int device = 0, L = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0;
     ade_stft_handle plan = nullptr;
     float* d_w = nullptr;
     const float* erb = nullptr;
@@ -320,8 +320,10 @@ struct UlunasEngine : SubEngine {
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
-    int in_len() const override { return L; }
-    int out_len() const override { return out_len_; }
+    // batch-fold (:866-871, :886-887): a call is n_win whole windows back to back; each is an independent clip and the outputs are
+    // stitched in place, so folding is only a reinterpretation of the rows (W is a multiple of the hop: every window returns W samples)
+    int in_len() const override { return L * n_win; }
+    int out_len() const override { return out_len_ * n_win; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
@@ -329,9 +331,10 @@ struct UlunasEngine : SubEngine {
     float* run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B);
 };
 
-int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err) {
+int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (in_len < kUNfft) return ufail(err, ADE_ERR_SHAPE_MISMATCH, "ul_unas: input_audio_length shorter than one 512-sample frame");
+    if (n_win < 1 || (n_win > 1 && in_len % kUHop)) return ufail(err, ADE_ERR_BAD_VALUE, "ul_unas: fold windows must be whole hops");
     // ULUNAS() defaults (:655-668)
     static const int types[5] = {0, 2, 1, 2, 1}, strides[5] = {2, 2, 1, 1, 1}, groups[5] = {1, 2, 2, 2, 2}, channels[5] = {12, 24, 24, 32, 16},
                      kts[5] = {3, 2, 2, 1, 1}, kfs[5] = {3, 3, 3, 5, 5}, widths[5] = {65, 33, 33, 33, 33};
@@ -354,7 +357,7 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     };
     UlunasEngine* e = new UlunasEngine();
     auto bail = [&](int st) { delete e; return st; };
-    e->device = device; e->L = in_len; e->T = in_len / kUHop + 1; e->out_len_ = kUHop * (e->T - 1);
+    e->device = device; e->L = in_len; e->n_win = n_win; e->T = in_len / kUHop + 1; e->out_len_ = kUHop * (e->T - 1);
     auto conv = [&](ConvDesc& d, const std::string& wname, const std::string& aname, int cin, int cout, int fi, int fo, int kt, int kf, int stride, int g, int deconv,
                     bool act, int shuffle) {
         d = ConvDesc{nullptr, nullptr, nullptr, nullptr, nullptr, cin, cout, fi, fo, kt, kf, stride, g, deconv, shuffle};
@@ -498,8 +501,9 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     return ADE_OK;
 }
 
-int UlunasEngine::reserve(int batch, std::string& err) {
-    if (batch <= capacity) return ADE_OK;
+int UlunasEngine::reserve(int calls, std::string& err) {
+    if (calls <= capacity) return ADE_OK;
+    const int batch = calls * n_win;
     UL_HIP(hipSetDevice(device));
     UL_HIP(hipDeviceSynchronize());
     if (ws) (void)hipFree(ws);
@@ -518,7 +522,7 @@ int UlunasEngine::reserve(int batch, std::string& err) {
     // let the STFT plan size its frame buffer now (it allocates lazily), so that run() never allocates
     UL_HIP(hipMemset(spec, 0, B * 2 * kUBins * T * sizeof(float)));
     if (ade_stft_synthesize(plan, spec, batch, T, yf, nullptr) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
-    capacity = batch;
+    capacity = calls;
     return ADE_OK;
 }
 
@@ -588,7 +592,7 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     if (batch == 0) return ADE_OK;
     int st = reserve(batch, err);
     if (st != ADE_OK) return st;
-    const int B = batch;
+    const int B = batch * n_win;
     const long long nfr = (long long)B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
@@ -623,7 +627,7 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
 }
 
 int UlunasEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
-    const size_t n = (size_t)batch * T * kUBins;
+    const size_t n = (size_t)batch * n_win * T * kUBins;
     if (strcmp(name, "mask") != 0) return ufail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
     if (!mask_tap || batch <= 0) return ufail(err, ADE_ERR_NOT_FOUND, "tap has no data yet");
     if (count < n) return ufail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");

@@ -125,3 +125,30 @@ def test_upstream_checkpoint_keys_convert_and_export(fixture, tmp_path):
     path = export.export_ulunas(tmp_path / "ckpt.npz", tmp_path / "out", 16000)
     blob = load_blob(path)
     assert set(blob) == set(fused) and (tmp_path / "out" / "UL_UNAS_Metadata.json").exists()
+
+
+def _fold_oracle_out(fused, zf):
+    W = int(zf["fold_window_length"])
+    rows = np.ascontiguousarray(zf["pcm_in"].reshape(-1, W))
+    return _oracle(fused, W).process(rows).reshape(-1)
+
+
+def test_oracle_batch_fold_matches_reference_forward(fixture):
+    """USE_BATCH_FOLD in the reference (3 windows of 4096 samples) = the oracle on the windows as independent clips, stitched."""
+    zf = np.load(os.path.join(HERE, "golden", "ulunas_seed0_fold.npz"))
+    d = _fold_oracle_out(fixture[1], zf).astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_gpu_batch_fold_matches_reference_fixture(fixture):
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    zf = np.load(os.path.join(HERE, "golden", "ulunas_seed0_fold.npz"))
+    meta = ulunas.metadata(int(zf["input_audio_length"]), use_batch_fold=True, batch_window_seconds=float(zf["batch_window_seconds"]))
+    assert int(meta["fold_window_length"]) == int(zf["fold_window_length"]) and int(meta["export_audio_length"]) == zf["pcm_in"].shape[0]
+    with InferenceSession(weights=pack_blob(fixture[1]), metadata=meta) as sess:
+        assert sess.in_len == 12288 and sess.out_len == 12288 and sess.frames == 17
+        out = sess.run(None, {"noisy_audio": np.stack((zf["pcm_in"], zf["pcm_in"]))[:, None]})[0][:, 0]
+    d = out[0].astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02 and np.array_equal(out[0], out[1])

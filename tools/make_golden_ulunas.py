@@ -29,12 +29,12 @@ from ref_import import REF_ROOT, _stub_absent_modules, import_stft_process  # no
 L = 16000
 
 
-def import_namespace(length: int) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "UL-UNAS", "Export_UL_UNAS.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
-    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": False}
+    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -124,5 +124,32 @@ def main(seed=0):
           "mask mean", float(masks[0].mean()), "mask std", float(masks[0].std()))
 
 
+def fold_fixture(seed=0):
+    """USE_BATCH_FOLD = True (:41-44, :866-871, :886-887): BATCH_WINDOW_SECONDS = 0.256 -> W = 4096 (17 frames); INPUT_AUDIO_LENGTH = 10000 ->
+    the graph input is 3 whole windows = 12288 samples, folded into the batch; same seeded network as the plain fixture."""
+    ns = import_namespace(10000, True, 0.256)
+    assert ns["FOLD_WINDOW_LENGTH"] == 4096 and ns["EXPORT_AUDIO_LENGTH"] == 12288 and ns["STATIC_SIGNAL_LENGTH"] == 17
+    STFT_Process = import_stft_process("UL-UNAS").STFT_Process
+    stft = STFT_Process(model_type="stft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"], max_frames=0,
+                        window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"], input_scale=ns["INV_INT16"]).eval()
+    istft = STFT_Process(model_type="istft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"],
+                         max_frames=ns["MAX_SIGNAL_LENGTH"], window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"],
+                         output_scale=32767.0, static_norm=True).eval()
+    torch.manual_seed(seed)
+    net = ns["ULUNAS"]().eval()
+    seed_network(net, seed)
+    net.prepare_for_export_()
+    model = ns["ULUNAS_CUSTOM"](net.float(), stft, istft, 16000, 16000, remove_dc_offset=False, use_batch_fold=True, fold_window=4096,
+                                input_scale_folded=True, output_scale_folded=True).eval()
+    z = np.load(os.path.join(mg.GOLD, f"ulunas_seed{seed}.npz"))
+    pcm = np.ascontiguousarray(np.concatenate((z["pcm_in"][0][:6000], z["pcm_in"][1][:6288])))
+    with torch.inference_mode():
+        out = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+    np.savez_compressed(os.path.join(mg.GOLD, f"ulunas_seed{seed}_fold.npz"), pcm_in=pcm, pcm_out=out, input_audio_length=np.int64(10000),
+                        fold_window_length=np.int64(4096), batch_window_seconds=np.float64(0.256))
+    print("fold out", out.shape, int(np.abs(out).max()))
+
+
 if __name__ == "__main__":
     main()
+    fold_fixture()
