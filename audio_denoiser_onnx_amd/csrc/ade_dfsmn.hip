@@ -35,13 +35,15 @@ constexpr int kMel = 120, kHid = 256;
 struct PcmFrameB {             // B(k, j) = sample k of frame j = (b, t), * 2^-15 (Export_DFSMN.py:186-190, conv1d stride 960, no padding)
     static constexpr bool kAlongN = false;
     const int16_t* pcm;
+    const float* fpcm;         // resampled input (floats in int16 units, :186-193) replaces pcm when set
     int L, T;
     __device__ float operator()(int k, int j) const {
         const int b = j / T, t = j - b * T;
-        return (float)pcm[(size_t)b * L + t * kHopD + k] * (1.0f / 32768.0f);
+        const size_t at = (size_t)b * L + t * kHopD + k;
+        return (fpcm ? fpcm[at] : (float)pcm[at]) * (1.0f / 32768.0f);
     }
     // four consecutive samples as one 8-byte load (frames start at multiples of 960 samples, so row starts are 8-byte aligned when L % 4 == 0)
-    __device__ bool can_vec4(int K) const { return (K & 3) == 0 && (L & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0; }
+    __device__ bool can_vec4(int K) const { return !fpcm && (K & 3) == 0 && (L & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0; }
     __device__ float4 vec4(int j, int k) const {
         const int b = j / T, t = j - b * T;
         const short4 v = *reinterpret_cast<const short4*>(pcm + (size_t)b * L + t * kHopD + k);
@@ -113,7 +115,7 @@ void hamming_f32(int n, bool periodic, std::vector<float>& w) {   // the fp32 ev
 }  // namespace
 
 struct DfsmnEngine : SubEngine {
-    int device = 0, in_len_ = 0, T = 0, out_len_ = 0, depth = 0, lorder = 0;
+    int device = 0, in_len_ = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0, depth = 0, lorder = 0;
     float* d_w = nullptr;      // one arena: tables + weights
     const float *k_an = nullptr, *k_inv = nullptr, *wsum = nullptr, *mel = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *lin2_w = nullptr,
                 *lin2_b = nullptr;
@@ -128,8 +130,10 @@ struct DfsmnEngine : SubEngine {
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
-    int in_len() const override { return in_len_; }
-    int out_len() const override { return out_len_; }
+    // batch-fold (:194-198, :231-232): a call is n_win windows back to back, each an independent clip whose raw overlap-add length equals the window
+    int in_len() const override { return in_len_ * n_win; }
+    int out_len() const override { return out_len_ * n_win; }
+    bool accepts_float_input() const override { return true; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
@@ -144,7 +148,7 @@ int dfail(std::string& err, int st, const std::string& msg) { err = msg; return 
     } while (0)
 }  // namespace
 
-int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err) {
+int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (in_len < kFrame) return dfail(err, ADE_ERR_SHAPE_MISMATCH, "dfsmn: input_audio_length shorter than one 1920-sample frame");
     auto get = [&](const std::string& name, std::vector<int> dims, const float** p) -> bool {
@@ -175,6 +179,7 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
     DfsmnEngine* d = new DfsmnEngine();
     d->device = device;
     d->in_len_ = in_len;
+    d->n_win = n_win;
     d->T = (in_len - kFrame) / kHopD + 1;                       // STFT_SIGNAL_LENGTH (Export_DFSMN.py:66)
     d->out_len_ = kNfftD + kHopD * (d->T - 1);                   // raw conv_transpose length, no centre trim
     d->depth = depth;
@@ -248,9 +253,10 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int d
     return ADE_OK;
 }
 
-int DfsmnEngine::reserve(int batch, std::string& err) {
+int DfsmnEngine::reserve(int calls, std::string& err) {
     DfsmnEngine* d = this;
-    if (batch <= d->capacity) return ADE_OK;
+    if (calls <= d->capacity) return ADE_OK;
+    const int batch = calls * n_win;
     DF_HIP(hipSetDevice(d->device));
     DF_HIP(hipDeviceSynchronize());
     if (d->ws) (void)hipFree(d->ws);
@@ -265,7 +271,7 @@ int DfsmnEngine::reserve(int batch, std::string& err) {
     float** ptrs[7] = {&d->an, &d->feat, &d->x, &d->f1, &d->p1, &d->mask, &d->frames_buf};
     size_t off = 0;
     for (int i = 0; i < 7; ++i) { *ptrs[i] = d->ws + off; off += (sizes[i] + 63) & ~(size_t)63; }
-    d->capacity = batch;
+    d->capacity = calls;
     return ADE_OK;
 }
 
@@ -274,10 +280,11 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
     if (batch == 0) return ADE_OK;
     int st = reserve(batch, err);
     if (st != ADE_OK) return st;
+    batch *= n_win;
     using namespace gemm;
     const int N = batch * d->T;
     // fused analysis convolution: [fbank re | fbank im | stft re | stft im] x frames                       (Export_DFSMN.py:205-209)
-    launch(s, RowMajorA{d->k_an, kFrame}, PcmFrameB{d_in, d->in_len_, d->T}, BiasActStore<kActNone>{d->an, N, nullptr, 0.0f}, kAnRows, N, kFrame);
+    launch(s, RowMajorA{d->k_an, kFrame}, PcmFrameB{d_in, float_in, d->in_len_, d->T}, BiasActStore<kActNone>{d->an, N, nullptr, 0.0f}, kAnRows, N, kFrame);
     // Kaldi log-mel: mel_banks x power, clamp(eps), log                                                  (:216-217)
     launch(s, RowMajorA{d->mel, kFbBins}, PowerB{d->an, N}, BiasActStore<kActLogFloor>{d->feat, N, nullptr, 1.1920928955078125e-07f}, kMel, N, kFbBins);
     // mask network                                                                                          (:224-230)
@@ -302,7 +309,7 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
 
 int DfsmnEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
     DfsmnEngine* d = this;
-    const size_t N = (size_t)batch * d->T;
+    const size_t N = (size_t)batch * n_win * d->T;
     const float* src = nullptr;
     size_t n = 0;
     if (strcmp(name, "logmel") == 0) { src = d->feat; n = kMel * N; }

@@ -898,17 +898,21 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (dyn_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
-        if (fold_d && fam_dfsmn) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dfsmn: use_batch_fold is not implemented"));
+        if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
+            long fw = 0;
+            if (!e->meta.count("fold_window_length") || !parse_int(e->meta["fold_window_length"], &fw) || fw < 1920 || fw % 960)
+                return bail(fail(e, ADE_ERR_BAD_VALUE, "dfsmn: use_batch_fold=1 needs fold_window_length: a multiple of the 960-sample hop, at least 1920"));
+        }
         long sri = 0, sro = 0, srm = 0, Ld = 0;
         if (!parse_int(e->meta["in_sample_rate"], &sri) || !parse_int(e->meta["out_sample_rate"], &sro) ||
             !parse_int(e->meta["model_sample_rate"], &srm) || !parse_int(e->meta["input_audio_length"], &Ld))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
         const bool rates_differ = sri != srm || sro != srm;
         if (srm != rate) return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at a model rate of " + std::to_string(rate) + " Hz"));
-        // Resampling edges exist where the reference's STATIC export is self-consistent: MossFormer2 sizes its frames from the model-rate
-        // length (Export_MossFormer2_SS_16K.py:36-37,99-104).  DFSMN has no such path; Mel-Band-Roformer (like GTCRN) sizes its static frame
-        // count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with its STFT when the rates are equal.
-        if (rates_differ && !fam_moss)
+        // Resampling edges exist where the reference's STATIC export is self-consistent: MossFormer2 and DFSMN size their frames from the
+        // model-rate length (Export_MossFormer2_SS_16K.py:36-37,99-104; Export_DFSMN.py:48,67).  Mel-Band-Roformer (like GTCRN) and UL-UNAS size
+        // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
+        if (rates_differ && !fam_moss && !fam_dfsmn)
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
@@ -949,7 +953,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
-        const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, device, &e->sub, derr)
+        const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
@@ -966,8 +970,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             e->rs_model_out = e->sub->out_len();
             e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);
             e->rs_scale_out = (float)((double)e->rs_model_out / (double)out_caller);
-            e->rs_pcm_scale = 1.0f;            // MossFormer2's waveform is already in PCM units (rms restore, :622-623)
-            e->rs_truncate_i32 = true;         // .to(int32).clamp().to(int16) (:645)
+            e->rs_pcm_scale = fam_dfsmn ? 32768.0f : 1.0f;   // DFSMN: * 32768 after the interpolation (Export_DFSMN.py:241-243); MossFormer2's waveform
+            e->rs_truncate_i32 = !fam_dfsmn;                 // is already in PCM units and goes through .to(int32).clamp().to(int16) (:645)
             e->in_len = (int)caller_len * e->channels;
             e->out_len = (int)out_caller * e->channels * e->n_outputs;
         }

@@ -168,7 +168,7 @@ struct SubEngine {
     virtual int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) = 0;
 };
 // model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip
-int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int device, SubEngine** out, std::string& err);
+int dfsmn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
 // model_family "mossformer2_ss" (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662), csrc/ade_mossformer.hip
 int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);

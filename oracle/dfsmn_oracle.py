@@ -61,6 +61,17 @@ def stft_kernels(exact: bool = False):
     return fwd, inv, ws
 
 
+def interpolate_linear(x, out_len):
+    """F.interpolate(x, size=out_len, mode='linear', align_corners=False) over the last axis in fp32: src = (in / out) (dst + 0.5) - 0.5
+    clamped at 0, y = (1 - l) x[i0] + l x[min(i0 + 1, in - 1)]."""
+    n = x.shape[-1]
+    src = np.maximum(F32(n / out_len) * (np.arange(out_len, dtype=F32) + F32(0.5)) - F32(0.5), F32(0.0)).astype(F32)
+    i0 = np.minimum(src.astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    l1 = (src - i0.astype(F32)).astype(F32)
+    return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
 class DfsmnOracle:
     def __init__(self, tensors: dict, in_len: int, exact_dft: bool = False):
         self.w = {k: np.ascontiguousarray(v, F32) for k, v in tensors.items()}
@@ -86,9 +97,16 @@ class DfsmnOracle:
             out_pcm[b] = np.clip(out_f32[b] * F32(32768.0), F32(-32768.0), F32(32767.0)).astype(np.int16)   # trunc toward zero (:243-244)
         return out_pcm, out_f32
 
+    def process_resampled(self, pcm: np.ndarray, out_len: int):
+        """Resampling edges (:186-193, :233-240): int16 (n,) at another input rate -> F.interpolate(size = in_len) -> model ->
+        F.interpolate(size = out_len) -> * 32768, clamp, truncate."""
+        x = interpolate_linear(np.asarray(pcm, np.int16).astype(F32), self.in_len)
+        y = interpolate_linear(self._one(x, False), out_len)
+        return np.clip(y * F32(32768.0), F32(-32768.0), F32(32767.0)).astype(np.int16)
+
     def _one(self, pcm: np.ndarray, keep: bool) -> np.ndarray:
         w, T = self.w, self.frames
-        audio = pcm.astype(F32) * F32(1.0 / 32768.0)                                            # :186-190
+        audio = pcm.astype(F32) * F32(1.0 / 32768.0)                                            # :186-190 (pcm: int16, or floats in int16 units)
         frames = np.stack([audio[t * HOP:t * HOP + FRAME] for t in range(T)], axis=1)           # (1920, T): conv1d stride 960, no pad
         fb = self.kfb @ frames                                                                  # :205-209 (fused analysis conv)
         spec = self.kst @ frames                                                                # (2*961, T)

@@ -43,11 +43,11 @@ def test_dfsmn_oracle_matches_reference(gold, tensors):
     assert float(m.std()) > 0.05 and float(m.min()) < 0.2 and float(m.max()) > 0.8      # a non-degenerate mask
 
 
-def _dfsmn_meta(length):
+def _dfsmn_meta(length, in_rate=48000, out_rate=48000, **kw):
     from audio_denoiser_onnx_amd.metadata import build_audio_metadata
     return build_audio_metadata(producer="tests", model_name="DFSMN", task="denoise", model_family="dfsmn", input_audio_length=length,
-                                in_sample_rate=48000, nfft=1920, window_length=1920, hop_length=960, window_type="hamming",
-                                center_pad=False, pad_mode="constant", feature_kind="kaldi_fbank_stft")
+                                in_sample_rate=in_rate, out_sample_rate=out_rate, model_sample_rate=48000, nfft=1920, window_length=1920,
+                                hop_length=960, window_type="hamming", center_pad=False, pad_mode="constant", feature_kind="kaldi_fbank_stft", **kw)
 
 
 def _blob_bytes():
@@ -143,3 +143,33 @@ def test_gpu_dfsmn_file_driver(tensors, tmp_path):
     slices, _ = cut_slices(audio, L, L, "noise", np.random.default_rng(11))
     ref, _ = DfsmnOracle(tensors, L, exact_dft=True).process(slices)
     assert np.abs(got.astype(np.int32) - ref.reshape(-1)[:len(audio)].astype(np.int32)).max() <= 1
+
+
+def test_dfsmn_oracle_fold_and_resampling_match_reference(tensors):
+    """USE_BATCH_FOLD (3 windows of 9600) and the 16 kHz -> 48 kHz -> 24 kHz interpolation edges of the reference against the oracle."""
+    z = np.load(os.path.join(GOLD, "dfsmn_seed0_edges.npz"))
+    W = int(z["fold_window_length"])
+    pcm, _ = DfsmnOracle(tensors, W).process(z["fold_in"].reshape(-1, W))
+    d = pcm.reshape(-1).astype(np.int32) - z["fold_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+    out = DfsmnOracle(tensors, 24000).process_resampled(z["rs_in"], z["rs_out"].shape[0])
+    d = out.astype(np.int32) - z["rs_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+
+
+@pytest.mark.gpu
+def test_gpu_dfsmn_fold_and_resampling_match_reference():
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    z = np.load(os.path.join(GOLD, "dfsmn_seed0_edges.npz"))
+    meta = _dfsmn_meta(int(z["fold_input_audio_length"]), use_batch_fold=True, batch_window_seconds=float(z["fold_batch_window_seconds"]))
+    assert int(meta["fold_window_length"]) == int(z["fold_window_length"]) and int(meta["export_audio_length"]) == z["fold_in"].shape[0]
+    with InferenceSession(weights=_blob_bytes(), metadata=meta) as sess:
+        assert sess.in_len == 28800 and sess.out_len == 28800 and sess.frames == 9
+        out = sess.run(None, {"noisy_audio": np.stack((z["fold_in"], z["fold_in"]))[:, None]})[0][:, 0]
+    d = out[0].astype(np.int32) - z["fold_out"].astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05 and np.array_equal(out[0], out[1])
+    with InferenceSession(weights=_blob_bytes(), metadata=_dfsmn_meta(z["rs_in"].shape[0], int(z["rs_in_rate"]), int(z["rs_out_rate"]))) as sess:
+        assert sess.in_len == 8000 and sess.out_len == 12000 and sess.frames == 24
+        out = sess.run(None, {"noisy_audio": z["rs_in"][None, None]})[0][0, 0]
+    d = out.astype(np.int32) - z["rs_out"].astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05

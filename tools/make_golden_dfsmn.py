@@ -35,7 +35,7 @@ from audio_denoiser_onnx_amd.weights import save_blob  # noqa: E402
 DEPTH, LORDER, HID, NMEL, NBINS = 9, 20, 256, 120, 961
 
 
-def import_dfsmn_namespace(input_audio_length: int) -> dict:
+def import_dfsmn_namespace(input_audio_length: int, overrides: dict = None) -> dict:
     path = os.path.join(REF_ROOT, "DFSMN", "Export_DFSMN.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
@@ -48,6 +48,8 @@ def import_dfsmn_namespace(input_audio_length: int) -> dict:
             if names and all(n.upper() == n for n in names):
                 if names == ["INPUT_AUDIO_LENGTH"]:
                     node = ast.parse(f"INPUT_AUDIO_LENGTH = {int(input_audio_length)}").body[0]
+                elif overrides and len(names) == 1 and names[0] in overrides:
+                    node = ast.parse(f"{names[0]} = {overrides[names[0]]!r}").body[0]
                 keep.append(node)
         elif isinstance(node, ast.If):      # the HOP_LENGTH > INPUT_AUDIO_LENGTH guard
             keep.append(node)
@@ -84,14 +86,15 @@ def fake_dfsmn(seed: int):
                                  linear2=types.SimpleNamespace(linear=lin(HID, NBINS, gain=0.5)), deepfsmn=layers)
 
 
-def build(seed: int, length: int):
-    ns = import_dfsmn_namespace(length)
+def build(seed: int, length: int, overrides: dict = None):
+    ns = import_dfsmn_namespace(length, overrides)
     STFT_Process = import_stft_process("DFSMN").STFT_Process
     stft = STFT_Process("stft_B", ns["NFFT_STFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], 0, ns["WINDOW_TYPE"], False, "constant").eval()
     istft = STFT_Process("istft_B", ns["NFFT_STFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], ns["MAX_SIGNAL_LENGTH"],
                          ns["ISTFT_WINDOW_TYPE"], False, "constant", static_norm=True).eval()
     net = fake_dfsmn(seed)
-    model = ns["DFSMN"](net, stft, istft, ns["NFFT_STFT"], ns["N_MELS"], 48000, 48000).eval()
+    model = ns["DFSMN"](net, stft, istft, ns["NFFT_STFT"], ns["N_MELS"], ns["IN_SAMPLE_RATE"], ns["OUT_SAMPLE_RATE"], ns["USE_BATCH_FOLD"],
+                        ns["FOLD_WINDOW_LENGTH"] if ns["USE_BATCH_FOLD"] else 0, ns["STATIC_MODEL_BATCH"]).eval()
     return ns, model
 
 
@@ -144,6 +147,23 @@ def main():
             out["speech0.mask"] = 1.0 / (1.0 + np.exp(-taps["mask_pre"].reshape(NBINS, -1)))
         print(name, y.shape, int(np.abs(y.numpy()).max()))
     np.savez_compressed(os.path.join(mg.GOLD, "dfsmn_seed0_io.npz"), **out)
+
+    # USE_BATCH_FOLD (:53-57, :194-198, :231-232): BATCH_WINDOW_SECONDS = 0.2 -> W = 9600 (9 frames); INPUT_AUDIO_LENGTH = 20000 -> 3 windows
+    ns, model = build(0, 20000, {"USE_BATCH_FOLD": True, "BATCH_WINDOW_SECONDS": 0.2})
+    assert ns["FOLD_WINDOW_LENGTH"] == 9600 and ns["EXPORT_AUDIO_LENGTH"] == 28800 and ns["STFT_SIGNAL_LENGTH"] == 9
+    pcm = wav[60000:60000 + 28800].copy()
+    with torch.inference_mode():
+        y = model(torch.from_numpy(pcm.reshape(1, 1, -1))).numpy().reshape(-1)
+    # resampling edges (:186-193, :233-240): 16 kHz in -> 48 kHz model (8000 -> 24000 samples, 24 frames) -> 24 kHz out (12000)
+    ns, model = build(0, 8000, {"IN_SAMPLE_RATE": 16000, "OUT_SAMPLE_RATE": 24000})
+    assert ns["MODEL_AUDIO_LENGTH"] == 24000 and ns["OUTPUT_AUDIO_LENGTH"] == 12000
+    pcm2 = np.ascontiguousarray(wav[48000:48000 + 24000:3])
+    with torch.inference_mode():
+        y2 = model(torch.from_numpy(pcm2.reshape(1, 1, -1))).numpy().reshape(-1)
+    np.savez_compressed(os.path.join(mg.GOLD, "dfsmn_seed0_edges.npz"), fold_in=pcm, fold_out=y, fold_input_audio_length=np.int64(20000),
+                        fold_window_length=np.int64(9600), fold_batch_window_seconds=np.float64(0.2), rs_in=pcm2, rs_out=y2, rs_in_rate=np.int64(16000),
+                        rs_out_rate=np.int64(24000))
+    print("fold", y.shape, int(np.abs(y).max()), "resample", y2.shape, int(np.abs(y2).max()))
 
 
 if __name__ == "__main__":
