@@ -101,61 +101,80 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
     }
 }
 
-// time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  One wavefront per clip, lane = hidden unit; the
-// recurrence is a chain of T dependent steps, so the weights live in LDS (one copy per workgroup) instead of being re-fetched per step.
+// time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  The recurrence is a chain of T dependent steps, so
+// everything it touches lives in LDS (weights once per workgroup, the clip's inputs 64 frames at a time) and one step is spread over four
+// wavefronts: wavefront p accumulates a quarter of the C + 2C contraction for every hidden unit (lane = unit), wavefront 0 adds the
+// four partial sums, applies the gates and the output Linear.
 // wih_t [C][3][2C], whh_t [2C][3][2C] (transposed so that lanes read consecutive floats), fc_t [2C][C].
 template <int C>               // compile-time channel count: the k loops unroll and their LDS reads pipeline
-__global__ __launch_bounds__(64) void k_ulu_ta(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
-                                               const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
-                                               const float* __restrict__ fc_b, float* __restrict__ at, int T) {
+__global__ __launch_bounds__(256) void k_ulu_ta(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
+                                                const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
+                                                const float* __restrict__ fc_b, float* __restrict__ at, int T) {
     HIP_DYNAMIC_SHARED(float, lds)
     __shared__ float hs[64];
-    constexpr int H = 2 * C;
-    const int b = blockIdx.x, j = threadIdx.x;
+    __shared__ float part[4][6][64];
+    constexpr int H = 2 * C, KI = (C + 3) / 4, KH = (H + 3) / 4;       // per-wavefront slices of the two contractions
+    const int b = blockIdx.x, tid = threadIdx.x, j = tid & 63, p = tid >> 6;
     float* s_wih = lds;                       // C * 3 * H
     float* s_whh = s_wih + C * 3 * H;         // H * 3 * H
     float* s_fc = s_whh + H * 3 * H;          // H * C
-    for (int i = j; i < C * 3 * H; i += 64) s_wih[i] = wih_t[i];
-    for (int i = j; i < H * 3 * H; i += 64) s_whh[i] = whh_t[i];
-    for (int i = j; i < H * C; i += 64) s_fc[i] = fc_t[i];
+    float* s_z = s_fc + H * C;                // 64 frames of the clip's zt rows
+    for (int i = tid; i < C * 3 * H; i += 256) s_wih[i] = wih_t[i];
+    for (int i = tid; i < H * 3 * H; i += 256) s_whh[i] = whh_t[i];
+    for (int i = tid; i < H * C; i += 256) s_fc[i] = fc_t[i];
     const bool unit = j < H;
     float bi[3] = {0.0f, 0.0f, 0.0f}, bh[3] = {0.0f, 0.0f, 0.0f};
-    if (unit)
+    if (unit && p == 0)
         for (int g = 0; g < 3; ++g) { bi[g] = bih[g * H + j]; bh[g] = bhh[g * H + j]; }
-    const float fb = j < C ? fc_b[j] : 0.0f;
-    float* s_z = s_fc + H * C;                // 64 frames of the clip's zt rows: the recurrence must not wait on HBM every step
+    const float fb = (p == 0 && j < C) ? fc_b[j] : 0.0f;
     float h = 0.0f;
-    hs[j] = 0.0f;
+    if (tid < 64) hs[tid] = 0.0f;
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         if ((t & 63) == 0) {
             __syncthreads();
             const int n = min(64, T - t) * C;
-            for (int i = j; i < n; i += 64) s_z[i] = zt[((size_t)b * T + t) * C + i];
+            for (int i = tid; i < n; i += 256) s_z[i] = zt[((size_t)b * T + t) * C + i];
             __syncthreads();
         }
         const float* z = s_z + (t & 63) * C;
+        float gi[3] = {0.0f, 0.0f, 0.0f}, gh[3] = {0.0f, 0.0f, 0.0f};
         if (unit) {
-            float gi[3] = {bi[0], bi[1], bi[2]}, gh[3] = {bh[0], bh[1], bh[2]};
 #pragma unroll
-            for (int k = 0; k < C; ++k) {
-                const float zk = z[k];
+            for (int kk = 0; kk < KI; ++kk) {
+                const int k = p * KI + kk;
+                if (k < C) {
+                    const float zk = z[k];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gi[g] += s_wih[(k * 3 + g) * H + j] * zk;
+                    for (int g = 0; g < 3; ++g) gi[g] += s_wih[(k * 3 + g) * H + j] * zk;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < H; ++k) {
-                const float hk = hs[k];
+            for (int kk = 0; kk < KH; ++kk) {
+                const int k = p * KH + kk;
+                if (k < H) {
+                    const float hk = hs[k];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) gh[g] += s_whh[(k * 3 + g) * H + j] * hk;
+                    for (int g = 0; g < 3; ++g) gh[g] += s_whh[(k * 3 + g) * H + j] * hk;
+                }
             }
-            const float r = usig(gi[0] + gh[0]), zg = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
-            h = (1.0f - zg) * n + zg * h;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { part[p][g][j] = gi[g]; part[p][3 + g][j] = gh[g]; }
         }
         __syncthreads();
-        if (unit) hs[j] = h;
+        if (p == 0 && unit) {
+            float si[3], sh[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                si[g] = bi[g] + ((part[0][g][j] + part[1][g][j]) + (part[2][g][j] + part[3][g][j]));
+                sh[g] = bh[g] + ((part[0][3 + g][j] + part[1][3 + g][j]) + (part[2][3 + g][j] + part[3][3 + g][j]));
+            }
+            const float r = usig(si[0] + sh[0]), zg = usig(si[1] + sh[1]), n = tanhf(si[2] + r * sh[2]);
+            h = (1.0f - zg) * n + zg * h;
+            hs[j] = h;
+        }
         __syncthreads();
-        if (j < C) {
+        if (p == 0 && j < C) {
             float a = fb;
 #pragma unroll
             for (int k = 0; k < H; ++k) a += s_fc[k * C + j] * hs[k];
@@ -531,7 +550,7 @@ void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const fl
     const long long nfr = (long long)B * T;
     const size_t ta_lds = (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float);
 #define ADE_ULU_TA(CC)                                                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta<CC>), dim3((unsigned)B), dim3(64), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta<CC>), dim3((unsigned)B), dim3(256), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
                        bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t, bk.ctfa.ta_fc_b, at, T)
     switch (C) {               // the channel counts of ULUNAS() (:665); create() rejects anything else
         case 1: ADE_ULU_TA(1); break;
