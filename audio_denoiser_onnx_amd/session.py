@@ -70,9 +70,9 @@ class InferenceSession:
                 raise ValueError("pass either model_path or both weights and metadata")
             reader = MetadataReader(metadata)
         self.metadata = reader
-        self._weights = bytes(weights)
-        st = self._lib.c.ade_create(reader.to_json().encode(), self._weights, len(self._weights), int(device_id),
-                                    C.byref(self._h))
+        blob = bytes(weights)                            # libade parses and uploads it inside ade_create; nothing keeps it afterwards
+        st = self._lib.c.ade_create(reader.to_json().encode(), blob, len(blob), int(device_id), C.byref(self._h))
+        del blob, weights
         self._lib.check(st, None)
         io = _lib.IoDesc()
         self._lib.check(self._lib.c.ade_get_io(self._h, C.byref(io)), self._h)
