@@ -54,6 +54,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
     long long* const clk0 = kClk ? A.clk : nullptr;
     const int chunk = blockIdx.x;
     float* fsm = reinterpret_cast<float*>(smem);
+    // De-phase the workgroups.  Every stage begins and ends with an HBM burst (its inputs / skip tensors in, its output out) and at 256
+    // chunks all 256 workgroups -- one per CU -- would issue the same burst at the same instant: measured, the stages run 28 % slower at
+    // 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one GTConvBlock (27 us) makes
+    // one half's bursts land in the other half's compute phases: -3.5 % per step, the delay included (tools/stagger_probe.py).
+    if (A.stagger > 0 && ((chunk >> 3) & 1)) {
+        const long long t0 = wall_clock64();                 // 100 MHz, independent of the shader clock
+        while (wall_clock64() - t0 < A.stagger) __builtin_amdgcn_s_sleep(8);
+    }
     front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, clk0, A.dc);
     __syncthreads();
     const float* x = A.e1;

@@ -139,6 +139,8 @@ struct ChunkArgs {
     float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3], *d3, *mask;
     long long* clk;          // optional phase clocks
     const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
+    int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late, so that the workgroups do not all hit
+                             // HBM with the same stage's burst at the same instant (ade_set_option "stagger_us")
 };
 void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B);
 

@@ -138,6 +138,7 @@ static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); retur
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __builtin_amdgcn_readlane(int x, int lane) { return (int)::hipsim::wave_exchange((uint32_t)x, lane); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 // v_mfma_f32_16x16x4_f32: D = A(16x4) B(4x16) + C, operand layout as documented in csrc/ade_device.h; k-ordered fmaf chain.
 typedef float hipsim_v4f __attribute__((vector_size(16)));
 static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim_v4f c, int, int, int) {
@@ -159,7 +160,7 @@ static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
 }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values here
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
-static inline long long wall_clock64() { return 0; }
+static inline long long wall_clock64() { static thread_local long long ticks = 0; return ticks += 1000; }   // monotonic, so timed waits end
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }   // fibers never preempt
 static inline void __builtin_amdgcn_wave_barrier() { (void)::hipsim::wave_exchange(0u, ::hipsim::lane_id()); }
 static inline long long clock64() { return 0; }
