@@ -84,17 +84,39 @@ __global__ __launch_bounds__(1024) void k_norm_audio(const int16_t* __restrict__
     }
 }
 
-// mean / rstd of one window's (frames x 512) block, two passes (group_norm_static :398-401); one workgroup per window
-__global__ __launch_bounds__(1024) void k_window_stats(const float* __restrict__ x, long long count, float eps, float2* __restrict__ stats) {
+// mean / rstd of one window's (frames x 512) block (group_norm_static :398-401): kWsSlices workgroups per window each reduce a slice
+// to (count, mean, M2) in two passes; k_window_stats_final merges the slices in a fixed order (Chan's update): deterministic, and a
+// single window still fills 32 CUs instead of one.
+constexpr int kWsSlices = 32;
+// split-K factor of the linear-attention key / value product: FIXED, so that a window's result does not depend on how many other windows
+// share the call (16 output tiles per window x 8 = 128 workgroups for a single window; at 32 windows the partial sums cost ~1 %)
+constexpr int kLkvSplits = 8;
+__global__ __launch_bounds__(1024) void k_window_stats_partial(const float* __restrict__ x, long long count, float4* __restrict__ part) {
     __shared__ float red[16];
+    const long long per = (count + kWsSlices - 1) / kWsSlices, lo = (long long)blockIdx.y * per, hi = lo + per < count ? lo + per : count;
     const float* p = x + (size_t)blockIdx.x * count;
     float s = 0.0f;
-    for (long long i = threadIdx.x; i < count; i += blockDim.x) s += p[i];
-    const float mean = block_sum(s, red) / (float)count;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) s += p[i];
+    const float nn = (float)(hi > lo ? hi - lo : 0);
+    const float mean = block_sum(s, red) / fmaxf(nn, 1.0f);
     float q = 0.0f;
-    for (long long i = threadIdx.x; i < count; i += blockDim.x) { const float d = p[i] - mean; q += d * d; }
-    const float var = block_sum(q, red) / (float)count;
-    if (threadIdx.x == 0) stats[blockIdx.x] = make_float2(mean, 1.0f / sqrtf(var + eps));
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) { const float d = p[i] - mean; q += d * d; }
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * kWsSlices + blockIdx.y] = make_float4(nn, mean, q, 0.0f);
+}
+__global__ __launch_bounds__(64) void k_window_stats_final(const float4* __restrict__ part, float eps, float2* __restrict__ stats, int B) {
+    const int b = (int)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float na = 0.0f, mean = 0.0f, M2 = 0.0f;
+    for (int i = 0; i < kWsSlices; ++i) {
+        const float4 p = part[(size_t)b * kWsSlices + i];
+        if (p.x <= 0.0f) continue;
+        const float nb = p.x, delta = p.y - mean, nn = na + nb;
+        mean += delta * (nb / nn);
+        M2 += p.z + delta * delta * (na * nb / nn);
+        na = nn;
+    }
+    stats[b] = make_float2(mean, 1.0f / sqrtf(M2 / fmaxf(na, 1.0f) + eps));
 }
 
 // ---- operand / store functors ------------------------------------------------------------------------------------------------
@@ -258,13 +280,14 @@ struct VuLkvB {                // B(k, n) = k < g ? value row k of the group (ze
         return k < valid ? rows[(size_t)k * ld + n] : 0.0f;
     }
 };
-struct LinKvProb {             // z = window: LKV_z (128 x 2048) = lin_k^T x value rows   (:490-492; padded keys are zero rows, so K = frames)
-    const float *lk, *vu;
-    float* lkv;
-    int n, padded;
+struct LinKvProb {             // z = (window, split): partial LKV (128 x 2048) = lin_k^T x value rows over the split's frames   (:490-492; padded keys are
+    const float *lk, *vu;      // zero rows, so K = frames).  A single window has only 16 output tiles: splitting its long contraction over
+    float* lkv;                // `splits` workgroups per tile keeps the chip busy; k_lkv_reduce adds the partial sums in split order.
+    int n, padded, splits;
     __device__ Prob<ColMajorA, gemm::RowMajorB, GuardedStore> operator()(int z) const {
-        return {ColMajorA{lk + (size_t)z * padded * kQk, kQk}, gemm::RowMajorB{vu + (size_t)z * n * kIn, kIn},
-                GuardedStore{lkv + (size_t)z * kQk * kVu2, kVu2, kQk, 0}, kQk, kVu2, n};
+        const int b = z / splits, sp = z - b * splits, per = ((n + splits - 1) / splits + 15) & ~15, k0 = sp * per, kn = max(0, min(per, n - k0));
+        return {ColMajorA{lk + ((size_t)b * padded + k0) * kQk, kQk}, gemm::RowMajorB{vu + ((size_t)b * n + k0) * kIn, kIn},
+                GuardedStore{lkv + (size_t)z * kQk * kVu2, kVu2, kQk, 0}, kQk, kVu2, kn};
     }
 };
 struct AttOutProb {            // z = (window, group): AO rows of the group = ATT_z x value rows + lin_q x LKV_window   (:488, :495-497), K = g + 128
@@ -278,6 +301,16 @@ struct AttOutProb {            // z = (window, group): AO rows of the group = AT
                 VuLkvB{vu + row0 * kIn, lkv + (size_t)b * kQk * kVu2, kIn, valid, g}, GuardedStore{ao + row0 * kVu2, kVu2, valid, 0}, g, kVu2, g + kQk};
     }
 };
+
+// LKV[b] = sum over splits of the partial products, in split order (deterministic)
+__global__ __launch_bounds__(256) void k_lkv_reduce(const float* __restrict__ part, float* __restrict__ lkv, int splits, long long per_window, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / per_window, e = i - b * per_window;
+    float s = 0.0f;
+    for (int sp = 0; sp < splits; ++sp) s += part[((size_t)b * splits + sp) * per_window + e];
+    lkv[i] = s;
+}
 
 // ---- row-wise and time-wise kernels ------------------------------------------------------------------------------------------
 // inv[m] = 1 / max(|token-shifted row m|, eps)   (:457)
@@ -370,13 +403,19 @@ __global__ __launch_bounds__(256) void k_chan_finalize(const float4* __restrict_
     if (i >= total) return;
     const int b = i / C, c = i - b * C;
     float na = 0.0f, mean = 0.0f, M2 = 0.0f;
-    for (int t = 0; t < tiles; ++t) {
-        const float4 p = partial[((size_t)b * tiles + t) * C + c];
-        if (p.x <= 0.0f) continue;
-        const float nb = p.x, delta = p.y - mean, nn = na + nb;
-        mean += delta * (nb / nn);
-        M2 += p.z + delta * delta * (na * nb / nn);
-        na = nn;
+    for (int t0 = 0; t0 < tiles; t0 += 8) {                  // the 8 loads of a group are independent: one memory latency per group, not per tile
+        float4 p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p8[u] = t0 + u < tiles ? partial[((size_t)b * tiles + t0 + u) * C + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 p = p8[u];
+            if (p.x <= 0.0f) continue;
+            const float nb = p.x, delta = p.y - mean, nn = na + nb;
+            mean += delta * (nb / nn);
+            M2 += p.z + delta * delta * (na * nb / nn);
+            na = nn;
+        }
     }
     stats[i] = make_float2(mean, 1.0f / sqrtf(M2 / fmaxf(na, 1.0f) + eps));
 }
@@ -572,6 +611,9 @@ struct MossformerEngine : SubEngine {
     float* ws = nullptr;
     float2 *gains = nullptr, *wstats = nullptr, *cstats = nullptr;
     float4* partial = nullptr;     // per (window, time tile, channel) partial statistics of the memory convolutions
+    float4* wpart = nullptr;       // per (window, slice) partial statistics of the two window norms
+    float* lkv_part = nullptr;     // split-K partial sums of the linear-attention key / value product
+    int lkv_splits = 1;
     float *rms_in = nullptr, *XE = nullptr, *MI = nullptr, *H = nullptr, *inv = nullptr, *P = nullptr, *P2 = nullptr, *heads = nullptr, *ATT = nullptr, *AO = nullptr,
           *LKV = nullptr, *G = nullptr, *Y = nullptr, *C1 = nullptr, *GF = nullptr, *XN = nullptr, *UV = nullptr, *UV2 = nullptr, *F1 = nullptr, *XP = nullptr,
           *M0 = nullptr, *M1 = nullptr, *N2 = nullptr, *HL = nullptr, *MO = nullptr, *GP = nullptr, *SEP = nullptr, *FR = nullptr, *WAV = nullptr;
@@ -696,8 +738,8 @@ int MossformerEngine::reserve(int batch, std::string& err) {
     capacity = 0;
     const size_t B = (size_t)batch * n_win, R = B * n, RP = B * padded, g = (size_t)hyper[hGroup];
     struct Carve { float** p; size_t count; };
-    float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr, *f_partial = nullptr;
-    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&f_partial, 4 * B * (size_t)((n + 31) / 32) * kInner}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
+    float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr, *f_partial = nullptr, *f_wpart = nullptr;
+    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&f_partial, 4 * B * (size_t)((n + 31) / 32) * kInner}, {&f_wpart, 4 * B * kWsSlices}, {&lkv_part, (size_t)kLkvSplits * B * kQk * kVu2}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
                              {&inv, R}, {&P, R * kIn}, {&P2, R * kIn}, {&heads, 4 * RP * kQk}, {&ATT, B * groups * g * g}, {&AO, R * kVu2},
                              {&LKV, B * kQk * kVu2}, {&G, R * kVu}, {&Y, R * kDim}, {&C1, R * kInner}, {&GF, R * kInner}, {&XN, R * kInner}, {&UV, R * kDim},
                              {&UV2, R * kDim}, {&F1, R * kInner}, {&XP, R * kInner}, {&M0, R * kInner}, {&M1, R * kInner}, {&N2, R * kInner}, {&HL, R * kDim},
@@ -711,6 +753,7 @@ int MossformerEngine::reserve(int batch, std::string& err) {
     wstats = reinterpret_cast<float2*>(f_wstats);
     cstats = reinterpret_cast<float2*>(f_cstats);
     partial = reinterpret_cast<float4*>(f_partial);
+    wpart = reinterpret_cast<float4*>(f_wpart);
     capacity = batch;
     return ADE_OK;
 }
@@ -722,8 +765,13 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     using namespace gemm;
     const int B = batch * n_win, R = B * n, g = (int)hyper[hGroup], rot = (int)hyper[hRotDim], depth = (int)hyper[hMemDepth], lorder = (int)hyper[hLorder];
     const long long head_stride = (long long)B * padded * kQk;
+    lkv_splits = kLkvSplits;
     auto rows4 = [&](int rows) { return dim3((unsigned)((rows + 3) / 4)); };
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+    auto window_stats = [&](hipStream_t st_, const float* x, float eps) {
+        hipLaunchKernelGGL(k_window_stats_partial, dim3((unsigned)B, kWsSlices), dim3(1024), 0, st_, x, (long long)n * kDim, wpart);
+        hipLaunchKernelGGL(k_window_stats_final, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st_, (const float4*)wpart, eps, wstats, B);
+    };
     auto dwconv = [&](hipStream_t st_, const float* x, const float* w, const float* res, float* y, int C, int nb) {   // y = res + x + depthwise_17(x)
         constexpr int kTT = 64;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kDw, 1, kTT, true>), dim3((unsigned)((n + kTT - 1) / kTT), (unsigned)(C / 64), (unsigned)nb), dim3(256),
@@ -733,7 +781,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     // front end: RMS stages, encoder, window norm folded into the 1x1 conv, positions                         (:571-591)
     hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, float_in, W, hyper[hNormFactor], gains, rms_in);
     launch(s, EncFrameA{d_in, float_in, gains, W, n}, WeightNK{encoder_w, kEncK}, BiasActRowStore<1>{XE, nullptr, kDim, 0.0f}, R, kDim, kEncK);
-    hipLaunchKernelGGL(k_window_stats, dim3((unsigned)B), dim3(1024), 0, s, (const float*)XE, (long long)n * kDim, hyper[hFrontEps], wstats);
+    window_stats(s, XE, hyper[hFrontEps]);
     launch(s, RowMajorA{XE, kDim}, WeightNK{front_w, kDim}, FrontStore{H, MI, wstats, front_wsum, front_b, emb_pos, n}, R, kDim, kDim);
 
     for (int i = 0; i < layers; ++i) {
@@ -746,7 +794,12 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
                            padded, rot, head_stride);
         const float *quad_q = heads, *lin_q = heads + head_stride, *quad_k = heads + 2 * head_stride, *lin_k = heads + 3 * head_stride;
         launch_batched(s, QuadScoreProb{quad_q, quad_k, ATT, g}, B * groups, g, g);
-        launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded}, B, kQk, kVu2);
+        if (lkv_splits == 1) launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded, 1}, B, kQk, kVu2);
+        else {
+            launch_batched(s, LinKvProb{lin_k, P2, lkv_part, n, padded, lkv_splits}, B * lkv_splits, kQk, kVu2);
+            hipLaunchKernelGGL(k_lkv_reduce, flat((long long)B * kQk * kVu2), dim3(256), 0, s, (const float*)lkv_part, LKV, lkv_splits, (long long)kQk * kVu2,
+                               (long long)B * kQk * kVu2);
+        }
         launch_batched(s, AttOutProb{ATT, P2, lin_q, LKV, AO, g, groups, n, padded}, B * groups, g, kVu2);
         hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
         launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu);
@@ -785,7 +838,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     }
     // final norms + skip (:544-551)
     hipLaunchKernelGGL(k_ln512, rows4(R), dim3(256), 0, s, (const float*)H, mm_w, mm_b, HL, R, hyper[hMmEps]);
-    hipLaunchKernelGGL(k_window_stats, dim3((unsigned)B), dim3(1024), 0, s, (const float*)HL, (long long)n * kDim, hyper[hIntraEps], wstats);
+    window_stats(s, HL, hyper[hIntraEps]);
     hipLaunchKernelGGL(k_window_affine_skip, flat((long long)R * kDim), dim3(256), 0, s, (const float*)HL, (const float2*)wstats, intra_w, intra_b,
                        (const float*)MI, MO, n, (long long)R * kDim);
     // speaker tail, decoder, RMS restore (:599-645)
