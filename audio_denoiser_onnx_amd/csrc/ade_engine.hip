@@ -5,6 +5,7 @@
 // `capacity` independent chunks (~2.6 MB of fp32 activations per 1 s chunk; 288 GB of HBM3E holds >100k chunks).
 // There is no CPU execution mode: without a HIP device ade_create fails with ADE_ERR_DEVICE.
 #include "ade_internal.h"
+#include "ade_gtcrn_pack.h"
 
 #include "../../include/ade.h"
 
@@ -50,7 +51,7 @@ struct ade_engine {
     std::map<std::string, Tensor> tensors;
 
     ade::SubEngine* sub = nullptr;        // model_family "dfsmn" / "mel_band_roformer": a sub-engine (everything below is GTCRN's)
-    int channels = 1, n_outputs = 1;      // in_len / out_len below count one batch item: channels * samples in, n_outputs * channels * samples out
+    int channels = 1, out_channels = 1, n_outputs = 1;   // in_len / out_len below count one batch item: channels * samples in, n_outputs * out_channels * samples out
     // driver-edge resampling around a sub-engine (in / out sample rate != model rate): caller-side lengths above, model-side below
     bool resample = false;
     int rs_model_in = 0, rs_model_out = 0;     // per channel row, at the model rate
@@ -248,16 +249,6 @@ ade_status parse_blob(ade_engine* e, const void* blob, size_t nbytes) {
     return ADE_OK;
 }
 
-// ---- weight arena builder: canonical kernel layouts, every tensor 64-byte aligned ------------------------
-struct Arena {
-    std::vector<float> f;
-    size_t alloc(size_t n) {
-        size_t off = (f.size() + 15) & ~(size_t)15;
-        f.resize(off + n, 0.0f);
-        return off;
-    }
-};
-
 struct Loader {
     ade_engine* e;
     ade_status st = ADE_OK;
@@ -276,130 +267,7 @@ struct Loader {
     }
 };
 
-// PyTorch GRU rows of hidden unit j -> [3x8 ih | 3xH hh | 3 b_ih | 3 b_hh]
-void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* bih, const float* bhh, int H, int j) {
-    for (int g = 0; g < 3; ++g)
-        for (int k = 0; k < 8; ++k) dst[g * 8 + k] = wih[(g * H + j) * 8 + k];
-    for (int g = 0; g < 3; ++g)
-        for (int k = 0; k < H; ++k) dst[24 + g * H + k] = whh[(g * H + j) * H + k];
-    for (int g = 0; g < 3; ++g) {
-        dst[24 + 3 * H + g] = bih[g * H + j];
-        dst[24 + 3 * H + 3 + g] = bhh[g * H + j];
-    }
-}
-
 constexpr int kClkSlots = 64 * 10;
-
-struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc; float s1, s2; };
-struct DpOff { size_t intra_gru, inter_gru, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
-
-bool load_gt(Loader& L, Arena& A, const std::string& p, bool deconv, GtOff& o) {
-    const float* pw1 = deconv ? L.get(p + "point_conv1.weight", {24, 16, 1, 1}) : L.get(p + "point_conv1.weight", {16, 24, 1, 1});
-    const float* pw1b = L.get(p + "point_conv1.bias", {16});
-    const float* a1 = L.get(p + "point_act.weight", {1});
-    const float* dw = L.get(p + "depth_conv.weight", {16, 1, 3, 3});
-    const float* dwb = L.get(p + "depth_conv.bias", {16});
-    const float* a2 = L.get(p + "depth_act.weight", {1});
-    const float* pw2 = deconv ? L.get(p + "point_conv2.weight", {16, 8, 1, 1}) : L.get(p + "point_conv2.weight", {8, 16, 1, 1});
-    const float* pw2b = L.get(p + "point_conv2.bias", {8});
-    const float* wih = L.get(p + "tra.att_gru.weight_ih_l0", {48, 8});
-    const float* whh = L.get(p + "tra.att_gru.weight_hh_l0", {48, 16});
-    const float* bih = L.get(p + "tra.att_gru.bias_ih_l0", {48});
-    const float* bhh = L.get(p + "tra.att_gru.bias_hh_l0", {48});
-    const float* fcw = L.get(p + "tra.att_fc.weight", {8, 16});
-    const float* fcb = L.get(p + "tra.att_fc.bias", {8});
-    if (L.st != ADE_OK) return false;
-    o.pw1 = A.alloc(24 * 16);
-    for (int ci = 0; ci < 24; ++ci)
-        for (int co = 0; co < 16; ++co) A.f[o.pw1 + ci * 16 + co] = deconv ? pw1[ci * 16 + co] : pw1[co * 24 + ci];
-    o.pw1_b = A.alloc(16);
-    memcpy(&A.f[o.pw1_b], pw1b, 64);
-    o.dw = A.alloc(9 * 16);
-    for (int c = 0; c < 16; ++c)
-        for (int kt = 0; kt < 3; ++kt)
-            for (int kf = 0; kf < 3; ++kf) {
-                // decoder ConvTranspose2d taps y[t,f] += W[kt][kf] h[t-kt*d, f+1-kf] == encoder-form taps flipped in kt and kf
-                const int ekt = deconv ? 2 - kt : kt, ekf = deconv ? 2 - kf : kf;
-                A.f[o.dw + (ekt * 3 + ekf) * 16 + c] = dw[c * 9 + kt * 3 + kf];
-            }
-    o.dw_b = A.alloc(16);
-    memcpy(&A.f[o.dw_b], dwb, 64);
-    o.pw2 = A.alloc(16 * 8);
-    for (int ci = 0; ci < 16; ++ci)
-        for (int co = 0; co < 8; ++co) A.f[o.pw2 + ci * 8 + co] = deconv ? pw2[ci * 8 + co] : pw2[co * 16 + ci];
-    o.pw2_b = A.alloc(8);
-    memcpy(&A.f[o.pw2_b], pw2b, 32);
-    o.gru = A.alloc(16 * 78);
-    for (int j = 0; j < 16; ++j) pack_gru_lane(&A.f[o.gru + j * 78], wih, whh, bih, bhh, 16, j);
-    o.fc = A.alloc(8 * 17);
-    for (int c = 0; c < 8; ++c) {
-        for (int k = 0; k < 16; ++k) A.f[o.fc + c * 17 + k] = fcw[c * 16 + k];
-        A.f[o.fc + c * 17 + 16] = fcb[c];
-    }
-    o.s1 = a1[0];
-    o.s2 = a2[0];
-    return true;
-}
-
-bool load_dp(Loader& L, Arena& A, const std::string& p, DpOff& o) {
-    o.intra_gru = A.alloc(16 * 42);
-    o.inter_gru = A.alloc(16 * 54);
-    for (int grp = 0; grp < 2; ++grp) {
-        const std::string r = p + "intra_rnn.rnn" + std::to_string(grp + 1) + ".";
-        for (int dir = 0; dir < 2; ++dir) {
-            const std::string sfx = dir ? "_reverse" : "";
-            const float* wih = L.get(r + "weight_ih_l0" + sfx, {12, 8});
-            const float* whh = L.get(r + "weight_hh_l0" + sfx, {12, 4});
-            const float* bih = L.get(r + "bias_ih_l0" + sfx, {12});
-            const float* bhh = L.get(r + "bias_hh_l0" + sfx, {12});
-            if (L.st != ADE_OK) return false;
-            for (int j = 0; j < 4; ++j) pack_gru_lane(&A.f[o.intra_gru + (grp * 8 + dir * 4 + j) * 42], wih, whh, bih, bhh, 4, j);
-        }
-        const std::string q = p + "inter_rnn.rnn" + std::to_string(grp + 1) + ".";
-        const float* wih = L.get(q + "weight_ih_l0", {24, 8});
-        const float* whh = L.get(q + "weight_hh_l0", {24, 8});
-        const float* bih = L.get(q + "bias_ih_l0", {24});
-        const float* bhh = L.get(q + "bias_hh_l0", {24});
-        if (L.st != ADE_OK) return false;
-        for (int j = 0; j < 8; ++j) pack_gru_lane(&A.f[o.inter_gru + (grp * 8 + j) * 54], wih, whh, bih, bhh, 8, j);
-    }
-    const char* part[2] = {"intra", "inter"};
-    for (int i = 0; i < 2; ++i) {
-        const float* fw = L.get(p + part[i] + "_fc.weight", {16, 16});
-        const float* fb = L.get(p + part[i] + "_fc.bias", {16});
-        const float* lw = L.get(p + part[i] + "_ln.weight", {kFw, 16});
-        const float* lb = L.get(p + part[i] + "_ln.bias", {kFw, 16});
-        if (L.st != ADE_OK) return false;
-        o.fc[i] = A.alloc(256);
-        for (int k = 0; k < 16; ++k)
-            for (int co = 0; co < 16; ++co) A.f[o.fc[i] + k * 16 + co] = fw[co * 16 + k];
-        o.fc_b[i] = A.alloc(16);
-        memcpy(&A.f[o.fc_b[i]], fb, 64);
-        o.ln_w[i] = A.alloc(kFw * 16);
-        memcpy(&A.f[o.ln_w[i]], lw, kFw * 64);
-        o.ln_b[i] = A.alloc(kFw * 16);
-        memcpy(&A.f[o.ln_b[i]], lb, kFw * 64);
-    }
-    return true;
-}
-
-// banded form of a dense (n_in x n_out) row-major matrix: per output column the run [first nz, last nz]
-void band_table(const float* m, int n_in, int n_out, std::vector<int>& start, std::vector<float>& w, int& count) {
-    start.assign(n_out, 0);
-    std::vector<int> len(n_out, 0);
-    count = 0;
-    for (int o = 0; o < n_out; ++o) {
-        int lo = -1, hi = -1;
-        for (int i = 0; i < n_in; ++i)
-            if (m[(size_t)i * n_out + o] != 0.0f) { if (lo < 0) lo = i; hi = i; }
-        if (lo >= 0) { start[o] = lo; len[o] = hi - lo + 1; }
-        if (len[o] > count) count = len[o];
-    }
-    if (count == 0) count = 1;
-    w.assign((size_t)count * n_out, 0.0f);
-    for (int o = 0; o < n_out; ++o)
-        for (int n = 0; n < len[o]; ++n) w[(size_t)n * n_out + o] = m[(size_t)(start[o] + n) * n_out + o];
-}
 
 ade_status build_device_constants(ade_engine* e) {
     Loader L{e};
@@ -565,7 +433,7 @@ ade_status reserve(ade_engine* e, int batch) {
         HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
         if (e->resample) {
             HIP_TRY(e, hipMalloc((void**)&e->rs_in, B * e->channels * e->rs_model_in * sizeof(float)));
-            HIP_TRY(e, hipMalloc((void**)&e->rs_out, B * e->channels * e->n_outputs * e->rs_model_out * sizeof(float)));
+            HIP_TRY(e, hipMalloc((void**)&e->rs_out, B * e->out_channels * e->n_outputs * e->rs_model_out * sizeof(float)));
         }
         e->capacity = batch;
         return ADE_OK;
@@ -723,12 +591,12 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     // the launch sequence of one call: a sub-engine's (hundreds of GEMM / row kernels) or GTCRN's
     auto launch_all = [&](bool timed) {
         if (e->sub && e->resample) {   // interpolate to the model rate, run on floats, interpolate the float waveform back and apply the PCM tail
-            const long long rows_in = (long long)B * e->channels, rows_out = (long long)B * e->channels * e->n_outputs;
+            const long long rows_in = (long long)B * e->channels, rows_out = (long long)B * e->out_channels * e->n_outputs;
             launch_resample_in(s, d_in, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in);
             e->sub->float_in = e->rs_in;
             sub_rc = e->sub->run(s, d_in, B, nullptr, e->rs_out, sub_err);
             e->sub->float_in = nullptr;
-            launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->channels * e->n_outputs), e->rs_scale_out,
+            launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out,
                                 e->rs_pcm_scale, e->rs_truncate_i32);
         } else if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
         else enqueue(e, s, d_in, B, d_out, d_f32, timed);
@@ -890,8 +758,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             return bail(fail(e, ADE_ERR_MISSING_KEY, std::string("Required metadata key ") + k + " is missing."));
     }
     const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer",
-               fam_moss = e->meta["model_family"] == "mossformer2_ss", fam_ulu = e->meta["model_family"] == "ul_unas";
-    if (fam_dfsmn || fam_melband || fam_moss || fam_ulu) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
+               fam_moss = e->meta["model_family"] == "mossformer2_ss", fam_ulu = e->meta["model_family"] == "ul_unas",
+               fam_hg = e->meta["model_family"] == "h_gtcrn";
+    if (fam_dfsmn || fam_melband || fam_moss || fam_ulu || fam_hg) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
         const std::string fam = e->meta["model_family"];
         const long rate = fam_dfsmn ? 48000 : fam_melband ? 44100 : 16000;
         bool dyn_d = false, fold_d = false;
@@ -914,6 +783,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // Resampling edges exist where the reference's STATIC export is self-consistent: MossFormer2 and DFSMN size their frames from the
         // model-rate length (Export_MossFormer2_SS_16K.py:36-37,99-104; Export_DFSMN.py:48,67).  Mel-Band-Roformer (like GTCRN) and UL-UNAS size
         // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
+        // H-GTCRN's static export is consistent too, but it centres between the two interpolation orders (:953-970): not built, rejected here.
         if (rates_differ && !fam_moss && !fam_dfsmn)
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
@@ -958,13 +828,15 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
+                       : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
+        e->out_channels = e->sub->out_channels();
         e->n_outputs = e->sub->n_outputs();
         e->in_len = e->sub->in_len() * e->channels;
         e->T = e->sub->frames();
-        e->out_len = e->sub->out_len() * e->channels * e->n_outputs;
+        e->out_len = e->sub->out_len() * e->out_channels * e->n_outputs;
         if (rates_differ) {   // F.interpolate(size = ...) on both edges (:562-571, :625-640): source scale = source length / target length
             const long out_caller = (long)llround((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
             e->resample = true;
@@ -975,7 +847,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             e->rs_pcm_scale = fam_dfsmn ? 32768.0f : 1.0f;   // DFSMN: * 32768 after the interpolation (Export_DFSMN.py:241-243); MossFormer2's waveform
             e->rs_truncate_i32 = !fam_dfsmn;                 // is already in PCM units and goes through .to(int32).clamp().to(int16) (:645)
             e->in_len = (int)caller_len * e->channels;
-            e->out_len = (int)out_caller * e->channels * e->n_outputs;
+            e->out_len = (int)out_caller * e->out_channels * e->n_outputs;
         }
         e->sample_rate = (int)rate;
         e->in_rate = (int)sri;
@@ -987,7 +859,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return ADE_OK;
     }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, dfsmn, mel_band_roformer, mossformer2_ss, ul_unas)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, h_gtcrn, dfsmn, mel_band_roformer, mossformer2_ss, ul_unas)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
@@ -1074,10 +946,10 @@ ade_status ade_get_io(ade_handle h, ade_io_desc* d) {
     if (!h || !d) return ADE_ERR_BAD_VALUE;
     d->abi_version = ADE_ABI_VERSION;
     d->in_channels = h->channels;
-    d->out_channels = h->channels;
+    d->out_channels = h->out_channels;
     d->n_outputs = h->n_outputs;
     d->in_len = h->in_len / h->channels * h->n_win;       // per channel; what one call sees (the fold is internal)
-    d->out_len = h->out_len / (h->channels * h->n_outputs) * h->n_win;
+    d->out_len = h->out_len / (h->out_channels * h->n_outputs) * h->n_win;
     d->model_sample_rate = h->sample_rate;
     d->in_sample_rate = h->in_rate ? h->in_rate : h->sample_rate;
     d->out_sample_rate = h->out_rate ? h->out_rate : h->sample_rate;

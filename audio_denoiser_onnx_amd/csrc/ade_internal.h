@@ -160,11 +160,12 @@ struct SubEngine {
     virtual int in_len() const = 0;      // samples per channel row
     virtual int out_len() const = 0;
     virtual int channels() const { return 1; }
+    virtual int out_channels() const { return channels(); }   // H-GTCRN: two microphones in, one channel out
     // Resampled input (in_sample_rate != model_sample_rate): when set, run() reads its PCM from here -- floats in int16 units, same
     // [batch][channels()][in_len()] layout -- instead of d_in (the reference interpolates `audio.float()` before anything else).
     const float* float_in = nullptr;
     virtual bool accepts_float_input() const { return false; }
-    virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][channels()][out_len()]
+    virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][out_channels()][out_len()]
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status
     virtual int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) = 0;
     virtual int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) = 0;
@@ -176,6 +177,8 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int window_len, i
 int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "ul_unas" (UL-UNAS/Export_UL_UNAS.py:51-913), csrc/ade_ulunas.hip
 int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
+// model_family "h_gtcrn" (H-GTCRN/Export_H_GTCRN.py:428-1063), csrc/ade_hgtcrn.hip
+int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

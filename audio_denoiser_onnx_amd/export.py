@@ -137,6 +137,17 @@ def export_ulunas(checkpoint, out_dir, input_audio_length: int = 16000, name: st
     return model_path
 
 
+def export_hgtcrn(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = False, name: str = "H_GTCRN") -> Path:
+    """H-GTCRN checkpoint (``ckpt['model']`` of GTCRN_IVA) -> ``<name>.adew`` + manifest (Export_H_GTCRN.py:1119-1186 minus ONNX)."""
+    from . import hgtcrn
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    save_blob(model_path, hgtcrn.fold_state_dict(load_state_dict(checkpoint)))
+    write_metadata(model_path, hgtcrn.metadata(input_audio_length, use_batch_fold))
+    return model_path
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     length, family, fold = None, "gtcrn", False
@@ -151,7 +162,7 @@ def main(argv=None) -> int:
     if "--fold" in argv:
         argv.remove("--fold")
         fold = True
-    if len(argv) != 2 or family not in ("gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas"):
+    if len(argv) != 2 or family not in ("gtcrn", "h_gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas"):
         print(__doc__)
         return 2
     if family == "mel_band_roformer":
@@ -160,6 +171,8 @@ def main(argv=None) -> int:
         path = export_mossformer(argv[0], argv[1], length or 24000, fold)
     elif family == "ul_unas":
         path = export_ulunas(argv[0], argv[1], length or 16000)
+    elif family == "h_gtcrn":
+        path = export_hgtcrn(argv[0], argv[1], length or 32000, fold)
     else:
         path = export_gtcrn(argv[0], argv[1], length or 16000)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")

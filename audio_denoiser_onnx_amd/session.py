@@ -77,6 +77,7 @@ class InferenceSession:
         io = _lib.IoDesc()
         self._lib.check(self._lib.c.ade_get_io(self._h, C.byref(io)), self._h)
         self.in_len, self.out_len, self.frames = io.in_len, io.out_len, io.frames
+        self.out_channels = io.out_channels
         self.channels = io.in_channels                    # 1 (GTCRN, DFSMN) or 2 (Mel-Band-Roformer stereo)
         self.n_outputs = io.n_outputs                     # 1, or 2 for MossFormer2-SS ("separated_0", "separated_1")
         self.row_in, self.row_out = io.in_channels * io.in_len, io.n_outputs * io.out_channels * io.out_len   # one batch item, planar
@@ -112,10 +113,10 @@ class InferenceSession:
         if x.ndim != 3 or x.shape[1] != self.channels or x.shape[2] != self.in_len:
             raise ValueError(f"{INPUT_NAME} must have shape (B, {self.channels}, {self.in_len}), got {x.shape}")
         pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32)
-        pcm = pcm.reshape(-1, self.n_outputs, self.channels, self.out_len)
+        pcm = pcm.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
         out = [np.ascontiguousarray(pcm[:, i]) for i in range(self.n_outputs)]               # one array per graph output
         if return_f32:
-            f32 = f32.reshape(-1, self.n_outputs, self.channels, self.out_len)
+            f32 = f32.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
             out += [np.ascontiguousarray(f32[:, i]) for i in range(self.n_outputs)]
         return out
 

@@ -1,0 +1,173 @@
+"""H-GTCRN: oracle + checkpoint fold pinned to the reference (CPU) and HIP parity through the C ABI (GPU).
+
+Fixtures: tests/golden/hgtcrn_seed0.npz / _fold.npz = the reference's own modules (seeded GTCRN_IVA -> fuse_bn_ -> H_GTCRN_CUSTOM forward
+with OnnxFriendlyWPE / OnnxFriendlyAuxIVA and its STFT_Process) run in the build container (tools/make_golden_hgtcrn.py): the
+checkpoint-format state_dict, four stereo rows (the reference's example, two synthetic rooms, silence), their outputs, the WPE output of
+every row and the later taps of row 1.
+
+THE PARITY CONTRACT HAS TWO PARTS, because the reference's fp32 WPE solve (six conjugate-gradient steps on a 36 x 36 system built from a
+few dozen frames) is ill-conditioned for some bins: the reference's OWN fp32 and fp64 runs differ there by O(1), so no independent
+implementation -- the oracle, the HIP path, ONNX Runtime -- can reproduce those bins, and they move the output by hundreds of LSB.
+  (1) WPE stage: on the bins where the oracle's fp32 and fp64 solves agree (the well-conditioned ones, 80-90 % of them) the result must
+      match the reference's tap; on the others it must be finite and no further from the fp64 solve than the fp32 oracle is (x 30).
+  (2) everything after WPE (AuxIVA, features, network, mask, ISTFT, PCM) is pinned to <= 1-3 LSB by continuing from a GIVEN WPE output:
+      the oracle from the reference's tap against the reference's PCM, the HIP path's PCM against the oracle continued from the HIP
+      path's own WPE tap.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+from audio_denoiser_onnx_amd import hgtcrn  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "hgtcrn_seed0.npz")
+GOLD_FOLD = os.path.join(HERE, "golden", "hgtcrn_seed0_fold.npz")
+L = 16384
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    z = np.load(GOLD)
+    state = {str(k): z["w:" + str(k)] for k in z["keys"]}
+    return z, hgtcrn.fold_state_dict(state)
+
+
+def _oracle(fused, window=L, n_win=1, exact_dft=False):
+    from hgtcrn_oracle import HgtcrnOracle
+    return HgtcrnOracle(fused, window, n_win, exact_dft)
+
+
+def _wpe_contract(got_r, got_i, stft_r, stft_i, ref=None):
+    """got / stft: (B, 2, F, T).  Returns (#well-conditioned bins, worst error on them)."""
+    import hgtcrn_oracle as ho
+    re, im = np.ascontiguousarray(stft_r.transpose(0, 2, 1, 3)), np.ascontiguousarray(stft_i.transpose(0, 2, 1, 3))
+    with np.errstate(all="ignore"):
+        a32 = ho.wpe(re, im)
+        a64 = ho.wpe(re, im, np.float64)
+    worst, n_stable = 0.0, 0
+    for b in range(re.shape[0]):
+        if not np.isfinite(a64[0][b]).all():
+            continue                                                      # the silent row: 0 / 0 everywhere in every implementation
+        spread = np.maximum(np.abs(a32[0][b] - a64[0][b]), np.abs(a32[1][b] - a64[1][b])).max(axis=(1, 2))          # per bin
+        stable = spread < 1e-4
+        target = (a32[0][b], a32[1][b]) if ref is None else (ref[0][b].transpose(1, 0, 2), ref[1][b].transpose(1, 0, 2))
+        err = np.maximum(np.abs(got_r[b].transpose(1, 0, 2) - target[0]), np.abs(got_i[b].transpose(1, 0, 2) - target[1])).max(axis=(1, 2))
+        err64 = np.maximum(np.abs(got_r[b].transpose(1, 0, 2) - a64[0][b]), np.abs(got_i[b].transpose(1, 0, 2) - a64[1][b])).max(axis=(1, 2))
+        assert stable.sum() >= 120, stable.sum()
+        assert np.isfinite(err64).all()
+        assert np.all(err64[~stable] <= 30.0 * spread[~stable] + 1e-3), float((err64[~stable] / (spread[~stable] + 1e-9)).max())
+        worst, n_stable = max(worst, float(err[stable].max())), n_stable + int(stable.sum())
+    return n_stable, worst
+
+
+def test_fold_and_oracle_match_reference(fixture):
+    z, fused = fixture
+    o = _oracle(fused)
+    out = o.process(z["pcm_in"], inject_wpe=(z["wpe_r"], z["wpe_i"]))           # part (2): downstream of the reference's WPE output
+    for name in ("iva_r", "iva_i", "s_r", "s_i"):
+        assert np.abs(o.taps[name][1] - z["tap_" + name]).max() < 3e-4, name
+    assert np.abs(o.taps["features"][1] - z["tap_features"]).max() < 3e-4
+    d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
+    assert np.abs(d[1:]).max() <= 1 and (d[1:] != 0).mean() < 0.01
+    assert np.abs(d[0]).max() <= 4                                              # the example recording has one AuxIVA bin at the edge of fp32 too
+    assert not out[3].any() and not z["pcm_out"][3].any()                       # silence: NaN -> 0 (:1054)
+    o.process(z["pcm_in"][:3])                                                  # part (1): the oracle's own WPE against the reference's
+    n, worst = _wpe_contract(o.taps["wpe_r"], o.taps["wpe_i"], o.taps["stft_r"], o.taps["stft_i"], ref=(z["wpe_r"], z["wpe_i"]))
+    assert n > 600 and worst < 5e-4, (n, worst)
+
+
+def test_fold_fixture_oracle(fixture):
+    _, fused = fixture
+    zf = np.load(GOLD_FOLD)
+    o = _oracle(fused, 8192, 3)
+    out = o.process(zf["pcm_in"][None], inject_wpe=(zf["wpe_r"], zf["wpe_i"]))[0]
+    d = out.astype(np.int32) - zf["pcm_out"].astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+
+
+def test_erb_table_and_manifest(fixture):
+    z, _ = fixture
+    assert np.array_equal(hgtcrn.erb_filters(), z["w:erb.erb_fc.weight"])
+    meta = hgtcrn.metadata(20000, True, 0.512)
+    assert meta["model_family"] == "h_gtcrn" and meta["input_channels"] == "2" and meta["output_channels"] == "1"
+    assert meta["fold_window_length"] == "8192" and meta["export_audio_length"] == "24576"
+
+
+def _session(fused, length=L, library=None, **kw):
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    return InferenceSession(weights=pack_blob(fused), metadata=hgtcrn.metadata(length, **kw), library=library)
+
+
+def _run_and_check(sess, fused, pcm, window, n_win, exact_dft, lsb):
+    """HIP (or simulated) run against the two-part contract; returns the PCM."""
+    B = pcm.shape[0] * n_win
+    got = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
+    T = sess.frames
+    n = B * 2 * 514 * T
+    stft = sess.tap("stft", n).reshape(B, 2, 2, 257, T)
+    wpe = sess.tap("wpe", n).reshape(B, 2, 2, 257, T)
+    o = _oracle(fused, window, n_win, exact_dft)
+    o.process(pcm)
+    assert np.abs(stft[:, :, 0] - o.taps["stft_r"]).max() < 2e-4 and np.abs(stft[:, :, 1] - o.taps["stft_i"]).max() < 2e-4
+    n_stable, worst = _wpe_contract(wpe[:, :, 0], wpe[:, :, 1], stft[:, :, 0], stft[:, :, 1])
+    assert worst < 2e-3, (n_stable, worst)
+    want = o.process(pcm, inject_wpe=(wpe[:, :, 0], wpe[:, :, 1]))
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= lsb and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
+    return got
+
+
+@pytest.mark.hipsim
+def test_hipsim_short_clip(fixture):
+    """The same csrc/ade_hgtcrn.hip compiled for the host simulator: a 25-frame stereo clip against the two-part contract."""
+    from ade_testlib import hipsim_library
+    z, fused = fixture
+    W = 6144
+    pcm = np.ascontiguousarray(z["pcm_in"][1:2, :, 2000:2000 + W])
+    with _session(fused, W, hipsim_library()) as sess:
+        assert sess.channels == 2 and sess.out_channels == 1 and sess.frames == 25 and sess.out_len == W
+        _run_and_check(sess, fused, pcm, W, 1, True, 2)
+
+
+@pytest.mark.gpu
+def test_gpu_fixture_rows(fixture):
+    z, fused = fixture
+    with _session(fused) as sess:
+        assert sess.frames == 65 and sess.out_len == L and sess.channels == 2 and sess.out_channels == 1
+        got = _run_and_check(sess, fused, z["pcm_in"], L, 1, True, 3)
+        one = sess.run(None, {"noisy_audio": z["pcm_in"][1:2]})[0][0, 0]
+    assert not got[3].any() and np.array_equal(one, got[1])                     # silence; rows are independent of the batch
+    # end to end against the reference's PCM: bounded by the ill-conditioned bins, not by this implementation (see the module docstring)
+    for i in range(3):
+        ref = z["pcm_out"][i].astype(np.float64)
+        err = got[i].astype(np.float64) - ref
+        assert np.sqrt((err ** 2).mean()) < 0.08 * np.sqrt((ref ** 2).mean()), i
+
+
+@pytest.mark.gpu
+def test_gpu_fold(fixture):
+    _, fused = fixture
+    zf = np.load(GOLD_FOLD)
+    with _session(fused, 20000, use_batch_fold=True, batch_window_seconds=0.512) as sess:
+        assert sess.in_len == 24576 and sess.out_len == 24576
+        _run_and_check(sess, fused, zf["pcm_in"][None], 8192, 3, True, 3)
+
+
+def test_export_writes_blob_and_manifest(fixture, tmp_path):
+    from audio_denoiser_onnx_amd import export
+    from audio_denoiser_onnx_amd.weights import load_blob
+    z, fused = fixture
+    state = {str(k): z["w:" + str(k)] for k in z["keys"]}
+    ck = tmp_path / "ck.npz"
+    np.savez(ck, **state)
+    path = export.export_hgtcrn(ck, tmp_path / "out", 32000)
+    blob = load_blob(path)
+    assert set(blob) == set(fused) and all(np.array_equal(blob[k], fused[k]) for k in fused)
+    assert export.main(["--family", "h_gtcrn", "--length", "16384", str(ck), str(tmp_path / "out2")]) == 0
