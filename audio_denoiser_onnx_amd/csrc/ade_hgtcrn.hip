@@ -106,23 +106,47 @@ __global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, 
         il[t] = 1.0f / fmaxf((p0 + p1) * 0.5f, eps);                         // lambda = clamp(mean_m |Y|^2, eps), Y = X on the only iteration
     }
     __syncthreads();
-    // R = (D / lambda) D^H + eps I ; P = (D / lambda) X^H     (:706-718)
-    for (int e = tid; e < kTaps * kTaps + kTaps * 2; e += 256) {
-        const bool isR = e < kTaps * kTaps;
-        const int i = isR ? e / kTaps : (e - kTaps * kTaps) >> 1;
-        const int j = isR ? e - i * kTaps : (e - kTaps * kTaps) & 1;
-        const int si = kDelay + (i >> 1), mi = i & 1;
-        const int sj = isR ? kDelay + (j >> 1) : 0, mj = isR ? (j & 1) : j;
-        float a_rr = 0.0f, a_ii = 0.0f, a_ir = 0.0f, a_ri = 0.0f;
+    // R = (D / lambda) D^H + eps I ; P = (D / lambda) X^H     (:706-718).  One thread per 2 x 2 block (the two microphones of tap l against the
+    // two of tap l' >= l, or against the undelayed pair for P): nine LDS reads feed 32 multiply-adds.  R is Hermitian; the lower blocks are
+    // the conjugate transposes of the upper ones.
+    constexpr int kBlocks = kLg * (kLg + 1) / 2;
+    for (int e = tid; e < kBlocks + kLg; e += 256) {
+        int l = 0, l2 = 0;
+        const bool isR = e < kBlocks;
+        if (isR) {
+            int rem = e;
+            while (rem >= kLg - l) { rem -= kLg - l; ++l; }
+            l2 = l + rem;
+        } else l = e - kBlocks;
+        const int si = kDelay + l, sj = isR ? kDelay + l2 : 0;
+        float a_rr[4] = {}, a_ii[4] = {}, a_ir[4] = {}, a_ri[4] = {};
         for (int t = si > sj ? si : sj; t < T; ++t) {
             const float w = il[t];
-            const float dr = Xr[mi * T + t - si] * w, di = Xi[mi * T + t - si] * w;
-            const float er = Xr[mj * T + t - sj], ei = Xi[mj * T + t - sj];
-            a_rr += dr * er; a_ii += di * ei; a_ir += di * er; a_ri += dr * ei;
+            const float dr[2] = {Xr[t - si] * w, Xr[T + t - si] * w}, di[2] = {Xi[t - si] * w, Xi[T + t - si] * w};
+            const float er[2] = {Xr[t - sj], Xr[T + t - sj]}, ei[2] = {Xi[t - sj], Xi[T + t - sj]};
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int mj = 0; mj < 2; ++mj) {
+                    a_rr[mi * 2 + mj] += dr[mi] * er[mj];
+                    a_ii[mi * 2 + mj] += di[mi] * ei[mj];
+                    a_ir[mi * 2 + mj] += di[mi] * er[mj];
+                    a_ri[mi * 2 + mj] += dr[mi] * ei[mj];
+                }
         }
-        const float re = a_rr + a_ii, im = a_ir - a_ri;
-        if (isR) { Rr[e] = re + (i == j ? eps : 0.0f); Ri[e] = im; }
-        else { Pr[i * 2 + j] = re; Pi[i * 2 + j] = im; }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int mj = 0; mj < 2; ++mj) {
+                const float re = a_rr[mi * 2 + mj] + a_ii[mi * 2 + mj], im = a_ir[mi * 2 + mj] - a_ri[mi * 2 + mj];
+                const int i = 2 * l + mi;
+                if (isR) {
+                    const int j = 2 * l2 + mj;
+                    Rr[i * kTaps + j] = re + (i == j ? eps : 0.0f);
+                    Ri[i * kTaps + j] = im;
+                    if (l2 != l) { Rr[j * kTaps + i] = re; Ri[j * kTaps + i] = -im; }
+                } else { Pr[i * 2 + mj] = re; Pi[i * 2 + mj] = im; }
+            }
     }
     __syncthreads();
     // conjugate gradient, both right-hand sides at once (:499-555)
@@ -194,17 +218,25 @@ __global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, 
     }
 }
 
-// AuxIVA source activity (:814-818): rinv[b][m][t] = 1 / (2 sqrt(sum_f |Y|^2 + 1e-10))
-__global__ __launch_bounds__(256) void k_hg_iva_r(const float* __restrict__ Y, float* __restrict__ rinv, int T, long long total) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const long long row = i / T;                  // b * 2 + m
-    const int t = (int)(i - row * T);
-    const float* re = Y + (size_t)row * 2 * kHBins * T + t;
-    const float* im = re + (size_t)kHBins * T;
+// AuxIVA source activity (:814-818): rinv[b][m][t] = 1 / (2 sqrt(sum_f |Y|^2 + 1e-10)).  grid (ceil(T / 32), B * 2); 8 groups of bins x 32 frames
+// per workgroup, the eight partial sums added in a fixed order.
+__global__ __launch_bounds__(256) void k_hg_iva_r(const float* __restrict__ Y, float* __restrict__ rinv, int T) {
+    __shared__ float part[8][32];
+    const int tt = threadIdx.x & 31, g = threadIdx.x >> 5, t = blockIdx.x * 32 + tt, row = blockIdx.y;      // row = b * 2 + m
     float s = 0.0f;
-    for (int f = 0; f < kHBins; ++f) s += re[(size_t)f * T] * re[(size_t)f * T] + im[(size_t)f * T] * im[(size_t)f * T];
-    rinv[i] = 1.0f / (2.0f * sqrtf(s + 1e-10f));
+    if (t < T) {
+        const float* re = Y + (size_t)row * 2 * kHBins * T + t;
+        const float* im = re + (size_t)kHBins * T;
+        for (int f = g; f < kHBins; f += 8) s += re[(size_t)f * T] * re[(size_t)f * T] + im[(size_t)f * T] * im[(size_t)f * T];
+    }
+    part[g][tt] = s;
+    __syncthreads();
+    if (g == 0 && t < T) {
+        float tot = part[0][tt];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += part[k][tt];
+        rinv[(size_t)row * T + t] = 1.0f / (2.0f * sqrtf(tot + 1e-10f));
+    }
 }
 
 // A butterfly leaves every lane with the sum of the same 64 numbers but in a lane-dependent association, i.e. with lane-dependent
@@ -660,7 +692,7 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     // AuxIVA: Y starts as the dereverberated spectrum (W = I)
     const dim3 bins((kHBins + 3) / 4, (unsigned)B);
     for (int it = 0; it < kIvaIter; ++it) {
-        hipLaunchKernelGGL(k_hg_iva_r, flat((long long)B * 2 * T), dim3(256), 0, s, (const float*)(it == 0 ? drb : iva), rinv, T, (long long)B * 2 * T);
+        hipLaunchKernelGGL(k_hg_iva_r, dim3((unsigned)((T + 31) / 32), (unsigned)(B * 2)), dim3(256), 0, s, (const float*)(it == 0 ? drb : iva), rinv, T);
         hipLaunchKernelGGL(k_hg_iva_step, bins, dim3(256), 0, s, (const float*)drb, (const float*)rinv, wst, iva, T, it == 0 ? 1 : 0);
     }
     hipLaunchKernelGGL(k_hg_iva_project, bins, dim3(256), 0, s, (const float*)drb, iva, epart, T);

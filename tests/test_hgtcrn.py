@@ -171,3 +171,35 @@ def test_export_writes_blob_and_manifest(fixture, tmp_path):
     blob = load_blob(path)
     assert set(blob) == set(fused) and all(np.array_equal(blob[k], fused[k]) for k in fused)
     assert export.main(["--family", "h_gtcrn", "--length", "16384", str(ck), str(tmp_path / "out2")]) == 0
+
+
+def test_driver_slices_and_reflect_tail():
+    from audio_denoiser_onnx_amd import inference_hgtcrn as drv
+    a = np.arange(2 * 10, dtype=np.int16).reshape(2, 10)
+    s = drv.cut_slices(a, 8, False)
+    assert s.shape == (2, 2, 8) and np.array_equal(s[0], a[:, :8])
+    assert np.array_equal(s[1, 0], [8, 9, 8, 7, 6, 5, 4, 3])                     # np.pad(mode="reflect") of the whole signal (:149)
+    z = drv.cut_slices(a, 8, True)
+    assert np.array_equal(z[1, 0], [8, 9, 0, 0, 0, 0, 0, 0])                     # fold graphs get silence (:161-166)
+    assert np.array_equal(drv.pad_tail(a[:, :1], 4, False), np.repeat(a[:, :1], 4, axis=1))
+
+
+@pytest.mark.gpu
+def test_gpu_file_driver(fixture, tmp_path):
+    """Export -> file driver -> wav: two slices of the example recording, equal to the session called on the same slices."""
+    from audio_denoiser_onnx_amd import export, inference_hgtcrn as drv
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.wavio import read_pcm16, write_pcm16
+    z, fused = fixture
+    ck = tmp_path / "ck.npz"
+    np.savez(ck, **{str(k): z["w:" + str(k)] for k in z["keys"]})
+    model = export.export_hgtcrn(ck, tmp_path / "m", L)
+    audio = np.ascontiguousarray(np.concatenate((z["pcm_in"][0], z["pcm_in"][1][:, :5000]), axis=1))
+    wav_in, wav_out = tmp_path / "in.wav", tmp_path / "out.wav"
+    write_pcm16(wav_in, audio, 16000)
+    assert drv.main([str(model), str(wav_in), str(wav_out)]) == 0
+    got, sr = read_pcm16(wav_out)
+    assert sr == 16000 and got.shape == (1, audio.shape[1])
+    with InferenceSession(str(model)) as sess:
+        want = sess.run(None, {"noisy_audio": drv.cut_slices(audio, L, False)})[0].reshape(-1)[:audio.shape[1]]
+    assert np.array_equal(got[0], want)
