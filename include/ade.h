@@ -43,7 +43,7 @@ typedef struct ade_engine* ade_handle;
 typedef struct ade_io_desc {
     int32_t abi_version;
     int32_t in_channels;       /* 1; 2 for Mel-Band-Roformer stereo (Export_MelBandRoformer.py:714)                  */
-    int32_t out_channels;      /* = in_channels                                                                       */
+    int32_t out_channels;      /* = in_channels, except H-GTCRN: 2 in, 1 out (Export_H_GTCRN.py:1181-1182)             */
     int32_t n_outputs;         /* 1 ("denoised_audio"); 2 for MossFormer2-SS ("separated_0/1", Export_MossFormer2_SS_16K.py:689) */
     int32_t in_len;            /* L: static input length in samples                      */
     int32_t out_len;           /* L_out = 256 * (L / 256): 15872 for L = 16000           */
@@ -61,7 +61,9 @@ typedef struct ade_io_desc {
  * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode).
  * The manifest key `model_family` selects the engine: "gtcrn" (GTCRN/Export_GTCRN.py), "dfsmn" (DFSMN/Export_DFSMN.py),
  * "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py), "mossformer2_ss"
- * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py) or "ul_unas" (UL-UNAS/Export_UL_UNAS.py); the blob then carries that export's fused buffers. */
+ * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py), "ul_unas" (UL-UNAS/Export_UL_UNAS.py) or "h_gtcrn"
+ * (H-GTCRN/Export_H_GTCRN.py: two microphones in, one channel out); the blob then carries that export's fused buffers
+ * (INTEGRATION.md). */
 ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device,
                       ade_handle* out);
 
