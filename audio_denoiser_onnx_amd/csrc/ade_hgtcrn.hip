@@ -380,14 +380,16 @@ __global__ __launch_bounds__(64) void k_hg_pred(const float* __restrict__ epart,
 // Six features, ERB-merged (:1005-1024, ERB.bm :125-128): feat[frame][c][132]; c = re0, im0, re1, im1, selected log-magnitude, the other one.
 __global__ __launch_bounds__(256) void k_hg_feat(const float* __restrict__ spec, const float* __restrict__ iva, const int* __restrict__ pred, BandTab bm,
                                                  float* __restrict__ feat, int T, long long total) {
+    // frames fastest: the spectra are read along their contiguous axis (the 132-float feature rows are written strided instead)
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int e = (int)(i % kErb);
-    const long long q = i / kErb;
+    const int t = (int)(i % T);
+    long long q = i / T;
+    const int e = (int)(q % kErb);
+    q /= kErb;
     const int c = (int)(q % 6);
-    const long long frame = q / 6;
-    const long long b = frame / T;
-    const int t = (int)(frame - b * T);
+    const long long b = q / 6;
+    const long long frame = b * T + t;
     const float* src;
     bool logm = false;
     if (c < 4) src = spec + ((size_t)(b * 2 + (c >> 1)) * 2 + (c & 1)) * kHBins * T + t;

@@ -203,3 +203,25 @@ def test_gpu_file_driver(fixture, tmp_path):
     with InferenceSession(str(model)) as sess:
         want = sess.run(None, {"noisy_audio": drv.cut_slices(audio, L, False)})[0].reshape(-1)[:audio.shape[1]]
     assert np.array_equal(got[0], want)
+
+
+@pytest.mark.gpu
+def test_gpu_four_second_windows(fixture):
+    """A length no fixture covers (64000 samples, 251 frames), two calls: the same two-part contract against the oracle.  Inputs: one of the
+    fixture's synthetic rooms repeated (with dither, to break the exact periodicity) and a fresh room made here."""
+    z, fused = fixture
+    W = 64000
+    rng = np.random.default_rng(9)
+    a = np.tile(z["pcm_in"][2], (1, 4))[:, :W].astype(np.int32) + rng.integers(-200, 200, (2, W))
+    t = np.arange(W) / 16000.0
+    voice = sum(np.sin(2 * np.pi * k * 140 * t + k) / k for k in range(1, 16)) * (0.5 - 0.5 * np.cos(2 * np.pi * 3.0 * t))
+    other = rng.standard_normal(W)
+    mics = []
+    for _ in range(2):
+        h1 = rng.standard_normal(1200) * np.exp(-np.arange(1200) / 300.0); h1[0] = 3.0
+        h2 = rng.standard_normal(1200) * np.exp(-np.arange(1200) / 300.0); h2[0] = 3.0
+        mics.append(np.convolve(voice, h1)[:W] * 600 + np.convolve(other, h2)[:W] * 150 + rng.standard_normal(W) * 40)
+    pcm = np.clip(np.round(np.stack((a, np.stack(mics)))), -32768, 32767).astype(np.int16)
+    with _session(fused, W) as sess:
+        assert sess.frames == 251
+        _run_and_check(sess, fused, pcm, W, 1, True, 3)
