@@ -1008,15 +1008,24 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
     const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
-    memcpy(h->h_pcm_in, in, nin * sizeof(int16_t));
-    HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in, h->h_pcm_in, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    // Page-locked caller buffers (hipHostMalloc / hipHostRegister / a pinned torch tensor) are DMA'd directly; pageable ones go through the
+    // engine's own page-locked staging buffers (an async copy from pageable memory would be staged by the runtime anyway, synchronously).
+    auto page_locked = [](const void* p) {
+        hipPointerAttribute_t a;
+        if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool in_direct = page_locked(in), pcm_direct = page_locked(out_pcm), f32_direct = page_locked(out_f32);
+    const int16_t* src = in;
+    if (!in_direct) { memcpy(h->h_pcm_in, in, nin * sizeof(int16_t)); src = h->h_pcm_in; }
+    HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in, src, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
     st = run(h, h->stream, h->d_pcm_in, rows, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
     if (st != ADE_OK) return st;
-    HIP_TRY(h, hipMemcpyAsync(h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
-    if (out_f32) HIP_TRY(h, hipMemcpyAsync(h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (out_pcm) HIP_TRY(h, hipMemcpyAsync(pcm_direct ? out_pcm : h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(f32_direct ? out_f32 : h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (out_pcm) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
-    if (out_f32) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
+    if (out_pcm && !pcm_direct) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
+    if (out_f32 && !f32_direct) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
     return ADE_OK;
 }
 

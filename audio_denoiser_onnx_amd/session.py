@@ -133,6 +133,19 @@ class InferenceSession:
         return out, f32
 
     # -- batch call on device buffers (torch tensors on this session's GPU) ------------------------------------
+    def process_into(self, pcm: np.ndarray, out: np.ndarray, f32: Optional[np.ndarray] = None) -> None:
+        """``process`` on caller-owned, re-used buffers -- the reference's io_binding pattern (Inference_GTCRN_ONNX.py:307-317): nothing is
+        allocated per call.  Page-locked buffers (hipHostMalloc / a pinned torch tensor's ``.numpy()``) make both copies plain DMA."""
+        B = pcm.shape[0]
+        if pcm.dtype != np.int16 or out.dtype != np.int16 or pcm.shape != (B, self.row_in) or out.shape != (B, self.row_out):
+            raise ValueError(f"expected int16 (B, {self.row_in}) -> int16 (B, {self.row_out})")
+        if not pcm.flags.c_contiguous or not out.flags.c_contiguous or (f32 is not None and not f32.flags.c_contiguous):
+            raise ValueError("buffers must be C-contiguous")
+        if f32 is not None and (f32.dtype != np.float32 or f32.shape != out.shape):
+            raise ValueError("f32 must be float32 with the shape of out")
+        st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if f32 is not None else None)
+        self._lib.check(st, self._h)
+
     def run_device(self, d_in, d_out, d_f32=None, stream: Optional[int] = None) -> None:
         """``d_in`` int16 (B, L) / ``d_out`` int16 (B, L_out) CUDA(HIP) tensors; enqueues on ``stream`` (a raw
         hipStream_t handle, e.g. ``torch.cuda.current_stream().cuda_stream``) or runs synchronously when None."""

@@ -206,6 +206,9 @@ extern "C" {
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);

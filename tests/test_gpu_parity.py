@@ -219,3 +219,25 @@ def test_batch_fold_single_launch_window():
     opcm, of32 = o.process_fold(x, 3, threads=4)
     assert np.abs(f32 - of32).max() <= 1e-5
     assert np.abs(pcm.astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_process_into_pageable_and_page_locked_buffers_agree():
+    """ade_process DMAs page-locked caller buffers directly and stages pageable ones: same bytes either way, nothing allocated per call."""
+    import torch
+    sess = make_session()
+    B = 5
+    pcm = np.ascontiguousarray(synth_batch(B, 16000)).reshape(B, -1)
+    want, _ = sess.process(pcm)
+    out = np.zeros((B, sess.row_out), np.int16)
+    f32 = np.zeros((B, sess.row_out), np.float32)
+    sess.process_into(pcm, out, f32)
+    assert np.array_equal(out, want) and np.abs(f32).max() > 0
+    pin_in = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
+    pin_out = torch.empty(out.shape, dtype=torch.int16).pin_memory()
+    pin_f32 = torch.empty(out.shape, dtype=torch.float32).pin_memory()
+    pin_in.numpy()[...] = pcm
+    sess.process_into(pin_in.numpy(), pin_out.numpy(), pin_f32.numpy())
+    assert np.array_equal(pin_out.numpy(), want) and np.array_equal(pin_f32.numpy(), f32)
+    with pytest.raises(ValueError):
+        sess.process_into(pcm[:, :-1], out)
