@@ -72,8 +72,15 @@ __global__ __launch_bounds__(256) void k_hg_wpe_eps(const float* __restrict__ sp
     if (threadIdx.x == 0) eps[b] = 1e-3f * (part[0] / (float)kHBins);
 }
 
-// WPE, one iteration (:686-757).  grid (257, B), 256 threads, dynamic LDS: X (4 T) | 1 / lambda (T) | R (2 x 36 x 36) | P, x, r, p, Ap (2 x 72 each)
-// | 4 scalars per column.  Delay-bank row k = l * 2 + m is microphone m delayed kDelay + l frames (:627-684).
+// A butterfly leaves every lane with the sum of the same 64 numbers but in a lane-dependent association, i.e. with lane-dependent
+// rounding; the demixing algebra below must be identical in all lanes (each lane applies W to its own frames), so lane 0's sum is broadcast.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return __shfl(v, 0, 64);
+}
+
+// WPE, one iteration (:686-757).  grid (257, B), 256 threads, dynamic LDS: X (4 T) | 1 / lambda (T) | R (2 x 36 x 36) | P, x, p (2 x 72 each).  Delay-bank row k = l * 2 + m is microphone m delayed kDelay + l frames (:627-684).
 __global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, const float* __restrict__ eps_b, float* __restrict__ out, int T) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* Xr = lds;                 // [2][T]
@@ -85,13 +92,8 @@ __global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, 
     float* Pi = Pr + 72;
     float* xr = Pi + 72;
     float* xi = xr + 72;
-    float* rr = xi + 72;
-    float* ri = rr + 72;
-    float* pr = ri + 72;
+    float* pr = xi + 72;
     float* pi = pr + 72;
-    float* Ar = pi + 72;
-    float* Ai = Ar + 72;
-    float* sc = Ai + 72;             // [2][4]: rr, pAp, rr_new
     const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float eps = eps_b[b];
     for (int i = tid; i < 2 * T; i += 256) {
@@ -149,58 +151,43 @@ __global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, 
             }
     }
     __syncthreads();
-    // conjugate gradient, both right-hand sides at once (:499-555)
-    if (tid < 72) { xr[tid] = 0.0f; xi[tid] = 0.0f; rr[tid] = Pr[tid]; ri[tid] = Pi[tid]; pr[tid] = Pr[tid]; pi[tid] = Pi[tid]; }
-    __syncthreads();
-    if (tid < 2) {
-        float s = 0.0f;
-        for (int k = 0; k < kTaps; ++k) s += rr[k * 2 + tid] * rr[k * 2 + tid] + ri[k * 2 + tid] * ri[k * 2 + tid];
-        sc[tid * 4] = s + 1e-12f;
-    }
-    __syncthreads();
-    for (int it = 0; it < kCgIter; ++it) {
-        if (tid < 72) {
-            const int i = tid >> 1, c = tid & 1;
+    // conjugate gradient (:499-555): wavefront c solves right-hand side c; lane i owns entry i of x, r, p (registers), p is mirrored in LDS for
+    // the matrix-vector product (row i of R read as column i of the Hermitian R: consecutive lanes, consecutive words), the dot products are
+    // wavefront reductions; one barrier per step.
+    {
+        const int c = (tid >> 6) & 1, lane = tid & 63;
+        const bool act = tid < 128 && lane < kTaps;
+        const int i = lane < kTaps ? lane : kTaps - 1;
+        float x_r = 0.0f, x_i = 0.0f;
+        float r_r = act ? Pr[i * 2 + c] : 0.0f, r_i = act ? Pi[i * 2 + c] : 0.0f;
+        float p_r = r_r, p_i = r_i;
+        if (act) { pr[i * 2 + c] = p_r; pi[i * 2 + c] = p_i; }
+        float rr = wave_sum(r_r * r_r + r_i * r_i) + 1e-12f;
+        __syncthreads();
+        for (int it = 0; it < kCgIter; ++it) {
             float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
-            for (int k = 0; k < kTaps; ++k) {
-                const float a = Rr[i * kTaps + k], bb = Ri[i * kTaps + k], u = pr[k * 2 + c], v = pi[k * 2 + c];
-                s1 += a * u; s2 += bb * v; s3 += a * v; s4 += bb * u;
+            if (act) {
+                for (int k = 0; k < kTaps; ++k) {
+                    const float a = Rr[k * kTaps + i], bb = -Ri[k * kTaps + i], u = pr[k * 2 + c], v = pi[k * 2 + c];
+                    s1 += a * u; s2 += bb * v; s3 += a * v; s4 += bb * u;
+                }
             }
-            Ar[tid] = s1 - s2;
-            Ai[tid] = s3 + s4;
+            const float a_r = s1 - s2, a_i = s3 + s4;
+            const float pAp = wave_sum(p_r * a_r + p_i * a_i) + 1e-12f;
+            const float alpha = rr / pAp;
+            x_r += alpha * p_r; x_i += alpha * p_i;
+            r_r -= alpha * a_r; r_i -= alpha * a_i;
+            const float rr_new = wave_sum(r_r * r_r + r_i * r_i) + 1e-12f;
+            const float beta = rr_new / rr;
+            p_r = r_r + beta * p_r; p_i = r_i + beta * p_i;
+            rr = rr_new;
+            __syncthreads();                                                   // every lane has read the old p
+            if (act) { pr[i * 2 + c] = p_r; pi[i * 2 + c] = p_i; }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid < 2) {
-            float s = 0.0f;
-            for (int k = 0; k < kTaps; ++k) s += pr[k * 2 + tid] * Ar[k * 2 + tid] + pi[k * 2 + tid] * Ai[k * 2 + tid];
-            sc[tid * 4 + 1] = s + 1e-12f;
-        }
-        __syncthreads();
-        if (tid < 72) {
-            const int c = tid & 1;
-            const float alpha = sc[c * 4] / sc[c * 4 + 1];
-            xr[tid] += alpha * pr[tid];
-            xi[tid] += alpha * pi[tid];
-            rr[tid] -= alpha * Ar[tid];
-            ri[tid] -= alpha * Ai[tid];
-        }
-        __syncthreads();
-        if (tid < 2) {
-            float s = 0.0f;
-            for (int k = 0; k < kTaps; ++k) s += rr[k * 2 + tid] * rr[k * 2 + tid] + ri[k * 2 + tid] * ri[k * 2 + tid];
-            sc[tid * 4 + 2] = s + 1e-12f;
-        }
-        __syncthreads();
-        if (tid < 72) {
-            const int c = tid & 1;
-            const float beta = sc[c * 4 + 2] / sc[c * 4];
-            pr[tid] = rr[tid] + beta * pr[tid];
-            pi[tid] = ri[tid] + beta * pi[tid];
-        }
-        __syncthreads();
-        if (tid < 2) sc[tid * 4] = sc[tid * 4 + 2];
-        __syncthreads();
+        if (act) { xr[i * 2 + c] = x_r; xi[i * 2 + c] = x_i; }
     }
+    __syncthreads();
     // Y = X - conj(G)^T D    (:741-750)
     for (int i = tid; i < 2 * T; i += 256) {
         const int m = i / T, t = i - m * T;
@@ -237,14 +224,6 @@ __global__ __launch_bounds__(256) void k_hg_iva_r(const float* __restrict__ Y, f
         for (int k = 1; k < 8; ++k) tot += part[k][tt];
         rinv[(size_t)row * T + t] = 1.0f / (2.0f * sqrtf(tot + 1e-10f));
     }
-}
-
-// A butterfly leaves every lane with the sum of the same 64 numbers but in a lane-dependent association, i.e. with lane-dependent
-// rounding; the demixing algebra below must be identical in all lanes (each lane applies W to its own frames), so lane 0's sum is broadcast.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return __shfl(v, 0, 64);
 }
 
 // One AuxIVA iteration for one (window, bin): both source updates (:820-878) and Y = W X (:880-884).  One wavefront per bin, lanes over frames.
@@ -640,7 +619,7 @@ int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, 
         const DpOff& o = dpo_[i];
         e->dp[i] = DpW{Wd + o.intra_gru, Wd + o.inter_gru, Wd + o.fc[0], Wd + o.fc_b[0], Wd + o.ln_w[0], Wd + o.ln_b[0], Wd + o.fc[1], Wd + o.fc_b[1], Wd + o.ln_w[1], Wd + o.ln_b[1]};
     }
-    const size_t wpe_lds = (size_t)(5 * T + 2 * kTaps * kTaps + 10 * 72 + 8) * sizeof(float);
+    const size_t wpe_lds = (size_t)(5 * T + 2 * kTaps * kTaps + 6 * 72) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hg_wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wpe_lds);
     ade_stft_config cfg{kHNfft, kHNfft, kHHop, "hann", nullptr, 1, "reflect"};          // H-GTCRN/Export_H_GTCRN.py:36-40, 1076-1097
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: STFT plan: ") + ade_stft_last_error(nullptr)));
@@ -689,7 +668,7 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     if (ade_stft_analyze(plan, xf, B * 2, W, spec, (void*)s) != ADE_OK) return hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: ") + ade_stft_last_error(plan));
     // WPE
     hipLaunchKernelGGL(k_hg_wpe_eps, dim3((unsigned)B), dim3(256), 0, s, (const float*)spec, eps, T);
-    const size_t wpe_lds = (size_t)(5 * T + 2 * kTaps * kTaps + 10 * 72 + 8) * sizeof(float);
+    const size_t wpe_lds = (size_t)(5 * T + 2 * kTaps * kTaps + 6 * 72) * sizeof(float);
     hipLaunchKernelGGL(k_hg_wpe, dim3(kHBins, (unsigned)B), dim3(256), wpe_lds, s, (const float*)spec, (const float*)eps, drb, T);
     // AuxIVA: Y starts as the dereverberated spectrum (W = I)
     const dim3 bins((kHBins + 3) / 4, (unsigned)B);
