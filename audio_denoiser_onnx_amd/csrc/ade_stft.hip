@@ -65,6 +65,19 @@ struct SpecA {                 // synthesis A operand: A(j, c) = spec[b][c][t]; 
     }
 };
 
+struct PolarSpecA {            // the same operand from polar inputs (istft_A, STFT_Process.py:343-347): real = mag cos(phase), imag = mag sin(phase)
+    static constexpr bool kAlongK = false;
+    const float *mag, *phase;
+    int F, T;
+    __device__ float operator()(int j, int c) const {
+        const int b = j / T, t = j - b * T;
+        const int f = c < F ? c : c - F;
+        const size_t at = ((size_t)b * F + f) * T + t;
+        const float m = mag[at], ph = phase[at];
+        return c < F ? m * cosf(ph) : m * sinf(ph);
+    }
+};
+
 // overlap-add as a gather (every output sample sums its <= ceil(n_fft/hop) contributing frames in a fixed order), trim,
 // divide by the matching sum of squared window samples (static_norm, STFT_Process.py:253-273,326-336)
 __global__ __launch_bounds__(256) void k_stft_ola(const float* __restrict__ frames, const float* __restrict__ wsq, float* __restrict__ y,
@@ -225,9 +238,11 @@ ade_status ade_stft_analyze(ade_stft_handle p, const float* d_x, int batch, int 
     return ADE_OK;
 }
 
-ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
-    if (!p || batch < 0 || frames < 1 || (batch > 0 && (!d_spec || !d_y))) return sfail(p, ADE_ERR_BAD_VALUE, "ade_stft_synthesize: bad arguments");
-    if (batch == 0) return ADE_OK;
+}  // extern "C"
+
+namespace {
+template <class ALoader>
+ade_status synthesize_from(ade_stft_handle p, ALoader a, int batch, int frames, float* d_y, void* hip_stream) {
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
     const size_t need = (size_t)batch * frames * p->d.n_fft;
@@ -239,8 +254,8 @@ ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch
         STFT_HIP(p, hipMalloc((void**)&p->d_frames, need * sizeof(float)));
         p->frames_cap = need;
     }
-    ade::gemm::launch(s, ade::SpecA{d_spec, p->d.F2, frames}, ade::gemm::RowMajorB{p->d_inv, p->d.n_fft},
-                      ade::gemm::BiasActStore<ade::gemm::kActNone>{p->d_frames, p->d.n_fft, nullptr, 0.0f}, batch * frames, p->d.n_fft, p->d.F2);
+    ade::gemm::launch(s, a, ade::gemm::RowMajorB{p->d_inv, p->d.n_fft}, ade::gemm::BiasActStore<ade::gemm::kActNone>{p->d_frames, p->d.n_fft, nullptr, 0.0f},
+                      batch * frames, p->d.n_fft, p->d.F2);
     int out_len = 0;
     (void)ade_stft_output_length(p, frames, &out_len);
     const long long total = (long long)batch * out_len;
@@ -249,6 +264,21 @@ ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch
     STFT_HIP(p, hipGetLastError());
     if (!hip_stream) STFT_HIP(p, hipStreamSynchronize(s));
     return ADE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
+    if (!p || batch < 0 || frames < 1 || (batch > 0 && (!d_spec || !d_y))) return sfail(p, ADE_ERR_BAD_VALUE, "ade_stft_synthesize: bad arguments");
+    if (batch == 0) return ADE_OK;
+    return synthesize_from(p, ade::SpecA{d_spec, p->d.F2, frames}, batch, frames, d_y, hip_stream);
+}
+
+ade_status ade_stft_synthesize_polar(ade_stft_handle p, const float* d_mag, const float* d_phase, int batch, int frames, float* d_y, void* hip_stream) {
+    if (!p || batch < 0 || frames < 1 || (batch > 0 && (!d_mag || !d_phase || !d_y))) return sfail(p, ADE_ERR_BAD_VALUE, "ade_stft_synthesize_polar: bad arguments");
+    if (batch == 0) return ADE_OK;
+    return synthesize_from(p, ade::PolarSpecA{d_mag, d_phase, p->d.F2 / 2, frames}, batch, frames, d_y, hip_stream);
 }
 
 const char* ade_stft_last_error(ade_stft_handle p) { return p ? p->last_error.c_str() : g_stft_create_error.c_str(); }

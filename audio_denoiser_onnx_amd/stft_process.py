@@ -29,10 +29,10 @@ class STFT_Process:
     def __init__(self, model_type: str, n_fft: int = 512, win_length: int = 512, hop_len: int = 256, max_frames: int = 0,
                  window_type: str = "hann_sqrt", center_pad: bool = True, pad_mode: str = "reflect", static_norm: bool = True,
                  device_id: int = 0, library: Optional[_lib.AdeLibrary] = None):
-        if model_type not in ("stft_B", "istft_B"):
-            raise ValueError(f"Unknown model_type: {model_type} (this build implements 'stft_B' and 'istft_B')")
-        if model_type == "istft_B" and not static_norm:
-            raise ValueError("istft_B is implemented with static_norm=True (the exported, static-shape form)")
+        if model_type not in ("stft_A", "stft_B", "istft_A", "istft_B"):
+            raise ValueError(f"Unknown model_type: {model_type}")
+        # static_norm only chooses between a precomputed and a per-call sum of squared windows in the reference (:253-273 vs :355-361);
+        # the operator always divides by the exact per-sample sum, which both forms equal.
         self._lib = library or _lib.get_library()
         self.model_type, self.n_fft, self.hop_len, self.n_frames = model_type, n_fft, hop_len, max_frames
         self.half_n_fft = n_fft // 2
@@ -58,22 +58,26 @@ class STFT_Process:
         self._check(self._lib.c.ade_stft_output_length(self._h, int(frames), C.byref(n)))
         return n.value
 
-    def __call__(self, x, stream: Optional[int] = None):
-        return self.forward(x, stream)
+    def __call__(self, x, *more, stream: Optional[int] = None):
+        return self.forward_polar(x, more[0], stream) if self.model_type == "istft_A" else self.forward(x, stream)
 
     def forward(self, x, stream: Optional[int] = None):
-        """stft_B: (B, 1, L) or (B, L) float32 CUDA tensor -> packed (B, 2F, T).  istft_B: (B, 2F, T) -> (B, 1, L_out)."""
+        """stft_B: (B, 1, L) or (B, L) float32 CUDA tensor -> packed (B, 2F, T) (``split()`` gives the reference's ``_stft_B_forward`` pair
+        :298-301); stft_A: the real rows only (B, F, T) (:285-296).  istft_B: (B, 2F, T) -> (B, 1, L_out); istft_A: ``forward(magnitude,
+        phase)``, each (B, F, T) (:343-361)."""
         import torch
+        if self.model_type == "istft_A":
+            raise TypeError("istft_A takes (magnitude, phase): call forward_polar")
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError("STFT_Process takes float32 device tensors")
         x = x.contiguous()
         sp = C.c_void_p(stream) if stream else None
-        if self.model_type == "stft_B":
+        if self.model_type in ("stft_A", "stft_B"):
             B, L = int(x.shape[0]), int(x.shape[-1])
             T = self.frames(L)
             out = torch.empty((B, self.n_fft + 2, T), dtype=torch.float32, device=x.device)
             self._check(self._lib.c.ade_stft_analyze(self._h, C.c_void_p(x.data_ptr()), B, L, C.c_void_p(out.data_ptr()), sp))
-            return out
+            return out if self.model_type == "stft_B" else out[:, :self.half_n_fft + 1]
         B, T = int(x.shape[0]), int(x.shape[2])
         if int(x.shape[1]) != self.n_fft + 2:
             raise ValueError(f"packed spectrum must have {self.n_fft + 2} rows, got {tuple(x.shape)}")
@@ -81,6 +85,31 @@ class STFT_Process:
             raise ValueError(f"static ISTFT was built for {self.n_frames} frames, got {T}")
         out = torch.empty((B, 1, self.output_length(T)), dtype=torch.float32, device=x.device)
         self._check(self._lib.c.ade_stft_synthesize(self._h, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(out.data_ptr()), sp))
+        return out
+
+    @staticmethod
+    def split(packed):
+        """(B, 2F, T) -> (real, imag), each (B, F, T): the two outputs of the reference's un-packed ``_stft_B_forward`` (:298-301)."""
+        F = packed.shape[1] // 2
+        return packed[:, :F], packed[:, F:]
+
+    def forward_polar(self, magnitude, phase, stream: Optional[int] = None):
+        """istft_A (:343-361): magnitude, phase (B, F, T) float32 device tensors -> (B, 1, L_out); the polar -> rectangular step runs inside
+        the synthesis GEMM's operand loader."""
+        import torch
+        if self.model_type != "istft_A":
+            raise TypeError("forward_polar belongs to model_type 'istft_A'")
+        if magnitude.shape != phase.shape or magnitude.dim() != 3 or int(magnitude.shape[1]) != self.half_n_fft + 1:
+            raise ValueError(f"magnitude / phase must both be (B, {self.half_n_fft + 1}, T)")
+        if not (magnitude.is_cuda and phase.is_cuda) or magnitude.dtype != torch.float32 or phase.dtype != torch.float32:
+            raise ValueError("STFT_Process takes float32 device tensors")
+        magnitude, phase = magnitude.contiguous(), phase.contiguous()
+        B, T = int(magnitude.shape[0]), int(magnitude.shape[2])
+        if self.n_frames and T != self.n_frames:
+            raise ValueError(f"static ISTFT was built for {self.n_frames} frames, got {T}")
+        out = torch.empty((B, 1, self.output_length(T)), dtype=torch.float32, device=magnitude.device)
+        self._check(self._lib.c.ade_stft_synthesize_polar(self._h, C.c_void_p(magnitude.data_ptr()), C.c_void_p(phase.data_ptr()), B, T,
+                                                          C.c_void_p(out.data_ptr()), C.c_void_p(stream) if stream else None))
         return out
 
     def close(self) -> None:

@@ -159,6 +159,9 @@ ade_status ade_stft_frames(ade_stft_handle h, int length, int* frames);         
 ade_status ade_stft_output_length(ade_stft_handle h, int frames, int* out_len);     /* ISTFT output length for T frames */
 ade_status ade_stft_analyze(ade_stft_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
 ade_status ade_stft_synthesize(ade_stft_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
+/* The polar form (model_type "istft_A", STFT_Process.py:343-361): magnitude and phase, each [batch][F][T]; real = mag cos(phase),
+ * imag = mag sin(phase) are formed inside the GEMM's operand loader. */
+ade_status ade_stft_synthesize_polar(ade_stft_handle h, const float* d_mag, const float* d_phase, int batch, int frames, float* d_y, void* hip_stream);
 const char* ade_stft_last_error(ade_stft_handle h);   /* h == NULL: the last failing ade_stft_create of this thread */
 void ade_stft_destroy(ade_stft_handle h);
 

@@ -107,3 +107,27 @@ def test_gpu_stft_process_large_batch_properties():
     assert torch.equal(a[3:5], b)                                              # rows are independent, kernels deterministic
     c = stft(2.0 * x[:2] + x[2:4])
     assert float((c - (2.0 * a[:2] + a[2:4])).abs().max()) <= 1e-4 * float(a.abs().max())
+
+
+@pytest.mark.gpu
+def test_gpu_stft_a_and_polar_istft_a():
+    """model_type 'stft_A' (real rows), the split pair of 'stft_B', and 'istft_A' (magnitude, phase) against GTCRN's own STFT_Process copy
+    (tests/golden/stft_gtcrn_polar.npz, tools/make_golden_stft.py::polar)."""
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    g, n_fft, win, hop, center, pad = _load("gtcrn")
+    p = np.load(os.path.join(GOLD, "stft_gtcrn_polar.npz"))
+    x = torch.from_numpy(g["x"]).cuda()
+    real_a = STFT_Process("stft_A", n_fft, win, hop, 0, "hann_sqrt", center, pad)(x[:, None, :])
+    assert tuple(real_a.shape) == p["real_a"].shape and np.abs(real_a.cpu().numpy() - p["real_a"]).max() <= 2e-4 * float(np.abs(p["real_a"]).max())
+    packed = STFT_Process("stft_B", n_fft, win, hop, 0, "hann_sqrt", center, pad)(x[:, None, :])
+    re, im = STFT_Process.split(packed)
+    assert torch.equal(re, real_a) and tuple(im.shape) == tuple(re.shape)
+    T = p["magnitude"].shape[2]
+    ist = STFT_Process("istft_A", n_fft, win, hop, T, "hann_sqrt", center, pad, static_norm=True)
+    y = ist(torch.from_numpy(p["magnitude"]).cuda(), torch.from_numpy(p["phase"]).cuda()).cpu().numpy().reshape(2, -1)
+    assert y.shape == p["y"].shape and np.abs(y - p["y"]).max() <= 1e-4
+    with pytest.raises(TypeError):
+        ist.forward(torch.from_numpy(p["magnitude"]).cuda())
+    with pytest.raises(ValueError):
+        ist(torch.from_numpy(p["magnitude"][:, :100]).cuda(), torch.from_numpy(p["phase"][:, :100]).cuda())

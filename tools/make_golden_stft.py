@@ -56,5 +56,22 @@ def main():
         print(f"{name}: spec {tuple(spec.shape)} y {tuple(y.shape)} roundtrip err {err:.2e}")
 
 
+def polar():
+    """model_type 'stft_A' (real rows only, :285-296) and 'istft_A' (polar synthesis, :343-361) of GTCRN's copy, on the gtcrn case's input."""
+    mod = import_stft_process("GTCRN")
+    z = np.load(os.path.join(GOLD, "stft_gtcrn.npz"))
+    x = torch.from_numpy(z["x"]).reshape(2, 1, -1)
+    spec = torch.from_numpy(z["spec"])
+    F, T = 257, spec.shape[2]
+    with torch.inference_mode():
+        real_a = mod.STFT_Process("stft_A", 512, 512, 256, 0, "hann_sqrt", True, "reflect").eval()(x)
+        mag = torch.sqrt(spec[:, :F] ** 2 + spec[:, F:] ** 2)
+        phase = torch.atan2(spec[:, F:], spec[:, :F])
+        y = mod.STFT_Process("istft_A", 512, 512, 256, T, "hann_sqrt", True, "reflect", static_norm=True).eval()(mag, phase)
+    np.savez_compressed(os.path.join(GOLD, "stft_gtcrn_polar.npz"), real_a=real_a.numpy(), magnitude=mag.numpy(), phase=phase.numpy(), y=y.numpy().reshape(2, -1))
+    print("polar:", tuple(real_a.shape), tuple(y.shape), float((y.reshape(2, -1) - torch.from_numpy(z["y"])).abs().max()))
+
+
 if __name__ == "__main__":
     main()
+    polar()
