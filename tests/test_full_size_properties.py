@@ -49,3 +49,36 @@ def test_melband_depth_6_fold_window_and_eight_second_clip():
             one = sess.run(None, {"noisy_audio": rows[1:2]})[0]
         assert np.array_equal(a[::-1], b) and np.array_equal(one[0], a[1])
         assert np.isfinite(a.astype(np.float64)).all() and np.abs(a[0]).max() > 200
+
+
+def test_hgtcrn_and_ulunas_256_calls():
+    """The two GTCRN-kernel families at batch 256 (H-GTCRN: 2 s stereo calls, the export's default length; UL-UNAS: 1 s): a row inside the
+    big batch equals the same row in a batch of three, reversed order gives reversed results, silence stays silent."""
+    import os
+    from audio_denoiser_onnx_amd import hgtcrn, ulunas
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rng = np.random.default_rng(2)
+    z = np.load(os.path.join(gold, "hgtcrn_seed0.npz"))
+    fused = hgtcrn.fold_state_dict({str(k): z["w:" + str(k)] for k in z["keys"]})
+    L = 32000
+    rows = np.stack([np.stack((_signal(rng, (L,), 200.0 + 40.0 * i), _signal(rng, (L,), 150.0 + 30.0 * i))) for i in range(256)])
+    rows[17] = 0
+    with InferenceSession(weights=pack_blob(fused), metadata=hgtcrn.metadata(L)) as sess:
+        assert sess.frames == 126 and sess.out_len == L
+        a = sess.run(None, {"noisy_audio": rows})[0][:, 0]
+        b = sess.run(None, {"noisy_audio": rows[::-1].copy()})[0][:, 0]
+        few = sess.run(None, {"noisy_audio": rows[[200, 17, 3]]})[0][:, 0]
+    assert np.array_equal(a[::-1], b) and np.array_equal(few, a[[200, 17, 3]])
+    assert not a[17].any() and np.abs(a[200]).max() > 100
+    z = np.load(os.path.join(gold, "ulunas_seed0.npz"))
+    fused = ulunas.fold_state_dict({str(k): z["w:" + str(k)] for k in z["keys"]})
+    rows = np.stack([_signal(rng, (16000,), 300.0 + 50.0 * i) for i in range(256)])
+    rows[5] = 0
+    with InferenceSession(weights=pack_blob(fused), metadata=ulunas.metadata(16000)) as sess:
+        a = sess.run(None, {"noisy_audio": rows[:, None]})[0][:, 0]
+        b = sess.run(None, {"noisy_audio": rows[::-1][:, None].copy()})[0][:, 0]
+        few = sess.run(None, {"noisy_audio": rows[[250, 5, 0]][:, None]})[0][:, 0]
+    assert np.array_equal(a[::-1], b) and np.array_equal(few, a[[250, 5, 0]])
+    assert not a[5].any() and np.abs(a[250]).max() > 100
