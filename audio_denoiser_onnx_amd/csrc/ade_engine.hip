@@ -783,8 +783,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // Resampling edges exist where the reference's STATIC export is self-consistent: MossFormer2 and DFSMN size their frames from the
         // model-rate length (Export_MossFormer2_SS_16K.py:36-37,99-104; Export_DFSMN.py:48,67).  Mel-Band-Roformer (like GTCRN) and UL-UNAS size
         // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
-        // H-GTCRN's static export is consistent too, but it centres between the two interpolation orders (:953-970): not built, rejected here.
-        if (rates_differ && !fam_moss && !fam_dfsmn)
+        // H-GTCRN's static export is consistent too (frames from MODEL_AUDIO_LENGTH, Export_H_GTCRN.py:45-46); it interpolates by SCALE FACTOR.
+        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg)
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
@@ -794,7 +794,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         const long caller_len = Ld;
         if (rates_differ) {   // MODEL_AUDIO_LENGTH = round(L * model / in) (:36); batch-fold needs equal rates (:92-93)
             if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
-            Ld = (long)llround((double)caller_len * (double)srm / (double)sri);
+            Ld = fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
+                        : (long)llround((double)caller_len * (double)srm / (double)sri);
         }
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
             long fw = 0;    //                                                            (Export_MelBandRoformer.py:47-51, 644-647)
@@ -838,14 +839,22 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         e->T = e->sub->frames();
         e->out_len = e->sub->out_len() * e->out_channels * e->n_outputs;
         if (rates_differ) {   // F.interpolate(size = ...) on both edges (:562-571, :625-640): source scale = source length / target length
-            const long out_caller = (long)llround((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
             e->resample = true;
             e->rs_model_in = e->sub->in_len();
             e->rs_model_out = e->sub->out_len();
-            e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);
-            e->rs_scale_out = (float)((double)e->rs_model_out / (double)out_caller);
-            e->rs_pcm_scale = fam_dfsmn ? 32768.0f : 1.0f;   // DFSMN: * 32768 after the interpolation (Export_DFSMN.py:241-243); MossFormer2's waveform
-            e->rs_truncate_i32 = !fam_dfsmn;                 // is already in PCM units and goes through .to(int32).clamp().to(int16) (:645)
+            long out_caller;
+            if (fam_hg) {   // F.interpolate(scale_factor = ...) (Export_H_GTCRN.py:953-970, 1036-1052): floor(length * factor) samples, source step 1 / factor
+                out_caller = (long)floor((double)e->rs_model_out * ((double)sro / (double)srm));
+                e->rs_scale_in = (float)((double)sri / (double)srm);
+                e->rs_scale_out = (float)((double)srm / (double)sro);
+                e->sub->float_src_len = (int)caller_len;
+            } else {
+                out_caller = (long)llround((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
+                e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);
+                e->rs_scale_out = (float)((double)e->rs_model_out / (double)out_caller);
+            }
+            e->rs_pcm_scale = fam_dfsmn ? 32768.0f : fam_hg ? 32767.0f : 1.0f;   // DFSMN: * 32768 after the interpolation (Export_DFSMN.py:241-243); H-GTCRN: * 32767
+            e->rs_truncate_i32 = !fam_dfsmn && !fam_hg;      // (:1045); MossFormer2's waveform is already in PCM units and goes through .to(int32).clamp().to(int16) (:645)
             e->in_len = (int)caller_len * e->channels;
             e->out_len = (int)out_caller * e->out_channels * e->n_outputs;
         }

@@ -49,6 +49,27 @@ __global__ __launch_bounds__(256) void k_hg_pcm2f(const int16_t* __restrict__ pc
     x[i] = v - mean[call];
 }
 
+// the resampled entry (:953-970): x = float_in / 32768 - mean.  The mean is that of the tensor the reference centres: the interpolated one when
+// the input rate is above the model rate (mean_src = that float tensor), the caller-rate PCM otherwise (interpolation commutes with the shift).
+__global__ __launch_bounds__(256) void k_hg_mean_f32(const float* __restrict__ x, long long n, float* __restrict__ mean) {
+    __shared__ double part[256];
+    const float* base = x + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) s += (double)base[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 256; ++i) tot += part[i];
+        mean[blockIdx.x] = (float)(tot / ((double)n * 32768.0));
+    }
+}
+__global__ __launch_bounds__(256) void k_hg_f2f(const float* __restrict__ in, const float* __restrict__ mean, float* __restrict__ x, int W, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    x[i] = in[i] * (1.0f / 32768.0f) - mean[i / (2 * (long long)W)];          // rows are already (call, channel): no fold with resampling
+}
+
 // eps[b] = 1e-3 * mean_f( max_{m,t} |X|^2 )  (:690-691)
 __global__ __launch_bounds__(256) void k_hg_wpe_eps(const float* __restrict__ spec, float* __restrict__ eps, int T) {
     __shared__ float part[256];
@@ -465,7 +486,8 @@ __global__ __launch_bounds__(256) void k_hg_mask(const float* __restrict__ mask,
 __global__ __launch_bounds__(256) void k_hg_f2pcm(const float* __restrict__ y, int16_t* __restrict__ pcm, float* __restrict__ f32, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    if (f32) f32[i] = y[i];
+    const float w = y[i] == y[i] ? y[i] : 0.0f;                      // the NaN guard sits before every output dtype's return (:1054-1060)
+    if (f32) f32[i] = w;
     float v = y[i] * 32767.0f;
     if (v != v) v = 0.0f;
     if (pcm) pcm[i] = (int16_t)(int)fminf(fmaxf(v, -32768.0f), 32767.0f);
@@ -526,6 +548,7 @@ struct HgtcrnEngine : SubEngine {
     int out_len() const override { return out_len_ * n_win; }
     int channels() const override { return 2; }
     int out_channels() const override { return 1; }
+    bool accepts_float_input() const override { return true; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
@@ -657,14 +680,20 @@ int HgtcrnEngine::reserve(int calls, std::string& err) {
 
 int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
     if (batch == 0) return ADE_OK;
-    if (float_in) return hfail(err, ADE_ERR_BAD_VALUE, "h_gtcrn: float input is not supported");
     int st = reserve(batch, err);
     if (st != ADE_OK) return st;
     const int B = batch * n_win;
     const int nfr = B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
-    launch_pcm_mean(s, d_in, batch, 2 * n_win * W, mean, 1);
-    hipLaunchKernelGGL(k_hg_pcm2f, flat((long long)B * 2 * W), dim3(256), 0, s, d_in, (const float*)mean, xf, W, n_win, (long long)B * 2 * W);
+    if (float_in) {
+        if (n_win != 1) return hfail(err, ADE_ERR_BAD_VALUE, "h_gtcrn: resampled input cannot be folded");
+        if (float_src_len > 0 && float_src_len < W) launch_pcm_mean(s, d_in, batch, 2 * float_src_len, mean, 1);      // upsampled: centred before the interpolation
+        else hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_in, (long long)2 * W, mean);
+        hipLaunchKernelGGL(k_hg_f2f, flat((long long)B * 2 * W), dim3(256), 0, s, float_in, (const float*)mean, xf, W, (long long)B * 2 * W);
+    } else {
+        launch_pcm_mean(s, d_in, batch, 2 * n_win * W, mean, 1);
+        hipLaunchKernelGGL(k_hg_pcm2f, flat((long long)B * 2 * W), dim3(256), 0, s, d_in, (const float*)mean, xf, W, n_win, (long long)B * 2 * W);
+    }
     if (ade_stft_analyze(plan, xf, B * 2, W, spec, (void*)s) != ADE_OK) return hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: ") + ade_stft_last_error(plan));
     // WPE
     hipLaunchKernelGGL(k_hg_wpe_eps, dim3((unsigned)B), dim3(256), 0, s, (const float*)spec, eps, T);

@@ -164,6 +164,7 @@ struct SubEngine {
     // Resampled input (in_sample_rate != model_sample_rate): when set, run() reads its PCM from here -- floats in int16 units, same
     // [batch][channels()][in_len()] layout -- instead of d_in (the reference interpolates `audio.float()` before anything else).
     const float* float_in = nullptr;
+    int float_src_len = 0;               // samples per channel row of the caller-rate PCM behind float_in (set once by the engine; H-GTCRN's DC mean)
     virtual bool accepts_float_input() const { return false; }
     virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][out_channels()][out_len()]
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status

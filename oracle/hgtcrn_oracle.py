@@ -238,9 +238,53 @@ class HgtcrnOracle:
         """pcm int16 (calls, 2, n_win * W) -> int16 (calls, n_win * out_len).  inject_wpe = (re, im), each (B, 2, F, T): continue from a given WPE
         output instead of this module's own (how the tests pin everything downstream of the ill-conditioned solve on identical inputs)."""
         assert pcm.ndim == 3 and pcm.shape[1] == 2 and pcm.shape[2] == self.W * self.n_win and pcm.dtype == np.int16
-        calls, T, half = pcm.shape[0], self.T, NFFT // 2
+        calls = pcm.shape[0]
         x = (pcm.astype(F32) * F32(1.0 / 32768.0)).astype(F32)
         x = (x - x.reshape(calls, -1).mean(axis=1, dtype=F32)[:, None, None]).astype(F32)                 # (:963-964) the mean of the whole call
+        with np.errstate(all="ignore"):
+            y = (self._core(x, inject_wpe) * F32(32767.0)).astype(F32)
+            y = np.where(np.isnan(y), F32(0.0), y)                                                         # (:1054)
+        return np.clip(y, -32768.0, 32767.0).astype(np.int16)
+
+    @staticmethod
+    def _interp(x, factor):
+        """F.interpolate(x, scale_factor=factor, mode='linear', align_corners=False) over the last axis: floor(n * factor) samples, source
+        coordinate (dst + 0.5) / factor - 0.5 clamped at 0 (the given factor is used as is)."""
+        n = x.shape[-1]
+        m = int(np.floor(n * factor))
+        step = F32(1.0 / factor)
+        src = np.maximum(step * (np.arange(m, dtype=F32) + F32(0.5)) - F32(0.5), F32(0.0)).astype(F32)
+        i0 = np.minimum(src.astype(np.int64), n - 1)
+        i1 = np.minimum(i0 + 1, n - 1)
+        l1 = (src - i0.astype(F32)).astype(F32)
+        return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+    def process_resampled(self, pcm: np.ndarray, in_rate: int, out_rate: int, inject_wpe=None) -> np.ndarray:
+        """The resampling edges (:953-970, :1036-1052): interpolate to 16 kHz before the scaling / centring when the input rate is higher,
+        after them when it is lower; on the way out interpolate before the PCM scale when the output rate is lower, after it when higher."""
+        assert self.n_win == 1 and pcm.ndim == 3 and pcm.shape[1] == 2 and pcm.dtype == np.int16
+        calls = pcm.shape[0]
+        x = pcm.astype(F32)
+        if in_rate > 16000:
+            x = self._interp(x, 16000.0 / in_rate)
+        x = (x * F32(1.0 / 32768.0)).astype(F32)
+        x = (x - x.reshape(calls, -1).mean(axis=1, dtype=F32)[:, None, None]).astype(F32)
+        if in_rate < 16000:
+            x = self._interp(x, 16000.0 / in_rate)
+        assert x.shape[2] == self.W, x.shape
+        with np.errstate(all="ignore"):
+            y = self._core(x, inject_wpe)
+            if out_rate < 16000:
+                y = self._interp(y, out_rate / 16000.0)
+            y = (y * F32(32767.0)).astype(F32)
+            if out_rate > 16000:
+                y = self._interp(y, out_rate / 16000.0)
+            y = np.where(np.isnan(y), F32(0.0), y)
+        return np.clip(y, -32768.0, 32767.0).astype(np.int16)
+
+    def _core(self, x, inject_wpe=None):
+        """Centred model-rate waveform (calls, 2, n_win * W) -> enhanced waveform (calls, n_win * out_len), everything between the two PCM edges."""
+        calls, T, half = x.shape[0], self.T, NFFT // 2
         x = x.reshape(calls, 2, self.n_win, self.W).transpose(0, 2, 1, 3).reshape(-1, self.W)             # (:972-981) row = (window, channel)
         xp = np.concatenate((x[:, 1:half + 1][:, ::-1], x, x[:, -(half + 1):-1][:, ::-1]), axis=1)
         frames = np.stack([xp[:, t * HOP:t * HOP + NFFT] for t in range(T)], axis=1)
@@ -248,7 +292,7 @@ class HgtcrnOracle:
         B = calls * self.n_win
         re = spec[..., :FB].reshape(B, 2, T, FB).transpose(0, 3, 1, 2)                                     # (B, F, 2, T)
         im = spec[..., FB:].reshape(B, 2, T, FB).transpose(0, 3, 1, 2)
-        with np.errstate(all="ignore"):
+        if True:
             self.taps.update(stft_r=re.transpose(0, 2, 1, 3), stft_i=im.transpose(0, 2, 1, 3))
             if inject_wpe is None:
                 dr, di = wpe(re, im)
@@ -276,6 +320,4 @@ class HgtcrnOracle:
                 raw[:, t * HOP:t * HOP + NFFT] += fr[:, t]
             wav = (raw[:, half:half + self.out_len] / self.win_sum).astype(F32)
             self.taps["wav"] = wav.reshape(calls, -1)
-            y = (wav * F32(32767.0)).astype(F32)
-            y = np.where(np.isnan(y), F32(0.0), y)                                                         # (:1054)
-        return np.clip(y, -32768.0, 32767.0).astype(np.int16).reshape(calls, self.n_win * self.out_len)
+        return wav.reshape(calls, self.n_win * self.out_len)

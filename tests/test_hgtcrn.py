@@ -225,3 +225,37 @@ def test_gpu_four_second_windows(fixture):
     with _session(fused, W) as sess:
         assert sess.frames == 251
         _run_and_check(sess, fused, pcm, W, 1, True, 3)
+
+
+GOLD_RS = os.path.join(HERE, "golden", "hgtcrn_seed0_resample.npz")
+
+
+@pytest.mark.parametrize("tag", ["down", "up"])
+def test_resampling_edges_oracle(fixture, tag):
+    """24 kHz -> 16 kHz -> 8 kHz (interpolations before the scalings) and 8 kHz -> 16 kHz -> 48 kHz (after them), reference-run fixture;
+    downstream of the reference's WPE tap, as above."""
+    _, fused = fixture
+    z = np.load(GOLD_RS)
+    in_rate, out_rate = (int(v) for v in z[tag + "_rates"])
+    out = _oracle(fused, 8192).process_resampled(z[tag + "_pcm_in"][None], in_rate, out_rate, inject_wpe=(z[tag + "_wpe_r"], z[tag + "_wpe_i"]))[0]
+    d = out.astype(np.int32) - z[tag + "_pcm_out"].astype(np.int32)
+    assert out.shape == z[tag + "_pcm_out"].shape and np.abs(d).max() <= 1 and (d != 0).mean() < 0.02, (np.abs(d).max(), (d != 0).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["down", "up"])
+def test_gpu_resampling_edges(fixture, tag):
+    _, fused = fixture
+    z = np.load(GOLD_RS)
+    in_rate, out_rate = (int(v) for v in z[tag + "_rates"])
+    pcm = z[tag + "_pcm_in"][None]
+    with _session(fused, pcm.shape[2], in_sample_rate=in_rate, out_sample_rate=out_rate) as sess:
+        assert sess.in_len == pcm.shape[2] and sess.out_len == z[tag + "_pcm_out"].shape[0] and sess.frames == 33
+        got = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
+        n = 2 * 514 * 33
+        wpe = sess.tap("wpe", n).reshape(1, 2, 2, 257, 33)
+    want = _oracle(fused, 8192, 1, True).process_resampled(pcm, in_rate, out_rate, inject_wpe=(wpe[:, :, 0], wpe[:, :, 1]))
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 3 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
+    ref = z[tag + "_pcm_out"].astype(np.float64)
+    assert np.sqrt(((got[0] - ref) ** 2).mean()) < 0.15 * np.sqrt((ref ** 2).mean())        # end to end: bounded by the ill-conditioned bins

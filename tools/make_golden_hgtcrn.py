@@ -28,12 +28,13 @@ from ref_import import REF_ROOT, _stub_absent_modules, import_stft_process  # no
 L = 16384                                                            # a whole number of hops (Export_H_GTCRN.py:33) -> 65 frames
 
 
-def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5, in_rate: int = 16000, out_rate: int = 16000) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "H-GTCRN", "Export_H_GTCRN.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
-    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds, "IN_SAMPLE_RATE": in_rate,
+            "OUT_SAMPLE_RATE": out_rate}
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -93,7 +94,7 @@ def build(ns, seed, fold_window=0):
     state = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()
              if v.dtype.is_floating_point and not k.endswith("_weight_t") and not k.endswith("_h0") and "zero" not in k}
     net.fuse_bn_()
-    model = ns["H_GTCRN_CUSTOM"](net, stft, istft, wpe, iva, n_fft=512, in_sample_rate=16000, out_sample_rate=16000,
+    model = ns["H_GTCRN_CUSTOM"](net, stft, istft, wpe, iva, n_fft=512, in_sample_rate=ns["IN_SAMPLE_RATE"], out_sample_rate=ns["OUT_SAMPLE_RATE"],
                                  use_batch_fold=bool(fold_window), fold_window=fold_window, model_audio_length=ns["MODEL_AUDIO_LENGTH"],
                                  n_frames=frames, frontend_batch=fb, fold_input_pcm_scale=False, fold_output_pcm_scale=False).eval()
     return model, net, wpe, iva, state
@@ -179,6 +180,32 @@ def fold_fixture(seed=0):
     print("fold out", out.shape, int(np.abs(out).max()))
 
 
+def resample_fixture(seed=0):
+    """The resampling edges (:953-970, :1036-1052) with the same seeded network: 24 kHz in / 8 kHz out (both interpolations BEFORE the scale /
+    centring and the PCM scale) and 8 kHz in / 48 kHz out (both AFTER); model length 8192 samples = 33 frames in either case."""
+    z = np.load(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}.npz"))
+    out = {}
+    for tag, in_rate, out_rate, length in (("down", 24000, 8000, 12288), ("up", 8000, 48000, 4096)):
+        ns = import_namespace(length, in_rate=in_rate, out_rate=out_rate)
+        assert ns["MODEL_AUDIO_LENGTH"] == 8192 and ns["MAX_SIGNAL_LENGTH"] == 33
+        model, _, wpe, *_ = build(ns, seed)
+        taps = {}
+        orig = wpe.forward
+        def tapped(*a, orig=orig, taps=taps):
+            y = orig(*a)
+            taps["wpe"] = [t.clone().numpy() for t in y]
+            return y
+        wpe.forward = tapped
+        pcm = np.ascontiguousarray(z["pcm_in"][1 if tag == "down" else 2][:, 1000:1000 + length])
+        with torch.inference_mode():
+            y = model(torch.from_numpy(pcm.reshape(1, 2, -1).copy())).numpy().reshape(-1)
+        out.update({f"{tag}_pcm_in": pcm, f"{tag}_pcm_out": y, f"{tag}_wpe_r": taps["wpe"][0], f"{tag}_wpe_i": taps["wpe"][1],
+                    f"{tag}_rates": np.array([in_rate, out_rate], np.int64)})
+        print(tag, "in", pcm.shape, "out", y.shape, int(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}_resample.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
     fold_fixture()
+    resample_fixture()
