@@ -31,7 +31,19 @@ __global__ __launch_bounds__(256) void k_pcm_mean(const int16_t* __restrict__ pc
     const int16_t* base = pcm + (size_t)blockIdx.x * rows * L;
     const long long n = (long long)rows * L;
     long long s = 0;
-    for (long long i = threadIdx.x; i < n; i += 256) s += (long long)base[i];
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {                 // eight samples per 16-byte load; integer sums are order-free
+        const long long n8 = n >> 3;
+        const int4* v = reinterpret_cast<const int4*>(base);
+        for (long long i = threadIdx.x; i < n8; i += 256) {
+            const int4 q = v[i];
+            const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += (long long)(short)(w[k] & 0xffff) + (long long)(w[k] >> 16);
+        }
+        for (long long i = (n8 << 3) + threadIdx.x; i < n; i += 256) s += (long long)base[i];
+    } else {
+        for (long long i = threadIdx.x; i < n; i += 256) s += (long long)base[i];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
