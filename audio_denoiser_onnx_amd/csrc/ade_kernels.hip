@@ -431,14 +431,25 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
     for (int k = 0; k < 16; ++k) fw[k] = fc[(j & 7) * 17 + k];
     const float fb = fc[(j & 7) * 17 + 16];
     float h = state ? state[(size_t)b * 16 + j] : 0.0f;              // streaming: the hidden state carried from the previous push
-    for (int t = 0; t < T; ++t) {
-        float x[8];
-        ld8(zt + ((size_t)b * T + t) * 8, x);
-        h = g.step(x, h);
-        float a = fb;
+    // the inputs do not depend on h: a 4-slot register ring keeps three frames of loads in flight, so a step costs the recurrence, not a
+    // trip to L2 (the loop was latency-bound on that load: 0.85 us per frame)
+    float xq[4][8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a += fw[k] * __shfl(h, k, 16);
-        if (live && j < 8) at[((size_t)b * T + t) * 8 + j] = sigmoid_f(a);
+    for (int d = 0; d < 3; ++d)
+        if (d < T) ld8(zt + ((size_t)b * T + d) * 8, xq[d]);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                if (t + 3 < T) ld8(zt + ((size_t)b * T + t + 3) * 8, xq[(u + 3) & 3]);
+                h = g.step(xq[u], h);
+                float a = fb;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a += fw[k] * __shfl(h, k, 16);
+                if (live && j < 8) at[((size_t)b * T + t) * 8 + j] = sigmoid_f(a);
+            }
+        }
     }
     if (state && live) state[(size_t)b * 16 + j] = h;
 }
@@ -480,12 +491,21 @@ __global__ __launch_bounds__(256) void k_inter_gru(const float* __restrict__ x, 
     GruLane<8> g;
     g.load(gru + q * 54);
     float h = state ? state[(size_t)sc * kCh + q] : 0.0f;             // streaming: carried per (stream, bin) column
-    for (int t = 0; t < T; ++t) {
-        const size_t pos = ((size_t)b * T + t) * kFw + f;
-        float xv[8];
-        ld8(x + pos * kCh + grp * 8, xv);
-        h = g.step(xv, h);
-        if (live) rnn[pos * kCh + q] = h;
+    float xq[4][8];                                                   // input ring as in k_tra: three frames of loads in flight
+    const float* xb = x + ((size_t)b * T * kFw + f) * kCh + grp * 8;  // frame t at xb + t * kFw * kCh
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < T) ld8(xb + (size_t)d * kFw * kCh, xq[d]);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                if (t + 3 < T) ld8(xb + (size_t)(t + 3) * kFw * kCh, xq[(u + 3) & 3]);
+                h = g.step(xq[u], h);
+                if (live) rnn[(((size_t)b * T + t) * kFw + f) * kCh + q] = h;
+            }
+        }
     }
     if (state && live) state[(size_t)sc * kCh + q] = h;
 }
