@@ -426,14 +426,52 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
     const int b = live ? site : B - 1;
     GruLane<16> g;
     g.load(gru + j * 78);
-    float fw[16];
+    // The 16 hidden values of a site live in one 16-lane DPP row: rotation s delivers the value of lane ks[s] (measured by rotating the lane
+    // number itself, so the rotation's direction convention cannot matter); the recurrent weights are re-ordered to match, and a step
+    // gathers h with 15 row rotations (VALU) instead of 16 ds_bpermutes.
+    int ks[16];
+    ks[0] = j;
+#define ADE_KS(S) ks[S] = (int)row_ror<S>((float)j);
+    ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7) ADE_KS(8) ADE_KS(9) ADE_KS(10) ADE_KS(11) ADE_KS(12) ADE_KS(13) ADE_KS(14) ADE_KS(15)
+#undef ADE_KS
+    float whr[3][16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) fw[k] = fc[(j & 7) * 17 + k];
+    for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+        for (int sft = 0; sft < 16; ++sft) whr[gg][sft] = gru[j * 78 + 24 + gg * 16 + ks[sft]];
+    float hs[16];                                                     // hs[s] = hidden value delivered by rotation s (hs[0] = this lane's own)
+    auto rotate = [&](float hcur) {
+        hs[0] = hcur;
+#define ADE_ROT(S) hs[S] = row_ror<S>(hcur);
+        ADE_ROT(1) ADE_ROT(2) ADE_ROT(3) ADE_ROT(4) ADE_ROT(5) ADE_ROT(6) ADE_ROT(7) ADE_ROT(8) ADE_ROT(9) ADE_ROT(10) ADE_ROT(11) ADE_ROT(12) ADE_ROT(13) ADE_ROT(14) ADE_ROT(15)
+#undef ADE_ROT
+    };
+    auto gru_step = [&](const float* x) {                             // reads hs (rotations of the current h), returns the next h
+        float gi[3], gh[3];
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg) { gi[gg] = g.bi[gg]; gh[gg] = g.bh[gg]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg) gi[gg] += g.wi[gg][k] * x[k];
+#pragma unroll
+        for (int sft = 0; sft < 16; ++sft)
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg) gh[gg] += whr[gg][sft] * hs[sft];
+        const float r = sigmoid_f(gi[0] + gh[0]);
+        const float z = sigmoid_f(gi[1] + gh[1]);
+        const float n = tanh_f(gi[2] + r * gh[2]);
+        return (1.0f - z) * n + z * hs[0];
+    };
+    float fw[16];                                                     // the Linear row of output j & 7, in rotation order as well
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fw[k] = fc[(j & 7) * 17 + ks[k]];
     const float fb = fc[(j & 7) * 17 + 16];
     float h = state ? state[(size_t)b * 16 + j] : 0.0f;              // streaming: the hidden state carried from the previous push
     // the inputs do not depend on h: a 4-slot register ring keeps three frames of loads in flight, so a step costs the recurrence, not a
     // trip to L2 (the loop was latency-bound on that load: 0.85 us per frame)
     float xq[4][8];
+    rotate(h);
 #pragma unroll
     for (int d = 0; d < 3; ++d)
         if (d < T) ld8(zt + ((size_t)b * T + d) * 8, xq[d]);
@@ -443,10 +481,11 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
             const int t = t0 + u;
             if (t < T) {
                 if (t + 3 < T) ld8(zt + ((size_t)b * T + t + 3) * 8, xq[(u + 3) & 3]);
-                h = g.step(xq[u], h);
+                h = gru_step(xq[u]);
+                rotate(h);                                            // feeds this frame's Linear and the next frame's recurrence
                 float a = fb;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a += fw[k] * __shfl(h, k, 16);
+                for (int k = 0; k < 16; ++k) a += fw[k] * hs[k];
                 if (live && j < 8) at[((size_t)b * T + t) * 8 + j] = sigmoid_f(a);
             }
         }
