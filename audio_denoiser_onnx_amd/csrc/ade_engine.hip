@@ -376,7 +376,7 @@ ade_status build_device_constants(ade_engine* e) {
         for (int k = 0; k < 2; ++k) {
             const GtOff& o = *src[k];
             *dst[k] = GtConvW{W + o.pw1, W + o.pw1_b, W + o.dw, W + o.dw_b, W + o.pw2, W + o.pw2_b, W + o.gru, W + o.fc,
-                              o.s1, o.s2, k == 0 ? en_dil[i] : de_dil[i]};
+                              o.s1, o.s2, k == 0 ? en_dil[i] : de_dil[i], W + o.tra_rot};
         }
     }
     for (int i = 0; i < 2; ++i) {

@@ -35,7 +35,7 @@ inline void pack_gru_lane(float* dst, const float* wih, const float* whh, const 
     }
 }
 
-struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc; float s1, s2; };
+struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc, tra_rot; float s1, s2; };
 struct DpOff { size_t intra_gru, inter_gru, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
 
 template <class Loader>
@@ -81,6 +81,18 @@ bool load_gt(Loader& L, Arena& A, const std::string& p, bool deconv, GtOff& o) {
     for (int c = 0; c < 8; ++c) {
         for (int k = 0; k < 16; ++k) A.f[o.fc + c * 17 + k] = fcw[c * 16 + k];
         A.f[o.fc + c * 17 + 16] = fcb[c];
+    }
+    // k_tra gathers the 16 hidden values of a site with DPP row rotations: rotation s hands lane j the value of lane (j + dir * s) & 15
+    {
+        const int dir = dpp_row_ror_direction();
+        if (dir == 0) { if (L.st == ADE_OK) L.st = ADE_ERR_DEVICE; return false; }
+        o.tra_rot = A.alloc(16 * 64);
+        for (int j = 0; j < 16; ++j)
+            for (int sft = 0; sft < 16; ++sft) {
+                const int k = (j + dir * sft) & 15;
+                for (int g = 0; g < 3; ++g) A.f[o.tra_rot + j * 64 + g * 16 + sft] = whh[(g * 16 + j) * 16 + k];
+                A.f[o.tra_rot + j * 64 + 48 + sft] = fcw[(j & 7) * 16 + k];
+            }
     }
     o.s1 = a1[0];
     o.s2 = a2[0];

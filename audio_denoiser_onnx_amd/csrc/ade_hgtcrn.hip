@@ -635,7 +635,7 @@ int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, 
         GtConvW* dst[2] = {&e->en_gt[i], &e->de_gt[i]};
         for (int k = 0; k < 2; ++k) {
             const GtOff& o = *src[k];
-            *dst[k] = GtConvW{Wd + o.pw1, Wd + o.pw1_b, Wd + o.dw, Wd + o.dw_b, Wd + o.pw2, Wd + o.pw2_b, Wd + o.gru, Wd + o.fc, o.s1, o.s2, k == 0 ? en_dil[i] : de_dil[i]};
+            *dst[k] = GtConvW{Wd + o.pw1, Wd + o.pw1_b, Wd + o.dw, Wd + o.dw_b, Wd + o.pw2, Wd + o.pw2_b, Wd + o.gru, Wd + o.fc, o.s1, o.s2, k == 0 ? en_dil[i] : de_dil[i], Wd + o.tra_rot};
         }
     }
     for (int i = 0; i < 2; ++i) {

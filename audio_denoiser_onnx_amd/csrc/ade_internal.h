@@ -68,6 +68,7 @@ struct GtConvW {           // GTConvBlock after BN fold, canonical ("encoder") t
     const float* fc;       // [8][17]         TRA Linear rows (16 w | bias)
     float pw1_slope, dw_slope;
     int dilation;
+    const float* tra_rot;  // [16 lanes][64]  the TRA recurrent rows (3x16) and Linear row (16) of each lane in DPP-rotation order (k_tra)
 };
 
 struct DpW {               // one DPGRNN block
@@ -93,6 +94,10 @@ void launch_conv1(hipStream_t s, const float* e0, ConvW w, float* e1, int nframe
 void launch_gt_pw1(hipStream_t s, View a, View skip, GtConvW w, float* h, int nframes);
 void launch_gt_dw_pw2(hipStream_t s, const float* h, View a, View skip, GtConvW w, float* xn, float* zt, int B, int T, const float* hist = nullptr);
 void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T, float* state = nullptr);
+// +1 if a DPP row_ror:1 hands lane i the value of lane (i + 1) & 15, -1 if of lane (i - 1) & 15 (probed once on the device; the host
+// packs the TRA weights of k_tra in the order the rotations deliver the hidden values).  0 = the probe failed.
+int dpp_row_ror_direction();
+
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes);
 void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state = nullptr);
 void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,

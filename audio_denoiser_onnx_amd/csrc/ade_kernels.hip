@@ -419,26 +419,23 @@ struct GruLane {
 // TRA (Export_GTCRN.py:144-156): zt (B,T,8) -> GRU(8->16) over T -> Linear(16->8) -> sigmoid -> at (B,T,8).
 // 16 lanes per chunk (one per hidden unit), 16 chunks per workgroup.
 __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const float* __restrict__ gru,
-                                             const float* __restrict__ fc, float* __restrict__ at, int B, int T, float* __restrict__ state) {
+                                             const float* __restrict__ fc, const float* __restrict__ tra_rot, float* __restrict__ at, int B, int T,
+                                             float* __restrict__ state) {
     const int site = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int j = threadIdx.x & 15;
     const bool live = site < B;
     const int b = live ? site : B - 1;
     GruLane<16> g;
     g.load(gru + j * 78);
-    // The 16 hidden values of a site live in one 16-lane DPP row: rotation s delivers the value of lane ks[s] (measured by rotating the lane
-    // number itself, so the rotation's direction convention cannot matter); the recurrent weights are re-ordered to match, and a step
-    // gathers h with 15 row rotations (VALU) instead of 16 ds_bpermutes.
-    int ks[16];
-    ks[0] = j;
-#define ADE_KS(S) ks[S] = (int)row_ror<S>((float)j);
-    ADE_KS(1) ADE_KS(2) ADE_KS(3) ADE_KS(4) ADE_KS(5) ADE_KS(6) ADE_KS(7) ADE_KS(8) ADE_KS(9) ADE_KS(10) ADE_KS(11) ADE_KS(12) ADE_KS(13) ADE_KS(14) ADE_KS(15)
-#undef ADE_KS
+    // The 16 hidden values of a site live in one 16-lane DPP row: a step gathers them with 15 row rotations (VALU) instead of 16
+    // ds_bpermutes; the recurrent rows and the Linear row come pre-ordered to the rotations' arrival order (rot: [3][16] | [16], packed by the
+    // host from the probed rotation direction, ade_gtcrn_pack.h).
+    const float* rot = tra_rot + j * 64;
     float whr[3][16];
 #pragma unroll
     for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
-        for (int sft = 0; sft < 16; ++sft) whr[gg][sft] = gru[j * 78 + 24 + gg * 16 + ks[sft]];
+        for (int sft = 0; sft < 16; ++sft) whr[gg][sft] = rot[gg * 16 + sft];
     float hs[16];                                                     // hs[s] = hidden value delivered by rotation s (hs[0] = this lane's own)
     auto rotate = [&](float hcur) {
         hs[0] = hcur;
@@ -465,7 +462,7 @@ __global__ __launch_bounds__(256) void k_tra(const float* __restrict__ zt, const
     };
     float fw[16];                                                     // the Linear row of output j & 7, in rotation order as well
 #pragma unroll
-    for (int k = 0; k < 16; ++k) fw[k] = fc[(j & 7) * 17 + ks[k]];
+    for (int k = 0; k < 16; ++k) fw[k] = rot[48 + k];
     const float fb = fc[(j & 7) * 17 + 16];
     float h = state ? state[(size_t)b * 16 + j] : 0.0f;              // streaming: the hidden state carried from the previous push
     // the inputs do not depend on h: a 4-slot register ring keeps three frames of loads in flight, so a step costs the recurrence, not a
@@ -900,7 +897,29 @@ __global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ 
     }
 }
 
+__global__ void k_probe_row_ror(int* out) {
+    const int lane = threadIdx.x & 15;
+    out[threadIdx.x] = (int)row_ror<1>((float)lane);
+}
+
 }  // namespace
+
+int dpp_row_ror_direction() {
+    static int cached = -2;
+    if (cached != -2) return cached;
+    int* d = nullptr;
+    int h[64] = {};
+    cached = 0;
+    if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return cached;
+    hipLaunchKernelGGL(k_probe_row_ror, dim3(1), dim3(64), 0, nullptr, d);
+    const bool ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return cached;
+    bool up = true, down = true;
+    for (int i = 0; i < 64; ++i) { up = up && h[i] == (((i & 15) + 1) & 15); down = down && h[i] == (((i & 15) + 15) & 15); }
+    cached = up ? 1 : down ? -1 : 0;
+    return cached;
+}
 
 // ---- launchers -------------------------------------------------------------------------------------------
 void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call) {
@@ -957,7 +976,7 @@ void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, Fft
     hipLaunchKernelGGL(k_carry_keep, grid1((long long)B * kHop, 256), dim3(256), 0, s, frames, carry, T, (long long)B * kHop);
 }
 void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int T, float* state) {
-    hipLaunchKernelGGL(k_tra, grid1(B, 16), dim3(256), 0, s, zt, w.gru, w.fc, at, B, T, state);
+    hipLaunchKernelGGL(k_tra, grid1(B, 16), dim3(256), 0, s, zt, w.gru, w.fc, w.tra_rot, at, B, T, state);
 }
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes) {
     hipLaunchKernelGGL(k_intra_gru, grid1(nframes, 16), dim3(256), 0, s, x, gru, rnn, nframes);
