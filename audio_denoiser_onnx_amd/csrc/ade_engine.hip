@@ -382,7 +382,7 @@ ade_status build_device_constants(ade_engine* e) {
     for (int i = 0; i < 2; ++i) {
         const DpOff& o = dpo[i];
         e->dp[i] = DpW{W + o.intra_gru, W + o.inter_gru, W + o.fc[0], W + o.fc_b[0], W + o.ln_w[0], W + o.ln_b[0],
-                       W + o.fc[1], W + o.fc_b[1], W + o.ln_w[1], W + o.ln_b[1]};
+                       W + o.fc[1], W + o.fc_b[1], W + o.ln_w[1], W + o.ln_b[1], W + o.inter_rot};
     }
     return ADE_OK;
 }
@@ -565,7 +565,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         q.begin("intra_gru"); launch_intra_gru(s, x, e->dp[i].intra_gru, e->rnn, nfr); q.end();
         q.begin("fc_ln_res"); launch_fc_ln_res(s, e->rnn, x, e->dp[i].intra_fc, e->dp[i].intra_fc_b, e->dp[i].intra_ln_w,
                                                e->dp[i].intra_ln_b, e->dpm[i], B, T); q.end();
-        q.begin("inter_gru"); launch_inter_gru(s, e->dpm[i], e->dp[i].inter_gru, e->rnn, B, T); q.end();
+        q.begin("inter_gru"); launch_inter_gru(s, e->dpm[i], e->dp[i].inter_gru, e->rnn, B, T, nullptr, e->dp[i].inter_rot); q.end();
         q.begin("fc_ln_res"); launch_fc_ln_res(s, e->rnn, View{e->dpm[i], nullptr}, e->dp[i].inter_fc, e->dp[i].inter_fc_b,
                                                e->dp[i].inter_ln_w, e->dp[i].inter_ln_b, e->dpo[i], B, T); q.end();
         x = View{e->dpo[i], nullptr};
@@ -716,7 +716,7 @@ void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t*
     for (int i = 0; i < 2; ++i) {
         launch_intra_gru(s, x, e->dp[i].intra_gru, st->rnn, nfr);
         launch_fc_ln_res(s, st->rnn, x, e->dp[i].intra_fc, e->dp[i].intra_fc_b, e->dp[i].intra_ln_w, e->dp[i].intra_ln_b, st->dpm[i], B, T);
-        launch_inter_gru(s, st->dpm[i], e->dp[i].inter_gru, st->rnn, B, T, st->inter_h[i]);
+        launch_inter_gru(s, st->dpm[i], e->dp[i].inter_gru, st->rnn, B, T, st->inter_h[i], e->dp[i].inter_rot);
         launch_fc_ln_res(s, st->rnn, View{st->dpm[i], nullptr}, e->dp[i].inter_fc, e->dp[i].inter_fc_b, e->dp[i].inter_ln_w, e->dp[i].inter_ln_b,
                          st->dpo[i], B, T);
         x = View{st->dpo[i], nullptr};

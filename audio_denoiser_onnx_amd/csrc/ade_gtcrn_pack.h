@@ -36,7 +36,7 @@ inline void pack_gru_lane(float* dst, const float* wih, const float* whh, const 
 }
 
 struct GtOff { size_t pw1, pw1_b, dw, dw_b, pw2, pw2_b, gru, fc, tra_rot; float s1, s2; };
-struct DpOff { size_t intra_gru, inter_gru, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
+struct DpOff { size_t intra_gru, inter_gru, inter_rot, fc[2], fc_b[2], ln_w[2], ln_b[2]; };
 
 template <class Loader>
 bool load_gt(Loader& L, Arena& A, const std::string& p, bool deconv, GtOff& o) {
@@ -103,6 +103,9 @@ template <class Loader>
 bool load_dp(Loader& L, Arena& A, const std::string& p, DpOff& o) {
     o.intra_gru = A.alloc(16 * 42);
     o.inter_gru = A.alloc(16 * 54);
+    o.inter_rot = A.alloc(16 * 24);
+    const int dir = dpp_row_ror_direction();
+    if (dir == 0) { if (L.st == ADE_OK) L.st = ADE_ERR_DEVICE; return false; }
     for (int grp = 0; grp < 2; ++grp) {
         const std::string r = p + "intra_rnn.rnn" + std::to_string(grp + 1) + ".";
         for (int dir = 0; dir < 2; ++dir) {
@@ -121,6 +124,11 @@ bool load_dp(Loader& L, Arena& A, const std::string& p, DpOff& o) {
         const float* bhh = L.get(q + "bias_hh_l0", {24});
         if (L.st != ADE_OK) return false;
         for (int j = 0; j < 8; ++j) pack_gru_lane(&A.f[o.inter_gru + (grp * 8 + j) * 54], wih, whh, bih, bhh, 8, j);
+        // k_inter_gru's DPP form: lane = 2 * unit + group, rotation by 2 s hands it the hidden value of unit (unit + dir * s) & 7 of its own group
+        for (int unit = 0; unit < 8; ++unit)
+            for (int g = 0; g < 3; ++g)
+                for (int sft = 0; sft < 8; ++sft)
+                    A.f[o.inter_rot + (2 * unit + grp) * 24 + g * 8 + sft] = whh[(g * 8 + unit) * 8 + ((unit + dir * sft) & 7)];
     }
     const char* part[2] = {"intra", "inter"};
     for (int i = 0; i < 2; ++i) {

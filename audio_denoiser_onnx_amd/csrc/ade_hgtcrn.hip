@@ -640,7 +640,7 @@ int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, 
     }
     for (int i = 0; i < 2; ++i) {
         const DpOff& o = dpo_[i];
-        e->dp[i] = DpW{Wd + o.intra_gru, Wd + o.inter_gru, Wd + o.fc[0], Wd + o.fc_b[0], Wd + o.ln_w[0], Wd + o.ln_b[0], Wd + o.fc[1], Wd + o.fc_b[1], Wd + o.ln_w[1], Wd + o.ln_b[1]};
+        e->dp[i] = DpW{Wd + o.intra_gru, Wd + o.inter_gru, Wd + o.fc[0], Wd + o.fc_b[0], Wd + o.ln_w[0], Wd + o.ln_b[0], Wd + o.fc[1], Wd + o.fc_b[1], Wd + o.ln_w[1], Wd + o.ln_b[1], Wd + o.inter_rot};
     }
     const size_t wpe_lds = (size_t)(5 * T + 2 * kTaps * kTaps + 6 * 72) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hg_wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wpe_lds);
@@ -722,7 +722,7 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     for (int i = 0; i < 2; ++i) {
         launch_intra_gru(s, x, dp[i].intra_gru, rnn, nfr);
         launch_fc_ln_res(s, rnn, x, dp[i].intra_fc, dp[i].intra_fc_b, dp[i].intra_ln_w, dp[i].intra_ln_b, dpm, B, T);
-        launch_inter_gru(s, dpm, dp[i].inter_gru, rnn, B, T);
+        launch_inter_gru(s, dpm, dp[i].inter_gru, rnn, B, T, nullptr, dp[i].inter_rot);
         launch_fc_ln_res(s, rnn, View{dpm, nullptr}, dp[i].inter_fc, dp[i].inter_fc_b, dp[i].inter_ln_w, dp[i].inter_ln_b, dpo[i], B, T);
         x = View{dpo[i], nullptr};
     }

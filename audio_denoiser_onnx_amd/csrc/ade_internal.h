@@ -82,6 +82,7 @@ struct DpW {               // one DPGRNN block
     const float* inter_fc_b;
     const float* inter_ln_w;
     const float* inter_ln_b;
+    const float* inter_rot;   // [16 lanes][24]   lane = 2 * unit + group: the 3 x 8 recurrent rows in DPP-rotation order (k_inter_gru)
 };
 
 // ---- launchers (ade_kernels.hip) ---------------------------------------------------------------------------
@@ -99,7 +100,7 @@ void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int
 int dpp_row_ror_direction();
 
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes);
-void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state = nullptr);
+void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state = nullptr, const float* rot = nullptr);
 void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,
                       const float* ln_b, float* out, int B, int T);
 void launch_deconv3(hipStream_t s, View a, View skip, ConvW w, float* d3, int nframes);

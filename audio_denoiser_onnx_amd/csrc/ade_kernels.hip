@@ -546,6 +546,65 @@ __global__ __launch_bounds__(256) void k_inter_gru(const float* __restrict__ x, 
     if (state && live) state[(size_t)sc * kCh + q] = h;
 }
 
+// The same recurrence with the hidden state gathered by DPP row rotations (callers that pack `rot`, DpW::inter_rot): lane = 2 * unit + group
+// inside the site's 16-lane row, so a rotation by 2 s stays inside the lane's own group and the 8 hidden values arrive by 7 rotations (VALU)
+// instead of 8 ds_bpermutes; rot holds each lane's 3 x 8 recurrent rows in the rotations' arrival order.
+__global__ __launch_bounds__(256) void k_inter_gru_rot(const float* __restrict__ x, const float* __restrict__ gru, const float* __restrict__ rot,
+                                                       float* __restrict__ rnn, int B, int T, float* __restrict__ state) {
+    const int site = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 15;
+    const int grp = lane & 1, unit = lane >> 1, q = grp * 8 + unit;   // q = output channel = packed row of the input weights / biases
+    const bool live = site < B * kFw;
+    const int sc = live ? site : B * kFw - 1;
+    const int b = sc / kFw, f = sc - b * kFw;
+    const float* pk = gru + q * 54;
+    float wi[3][8], whr[3][8], bi[3], bh[3];
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { wi[gg][k] = pk[gg * 8 + k]; whr[gg][k] = rot[lane * 24 + gg * 8 + k]; }
+        bi[gg] = pk[48 + gg];
+        bh[gg] = pk[51 + gg];
+    }
+    float h = state ? state[(size_t)sc * kCh + q] : 0.0f;
+    float xq[4][8];
+    const float* xb = x + ((size_t)b * T * kFw + f) * kCh + grp * 8;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (d < T) ld8(xb + (size_t)d * kFw * kCh, xq[d]);
+    for (int t0 = 0; t0 < T; t0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                if (t + 3 < T) ld8(xb + (size_t)(t + 3) * kFw * kCh, xq[(u + 3) & 3]);
+                float hs[8];
+                hs[0] = h;
+#define ADE_ROT(S) hs[S] = row_ror<2 * S>(h);
+                ADE_ROT(1) ADE_ROT(2) ADE_ROT(3) ADE_ROT(4) ADE_ROT(5) ADE_ROT(6) ADE_ROT(7)
+#undef ADE_ROT
+                float gi[3], gh[3];
+#pragma unroll
+                for (int gg = 0; gg < 3; ++gg) { gi[gg] = bi[gg]; gh[gg] = bh[gg]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int gg = 0; gg < 3; ++gg) gi[gg] += wi[gg][k] * xq[u][k];
+#pragma unroll
+                for (int sft = 0; sft < 8; ++sft)
+#pragma unroll
+                    for (int gg = 0; gg < 3; ++gg) gh[gg] += whr[gg][sft] * hs[sft];
+                const float r = sigmoid_f(gi[0] + gh[0]);
+                const float z = sigmoid_f(gi[1] + gh[1]);
+                const float n = tanh_f(gi[2] + r * gh[2]);
+                h = (1.0f - z) * n + z * h;
+                if (live) rnn[(((size_t)b * T + t) * kFw + f) * kCh + q] = h;
+            }
+        }
+    }
+    if (state && live) state[(size_t)sc * kCh + q] = h;
+}
+
 // Linear(16,16) + LayerNorm((33,16), eps 1e-8, affine) + residual (Export_GTCRN.py:447-448,473-475,479-481).
 // Workgroup = 7 frames x 33 bins; two-pass moments (mean, then centred sum of squares) through LDS.
 __global__ __launch_bounds__(256) void k_fc_ln_res(const float* __restrict__ rnn, View res, const float* __restrict__ fc,
@@ -981,8 +1040,9 @@ void launch_tra(hipStream_t s, const float* zt, GtConvW w, float* at, int B, int
 void launch_intra_gru(hipStream_t s, View x, const float* gru, float* rnn, int nframes) {
     hipLaunchKernelGGL(k_intra_gru, grid1(nframes, 16), dim3(256), 0, s, x, gru, rnn, nframes);
 }
-void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state) {
-    hipLaunchKernelGGL(k_inter_gru, grid1((long long)B * kFw, 16), dim3(256), 0, s, x, gru, rnn, B, T, state);
+void launch_inter_gru(hipStream_t s, const float* x, const float* gru, float* rnn, int B, int T, float* state, const float* rot) {
+    if (rot) hipLaunchKernelGGL(k_inter_gru_rot, grid1((long long)B * kFw, 16), dim3(256), 0, s, x, gru, rot, rnn, B, T, state);
+    else hipLaunchKernelGGL(k_inter_gru, grid1((long long)B * kFw, 16), dim3(256), 0, s, x, gru, rnn, B, T, state);
 }
 void launch_fc_ln_res(hipStream_t s, const float* rnn, View res, const float* fc, const float* fc_b, const float* ln_w,
                       const float* ln_b, float* out, int B, int T) {
