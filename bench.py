@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed power-state ramp before the W warm-up steps (0 = none)")
     return ap.parse_args()
 
 
@@ -146,6 +147,15 @@ def main():
         if gathered is not None:
             stitch_device(d_out, gathered)
 
+    # Power-state ramp (untimed, disclosed in config.clock_ramp_ms): after process start the GPU needs tens of milliseconds of work before its
+    # clocks settle, far more than W = 10 steps of 0.4 ms; without it the first timed steps run at a lower clock and the result depends on
+    # how long the process has been alive.  The W warm-up steps and the K timed steps below are unchanged.
+    if args.ramp_ms > 0:
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -242,7 +252,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
                                    "(BASELINE.json configs[1])",
-                       "chunks_per_gpu": B, "chunk_samples": CHUNK, "out_samples": sess.out_len,
+                       "chunks_per_gpu": B, "chunk_samples": CHUNK, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
                        "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)",
                        "launch": "one kernel per step (k_gtcrn_chunk), plain launch" if not args.no_graph else "one kernel per step, hipGraph disabled",
                        "stitch_all_gather": bool(gathered is not None)},
