@@ -9,6 +9,7 @@
 
 #include "../../include/ade.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +51,7 @@ struct ade_engine {
     std::vector<float> blob_storage;
     std::map<std::string, Tensor> tensors;
 
+    std::vector<struct ade_stream*> live_streams;   // streams created on this engine: ade_destroy releases their device state and orphans them
     ade::SubEngine* sub = nullptr;        // model_family "dfsmn" / "mel_band_roformer": a sub-engine (everything below is GTCRN's)
     int channels = 1, out_channels = 1, n_outputs = 1;   // in_len / out_len below count one batch item: channels * samples in, n_outputs * out_channels * samples out
     // driver-edge resampling around a sub-engine (in / out sample rate != model rate): caller-side lengths above, model-side below
@@ -223,6 +225,7 @@ ade_status parse_blob(ade_engine* e, const void* blob, size_t nbytes) {
             memcpy(&v, p + pos, 4);
             pos += 4;
             en.dims.push_back((int)v);
+            if (v != 0 && en.count > (size_t)0x3fffffffffffull / v) return fail(e, ADE_ERR_BAD_VALUE, "weights: tensor too large " + en.name);
             en.count *= v;
         }
         memcpy(&en.off, p + pos, 8);
@@ -232,12 +235,16 @@ ade_status parse_blob(ade_engine* e, const void* blob, size_t nbytes) {
         ents.push_back(en);
     }
     const size_t data0 = (pos + 63) & ~(size_t)63;
+    if (data0 > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: truncated header");
+    const size_t avail = nbytes - data0;
     size_t total = 0;
-    for (auto& en : ents) total += en.count;
+    for (auto& en : ents) {
+        if (en.off > avail || en.nb > avail - en.off) return fail(e, ADE_ERR_BAD_VALUE, "weights: data out of range " + en.name);
+        total += en.count;
+    }
     e->blob_storage.resize(total + 1);
     size_t w = 0;
     for (auto& en : ents) {
-        if (data0 + en.off + en.nb > nbytes) return fail(e, ADE_ERR_BAD_VALUE, "weights: data out of range " + en.name);
         memcpy(e->blob_storage.data() + w, p + data0 + en.off, en.nb);
         Tensor t;
         t.dims = en.dims;
@@ -667,7 +674,8 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
 }  // namespace
 
 struct ade_stream {
-    ade_engine* e = nullptr;
+    ade_engine* e = nullptr;     // nullptr once the engine has been destroyed (orphan: every call but destroy answers BAD_VALUE)
+    int device = 0;
     int S = 0, N = 0;
     bool first = true, flushed = false;
     int16_t *pcm_prev = nullptr, *pcm_hist = nullptr, *concat = nullptr, *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
@@ -795,7 +803,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (rates_differ) {   // MODEL_AUDIO_LENGTH = round(L * model / in) (:36); batch-fold needs equal rates (:92-93)
             if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
             Ld = fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
-                        : (long)llround((double)caller_len * (double)srm / (double)sri);
+                        : (long)nearbyint((double)caller_len * (double)srm / (double)sri)   /* Python round(): half to even */;
         }
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
             long fw = 0;    //                                                            (Export_MelBandRoformer.py:47-51, 644-647)
@@ -849,7 +857,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                 e->rs_scale_out = (float)((double)srm / (double)sro);
                 e->sub->float_src_len = (int)caller_len;
             } else {
-                out_caller = (long)llround((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
+                out_caller = (long)nearbyint((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
                 e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);
                 e->rs_scale_out = (float)((double)e->rs_model_out / (double)out_caller);
             }
@@ -1124,12 +1132,15 @@ ade_status ade_kernel_ms(ade_handle h, int i, float* total_ms, int* launches) {
 
 const char* ade_last_error(ade_handle h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
 
+static void ade_orphan_streams(ade_handle h);
+
 void ade_destroy(ade_handle h) {
     if (!h) return;
     if (h->stream) {
         hipSetDevice(h->device);
         hipStreamSynchronize(h->stream);
     }
+    ade_orphan_streams(h);
     free_workspace(h);
     delete h->sub;
     for (auto& ev : h->events) {
@@ -1184,7 +1195,7 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
         return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_create: need n_streams >= 1 and 2 <= frames_per_push <= 4096 (the first push reflects 257 samples)");
     HIP_TRY(h, hipSetDevice(h->device));
     ade_stream* st = new ade_stream();
-    st->e = h; st->S = n_streams; st->N = frames_per_push;
+    st->e = h; st->device = h->device; st->S = n_streams; st->N = frames_per_push;
     const size_t S = (size_t)n_streams, nfr = S * frames_per_push, P = (size_t)frames_per_push * kHop;
     auto bail = [&](const char* what) { h->last_error = what; ade_stream_destroy(st); return ADE_ERR_DEVICE; };
     // state
@@ -1227,12 +1238,18 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
         hipHostMalloc((void**)&st->h_out, S * P * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&st->h_f32, S * P * sizeof(float), hipHostMallocDefault) != hipSuccess)
         return bail("ade_stream_create: allocation of the PCM staging buffers failed");
+    h->live_streams.push_back(st);
+    const ade_status rc = ade_stream_reset(st);
+    if (rc != ADE_OK) {
+        ade_stream_destroy(st);
+        return rc;
+    }
     *out = st;
-    return ade_stream_reset(st);
+    return ADE_OK;
 }
 
 ade_status ade_stream_reset(ade_stream_handle st) {
-    if (!st) return ADE_ERR_BAD_VALUE;
+    if (!st || !st->e) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1246,7 +1263,7 @@ ade_status ade_stream_reset(ade_stream_handle st) {
 }
 
 ade_status ade_stream_push_device(ade_stream_handle st, const int16_t* d_in, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream) {
-    if (!st || !d_in || (!d_out_pcm && !d_out_f32)) return ADE_ERR_BAD_VALUE;
+    if (!st || !st->e || !d_in || (!d_out_pcm && !d_out_f32)) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
     if (st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_push: the stream was flushed; reset it first");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1258,7 +1275,7 @@ ade_status ade_stream_push_device(ade_stream_handle st, const int16_t* d_in, int
 }
 
 ade_status ade_stream_push(ade_stream_handle st, const int16_t* in, int16_t* out_pcm, float* out_f32) {
-    if (!st || !in || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
+    if (!st || !st->e || !in || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
     if (st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_push: the stream was flushed; reset it first");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1276,7 +1293,7 @@ ade_status ade_stream_push(ade_stream_handle st, const int16_t* in, int16_t* out
 }
 
 ade_status ade_stream_flush(ade_stream_handle st, int16_t* out_pcm, float* out_f32) {
-    if (!st || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
+    if (!st || !st->e || (!out_pcm && !out_f32)) return ADE_ERR_BAD_VALUE;
     ade_engine* h = st->e;
     if (st->first || st->flushed) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_flush: nothing to flush (no push since the last reset, or already flushed)");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1292,9 +1309,9 @@ ade_status ade_stream_flush(ade_stream_handle st, int16_t* out_pcm, float* out_f
     return ADE_OK;
 }
 
-void ade_stream_destroy(ade_stream_handle st) {
-    if (!st) return;
-    (void)hipSetDevice(st->e->device);
+namespace {
+void release_stream_buffers(ade_stream* st) {
+    (void)hipSetDevice(st->device);
     (void)hipDeviceSynchronize();
     if (st->state) (void)hipFree(st->state);
     if (st->ws) (void)hipFree(st->ws);
@@ -1307,7 +1324,29 @@ void ade_stream_destroy(ade_stream_handle st) {
     if (st->h_in) (void)hipHostFree(st->h_in);
     if (st->h_out) (void)hipHostFree(st->h_out);
     if (st->h_f32) (void)hipHostFree(st->h_f32);
+    st->state = st->ws = nullptr;
+    st->pcm_hist = st->pcm_prev = st->concat = st->d_in = st->d_out = st->h_in = st->h_out = nullptr;
+    st->d_f32 = st->h_f32 = nullptr;
+}
+}  // namespace
+
+void ade_stream_destroy(ade_stream_handle st) {
+    if (!st) return;
+    if (st->e) {                 // still attached: release the device state and leave the engine's list
+        release_stream_buffers(st);
+        auto& v = st->e->live_streams;
+        v.erase(std::remove(v.begin(), v.end(), st), v.end());
+    }
     delete st;
+}
+
+// called by ade_destroy: the engine goes away first -> its streams keep only their shell (the caller still owns the handle)
+static void ade_orphan_streams(ade_handle h) {
+    for (ade_stream* st : h->live_streams) {
+        release_stream_buffers(st);
+        st->e = nullptr;
+    }
+    h->live_streams.clear();
 }
 
 }  // extern "C"

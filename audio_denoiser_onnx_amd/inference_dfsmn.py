@@ -16,7 +16,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .inference_gtcrn import denoise, normalise_audio, plan_slices, read_wav_int16, write_wav_int16
+from .inference_gtcrn import denoise, example_audio, normalise_audio, plan_slices, read_wav_int16, write_wav_int16
 from .metadata import runtime_config_from_metadata
 from .session import InferenceSession
 
@@ -33,7 +33,7 @@ def main(argv=None) -> int:
         print(__doc__)
         return 2
     here = Path(__file__).resolve().parent
-    noisy = Path(argv[1]) if len(argv) > 1 else Path("/root/reference/Test_Examples/denoise/speech_with_noise_48k.wav")
+    noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "speech_with_noise_48k.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_dfsmn.wav"
     session = InferenceSession(argv[0])
     if session.metadata.metadata.get("model_family") != "dfsmn":
@@ -42,9 +42,10 @@ def main(argv=None) -> int:
     print(f"\nUsable Providers: {session.get_providers()}\n\nTest Input Audio: {noisy}")
     audio = normalise_audio(read_wav_int16(noisy, cfg["IN_SAMPLE_RATE"]), cfg["NORMALIZE_AUDIO"], cfg["NORMALIZE_TARGET_RMS"])
     print("\nRunning the DFSMN on the MI355X engine.")
-    session.reserve(plan_slices(len(audio), session.in_len, session.out_len)[1])
+    session.reserve(plan_slices(len(audio), session.in_len, session.out_len, out_stride=False)[1])
+    fold_active = bool(session.metadata.optional_bool("use_batch_fold", False))      # zeros under batch-fold (:292-295, :300-302)
     t0 = time.time()
-    denoised = denoise(session, audio, tail_pad="noise", rng=np.random.default_rng(seed))
+    denoised = denoise(session, audio, tail_pad="zeros" if fold_active else "noise", rng=np.random.default_rng(seed), family="dfsmn")
     elapsed = time.time() - t0
     write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])
     duration = len(denoised) / cfg["OUT_SAMPLE_RATE"]

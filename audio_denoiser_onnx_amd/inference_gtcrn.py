@@ -31,6 +31,19 @@ from .session import InferenceSession
 NORMALIZE_TARGET_RMS = 4096.0
 
 
+def example_audio(task: str, name: str) -> Path:
+    """Default test clip of a driver, like the reference's ``Example_Audio.py`` registry: ``<ADE_TEST_EXAMPLES or
+    ./Test_Examples>/<task>/<name>``.  The clips belong to the reference checkout; nothing of it is bundled here, so a
+    missing file is a plain ``FileNotFoundError`` asking for an explicit path."""
+    import os
+    root = Path(os.environ.get("ADE_TEST_EXAMPLES", "Test_Examples"))
+    p = root / task / name
+    if not p.exists():
+        raise FileNotFoundError(f"default example clip {p} not found: pass the wav path explicitly or set ADE_TEST_EXAMPLES "
+                                f"to the reference's Test_Examples directory")
+    return p
+
+
 def read_wav_int16(path, sample_rate: int) -> np.ndarray:
     """Mono int16 at ``sample_rate`` — what ``AudioSegment.from_file(..).set_channels(1).set_frame_rate(sr)`` yields
     (Inference_GTCRN_ONNX.py:272).  Multi-channel files are averaged; other rates are not resampled here."""
@@ -66,24 +79,43 @@ def normalise_audio(audio: np.ndarray, enable: bool, target_rms: float = NORMALI
     return x.astype(np.int16)
 
 
-def plan_slices(audio_len: int, in_len: int, out_len: int) -> Tuple[int, int, int]:
-    """(stride, number of slices, zero-padded length) exactly as Inference_GTCRN_ONNX.py:287-299 computes them."""
+def plan_slices(audio_len: int, in_len: int, out_len: int, out_stride: bool = True) -> Tuple[int, int, int]:
+    """(stride, number of slices, zero-padded length) exactly as Inference_GTCRN_ONNX.py:287-299 computes them.
+    ``out_stride``: whether a graph whose output is shorter than its input is stepped by the OUTPUT length.  The GTCRN
+    driver does that only when IN_SAMPLE_RATE == OUT_SAMPLE_RATE (:289: a hop-truncated output, not a resampled one);
+    the DFSMN / MossFormer2 drivers always step by the input length (DFSMN/Inference_DFSMN_ONNX.py:289-291)."""
     stride = in_len
     if audio_len > in_len:
-        if in_len != out_len:
+        if in_len != out_len and out_stride:
             stride = out_len
         n = int(np.ceil((audio_len - in_len) / stride)) + 1
         return stride, n, (n - 1) * stride + in_len
     return stride, 1, in_len
 
 
-def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "zeros", rng=None) -> Tuple[np.ndarray, int]:
+def output_length(audio_len: int, in_rate: int, out_rate: int, rounded: bool = False) -> int:
+    """Length the concatenated output is trimmed to, in OUTPUT samples: ``int(audio_len * OUT / IN)`` in the GTCRN /
+    H-GTCRN drivers (Inference_GTCRN_ONNX.py:303), ``int(round(audio_len * INPUT_TO_OUTPUT_SCALE))`` in the DFSMN /
+    MossFormer2 drivers (DFSMN/Inference_DFSMN_ONNX.py:312)."""
+    if in_rate == out_rate or in_rate <= 0:
+        return int(audio_len)
+    x = audio_len * (float(out_rate) / float(in_rate)) if rounded else audio_len * out_rate / in_rate
+    return int(round(x)) if rounded else int(x)
+
+
+def session_rates(session) -> Tuple[int, int]:
+    """(IN_SAMPLE_RATE, OUT_SAMPLE_RATE) of a session; objects without the attributes count as equal-rate."""
+    return int(getattr(session, "in_sample_rate", 0)), int(getattr(session, "out_sample_rate", 0))
+
+
+def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "zeros", rng=None,
+               out_stride: bool = True) -> Tuple[np.ndarray, int]:
     """Slices exactly as the reference drivers cut them.  ``tail_pad``: ``"zeros"`` (GTCRN / ZipEnhancer,
     Inference_GTCRN_ONNX.py:291-299) or ``"noise"`` -- Gaussian noise scaled to the RMS of the last ``pad`` samples (of
     the whole file when it is shorter than one slice), the reference's policy for DFSMN / Mel-Band / MossFormer2 when
     batch-fold is inactive (DFSMN/Inference_DFSMN_ONNX.py:292-305).  The reference draws that noise unseeded; pass a
     ``numpy.random.Generator`` as ``rng`` for a reproducible run (it only affects the last, partial slice)."""
-    stride, n, total = plan_slices(len(audio), in_len, out_len)
+    stride, n, total = plan_slices(len(audio), in_len, out_len, out_stride)
     padded = np.zeros(total, np.int16)
     padded[: len(audio)] = audio
     pad = total - len(audio)
@@ -98,10 +130,14 @@ def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "ze
 
 
 def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = False, rank: int = 0, world: int = 1,
-            group=None, tail_pad: str = "zeros", rng=None) -> np.ndarray:
-    """int16 mono waveform in -> int16 denoised waveform out (length preserved)."""
-    audio_len = len(audio)
-    slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng)
+            group=None, tail_pad: str = "zeros", rng=None, family: str = "gtcrn") -> np.ndarray:
+    """int16 mono waveform in -> int16 denoised waveform out: the input's duration at the OUTPUT sample rate.
+    ``family`` selects the reference driver whose stride / trim rules apply (``"gtcrn"`` or ``"dfsmn"``)."""
+    in_rate, out_rate = session_rates(session)
+    dfsmn = family == "dfsmn"
+    audio_len = output_length(len(audio), in_rate, out_rate, rounded=dfsmn)
+    slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng,
+                           out_stride=(not dfsmn) and in_rate == out_rate)
     lo, hi = shard_bounds(len(slices), world, rank)
     mine = slices[lo:hi]
     if sequential:
@@ -143,8 +179,7 @@ def main(argv=None) -> int:
         return 2
     model = argv[0]
     here = Path(__file__).resolve().parent
-    default_in = Path("/root/reference/Test_Examples/denoise/gtcrn_mix.wav")   # Example_Audio.py registry entry "gtcrn"
-    noisy = Path(argv[1]) if len(argv) > 1 else default_in
+    noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "gtcrn_mix.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised.wav"
 
     session = InferenceSession(model)
@@ -154,7 +189,7 @@ def main(argv=None) -> int:
     audio = read_wav_int16(noisy, cfg["IN_SAMPLE_RATE"])
     audio = normalise_audio(audio, cfg["NORMALIZE_AUDIO"], cfg["NORMALIZE_TARGET_RMS"])
     print("\nRunning the GTCRN on the MI355X engine.")
-    session.reserve(plan_slices(len(audio), session.in_len, session.out_len)[1])
+    session.reserve(plan_slices(len(audio), session.in_len, session.out_len, cfg["IN_SAMPLE_RATE"] == cfg["OUT_SAMPLE_RATE"])[1])
     t0 = time.time()
     denoised = denoise_streaming(session, audio, stream_frames) if stream_frames else denoise(session, audio, sequential=sequential)
     elapsed = time.time() - t0

@@ -18,7 +18,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .inference_gtcrn import normalise_audio
+from .inference_gtcrn import example_audio, normalise_audio, output_length, session_rates, plan_slices
 from .inference_melband import load_stereo
 from .metadata import runtime_config_from_metadata
 from .session import InferenceSession
@@ -40,18 +40,25 @@ def pad_tail(audio: np.ndarray, target: int, fold_active: bool) -> np.ndarray:
     return np.concatenate((audio, block.astype(audio.dtype, copy=False)), axis=-1)
 
 
-def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool) -> np.ndarray:
-    """(2, n) -> (n_slices, 2, in_len), stride in_len (input and output lengths are equal: the length is whole hops)."""
-    n_slices = max(1, -(-audio.shape[1] // in_len))
-    audio = pad_tail(audio, n_slices * in_len, fold_active)
-    return np.ascontiguousarray(audio.reshape(audio.shape[0], n_slices, in_len).transpose(1, 0, 2))
+def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool, out_len: int = 0, rates_equal: bool = True) -> np.ndarray:
+    """(2, n) -> (n_slices, 2, in_len).  Stride = the graph's OUTPUT length when it is a hop-truncated copy of the input
+    length at the same rate, else the input length.  (The reference's H-GTCRN driver takes the output-length stride
+    whenever the two lengths differ, :341-343, without the GTCRN driver's IN == OUT rate condition; with resampling
+    edges that would skip input samples, so the GTCRN driver's condition is applied here.)"""
+    stride, n_slices, total = plan_slices(audio.shape[1], in_len, out_len or in_len, out_stride=rates_equal)
+    audio = pad_tail(audio, total, fold_active)
+    idx = np.arange(n_slices)[:, None] * stride + np.arange(in_len)[None, :]
+    return np.ascontiguousarray(audio[:, idx].transpose(1, 0, 2))
 
 
 def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool) -> np.ndarray:
-    """(2, n) int16 -> (n,) int16: every slice of the file in one batched call."""
-    slices = cut_slices(audio, session.in_len, fold_active)
+    """(2, n) int16 -> int16 mono of the input's duration at the OUTPUT rate (``int(n * OUT / IN)`` samples, :352):
+    every slice of the file in one batched call."""
+    in_rate, out_rate = session_rates(session)
+    slices = cut_slices(audio, session.in_len, fold_active, session.out_len, in_rate == out_rate)
     out = session.run(None, {session.get_inputs()[0].name: slices})[0]                     # (n_slices, 1, out_len)
-    return np.ascontiguousarray(out.reshape(-1)[:audio.shape[1]])
+    n_out = output_length(audio.shape[1], in_rate, out_rate)
+    return np.ascontiguousarray(out.reshape(-1)[:n_out])
 
 
 def main(argv=None) -> int:
@@ -60,7 +67,7 @@ def main(argv=None) -> int:
         print(__doc__)
         return 2
     here = Path(__file__).resolve().parent
-    noisy = Path(argv[1]) if len(argv) > 1 else Path("/root/reference/Test_Examples/denoise/h_gtcrn_noisy.wav")
+    noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "h_gtcrn_noisy.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_hgtcrn.wav"
     session = InferenceSession(argv[0])
     if session.metadata.metadata.get("model_family") != "h_gtcrn":

@@ -18,7 +18,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .inference_gtcrn import normalise_audio
+from .inference_gtcrn import example_audio, normalise_audio
 from .metadata import runtime_config_from_metadata
 from .session import InferenceSession
 from .wavio import read_pcm16, write_pcm16
@@ -72,7 +72,7 @@ def main(argv=None) -> int:
         print(__doc__)
         return 2
     here = Path(__file__).resolve().parent
-    noisy = Path(argv[1]) if len(argv) > 1 else Path("/root/reference/Test_Examples/denoise/mel_band_roformer.wav")
+    noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "mel_band_roformer.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_melband.wav"
     session = InferenceSession(argv[0])
     if session.metadata.metadata.get("model_family") != "mel_band_roformer":

@@ -17,7 +17,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .inference_gtcrn import normalise_audio, read_wav_int16
+from .inference_gtcrn import example_audio, normalise_audio, output_length, session_rates, read_wav_int16
 from .metadata import runtime_config_from_metadata
 from .session import InferenceSession
 from .wavio import write_pcm16
@@ -45,7 +45,10 @@ def separate(session: InferenceSession, audio: np.ndarray, pad_head: int, fold_a
     padded = np.concatenate((np.zeros(pad_head, audio.dtype), audio))
     slices = cut_slices(padded, session.in_len, fold_active, rng)
     outs = session.run(None, {session.get_inputs()[0].name: slices[:, None, :]})
-    return [np.ascontiguousarray(o.reshape(-1)[pad_head:len(padded)]) for o in outs]
+    in_rate, out_rate = session_rates(session)
+    head_out = output_length(pad_head, in_rate, out_rate, rounded=True)          # pad_head_out, out_audio_len (:308-309)
+    end_out = output_length(len(padded), in_rate, out_rate, rounded=True)
+    return [np.ascontiguousarray(o.reshape(-1)[head_out:end_out]) for o in outs]
 
 
 def main(argv=None) -> int:
@@ -60,7 +63,7 @@ def main(argv=None) -> int:
         print(__doc__)
         return 2
     here = Path(__file__).resolve().parent
-    mix = Path(argv[1]) if len(argv) > 1 else Path("/root/reference/Test_Examples/separation/mixed_speech.wav")
+    mix = Path(argv[1]) if len(argv) > 1 else example_audio("separation", "mixed_speech.wav")
     prefix = Path(argv[2]) if len(argv) > 2 else here / "separated"
     session = InferenceSession(argv[0])
     if session.metadata.metadata.get("model_family") != "mossformer2_ss":

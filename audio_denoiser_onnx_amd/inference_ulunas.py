@@ -26,7 +26,7 @@ def main(argv=None) -> int:
     if family != "ul_unas":
         raise ValueError(f"this driver expects a model_family=ul_unas manifest, got {family!r}")
     if len(args) == 1:
-        argv = argv + ["/root/reference/Test_Examples/denoise/ul_unas_0174.wav"]
+        argv = argv + [str(inference_gtcrn.example_audio("denoise", "ul_unas_0174.wav"))]
     return inference_gtcrn.main(argv)
 
 

@@ -82,6 +82,7 @@ class InferenceSession:
         self.n_outputs = io.n_outputs                     # 1, or 2 for MossFormer2-SS ("separated_0", "separated_1")
         self.row_in, self.row_out = io.in_channels * io.in_len, io.n_outputs * io.out_channels * io.out_len   # one batch item, planar
         self.sample_rate = io.model_sample_rate
+        self.in_sample_rate, self.out_sample_rate = io.in_sample_rate, io.out_sample_rate
         self.device_id = io.device
         in_name = "mix_audio" if reader.string("model_family", "") == "mossformer2_ss" else INPUT_NAME        # :688
         self._inputs = [NodeArg(in_name, [1, io.in_channels, io.in_len])]
@@ -203,6 +204,11 @@ class InferenceSession:
         self._lib.check(st, self._h)
 
     def close(self) -> None:
+        for ref in list(getattr(self, "_streams", ())):          # child streams first: they hold device state of this engine
+            child = ref()
+            if child is not None:
+                child.close()
+        self._streams = []
         if getattr(self, "_h", None) and self._h:
             self._lib.c.ade_destroy(self._h)
             self._h = C.c_void_p()
@@ -234,6 +240,10 @@ class StreamingSession:
         self.n_streams, self.frames_per_push, self.samples_per_push = int(n_streams), int(frames_per_push), int(frames_per_push) * 256
         self._h = C.c_void_p()
         self._lib.check(self._lib.c.ade_stream_create(session._h, self.n_streams, self.frames_per_push, C.byref(self._h)), session._h)
+        import weakref
+        if not hasattr(session, "_streams"):
+            session._streams = []
+        session._streams.append(weakref.ref(self))
 
     def push(self, pcm: np.ndarray, want_f32: bool = False):
         """int16 (n_streams, samples_per_push) -> int16 of the same shape (+ fp32 pre-PCM waveform)."""

@@ -167,3 +167,36 @@ def test_mossformer_driver_head_padding_and_slicing():
     assert np.array_equal(s0, audio) and np.array_equal(s1, -audio)          # head zeros dropped, tail padding trimmed
     sl = drv.cut_slices(np.concatenate((np.zeros(4, np.int16), audio)), 10, True)
     assert sl.shape == (3, 10) and np.all(sl[0, :4] == 0) and np.all(sl[2, 7:] == 0)
+
+
+def test_drivers_with_unequal_sample_rates():
+    """A 16 kHz -> 48 kHz manifest: the GTCRN driver steps by the INPUT length (its output-length stride applies only when
+    IN_SAMPLE_RATE == OUT_SAMPLE_RATE, Inference_GTCRN_ONNX.py:289) and trims to int(n * OUT / IN) output samples (:303); the
+    DFSMN / MossFormer2 drivers always step by the input length and trim to int(round(n * scale))."""
+    from audio_denoiser_onnx_amd import inference_gtcrn as g, inference_mossformer as m, inference_hgtcrn as h
+    assert g.plan_slices(100000, 16000, 48000, out_stride=False) == (16000, 7, 112000)
+    assert g.output_length(100000, 16000, 48000) == 300000
+    assert g.output_length(100001, 48000, 16000) == 33333 and g.output_length(100001, 48000, 16000, rounded=True) == 33334
+
+    class Up3:                                 # stand-in engine: 16 kHz in, 48 kHz out, every sample repeated three times
+        in_len, out_len, in_sample_rate, out_sample_rate = 16000, 48000, 16000, 48000
+
+        def process(self, pcm, want_f32=False):
+            return np.repeat(pcm, 3, axis=1), None
+
+        def get_inputs(self):
+            return [type("A", (), {"name": "mix_audio"})()]
+
+        def run(self, _, feed):
+            x = next(iter(feed.values()))
+            return [np.repeat(x[:, :1], 3, axis=2), np.repeat(-x[:, :1], 3, axis=2)]
+    audio = (np.arange(100000) % 30000).astype(np.int16)
+    for fam in ("gtcrn", "dfsmn"):
+        out = g.denoise(Up3(), audio, family=fam)
+        assert out.shape == (300000,) and np.array_equal(out, np.repeat(audio, 3)), fam      # nothing skipped, nothing cut short
+    s0, s1 = m.separate(Up3(), audio, pad_head=8000, fold_active=True)
+    assert s0.shape == (300000,) and np.array_equal(s0, np.repeat(audio, 3)) and np.array_equal(s1, -s0)
+    st = h.denoise(Up3(), np.stack((audio, audio)), True)
+    assert st.shape == (300000,)
+    # equal rates, hop-truncated output: stride = output length as before
+    assert g.cut_slices(audio, 16000, 15872, out_stride=True)[1] == 15872
