@@ -767,8 +767,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
     }
     const bool fam_dfsmn = e->meta["model_family"] == "dfsmn", fam_melband = e->meta["model_family"] == "mel_band_roformer",
                fam_moss = e->meta["model_family"] == "mossformer2_ss", fam_ulu = e->meta["model_family"] == "ul_unas",
-               fam_hg = e->meta["model_family"] == "h_gtcrn";
-    if (fam_dfsmn || fam_melband || fam_moss || fam_ulu || fam_hg) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
+               fam_hg = e->meta["model_family"] == "h_gtcrn", fam_zip = e->meta["model_family"] == "zipenhancer";
+    if (fam_dfsmn || fam_melband || fam_moss || fam_ulu || fam_hg || fam_zip) {   // DFSMN/Export_DFSMN.py (48 kHz mono) / Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py (44.1 kHz stereo)
         const std::string fam = e->meta["model_family"];
         const long rate = fam_dfsmn ? 48000 : fam_melband ? 44100 : 16000;
         bool dyn_d = false, fold_d = false;
@@ -792,7 +792,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // model-rate length (Export_MossFormer2_SS_16K.py:36-37,99-104; Export_DFSMN.py:48,67).  Mel-Band-Roformer (like GTCRN) and UL-UNAS size
         // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
         // H-GTCRN's static export is consistent too (frames from MODEL_AUDIO_LENGTH, Export_H_GTCRN.py:45-46); it interpolates by SCALE FACTOR.
-        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg)
+        // ZipEnhancer sizes its frames from MODEL_AUDIO_LENGTH too (Export_ZipEnhancer.py:55, 61) and interpolates by size (:826-832, :905-911).
+        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg && !fam_zip)
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
@@ -838,6 +839,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
+                       : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
@@ -876,7 +878,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         return ADE_OK;
     }
     if (e->meta["model_family"] != "gtcrn")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, h_gtcrn, dfsmn, mel_band_roformer, mossformer2_ss, ul_unas)"));
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "model_family '" + e->meta["model_family"] + "' is not implemented (gtcrn, h_gtcrn, dfsmn, mel_band_roformer, mossformer2_ss, ul_unas, zipenhancer)"));
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));

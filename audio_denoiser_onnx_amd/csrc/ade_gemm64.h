@@ -1,0 +1,121 @@
+// ade_gemm64.h — fp32 matrix-core GEMM for TALL-SKINNY problems: millions of rows (tokens), 48..336 output columns, K = 48..1536.
+//
+//   C(m, n) = sum_k A(m, k) * B(k, n)        exact fp32 (v_mfma_f32_16x16x4_f32)
+//
+// ZipEnhancer's channel width is 64, so every one of its products -- the causal dense convolutions as implicit GEMMs, the
+// Zipformer projections -- has N that is 64 or a small multiple of 16.  The 128 x 128 tile of ade_gemm.h would spend half of
+// its matrix-core work on padding there; this variant computes a 256 x 64 tile per 256-thread workgroup (each wavefront a
+// 64 x 64 block as 4 x 4 MFMA tiles, 64 accumulator VGPRs) and leaves everything else as in ade_gemm.h: slabs of 16 k staged
+// row-major in LDS at 20 floats per row (one ds_read_b128 per operand tile, all 64 banks covered once), slab k + 1 requested
+// into registers before the 64 MFMAs of slab k.
+// Operands are FUNCTORS, both contiguous along k and fetched as float4 (whole 64-byte lines per 4 lanes):
+//   struct ALoad { struct Row {...}; __device__ Row row(int m) const;                    // per-row state, computed ONCE per tile
+//                  __device__ float4 vec4(const Row&, int k) const; };                   // k % 4 == 0, k + 3 < K
+//   struct BLoad { __device__ float4 vec4(int n, int k) const; };                        // weights stored (N, K) row-major
+//   struct Store { __device__ void operator()(int m, int n, float v) const; };
+// The Row hook is what lets an implicit-convolution loader do its (batch, frame, bin) index split once instead of per fetch.
+// K must be a multiple of 4.
+#pragma once
+#include "ade_device.h"
+#include "ade_gemm.h"
+
+namespace ade {
+namespace gemm64 {
+
+using namespace dev;
+
+constexpr int kTM = 256, kTN = 64, kTK = 16, kRow = gemm::kRow;
+
+template <class AL, class BL, class ST>
+__global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) float As[kTM * kRow];
+    __shared__ __attribute__((aligned(16))) float Bs[kTN * kRow];
+    const int gx = (int)gridDim.x, id = gemm::xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
+    const int m_blk = (id / gx) * kTM, n_blk = (id % gx) * kTN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave * 64, j16 = lane & 15, g = lane >> 4;
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int r = tid >> 2, kq = 4 * (tid & 3);          // this lane fetches k quarter kq of rows r, r + 64, r + 128, r + 192 and of column r
+    typename AL::Row rows[4];
+    bool rok[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int m = m_blk + r + 64 * h;
+        rok[h] = m < M;
+        rows[h] = a_of.row(rok[h] ? m : 0);
+    }
+    const int nb = n_blk + r;
+    const bool nok = nb < N;
+    float4 ra[4], rb;
+    auto fetch = [&](int k0) {
+        const int k = k0 + kq;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) ra[h] = (rok[h] && k < K) ? a_of.vec4(rows[h], k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rb = (nok && k < K) ? b_of.vec4(nb, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
+        *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;
+        __syncthreads();
+        if (k0 + kTK < K) fetch(k0 + kTK);
+        float4 a4[4], b4[4];                // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (16 * j + j16) * kRow + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+            }
+        __syncthreads();
+    }
+    // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m_blk + wm + 16 * i + 4 * g + q;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n_blk + 16 * j + j16;
+                if (n < N) store(m, n, acc[i][j][q]);
+            }
+        }
+}
+
+template <class AL, class BL, class ST>
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
+    if (M <= 0 || N <= 0) return;
+    const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+}
+
+// ---- common operands ---------------------------------------------------------------------------------------------------
+struct RowsA {           // A(m, k) = p[m * ld + k]
+    const float* p;
+    int ld;
+    struct Row { const float* q; };
+    __device__ Row row(int m) const { return Row{p + (size_t)m * ld}; }
+    __device__ float4 vec4(const Row& r, int k) const { return *reinterpret_cast<const float4*>(r.q + k); }
+};
+struct WeightB {         // B(k, n) = p[n * ld + k]: a (N, K) row-major weight used as x @ W^T
+    const float* p;
+    int ld;
+    __device__ float4 vec4(int n, int k) const { return *reinterpret_cast<const float4*>(p + (size_t)n * ld + k); }
+};
+
+}  // namespace gemm64
+}  // namespace ade

@@ -1,0 +1,1001 @@
+// ade_zipenhancer.hip — ZipEnhancer (16 kHz speech enhancement, dual-path Zipformer2) on the MI355X: SURVEY.md section 8 rows a15 / a16.
+//
+// Reference: ZipEnhancer.forward over the FUSED tensors its constructor registers (ZipEnhancer/Export_ZipEnhancer.py:818-927, :437-664)
+// with the ten forward overrides it installs on the ModelScope layers (:118-355):
+//   int16 (B, 1, n_win W) -> float, fold into windows (:837) -> / sqrt(mean x^2 + 1e-6) per window (:839) -> STFT(400, hop 100, hann,
+//   reflect) -> (|X|^2 + 1e-9)^0.15 and atan2(im, re + 1e-5) (:843-844) -> DenseEncoder: 1x1 conv, causal dilated 2 x 3 dense block of
+//   depth 4, (1, 3) stride-2 conv, each + InstanceNorm + PReLU (:847-853, :701-723) -> 4 dual-path Zipformer2 encoders, the middle
+//   two on a 2 x 2 down-sampled grid (:859-863, :782-816) -> the mask | phase decoder pair: dense block, sub-pixel (1, 3) up-sampling,
+//   (1, 2) heads (:864-877, :725-780) -> relu(mask)^(1/0.3) x unit phase vector (:882-892) -> ISTFT (x 1 / sum w^2) -> x the window's
+//   norm factor (:900) -> NaN -> 0, clamp, truncate to int16 (:917-918).
+// One Zipformer2 layer on S sequences of n tokens (:143-187), batch-major:
+//   [attn | ff1] = x W^T + b;  A = softmax(q k^T + skew(p P_h))  (:232-289);  x += W swooshL(ff1);  x += W ((A_0 (tanh(s) u)) y)  (:304-317);
+//   x += W (A v) (:292-301);  x += W swooshR(dw15(a sigmoid(g)))  (:320-339);  x += ff2;  x = x0 + (x - x0) c_mid;  x += W (A v');
+//   x += conv';  x += ff3;  x = x / |x - nb|_2 * fs + x0 * rs  (:175-183).
+//
+// MI355X mapping.  Activations are token-major, channels-last fp32: X[(b, t, f)][64].  Both attention axes read X in place (a frequency
+// sequence is F consecutive rows, a time sequence F rows apart): the reference's four permutes per encoder never materialise.
+//   * every Linear / 1x1 conv AND every dense 2 x 3 / (1, 3) convolution is a tall-skinny fp32 matrix-core GEMM (csrc/ade_gemm64.h,
+//     256 x 64 tiles, v_mfma_f32_16x16x4_f32): the convolutions are implicit GEMMs whose A-operand loader shifts (frame, bin), zero-pads
+//     and applies the PRODUCER's InstanceNorm + PReLU on the fly -- the dense block's skip tensors are stored once, raw, and never
+//     rewritten (the reference concatenates and normalises them layer by layer);
+//   * InstanceNorm statistics: one deterministic two-stage fp64 reduction per produced tensor; for the first (1x1) layer they follow
+//     analytically from five moments of (mag, phase), so that layer costs no reduction over its 64-channel output at all;
+//   * Swoosh activations, biases, residual adds, the mid bypass and the sub-pixel shuffle are GEMM loaders / stores;
+//   * attention weights are materialised once per layer (they are used three times: head 0 by NonlinAttention, all heads by both
+//     SelfAttention modules) with rows padded to 4 floats; the three weighted sums run on the matrix cores with the weights as the
+//     A operand straight from HBM (float4 per lane) and the values staged in LDS;
+//   * STFT / ISTFT are the reference's dense windowed DFT as MFMA GEMMs with ITS fp32-angle tables by default (manifest
+//     ade_dft_tables = "exact" for exactly reduced angles): the phase feature of a near-silent bin is ill-conditioned, so the tables'
+//     own error is part of what the network sees (as for Mel-Band-Roformer).
+// Geometry (channels, heads, kernel sizes) comes from the blob's `zip_config` (audio_denoiser_onnx_amd/zipenhancer.py).
+#include "ade_gemm64.h"
+#include "ade_internal.h"
+#include "../../include/ade.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace ade {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kZN = 400, kZHop = 100, kZF = kZN / 2 + 1, kZC2 = 2 * kZF;   // Export_ZipEnhancer.py:47-49
+constexpr int kChunkTok = 2048;                                             // tokens per partial-statistics block
+
+// ---- small device helpers -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }     // F.softplus (threshold 20)
+__device__ __forceinline__ float swoosh_l(float x) { return softplus_f(x - 4.0f) - 0.08f * x; }        // (:135-136), offset folded into the bias
+__device__ __forceinline__ float swoosh_r(float x) { return softplus_f(x - 1.0f) - 0.08f * x; }        // (:138)
+__device__ __forceinline__ float sigmoid_p(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// rows of a sequence: row(seq, p) = (seq / sdiv) * sa + (seq % sdiv) * sb + p * ps
+struct SeqGeo {
+    int nseq, n, sdiv;
+    long long sa, sb, ps;
+    __device__ __forceinline__ long long row0(int seq) const { return (long long)(seq / sdiv) * sa + (long long)(seq % sdiv) * sb; }
+};
+
+// ---- front: window norm, STFT operands, features ------------------------------------------------------------------------------
+// norm[r] = sqrt(mean(x^2) + 1e-6) over the window's L samples (int16 amplitude, :819, :839)
+__global__ __launch_bounds__(256) void k_zip_window_norm(const int16_t* __restrict__ pcm, const float* __restrict__ fin, float* __restrict__ norm, int L) {
+    __shared__ double red[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < L; i += 256) {
+        const float v = fin ? fin[(size_t)r * L + i] : (float)pcm[(size_t)r * L + i];
+        s += (double)(v * v);
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) norm[r] = sqrtf((float)(red[0] / (double)L) + 1e-6f);
+}
+
+struct ZFrameB {               // B(k, j) = reflect-padded sample k of frame j = (window r, t), divided by the window's norm (:840, STFT_Process.py:268-281)
+    static constexpr bool kAlongN = false;
+    const int16_t* pcm;
+    const float* fin;
+    const float* norm;
+    int L, T;
+    __device__ float operator()(int k, int j) const {
+        const int r = j / T, t = j - r * T;
+        int idx = t * kZHop + k - kZN / 2;
+        if (idx < 0) idx = -idx;
+        else if (idx >= L) idx = 2 * (L - 1) - idx;
+        const float v = fin ? fin[(size_t)r * L + idx] : (float)pcm[(size_t)r * L + idx];
+        return v / norm[r];
+    }
+};
+struct ZSpecStore {            // C(c, j) -> spec[c][j]   (re rows 0..200, im rows 201..401)
+    float* spec;
+    int J;
+    __device__ void operator()(int m, int n, float v) const { spec[(size_t)m * J + n] = v; }
+};
+
+// feat[(j, f)] = (mag, pha) and the per-block partial moments of (mag, pha) for the analytic InstanceNorm of the 1x1 layer.
+// grid (chunks over the T * 201 positions of one window, windows); partial[(r * nchunk + chunk) * 5 + q]
+__global__ __launch_bounds__(256) void k_zip_features(const float* __restrict__ spec, float2* __restrict__ feat, double* __restrict__ partial, int T, int J,
+                                                      int per_chunk) {
+    __shared__ double red[5][256];
+    const int r = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, TF = T * kZF;
+    const int lo = chunk * per_chunk, hi = min(TF, lo + per_chunk);
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = lo + tid; i < hi; i += 256) {
+        const int t = i / kZF, f = i - t * kZF, j = r * T + t;
+        const float re = spec[(size_t)f * J + j], im = spec[(size_t)(kZF + f) * J + j];
+        const float mag = powf(re * re + im * im + 1e-9f, 0.15f);                      // compress_factor / 2 (:365, :843)
+        const float pha = atan2f(im, re + 1e-5f);                                     // (:844)
+        feat[(size_t)r * TF + i] = make_float2(mag, pha);
+        acc[0] += mag; acc[1] += pha; acc[2] += (double)mag * mag; acc[3] += (double)pha * pha; acc[4] += (double)mag * pha;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) red[q][tid] = acc[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) red[q][tid] += red[q][tid + o];
+        __syncthreads();
+    }
+    if (tid < 5) partial[((size_t)r * gridDim.x + chunk) * 5 + tid] = red[tid][0];
+}
+
+// coef[r][c] = (a, b, d): the 1x1 conv (2 -> C) followed by its InstanceNorm collapses to a * mag + b * pha + d per (window, channel)  (:851)
+__global__ void k_zip_conv1_coef(const double* __restrict__ partial, int nchunk, double count, const float* __restrict__ w, const float* __restrict__ bias,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float4* __restrict__ coef, int C) {
+    const int r = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    double m[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < nchunk; ++k)
+        for (int q = 0; q < 5; ++q) m[q] += partial[((size_t)r * nchunk + k) * 5 + q];
+    const double em = m[0] / count, ep = m[1] / count;
+    const double vm = m[2] / count - em * em, vp = m[3] / count - ep * ep, cov = m[4] / count - em * ep;
+    const double w0 = w[c * 2], w1 = w[c * 2 + 1];
+    const double mean = w0 * em + w1 * ep + bias[c];
+    double var = w0 * w0 * vm + w1 * w1 * vp + 2.0 * w0 * w1 * cov;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + 1e-5);
+    coef[(size_t)r * C + c] = make_float4((float)(w0 * sc), (float)(w1 * sc), (float)(((double)bias[c] - mean) * sc + beta[c]), 0.0f);
+}
+
+// E0[(r, t, f)][c] = prelu(a mag + b pha + d): the dense block's input, final values
+__global__ __launch_bounds__(256) void k_zip_conv1_apply(const float2* __restrict__ feat, const float4* __restrict__ coef, const float* __restrict__ slope,
+                                                         float* __restrict__ e0, int TF, int C, long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;             // (token, channel quad)
+    if (i >= total4) return;
+    const int cq = C >> 2;
+    const long long tok = i / cq;
+    const int c = (int)(i - tok * cq) * 4, r = (int)(tok / TF);
+    const float2 mp = feat[tok];
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 k = coef[(size_t)r * C + c + u];
+        v[u] = prelu_f(k.x * mp.x + k.y * mp.y + k.z, slope[c + u]);
+    }
+    st4(e0 + tok * C + c, v);
+}
+
+// ---- InstanceNorm statistics of a raw tensor: 64 channels at column ch0 of a [tokens][ld] matrix, per window ------------------------
+// stage 1: grid (chunks, windows), thread = (channel quad, token lane); partial[((r * nchunk + chunk) * 64 + c) * 2 + {sum, sumsq}]
+__global__ __launch_bounds__(256) void k_zip_stats_partial(const float* __restrict__ x, int ld, int ch0, int tok_per_win, double* __restrict__ partial) {
+    __shared__ double red[16][16][8];
+    const int r = blockIdx.y, chunk = blockIdx.x, q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int lo = chunk * kChunkTok, hi = min(tok_per_win, lo + kChunkTok);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* base = x + (size_t)r * tok_per_win * ld + ch0 + 4 * q;
+    for (int i = lo + tl; i < hi; i += 16) {
+        float v[4];
+        ld4(base + (size_t)i * ld, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[u] += v[u]; ss[u] += (double)v[u] * v[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { red[tl][q][u] = s[u]; red[tl][q][4 + u] = ss[u]; }
+    __syncthreads();
+    if (tl == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 16; ++k) { a += red[k][q][u]; b += red[k][q][4 + u]; }
+            double* dst = partial + (((size_t)r * gridDim.x + chunk) * 64 + 4 * q + u) * 2;
+            dst[0] = a; dst[1] = b;
+        }
+    }
+}
+// stage 2: nrm[(r * nrm_ld + nrm_ch0 + c) * 2 + {scale, shift}] = (gamma / sqrt(var + eps), beta - mean * scale)     (eps 1e-5, biased variance)
+__global__ void k_zip_stats_final(const double* __restrict__ partial, int nchunk, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  float* __restrict__ nrm, int nrm_ld, int nrm_ch0) {
+    const int r = blockIdx.x, c = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const double* src = partial + (((size_t)r * nchunk + k) * 64 + c) * 2;
+        a += src[0]; b += src[1];
+    }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + 1e-5);
+    float* dst = nrm + ((size_t)r * nrm_ld + nrm_ch0 + c) * 2;
+    dst[0] = (float)sc;
+    dst[1] = (float)((double)beta[c] - mean * sc);
+}
+// in-place normalise + PReLU of a [tokens][C] tensor (the encoder input: it has many consumers)
+__global__ __launch_bounds__(256) void k_zip_norm_apply(float* __restrict__ x, const float* __restrict__ nrm, const float* __restrict__ slope, int tok_per_win, int C,
+                                                        long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int cq = C >> 2;
+    const long long tok = i / cq;
+    const int c = (int)(i - tok * cq) * 4, r = (int)(tok / tok_per_win);
+    float v[4];
+    ld4(x + tok * C + c, v);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float* k = nrm + ((size_t)r * C + c + u) * 2;
+        v[u] = prelu_f(v[u] * k[0] + k[1], slope[c + u]);
+    }
+    st4(x + tok * C + c, v);
+}
+
+// ---- implicit-GEMM operand: one layer of a causal dense block (:701-757) ---------------------------------------------------------
+// A(token, k): k = tap * cin + ci, tap = kt * 3 + kf; the value is input channel ci of position (t - (1 - kt) dil, f + kf - 1), zero outside the
+// map.  Input channels are [this group's newer dense outputs ..., block input]: the first hist_n live RAW in `hist` (normalised + PReLU'd
+// here with their producer's statistics), the last C in `inp` (final values).
+__device__ __forceinline__ float4 norm_prelu4(float4 v, const float* nrm2, const float* slope) {
+    const float4 s0 = *reinterpret_cast<const float4*>(nrm2), s1 = *reinterpret_cast<const float4*>(nrm2 + 4), sl = *reinterpret_cast<const float4*>(slope);
+    v.x = prelu_f(v.x * s0.x + s0.y, sl.x);
+    v.y = prelu_f(v.y * s0.z + s0.w, sl.y);
+    v.z = prelu_f(v.z * s1.x + s1.y, sl.z);
+    v.w = prelu_f(v.w * s1.z + s1.w, sl.w);
+    return v;
+}
+struct DenseA {
+    const float* hist;     // [tokens][hist_ld] raw
+    const float* inp;      // [tokens][C]
+    const float* nrm;      // [windows][hist_ld][2]
+    const float* slope;    // [hist_ld]
+    int hist_ld, hist_off, hist_n, cin, C, T, F, dil;
+    struct Row { int b, t, f; };
+    __device__ Row row(int m) const {
+        const int tf = T * F, b = m / tf, rem = m - b * tf, t = rem / F;
+        return Row{b, t, rem - t * F};
+    }
+    __device__ float4 vec4(const Row& r, int k) const {
+        const int tap = k / cin, ci = k - tap * cin, kt = tap >= 3 ? 1 : 0, kf = tap - 3 * kt;
+        const int t2 = r.t - (1 - kt) * dil, f2 = r.f + kf - 1;
+        if (t2 < 0 || f2 < 0 || f2 >= F) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const size_t tok = ((size_t)r.b * T + t2) * F + f2;
+        if (ci >= hist_n) return *reinterpret_cast<const float4*>(inp + tok * C + (ci - hist_n));
+        const int ch = hist_off + ci;
+        return norm_prelu4(*reinterpret_cast<const float4*>(hist + tok * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+    }
+};
+struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
+    float* out;
+    const float* bias;
+    int ld, off;
+    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + off + n] = v + bias[n]; }
+};
+// (1, K3) convolution along f of a normalised dense output (channel block `ch0` of hist): stride 2 / pad 1 for dense_conv_2 (:853), stride 1 /
+// pad 1 for the sub-pixel up-sampler (:761-766).  A(token_out, k): k = kf * C + ci.
+struct RowConvA {
+    const float* hist;
+    const float* nrm;
+    const float* slope;
+    int hist_ld, ch0, C, T, Fin, Fout, stride;
+    struct Row { int b; long long base; int f0; };
+    __device__ Row row(int m) const {
+        const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
+        return Row{b, ((long long)b * T + t) * Fin, f * stride - 1};
+    }
+    __device__ float4 vec4(const Row& r, int k) const {
+        const int kf = k / C, ci = k - kf * C, f2 = r.f0 + kf;
+        if (f2 < 0 || f2 >= Fin) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int ch = ch0 + ci;
+        return norm_prelu4(*reinterpret_cast<const float4*>(hist + (size_t)(r.base + f2) * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+    }
+};
+struct SubPixelStore {         // conv channel n = c * r + u of sub-band f -> U[(b, t, f * r + u)][ch0 + c] (+ bias)   (:767-769)
+    float* u;
+    const float* bias;
+    int ld, ch0, r;
+    __device__ void operator()(int m, int n, float v) const {
+        const int c = n / r, s = n - c * r;
+        u[((size_t)m * r + s) * ld + ch0 + c] = v + bias[n];
+    }
+};
+
+// ---- Zipformer2 layer pieces ----------------------------------------------------------------------------------------------------
+template <int KIND>            // activation applied while loading a row-major operand: 0 none, 1 SwooshL, 2 SwooshR
+struct ActRowsA {
+    const float* p;
+    int ld;
+    struct Row { const float* q; };
+    __device__ Row row(int m) const { return Row{p + (size_t)m * ld}; }
+    __device__ float4 vec4(const Row& r, int k) const {
+        float4 v = *reinterpret_cast<const float4*>(r.q + k);
+        if (KIND == 1) { v.x = swoosh_l(v.x); v.y = swoosh_l(v.y); v.z = swoosh_l(v.z); v.w = swoosh_l(v.w); }
+        if (KIND == 2) { v.x = swoosh_r(v.x); v.y = swoosh_r(v.y); v.z = swoosh_r(v.z); v.w = swoosh_r(v.w); }
+        return v;
+    }
+};
+struct AddFromStore {          // y[m][n] = x[m][n] + v + bias[n]     (the layer's first residual: x stays the layer input, :146, :160)
+    const float* x;
+    float* y;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const { y[(size_t)m * ld + n] = x[(size_t)m * ld + n] + (v + bias[n]); }
+};
+struct ResidualBiasStore {     // y[m][n] += v + bias[n]
+    float* y;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const {
+        float* p = y + (size_t)m * ld + n;
+        *p = *p + (v + bias[n]);
+    }
+};
+struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_forward2's residual then bypass_mid, :170-171, :190-191)
+    const float* x0;
+    float* y;
+    const float* bias;
+    const float* c;
+    int ld;
+    __device__ void operator()(int m, int n, float v) const {
+        const size_t i = (size_t)m * ld + n;
+        const float s = y[i] + (v + bias[n]), o = x0[i];
+        y[i] = o + (s - o) * c[n];
+    }
+};
+
+// attention weights (:232-289): one (sequence, head) per workgroup; a wavefront takes query rows i = wave, wave + 4, ..., its lanes the keys.
+//   s[i][j] = q_i . k_j + p_i . P[:, n - 1 - i + j]   -> softmax over j -> AW[((seq * H + h) * n + i) * np + j], pad columns j in [n, np) = 0
+// LDS: K rows (stride qd + 1), Q rows, P rows, the head's projected position table (pd, 2 n - 1).
+constexpr int kMaxKeysPerLane = 5;          // n <= 320: the workgroup's operands stay under the 64 KB static-launch LDS limit
+__global__ __launch_bounds__(256) void k_zip_attn_weights(const float* __restrict__ proj, int ldp, const float* __restrict__ pos, float* __restrict__ aw, SeqGeo geo,
+                                                          int H, int qd, int pd, int np) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
+    float* Ks = lds;                               // [n][qd + 1]
+    float* Qs = Ks + (size_t)n * (qd + 1);         // [n][qd]
+    float* Ps = Qs + (size_t)n * qd;               // [n][pd]
+    float* Pt = Ps + (size_t)n * pd;               // [pd][2 n - 1]
+    const long long r0 = geo.row0(seq);
+    const int hd = 2 * qd + pd;
+    for (int i = tid; i < n * hd; i += 256) {
+        const int p = i / hd, d = i - p * hd;
+        const float v = proj[(size_t)(r0 + (long long)p * geo.ps) * ldp + h * hd + d];
+        if (d < qd) Qs[p * qd + d] = v;
+        else if (d < 2 * qd) Ks[p * (qd + 1) + d - qd] = v;
+        else Ps[p * pd + d - 2 * qd] = v;
+    }
+    const int n2 = 2 * n - 1;
+    for (int i = tid; i < pd * n2; i += 256) Pt[i] = pos[(size_t)h * pd * n2 + i];
+    __syncthreads();
+    float* out = aw + ((size_t)seq * H + h) * n * np;
+    for (int i = wave; i < n; i += 4) {
+        float s[kMaxKeysPerLane];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < kMaxKeysPerLane; ++u) {
+            const int j = lane + 64 * u;
+            s[u] = -INFINITY;
+            if (j < n) {
+                float a = 0.0f;
+                for (int d = 0; d < qd; ++d) a = fmaf(Qs[i * qd + d], Ks[j * (qd + 1) + d], a);
+                float b = 0.0f;
+                for (int d = 0; d < pd; ++d) b = fmaf(Ps[i * pd + d], Pt[d * n2 + (n - 1 - i + j)], b);
+                s[u] = a + b;
+                mx = fmaxf(mx, s[u]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int u = 0; u < kMaxKeysPerLane; ++u) {
+            const int j = lane + 64 * u;
+            if (j < n) { s[u] = expf(s[u] - mx); sum += s[u]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+        for (int u = 0; u < kMaxKeysPerLane; ++u) {
+            const int j = lane + 64 * u;
+            if (j < np) out[(size_t)i * np + j] = j < n ? s[u] / sum : 0.0f;
+        }
+    }
+}
+
+// weighted sums O = A V on the matrix cores.  grid (sequence, head, 64-query blocks); wave w owns queries 16 w .. 16 w + 15 of the block.
+//   A operand: AW[i0 + j16][c + 4 g .. c + 4 g + 3] -- one float4 per lane straight from HBM (rows are padded to np, a multiple of 4)
+//   B operand: the values of 64 keys staged in LDS, V[key][DT * 16] (zero rows / columns beyond n / the value width)
+// MODE 0 (NonlinAttention, :304-317): head 0 only; value = tanh(s) * u from the (s | u | y) projection, result multiplied by y.
+// MODE 1 (SelfAttention, :292-301): value = head h's slice of the value projection.
+template <int MODE, int DT>
+__global__ __launch_bounds__(256) void k_zip_attn_apply(const float* __restrict__ aw, const float* __restrict__ src, int lds_, float* __restrict__ out, int ldo, SeqGeo geo,
+                                                        int H, int dv, int np) {
+    constexpr int kVs = DT * 16 + 4;
+    __shared__ float Vs[64 * kVs];
+    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
+    const int j16 = lane & 15, g = lane >> 4;
+    const long long r0 = geo.row0(seq);
+    const int i0 = (int)blockIdx.z * 64 + wave * 16;
+    const bool live = i0 < n;
+    const int qi = i0 + j16;
+    const float* arow = aw + (((size_t)seq * H + h) * n + (qi < n ? qi : 0)) * np;
+    v4f acc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc[d] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * DT * 16; i += 256) {
+            const int p = i / (DT * 16), d = i - p * (DT * 16), key = c0 + p;
+            float v = 0.0f;
+            if (key < n && d < dv) {
+                const float* q = src + (size_t)(r0 + (long long)key * geo.ps) * lds_;
+                v = MODE == 0 ? tanhf(q[d]) * q[dv + d] : q[h * dv + d];
+            }
+            Vs[p * kVs + d] = v;
+        }
+        __syncthreads();
+        if (!live) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int kk = c0 + 16 * kt + 4 * g;
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (qi < n && kk < np) a = *reinterpret_cast<const float4*>(arow + kk);
+            const float* vr = Vs + (16 * kt + 4 * g) * kVs + j16;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                acc[d] = mfma16x16x4(a.x, vr[16 * d], acc[d]);
+                acc[d] = mfma16x16x4(a.y, vr[kVs + 16 * d], acc[d]);
+                acc[d] = mfma16x16x4(a.z, vr[2 * kVs + 16 * d], acc[d]);
+                acc[d] = mfma16x16x4(a.w, vr[3 * kVs + 16 * d], acc[d]);
+            }
+        }
+    }
+    if (!live) return;
+    // lane (g, j16) holds O[query i0 + 4 g + r][dim 16 d + j16]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * g + r;
+        if (i >= n) continue;
+        const size_t row = (size_t)(r0 + (long long)i * geo.ps);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const int col = 16 * d + j16;
+            if (col >= dv) continue;
+            float v = acc[d][r];
+            if (MODE == 0) v *= src[row * lds_ + 2 * dv + col];
+            out[row * ldo + (MODE == 0 ? 0 : h * dv) + col] = v;
+        }
+    }
+}
+
+// ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
+// the block's gated rows (+ k / 2 halo on both sides) are staged in LDS once.  g: [rows][2 C] = (value | gate); out: [rows][C].
+__global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                                                    SeqGeo geo, int C, int K) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int seq = blockIdx.x, p0 = (int)blockIdx.y * 64, tid = threadIdx.x, n = geo.n, half = K / 2, rowsN = 64 + K - 1;
+    const long long r0 = geo.row0(seq);
+    for (int i = tid; i < rowsN * C; i += 256) {
+        const int p = i / C, c = i - p * C, pos = p0 - half + p;
+        float v = 0.0f;
+        if (pos >= 0 && pos < n) {
+            const float* q = g + (size_t)(r0 + (long long)pos * geo.ps) * (2 * C);
+            v = q[c] * sigmoid_p(q[C + c]);
+        }
+        lds[p * C + c] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * C; i += 256) {
+        const int p = i / C, c = i - p * C, pos = p0 + p;
+        if (pos >= n) continue;
+        float a = 0.0f;
+        for (int k = 0; k < K; ++k) a = fmaf(w[c * K + k], lds[(p + k) * C + c], a);
+        out[(size_t)(r0 + (long long)pos * geo.ps) * C + c] = a + bias[c];
+    }
+}
+
+// x = y / |y - nb|_2 * fs + x * rs  (:175-183): 16 lanes per row (float4 each, C = 64) or a generic loop
+__global__ __launch_bounds__(256) void k_zip_final_norm(float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ nb, const float* __restrict__ fs,
+                                                        const float* __restrict__ rs, long long rows, int C) {
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    float s = 0.0f;
+    if (row < rows)
+        for (int c = l; c < C; c += 16) { const float d = y[row * C + c] - nb[c]; s = fmaf(d, d, s); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (row >= rows) return;
+    const float nrm = sqrtf(s);
+    for (int c = l; c < C; c += 16) x[row * C + c] = (y[row * C + c] / nrm) * fs[c] + x[row * C + c] * rs[c];
+}
+
+// SimpleDownsample over time then sub-bands (:194-218, :799-801): the tail group repeats the last frame / sub-band
+__global__ __launch_bounds__(256) void k_zip_downsample(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ wt, const float* __restrict__ wf,
+                                                        int T, int F, int dT, int dF, int dst, int dsf, int C, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long tok = i / C;
+    const int f = (int)(tok % dF);
+    tok /= dF;
+    const int t = (int)(tok % dT), b = (int)(tok / dT);
+    float acc = 0.0f;
+    for (int v = 0; v < dsf; ++v) {
+        const int f2 = min(f * dsf + v, F - 1);
+        float at = 0.0f;
+        for (int u = 0; u < dst; ++u) {
+            const int t2 = min(t * dst + u, T - 1);
+            at += x[(((size_t)b * T + t2) * F + f2) * C + c] * wt[u];        // time first (:799) ...
+        }
+        acc += at * wf[v];                                                      // ... then sub-bands (:801)
+    }
+    y[i] = acc;
+}
+// x = x * rs + up(y) * os  (:812-816)
+__global__ __launch_bounds__(256) void k_zip_upsample_combine(float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ os, const float* __restrict__ rs,
+                                                              int T, int F, int dT, int dF, int dst, int dsf, int C, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    long long tok = i / C;
+    const int f = (int)(tok % F);
+    tok /= F;
+    const int t = (int)(tok % T), b = (int)(tok / T);
+    x[i] = x[i] * rs[c] + (y[(((size_t)b * dT + t / dst) * dF + f / dsf) * C + c] * os[c]);
+}
+
+// decoder heads (:868, :874-893): (1, 2) convolutions over the normalised up-sampled maps, then relu(mask)^(1/0.3) x unit phase vector, stored
+// planar for the synthesis GEMM: packed[c][j], c = re bin | 201 + im bin.  thread = (frame j, bin f).
+__global__ __launch_bounds__(256) void k_zip_heads(const float* __restrict__ u, const float* __restrict__ nrm, const float* __restrict__ slope, const float* __restrict__ mw,
+                                                   const float* __restrict__ mb, const float* __restrict__ pw, const float* __restrict__ pb, float* __restrict__ packed,
+                                                   float* __restrict__ mask_tap, int T, int F2, int C, int J) {
+    const int f = (int)blockIdx.x * 64 + (threadIdx.x & 63), j = (int)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (f >= kZF || j >= J) return;
+    const int r = j / T;
+    float m = mb[0], pr = pb[0], pi = pb[1];
+    for (int kf = 0; kf < 2; ++kf) {
+        const float* row = u + ((size_t)j * F2 + f + kf) * (2 * C);
+        for (int c = 0; c < C; c += 4) {
+            const float4 a = norm_prelu4(*reinterpret_cast<const float4*>(row + c), nrm + ((size_t)r * 2 * C + c) * 2, slope + c);
+            const float4 b = norm_prelu4(*reinterpret_cast<const float4*>(row + C + c), nrm + ((size_t)r * 2 * C + C + c) * 2, slope + C + c);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m = fmaf(mw[(c + q) * 2 + kf], av[q], m);
+                pr = fmaf(pw[(c + q) * 2 + kf], bv[q], pr);
+                pi = fmaf(pw[(C + c + q) * 2 + kf], bv[q], pi);
+            }
+        }
+    }
+    if (mask_tap) mask_tap[(size_t)j * kZF + f] = m;
+    const float mag = powf(fmaxf(m, 0.0f), 1.0f / 0.3f);                        // (:882-883)
+    float pn = sqrtf(pr * pr + pi * pi);                                        // (:885)
+    if (!(pn > 0.0f)) { pr = 1.0f; pi = 0.0f; pn = 1.0f; }                      // zero phase vector -> (1, 0) (:886-888)
+    const float gain = mag / pn;                                                // (:891)
+    packed[(size_t)f * J + j] = pr * gain;
+    packed[(size_t)(kZF + f) * J + j] = pi * gain;
+}
+struct PlanarA {               // synthesis A operand: A(j, c) = packed[c][j]
+    static constexpr bool kAlongK = false;
+    const float* p;
+    int J;
+    __device__ float operator()(int j, int c) const { return p[(size_t)c * J + j]; }
+};
+// overlap-add gather, x 1 / sum w^2, x the window's norm factor, then the PCM tail (:893-918)
+__global__ __launch_bounds__(256) void k_zip_ola_pcm(const float* __restrict__ frames, const float* __restrict__ inv_wsum, const float* __restrict__ norm,
+                                                     int16_t* __restrict__ pcm, float* __restrict__ f32, int T, int L, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int r = (int)(i / L), m = (int)(i - (long long)r * L) + kZN / 2;
+    int t_hi = m / kZHop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    const int t_lo = m - kZN + 1 <= 0 ? 0 : (m - kZN + kZHop) / kZHop;
+    float s = 0.0f;
+    for (int t = t_lo; t <= t_hi; ++t) s += frames[((size_t)r * T + t) * kZN + (m - t * kZHop)];
+    float y = (s * inv_wsum[m - kZN / 2]) * norm[r];
+    if (f32) f32[i] = y;
+    if (pcm) {
+        if (y != y) y = 0.0f;                                                   // NaN -> 0 (:917)
+        pcm[i] = (short)(int)fminf(fmaxf(y, -32768.0f), 32767.0f);              // clamp, truncate (:918)
+    }
+}
+
+int zfail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
+#define ZP_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return zfail(err, ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct ZLayer {
+    const float *attn_ff1_w, *attn_ff1_b, *pos, *ff1_out_w, *ff1_out_b, *nonlin_in_w, *nonlin_in_b, *nonlin_out_w, *nonlin_out_b;
+    const float *sa_in_w[2], *sa_in_b[2], *sa_out_w[2], *sa_out_b[2];
+    const float *cv_in_w[2], *cv_in_b[2], *cv_dw_w[2], *cv_dw_b[2], *cv_out_w[2], *cv_out_b[2];
+    const float *ff_in_w[2], *ff_in_b[2], *ff_out_w[2], *ff_out_b[2];      // feed_forward2, feed_forward3
+    const float *bypass_mid, *norm_bias, *fnorm, *fres;
+};
+struct ZDense {                // one causal dense block: per layer the repacked weights [co][tap][ci] (per group), bias, norm affine; slopes per hist channel
+    const float* w[2][8];
+    const float* b[2][8];
+    const float* gamma[2][8];
+    const float* beta[2][8];
+    const float* slope;        // [groups * depth * C] in hist-channel order
+};
+
+}  // namespace
+
+struct ZipEngine : SubEngine {
+    int device = 0, L = 0 /* samples per window in */, Lo = 0 /* out: whole hops, hop * (T - 1) */, n_win = 1, T = 0, F = 0;
+    int C = 64, H = 4, qd = 16, pd = 4, vd = 12, pos_dim = 48, ffd = 256, K = 15, dst = 2, dsf = 2, up = 2, depth = 4;
+    int hid = 48, ff1 = 192, ff3 = 320, attn_dim = 144, dT = 0, dF = 0;
+    bool exact = false;
+    float* d_w = nullptr;
+    const float *k_fwd = nullptr, *k_inv = nullptr, *inv_wsum = nullptr;
+    const float *c1_w = nullptr, *c1_b = nullptr, *c1_g = nullptr, *c1_beta = nullptr, *c1_slope = nullptr;
+    const float *c2_w = nullptr, *c2_b = nullptr, *c2_g = nullptr, *c2_beta = nullptr, *c2_slope = nullptr;
+    ZDense enc_dense{}, dec_dense{};
+    ZLayer layers[4][2]{};
+    const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
+    const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
+    const float *mask_w = nullptr, *mask_b = nullptr, *phase_w = nullptr, *phase_b = nullptr;
+    int capacity = 0;
+    float* ws = nullptr;
+    double* partial = nullptr;
+    float *norm = nullptr, *spec = nullptr, *feat = nullptr, *coef = nullptr, *E0 = nullptr, *Dh = nullptr, *nrm = nullptr, *nrm2 = nullptr, *X = nullptr, *Y = nullptr, *X2 = nullptr,
+          *P = nullptr, *S1 = nullptr, *O = nullptr, *AW = nullptr, *U = nullptr, *packed = nullptr, *frames_buf = nullptr, *mask_tap = nullptr, *enc_tap[5] = {};
+    bool keep_taps = false;
+
+    ~ZipEngine() override {
+        (void)hipSetDevice(device);
+        if (d_w) (void)hipFree(d_w);
+        if (ws) (void)hipFree(ws);
+        if (partial) (void)hipFree(partial);
+    }
+    int frames() const override { return T; }
+    int in_len() const override { return L * n_win; }
+    int out_len() const override { return Lo * n_win; }
+    bool accepts_float_input() const override { return true; }
+    int reserve(int batch, std::string& err) override;
+    int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
+    int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
+
+    void stats(hipStream_t s, const float* x, int ld, int ch0, int tok_per_win, int windows, const float* gamma, const float* beta, float* nrm_, int nrm_ld, int nrm_ch0);
+    void dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd);
+    void layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo);
+    void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
+};
+
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err) {
+    *out = nullptr;
+    if (n_win < 1) return zfail(err, ADE_ERR_BAD_VALUE, "zipenhancer: n_win must be >= 1");
+    if (window_len < kZN || (n_win > 1 && window_len % kZHop))
+        return zfail(err, ADE_ERR_SHAPE_MISMATCH, "zipenhancer: the window length must be at least 400 samples (a fold window a multiple of the 100-sample hop)");
+    auto find = [&](const std::string& name) -> const Tensor* {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) { if (err.empty()) err = "weights: tensor missing: " + name; return nullptr; }
+        return &it->second;
+    };
+    const Tensor* cfg = find("zip_config");
+    if (!cfg) return ADE_ERR_MISSING_KEY;
+    if (cfg->count < 14) return zfail(err, ADE_ERR_SHAPE_MISMATCH, "weights: tensor has the wrong shape: zip_config");
+    ZipEngine* e = new ZipEngine();
+    auto bail = [&](int st) { delete e; return st; };
+    auto ci = [&](int i) { return (int)lrintf(cfg->data[i]); };
+    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft;
+    e->C = ci(0); e->H = ci(1); e->qd = ci(2); e->pd = ci(3); e->vd = ci(4); e->pos_dim = ci(5); e->ffd = ci(6); e->K = ci(7);
+    e->dst = ci(10); e->dsf = ci(11); e->up = ci(12); e->depth = ci(13);
+    const int C = e->C;
+    if (ci(8) != 1 || ci(9) != 1) return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: encoders 0 and 3 must not be down-sampled"));
+    if (C != 64) return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: this build's statistics / norm kernels are specialised for 64 channels"));
+    if (e->depth < 1 || e->depth > 4 || e->up < 1 || e->up > 4 || e->dst < 1 || e->dsf < 1 || e->dst > 8 || e->dsf > 8 || !(e->K & 1) || e->K > 63)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: unsupported geometry (dense depth <= 4, up-scale <= 4, down-sampling <= 8, odd depthwise kernel <= 63)"));
+    e->hid = C * 3 / 4; e->ff1 = e->ffd * 3 / 4; e->ff3 = e->ffd * 5 / 4; e->attn_dim = e->H * (2 * e->qd + e->pd);
+    if ((e->hid % 4) || (e->ff1 % 4) || (e->ff3 % 4) || (e->ffd % 4) || (e->attn_dim % 4) || ((e->H * e->vd) % 4) || e->hid > 64 || e->vd > 16 || e->H < 1)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: projection widths must be multiples of 4, hidden_channels <= 64, value_head_dim <= 16"));
+    e->T = window_len / kZHop + 1;
+    e->Lo = kZHop * (e->T - 1);                       // STFT (centre pad) -> ISTFT reconstructs whole hops (STFT_Process.py:168-172)
+    e->F = (kZF + 2 - 3) / 2 + 1;
+    e->dT = (e->T + e->dst - 1) / e->dst;
+    e->dF = (e->F + e->dsf - 1) / e->dsf;
+    if (std::max(e->T, e->F) > 64 * kMaxKeysPerLane)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: at most 320 frames per window; fold longer audio into windows (use_batch_fold)"));
+
+    // ---- arena: blob tensors (some repacked), DFT tables, position tables
+    std::vector<float> arena;
+    auto place = [&](const float* src, size_t n) { const size_t at = arena.size(); arena.insert(arena.end(), src, src + n); arena.resize((arena.size() + 63) & ~(size_t)63); return at; };
+    auto need = [&](const std::string& name, std::vector<int> dims) -> const Tensor* {
+        const Tensor* t = find(name);
+        if (t && t->dims != dims) { if (err.empty() || err.find("missing") != std::string::npos) err = "weights: tensor has the wrong shape: " + name; return nullptr; }
+        return t;
+    };
+    bool ok = true;
+    auto put = [&](const std::string& name, std::vector<int> dims) -> size_t {
+        const Tensor* t = need(name, dims);
+        if (!t) { ok = false; return 0; }
+        return place(t->data, t->count);
+    };
+    auto put_conv = [&](const std::string& name, int co0, int co_n, int cin, int kh, int kw, int co_total) -> size_t {   // [co][ci][kh][kw] rows co0.. -> [co][tap][ci]
+        const Tensor* t = need(name, {co_total, cin, kh, kw});
+        if (!t) { ok = false; return 0; }
+        std::vector<float> r((size_t)co_n * kh * kw * cin);
+        for (int co = 0; co < co_n; ++co)
+            for (int c = 0; c < cin; ++c)
+                for (int tap = 0; tap < kh * kw; ++tap) r[((size_t)co * kh * kw + tap) * cin + c] = t->data[((size_t)(co0 + co) * cin + c) * kh * kw + tap];
+        return place(r.data(), r.size());
+    };
+    struct Off { size_t v; };
+    std::vector<std::pair<const float**, size_t>> fix;      // pointer slots to patch once the arena is on the device
+    auto bind = [&](const float** slot, size_t at) { fix.push_back({slot, at}); };
+    auto slice = [&](const float** slot, const std::string& name, std::vector<int> dims, size_t off = 0) { const size_t at = put(name, dims); bind(slot, at + off); };
+
+    slice(&e->c1_w, "enc_conv1_w", {C, 2}); slice(&e->c1_b, "enc_conv1_b", {C}); slice(&e->c1_g, "enc_norm1_w", {C}); slice(&e->c1_beta, "enc_norm1_b", {C});
+    slice(&e->c1_slope, "enc_prelu1", {C});
+    bind(&e->c2_w, put_conv("enc_conv2_w", 0, C, C, 1, 3, C)); slice(&e->c2_b, "enc_conv2_b", {C}); slice(&e->c2_g, "enc_norm2_w", {C}); slice(&e->c2_beta, "enc_norm2_b", {C});
+    slice(&e->c2_slope, "enc_prelu2", {C});
+    auto dense = [&](ZDense& d, const std::string& pre, int groups) {
+        std::vector<float> slopes((size_t)groups * 4 * C, 1.0f);
+        for (int i = 0; i < e->depth; ++i) {
+            const std::string p = pre + std::to_string(i);
+            const Tensor* pr = need(p + "_pr", {groups * C});
+            if (!pr) { ok = false; return; }
+            const size_t a_b = put(p + "_b", {groups * C}), a_g = put(p + "_nw", {groups * C}), a_be = put(p + "_nb", {groups * C});
+            for (int g = 0; g < groups; ++g) {
+                bind(&d.w[g][i], put_conv(p + "_w", g * C, C, C * (i + 1), 2, 3, groups * C));
+                bind(&d.b[g][i], a_b + (size_t)g * C); bind(&d.gamma[g][i], a_g + (size_t)g * C); bind(&d.beta[g][i], a_be + (size_t)g * C);
+                for (int c = 0; c < C; ++c) slopes[((size_t)g * 4 + (3 - i)) * C + c] = pr->data[g * C + c];      // layer i's output lives in slot 3 - i
+            }
+        }
+        bind(&d.slope, place(slopes.data(), slopes.size()));
+    };
+    dense(e->enc_dense, "enc_dense", 1);
+    dense(e->dec_dense, "dec_dense", 2);
+    const int ad = e->attn_dim, vdim = e->H * e->vd;
+    size_t pos_w_at[4][2];
+    for (int en = 0; en < 4; ++en) {
+        for (int p = 0; p < 2; ++p) {
+            const std::string pre = "enc" + std::to_string(en) + (p ? "_t_" : "_f_");
+            ZLayer& w = e->layers[en][p];
+            slice(&w.attn_ff1_w, pre + "attn_ff1_w", {ad + e->ff1, C}); slice(&w.attn_ff1_b, pre + "attn_ff1_b", {ad + e->ff1});
+            pos_w_at[en][p] = put(pre + "pos_w", {e->H * e->pd, e->pos_dim});
+            slice(&w.ff1_out_w, pre + "ff1_out_w", {C, e->ff1}); slice(&w.ff1_out_b, pre + "ff1_out_b", {C});
+            slice(&w.nonlin_in_w, pre + "nonlin_in_w", {3 * e->hid, C}); slice(&w.nonlin_in_b, pre + "nonlin_in_b", {3 * e->hid});
+            slice(&w.nonlin_out_w, pre + "nonlin_out_w", {C, e->hid}); slice(&w.nonlin_out_b, pre + "nonlin_out_b", {C});
+            for (int i = 0; i < 2; ++i) {
+                const std::string a = pre + "sa" + std::to_string(i + 1), cv = pre + "conv" + std::to_string(i + 1), ff = pre + "ff" + std::to_string(i + 2);
+                const int fd = i ? e->ff3 : e->ffd;
+                slice(&w.sa_in_w[i], a + "_in_w", {vdim, C}); slice(&w.sa_in_b[i], a + "_in_b", {vdim}); slice(&w.sa_out_w[i], a + "_out_w", {C, vdim});
+                slice(&w.sa_out_b[i], a + "_out_b", {C});
+                slice(&w.cv_in_w[i], cv + "_in_w", {2 * C, C}); slice(&w.cv_in_b[i], cv + "_in_b", {2 * C}); slice(&w.cv_dw_w[i], cv + "_dw_w", {C, e->K});
+                slice(&w.cv_dw_b[i], cv + "_dw_b", {C}); slice(&w.cv_out_w[i], cv + "_out_w", {C, C}); slice(&w.cv_out_b[i], cv + "_out_b", {C});
+                slice(&w.ff_in_w[i], ff + "_in_w", {fd, C}); slice(&w.ff_in_b[i], ff + "_in_b", {fd}); slice(&w.ff_out_w[i], ff + "_out_w", {C, fd});
+                slice(&w.ff_out_b[i], ff + "_out_b", {C});
+            }
+            slice(&w.bypass_mid, pre + "bypass_mid", {C}); slice(&w.norm_bias, pre + "norm_bias", {C}); slice(&w.fnorm, pre + "final_norm_scale", {C});
+            slice(&w.fres, pre + "final_residual_scale", {C});
+        }
+        if (en == 1 || en == 2) {
+            const std::string pre = "enc" + std::to_string(en);
+            slice(&e->down_t[en], pre + "_down_t_w", {e->dst}); slice(&e->down_f[en], pre + "_down_f_w", {e->dsf});
+            slice(&e->out_scale[en], pre + "_out_scale", {C}); slice(&e->res_scale[en], pre + "_res_scale", {C});
+        }
+    }
+    for (int g = 0; g < 2; ++g) bind(&e->up_w[g], put_conv("dec_up_w", g * C * e->up, C * e->up, C, 1, 3, 2 * C * e->up));
+    {
+        const size_t a = put("dec_up_b", {2 * C * e->up});
+        bind(&e->up_b[0], a); bind(&e->up_b[1], a + (size_t)C * e->up);
+    }
+    slice(&e->up_g, "dec_up_nw", {2 * C}); slice(&e->up_beta, "dec_up_nb", {2 * C}); slice(&e->up_slope, "dec_up_pr", {2 * C});
+    slice(&e->mask_w, "mask_out_w", {1, C, 1, 2}); slice(&e->mask_b, "mask_out_b", {1}); slice(&e->phase_w, "phase_out_w", {2, C, 1, 2}); slice(&e->phase_b, "phase_out_b", {2});
+    if (!ok) return bail(err.find("missing") != std::string::npos ? ADE_ERR_MISSING_KEY : ADE_ERR_SHAPE_MISMATCH);
+
+    // ---- DFT tables (ZipEnhancer/STFT_Process.py:205-249): torch.hann_window(periodic=True) in fp32; angles fp32(2 pi / N) * f * n in fp32 unless "exact"
+    {
+        const int N = kZN;
+        std::vector<float> fwd((size_t)kZC2 * N), inv((size_t)kZC2 * N), win((size_t)N), iws((size_t)e->Lo);
+        const float step = (float)(2.0 * M_PI / (double)N);
+        for (int n = 0; n < N; ++n) win[n] = cosf((float)n * step) * (-0.5f) + 0.5f;
+        for (int f = 0; f < kZF; ++f) {
+            const float scale = (f == 0 || f == kZF - 1) ? 1.0f : 2.0f;
+            for (int n = 0; n < N; ++n) {
+                float c, s;
+                if (exact_dft) {
+                    const double a = 2.0 * M_PI * (double)(((long long)f * n) % N) / N;
+                    c = (float)cos(a); s = (float)sin(a);
+                } else {
+                    const float omega = (step * (float)f) * (float)n;
+                    c = cosf(omega); s = sinf(omega);
+                }
+                fwd[(size_t)f * N + n] = c * win[n];
+                fwd[(size_t)(kZF + f) * N + n] = -s * win[n];
+                inv[(size_t)f * N + n] = ((scale * c) * (float)(1.0 / N)) * win[n];
+                inv[(size_t)(kZF + f) * N + n] = ((scale * -s) * (float)(1.0 / N)) * win[n];
+            }
+        }
+        std::vector<float> raw((size_t)N + (size_t)kZHop * (e->T - 1), 0.0f);
+        for (int t = 0; t < e->T; ++t)
+            for (int n = 0; n < N; ++n) raw[(size_t)t * kZHop + n] += win[n] * win[n];
+        for (int m = 0; m < e->Lo; ++m) iws[m] = 1.0f / raw[(size_t)m + N / 2];          // inv_win_sum (static_norm, :245-249)
+        bind(&e->k_fwd, place(fwd.data(), fwd.size())); bind(&e->k_inv, place(inv.data(), inv.size())); bind(&e->inv_wsum, place(iws.data(), iws.size()));
+    }
+    // ---- projected position tables (:597-604): rows x = -(n - 1) .. n - 1 of CompactRelPositionalEncoding (the published Zipformer2 table, fp32 like
+    //      torch), times linear_pos, stored (head, pos_head_dim, 2 n - 1)
+    for (int en = 0; en < 4; ++en)
+        for (int p = 0; p < 2; ++p) {
+            const bool down = en == 1 || en == 2;
+            const int n = p ? (down ? e->dT : e->T) : (down ? e->dF : e->F), n2 = 2 * n - 1, D = e->pos_dim, HP = e->H * e->pd;
+            std::vector<float> pe((size_t)n2 * D), tab((size_t)HP * n2);
+            const float cl = sqrtf((float)D), lcl = (float)log(sqrt((double)D)), ls = (float)((double)D / (2.0 * M_PI));
+            for (int r = 0; r < n2; ++r) {
+                const float x = (float)(r - (n - 1)), sg = x > 0.0f ? 1.0f : x < 0.0f ? -1.0f : 0.0f;
+                const float xc = cl * sg * (logf(fabsf(x) + cl) - lcl), xa = atanf(xc / ls);
+                for (int k = 0; k < D / 2; ++k) { pe[(size_t)r * D + 2 * k] = cosf(xa * (float)(1 + k)); pe[(size_t)r * D + 2 * k + 1] = sinf(xa * (float)(1 + k)); }
+                pe[(size_t)r * D + D - 1] = 1.0f;
+            }
+            const float* W = arena.data() + pos_w_at[en][p];
+            for (int hp = 0; hp < HP; ++hp)
+                for (int r = 0; r < n2; ++r) {
+                    float a = 0.0f;
+                    for (int k = 0; k < D; ++k) a += pe[(size_t)r * D + k] * W[(size_t)hp * D + k];
+                    tab[(size_t)hp * n2 + r] = a;
+                }
+            bind(&e->layers[en][p].pos, place(tab.data(), tab.size()));
+        }
+
+    if (hipSetDevice(device) != hipSuccess) return bail(zfail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipMalloc((void**)&e->d_w, arena.size() * sizeof(float)) != hipSuccess) return bail(zfail(err, ADE_ERR_DEVICE, "hipMalloc of the ZipEnhancer weights failed"));
+    if (hipMemcpy(e->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer weights failed"));
+    for (auto& f : fix) *f.first = e->d_w + f.second;
+    *out = e;
+    return ADE_OK;
+}
+
+int ZipEngine::reserve(int batch, std::string& err) {
+    if (batch <= capacity) return ADE_OK;
+    ZP_HIP(hipSetDevice(device));
+    ZP_HIP(hipDeviceSynchronize());
+    if (ws) (void)hipFree(ws);
+    if (partial) (void)hipFree(partial);
+    ws = nullptr; partial = nullptr; capacity = 0;
+    const size_t B = (size_t)batch * n_win, J = B * T, tok0 = J * kZF, R = J * F, Rd = B * dT * dF, F2 = (size_t)F * up;
+    const size_t wide = (size_t)std::max({3 * hid, H * vd, 2 * C, ffd, ff3});
+    const size_t np_f = (size_t)(F + 3) & ~(size_t)3, np_t = (size_t)(T + 3) & ~(size_t)3;
+    const size_t aw = std::max(J * H * F * np_f, B * F * H * T * np_t);
+    const size_t dh = std::max(tok0 * 4 * C, R * 8 * C);
+    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C, aw,
+                            J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, R * C, R * C, R * C, R * C, R * C};
+    float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &AW, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
+                      &enc_tap[3], &enc_tap[4]};
+    keep_taps = B <= 8;                            // encoder snapshots (5 device copies per call) only for test-sized calls
+    const int nbuf = keep_taps ? 23 : 18;
+    size_t total = 0;
+    for (int i = 0; i < nbuf; ++i) total += (sizes[i] + 63) & ~(size_t)63;
+    ZP_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
+    size_t at = 0;
+    for (int i = 0; i < nbuf; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
+    if (!keep_taps) for (int i = 0; i < 5; ++i) enc_tap[i] = nullptr;
+    nrm2 = nrm + B * 8 * C * 2;                    // statistics of the tensors normalised outside the dense blocks (dense_conv_2, the up-sampler)
+    const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
+    ZP_HIP(hipMalloc((void**)&partial, B * std::max(nchunk0, nchunk2) * 64 * 2 * sizeof(double)));
+    capacity = batch;
+    return ADE_OK;
+}
+
+void ZipEngine::stats(hipStream_t s, const float* x, int ld, int ch0, int tok_per_win, int windows, const float* gamma, const float* beta, float* nrm_, int nrm_ld, int nrm_ch0) {
+    const int nchunk = (tok_per_win + kChunkTok - 1) / kChunkTok;
+    hipLaunchKernelGGL(k_zip_stats_partial, dim3((unsigned)nchunk, (unsigned)windows), dim3(256), 0, s, x, ld, ch0, tok_per_win, partial);
+    hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nchunk, (double)tok_per_win, gamma, beta, nrm_, nrm_ld, nrm_ch0);
+}
+
+// DenseBlockV2 (:701-757): layer i of group g writes its raw output (+ bias) to hist channels [g 4 C + (3 - i) C, + C) and its statistics to nrm
+void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd) {
+    const int ld = groups * 4 * C, M = windows * T * Fd;
+    for (int i = 0; i < depth; ++i)
+        for (int g = 0; g < groups; ++g) {
+            const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
+            gemm64::launch(s, DenseA{Dh, inp, nrm, d.slope, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
+                           BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin);
+            stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
+        }
+}
+
+// one fused Zipformer2 encoder layer in place on x (R rows), sequences described by geo (:143-187)
+void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
+    using namespace gemm64;
+    const int M = (int)R, ldp = attn_dim + ff1, np = (geo.n + 3) & ~3, n = geo.n, vdim = H * vd;
+    launch(s, RowsA{x, C}, WeightB{w.attn_ff1_w, C}, BiasColStore{P, w.attn_ff1_b, ldp, 0}, M, ldp, C);                                        // (:148-153)
+    const size_t lds_w = ((size_t)n * (qd + 1) + (size_t)n * qd + (size_t)n * pd + (size_t)pd * (2 * n - 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_zip_attn_weights, dim3((unsigned)geo.nseq, (unsigned)H), dim3(256), lds_w, s, (const float*)P, ldp, w.pos, AW, geo, H, qd, pd, np);   // (:154-159)
+    launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1);                      // (:160)
+    const dim3 ag((unsigned)geo.nseq, 1, (unsigned)((n + 63) / 64)), agh((unsigned)geo.nseq, (unsigned)H, (unsigned)((n + 63) / 64));
+    launch(s, RowsA{Y, C}, WeightB{w.nonlin_in_w, C}, BiasColStore{S1, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid, C);                           // (:305)
+    if (hid <= 48) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<0, 3>), ag, dim3(256), 0, s, (const float*)AW, (const float*)S1, 3 * hid, O, hid, geo, H, hid, np);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<0, 4>), ag, dim3(256), 0, s, (const float*)AW, (const float*)S1, 3 * hid, O, hid, geo, H, hid, np);   // (:310-316)
+    launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid);                              // (:317, :167)
+    for (int i = 0; i < 2; ++i) {
+        launch(s, RowsA{Y, C}, WeightB{w.sa_in_w[i], C}, BiasColStore{S1, w.sa_in_b[i], vdim, 0}, M, vdim, C);                               // (:296)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<1, 1>), agh, dim3(256), 0, s, (const float*)AW, (const float*)S1, vdim, O, vdim, geo, H, vd, np);   // (:297-300)
+        launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim);                         // (:301, :168 / :172)
+        launch(s, RowsA{Y, C}, WeightB{w.cv_in_w[i], C}, BiasColStore{S1, w.cv_in_b[i], 2 * C, 0}, M, 2 * C, C);                             // (:321)
+        hipLaunchKernelGGL(k_zip_dwconv, dim3((unsigned)geo.nseq, (unsigned)((n + 63) / 64)), dim3(256), (size_t)(64 + K - 1) * C * sizeof(float), s, (const float*)S1,
+                           w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);                                                                         // (:325-336)
+        launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
+        const int fd = i ? ff3 : ffd;
+        launch(s, RowsA{Y, C}, WeightB{w.ff_in_w[i], C}, BiasColStore{S1, w.ff_in_b[i], fd, 0}, M, fd, C);
+        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd);   // (:170-171)
+        else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
+    }
+    hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+}
+
+void ZipEngine::dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff) {        // (:782-792)
+    const long long R = (long long)B * Tt * Ff;
+    layer(s, layers[e][0], x, R, SeqGeo{B * Tt, Ff, 1, (long long)Ff, 0, 1});                               // frequency path: (b, t) sequences of Ff consecutive rows
+    layer(s, layers[e][1], x, R, SeqGeo{B * Ff, Tt, Ff, (long long)Tt * Ff, 1, (long long)Ff});             // time path: (b, f) sequences, rows Ff apart
+}
+
+int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
+    if (batch == 0) return ADE_OK;
+    int st = reserve(batch, err);
+    if (st != ADE_OK) return st;
+    const int B = batch * n_win, J = B * T, TF0 = T * kZF, F2 = F * up;
+    const long long tok0 = (long long)J * kZF, R = (long long)J * F;
+    auto flat = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+    auto snap = [&](int i) { if (enc_tap[i]) (void)hipMemcpyAsync(enc_tap[i], X, (size_t)R * C * sizeof(float), hipMemcpyDeviceToDevice, s); };
+    // ---- front (:819-844)
+    hipLaunchKernelGGL(k_zip_window_norm, dim3((unsigned)B), dim3(256), 0, s, d_in, float_in, norm, L);
+    gemm::launch(s, gemm::RowMajorA{k_fwd, kZN}, ZFrameB{d_in, float_in, norm, L, T}, ZSpecStore{spec, J}, kZC2, J, kZN);
+    const int nchunk0 = (TF0 + kChunkTok - 1) / kChunkTok;
+    hipLaunchKernelGGL(k_zip_features, dim3((unsigned)nchunk0, (unsigned)B), dim3(256), 0, s, (const float*)spec, (float2*)feat, partial, T, J, kChunkTok);
+    hipLaunchKernelGGL(k_zip_conv1_coef, dim3((unsigned)B), dim3(64), 0, s, (const double*)partial, nchunk0, (double)TF0, c1_w, c1_b, c1_g, c1_beta, (float4*)coef, C);
+    hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
+    // ---- DenseEncoder (:852-853)
+    dense_block(s, enc_dense, 1, E0, B, kZF);
+    if (getenv("ADE_ZIP_DEBUG_STOP")) { snap(0); (void)hipMemcpyAsync(X, Dh, std::min((size_t)R * C, (size_t)tok0 * 4 * C) * sizeof(float), hipMemcpyDeviceToDevice, s); snap(1); return ADE_OK; }
+    gemm64::launch(s, RowConvA{Dh, nrm, enc_dense.slope, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
+    stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
+    hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
+    snap(0);
+    // ---- the four dual-path encoders (:859-863)
+    for (int e = 0; e < 4; ++e) {
+        if (e == 1 || e == 2) {                                                                                     // (:794-816)
+            const long long Rd = (long long)B * dT * dF;
+            hipLaunchKernelGGL(k_zip_downsample, flat(Rd * C), dim3(256), 0, s, (const float*)X, X2, down_t[e], down_f[e], T, F, dT, dF, dst, dsf, C, Rd * C);
+            dualpath(s, e, X2, B, dT, dF);
+            hipLaunchKernelGGL(k_zip_upsample_combine, flat(R * C), dim3(256), 0, s, X, (const float*)X2, out_scale[e], res_scale[e], T, F, dT, dF, dst, dsf, C, R * C);
+        } else dualpath(s, e, X, B, T, F);
+        snap(e + 1);
+    }
+    // ---- mask | phase decoder pair (:864-893)
+    dense_block(s, dec_dense, 2, X, B, F);
+    for (int g = 0; g < 2; ++g) {
+        gemm64::launch(s, RowConvA{Dh, nrm, dec_dense.slope, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
+                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
+        stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
+    }
+    hipLaunchKernelGGL(k_zip_heads, dim3((unsigned)((kZF + 63) / 64), (unsigned)((J + 3) / 4)), dim3(256), 0, s, (const float*)U, (const float*)nrm2, up_slope, mask_w, mask_b,
+                       phase_w, phase_b, packed, mask_tap, T, F2, C, J);
+    gemm::launch(s, PlanarA{packed, J}, gemm::RowMajorB{k_inv, kZN}, gemm::BiasActStore<gemm::kActNone>{frames_buf, kZN, nullptr, 0.0f}, J, kZN, kZC2);
+    const long long total = (long long)B * Lo;
+    hipLaunchKernelGGL(k_zip_ola_pcm, flat(total), dim3(256), 0, s, (const float*)frames_buf, inv_wsum, (const float*)norm, d_out, d_f32, T, Lo, total);
+    ZP_HIP(hipGetLastError());
+    return ADE_OK;
+}
+
+// taps: "enc_in", "enc0" .. "enc3": (windows, T, F, C) after the dense encoder / each dual-path encoder (kept for calls of at most 8 windows); "mask": (windows, T, 201) raw mask head; "packed": (402, windows * T) synthesis input.
+int ZipEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {
+    const size_t B = (size_t)batch * n_win, J = B * T;
+    const float* src = nullptr;
+    size_t n = 0;
+    if (strcmp(name, "enc_in") == 0) { src = enc_tap[0]; n = J * F * C; }
+    else if (strncmp(name, "enc", 3) == 0 && name[3] >= '0' && name[3] <= '3' && !name[4]) { src = enc_tap[1 + name[3] - '0']; n = J * F * C; }
+    else if (strcmp(name, "mask") == 0) { src = mask_tap; n = J * kZF; }
+    else if (strcmp(name, "packed") == 0) { src = packed; n = (size_t)kZC2 * J; }
+    else if (strcmp(name, "spec") == 0) { src = spec; n = (size_t)kZC2 * J; }                     // (402, windows * T)
+    else if (strcmp(name, "feat") == 0) { src = feat; n = J * kZF * 2; }                          // (windows, T, 201, {mag, pha})
+    else if (strcmp(name, "e0") == 0) { src = E0; n = J * kZF * C; }                              // (windows, T, 201, C): dense-encoder input
+    else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's raw dense outputs (windows, T, F, 8 C)
+    else if (strcmp(name, "nrm") == 0) { src = nrm; n = B * 8 * C * 2; }
+    else return zfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    if (!src || batch <= 0) return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet (encoder taps are kept for calls of at most 8 windows)");
+    if (count < n) return zfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+    ZP_HIP(hipStreamSynchronize(s));
+    ZP_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    *written = n;
+    return ADE_OK;
+}
+
+}  // namespace ade

@@ -286,8 +286,13 @@ class ZipEnhancerOracle:
             out = y
         return out
 
-    def process(self, pcm, taps=False):
-        """int16 (B, n_win * L) -> (int16 (B, n_win * L), fp32 pre-cast waveform, taps)."""
+    def process(self, pcm, taps=False, spectrum=None):
+        """int16 (B, n_win * L) -> (int16 (B, n_win * L), fp32 pre-cast waveform, taps).
+        ``spectrum`` = (re, im), each (windows, 201, T): continue from a given STFT instead of this oracle's own.  The phase feature
+        atan2(im, re + 1e-5) (:844) has a branch cut on the negative real axis, and the two reflect-padded edge frames are symmetric, so
+        their spectra are real up to round-off: for a low bin with re < 0 the SIGN of that round-off -- i.e. +pi or -pi -- depends on the
+        summation order of whoever computed the STFT (torch's conv1d, ONNX Runtime, this numpy einsum and the HIP GEMM all differ).
+        Tests therefore pin the network on identical spectra and the spectrum separately."""
         w = self.w
         C = self.C
         pcm = np.asarray(pcm)
@@ -295,7 +300,9 @@ class ZipEnhancerOracle:
         audio = pcm.astype(F32).reshape(Bc * self.n_win, self.L)                      # fold (:837); int16 amplitude (:819)
         norm = np.sqrt(np.mean(audio * audio, axis=-1, keepdims=True, dtype=F32) + F32(1e-6)).astype(F32)   # (:839)
         audio = (audio / norm).astype(F32)
-        re, im = self.stft(audio)
+        re, im = self.stft(audio) if spectrum is None else (np.asarray(spectrum[0], F32), np.asarray(spectrum[1], F32))
+        if taps:
+            tp0 = {"spec_re": re, "spec_im": im}
         mag = np.power(re * re + im * im + F32(1e-9), F32(0.15)).astype(F32)           # (:843)
         pha = np.arctan2(im, re + F32(1e-5)).astype(F32)                              # (:844)
         x = np.stack((mag, pha), axis=-1).transpose(0, 2, 1, 3)                       # (B, T, 201, 2) channels-last (:850)
@@ -306,7 +313,7 @@ class ZipEnhancerOracle:
         F = (FBINS + 2 - 3) // 2 + 1
         y = sum(xp[:, :, kf:kf + 2 * F - 1:2] @ w2[:, :, 0, kf].T for kf in range(3)) + w["enc_conv2_b"]
         x = prelu(instance_norm(y.astype(F32), w["enc_norm2_w"], w["enc_norm2_b"]), w["enc_prelu2"])
-        tp = {"enc_in": x} if taps else {}
+        tp = dict(tp0, enc_in=x) if taps else {}
         for e in range(4):                                                            # (:860-863)
             x = self.downsampled(e, x) if e in (1, 2) else self.dualpath(e, x)
             if taps:
