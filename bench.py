@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""bench.py — RTF / audio-seconds-per-second of the GTCRN chunk path at batch = 256 x 1 s chunks (BASELINE.json).
+"""bench.py — RTF / audio-seconds-per-second of the chunk path; default = GTCRN at batch = 256 x 1 s chunks (BASELINE.json configs[1]).
+
+`--workload zipenhancer | melband | mossformer` selects the other BASELINE configs (configs[2] / [3] / [4]) at their own batch shapes;
+the default invocation is unchanged.
 
 A "step" is one pass of the hot path (int16 PCM in HBM -> STFT -> GTCRN -> mask -> ISTFT/OLA -> int16 PCM in HBM)
 over one batch of 256 synthetic 1 s chunks per GPU (`configs[1]`), through libade's C ABI on device buffers.
@@ -70,7 +73,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="chunks per GPU per step")
+    ap.add_argument("--workload", default="gtcrn", choices=["gtcrn", "zipenhancer", "melband", "mossformer"],
+                    help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]")
+    ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = the workload's BASELINE batch: 256 / 128 / 32 / 64)")
+    ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-inclusive leg (pinned host buffers through ade_process; 0 = skip)")
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
@@ -98,6 +104,70 @@ def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
                       f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5)}
 
 
+def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, what: str):
+    """The numpy oracle of a GEMM-shaped family timed on ONE row of the workload (these oracles take 10 - 60 s per row on a host CPU)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    o = make_oracle()
+    t0 = time.perf_counter()
+    o.process(x_row)
+    dt = time.perf_counter() - t0
+    return {"value": round(seconds_per_row / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"1 row of the workload ({what}) through the numpy fp32 oracle (BLAS threads = host default), {dt:.1f} s wall",
+            "rtf": round(dt / seconds_per_row, 4)}
+
+
+def build_workload(name: str, batch: int, rank: int, local_rank: int):
+    """-> dict(sess, B, x_host (B, row_in) int16, sr, out_seconds_per_row, flop_per_row, metric, workload, weights, cpu)"""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch, synth_chunk
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    if name == "zipenhancer":                                      # BASELINE configs[2]: 128 x 1 s chunks
+        from audio_denoiser_onnx_amd import zipenhancer as zp
+        cfg, B = zp.ZipConfig(), batch or 128
+        tensors = zp.synthetic_tensors(cfg)
+        sess = InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK), device_id=local_rank)
+        x = synth_batch(B, CHUNK, first_index=rank * B)
+
+        def cpu():
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            from zipenhancer_oracle import ZipEnhancerOracle
+            return cpu_baseline_numpy(lambda: ZipEnhancerOracle(tensors, CHUNK), x[:1], 1.0, "one 1 s chunk, 161 frames x 101 sub-bands")
+        return dict(sess=sess, B=B, x=x, sr=16000, flop=2.0 * zp.macs_per_window(sess.frames, cfg)["total"], cpu=cpu,
+                    metric="audio_seconds_per_second (ZipEnhancer 16 kHz, batch=128 x 1 s chunks; RTF = 1/value)",
+                    workload="ZipEnhancer 16 kHz, batch=128 x 1 s chunks (161 frames x 101 sub-bands), fp32 matrix cores, int16 PCM in/out resident in HBM "
+                             "(BASELINE.json configs[2]; bf16 there, fp32 here: the parity dtype)",
+                    weights="random-init weights of the architecture (zipenhancer.synthetic_tensors, 2.1 M parameters; no checkpoint is available offline)",
+                    target_rtf=0.01)
+    if name == "melband":                                          # BASELINE configs[3]: 32 x 8 s stereo segments @ 44.1 kHz
+        from audio_denoiser_onnx_amd import melband, weightgen
+        B, L, depth = batch or 32, 352800, 6
+        w = weightgen.materialise(melband.synthetic_spec(depth))
+        sess = InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(L), device_id=local_rank)
+        del w
+        x = np.stack([np.stack((synth_chunk(rank * B + i, L, 44100), np.roll(synth_chunk(rank * B + i, L, 44100), 7))).reshape(-1) for i in range(B)])
+        return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=None,
+                    metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
+                    workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), fp32 matrix cores, int16 PCM resident in HBM "
+                             "(BASELINE.json configs[3]; bf16 there, fp32 here)",
+                    weights="random-init weights of the architecture (melband.synthetic_spec, depth 6)", target_rtf=None)
+    if name == "mossformer":                                       # BASELINE configs[4]: 64 x 4 s
+        from audio_denoiser_onnx_amd import mossformer
+        B, L, layers = batch or 64, 64000, 24
+        frames = mossformer.frames_of(L)
+        fused = {n: mossformer.synthetic_tensor(n, sh, sc, frames) for n, sh, sc in mossformer.synthetic_spec(layers)}
+        scalars = dict(mossformer.DEFAULT_SCALARS, fs_front_alpha=[0.25] * layers)
+        sess = InferenceSession(weights=pack_blob(mossformer.model_tensors(fused, scalars, L)), metadata=mossformer.metadata(L), device_id=local_rank)
+        del fused
+        x = np.stack([(synth_chunk(rank * B + i, L).astype(np.int32) + synth_chunk(10000 + rank * B + i, L)).clip(-32768, 32767).astype(np.int16) for i in range(B)])
+        return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=None,
+                    metric="audio_seconds_per_second (MossFormer2-SS-16K, batch=64 x 4 s; RTF = 1/value)",
+                    workload="MossFormer2-SS-16K two-speaker separation, 24 layers, batch=64 x 4 s (7999 frames), fp32 matrix cores, int16 PCM resident in HBM "
+                             "(BASELINE.json configs[4])",
+                    weights="random-init weights of the published geometry (mossformer.synthetic_spec, 24 layers)", target_rtf=None)
+    raise SystemExit(f"unknown workload {name}")
+
+
 def main():
     args = parse_args()
     import torch
@@ -122,19 +192,28 @@ def main():
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_batch
 
-    with open(os.path.join(REPO, "tests", "golden", "gtcrn_seed0.adew"), "rb") as f:
-        blob = f.read()
-    meta = build_audio_metadata(producer="bench.py", model_name="GTCRN", task="denoise", model_family="gtcrn",
-                                input_audio_length=CHUNK)
-    sess = InferenceSession(weights=blob, metadata=meta, device_id=local_rank)
+    gtcrn = args.workload == "gtcrn"
+    if gtcrn:
+        with open(os.path.join(REPO, "tests", "golden", "gtcrn_seed0.adew"), "rb") as f:
+            blob = f.read()
+        meta = build_audio_metadata(producer="bench.py", model_name="GTCRN", task="denoise", model_family="gtcrn",
+                                    input_audio_length=CHUNK)
+        sess = InferenceSession(weights=blob, metadata=meta, device_id=local_rank)
+        B = args.batch or 256
+        x_host = synth_batch(B, CHUNK, first_index=rank * B)
+        sr, wl = SR, None
+    else:
+        wl = build_workload(args.workload, args.batch, rank, local_rank)
+        sess, B, x_host, sr = wl["sess"], wl["B"], wl["x"], wl["sr"]
+        if args.steps == 100 and args.warmup == 10:      # the defaults are sized for GTCRN's 0.4 ms steps; these steps take 0.2 - 1.2 s
+            args.steps, args.warmup = 5, 1
+        args.ramp_ms = 0.0
     if args.no_graph:
         sess.set_option("graph", "0")
-    B = args.batch
     sess.reserve(B)
-    x_host = synth_batch(B, CHUNK, first_index=rank * B)
     d_in = torch.from_numpy(x_host).cuda()
-    d_out = torch.empty((B, sess.out_len), dtype=torch.int16, device="cuda")
-    gathered = torch.empty((world * B, sess.out_len), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
+    d_out = torch.empty((B, sess.row_out), dtype=torch.int16, device="cuda")
+    gathered = torch.empty((world * B, sess.row_out), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
     # A real (non-null) stream: ade_process_device treats a NULL stream handle as "run synchronously", which would put a
     # host round trip between consecutive steps.  Steps are enqueued back to back; the timed region is still bracketed
     # by barrier + torch.cuda.synchronize() on both sides.
@@ -175,12 +254,31 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    audio_s_per_step = world * B * (sess.out_len / SR)
+    out_seconds_per_row = sess.out_len / sr
+    audio_s_per_step = world * B * out_seconds_per_row
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = audio_s_per_step * args.steps / elapsed
 
+    # the reference's own timing convention (wall clock around the slice loop INCLUDING the host <-> device copies, Inference_GTCRN_ONNX.py:323-343;
+    # SURVEY.md section 8 d1): the same batch through the host-buffer entry ade_process on page-locked caller buffers.  Reported beside the
+    # device-resident headline, never as `value`.
+    host_inclusive = None
+    if rank == 0 and args.host_steps > 0:
+        pin_in = torch.from_numpy(x_host.copy()).pin_memory()
+        pin_out = torch.empty((B, sess.row_out), dtype=torch.int16).pin_memory()
+        p_in, p_out = pin_in.numpy(), pin_out.numpy()
+        hs = args.host_steps if gtcrn else min(args.host_steps, 3)
+        sess.process_into(p_in, p_out)
+        t_h = time.perf_counter()
+        for _ in range(hs):
+            sess.process_into(p_in, p_out)
+        h_ms = (time.perf_counter() - t_h) / hs * 1e3
+        host_inclusive = {"ms_per_step": round(h_ms, 4), "value": round(B * out_seconds_per_row / (h_ms * 1e-3), 1), "unit": "audio-s/s",
+                          "rtf": float(f"{h_ms * 1e-3 / (B * out_seconds_per_row):.3e}"), "steps": hs,
+                          "note": "synchronous ade_process on page-locked host buffers: H2D + kernels + D2H per step, one GPU"}
+
     roofline = cpu = kernels = None
-    if rank == 0:
+    if rank == 0 and gtcrn:
         # per-kernel device time, HIP events on the launch stream (ade_profile_last), averaged over a few forwards
         def timed(mode, reps=10):
             sess.profile(mode)
@@ -205,9 +303,9 @@ def main():
         tf = flops_launch / t_launch / 1e12
         gbs = bytes_launch / t_launch / 1e9
         if tf / FP32_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            roofline = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                        "peak_note": "fp32 dense peak (f32-MFMA rate == fp32 VALU rate, 157.3 TF); this kernel is fp32 VALU work",
+                        "peak_note": "packed-fp32 VALU peak, 157.3 TFLOP/s (numerically the same as the dense f32-MFMA rate on gfx950); the kernel has no matrix-core work",
                         "avg_launch_us": round(t_launch * 1e6, 2), "alt_hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -234,10 +332,29 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(blob, x_host, args.cpu_seconds)
+    elif rank == 0:
+        # A GEMM-shaped family is hundreds of launches per step (fp32 matrix-core GEMMs + row kernels), so the roofline object prices the WHOLE
+        # step against the dense fp32 matrix rate: achieved = algorithmic flops of the step / the step's device time.  Per-kernel device times and the
+        # MFMA-busy counters of the same command are the committed rocprofv3 summaries under profiles/ (named in `evidence`).
+        per_gpu_step_s = elapsed / max(1, args.steps)
+        tf = wl["flop"] * B / per_gpu_step_s / 1e12
+        roofline = {"kernel": "whole step (all launches)", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                    "peak_note": "dense f32-MFMA rate (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s; flops = 2 x MACs of the model's matrix products per row x rows",
+                    "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}
+        for cand in (f"r02_{args.workload}_mfma_busy.json",):
+            try:
+                with open(os.path.join(REPO, "profiles", cand)) as f:
+                    roofline["mfma_busy"] = json.load(f)
+                    roofline["evidence"] = "profiles/" + cand
+            except (OSError, ValueError):
+                pass
+        if world == 1 and args.cpu_seconds > 0 and wl["cpu"] is not None:
+            cpu = wl["cpu"]()
 
     if rank == 0:
         line = {
-            "metric": "audio_seconds_per_second (GTCRN 16 kHz, batch=256 x 1 s chunks; RTF = 1/value)",
+            "metric": "audio_seconds_per_second (GTCRN 16 kHz, batch=256 x 1 s chunks; RTF = 1/value)" if gtcrn else wl["metric"],
             "value": round(value, 1),
             "unit": "audio-s/s",
             "rtf": float(f"{1.0 / value:.3e}"),
@@ -250,16 +367,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
-                                   "(BASELINE.json configs[1])",
-                       "chunks_per_gpu": B, "chunk_samples": CHUNK, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
-                       "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)",
-                       "launch": "one kernel per step (k_gtcrn_chunk), plain launch" if not args.no_graph else "one kernel per step, hipGraph disabled",
+            "config": {"workload": ("GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
+                                    "(BASELINE.json configs[1])") if gtcrn else wl["workload"],
+                       "chunks_per_gpu": B, "chunk_samples": sess.in_len, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
+                       "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)" if gtcrn else wl["weights"],
+                       "launch": ("one kernel per step (k_gtcrn_chunk), plain launch" if not args.no_graph else "one kernel per step, hipGraph disabled") if gtcrn
+                                 else "the sub-engine's launch sequence (replayed from a captured hipGraph unless --no-graph)",
                        "stitch_all_gather": bool(gathered is not None)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "host_inclusive": host_inclusive,
             "kernels": kernels,
         }
+        if not gtcrn and wl.get("target_rtf"):
+            line["target_rtf"] = wl["target_rtf"]
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
