@@ -71,6 +71,7 @@ class AdeLibrary:
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "The engine has no CPU fallback.")
         self.path = path
+        self.is_simulator = "hipsim" in os.path.basename(path)     # tests/hipsim build: device memory is host memory (TEST-ONLY library)
         # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64/libhsa-runtime64, and a second
         # copy loaded later reports "No HIP GPUs are available".  Loading torch's first makes libade's
         # DT_NEEDED libamdhip64.so.7 resolve to the copy already in the process (torch is this package's

@@ -43,6 +43,31 @@ def stitch_rows(local: np.ndarray, n_rows: int, world: int, rank: int, group=Non
     return gathered[:n_rows].cpu().numpy()
 
 
+def sharded_run(session, rows: np.ndarray, world: int, rank: int, group=None) -> np.ndarray:
+    """``rows`` (n, row_in) int16 -> (n, row_out) int16 on every rank: this rank's contiguous block goes through ``run_device`` on DEVICE
+    tensors straight into its padded gather block, the blocks are all-gathered where they are (RCCL over xGMI with the "nccl" backend), and the
+    stitched result crosses to the host once.  No host round trip between the engine and the collective.  With the gloo backend (CPU tests on
+    the host-simulated engine, whose device memory is host memory) the same code runs on CPU tensors."""
+    import torch
+    import torch.distributed as dist
+
+    n = rows.shape[0]
+    per = (n + world - 1) // world
+    lo, hi = shard_bounds(n, world, rank)
+    on_gpu = torch.cuda.is_available() and getattr(session, "device_id", -1) >= 0 and not getattr(session._lib, "is_simulator", False)
+    compute = torch.device("cuda", session.device_id) if on_gpu else torch.device("cpu")
+    comm = compute if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    block = torch.zeros((per, session.row_out), dtype=torch.int16, device=compute)
+    if hi > lo:
+        d_in = torch.from_numpy(np.ascontiguousarray(rows[lo:hi], dtype=np.int16)).to(compute)
+        session.run_device(d_in, block[: hi - lo])                         # synchronous on the engine's own stream
+    block = block.to(comm)
+    gathered = torch.empty((world * per, session.row_out), dtype=torch.int16, device=comm)
+    # neither RCCL/NCCL nor gloo has an int16 datatype: move the rows as raw bytes
+    dist.all_gather_into_tensor(gathered.view(torch.uint8), block.view(torch.uint8), group=group)
+    return gathered[:n].cpu().numpy()
+
+
 def stitch_device(d_local, d_gathered, group=None) -> None:
     """Device-tensor form used by bench.py --stitch: ``d_gathered[(world*B), out_len] <- all ranks' d_local[B, out_len]``."""
     import torch.distributed as dist

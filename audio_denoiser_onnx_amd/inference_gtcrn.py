@@ -138,6 +138,9 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
     audio_len = output_length(len(audio), in_rate, out_rate, rounded=dfsmn)
     slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng,
                            out_stride=(not dfsmn) and in_rate == out_rate)
+    if world > 1 and not sequential and hasattr(session, "run_device"):
+        from .distributed import sharded_run
+        return sharded_run(session, slices, world, rank, group).reshape(-1)[:audio_len]      # device block -> all-gather -> one D2H
     lo, hi = shard_bounds(len(slices), world, rank)
     mine = slices[lo:hi]
     if sequential:

@@ -27,3 +27,12 @@ def synth_chunk(index: int, length: int = 16000, sample_rate: int = 16000) -> np
 def synth_batch(batch: int, length: int = 16000, first_index: int = 0, sample_rate: int = 16000) -> np.ndarray:
     return np.stack([synth_chunk(first_index + i, length, sample_rate) for i in range(batch)]) if batch else \
         np.zeros((0, length), np.int16)
+
+
+def synth_stereo(index: int, length: int, sample_rate: int = 44100) -> np.ndarray:
+    """(2, length) int16: right = left delayed by 7 samples + independent noise (the Mel-Band-Roformer workload)."""
+    left = synth_chunk(index, length, sample_rate)
+    rng = np.random.default_rng(99991 + int(index))
+    right = np.roll(left.astype(np.float64), 7) + rng.normal(0.0, 0.02 * 32768.0, length)
+    right[:7] = 0.0
+    return np.stack((left, np.clip(np.round(right), -32768, 32767).astype(np.int16)))

@@ -145,7 +145,8 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int):
         w = weightgen.materialise(melband.synthetic_spec(depth))
         sess = InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(L), device_id=local_rank)
         del w
-        x = np.stack([np.stack((synth_chunk(rank * B + i, L, 44100), np.roll(synth_chunk(rank * B + i, L, 44100), 7))).reshape(-1) for i in range(B)])
+        from audio_denoiser_onnx_amd.synth import synth_stereo
+        x = np.stack([synth_stereo(rank * B + i, L, 44100).reshape(-1) for i in range(B)])
         return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=None,
                     metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
                     workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), fp32 matrix cores, int16 PCM resident in HBM "

@@ -34,7 +34,8 @@ def default_meta(length: int = 16000, **over):
 
 def hipsim_library() -> _lib.AdeLibrary:
     """Build (if stale) and load the host-simulated engine.  TEST-ONLY: same csrc/*.hip, g++ + tests/hipsim shim."""
-    srcs = [os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", f) for f in ("ade_kernels.hip", "ade_fused.hip", "ade_stage_net.h", "ade_stage_frontback.h", "ade_engine.hip", "ade_internal.h", "ade_device.h")]
+    import glob
+    srcs = sorted(glob.glob(os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", "*.h")))
     srcs += [os.path.join(HERE, "hipsim", "hipsim.cpp"), os.path.join(HERE, "hipsim", "hip", "hip_runtime.h")]
     if not os.path.exists(HIPSIM_LIB) or any(os.path.getmtime(s) > os.path.getmtime(HIPSIM_LIB) for s in srcs):
         subprocess.run([os.path.join(HERE, "hipsim", "build.sh")], check=True)

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard the slices of one file, run a stand-in compute on their block
-and stitch with the same all-gather the GPU path uses (audio_denoiser_onnx_amd/distributed.py).  The compute stand-in
-is a pure function of each row, like the real engine (rows are independent reference calls)."""
+"""N>1 path on CPU: world_size-2 gloo processes shard the slices of one file, run THE ENGINE on their block -- the same csrc/*.hip sources
+under the host simulator (tests/hipsim, test-only), called through libade's C ABI exactly like on a GPU -- and stitch with the same
+all-gather the GPU path uses (audio_denoiser_onnx_amd/distributed.py::sharded_run).  The stitched file must equal the single-process answer
+bit for bit and the oracle within the parity tolerance."""
 import os
 import socket
 import subprocess
@@ -28,31 +29,37 @@ def test_world_size_2_gloo_shard_and_stitch(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(textwrap.dedent(f"""
         import os, sys
-        sys.path.insert(0, {REPO!r})
+        sys.path.insert(0, {REPO!r}); sys.path.insert(0, {HERE!r})
         import numpy as np, torch.distributed as dist
+        from ade_testlib import golden_blob, golden_inputs, hipsim_library, make_session
         from audio_denoiser_onnx_amd.inference_gtcrn import cut_slices, denoise
-
-        class FakeSession:                      # stand-in for the engine: out row = f(in row), rows independent
-            in_len, out_len = 16000, 15872
-            def process(self, pcm, want_f32=False):
-                return (pcm[:, :15872].astype(np.int32) // 2 + 7).astype(np.int16), None
+        from oracle_lib import GtcrnOracle
 
         dist.init_process_group("gloo")
         rank, world = dist.get_rank(), dist.get_world_size()
-        audio = (np.arange(156302) % 20011 - 10000).astype(np.int16)
-        out = denoise(FakeSession(), audio, rank=rank, world=world)
-        ref = denoise(FakeSession(), audio)                       # single-process answer
-        assert out.shape == ref.shape == (156302,) and np.array_equal(out, ref), rank
+        ins = golden_inputs()
+        audio = np.concatenate((ins["wav0"], ins["randn"], ins["wav1"]))[:40000]       # 3 slices of 16000 at stride 15872: ranks get 2 + 1
+        sess = make_session(hipsim_library(), seed=0)                                   # the engine (host-simulated), one per rank
+        out = denoise(sess, audio, rank=rank, world=world)                              # sharded_run: device block -> all-gather
+        assert out.shape == (40000,), out.shape
+        if rank == 0:
+            ref = denoise(sess, audio)                                                  # single-process answer, same engine
+            assert np.array_equal(out, ref)
+            slices, _ = cut_slices(audio, 16000, 15872)
+            want = GtcrnOracle(golden_blob(0), 16000).process(slices)[0].reshape(-1)[:40000]
+            assert np.abs(out.astype(np.int32) - want.astype(np.int32)).max() <= 1
         dist.barrier()
         dist.destroy_process_group()
         print("rank", rank, "ok")
     """))
+    from ade_testlib import hipsim_library
+    hipsim_library()                                   # build once here, not concurrently in both workers
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\\n".join(outs)
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("ok" in o for o in outs)

@@ -84,7 +84,8 @@ def weight_spec(model) -> list:
     return spec
 
 
-def build_model(ns, length):
+def build_model(ns, length, depth=None):
+    depth = DEPTH if depth is None else depth
     T = ns["MAX_SIGNAL_LENGTH"]
     fold = bool(ns["USE_BATCH_FOLD"])
     STFT_Process = import_stft_process("Mel_Band_Roformer/Stereo").STFT_Process
@@ -96,7 +97,7 @@ def build_model(ns, length):
     nn.Module.load_state_dict = lambda self, sd, strict=True: types.SimpleNamespace(missing_keys=[], unexpected_keys=[])
     try:
         torch.manual_seed(0)
-        model = ns["MelBandRoformer"](stft, istft, T, fold, ns["FOLD_WINDOW_LENGTH"] if fold else 0, ns["EXPORT_AUDIO_LENGTH"], dim=384, depth=DEPTH,
+        model = ns["MelBandRoformer"](stft, istft, T, fold, ns["FOLD_WINDOW_LENGTH"] if fold else 0, ns["EXPORT_AUDIO_LENGTH"], dim=384, depth=depth,
                                       stereo=True, num_stems=1, time_transformer_depth=1, freq_transformer_depth=1, num_bands=60, dim_head=64,
                                       heads=8, mask_estimator_depth=2).eval()
     finally:
@@ -157,6 +158,39 @@ def main():
     print("fold out", out.shape, int(np.abs(out).max()))
 
 
+def production_size():
+    """Fixtures at production-relevant sizes: depth 2 x one 1.5 s batch-fold window (66150 samples, 151 frames) and
+    depth 1 x one 8 s clip (352800 samples, 801 frames = BASELINE configs[3]'s segment).  PCM in / out, the fp32 waveform BEFORE the PCM tail
+    (the ISTFT module's output) and frame-sub-sampled taps."""
+    for tag, depth, length, start, tstep in (("d2_151", 2, 66150, 44100, 1), ("d1_801", 1, 352800, 0, 4)):
+        ns = import_namespace(length)
+        model, spec, T = build_model(ns, length, depth)
+        if tstep == 1:
+            pcm = read_clip(start, length)
+        else:                                                       # the 8 s clip: this package's deterministic synthetic stereo (not stored: tests regenerate it)
+            from audio_denoiser_onnx_amd.synth import synth_stereo
+            pcm = synth_stereo(900, length, 44100)
+        taps = {}
+        orig = model._band_split
+        model._band_split = lambda x: taps.setdefault("band_split", orig(x))
+        orig_me = model._mask_estimator
+        model._mask_estimator = lambda x: taps.setdefault("masks", orig_me(taps.setdefault("tf_out", x)))
+        hook = model.istft_model.register_forward_hook(lambda m, i, o: taps.__setitem__("wave", o.detach().clone()))
+        with torch.inference_mode():
+            out = model(torch.from_numpy(pcm.reshape(1, 2, length).copy())).numpy().reshape(2, length)
+        hook.remove()
+        wave = taps["wave"].numpy().reshape(2, length)
+        np.savez_compressed(os.path.join(mg.GOLD, f"melband_seed0_{tag}_io.npz"), pcm_in=pcm if tstep == 1 else np.zeros((2, 0), np.int16), synth_index=np.int64(900),
+                            pcm_out=out, wave=wave[:, ::2 * tstep].copy(), wave_step=np.int64(2 * tstep),
+                            frames=np.int64(T), depth=np.int64(depth), spec=np.array(json.dumps(spec)), tap_step=np.int64(tstep),
+                            band_split_b0=taps["band_split"][0].numpy().reshape(T, 384)[::tstep].copy(),
+                            tf_out_b7=taps["tf_out"][7].numpy().reshape(T, 384)[::tstep].copy(),
+                            tf_out_b55=taps["tf_out"][55].numpy().reshape(T, 384)[::tstep].copy(),
+                            masks=taps["masks"].numpy().reshape(T, -1)[::tstep, :256].copy())
+        print(tag, "out", out.shape, int(np.abs(out).max()), "T", T, "tf_out rms", float(taps["tf_out"].pow(2).mean().sqrt()), flush=True)
+        del model
+
+
 def fusion_fixture():
     """Pins audio_denoiser_onnx_amd.melband.fuse_checkpoint: the reference's constructor at REDUCED width (dim 32, 2 heads of 16;
     the fold algebra :455-538 is width-generic) over a checkpoint-shaped tree whose parameters come from the generator, keyed by
@@ -196,6 +230,10 @@ def fusion_fixture():
                         names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
     print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
 
+
+if __name__ == "__main__" and "--production-size" in sys.argv:
+    production_size()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()

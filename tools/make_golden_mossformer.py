@@ -195,9 +195,9 @@ SCALAR_ATTRS = ("norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fl_norm
                 "static_window_batch", "static_window_output", "fl_inv_g", "static_inv_n")
 
 
-def build(ns, length, fold, window, in_rate=16000, out_rate=16000):
+def build(ns, length, fold, window, in_rate=16000, out_rate=16000, layers=None):
     torch.manual_seed(0)
-    net = stand_in_network(LAYERS)
+    net = stand_in_network(LAYERS if layers is None else layers)
     model = ns["MOSSFORMER_SS"](net, length, in_rate, out_rate, fold, window if fold else 0).eval()
     spec = []
     skip = ("inv_int16", "emb_pos", "rot_cos", "rot_sin", "rot_signed_sin", "rot_pair_index", "shift_pad", "pad_A4", "pad_VU", "gn_one", "gn_zero")
@@ -276,6 +276,37 @@ def main():
     print("resample out", out.shape, np.abs(out).max(axis=1))
 
 
+def production_size():
+    """Fixtures at production-relevant sizes: 4 layers x one 1.5 s window (24000 samples, 2999 frames = 12 FLASH groups,
+    the last padded) and 2 layers x one 4 s window (64000 samples, 7999 frames = 32 groups: BASELINE configs[4]'s window).  Both speakers' PCM,
+    the fp32 waveform before the integer cast (the same graph run with OUT_AUDIO_DTYPE = F32, x 32768) and channel-sub-sampled taps."""
+    for tag, layers, length, start in (("l4_2999", 4, 24000, 32000), ("l2_7999", 2, 64000, 16000)):
+        ns = import_namespace(length, False, 1.5)
+        model, spec, scalars = build(ns, length, False, 0, layers=layers)
+        pcm = read_mix(start, length)
+        taps = {}
+        orig = model._run_mdl
+
+        def tapped(mdl_input, n):
+            taps["mdl_in"] = mdl_input.clone()
+            out = orig(mdl_input, n)
+            taps["mdl_out"] = out.clone()
+            return out
+        model._run_mdl = tapped
+        x = torch.from_numpy(pcm.reshape(1, 1, -1).copy())
+        with torch.inference_mode():
+            out = np.stack([o.numpy().reshape(-1) for o in model(x)])
+            ns["OUT_AUDIO_DTYPE"] = "F32"                                      # read at call time (:649-656): the un-cast waveform / 32768
+            wave = np.stack([o.numpy().reshape(-1) for o in model(x)]) * np.float32(32768.0)
+            ns["OUT_AUDIO_DTYPE"] = "INT16"
+        assert np.abs(wave.astype(np.int32).clip(-32768, 32767) - out).max() == 0
+        np.savez_compressed(os.path.join(mg.GOLD, f"mossformer_seed0_{tag}_io.npz"), pcm_in=pcm, pcm_out=out, wave=wave[:, ::2].copy(), wave_step=np.int64(2),
+                            layers=np.int64(layers), spec=np.array(json.dumps(spec)), scalars=np.array(json.dumps(scalars)),
+                            mdl_in=taps["mdl_in"][0].numpy()[::8, ::7].copy(), mdl_out=taps["mdl_out"][0].numpy()[::8, ::7].copy())
+        print(tag, "out", out.shape, np.abs(out).max(axis=1), "frames", model.static_frames, "mdl_out rms", float(taps["mdl_out"].pow(2).mean().sqrt()), flush=True)
+        del model
+
+
 def fusion_fixture():
     """Pins audio_denoiser_onnx_amd.mossformer.fuse_checkpoint: the reference's constructor over a ONE-layer stand-in tree whose
     parameters come from the generator keyed by their state_dict names; the fixture keeps the (key, shape, scale) spec and, per
@@ -309,6 +340,10 @@ def fusion_fixture():
                         names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
     print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
 
+
+if __name__ == "__main__" and "--production-size" in sys.argv:
+    production_size()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
