@@ -336,136 +336,146 @@ struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_f
     }
 };
 
-// attention weights (:232-289): one (sequence, head) per workgroup; a wavefront takes query rows i = wave, wave + 4, ..., its lanes the keys.
-//   s[i][j] = q_i . k_j + p_i . P[:, n - 1 - i + j]   -> softmax over j -> AW[((seq * H + h) * n + i) * np + j], pad columns j in [n, np) = 0
-// LDS: K rows (stride qd + 1), Q rows, P rows, the head's projected position table (pd, 2 n - 1).
-constexpr int kMaxKeysPerLane = 5;          // n <= 320: the workgroup's operands stay under the 64 KB static-launch LDS limit
-__global__ __launch_bounds__(256) void k_zip_attn_weights(const float* __restrict__ proj, int ldp, const float* __restrict__ pos, float* __restrict__ aw, SeqGeo geo,
-                                                          int H, int qd, int pd, int np) {
+// Relative-position attention (:232-301, :304-317), fused: scores, softmax and the weighted sum of the values in ONE kernel -- the (n, n) weights
+// never leave the CU.  The layer uses the same weights three times (head 0 in NonlinAttention, all heads in both SelfAttention modules) on three
+// DIFFERENT value tensors with residual updates in between, so each use recomputes them: 6 MFMAs per 16 x 16 score tile against streaming 0.4 MB
+// of weights per sequence and use through HBM.
+//   grid (sequence, head); 4 wavefronts; wave w takes the query tiles w, w + 4, ...; per query tile ALL key tiles' scores stay in registers.
+// Everything is computed TRANSPOSED so that no operand changes lanes (v_mfma_f32_16x16x4_f32: lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15] and
+// holds D[4 (l >> 4) + r][l & 15]; with one float4 per lane the four k-steps of a slab take k = 4 g + s on both operands):
+//   S^T tile   = K_tile (16 keys x 16 dims) . Q^T (16 dims x 16 queries)            -> lane (g, j) holds S[query j][key 4 g + r]
+//   pos term   : U^T (32 offsets x 16 queries) = P_h^T[c0 .. c0 + 31] (x 4 dims) . p^T (4 dims x 16 queries): TWO one-step MFMAs; the element that
+//                belongs to (query j, key 4 g + r) is U^T[15 - j + 4 g + r][j] (out[i][j] = (p_i . P_h)[n - 1 - i + j], the reference's skew :270-284)
+//                -- same lane column, other rows -- fetched through a per-wave LDS scratch
+//   softmax    : per lane column (= query): max / sum over the lane's registers, then over the four lane groups (two shuffles)
+//   O^T tile  += V^T (16 dims x 16 keys) . P^T (16 keys x 16 queries): the B operand is the lane's own exp() registers, V^T rows come from LDS as float4
+// MODE 0 (NonlinAttention): value = tanh(s) * u of the (s | u | y) projection, head 0, DT = 3 tiles of 16 dims; result x y.
+// MODE 1 (SelfAttention): value = head h's dv <= 16 columns of the value projection; DT = 1.
+// NT = key tiles held in registers (n <= 16 NT).
+constexpr int kQKs = 20;                    // floats per staged Q / K row (16 + 4: conflict-free ds_read_b128, as in ade_gemm.h)
+constexpr int kUs = 18;                     // floats per scratch row
+template <int MODE, int NT, int DT>
+__global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj, int ldp, const float* __restrict__ pos, const float* __restrict__ src, int lds_,
+                                                  float* __restrict__ out, int ldo, SeqGeo geo, int qd_, int pd_, int dv) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
-    float* Ks = lds;                               // [n][qd + 1]
-    float* Qs = Ks + (size_t)n * (qd + 1);         // [n][qd]
-    float* Ps = Qs + (size_t)n * qd;               // [n][pd]
-    float* Pt = Ps + (size_t)n * pd;               // [pd][2 n - 1]
+    const int j16 = lane & 15, g = lane >> 4;
+    const int np16 = NT * 16, n2 = 2 * n - 1, vst = np16 + 4;
+    float* Qs = lds;                               // [np16][kQKs]
+    float* Ks = Qs + np16 * kQKs;                  // [np16][kQKs]
+    float* Pq = Ks + np16 * kQKs;                  // [np16][4]
+    float* Pt = Pq + np16 * 4;                     // [4][n2 (+ pad)]
+    float* Vt = Pt + 4 * ((n2 + 3) & ~3);          // [DT * 16][vst]   values, transposed
+    float* Us0 = Vt + DT * 16 * vst + wave * 2 * 32 * kUs;   // per-wave scratch, two [32][kUs] buffers used alternately (one wave-level sync per tile)
     const long long r0 = geo.row0(seq);
-    const int hd = 2 * qd + pd;
-    for (int i = tid; i < n * hd; i += 256) {
+    const int hd = 36;                             // 2 * 16 + 4 (checked by the host: query_head_dim 16, pos_head_dim 4)
+    for (int i = tid; i < np16 * hd; i += 256) {
         const int p = i / hd, d = i - p * hd;
-        const float v = proj[(size_t)(r0 + (long long)p * geo.ps) * ldp + h * hd + d];
-        if (d < qd) Qs[p * qd + d] = v;
-        else if (d < 2 * qd) Ks[p * (qd + 1) + d - qd] = v;
-        else Ps[p * pd + d - 2 * qd] = v;
+        const float v = p < n ? proj[(size_t)(r0 + (long long)p * geo.ps) * ldp + h * hd + d] : 0.0f;
+        if (d < 16) Qs[p * kQKs + d] = v;
+        else if (d < 32) Ks[p * kQKs + d - 16] = v;
+        else Pq[p * 4 + d - 32] = v;
     }
-    const int n2 = 2 * n - 1;
-    for (int i = tid; i < pd * n2; i += 256) Pt[i] = pos[(size_t)h * pd * n2 + i];
+    for (int i = tid; i < 4 * n2; i += 256) { const int d = i / n2, c = i - d * n2; Pt[d * ((n2 + 3) & ~3) + c] = pos[(size_t)(h * 4 + d) * n2 + c]; }
+    for (int i = tid; i < DT * 16 * np16; i += 256) {
+        const int d = i / np16, key = i - d * np16;
+        float v = 0.0f;
+        if (key < n && d < dv) {
+            const float* q = src + (size_t)(r0 + (long long)key * geo.ps) * lds_;
+            v = MODE == 0 ? tanhf(q[d]) * q[dv + d] : q[h * dv + d];
+        }
+        Vt[d * vst + key] = v;
+    }
     __syncthreads();
-    float* out = aw + ((size_t)seq * H + h) * n * np;
-    for (int i = wave; i < n; i += 4) {
-        float s[kMaxKeysPerLane];
+    const int ptst = (n2 + 3) & ~3;
+    for (int qt = wave; qt * 16 < n; qt += 4) {
+        const int q0 = qt * 16, qi = q0 + j16;
+        const float4 qv = *reinterpret_cast<const float4*>(Qs + qi * kQKs + 4 * g);       // B operand of the score product: Q[query j16][dims 4 g ..]
+        const float pq = Pq[qi * 4 + g];                                                 // B operand of the position product: p[query j16][dim g]
+        float st[NT][4];
         float mx = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < kMaxKeysPerLane; ++u) {
-            const int j = lane + 64 * u;
-            s[u] = -INFINITY;
-            if (j < n) {
-                float a = 0.0f;
-                for (int d = 0; d < qd; ++d) a = fmaf(Qs[i * qd + d], Ks[j * (qd + 1) + d], a);
-                float b = 0.0f;
-                for (int d = 0; d < pd; ++d) b = fmaf(Ps[i * pd + d], Pt[d * n2 + (n - 1 - i + j)], b);
-                s[u] = a + b;
-                mx = fmaxf(mx, s[u]);
+        for (int kt = 0; kt < NT; ++kt) {
+            const int k0 = kt * 16;
+            const float4 kv = *reinterpret_cast<const float4*>(Ks + (k0 + j16) * kQKs + 4 * g);
+            v4f sc = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            sc = mfma16x16x4(kv.x, qv.x, sc);
+            sc = mfma16x16x4(kv.y, qv.y, sc);
+            sc = mfma16x16x4(kv.z, qv.z, sc);
+            sc = mfma16x16x4(kv.w, qv.w, sc);
+            const int c0 = n - 16 - q0 + k0;                   // offset index of (query q0 + 15, key k0): u = 0
+            int ca = c0 + j16, cb = c0 + 16 + j16;
+            ca = ca < 0 ? 0 : (ca > n2 - 1 ? n2 - 1 : ca);       // outside the table only for padded queries / keys
+            cb = cb < 0 ? 0 : (cb > n2 - 1 ? n2 - 1 : cb);
+            const v4f u0 = mfma16x16x4(Pt[g * ptst + ca], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 4 g + r][query j16]
+            const v4f u1 = mfma16x16x4(Pt[g * ptst + cb], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 16 + 4 g + r][query j16]
+            float* Us = Us0 + (kt & 1) * 32 * kUs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Us[(4 * g + r) * kUs + j16] = u0[r]; Us[(16 + 4 * g + r) * kUs + j16] = u1[r]; }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sc[r] + Us[(15 - j16 + 4 * g + r) * kUs + j16];
+                st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.0f;
+        v4f acc[DT];
 #pragma unroll
-        for (int u = 0; u < kMaxKeysPerLane; ++u) {
-            const int j = lane + 64 * u;
-            if (j < n) { s[u] = expf(s[u] - mx); sum += s[u]; }
+        for (int d = 0; d < DT; ++d) acc[d] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = __expf(st[kt][r] - mx); sum += pr[r]; }          // hardware exp2 (~1 ulp); exp(-inf) = 0 for the padded keys
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * d + j16) * vst + kt * 16 + 4 * g);   // V^T[dim 16 d + j16][keys k0 + 4 g ..]
+                acc[d] = mfma16x16x4(vv.x, pr[0], acc[d]);
+                acc[d] = mfma16x16x4(vv.y, pr[1], acc[d]);
+                acc[d] = mfma16x16x4(vv.z, pr[2], acc[d]);
+                acc[d] = mfma16x16x4(vv.w, pr[3], acc[d]);
+            }
         }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (qi < n) {
+            // lane (g, j16) holds O[query qi][dims 16 d + 4 g + r]
+            const size_t row = (size_t)(r0 + (long long)qi * geo.ps);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            for (int d = 0; d < DT; ++d) {
+                const int col = 16 * d + 4 * g;
+                if (col >= dv) continue;
+                float o[4];
 #pragma unroll
-        for (int u = 0; u < kMaxKeysPerLane; ++u) {
-            const int j = lane + 64 * u;
-            if (j < np) out[(size_t)i * np + j] = j < n ? s[u] / sum : 0.0f;
+                for (int r = 0; r < 4; ++r) o[r] = acc[d][r] / sum;
+                if (MODE == 0) {
+                    float y[4];
+                    ld4(src + row * lds_ + 2 * dv + col, y);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] *= y[r];
+                }
+                st4(out + row * ldo + (MODE == 0 ? 0 : h * dv) + col, o);
+            }
         }
     }
 }
-
-// weighted sums O = A V on the matrix cores.  grid (sequence, head, 64-query blocks); wave w owns queries 16 w .. 16 w + 15 of the block.
-//   A operand: AW[i0 + j16][c + 4 g .. c + 4 g + 3] -- one float4 per lane straight from HBM (rows are padded to np, a multiple of 4)
-//   B operand: the values of 64 keys staged in LDS, V[key][DT * 16] (zero rows / columns beyond n / the value width)
-// MODE 0 (NonlinAttention, :304-317): head 0 only; value = tanh(s) * u from the (s | u | y) projection, result multiplied by y.
-// MODE 1 (SelfAttention, :292-301): value = head h's slice of the value projection.
-template <int MODE, int DT>
-__global__ __launch_bounds__(256) void k_zip_attn_apply(const float* __restrict__ aw, const float* __restrict__ src, int lds_, float* __restrict__ out, int ldo, SeqGeo geo,
-                                                        int H, int dv, int np) {
-    constexpr int kVs = DT * 16 + 4;
-    __shared__ float Vs[64 * kVs];
-    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
-    const int j16 = lane & 15, g = lane >> 4;
-    const long long r0 = geo.row0(seq);
-    const int i0 = (int)blockIdx.z * 64 + wave * 16;
-    const bool live = i0 < n;
-    const int qi = i0 + j16;
-    const float* arow = aw + (((size_t)seq * H + h) * n + (qi < n ? qi : 0)) * np;
-    v4f acc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d) acc[d] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        __syncthreads();
-        for (int i = tid; i < 64 * DT * 16; i += 256) {
-            const int p = i / (DT * 16), d = i - p * (DT * 16), key = c0 + p;
-            float v = 0.0f;
-            if (key < n && d < dv) {
-                const float* q = src + (size_t)(r0 + (long long)key * geo.ps) * lds_;
-                v = MODE == 0 ? tanhf(q[d]) * q[dv + d] : q[h * dv + d];
-            }
-            Vs[p * kVs + d] = v;
-        }
-        __syncthreads();
-        if (!live) continue;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int kk = c0 + 16 * kt + 4 * g;
-            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (qi < n && kk < np) a = *reinterpret_cast<const float4*>(arow + kk);
-            const float* vr = Vs + (16 * kt + 4 * g) * kVs + j16;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                acc[d] = mfma16x16x4(a.x, vr[16 * d], acc[d]);
-                acc[d] = mfma16x16x4(a.y, vr[kVs + 16 * d], acc[d]);
-                acc[d] = mfma16x16x4(a.z, vr[2 * kVs + 16 * d], acc[d]);
-                acc[d] = mfma16x16x4(a.w, vr[3 * kVs + 16 * d], acc[d]);
-            }
-        }
-    }
-    if (!live) return;
-    // lane (g, j16) holds O[query i0 + 4 g + r][dim 16 d + j16]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + 4 * g + r;
-        if (i >= n) continue;
-        const size_t row = (size_t)(r0 + (long long)i * geo.ps);
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            const int col = 16 * d + j16;
-            if (col >= dv) continue;
-            float v = acc[d][r];
-            if (MODE == 0) v *= src[row * lds_ + 2 * dv + col];
-            out[row * ldo + (MODE == 0 ? 0 : h * dv) + col] = v;
-        }
-    }
+template <int MODE, int NT, int DT>
+inline size_t zip_attn_lds(int n) {
+    const int np16 = NT * 16, n2 = 2 * n - 1;
+    return ((size_t)np16 * kQKs * 2 + (size_t)np16 * 4 + 4 * (size_t)((n2 + 3) & ~3) + (size_t)DT * 16 * (np16 + 4) + 4 * 2 * 32 * kUs) * sizeof(float);
 }
 
 // ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
 // the block's gated rows (+ k / 2 halo on both sides) are staged in LDS once.  g: [rows][2 C] = (value | gate); out: [rows][C].
+template <int CC, int KK>       // CC, KK > 0: channel count / kernel size known at compile time (the published geometry: 64, 15); 0: run-time values
 __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
-                                                    SeqGeo geo, int C, int K) {
+                                                    SeqGeo geo, int C_, int K_) {
     HIP_DYNAMIC_SHARED(float, lds)
+    const int C = CC > 0 ? CC : C_, K = KK > 0 ? KK : K_;
     const int seq = blockIdx.x, p0 = (int)blockIdx.y * 64, tid = threadIdx.x, n = geo.n, half = K / 2, rowsN = 64 + K - 1;
     const long long r0 = geo.row0(seq);
     for (int i = tid; i < rowsN * C; i += 256) {
@@ -593,6 +603,34 @@ __global__ __launch_bounds__(256) void k_zip_ola_pcm(const float* __restrict__ f
     }
 }
 
+// the fused attention kernel for this sequence length: NT = key tiles kept in registers (16 NT >= n)
+template <int MODE, int NT, int DT>
+bool launch_attn_nt(hipStream_t s, int heads, const float* proj, int ldp, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
+    if (geo.n > 16 * NT) return false;
+    const size_t bytes = zip_attn_lds<MODE, NT, DT>(geo.n);
+    auto kern = k_zip_attn<MODE, NT, DT>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)geo.nseq, (unsigned)heads), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, 16, 4, dv);
+    return true;
+}
+template <int MODE, int DT>
+void launch_attn(hipStream_t s, int heads, const float* proj, int ldp, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
+    (void)(launch_attn_nt<MODE, 4, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 6, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 7, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 11, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 20, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv));
+}
+template <int MODE, int NT, int DT>
+hipError_t raise_one() {
+    auto kern = k_zip_attn<MODE, NT, DT>;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int MODE, int DT>
+hipError_t raise_attn_lds() {         // the long-window instantiations need more than the default 64 KB of dynamic LDS
+    hipError_t e = raise_one<MODE, 11, DT>();
+    if (e == hipSuccess) e = raise_one<MODE, 16, DT>();
+    if (e == hipSuccess) e = raise_one<MODE, 20, DT>();
+    return e;
+}
+
 int zfail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
 #define ZP_HIP(expr)                                                                                  \
     do {                                                                                              \
@@ -635,7 +673,7 @@ struct ZipEngine : SubEngine {
     float* ws = nullptr;
     double* partial = nullptr;
     float *norm = nullptr, *spec = nullptr, *feat = nullptr, *coef = nullptr, *E0 = nullptr, *Dh = nullptr, *nrm = nullptr, *nrm2 = nullptr, *X = nullptr, *Y = nullptr, *X2 = nullptr,
-          *P = nullptr, *S1 = nullptr, *O = nullptr, *AW = nullptr, *U = nullptr, *packed = nullptr, *frames_buf = nullptr, *mask_tap = nullptr, *enc_tap[5] = {};
+          *P = nullptr, *S1 = nullptr, *O = nullptr, *U = nullptr, *packed = nullptr, *frames_buf = nullptr, *mask_tap = nullptr, *enc_tap[5] = {};
     bool keep_taps = false;
 
     ~ZipEngine() override {
@@ -655,6 +693,7 @@ struct ZipEngine : SubEngine {
     void stats(hipStream_t s, const float* x, int ld, int ch0, int tok_per_win, int windows, const float* gamma, const float* beta, float* nrm_, int nrm_ld, int nrm_ch0);
     void dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd);
     void layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo);
+    void attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv);
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
 
@@ -685,12 +724,14 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     e->hid = C * 3 / 4; e->ff1 = e->ffd * 3 / 4; e->ff3 = e->ffd * 5 / 4; e->attn_dim = e->H * (2 * e->qd + e->pd);
     if ((e->hid % 4) || (e->ff1 % 4) || (e->ff3 % 4) || (e->ffd % 4) || (e->attn_dim % 4) || ((e->H * e->vd) % 4) || e->hid > 64 || e->vd > 16 || e->H < 1)
         return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: projection widths must be multiples of 4, hidden_channels <= 64, value_head_dim <= 16"));
+    if (e->qd != 16 || e->pd != 4)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: the attention kernel is built for query_head_dim 16 and pos_head_dim 4"));
     e->T = window_len / kZHop + 1;
     e->Lo = kZHop * (e->T - 1);                       // STFT (centre pad) -> ISTFT reconstructs whole hops (STFT_Process.py:168-172)
     e->F = (kZF + 2 - 3) / 2 + 1;
     e->dT = (e->T + e->dst - 1) / e->dst;
     e->dF = (e->F + e->dsf - 1) / e->dsf;
-    if (std::max(e->T, e->F) > 64 * kMaxKeysPerLane)
+    if (std::max(e->T, e->F) > 320)
         return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: at most 320 frames per window; fold longer audio into windows (use_batch_fold)"));
 
     // ---- arena: blob tensors (some repacked), DFT tables, position tables
@@ -839,6 +880,8 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     if (hipMemcpy(e->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer weights failed"));
     for (auto& f : fix) *f.first = e->d_w + f.second;
+    if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
+        return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
     *out = e;
     return ADE_OK;
 }
@@ -852,15 +895,13 @@ int ZipEngine::reserve(int batch, std::string& err) {
     ws = nullptr; partial = nullptr; capacity = 0;
     const size_t B = (size_t)batch * n_win, J = B * T, tok0 = J * kZF, R = J * F, Rd = B * dT * dF, F2 = (size_t)F * up;
     const size_t wide = (size_t)std::max({3 * hid, H * vd, 2 * C, ffd, ff3});
-    const size_t np_f = (size_t)(F + 3) & ~(size_t)3, np_t = (size_t)(T + 3) & ~(size_t)3;
-    const size_t aw = std::max(J * H * F * np_f, B * F * H * T * np_t);
     const size_t dh = std::max(tok0 * 4 * C, R * 8 * C);
-    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C, aw,
+    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
                             J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, R * C, R * C, R * C, R * C, R * C};
-    float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &AW, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
+    float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
                       &enc_tap[3], &enc_tap[4]};
     keep_taps = B <= 8;                            // encoder snapshots (5 device copies per call) only for test-sized calls
-    const int nbuf = keep_taps ? 23 : 18;
+    const int nbuf = keep_taps ? 22 : 17;
     size_t total = 0;
     for (int i = 0; i < nbuf; ++i) total += (sizes[i] + 63) & ~(size_t)63;
     ZP_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
@@ -892,26 +933,32 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
         }
 }
 
+void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
+    const int ldp = attn_dim + ff1;
+    if (mode == 0) {
+        if (dv <= 48) launch_attn<0, 3>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+        else launch_attn<0, 4>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+    } else launch_attn<1, 1>(s, H, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+}
+
 // one fused Zipformer2 encoder layer in place on x (R rows), sequences described by geo (:143-187)
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
-    const int M = (int)R, ldp = attn_dim + ff1, np = (geo.n + 3) & ~3, n = geo.n, vdim = H * vd;
+    const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
     launch(s, RowsA{x, C}, WeightB{w.attn_ff1_w, C}, BiasColStore{P, w.attn_ff1_b, ldp, 0}, M, ldp, C);                                        // (:148-153)
-    const size_t lds_w = ((size_t)n * (qd + 1) + (size_t)n * qd + (size_t)n * pd + (size_t)pd * (2 * n - 1)) * sizeof(float);
-    hipLaunchKernelGGL(k_zip_attn_weights, dim3((unsigned)geo.nseq, (unsigned)H), dim3(256), lds_w, s, (const float*)P, ldp, w.pos, AW, geo, H, qd, pd, np);   // (:154-159)
     launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1);                      // (:160)
-    const dim3 ag((unsigned)geo.nseq, 1, (unsigned)((n + 63) / 64)), agh((unsigned)geo.nseq, (unsigned)H, (unsigned)((n + 63) / 64));
     launch(s, RowsA{Y, C}, WeightB{w.nonlin_in_w, C}, BiasColStore{S1, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid, C);                           // (:305)
-    if (hid <= 48) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<0, 3>), ag, dim3(256), 0, s, (const float*)AW, (const float*)S1, 3 * hid, O, hid, geo, H, hid, np);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<0, 4>), ag, dim3(256), 0, s, (const float*)AW, (const float*)S1, 3 * hid, O, hid, geo, H, hid, np);   // (:310-316)
+    attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
     launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid);                              // (:317, :167)
     for (int i = 0; i < 2; ++i) {
         launch(s, RowsA{Y, C}, WeightB{w.sa_in_w[i], C}, BiasColStore{S1, w.sa_in_b[i], vdim, 0}, M, vdim, C);                               // (:296)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_attn_apply<1, 1>), agh, dim3(256), 0, s, (const float*)AW, (const float*)S1, vdim, O, vdim, geo, H, vd, np);   // (:297-300)
+        attention(s, 1, w.pos, S1, vdim, O, vdim, geo, vd);                                                                                   // (:297-300) all heads
         launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim);                         // (:301, :168 / :172)
         launch(s, RowsA{Y, C}, WeightB{w.cv_in_w[i], C}, BiasColStore{S1, w.cv_in_b[i], 2 * C, 0}, M, 2 * C, C);                             // (:321)
-        hipLaunchKernelGGL(k_zip_dwconv, dim3((unsigned)geo.nseq, (unsigned)((n + 63) / 64)), dim3(256), (size_t)(64 + K - 1) * C * sizeof(float), s, (const float*)S1,
-                           w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);                                                                         // (:325-336)
+        const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
+        const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
+        if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
         launch(s, RowsA{Y, C}, WeightB{w.ff_in_w[i], C}, BiasColStore{S1, w.ff_in_b[i], fd, 0}, M, fd, C);

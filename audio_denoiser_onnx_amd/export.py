@@ -9,6 +9,7 @@ matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the
     python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold]
     python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
     python -m audio_denoiser_onnx_amd.export --family ul_unas <model_trained_on_dns3.tar> <out_dir> [--length 16000]
+    python -m audio_denoiser_onnx_amd.export --family zipenhancer <pytorch_model.bin> <out_dir> [--length 32000] [--fold]
 
 The other two families fold their checkpoints the way their export constructors do (``melband.fuse_checkpoint`` =
 Export_MelBandRoformer.py:455-538; ``mossformer.fuse_checkpoint`` = Export_MossFormer2_SS_16K.py:130-395); both folds are
@@ -148,6 +149,25 @@ def export_hgtcrn(checkpoint, out_dir, input_audio_length: int = 32000, use_batc
     return model_path
 
 
+def export_zipenhancer(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = True, name: str = "ZipEnhancer") -> Path:
+    """ModelScope ``speech_zipenhancer_ans_multiloss_16k_base`` state dict -> ``<name>.adew`` + manifest (the constructor folds of
+    ZipEnhancer/Export_ZipEnhancer.py:437-664 minus ONNX; the reference's default export folds 1.5 s windows, :57-60).  The geometry is read from the
+    tensor shapes; wrapper prefixes (``module.``, ``model.``, ``generator.``) are dropped; training-only tensors (balancers, whiteners) are ignored."""
+    from . import zipenhancer as zp
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    model_path = out_dir / f"{name}.adew"
+    sd = {}
+    for k, v in load_state_dict(checkpoint).items():
+        for pre in ("module.", "model.", "generator."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        sd[k] = v
+    save_blob(model_path, zp.fuse_state_dict(sd, zp.config_from_state_dict(sd)))
+    write_metadata(model_path, zp.metadata(input_audio_length, use_batch_fold=use_batch_fold))
+    return model_path
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     length, family, fold = None, "gtcrn", False
@@ -162,7 +182,7 @@ def main(argv=None) -> int:
     if "--fold" in argv:
         argv.remove("--fold")
         fold = True
-    if len(argv) != 2 or family not in ("gtcrn", "h_gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas"):
+    if len(argv) != 2 or family not in ("gtcrn", "h_gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas", "zipenhancer"):
         print(__doc__)
         return 2
     if family == "mel_band_roformer":
@@ -173,6 +193,8 @@ def main(argv=None) -> int:
         path = export_ulunas(argv[0], argv[1], length or 16000)
     elif family == "h_gtcrn":
         path = export_hgtcrn(argv[0], argv[1], length or 32000, fold)
+    elif family == "zipenhancer":
+        path = export_zipenhancer(argv[0], argv[1], length or 32000, fold)
     else:
         path = export_gtcrn(argv[0], argv[1], length or 16000)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")

@@ -227,6 +227,24 @@ def fuse_state_dict(sd: Mapping[str, np.ndarray], cfg: ZipConfig) -> Dict[str, n
     return {k: np.ascontiguousarray(out[k], np.float32) for k in want}
 
 
+def config_from_state_dict(sd: Mapping[str, np.ndarray], heads: int = 4, query_head_dim: int = 0) -> ZipConfig:
+    """Geometry of a checkpoint-format state dict, read from its tensor shapes.  ``heads`` cannot be inferred from shapes alone (it is 4 in the
+    published model, ZipEnhancer/Optimize_ONNX.py:70); ``query_head_dim`` defaults to the split in_proj = heads * (2 q + p), p = linear_pos / heads."""
+    L = "TSConformer.encoders.0.f_layers.0."
+    C = int(sd["dense_encoder.dense_conv_1.0.weight"].shape[0])
+    attn = int(sd[L + "self_attn_weights.in_proj.weight"].shape[0])
+    pos_out, pos_dim = (int(x) for x in sd[L + "self_attn_weights.linear_pos.weight"].shape)
+    p = pos_out // heads
+    q = query_head_dim or (attn // heads - p) // 2
+    depth = sum(1 for k in sd if k.startswith("dense_encoder.dense_block.dense_block.") and k.endswith(".1.weight"))
+    return ZipConfig(channels=C, heads=heads, query_head_dim=q, pos_head_dim=p,
+                     value_head_dim=int(sd[L + "self_attn1.in_proj.weight"].shape[0]) // heads, pos_dim=pos_dim,
+                     ff_dim=int(sd[L + "feed_forward2.in_proj.weight"].shape[0]),
+                     conv_kernel=int(sd[L + "conv_module1.depthwise_conv.weight"].shape[-1]),
+                     down_t2=int(sd["TSConformer.encoders.1.downsample_t.bias"].shape[0]), down_f2=int(sd["TSConformer.encoders.1.downsample_f.bias"].shape[0]),
+                     upscale=int(sd["mask_decoder.mask_conv.0.conv1.weight"].shape[0]) // C, dense_depth=depth)
+
+
 def state_dict_spec(cfg: ZipConfig) -> List[Tuple[str, List[int], float]]:
     """(name, shape, scale) of a checkpoint-format state dict for ``weightgen.materialise``: random-init weights of the
     architecture (no checkpoint is available offline).  Scales keep every activation O(1) through the residual stack;

@@ -251,9 +251,15 @@ def test_gpu_production_size_clips_match_reference(tag):
         out, f32 = sess.process(pcm.reshape(1, -1), want_f32=True)
         tokens = sess.tap("tokens", 60 * T * 384).reshape(60, T, 384)
     out, f32 = out.reshape(2, L), f32.reshape(2, L)
-    for band, key in ((7, "tf_out_b7"), (55, "tf_out_b55")):
-        err = np.abs(tokens[band][::step] - z[key])
-        assert np.median(err) < 5e-5 and err.max() < 3e-2, (key, np.median(err), err.max())     # max: L2-normalised near-silent bands (values reach 19.6)
-    assert np.abs(f32[:, ::int(z["wave_step"])] - z["wave"]).max() <= 1e-4
-    d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
-    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10, (np.abs(d).max(), (d != 0).mean())
+    # band 7 carries signal; band 55 (15 - 22 kHz) is nearly silent and L2-normalised before its Linear (:576), so the 1-ulp differences between
+    # libm's and torch's cos / sin in the DFT tables ARE part of its input: its gate is wider, and stated per band
+    m7, m55 = (np.abs(tokens[b][::step] - z[k]) for b, k in ((7, "tf_out_b7"), (55, "tf_out_b55")))
+    wave_err = float(np.abs(f32[:, ::int(z["wave_step"])] - z["wave"]).max())
+    d = np.abs(out.astype(np.int32) - z["pcm_out"].astype(np.int32))
+    report = dict(b7_median=float(np.median(m7)), b7_max=float(m7.max()), b55_median=float(np.median(m55)), b55_max=float(m55.max()), wave=wave_err,
+                  pcm_max=int(d.max()), pcm_diff_frac=float((d != 0).mean()))
+    print(tag, report)
+    assert np.median(m7) < 5e-5 and m7.max() < 5e-3, report
+    assert np.median(m55) < 3e-4 and m55.max() < 3e-2, report
+    assert wave_err <= 1e-4, report                             # the north-star tolerance on the fp32 waveform before the PCM tail
+    assert d.max() <= 2 and (d != 0).mean() < 0.10, report

@@ -228,3 +228,31 @@ def test_gpu_zipenhancer_resampling_edges(model):
     want = interp(rw / np.sqrt(np.float32(1e-6)) * norm, 24000)                   # the oracle normalised a zero waveform: undo its norm factor, apply ours
     assert np.abs(f32 - want).max() <= 0.5
     assert np.abs(out.astype(np.int32) - np.clip(want, -32768, 32767).astype(np.int16).astype(np.int32)).max() <= 1
+
+
+def test_export_and_driver_host_logic(model, tmp_path):
+    """export.py --family zipenhancer on a checkpoint-format state dict (wrapper prefix, training-only extras): geometry inferred from the shapes,
+    the same blob as the direct fold; the file driver's slicing rules (input-length stride, zero tail) on a stand-in session."""
+    from audio_denoiser_onnx_amd import export
+    from audio_denoiser_onnx_amd.inference_gtcrn import denoise
+    from audio_denoiser_onnx_amd.weights import load_blob
+    _, cfg, sd, t = model
+    assert zp.config_from_state_dict(sd) == cfg
+    ck = {"module." + k: v for k, v in sd.items()}
+    ck["module.TSConformer.encoders.0.f_layers.0.balancer.count"] = np.zeros(1, np.float32)           # ignored
+    np.savez(tmp_path / "ck.npz", **ck)
+    path = export.export_zipenhancer(tmp_path / "ck.npz", tmp_path / "out", 40000, True)
+    got = load_blob(path)
+    assert set(got) == set(t) and all(np.array_equal(got[k], t[k]) for k in t)
+    import json
+    meta = json.loads(path.with_name("ZipEnhancer_Metadata.json").read_text())
+    assert meta["model_family"] == "zipenhancer" and meta["export_audio_length"] == "48000" and meta["use_batch_fold"] == "1"
+
+    class Echo:
+        in_len = out_len = 1000
+        in_sample_rate = out_sample_rate = 16000
+
+        def process(self, pcm, want_f32=False):
+            return pcm.copy(), None
+    a = (np.arange(2500) % 1000).astype(np.int16)
+    assert np.array_equal(denoise(Echo(), a, tail_pad="zeros", family="dfsmn"), a)
