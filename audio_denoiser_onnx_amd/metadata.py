@@ -127,56 +127,44 @@ def read_metadata(model_path) -> Dict[str, str]:
     return build_model_metadata(raw)
 
 
-def _missing(key: str) -> str:
-    return f"Required metadata key {key} is missing. Re-export the model to regenerate its manifest."
+_REQUIRED = object()
 
 
-def _parse_bool(value, key):
-    text = str(value).strip().lower()
-    if text in _TRUE:
-        return True
-    if text in _FALSE:
-        return False
-    raise ValueError(f"Metadata key {key} must be a boolean encoded as 1/0, got {value!r}.")
+def _as_bool(text: str, key: str) -> bool:
+    low = text.strip().lower()
+    if low in _TRUE or low in _FALSE:
+        return low in _TRUE
+    raise ValueError(f"Metadata key {key} must be a boolean encoded as 1/0, got {text!r}.")
 
 
 class MetadataReader:
-    """Typed view over the string map; missing required keys raise ``KeyError`` (audio_onnx_metadata.py:247-278)."""
+    """Typed view over the manifest's string map.  One accessor, ``get(key, kind, default)``; the ``required_* / optional_*`` names the reference's
+    drivers call (audio_onnx_metadata.py:247-287) are generated from it.  A missing REQUIRED key is a ``KeyError`` (the reference's contract),
+    an unparsable value a ``ValueError``."""
+
+    _KINDS = {"int": int, "float": float, "string": str}
 
     def __init__(self, metadata: Optional[Mapping[str, str]]):
         self.metadata = dict(metadata or {})
 
-    def string(self, key, default=None, required=False):
-        value = self.metadata.get(key)
-        if value in (None, ""):
-            if required:
-                raise KeyError(_missing(key))
+    def get(self, key: str, kind: str = "string", default=_REQUIRED):
+        raw = self.metadata.get(key)
+        if raw is None or raw == "":
+            if default is _REQUIRED:
+                raise KeyError(f"Required metadata key {key} is missing. Re-export the model to regenerate its manifest.")
             return default
-        return value
+        return _as_bool(str(raw), key) if kind == "bool" else self._KINDS[kind](raw)
 
-    def required_int(self, key):
-        return int(self.string(key, required=True))
-
-    def optional_int(self, key, default=None):
-        value = self.string(key)
-        return default if value is None else int(value)
-
-    def required_float(self, key):
-        return float(self.string(key, required=True))
-
-    def optional_float(self, key, default=None):
-        value = self.string(key)
-        return default if value is None else float(value)
-
-    def required_bool(self, key):
-        return _parse_bool(self.string(key, required=True), key)
-
-    def optional_bool(self, key, default=None):
-        value = self.string(key)
-        return default if value is None else _parse_bool(value, key)
+    def string(self, key, default=None, required=False):
+        return self.get(key, "string", _REQUIRED if required else default)
 
     def to_json(self) -> str:
         return json.dumps(self.metadata, sort_keys=True)
+
+
+for _kind in ("int", "float", "bool"):
+    setattr(MetadataReader, f"required_{_kind}", (lambda k: lambda self, key: self.get(key, k))(_kind))
+    setattr(MetadataReader, f"optional_{_kind}", (lambda k: lambda self, key, default=None: self.get(key, k, default))(_kind))
 
 
 def load_runtime_metadata(model_path, required_keys: Iterable[str] = REQUIRED_AUDIO_METADATA_KEYS) -> MetadataReader:
@@ -214,34 +202,25 @@ def validate_audio_metadata(reader: MetadataReader, session) -> None:
         raise ValueError(f"Model has {len(inputs)} inputs, metadata num_audio_inputs={n_in}.")
 
 
+# manifest key -> (runtime constant of the reference's drivers, kind, default; _REQUIRED = must be present)   (audio_onnx_metadata.py:354-386)
+_RUNTIME_FIELDS = (
+    ("in_sample_rate", "IN_SAMPLE_RATE", "int", _REQUIRED), ("out_sample_rate", "OUT_SAMPLE_RATE", "int", _REQUIRED),
+    ("model_sample_rate", "MODEL_SAMPLE_RATE", "int", _REQUIRED), ("input_to_output_scale", "INPUT_TO_OUTPUT_SCALE", "float", _REQUIRED),
+    ("max_dynamic_audio_seconds", "MAX_DYNAMIC_AUDIO_SECONDS", "int", _REQUIRED), ("normalize_audio_default", "NORMALIZE_AUDIO", "bool", _REQUIRED),
+    ("normalize_target_rms", "NORMALIZE_TARGET_RMS", "float", _REQUIRED), ("batch_window_seconds", "BATCH_WINDOW_SECONDS", "float", 0.0),
+    ("hop_length", "HOP_LENGTH", "int", 0), ("fold_window_length", "FOLD_WINDOW_LENGTH", "int", 0),
+    ("batch_fold_inference_default", "BATCH_FOLD_INFERENCE", "bool", False), ("input_channels", "INPUT_CHANNELS", "int", 1),
+    ("output_channels", "OUTPUT_CHANNELS", "int", 1), ("input_channels", "N_CHANNELS", "int", 1), ("num_audio_inputs", "NUM_AUDIO_INPUTS", "int", 1),
+    ("pad_head", "PAD_HEAD", "int", 0), ("enc_stride", "ENC_STRIDE", "int", 0), ("output_sources", "OUTPUT_SOURCES", "int", 1),
+)
+
+
 def runtime_config_from_metadata(reader: MetadataReader) -> Dict[str, Any]:
-    """The UPPER_CASE runtime constants the inference script repopulates (audio_onnx_metadata.py:354-386)."""
-    in_sr = reader.required_int("in_sample_rate")
-    out_sr = reader.required_int("out_sample_rate")
-    model_sr = reader.required_int("model_sample_rate")
-    fold_window = reader.optional_int("fold_window_length", 0)
-    fold_input_default = max(1, int(round(fold_window * in_sr / model_sr))) if fold_window else 0
-    return {
-        "IN_SAMPLE_RATE": in_sr,
-        "OUT_SAMPLE_RATE": out_sr,
-        "MODEL_SAMPLE_RATE": model_sr,
-        "INPUT_TO_OUTPUT_SCALE": reader.required_float("input_to_output_scale"),
-        "BATCH_WINDOW_SECONDS": reader.optional_float("batch_window_seconds", 0.0),
-        "HOP_LENGTH": reader.optional_int("hop_length", 0),
-        "FOLD_WINDOW_LENGTH": fold_window,
-        "FOLD_INPUT_LENGTH": reader.optional_int("fold_input_length", fold_input_default),
-        "BATCH_FOLD_INFERENCE": reader.optional_bool("batch_fold_inference_default", False),
-        "MAX_DYNAMIC_AUDIO_SECONDS": reader.required_int("max_dynamic_audio_seconds"),
-        "NORMALIZE_AUDIO": reader.required_bool("normalize_audio_default"),
-        "NORMALIZE_TARGET_RMS": reader.required_float("normalize_target_rms"),
-        "INPUT_CHANNELS": reader.optional_int("input_channels", 1),
-        "OUTPUT_CHANNELS": reader.optional_int("output_channels", 1),
-        "N_CHANNELS": reader.optional_int("input_channels", 1),
-        "NUM_AUDIO_INPUTS": reader.optional_int("num_audio_inputs", 1),
-        "PAD_HEAD": reader.optional_int("pad_head", 0),
-        "ENC_STRIDE": reader.optional_int("enc_stride", 0),
-        "OUTPUT_SOURCES": reader.optional_int("output_sources", 1),
-        "ORIGINAL_SAMPLE_RATE": reader.optional_int("original_sample_rate", in_sr),
-        "SUPER_SAMPLE_RATE": reader.optional_int("super_sample_rate", out_sr),
-        "SCALE_FACTOR": reader.optional_float("scale_factor", float(out_sr / in_sr)),
-    }
+    """The UPPER_CASE runtime constants an inference script repopulates from the manifest; rate-derived defaults are filled in afterwards."""
+    cfg = {const: reader.get(key, kind, default) for key, const, kind, default in _RUNTIME_FIELDS}
+    in_sr, out_sr, model_sr, window = cfg["IN_SAMPLE_RATE"], cfg["OUT_SAMPLE_RATE"], cfg["MODEL_SAMPLE_RATE"], cfg["FOLD_WINDOW_LENGTH"]
+    cfg["FOLD_INPUT_LENGTH"] = reader.get("fold_input_length", "int", max(1, int(round(window * in_sr / model_sr))) if window else 0)
+    cfg["ORIGINAL_SAMPLE_RATE"] = reader.get("original_sample_rate", "int", in_sr)
+    cfg["SUPER_SAMPLE_RATE"] = reader.get("super_sample_rate", "int", out_sr)
+    cfg["SCALE_FACTOR"] = reader.get("scale_factor", "float", float(out_sr / in_sr))
+    return cfg

@@ -46,7 +46,7 @@ def test_manifest_errors_map_to_reference_exceptions(lib):
     assert _create(lib, bad, blob)[0] == _lib.ADE_ERR_BAD_VALUE                # ValueError (_parse_bool)
     bad = dict(meta, export_audio_length="32000")
     assert _create(lib, bad, blob)[0] == _lib.ADE_ERR_SHAPE_MISMATCH           # ValueError (length mismatch)
-    bad = dict(meta, model_family="zipenhancer")
+    bad = dict(meta, model_family="sdaec")                                     # a model folder of the reference that is out of scope here
     assert _create(lib, bad, blob)[0] == _lib.ADE_ERR_UNSUPPORTED
     bad = dict(meta, in_sample_rate="48000")
     assert _create(lib, bad, blob)[0] == _lib.ADE_ERR_UNSUPPORTED
@@ -98,7 +98,9 @@ def test_model_family_manifest_checks_precede_the_device(lib):
     assert st == _lib.ADE_ERR_BAD_VALUE and "equal input/model/output sample rates" in msg
     st, msg = _create(lib, mossformer.metadata(2408) | {"model_sample_rate": "8000"}, blob)
     assert st == _lib.ADE_ERR_UNSUPPORTED and "16000" in msg
-    st, msg = _create(lib, mossformer.metadata(2408) | {"model_family": "zipenhancer"}, blob)
-    assert st == _lib.ADE_ERR_UNSUPPORTED and "zipenhancer" in msg
+    st, msg = _create(lib, mossformer.metadata(2408) | {"model_family": "nkf_aec"}, blob)
+    assert st == _lib.ADE_ERR_UNSUPPORTED and "nkf_aec" in msg
+    st, msg = _create(lib, mossformer.metadata(2408) | {"model_family": "zipenhancer", "use_batch_fold": "1", "in_sample_rate": "8000"}, blob)
+    assert st == _lib.ADE_ERR_BAD_VALUE and "equal input/model/output sample rates" in msg       # ZipEnhancer's fold rule (Export_ZipEnhancer.py:80-81)
     st, msg = _create(lib, melband.metadata(13230) | {"ade_dft_tables": "fast"}, golden_blob(0))
     assert st in (_lib.ADE_ERR_BAD_VALUE, _lib.ADE_ERR_DEVICE)     # the table option is validated after the blob parse; without a GPU the device check comes first

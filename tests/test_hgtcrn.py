@@ -43,8 +43,11 @@ def _oracle(fused, window=L, n_win=1, exact_dft=False):
     return HgtcrnOracle(fused, window, n_win, exact_dft)
 
 
-def _wpe_contract(got_r, got_i, stft_r, stft_i, ref=None):
-    """got / stft: (B, 2, F, T).  Returns (#well-conditioned bins, worst error on them)."""
+def _wpe_contract(got_r, got_i, stft_r, stft_i, ref=None, ref_spread=None):
+    """got / stft: (B, 2, F, T).  Returns (#well-conditioned bins, worst error on them).
+    Which bins are well-conditioned is decided by the REFERENCE when the rows are the fixture's: ``ref_spread[b][f]`` = the distance between
+    the reference's own ``OnnxFriendlyWPE`` run in fp32 and the same module ``.double()`` on the same spectrum (tools/make_golden_hgtcrn.py);
+    for other inputs (no reference run exists) the oracle's fp32-vs-fp64 distance stands in."""
     import hgtcrn_oracle as ho
     re, im = np.ascontiguousarray(stft_r.transpose(0, 2, 1, 3)), np.ascontiguousarray(stft_i.transpose(0, 2, 1, 3))
     with np.errstate(all="ignore"):
@@ -55,12 +58,16 @@ def _wpe_contract(got_r, got_i, stft_r, stft_i, ref=None):
         if not np.isfinite(a64[0][b]).all():
             continue                                                      # the silent row: 0 / 0 everywhere in every implementation
         spread = np.maximum(np.abs(a32[0][b] - a64[0][b]), np.abs(a32[1][b] - a64[1][b])).max(axis=(1, 2))          # per bin
-        stable = spread < 1e-4
+        stable = (ref_spread[b] if ref_spread is not None else spread) < 1e-4
+        if ref_spread is not None:
+            spread = np.maximum(spread, ref_spread[b])
         target = (a32[0][b], a32[1][b]) if ref is None else (ref[0][b].transpose(1, 0, 2), ref[1][b].transpose(1, 0, 2))
         err = np.maximum(np.abs(got_r[b].transpose(1, 0, 2) - target[0]), np.abs(got_i[b].transpose(1, 0, 2) - target[1])).max(axis=(1, 2))
         err64 = np.maximum(np.abs(got_r[b].transpose(1, 0, 2) - a64[0][b]), np.abs(got_i[b].transpose(1, 0, 2) - a64[1][b])).max(axis=(1, 2))
         assert stable.sum() >= 120, stable.sum()
         assert np.isfinite(err64).all()
+        if ref_spread is not None:          # uniform, reference-derived bound: no further from the target than 30 x the reference's own fp32-vs-fp64 distance
+            assert np.all(err <= 30.0 * spread + 2e-4), float((err / (30.0 * spread + 2e-4)).max())
         assert np.all(err64[~stable] <= 30.0 * spread[~stable] + 1e-3), float((err64[~stable] / (spread[~stable] + 1e-9)).max())
         worst, n_stable = max(worst, float(err[stable].max())), n_stable + int(stable.sum())
     return n_stable, worst
@@ -78,8 +85,11 @@ def test_fold_and_oracle_match_reference(fixture):
     assert np.abs(d[0]).max() <= 4                                              # the example recording has one AuxIVA bin at the edge of fp32 too
     assert not out[3].any() and not z["pcm_out"][3].any()                       # silence: NaN -> 0 (:1054)
     o.process(z["pcm_in"][:3])                                                  # part (1): the oracle's own WPE against the reference's
-    n, worst = _wpe_contract(o.taps["wpe_r"], o.taps["wpe_i"], o.taps["stft_r"], o.taps["stft_i"], ref=(z["wpe_r"], z["wpe_i"]))
-    assert n > 600 and worst < 5e-4, (n, worst)
+    n, worst = _wpe_contract(o.taps["wpe_r"], o.taps["wpe_i"], o.taps["stft_r"], o.taps["stft_i"], ref=(z["wpe_r"], z["wpe_i"]),
+                             ref_spread=z["wpe_ref_spread"])
+    assert n > 600 and worst < 1e-3, (n, worst)
+    unstable = [int((z["wpe_ref_spread"][b] >= 1e-4).sum()) for b in range(3)]
+    assert unstable == [23, 45, 48], unstable          # the reference disagrees with ITSELF (fp32 vs fp64) on 9 - 19 % of the bins
 
 
 def test_fold_fixture_oracle(fixture):
@@ -105,7 +115,7 @@ def _session(fused, length=L, library=None, **kw):
     return InferenceSession(weights=pack_blob(fused), metadata=hgtcrn.metadata(length, **kw), library=library)
 
 
-def _run_and_check(sess, fused, pcm, window, n_win, exact_dft, lsb):
+def _run_and_check(sess, fused, pcm, window, n_win, exact_dft, lsb, ref_spread=None):
     """HIP (or simulated) run against the two-part contract; returns the PCM."""
     B = pcm.shape[0] * n_win
     got = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
@@ -116,7 +126,7 @@ def _run_and_check(sess, fused, pcm, window, n_win, exact_dft, lsb):
     o = _oracle(fused, window, n_win, exact_dft)
     o.process(pcm)
     assert np.abs(stft[:, :, 0] - o.taps["stft_r"]).max() < 2e-4 and np.abs(stft[:, :, 1] - o.taps["stft_i"]).max() < 2e-4
-    n_stable, worst = _wpe_contract(wpe[:, :, 0], wpe[:, :, 1], stft[:, :, 0], stft[:, :, 1])
+    n_stable, worst = _wpe_contract(wpe[:, :, 0], wpe[:, :, 1], stft[:, :, 0], stft[:, :, 1], ref_spread=ref_spread)
     assert worst < 2e-3, (n_stable, worst)
     want = o.process(pcm, inject_wpe=(wpe[:, :, 0], wpe[:, :, 1]))
     d = got.astype(np.int32) - want.astype(np.int32)
@@ -141,7 +151,7 @@ def test_gpu_fixture_rows(fixture):
     z, fused = fixture
     with _session(fused) as sess:
         assert sess.frames == 65 and sess.out_len == L and sess.channels == 2 and sess.out_channels == 1
-        got = _run_and_check(sess, fused, z["pcm_in"], L, 1, True, 3)
+        got = _run_and_check(sess, fused, z["pcm_in"], L, 1, True, 3, ref_spread=z["wpe_ref_spread"])
         one = sess.run(None, {"noisy_audio": z["pcm_in"][1:2]})[0][0, 0]
     assert not got[3].any() and np.array_equal(one, got[1])                     # silence; rows are independent of the batch
     # end to end against the reference's PCM: bounded by the ill-conditioned bins, not by this implementation (see the module docstring)

@@ -132,6 +132,9 @@ def main(seed=0):
     model, net, wpe, iva, state = build(ns, seed)
     rows = stereo_rows(3, L) + [np.zeros((2, L), np.int16)]
     taps = {}
+    import copy
+    wpe64 = copy.deepcopy(wpe).double()                            # the reference's OWN WPE module in float64: its distance from the
+    spread = []                                                     # fp32 run, per bin, is what decides which bins are well-conditioned
 
     def wrap(mod, name):
         orig = mod.forward
@@ -140,6 +143,8 @@ def main(seed=0):
             taps[name] = [t.clone() for t in y] if isinstance(y, tuple) else y.clone()
             if name == "net":
                 taps["features"] = a[0].clone()
+            if name == "wpe":
+                taps["wpe_in"] = [t.clone() for t in a]
             return y
         mod.forward = f
     wrap(wpe, "wpe"); wrap(iva, "iva"); wrap(net, "net")
@@ -148,12 +153,16 @@ def main(seed=0):
         for i, r in enumerate(rows):
             outs.append(model(torch.from_numpy(r.reshape(1, 2, -1).copy())).numpy().reshape(-1))
             wr.append(taps["wpe"][0].numpy()[0].copy()); wi.append(taps["wpe"][1].numpy()[0].copy())
+            y64 = wpe64(*[t.double() for t in taps["wpe_in"]])
+            d = torch.maximum((y64[0] - taps["wpe"][0].double()).abs(), (y64[1] - taps["wpe"][1].double()).abs())[0]     # (2, F, T) or (F, ...)
+            spread.append(torch.nan_to_num(d, nan=float("inf")).reshape(2, 257, -1).amax(dim=(0, 2)).numpy())
             if i == 1:
                 saved = {"tap_iva_r": taps["iva"][0].numpy()[0],
                          "tap_iva_i": taps["iva"][1].numpy()[0], "tap_features": taps["features"].numpy()[0],
                          "tap_s_r": taps["net"][0].numpy()[0], "tap_s_i": taps["net"][1].numpy()[0]}
     np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}.npz"), pcm_in=np.stack(rows), pcm_out=np.stack(outs), wpe_r=np.stack(wr), wpe_i=np.stack(wi),
-                        keys=np.array(list(state)), **saved, **{"w:" + k: v for k, v in state.items()})
+                        wpe_ref_spread=np.stack(spread).astype(np.float32), keys=np.array(list(state)), **saved, **{"w:" + k: v for k, v in state.items()})
+    print("reference WPE fp32-vs-fp64: bins with spread >= 1e-4 per row:", [int((sp >= 1e-4).sum()) for sp in spread])
     print("state tensors", len(state), "floats", sum(v.size for v in state.values()), "out max", [int(np.abs(o).max()) for o in outs],
           "in max", [int(np.abs(r).max()) for r in rows])
 
