@@ -15,6 +15,9 @@
 //   struct Store { __device__ void operator()(int m, int n, float v) const; };
 // The Row hook is what lets an implicit-convolution loader do its (batch, frame, bin) index split once instead of per fetch.
 // K must be a multiple of 4.
+// BF16 = true: the same tile with bf16 INPUTS and fp32 accumulation (v_mfma_f32_16x16x16_bf16: one instruction per 16-deep slab and tile instead of
+// four): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS, so a model can be switched between the exact
+// fp32 path (parity) and the bf16 path (throughput; BASELINE.json's dtype for the transformer families) without touching its data layout.
 #pragma once
 #include "ade_device.h"
 #include "ade_gemm.h"
@@ -26,10 +29,24 @@ using namespace dev;
 
 constexpr int kTM = 256, kTN = 64, kTK = 16, kRow = gemm::kRow;
 
-template <class AL, class BL, class ST>
+#if defined(__clang__)
+typedef short v4s __attribute__((ext_vector_type(4)));
+#else
+typedef short v4s __attribute__((vector_size(8)));
+#endif
+__device__ __forceinline__ unsigned bf16_bits(float x) {            // fp32 -> bf16, round to nearest even (NaN payloads are not preserved: inputs are finite activations / weights)
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint2 bf16x4(const float4& v) { return make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)); }
+__device__ __forceinline__ v4f mfma16x16x16_bf16(v4s a, v4s b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+template <class AL, class BL, class ST, bool BF16>
 __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[kTM * kRow];
+    __shared__ __attribute__((aligned(16))) float As[kTM * kRow];          // bf16: the same rows at half the pitch (10 words: 16 bf16 + 4 padding)
     __shared__ __attribute__((aligned(16))) float Bs[kTN * kRow];
+    constexpr int kRowW = BF16 ? kRow / 2 : kRow;                          // row pitch in 32-bit words
     const int gx = (int)gridDim.x, id = gemm::xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
     const int m_blk = (id / gx) * kTM, n_blk = (id % gx) * kTN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,25 +77,43 @@ __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, 
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
+        if constexpr (BF16) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
-        *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<uint2*>(As + (r + 64 * h) * kRowW + kq / 2) = bf16x4(ra[h]);
+            *reinterpret_cast<uint2*>(Bs + r * kRowW + kq / 2) = bf16x4(rb);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
+            *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;
+        }
         __syncthreads();
         if (k0 + kTK < K) fetch(k0 + kTK);
-        float4 a4[4], b4[4];                // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16]
+        if constexpr (BF16) {               // lane (g, j16): A[row 16 i + j16][k = 4 g .. 4 g + 3] as four bf16 = one ds_read_b64
+            v4s a8[4], b8[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+            for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (16 * j + j16) * kRow + 4 * g);
+            for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (16 * j + j16) * kRowW + 2 * g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
+        } else {
+            float4 a4[4], b4[4];            // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (16 * j + j16) * kRow + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+                }
+        }
         __syncthreads();
     }
     // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
@@ -97,10 +132,11 @@ __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, 
 }
 
 template <class AL, class BL, class ST>
-inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K, bool bf16 = false) {
     if (M <= 0 || N <= 0) return;
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST, true>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST, false>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }
 
 // ---- common operands ---------------------------------------------------------------------------------------------------

@@ -659,7 +659,7 @@ struct ZipEngine : SubEngine {
     int device = 0, L = 0 /* samples per window in */, Lo = 0 /* out: whole hops, hop * (T - 1) */, n_win = 1, T = 0, F = 0;
     int C = 64, H = 4, qd = 16, pd = 4, vd = 12, pos_dim = 48, ffd = 256, K = 15, dst = 2, dsf = 2, up = 2, depth = 4;
     int hid = 48, ff1 = 192, ff3 = 320, attn_dim = 144, dT = 0, dF = 0;
-    bool exact = false;
+    bool exact = false, bf16 = false;     // bf16: ade_gemm_dtype = "bf16" -- every 256 x 64 GEMM takes bf16 inputs (fp32 accumulation); front / attention / norms / PCM tail stay fp32
     float* d_w = nullptr;
     const float *k_fwd = nullptr, *k_inv = nullptr, *inv_wsum = nullptr;
     const float *c1_w = nullptr, *c1_b = nullptr, *c1_g = nullptr, *c1_beta = nullptr, *c1_slope = nullptr;
@@ -697,7 +697,7 @@ struct ZipEngine : SubEngine {
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
 
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err) {
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return zfail(err, ADE_ERR_BAD_VALUE, "zipenhancer: n_win must be >= 1");
     if (window_len < kZN || (n_win > 1 && window_len % kZHop))
@@ -713,7 +713,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     ZipEngine* e = new ZipEngine();
     auto bail = [&](int st) { delete e; return st; };
     auto ci = [&](int i) { return (int)lrintf(cfg->data[i]); };
-    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft;
+    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft; e->bf16 = bf16;
     e->C = ci(0); e->H = ci(1); e->qd = ci(2); e->pd = ci(3); e->vd = ci(4); e->pos_dim = ci(5); e->ffd = ci(6); e->K = ci(7);
     e->dst = ci(10); e->dsf = ci(11); e->up = ci(12); e->depth = ci(13);
     const int C = e->C;
@@ -928,7 +928,7 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
             gemm64::launch(s, DenseA{Dh, inp, nrm, d.slope, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
-                           BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin);
+                           BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin, bf16);
             stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
         }
 }
@@ -945,25 +945,25 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
-    launch(s, RowsA{x, C}, WeightB{w.attn_ff1_w, C}, BiasColStore{P, w.attn_ff1_b, ldp, 0}, M, ldp, C);                                        // (:148-153)
-    launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1);                      // (:160)
-    launch(s, RowsA{Y, C}, WeightB{w.nonlin_in_w, C}, BiasColStore{S1, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid, C);                           // (:305)
+    launch(s, RowsA{x, C}, WeightB{w.attn_ff1_w, C}, BiasColStore{P, w.attn_ff1_b, ldp, 0}, M, ldp, C, bf16);                                        // (:148-153)
+    launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                      // (:160)
+    launch(s, RowsA{Y, C}, WeightB{w.nonlin_in_w, C}, BiasColStore{S1, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid, C, bf16);                           // (:305)
     attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
-    launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid);                              // (:317, :167)
+    launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid, bf16);                              // (:317, :167)
     for (int i = 0; i < 2; ++i) {
-        launch(s, RowsA{Y, C}, WeightB{w.sa_in_w[i], C}, BiasColStore{S1, w.sa_in_b[i], vdim, 0}, M, vdim, C);                               // (:296)
+        launch(s, RowsA{Y, C}, WeightB{w.sa_in_w[i], C}, BiasColStore{S1, w.sa_in_b[i], vdim, 0}, M, vdim, C, bf16);                               // (:296)
         attention(s, 1, w.pos, S1, vdim, O, vdim, geo, vd);                                                                                   // (:297-300) all heads
-        launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim);                         // (:301, :168 / :172)
-        launch(s, RowsA{Y, C}, WeightB{w.cv_in_w[i], C}, BiasColStore{S1, w.cv_in_b[i], 2 * C, 0}, M, 2 * C, C);                             // (:321)
+        launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim, bf16);                         // (:301, :168 / :172)
+        launch(s, RowsA{Y, C}, WeightB{w.cv_in_w[i], C}, BiasColStore{S1, w.cv_in_b[i], 2 * C, 0}, M, 2 * C, C, bf16);                             // (:321)
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
-        launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
+        launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C, bf16);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
-        launch(s, RowsA{Y, C}, WeightB{w.ff_in_w[i], C}, BiasColStore{S1, w.ff_in_b[i], fd, 0}, M, fd, C);
-        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd);   // (:170-171)
-        else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
+        launch(s, RowsA{Y, C}, WeightB{w.ff_in_w[i], C}, BiasColStore{S1, w.ff_in_b[i], fd, 0}, M, fd, C, bf16);
+        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd, bf16);   // (:170-171)
+        else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd, bf16);                   // (:174)
     }
     hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
 }
@@ -992,7 +992,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
     if (getenv("ADE_ZIP_DEBUG_STOP")) { snap(0); (void)hipMemcpyAsync(X, Dh, std::min((size_t)R * C, (size_t)tok0 * 4 * C) * sizeof(float), hipMemcpyDeviceToDevice, s); snap(1); return ADE_OK; }
-    gemm64::launch(s, RowConvA{Dh, nrm, enc_dense.slope, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
+    gemm64::launch(s, RowConvA{Dh, nrm, enc_dense.slope, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C, bf16);
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
     snap(0);
@@ -1010,7 +1010,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
         gemm64::launch(s, RowConvA{Dh, nrm, dec_dense.slope, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
-                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
+                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C, bf16);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
     }
     hipLaunchKernelGGL(k_zip_heads, dim3((unsigned)((kZF + 63) / 64), (unsigned)((J + 3) / 4)), dim3(256), 0, s, (const float*)U, (const float*)nrm2, up_slope, mask_w, mask_b,

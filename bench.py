@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="gtcrn", choices=["gtcrn", "zipenhancer", "melband", "mossformer"],
                     help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the projection / convolution GEMMs: f32 = exact fp32 matrix-core products (parity path, default); bf16 = bf16 inputs, "
+                         "fp32 accumulation (zipenhancer only; the deviation from the f32 path is measured and reported)")
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = the workload's BASELINE batch: 256 / 128 / 32 / 64)")
     ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-inclusive leg (pinned host buffers through ade_process; 0 = skip)")
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
@@ -117,7 +120,7 @@ def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, w
             "rtf": round(dt / seconds_per_row, 4)}
 
 
-def build_workload(name: str, batch: int, rank: int, local_rank: int):
+def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str = "f32"):
     """-> dict(sess, B, x_host (B, row_in) int16, sr, out_seconds_per_row, flop_per_row, metric, workload, weights, cpu)"""
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_batch, synth_chunk
@@ -126,8 +129,18 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int):
         from audio_denoiser_onnx_amd import zipenhancer as zp
         cfg, B = zp.ZipConfig(), batch or 128
         tensors = zp.synthetic_tensors(cfg)
-        sess = InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK), device_id=local_rank)
+        sess = InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK, gemm_dtype=dtype), device_id=local_rank)
         x = synth_batch(B, CHUNK, first_index=rank * B)
+        deviation = None
+        if dtype != "f32":                                         # what the reduced-precision inputs cost: the same rows through the exact path
+            with InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK), device_id=local_rank) as ref:
+                want, wf = ref.process(x[:4], want_f32=True)
+            got, gf = sess.process(x[:4], want_f32=True)
+            err = gf.astype(np.float64) - wf.astype(np.float64)
+            deviation = {"vs": "the f32 path on 4 rows of the workload", "max_abs_int16_units": round(float(np.abs(err).max()), 2),
+                         "rms_int16_units": round(float(np.sqrt((err ** 2).mean())), 3), "signal_rms_int16_units": round(float(np.sqrt((wf.astype(np.float64) ** 2).mean())), 1),
+                         "snr_db": round(float(10 * np.log10((wf.astype(np.float64) ** 2).mean() / max((err ** 2).mean(), 1e-30))), 1),
+                         "max_pcm_lsb": int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())}
 
         def cpu():
             sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -136,9 +149,9 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int):
         return dict(sess=sess, B=B, x=x, sr=16000, flop=2.0 * zp.macs_per_window(sess.frames, cfg)["total"], cpu=cpu,
                     metric="audio_seconds_per_second (ZipEnhancer 16 kHz, batch=128 x 1 s chunks; RTF = 1/value)",
                     workload="ZipEnhancer 16 kHz, batch=128 x 1 s chunks (161 frames x 101 sub-bands), fp32 matrix cores, int16 PCM in/out resident in HBM "
-                             "(BASELINE.json configs[2]; bf16 there, fp32 here: the parity dtype)",
+                             "(BASELINE.json configs[2]; bf16 there: --dtype bf16 runs the GEMMs on bf16 inputs, the default f32 is the parity dtype)",
                     weights="random-init weights of the architecture (zipenhancer.synthetic_tensors, 2.1 M parameters; no checkpoint is available offline)",
-                    target_rtf=0.01)
+                    target_rtf=0.01, deviation=deviation)
     if name == "melband":                                          # BASELINE configs[3]: 32 x 8 s stereo segments @ 44.1 kHz
         from audio_denoiser_onnx_amd import melband, weightgen
         B, L, depth = batch or 32, 352800, 6
@@ -204,7 +217,9 @@ def main():
         x_host = synth_batch(B, CHUNK, first_index=rank * B)
         sr, wl = SR, None
     else:
-        wl = build_workload(args.workload, args.batch, rank, local_rank)
+        if args.dtype != "f32" and args.workload != "zipenhancer":
+            raise SystemExit("--dtype bf16 is implemented for --workload zipenhancer")
+        wl = build_workload(args.workload, args.batch, rank, local_rank, args.dtype)
         sess, B, x_host, sr = wl["sess"], wl["B"], wl["x"], wl["sr"]
         if args.steps == 100 and args.warmup == 10:      # the defaults are sized for GTCRN's 0.4 ms steps; these steps take 0.2 - 1.2 s
             args.steps, args.warmup = 5, 1
@@ -343,7 +358,7 @@ def main():
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "peak_note": "dense f32-MFMA rate (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s; flops = 2 x MACs of the model's matrix products per row x rows",
                     "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}
-        for cand in (f"r02_{args.workload}_mfma_busy.json",):
+        for cand in (f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json",):
             try:
                 with open(os.path.join(REPO, "profiles", cand)) as f:
                     roofline["mfma_busy"] = json.load(f)
@@ -366,7 +381,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype if not gtcrn else "f32",
             "data": "synthetic",
             "config": {"workload": ("GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
                                     "(BASELINE.json configs[1])") if gtcrn else wl["workload"],
@@ -382,6 +397,10 @@ def main():
         }
         if not gtcrn and wl.get("target_rtf"):
             line["target_rtf"] = wl["target_rtf"]
+        if not gtcrn and wl.get("deviation"):
+            line["deviation_from_f32"] = wl["deviation"]
+            roofline["peak_note"] = ("priced against the dense f32-MFMA rate (157.3 TFLOP/s) for comparability with the f32 line; the bf16 matrix rate is "
+                                     "~2.5 PFLOP/s, but operands stay fp32 in HBM, so the projections are bound by operand traffic, not by the matrix cores")
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -158,6 +158,28 @@ static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
         }
     return d;
 }
+// v_mfma_f32_16x16x16_bf16 (the _1k form): lane l supplies A[i = l & 15][k = 4 (l >> 4) .. + 3] and B[k = 4 (l >> 4) .. + 3][j = l & 15] as four bf16;
+// D = A B + C in fp32 (products of bf16 values are exact in fp32; accumulated k-ordered here).
+typedef short hipsim_v4s __attribute__((vector_size(8)));
+static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hipsim_v4s a, hipsim_v4s b, hipsim_v4f c, int, int, int) {
+    const int lane = ::hipsim::lane_id();
+    const int j = lane & 15, g = lane >> 4;
+    uint32_t aw[2], bw[2], all_a[2][64], all_b[2][64];
+    std::memcpy(aw, &a, 8);
+    std::memcpy(bw, &b, 8);
+    ::hipsim::wave_allgather2(aw[0], bw[0], all_a[0], all_b[0]);
+    ::hipsim::wave_allgather2(aw[1], bw[1], all_a[1], all_b[1]);
+    auto bf = [](uint32_t word, int hi) { const uint32_t u = (hi ? (word >> 16) : (word & 0xffffu)) << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    hipsim_v4f d = c;
+    for (int r = 0; r < 4; ++r)
+        for (int kg = 0; kg < 4; ++kg)
+            for (int q = 0; q < 4; ++q)
+                d[r] = fmaf(bf(all_a[q >> 1][(4 * g + r) + 16 * kg], q & 1), bf(all_b[q >> 1][j + 16 * kg], q & 1), d[r]);
+    return d;
+}
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline unsigned __float_as_uint(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values here
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 static inline long long wall_clock64() { static thread_local long long ticks = 0; return ticks += 1000; }   // monotonic, so timed waits end
