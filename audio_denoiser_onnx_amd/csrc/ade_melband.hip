@@ -230,27 +230,35 @@ __global__ __launch_bounds__(256) void k_band_invnorm(const float* __restrict__ 
 //               rescale is lane-local.
 // row(seq, p) = seq * seq_stride + p * pos_stride.
 constexpr int kKc = 64;            // keys per LDS chunk
-constexpr int kKvStride = 68;      // floats per K / V row in LDS: 16 rows x 4 consecutive floats (K) and 4 rows x 16 floats (V) both cover all 64 banks once
+constexpr int kKvStride = 68;      // floats per staged row: 16 rows x one float4 per lane group cover all 64 banks once (conflict-free ds_read_b128)
 
+// One chunk = 64 keys.  Contraction indices are mapped k = 16 ks + 4 g + s (ks = 0..3 slabs, g = lane >> 4, s = the four steps of a slab) on BOTH operands, so a
+// lane's operands of four MFMA steps are ONE ds_read_b128: K rows are staged row-major (key, dim), V TRANSPOSED (dim, key).  The online-softmax rescale runs once per
+// chunk (after all four score tiles), not once per 16 keys: per chunk and wave 64 + 64 MFMAs against 32 ds_read_b128, 17 exps and 16 accumulator multiplies.
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, const float* __restrict__ rcos,
                                                    const float* __restrict__ rsin, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
-    __shared__ float Ks[kKc * kKvStride];
-    __shared__ float Vs[kKc * kKvStride];
+    __shared__ __attribute__((aligned(16))) float Ks[kKc * kKvStride];         // [key][dim]
+    __shared__ __attribute__((aligned(16))) float Vt[kDh * kKvStride];         // [dim][key]
     const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, g = lane >> 4;
     const long long row0 = (long long)seq * seq_stride;
     const int qi = (int)blockIdx.z * 64 + wave * 16 + j16;                      // this lane's query
     const bool q_ok = qi < n;
     const size_t qrow = (size_t)(row0 + (long long)(q_ok ? qi : 0) * pos_stride);
-    float qreg[16];                                                             // Q[query j16][d = 4 ks + g], rotary applied (:552)
+    float4 qreg[4];                                                             // Q[query j16][d = 16 ks + 4 g + s], rotary applied (:552)
     {
         const float* src = qkvg + qrow * ldq + head * kDh;
         const float* rc = rcos + (size_t)(q_ok ? qi : 0) * kDh;
         const float* rs = rsin + (size_t)(q_ok ? qi : 0) * kDh;
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int d = 4 * ks + g;
-            qreg[ks] = q_ok ? src[d] * rc[d] + src[d ^ 1] * rs[d] : 0.0f;      // rotate_half = pair swap, sign folded into rsin (:438-453)
+        for (int ks = 0; ks < 4; ++ks) {
+            float t[4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int d = 16 * ks + 4 * g + sidx;
+                t[sidx] = q_ok ? src[d] * rc[d] + src[d ^ 1] * rs[d] : 0.0f;    // rotate_half = pair swap, sign folded into rsin (:438-453)
+            }
+            qreg[ks] = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
     float m = -INFINITY, l = 0.0f;
@@ -261,49 +269,64 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 
     for (int c0 = 0; c0 < n; c0 += kKc) {
         __syncthreads();
-        for (int i = tid; i < kKc * kDh; i += 256) {
-            const int p = i >> 6, d = i & 63, key = c0 + p;
-            float kv = 0.0f, vv = 0.0f;
+        for (int i = tid; i < kKc * kDh / 4; i += 256) {                      // four dims per lane: one 16-byte load each of K, V, cos, sin (ldq, di are multiples of 4)
+            const int p = i >> 4, d = (i & 15) * 4, key = c0 + p;
+            float4 kr = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vv = kr;
             if (key < n) {
                 const float* src = qkvg + (size_t)(row0 + (long long)key * pos_stride) * ldq + head * kDh;
-                kv = src[di + d] * rcos[(size_t)key * kDh + d] + src[di + (d ^ 1)] * rsin[(size_t)key * kDh + d];
-                vv = src[2 * di + d];
+                const float4 k4 = *reinterpret_cast<const float4*>(src + di + d), c4 = *reinterpret_cast<const float4*>(rcos + (size_t)key * kDh + d),
+                             s4 = *reinterpret_cast<const float4*>(rsin + (size_t)key * kDh + d);
+                kr = make_float4(k4.x * c4.x + k4.y * s4.x, k4.y * c4.y + k4.x * s4.y, k4.z * c4.z + k4.w * s4.z, k4.w * c4.w + k4.z * s4.w);   // rotate_half = pair swap
+                vv = *reinterpret_cast<const float4*>(src + 2 * di + d);
             }
-            Ks[p * kKvStride + d] = kv;                                         // padded keys are zero rows: their p is 0 and 0 * 0 stays 0
-            Vs[p * kKvStride + d] = vv;
+            *reinterpret_cast<float4*>(Ks + p * kKvStride + d) = kr;             // padded keys are zero rows: their p is 0 and 0 * 0 stays 0
+            Vt[d * kKvStride + p] = vv.x; Vt[(d + 1) * kKvStride + p] = vv.y; Vt[(d + 2) * kKvStride + p] = vv.z; Vt[(d + 3) * kKvStride + p] = vv.w;
         }
         __syncthreads();
         if (!wave_live) continue;
-        const int tiles = (n - c0 + 15) / 16 < kKc / 16 ? (n - c0 + 15) / 16 : kKc / 16;
-        for (int kt = 0; kt < tiles; ++kt) {
-            v4f st = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-            const float* kr = Ks + (16 * kt + j16) * kKvStride + g;
+        v4f st[4];
+        float mx = -INFINITY;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) st = mfma16x16x4(kr[4 * ks], qreg[ks], st);
+        for (int kt = 0; kt < 4; ++kt) {
+            st[kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kKvStride + 16 * ks + 4 * g);
+                st[kt] = mfma16x16x4(kv.x, qreg[ks].x, st[kt]);
+                st[kt] = mfma16x16x4(kv.y, qreg[ks].y, st[kt]);
+                st[kt] = mfma16x16x4(kv.z, qreg[ks].z, st[kt]);
+                st[kt] = mfma16x16x4(kv.w, qreg[ks].w, st[kt]);
+            }
             const int key0 = c0 + 16 * kt + 4 * g;
-            float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (key0 + r >= n) st[r] = -INFINITY;
-                mx = fmaxf(mx, st[r]);
+                if (key0 + r >= n) st[kt][r] = -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);                                   // finite: every visited tile has at least one real key
-            const float alpha = expf(m - m_new);
-            float pr[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pr[r] = expf(st[r] - m_new);
-            l = l * alpha + ((pr[0] + pr[1]) + (pr[2] + pr[3]));               // this lane's share of the row sum; the four g-lanes are added at the end
-            m = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) acc[dt] = acc[dt] * alpha;
-            const float* vr = Vs + (16 * kt + 4 * g) * kKvStride + j16;
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16x16x4(vr[sidx * kKvStride + 16 * dt], pr[sidx], acc[dt]);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);                                       // finite: every chunk starts with a real key
+        const float alpha = __expf(m - m_new);
+        m = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m_new); psum += st[kt][r]; }
+        l = l * alpha + psum;                                                   // this lane's share of the row sum; the four g-lanes are added at the end
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = acc[dt] * alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kKvStride + 16 * kt + 4 * g);   // V^T[dim 16 dt + j16][keys 16 kt + 4 g ..]
+                acc[dt] = mfma16x16x4(vv.x, st[kt][0], acc[dt]);
+                acc[dt] = mfma16x16x4(vv.y, st[kt][1], acc[dt]);
+                acc[dt] = mfma16x16x4(vv.z, st[kt][2], acc[dt]);
+                acc[dt] = mfma16x16x4(vv.w, st[kt][3], acc[dt]);
+            }
     }
     if (!q_ok) return;
     l += __shfl_xor(l, 16, 64);
@@ -441,6 +464,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
     const int di = t_ow->dims[1], ffd = t_f1->dims[0], med = t_m1->dims[2];
     if (di % kDh) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: dim_inner must be a multiple of dim_head = 64");
     const int heads = di / kDh, ldq = 3 * di + heads;
+    if (ldq % 4) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: the attention kernel stages K / V with 16-byte loads: heads must be a multiple of 4");
 
     MelbandEngine* e = new MelbandEngine();
     e->device = device; e->L = in_len; e->n_win = n_win; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;

@@ -47,10 +47,13 @@ constexpr int kZN = 400, kZHop = 100, kZF = kZN / 2 + 1, kZC2 = 2 * kZF;   // Ex
 constexpr int kChunkTok = 2048;                                             // tokens per partial-statistics block
 
 // ---- small device helpers -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }     // F.softplus (threshold 20)
+// F.softplus (threshold 20) on the hardware exp2 / log2 units (v_exp_f32, v_log_f32, ~1 ulp each): log(1 + e^x) loses RELATIVE accuracy where e^x < 1e-7,
+// i.e. where the result is below 1e-7 ABSOLUTE next to the -0.08 x term of the Swoosh it feeds -- far inside the parity tolerance; libm's expf + log1pf cost
+// ~50 VALU instructions per element and made the Swoosh-loading GEMMs VALU-bound (19 % matrix-core busy, profiles/r02_zipenhancer_mfma_busy.txt).
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
 __device__ __forceinline__ float swoosh_l(float x) { return softplus_f(x - 4.0f) - 0.08f * x; }        // (:135-136), offset folded into the bias
 __device__ __forceinline__ float swoosh_r(float x) { return softplus_f(x - 1.0f) - 0.08f * x; }        // (:138)
-__device__ __forceinline__ float sigmoid_p(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_p(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // rows of a sequence: row(seq, p) = (seq / sdiv) * sa + (seq % sdiv) * sb + p * ps
 struct SeqGeo {
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
         float v = 0.0f;
         if (key < n && d < dv) {
             const float* q = src + (size_t)(r0 + (long long)key * geo.ps) * lds_;
-            v = MODE == 0 ? tanhf(q[d]) * q[dv + d] : q[h * dv + d];
+            v = MODE == 0 ? tanh_f(q[d]) * q[dv + d] : q[h * dv + d];
         }
         Vt[d * vst + key] = v;
     }
