@@ -839,14 +839,15 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (e->meta.count("ade_gemm_dtype") && !e->meta["ade_gemm_dtype"].empty()) {
             if (e->meta["ade_gemm_dtype"] == "bf16") gemm_bf16 = true;
             else if (e->meta["ade_gemm_dtype"] != "f32") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_gemm_dtype must be 'f32' or 'bf16'"));
-            if (gemm_bf16 && !fam_zip) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 is implemented for model_family zipenhancer"));
+            if (gemm_bf16 && !fam_zip && !fam_melband && !fam_moss)
+                return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 is implemented for the transformer families (zipenhancer, mel_band_roformer, mossformer2_ss)"));
         }
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
-                       : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, device, &e->sub, derr)
+                       : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
-                                     : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr);
+                                     : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
         e->out_channels = e->sub->out_channels();

@@ -37,15 +37,35 @@ constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kRow = 20;               // LDS floats per staged row
 constexpr int kSlab = kTM * kRow;      // floats per operand slab
 
+// bf16-input mode (BF16 = true on the tile functions below): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS; the products
+// run as v_mfma_f32_16x16x16_bf16 with fp32 accumulation -- one instruction per 16-deep slab and tile instead of four.  A throughput mode, not the parity path.
+#if defined(__clang__)
+typedef short v4s __attribute__((ext_vector_type(4)));
+#else
+typedef short v4s __attribute__((vector_size(8)));
+#endif
+__device__ __forceinline__ unsigned bf16_bits(float x) {            // fp32 -> bf16, round to nearest even (inputs are finite activations / weights)
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint2 bf16x4(const float4& v) { return make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)); }
+__device__ __forceinline__ v4f mfma16x16x16_bf16(v4s a, v4s b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
 template <class T, class = void>
 struct HasVec4 : std::false_type {};
 template <class T>
 struct HasVec4<T, std::void_t<decltype(&T::vec4)>> : std::true_type {};
 
 // one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kSlab LDS slabs
-template <class AL, class BL, class ST>
+template <bool BF16 = false, class AL, class BL, class ST>
 __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const ST& store, int M, int N, int K, int m_blk, int n_blk,
                                           float* As, float* Bs) {
+    constexpr int kRowW = BF16 ? kRow / 2 : kRow;      // row pitch in 32-bit words (bf16: 16 values + 4 padding = 10 words)
+    auto put4 = [&](float* base, int row, int kk, const float4& v) {           // four consecutive k of one row
+        if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kk / 2) = bf16x4(v);
+        else *reinterpret_cast<float4*>(base + row * kRow + kk) = v;
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int j16 = lane & 15, g = lane >> 4;
@@ -113,26 +133,29 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
     auto stash = [&]() {                    // registers -> row-major LDS slabs (same lane maps as fetch)
         if (a_v4) {
             const int r = tid >> 2, kq = 4 * (tid & 3);
-            *reinterpret_cast<float4*>(As + r * kRow + kq) = ra[0];
-            *reinterpret_cast<float4*>(As + (r + 64) * kRow + kq) = ra[1];
+            put4(As, r, kq, ra[0]);
+            put4(As, r + 64, kq, ra[1]);
         } else {
             const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8;
-            *reinterpret_cast<float4*>(As + r * kRow + kh) = ra[0];
-            *reinterpret_cast<float4*>(As + r * kRow + kh + 4) = ra[1];
+            put4(As, r, kh, ra[0]);
+            put4(As, r, kh + 4, ra[1]);
         }
         if (b_v4) {
             const int c = tid >> 2, kq = 4 * (tid & 3);
-            *reinterpret_cast<float4*>(Bs + c * kRow + kq) = rb[0];
-            *reinterpret_cast<float4*>(Bs + (c + 64) * kRow + kq) = rb[1];
+            put4(Bs, c, kq, rb[0]);
+            put4(Bs, c + 64, kq, rb[1]);
         } else if (BL::kAlongN) {
             const int c = tid & 127, kh = (tid >> 7) * 8;
-            *reinterpret_cast<float4*>(Bs + c * kRow + kh) = rb[0];
-            *reinterpret_cast<float4*>(Bs + c * kRow + kh + 4) = rb[1];
+            put4(Bs, c, kh, rb[0]);
+            put4(Bs, c, kh + 4, rb[1]);
         } else {
             const int kk = tid & 15, cg = tid >> 4;
             const float t[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) Bs[(cg + 16 * u) * kRow + kk] = t[u];
+            for (int u = 0; u < 8; ++u) {
+                if constexpr (BF16) reinterpret_cast<unsigned short*>(Bs)[(cg + 16 * u) * (2 * kRowW) + kk] = (unsigned short)bf16_bits(t[u]);
+                else Bs[(cg + 16 * u) * kRow + kk] = t[u];
+            }
         }
     };
     fetch(0);
@@ -140,20 +163,32 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
         stash();
         __syncthreads();
         if (k0 + kTK < K) fetch(k0 + kTK);
-        float4 a4[4], b4[4];                // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
+        if constexpr (BF16) {               // lane (g, j16): four consecutive k (= 4 g ..) of its row as four bf16: one ds_read_b64 per operand tile
+            v4s a8[4], b8[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+            for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
+            for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (wn + 16 * j + j16) * kRowW + 2 * g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
-                acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
+        } else {
+            float4 a4[4], b4[4];            // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+                }
+        }
         __syncthreads();
     }
     // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
@@ -177,24 +212,25 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
     return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
 }
 
-template <class AL, class BL, class ST>
+template <class AL, class BL, class ST, bool BF16 = false>
 __global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
-    gemm_tile(a_of, b_of, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, As, Bs);
+    gemm_tile<BF16>(a_of, b_of, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, As, Bs);
 }
 
 template <class AL, class BL, class ST>
-inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K, bool bf16 = false) {
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST, true>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST, false>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }
 
 // Batched form: blockIdx.z selects a problem.  `prob(z)` (evaluated once per workgroup, so its table reads are scalar loads)
 // returns a struct with members a, b, st (functors as above) and M, N, K; problems may differ in every one of them -- tiles
 // outside a problem's own M x N exit at once, the grid is sized for the largest.
-template <class P>
+template <class P, bool BF16 = false>
 __global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
@@ -204,13 +240,14 @@ __global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
     const auto q = prob(z);
     const int m_blk = (in_z / gx) * kTM, n_blk = (in_z % gx) * kTN;
     if (m_blk >= q.M || n_blk >= q.N) return;
-    gemm_tile(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
+    gemm_tile<BF16>(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
 }
 
 template <class P>
-inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N) {
+inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N, bool bf16 = false) {
     const dim3 grid((unsigned)((max_N + kTN - 1) / kTN), (unsigned)((max_M + kTM - 1) / kTM), (unsigned)batch);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P>), grid, dim3(256), 0, s, prob);
+    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P, true>), grid, dim3(256), 0, s, prob);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P, false>), grid, dim3(256), 0, s, prob);
 }
 
 // ---- common functors ------------------------------------------------------------------------------------------

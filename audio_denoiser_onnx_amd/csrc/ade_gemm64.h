@@ -29,18 +29,10 @@ using namespace dev;
 
 constexpr int kTM = 256, kTN = 64, kTK = 16, kRow = gemm::kRow;
 
-#if defined(__clang__)
-typedef short v4s __attribute__((ext_vector_type(4)));
-#else
-typedef short v4s __attribute__((vector_size(8)));
-#endif
-__device__ __forceinline__ unsigned bf16_bits(float x) {            // fp32 -> bf16, round to nearest even (NaN payloads are not preserved: inputs are finite activations / weights)
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ uint2 bf16x4(const float4& v) { return make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)); }
-__device__ __forceinline__ v4f mfma16x16x16_bf16(v4s a, v4s b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+using gemm::v4s;
+using gemm::bf16_bits;
+using gemm::bf16x4;
+using gemm::mfma16x16x16_bf16;
 
 template <class AL, class BL, class ST, bool BF16>
 __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {

@@ -400,6 +400,7 @@ struct MelbandEngine : SubEngine {
     std::vector<TfW> time_tf, freq_tf;
     const int *gcol = nullptr, *off = nullptr, *csr_start = nullptr, *csr_col = nullptr, *csr_d = nullptr;
     BandTable bt{};
+    bool bf16 = false;             // ade_gemm_dtype = "bf16": every projection / FFN / mask-estimator GEMM on bf16 inputs (fp32 accumulation); STFT, attention core, norms, ISTFT fp32
     int capacity = 0;
     float* ws = nullptr;
     float *Sp = nullptr, *X = nullptr, *invn = nullptr, *bufA = nullptr, *bufB = nullptr, *AO = nullptr, *YT = nullptr, *MS = nullptr,
@@ -422,7 +423,7 @@ struct MelbandEngine : SubEngine {
     void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
 };
 
-int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, int device, SubEngine** out, std::string& err) {
+int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return mfail(err, ADE_ERR_BAD_VALUE, "melband: n_win must be >= 1");
     if (in_len < kNfftM || in_len % kHopM != 0)
@@ -467,6 +468,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
     if (ldq % 4) return mfail(err, ADE_ERR_UNSUPPORTED, "melband: the attention kernel stages K / V with 16-byte loads: heads must be a multiple of 4");
 
     MelbandEngine* e = new MelbandEngine();
+    e->bf16 = bf16;
     e->device = device; e->L = in_len; e->n_win = n_win; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
     e->S2 = off[nb];
     for (int i = 0; i < nb; ++i) e->max_d = std::max(e->max_d, off[i + 1] - off[i]);
@@ -639,13 +641,13 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     using namespace gemm;
     const int ldq = 3 * di + heads;
     // invn holds 1 / |x_row| on entry (written by whoever produced X)
-    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, ScaleBiasStore{bufA, invn, w.in_b, ldq}, R, ldq, dim);                     // (:547-548)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, ScaleBiasStore{bufA, invn, w.in_b, ldq}, R, ldq, dim, bf16);                     // (:547-548)
     hipLaunchKernelGGL(k_attention, dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)bufA, AO, rc, rs, n,
                        seq_stride, pos_stride, ldq, di);                                                                     // (:549-560)
-    launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di);                               // (:561, :569)
+    launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di, bf16);                               // (:561, :569)
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
-    launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim);               // (:564)
-    launch(s, RowMajorA{bufB, ffd}, WeightNK{w.ff2_w, ffd}, ResidualStore{X, w.ff2_b, dim}, R, dim, ffd);                          // (:565, :570)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim, bf16);               // (:564)
+    launch(s, RowMajorA{bufB, ffd}, WeightNK{w.ff2_w, ffd}, ResidualStore{X, w.ff2_b, dim}, R, dim, ffd, bf16);                          // (:565, :570)
     hipLaunchKernelGGL(k_row_normalize_gain, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, X, w.out_g, invn, R, dim);            // (:571)
 }
 
@@ -659,7 +661,7 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB{d_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
     // band split                                                                                                                   (:597-599)
     hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
-    launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim);
+    launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim, bf16);
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     // axial transformers: time = T consecutive rows per (band, clip); frequency = nb rows B*T apart per (clip, frame)              (:609-614)
     for (int i = 0; i < depth; ++i) {
@@ -667,9 +669,9 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
         transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin);
     }
     // mask estimator: per band 384 -> 1536 -> 1536 (tanh) -> 2 d_i, kept raw and column-major for the GLU / scatter kernel         (:579-585)
-    launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med);
-    launch_batched(s, MeHiddenProb{bufB, me_w2t, me_b2, bufA, BT, med, med}, nb, BT, med);
-    launch_batched(s, MeOutProb{bufA, d_w, bt, YT, BT, med}, nb, BT, 2 * max_d);
+    launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med, bf16);
+    launch_batched(s, MeHiddenProb{bufB, me_w2t, me_b2, bufA, BT, med, med}, nb, BT, med, bf16);
+    launch_batched(s, MeOutProb{bufA, d_w, bt, YT, BT, med}, nb, BT, 2 * max_d, bf16);
     hipLaunchKernelGGL(k_mask_apply, dim3((unsigned)((BT + 255) / 256), (unsigned)kFc), dim3(256), 0, s, (const float*)Sp, (const float*)YT, csr_start, csr_col,
                        csr_d, MS, mask_tap, B, T);                                                                                  // (:616-624)
     // synthesis GEMM + overlap-add + PCM tail                                                                                      (:661, :667-676)

@@ -29,7 +29,7 @@ def model_tensors(fused: Mapping[str, np.ndarray], num_bands: int = NUM_BANDS) -
 
 
 def metadata(input_audio_length: int, dft_tables: str = "reference", use_batch_fold: bool = False,
-             batch_window_seconds: float = 1.5) -> Dict[str, str]:
+             batch_window_seconds: float = 1.5, gemm_dtype: str = "f32") -> Dict[str, str]:
     """Manifest of a static stereo export.  ``use_batch_fold`` as in the reference (Export_MelBandRoformer.py:47-51): the graph
     input is ``input_audio_length`` rounded up to whole windows of ``batch_window_seconds`` (itself rounded up to the hop),
     each window an independent stereo clip; without it the clip is ``input_audio_length`` long (a multiple of the hop) and
@@ -42,7 +42,7 @@ def metadata(input_audio_length: int, dft_tables: str = "reference", use_batch_f
                                 model_family="mel_band_roformer", input_audio_length=input_audio_length, in_sample_rate=SAMPLE_RATE,
                                 nfft=NFFT, window_length=NFFT, hop_length=HOP, window_type="hann", center_pad=True, pad_mode="reflect",
                                 use_batch_fold=use_batch_fold, batch_window_seconds=batch_window_seconds, input_channels=2,
-                                output_channels=2, extra={"ade_dft_tables": dft_tables})
+                                output_channels=2, extra={"ade_dft_tables": dft_tables, "ade_gemm_dtype": gemm_dtype})
 
 
 def synthetic_spec(depth: int, dim: int = 384, heads: int = 8, dim_head: int = 64, ff_mult: int = 4, me_hidden: int = 1536,

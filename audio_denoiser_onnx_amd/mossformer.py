@@ -57,7 +57,7 @@ def model_tensors(fused: Mapping[str, np.ndarray], scalars: Mapping, window: int
 
 
 def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window_seconds: float = 1.5, in_sample_rate: int = SAMPLE_RATE,
-             out_sample_rate: int = SAMPLE_RATE) -> Dict[str, str]:
+             out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32") -> Dict[str, str]:
     """Manifest keys the reference stamps for this model (:712-718): two output sources, conv encoder/decoder features.
     ``input_audio_length`` counts INPUT-rate samples; with in / out rates other than 16 kHz the engine interpolates linearly on both
     edges like the export (:562-571, :625-640) and the model sees round(length * 16000 / in_rate) samples."""
@@ -66,7 +66,8 @@ def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window
                                 out_sample_rate=out_sample_rate, model_sample_rate=SAMPLE_RATE,
                                 nfft=ENC_KERNEL, window_length=ENC_KERNEL, hop_length=ENC_STRIDE, window_type="none", center_pad=False,
                                 pad_mode="none", use_batch_fold=use_batch_fold, batch_window_seconds=batch_window_seconds,
-                                feature_kind="conv_encoder_decoder", extra={"pad_head": 8000, "enc_stride": ENC_STRIDE, "output_sources": 2})
+                                feature_kind="conv_encoder_decoder", extra={"pad_head": 8000, "enc_stride": ENC_STRIDE, "output_sources": 2,
+                                                                             "ade_gemm_dtype": gemm_dtype})
     return meta
 
 

@@ -77,7 +77,7 @@ def parse_args():
                     help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the projection / convolution GEMMs: f32 = exact fp32 matrix-core products (parity path, default); bf16 = bf16 inputs, "
-                         "fp32 accumulation (zipenhancer only; the deviation from the f32 path is measured and reported)")
+                         "fp32 accumulation (the transformer workloads; the deviation from the f32 path is measured and reported)")
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = the workload's BASELINE batch: 256 / 128 / 32 / 64)")
     ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-inclusive leg (pinned host buffers through ade_process; 0 = skip)")
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
@@ -120,6 +120,19 @@ def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, w
             "rtf": round(dt / seconds_per_row, 4)}
 
 
+def deviation_from_f32(make_session, x, rows: int = 2):
+    """What the reduced-precision GEMM inputs cost: the same rows through the exact (f32) path and the selected one."""
+    with make_session("f32") as ref:
+        want, wf = ref.process(x[:rows], want_f32=True)
+    with make_session("bf16") as low:
+        got, gf = low.process(x[:rows], want_f32=True)
+    err = gf.astype(np.float64) - wf.astype(np.float64)
+    sig = float((wf.astype(np.float64) ** 2).mean())
+    return {"vs": f"the f32 path on {rows} rows of the workload", "max_abs": round(float(np.abs(err).max()), 6), "rms": round(float(np.sqrt((err ** 2).mean())), 6),
+            "signal_rms": round(sig ** 0.5, 6), "units": "the engine's fp32 pre-PCM waveform", "snr_db": round(float(10 * np.log10(sig / max((err ** 2).mean(), 1e-30))), 1),
+            "max_pcm_lsb": int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())}
+
+
 def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str = "f32"):
     """-> dict(sess, B, x_host (B, row_in) int16, sr, out_seconds_per_row, flop_per_row, metric, workload, weights, cpu)"""
     from audio_denoiser_onnx_amd.session import InferenceSession
@@ -129,18 +142,11 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         from audio_denoiser_onnx_amd import zipenhancer as zp
         cfg, B = zp.ZipConfig(), batch or 128
         tensors = zp.synthetic_tensors(cfg)
-        sess = InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK, gemm_dtype=dtype), device_id=local_rank)
         x = synth_batch(B, CHUNK, first_index=rank * B)
-        deviation = None
-        if dtype != "f32":                                         # what the reduced-precision inputs cost: the same rows through the exact path
-            with InferenceSession(weights=pack_blob(tensors), metadata=zp.metadata(CHUNK), device_id=local_rank) as ref:
-                want, wf = ref.process(x[:4], want_f32=True)
-            got, gf = sess.process(x[:4], want_f32=True)
-            err = gf.astype(np.float64) - wf.astype(np.float64)
-            deviation = {"vs": "the f32 path on 4 rows of the workload", "max_abs_int16_units": round(float(np.abs(err).max()), 2),
-                         "rms_int16_units": round(float(np.sqrt((err ** 2).mean())), 3), "signal_rms_int16_units": round(float(np.sqrt((wf.astype(np.float64) ** 2).mean())), 1),
-                         "snr_db": round(float(10 * np.log10((wf.astype(np.float64) ** 2).mean() / max((err ** 2).mean(), 1e-30))), 1),
-                         "max_pcm_lsb": int(np.abs(got.astype(np.int32) - want.astype(np.int32)).max())}
+        blob = pack_blob(tensors)
+        deviation = deviation_from_f32(lambda dt: InferenceSession(weights=blob, metadata=zp.metadata(CHUNK, gemm_dtype=dt), device_id=local_rank), x, 4) if dtype != "f32" else None
+
+        sess = InferenceSession(weights=blob, metadata=zp.metadata(CHUNK, gemm_dtype=dtype), device_id=local_rank)
 
         def cpu():
             sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -156,11 +162,14 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         from audio_denoiser_onnx_amd import melband, weightgen
         B, L, depth = batch or 32, 352800, 6
         w = weightgen.materialise(melband.synthetic_spec(depth))
-        sess = InferenceSession(weights=pack_blob(melband.model_tensors(w)), metadata=melband.metadata(L), device_id=local_rank)
+        blob = pack_blob(melband.model_tensors(w))
         del w
         from audio_denoiser_onnx_amd.synth import synth_stereo
         x = np.stack([synth_stereo(rank * B + i, L, 44100).reshape(-1) for i in range(B)])
-        return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=None,
+        deviation = deviation_from_f32(lambda dt: InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=dt), device_id=local_rank), x, 1) if dtype != "f32" else None
+        sess = InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=dtype), device_id=local_rank)
+        del blob
+        return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=None, deviation=deviation,
                     metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
                     workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), fp32 matrix cores, int16 PCM resident in HBM "
                              "(BASELINE.json configs[3]; bf16 there, fp32 here)",
@@ -171,10 +180,13 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         frames = mossformer.frames_of(L)
         fused = {n: mossformer.synthetic_tensor(n, sh, sc, frames) for n, sh, sc in mossformer.synthetic_spec(layers)}
         scalars = dict(mossformer.DEFAULT_SCALARS, fs_front_alpha=[0.25] * layers)
-        sess = InferenceSession(weights=pack_blob(mossformer.model_tensors(fused, scalars, L)), metadata=mossformer.metadata(L), device_id=local_rank)
+        blob = pack_blob(mossformer.model_tensors(fused, scalars, L))
         del fused
         x = np.stack([(synth_chunk(rank * B + i, L).astype(np.int32) + synth_chunk(10000 + rank * B + i, L)).clip(-32768, 32767).astype(np.int16) for i in range(B)])
-        return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=None,
+        deviation = deviation_from_f32(lambda dt: InferenceSession(weights=blob, metadata=mossformer.metadata(L, gemm_dtype=dt), device_id=local_rank), x, 1) if dtype != "f32" else None
+        sess = InferenceSession(weights=blob, metadata=mossformer.metadata(L, gemm_dtype=dtype), device_id=local_rank)
+        del blob
+        return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=None, deviation=deviation,
                     metric="audio_seconds_per_second (MossFormer2-SS-16K, batch=64 x 4 s; RTF = 1/value)",
                     workload="MossFormer2-SS-16K two-speaker separation, 24 layers, batch=64 x 4 s (7999 frames), fp32 matrix cores, int16 PCM resident in HBM "
                              "(BASELINE.json configs[4])",
@@ -217,8 +229,6 @@ def main():
         x_host = synth_batch(B, CHUNK, first_index=rank * B)
         sr, wl = SR, None
     else:
-        if args.dtype != "f32" and args.workload != "zipenhancer":
-            raise SystemExit("--dtype bf16 is implemented for --workload zipenhancer")
         wl = build_workload(args.workload, args.batch, rank, local_rank, args.dtype)
         sess, B, x_host, sr = wl["sess"], wl["B"], wl["x"], wl["sr"]
         if args.steps == 100 and args.warmup == 10:      # the defaults are sized for GTCRN's 0.4 ms steps; these steps take 0.2 - 1.2 s

@@ -263,3 +263,21 @@ def test_gpu_production_size_clips_match_reference(tag):
     assert np.median(m55) < 3e-4 and m55.max() < 3e-2, report
     assert wave_err <= 1e-4, report                             # the north-star tolerance on the fp32 waveform before the PCM tail
     assert d.max() <= 2 and (d != 0).mean() < 0.10, report
+
+
+@pytest.mark.gpu
+def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
+    """ade_gemm_dtype = "bf16" (bf16 inputs, fp32 accumulation in every projection / FFN / mask-estimator GEMM): a throughput mode, NOT the parity path."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    z, _, w = fixture
+    L = z["pcm_in"].shape[1]
+    blob = pack_blob(melband.model_tensors(w))
+    with InferenceSession(weights=blob, metadata=melband.metadata(L)) as a, InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype="bf16")) as b:
+        _, fa = a.process(z["pcm_in"].reshape(1, -1), want_f32=True)
+        _, fb = b.process(z["pcm_in"].reshape(1, -1), want_f32=True)
+    err, sig = fb.astype(np.float64) - fa, fa.astype(np.float64)
+    snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
+    print(f"mel_band_roformer bf16 vs f32: SNR {snr:.1f} dB")
+    assert snr > 20.0

@@ -222,3 +222,16 @@ def test_gpu_baseline_batch_64_windows_of_4s_properties():
     d = outs[0].astype(np.int32) - z["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 2
     assert np.abs(outs[0].astype(np.int32) - solo.reshape(2, W).astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
+    """ade_gemm_dtype = "bf16" (the masking network's GEMMs on bf16 inputs, fp32 accumulation): a throughput mode, NOT the parity path."""
+    z, _, _, W = fixture
+    with _session(fixture, W) as a, _session(fixture, W, gemm_dtype="bf16") as b:
+        _, fa = a.process(z["pcm_in"][None], want_f32=True)
+        _, fb = b.process(z["pcm_in"][None], want_f32=True)
+    err, sig = fb.astype(np.float64) - fa, fa.astype(np.float64)
+    snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
+    print(f"mossformer2_ss bf16 vs f32: SNR {snr:.1f} dB")
+    assert snr > 15.0
