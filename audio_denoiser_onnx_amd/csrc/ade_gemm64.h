@@ -131,6 +131,110 @@ inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M,
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST, false>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }
 
+// ---- K = 64 projections: out(m, off + n) = sum_{k < 64} x(m, k) w(n, k) + bias(n) ------------------------------------------------------------------------
+// ZipEnhancer's eight in-projections per layer all contract over the 64 channels.  With K that short a slab pipeline is mostly prologue, so this kernel drops it:
+//   * a workgroup owns 64 RT rows and ALL output columns; each wavefront's 16 RT x 64 activation block is fetched ONCE, straight from global memory into the registers the
+//     matrix cores read (lane (g, j16): row 16 i + j16, k = 16 ks + 4 g .. + 3 as one float4 -- no LDS round trip for the activations);
+//   * the weights stream through LDS 64 columns at a time, double-buffered (one barrier per 64 columns);
+//   * the product is formed TRANSPOSED (weights as the A operand, activations as B), so a lane's four accumulator registers are four CONSECUTIVE output columns of one
+//     row: one 16-byte store per tile instead of four 4-byte ones.
+// ldx, ldo, off: multiples of 4; w: (N, 64) row-major; N a multiple of 16.  BF16 as above.
+template <bool BF16, int RT>
+__global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                                                int ldo, int off, int M, int N) {
+    __shared__ __attribute__((aligned(16))) float Ws[2][4 * 64 * kRow];     // [buffer][ks][column][16 k + pad]
+    constexpr int kRowW = BF16 ? kRow / 2 : kRow;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j16 = lane & 15, g = lane >> 4;
+    const int m0 = (int)blockIdx.x * (64 * RT) + wave * (16 * RT);
+    float4 xa[RT][4];                        // [row tile i][ks]
+    v4s xb[RT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int m = m0 + 16 * i + j16;
+        const float* row = x + (size_t)(m < M ? m : 0) * ldx + 4 * g;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 v = m < M ? *reinterpret_cast<const float4*>(row + 16 * ks) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (BF16) { const uint2 q = bf16x4(v); xb[i][ks] = *reinterpret_cast<const v4s*>(&q); }
+            else xa[i][ks] = v;
+        }
+    }
+    auto stage = [&](int n0, int buf) {       // 64 columns x 64 k: 1024 float4, four per lane
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u, c = idx >> 4, k4 = (idx & 15) * 4, n = n0 + c;
+            const float4 v = n < N ? *reinterpret_cast<const float4*>(w + (size_t)n * 64 + k4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float* dst = Ws[buf] + ((k4 >> 4) * 64 + c) * kRowW;
+            if constexpr (BF16) *reinterpret_cast<uint2*>(dst + (k4 & 15) / 2) = bf16x4(v);
+            else *reinterpret_cast<float4*>(dst + (k4 & 15)) = v;
+        }
+    };
+    stage(0, 0);
+    int buf = 0;
+    for (int n0 = 0; n0 < N; n0 += 64, buf ^= 1) {
+        __syncthreads();                     // Ws[buf] is complete; every wave has finished reading Ws[buf ^ 1] (previous iteration)
+        if (n0 + 64 < N) stage(n0 + 64, buf ^ 1);
+        v4f acc[4][RT];                       // [column tile jn][row tile i]: lane (g, j16) holds out[row 16 i + j16][columns 16 jn + 4 g .. + 3]
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[jn][i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (BF16) {
+                v4s wb[4];
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) wb[jn] = *reinterpret_cast<const v4s*>(Ws[buf] + (ks * 64 + 16 * jn + j16) * kRowW + 2 * g);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x16_bf16(wb[jn], xb[i][ks], acc[jn][i]);
+            } else {
+                float4 wv[4];
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn) wv[jn] = *reinterpret_cast<const float4*>(Ws[buf] + (ks * 64 + 16 * jn + j16) * kRow + 4 * g);
+                // k-step outermost: sixteen independent accumulators between two steps of the same one (no back-to-back dependent MFMAs)
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x4(wv[jn].x, xa[i][ks].x, acc[jn][i]);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x4(wv[jn].y, xa[i][ks].y, acc[jn][i]);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x4(wv[jn].z, xa[i][ks].z, acc[jn][i]);
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x4(wv[jn].w, xa[i][ks].w, acc[jn][i]);
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int n = n0 + 16 * jn + 4 * g;
+            if (n >= N) continue;
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int m = m0 + 16 * i + j16;
+                if (m < M)
+                    *reinterpret_cast<float4*>(out + (size_t)m * ldo + off + n) =
+                        make_float4(acc[jn][i][0] + b.x, acc[jn][i][1] + b.y, acc[jn][i][2] + b.z, acc[jn][i][3] + b.w);
+            }
+        }
+    }
+}
+inline void launch_proj64(hipStream_t s, const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int off, int M, int N, bool bf16 = false) {
+    if (M <= 0 || N <= 0) return;
+    constexpr int RT = 2;                        // 16-row tiles per wavefront: 2 -> 128 rows per workgroup, ~120 VGPRs, four wavefronts per SIMD (4 -> 232 VGPRs, two)
+    const dim3 grid((unsigned)((M + 64 * RT - 1) / (64 * RT)));
+    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_proj64<true, RT>), grid, dim3(256), 0, s, x, ldx, w, bias, out, ldo, off, M, N);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_proj64<false, RT>), grid, dim3(256), 0, s, x, ldx, w, bias, out, ldo, off, M, N);
+}
+
 // ---- common operands ---------------------------------------------------------------------------------------------------
 struct RowsA {           // A(m, k) = p[m * ld + k]
     const float* p;

@@ -948,23 +948,23 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
-    launch(s, RowsA{x, C}, WeightB{w.attn_ff1_w, C}, BiasColStore{P, w.attn_ff1_b, ldp, 0}, M, ldp, C, bf16);                                        // (:148-153)
+    launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp, bf16);                                        // (:148-153)
     launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                      // (:160)
-    launch(s, RowsA{Y, C}, WeightB{w.nonlin_in_w, C}, BiasColStore{S1, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid, C, bf16);                           // (:305)
+    launch_proj64(s, Y, C, w.nonlin_in_w, w.nonlin_in_b, S1, 3 * hid, 0, M, 3 * hid, bf16);                           // (:305)
     attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
     launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid, bf16);                              // (:317, :167)
     for (int i = 0; i < 2; ++i) {
-        launch(s, RowsA{Y, C}, WeightB{w.sa_in_w[i], C}, BiasColStore{S1, w.sa_in_b[i], vdim, 0}, M, vdim, C, bf16);                               // (:296)
+        launch_proj64(s, Y, C, w.sa_in_w[i], w.sa_in_b[i], S1, vdim, 0, M, vdim, bf16);                               // (:296)
         attention(s, 1, w.pos, S1, vdim, O, vdim, geo, vd);                                                                                   // (:297-300) all heads
         launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim, bf16);                         // (:301, :168 / :172)
-        launch(s, RowsA{Y, C}, WeightB{w.cv_in_w[i], C}, BiasColStore{S1, w.cv_in_b[i], 2 * C, 0}, M, 2 * C, C, bf16);                             // (:321)
+        launch_proj64(s, Y, C, w.cv_in_w[i], w.cv_in_b[i], S1, 2 * C, 0, M, 2 * C, bf16);                             // (:321)
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C, bf16);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
-        launch(s, RowsA{Y, C}, WeightB{w.ff_in_w[i], C}, BiasColStore{S1, w.ff_in_b[i], fd, 0}, M, fd, C, bf16);
+        launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd, bf16);
         if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd, bf16);   // (:170-171)
         else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd, bf16);                   // (:174)
     }
