@@ -129,8 +129,7 @@ def test_gpu_batch_rows_are_independent_clips(fixture, session):
     one_b = session.run(None, {"noisy_audio": b[None]})[0][0]
     both = session.run(None, {"noisy_audio": np.stack((a, b, a))})[0]
     for got, want in ((both[0], one_a), (both[1], one_b), (both[2], one_a)):
-        d = got.astype(np.int32) - want.astype(np.int32)
-        assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
+        assert np.array_equal(got, want)            # bit for bit: no product's summation order depends on the batch size (tools/debug_melband_batch.py)
 
 
 @pytest.mark.gpu

@@ -235,3 +235,30 @@ def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
     snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
     print(f"mossformer2_ss bf16 vs f32: SNR {snr:.1f} dB")
     assert snr > 15.0
+
+
+@pytest.mark.gpu
+def test_gpu_file_driver_head_padding_two_outputs(fixture, tmp_path):
+    """inference_mossformer.main() end to end on the GPU (this driver was only CPU-tested): model directory from the blob + manifest, 8000 zeros of
+    head padding, static slices, one batched call, head drop + trim, two wav files; equals the per-slice session calls (Inference_MossFormer_SS_ONNX.py:273-340)."""
+    from audio_denoiser_onnx_amd import inference_mossformer
+    from audio_denoiser_onnx_amd.inference_gtcrn import read_wav_int16, write_wav_int16
+    from audio_denoiser_onnx_amd.metadata import write_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_chunk
+    from audio_denoiser_onnx_amd.weights import save_blob
+    _, fused, scalars, W = fixture
+    model = tmp_path / "MossFormer2_SS_16K.adew"
+    save_blob(model, mossformer.model_tensors(fused, scalars, W))
+    write_metadata(model, mossformer.metadata(W, use_batch_fold=False))
+    audio = (synth_chunk(7, 5000).astype(np.int32) + synth_chunk(8, 5000)).clip(-32768, 32767).astype(np.int16)
+    write_wav_int16(tmp_path / "mix.wav", audio, 16000)
+    assert inference_mossformer.main([str(model), str(tmp_path / "mix.wav"), str(tmp_path / "sep"), "--seed", "3"]) == 0
+    outs = [read_wav_int16(tmp_path / f"sep_{i}.wav", 16000) for i in range(2)]
+    assert all(o.shape == audio.shape for o in outs)
+    padded = np.concatenate((np.zeros(8000, np.int16), audio))
+    slices = inference_mossformer.cut_slices(padded, W, False, np.random.default_rng(3))
+    with InferenceSession(str(model)) as sess:
+        want = sess.run(None, {"mix_audio": slices[:, None, :]})
+    for spk in range(2):
+        assert np.array_equal(outs[spk], want[spk].reshape(-1)[8000:len(padded)])

@@ -277,3 +277,27 @@ def test_gpu_zipenhancer_bf16_gemm_mode_stays_close_to_f32(model):
         assert snr > 20.0
     with pytest.raises(Exception):
         InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype="fp8"))
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_file_driver(model, tmp_path):
+    """inference_zipenhancer.main() on a wav file with a batch-fold model directory: export -> manifest + blob -> slices (input-length stride, zero tail) ->
+    one batched call -> concat -> trim; equals the per-slice session calls sample for sample (Inference_ZipEnhancer_ONNX.py:268-352)."""
+    from audio_denoiser_onnx_amd import export, inference_zipenhancer
+    from audio_denoiser_onnx_amd.inference_gtcrn import read_wav_int16, write_wav_int16
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_chunk
+    _, _, sd, _ = model
+    np.savez(tmp_path / "ck.npz", **sd)
+    path = export.export_zipenhancer(tmp_path / "ck.npz", tmp_path / "model", 40000, True)        # 2 fold windows of 24000 per call
+    audio = np.concatenate([synth_chunk(40 + i) for i in range(7)])[:107003]                       # 6.7 s: 3 slices of 48000, ragged tail
+    write_wav_int16(tmp_path / "in.wav", audio, 16000)
+    assert inference_zipenhancer.main([str(path), str(tmp_path / "in.wav"), str(tmp_path / "out.wav")]) == 0
+    got = read_wav_int16(tmp_path / "out.wav", 16000)
+    assert got.shape == audio.shape
+    padded = np.zeros(3 * 48000, np.int16)
+    padded[:len(audio)] = audio
+    with InferenceSession(str(path)) as sess:
+        assert sess.in_len == 48000
+        want = np.concatenate([sess.run(None, {"noisy_audio": padded[i * 48000:(i + 1) * 48000].reshape(1, 1, -1)})[0].reshape(-1) for i in range(3)])[:len(audio)]
+    assert np.array_equal(got, want) and np.abs(got).max() > 100
