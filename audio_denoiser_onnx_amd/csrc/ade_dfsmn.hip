@@ -6,13 +6,17 @@
 //   Linear(120,256)+ReLU -> 9 x [Linear+ReLU, Linear (no bias), causal depthwise memory (lorder 20) with the inner
 //   residual folded into the current tap, outer residual] -> Linear(256,961)+Sigmoid -> mask * spectrum ->
 //   ISTFT (periodic hamming, no centre pad, static COLA) -> * 32768, clamp, truncate -> int16.
-// Every step but the depthwise memory is a matrix product, so the whole model is the generic matrix-core GEMM of
-// csrc/ade_gemm.h with functor operands / stores (activations are channels-first (C, N) with N = batch * frames):
-//   analysis   AN(3972, N)  = K_an(3972, 1920) x frames(1920, N)        B operand = int16 samples * 2^-15, framed by index
-//   log-mel    F(120, N)    = mel(120, 1025) x power(1025, N)            B operand = (re^2 + im^2) * 2^30 of AN rows ; store = log(max(., eps))
-//   layers     X(256, N)    = relu(W x + b) ...                          store = bias + ReLU / none / bias + sigmoid
-//   synthesis  frames(N, 1920) = (mask * spectrum)^T(N, 1922) x K_inv(1922, 1920)   A operand = AN row * mask row
-// followed by a gather overlap-add with the PCM tail fused.  DFT tables use exact angles (see ade_stft.hip).
+// The two analysis transforms and the synthesis are FFTs (csrc/ade_fft.h: one workgroup per frame, mixed-radix Stockham passes in LDS -- 2048 = 4^5 x 2 for the
+// Kaldi filter bank, 1920 = 4^3 x 2 x 3 x 5 for the mask STFT and its inverse): 0.3 MFLOP per frame instead of the 22.9 MFLOP of the reference's dense
+// (3972 + 1922) x 1920 windowed-DFT products, which used to be 67 % of this model's step as matrix-core GEMMs.  The steps the reference folds into its
+// analysis matrix -- DC removal, 0.97 pre-emphasis, symmetric hamming (:97-120) -- are applied to the frame explicitly before the 2048-point transform.
+// The mask network is matrix products and stays on the generic matrix-core GEMM of csrc/ade_gemm.h (activations channels-first (C, N), N = batch * frames):
+//   analysis   P(N, 1025) = |FFT_2048(hamming * preemph(frame - mean))|^2 * 2^30 ;  S(N, 2 x 961) = FFT_1920(hamming * frame)         k_dfsmn_analysis
+//   log-mel    F(120, N)  = mel(120, 1025) x P^T                         store = log(max(., eps))
+//   layers     X(256, N)  = relu(W x + b) ...                            store = bias + ReLU / none ; the last one bias + sigmoid, transposed to (N, 961)
+//   synthesis  frames(N, 1920) = hamming_periodic * Re IFFT_1920(hermitian(mask * S))                                                   k_dfsmn_synthesis
+// followed by a gather overlap-add with the PCM tail fused.  Twiddles are exact (double-precision angles), like the dense tables they replace.
+#include "ade_fft.h"
 #include "ade_gemm.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
@@ -29,46 +33,77 @@ using namespace dev;
 constexpr int kKaldiNfft = 2048, kFrame = 1920, kHopD = 960, kNfftD = 1920;
 constexpr int kFbBins = kKaldiNfft / 2 + 1;      // 1025
 constexpr int kStBins = kNfftD / 2 + 1;          // 961
-constexpr int kAnRows = 2 * kFbBins + 2 * kStBins;   // 3972
 constexpr int kMel = 120, kHid = 256;
 
-struct PcmFrameB {             // B(k, j) = sample k of frame j = (b, t), * 2^-15 (Export_DFSMN.py:186-190, conv1d stride 960, no padding)
+struct PowerFrameB {           // B(f, j) = power bin f of frame j (frame-major P, written by k_dfsmn_analysis)   (:216)
     static constexpr bool kAlongN = false;
-    const int16_t* pcm;
-    const float* fpcm;         // resampled input (floats in int16 units, :186-193) replaces pcm when set
-    int L, T;
-    __device__ float operator()(int k, int j) const {
-        const int b = j / T, t = j - b * T;
-        const size_t at = (size_t)b * L + t * kHopD + k;
-        return (fpcm ? fpcm[at] : (float)pcm[at]) * (1.0f / 32768.0f);
-    }
-    // four consecutive samples as one 8-byte load (frames start at multiples of 960 samples, so row starts are 8-byte aligned when L % 4 == 0)
-    __device__ bool can_vec4(int K) const { return !fpcm && (K & 3) == 0 && (L & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0; }
-    __device__ float4 vec4(int j, int k) const {
-        const int b = j / T, t = j - b * T;
-        const short4 v = *reinterpret_cast<const short4*>(pcm + (size_t)b * L + t * kHopD + k);
-        return make_float4((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f), (float)v.z * (1.0f / 32768.0f), (float)v.w * (1.0f / 32768.0f));
-    }
+    const float* p;
+    __device__ float operator()(int f, int j) const { return p[(size_t)j * kFbBins + f]; }
 };
-struct PowerB {                // B(f, j) = (re^2 + im^2) * 32768^2 of the fbank half of AN (:216)
-    static constexpr bool kAlongN = true;
-    const float* an;
-    int N;
-    __device__ float operator()(int f, int j) const {
-        const float re = an[(size_t)f * N + j], im = an[(size_t)(kFbBins + f) * N + j];
-        return (re * re + im * im) * (32768.0f * 32768.0f);
-    }
+struct SigmoidTStore {         // mask[j][f] = sigmoid(v + bias[f]): the last Linear, stored frame-major for the per-frame synthesis kernel   (:230)
+    float* out;
+    const float* bias;
+    __device__ void operator()(int f, int j, float v) const { out[(size_t)j * kStBins + f] = 1.0f / (1.0f + expf(-(v + bias[f]))); }
 };
-struct MaskedSpecA {           // A(j, k) = spectrum row k * mask row (k mod 961)  (:236-237); consecutive j contiguous
-    static constexpr bool kAlongK = false;
-    const float* spec;         // AN + 2050 * N
-    const float* mask;
-    int N;
-    __device__ float operator()(int j, int k) const {
-        const int f = k < kStBins ? k : k - kStBins;
-        return spec[(size_t)k * N + j] * mask[(size_t)f * N + j];
+
+// One workgroup per frame: [Kaldi filter-bank power | mask STFT] of the frame's 1920 samples.
+//   x = samples * 2^-15 (:186-190); fbank branch: y = x - mean(x); z[n] = y[n] - 0.97 y[n - 1] (z[0] = 0.03 y[0]); * symmetric hamming; zero-pad to 2048;
+//   FFT; power = (re^2 + im^2) * 2^30 -- the steps Export_DFSMN.py:97-120 folds into its analysis matrix, in Kaldi's order.  STFT branch: x * hamming; FFT_1920.
+__global__ __launch_bounds__(256) void k_dfsmn_analysis(const int16_t* __restrict__ pcm, const float* __restrict__ fpcm, int L, int T, fft::Plan p2048, fft::Plan p1920,
+                                                        const float2* __restrict__ tw2048, const float2* __restrict__ tw1920, const float* __restrict__ win_fb,
+                                                        const float* __restrict__ win_st, float* __restrict__ power, float* __restrict__ spec) {
+    __shared__ float2 A[kKaldiNfft];
+    __shared__ float2 B[kKaldiNfft];
+    __shared__ double red[256];
+    const int frame = blockIdx.x, tid = threadIdx.x, b = frame / T, t = frame - b * T;
+    const size_t at = (size_t)b * L + (size_t)t * kHopD;
+    auto sample = [&](int n) { return (fpcm ? fpcm[at + n] : (float)pcm[at + n]) * (1.0f / 32768.0f); };
+    double part = 0.0;
+    for (int n = tid; n < kFrame; n += 256) part += (double)sample(n);
+    red[tid] = part;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
     }
-};
+    const float mean = (float)(red[0] / (double)kFrame);
+    for (int n = tid; n < kKaldiNfft; n += 256) {
+        float v = 0.0f;
+        if (n < kFrame) {
+            const float y = sample(n) - mean, yp = sample(n > 0 ? n - 1 : 0) - mean;
+            v = (y - 0.97f * yp) * win_fb[n];
+        }
+        A[n] = make_float2(v, 0.0f);
+    }
+    float2* r = fft::forward(A, B, p2048, tw2048, tid, 256);
+    for (int f = tid; f < kFbBins; f += 256) power[(size_t)frame * kFbBins + f] = (r[f].x * r[f].x + r[f].y * r[f].y) * (32768.0f * 32768.0f);
+    __syncthreads();
+    for (int n = tid; n < kNfftD; n += 256) A[n] = make_float2(sample(n) * win_st[n], 0.0f);
+    r = fft::forward(A, B, p1920, tw1920, tid, 256);
+    for (int f = tid; f < kStBins; f += 256) {
+        spec[(size_t)frame * 2 * kStBins + f] = r[f].x;
+        spec[(size_t)frame * 2 * kStBins + kStBins + f] = r[f].y;
+    }
+}
+
+// One workgroup per frame: mask * spectrum (:236-237) -> Hermitian extension -> inverse FFT_1920 -> * periodic hamming / N = the reference's inverse table applied to the
+// masked half spectrum (its sine rows of the DC and Nyquist bins are zero, so their imaginary parts do not contribute: set to zero here).
+// x N = sum_f Z[f] e^{+i theta} = conj(DFT(conj Z)); Z is Hermitian, so the result is real: Re DFT(conj Z).
+__global__ __launch_bounds__(256) void k_dfsmn_synthesis(const float* __restrict__ spec, const float* __restrict__ mask, fft::Plan p1920, const float2* __restrict__ tw1920,
+                                                         const float* __restrict__ win_syn, float* __restrict__ frames) {
+    __shared__ float2 A[kNfftD];
+    __shared__ float2 B[kNfftD];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const float* sp = spec + (size_t)frame * 2 * kStBins;
+    const float* mk = mask + (size_t)frame * kStBins;
+    for (int f = tid; f < kStBins; f += 256) {
+        const float m = mk[f], re = sp[f] * m, im = (f == 0 || f == kStBins - 1) ? 0.0f : sp[kStBins + f] * m;
+        A[f] = make_float2(re, -im);                                   // conj Z[f]
+        if (f > 0 && f < kStBins - 1) A[kNfftD - f] = make_float2(re, im);   // conj Z[N - f] = Z[f]
+    }
+    const float2* r = fft::forward(A, B, p1920, tw1920, tid, 256);
+    for (int n = tid; n < kNfftD; n += 256) frames[(size_t)frame * kNfftD + n] = (r[n].x * (1.0f / (float)kNfftD)) * win_syn[n];
+}
 
 // causal depthwise memory + outer residual: x[c][j] += sum_k w[c][k] * p1[c][j - (lo-1) + k], zero before the row's first frame (:228-229)
 __global__ __launch_bounds__(256) void k_fsmn_memory(const float* __restrict__ p1, const float* __restrict__ w, float* __restrict__ x, int N, int T,
@@ -117,12 +152,14 @@ void hamming_f32(int n, bool periodic, std::vector<float>& w) {   // the fp32 ev
 struct DfsmnEngine : SubEngine {
     int device = 0, in_len_ = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0, depth = 0, lorder = 0;
     float* d_w = nullptr;      // one arena: tables + weights
-    const float *k_an = nullptr, *k_inv = nullptr, *wsum = nullptr, *mel = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *lin2_w = nullptr,
+    const float *win_fb = nullptr, *win_st = nullptr, *win_syn = nullptr, *wsum = nullptr, *mel = nullptr, *lin1_w = nullptr, *lin1_b = nullptr, *lin2_w = nullptr,
                 *lin2_b = nullptr;
+    const float2 *tw2048 = nullptr, *tw1920 = nullptr;
+    fft::Plan p2048, p1920;
     std::vector<const float*> uf_lin_w, uf_lin_b, uf_proj_w, uf_conv_w;
     int capacity = 0;
     float* ws = nullptr;
-    float *an = nullptr, *feat = nullptr, *x = nullptr, *f1 = nullptr, *p1 = nullptr, *mask = nullptr, *frames_buf = nullptr;
+    float *power = nullptr, *spec = nullptr, *feat = nullptr, *x = nullptr, *f1 = nullptr, *p1 = nullptr, *mask = nullptr, *frames_buf = nullptr;
 
     ~DfsmnEngine() override {
         (void)hipSetDevice(device);
@@ -188,42 +225,23 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int n
     // ---- host tables
     std::vector<float> arena;
     auto push = [&](const float* src, size_t n) { const size_t off = arena.size(); arena.resize(off + ((n + 63) & ~(size_t)63)); if (src) memcpy(&arena[off], src, n * sizeof(float)); return off; };
-    const size_t o_an = push(nullptr, (size_t)kAnRows * kFrame);
-    {   // fbank rows (Export_DFSMN.py:97-120): float64, rounded once
+    // ---- windows and twiddles
+    std::vector<float> wa, wsyn, wfb((size_t)kFrame);
+    {
         std::vector<double> win;
-        hamming(kFrame, false, win);
-        std::vector<double> basis((size_t)kFrame), filt((size_t)kFrame);
-        for (int half = 0; half < 2; ++half)
-            for (int f = 0; f < kFbBins; ++f) {
-                for (int n = 0; n < kFrame; ++n) {
-                    const double a = 2.0 * M_PI * (double)(((long long)f * n) % kKaldiNfft) / kKaldiNfft;
-                    basis[n] = (half == 0 ? cos(a) : -sin(a)) * win[n];
-                }
-                filt[0] = (1.0 - 0.97) * basis[0] - 0.97 * basis[1];
-                for (int n = 1; n < kFrame - 1; ++n) filt[n] = basis[n] - 0.97 * basis[n + 1];
-                filt[kFrame - 1] = basis[kFrame - 1];
-                double mean = 0.0;
-                for (int n = 0; n < kFrame; ++n) mean += filt[n];
-                mean /= kFrame;
-                float* row = &arena[o_an + (size_t)(half * kFbBins + f) * kFrame];
-                for (int n = 0; n < kFrame; ++n) row[n] = (float)(filt[n] - mean);
-            }
+        hamming(kFrame, false, win);        // the Kaldi filter bank's symmetric hamming, float64 rounded once like the folded matrix it replaces (Export_DFSMN.py:97-120)
+        for (int n = 0; n < kFrame; ++n) wfb[n] = (float)win[n];
     }
-    std::vector<float> wa, wsyn;
     hamming_f32(kNfftD, false, wa);     // analysis: symmetric hamming (DFSMN/STFT_Process.py:92)
     hamming_f32(kNfftD, true, wsyn);    // synthesis: periodic hamming (:93)
-    const size_t o_inv = push(nullptr, (size_t)2 * kStBins * kNfftD);
-    for (int f = 0; f < kStBins; ++f) {
-        const float scale = (f == 0 || f == kStBins - 1) ? 1.0f : 2.0f;
-        for (int n = 0; n < kNfftD; ++n) {
-            const double a = 2.0 * M_PI * (double)(((long long)f * n) % kNfftD) / kNfftD;
-            const float c = (float)cos(a), s = (float)sin(a);
-            arena[o_an + (size_t)(2 * kFbBins + f) * kFrame + n] = c * wa[n];
-            arena[o_an + (size_t)(2 * kFbBins + kStBins + f) * kFrame + n] = -s * wa[n];
-            arena[o_inv + (size_t)f * kNfftD + n] = ((scale * c) * (float)(1.0 / kNfftD)) * wsyn[n];
-            arena[o_inv + (size_t)(kStBins + f) * kNfftD + n] = ((scale * -s) * (float)(1.0 / kNfftD)) * wsyn[n];
-        }
-    }
+    const size_t o_wfb = push(wfb.data(), wfb.size()), o_wst = push(wa.data(), wa.size()), o_wsyn = push(wsyn.data(), wsyn.size());
+    auto twiddles = [&](int n) {
+        std::vector<float> tw((size_t)2 * n);
+        for (int m = 0; m < n; ++m) { const double a = -2.0 * M_PI * (double)m / (double)n; tw[2 * m] = (float)cos(a); tw[2 * m + 1] = (float)sin(a); }
+        return push(tw.data(), tw.size());
+    };
+    const size_t o_tw2048 = twiddles(kKaldiNfft), o_tw1920 = twiddles(kNfftD);
+    if (!fft::make_plan(kKaldiNfft, &d->p2048) || !fft::make_plan(kNfftD, &d->p1920)) { delete d; return dfail(err, ADE_ERR_UNSUPPORTED, "dfsmn: FFT plan"); }
     const size_t o_ws = push(nullptr, (size_t)d->out_len_);
     for (int t = 0; t < d->T; ++t)
         for (int n = 0; n < kNfftD; ++n) arena[o_ws + (size_t)t * kHopD + n] += wsyn[n] * wsyn[n];
@@ -241,7 +259,8 @@ int dfsmn_create(const std::map<std::string, Tensor>& tensors, int in_len, int n
     if (hipMalloc((void**)&d->d_w, arena.size() * sizeof(float)) != hipSuccess) return bail(dfail(err, ADE_ERR_DEVICE, "hipMalloc of the DFSMN weights failed"));
     if (hipMemcpy(d->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(dfail(err, ADE_ERR_DEVICE, "upload of the DFSMN weights failed"));
-    d->k_an = d->d_w + o_an; d->k_inv = d->d_w + o_inv; d->wsum = d->d_w + o_ws; d->mel = d->d_w + o_mel;
+    d->win_fb = d->d_w + o_wfb; d->win_st = d->d_w + o_wst; d->win_syn = d->d_w + o_wsyn; d->wsum = d->d_w + o_ws; d->mel = d->d_w + o_mel;
+    d->tw2048 = reinterpret_cast<const float2*>(d->d_w + o_tw2048); d->tw1920 = reinterpret_cast<const float2*>(d->d_w + o_tw1920);
     d->lin1_w = d->d_w + o_l1w; d->lin1_b = d->d_w + o_l1b; d->lin2_w = d->d_w + o_l2w; d->lin2_b = d->d_w + o_l2b;
     for (int i = 0; i < depth; ++i) {
         d->uf_lin_w.push_back(d->d_w + o_h[4 * i]);
@@ -263,14 +282,14 @@ int DfsmnEngine::reserve(int calls, std::string& err) {
     d->ws = nullptr;
     d->capacity = 0;
     const size_t N = (size_t)batch * d->T;
-    const size_t sizes[7] = {(size_t)kAnRows * N, (size_t)kMel * N, (size_t)kHid * N, (size_t)kHid * N, (size_t)kHid * N, (size_t)kStBins * N,
+    const size_t sizes[8] = {(size_t)kFbBins * N, (size_t)2 * kStBins * N, (size_t)kMel * N, (size_t)kHid * N, (size_t)kHid * N, (size_t)kHid * N, (size_t)kStBins * N,
                              N * kNfftD};
     size_t total = 0;
     for (size_t s : sizes) total += (s + 63) & ~(size_t)63;
     DF_HIP(hipMalloc((void**)&d->ws, total * sizeof(float)));
-    float** ptrs[7] = {&d->an, &d->feat, &d->x, &d->f1, &d->p1, &d->mask, &d->frames_buf};
+    float** ptrs[8] = {&d->power, &d->spec, &d->feat, &d->x, &d->f1, &d->p1, &d->mask, &d->frames_buf};
     size_t off = 0;
-    for (int i = 0; i < 7; ++i) { *ptrs[i] = d->ws + off; off += (sizes[i] + 63) & ~(size_t)63; }
+    for (int i = 0; i < 8; ++i) { *ptrs[i] = d->ws + off; off += (sizes[i] + 63) & ~(size_t)63; }
     d->capacity = calls;
     return ADE_OK;
 }
@@ -283,10 +302,11 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
     batch *= n_win;
     using namespace gemm;
     const int N = batch * d->T;
-    // fused analysis convolution: [fbank re | fbank im | stft re | stft im] x frames                       (Export_DFSMN.py:205-209)
-    launch(s, RowMajorA{d->k_an, kFrame}, PcmFrameB{d_in, float_in, d->in_len_, d->T}, BiasActStore<kActNone>{d->an, N, nullptr, 0.0f}, kAnRows, N, kFrame);
+    // analysis: Kaldi filter-bank power and the mask STFT of every frame as FFTs                              (Export_DFSMN.py:205-209, 216)
+    hipLaunchKernelGGL(k_dfsmn_analysis, dim3((unsigned)N), dim3(256), 0, s, d_in, float_in, d->in_len_, d->T, d->p2048, d->p1920, d->tw2048, d->tw1920, d->win_fb, d->win_st,
+                       d->power, d->spec);
     // Kaldi log-mel: mel_banks x power, clamp(eps), log                                                  (:216-217)
-    launch(s, RowMajorA{d->mel, kFbBins}, PowerB{d->an, N}, BiasActStore<kActLogFloor>{d->feat, N, nullptr, 1.1920928955078125e-07f}, kMel, N, kFbBins);
+    launch(s, RowMajorA{d->mel, kFbBins}, PowerFrameB{d->power}, BiasActStore<kActLogFloor>{d->feat, N, nullptr, 1.1920928955078125e-07f}, kMel, N, kFbBins);
     // mask network                                                                                          (:224-230)
     launch(s, RowMajorA{d->lin1_w, kMel}, RowMajorB{d->feat, N}, BiasActStore<kActRelu>{d->x, N, d->lin1_b, 0.0f}, kHid, N, kMel);
     for (int i = 0; i < d->depth; ++i) {
@@ -296,10 +316,9 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
         hipLaunchKernelGGL(k_fsmn_memory, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->p1, d->uf_conv_w[i], d->x, N, d->T,
                            d->lorder, total);
     }
-    launch(s, RowMajorA{d->lin2_w, kHid}, RowMajorB{d->x, N}, BiasActStore<kActSigmoid>{d->mask, N, d->lin2_b, 0.0f}, kStBins, N, kHid);
+    launch(s, RowMajorA{d->lin2_w, kHid}, RowMajorB{d->x, N}, SigmoidTStore{d->mask, d->lin2_b}, kStBins, N, kHid);
     // masked spectrum -> ISTFT frames, then overlap-add + PCM tail                                        (:236-244)
-    launch(s, MaskedSpecA{d->an + (size_t)2 * kFbBins * N, d->mask, N}, RowMajorB{d->k_inv, kNfftD}, BiasActStore<kActNone>{d->frames_buf, kNfftD, nullptr, 0.0f},
-           N, kNfftD, 2 * kStBins);
+    hipLaunchKernelGGL(k_dfsmn_synthesis, dim3((unsigned)N), dim3(256), 0, s, (const float*)d->spec, (const float*)d->mask, d->p1920, d->tw1920, d->win_syn, d->frames_buf);
     const long long total = (long long)batch * d->out_len_;
     hipLaunchKernelGGL(k_dfsmn_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->frames_buf, d->wsum, d_out, d_f32, d->T,
                        d->out_len_, total);
@@ -313,7 +332,7 @@ int DfsmnEngine::tap(hipStream_t s, const char* name, int batch, float* out, siz
     const float* src = nullptr;
     size_t n = 0;
     if (strcmp(name, "logmel") == 0) { src = d->feat; n = kMel * N; }
-    else if (strcmp(name, "mask") == 0) { src = d->mask; n = kStBins * N; }
+    else if (strcmp(name, "mask") == 0) { src = d->mask; n = kStBins * N; }          // frame-major (frames, 961)
     else return dfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
     if (!src || batch <= 0) return dfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet");
     if (count < n) return dfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
