@@ -375,6 +375,13 @@ def main():
                     roofline["evidence"] = "profiles/" + cand
             except (OSError, ValueError):
                 pass
+        try:                # fabric-side bytes of one step from the committed FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic_workload.sh)
+            with open(os.path.join(REPO, "profiles", f"r02_{args.workload}_{args.dtype}_traffic.json")) as f:
+                tp = json.load(f)
+            roofline["traffic"] = int(tp["bytes_per_step"] * B / (wl["B"] if args.batch == 0 else B))
+            roofline["traffic_note"] = "bytes per step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over every kernel of a step, separate rocprofv3 --pmc passes; fabric-side incl. Infinity-Cache hits"
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and args.cpu_seconds > 0 and wl["cpu"] is not None:
             cpu = wl["cpu"]()
 

@@ -301,3 +301,42 @@ def test_gpu_zipenhancer_file_driver(model, tmp_path):
         assert sess.in_len == 48000
         want = np.concatenate([sess.run(None, {"noisy_audio": padded[i * 48000:(i + 1) * 48000].reshape(1, 1, -1)})[0].reshape(-1) for i in range(3)])[:len(audio)]
     assert np.array_equal(got, want) and np.abs(got).max() > 100
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_edges(model):
+    """Empty batch; the longest window the attention kernel holds in registers (320 frames); a plain length that is not whole hops (the STFT -> ISTFT pair
+    reconstructs hop * (T - 1) samples); geometry / tensor errors keep the reference's exception classes."""
+    from audio_denoiser_onnx_amd import _lib
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_chunk
+    from zipenhancer_oracle import ZipEnhancerOracle
+    _, cfg, sd, t = model
+    blob = pack_blob(t)
+    with InferenceSession(weights=blob, metadata=zp.metadata(16000)) as sess:
+        empty, _ = sess.process(np.zeros((0, 16000), np.int16))
+        assert empty.shape == (0, 16000)
+        with pytest.raises(ValueError):
+            sess.process(np.zeros((1, 15999), np.int16))
+    L = 31900                                                     # 320 frames: T = 320, dT = 160
+    with InferenceSession(weights=blob, metadata=zp.metadata(L)) as sess:
+        assert sess.frames == 320
+        x = synth_chunk(5, L)[None]
+        out, f32 = sess.process(x, want_f32=True)
+        spec = sess.tap("spec", 402 * 320).reshape(1, 402, 320)
+        ro, rw, _ = ZipEnhancerOracle(t, L).process(x, spectrum=(spec[:, :201], spec[:, 201:]))
+        assert np.abs(f32 - rw).max() <= 0.25 and np.abs(out.astype(np.int32) - ro.astype(np.int32)).max() <= 1
+    with pytest.raises(_lib.AdeUnsupportedError):
+        InferenceSession(weights=blob, metadata=zp.metadata(32000))                                  # 321 frames: fold longer audio into windows
+    meta = zp.metadata(16000) | {"input_audio_length": "16050", "export_audio_length": "16050", "model_audio_length": "16050", "output_audio_length": "16050"}
+    with InferenceSession(weights=blob, metadata=meta) as sess:
+        assert (sess.in_len, sess.out_len, sess.frames) == (16050, 16000, 161)
+        y, _ = sess.process(np.concatenate((synth_chunk(6, 16000), np.zeros(50, np.int16)))[None])
+        assert y.shape == (1, 16000) and np.abs(y).max() > 50
+    bad = dict(t)
+    bad.pop("enc2_t_conv1_dw_w")
+    with pytest.raises(KeyError):
+        InferenceSession(weights=pack_blob(bad), metadata=zp.metadata(16000))
+    other = zp.fuse_state_dict(zp.synthetic_state_dict(zp.ZipConfig(query_head_dim=8)), zp.ZipConfig(query_head_dim=8))
+    with pytest.raises(_lib.AdeUnsupportedError):
+        InferenceSession(weights=pack_blob(other), metadata=zp.metadata(16000))                      # the attention kernel is built for query_head_dim 16
