@@ -112,9 +112,14 @@ def test_gpu_exact_tables_match_exact_oracle(fixture):
         mk = session.tap("mask", 2050 * 2 * T).reshape(2050, 2, T).transpose(0, 2, 1)
     assert np.abs(sp - o.taps["spec"]).max() < 2e-3          # |spec| reaches ~225
     e = np.abs(mk - o.taps["mask_avg"])
-    assert np.median(e) < 5e-5 and e.max() < 2e-2, (np.median(e), e.max())
     err = np.abs(tokens - o.taps["tf_out"])
-    assert np.median(err) < 2e-5 and err.max() < 3e-2, (np.median(err), err.max())   # max: the near-silent top bands (values reach 19.6)
+    per_band = err.max(axis=(1, 2))
+    print("melband exact-table taps: mask median %.2e max %.2e; tokens median %.2e, max over bands 0-49 %.2e, max over bands 50-59 %.2e"
+          % (np.median(e), e.max(), np.median(err), per_band[:50].max(), per_band[50:].max()))
+    assert np.median(e) < 3e-5 and e.max() < 8e-3, (np.median(e), e.max())          # observed 7.9e-6 / 2.7e-3
+    # gated per band: the bands that carry signal to fp32 round-off; the near-silent top bands (15 - 22 kHz, L2-normalised before their Linear, values reach 19.6) wider
+    assert np.median(err) < 2e-5 and per_band[:50].max() < 1e-3 and per_band[50:].max() < 2.5e-2,      # observed 3.9e-6 / 3.1e-4 / 8.1e-3
+         (np.median(err), per_band[:50].max(), per_band[50:].max())
     d = got.astype(np.int32) - want.astype(np.int32)
     assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.10
 

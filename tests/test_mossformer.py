@@ -98,8 +98,10 @@ def test_gpu_matches_reference_fixture(fixture):
         mdl_in = sess.tap("mdl_in", sess.frames * 512).reshape(sess.frames, 512).T
         mdl_out = sess.tap("mdl_out", sess.frames * 512).reshape(sess.frames, 512).T
     assert len(outs) == 2 and outs[0].shape == (1, 1, W) and outs[0].dtype == np.int16
-    assert np.abs(mdl_in[:, ::7] - z["mdl_in"]).max() < 1e-3
-    assert np.abs(mdl_out[:, ::7] - z["mdl_out"]).max() < 5e-3
+    print("mossformer taps vs the reference: mdl_in %.2e, mdl_out %.2e (|mdl_out| max %.1f)"
+          % (np.abs(mdl_in[:, ::7] - z["mdl_in"]).max(), np.abs(mdl_out[:, ::7] - z["mdl_out"]).max(), np.abs(z["mdl_out"]).max()))
+    assert np.abs(mdl_in[:, ::7] - z["mdl_in"]).max() < 3e-4          # observed 5.9e-5
+    assert np.abs(mdl_out[:, ::7] - z["mdl_out"]).max() < 3e-4         # observed 6.2e-5 on values up to 11.9
     for spk in range(2):
         d = outs[spk][0, 0].astype(np.int32) - z["pcm_out"][spk].astype(np.int32)
         assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (spk, np.abs(d).max(), (d != 0).mean())
