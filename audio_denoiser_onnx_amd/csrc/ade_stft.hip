@@ -1,4 +1,9 @@
-// ade_stft.hip — generic STFT_Process operator on the MI355X matrix cores.
+// ade_stft.hip — generic STFT_Process operator.
+//
+// Two formulations of the same transform.  When n_fft factors into 2, 3 and 5 (every starred model: 512, 400, 2048, 1920) the frames go through the
+// mixed-radix LDS FFT of csrc/ade_fft.h: two real frames per complex transform, one to eight frame pairs per workgroup (k_stft_fft_analyze /
+// k_stft_fft_synth) -- 2048-point analysis is ~0.1 MFLOP per frame pair against 8.4 MFLOP per frame as the dense product.  Any other size keeps the
+// reference's own formulation, below, on the matrix cores.
 //
 // The reference implements STFT / ISTFT for every model as a dense windowed-DFT convolution (STFT_Process.py:213-251,
 // 303-336 in each model folder): a (2F, 1, n_fft) Conv1d kernel [cos*w ; -sin*w] with stride = hop, and the transposed
@@ -13,6 +18,7 @@
 // The GEMM itself is csrc/ade_gemm.h (128 x 128 workgroup tiles, functor operands).
 // Tables use exact angles (reduced f*n mod N, evaluated in double); the reference evaluates cos/sin of fp32 angles up
 // to 2*pi*N/2, which costs it up to 1e-4 relative -- the parity tests price that difference explicitly.
+#include "ade_fft.h"
 #include "ade_gemm.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
@@ -97,6 +103,94 @@ __global__ __launch_bounds__(256) void k_stft_ola(const float* __restrict__ fram
     y[i] = s / w;
 }
 
+
+// ---- FFT formulation ----
+// Frame pairs: z[n] = w[n] (x_t[n] + i x_{t+1}[n]); Z = FFT(z); X_t[f] = (Z[f] + conj Z[N - f]) / 2, X_{t+1}[f] = (Z[f] - conj Z[N - f]) / (2 i).
+// A workgroup of 256 threads holds G pairs of one batch row (256 / G threads each, every group running the same passes so the barriers line up).
+__device__ __forceinline__ float padded_sample(const float* __restrict__ row, const StftDims& d, int L, int at) {
+    int idx = at - d.pad;
+    if (idx < 0) { if (!d.reflect) return 0.0f; idx = -idx; }
+    else if (idx >= L) { if (!d.reflect) return 0.0f; idx = 2 * (L - 1) - idx; }
+    return row[idx];
+}
+
+__global__ __launch_bounds__(256) void k_stft_fft_analyze(const float* __restrict__ x, const float* __restrict__ win, fft::Plan plan, const float2* __restrict__ tw, StftDims d,
+                                                          int L, int T, int G, float* __restrict__ spec) {
+    HIP_DYNAMIC_SHARED(float2, lds)
+    const int N = d.n_fft, F = d.F2 / 2, per = 256 / G, g = threadIdx.x / per, lt = threadIdx.x - g * per;
+    const int ppr = (T + 1) / 2, bpr = (ppr + G - 1) / G;
+    const int b = blockIdx.x / bpr, pair = (blockIdx.x - b * bpr) * G + g, t0 = 2 * pair;
+    const bool live = pair < ppr, two = t0 + 1 < T;
+    float2 *A = lds + (size_t)g * 2 * N, *B = A + N;
+    const float* row = x + (size_t)b * L;
+    for (int n = lt; n < N; n += per) {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (live) {
+            const float w = win[n];
+            v.x = padded_sample(row, d, L, t0 * d.hop + n) * w;
+            if (two) v.y = padded_sample(row, d, L, (t0 + 1) * d.hop + n) * w;
+        }
+        A[n] = v;
+    }
+    const float2* r = fft::forward(A, B, plan, tw, lt, per);
+    if (!live) return;
+    float* re = spec + (size_t)b * d.F2 * T + t0;
+    float* im = re + (size_t)F * T;
+    for (int f = lt; f < F; f += per) {
+        const float2 z = r[f], zc = r[f == 0 ? 0 : N - f];
+        re[(size_t)f * T] = 0.5f * (z.x + zc.x);
+        im[(size_t)f * T] = 0.5f * (z.y - zc.y);
+        if (two) {
+            re[(size_t)f * T + 1] = 0.5f * (z.y + zc.y);
+            im[(size_t)f * T + 1] = 0.5f * (zc.x - z.x);
+        }
+    }
+}
+
+// Synthesis: W = H(Z_t) + i H(Z_{t+1}) with H the Hermitian extension of a half spectrum (the imaginary parts of the DC and Nyquist bins do not
+// contribute: their sine rows are zero in the reference's inverse table); x_t + i x_{t+1} = conj(FFT(conj W)) / N; frames = x * synthesis window.
+template <bool POLAR>
+__global__ __launch_bounds__(256) void k_stft_fft_synth(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ win, fft::Plan plan,
+                                                        const float2* __restrict__ tw, StftDims d, int T, int G, float* __restrict__ frames) {
+    HIP_DYNAMIC_SHARED(float2, lds)
+    const int N = d.n_fft, F = d.F2 / 2, per = 256 / G, g = threadIdx.x / per, lt = threadIdx.x - g * per;
+    const int ppr = (T + 1) / 2, bpr = (ppr + G - 1) / G;
+    const int b = blockIdx.x / bpr, pair = (blockIdx.x - b * bpr) * G + g, t0 = 2 * pair;
+    const bool live = pair < ppr, two = t0 + 1 < T;
+    float2 *A = lds + (size_t)g * 2 * N, *B = A + N;
+    auto bin = [&](int f, int t) -> float2 {
+        float2 v;
+        if (POLAR) {                                  // istft_A: real = mag cos(phase), imag = mag sin(phase)   (STFT_Process.py:343-347)
+            const size_t at = ((size_t)b * F + f) * T + t;
+            const float m = p0[at], ph = p1[at];
+            v = make_float2(m * cosf(ph), m * sinf(ph));
+        } else {
+            v = make_float2(p0[((size_t)b * d.F2 + f) * T + t], p0[((size_t)b * d.F2 + F + f) * T + t]);
+        }
+        if (f == 0 || (N % 2 == 0 && f == F - 1)) v.y = 0.0f;
+        return v;
+    };
+    for (int f = lt; f < F; f += per) {
+        float2 z0 = make_float2(0.0f, 0.0f), z1 = z0;
+        if (live) {
+            z0 = bin(f, t0);
+            if (two) z1 = bin(f, t0 + 1);
+        }
+        // W[f] = z0 + i z1 = (z0.x - z1.y, z0.y + z1.x); W[N - f] = conj z0 + i conj z1 = (z0.x + z1.y, z1.x - z0.y); both stored conjugated
+        A[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
+        if (f > 0 && f < N - f) A[N - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
+    }
+    const float2* r = fft::forward(A, B, plan, tw, lt, per);
+    if (!live) return;
+    const float inv = 1.0f / (float)N;
+    float* out = frames + ((size_t)b * T + t0) * N;
+    for (int n = lt; n < N; n += per) {
+        const float w = win[n];
+        out[n] = (r[n].x * inv) * w;
+        if (two) out[N + n] = (-r[n].y * inv) * w;
+    }
+}
+
 // torch.{hann,hamming}_window in fp32 (STFT_Process.py:88-113 registries), centre pad / crop to n_fft
 bool make_window(const std::string& name_in, int win_length, int n_fft, std::vector<float>& w, std::string& err) {
     std::string name = name_in;
@@ -133,7 +227,12 @@ struct ade_stft_plan {
     int device = 0;
     ade::StftDims d{};
     int center = 1;
-    float *d_fwd = nullptr, *d_inv = nullptr, *d_wsq = nullptr, *d_frames = nullptr;
+    float *d_fwd = nullptr, *d_inv = nullptr, *d_wsq = nullptr, *d_frames = nullptr;      // dense tables: only when n_fft has a prime factor above 5
+    bool use_fft = false;
+    ade::fft::Plan fft_plan{};
+    float2* d_tw = nullptr;                       // exp(-2 pi i m / n_fft), m < n_fft
+    float *d_wa = nullptr, *d_ws = nullptr;       // analysis / synthesis windows
+    int pairs_per_group = 1;                      // frame pairs per workgroup
     size_t frames_cap = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -178,8 +277,41 @@ ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_hand
     const int N = cfg->n_fft, F = N / 2 + 1;
     p->d = ade::StftDims{N, cfg->hop, 2 * F, cfg->center_pad ? N / 2 : 0, pad == "reflect" ? 1 : 0};
     p->center = cfg->center_pad ? 1 : 0;
-    // tables (STFT_Process.py:213-251), exact angles
-    std::vector<float> fwd((size_t)2 * F * N), inv((size_t)2 * F * N), wsq((size_t)N);
+    std::vector<float> wsq((size_t)N);
+    for (int n = 0; n < N; ++n) wsq[n] = ws[n] * ws[n];
+    auto bail = [&](ade_status st) { g_stft_create_error = p->last_error; ade_stft_destroy(p); return st; };
+    if (hipSetDevice(device) != hipSuccess) return bail(sfail(p, ADE_ERR_DEVICE, "hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return bail(sfail(p, ADE_ERR_DEVICE, "hipStreamCreate failed"));
+    if (hipMalloc((void**)&p->d_wsq, wsq.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(p->d_wsq, wsq.data(), wsq.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(sfail(p, ADE_ERR_DEVICE, "upload of the window table failed"));
+    p->use_fft = ade::fft::make_plan(N, &p->fft_plan);
+    if (p->use_fft) {
+        // twiddles with exact angles (the same values the dense tables below hold); 16 N bytes of LDS per frame pair
+        std::vector<float2> tw((size_t)N);
+        for (int m = 0; m < N; ++m) {
+            const double a = 2.0 * M_PI * (double)m / (double)N;
+            tw[m] = make_float2((float)cos(a), (float)-sin(a));
+        }
+        p->pairs_per_group = 1;
+        while (p->pairs_per_group < 8 && (size_t)(2 * p->pairs_per_group) * N <= 4096) p->pairs_per_group *= 2;
+        const int lds_max = 16 * 8192;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ade::k_stft_fft_analyze), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ade::k_stft_fft_synth<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(ade::k_stft_fft_synth<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
+            return bail(sfail(p, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the FFT kernels"));
+        if (hipMalloc((void**)&p->d_tw, tw.size() * sizeof(float2)) != hipSuccess || hipMalloc((void**)&p->d_wa, (size_t)N * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&p->d_ws, (size_t)N * sizeof(float)) != hipSuccess)
+            return bail(sfail(p, ADE_ERR_DEVICE, "hipMalloc of the FFT tables failed"));
+        if (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_wa, wa.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->d_ws, ws.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(sfail(p, ADE_ERR_DEVICE, "upload of the FFT tables failed"));
+        *out = p;
+        return ADE_OK;
+    }
+    // dense tables (STFT_Process.py:213-251), exact angles
+    std::vector<float> fwd((size_t)2 * F * N), inv((size_t)2 * F * N);
     for (int f = 0; f < F; ++f) {
         const double scale = (f == 0 || (N % 2 == 0 && f == F - 1)) ? 1.0 : 2.0;
         for (int n = 0; n < N; ++n) {
@@ -191,17 +323,11 @@ ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_hand
             inv[(size_t)(F + f) * N + n] = (((float)scale * -s) * (float)(1.0 / N)) * ws[n];
         }
     }
-    for (int n = 0; n < N; ++n) wsq[n] = ws[n] * ws[n];
-    auto bail = [&](ade_status st) { g_stft_create_error = p->last_error; ade_stft_destroy(p); return st; };
-    if (hipSetDevice(device) != hipSuccess) return bail(sfail(p, ADE_ERR_DEVICE, "hipSetDevice failed"));
-    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return bail(sfail(p, ADE_ERR_DEVICE, "hipStreamCreate failed"));
     const size_t tb = fwd.size() * sizeof(float);
-    if (hipMalloc((void**)&p->d_fwd, tb) != hipSuccess || hipMalloc((void**)&p->d_inv, tb) != hipSuccess ||
-        hipMalloc((void**)&p->d_wsq, wsq.size() * sizeof(float)) != hipSuccess)
+    if (hipMalloc((void**)&p->d_fwd, tb) != hipSuccess || hipMalloc((void**)&p->d_inv, tb) != hipSuccess)
         return bail(sfail(p, ADE_ERR_DEVICE, "hipMalloc of the DFT tables failed"));
     if (hipMemcpy(p->d_fwd, fwd.data(), tb, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p->d_inv, inv.data(), tb, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p->d_wsq, wsq.data(), wsq.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpy(p->d_inv, inv.data(), tb, hipMemcpyHostToDevice) != hipSuccess)
         return bail(sfail(p, ADE_ERR_DEVICE, "upload of the DFT tables failed"));
     *out = p;
     return ADE_OK;
@@ -231,8 +357,14 @@ ade_status ade_stft_analyze(ade_stft_handle p, const float* d_x, int batch, int 
     if (st != ADE_OK) return st;
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
-    ade::gemm::launch(s, ade::gemm::RowMajorA{p->d_fwd, p->d.n_fft}, ade::FrameB{d_x, p->d, length, T}, ade::SpecStore{d_spec, p->d.F2, T},
-                      p->d.F2, batch * T, p->d.n_fft);
+    if (p->use_fft) {
+        const int G = p->pairs_per_group, groups = ((T + 1) / 2 + G - 1) / G;
+        hipLaunchKernelGGL(ade::k_stft_fft_analyze, dim3((unsigned)(batch * groups)), dim3(256), (size_t)G * 2 * p->d.n_fft * sizeof(float2), s, d_x, (const float*)p->d_wa,
+                           p->fft_plan, (const float2*)p->d_tw, p->d, length, T, G, d_spec);
+    } else {
+        ade::gemm::launch(s, ade::gemm::RowMajorA{p->d_fwd, p->d.n_fft}, ade::FrameB{d_x, p->d, length, T}, ade::SpecStore{d_spec, p->d.F2, T},
+                          p->d.F2, batch * T, p->d.n_fft);
+    }
     STFT_HIP(p, hipGetLastError());
     if (!hip_stream) STFT_HIP(p, hipStreamSynchronize(s));
     return ADE_OK;
@@ -241,8 +373,8 @@ ade_status ade_stft_analyze(ade_stft_handle p, const float* d_x, int batch, int 
 }  // extern "C"
 
 namespace {
-template <class ALoader>
-ade_status synthesize_from(ade_stft_handle p, ALoader a, int batch, int frames, float* d_y, void* hip_stream) {
+template <bool POLAR, class ALoader>
+ade_status synthesize_from(ade_stft_handle p, ALoader a, const float* p0, const float* p1, int batch, int frames, float* d_y, void* hip_stream) {
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
     const size_t need = (size_t)batch * frames * p->d.n_fft;
@@ -254,8 +386,14 @@ ade_status synthesize_from(ade_stft_handle p, ALoader a, int batch, int frames, 
         STFT_HIP(p, hipMalloc((void**)&p->d_frames, need * sizeof(float)));
         p->frames_cap = need;
     }
-    ade::gemm::launch(s, a, ade::gemm::RowMajorB{p->d_inv, p->d.n_fft}, ade::gemm::BiasActStore<ade::gemm::kActNone>{p->d_frames, p->d.n_fft, nullptr, 0.0f},
-                      batch * frames, p->d.n_fft, p->d.F2);
+    if (p->use_fft) {
+        const int G = p->pairs_per_group, groups = ((frames + 1) / 2 + G - 1) / G;
+        hipLaunchKernelGGL(ade::k_stft_fft_synth<POLAR>, dim3((unsigned)(batch * groups)), dim3(256), (size_t)G * 2 * p->d.n_fft * sizeof(float2), s, p0, p1,
+                           (const float*)p->d_ws, p->fft_plan, (const float2*)p->d_tw, p->d, frames, G, p->d_frames);
+    } else {
+        ade::gemm::launch(s, a, ade::gemm::RowMajorB{p->d_inv, p->d.n_fft}, ade::gemm::BiasActStore<ade::gemm::kActNone>{p->d_frames, p->d.n_fft, nullptr, 0.0f},
+                          batch * frames, p->d.n_fft, p->d.F2);
+    }
     int out_len = 0;
     (void)ade_stft_output_length(p, frames, &out_len);
     const long long total = (long long)batch * out_len;
@@ -272,13 +410,13 @@ extern "C" {
 ade_status ade_stft_synthesize(ade_stft_handle p, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream) {
     if (!p || batch < 0 || frames < 1 || (batch > 0 && (!d_spec || !d_y))) return sfail(p, ADE_ERR_BAD_VALUE, "ade_stft_synthesize: bad arguments");
     if (batch == 0) return ADE_OK;
-    return synthesize_from(p, ade::SpecA{d_spec, p->d.F2, frames}, batch, frames, d_y, hip_stream);
+    return synthesize_from<false>(p, ade::SpecA{d_spec, p->d.F2, frames}, d_spec, nullptr, batch, frames, d_y, hip_stream);
 }
 
 ade_status ade_stft_synthesize_polar(ade_stft_handle p, const float* d_mag, const float* d_phase, int batch, int frames, float* d_y, void* hip_stream) {
     if (!p || batch < 0 || frames < 1 || (batch > 0 && (!d_mag || !d_phase || !d_y))) return sfail(p, ADE_ERR_BAD_VALUE, "ade_stft_synthesize_polar: bad arguments");
     if (batch == 0) return ADE_OK;
-    return synthesize_from(p, ade::PolarSpecA{d_mag, d_phase, p->d.F2 / 2, frames}, batch, frames, d_y, hip_stream);
+    return synthesize_from<true>(p, ade::PolarSpecA{d_mag, d_phase, p->d.F2 / 2, frames}, d_mag, d_phase, batch, frames, d_y, hip_stream);
 }
 
 const char* ade_stft_last_error(ade_stft_handle p) { return p ? p->last_error.c_str() : g_stft_create_error.c_str(); }
@@ -290,6 +428,9 @@ void ade_stft_destroy(ade_stft_handle p) {
     if (p->d_inv) (void)hipFree(p->d_inv);
     if (p->d_wsq) (void)hipFree(p->d_wsq);
     if (p->d_frames) (void)hipFree(p->d_frames);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_wa) (void)hipFree(p->d_wa);
+    if (p->d_ws) (void)hipFree(p->d_ws);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }

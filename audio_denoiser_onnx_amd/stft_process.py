@@ -3,8 +3,9 @@
 The reference builds one ``STFT_Process(model_type, n_fft, win_length, hop_len, max_frames, window_type, center_pad,
 pad_mode, static_norm=...)`` per direction (GTCRN/STFT_Process.py:129-341; e.g. GTCRN/Export_GTCRN.py:719-741,
 ZipEnhancer/Export_ZipEnhancer.py:947-948, DFSMN/Export_DFSMN.py:273-274) and calls it with ``(B, 1, L)`` audio or
-``(B, 2F, T)`` packed spectra.  This class keeps those constructor arguments and call shapes; the compute is the dense
-windowed DFT as fp32 MFMA GEMMs in ``csrc/ade_stft.hip`` — device tensors in, device tensors out, no CPU path.
+``(B, 2F, T)`` packed spectra.  This class keeps those constructor arguments and call shapes; the compute is
+``csrc/ade_stft.hip`` (an LDS FFT when n_fft is 5-smooth, as in every starred folder; the dense windowed DFT as fp32 MFMA
+GEMMs otherwise) — device tensors in, device tensors out, no CPU path.
 
 Window names: every model folder carries its own registry; the periodic / symmetric choice is explicit here
 (``"hann"``, ``"hann_sqrt"``, ``"hamming"`` = torch ``periodic=True``; suffix ``"_sym"`` = ``periodic=False``;

@@ -60,6 +60,47 @@ def test_hipsim_generic_stft_small():
     assert b"kaiser" in lib.c.ade_stft_last_error(None)
 
 
+@pytest.mark.hipsim
+@pytest.mark.parametrize("n_fft,hop,length,center", [(60, 15, 333, True),      # 4 * 3 * 5: FFT path, odd frame count (last pair half empty)
+                                                      (45, 9, 200, True),       # odd n_fft (no Nyquist bin), radices 3 and 5 only
+                                                      (64, 32, 256, False),     # no centre padding
+                                                      (44, 11, 180, True)])     # 4 * 11: not 5-smooth -> the dense-table MFMA path
+def test_hipsim_generic_stft_fft_and_dense_paths(n_fft, hop, length, center):
+    """Both formulations of the operator (LDS FFT for 5-smooth sizes, dense tables otherwise) against the oracle with exact tables, including the polar entry."""
+    lib = hipsim_library()
+    rng = np.random.default_rng(n_fft)
+    x = rng.standard_normal((3, length)).astype(np.float32)
+    cfg = _lib.StftConfig(n_fft, n_fft, hop, b"hamming", None, int(center), b"reflect")
+    h = C.c_void_p()
+    assert lib.c.ade_stft_create(C.byref(cfg), 0, C.byref(h)) == 0
+    oracle_set_generic_exact_dft(True)
+    try:
+        t = C.c_int()
+        assert lib.c.ade_stft_frames(h, length, C.byref(t)) == 0
+        ref = oracle_stft(x, n_fft, n_fft, hop, "hamming", center, "reflect")
+        assert ref.shape[2] == t.value
+        spec = np.empty_like(ref)
+        assert lib.c.ade_stft_analyze(h, x.ctypes.data, 3, length, spec.ctypes.data, None) == 0
+        assert np.abs(spec - ref).max() <= 2e-6 * np.abs(ref).max()
+        n = C.c_int()
+        assert lib.c.ade_stft_output_length(h, t.value, C.byref(n)) == 0
+        want = oracle_istft(ref, n_fft, n_fft, hop, "hamming", center)
+        assert want.shape[1] == n.value
+        y = np.empty_like(want)
+        assert lib.c.ade_stft_synthesize(h, ref.ctypes.data, 3, t.value, y.ctypes.data, None) == 0
+        tol = 3e-6 if center else 5e-5                  # without centre padding the first / last hop divides by a tiny sum(w^2)
+        assert np.abs(y - want).max() <= tol
+        F = n_fft // 2 + 1
+        mag = np.ascontiguousarray(np.hypot(ref[:, :F], ref[:, F:]))
+        ph = np.ascontiguousarray(np.arctan2(ref[:, F:], ref[:, :F]))
+        y2 = np.empty_like(want)
+        assert lib.c.ade_stft_synthesize_polar(h, mag.ctypes.data, ph.ctypes.data, 3, t.value, y2.ctypes.data, None) == 0
+        assert np.abs(y2 - want).max() <= 4 * tol
+    finally:
+        oracle_set_generic_exact_dft(False)
+        lib.c.ade_stft_destroy(h)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_gpu_stft_process_configs(name):
