@@ -327,73 +327,98 @@ __global__ __launch_bounds__(256) void k_shift_invnorm(const float* __restrict__
     if (lane == 0) inv[m] = 1.0f / fmaxf(sqrtf(s), eps);
 }
 
-// Depthwise convolution over time through an LDS tile (:460, :504-505, :516 with TAPS = 17; the dilated dense memory
-// convolutions :521-527 with TAPS = 39, CIN = j + 1 input channels per group).  grid = (time tiles of TT frames, channels / 64,
-// windows); the block stages rows t0 - pad .. t0 + TT - 1 + (TAPS - 1) dil - pad of its 64 * CIN input channels once (frames
-// outside the window read as zero) and every thread produces TT / 4 consecutive frames of one channel from LDS: HBM / L2 sees each
-// input about (1 + (TAPS - 1) dil / TT) times instead of TAPS times.
+// Depthwise / grouped convolution over time, register form (:460, :504-505, :516 with TAPS = 17; the dilated dense memory convolutions :521-527 with
+// TAPS = 39, CIN = j + 1 input channels per group).
 //   out = (res ? res : 0) + (CENTER ? x : 0) + sum_{c < CIN} sum_k w[g][c][k] * in[g * CIN + c][t + k dil - pad]
 // The input channels of group g are g * CIN + c of the concatenation [src0 (split channels) | src1] (:534-535).
-// With `partial` set, the block also writes (count, mean, M2) of its outputs per channel for the instance norm that follows
-// (:528-531); k_chan_finalize merges the tiles in a fixed order (Chan's update), so the statistics are deterministic.
-template <int TAPS, int CIN, int TT, bool CENTER>
+// A lane owns one output channel (64 consecutive channels per wavefront: 256-byte rows) and one run of `kTconvRun` outputs of one dilation phase
+// (t = phase + dil (j0 + i)); it streams the run's input rows from global memory once and keeps TAPS output accumulators in a register ring
+// (acc[(row - k) mod TAPS] += w[k] x[row]; after its last tap an accumulator is stored and recycled), so the unrolled body has static register
+// indices, no LDS and no barrier, and HBM / L2 sees each input (1 + (TAPS - 1) / run) times instead of TAPS times.  grid = (channels / 64,
+// ceil(runs dil / 4), windows).
+// With `partial` set every lane also writes (count, mean, M2) of its run for the instance norm that follows (:528-531); k_chan_finalize merges the runs
+// in a fixed order (Chan's update), so the statistics are deterministic and independent of the batch size.
+constexpr int kTconvRun = 128;
+struct TconvRun {              // per-lane state of one run
+    float* y;
+    size_t base;
+    int ldy, n, dil, pad, phase, j0, count, total, c;
+    float shift, s1, s2;
+};
+// rows row0 + U .. row0 + TAPS - 1 of the ring (compile-time recursion instead of a 39 x 39 unrolled loop nest: every accumulator index is a constant);
+// xs / rs are the rows' inputs and residuals, loaded beforehand in one batch so that TAPS * CIN loads are in flight per lane
+template <int TAPS, int CIN, int U>
+__device__ __forceinline__ void tconv_rows(float (&acc)[TAPS], const float (&wreg)[CIN][TAPS], const float (&xs)[TAPS][CIN], const float (&rs)[TAPS], TconvRun& q, int row0) {
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k)
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) acc[(U - k + TAPS) % TAPS] += wreg[i][k] * xs[U][i];
+    const int done = row0 + U - (TAPS - 1);                                  // this output has now seen all its taps
+    if (done >= 0 && done < q.count) {
+        const float v = acc[(U + 1) % TAPS];
+        q.y[(q.base + q.phase + (size_t)q.dil * (q.j0 + done)) * q.ldy + q.c] = rs[U] + v;
+        if (done == 0) q.shift = v;
+        const float d = v - q.shift;
+        q.s1 += d;
+        q.s2 += d * d;
+    }
+    acc[(U + 1) % TAPS] = 0.0f;
+    if constexpr (U + 1 < TAPS) tconv_rows<TAPS, CIN, U + 1>(acc, wreg, xs, rs, q, row0);
+}
+
+template <int TAPS, int CIN, bool CENTER, bool RES>
 __global__ __launch_bounds__(256) void k_tconv(const float* __restrict__ src0, const float* __restrict__ src1, int ld0, int ld1, int split,
                                                const float* __restrict__ w, const float* __restrict__ res, float* __restrict__ y, int ldy, int n, int dil,
-                                               int pad, float4* __restrict__ partial) {
-    HIP_DYNAMIC_SHARED(float, tile)
-    __shared__ float red[2][4][64];
-    constexpr int kCols = 64 * CIN, kPer = TT / 4;
-    const int t0 = (int)blockIdx.x * TT, g0 = (int)blockIdx.y * 64, b = blockIdx.z, tid = threadIdx.x;
-    const int rows = TT + (TAPS - 1) * dil;
-    const size_t base = (size_t)b * n;
-    for (int idx = tid; idx < rows * kCols; idx += 256) {
-        const int r = idx / kCols, cc = idx - r * kCols, t = t0 - pad + r, ch = g0 * CIN + cc;
-        float v = 0.0f;
-        if (t >= 0 && t < n) v = ch < split ? src0[(base + t) * ld0 + ch] : src1[(base + t) * ld1 + (ch - split)];
-        tile[idx] = v;
+                                               int pad, int runs, float4* __restrict__ partial) {
+    const int c = (int)blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.z, C = (int)gridDim.x * 64;
+    const int slot = (int)blockIdx.y * 4 + (threadIdx.x >> 6), tiles = runs * dil;
+    if (slot >= tiles) return;
+    const int r = slot / dil, phase = slot - r * dil, j0 = r * kTconvRun;
+    const int nsub = phase < n ? (n - phase + dil - 1) / dil : 0;           // outputs of this dilation phase
+    const int count = nsub - j0 < kTconvRun ? nsub - j0 : kTconvRun;
+    if (count <= 0) {
+        if (partial) partial[((size_t)b * tiles + slot) * C + c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
     }
-    const int cl = tid & 63, tl = tid >> 6;
-    float wreg[TAPS * CIN];
+    float wreg[CIN][TAPS];
 #pragma unroll
-    for (int i = 0; i < TAPS * CIN; ++i) wreg[i] = w[(size_t)(g0 + cl) * CIN * TAPS + i];
-    __syncthreads();
-    float outv[kPer];
-    float sum = 0.0f;
-    int cnt = 0;
+    for (int i = 0; i < CIN; ++i)
 #pragma unroll
-    for (int o = 0; o < kPer; ++o) {
-        const int tt = tl * kPer + o, t = t0 + tt;
-        float acc = 0.0f;
+        for (int k = 0; k < TAPS; ++k) wreg[i][k] = w[((size_t)c * CIN + i) * TAPS + k];
+    // the wavefront's 64 * CIN input channels lie in one source (split is a multiple of 64 * CIN): uniform row pointers + one lane offset
+    const int ch0 = (int)blockIdx.x * 64 * CIN, lane_off = (threadIdx.x & 63) * CIN;
+    const float* in = ch0 < split ? src0 + ch0 : src1 + (ch0 - split);
+    const int ld = ch0 < split ? ld0 : ld1;
+    if (CENTER) wreg[0][(TAPS - 1) / 2] += 1.0f;                             // + x[t]: the centre tap (dil = 1, pad = (TAPS - 1) / 2)
+    float acc[TAPS];
 #pragma unroll
-        for (int c = 0; c < CIN; ++c)
+    for (int k = 0; k < TAPS; ++k) acc[k] = 0.0f;
+    TconvRun q{y, (size_t)b * n, ldy, n, dil, pad, phase, j0, count, count + TAPS - 1, c, 0.0f, 0.0f, 0.0f};
+    for (int row0 = 0; row0 < q.total; row0 += TAPS) {
+        float xs[TAPS][CIN], rs[TAPS];
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) acc += wreg[c * TAPS + k] * tile[(tt + k * dil) * kCols + cl * CIN + c];
-        if (CENTER) acc += tile[(tt + pad) * kCols + cl];
-        outv[o] = acc;
-        if (t < n) {
-            const size_t at = (base + t) * ldy + g0 + cl;
-            y[at] = res ? res[at] + acc : acc;
-            sum += acc;
-            ++cnt;
+        for (int u = 0; u < TAPS; ++u) {                                     // unconditional loads from clamped addresses (no branches between them), masked afterwards
+            const int row = row0 + u, t_in = phase - pad + dil * (j0 + row);
+            const bool ok = row < q.total && t_in >= 0 && t_in < n;
+            const float* rowp = in + (q.base + (size_t)(ok ? t_in : 0)) * ld;
+#pragma unroll
+            for (int i = 0; i < CIN; ++i) {
+                const float v = rowp[lane_off + i];
+                xs[u][i] = ok ? v : 0.0f;
+            }
+            if (RES) {
+                const int done = row - (TAPS - 1);
+                const int dc = done < 0 ? 0 : (done < count ? done : count - 1);
+                rs[u] = (res + (q.base + phase + (size_t)dil * (j0 + dc)) * ldy)[c];
+            } else {
+                rs[u] = 0.0f;
+            }
         }
+        tconv_rows<TAPS, CIN, 0>(acc, wreg, xs, rs, q, row0);
     }
-    if (!partial) return;
-    red[0][tl][cl] = sum;
-    red[1][tl][cl] = (float)cnt;
-    __syncthreads();
-    const float total = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    const float count = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-    const float mean = total / fmaxf(count, 1.0f);
-    float m2 = 0.0f;
-#pragma unroll
-    for (int o = 0; o < kPer; ++o)
-        if (t0 + tl * kPer + o < n) { const float d = outv[o] - mean; m2 += d * d; }
-    __syncthreads();
-    red[0][tl][cl] = m2;
-    __syncthreads();
-    if (tl == 0) {
-        const float M2 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        partial[((size_t)b * gridDim.x + blockIdx.x) * (gridDim.y * 64) + g0 + cl] = make_float4(count, mean, M2, 0.0f);
+    if (partial) {                                                           // shifted sums: mean = shift + s1 / count, M2 = s2 - s1^2 / count
+        const float cn = (float)count, m = q.s1 / cn;
+        partial[((size_t)b * tiles + slot) * C + c] = make_float4(cn, q.shift + m, fmaxf(q.s2 - q.s1 * m, 0.0f), 0.0f);
     }
 }
 
@@ -741,7 +766,7 @@ int MossformerEngine::reserve(int batch, std::string& err) {
     const size_t B = (size_t)batch * n_win, R = B * n, RP = B * padded, g = (size_t)hyper[hGroup];
     struct Carve { float** p; size_t count; };
     float *f_gains = nullptr, *f_wstats = nullptr, *f_cstats = nullptr, *f_partial = nullptr, *f_wpart = nullptr;
-    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&f_partial, 4 * B * (size_t)((n + 31) / 32) * kInner}, {&f_wpart, 4 * B * kWsSlices}, {&lkv_part, (size_t)kLkvSplits * B * kQk * kVu2}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
+    std::vector<Carve> cs = {{&f_gains, 2 * B}, {&f_wstats, 2 * B}, {&f_cstats, 2 * B * kInner}, {&f_partial, 4 * B * (size_t)((n + 31) / 32 + 2) * kInner}, {&f_wpart, 4 * B * kWsSlices}, {&lkv_part, (size_t)kLkvSplits * B * kQk * kVu2}, {&rms_in, B}, {&XE, R * kDim}, {&MI, R * kDim}, {&H, R * kDim},
                              {&inv, R}, {&P, R * kIn}, {&P2, R * kIn}, {&heads, 4 * RP * kQk}, {&ATT, B * groups * g * g}, {&AO, R * kVu2},
                              {&LKV, B * kQk * kVu2}, {&G, R * kVu}, {&Y, R * kDim}, {&C1, R * kInner}, {&GF, R * kInner}, {&XN, R * kInner}, {&UV, R * kDim},
                              {&UV2, R * kDim}, {&F1, R * kInner}, {&XP, R * kInner}, {&M0, R * kInner}, {&M1, R * kInner}, {&N2, R * kInner}, {&HL, R * kDim},
@@ -775,9 +800,12 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
         hipLaunchKernelGGL(k_window_stats_final, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st_, (const float4*)wpart, eps, wstats, B);
     };
     auto dwconv = [&](hipStream_t st_, const float* x, const float* w, const float* res, float* y, int C, int nb) {   // y = res + x + depthwise_17(x)
-        constexpr int kTT = 64;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kDw, 1, kTT, true>), dim3((unsigned)((n + kTT - 1) / kTT), (unsigned)(C / 64), (unsigned)nb), dim3(256),
-                           (size_t)(kTT + kDw - 1) * 64 * sizeof(float), st_, x, x, C, C, C, w, res, y, C, n, 1, (kDw - 1) / 2, (float4*)nullptr);
+        const int runs = (n + kTconvRun - 1) / kTconvRun;
+        const dim3 grid((unsigned)(C / 64), (unsigned)((runs + 3) / 4), (unsigned)nb);
+        if (res)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kDw, 1, true, true>), grid, dim3(256), 0, st_, x, x, C, C, C, w, res, y, C, n, 1, (kDw - 1) / 2, runs, (float4*)nullptr);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kDw, 1, true, false>), grid, dim3(256), 0, st_, x, x, C, C, C, w, res, y, C, n, 1, (kDw - 1) / 2, runs, (float4*)nullptr);
     };
 
     // front end: RMS stages, encoder, window norm folded into the 1x1 conv, positions                         (:571-591)
@@ -818,16 +846,14 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
             float* dst = (j & 1) ? M1 : M0;
             const int dil = 1 << j, pad = lorder + (dil - 1) * (lorder - 1) - 1;
             // dense input of conv j = [out_{j-1}, xp] (depth <= 2): group g reads concatenated channels g (j + 1) .. g (j + 1) + j
-            constexpr int kTT = 32;
-            const int tiles = (n + kTT - 1) / kTT;
-            const dim3 grid((unsigned)tiles, kInner / 64, (unsigned)B);
-            const size_t lds = (size_t)(kTT + (kMemK - 1) * dil) * 64 * (j + 1) * sizeof(float);
+            const int runs = ((n + dil - 1) / dil + kTconvRun - 1) / kTconvRun, tiles = runs * dil;
+            const dim3 grid(kInner / 64, (unsigned)((tiles + 3) / 4), (unsigned)B);
             if (j == 0)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 1, kTT, false>), grid, dim3(256), lds, s, (const float*)XP, (const float*)XP, kInner, kInner, kInner,
-                                   l.mem_w[0], (const float*)nullptr, dst, kInner, n, dil, pad, partial);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 1, false, false>), grid, dim3(256), 0, s, (const float*)XP, (const float*)XP, kInner, kInner, kInner,
+                                   l.mem_w[0], (const float*)nullptr, dst, kInner, n, dil, pad, runs, partial);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 2, kTT, false>), grid, dim3(256), lds, s, (const float*)mem_prev, (const float*)XP, kInner, kInner,
-                                   kInner, l.mem_w[1], (const float*)nullptr, dst, kInner, n, dil, pad, partial);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tconv<kMemK, 2, false, false>), grid, dim3(256), 0, s, (const float*)mem_prev, (const float*)XP, kInner, kInner,
+                                   kInner, l.mem_w[1], (const float*)nullptr, dst, kInner, n, dil, pad, runs, partial);
             hipLaunchKernelGGL(k_chan_finalize, flat((long long)B * kInner), dim3(256), 0, s, (const float4*)partial, tiles, kInner, hyper[hMemNormEps], cstats,
                                B * kInner);
             hipLaunchKernelGGL(k_mem_norm_prelu, flat((long long)R * kInner), dim3(256), 0, s, dst, (const float2*)cstats, l.mn_w[j], l.mn_b[j], l.mprelu[j], n,
