@@ -35,7 +35,8 @@ using namespace dev;
 
 constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kRow = 20;               // LDS floats per staged row
-constexpr int kSlab = kTM * kRow;      // floats per operand slab
+constexpr int kSub = 1;                // 16-k slabs staged per barrier pair; 2 measured SLOWER (MossFormer in-projection 1384 -> 1616 us: the 40 KB of LDS cost a resident workgroup)
+constexpr int kSlab = kSub * kTM * kRow;   // floats per operand staging area
 
 // bf16-input mode (BF16 = true on the tile functions below): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS; the products
 // run as v_mfma_f32_16x16x16_bf16 with fp32 accumulation -- one instruction per 16-deep slab and tile instead of four.  A throughput mode, not the parity path.
@@ -60,8 +61,9 @@ struct HasVec4<T, std::void_t<decltype(&T::vec4)>> : std::true_type {};
 // one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kSlab LDS slabs
 template <bool BF16 = false, class AL, class BL, class ST>
 __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const ST& store, int M, int N, int K, int m_blk, int n_blk,
-                                          float* As, float* Bs) {
+                                          float* As_all, float* Bs_all) {
     constexpr int kRowW = BF16 ? kRow / 2 : kRow;      // row pitch in 32-bit words (bf16: 16 values + 4 padding = 10 words)
+    constexpr int kSlabW = kTM * kRowW;                // words per staged 16-k slab
     auto put4 = [&](float* base, int row, int kk, const float4& v) {           // four consecutive k of one row
         if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kk / 2) = bf16x4(v);
         else *reinterpret_cast<float4*>(base + row * kRow + kk) = v;
@@ -75,23 +77,28 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
-    bool a_v4 = false, b_v4 = false;
-    if constexpr (AL::kAlongK && HasVec4<AL>::value) a_v4 = a_of.can_vec4(K);
-    if constexpr (!BL::kAlongN && HasVec4<BL>::value) b_v4 = b_of.can_vec4(K);
+    constexpr bool kAVec = AL::kAlongK && HasVec4<AL>::value, kBVec = !BL::kAlongN && HasVec4<BL>::value;
+    bool a_rt = false, b_rt = false;
+    if constexpr (kAVec) a_rt = a_of.can_vec4(K);
+    if constexpr (kBVec) b_rt = b_of.can_vec4(K);
 
     // Software pipeline: the operand elements of slab k+1 are requested (into registers) before the 64 MFMAs of slab k
     // run and are written to LDS after them, so the HBM / L2 latency of a slab hides under the matrix work of the
     // previous one.  Which lane fetches which element depends on the operand's contiguous direction (see the header);
     // every variant leaves each lane with two runs of 4 consecutive k of one row, stored as two ds_write_b128.
-    float4 ra[2], rb[2];
-    auto fetch = [&](int k0) {
+    // The vector / scalar choice of each operand is a run-time property (alignment); the k loop is instantiated per combination and entered once, so
+    // that each copy keeps only its own addressing live (one loop with both paths hoists the address registers of both).
+    auto k_loop = [&](auto av_c, auto bv_c) {
+    constexpr bool a_v4 = decltype(av_c)::value, b_v4 = decltype(bv_c)::value;
+    float4 ra[kSub][2], rb[kSub][2];
+    auto fetch = [&](int k0, int sub) {
         if (a_v4) {                         // lane = (row, quarter): 4 lanes read one row's 64-byte line; rows r and r + 64
             if constexpr (AL::kAlongK && HasVec4<AL>::value) {
                 const int r = tid >> 2, k = k0 + 4 * (tid & 3);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int m = m_blk + r + 64 * h;
-                    ra[h] = (m < M && k < K) ? a_of.vec4(m, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    ra[sub][h] = (m < M && k < K) ? a_of.vec4(m, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
         } else {                            // lane = (row, half slab): 8 k of one row; consecutive lanes = consecutive k-halves / rows
@@ -99,8 +106,8 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
-            ra[0] = make_float4(t[0], t[1], t[2], t[3]);
-            ra[1] = make_float4(t[4], t[5], t[6], t[7]);
+            ra[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
+            ra[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
         if (b_v4) {
             if constexpr (!BL::kAlongN && HasVec4<BL>::value) {
@@ -108,7 +115,7 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = n_blk + c + 64 * h;
-                    rb[h] = (n < N && k < K) ? b_of.vec4(n, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    rb[sub][h] = (n < N && k < K) ? b_of.vec4(n, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
             }
         } else if (BL::kAlongN) {           // lane = (column, half slab): consecutive lanes = consecutive columns
@@ -116,8 +123,8 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             float t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
-            rb[0] = make_float4(t[0], t[1], t[2], t[3]);
-            rb[1] = make_float4(t[4], t[5], t[6], t[7]);
+            rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
+            rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         } else {                            // lane = (k, column group): consecutive lanes = consecutive k of one column; columns cg + 16 u
             const int kk = tid & 15, cg = tid >> 4;
             float t[8];
@@ -126,31 +133,33 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                 const int n = n_blk + cg + 16 * u;
                 t[u] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
             }
-            rb[0] = make_float4(t[0], t[1], t[2], t[3]);
-            rb[1] = make_float4(t[4], t[5], t[6], t[7]);
+            rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
+            rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
     };
-    auto stash = [&]() {                    // registers -> row-major LDS slabs (same lane maps as fetch)
+    auto stash = [&](int sub) {
+        float* As = As_all + sub * kSlabW;
+        float* Bs = Bs_all + sub * kSlabW;                    // registers -> row-major LDS slabs (same lane maps as fetch)
         if (a_v4) {
             const int r = tid >> 2, kq = 4 * (tid & 3);
-            put4(As, r, kq, ra[0]);
-            put4(As, r + 64, kq, ra[1]);
+            put4(As, r, kq, ra[sub][0]);
+            put4(As, r + 64, kq, ra[sub][1]);
         } else {
             const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8;
-            put4(As, r, kh, ra[0]);
-            put4(As, r, kh + 4, ra[1]);
+            put4(As, r, kh, ra[sub][0]);
+            put4(As, r, kh + 4, ra[sub][1]);
         }
         if (b_v4) {
             const int c = tid >> 2, kq = 4 * (tid & 3);
-            put4(Bs, c, kq, rb[0]);
-            put4(Bs, c + 64, kq, rb[1]);
+            put4(Bs, c, kq, rb[sub][0]);
+            put4(Bs, c + 64, kq, rb[sub][1]);
         } else if (BL::kAlongN) {
             const int c = tid & 127, kh = (tid >> 7) * 8;
-            put4(Bs, c, kh, rb[0]);
-            put4(Bs, c, kh + 4, rb[1]);
+            put4(Bs, c, kh, rb[sub][0]);
+            put4(Bs, c, kh + 4, rb[sub][1]);
         } else {
             const int kk = tid & 15, cg = tid >> 4;
-            const float t[8] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w, rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+            const float t[8] = {rb[sub][0].x, rb[sub][0].y, rb[sub][0].z, rb[sub][0].w, rb[sub][1].x, rb[sub][1].y, rb[sub][1].z, rb[sub][1].w};
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if constexpr (BF16) reinterpret_cast<unsigned short*>(Bs)[(cg + 16 * u) * (2 * kRowW) + kk] = (unsigned short)bf16_bits(t[u]);
@@ -158,38 +167,64 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             }
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += kTK) {
-        stash();
+#pragma unroll
+    for (int sub = 0; sub < kSub; ++sub) fetch(kTK * sub, sub);
+    for (int k0 = 0; k0 < K; k0 += kTK * kSub) {
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) stash(sub);
         __syncthreads();
-        if (k0 + kTK < K) fetch(k0 + kTK);
-        if constexpr (BF16) {               // lane (g, j16): four consecutive k (= 4 g ..) of its row as four bf16: one ds_read_b64 per operand tile
-            v4s a8[4], b8[4];
+        if (k0 + kTK * kSub < K) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
+            for (int sub = 0; sub < kSub; ++sub) fetch(k0 + kTK * (kSub + sub), sub);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (wn + 16 * j + j16) * kRowW + 2 * g);
+        for (int sub = 0; sub < kSub; ++sub) {
+            if (sub > 0 && k0 + kTK * sub >= K) break;                        // the tail of K (uniform)
+            const float* As = As_all + sub * kSlabW;
+            const float* Bs = Bs_all + sub * kSlabW;
+            if constexpr (BF16) {           // lane (g, j16): four consecutive k (= 4 g ..) of its row as four bf16: one ds_read_b64 per operand tile
+                v4s a8[4], b8[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
-        } else {
-            float4 a4[4], b4[4];            // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
+                for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (wn + 16 * j + j16) * kRowW + 2 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
+            } else {
+                float4 a4[4];               // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+                for (int j = 0; j < 4; ++j) {                                 // one B operand at a time: 16 MFMAs hide the next ds_read, and 12 fewer live VGPRs
+                    const float4 b4 = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].y, b4.y, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].z, b4.z, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].w, b4.w, acc[i][j]);
+                    }
                 }
+            }
         }
         __syncthreads();
+    }
+    };
+    if constexpr (kAVec && kBVec) {
+        if (a_rt && b_rt) k_loop(std::true_type{}, std::true_type{});
+        else if (a_rt) k_loop(std::true_type{}, std::false_type{});
+        else if (b_rt) k_loop(std::false_type{}, std::true_type{});
+        else k_loop(std::false_type{}, std::false_type{});
+    } else if constexpr (kAVec) {
+        if (a_rt) k_loop(std::true_type{}, std::false_type{});
+        else k_loop(std::false_type{}, std::false_type{});
+    } else if constexpr (kBVec) {
+        if (b_rt) k_loop(std::false_type{}, std::true_type{});
+        else k_loop(std::false_type{}, std::false_type{});
+    } else {
+        k_loop(std::false_type{}, std::false_type{});
     }
     // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
 #pragma unroll
@@ -213,7 +248,7 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
 }
 
 template <class AL, class BL, class ST, bool BF16 = false>
-__global__ __launch_bounds__(256) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
+__global__ __launch_bounds__(256, 4) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
@@ -231,7 +266,7 @@ inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M,
 // returns a struct with members a, b, st (functors as above) and M, N, K; problems may differ in every one of them -- tiles
 // outside a problem's own M x N exit at once, the grid is sized for the largest.
 template <class P, bool BF16 = false>
-__global__ __launch_bounds__(256) void k_gemm128_batched(P prob) {
+__global__ __launch_bounds__(256, 4) void k_gemm128_batched(P prob) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     const int gx = (int)gridDim.x, gy = (int)gridDim.y;
