@@ -86,6 +86,25 @@ struct ScaleBiasStore {        // out[(row0 + m) * ld + n] = v * scale[m] + bias
     int ld;
     __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = v * scale[m] + bias[n]; }
 };
+// The attention in-projection's store: columns n < rot_cols (the q and k blocks) also get the rotary embedding (:552, :438-453) here, so the attention core
+// reads them ready-made instead of rotating every key once per query block.  rotate_half is a swap inside (even, odd) column pairs with the sign folded into
+// rsin; the partner column lives in the neighbouring lane of the accumulator tile (same row), and whole 128-column tiles are either rotated or not.
+struct RotaryQkStore {
+    float* out;
+    const float* scale;
+    const float* bias;
+    const float *rcos, *rsin;      // [position][kDh]
+    int ld, rot_cols, pos_stride, n_pos;
+    __device__ void operator()(int m, int n, float v) const {
+        float u = v * scale[m] + bias[n];
+        if (n < rot_cols) {
+            const float partner = __shfl_xor(u, 1, 64);
+            const int p = (m / pos_stride) % n_pos, d = n & (kDh - 1);
+            u = u * rcos[(size_t)p * kDh + d] + partner * rsin[(size_t)p * kDh + d];
+        }
+        out[(size_t)m * ld + n] = u;
+    }
+};
 struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
     float* out;
     const float* scale;
@@ -234,109 +253,141 @@ constexpr int kKvStride = 68;      // floats per staged row: 16 rows x one float
 
 // One chunk = 64 keys.  Contraction indices are mapped k = 16 ks + 4 g + s (ks = 0..3 slabs, g = lane >> 4, s = the four steps of a slab) on BOTH operands, so a
 // lane's operands of four MFMA steps are ONE ds_read_b128: K rows are staged row-major (key, dim), V TRANSPOSED (dim, key).  The online-softmax rescale runs once per
-// chunk (after all four score tiles), not once per 16 keys: per chunk and wave 64 + 64 MFMAs against 32 ds_read_b128, 17 exps and 16 accumulator multiplies.
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, const float* __restrict__ rcos,
-                                                   const float* __restrict__ rsin, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
+// chunk (after all four score tiles), not once per 16 keys.  A wave owns QT tiles of 16 queries: every K / V operand read from LDS feeds QT MFMA chains, so with
+// QT = 2 (sequences longer than 64) a chunk is 128 + 128 MFMAs per wave against 32 ds_read_b128 -- at QT = 1 the sixteen waves of a CU ask LDS for its full
+// 128 bytes per cycle and the matrix cores wait for it.
+template <int QT>
+__global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq,
+                                                      int di) {
     __shared__ __attribute__((aligned(16))) float Ks[kKc * kKvStride];         // [key][dim]
     __shared__ __attribute__((aligned(16))) float Vt[kDh * kKvStride];         // [dim][key]
+    constexpr int kQw = 16 * QT, kQb = 4 * kQw;                                 // queries per wave / per workgroup
     const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, g = lane >> 4;
     const long long row0 = (long long)seq * seq_stride;
-    const int qi = (int)blockIdx.z * 64 + wave * 16 + j16;                      // this lane's query
-    const bool q_ok = qi < n;
-    const size_t qrow = (size_t)(row0 + (long long)(q_ok ? qi : 0) * pos_stride);
-    float4 qreg[4];                                                             // Q[query j16][d = 16 ks + 4 g + s], rotary applied (:552)
-    {
-        const float* src = qkvg + qrow * ldq + head * kDh;
-        const float* rc = rcos + (size_t)(q_ok ? qi : 0) * kDh;
-        const float* rs = rsin + (size_t)(q_ok ? qi : 0) * kDh;
+    int qi[QT];
+    bool q_ok[QT];
+    size_t qrow[QT];
+    float4 qreg[QT][4];                                                         // Q[query j16 of tile t][d = 16 ks + 4 g + s] (rotary applied by the in-projection's store)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        qi[t] = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;              // this lane's query of tile t
+        q_ok[t] = qi[t] < n;
+        qrow[t] = (size_t)(row0 + (long long)(q_ok[t] ? qi[t] : 0) * pos_stride);
+        const float* src = qkvg + qrow[t] * ldq + head * kDh + 4 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float t[4];
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int d = 16 * ks + 4 * g + sidx;
-                t[sidx] = q_ok ? src[d] * rc[d] + src[d ^ 1] * rs[d] : 0.0f;    // rotate_half = pair swap, sign folded into rsin (:438-453)
-            }
-            qreg[ks] = make_float4(t[0], t[1], t[2], t[3]);
+            const float4 v = *reinterpret_cast<const float4*>(src + 16 * ks);
+            qreg[t][ks] = q_ok[t] ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
-    float m = -INFINITY, l = 0.0f;
-    v4f acc[4];
+    float m[QT], l[QT];
+    v4f acc[QT][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    const bool wave_live = (int)blockIdx.z * 64 + wave * 16 < n;               // a wave whose 16 queries are all padding only helps loading
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[t][dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const bool wave_live = (int)blockIdx.z * kQb + wave * kQw < n;             // a wave whose queries are all padding only helps loading
 
+    // K / V staging, software-pipelined: the 64 keys of chunk c + 1 are requested into registers (four 16-byte K and V pieces per lane: key p = i >> 4, dims 4 (i & 15) ..)
+    // right after chunk c has been written to LDS, and land under chunk c's 256 MFMAs.  Padded keys are zero rows: their p is 0 and 0 * 0 stays 0.
+    float4 pk[4], pv[4];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4, key = c0 + p;
+            const bool ok = key < n;
+            const float* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + d;
+            const float4 k4 = *reinterpret_cast<const float4*>(src + di), v4 = *reinterpret_cast<const float4*>(src + 2 * di);
+            pk[u] = ok ? k4 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pv[u] = ok ? v4 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    request(0);
     for (int c0 = 0; c0 < n; c0 += kKc) {
         __syncthreads();
-        for (int i = tid; i < kKc * kDh / 4; i += 256) {                      // four dims per lane: one 16-byte load each of K, V, cos, sin (ldq, di are multiples of 4)
-            const int p = i >> 4, d = (i & 15) * 4, key = c0 + p;
-            float4 kr = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vv = kr;
-            if (key < n) {
-                const float* src = qkvg + (size_t)(row0 + (long long)key * pos_stride) * ldq + head * kDh;
-                const float4 k4 = *reinterpret_cast<const float4*>(src + di + d), c4 = *reinterpret_cast<const float4*>(rcos + (size_t)key * kDh + d),
-                             s4 = *reinterpret_cast<const float4*>(rsin + (size_t)key * kDh + d);
-                kr = make_float4(k4.x * c4.x + k4.y * s4.x, k4.y * c4.y + k4.x * s4.y, k4.z * c4.z + k4.w * s4.z, k4.w * c4.w + k4.z * s4.w);   // rotate_half = pair swap
-                vv = *reinterpret_cast<const float4*>(src + 2 * di + d);
-            }
-            *reinterpret_cast<float4*>(Ks + p * kKvStride + d) = kr;             // padded keys are zero rows: their p is 0 and 0 * 0 stays 0
-            Vt[d * kKvStride + p] = vv.x; Vt[(d + 1) * kKvStride + p] = vv.y; Vt[(d + 2) * kKvStride + p] = vv.z; Vt[(d + 3) * kKvStride + p] = vv.w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4;
+            *reinterpret_cast<float4*>(Ks + p * kKvStride + d) = pk[u];
+            Vt[d * kKvStride + p] = pv[u].x; Vt[(d + 1) * kKvStride + p] = pv[u].y; Vt[(d + 2) * kKvStride + p] = pv[u].z; Vt[(d + 3) * kKvStride + p] = pv[u].w;
         }
         __syncthreads();
+        if (c0 + kKc < n) request(c0 + kKc);
         if (!wave_live) continue;
-        v4f st[4];
-        float mx = -INFINITY;
+        v4f st[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < QT; ++t) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kKvStride + 16 * ks + 4 * g);
-                st[kt] = mfma16x16x4(kv.x, qreg[ks].x, st[kt]);
-                st[kt] = mfma16x16x4(kv.y, qreg[ks].y, st[kt]);
-                st[kt] = mfma16x16x4(kv.z, qreg[ks].z, st[kt]);
-                st[kt] = mfma16x16x4(kv.w, qreg[ks].w, st[kt]);
-            }
-            const int key0 = c0 + 16 * kt + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (key0 + r >= n) st[kt][r] = -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
+                for (int t = 0; t < QT; ++t) {
+                    st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.w, qreg[t][ks].w, st[t][kt]);
+                }
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);                                       // finite: every chunk starts with a real key
-        const float alpha = __expf(m - m_new);
-        m = m_new;
-        float psum = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int t = 0; t < QT; ++t) {
+            float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st[kt][r] = __expf(st[kt][r] - m_new); psum += st[kt][r]; }
-        l = l * alpha + psum;                                                   // this lane's share of the row sum; the four g-lanes are added at the end
+            for (int kt = 0; kt < 4; ++kt) {
+                const int key0 = c0 + 16 * kt + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = acc[dt] * alpha;
+                for (int r = 0; r < 4; ++r) {
+                    if (key0 + r >= n) st[t][kt][r] = -INFINITY;
+                    mx = fmaxf(mx, st[t][kt][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[t], mx);                                // finite: every chunk starts with a real key
+            const float alpha = __expf(m[t] - m_new);
+            m[t] = m_new;
+            float psum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[t][kt][r] = __expf(st[t][kt][r] - m_new); psum += st[t][kt][r]; }
+            l[t] = l[t] * alpha + psum;                                         // this lane's share of the row sum; the four g-lanes are added at the end
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[t][dt] = acc[t][dt] * alpha;
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kKvStride + 16 * kt + 4 * g);   // V^T[dim 16 dt + j16][keys 16 kt + 4 g ..]
-                acc[dt] = mfma16x16x4(vv.x, st[kt][0], acc[dt]);
-                acc[dt] = mfma16x16x4(vv.y, st[kt][1], acc[dt]);
-                acc[dt] = mfma16x16x4(vv.z, st[kt][2], acc[dt]);
-                acc[dt] = mfma16x16x4(vv.w, st[kt][3], acc[dt]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.y, st[t][kt][1], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.z, st[t][kt][2], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.w, st[t][kt][3], acc[t][dt]);
+                }
             }
     }
-    if (!q_ok) return;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float gate = 1.0f / (1.0f + expf(-qkvg[qrow * ldq + 3 * di + head]));      // sigmoid(gates) (:559)
-    const float sc = gate / l;
-    float* dst = ao + qrow * di + head * kDh + 4 * g;                                 // lane (g, j): dims 16 dt + 4 g + r of query j
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(acc[dt][0] * sc, acc[dt][1] * sc, acc[dt][2] * sc, acc[dt][3] * sc);
+    for (int t = 0; t < QT; ++t) {
+        if (!q_ok[t]) continue;
+        float lt = l[t];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float gate = 1.0f / (1.0f + expf(-qkvg[qrow[t] * ldq + 3 * di + head]));    // sigmoid(gates) (:559)
+        const float sc = gate / lt;
+        float* dst = ao + qrow[t] * di + head * kDh + 4 * g;                             // lane (g, j): dims 16 dt + 4 g + r of query j
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(acc[t][dt][0] * sc, acc[t][dt][1] * sc, acc[t][dt][2] * sc, acc[t][dt][3] * sc);
+    }
 }
 
 // GLU + scatter-add + complex mask (:583, :616-624).  thread = (bt, fc); the bands that own bin fc are listed in CSR order (ascending
@@ -641,9 +692,12 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     using namespace gemm;
     const int ldq = 3 * di + heads;
     // invn holds 1 / |x_row| on entry (written by whoever produced X)
-    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, ScaleBiasStore{bufA, invn, w.in_b, ldq}, R, ldq, dim, bf16);                     // (:547-548)
-    hipLaunchKernelGGL(k_attention, dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)bufA, AO, rc, rs, n,
-                       seq_stride, pos_stride, ldq, di);                                                                     // (:549-560)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, RotaryQkStore{bufA, invn, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim, bf16);   // (:547-548, :552)
+    if (n > 64)                                                                                                              // (:549-560)
+        hipLaunchKernelGGL(k_attention<2>, dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s, (const float*)bufA, AO, n,
+                           seq_stride, pos_stride, ldq, di);
+    else
+        hipLaunchKernelGGL(k_attention<1>, dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
     launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di, bf16);                               // (:561, :569)
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim, bf16);               // (:564)
