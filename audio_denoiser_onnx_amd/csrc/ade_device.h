@@ -198,6 +198,12 @@ __device__ __forceinline__ void fft256_inplace(float2* v, float2* buf, int lane,
     }
 }
 
+// keep(ok, v) = ok ? v : 0 per component.  (A ?: between two float4 OBJECTS makes the compiler select between their addresses and park both on the stack.)
+__device__ __forceinline__ float4 keep4(bool ok, const float4& v) { return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f); }
+__device__ __forceinline__ float4 pick4(bool first, const float4& a, const float4& b) {
+    return make_float4(first ? a.x : b.x, first ? a.y : b.y, first ? a.z : b.z, first ? a.w : b.w);
+}
+
 inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace dev

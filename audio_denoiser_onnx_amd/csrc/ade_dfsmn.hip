@@ -41,9 +41,13 @@ struct PowerFrameB {           // B(f, j) = power bin f of frame j (frame-major 
     __device__ float operator()(int f, int j) const { return p[(size_t)j * kFbBins + f]; }
 };
 struct SigmoidTStore {         // mask[j][f] = sigmoid(v + bias[f]): the last Linear, stored frame-major for the per-frame synthesis kernel   (:230)
+    static constexpr bool kCtx = true;
     float* out;
     const float* bias;
-    __device__ void operator()(int f, int j, float v) const { out[(size_t)j * kStBins + f] = 1.0f / (1.0f + expf(-(v + bias[f]))); }
+    __device__ float row(int f) const { return bias[f]; }
+    __device__ gemm::None col(int) const { return gemm::None{}; }
+    __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
+    __device__ void operator()(int f, int j, float v, float b, gemm::None, gemm::None) const { out[(size_t)j * kStBins + f] = 1.0f / (1.0f + expf(-(v + b))); }
 };
 
 // One workgroup per frame: [Kaldi filter-bank power | mask STFT] of the frame's 1920 samples.

@@ -53,6 +53,16 @@ __device__ __forceinline__ unsigned bf16_bits(float x) {            // fp32 -> b
 __device__ __forceinline__ uint2 bf16x4(const float4& v) { return make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)); }
 __device__ __forceinline__ v4f mfma16x16x16_bf16(v4s a, v4s b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
+// A Store may declare `static constexpr bool kCtx = true` and then provides, instead of operator()(m, n, v),
+//     RowT row(int m) const;  ColT col(int n) const;  PreT pre(int m, int n, const RowT&) const;      (what it needs to READ: per row, per column, per element; `None` if nothing)
+//     void operator()(int m, int n, float v, const RowT&, const ColT&, const PreT&) const;
+// The tile epilogue calls the three readers in batches ahead of the writes (arguments always in range).
+struct None {};
+template <class T, class = void>
+struct HasCtx : std::false_type {};
+template <class T>
+struct HasCtx<T, std::void_t<decltype(T::kCtx)>> : std::true_type {};
+
 template <class T, class = void>
 struct HasVec4 : std::false_type {};
 template <class T>
@@ -97,15 +107,21 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                 const int r = tid >> 2, k = k0 + 4 * (tid & 3);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int m = m_blk + r + 64 * h;
-                    ra[sub][h] = (m < M && k < K) ? a_of.vec4(m, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const int m = m_blk + r + 64 * h;                       // unconditional load from an in-range address, zeroed afterwards: a branch
+                    const bool ok = m < M && k < K;                         // around a load costs a full s_waitcnt and serialises the slab's fetches
+                    const float4 v = a_of.vec4(ok ? m : M - 1, ok ? k : 0);
+                    ra[sub][h] = keep4(ok, v);
                 }
             }
         } else {                            // lane = (row, half slab): 8 k of one row; consecutive lanes = consecutive k-halves / rows
             const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8, m = m_blk + r;
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (m < M && k0 + kh + u < K) ? a_of(m, k0 + kh + u) : 0.0f;
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = m < M && k0 + kh + u < K;
+                const float v = a_of(ok ? m : M - 1, ok ? k0 + kh + u : 0);
+                t[u] = ok ? v : 0.0f;
+            }
             ra[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             ra[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
@@ -115,14 +131,20 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = n_blk + c + 64 * h;
-                    rb[sub][h] = (n < N && k < K) ? b_of.vec4(n, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const bool ok = n < N && k < K;
+                    const float4 v = b_of.vec4(ok ? n : N - 1, ok ? k : 0);
+                    rb[sub][h] = keep4(ok, v);
                 }
             }
         } else if (BL::kAlongN) {           // lane = (column, half slab): consecutive lanes = consecutive columns
             const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (n < N && k0 + kh + u < K) ? b_of(k0 + kh + u, n) : 0.0f;
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = n < N && k0 + kh + u < K;
+                const float v = b_of(ok ? k0 + kh + u : 0, ok ? n : N - 1);
+                t[u] = ok ? v : 0.0f;
+            }
             rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         } else {                            // lane = (k, column group): consecutive lanes = consecutive k of one column; columns cg + 16 u
@@ -131,7 +153,9 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int n = n_blk + cg + 16 * u;
-                t[u] = (n < N && k0 + kk < K) ? b_of(k0 + kk, n) : 0.0f;
+                const bool ok = n < N && k0 + kk < K;
+                const float v = b_of(ok ? k0 + kk : 0, ok ? n : N - 1);
+                t[u] = ok ? v : 0.0f;
             }
             rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
@@ -227,15 +251,53 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
         k_loop(std::false_type{}, std::false_type{});
     }
     // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
+    if constexpr (HasCtx<ST>::value) {
+        // context form (see the header): everything the store READS is requested in batches -- 4 column contexts, then per 16-row band 4 row contexts and 16
+        // per-element values -- before the band's 16 writes, and interior tiles run without bounds checks.  With the plain form every element is load, wait, store.
+        auto emit = [&](auto guard_c) {
+            constexpr bool G = decltype(guard_c)::value;
+            decltype(store.col(0)) cc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_blk + wm + 16 * i + 4 * g + r, n = n_blk + wn + 16 * j + j16;
-                if (m < M && n < N) store(m, n, acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n_blk + wn + 16 * j + j16;
+                cc[j] = store.col(G && n >= N ? N - 1 : n);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                decltype(store.row(0)) rc[4];
+                decltype(store.pre(0, 0, store.row(0))) pc[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m_blk + wm + 16 * i + 4 * g + r, mc = G && m >= M ? M - 1 : m;
+                    rc[r] = store.row(mc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n_blk + wn + 16 * j + j16;
+                        pc[r][j] = store.pre(mc, G && n >= N ? N - 1 : n, rc[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = m_blk + wm + 16 * i + 4 * g + r, n = n_blk + wn + 16 * j + j16;
+                        if (!G || (m < M && n < N)) store(m, n, acc[i][j][r], rc[r], cc[j], pc[r][j]);
+                    }
+            }
+        };
+        if (m_blk + kTM <= M && n_blk + kTN <= N) emit(std::false_type{});
+        else emit(std::true_type{});
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m_blk + wm + 16 * i + 4 * g + r, n = n_blk + wn + 16 * j + j16;
+                    if (m < M && n < N) store(m, n, acc[i][j][r]);
+                }
+    }
 }
 
 // Workgroups are dispatched round-robin over the 8 XCDs (id mod 8), each with its own 4 MB L2.  Renumbering them so that
@@ -314,12 +376,16 @@ struct RowMajorB {      // B(k, n) = p[k * ld + n]
 enum { kActNone = 0, kActRelu = 1, kActSigmoid = 2, kActLogFloor = 3 };
 template <int ACT>
 struct BiasActStore {   // C(m, n) -> p[m * ld + n] = act(v + bias[m])   (bias may be null)
+    static constexpr bool kCtx = true;
     float* p;
     int ld;
     const float* bias;
     float floor_;       // kActLogFloor: log(max(v, floor_))
-    __device__ void operator()(int m, int n, float v) const {
-        if (bias) v += bias[m];
+    __device__ float row(int m) const { return bias ? bias[m] : 0.0f; }
+    __device__ None col(int) const { return None{}; }
+    __device__ None pre(int, int, float) const { return None{}; }
+    __device__ void operator()(int m, int n, float v, float b, None, None) const {
+        v += b;
         if (ACT == kActRelu) v = v > 0.0f ? v : 0.0f;
         if (ACT == kActSigmoid) v = 1.0f / (1.0f + expf(-v));
         if (ACT == kActLogFloor) v = logf(v > floor_ ? v : floor_);

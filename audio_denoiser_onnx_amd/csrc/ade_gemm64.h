@@ -34,8 +34,15 @@ using gemm::bf16_bits;
 using gemm::bf16x4;
 using gemm::mfma16x16x16_bf16;
 
+// waves per SIMD the register allocator aims for: 4 (128 VGPRs) unless the A loader says otherwise -- the implicit-convolution loaders keep per-row state in
+// registers and spill at 128 (measured: the ZipEnhancer step 170 -> 188 ms with spills), so they declare kWavesPerSimd = 3
+template <class T, class = void>
+struct WavesPerSimd { static constexpr int value = 4; };
+template <class T>
+struct WavesPerSimd<T, std::void_t<decltype(T::kWavesPerSimd)>> { static constexpr int value = T::kWavesPerSimd; };
+
 template <class AL, class BL, class ST, bool BF16>
-__global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
+__global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kTM * kRow];          // bf16: the same rows at half the pitch (10 words: 16 bf16 + 4 padding)
     __shared__ __attribute__((aligned(16))) float Bs[kTN * kRow];
     constexpr int kRowW = BF16 ? kRow / 2 : kRow;                          // row pitch in 32-bit words
@@ -61,11 +68,17 @@ __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, 
     const int nb = n_blk + r;
     const bool nok = nb < N;
     float4 ra[4], rb;
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0) {                           // unconditional loads from in-range addresses, zeroed afterwards: a branch around a load costs a full s_waitcnt
         const int k = k0 + kq;
+        const bool kok = k < K;
+        const int kc = kok ? k : 0;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) ra[h] = (rok[h] && k < K) ? a_of.vec4(rows[h], k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        rb = (nok && k < K) ? b_of.vec4(nb, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int h = 0; h < 4; ++h) {
+            const float4 v = a_of.vec4(rows[h], kc);
+            ra[h] = keep4(rok[h] && kok, v);
+        }
+        const float4 w = b_of.vec4(nok ? nb : 0, kc);
+        rb = keep4(nok && kok, w);
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
@@ -109,18 +122,54 @@ __global__ __launch_bounds__(256) void k_gemm256x64(AL a_of, BL b_of, ST store, 
         __syncthreads();
     }
     // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m_blk + wm + 16 * i + 4 * g + q;
-            if (m >= M) continue;
+    if constexpr (gemm::HasCtx<ST>::value) {                 // context form (ade_gemm.h): batched reads ahead of each band's 16 writes, interior tiles unguarded
+        auto emit = [&](auto guard_c) {
+            constexpr bool G = decltype(guard_c)::value;
+            decltype(store.col(0)) cc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = n_blk + 16 * j + j16;
-                if (n < N) store(m, n, acc[i][j][q]);
+                cc[j] = store.col(G && n >= N ? N - 1 : n);
             }
-        }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                decltype(store.row(0)) rc[4];
+                decltype(store.pre(0, 0, store.row(0))) pc[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m_blk + wm + 16 * i + 4 * g + q, mc = G && m >= M ? M - 1 : m;
+                    rc[q] = store.row(mc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n_blk + 16 * j + j16;
+                        pc[q][j] = store.pre(mc, G && n >= N ? N - 1 : n, rc[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int m = m_blk + wm + 16 * i + 4 * g + q, n = n_blk + 16 * j + j16;
+                        if (!G || (m < M && n < N)) store(m, n, acc[i][j][q], rc[q], cc[j], pc[q][j]);
+                    }
+            }
+        };
+        if (m_blk + kTM <= M && n_blk + kTN <= N) emit(std::false_type{});
+        else emit(std::true_type{});
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m_blk + wm + 16 * i + 4 * g + q;
+                if (m >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_blk + 16 * j + j16;
+                    if (n < N) store(m, n, acc[i][j][q]);
+                }
+            }
+    }
 }
 
 template <class AL, class BL, class ST>

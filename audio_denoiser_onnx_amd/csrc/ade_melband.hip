@@ -90,39 +90,50 @@ struct ScaleBiasStore {        // out[(row0 + m) * ld + n] = v * scale[m] + bias
 // reads them ready-made instead of rotating every key once per query block.  rotate_half is a swap inside (even, odd) column pairs with the sign folded into
 // rsin; the partner column lives in the neighbouring lane of the accumulator tile (same row), and whole 128-column tiles are either rotated or not.
 struct RotaryQkStore {
+    static constexpr bool kCtx = true;
     float* out;
     const float* scale;
     const float* bias;
     const float *rcos, *rsin;      // [position][kDh]
     int ld, rot_cols, pos_stride, n_pos;
-    __device__ void operator()(int m, int n, float v) const {
-        float u = v * scale[m] + bias[n];
-        if (n < rot_cols) {
-            const float partner = __shfl_xor(u, 1, 64);
-            const int p = (m / pos_stride) % n_pos, d = n & (kDh - 1);
-            u = u * rcos[(size_t)p * kDh + d] + partner * rsin[(size_t)p * kDh + d];
-        }
-        out[(size_t)m * ld + n] = u;
+    struct RowC { float sc; int tab; };                              // row scale, offset of the row's position in the rotary tables
+    __device__ RowC row(int m) const { return RowC{scale[m], ((m / pos_stride) % n_pos) * kDh}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ float2 pre(int, int n, const RowC& r) const {         // (cos, sin) of (position, n mod 64); the v / gate columns are not rotated
+        const int at = r.tab + (n & (kDh - 1));
+        return n < rot_cols ? make_float2(rcos[at], rsin[at]) : make_float2(1.0f, 0.0f);
+    }
+    __device__ void operator()(int m, int n, float v, const RowC& r, float b, float2 cs) const {
+        const float u = v * r.sc + b;
+        const float partner = __shfl_xor(u, 1, 64);                  // same row, column n ^ 1
+        // explicit rounding order: the guarded and the interior copy of the epilogue must not contract this sum of two products differently
+        out[(size_t)m * ld + n] = n < rot_cols ? __fmaf_rn(u, cs.x, __fmul_rn(partner, cs.y)) : u;
     }
 };
 struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
+    static constexpr bool kCtx = true;
     float* out;
     const float* scale;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const {
-        const float x = v * scale[m] + bias[n];
+    __device__ float row(int m) const { return scale[m]; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const {
+        const float x = v * sc + b;
         out[(size_t)m * ld + n] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     }
 };
 struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)
+    static constexpr bool kCtx = true;
     float* x;
     const float* bias;         // may be null
     int ld;
-    __device__ void operator()(int m, int n, float v) const {
-        float* p = x + (size_t)m * ld + n;
-        *p = *p + (bias ? v + bias[n] : v);
-    }
+    struct ColC { float b; bool has; };
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ ColC col(int n) const { return ColC{bias ? bias[n] : 0.0f, bias != nullptr}; }
+    __device__ float pre(int m, int n, gemm::None) const { return x[(size_t)m * ld + n]; }
+    __device__ void operator()(int m, int n, float v, gemm::None, const ColC& c, float old) const { x[(size_t)m * ld + n] = old + (c.has ? v + c.b : v); }
 };
 struct BiasTanhStore {         // tanh(v + bias[n])   (:581-582)
     float* out;

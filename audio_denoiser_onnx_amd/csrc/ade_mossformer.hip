@@ -135,12 +135,16 @@ struct EncFrameA {             // A((b, t), k) = normalised sample 8 t + k of wi
 };
 template <int ACT>             // 0 none, 1 relu, 2 silu, 3 leaky(alpha)
 struct BiasActRowStore {       // out[m * ld + n] = act(v + bias[n])
+    static constexpr bool kCtx = true;
     float* out;
     const float* bias;         // may be null
     int ld;
     float alpha;
-    __device__ void operator()(int m, int n, float v) const {
-        if (bias) v += bias[n];
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias ? bias[n] : 0.0f; }
+    __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, gemm::None) const {
+        v += b;
         if (ACT == 1) v = fmaxf(v, 0.0f);
         if (ACT == 2) v = silu(v);
         if (ACT == 3) v = v >= 0.0f ? v : v * alpha;
@@ -169,17 +173,22 @@ struct ShiftA {                // token shift (:454-456): first half of the chan
         return (m % n) ? h[(size_t)(m - 1) * kDim + k] : 0.0f;
     }
     __device__ bool can_vec4(int) const { return true; }
-    __device__ float4 vec4(int m, int k) const {
-        if (k >= kHalf) return *reinterpret_cast<const float4*>(h + (size_t)m * kDim + k);
-        return (m % n) ? *reinterpret_cast<const float4*>(h + (size_t)(m - 1) * kDim + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __device__ float4 vec4(int m, int k) const {          // branch-free: one load from a valid row, zeroed for the first frame's shifted half
+        const bool shifted = k < kHalf, first = (m % n) == 0;
+        const float4 v = *reinterpret_cast<const float4*>(h + (size_t)(shifted && !first ? m - 1 : m) * kDim + k);
+        return keep4(!(shifted && first), v);
     }
 };
 struct ScaleSiluStore {        // silu(v * inv[m] + bias[n])   (ScaleNorm folded, :458-459, :502-503)
+    static constexpr bool kCtx = true;
     float* out;
     const float* inv;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = silu(v * inv[m] + bias[n]); }
+    __device__ float row(int m) const { return inv[m]; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const { out[(size_t)m * ld + n] = silu(v * sc + b); }
 };
 struct Relu2Store {            // attn = relu(q k^T)^2   (:487-488)
     float* out;
@@ -199,22 +208,25 @@ struct ColMajorA {             // A(m, k) = p[k * ld + m]: lin_k^T (:490), conse
     __device__ float operator()(int m, int k) const { return p[(size_t)k * ld + m]; }
 };
 struct GuardedStore {          // out[m * ld + n] (=|+=) v for m < valid
+    static constexpr bool kCtx = true;
     float* out;
     int ld, valid, accumulate;
-    __device__ void operator()(int m, int n, float v) const {
-        if (m >= valid) return;
-        float* p = out + (size_t)m * ld + n;
-        *p = accumulate ? *p + v : v;
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ gemm::None col(int) const { return gemm::None{}; }
+    __device__ float pre(int m, int n, gemm::None) const { return accumulate ? out[(size_t)(m < valid ? m : 0) * ld + n] : 0.0f; }
+    __device__ void operator()(int m, int n, float v, gemm::None, gemm::None, float old) const {
+        if (m < valid) out[(size_t)m * ld + n] = old + v;
     }
 };
 struct ResidualBiasStore {     // x[m][n] += v + bias[n]   (:541)
+    static constexpr bool kCtx = true;
     float* x;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const {
-        float* p = x + (size_t)m * ld + n;
-        *p = *p + (v + bias[n]);
-    }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ float pre(int m, int n, gemm::None) const { return x[(size_t)m * ld + n]; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, float old) const { x[(size_t)m * ld + n] = old + (v + b); }
 };
 struct LeakyA {                // A(m, k) = leaky_relu(x[m][k], alpha)   (:599)
     static constexpr bool kAlongK = true;
@@ -267,17 +279,20 @@ struct AttLinA {               // A(m, k) = k < g ? ATT_z[m][k] : lin_q[row m][k
     int g;
     __device__ float operator()(int m, int k) const { return k < g ? att[(size_t)m * g + k] : lq[(size_t)m * kQk + (k - g)]; }
     __device__ bool can_vec4(int) const { return (g & 3) == 0; }
-    __device__ float4 vec4(int m, int k) const {
-        return k < g ? *reinterpret_cast<const float4*>(att + (size_t)m * g + k) : *reinterpret_cast<const float4*>(lq + (size_t)m * kQk + (k - g));
+    __device__ float4 vec4(int m, int k) const {          // one load through a selected pointer (no branch around the load)
+        const float* p = k < g ? att + (size_t)m * g + k : lq + (size_t)m * kQk + (k - g);
+        return *reinterpret_cast<const float4*>(p);
     }
 };
 struct VuLkvB {                // B(k, n) = k < g ? value row k of the group (zero beyond the window's frames, :480-484) : LKV[k - g][n]
     static constexpr bool kAlongN = true;
     const float *rows, *lkv;
     int ld, valid, g;
-    __device__ float operator()(int k, int n) const {
-        if (k >= g) return lkv[(size_t)(k - g) * kVu2 + n];
-        return k < valid ? rows[(size_t)k * ld + n] : 0.0f;
+    __device__ float operator()(int k, int n) const {     // one load through a selected pointer, zeroed for the padded rows (no branch around the load)
+        const bool lin = k >= g, ok = lin || k < valid;
+        const float* p = lin ? lkv + (size_t)(k - g) * kVu2 + n : rows + (size_t)(ok ? k : 0) * ld + n;
+        const float v = *p;
+        return ok ? v : 0.0f;
     }
 };
 struct LinKvProb {             // z = (window, split): partial LKV (128 x 2048) = lin_k^T x value rows over the split's frames   (:490-492; padded keys are

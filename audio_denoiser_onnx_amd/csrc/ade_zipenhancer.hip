@@ -241,6 +241,7 @@ __device__ __forceinline__ float4 norm_prelu4(float4 v, const float* nrm2, const
     return v;
 }
 struct DenseA {
+    static constexpr int kWavesPerSimd = 3;
     const float* hist;     // [tokens][hist_ld] raw
     const float* inp;      // [tokens][C]
     const float* nrm;      // [windows][hist_ld][2]
@@ -251,25 +252,35 @@ struct DenseA {
         const int tf = T * F, b = m / tf, rem = m - b * tf, t = rem / F;
         return Row{b, t, rem - t * F};
     }
+    // Branch-free on purpose: an early return around the loads makes the compiler fence each fetch with s_waitcnt vmcnt(0), which serialises the four row fetches of a
+    // slab and lands them BEFORE the slab's MFMAs instead of under them.  Out-of-map taps read token 0 and are zeroed afterwards; block-input channels take the
+    // normalisation arithmetic of channel 0 and discard it.
     __device__ float4 vec4(const Row& r, int k) const {
         const int tap = k / cin, ci = k - tap * cin, kt = tap >= 3 ? 1 : 0, kf = tap - 3 * kt;
         const int t2 = r.t - (1 - kt) * dil, f2 = r.f + kf - 1;
-        if (t2 < 0 || f2 < 0 || f2 >= F) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const size_t tok = ((size_t)r.b * T + t2) * F + f2;
-        if (ci >= hist_n) return *reinterpret_cast<const float4*>(inp + tok * C + (ci - hist_n));
-        const int ch = hist_off + ci;
-        return norm_prelu4(*reinterpret_cast<const float4*>(hist + tok * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+        const bool ok = t2 >= 0 && f2 >= 0 && f2 < F, from_hist = ci < hist_n;
+        const size_t tok = ok ? ((size_t)r.b * T + t2) * F + f2 : 0;
+        const int ch = from_hist ? hist_off + ci : 0;
+        const float* src = from_hist ? hist + tok * hist_ld + ch : inp + tok * C + (ci - hist_n);
+        const float4 raw = *reinterpret_cast<const float4*>(src);
+        const float4 act = norm_prelu4(raw, nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+        return keep4(ok, pick4(from_hist, act, raw));
     }
 };
 struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
+    static constexpr bool kCtx = true;
     float* out;
     const float* bias;
     int ld, off;
-    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + off + n] = v + bias[n]; }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, gemm::None) const { out[(size_t)m * ld + off + n] = v + b; }
 };
 // (1, K3) convolution along f of a normalised dense output (channel block `ch0` of hist): stride 2 / pad 1 for dense_conv_2 (:853), stride 1 /
 // pad 1 for the sub-pixel up-sampler (:761-766).  A(token_out, k): k = kf * C + ci.
 struct RowConvA {
+    static constexpr int kWavesPerSimd = 3;
     const float* hist;
     const float* nrm;
     const float* slope;
@@ -279,21 +290,24 @@ struct RowConvA {
         const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
         return Row{b, ((long long)b * T + t) * Fin, f * stride - 1};
     }
-    __device__ float4 vec4(const Row& r, int k) const {
+    __device__ float4 vec4(const Row& r, int k) const {                  // branch-free, like DenseA::vec4
         const int kf = k / C, ci = k - kf * C, f2 = r.f0 + kf;
-        if (f2 < 0 || f2 >= Fin) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool ok = f2 >= 0 && f2 < Fin;
         const int ch = ch0 + ci;
-        return norm_prelu4(*reinterpret_cast<const float4*>(hist + (size_t)(r.base + f2) * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+        const float4 v = norm_prelu4(*reinterpret_cast<const float4*>(hist + (size_t)(r.base + (ok ? f2 : 0)) * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
+        return keep4(ok, v);
     }
 };
 struct SubPixelStore {         // conv channel n = c * r + u of sub-band f -> U[(b, t, f * r + u)][ch0 + c] (+ bias)   (:767-769)
+    static constexpr bool kCtx = true;
     float* u;
     const float* bias;
     int ld, ch0, r;
-    __device__ void operator()(int m, int n, float v) const {
-        const int c = n / r, s = n - c * r;
-        u[((size_t)m * r + s) * ld + ch0 + c] = v + bias[n];
-    }
+    struct ColC { float b; int c, s; };
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ ColC col(int n) const { const int c = n / r; return ColC{bias[n], c, n - c * r}; }
+    __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ void operator()(int m, int, float v, gemm::None, const ColC& k, gemm::None) const { u[((size_t)m * r + k.s) * ld + ch0 + k.c] = v + k.b; }
 };
 
 // ---- Zipformer2 layer pieces ----------------------------------------------------------------------------------------------------
@@ -311,31 +325,39 @@ struct ActRowsA {
     }
 };
 struct AddFromStore {          // y[m][n] = x[m][n] + v + bias[n]     (the layer's first residual: x stays the layer input, :146, :160)
+    static constexpr bool kCtx = true;
     const float* x;
     float* y;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const { y[(size_t)m * ld + n] = x[(size_t)m * ld + n] + (v + bias[n]); }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ float pre(int m, int n, gemm::None) const { return x[(size_t)m * ld + n]; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, float old) const { y[(size_t)m * ld + n] = old + (v + b); }
 };
 struct ResidualBiasStore {     // y[m][n] += v + bias[n]
+    static constexpr bool kCtx = true;
     float* y;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const {
-        float* p = y + (size_t)m * ld + n;
-        *p = *p + (v + bias[n]);
-    }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ float pre(int m, int n, gemm::None) const { return y[(size_t)m * ld + n]; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, float old) const { y[(size_t)m * ld + n] = old + (v + b); }
 };
 struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_forward2's residual then bypass_mid, :170-171, :190-191)
+    static constexpr bool kCtx = true;
     const float* x0;
     float* y;
     const float* bias;
     const float* c;
     int ld;
-    __device__ void operator()(int m, int n, float v) const {
-        const size_t i = (size_t)m * ld + n;
-        const float s = y[i] + (v + bias[n]), o = x0[i];
-        y[i] = o + (s - o) * c[n];
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float2 col(int n) const { return make_float2(bias[n], c[n]); }
+    __device__ float2 pre(int m, int n, gemm::None) const { const size_t i = (size_t)m * ld + n; return make_float2(y[i], x0[i]); }
+    __device__ void operator()(int m, int n, float v, gemm::None, float2 bc, float2 yo) const {
+        const float s = yo.x + (v + bc.x);
+        y[(size_t)m * ld + n] = yo.y + (s - yo.y) * bc.y;
     }
 };
 
