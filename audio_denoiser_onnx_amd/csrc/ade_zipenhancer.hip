@@ -324,6 +324,128 @@ struct ActRowsA {
         return v;
     }
 };
+// ---- fused feed-forward module (:160, :170-174): out = epilogue(W2 swooshL(W1 x + b1) + b2), the hidden activations never leave the CU ---------------------
+// Both products are formed TRANSPOSED on v_mfma_f32_16x16x4_f32 (lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15] and holds D[4 (l >> 4) + r][l & 15]):
+//   H^T tile (16 hidden x 16 rows) = W1 (16 x 64) . X^T :  lane (g, j) ends with hidden units 4 g + r of row j in its four accumulator registers;
+//   Y^T tile (16 out x 16 rows)   += W2 (16 x 16 hidden) . act(H^T): contraction step s takes hidden 4 g' + s, so the B operand of lane (g, j) is its own register s --
+// the hidden tile feeds the second product straight from the accumulators (bias + SwooshL applied in place): no LDS round trip, no M x fd tensor in HBM (the unfused
+// form wrote and re-read 2 x 4 fd bytes per token; the module moves 512).  A 512-thread workgroup owns 256 rows (wavefront: two 16-row tiles, X in registers for the
+// whole kernel); the weights stream through LDS 64 hidden units at a time (W1 rows and W2 columns of the chunk, 68-float pitch: conflict-free ds_read_b128),
+// double-buffered with one barrier per chunk: 256 MFMAs per wavefront and chunk against 32 ds_read_b128.
+// MODE 0: out = res + ff (feed_forward1: res = the layer input)   1: out = in + ff (in place)   2: out = res + ((in + ff) - res) * cmid (feed_forward2 + bypass_mid)
+constexpr int kFfChunk = 64, kFfPitch = 68, kFfRows = 256;
+constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float);
+template <int MODE>
+__global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j16 = lane & 15, g = lane >> 4;
+    const int row_base = (int)blockIdx.x * kFfRows + wave * 32;
+    float4 xr[2][4];                                                        // X[row j16 of tile t][16 ks + 4 g ..]
+    int row[2];
+    bool rok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        row[t] = row_base + 16 * t + j16;
+        rok[t] = row[t] < M;
+        const float* src = xin + (size_t)(rok[t] ? row[t] : 0) * 64 + 4 * g;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xr[t][ks] = *reinterpret_cast<const float4*>(src + 16 * ks);
+    }
+    v4f acc2[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc2[t][jt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    // staging: chunk cg of W1 = rows 64 cg .. + 63 (64 k each), of W2 = columns 64 cg .. + 63 of its 64 rows: 1024 float4 each, two per thread
+    const int sr = tid >> 4, sk = (tid & 15) * 4;                           // staged row (0..31, + 32), first of its four columns
+    float4 p1[2], p2[2];
+    auto request = [&](int cg) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            p1[h] = *reinterpret_cast<const float4*>(w1 + (size_t)(64 * cg + sr + 32 * h) * 64 + sk);
+            p2[h] = *reinterpret_cast<const float4*>(w2 + (size_t)(sr + 32 * h) * fd + 64 * cg + sk);
+        }
+    };
+    auto deposit = [&](float* buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kFfPitch + sk) = p1[h];
+            *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kFfPitch + sk) = p2[h];
+        }
+    };
+    const int ncg = fd / kFfChunk;
+    request(0);
+    deposit(lds);
+    __syncthreads();
+    for (int cg = 0; cg < ncg; ++cg) {
+        const float* W1s = lds + (cg & 1) * (2 * kFfChunk * kFfPitch);
+        const float* W2s = W1s + kFfChunk * kFfPitch;
+        if (cg + 1 < ncg) request(cg + 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                       // 16 hidden units at a time
+            v4f h[2] = {v4f{0.0f, 0.0f, 0.0f, 0.0f}, v4f{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 a = *reinterpret_cast<const float4*>(W1s + (16 * c + j16) * kFfPitch + 16 * ks + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    h[t] = mfma16x16x4(a.x, xr[t][ks].x, h[t]);
+                    h[t] = mfma16x16x4(a.y, xr[t][ks].y, h[t]);
+                    h[t] = mfma16x16x4(a.z, xr[t][ks].z, h[t]);
+                    h[t] = mfma16x16x4(a.w, xr[t][ks].w, h[t]);
+                }
+            }
+            const float4 bb = *reinterpret_cast<const float4*>(b1 + 64 * cg + 16 * c + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                h[t][0] = swoosh_l(h[t][0] + bb.x); h[t][1] = swoosh_l(h[t][1] + bb.y);
+                h[t][2] = swoosh_l(h[t][2] + bb.z); h[t][3] = swoosh_l(h[t][3] + bb.w);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const float4 a = *reinterpret_cast<const float4*>(W2s + (16 * jt + j16) * kFfPitch + 16 * c + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc2[t][jt] = mfma16x16x4(a.x, h[t][0], acc2[t][jt]);
+                    acc2[t][jt] = mfma16x16x4(a.y, h[t][1], acc2[t][jt]);
+                    acc2[t][jt] = mfma16x16x4(a.z, h[t][2], acc2[t][jt]);
+                    acc2[t][jt] = mfma16x16x4(a.w, h[t][3], acc2[t][jt]);
+                }
+            }
+        }
+        if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * (2 * kFfChunk * kFfPitch));      // the other buffer: last read in iteration cg - 1, behind that iteration's barrier
+        __syncthreads();
+    }
+    // lane (g, j16): output columns 16 jt + 4 g .. + 3 of row j16 of tile t
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (!rok[t]) continue;
+        const size_t at = (size_t)row[t] * 64 + 4 * g;
+        float4 rv[4], cv[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            rv[jt] = MODE != 1 ? *reinterpret_cast<const float4*>(res + at + 16 * jt) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            cv[jt] = MODE == 2 ? *reinterpret_cast<const float4*>(cmid + 16 * jt + 4 * g) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const float4 bo = *reinterpret_cast<const float4*>(b2 + 16 * jt + 4 * g);
+            // this lane's slice of the input row, columns 16 jt + 4 g .. + 3, is xr[t][jt] (the same 16 ks + 4 g mapping)
+            auto fin = [](float acc, float b, float xi, float r, float c) -> float {
+                const float f = acc + b;
+                if (MODE == 0) return r + f;
+                if (MODE == 1) return xi + f;
+                const float sum = xi + f;
+                return r + (sum - r) * c;
+            };
+            const float4 o = make_float4(fin(acc2[t][jt][0], bo.x, xr[t][jt].x, rv[jt].x, cv[jt].x), fin(acc2[t][jt][1], bo.y, xr[t][jt].y, rv[jt].y, cv[jt].y),
+                                         fin(acc2[t][jt][2], bo.z, xr[t][jt].z, rv[jt].z, cv[jt].z), fin(acc2[t][jt][3], bo.w, xr[t][jt].w, rv[jt].w, cv[jt].w));
+            *reinterpret_cast<float4*>(out + at + 16 * jt) = o;
+        }
+    }
+}
+
 struct AddFromStore {          // y[m][n] = x[m][n] + v + bias[n]     (the layer's first residual: x stays the layer input, :146, :160)
     static constexpr bool kCtx = true;
     const float* x;
@@ -907,6 +1029,10 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     for (auto& f : fix) *f.first = e->d_w + f.second;
     if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
+        return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the feed-forward kernel"));
     *out = e;
     return ADE_OK;
 }
@@ -970,8 +1096,17 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
-    launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp, bf16);                                        // (:148-153)
-    launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                      // (:160)
+    // feed-forward modules run fused (k_zip_ff) on the exact path when their width is a multiple of the 64-unit weight chunk
+    auto fused_ff = [&](int fd) { return !bf16 && C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
+    const dim3 ffg((unsigned)((M + kFfRows - 1) / kFfRows));
+    if (fused_ff(ff1)) {
+        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim, bf16);                               // (:148-153) attention part of the joint projection
+        hipLaunchKernelGGL(k_zip_ff<0>, ffg, dim3(512), kFfLds, s, (const float*)x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b,
+                           (const float*)x, (const float*)nullptr, Y, M, ff1);                                                    // (:160)
+    } else {
+        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp, bf16);                                    // (:148-153)
+        launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                  // (:160)
+    }
     launch_proj64(s, Y, C, w.nonlin_in_w, w.nonlin_in_b, S1, 3 * hid, 0, M, 3 * hid, bf16);                           // (:305)
     attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
     launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid, bf16);                              // (:317, :167)
@@ -986,6 +1121,13 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, Seq
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C, bf16);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
+        if (fused_ff(fd)) {
+            if (i == 0) hipLaunchKernelGGL(k_zip_ff<2>, ffg, dim3(512), kFfLds, s, (const float*)Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], (const float*)x,
+                                           w.bypass_mid, Y, M, fd);                                                               // (:170-171)
+            else hipLaunchKernelGGL(k_zip_ff<1>, ffg, dim3(512), kFfLds, s, (const float*)Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], (const float*)nullptr,
+                                    (const float*)nullptr, Y, M, fd);                                                             // (:174)
+            continue;
+        }
         launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd, bf16);
         if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd, bf16);   // (:170-171)
         else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd, bf16);                   // (:174)
