@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void k_zip_norm_apply(float* __restrict__ x, c
 
 // ---- implicit-GEMM operand: one layer of a causal dense block (:701-757) ---------------------------------------------------------
 // A(token, k): k = tap * cin + ci, tap = kt * 3 + kf; the value is input channel ci of position (t - (1 - kt) dil, f + kf - 1), zero outside the
-// map.  Input channels are [this group's newer dense outputs ..., block input]: the first hist_n live RAW in `hist` (normalised + PReLU'd
-// here with their producer's statistics), the last C in `inp` (final values).
+// map.  Input channels are [this group's newer dense outputs ..., block input]: the first hist_n live in `hist` (normalised + PReLU'd in place by
+// k_zip_hist_norm once their producer's statistics were known), the last C in `inp`.
 __device__ __forceinline__ float4 norm_prelu4(float4 v, const float* nrm2, const float* slope) {
     const float4 s0 = *reinterpret_cast<const float4*>(nrm2), s1 = *reinterpret_cast<const float4*>(nrm2 + 4), sl = *reinterpret_cast<const float4*>(slope);
     v.x = prelu_f(v.x * s0.x + s0.y, sl.x);
@@ -240,12 +240,22 @@ __device__ __forceinline__ float4 norm_prelu4(float4 v, const float* nrm2, const
     v.w = prelu_f(v.w * s1.z + s1.w, sl.w);
     return v;
 }
+// in-place InstanceNorm + PReLU of one 64-channel block of the dense history ([tokens][ld], channels ch0 .. ch0 + 63) once its statistics are known: the block has up
+// to three consumers with six taps each, and a loader that normalises on the fly has to wait for its loads BEFORE the slab's MFMAs (the arithmetic depends on them),
+// which forfeits the fetch / MFMA overlap of the tile pipeline.  One extra 2 x 256 B per token here buys plain loads there.
+__global__ __launch_bounds__(256) void k_zip_hist_norm(float* __restrict__ hist, int ld, int ch0, const float* __restrict__ nrm, const float* __restrict__ slope, int tok_per_win,
+                                                       long long total16) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total16) return;
+    const long long tok = i >> 4;
+    const int ch = ch0 + (int)(i & 15) * 4, b = (int)(tok / tok_per_win);
+    float4* p = reinterpret_cast<float4*>(hist + tok * ld + ch);
+    *p = norm_prelu4(*p, nrm + ((size_t)b * ld + ch) * 2, slope + ch);
+}
 struct DenseA {
     static constexpr int kWavesPerSimd = 3;
-    const float* hist;     // [tokens][hist_ld] raw
+    const float* hist;     // [tokens][hist_ld]
     const float* inp;      // [tokens][C]
-    const float* nrm;      // [windows][hist_ld][2]
-    const float* slope;    // [hist_ld]
     int hist_ld, hist_off, hist_n, cin, C, T, F, dil;
     struct Row { int b, t, f; };
     __device__ Row row(int m) const {
@@ -253,18 +263,14 @@ struct DenseA {
         return Row{b, t, rem - t * F};
     }
     // Branch-free on purpose: an early return around the loads makes the compiler fence each fetch with s_waitcnt vmcnt(0), which serialises the four row fetches of a
-    // slab and lands them BEFORE the slab's MFMAs instead of under them.  Out-of-map taps read token 0 and are zeroed afterwards; block-input channels take the
-    // normalisation arithmetic of channel 0 and discard it.
+    // slab and lands them BEFORE the slab's MFMAs instead of under them.  Out-of-map taps read token 0 and are zeroed afterwards.
     __device__ float4 vec4(const Row& r, int k) const {
         const int tap = k / cin, ci = k - tap * cin, kt = tap >= 3 ? 1 : 0, kf = tap - 3 * kt;
         const int t2 = r.t - (1 - kt) * dil, f2 = r.f + kf - 1;
         const bool ok = t2 >= 0 && f2 >= 0 && f2 < F, from_hist = ci < hist_n;
         const size_t tok = ok ? ((size_t)r.b * T + t2) * F + f2 : 0;
-        const int ch = from_hist ? hist_off + ci : 0;
-        const float* src = from_hist ? hist + tok * hist_ld + ch : inp + tok * C + (ci - hist_n);
-        const float4 raw = *reinterpret_cast<const float4*>(src);
-        const float4 act = norm_prelu4(raw, nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
-        return keep4(ok, pick4(from_hist, act, raw));
+        const float* src = from_hist ? hist + tok * hist_ld + hist_off + ci : inp + tok * C + (ci - hist_n);
+        return keep4(ok, *reinterpret_cast<const float4*>(src));
     }
 };
 struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
@@ -277,25 +283,22 @@ struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
     __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
     __device__ void operator()(int m, int n, float v, gemm::None, float b, gemm::None) const { out[(size_t)m * ld + off + n] = v + b; }
 };
-// (1, K3) convolution along f of a normalised dense output (channel block `ch0` of hist): stride 2 / pad 1 for dense_conv_2 (:853), stride 1 /
+// (1, K3) convolution along f of a dense output (channel block `ch0` of hist, normalised in place): stride 2 / pad 1 for dense_conv_2 (:853), stride 1 /
 // pad 1 for the sub-pixel up-sampler (:761-766).  A(token_out, k): k = kf * C + ci.
 struct RowConvA {
     static constexpr int kWavesPerSimd = 3;
     const float* hist;
-    const float* nrm;
-    const float* slope;
     int hist_ld, ch0, C, T, Fin, Fout, stride;
-    struct Row { int b; long long base; int f0; };
+    struct Row { long long base; int f0; };
     __device__ Row row(int m) const {
         const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
-        return Row{b, ((long long)b * T + t) * Fin, f * stride - 1};
+        return Row{((long long)b * T + t) * Fin, f * stride - 1};
     }
     __device__ float4 vec4(const Row& r, int k) const {                  // branch-free, like DenseA::vec4
         const int kf = k / C, ci = k - kf * C, f2 = r.f0 + kf;
         const bool ok = f2 >= 0 && f2 < Fin;
         const int ch = ch0 + ci;
-        const float4 v = norm_prelu4(*reinterpret_cast<const float4*>(hist + (size_t)(r.base + (ok ? f2 : 0)) * hist_ld + ch), nrm + ((size_t)r.b * hist_ld + ch) * 2, slope + ch);
-        return keep4(ok, v);
+        return keep4(ok, *reinterpret_cast<const float4*>(hist + (size_t)(r.base + (ok ? f2 : 0)) * hist_ld + ch));
     }
 };
 struct SubPixelStore {         // conv channel n = c * r + u of sub-band f -> U[(b, t, f * r + u)][ch0 + c] (+ bias)   (:767-769)
@@ -1078,9 +1081,11 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            gemm64::launch(s, DenseA{Dh, inp, nrm, d.slope, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
+            gemm64::launch(s, DenseA{Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
                            BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin, bf16);
             stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
+            const long long total16 = (long long)M * 16;
+            hipLaunchKernelGGL(k_zip_hist_norm, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, Dh, ld, off_out, (const float*)nrm, d.slope, T * Fd, total16);
         }
 }
 
@@ -1159,7 +1164,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
     if (getenv("ADE_ZIP_DEBUG_STOP")) { snap(0); (void)hipMemcpyAsync(X, Dh, std::min((size_t)R * C, (size_t)tok0 * 4 * C) * sizeof(float), hipMemcpyDeviceToDevice, s); snap(1); return ADE_OK; }
-    gemm64::launch(s, RowConvA{Dh, nrm, enc_dense.slope, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C, bf16);
+    gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C, bf16);
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
     snap(0);
@@ -1176,7 +1181,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     // ---- mask | phase decoder pair (:864-893)
     dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
-        gemm64::launch(s, RowConvA{Dh, nrm, dec_dense.slope, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
+        gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
                        SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C, bf16);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
     }
@@ -1201,7 +1206,7 @@ int ZipEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_
     else if (strcmp(name, "spec") == 0) { src = spec; n = (size_t)kZC2 * J; }                     // (402, windows * T)
     else if (strcmp(name, "feat") == 0) { src = feat; n = J * kZF * 2; }                          // (windows, T, 201, {mag, pha})
     else if (strcmp(name, "e0") == 0) { src = E0; n = J * kZF * C; }                              // (windows, T, 201, C): dense-encoder input
-    else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's raw dense outputs (windows, T, F, 8 C)
+    else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's dense outputs, normalised + PReLU (windows, T, F, 8 C)
     else if (strcmp(name, "nrm") == 0) { src = nrm; n = B * 8 * C * 2; }
     else return zfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
     if (!src || batch <= 0) return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet (encoder taps are kept for calls of at most 8 windows)");
