@@ -518,26 +518,66 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
     float* Vt = Pt + 4 * ((n2 + 3) & ~3);          // [DT * 16][vst]   values, transposed
     float* Us0 = Vt + DT * 16 * vst + wave * 2 * 32 * kUs;   // per-wave scratch, two [32][kUs] buffers used alternately (one wave-level sync per tile)
     const long long r0 = geo.row0(seq);
-    const int hd = 36;                             // 2 * 16 + 4 (checked by the host: query_head_dim 16, pos_head_dim 4)
-    for (int i = tid; i < np16 * hd; i += 256) {
-        const int p = i / hd, d = i - p * hd;
-        const float v = p < n ? proj[(size_t)(r0 + (long long)p * geo.ps) * ldp + h * hd + d] : 0.0f;
-        if (d < 16) Qs[p * kQKs + d] = v;
-        else if (d < 32) Ks[p * kQKs + d - 16] = v;
-        else Pq[p * 4 + d - 32] = v;
-    }
-    for (int i = tid; i < 4 * n2; i += 256) { const int d = i / n2, c = i - d * n2; Pt[d * ((n2 + 3) & ~3) + c] = pos[(size_t)(h * 4 + d) * n2 + c]; }
-    for (int i = tid; i < DT * 16 * np16; i += 256) {
-        const int d = i / np16, key = i - d * np16;
-        float v = 0.0f;
-        if (key < n && d < dv) {
-            const float* q = src + (size_t)(r0 + (long long)key * geo.ps) * lds_;
-            v = MODE == 0 ? tanh_f(q[d]) * q[dv + d] : q[h * dv + d];
+    // Staging.  Every loop below issues its global loads as one batch from in-range addresses (clamped position, zeroed afterwards) before it touches LDS: with a
+    // branch around each load the compiler fences every single one (s_waitcnt vmcnt(0)) and the ~40 loads per lane cost ~40 memory latencies -- more than the 30 score
+    // tiles per wavefront that follow.
+    constexpr int hd = 36;                         // 2 * 16 + 4 (checked by the host: query_head_dim 16, pos_head_dim 4): nine float4 per position = (4 q | 4 k | 1 p)
+    {
+        constexpr int kIt = (NT * 16 * 9 + 255) / 256;
+        float4 t4[kIt];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i / 9, q = i - 9 * p;
+            const bool ok = p < n;                                                       // (p >= np16 only in the last, partial round: those lanes skip the store)
+            t4[u] = keep4(ok, *reinterpret_cast<const float4*>(proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 4 * q));
         }
-        Vt[d * vst + key] = v;
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i / 9, q = i - 9 * p;
+            if (p >= np16) continue;
+            float* dst = q < 4 ? Qs + p * kQKs + 4 * q : (q < 8 ? Ks + p * kQKs + 4 * (q - 4) : Pq + p * 4);
+            *reinterpret_cast<float4*>(dst) = t4[u];
+        }
+    }
+    const int ptst = (n2 + 3) & ~3;
+    {
+        constexpr int kIt = (4 * (2 * NT * 16 - 1) + 255) / 256;                         // n2 <= 2 np16 - 1
+        float t[kIt];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u;
+            t[u] = pos[(size_t)h * 4 * n2 + (i < 4 * n2 ? i : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, d = i / n2, c = i - d * n2;
+            if (i < 4 * n2) Pt[d * ptst + c] = t[u];
+        }
+    }
+    {   // values, transposed into Vt[dim][key]: four dims per lane and load
+        constexpr int kQuads = DT * 4, kIt = (NT * 16 * kQuads + 255) / 256, kBatch = 4;
+#pragma unroll
+        for (int u0 = 0; u0 < kIt; u0 += kBatch) {
+            float4 va[kBatch], vb[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
+                const bool ok = key < n && d < dv;
+                const float* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0);
+                va[u] = keep4(ok, *reinterpret_cast<const float4*>(MODE == 0 ? q : q + h * dv));
+                if (MODE == 0) vb[u] = keep4(ok, *reinterpret_cast<const float4*>(q + dv));
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
+                if (u0 + u >= kIt || key >= np16) continue;
+                float4 v = va[u];
+                if (MODE == 0) v = make_float4(tanh_f(v.x) * vb[u].x, tanh_f(v.y) * vb[u].y, tanh_f(v.z) * vb[u].z, tanh_f(v.w) * vb[u].w);
+                Vt[d * vst + key] = v.x; Vt[(d + 1) * vst + key] = v.y; Vt[(d + 2) * vst + key] = v.z; Vt[(d + 3) * vst + key] = v.w;
+            }
+        }
     }
     __syncthreads();
-    const int ptst = (n2 + 3) & ~3;
     for (int qt = wave; qt * 16 < n; qt += 4) {
         const int q0 = qt * 16, qi = q0 + j16;
         const float4 qv = *reinterpret_cast<const float4*>(Qs + qi * kQKs + 4 * g);       // B operand of the score product: Q[query j16][dims 4 g ..]
@@ -872,8 +912,8 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     if (e->depth < 1 || e->depth > 4 || e->up < 1 || e->up > 4 || e->dst < 1 || e->dsf < 1 || e->dst > 8 || e->dsf > 8 || !(e->K & 1) || e->K > 63)
         return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: unsupported geometry (dense depth <= 4, up-scale <= 4, down-sampling <= 8, odd depthwise kernel <= 63)"));
     e->hid = C * 3 / 4; e->ff1 = e->ffd * 3 / 4; e->ff3 = e->ffd * 5 / 4; e->attn_dim = e->H * (2 * e->qd + e->pd);
-    if ((e->hid % 4) || (e->ff1 % 4) || (e->ff3 % 4) || (e->ffd % 4) || (e->attn_dim % 4) || ((e->H * e->vd) % 4) || e->hid > 64 || e->vd > 16 || e->H < 1)
-        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: projection widths must be multiples of 4, hidden_channels <= 64, value_head_dim <= 16"));
+    if ((e->hid % 4) || (e->ff1 % 4) || (e->ff3 % 4) || (e->ffd % 4) || (e->attn_dim % 4) || ((e->H * e->vd) % 4) || (e->vd % 4) || e->hid > 64 || e->vd > 16 || e->H < 1)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: projection widths and value_head_dim must be multiples of 4, hidden_channels <= 64, value_head_dim <= 16"));
     if (e->qd != 16 || e->pd != 4)
         return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: the attention kernel is built for query_head_dim 16 and pos_head_dim 4"));
     e->T = window_len / kZHop + 1;
