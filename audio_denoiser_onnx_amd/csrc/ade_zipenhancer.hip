@@ -273,6 +273,132 @@ struct DenseA {
         return keep4(ok, *reinterpret_cast<const float4*>(src));
     }
 };
+// ---- dense-block layer as its own token-tiled kernel: the three frequency taps of a time tap share ONE staged operand -------------------------------------------
+// The generic implicit GEMM above fetches every (token, channel) six times, once per tap.  Taps (kt, kf = 0..2) of one kt read the SAME 16-channel slab of the
+// same rows shifted by -1 / 0 / +1 token, so this kernel stages rows m_blk - 1 .. m_blk + 256 of a (kt, channel block) once and runs the three kf products
+// against it (the A operand of tap kf is LDS row r + kf; positions whose neighbour lies outside the map -- f = 0 for kf = 0, f = F - 1 for kf = 2 -- are zeroed
+// in the operand register): a third of the global / L2 operand traffic, a third of the staging stores and barriers per MFMA.  256 tokens x 64 output
+// channels per workgroup, wavefront tile 64 x 64, pipeline and LDS layout as in ade_gemm64.h.  k runs (kt, channel block, kf, channel) instead of
+// (tap, channel): the same sum in another order.
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const float* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T, int F,
+                                                      int dil, const float* __restrict__ w, const float* __restrict__ bias, float* out, int out_ld, int out_off, int M) {
+    constexpr int kRowW = BF16 ? gemm::kRow / 2 : gemm::kRow, kARows = 264;
+    __shared__ __attribute__((aligned(16))) float As[kARows * kRowW];
+    __shared__ __attribute__((aligned(16))) float Bs[3 * 64 * kRowW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, j16 = lane & 15, g = lane >> 4;
+    const int m_blk = gemm::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x) * 256;
+    const int TF = T * F;
+    // staged rows of this lane: r = (tid >> 2) + 64 h, h < 4, and for tid < 8 the two halo rows 256, 257; token = m_blk - 1 + r
+    const int sr = tid >> 2, kq = 4 * (tid & 3);
+    long long stok[5];
+    bool sok0[5], sok1[5];
+#pragma unroll
+    for (int h = 0; h < 5; ++h) {
+        const int r = h < 4 ? sr + 64 * h : 256 + sr;
+        const int m = m_blk - 1 + r;
+        const bool in = m >= 0 && m < M && (h < 4 || tid < 8);
+        const int mc = in ? m : 0, b = mc / TF, t = (mc - b * TF) / F;
+        stok[h] = mc;
+        sok1[h] = in;                               // kt = 1: the row itself
+        sok0[h] = in && t >= dil;                   // kt = 0: the row dil frames earlier, inside the window
+    }
+    // operand masks of the rows this lane feeds to the matrix cores: bit i = row wm + 16 i + j16 has a left (kf = 0) / right (kf = 2) neighbour
+    unsigned left = 0, right = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_blk + wm + 16 * i + j16, f = m % F;
+        if (f != 0) left |= 1u << i;
+        if (f != F - 1) right |= 1u << i;
+    }
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    const int ncb = cin / 16, nstage = 2 * ncb;
+    float4 ra[5], rb0, rb1, rb2;
+    auto fetch = [&](int st) {
+        const int kt = st / ncb, ci0 = (st - kt * ncb) * 16;
+        const bool from_hist = ci0 < hist_n;
+        const float* src = from_hist ? hist + hist_off + ci0 + kq : inp + (ci0 - hist_n) + kq;
+        const long long ld = from_hist ? hist_ld : 64, shift = kt ? 0 : (long long)dil * F;
+#pragma unroll
+        for (int h = 0; h < 5; ++h) {
+            const bool ok = kt ? sok1[h] : sok0[h];
+            ra[h] = keep4(ok, *reinterpret_cast<const float4*>(src + (stok[h] - (ok ? shift : 0)) * ld));
+        }
+        const float* wp = w + (size_t)sr * (6 * cin) + (size_t)(kt * 3) * cin + ci0 + kq;
+        rb0 = *reinterpret_cast<const float4*>(wp);
+        rb1 = *reinterpret_cast<const float4*>(wp + cin);
+        rb2 = *reinterpret_cast<const float4*>(wp + 2 * cin);
+    };
+    auto put4 = [&](float* base, int row, const float4& v) {
+        if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kq / 2) = gemm::bf16x4(v);
+        else *reinterpret_cast<float4*>(base + row * kRowW + kq) = v;
+    };
+    fetch(0);
+    for (int st = 0; st < nstage; ++st) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) put4(As, sr + 64 * h, ra[h]);
+        if (tid < 8) put4(As, 256 + sr, ra[4]);
+        put4(Bs, sr, rb0);
+        put4(Bs + 64 * kRowW, sr, rb1);
+        put4(Bs + 2 * 64 * kRowW, sr, rb2);
+        __syncthreads();
+        if (st + 1 < nstage) fetch(st + 1);
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) {
+            const unsigned mask = kf == 0 ? left : (kf == 2 ? right : 0xfu);
+            if constexpr (BF16) {
+                gemm::v4s a8[4], b8[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint2 raw = *reinterpret_cast<const uint2*>(As + (wm + 16 * i + j16 + kf) * kRowW + 2 * g);
+                    const bool ok = (mask >> i) & 1u;
+                    const uint2 sel = make_uint2(ok ? raw.x : 0u, ok ? raw.y : 0u);
+                    a8[i] = *reinterpret_cast<const gemm::v4s*>(&sel);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const gemm::v4s*>(Bs + (kf * 64 + 16 * j + j16) * kRowW + 2 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = gemm::mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
+            } else {
+                float4 a4[4], b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a4[i] = keep4((mask >> i) & 1u, *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16 + kf) * kRowW + 4 * g));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (kf * 64 + 16 * j + j16) * kRowW + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bj[j] = bias[16 * j + j16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m_blk + wm + 16 * i + 4 * g + q;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(size_t)m * out_ld + out_off + 16 * j + j16] = acc[i][j][q] + bj[j];
+        }
+}
+
 struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
     static constexpr bool kCtx = true;
     float* out;
@@ -668,6 +794,42 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g,
     const int C = CC > 0 ? CC : C_, K = KK > 0 ? KK : K_;
     const int seq = blockIdx.x, p0 = (int)blockIdx.y * 64, tid = threadIdx.x, n = geo.n, half = K / 2, rowsN = 64 + K - 1;
     const long long r0 = geo.row0(seq);
+    if constexpr (CC == 64 && KK > 0) {
+        // the published geometry: 16 lanes per staged row, four channels each; all of a lane's loads are issued as one batch from clamped rows (no branch around a
+        // load: see k_zip_attn), the lane's 15 taps live in registers, and a lane owns ONE channel for its sixteen outputs
+        constexpr int kRows = 64 + KK - 1, kIt = (kRows * 16 + 255) / 256;
+        float4 va[kIt], vg[kIt];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i >> 4, c = (i & 15) * 4, pos = p0 - half + p;
+            const bool ok = p < kRows && pos >= 0 && pos < n;
+            const float* q = g + (size_t)(r0 + (long long)(ok ? pos : 0) * geo.ps) * (2 * CC) + c;
+            va[u] = keep4(ok, *reinterpret_cast<const float4*>(q));
+            vg[u] = *reinterpret_cast<const float4*>(q + CC);
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i >> 4, c = (i & 15) * 4;
+            if (p < kRows)
+                *reinterpret_cast<float4*>(lds + p * CC + c) = make_float4(va[u].x * sigmoid_p(vg[u].x), va[u].y * sigmoid_p(vg[u].y), va[u].z * sigmoid_p(vg[u].z),
+                                                                           va[u].w * sigmoid_p(vg[u].w));
+        }
+        const int c = tid & 63;
+        float wk[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) wk[k] = w[c * KK + k];
+        const float bc = bias[c];
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int p = (tid >> 6) + 4 * it, pos = p0 + p;
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KK; ++k) a = fmaf(wk[k], lds[(p + k) * CC + c], a);
+            if (pos < n) out[(size_t)(r0 + (long long)pos * geo.ps) * CC + c] = a + bc;
+        }
+        return;
+    }
     for (int i = tid; i < rowsN * C; i += 256) {
         const int p = i / C, c = i - p * C, pos = p0 - half + p;
         float v = 0.0f;
@@ -1121,8 +1283,16 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            gemm64::launch(s, DenseA{Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
-                           BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin, bf16);
+            if (C == 64) {
+                const dim3 grid((unsigned)((M + 255) / 256));
+                if (bf16) hipLaunchKernelGGL(k_zip_dense<true>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
+                                             d.b[g][i], Dh, ld, off_out, M);
+                else hipLaunchKernelGGL(k_zip_dense<false>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
+                                        d.b[g][i], Dh, ld, off_out, M);
+            } else {
+                gemm64::launch(s, DenseA{Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
+                               BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin, bf16);
+            }
             stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = (long long)M * 16;
             hipLaunchKernelGGL(k_zip_hist_norm, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, Dh, ld, off_out, (const float*)nrm, d.slope, T * Fd, total16);
