@@ -80,11 +80,15 @@ struct BandGatherA {           // A(bt, k) = S[gcol[off + k]][bt]: column k of b
     __device__ float operator()(int m, int k) const { return S[(size_t)gcol[k] * BT + m]; }
 };
 struct ScaleBiasStore {        // out[(row0 + m) * ld + n] = v * scale[m] + bias[n]
+    static constexpr bool kCtx = true;
     float* out;
     const float* scale;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = v * scale[m] + bias[n]; }
+    __device__ float row(int m) const { return scale[m]; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const { out[(size_t)m * ld + n] = v * sc + b; }
 };
 // The attention in-projection's store: columns n < rot_cols (the q and k blocks) also get the rotary embedding (:552, :438-453) here, so the attention core
 // reads them ready-made instead of rotating every key once per query block.  rotate_half is a swap inside (even, odd) column pairs with the sign folded into
@@ -136,16 +140,24 @@ struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)
     __device__ void operator()(int m, int n, float v, gemm::None, const ColC& c, float old) const { x[(size_t)m * ld + n] = old + (c.has ? v + c.b : v); }
 };
 struct BiasTanhStore {         // tanh(v + bias[n])   (:581-582)
+    static constexpr bool kCtx = true;
     float* out;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float v) const { out[(size_t)m * ld + n] = tanhf(v + bias[n]); }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, gemm::None) const { out[(size_t)m * ld + n] = tanhf(v + b); }
 };
 struct BiasTransposedStore {   // YT[(col0 + n) * BT + m] = v + bias[n]: the raw last Linear of the mask estimator, column-major
+    static constexpr bool kCtx = true;
     float* yt;
     const float* bias;
     int BT;
-    __device__ void operator()(int m, int n, float v) const { yt[(size_t)n * BT + m] = v + bias[n]; }
+    __device__ gemm::None row(int) const { return gemm::None{}; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ gemm::None pre(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ void operator()(int m, int n, float v, gemm::None, float b, gemm::None) const { yt[(size_t)n * BT + m] = v + b; }
 };
 struct PlanarSpecA {           // A(j, k) = MS[k][j]: masked spectrum, k = c*1025 + f, j = (b, ch, t)
     static constexpr bool kAlongK = false;
