@@ -66,6 +66,7 @@ PIPELINE_BYTES_PER_CHUNK = 32000 + 31744          # int16 in + int16 out (SURVEY
 PIPELINE_FLOP_PER_CHUNK = 54.5e6                   # 2 x 26.52 MMAC network + FFT-form STFT/ISTFT
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3                           # fp32 dense: f32-MFMA rate == fp32 VALU rate on gfx950
+BF16_PEAK_TFLOPS = 2500.0                          # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -416,8 +417,12 @@ def main():
             line["target_rtf"] = wl["target_rtf"]
         if not gtcrn and wl.get("deviation"):
             line["deviation_from_f32"] = wl["deviation"]
-            roofline["peak_note"] = ("priced against the dense f32-MFMA rate (157.3 TFLOP/s) for comparability with the f32 line; the bf16 matrix rate is "
-                                     "~2.5 PFLOP/s, but operands stay fp32 in HBM, so the projections are bound by operand traffic, not by the matrix cores")
+            roofline["frac_of_f32_peak"] = roofline["frac"]                    # comparability with the f32 line (can exceed 1: bf16 inputs run on a faster pipe)
+            roofline["peak"] = BF16_PEAK_TFLOPS
+            roofline["frac"] = round(roofline["achieved"] / BF16_PEAK_TFLOPS, 4)
+            roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); operands stay fp32 in HBM and are rounded on "
+                                     "their way into LDS, so the GEMMs are bound by operand traffic / staging, not by the matrix cores; attention cores, norms, "
+                                     "front / back ends stay fp32")
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
