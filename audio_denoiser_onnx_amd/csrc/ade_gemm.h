@@ -36,7 +36,9 @@ using namespace dev;
 constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kRow = 20;               // LDS floats per staged row
 constexpr int kSub = 1;                // 16-k slabs staged per barrier pair; 2 measured SLOWER (MossFormer in-projection 1384 -> 1616 us: the 40 KB of LDS cost a resident workgroup)
-constexpr int kSlab = kSub * kTM * kRow;   // floats per operand staging area
+constexpr bool kDouble = false;        // two LDS slabs used alternately, ONE barrier per 16-k slab (needs kSub == 1): measured SLOWER on the final round-2 tree (MossFormer 960 -> 1007 ms,
+                                       // Mel-Band 981 -> 1042 ms; the bf16 mode unchanged) -- 40 KB of LDS per workgroup costs a resident workgroup, which hides more than the second barrier costs
+constexpr int kSlab = (kDouble ? 2 : kSub) * kTM * kRow;   // floats per operand staging area
 
 // bf16-input mode (BF16 = true on the tile functions below): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS; the products
 // run as v_mfma_f32_16x16x16_bf16 with fp32 accumulation -- one instruction per 16-deep slab and tile instead of four.  A throughput mode, not the parity path.
@@ -161,9 +163,9 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
     };
-    auto stash = [&](int sub) {
-        float* As = As_all + sub * kSlabW;
-        float* Bs = Bs_all + sub * kSlabW;                    // registers -> row-major LDS slabs (same lane maps as fetch)
+    auto stash = [&](int sub, int buf) {
+        float* As = As_all + buf * kSlabW;
+        float* Bs = Bs_all + buf * kSlabW;                    // registers -> row-major LDS slabs (same lane maps as fetch)
         if (a_v4) {
             const int r = tid >> 2, kq = 4 * (tid & 3);
             put4(As, r, kq, ra[sub][0]);
@@ -191,21 +193,9 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             }
         }
     };
-#pragma unroll
-    for (int sub = 0; sub < kSub; ++sub) fetch(kTK * sub, sub);
-    for (int k0 = 0; k0 < K; k0 += kTK * kSub) {
-#pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) stash(sub);
-        __syncthreads();
-        if (k0 + kTK * kSub < K) {
-#pragma unroll
-            for (int sub = 0; sub < kSub; ++sub) fetch(k0 + kTK * (kSub + sub), sub);
-        }
-#pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) {
-            if (sub > 0 && k0 + kTK * sub >= K) break;                        // the tail of K (uniform)
-            const float* As = As_all + sub * kSlabW;
-            const float* Bs = Bs_all + sub * kSlabW;
+    auto compute = [&](int buf) {
+            const float* As = As_all + buf * kSlabW;
+            const float* Bs = Bs_all + buf * kSlabW;
             if constexpr (BF16) {           // lane (g, j16): four consecutive k (= 4 g ..) of its row as four bf16: one ds_read_b64 per operand tile
                 v4s a8[4], b8[4];
 #pragma unroll
@@ -232,8 +222,39 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                     }
                 }
             }
-        }
+    };
+    if constexpr (kDouble) {
+        static_assert(!kDouble || kSub == 1, "the double-buffered loop stages one slab at a time");
+        fetch(0, 0);
+        stash(0, 0);
         __syncthreads();
+        int cur = 0;
+        for (int k0 = 0; k0 < K; k0 += kTK) {
+            const bool more = k0 + kTK < K;
+            if (more) fetch(k0 + kTK, 0);
+            compute(cur);
+            if (more) stash(0, cur ^ 1);             // the other slab: last read in the previous iteration, behind that iteration's barrier
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) fetch(kTK * sub, sub);
+        for (int k0 = 0; k0 < K; k0 += kTK * kSub) {
+#pragma unroll
+            for (int sub = 0; sub < kSub; ++sub) stash(sub, sub);
+            __syncthreads();
+            if (k0 + kTK * kSub < K) {
+#pragma unroll
+                for (int sub = 0; sub < kSub; ++sub) fetch(k0 + kTK * (kSub + sub), sub);
+            }
+#pragma unroll
+            for (int sub = 0; sub < kSub; ++sub) {
+                if (sub > 0 && k0 + kTK * sub >= K) break;                    // the tail of K (uniform)
+                compute(sub);
+            }
+            __syncthreads();
+        }
     }
     };
     if constexpr (kAVec && kBVec) {
