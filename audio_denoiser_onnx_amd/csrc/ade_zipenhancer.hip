@@ -1373,7 +1373,6 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
-    if (getenv("ADE_ZIP_DEBUG_STOP")) { snap(0); (void)hipMemcpyAsync(X, Dh, std::min((size_t)R * C, (size_t)tok0 * 4 * C) * sizeof(float), hipMemcpyDeviceToDevice, s); snap(1); return ADE_OK; }
     gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C, bf16);
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));

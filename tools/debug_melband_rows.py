@@ -18,12 +18,6 @@ with InferenceSession(weights=blob, metadata=melband.metadata(L)) as sess:
     a2 = sess.run(None, {"noisy_audio": rows})[0]
     b = sess.run(None, {"noisy_audio": rows[::-1].copy()})[0]
     one = sess.run(None, {"noisy_audio": rows[1:2]})[0]
-    taps = {}
-    for name in ("tokens", "mask"):
-        try:
-            taps[name] = sess.tap(name)
-        except Exception as e:
-            print("tap", name, e)
 d = lambda x, y: (int(np.abs(x.astype(np.int32) - y.astype(np.int32)).max()), float((x != y).mean()))
 print("depth", D, "L", L)
 print("same input twice:", d(a, a2))
