@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
         const float* row = x + (size_t)(m < M ? m : 0) * ldx + 4 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float4 v = m < M ? *reinterpret_cast<const float4*>(row + 16 * ks) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 v = keep4(m < M, *reinterpret_cast<const float4*>(row + 16 * ks));      // clamped row, no branch around the load
             if constexpr (BF16) { const uint2 q = bf16x4(v); xb[i][ks] = *reinterpret_cast<const v4s*>(&q); }
             else xa[i][ks] = v;
         }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = tid + 256 * u, c = idx >> 4, k4 = (idx & 15) * 4, n = n0 + c;
-            const float4 v = n < N ? *reinterpret_cast<const float4*>(w + (size_t)n * 64 + k4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 v = keep4(n < N, *reinterpret_cast<const float4*>(w + (size_t)(n < N ? n : 0) * 64 + k4));
             float* dst = Ws[buf] + ((k4 >> 4) * 64 + c) * kRowW;
             if constexpr (BF16) *reinterpret_cast<uint2*>(dst + (k4 & 15) / 2) = bf16x4(v);
             else *reinterpret_cast<float4*>(dst + (k4 & 15)) = v;
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
     for (int n0 = 0; n0 < N; n0 += 64, buf ^= 1) {
         __syncthreads();                     // Ws[buf] is complete; every wave has finished reading Ws[buf ^ 1] (previous iteration)
         if (n0 + 64 < N) stage(n0 + 64, buf ^ 1);
+        float4 bj[4];                         // the column block's biases, requested before the products (clamped: no branch around the loads)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) { const int n = n0 + 16 * jn + 4 * g; bj[jn] = *reinterpret_cast<const float4*>(bias + (n < N ? n : 0)); }
         v4f acc[4][RT];                       // [column tile jn][row tile i]: lane (g, j16) holds out[row 16 i + j16][columns 16 jn + 4 g .. + 3]
 #pragma unroll
         for (int jn = 0; jn < 4; ++jn)
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
         for (int jn = 0; jn < 4; ++jn) {
             const int n = n0 + 16 * jn + 4 * g;
             if (n >= N) continue;
-            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            const float4 b = bj[jn];
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
                 const int m = m0 + 16 * i + j16;
