@@ -462,9 +462,12 @@ struct ActRowsA {
 // whole kernel); the weights stream through LDS 64 hidden units at a time (W1 rows and W2 columns of the chunk, 68-float pitch: conflict-free ds_read_b128),
 // double-buffered with one barrier per chunk: 256 MFMAs per wavefront and chunk against 32 ds_read_b128.
 // MODE 0: out = res + ff (feed_forward1: res = the layer input)   1: out = in + ff (in place)   2: out = res + ((in + ff) - res) * cmid (feed_forward2 + bypass_mid)
-constexpr int kFfChunk = 64, kFfPitch = 68, kFfRows = 256;
-constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float);
-template <int MODE>
+// BF16 = true (ade_gemm_dtype = bf16): the same kernel with bf16 INPUTS to both products (v_mfma_f32_16x16x16_bf16, fp32 accumulation): weights are rounded on their
+// way into LDS (34-word pitch), X once into registers, the activated hidden tile when it leaves the accumulators -- whose four registers are exactly the four
+// consecutive k a lane supplies to that instruction; bias, SwooshL, residual and the output stay fp32.
+constexpr int kFfChunk = 64, kFfPitch = 68, kFfPitchB = 34, kFfRows = 256;
+constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float), kFfLdsB = (size_t)2 * 2 * kFfChunk * kFfPitchB * sizeof(float);
+template <int MODE, bool BF16>
 __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                 const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -481,6 +484,14 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xr[t][ks] = *reinterpret_cast<const float4*>(src + 16 * ks);
     }
+    gemm::v4s xb[2][4];                                                     // the same operand as four bf16 (BF16 only)
+    if constexpr (BF16) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { const uint2 q = gemm::bf16x4(xr[t][ks]); xb[t][ks] = *reinterpret_cast<const gemm::v4s*>(&q); }
+    }
+    constexpr int kPitch = BF16 ? kFfPitchB : kFfPitch;                     // 32-bit words per staged row
     v4f acc2[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -499,8 +510,13 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
     auto deposit = [&](float* buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kFfPitch + sk) = p1[h];
-            *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kFfPitch + sk) = p2[h];
+            if constexpr (BF16) {
+                *reinterpret_cast<uint2*>(buf + (sr + 32 * h) * kPitch + sk / 2) = gemm::bf16x4(p1[h]);
+                *reinterpret_cast<uint2*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk / 2) = gemm::bf16x4(p2[h]);
+            } else {
+                *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kPitch + sk) = p1[h];
+                *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk) = p2[h];
+            }
         }
     };
     const int ncg = fd / kFfChunk;
@@ -508,21 +524,27 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
     deposit(lds);
     __syncthreads();
     for (int cg = 0; cg < ncg; ++cg) {
-        const float* W1s = lds + (cg & 1) * (2 * kFfChunk * kFfPitch);
-        const float* W2s = W1s + kFfChunk * kFfPitch;
+        const float* W1s = lds + (cg & 1) * (2 * kFfChunk * kPitch);
+        const float* W2s = W1s + kFfChunk * kPitch;
         if (cg + 1 < ncg) request(cg + 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                                       // 16 hidden units at a time
             v4f h[2] = {v4f{0.0f, 0.0f, 0.0f, 0.0f}, v4f{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float4 a = *reinterpret_cast<const float4*>(W1s + (16 * c + j16) * kFfPitch + 16 * ks + 4 * g);
+                if constexpr (BF16) {
+                    const gemm::v4s a = *reinterpret_cast<const gemm::v4s*>(W1s + (16 * c + j16) * kPitch + 8 * ks + 2 * g);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    h[t] = mfma16x16x4(a.x, xr[t][ks].x, h[t]);
-                    h[t] = mfma16x16x4(a.y, xr[t][ks].y, h[t]);
-                    h[t] = mfma16x16x4(a.z, xr[t][ks].z, h[t]);
-                    h[t] = mfma16x16x4(a.w, xr[t][ks].w, h[t]);
+                    for (int t = 0; t < 2; ++t) h[t] = gemm::mfma16x16x16_bf16(a, xb[t][ks], h[t]);
+                } else {
+                    const float4 a = *reinterpret_cast<const float4*>(W1s + (16 * c + j16) * kPitch + 16 * ks + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        h[t] = mfma16x16x4(a.x, xr[t][ks].x, h[t]);
+                        h[t] = mfma16x16x4(a.y, xr[t][ks].y, h[t]);
+                        h[t] = mfma16x16x4(a.z, xr[t][ks].z, h[t]);
+                        h[t] = mfma16x16x4(a.w, xr[t][ks].w, h[t]);
+                    }
                 }
             }
             const float4 bb = *reinterpret_cast<const float4*>(b1 + 64 * cg + 16 * c + 4 * g);
@@ -531,19 +553,31 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
                 h[t][0] = swoosh_l(h[t][0] + bb.x); h[t][1] = swoosh_l(h[t][1] + bb.y);
                 h[t][2] = swoosh_l(h[t][2] + bb.z); h[t][3] = swoosh_l(h[t][3] + bb.w);
             }
+            if constexpr (BF16) {
+                gemm::v4s hb[2];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const float4 a = *reinterpret_cast<const float4*>(W2s + (16 * jt + j16) * kFfPitch + 16 * c + 4 * g);
+                for (int t = 0; t < 2; ++t) { const uint2 q = gemm::bf16x4(make_float4(h[t][0], h[t][1], h[t][2], h[t][3])); hb[t] = *reinterpret_cast<const gemm::v4s*>(&q); }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc2[t][jt] = mfma16x16x4(a.x, h[t][0], acc2[t][jt]);
-                    acc2[t][jt] = mfma16x16x4(a.y, h[t][1], acc2[t][jt]);
-                    acc2[t][jt] = mfma16x16x4(a.z, h[t][2], acc2[t][jt]);
-                    acc2[t][jt] = mfma16x16x4(a.w, h[t][3], acc2[t][jt]);
+                for (int jt = 0; jt < 4; ++jt) {
+                    const gemm::v4s a = *reinterpret_cast<const gemm::v4s*>(W2s + (16 * jt + j16) * kPitch + 8 * c + 2 * g);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc2[t][jt] = gemm::mfma16x16x16_bf16(a, hb[t], acc2[t][jt]);
+                }
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const float4 a = *reinterpret_cast<const float4*>(W2s + (16 * jt + j16) * kPitch + 16 * c + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc2[t][jt] = mfma16x16x4(a.x, h[t][0], acc2[t][jt]);
+                        acc2[t][jt] = mfma16x16x4(a.y, h[t][1], acc2[t][jt]);
+                        acc2[t][jt] = mfma16x16x4(a.z, h[t][2], acc2[t][jt]);
+                        acc2[t][jt] = mfma16x16x4(a.w, h[t][3], acc2[t][jt]);
+                    }
                 }
             }
         }
-        if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * (2 * kFfChunk * kFfPitch));      // the other buffer: last read in iteration cg - 1, behind that iteration's barrier
+        if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * (2 * kFfChunk * kPitch));      // the other buffer: last read in iteration cg - 1, behind that iteration's barrier
         __syncthreads();
     }
     // lane (g, j16): output columns 16 jt + 4 g .. + 3 of row j16 of tile t
@@ -573,6 +607,14 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
             *reinterpret_cast<float4*>(out + at + 16 * jt) = o;
         }
     }
+}
+
+template <int MODE>
+inline void launch_zip_ff(hipStream_t s, bool bf16, int M, const float* xin, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, const float* cmid,
+                          float* out, int fd) {
+    const dim3 grid((unsigned)((M + kFfRows - 1) / kFfRows));
+    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff<MODE, true>), grid, dim3(512), kFfLdsB, s, xin, w1, b1, w2, b2, res, cmid, out, M, fd);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff<MODE, false>), grid, dim3(512), kFfLds, s, xin, w1, b1, w2, b2, res, cmid, out, M, fd);
 }
 
 struct AddFromStore {          // y[m][n] = x[m][n] + v + bias[n]     (the layer's first residual: x stays the layer input, :146, :160)
@@ -1234,9 +1276,9 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     for (auto& f : fix) *f.first = e->d_w + f.second;
     if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the feed-forward kernel"));
     *out = e;
     return ADE_OK;
@@ -1311,13 +1353,11 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
-    // feed-forward modules run fused (k_zip_ff) on the exact path when their width is a multiple of the 64-unit weight chunk
-    auto fused_ff = [&](int fd) { return !bf16 && C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
-    const dim3 ffg((unsigned)((M + kFfRows - 1) / kFfRows));
+    // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
+    auto fused_ff = [&](int fd) { return C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
     if (fused_ff(ff1)) {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim, bf16);                               // (:148-153) attention part of the joint projection
-        hipLaunchKernelGGL(k_zip_ff<0>, ffg, dim3(512), kFfLds, s, (const float*)x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b,
-                           (const float*)x, (const float*)nullptr, Y, M, ff1);                                                    // (:160)
+        launch_zip_ff<0>(s, bf16, M, x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b, x, nullptr, Y, ff1);        // (:160)
     } else {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp, bf16);                                    // (:148-153)
         launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                  // (:160)
@@ -1337,10 +1377,8 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, Seq
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C, bf16);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
         if (fused_ff(fd)) {
-            if (i == 0) hipLaunchKernelGGL(k_zip_ff<2>, ffg, dim3(512), kFfLds, s, (const float*)Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], (const float*)x,
-                                           w.bypass_mid, Y, M, fd);                                                               // (:170-171)
-            else hipLaunchKernelGGL(k_zip_ff<1>, ffg, dim3(512), kFfLds, s, (const float*)Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], (const float*)nullptr,
-                                    (const float*)nullptr, Y, M, fd);                                                             // (:174)
+            if (i == 0) launch_zip_ff<2>(s, bf16, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
+            else launch_zip_ff<1>(s, bf16, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
             continue;
         }
         launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd, bf16);
