@@ -279,11 +279,16 @@ constexpr int kKvStride = 68;      // floats per staged row: 16 rows x one float
 // chunk (after all four score tiles), not once per 16 keys.  A wave owns QT tiles of 16 queries: every K / V operand read from LDS feeds QT MFMA chains, so with
 // QT = 2 (sequences longer than 64) a chunk is 128 + 128 MFMAs per wave against 32 ds_read_b128 -- at QT = 1 the sixteen waves of a CU ask LDS for its full
 // 128 bytes per cycle and the matrix cores wait for it.
-template <int QT>
+// BF16 = true (ade_gemm_dtype = bf16): Q, K, V and the probabilities enter the matrix cores as bf16 (v_mfma_f32_16x16x16_bf16: a lane supplies four CONSECUTIVE k, which
+// for the P . V product are exactly its four score registers); scores, softmax statistics and the output accumulate in fp32.  K / V chunks are staged as bf16 (34-word
+// pitch): an eighth of the MFMA time and half the LDS traffic of the fp32 form.
+constexpr int kKvStrideB = 34;     // 32-bit words per staged bf16 row (64 values + 2 words: conflict-free ds_read_b64)
+template <int QT, bool BF16>
 __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq,
                                                       int di) {
-    __shared__ __attribute__((aligned(16))) float Ks[kKc * kKvStride];         // [key][dim]
-    __shared__ __attribute__((aligned(16))) float Vt[kDh * kKvStride];         // [dim][key]
+    constexpr int kPitch = BF16 ? kKvStrideB : kKvStride;
+    __shared__ __attribute__((aligned(16))) float Ks[kKc * kPitch];            // [key][dim]
+    __shared__ __attribute__((aligned(16))) float Vt[kDh * kPitch];            // [dim][key]
     constexpr int kQw = 16 * QT, kQb = 4 * kQw;                                 // queries per wave / per workgroup
     const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, g = lane >> 4;
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
     bool q_ok[QT];
     size_t qrow[QT];
     float4 qreg[QT][4];                                                         // Q[query j16 of tile t][d = 16 ks + 4 g + s] (rotary applied by the in-projection's store)
+    gemm::v4s qb[QT][4];                                                        // the same as four bf16 (BF16 only)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         qi[t] = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;              // this lane's query of tile t
@@ -300,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
         const float* src = qkvg + qrow[t] * ldq + head * kDh + 4 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float4 v = *reinterpret_cast<const float4*>(src + 16 * ks);
-            qreg[t][ks] = q_ok[t] ? v : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qreg[t][ks] = keep4(q_ok[t], *reinterpret_cast<const float4*>(src + 16 * ks));
+            if constexpr (BF16) { const uint2 q = gemm::bf16x4(qreg[t][ks]); qb[t][ks] = *reinterpret_cast<const gemm::v4s*>(&q); }
         }
     }
     float m[QT], l[QT];
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
     const bool wave_live = (int)blockIdx.z * kQb + wave * kQw < n;             // a wave whose queries are all padding only helps loading
 
     // K / V staging, software-pipelined: the 64 keys of chunk c + 1 are requested into registers (four 16-byte K and V pieces per lane: key p = i >> 4, dims 4 (i & 15) ..)
-    // right after chunk c has been written to LDS, and land under chunk c's 256 MFMAs.  Padded keys are zero rows: their p is 0 and 0 * 0 stays 0.
+    // right after chunk c has been written to LDS, and land under chunk c's MFMAs.  Padded keys are zero rows: their p is 0 and 0 * 0 stays 0.
     float4 pk[4], pv[4];
     auto request = [&](int c0) {
 #pragma unroll
@@ -324,9 +330,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
             const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4, key = c0 + p;
             const bool ok = key < n;
             const float* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + d;
-            const float4 k4 = *reinterpret_cast<const float4*>(src + di), v4 = *reinterpret_cast<const float4*>(src + 2 * di);
-            pk[u] = ok ? k4 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            pv[u] = ok ? v4 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            pk[u] = keep4(ok, *reinterpret_cast<const float4*>(src + di));
+            pv[u] = keep4(ok, *reinterpret_cast<const float4*>(src + 2 * di));
         }
     };
     request(0);
@@ -335,8 +340,17 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4;
-            *reinterpret_cast<float4*>(Ks + p * kKvStride + d) = pk[u];
-            Vt[d * kKvStride + p] = pv[u].x; Vt[(d + 1) * kKvStride + p] = pv[u].y; Vt[(d + 2) * kKvStride + p] = pv[u].z; Vt[(d + 3) * kKvStride + p] = pv[u].w;
+            if constexpr (BF16) {
+                *reinterpret_cast<uint2*>(Ks + p * kPitch + d / 2) = gemm::bf16x4(pk[u]);
+                unsigned short* vt = reinterpret_cast<unsigned short*>(Vt);
+                vt[d * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].x);
+                vt[(d + 1) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].y);
+                vt[(d + 2) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].z);
+                vt[(d + 3) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].w);
+            } else {
+                *reinterpret_cast<float4*>(Ks + p * kPitch + d) = pk[u];
+                Vt[d * kPitch + p] = pv[u].x; Vt[(d + 1) * kPitch + p] = pv[u].y; Vt[(d + 2) * kPitch + p] = pv[u].z; Vt[(d + 3) * kPitch + p] = pv[u].w;
+            }
         }
         __syncthreads();
         if (c0 + kKc < n) request(c0 + kKc);
@@ -348,13 +362,19 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
             for (int t = 0; t < QT; ++t) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kKvStride + 16 * ks + 4 * g);
+                if constexpr (BF16) {
+                    const gemm::v4s kb = *reinterpret_cast<const gemm::v4s*>(Ks + (16 * kt + j16) * kPitch + 8 * ks + 2 * g);
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
-                    st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
-                    st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
-                    st[t][kt] = mfma16x16x4(kv.w, qreg[t][ks].w, st[t][kt]);
+                    for (int t = 0; t < QT; ++t) st[t][kt] = gemm::mfma16x16x16_bf16(kb, qb[t][ks], st[t][kt]);
+                } else {
+                    const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kPitch + 16 * ks + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
+                        st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
+                        st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
+                        st[t][kt] = mfma16x16x4(kv.w, qreg[t][ks].w, st[t][kt]);
+                    }
                 }
             }
         }
@@ -385,18 +405,30 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
             for (int dt = 0; dt < 4; ++dt) acc[t][dt] = acc[t][dt] * alpha;
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+            gemm::v4s pb[QT];
+            if constexpr (BF16) {
+#pragma unroll
+                for (int t = 0; t < QT; ++t) { const uint2 q = gemm::bf16x4(make_float4(st[t][kt][0], st[t][kt][1], st[t][kt][2], st[t][kt][3])); pb[t] = *reinterpret_cast<const gemm::v4s*>(&q); }
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kKvStride + 16 * kt + 4 * g);   // V^T[dim 16 dt + j16][keys 16 kt + 4 g ..]
+                if constexpr (BF16) {
+                    const gemm::v4s vb = *reinterpret_cast<const gemm::v4s*>(Vt + (16 * dt + j16) * kPitch + 8 * kt + 2 * g);   // V^T[dim 16 dt + j16][keys 16 kt + 4 g ..]
 #pragma unroll
-                for (int t = 0; t < QT; ++t) {
-                    acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
-                    acc[t][dt] = mfma16x16x4(vv.y, st[t][kt][1], acc[t][dt]);
-                    acc[t][dt] = mfma16x16x4(vv.z, st[t][kt][2], acc[t][dt]);
-                    acc[t][dt] = mfma16x16x4(vv.w, st[t][kt][3], acc[t][dt]);
+                    for (int t = 0; t < QT; ++t) acc[t][dt] = gemm::mfma16x16x16_bf16(vb, pb[t], acc[t][dt]);
+                } else {
+                    const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kPitch + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
+                        acc[t][dt] = mfma16x16x4(vv.y, st[t][kt][1], acc[t][dt]);
+                        acc[t][dt] = mfma16x16x4(vv.z, st[t][kt][2], acc[t][dt]);
+                        acc[t][dt] = mfma16x16x4(vv.w, st[t][kt][3], acc[t][dt]);
+                    }
                 }
             }
+        }
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -716,11 +748,14 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     const int ldq = 3 * di + heads;
     // invn holds 1 / |x_row| on entry (written by whoever produced X)
     launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, RotaryQkStore{bufA, invn, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim, bf16);   // (:547-548, :552)
-    if (n > 64)                                                                                                              // (:549-560)
-        hipLaunchKernelGGL(k_attention<2>, dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s, (const float*)bufA, AO, n,
-                           seq_stride, pos_stride, ldq, di);
-    else
-        hipLaunchKernelGGL(k_attention<1>, dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    const dim3 g2((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), g1((unsigned)nseq, (unsigned)heads, 1);            // (:549-560)
+    if (n > 64) {
+        if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<2, true>), g2, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<2, false>), g2, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    } else {
+        if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<1, true>), g1, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<1, false>), g1, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    }
     launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di, bf16);                               // (:561, :569)
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim, bf16);               // (:564)
