@@ -76,6 +76,8 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                                           float* As_all, float* Bs_all) {
     constexpr int kRowW = BF16 ? kRow / 2 : kRow;      // row pitch in 32-bit words (bf16: 16 values + 4 padding = 10 words)
     constexpr int kSlabW = kTM * kRowW;                // words per staged 16-k slab
+    constexpr int kS = kSub;                           // (two bf16 slabs per barrier pair -- same LDS -- measured: Mel-Band bf16 447 -> 441 ms but MossFormer bf16 538 -> 585 ms: the extra
+                                                       // prefetch registers spill under the 128-VGPR cap)
     auto put4 = [&](float* base, int row, int kk, const float4& v) {           // four consecutive k of one row
         if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kk / 2) = bf16x4(v);
         else *reinterpret_cast<float4*>(base + row * kRow + kk) = v;
@@ -102,7 +104,7 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
     // that each copy keeps only its own addressing live (one loop with both paths hoists the address registers of both).
     auto k_loop = [&](auto av_c, auto bv_c) {
     constexpr bool a_v4 = decltype(av_c)::value, b_v4 = decltype(bv_c)::value;
-    float4 ra[kSub][2], rb[kSub][2];
+    float4 ra[kS][2], rb[kS][2];
     auto fetch = [&](int k0, int sub) {
         if (a_v4) {                         // lane = (row, quarter): 4 lanes read one row's 64-byte line; rows r and r + 64
             if constexpr (AL::kAlongK && HasVec4<AL>::value) {
@@ -224,7 +226,7 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             }
     };
     if constexpr (kDouble) {
-        static_assert(!kDouble || kSub == 1, "the double-buffered loop stages one slab at a time");
+        static_assert(!kDouble || (kSub == 1 && !BF16), "the double-buffered loop stages one f32 slab at a time");
         fetch(0, 0);
         stash(0, 0);
         __syncthreads();
@@ -239,17 +241,17 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
         }
     } else {
 #pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) fetch(kTK * sub, sub);
-        for (int k0 = 0; k0 < K; k0 += kTK * kSub) {
+        for (int sub = 0; sub < kS; ++sub) fetch(kTK * sub, sub);
+        for (int k0 = 0; k0 < K; k0 += kTK * kS) {
 #pragma unroll
-            for (int sub = 0; sub < kSub; ++sub) stash(sub, sub);
+            for (int sub = 0; sub < kS; ++sub) stash(sub, sub);
             __syncthreads();
-            if (k0 + kTK * kSub < K) {
+            if (k0 + kTK * kS < K) {
 #pragma unroll
-                for (int sub = 0; sub < kSub; ++sub) fetch(k0 + kTK * (kSub + sub), sub);
+                for (int sub = 0; sub < kS; ++sub) fetch(k0 + kTK * (kS + sub), sub);
             }
 #pragma unroll
-            for (int sub = 0; sub < kSub; ++sub) {
+            for (int sub = 0; sub < kS; ++sub) {
                 if (sub > 0 && k0 + kTK * sub >= K) break;                    // the tail of K (uniform)
                 compute(sub);
             }
