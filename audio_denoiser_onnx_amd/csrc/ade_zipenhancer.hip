@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_zip_norm_apply(float* __restrict__ x, c
     st4(x + tok * C + c, v);
 }
 
-// ---- implicit-GEMM operand: one layer of a causal dense block (:701-757) ---------------------------------------------------------
+// ---- one layer of a causal dense block (:701-757) as an implicit GEMM ----------------------------------------------------------------
 // A(token, k): k = tap * cin + ci, tap = kt * 3 + kf; the value is input channel ci of position (t - (1 - kt) dil, f + kf - 1), zero outside the
 // map.  Input channels are [this group's newer dense outputs ..., block input]: the first hist_n live in `hist` (normalised + PReLU'd in place by
 // k_zip_hist_norm once their producer's statistics were known), the last C in `inp`.
@@ -252,29 +252,8 @@ __global__ __launch_bounds__(256) void k_zip_hist_norm(float* __restrict__ hist,
     float4* p = reinterpret_cast<float4*>(hist + tok * ld + ch);
     *p = norm_prelu4(*p, nrm + ((size_t)b * ld + ch) * 2, slope + ch);
 }
-struct DenseA {
-    static constexpr int kWavesPerSimd = 3;
-    const float* hist;     // [tokens][hist_ld]
-    const float* inp;      // [tokens][C]
-    int hist_ld, hist_off, hist_n, cin, C, T, F, dil;
-    struct Row { int b, t, f; };
-    __device__ Row row(int m) const {
-        const int tf = T * F, b = m / tf, rem = m - b * tf, t = rem / F;
-        return Row{b, t, rem - t * F};
-    }
-    // Branch-free on purpose: an early return around the loads makes the compiler fence each fetch with s_waitcnt vmcnt(0), which serialises the four row fetches of a
-    // slab and lands them BEFORE the slab's MFMAs instead of under them.  Out-of-map taps read token 0 and are zeroed afterwards.
-    __device__ float4 vec4(const Row& r, int k) const {
-        const int tap = k / cin, ci = k - tap * cin, kt = tap >= 3 ? 1 : 0, kf = tap - 3 * kt;
-        const int t2 = r.t - (1 - kt) * dil, f2 = r.f + kf - 1;
-        const bool ok = t2 >= 0 && f2 >= 0 && f2 < F, from_hist = ci < hist_n;
-        const size_t tok = ok ? ((size_t)r.b * T + t2) * F + f2 : 0;
-        const float* src = from_hist ? hist + tok * hist_ld + hist_off + ci : inp + tok * C + (ci - hist_n);
-        return keep4(ok, *reinterpret_cast<const float4*>(src));
-    }
-};
-// ---- dense-block layer as its own token-tiled kernel: the three frequency taps of a time tap share ONE staged operand -------------------------------------------
-// The generic implicit GEMM above fetches every (token, channel) six times, once per tap.  Taps (kt, kf = 0..2) of one kt read the SAME 16-channel slab of the
+// The token-tiled kernel: the three frequency taps of a time tap share ONE staged operand.
+// A generic implicit GEMM (one fetch per (token, tap, channel): the first round-2 form, 84 TFLOP/s) reads every (token, channel) six times.  Taps (kt, kf = 0..2) of one kt read the SAME 16-channel slab of the
 // same rows shifted by -1 / 0 / +1 token, so this kernel stages rows m_blk - 1 .. m_blk + 256 of a (kt, channel block) once and runs the three kf products
 // against it (the A operand of tap kf is LDS row r + kf; positions whose neighbour lies outside the map -- f = 0 for kf = 0, f = F - 1 for kf = 2 -- are zeroed
 // in the operand register): a third of the global / L2 operand traffic, a third of the staging stores and barriers per MFMA.  256 tokens x 64 output
@@ -420,7 +399,7 @@ struct RowConvA {
         const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
         return Row{((long long)b * T + t) * Fin, f * stride - 1};
     }
-    __device__ float4 vec4(const Row& r, int k) const {                  // branch-free, like DenseA::vec4
+    __device__ float4 vec4(const Row& r, int k) const {                  // branch-free: clamped address, zeroed afterwards (a branch around the load would fence it)
         const int kf = k / C, ci = k - kf * C, f2 = r.f0 + kf;
         const bool ok = f2 >= 0 && f2 < Fin;
         const int ch = ch0 + ci;
@@ -1325,16 +1304,11 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            if (C == 64) {
-                const dim3 grid((unsigned)((M + 255) / 256));
-                if (bf16) hipLaunchKernelGGL(k_zip_dense<true>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
-                                             d.b[g][i], Dh, ld, off_out, M);
-                else hipLaunchKernelGGL(k_zip_dense<false>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
-                                        d.b[g][i], Dh, ld, off_out, M);
-            } else {
-                gemm64::launch(s, DenseA{Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, C, T, Fd, 1 << i}, gemm64::WeightB{d.w[g][i], 6 * cin},
-                               BiasColStore{Dh, d.b[g][i], ld, off_out}, M, C, 6 * cin, bf16);
-            }
+            const dim3 grid((unsigned)((M + 255) / 256));             // (C == 64: checked at create)
+            if (bf16) hipLaunchKernelGGL(k_zip_dense<true>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
+                                         d.b[g][i], Dh, ld, off_out, M);
+            else hipLaunchKernelGGL(k_zip_dense<false>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
+                                    d.b[g][i], Dh, ld, off_out, M);
             stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = (long long)M * 16;
             hipLaunchKernelGGL(k_zip_hist_norm, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, Dh, ld, off_out, (const float*)nrm, d.slope, T * Fd, total16);
