@@ -50,7 +50,8 @@ struct SigmoidTStore {         // mask[j][f] = sigmoid(v + bias[f]): the last Li
     __device__ void operator()(int f, int j, float v, float b, gemm::None, gemm::None) const { out[(size_t)j * kStBins + f] = 1.0f / (1.0f + expf(-(v + b))); }
 };
 
-// One workgroup per frame: [Kaldi filter-bank power | mask STFT] of the frame's 1920 samples.
+// One workgroup per PAIR of frames: [Kaldi filter-bank power | mask STFT] of each frame's 1920 samples.  Both transforms take real input, so the two frames ride one
+// complex FFT as real and imaginary part: Z = FFT(x0 + i x1), X0[f] = (Z[f] + conj Z[N - f]) / 2, X1[f] = (Z[f] - conj Z[N - f]) / (2 i) -- half the butterflies.
 //   x = samples * 2^-15 (:186-190); fbank branch: y = x - mean(x); z[n] = y[n] - 0.97 y[n - 1] (z[0] = 0.03 y[0]); * symmetric hamming; zero-pad to 2048;
 //   FFT; power = (re^2 + im^2) * 2^30 -- the steps Export_DFSMN.py:97-120 folds into its analysis matrix, in Kaldi's order.  STFT branch: x * hamming; FFT_1920.
 __global__ __launch_bounds__(256) void k_dfsmn_analysis(const int16_t* __restrict__ pcm, const float* __restrict__ fpcm, int L, int T, fft::Plan p2048, fft::Plan p1920,
@@ -58,55 +59,90 @@ __global__ __launch_bounds__(256) void k_dfsmn_analysis(const int16_t* __restric
                                                         const float* __restrict__ win_st, float* __restrict__ power, float* __restrict__ spec) {
     __shared__ float2 A[kKaldiNfft];
     __shared__ float2 B[kKaldiNfft];
-    __shared__ double red[256];
-    const int frame = blockIdx.x, tid = threadIdx.x, b = frame / T, t = frame - b * T;
-    const size_t at = (size_t)b * L + (size_t)t * kHopD;
-    auto sample = [&](int n) { return (fpcm ? fpcm[at + n] : (float)pcm[at + n]) * (1.0f / 32768.0f); };
-    double part = 0.0;
-    for (int n = tid; n < kFrame; n += 256) part += (double)sample(n);
-    red[tid] = part;
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    int frame[2];
+    size_t at[2];
+    bool live[2];
+    const int ppr = (T + 1) / 2, b = (int)blockIdx.x / ppr, t0 = 2 * ((int)blockIdx.x - b * ppr);      // pairs never straddle two calls: a row's result must not depend
+#pragma unroll                                                                                          // on which row shares its transform (batch rows are independent calls)
+    for (int u = 0; u < 2; ++u) {
+        live[u] = t0 + u < T;
+        const int t = live[u] ? t0 + u : t0;
+        frame[u] = b * T + t;
+        at[u] = (size_t)b * L + (size_t)t * kHopD;
+    }
+    auto sample = [&](int u, int n) { return (fpcm ? fpcm[at[u] + n] : (float)pcm[at[u] + n]) * (1.0f / 32768.0f); };
+    double part[2] = {0.0, 0.0};
+    for (int n = tid; n < kFrame; n += 256) { part[0] += (double)sample(0, n); part[1] += (double)sample(1, n); }
+    red[0][tid] = part[0];
+    red[1][tid] = part[1];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
         __syncthreads();
     }
-    const float mean = (float)(red[0] / (double)kFrame);
+    const float mean[2] = {(float)(red[0][0] / (double)kFrame), (float)(red[1][0] / (double)kFrame)};
     for (int n = tid; n < kKaldiNfft; n += 256) {
-        float v = 0.0f;
+        float v[2] = {0.0f, 0.0f};
         if (n < kFrame) {
-            const float y = sample(n) - mean, yp = sample(n > 0 ? n - 1 : 0) - mean;
-            v = (y - 0.97f * yp) * win_fb[n];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float y = sample(u, n) - mean[u], yp = sample(u, n > 0 ? n - 1 : 0) - mean[u];
+                v[u] = live[u] ? (y - 0.97f * yp) * win_fb[n] : 0.0f;          // an odd row's last frame is paired with zeros
+            }
         }
-        A[n] = make_float2(v, 0.0f);
+        A[n] = make_float2(v[0], v[1]);
     }
     float2* r = fft::forward(A, B, p2048, tw2048, tid, 256);
-    for (int f = tid; f < kFbBins; f += 256) power[(size_t)frame * kFbBins + f] = (r[f].x * r[f].x + r[f].y * r[f].y) * (32768.0f * 32768.0f);
+    for (int f = tid; f < kFbBins; f += 256) {
+        const float2 z = r[f], zc = r[f == 0 ? 0 : kKaldiNfft - f];
+        const float re0 = 0.5f * (z.x + zc.x), im0 = 0.5f * (z.y - zc.y), re1 = 0.5f * (z.y + zc.y), im1 = 0.5f * (zc.x - z.x);
+        if (live[0]) power[(size_t)frame[0] * kFbBins + f] = (re0 * re0 + im0 * im0) * (32768.0f * 32768.0f);
+        if (live[1]) power[(size_t)frame[1] * kFbBins + f] = (re1 * re1 + im1 * im1) * (32768.0f * 32768.0f);
+    }
     __syncthreads();
-    for (int n = tid; n < kNfftD; n += 256) A[n] = make_float2(sample(n) * win_st[n], 0.0f);
+    for (int n = tid; n < kNfftD; n += 256) { const float w = win_st[n]; A[n] = make_float2(sample(0, n) * w, live[1] ? sample(1, n) * w : 0.0f); }
     r = fft::forward(A, B, p1920, tw1920, tid, 256);
     for (int f = tid; f < kStBins; f += 256) {
-        spec[(size_t)frame * 2 * kStBins + f] = r[f].x;
-        spec[(size_t)frame * 2 * kStBins + kStBins + f] = r[f].y;
+        const float2 z = r[f], zc = r[f == 0 ? 0 : kNfftD - f];
+        if (live[0]) {
+            spec[(size_t)frame[0] * 2 * kStBins + f] = 0.5f * (z.x + zc.x);
+            spec[(size_t)frame[0] * 2 * kStBins + kStBins + f] = 0.5f * (z.y - zc.y);
+        }
+        if (live[1]) {
+            spec[(size_t)frame[1] * 2 * kStBins + f] = 0.5f * (z.y + zc.y);
+            spec[(size_t)frame[1] * 2 * kStBins + kStBins + f] = 0.5f * (zc.x - z.x);
+        }
     }
 }
 
-// One workgroup per frame: mask * spectrum (:236-237) -> Hermitian extension -> inverse FFT_1920 -> * periodic hamming / N = the reference's inverse table applied to the
-// masked half spectrum (its sine rows of the DC and Nyquist bins are zero, so their imaginary parts do not contribute: set to zero here).
-// x N = sum_f Z[f] e^{+i theta} = conj(DFT(conj Z)); Z is Hermitian, so the result is real: Re DFT(conj Z).
-__global__ __launch_bounds__(256) void k_dfsmn_synthesis(const float* __restrict__ spec, const float* __restrict__ mask, fft::Plan p1920, const float2* __restrict__ tw1920,
+// One workgroup per PAIR of frames: mask * spectrum (:236-237) -> Hermitian extension -> inverse FFT_1920 -> * periodic hamming / N = the reference's inverse table applied
+// to the masked half spectrum (its sine rows of the DC and Nyquist bins are zero, so their imaginary parts do not contribute: set to zero here).
+// x N = sum_f Z[f] e^{+i theta} = conj(DFT(conj Z)) with Z Hermitian; two frames share one transform as W = H(Z0) + i H(Z1): x0 + i x1 = conj(DFT(conj W)) / N.
+__global__ __launch_bounds__(256) void k_dfsmn_synthesis(const float* __restrict__ spec, const float* __restrict__ mask, int T, fft::Plan p1920, const float2* __restrict__ tw1920,
                                                          const float* __restrict__ win_syn, float* __restrict__ frames) {
     __shared__ float2 A[kNfftD];
     __shared__ float2 B[kNfftD];
-    const int frame = blockIdx.x, tid = threadIdx.x;
-    const float* sp = spec + (size_t)frame * 2 * kStBins;
-    const float* mk = mask + (size_t)frame * kStBins;
+    const int tid = threadIdx.x, ppr = (T + 1) / 2, b = (int)blockIdx.x / ppr, t0 = 2 * ((int)blockIdx.x - b * ppr);   // pairs inside one call's row, as in the analysis
+    const int f0 = b * T + t0, f1 = f0 + 1;
+    const bool two = t0 + 1 < T;
+    const float *sp0 = spec + (size_t)f0 * 2 * kStBins, *mk0 = mask + (size_t)f0 * kStBins;
+    const float *sp1 = spec + (size_t)(two ? f1 : f0) * 2 * kStBins, *mk1 = mask + (size_t)(two ? f1 : f0) * kStBins;
     for (int f = tid; f < kStBins; f += 256) {
-        const float m = mk[f], re = sp[f] * m, im = (f == 0 || f == kStBins - 1) ? 0.0f : sp[kStBins + f] * m;
-        A[f] = make_float2(re, -im);                                   // conj Z[f]
-        if (f > 0 && f < kStBins - 1) A[kNfftD - f] = make_float2(re, im);   // conj Z[N - f] = Z[f]
+        const bool edge = f == 0 || f == kStBins - 1;
+        const float m0 = mk0[f], m1 = two ? mk1[f] : 0.0f;
+        const float2 z0 = make_float2(sp0[f] * m0, edge ? 0.0f : sp0[kStBins + f] * m0), z1 = make_float2(sp1[f] * m1, edge ? 0.0f : sp1[kStBins + f] * m1);
+        // W[f] = z0 + i z1 = (z0.x - z1.y, z0.y + z1.x); W[N - f] = conj z0 + i conj z1 = (z0.x + z1.y, z1.x - z0.y); both stored conjugated
+        A[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
+        if (!edge) A[kNfftD - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
     }
     const float2* r = fft::forward(A, B, p1920, tw1920, tid, 256);
-    for (int n = tid; n < kNfftD; n += 256) frames[(size_t)frame * kNfftD + n] = (r[n].x * (1.0f / (float)kNfftD)) * win_syn[n];
+    for (int n = tid; n < kNfftD; n += 256) {
+        const float w = win_syn[n];
+        frames[(size_t)f0 * kNfftD + n] = (r[n].x * (1.0f / (float)kNfftD)) * w;
+        if (two) frames[(size_t)f1 * kNfftD + n] = (-r[n].y * (1.0f / (float)kNfftD)) * w;
+    }
 }
 
 // causal depthwise memory + outer residual: x[c][j] += sum_k w[c][k] * p1[c][j - (lo-1) + k], zero before the row's first frame (:228-229)
@@ -117,9 +153,12 @@ __global__ __launch_bounds__(256) void k_fsmn_memory(const float* __restrict__ p
     const int c = (int)(i / N), j = (int)(i - (long long)c * N);
     const int t = j % T;
     float s = 0.0f;
-    for (int k = 0; k < lo; ++k) {
+    const float* row = p1 + (size_t)c * N + j;
+    for (int k = 0; k < lo; ++k) {                   // unconditional loads from clamped frames, masked afterwards: a branch around each load would serialise the taps
         const int dt = k - (lo - 1);
-        if (t + dt >= 0) s += w[c * lo + k] * p1[(size_t)c * N + j + dt];
+        const bool ok = t + dt >= 0;
+        const float v = row[ok ? dt : 0];
+        s += ok ? w[c * lo + k] * v : 0.0f;
     }
     x[i] += s;
 }
@@ -307,7 +346,7 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
     using namespace gemm;
     const int N = batch * d->T;
     // analysis: Kaldi filter-bank power and the mask STFT of every frame as FFTs                              (Export_DFSMN.py:205-209, 216)
-    hipLaunchKernelGGL(k_dfsmn_analysis, dim3((unsigned)N), dim3(256), 0, s, d_in, float_in, d->in_len_, d->T, d->p2048, d->p1920, d->tw2048, d->tw1920, d->win_fb, d->win_st,
+    hipLaunchKernelGGL(k_dfsmn_analysis, dim3((unsigned)(batch * ((d->T + 1) / 2))), dim3(256), 0, s, d_in, float_in, d->in_len_, d->T, d->p2048, d->p1920, d->tw2048, d->tw1920, d->win_fb, d->win_st,
                        d->power, d->spec);
     // Kaldi log-mel: mel_banks x power, clamp(eps), log                                                  (:216-217)
     launch(s, RowMajorA{d->mel, kFbBins}, PowerFrameB{d->power}, BiasActStore<kActLogFloor>{d->feat, N, nullptr, 1.1920928955078125e-07f}, kMel, N, kFbBins);
@@ -322,7 +361,7 @@ int DfsmnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_o
     }
     launch(s, RowMajorA{d->lin2_w, kHid}, RowMajorB{d->x, N}, SigmoidTStore{d->mask, d->lin2_b}, kStBins, N, kHid);
     // masked spectrum -> ISTFT frames, then overlap-add + PCM tail                                        (:236-244)
-    hipLaunchKernelGGL(k_dfsmn_synthesis, dim3((unsigned)N), dim3(256), 0, s, (const float*)d->spec, (const float*)d->mask, d->p1920, d->tw1920, d->win_syn, d->frames_buf);
+    hipLaunchKernelGGL(k_dfsmn_synthesis, dim3((unsigned)(batch * ((d->T + 1) / 2))), dim3(256), 0, s, (const float*)d->spec, (const float*)d->mask, d->T, d->p1920, d->tw1920, d->win_syn, d->frames_buf);
     const long long total = (long long)batch * d->out_len_;
     hipLaunchKernelGGL(k_dfsmn_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)d->frames_buf, d->wsum, d_out, d_f32, d->T,
                        d->out_len_, total);
