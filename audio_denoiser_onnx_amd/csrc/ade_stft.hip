@@ -133,17 +133,20 @@ __global__ __launch_bounds__(256) void k_stft_fft_analyze(const float* __restric
         A[n] = v;
     }
     const float2* r = fft::forward(A, B, plan, tw, lt, per);
-    if (!live) return;
-    float* re = spec + (size_t)b * d.F2 * T + t0;
+    // the spectrum is (bin, frame) with the frame fastest: the whole workgroup writes its 2 G consecutive frames of one bin together (one 8 G-byte run per bin and part
+    // instead of 4-byte stores a row pitch apart); every group's result sits at the same offset of its own pair of buffers
+    const size_t roff = (size_t)(r - A);
+    const int nt = 2 * G, tb = 2 * ((int)blockIdx.x - b * bpr) * G;
+    float* re = spec + (size_t)b * d.F2 * T;
     float* im = re + (size_t)F * T;
-    for (int f = lt; f < F; f += per) {
-        const float2 z = r[f], zc = r[f == 0 ? 0 : N - f];
-        re[(size_t)f * T] = 0.5f * (z.x + zc.x);
-        im[(size_t)f * T] = 0.5f * (z.y - zc.y);
-        if (two) {
-            re[(size_t)f * T + 1] = 0.5f * (z.y + zc.y);
-            im[(size_t)f * T + 1] = 0.5f * (zc.x - z.x);
-        }
+    for (int idx = threadIdx.x; idx < F * nt; idx += 256) {
+        const int tl = idx & (nt - 1), f = idx / nt, t = tb + tl;
+        if (t >= T) continue;
+        const float2* rg = lds + (size_t)(tl >> 1) * 2 * N + roff;
+        const float2 z = rg[f], zc = rg[f == 0 ? 0 : N - f];
+        const bool odd = tl & 1;
+        re[(size_t)f * T + t] = odd ? 0.5f * (z.y + zc.y) : 0.5f * (z.x + zc.x);
+        im[(size_t)f * T + t] = odd ? 0.5f * (zc.x - z.x) : 0.5f * (z.y - zc.y);
     }
 }
 
@@ -158,6 +161,8 @@ __global__ __launch_bounds__(256) void k_stft_fft_synth(const float* __restrict_
     const int b = blockIdx.x / bpr, pair = (blockIdx.x - b * bpr) * G + g, t0 = 2 * pair;
     const bool live = pair < ppr, two = t0 + 1 < T;
     float2 *A = lds + (size_t)g * 2 * N, *B = A + N;
+    // load phase by the whole workgroup, pair index fastest: for one bin the G pairs' 2 G frames are adjacent in memory
+    const int tb = 2 * ((int)blockIdx.x - b * bpr) * G;
     auto bin = [&](int f, int t) -> float2 {
         float2 v;
         if (POLAR) {                                  // istft_A: real = mag cos(phase), imag = mag sin(phase)   (STFT_Process.py:343-347)
@@ -170,15 +175,15 @@ __global__ __launch_bounds__(256) void k_stft_fft_synth(const float* __restrict_
         if (f == 0 || (N % 2 == 0 && f == F - 1)) v.y = 0.0f;
         return v;
     };
-    for (int f = lt; f < F; f += per) {
+    for (int idx = threadIdx.x; idx < F * G; idx += 256) {
+        const int pl = idx & (G - 1), f = idx / G, t = tb + 2 * pl;
         float2 z0 = make_float2(0.0f, 0.0f), z1 = z0;
-        if (live) {
-            z0 = bin(f, t0);
-            if (two) z1 = bin(f, t0 + 1);
-        }
+        if (t < T) z0 = bin(f, t);
+        if (t + 1 < T) z1 = bin(f, t + 1);
+        float2* Ag = lds + (size_t)pl * 2 * N;
         // W[f] = z0 + i z1 = (z0.x - z1.y, z0.y + z1.x); W[N - f] = conj z0 + i conj z1 = (z0.x + z1.y, z1.x - z0.y); both stored conjugated
-        A[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
-        if (f > 0 && f < N - f) A[N - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
+        Ag[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
+        if (f > 0 && f < N - f) Ag[N - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
     }
     const float2* r = fft::forward(A, B, plan, tw, lt, per);
     if (!live) return;
