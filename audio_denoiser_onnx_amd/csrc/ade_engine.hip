@@ -61,6 +61,15 @@ struct ade_engine {
     bool rs_truncate_i32 = false;
     float *rs_in = nullptr, *rs_out = nullptr;
 
+    // GTCRN_CUSTOM's input / output sandwich (Export_GTCRN.py:636-693): float audio in, other sample rates and dynamic-length exports.  in_len / out_len above are the
+    // CALLER-side lengths; the model-rate ones live here.  The sandwich takes the multi-kernel launch sequence (its STFT reads the prepared fp32 waveform).
+    bool gt_sand = false, gt_float_in = false, gt_scale_first = false;
+    int gt_l1 = 0, gt_lm = 0, gt_keep = 0;            // stage-1 length, model-rate input length, model-rate output samples kept (256 T when dynamic)
+    float gt_lerp1 = 0.0f, gt_lerp2 = 0.0f, gt_gain = 1.0f, gt_lerp_out = 0.0f;
+    float *gt_tmp = nullptr, *gt_in = nullptr, *gt_wave = nullptr, *gt_mean = nullptr;
+    float* d_f32_in = nullptr;                        // staging of ade_process_f32
+    const float* cur_fin = nullptr;                   // the float input of the call being enqueued (float-input engines)
+
     hipStream_t stream = nullptr;
     float* d_weights = nullptr;
     int* d_ints = nullptr;
@@ -413,6 +422,7 @@ void free_workspace(ade_engine* e) {
     if (e->h_f32_out) hipHostFree(e->h_f32_out);
     if (e->rs_in) hipFree(e->rs_in);
     if (e->rs_out) hipFree(e->rs_out);
+    for (float** p : {&e->gt_tmp, &e->gt_in, &e->gt_wave, &e->gt_mean, &e->d_f32_in}) { if (*p) hipFree(*p); *p = nullptr; }
     e->rs_in = e->rs_out = nullptr;
     e->ws = nullptr;
     e->d_pcm_in = e->d_pcm_out = nullptr;
@@ -475,6 +485,13 @@ ade_status reserve(ade_engine* e, int batch) {
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
+    if (e->gt_sand) {
+        HIP_TRY(e, hipMalloc((void**)&e->gt_tmp, B * (size_t)e->gt_l1 * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->gt_in, B * (size_t)e->gt_lm * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->gt_wave, B * (size_t)e->gt_keep * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->gt_mean, B * sizeof(float)));
+        if (e->gt_float_in) HIP_TRY(e, hipMalloc((void**)&e->d_f32_in, B * (size_t)e->in_len * sizeof(float)));
+    }
     e->capacity = batch;
     return ADE_OK;
 }
@@ -513,7 +530,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     const int T = e->T, nfr = B * T;
     Seq q{e, s, prof};
     const View none{nullptr, nullptr};
-    const bool fused = e->use_fused && fused_supported(T);
+    const bool fused = e->use_fused && fused_supported(T) && !e->gt_sand;      // the sandwich (float audio / other rates / dynamic length) takes the multi-kernel sequence
     e->last_fused = fused;
     View x{e->e1, nullptr};
     if (fused) {
@@ -558,8 +575,16 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         return;
     }
     // ---- multi-kernel path (any T): channels-last tensors, deferred TRA gates (View)
-    q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean, e->n_win); q.end();
-    q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
+    if (e->gt_sand) {   // GTCRN_CUSTOM's input sandwich -> the final fp32 waveform at the model rate, which the STFT reads as it is   (Export_GTCRN.py:636-655)
+        q.begin("sandwich_in");
+        launch_gt_sandwich_in(s, e->cur_fin ? nullptr : d_in, e->cur_fin, B, e->in_len, e->gt_l1, e->gt_lm, e->gt_lerp1, e->gt_lerp2, e->gt_gain, e->gt_tmp, e->gt_mean,
+                              e->gt_in);
+        q.end();
+        q.begin("stft_feat"); launch_stft_pcm(s, nullptr, nullptr, B, e->gt_lm, T, e->tabs, e->erb_bm, e->spec, e->feat, true, e->gt_in); q.end();
+    } else {
+        q.begin("pcm_mean"); launch_pcm_mean(s, d_in, B, e->in_len, e->mean, e->n_win); q.end();
+        q.begin("stft_feat"); launch_stft_pcm(s, d_in, e->mean, B, e->in_len, T, e->tabs, e->erb_bm, e->spec, e->feat); q.end();
+    }
     q.begin("conv0"); launch_conv0(s, e->feat, e->en0, e->e0, nfr); q.end();
     q.begin("conv1"); launch_conv1(s, e->e0, e->en1, e->e1, nfr); q.end();
     for (int i = 0; i < 3; ++i) {   // Encoder GTConvBlocks (Export_GTCRN.py:502-504)
@@ -587,6 +612,12 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     q.begin("deconv3"); launch_deconv3(s, x, View{e->e1, nullptr}, e->de3, e->d3, nfr); q.end();
     q.begin("deconv4"); launch_deconv4(s, e->d3, e->e0, e->de4, e->mask, nfr); q.end();
     q.begin("istft_mask"); launch_istft_masked(s, e->spec, e->mask, e->erb_bs, e->tabs, e->frames, nfr); q.end();
+    if (e->gt_sand) {   // overlap-add (static or dynamic-length trim) and the output sandwich   (STFT_Process.py:326-341, Export_GTCRN.py:673-693)
+        q.begin("sandwich_out");
+        launch_gt_sandwich_out(s, e->frames, e->tabs, B, T, e->gt_keep, e->gt_wave, d_out, d_f32, e->out_len, e->gt_lerp_out, e->gt_scale_first);
+        q.end();
+        return;
+    }
     q.begin("ola_pcm"); launch_ola_pcm(s, e->frames, e->tabs, B, T, d_out, d_f32); q.end();
 }
 
@@ -631,7 +662,7 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     // depend on the caller's CPU (their workspace is reserved before capture; reserve() drops the graphs when it reallocates).  On the
     // bench host the replay measured the same as plain launches (MossFormer2, 1 window: 26.9 ms both ways): small batches are bound by
     // GPU-side kernel latency and by the few single-workgroup reductions, not by the host.
-    const bool one_kernel = !e->sub && e->use_fused && e->use_single && fused_supported(e->T);
+    const bool one_kernel = !e->sub && e->use_fused && e->use_single && fused_supported(e->T) && !e->gt_sand;
     if (e->use_graph && e->graph_supported && !one_kernel) {
         GraphEntry* hit = nullptr;
         for (auto& g : e->graphs)
@@ -889,15 +920,24 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
     bool dyn = false;
     if (!parse_bool(e->meta["dynamic_axes"], &dyn))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
-    if (dyn) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
     long sr_in = 0, sr_out = 0, sr_model = 0, L = 0;
     if (!parse_int(e->meta["in_sample_rate"], &sr_in) || !parse_int(e->meta["out_sample_rate"], &sr_out) ||
         !parse_int(e->meta["model_sample_rate"], &sr_model) || !parse_int(e->meta["input_audio_length"], &L))
         return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates / input_audio_length must be integers"));
-    if (sr_in != sr_model || sr_out != sr_model)
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "in/out sample rate != model sample rate (resampling path not implemented)"));
-    if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
-        return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
+    // GTCRN_CUSTOM's sandwich (Export_GTCRN.py:636-693).  A dynamic_axes export takes its frame count from the model-rate waveform and keeps 256 T samples of the
+    // overlap-add (STFT_Process.py:337-341); the engine still serves ONE input length per handle (the manifest's input_audio_length).  The STATIC export sizes its frame
+    // count from the input-rate length (:45), so other sample rates are only self-consistent with dynamic_axes = 1.
+    const bool rates_differ_g = sr_in != sr_model || sr_out != sr_model;
+    auto dtype_ok = [](const std::string& d) { return d == "INT16" || d == "F32" || d == "F16"; };
+    if (!dtype_ok(e->meta["input_audio_dtype"]) || !dtype_ok(e->meta["output_audio_dtype"]))
+        return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: input_audio_dtype / output_audio_dtype must be INT16, F32 or F16"));
+    const bool float_in = e->meta["input_audio_dtype"] != "INT16";       // F16 tensors cross the C ABI as fp32 (the host layer converts): the graph computes in fp32
+    if (rates_differ_g && !dyn)
+        return bail(fail(e, ADE_ERR_UNSUPPORTED, "gtcrn: in / out sample rates other than the model rate need dynamic_axes=1 (the static export sizes its frame count from "
+                                                 "the input-rate length, Export_GTCRN.py:45)"));
+    if (rates_differ_g && (sr_model != 16000 || sr_in < 1000 || sr_out < 1000 || sr_in > 384000 || sr_out > 384000))
+        return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
+    const bool sandwich = dyn || rates_differ_g || float_in;
     auto opt = [&](const char* k, const char* want) {
         auto it = e->meta.find(k);
         return it == e->meta.end() || it->second.empty() || it->second == want;
@@ -934,12 +974,43 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, std::string("metadata ") + k + " must be 1 for GTCRN"));
     if (L < kNfft / 2 + 2 || L > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
     e->in_len = (int)L;
-    e->T = e->in_len / kHop + 1;                 // STATIC_SIGNAL_LENGTH, Export_GTCRN.py:45
-    e->out_len = kHop * (e->T - 1);              // STFT_Process.py:169-176 with max_frames = T
     e->sample_rate = (int)sr_model;
-    if (e->meta.count("max_signal_length") && !e->meta["max_signal_length"].empty()) {
-        if (!parse_int(e->meta["max_signal_length"], &v) || v != e->T)
-            return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "max_signal_length does not equal input_audio_length // hop + 1"));
+    if (sandwich) {
+        if (fold) return bail(fail(e, ADE_ERR_UNSUPPORTED, "gtcrn: use_batch_fold with float audio, other sample rates or dynamic_axes is not implemented"));
+        // F.interpolate(scale_factor = f): floor(length * f) samples, source step 1 / f (the same evaluation order as the module's attributes, :623-626)
+        long Lm = L;
+        e->gt_l1 = (int)L;
+        if (sr_in != sr_model) {
+            const double f_in = 1.0 / ((double)sr_in / 16000.0);
+            Lm = (long)floor((double)L * f_in);
+            if (sr_in > sr_model) { e->gt_lerp1 = (float)(1.0 / f_in); e->gt_l1 = (int)Lm; }     // down: interpolate, scale, centre
+            else e->gt_lerp2 = (float)(1.0 / f_in);                                               // up: scale, centre, interpolate
+        }
+        if (Lm < kNfft / 2 + 2) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length is too short at the model rate"));
+        e->gt_sand = true;
+        e->gt_float_in = float_in;
+        e->gt_gain = float_in ? 1.0f : (float)(1.0 / 32768.0);
+        e->gt_lm = (int)Lm;
+        e->T = e->gt_lm / kHop + 1;
+        e->gt_keep = dyn ? kHop * e->T : kHop * (e->T - 1);                                       // STFT_Process.py:337-341 vs :169-176
+        long Lout = e->gt_keep;
+        if (sr_out != sr_model) {
+            const double f_out = (double)sr_out / 16000.0;
+            Lout = (long)floor((double)e->gt_keep * f_out);
+            e->gt_lerp_out = (float)(1.0 / f_out);
+            e->gt_scale_first = sr_out > sr_model;                                                // up: * 32767 BEFORE the interpolation (:680-688)
+        }
+        if (Lout < 1 || Lout > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "output length out of range"));
+        e->out_len = (int)Lout;
+        e->in_rate = (int)sr_in;
+        e->out_rate = (int)sr_out;
+    } else {
+        e->T = e->in_len / kHop + 1;                 // STATIC_SIGNAL_LENGTH, Export_GTCRN.py:45
+        e->out_len = kHop * (e->T - 1);              // STFT_Process.py:169-176 with max_frames = T
+        if (e->meta.count("max_signal_length") && !e->meta["max_signal_length"].empty()) {
+            if (!parse_int(e->meta["max_signal_length"], &v) || v != e->T)
+                return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "max_signal_length does not equal input_audio_length // hop + 1"));
+        }
     }
     ade_status st = parse_blob(e, weights, weights_nbytes);
     if (st != ADE_OK) return bail(st);
@@ -1014,6 +1085,7 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
 ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, void* hip_stream) {
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device: bad arguments");
+    if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_device_f32");
     HIP_TRY(h, hipSetDevice(h->device));
     const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
     ade_status st = reserve(h, rows);
@@ -1025,9 +1097,48 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
     return ADE_OK;
 }
 
+// fp32 audio in (input_audio_dtype F32 / F16): implemented for GTCRN handles (the sandwich path); out_pcm / out_f32 as in ade_process_device
+ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, int16_t* d_out, float* d_f32, void* hip_stream) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device_f32: bad arguments");
+    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16 (or its family has no float-input path): call ade_process_device");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    ade_status st = reserve(h, batch);
+    if (st != ADE_OK) return st;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    h->cur_fin = d_in;
+    st = run(h, s, reinterpret_cast<const int16_t*>(d_in), batch, d_out, d_f32);      // (the pointer only keys the graph cache: enqueue reads cur_fin)
+    h->cur_fin = nullptr;
+    if (st != ADE_OK) return st;
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* out_pcm, float* out_f32) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_f32: bad arguments");
+    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16 (or its family has no float-input path): call ade_process");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    ade_status st = reserve(h, batch);
+    if (st != ADE_OK) return st;
+    const size_t nin = (size_t)batch * h->in_len, nout = (size_t)batch * h->out_len;
+    HIP_TRY(h, hipMemcpyAsync(h->d_f32_in, in, nin * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->cur_fin = h->d_f32_in;
+    st = run(h, h->stream, reinterpret_cast<const int16_t*>(h->d_f32_in), batch, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
+    h->cur_fin = nullptr;
+    if (st != ADE_OK) return st;
+    if (out_pcm) HIP_TRY(h, hipMemcpyAsync(out_pcm, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(out_f32, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ADE_OK;
+}
+
 ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32) {
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process: bad arguments");
+    if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_f32");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     const int rows = batch * h->n_win;
@@ -1199,7 +1310,7 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
     if (!out) return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_create: out is NULL");
     *out = nullptr;
     if (!h) return ADE_ERR_BAD_VALUE;
-    if (h->sub || h->n_win != 1) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stream_create: streaming is implemented for plain GTCRN handles");
+    if (h->sub || h->n_win != 1 || h->gt_sand) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stream_create: streaming is implemented for plain GTCRN handles (int16 audio at the model rate)");
     if (n_streams < 1 || frames_per_push < 2 || frames_per_push > 4096)
         return fail(h, ADE_ERR_BAD_VALUE, "ade_stream_create: need n_streams >= 1 and 2 <= frames_per_push <= 4096 (the first push reflects 257 samples)");
     HIP_TRY(h, hipSetDevice(h->device));

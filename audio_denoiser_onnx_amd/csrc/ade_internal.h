@@ -88,7 +88,12 @@ struct DpW {               // one DPGRNN block
 // ---- launchers (ade_kernels.hip) ---------------------------------------------------------------------------
 void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call = 1);
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs,
-                     BandTab erb_bm, float* spec, float* feat, bool center = true);
+                     BandTab erb_bm, float* spec, float* feat, bool center = true, const float* final_f32 = nullptr);
+// GTCRN_CUSTOM's input / output sandwich (float audio, other sample rates, dynamic-length exports; Export_GTCRN.py:636-693): see ade_kernels.hip
+void launch_gt_sandwich_in(hipStream_t s, const int16_t* pcm, const float* fin, int rows, int Lin, int L1, int Lm, float lerp1, float lerp2, float gain, float* tmp,
+                           float* mean, float* out);
+void launch_gt_sandwich_out(hipStream_t s, const float* frames, FftTabs tabs, int rows, int T, int keep, float* wave, int16_t* pcm, float* f32, int Lout, float lerp,
+                            bool scale_first);
 void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec);
 void launch_conv0(hipStream_t s, const float* feat, ConvW w, float* e0, int nframes);
 void launch_conv1(hipStream_t s, const float* e0, ConvW w, float* e1, int nframes);

@@ -109,10 +109,12 @@ __device__ __forceinline__ void fft256_wave(float2* v, float2 (*buf)[256], int l
 // relative-accurate (fp32 angles); this exact FFT differs from it by that much at the spectrum.
 // PCM_IN=false is the STFT_Process operator form: float input, reference (B,2F,T) layout out, nothing else.
 // ---------------------------------------------------------------------------------------------------------
+// `fin` (PCM_IN only): the call's waveform as FINAL fp32 samples at the model rate -- already scaled and centred by the input sandwich (k_gt_in_*) --
+// read instead of the int16 PCM, with no scale and no DC term.
 template <bool PCM_IN>
 __global__ __launch_bounds__(256) void k_stft(const void* __restrict__ in, const float* __restrict__ mean, int L, int T,
                                               int nframes, FftTabs tabs, BandTab erb, float* __restrict__ spec,
-                                              float* __restrict__ feat, float* __restrict__ ref_spec, int center) {
+                                              float* __restrict__ feat, float* __restrict__ ref_spec, int center, const float* __restrict__ fin) {
     __shared__ float2 zbuf[4][2][256];
     __shared__ float hi[4][3][kErbHigh];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_stft(const void* __restrict__ in, const
     const int t = live ? frame - b * T : 0;
     float2 v[4];
     {
-        const float dc = (PCM_IN && live) ? mean[b] : 0.0f;
+        const float dc = (PCM_IN && live && !fin) ? mean[b] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = lane + 64 * r;
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(256) void k_stft(const void* __restrict__ in, const
                 }
                 float x = 0.0f;
                 if (live) {
-                    if (PCM_IN) x = (float)(reinterpret_cast<const int16_t*>(in)[(size_t)b * L + j]) * (1.0f / 32768.0f) - dc;
+                    if (PCM_IN && fin) x = fin[(size_t)b * L + j];
+                    else if (PCM_IN) x = (float)(reinterpret_cast<const int16_t*>(in)[(size_t)b * L + j]) * (1.0f / 32768.0f) - dc;
                     else x = reinterpret_cast<const float*>(in)[(size_t)b * L + j];
                 }
                 s[q] = x * tabs.win[2 * n + q];
@@ -956,6 +959,95 @@ __global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ 
     }
 }
 
+// ---- GTCRN_CUSTOM's input / output sandwich for float audio, other sample rates and dynamic-length exports (Export_GTCRN.py:636-693) -------------
+// input: audio.float(); [interpolate first when the caller rate is ABOVE the model rate]; * 2^-15 for int16 input; - mean; [interpolate afterwards when it is BELOW].
+// Stage 1 -> tmp (rows x L1): the (optionally interpolated) samples times `gain`; stage 2: one mean per row (double accumulation, fixed order);
+// stage 3 -> the model-rate waveform: tmp - mean, interpolated afterwards when lerp2 > 0.  lerp = source step of F.interpolate(scale_factor = 1 / lerp).
+__global__ __launch_bounds__(256) void k_gt_in_stage1(const int16_t* __restrict__ pcm, const float* __restrict__ fin, float* __restrict__ tmp, int Lin, int L1, float lerp,
+                                                      float gain, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / L1;
+    const int i = (int)(idx - r * L1);
+    auto at = [&](int j) { return fin ? fin[r * Lin + j] : (float)pcm[r * Lin + j]; };
+    float v;
+    if (lerp > 0.0f) {
+        int i0, i1;
+        float l1;
+        lerp_coords(i, Lin, lerp, i0, i1, l1);
+        v = (1.0f - l1) * at(i0) + l1 * at(i1);
+    } else {
+        v = at(i);
+    }
+    tmp[idx] = v * gain;
+}
+__global__ __launch_bounds__(256) void k_row_mean_f32(const float* __restrict__ x, int L, float* __restrict__ mean) {
+    __shared__ double part[256];
+    const float* row = x + (size_t)blockIdx.x * L;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < L; i += 256) s += (double)row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[blockIdx.x] = (float)(part[0] / (double)L);
+}
+__global__ __launch_bounds__(256) void k_gt_in_stage3(const float* __restrict__ tmp, const float* __restrict__ mean, float* __restrict__ out, int L1, int Lm, float lerp,
+                                                      long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / Lm;
+    const int i = (int)(idx - r * Lm);
+    const float* row = tmp + r * L1;
+    const float m = mean[r];
+    if (lerp > 0.0f) {
+        int i0, i1;
+        float l1;
+        lerp_coords(i, L1, lerp, i0, i1, l1);
+        out[idx] = (1.0f - l1) * (row[i0] - m) + l1 * (row[i1] - m);
+    } else {
+        out[idx] = row[i] - m;
+    }
+}
+// overlap-add for the sandwich path: `keep` model-rate samples per row.  Static exports keep 256 (T - 1) (STFT_Process.py:169-176, 330-333); dynamic-length exports
+// slice [n_fft / 2 : out_end(max_frames)] of the raw overlap-add, i.e. 256 T samples, and divide by the conv_transpose of the squared window over the frames that
+// exist (:337-341): the last hop has only frame T - 1 under it.
+__global__ __launch_bounds__(256) void k_ola_keep(const float* __restrict__ frames, const float* __restrict__ win_sum, const float* __restrict__ win, int T, int keep,
+                                                  float* __restrict__ out, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long b = idx / keep;
+    const int n = (int)(idx - b * keep), j = n >> 8, r = n & 255;
+    const float a = frames[((size_t)b * T + j) * kNfft + kHop + r];
+    if (j + 1 < T) out[idx] = (a + frames[((size_t)b * T + j + 1) * kNfft + r]) / win_sum[r];
+    else { const float w = win[kHop + r]; out[idx] = a / (w * w); }
+}
+// output: [interpolate first when the caller rate is BELOW the model rate]; * 32767 for int16 output; [interpolate afterwards when it is ABOVE]; clamp + truncating
+// cast for int16 (Export_GTCRN.py:673-693).  f32 receives the waveform at the output rate without the PCM scale (the F32 / F16 output of the export).
+__global__ __launch_bounds__(256) void k_gt_out(const float* __restrict__ wave, int16_t* __restrict__ pcm, float* __restrict__ f32, int Lw, int Lout, float lerp,
+                                                int scale_first, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / Lout;
+    const int i = (int)(idx - r * Lout);
+    const float* row = wave + r * Lw;
+    float y, q;
+    if (lerp > 0.0f) {
+        int i0, i1;
+        float l1;
+        lerp_coords(i, Lw, lerp, i0, i1, l1);
+        y = (1.0f - l1) * row[i0] + l1 * row[i1];
+        q = scale_first ? (1.0f - l1) * (row[i0] * 32767.0f) + l1 * (row[i1] * 32767.0f) : y * 32767.0f;
+    } else {
+        y = row[i];
+        q = y * 32767.0f;
+    }
+    if (f32) f32[idx] = y;
+    if (pcm) pcm[idx] = (int16_t)(int)fminf(fmaxf(q, -32768.0f), 32767.0f);
+}
+
 __global__ void k_probe_row_ror(int* out) {
     const int lane = threadIdx.x & 15;
     out[threadIdx.x] = (int)row_ror<1>((float)lane);
@@ -981,20 +1073,31 @@ int dpp_row_ror_direction() {
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------
+void launch_gt_sandwich_in(hipStream_t s, const int16_t* pcm, const float* fin, int rows, int Lin, int L1, int Lm, float lerp1, float lerp2, float gain, float* tmp,
+                           float* mean, float* out) {
+    hipLaunchKernelGGL(k_gt_in_stage1, grid1((long long)rows * L1, 256), dim3(256), 0, s, pcm, fin, tmp, Lin, L1, lerp1, gain, (long long)rows * L1);
+    hipLaunchKernelGGL(k_row_mean_f32, dim3((unsigned)rows), dim3(256), 0, s, (const float*)tmp, L1, mean);
+    hipLaunchKernelGGL(k_gt_in_stage3, grid1((long long)rows * Lm, 256), dim3(256), 0, s, (const float*)tmp, (const float*)mean, out, L1, Lm, lerp2, (long long)rows * Lm);
+}
+void launch_gt_sandwich_out(hipStream_t s, const float* frames, FftTabs tabs, int rows, int T, int keep, float* wave, int16_t* pcm, float* f32, int Lout, float lerp,
+                            bool scale_first) {
+    hipLaunchKernelGGL(k_ola_keep, grid1((long long)rows * keep, 256), dim3(256), 0, s, frames, tabs.win_sum, tabs.win, T, keep, wave, (long long)rows * keep);
+    hipLaunchKernelGGL(k_gt_out, grid1((long long)rows * Lout, 256), dim3(256), 0, s, (const float*)wave, pcm, f32, keep, Lout, lerp, scale_first ? 1 : 0, (long long)rows * Lout);
+}
 void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call) {
     hipLaunchKernelGGL(k_pcm_mean, dim3(B / rows_per_call), dim3(256), 0, s, pcm, L, rows_per_call, mean);
 }
 void launch_stft_pcm(hipStream_t s, const int16_t* pcm, const float* mean, int B, int L, int T, FftTabs tabs, BandTab erb_bm,
-                     float* spec, float* feat, bool center) {
+                     float* spec, float* feat, bool center, const float* final_f32) {
     const int nframes = B * T;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<true>), grid1(nframes, 4), dim3(256), 0, s, (const void*)pcm, mean, L, T, nframes,
-                       tabs, erb_bm, spec, feat, (float*)nullptr, center ? 1 : 0);
+                       tabs, erb_bm, spec, feat, (float*)nullptr, center ? 1 : 0, final_f32);
 }
 void launch_stft_ref(hipStream_t s, const float* x, int B, int L, int T, FftTabs tabs, float* ref_spec) {
     const int nframes = B * T;
     BandTab none = {nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stft<false>), grid1(nframes, 4), dim3(256), 0, s, (const void*)x, (const float*)nullptr, L,
-                       T, nframes, tabs, none, (float*)nullptr, (float*)nullptr, ref_spec, 1);
+                       T, nframes, tabs, none, (float*)nullptr, (float*)nullptr, ref_spec, 1, (const float*)nullptr);
 }
 void launch_conv0(hipStream_t s, const float* feat, ConvW w, float* e0, int nframes) {
     hipLaunchKernelGGL(k_conv0, grid1((long long)nframes * kF1, 256), dim3(256), 0, s, feat, w.w, w.b, w.slope, e0, nframes);

@@ -85,9 +85,13 @@ class InferenceSession:
         self.in_sample_rate, self.out_sample_rate = io.in_sample_rate, io.out_sample_rate
         self.device_id = io.device
         in_name = "mix_audio" if reader.string("model_family", "") == "mossformer2_ss" else INPUT_NAME        # :688
-        self._inputs = [NodeArg(in_name, [1, io.in_channels, io.in_len])]
+        # audio tensor dtypes of the export (Export_GTCRN.py:47-48, 757-760): INT16 PCM, or normalised F32 / F16 (an F16 tensor crosses libade's ABI as fp32)
+        self.in_dtype = {"INT16": np.int16, "F32": np.float32, "F16": np.float16}[reader.string("input_audio_dtype", "INT16")]
+        self.out_dtype = {"INT16": np.int16, "F32": np.float32, "F16": np.float16}[reader.string("output_audio_dtype", "INT16")]
+        tname = {np.int16: "tensor(int16)", np.float32: "tensor(float)", np.float16: "tensor(float16)"}
+        self._inputs = [NodeArg(in_name, [1, io.in_channels, io.in_len], tname[self.in_dtype])]
         out_names = [OUTPUT_NAME] if io.n_outputs == 1 else [f"separated_{i}" for i in range(io.n_outputs)]   # Export_MossFormer2_SS_16K.py:689-690
-        self._outputs = [NodeArg(name, [1, io.out_channels, io.out_len]) for name in out_names]
+        self._outputs = [NodeArg(name, [1, io.out_channels, io.out_len], tname[self.out_dtype]) for name in out_names]
         self._inputs_meta, self._outputs_meta = self._inputs, self._outputs   # names the reference script touches
         validate_audio_metadata(reader, self)
 
@@ -109,11 +113,18 @@ class InferenceSession:
         if self._inputs[0].name not in input_feed:
             raise KeyError(f"missing input {self._inputs[0].name!r}")
         x = np.asarray(input_feed[self._inputs[0].name])
-        if x.dtype != np.int16:
-            raise ValueError(f"{INPUT_NAME} must be int16, got {x.dtype}")
+        if x.dtype != self.in_dtype:
+            raise ValueError(f"{INPUT_NAME} must be {np.dtype(self.in_dtype).name}, got {x.dtype}")
         if x.ndim != 3 or x.shape[1] != self.channels or x.shape[2] != self.in_len:
             raise ValueError(f"{INPUT_NAME} must have shape (B, {self.channels}, {self.in_len}), got {x.shape}")
-        pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32)
+        float_out = self.out_dtype != np.int16
+        if self.in_dtype == np.int16:
+            pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32 or float_out)
+        else:
+            pcm, f32 = self.process_f32(x.reshape(x.shape[0], self.row_in).astype(np.float32, copy=False), want_pcm=not float_out, want_f32=return_f32 or float_out)
+        if float_out:        # the export's F32 / F16 output: the waveform without the PCM scale and clamp (Export_GTCRN.py:689-693)
+            f32 = f32.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
+            return [np.ascontiguousarray(f32[:, i]).astype(self.out_dtype, copy=False) for i in range(self.n_outputs)]
         pcm = pcm.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
         out = [np.ascontiguousarray(pcm[:, i]) for i in range(self.n_outputs)]               # one array per graph output
         if return_f32:
@@ -130,6 +141,20 @@ class InferenceSession:
         out = np.empty((B, self.row_out), np.int16)
         f32 = np.empty((B, self.row_out), np.float32) if want_f32 else None
         st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if want_f32 else None)
+        self._lib.check(st, self._h)
+        return out, f32
+
+    def process_f32(self, x: np.ndarray, want_pcm: bool = True, want_f32: bool = True):
+        """fp32 audio in (input_audio_dtype F32 / F16; ``ade_process_f32``): normalised samples (B, row_in) -> (int16 PCM or None, fp32 waveform or None)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.row_in:
+            raise ValueError(f"expected float32 (B, {self.row_in}), got {x.shape}")
+        if not (want_pcm or want_f32):
+            raise ValueError("ask for at least one output")
+        B = x.shape[0]
+        out = np.empty((B, self.row_out), np.int16) if want_pcm else None
+        f32 = np.empty((B, self.row_out), np.float32) if want_f32 else None
+        st = self._lib.c.ade_process_f32(self._h, x.ctypes.data, B, out.ctypes.data if want_pcm else None, f32.ctypes.data if want_f32 else None)
         self._lib.check(st, self._h)
         return out, f32
 

@@ -778,7 +778,10 @@ int ade_oracle_out_len(const ade_oracle* o) { return o->out_len; }
 #define TAP(o, on, name) ((on) ? tap_get((o), (name)) : NULL)
 
 /* One reference call: GTCRN_CUSTOM.forward (Export_GTCRN.py:636-693) with B = 1. */
-static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, float* out_f32, int taps_on, const float* call_mean) {
+/* `fin` (instead of `in`): the call's waveform as final fp32 samples at the model rate -- scaled and centred already (the input sandwich of GTCRN_CUSTOM,
+ * Export_GTCRN.py:636-655, restated in numpy by the tests) -- used as it is.  `dyn`: the dynamic-length ISTFT trim, 256 T samples divided by the conv_transpose of the
+ * squared window over the frames that exist (STFT_Process.py:337-341); out_f32 then holds 256 T samples and out_pcm must be NULL. */
+static void process_one_ex(ade_oracle* o, const int16_t* in, const float* fin, int16_t* out_pcm, float* out_f32, int taps_on, const float* call_mean, int dyn) {
     const int L = o->in_len, T = o->T;
     const size_t TT = (size_t)T;
     float* audio = (float*)malloc(sizeof(float) * (size_t)L);
@@ -798,10 +801,13 @@ static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, floa
     float* mfull = (float*)malloc(sizeof(float) * 2 * TT * FBINS);
     float* enh = (float*)malloc(sizeof(float) * 2 * FBINS * TT);
     float* raw = (float*)malloc(sizeof(float) * (size_t)(NFFT + HOP * (T - 1)));
-    float* wave = (float*)malloc(sizeof(float) * (size_t)o->out_len);
+    const int keep = dyn ? HOP * T : o->out_len;
+    float* wave = (float*)malloc(sizeof(float) * (size_t)keep);
 
     /* F1: int16 -> f32, * 1/32768, minus the mean of THIS call (Export_GTCRN.py:637,645-647) */
-    {
+    if (fin) {
+        memcpy(audio, fin, sizeof(float) * (size_t)L);
+    } else {
         const float inv = (float)(1.0 / 32768.0);
         double s = 0.0;
         for (int i = 0; i < L; ++i) { audio[i] = (float)in[i] * inv; s += audio[i]; }
@@ -909,9 +915,18 @@ static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, floa
         }
     if (taps_on) memcpy(tap_get(o, "spec_enh"), enh, sizeof(float) * 2 * FBINS * TT);
     /* F13 */
-    istft_packed_one(enh, T, o->istft_kernel, NFFT, HOP, o->win_sum, NFFT / 2, o->out_len, raw, wave);
-    if (taps_on) memcpy(tap_get(o, "wave_f32"), wave, sizeof(float) * (size_t)o->out_len);
-    if (out_f32) memcpy(out_f32, wave, sizeof(float) * (size_t)o->out_len);
+    if (dyn) {
+        /* win_sum = conv_transpose1d(ones(T), w^2, stride = hop)[n_fft / 2 : n_fft / 2 + 256 T] */
+        float* ws = (float*)calloc((size_t)(NFFT + HOP * (T - 1)), sizeof(float));
+        for (int t = 0; t < T; ++t)
+            for (int n = 0; n < NFFT; ++n) ws[(size_t)t * HOP + n] += o->window[n] * o->window[n];
+        istft_packed_one(enh, T, o->istft_kernel, NFFT, HOP, ws + NFFT / 2, NFFT / 2, keep, raw, wave);
+        free(ws);
+    } else {
+        istft_packed_one(enh, T, o->istft_kernel, NFFT, HOP, o->win_sum, NFFT / 2, o->out_len, raw, wave);
+    }
+    if (taps_on && !dyn) memcpy(tap_get(o, "wave_f32"), wave, sizeof(float) * (size_t)o->out_len);
+    if (out_f32) memcpy(out_f32, wave, sizeof(float) * (size_t)keep);
     /* F14: * 32767, clamp, truncating cast (Export_GTCRN.py:681,690) */
     if (out_pcm)
         for (int i = 0; i < o->out_len; ++i) {
@@ -922,6 +937,19 @@ static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, floa
     free(audio); free(xp); free(spec); free(feat); free(feat_e); free(feat_s);
     for (int i = 0; i < 5; ++i) free(e[i]);
     free(a); free(bb); free(d3); free(d3in); free(m); free(mfull); free(enh); free(raw); free(wave);
+}
+
+static void process_one(ade_oracle* o, const int16_t* in, int16_t* out_pcm, float* out_f32, int taps_on, const float* call_mean) {
+    process_one_ex(o, in, NULL, out_pcm, out_f32, taps_on, call_mean, 0);
+}
+
+/* The network between the two halves of GTCRN_CUSTOM's sandwich: rows of in_len final fp32 samples at the model rate in, the normalised waveform out --
+ * out_len samples per row (static export) or 256 T (dynamic_tail: the dynamic_axes export's ISTFT trim). */
+int ade_oracle_process_model_f32(ade_oracle* o, const float* in, int B, float* out_f32, int dynamic_tail) {
+    if (!o || !in || !out_f32 || B < 0) return fail("bad arguments", NULL);
+    const int keep = dynamic_tail ? HOP * o->T : o->out_len;
+    for (int b = 0; b < B; ++b) process_one_ex(o, NULL, in + (size_t)b * o->in_len, NULL, out_f32 + (size_t)b * keep, 0, NULL, dynamic_tail);
+    return 0;
 }
 
 int ade_oracle_process(ade_oracle* o, const int16_t* in, int B, int16_t* out_pcm, float* out_f32, int n_threads) {

@@ -41,6 +41,7 @@ def lib():
         L.ade_oracle_last_error.restype = C.c_char_p
         L.ade_oracle_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.ade_oracle_process_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ade_oracle_process_model_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.ade_oracle_set_generic_exact_dft.argtypes = [C.c_int]
         L.ade_oracle_set_generic_exact_dft.restype = None
         L.ade_oracle_tap.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
@@ -92,6 +93,16 @@ class GtcrnOracle:
         if rc != 0:
             raise OracleError(lib().ade_oracle_last_error().decode())
         return out_pcm, out_f32
+
+    def process_model_f32(self, x: np.ndarray, dynamic_tail: bool = False) -> np.ndarray:
+        """The network between the halves of GTCRN_CUSTOM's sandwich: final fp32 model-rate waveforms (B, in_len) -> normalised waveforms
+        (B, out_len), or (B, 256 T) with the dynamic-length export's ISTFT trim."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.in_len)
+        keep = 256 * self.T if dynamic_tail else self.out_len
+        out = np.empty((x.shape[0], keep), np.float32)
+        if lib().ade_oracle_process_model_f32(self._h, x.ctypes.data, x.shape[0], out.ctypes.data, int(bool(dynamic_tail))) != 0:
+            raise OracleError(lib().ade_oracle_last_error().decode())
+        return out
 
     def process_fold(self, pcm: np.ndarray, n_win: int, threads: int = 1):
         """USE_BATCH_FOLD calls: pcm (n_calls, n_win * in_len) -> (n_calls, n_win * out_len); mean over the whole call."""
