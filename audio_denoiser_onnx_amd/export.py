@@ -5,7 +5,8 @@ checkpoint-format ``state_dict`` (``torch.load(..)['model']``), fold every Batch
 ``ConvBlock.fuse_bn_`` / ``GTConvBlock.fuse_bn_`` do (Export_GTCRN.py:171-194, 244-267), pre-transpose the ERB
 matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the reference's own names.
 
-    python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000]
+    python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000] [--dynamic] [--in-rate 48000] [--out-rate 8000]
+                                                                                       [--in-dtype F32] [--out-dtype F32]
     python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold]
     python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
     python -m audio_denoiser_onnx_amd.export --family ul_unas <model_trained_on_dns3.tar> <out_dir> [--length 16000]
@@ -88,13 +89,17 @@ def load_state_dict(path) -> Dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def export_gtcrn(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "GTCRN") -> Path:
+def export_gtcrn(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "GTCRN", in_sample_rate: int = 16000, out_sample_rate: int = 16000,
+                 dynamic_axes: bool = False, input_audio_dtype: str = "INT16", output_audio_dtype: str = "INT16") -> Path:
+    """The export's I/O switches (Export_GTCRN.py:26-30, 47-48): other input / output sample rates need ``dynamic_axes`` (the static graph sizes its frame count
+    from the input-rate length, :45); float audio tensors are "F32" / "F16"."""
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     model_path = out_dir / f"{name}.adew"
     save_blob(model_path, fold_gtcrn_state_dict(load_state_dict(checkpoint)))
     meta = build_audio_metadata(producer=Path(__file__).name, model_name=name, task="denoise", model_family="gtcrn",
-                                input_audio_length=input_audio_length, extra={"n_mels": 100})
+                                input_audio_length=input_audio_length, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate, model_sample_rate=16000,
+                                dynamic_axes=dynamic_axes, input_audio_dtype=input_audio_dtype, output_audio_dtype=output_audio_dtype, extra={"n_mels": 100})
     write_metadata(model_path, meta)
     return model_path
 
@@ -182,6 +187,16 @@ def main(argv=None) -> int:
     if "--fold" in argv:
         argv.remove("--fold")
         fold = True
+    gt = {"dynamic_axes": False, "in_sample_rate": 16000, "out_sample_rate": 16000, "input_audio_dtype": "INT16", "output_audio_dtype": "INT16"}     # GTCRN's I/O switches
+    if "--dynamic" in argv:
+        argv.remove("--dynamic")
+        gt["dynamic_axes"] = True
+    for flag, key, conv in (("--in-rate", "in_sample_rate", int), ("--out-rate", "out_sample_rate", int), ("--in-dtype", "input_audio_dtype", str.upper),
+                            ("--out-dtype", "output_audio_dtype", str.upper)):
+        if flag in argv:
+            i = argv.index(flag)
+            gt[key] = conv(argv[i + 1])
+            del argv[i:i + 2]
     if len(argv) != 2 or family not in ("gtcrn", "h_gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas", "zipenhancer"):
         print(__doc__)
         return 2
@@ -196,7 +211,7 @@ def main(argv=None) -> int:
     elif family == "zipenhancer":
         path = export_zipenhancer(argv[0], argv[1], length or 32000, fold)
     else:
-        path = export_gtcrn(argv[0], argv[1], length or 16000)
+        path = export_gtcrn(argv[0], argv[1], length or 16000, **gt)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")
     return 0
 

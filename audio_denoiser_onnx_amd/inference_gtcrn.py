@@ -67,6 +67,17 @@ def write_wav_int16(path, pcm: np.ndarray, sample_rate: int) -> None:
         w.writeframes(np.ascontiguousarray(pcm, dtype="<i2").tobytes())
 
 
+def write_wav_float32(path, x: np.ndarray, sample_rate: int) -> None:
+    """Mono IEEE-float wav: what ``sf.write(..., subtype='FLOAT')`` produces for a float model output (Inference_GTCRN_ONNX.py:340)."""
+    import struct
+    data = np.ascontiguousarray(x, dtype="<f4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 1, int(sample_rate), int(sample_rate) * 4, 4, 32)          # WAVE_FORMAT_IEEE_FLOAT, mono
+    fact = struct.pack("<I", len(data) // 4)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<I", 4) + fact + b"data" + struct.pack("<I", len(data)) + data
+    with open(str(path), "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
 def normalise_audio(audio: np.ndarray, enable: bool, target_rms: float = NORMALIZE_TARGET_RMS) -> np.ndarray:
     """Optional RMS normalisation to ``target_rms`` with int16 clipping (Inference_GTCRN_ONNX.py:115-135)."""
     if not enable:
@@ -132,18 +143,27 @@ def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "ze
 def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = False, rank: int = 0, world: int = 1,
             group=None, tail_pad: str = "zeros", rng=None, family: str = "gtcrn") -> np.ndarray:
     """int16 mono waveform in -> int16 denoised waveform out: the input's duration at the OUTPUT sample rate.
-    ``family`` selects the reference driver whose stride / trim rules apply (``"gtcrn"`` or ``"dfsmn"``)."""
+    ``family`` selects the reference driver whose stride / trim rules apply (``"gtcrn"`` or ``"dfsmn"``).
+    A model whose audio tensors are float (input_audio_dtype / output_audio_dtype F32 or F16) gets the int16 samples cast straight to its input dtype and
+    returns its output dtype, as the reference driver does (Inference_GTCRN_ONNX.py:133-135, 336-340)."""
     in_rate, out_rate = session_rates(session)
+    in_dt, out_dt = getattr(session, "in_dtype", np.int16), getattr(session, "out_dtype", np.int16)
+    float_io = in_dt != np.int16 or out_dt != np.int16
     dfsmn = family == "dfsmn"
     audio_len = output_length(len(audio), in_rate, out_rate, rounded=dfsmn)
     slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng,
                            out_stride=(not dfsmn) and in_rate == out_rate)
-    if world > 1 and not sequential and hasattr(session, "run_device"):
+    if world > 1 and not sequential and hasattr(session, "run_device") and not float_io:
         from .distributed import sharded_run
         return sharded_run(session, slices, world, rank, group).reshape(-1)[:audio_len]      # device block -> all-gather -> one D2H
     lo, hi = shard_bounds(len(slices), world, rank)
     mine = slices[lo:hi]
-    if sequential:
+    if float_io:
+        name = session.get_inputs()[0].name
+        local = (session.run(None, {name: mine.astype(in_dt)[:, None, :]})[0][:, 0] if len(mine) else np.zeros((0, session.out_len), out_dt))
+        if out_dt == np.float16:
+            local = local.astype(np.float32)                                                      # (:336-337)
+    elif sequential:
         outs = [session.run(None, {"noisy_audio": s.reshape(1, 1, -1)})[0].reshape(1, -1) for s in mine]
         local = np.concatenate(outs, axis=0) if outs else np.zeros((0, session.out_len), np.int16)
     else:
@@ -197,7 +217,7 @@ def main(argv=None) -> int:
     denoised = denoise_streaming(session, audio, stream_frames) if stream_frames else denoise(session, audio, sequential=sequential)
     elapsed = time.time() - t0
     print("Complete: 100.00%")
-    write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])
+    (write_wav_int16 if denoised.dtype == np.int16 else write_wav_float32)(out_path, denoised, cfg["OUT_SAMPLE_RATE"])      # PCM_16 / FLOAT (:340)
     duration = len(denoised) / cfg["OUT_SAMPLE_RATE"] if cfg["OUT_SAMPLE_RATE"] > 0 else 0.0
     rtf = elapsed / duration if duration > 0 else float("inf")
     print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {rtf:.6f}")

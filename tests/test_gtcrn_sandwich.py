@@ -127,3 +127,30 @@ def test_static_export_at_other_rates_is_refused():
     with pytest.raises(Exception) as ei:
         InferenceSession(weights=golden_blob(0), metadata=meta, library=hipsim_library())
     assert "dynamic_axes" in str(ei.value)
+
+
+@pytest.mark.hipsim
+def test_hipsim_file_driver_with_float_tensors(tmp_path):
+    """The driver feeds a float model the int16 samples cast straight to its input dtype and returns / writes its float output (Inference_GTCRN_ONNX.py:133-135,
+    336-340); slices, stride and trim as for int16."""
+    from audio_denoiser_onnx_amd.inference_gtcrn import denoise, write_wav_float32
+    rng = np.random.default_rng(9)
+    audio = (rng.standard_normal(20000) * 2000).astype(np.int16)
+    with InferenceSession(weights=golden_blob(0), metadata=_meta("f32_static"), library=hipsim_library()) as sess:
+        assert sess.get_inputs()[0].type == "tensor(float)" and sess.in_dtype == np.float32 and sess.out_dtype == np.float32
+        out = denoise(sess, audio)
+        one = sess.run(None, {"noisy_audio": audio[:16000].astype(np.float32)[None, None, :]})[0][0, 0]
+    assert out.dtype == np.float32 and out.shape == (20000,) and np.isfinite(out).all()
+    assert np.array_equal(out[:15872], one)                     # slice 0 of the file = the same call
+    write_wav_float32(tmp_path / "o.wav", out, 16000)
+    import scipy.io.wavfile as wavfile
+    rate, back = wavfile.read(tmp_path / "o.wav")
+    assert rate == 16000 and back.dtype == np.float32 and np.array_equal(back, out)
+
+
+def test_export_manifest_carries_the_io_switches():
+    """`export.py --dynamic --in-rate 48000 --out-rate 8000 --in-dtype F32` stamps what the engine reads (the checkpoint side is tests/test_host_logic.py's)."""
+    from audio_denoiser_onnx_amd import export
+    meta = export.build_audio_metadata(producer="t", model_name="GTCRN", task="denoise", model_family="gtcrn", input_audio_length=48000, in_sample_rate=48000,
+                                       out_sample_rate=8000, model_sample_rate=16000, dynamic_axes=True, input_audio_dtype="F32", output_audio_dtype="INT16")
+    assert meta["dynamic_axes"] == "1" and meta["input_audio_dtype"] == "F32" and meta["in_sample_rate"] == "48000" and meta["out_sample_rate"] == "8000"
