@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void k_shift_invnorm(const float* __restrict__
 // With `partial` set every lane also writes (count, mean, M2) of its run for the instance norm that follows (:528-531); k_chan_finalize merges the runs
 // in a fixed order (Chan's update), so the statistics are deterministic and independent of the batch size.
 constexpr int kTconvRun = 128;
+static_assert(kIn % 64 == 0 && kDim % 64 == 0 && kInner % 128 == 0, "k_tconv: a wavefront's 64 * CIN input channels must lie in one source tensor");
 struct TconvRun {              // per-lane state of one run
     float* y;
     size_t base;
