@@ -658,32 +658,29 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
     const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
     const int j16 = lane & 15, g = lane >> 4;
     const int np16 = NT * 16, n2 = 2 * n - 1, vst = np16 + 4;
-    float* Qs = lds;                               // [np16][kQKs]
-    float* Ks = Qs + np16 * kQKs;                  // [np16][kQKs]
-    float* Pq = Ks + np16 * kQKs;                  // [np16][4]
-    float* Pt = Pq + np16 * 4;                     // [4][n2 (+ pad)]
+    float* Ks = lds;                               // [np16][kQKs]   (queries and their position projections are read straight from global memory by the wave that owns them:
+    float* Pt = Ks + np16 * kQKs;                  // [4][n2 (+ pad)]  keeping them out of LDS is what lets a third / fourth workgroup share the CU)
     float* Vt = Pt + 4 * ((n2 + 3) & ~3);          // [DT * 16][vst]   values, transposed
-    float* Us0 = Vt + DT * 16 * vst + wave * 2 * 32 * kUs;   // per-wave scratch, two [32][kUs] buffers used alternately (one wave-level sync per tile)
+    float* Us = Vt + DT * 16 * vst + wave * 32 * kUs;        // per-wave scratch [32][kUs]: a wave's LDS operations execute in issue order, so tile kt + 1's writes cannot
+                                                             // overtake tile kt's reads; the wave-level sync only orders the writes of a tile before its own reads
     const long long r0 = geo.row0(seq);
     // Staging.  Every loop below issues its global loads as one batch from in-range addresses (clamped position, zeroed afterwards) before it touches LDS: with a
     // branch around each load the compiler fences every single one (s_waitcnt vmcnt(0)) and the ~40 loads per lane cost ~40 memory latencies -- more than the 30 score
     // tiles per wavefront that follow.
-    constexpr int hd = 36;                         // 2 * 16 + 4 (checked by the host: query_head_dim 16, pos_head_dim 4): nine float4 per position = (4 q | 4 k | 1 p)
+    constexpr int hd = 36;                         // 2 * 16 + 4 (checked by the host: query_head_dim 16, pos_head_dim 4): a position's projection row is (16 q | 16 k | 4 p)
     {
-        constexpr int kIt = (NT * 16 * 9 + 255) / 256;
+        constexpr int kIt = (NT * 16 * 4 + 255) / 256;
         float4 t4[kIt];
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u, p = i / 9, q = i - 9 * p;
+            const int i = tid + 256 * u, p = i >> 2, q = i & 3;
             const bool ok = p < n;                                                       // (p >= np16 only in the last, partial round: those lanes skip the store)
-            t4[u] = keep4(ok, *reinterpret_cast<const float4*>(proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 4 * q));
+            t4[u] = keep4(ok, *reinterpret_cast<const float4*>(proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 4 * q));
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u, p = i / 9, q = i - 9 * p;
-            if (p >= np16) continue;
-            float* dst = q < 4 ? Qs + p * kQKs + 4 * q : (q < 8 ? Ks + p * kQKs + 4 * (q - 4) : Pq + p * 4);
-            *reinterpret_cast<float4*>(dst) = t4[u];
+            const int i = tid + 256 * u, p = i >> 2, q = i & 3;
+            if (p < np16) *reinterpret_cast<float4*>(Ks + p * kQKs + 4 * q) = t4[u];
         }
     }
     const int ptst = (n2 + 3) & ~3;
@@ -727,8 +724,10 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
     __syncthreads();
     for (int qt = wave; qt * 16 < n; qt += 4) {
         const int q0 = qt * 16, qi = q0 + j16;
-        const float4 qv = *reinterpret_cast<const float4*>(Qs + qi * kQKs + 4 * g);       // B operand of the score product: Q[query j16][dims 4 g ..]
-        const float pq = Pq[qi * 4 + g];                                                 // B operand of the position product: p[query j16][dim g]
+        const float* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
+        const float4 qv = keep4(qi < n, *reinterpret_cast<const float4*>(qrow + 4 * g));  // B operand of the score product: Q[query j16][dims 4 g ..]
+        const float pq_raw = qrow[32 + g];
+        const float pq = qi < n ? pq_raw : 0.0f;                                         // B operand of the position product: p[query j16][dim g]
         float st[NT][4];
         float mx = -INFINITY;
 #pragma unroll
@@ -746,7 +745,6 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
             cb = cb < 0 ? 0 : (cb > n2 - 1 ? n2 - 1 : cb);
             const v4f u0 = mfma16x16x4(Pt[g * ptst + ca], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 4 g + r][query j16]
             const v4f u1 = mfma16x16x4(Pt[g * ptst + cb], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 16 + 4 g + r][query j16]
-            float* Us = Us0 + (kt & 1) * 32 * kUs;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { Us[(4 * g + r) * kUs + j16] = u0[r]; Us[(16 + 4 * g + r) * kUs + j16] = u1[r]; }
             wave_sync();
@@ -803,7 +801,7 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
 template <int MODE, int NT, int DT>
 inline size_t zip_attn_lds(int n) {
     const int np16 = NT * 16, n2 = 2 * n - 1;
-    return ((size_t)np16 * kQKs * 2 + (size_t)np16 * 4 + 4 * (size_t)((n2 + 3) & ~3) + (size_t)DT * 16 * (np16 + 4) + 4 * 2 * 32 * kUs) * sizeof(float);
+    return ((size_t)np16 * kQKs + 4 * (size_t)((n2 + 3) & ~3) + (size_t)DT * 16 * (np16 + 4) + 4 * 32 * kUs) * sizeof(float);
 }
 
 // ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
