@@ -172,3 +172,24 @@ def test_gpu_stft_a_and_polar_istft_a():
         ist.forward(torch.from_numpy(p["magnitude"]).cuda())
     with pytest.raises(ValueError):
         ist(torch.from_numpy(p["magnitude"][:, :100]).cuda(), torch.from_numpy(p["phase"][:, :100]).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,length", [(512, 256, 300), (512, 256, 513), (400, 100, 250), (2048, 441, 1100), (1920, 960, 1921)])
+def test_gpu_stft_fft_path_few_frames(n_fft, hop, length):
+    """One to a handful of frames (a half-empty last pair, a single workgroup with idle pair groups) on the FFT path, against the oracle with exact tables."""
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    rng = np.random.default_rng(length)
+    x = (rng.standard_normal((3, length)) * 0.2).astype(np.float32)
+    stft = STFT_Process("stft_B", n_fft, n_fft, hop, 0, "hann", True, "reflect")
+    spec = stft(torch.from_numpy(x).cuda()[:, None, :]).cpu().numpy()
+    oracle_set_generic_exact_dft(True)
+    try:
+        ref = oracle_stft(x, n_fft, n_fft, hop, "hann", True, "reflect")
+        assert spec.shape == ref.shape and np.abs(spec - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+        y = STFT_Process("istft_B", n_fft, n_fft, hop, spec.shape[2], "hann", True, "reflect")(torch.from_numpy(ref).cuda()).cpu().numpy().reshape(3, -1)
+        want = oracle_istft(ref, n_fft, n_fft, hop, "hann", True)
+        assert y.shape == want.shape and np.abs(y - want).max() <= 1e-5
+    finally:
+        oracle_set_generic_exact_dft(False)
