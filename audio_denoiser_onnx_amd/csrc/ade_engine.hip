@@ -59,6 +59,8 @@ struct ade_engine {
     int rs_model_in = 0, rs_model_out = 0;     // per channel row, at the model rate
     float rs_scale_in = 1.0f, rs_scale_out = 1.0f, rs_pcm_scale = 1.0f;
     bool rs_truncate_i32 = false;
+    bool rs_sandwich_out = false;        // Mel-Band: the GTCRN-style output sandwich (interpolate before the PCM scale when down-sampling, after it when up-sampling)
+    bool rs_scale_first = false;
     float *rs_in = nullptr, *rs_out = nullptr;
 
     // GTCRN_CUSTOM's input / output sandwich (Export_GTCRN.py:636-693): float audio in, other sample rates and dynamic-length exports.  in_len / out_len above are the
@@ -634,8 +636,11 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
             e->sub->float_in = e->rs_in;
             sub_rc = e->sub->run(s, d_in, B, nullptr, e->rs_out, sub_err);
             e->sub->float_in = nullptr;
-            launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out,
-                                e->rs_pcm_scale, e->rs_truncate_i32);
+            if (e->rs_sandwich_out)
+                launch_gt_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out, e->rs_scale_first);
+            else
+                launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out,
+                                    e->rs_pcm_scale, e->rs_truncate_i32);
         } else if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
         else enqueue(e, s, d_in, B, d_out, d_f32, timed);
     };
@@ -805,7 +810,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         bool dyn_d = false, fold_d = false;
         if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
-        if (dyn_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented (static shapes only)"));
+        // A dynamic_axes export of Mel-Band-Roformer takes its frame count from the waveform and keeps everything after the first half window of the overlap-add
+        // (Stereo/STFT_Process.py:296-306); the engine still serves ONE input length per handle.  The other families' dynamic exports are not built.
+        if (dyn_d && !fam_melband) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn and mel_band_roformer (static shapes only for " + fam + ")"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
         if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
@@ -824,8 +831,10 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
         // H-GTCRN's static export is consistent too (frames from MODEL_AUDIO_LENGTH, Export_H_GTCRN.py:45-46); it interpolates by SCALE FACTOR.
         // ZipEnhancer sizes its frames from MODEL_AUDIO_LENGTH too (Export_ZipEnhancer.py:55, 61) and interpolates by size (:826-832, :905-911).
-        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg && !fam_zip)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path)"));
+        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg && !fam_zip && !(fam_melband && dyn_d))
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path" +
+                                                     (fam_melband ? ": export with dynamic_axes=1 for other rates)" : ")")));
+        if (dyn_d && fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires a static shape (dynamic_axes=0)."));     // (Export_MelBandRoformer.py:46)
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
             return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
@@ -835,6 +844,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (rates_differ) {   // MODEL_AUDIO_LENGTH = round(L * model / in) (:36); batch-fold needs equal rates (:92-93)
             if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
             Ld = fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
+                 : fam_melband ? (long)floor((double)caller_len * ((double)srm / (double)sri))       // F.interpolate(scale_factor = float(MODEL / IN)) (Export_MelBandRoformer.py:52, 631-644)
                         : (long)nearbyint((double)caller_len * (double)srm / (double)sri)   /* Python round(): half to even */;
         }
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
@@ -874,7 +884,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                 return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 is implemented for the transformer families (zipenhancer, mel_band_roformer, mossformer2_ss)"));
         }
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
-                       : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
+                       : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
@@ -896,6 +906,14 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                 e->rs_scale_in = (float)((double)sri / (double)srm);
                 e->rs_scale_out = (float)((double)srm / (double)sro);
                 e->sub->float_src_len = (int)caller_len;
+            } else if (fam_melband) {   // scale_factor on both edges; down-sampling precedes the * 32767 of an int16 output, up-sampling follows it (Export_MelBandRoformer.py:660-680)
+                const double f_in = (double)srm / (double)sri, f_out = (double)sro / (double)srm;
+                out_caller = sro == srm ? (long)e->rs_model_out : (long)floor((double)e->rs_model_out * f_out);
+                e->rs_scale_in = sri == srm ? 1.0f : (float)(1.0 / f_in);
+                e->rs_scale_out = sro == srm ? 0.0f : (float)(1.0 / f_out);
+                e->rs_sandwich_out = true;
+                e->rs_scale_first = sro > srm;
+                if (out_caller < 1) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "mel_band_roformer: the output-rate waveform is empty"));
             } else {
                 out_caller = (long)nearbyint((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
                 e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);

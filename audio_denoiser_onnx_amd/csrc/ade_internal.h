@@ -121,6 +121,7 @@ void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int
 void launch_stream_concat_flush(hipStream_t s, const int16_t* hist, const int16_t* prev, int16_t* concat, int B);
 // linear resampling of the driver edges (F.interpolate(mode='linear', align_corners=False)); src = scale * (dst + 0.5) - 0.5
 void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale);
+void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first);
 void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32);
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32);
 
@@ -193,6 +194,6 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, 
 int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "zipenhancer" (ZipEnhancer/Export_ZipEnhancer.py:357-927), csrc/ade_zipenhancer.hip
 int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err);
-int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err);
+int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

@@ -1079,6 +1079,9 @@ void launch_gt_sandwich_in(hipStream_t s, const int16_t* pcm, const float* fin, 
     hipLaunchKernelGGL(k_row_mean_f32, dim3((unsigned)rows), dim3(256), 0, s, (const float*)tmp, L1, mean);
     hipLaunchKernelGGL(k_gt_in_stage3, grid1((long long)rows * Lm, 256), dim3(256), 0, s, (const float*)tmp, (const float*)mean, out, L1, Lm, lerp2, (long long)rows * Lm);
 }
+void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first) {
+    hipLaunchKernelGGL(k_gt_out, grid1(rows * Lout, 256), dim3(256), 0, s, wave, pcm, f32, Lw, Lout, lerp, scale_first ? 1 : 0, rows * Lout);
+}
 void launch_gt_sandwich_out(hipStream_t s, const float* frames, FftTabs tabs, int rows, int T, int keep, float* wave, int16_t* pcm, float* f32, int Lout, float lerp,
                             bool scale_first) {
     hipLaunchKernelGGL(k_ola_keep, grid1((long long)rows * keep, 256), dim3(256), 0, s, frames, tabs.win_sum, tabs.win, T, keep, wave, (long long)rows * keep);

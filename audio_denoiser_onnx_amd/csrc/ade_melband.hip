@@ -51,9 +51,10 @@ __device__ __forceinline__ size_t pcm_row_offset(int r, int n_win, int L) {
     const int b = r >> 1, ch = r & 1, call = b / n_win, w = b - call * n_win;
     return ((size_t)(call * kChan + ch) * n_win + w) * L;
 }
+template <typename SAMPLE>      // int16_t: the caller's PCM; float: the same samples in PCM units after the engine's resampling edge (audio.float() + F.interpolate, :630-644)
 struct StereoFrameB {          // B(k, j) = reflect-padded sample k of frame j = (row r, t), * 2^-15 (:326-327, :649)
     static constexpr bool kAlongN = false;
-    const int16_t* pcm;
+    const SAMPLE* pcm;
     int L, T, n_win;
     __device__ float operator()(int k, int j) const {
         const int r = j / T, t = j - r * T;
@@ -520,8 +521,10 @@ struct MelbandEngine : SubEngine {
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
+    int Lo = 0;                // output samples per window: L for a static export; 441 (T - 1) + 1024 with the dynamic-length ISTFT trim (Stereo/STFT_Process.py:296-306)
     int in_len() const override { return L * n_win; }
-    int out_len() const override { return L * n_win; }
+    int out_len() const override { return Lo * n_win; }
+    bool accepts_float_input() const override { return true; }
     int channels() const override { return kChan; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
@@ -529,12 +532,15 @@ struct MelbandEngine : SubEngine {
     void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
 };
 
-int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err) {
+int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return mfail(err, ADE_ERR_BAD_VALUE, "melband: n_win must be >= 1");
-    if (in_len < kNfftM || in_len % kHopM != 0)
-        return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: input_audio_length must be a multiple of the 441-sample hop and at least 2048");
+    if (dynamic && n_win != 1) return mfail(err, ADE_ERR_BAD_VALUE, "melband: batch folding requires a static shape (Export_MelBandRoformer.py:315-316)");
+    if (in_len < kNfftM || (!dynamic && in_len % kHopM != 0))
+        return mfail(err, ADE_ERR_SHAPE_MISMATCH, "melband: input_audio_length must be a multiple of the 441-sample hop and at least 2048 (any length >= 2048 with dynamic_axes=1)");
     const int T = in_len / kHopM + 1;
+    // static export: the trim [n_fft / 2 : raw - n_fft / 2] = 441 (T - 1) samples (= in_len); dynamic: [n_fft / 2 : out_end(max_frames)] = everything after the first half window
+    const int out_one = dynamic ? kHopM * (T - 1) + kNfftM / 2 : kHopM * (T - 1);
     auto find = [&](const std::string& name) -> const Tensor* {
         auto it = tensors.find(name);
         if (it == tensors.end()) { err = "weights: tensor missing: " + name; return nullptr; }
@@ -575,7 +581,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
 
     MelbandEngine* e = new MelbandEngine();
     e->bf16 = bf16;
-    e->device = device; e->L = in_len; e->n_win = n_win; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
+    e->device = device; e->L = in_len; e->Lo = out_one; e->n_win = n_win; e->T = T; e->depth = depth; e->nb = nb; e->dim = dim; e->di = di; e->heads = heads; e->ffd = ffd; e->med = med;
     e->S2 = off[nb];
     for (int i = 0; i < nb; ++i) e->max_d = std::max(e->max_d, off[i + 1] - off[i]);
     auto bail = [&](int st) { delete e; return st; };
@@ -613,7 +619,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
     const size_t a_m1 = place(m1->data, m1->count), a_mb1 = place(mb1->data, mb1->count), a_m2 = place(m2->data, m2->count), a_mb2 = place(mb2->data, mb2->count);
 
     // ---- host-built tables: DFT matrices (exact angles), COLA sum, rotary tables (:395-401, :438-449)
-    std::vector<float> fwd((size_t)2 * kBinsM * kNfftM), inv((size_t)2 * kBinsM * kNfftM), win((size_t)kNfftM), wsum((size_t)in_len, 0.0f);
+    std::vector<float> fwd((size_t)2 * kBinsM * kNfftM), inv((size_t)2 * kBinsM * kNfftM), win((size_t)kNfftM), wsum((size_t)out_one, 0.0f);
     {
         const float step = (float)(2.0 * M_PI / (double)kNfftM);
         for (int n = 0; n < kNfftM; ++n) win[n] = cosf((float)n * step) * (-0.5f) + 0.5f;       // torch.hann_window(periodic=True) in fp32
@@ -637,7 +643,7 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
         std::vector<float> raw((size_t)kNfftM + (size_t)kHopM * (T - 1), 0.0f);
         for (int t = 0; t < T; ++t)
             for (int n = 0; n < kNfftM; ++n) raw[(size_t)t * kHopM + n] += win[n] * win[n];
-        for (int m = 0; m < in_len; ++m) wsum[m] = raw[(size_t)m + kNfftM / 2];
+        for (int m = 0; m < out_one; ++m) wsum[m] = raw[(size_t)m + kNfftM / 2];      // (the dynamic tail has only the last frame under it: w^2 down to ~0 at the end)
     }
     auto half_round = [](float v) {      // float -> IEEE binary16 -> float, round to nearest even (|v| <= 1 here: cos / sin)
         uint32_t u;
@@ -770,7 +776,8 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     using namespace gemm;
     const int B = batch * n_win, BT = B * T, R = nb * BT, J = BT * kChan;      // every fold window is an independent stereo clip (:588-594)
     // STFT of every (clip, channel) row into channel-interleaved bins                                                              (:648-651, :596)
-    launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB{d_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
+    if (float_in) launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB<float>{float_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
+    else launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB<int16_t>{d_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
     // band split                                                                                                                   (:597-599)
     hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
     launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim, bf16);
@@ -788,8 +795,8 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
                        csr_d, MS, mask_tap, B, T);                                                                                  // (:616-624)
     // synthesis GEMM + overlap-add + PCM tail                                                                                      (:661, :667-676)
     launch(s, PlanarSpecA{MS, J}, RowMajorB{k_inv, kNfftM}, BiasActStore<kActNone>{frames_buf, kNfftM, nullptr, 0.0f}, J, kNfftM, 2 * kBinsM);
-    const long long total = (long long)B * kChan * L;
-    hipLaunchKernelGGL(k_melband_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)frames_buf, wsum, d_out, d_f32, T, L, n_win, total);
+    const long long total = (long long)B * kChan * Lo;
+    hipLaunchKernelGGL(k_melband_ola_pcm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)frames_buf, wsum, d_out, d_f32, T, Lo, n_win, total);
     MB_HIP(hipGetLastError());
     return ADE_OK;
 }

@@ -7,7 +7,7 @@ matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the
 
     python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000] [--dynamic] [--in-rate 48000] [--out-rate 8000]
                                                                                        [--in-dtype F32] [--out-dtype F32]
-    python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold]
+    python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold] [--dynamic [--in-rate 48000] [--out-rate 48000]]
     python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
     python -m audio_denoiser_onnx_amd.export --family ul_unas <model_trained_on_dns3.tar> <out_dir> [--length 16000]
     python -m audio_denoiser_onnx_amd.export --family zipenhancer <pytorch_model.bin> <out_dir> [--length 32000] [--fold]
@@ -105,15 +105,17 @@ def export_gtcrn(checkpoint, out_dir, input_audio_length: int = 16000, name: str
 
 
 def export_melband(checkpoint, out_dir, input_audio_length: int = 66150, use_batch_fold: bool = False, heads: int = 8, dim_head: int = 64,
-                   name: str = "MelBandRoformer") -> Path:
-    """Upstream Mel-Band-Roformer ``.ckpt`` -> ``<name>.adew`` + manifest (the role of Export_MelBandRoformer.py:684-737 minus ONNX)."""
+                   name: str = "MelBandRoformer", dynamic_axes: bool = False, in_sample_rate: int = 44100, out_sample_rate: int = 44100) -> Path:
+    """Upstream Mel-Band-Roformer ``.ckpt`` -> ``<name>.adew`` + manifest (the role of Export_MelBandRoformer.py:684-737 minus ONNX).
+    ``dynamic_axes`` / other sample rates: the reference's DYNAMIC_AXES export (:33, :50-53); the engine serves ``input_audio_length`` per handle."""
     from . import melband
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     model_path = out_dir / f"{name}.adew"
     sd = {k: v for k, v in load_state_dict(checkpoint).items() if not k.endswith("rotary_embed.freqs")}
     save_blob(model_path, melband.model_tensors(melband.fuse_checkpoint(sd, heads=heads, dim_head=dim_head)))
-    write_metadata(model_path, melband.metadata(input_audio_length, use_batch_fold=use_batch_fold))
+    write_metadata(model_path, melband.metadata(input_audio_length, use_batch_fold=use_batch_fold, dynamic_axes=dynamic_axes, in_sample_rate=in_sample_rate,
+                                                out_sample_rate=out_sample_rate))
     return model_path
 
 
@@ -187,7 +189,7 @@ def main(argv=None) -> int:
     if "--fold" in argv:
         argv.remove("--fold")
         fold = True
-    gt = {"dynamic_axes": False, "in_sample_rate": 16000, "out_sample_rate": 16000, "input_audio_dtype": "INT16", "output_audio_dtype": "INT16"}     # GTCRN's I/O switches
+    gt = {"dynamic_axes": False, "in_sample_rate": None, "out_sample_rate": None, "input_audio_dtype": "INT16", "output_audio_dtype": "INT16"}     # GTCRN's / Mel-Band's I/O switches
     if "--dynamic" in argv:
         argv.remove("--dynamic")
         gt["dynamic_axes"] = True
@@ -200,8 +202,12 @@ def main(argv=None) -> int:
     if len(argv) != 2 or family not in ("gtcrn", "h_gtcrn", "mel_band_roformer", "mossformer2_ss", "ul_unas", "zipenhancer"):
         print(__doc__)
         return 2
+    model_rate = 44100 if family == "mel_band_roformer" else 16000
+    gt["in_sample_rate"] = gt["in_sample_rate"] or model_rate
+    gt["out_sample_rate"] = gt["out_sample_rate"] or model_rate
     if family == "mel_band_roformer":
-        path = export_melband(argv[0], argv[1], length or 66150, fold)
+        path = export_melband(argv[0], argv[1], length or 66150, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"],
+                              out_sample_rate=gt["out_sample_rate"])
     elif family == "mossformer2_ss":
         path = export_mossformer(argv[0], argv[1], length or 24000, fold)
     elif family == "ul_unas":

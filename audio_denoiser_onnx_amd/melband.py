@@ -29,17 +29,26 @@ def model_tensors(fused: Mapping[str, np.ndarray], num_bands: int = NUM_BANDS) -
 
 
 def metadata(input_audio_length: int, dft_tables: str = "reference", use_batch_fold: bool = False,
-             batch_window_seconds: float = 1.5, gemm_dtype: str = "f32") -> Dict[str, str]:
+             batch_window_seconds: float = 1.5, gemm_dtype: str = "f32", dynamic_axes: bool = False,
+             in_sample_rate: int = SAMPLE_RATE, out_sample_rate: int = SAMPLE_RATE) -> Dict[str, str]:
     """Manifest of a static stereo export.  ``use_batch_fold`` as in the reference (Export_MelBandRoformer.py:47-51): the graph
     input is ``input_audio_length`` rounded up to whole windows of ``batch_window_seconds`` (itself rounded up to the hop),
     each window an independent stereo clip; without it the clip is ``input_audio_length`` long (a multiple of the hop) and
     windows can still be passed as batch rows.
     ``dft_tables``: "reference" = the reference's fp32-angle DFT matrices (bit-compatible behaviour, default);
-    "exact" = exactly reduced angles (see csrc/ade_melband.hip)."""
-    if not use_batch_fold and input_audio_length % HOP:
+    "exact" = exactly reduced angles (see csrc/ade_melband.hip).
+    ``dynamic_axes`` = a DYNAMIC_AXES export (Export_MelBandRoformer.py:33, :50): any ``input_audio_length`` whose model-rate length reaches one window,
+    other input / output sample rates (:52-53, :630-644, :660-680), and an output that keeps the tail of the last frame (Stereo/STFT_Process.py:296-306).
+    The engine serves one input length per handle."""
+    if dynamic_axes and use_batch_fold:
+        raise ValueError("Batch folding requires a static shape (dynamic_axes=False)")
+    if not dynamic_axes and (in_sample_rate != SAMPLE_RATE or out_sample_rate != SAMPLE_RATE):
+        raise ValueError("other sample rates need dynamic_axes=True: the static export sizes its frames from the input-rate length (:50)")
+    if not use_batch_fold and not dynamic_axes and input_audio_length % HOP:
         raise ValueError(f"input_audio_length must be a multiple of the hop ({HOP})")
     return build_audio_metadata(producer="audio_denoiser_onnx_amd", model_name="MelBandRoformer", task="denoise",
-                                model_family="mel_band_roformer", input_audio_length=input_audio_length, in_sample_rate=SAMPLE_RATE,
+                                model_family="mel_band_roformer", input_audio_length=input_audio_length, in_sample_rate=in_sample_rate,
+                                out_sample_rate=out_sample_rate, model_sample_rate=SAMPLE_RATE, dynamic_axes=dynamic_axes,
                                 nfft=NFFT, window_length=NFFT, hop_length=HOP, window_type="hann", center_pad=True, pad_mode="reflect",
                                 use_batch_fold=use_batch_fold, batch_window_seconds=batch_window_seconds, input_channels=2,
                                 output_channels=2, extra={"ade_dft_tables": dft_tables, "ade_gemm_dtype": gemm_dtype})

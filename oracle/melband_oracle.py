@@ -73,17 +73,21 @@ def _gelu(x: np.ndarray) -> np.ndarray:
 
 class MelBandOracle:
     """tensors: the fused buffers by their registered names (bs_w_i, time0_in_w, ..., me_w3_i); freq_indices / dim_inputs:
-    the reference's band tables; frames: static frame count T; in_len = (T - 1) * 441."""
+    the reference's band tables; frames: static frame count T; in_len = (T - 1) * 441.
+    dynamic=True restates a DYNAMIC_AXES export (:33, :50, :696): `length` model-rate samples per channel (any length >= 2048; T = length // 441 + 1
+    frames) and the ISTFT keeps everything after the first half window, divided by the window sum of those T frames (Stereo/STFT_Process.py:296-306)."""
 
     def __init__(self, tensors: dict, freq_indices: np.ndarray, dim_inputs: np.ndarray, frames: int, depth: int,
-                 heads: int = 8, dim_head: int = 64, exact_dft: bool = False):
+                 heads: int = 8, dim_head: int = 64, exact_dft: bool = False, dynamic: bool = False, length: int | None = None):
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         self.fi = np.asarray(freq_indices, np.int64)
         self.dims = [int(d) for d in dim_inputs]
         self.T, self.depth, self.heads, self.dh = int(frames), int(depth), heads, dim_head
         self.di = heads * dim_head
         self.nb = len(self.dims)
-        self.L = (self.T - 1) * HOP
+        self.L = (self.T - 1) * HOP if length is None else int(length)
+        assert self.L // HOP + 1 == self.T and (dynamic or self.L % HOP == 0)
+        self.Lo = (self.T - 1) * HOP + NFFT // 2 if dynamic else self.L
         self.fwd, self.inv, win = stft_kernels(exact_dft)
         self.tcos, self.tsin = rotary_tables(self.T, dim_head, True)
         self.fcos, self.fsin = rotary_tables(self.nb, dim_head, False)
@@ -92,7 +96,7 @@ class MelBandOracle:
         w2 = (win * win).astype(F32)
         for t in range(self.T):
             raw[t * HOP:t * HOP + NFFT] += w2
-        self.win_sum = raw[NFFT // 2:NFFT // 2 + self.L].copy()
+        self.win_sum = raw[NFFT // 2:NFFT // 2 + self.Lo].copy()
         self.taps = {}
 
     # ---- transformer pieces (:540-572) ----
@@ -120,10 +124,33 @@ class MelBandOracle:
         return (_normalize(x) * self.w[p + "_out_g"]).astype(F32)
 
     def process(self, pcm: np.ndarray) -> np.ndarray:
-        """pcm int16 (2, L) -> int16 (2, L)   (forward :626-680, no fold, all rates 44.1 kHz)."""
+        """pcm int16 (2, L) -> int16 (2, Lo)   (forward :626-680, no fold, all rates 44.1 kHz)."""
         assert pcm.shape == (2, self.L) and pcm.dtype == np.int16
+        wav = self.process_wave(pcm.astype(F32))
+        return np.clip(wav * F32(32767.0), -32768.0, 32767.0).astype(np.int16)             # (:667, :676) trunc toward zero
+
+    def process_rates(self, pcm: np.ndarray, in_rate: int, out_rate: int) -> np.ndarray:
+        """The resampling sandwich of forward (:630-644, :660-680) around the network: F.interpolate(scale_factor = float(MODEL / IN)) on audio.float(),
+        down-sampling before the * 32767 of the int16 output and up-sampling after it.  pcm int16 (2, n) with floor(n * MODEL / IN) == self.L."""
+        from gtcrn_sandwich import interpolate_scale
+        x = pcm.astype(F32)                                                                # :630
+        if in_rate != SR:
+            x = interpolate_scale(x, float(SR / in_rate))                                  # :52, :631-644
+        assert x.shape == (2, self.L), (x.shape, self.L)
+        wav = self.process_wave(x)
+        f_out = float(out_rate / SR)                                                       # :53
+        if out_rate < SR:
+            wav = interpolate_scale(wav, f_out)                                            # :660-666
+        wav = (wav * F32(32767.0)).astype(F32)                                             # :667-668
+        if out_rate > SR:
+            wav = interpolate_scale(wav, f_out)                                            # :669-675
+        return np.clip(wav, -32768.0, 32767.0).astype(np.int16)                            # :676-677
+
+    def process_wave(self, samples: np.ndarray) -> np.ndarray:
+        """fp32 samples in PCM units (2, L) -> the normalised fp32 waveform (2, Lo) the ISTFT returns."""
+        assert samples.shape == (2, self.L) and samples.dtype == F32
         T, half = self.T, NFFT // 2
-        x = pcm.astype(F32) * F32(1.0 / 32768.0)                 # INV_INT16 folded into the STFT kernel (:326-327)
+        x = samples * F32(1.0 / 32768.0)                         # INV_INT16 folded into the STFT kernel (:326-327)
         xp = np.concatenate((x[:, 1:half + 1][:, ::-1], x, x[:, -(half + 1):-1][:, ::-1]), axis=1)
         frames = np.stack([xp[:, t * HOP:t * HOP + NFFT] for t in range(T)], axis=1)      # (2, T, 2048)
         spec = (frames @ self.fwd.T).astype(F32)                                           # (2, T, 2*1025)
@@ -166,8 +193,7 @@ class MelBandOracle:
         raw = np.zeros((2, NFFT + HOP * (T - 1)), F32)
         for t in range(T):
             raw[:, t * HOP:t * HOP + NFFT] += fr[:, t]
-        wav = (raw[:, half:half + self.L] / self.win_sum).astype(F32)
-        return np.clip(wav * F32(32767.0), -32768.0, 32767.0).astype(np.int16)             # (:667, :676) trunc toward zero
+        return (raw[:, half:half + self.Lo] / self.win_sum).astype(F32)
 
     def process_fold(self, pcm: np.ndarray, n_win: int) -> np.ndarray:
         """USE_BATCH_FOLD (:644-647, :663-664): (2, n_win * W) -> n_win independent stereo clips of W -> stitched back per channel."""

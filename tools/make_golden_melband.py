@@ -35,12 +35,13 @@ from audio_denoiser_onnx_amd import weightgen  # noqa: E402
 L, DEPTH = 13230, 1          # 0.3 s of stereo @ 44.1 kHz -> 31 frames; one (time, freq) transformer pair
 
 
-def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5, extra: dict | None = None) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "Mel_Band_Roformer", "Stereo", "Export_MelBandRoformer.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    over.update(extra or {})
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -91,7 +92,7 @@ def build_model(ns, length, depth=None):
     STFT_Process = import_stft_process("Mel_Band_Roformer/Stereo").STFT_Process
     stft = STFT_Process("stft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], 0, ns["WINDOW_TYPE"], True, "reflect").eval()
     istft = STFT_Process("istft_B", ns["NFFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], T, ns["WINDOW_TYPE"], True, "reflect",
-                         static_frames=True).eval()
+                         static_frames=not ns["DYNAMIC_AXES"]).eval()                      # (:696)
     real_load, real_lsd = torch.load, nn.Module.load_state_dict
     torch.load = lambda *a, **k: {}
     nn.Module.load_state_dict = lambda self, sd, strict=True: types.SimpleNamespace(missing_keys=[], unexpected_keys=[])
@@ -230,6 +231,32 @@ def fusion_fixture():
                         names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
     print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
 
+
+def dynamic_fixture():
+    """DYNAMIC_AXES = True exports (:33, :50): any input length, other input / output sample rates (:52-53, :630-644, :660-680), the dynamic ISTFT trim
+    (Stereo/STFT_Process.py:296-306).  tests/golden/melband_dynamic_seed0.npz; the weights are melband_seed0_io.npz's (same spec, depth 1)."""
+    cases = [("dyn_44100", 13000, 44100, 44100),          # a length that is not a multiple of the hop
+             ("dyn_48000_to_22050", 14400, 48000, 22050),  # down-sample on both edges
+             ("dyn_32000_to_48000", 9600, 32000, 48000),   # up-sample on both edges (the * 32767 precedes the output interpolation)
+             ("dyn_44100_to_48000", 13230, 44100, 48000)]  # output edge only
+    out = {}
+    for tag, n, sri, sro in cases:
+        ns = import_namespace(n, extra={"DYNAMIC_AXES": True, "IN_SAMPLE_RATE": sri, "OUT_SAMPLE_RATE": sro})
+        assert ns["MAX_SIGNAL_LENGTH"] == 2048 and not ns["USE_BATCH_FOLD"]
+        model, spec, _ = build_model(ns, n)
+        pcm = read_clip(44100, n)
+        with torch.inference_mode():
+            y = model(torch.from_numpy(pcm.reshape(1, 2, n).copy())).numpy()
+        y = y.reshape(2, -1)
+        out[tag + "_in"], out[tag + "_out"] = pcm, y
+        out[tag + "_rates"] = np.asarray([sri, sro], np.int64)
+        print(tag, "in", pcm.shape, "out", y.shape, y.dtype, "max", int(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, "melband_dynamic_seed0.npz"), cases=np.array(json.dumps([c[0] for c in cases])), **out)
+
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--production-size" in sys.argv:
     production_size()
