@@ -56,7 +56,7 @@ EXPORTED_SYMBOLS = (
     "ade_create", "ade_get_io", "ade_process", "ade_process_device", "ade_process_f32", "ade_process_device_f32", "ade_reserve", "ade_set_option", "ade_debug_tap",
     "ade_kernel_count", "ade_kernel_name", "ade_profile_last", "ade_kernel_ms", "ade_last_error", "ade_destroy",
     "ade_stft_forward", "ade_istft_forward",
-    "ade_stft_create", "ade_stft_frames", "ade_stft_output_length", "ade_stft_analyze", "ade_stft_synthesize", "ade_stft_synthesize_polar",
+    "ade_stft_create", "ade_stft_frames", "ade_stft_output_length", "ade_stft_keep_tail", "ade_stft_analyze", "ade_stft_synthesize", "ade_stft_synthesize_polar",
     "ade_stream_create", "ade_stream_push", "ade_stream_push_device", "ade_stream_flush", "ade_stream_reset", "ade_stream_destroy",
     "ade_stft_last_error", "ade_stft_destroy",
 )
@@ -112,6 +112,7 @@ class AdeLibrary:
         L.ade_stft_create.argtypes = [C.POINTER(StftConfig), C.c_int, C.POINTER(C.c_void_p)]
         L.ade_stft_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.ade_stft_output_length.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.ade_stft_keep_tail.argtypes = [C.c_void_p, C.c_int]
         L.ade_stft_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ade_stft_synthesize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ade_stft_synthesize_polar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

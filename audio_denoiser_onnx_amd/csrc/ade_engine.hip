@@ -811,8 +811,10 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (!parse_bool(e->meta["dynamic_axes"], &dyn_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key dynamic_axes must be a boolean encoded as 1/0, got '" + e->meta["dynamic_axes"] + "'."));
         // A dynamic_axes export of Mel-Band-Roformer takes its frame count from the waveform and keeps everything after the first half window of the overlap-add
-        // (Stereo/STFT_Process.py:296-306); the engine still serves ONE input length per handle.  The other families' dynamic exports are not built.
-        if (dyn_d && !fam_melband) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn and mel_band_roformer (static shapes only for " + fam + ")"));
+        // (Stereo/STFT_Process.py:296-306), UL-UNAS's slices that to the caller-rate input length (Export_UL_UNAS.py:851, 888-889); the engine still serves ONE input
+        // length per handle.  The other families' dynamic exports are not built (their static exports resample consistently).
+        const bool fam_sand = fam_melband || fam_ulu;       // families whose resampling follows GTCRN_CUSTOM's scale-factor sandwich and needs dynamic axes
+        if (dyn_d && !fam_sand) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer and ul_unas (static shapes only for " + fam + ")"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
         if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
@@ -831,9 +833,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // the static frame count from the INPUT-rate length (Export_MelBandRoformer.py:52), which only agrees with the STFT at equal rates.
         // H-GTCRN's static export is consistent too (frames from MODEL_AUDIO_LENGTH, Export_H_GTCRN.py:45-46); it interpolates by SCALE FACTOR.
         // ZipEnhancer sizes its frames from MODEL_AUDIO_LENGTH too (Export_ZipEnhancer.py:55, 61) and interpolates by size (:826-832, :905-911).
-        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg && !fam_zip && !(fam_melband && dyn_d))
+        if (rates_differ && !fam_moss && !fam_dfsmn && !fam_hg && !fam_zip && !(fam_sand && dyn_d))
             return bail(fail(e, ADE_ERR_UNSUPPORTED, fam + " runs at " + std::to_string(rate) + " Hz in, model and out (its static export has no consistent resampling path" +
-                                                     (fam_melband ? ": export with dynamic_axes=1 for other rates)" : ")")));
+                                                     (fam_sand ? ": export with dynamic_axes=1 for other rates)" : ")")));
         if (dyn_d && fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires a static shape (dynamic_axes=0)."));     // (Export_MelBandRoformer.py:46)
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
         if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
@@ -845,6 +847,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
             Ld = fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
                  : fam_melband ? (long)floor((double)caller_len * ((double)srm / (double)sri))       // F.interpolate(scale_factor = float(MODEL / IN)) (Export_MelBandRoformer.py:52, 631-644)
+                 : fam_ulu ? (long)floor((double)caller_len * (1.0 / ((double)sri / 16000.0)))       // scale_factor = 1 / (in_sample_rate / 16000.0) (Export_UL_UNAS.py:835-837, 852-868)
                         : (long)nearbyint((double)caller_len * (double)srm / (double)sri)   /* Python round(): half to even */;
         }
         if (fold_d) {   // the graph input is ceil(L / W) whole windows of W model-rate samples, folded into the batch inside the model
@@ -885,7 +888,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         }
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
-                       : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
+                       : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, dyn_d ? (int)caller_len : 0, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, device, &e->sub, derr);
@@ -906,14 +909,15 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                 e->rs_scale_in = (float)((double)sri / (double)srm);
                 e->rs_scale_out = (float)((double)srm / (double)sro);
                 e->sub->float_src_len = (int)caller_len;
-            } else if (fam_melband) {   // scale_factor on both edges; down-sampling precedes the * 32767 of an int16 output, up-sampling follows it (Export_MelBandRoformer.py:660-680)
-                const double f_in = (double)srm / (double)sri, f_out = (double)sro / (double)srm;
+            } else if (fam_sand) {   // scale_factor on both edges; down-sampling precedes the * 32767 of an int16 output, up-sampling follows it (Export_MelBandRoformer.py:660-680,
+                //                                                                                                                     Export_UL_UNAS.py:890-905)
+                const double f_in = fam_ulu ? 1.0 / ((double)sri / 16000.0) : (double)srm / (double)sri, f_out = fam_ulu ? (double)sro / 16000.0 : (double)sro / (double)srm;
                 out_caller = sro == srm ? (long)e->rs_model_out : (long)floor((double)e->rs_model_out * f_out);
                 e->rs_scale_in = sri == srm ? 1.0f : (float)(1.0 / f_in);
                 e->rs_scale_out = sro == srm ? 0.0f : (float)(1.0 / f_out);
                 e->rs_sandwich_out = true;
                 e->rs_scale_first = sro > srm;
-                if (out_caller < 1) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "mel_band_roformer: the output-rate waveform is empty"));
+                if (out_caller < 1) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, fam + ": the output-rate waveform is empty"));
             } else {
                 out_caller = (long)nearbyint((double)caller_len * (double)sro / (double)sri);     // OUTPUT_AUDIO_LENGTH (:37)
                 e->rs_scale_in = (float)((double)caller_len / (double)e->rs_model_in);

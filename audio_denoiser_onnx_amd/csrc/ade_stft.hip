@@ -232,6 +232,7 @@ struct ade_stft_plan {
     int device = 0;
     ade::StftDims d{};
     int center = 1;
+    int keep_tail = 0;                            // the dynamic-length trim: everything after the leading half window (ade_stft_keep_tail)
     float *d_fwd = nullptr, *d_inv = nullptr, *d_wsq = nullptr, *d_frames = nullptr;      // dense tables: only when n_fft has a prime factor above 5
     bool use_fft = false;
     ade::fft::Plan fft_plan{};
@@ -350,7 +351,13 @@ ade_status ade_stft_frames(ade_stft_handle p, int length, int* frames) {
 ade_status ade_stft_output_length(ade_stft_handle p, int frames, int* out_len) {
     if (!p || !out_len || frames < 1) return ADE_ERR_BAD_VALUE;
     const int raw = p->d.n_fft + p->d.hop * (frames - 1);
-    *out_len = p->center ? raw - p->d.n_fft : raw;
+    *out_len = p->center ? raw - (p->keep_tail ? p->d.n_fft / 2 : p->d.n_fft) : raw;
+    return ADE_OK;
+}
+
+ade_status ade_stft_keep_tail(ade_stft_handle p, int keep_tail) {
+    if (!p) return ADE_ERR_BAD_VALUE;
+    p->keep_tail = keep_tail ? 1 : 0;
     return ADE_OK;
 }
 

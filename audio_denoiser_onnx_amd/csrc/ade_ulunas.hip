@@ -242,6 +242,12 @@ __global__ __launch_bounds__(256) void k_ulu_pcm2f(const int16_t* __restrict__ p
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < total) x[i] = (float)pcm[i] * (1.0f / 32768.0f);
 }
+// the resampled entry (:851-867): fp32 samples in PCM units (audio.float() interpolated by the engine); the * INV_INT16 before or after the interpolation is the
+// same number either way (a power of two commutes with every rounding of the interpolation)
+__global__ __launch_bounds__(256) void k_ulu_f2f(const float* __restrict__ in, float* __restrict__ x, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) x[i] = in[i] * (1.0f / 32768.0f);
+}
 // log-power + ERB merge (:725-727, :97-100): feat[frame][j], j < 129; spec is [b][re 257 | im 257][T].  band_lo / band_hi: the non-zero
 // run of every ERB filter row (the filters are triangles: contiguous support).
 __global__ __launch_bounds__(256) void k_ulu_feat(const float* __restrict__ spec, const float* __restrict__ erb, const int* __restrict__ band_lo,
@@ -285,11 +291,14 @@ __global__ __launch_bounds__(256) void k_ulu_mask(const float* __restrict__ m129
     s[(size_t)(kUBins + f) * T] *= v;
     if (mask_tap) mask_tap[i] = v;
 }
-__global__ __launch_bounds__(256) void k_ulu_f2pcm(const float* __restrict__ y, int16_t* __restrict__ pcm, float* __restrict__ f32, long long total) {
+// rows of `stride` synthesised samples -> the first `keep` of each (the static trim: keep == stride; a dynamic export slices audio[..., :audio_len], :888-889)
+__global__ __launch_bounds__(256) void k_ulu_f2pcm(const float* __restrict__ y, int16_t* __restrict__ pcm, float* __restrict__ f32, int stride, int keep, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    if (f32) f32[i] = y[i];
-    if (pcm) pcm[i] = (int16_t)(int)fminf(fmaxf(y[i] * 32767.0f, -32768.0f), 32767.0f);
+    const long long r = i / keep;
+    const float v = y[r * stride + (i - r * keep)];
+    if (f32) f32[i] = v;
+    if (pcm) pcm[i] = (int16_t)(int)fminf(fmaxf(v * 32767.0f, -32768.0f), 32767.0f);
 }
 
 int ufail(std::string& err, int st, const std::string& msg) { err = msg; return st; }
@@ -320,6 +329,7 @@ void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* 
 
 struct UlunasEngine : SubEngine {
     int device = 0, L = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0;
+    int syn_len = 0;                   // samples per row the ISTFT writes: out_len_ for a static export, 256 T (the kept tail) for a dynamic one
     ade_stft_handle plan = nullptr;
     float* d_w = nullptr;
     const float* erb = nullptr;
@@ -343,6 +353,7 @@ struct UlunasEngine : SubEngine {
     // stitched in place, so folding is only a reinterpretation of the rows (W is a multiple of the hop: every window returns W samples)
     int in_len() const override { return L * n_win; }
     int out_len() const override { return out_len_ * n_win; }
+    bool accepts_float_input() const override { return true; }
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
@@ -350,8 +361,9 @@ struct UlunasEngine : SubEngine {
     float* run_block(hipStream_t s, const Block& bk, const float* x, const float* x2, float* t0, float* t1, float* dst, int B);
 };
 
-int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, int device, SubEngine** out, std::string& err) {
+int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, int dynamic_keep, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
+    if (dynamic_keep > 0 && n_win != 1) return ufail(err, ADE_ERR_BAD_VALUE, "ul_unas: batch folding requires a static shape (Export_UL_UNAS.py:39)");
     if (in_len < kUNfft) return ufail(err, ADE_ERR_SHAPE_MISMATCH, "ul_unas: input_audio_length shorter than one 512-sample frame");
     if (n_win < 1 || (n_win > 1 && in_len % kUHop)) return ufail(err, ADE_ERR_BAD_VALUE, "ul_unas: fold windows must be whole hops");
     // ULUNAS() defaults (:655-668)
@@ -376,7 +388,11 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     };
     UlunasEngine* e = new UlunasEngine();
     auto bail = [&](int st) { delete e; return st; };
-    e->device = device; e->L = in_len; e->n_win = n_win; e->T = in_len / kUHop + 1; e->out_len_ = kUHop * (e->T - 1);
+    e->device = device; e->L = in_len; e->n_win = n_win; e->T = in_len / kUHop + 1;
+    // static: the trim [256 : raw - 256] = 256 (T - 1) samples; dynamic (:43, :888-889): the ISTFT keeps everything after the first half window (256 T samples) and the
+    // wrapper slices audio[..., :audio_len] with audio_len = the CALLER-rate input length
+    e->syn_len = dynamic_keep > 0 ? kUHop * e->T : kUHop * (e->T - 1);
+    e->out_len_ = dynamic_keep > 0 ? std::min(e->syn_len, dynamic_keep) : e->syn_len;
     auto conv = [&](ConvDesc& d, const std::string& wname, const std::string& aname, int cin, int cout, int fi, int fo, int kt, int kf, int stride, int g, int deconv,
                     bool act, int shuffle) {
         d = ConvDesc{nullptr, nullptr, nullptr, nullptr, nullptr, cin, cout, fi, fo, kt, kf, stride, g, deconv, shuffle};
@@ -516,6 +532,7 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
+    if (dynamic_keep > 0) (void)ade_stft_keep_tail(e->plan, 1);
     *out = e;
     return ADE_OK;
 }
@@ -530,7 +547,7 @@ int UlunasEngine::reserve(int calls, std::string& err) {
     capacity = 0;
     const size_t B = batch, nfr = B * T, act = nfr * 1600;             // widest activation: 65 bins x 24 channels per frame
     struct Carve { float** p; size_t n; };
-    std::vector<Carve> cs = {{&xf, B * L}, {&spec, B * 2 * kUBins * T}, {&yf, B * out_len_}, {&bufA, act}, {&bufB, act}, {&bufC, act}, {&bufD, act}, {&dpa, nfr * kFw * kCh}, {&dpb, nfr * kFw * kCh}, {&zt, nfr * 32},
+    std::vector<Carve> cs = {{&xf, B * L}, {&spec, B * 2 * kUBins * T}, {&yf, B * syn_len}, {&bufA, act}, {&bufB, act}, {&bufC, act}, {&bufD, act}, {&dpa, nfr * kFw * kCh}, {&dpb, nfr * kFw * kCh}, {&zt, nfr * 32},
                              {&pfreq, nfr * 132}, {&at, nfr * 32}, {&fah, nfr * 33 * 8}, {&rnn, nfr * kFw * kCh}, {&dpm, nfr * kFw * kCh}, {&mask_tap, nfr * kUBins}};
     for (int i = 0; i < 5; ++i) cs.push_back({&skip[i], nfr * (size_t)blocks[i].width * blocks[i].cout});
     size_t total = 0;
@@ -614,7 +631,8 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     const int B = batch * n_win;
     const long long nfr = (long long)B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
-    hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
+    if (float_in) hipLaunchKernelGGL(k_ulu_f2f, flat((long long)B * L), dim3(256), 0, s, float_in, xf, (long long)B * L);
+    else hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
     if (ade_stft_analyze(plan, xf, B, L, spec, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
     hipLaunchKernelGGL(k_ulu_feat, flat(nfr * kUErb), dim3(256), 0, s, (const float*)spec, erb, (const int*)d_tab, (const int*)(d_tab + kUBands), bufC, T, nfr * kUErb);
     const float* x = bufC;
@@ -640,7 +658,7 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     hipLaunchKernelGGL(k_ulu_mask, flat(nfr * kUBins), dim3(256), 0, s, dx, erb, (const int*)(d_tab + 2 * kUBands), (const int*)(d_tab + 2 * kUBands + kUHigh), spec, mask_tap, T,
                        nfr * kUBins);
     if (ade_stft_synthesize(plan, spec, B, T, yf, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
-    hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, (long long)B * out_len_);
+    hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, syn_len, out_len_, (long long)B * out_len_);
     UL_HIP(hipGetLastError());
     return ADE_OK;
 }

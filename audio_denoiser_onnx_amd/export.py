@@ -134,14 +134,16 @@ def export_mossformer(checkpoint, out_dir, input_audio_length: int = 24000, use_
     return model_path
 
 
-def export_ulunas(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "UL_UNAS") -> Path:
-    """UL-UNAS checkpoint (``ckpt['model']``, upstream or optimised key names) -> ``<name>.adew`` + manifest (Export_UL_UNAS.py:959-962 minus ONNX)."""
+def export_ulunas(checkpoint, out_dir, input_audio_length: int = 16000, name: str = "UL_UNAS", dynamic_axes: bool = False, in_sample_rate: int = 16000,
+                  out_sample_rate: int = 16000) -> Path:
+    """UL-UNAS checkpoint (``ckpt['model']``, upstream or optimised key names) -> ``<name>.adew`` + manifest (Export_UL_UNAS.py:959-962 minus ONNX).
+    ``dynamic_axes`` / other sample rates: the reference's DYNAMIC_AXES export (:26, :41-43); the engine serves ``input_audio_length`` per handle."""
     from . import ulunas
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     model_path = out_dir / f"{name}.adew"
     save_blob(model_path, ulunas.fold_state_dict(ulunas.convert_state_dict(load_state_dict(checkpoint))))
-    write_metadata(model_path, ulunas.metadata(input_audio_length))
+    write_metadata(model_path, ulunas.metadata(input_audio_length, dynamic_axes=dynamic_axes, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate))
     return model_path
 
 
@@ -211,7 +213,7 @@ def main(argv=None) -> int:
     elif family == "mossformer2_ss":
         path = export_mossformer(argv[0], argv[1], length or 24000, fold)
     elif family == "ul_unas":
-        path = export_ulunas(argv[0], argv[1], length or 16000)
+        path = export_ulunas(argv[0], argv[1], length or 16000, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"], out_sample_rate=gt["out_sample_rate"])
     elif family == "h_gtcrn":
         path = export_hgtcrn(argv[0], argv[1], length or 32000, fold)
     elif family == "zipenhancer":

@@ -33,7 +33,12 @@ class STFT_Process:
         if model_type not in ("stft_A", "stft_B", "istft_A", "istft_B"):
             raise ValueError(f"Unknown model_type: {model_type}")
         # static_norm only chooses between a precomputed and a per-call sum of squared windows in the reference (:253-273 vs :355-361);
-        # the operator always divides by the exact per-sample sum, which both forms equal.
+        # the operator always divides by the exact per-sample sum, which both forms equal.  What static_norm = False changes is the LENGTH when the
+        # ISTFT is fed fewer frames than max_frames (a DYNAMIC_AXES export, e.g. UL-UNAS/Export_UL_UNAS.py:43, 957): the slice
+        # [out_start : out_end(max_frames)] then keeps the second half of the last frame (UL-UNAS/STFT_Process.py:170-177, 317-326).
+        self._dynamic = model_type in ("istft_A", "istft_B") and not static_norm and max_frames > 0
+        self._out_start = n_fft // 2 if center_pad else 0
+        self._out_end = n_fft + hop_len * (max_frames - 1) - self._out_start
         self._lib = library or _lib.get_library()
         self.model_type, self.n_fft, self.hop_len, self.n_frames = model_type, n_fft, hop_len, max_frames
         self.half_n_fft = n_fft // 2
@@ -43,6 +48,12 @@ class STFT_Process:
         if st != _lib.ADE_OK:
             msg = self._lib.c.ade_stft_last_error(None)
             _lib.raise_for_status(st, msg.decode() if msg else f"ade_stft_create status {st}")
+        if self._dynamic:
+            self._check(self._lib.c.ade_stft_keep_tail(self._h, 1))
+
+    def _kept(self, frames: int) -> int:
+        """Samples the reference's slice [out_start : out_end(max_frames)] keeps of a T-frame overlap-add."""
+        return max(0, min(self.n_fft + self.hop_len * (frames - 1), self._out_end) - self._out_start)
 
     def _check(self, st: int) -> None:
         if st != _lib.ADE_OK:
@@ -82,11 +93,11 @@ class STFT_Process:
         B, T = int(x.shape[0]), int(x.shape[2])
         if int(x.shape[1]) != self.n_fft + 2:
             raise ValueError(f"packed spectrum must have {self.n_fft + 2} rows, got {tuple(x.shape)}")
-        if self.n_frames and T != self.n_frames:
+        if self.n_frames and T != self.n_frames and not self._dynamic:
             raise ValueError(f"static ISTFT was built for {self.n_frames} frames, got {T}")
         out = torch.empty((B, 1, self.output_length(T)), dtype=torch.float32, device=x.device)
         self._check(self._lib.c.ade_stft_synthesize(self._h, C.c_void_p(x.data_ptr()), B, T, C.c_void_p(out.data_ptr()), sp))
-        return out
+        return out[..., :self._kept(T)] if self._dynamic else out
 
     @staticmethod
     def split(packed):
@@ -106,12 +117,12 @@ class STFT_Process:
             raise ValueError("STFT_Process takes float32 device tensors")
         magnitude, phase = magnitude.contiguous(), phase.contiguous()
         B, T = int(magnitude.shape[0]), int(magnitude.shape[2])
-        if self.n_frames and T != self.n_frames:
+        if self.n_frames and T != self.n_frames and not self._dynamic:
             raise ValueError(f"static ISTFT was built for {self.n_frames} frames, got {T}")
         out = torch.empty((B, 1, self.output_length(T)), dtype=torch.float32, device=magnitude.device)
         self._check(self._lib.c.ade_stft_synthesize_polar(self._h, C.c_void_p(magnitude.data_ptr()), C.c_void_p(phase.data_ptr()), B, T,
                                                           C.c_void_p(out.data_ptr()), C.c_void_p(stream) if stream else None))
-        return out
+        return out[..., :self._kept(T)] if self._dynamic else out
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h:

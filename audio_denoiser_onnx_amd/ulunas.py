@@ -150,10 +150,18 @@ def fold_state_dict(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return {k: np.ascontiguousarray(v, np.float32) for k, v in out.items()}
 
 
-def metadata(input_audio_length: int = 16000, use_batch_fold: bool = False, batch_window_seconds: float = 1.5) -> Dict[str, str]:
+def metadata(input_audio_length: int = 16000, use_batch_fold: bool = False, batch_window_seconds: float = 1.5, dynamic_axes: bool = False,
+             in_sample_rate: int = 16000, out_sample_rate: int = 16000) -> Dict[str, str]:
     """Manifest keys the reference stamps for this model (:1005-1012): 16 kHz, 512 / 256 'hann' STFT, no DC removal; optionally batch-fold
-    (the graph input is the length rounded up to whole windows of ``batch_window_seconds``, each an independent clip, :41-44)."""
+    (the graph input is the length rounded up to whole windows of ``batch_window_seconds``, each an independent clip, :41-44).
+    ``dynamic_axes`` = a DYNAMIC_AXES export (:26, :41-43): other input / output sample rates become consistent (:835-845, :851-868, :890-905) and the output is the
+    ISTFT's kept tail sliced to the caller-rate input length (:851, :888-889).  The engine serves one input length per handle."""
+    if dynamic_axes and use_batch_fold:
+        raise ValueError("Batch folding requires a static shape (dynamic_axes=False)")
+    if not dynamic_axes and (in_sample_rate != 16000 or out_sample_rate != 16000):
+        raise ValueError("other sample rates need dynamic_axes=True: the static export sizes its frames from the input-rate length (:42)")
     return build_audio_metadata(producer="audio_denoiser_onnx_amd", model_name="UL_UNAS", task="denoise", model_family="ul_unas",
-                                input_audio_length=input_audio_length, in_sample_rate=16000, nfft=NFFT, window_length=NFFT, hop_length=HOP,
+                                input_audio_length=input_audio_length, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate, model_sample_rate=16000,
+                                dynamic_axes=dynamic_axes, nfft=NFFT, window_length=NFFT, hop_length=HOP,
                                 window_type="hann", center_pad=True, pad_mode="reflect", use_batch_fold=use_batch_fold,
                                 batch_window_seconds=batch_window_seconds, extra={"n_mels": 100, "remove_dc_offset": 0})

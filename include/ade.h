@@ -163,6 +163,10 @@ typedef struct ade_stft_config {
 ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_handle* out);
 ade_status ade_stft_frames(ade_stft_handle h, int length, int* frames);             /* T for an input of `length` samples */
 ade_status ade_stft_output_length(ade_stft_handle h, int frames, int* out_len);     /* ISTFT output length for T frames */
+/* The dynamic-length trim of a DYNAMIC_AXES export: the reference's ISTFT slices [n_fft/2 : out_end(max_frames)] and is fed fewer frames than max_frames
+ * (UL-UNAS/STFT_Process.py:170-177, :317-326; Mel_Band_Roformer/Stereo/STFT_Process.py:296-306), so the output keeps the second half of the last frame:
+ * hop (T - 1) + n_fft / 2 samples, each divided by the squared-window sum of the frames that cover it.  keep_tail = 0 (default) is the static trim hop (T - 1). */
+ade_status ade_stft_keep_tail(ade_stft_handle h, int keep_tail);
 ade_status ade_stft_analyze(ade_stft_handle h, const float* d_x, int batch, int length, float* d_spec, void* hip_stream);
 ade_status ade_stft_synthesize(ade_stft_handle h, const float* d_spec, int batch, int frames, float* d_y, void* hip_stream);
 /* The polar form (model_type "istft_A", STFT_Process.py:343-361): magnitude and phase, each [batch][F][T]; real = mag cos(phase),

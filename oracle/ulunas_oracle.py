@@ -16,7 +16,8 @@ NFFT, HOP, FB = 512, 256, 257
 
 
 def _sig(x):
-    return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
+    with np.errstate(over="ignore"):            # exp(-x) -> inf for very negative x: 1 / (1 + inf) = 0, the limit
+        return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
 
 
 def _gru(x, wih, whh, bih, bhh, reverse=False):
@@ -58,7 +59,9 @@ def stft_tables(exact: bool = False):
 
 
 class UlunasOracle:
-    def __init__(self, tensors: dict, plan: list, in_len: int, exact_dft: bool = False):
+    def __init__(self, tensors: dict, plan: list, in_len: int, exact_dft: bool = False, dynamic_keep: int = 0):
+        """dynamic_keep > 0 restates a DYNAMIC_AXES export (:26, :41-43): the ISTFT keeps everything after the first half window (256 T samples,
+        UL-UNAS/STFT_Process.py:170-177, 317-326) and the wrapper slices audio[..., :audio_len] with audio_len = dynamic_keep, the caller-rate input length (:851, :888-889)."""
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         self.plan, self.L = plan, int(in_len)
         self.T = self.L // HOP + 1
@@ -66,7 +69,7 @@ class UlunasOracle:
         raw = np.zeros(NFFT + HOP * (self.T - 1), F32)
         for t in range(self.T):
             raw[t * HOP:t * HOP + NFFT] += (win * win).astype(F32)
-        self.out_len = HOP * (self.T - 1)
+        self.out_len = min(HOP * self.T, int(dynamic_keep)) if dynamic_keep > 0 else HOP * (self.T - 1)
         self.win_sum = raw[NFFT // 2:NFFT // 2 + self.out_len].copy()
         self.taps = {}
 
@@ -219,8 +222,30 @@ class UlunasOracle:
     def process(self, pcm: np.ndarray) -> np.ndarray:
         """pcm int16 (B, L) -> int16 (B, 256 * (T - 1))   (ULUNAS_CUSTOM.forward, static shapes, 16 kHz in and out, no DC removal)."""
         assert pcm.ndim == 2 and pcm.shape[1] == self.L and pcm.dtype == np.int16
-        B, T, half = pcm.shape[0], self.T, NFFT // 2
-        x = pcm.astype(F32) * F32(1.0 / 32768.0)                                              # input_scale folded into the STFT kernel (:944)
+        wav = self.process_wave(pcm.astype(F32))
+        return np.clip(wav * F32(32767.0), -32768.0, 32767.0).astype(np.int16)                # output_scale folded into the ISTFT kernel (:955)
+
+    def process_rates(self, pcm: np.ndarray, in_rate: int, out_rate: int) -> np.ndarray:
+        """The resampling sandwich of a dynamic export (:835-845, :851-868, :890-905) around the network.  pcm int16 (B, n), floor(n / (in_rate / 16000)) == in_len."""
+        from gtcrn_sandwich import interpolate_scale
+        x = pcm.astype(F32)                                                                    # :850
+        in_scale = in_rate / 16000.0                                                           # :835
+        if in_scale != 1.0:     # :852-868: interpolate, * INV_INT16 (down) or * INV_INT16, interpolate (up) -- the same numbers: a power of two commutes with the rounding
+            x = interpolate_scale(x, 1.0 / in_scale)
+        wav = self.process_wave(x)
+        out_scale = out_rate / 16000.0                                                         # :836
+        if out_scale < 1.0:                                                                    # :890-896
+            wav = interpolate_scale(wav, out_scale)
+        wav = (wav * F32(32767.0)).astype(F32)                                                 # :897-898 (or folded into the ISTFT at the model rate, :955)
+        if out_scale > 1.0:                                                                    # :899-905
+            wav = interpolate_scale(wav, out_scale)
+        return np.clip(wav, -32768.0, 32767.0).astype(np.int16)
+
+    def process_wave(self, samples: np.ndarray) -> np.ndarray:
+        """fp32 samples in PCM units (B, L) -> the normalised fp32 waveform (B, out_len)."""
+        assert samples.ndim == 2 and samples.shape[1] == self.L and samples.dtype == F32
+        B, T, half = samples.shape[0], self.T, NFFT // 2
+        x = samples * F32(1.0 / 32768.0)                                                      # input_scale folded into the STFT kernel (:944)
         xp = np.concatenate((x[:, 1:half + 1][:, ::-1], x, x[:, -(half + 1):-1][:, ::-1]), axis=1)
         frames = np.stack([xp[:, t * HOP:t * HOP + NFFT] for t in range(T)], axis=1)          # (B, T, 512)
         spec = (frames @ self.fwd.T).astype(F32)                                               # (B, T, 514)
@@ -250,4 +275,4 @@ class UlunasOracle:
             raw[:, t * HOP:t * HOP + NFFT] += fr[:, t]
         wav = (raw[:, half:half + self.out_len] / self.win_sum).astype(F32)
         self.taps["wav"] = wav.copy()
-        return np.clip(wav * F32(32767.0), -32768.0, 32767.0).astype(np.int16)                # output_scale folded into the ISTFT kernel (:955)
+        return wav

@@ -193,3 +193,35 @@ def test_gpu_stft_fft_path_few_frames(n_fft, hop, length):
         assert y.shape == want.shape and np.abs(y - want).max() <= 1e-5
     finally:
         oracle_set_generic_exact_dft(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,max_frames", [("gtcrn", 4096), ("melband", 2048)])
+def test_gpu_istft_dynamic_trim_keeps_the_tail(name, max_frames):
+    """An ISTFT built for a DYNAMIC_AXES export (max_frames above the frame count, per-call window sum): the reference's slice keeps the second half of the last frame
+    (GTCRN/STFT_Process.py:337-341, Mel_Band_Roformer/Stereo/STFT_Process.py:296-306).  tests/golden/stft_dynamic_tail.npz = that tail from each folder's own copy; the
+    tail divides the last frame alone by its squared window (down to 3.8e-5 / 5.5e-12 at the very end), so it is compared relative to the signal."""
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    g, n_fft, win, hop, center, pad = _load(name)
+    tail = np.load(os.path.join(GOLD, "stft_dynamic_tail.npz"))[name + "_tail"]
+    ws = CASES[name][1]
+    spec = torch.from_numpy(g["spec"]).cuda()
+    T = spec.shape[2]
+    y = STFT_Process("istft_B", n_fft, win, hop, max_frames, ws, center, pad, static_norm=False)(spec).cpu().numpy().reshape(2, -1)
+    static_len = hop * (T - 1)
+    assert y.shape == (2, static_len + n_fft // 2) and tail.shape == (2, n_fft // 2)
+    assert np.abs(y[:, :static_len] - g["y"]).max() <= 1e-4                            # the static part is unchanged
+    # the tail is (last frame) / w^2: an absolute error e of the frame (fp32 round-off here, the fp32-angle tables in the reference: ~3e-7 of the signal) becomes e / w^2
+    n = np.arange(n_fft // 2, n_fft)
+    hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    w2 = hann if ws == "hann_sqrt" else hann * hann
+    # (the reference's fp32-angle tables are off by up to ~1e-4 of the signal at n_fft = 2048, see test_gpu_stft_process_configs; the operator's are exact)
+    assert (np.abs(y[:, static_len:] - tail) <= 1e-4 + 1e-7 * n_fft * np.abs(g["x"]).max() / w2).all(), np.abs(y[:, static_len:] - tail).max()
+    body = slice(0, n_fft // 4)                                                         # where w^2 is still O(1): tight
+    assert np.abs(y[:, static_len:][:, body] - tail[:, body]).max() <= 1e-4
+    # max_frames equal to the frame count is the static trim again; fewer frames than fed truncates (the same slice)
+    y_eq = STFT_Process("istft_B", n_fft, win, hop, T, ws, center, pad, static_norm=False)(spec).cpu().numpy().reshape(2, -1)
+    assert y_eq.shape == (2, static_len) and np.array_equal(y_eq, y[:, :static_len])
+    y_lt = STFT_Process("istft_B", n_fft, win, hop, T - 2, ws, center, pad, static_norm=False)(spec).cpu().numpy().reshape(2, -1)
+    assert y_lt.shape == (2, hop * (T - 3)) and np.array_equal(y_lt, y[:, :hop * (T - 3)])

@@ -72,6 +72,32 @@ def polar():
     print("polar:", tuple(real_a.shape), tuple(y.shape), float((y.reshape(2, -1) - torch.from_numpy(z["y"])).abs().max()))
 
 
+def dynamic_tail():
+    """The ISTFT of a DYNAMIC_AXES export: built with max_frames above the frame count it is fed and the per-call window sum (static_norm / static_frames False), the
+    slice [n_fft / 2 : out_end(max_frames)] keeps the second half of the last frame (GTCRN/STFT_Process.py:337-341; Mel_Band_Roformer/Stereo/STFT_Process.py:296-306).
+    On the spectra of the gtcrn and melband cases; the fixture holds only the kept tail (the samples before it equal the static output, checked here)."""
+    out = {}
+    for name, mdir, n_fft, win, hop, ws, static_kw, max_frames in (("gtcrn", "GTCRN", 512, 512, 256, "hann_sqrt", "static_norm", 4096),
+                                                                   ("melband", "Mel_Band_Roformer/Stereo", 2048, 2048, 441, "hann", "static_frames", 2048)):
+        mod = import_stft_process(mdir)
+        z = np.load(os.path.join(GOLD, f"stft_{name}.npz"))
+        spec = torch.from_numpy(z["spec"])
+        F, T = n_fft // 2 + 1, spec.shape[2]
+        with torch.inference_mode():
+            istft = mod.STFT_Process("istft_B", n_fft, win, hop, max_frames, ws, True, "reflect", **{static_kw: False}).eval()
+            y = istft._istft_B_packed_forward(spec) if hasattr(istft, "_istft_B_packed_forward") else istft(spec[:, :F], spec[:, F:])
+        y = y.numpy().reshape(2, -1)
+        static_len = hop * (T - 1)
+        assert y.shape[1] == static_len + n_fft // 2, (y.shape, static_len)
+        print(f"dynamic {name}: {y.shape}, prefix vs static max diff {np.abs(y[:, :static_len] - z['y']).max():.2e}, tail max {np.abs(y[:, static_len:]).max():.3g}")
+        out[name + "_tail"] = y[:, static_len:]
+    np.savez_compressed(os.path.join(GOLD, "stft_dynamic_tail.npz"), **out)
+
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_tail()
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()
     polar()

@@ -11,6 +11,7 @@ own ``prepare_for_export_`` as well as the forward.
     python tools/make_golden_ulunas.py     # writes tests/golden/ulunas_seed0.npz
 """
 import ast
+import json
 import os
 import sys
 
@@ -29,12 +30,13 @@ from ref_import import REF_ROOT, _stub_absent_modules, import_stft_process  # no
 L = 16000
 
 
-def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5, extra: dict | None = None) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "UL-UNAS", "Export_UL_UNAS.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    over.update(extra or {})
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -124,6 +126,42 @@ def main(seed=0):
           "mask mean", float(masks[0].mean()), "mask std", float(masks[0].std()))
 
 
+def dynamic_fixture(seed=0):
+    """DYNAMIC_AXES = True exports (:26, :41-43): any input length, other input / output sample rates (:835-845, :851-868, :890-905), the ISTFT's dynamic trim
+    (UL-UNAS/STFT_Process.py:170-177, 317-326) sliced to the caller-rate input length (:851, :888-889).  Built exactly as the export's main does (:936-975):
+    the int16 scales are folded into the STFT / ISTFT kernels only where the rate equals the model rate.  tests/golden/ulunas_dynamic_seed{seed}.npz; the network is
+    ulunas_seed{seed}.npz's."""
+    cases = [("dyn_16000", 7000, 16000, 16000),            # not a multiple of the hop: 28 frames, 7000 samples back
+             ("dyn_48000_to_8000", 15000, 48000, 8000),    # down-sample on both edges: 5000 model-rate samples, the full 256 T = 5120 tail is kept (audio_len = 15000 > 5120)
+             ("dyn_8000_to_48000", 3500, 8000, 48000),     # up-sample on both edges: 7000 model-rate samples, sliced to audio_len = 3500 of them (:888-889), then x 3
+             ("dyn_16000_to_24000", 6144, 16000, 24000)]   # output edge only, whole hops
+    z = np.load(os.path.join(mg.GOLD, f"ulunas_seed{seed}.npz"))
+    out = {}
+    for tag, n, sri, sro in cases:
+        ns = import_namespace(n, extra={"DYNAMIC_AXES": True, "IN_SAMPLE_RATE": sri, "OUT_SAMPLE_RATE": sro})
+        assert ns["STATIC_SIGNAL_LENGTH"] is None and ns["MAX_SIGNAL_LENGTH"] == 4096
+        STFT_Process = import_stft_process("UL-UNAS").STFT_Process
+        stft = STFT_Process(model_type="stft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"], max_frames=0,
+                            window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"],
+                            input_scale=ns["INV_INT16"] if sri == 16000 else 1.0).eval()
+        istft = STFT_Process(model_type="istft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"],
+                             max_frames=ns["MAX_SIGNAL_LENGTH"], window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"],
+                             output_scale=32767.0 if sro == 16000 else 1.0, static_norm=False).eval()
+        torch.manual_seed(seed)
+        net = ns["ULUNAS"]().eval()
+        seed_network(net, seed)
+        net.prepare_for_export_()
+        model = ns["ULUNAS_CUSTOM"](net.float(), stft, istft, sri, sro, remove_dc_offset=False, use_batch_fold=False, fold_window=0,
+                                    input_scale_folded=sri == 16000, output_scale_folded=sro == 16000).eval()
+        pcm = np.ascontiguousarray(z["pcm_in"][0][1000:1000 + n])
+        assert pcm.shape == (n,)
+        with torch.inference_mode():
+            y = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+        out[tag + "_in"], out[tag + "_out"], out[tag + "_rates"] = pcm, y, np.asarray([sri, sro], np.int64)
+        print(tag, "in", pcm.shape, "out", y.shape, y.dtype, "max", int(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, f"ulunas_dynamic_seed{seed}.npz"), cases=np.array(json.dumps([c[0] for c in cases])), **out)
+
+
 def fold_fixture(seed=0):
     """USE_BATCH_FOLD = True (:41-44, :866-871, :886-887): BATCH_WINDOW_SECONDS = 0.256 -> W = 4096 (17 frames); INPUT_AUDIO_LENGTH = 10000 ->
     the graph input is 3 whole windows = 12288 samples, folded into the batch; same seeded network as the plain fixture."""
@@ -149,6 +187,10 @@ def fold_fixture(seed=0):
                         fold_window_length=np.int64(4096), batch_window_seconds=np.float64(0.256))
     print("fold out", out.shape, int(np.abs(out).max()))
 
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
