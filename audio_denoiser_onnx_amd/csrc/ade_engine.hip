@@ -61,6 +61,9 @@ struct ade_engine {
     bool rs_truncate_i32 = false;
     bool rs_sandwich_out = false;        // Mel-Band: the GTCRN-style output sandwich (interpolate before the PCM scale when down-sampling, after it when up-sampling)
     bool rs_scale_first = false;
+    bool rs_nan_to_num = false;          // torch.nan_to_num / where(isnan, 0) ahead of the PCM tail (ZipEnhancer always; UL-UNAS for float input)
+    float rs_in_gain = 32768.0f;         // float audio input: normalised samples -> the PCM units the sub-engines read (MossFormer2 is fed as it is: 1)
+    float rs_f32_scale = 1.0f;           // the export's F32 / F16 output from the model-rate waveform (2^-15 where that is in PCM units: MossFormer2, ZipEnhancer)
     float *rs_in = nullptr, *rs_out = nullptr;
 
     // GTCRN_CUSTOM's input / output sandwich (Export_GTCRN.py:636-693): float audio in, other sample rates and dynamic-length exports.  in_len / out_len above are the
@@ -454,6 +457,7 @@ ade_status reserve(ade_engine* e, int batch) {
             HIP_TRY(e, hipMalloc((void**)&e->rs_in, B * e->channels * e->rs_model_in * sizeof(float)));
             HIP_TRY(e, hipMalloc((void**)&e->rs_out, B * e->out_channels * e->n_outputs * e->rs_model_out * sizeof(float)));
         }
+        if (e->gt_float_in) HIP_TRY(e, hipMalloc((void**)&e->d_f32_in, B * (size_t)e->in_len * sizeof(float)));
         e->capacity = batch;
         return ADE_OK;
     }
@@ -632,15 +636,17 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     auto launch_all = [&](bool timed) {
         if (e->sub && e->resample) {   // interpolate to the model rate, run on floats, interpolate the float waveform back and apply the PCM tail
             const long long rows_in = (long long)B * e->channels, rows_out = (long long)B * e->out_channels * e->n_outputs;
-            launch_resample_in(s, d_in, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in);
+            if (e->cur_fin) launch_resample_in_f32(s, e->cur_fin, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in, e->rs_in_gain);
+            else launch_resample_in(s, d_in, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in);
             e->sub->float_in = e->rs_in;
             sub_rc = e->sub->run(s, d_in, B, nullptr, e->rs_out, sub_err);
             e->sub->float_in = nullptr;
             if (e->rs_sandwich_out)
-                launch_gt_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out, e->rs_scale_first);
+                launch_gt_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out, e->rs_scale_first,
+                              e->rs_nan_to_num);
             else
                 launch_resample_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out,
-                                    e->rs_pcm_scale, e->rs_truncate_i32);
+                                    e->rs_pcm_scale, e->rs_truncate_i32, e->rs_f32_scale, e->rs_nan_to_num);
         } else if (e->sub) sub_rc = e->sub->run(s, d_in, B, d_out, d_f32, sub_err);
         else enqueue(e, s, d_in, B, d_out, d_f32, timed);
     };
@@ -838,8 +844,13 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                                                      (fam_sand ? ": export with dynamic_axes=1 for other rates)" : ")")));
         if (dyn_d && fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires a static shape (dynamic_axes=0)."));     // (Export_MelBandRoformer.py:46)
         if (rates_differ && (sri < 1000 || sro < 1000 || sri > 384000 || sro > 384000)) return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: sample rates out of range"));
-        if (e->meta["input_audio_dtype"] != "INT16" || e->meta["output_audio_dtype"] != "INT16")
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "only INT16 audio I/O is implemented"));
+        // Float audio tensors (IN / OUT_AUDIO_DTYPE F32 / F16; F16 crosses the C ABI as fp32, the host layer converts): the graph is the same with the int16 scale steps
+        // left out, so such handles run through the resampling edges below (identity where the rates agree) with the family's input gain / output scale.
+        auto dtype_ok_d = [](const std::string& d) { return d == "INT16" || d == "F32" || d == "F16"; };
+        if (!dtype_ok_d(e->meta["input_audio_dtype"]) || !dtype_ok_d(e->meta["output_audio_dtype"]))
+            return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: input_audio_dtype / output_audio_dtype must be INT16, F32 or F16"));
+        const bool float_in_d = e->meta["input_audio_dtype"] != "INT16", float_io = float_in_d || e->meta["output_audio_dtype"] != "INT16";
+        if (float_io && fold_d) return bail(fail(e, ADE_ERR_UNSUPPORTED, "float audio tensors together with use_batch_fold=1 are not implemented (pass the windows as batch rows)"));
         if (Ld < 16 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
         long sub_win = 1;
         const long caller_len = Ld;
@@ -899,6 +910,22 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         e->in_len = e->sub->in_len() * e->channels;
         e->T = e->sub->frames();
         e->out_len = e->sub->out_len() * e->out_channels * e->n_outputs;
+        if (float_io && !rates_differ) {   // the same edges with identity interpolation (source step 1: every sample is reproduced exactly)
+            e->resample = true;
+            e->rs_model_in = e->sub->in_len();
+            e->rs_model_out = e->sub->out_len();
+            e->rs_scale_in = 1.0f;
+            e->rs_scale_out = fam_sand ? 0.0f : 1.0f;
+            e->rs_sandwich_out = fam_sand;
+            e->rs_pcm_scale = fam_dfsmn ? 32768.0f : fam_hg ? 32767.0f : 1.0f;     // as on the resampling path below
+            e->rs_truncate_i32 = !fam_dfsmn && !fam_hg;
+        }
+        if (float_io) {
+            e->gt_float_in = float_in_d;
+            e->rs_in_gain = fam_moss ? 1.0f : 32768.0f;                 // MossFormer2 normalises its input itself and returns its units (Export_MossFormer2_SS_16K.py:563, 585)
+            e->rs_f32_scale = (fam_moss || fam_zip) ? (float)(1.0 / 32768.0) : 1.0f;     // (:655; Export_ZipEnhancer.py:920-922)
+        }
+        e->rs_nan_to_num = fam_zip || fam_hg || (fam_ulu && float_in_d);          // (Export_ZipEnhancer.py:913-920; Export_H_GTCRN.py:1056; Export_UL_UNAS.py:906-907)
         if (rates_differ) {   // F.interpolate(size = ...) on both edges (:562-571, :625-640): source scale = source length / target length
             e->resample = true;
             e->rs_model_in = e->sub->in_len();

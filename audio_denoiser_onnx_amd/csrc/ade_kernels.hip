@@ -928,6 +928,22 @@ __device__ __forceinline__ void lerp_coords(int i, int Lin, float scale, int& i0
     i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
     l1 = src - (float)i0;
 }
+__device__ __forceinline__ float nan_to_num_pcm(float v) {      // torch.nan_to_num(nan=0, posinf=32767, neginf=-32768); finite values pass
+    return v != v ? 0.0f : (v > 3.4e38f ? 32767.0f : (v < -3.4e38f ? -32768.0f : v));
+}
+// float audio tensors (input_audio_dtype F32 / F16): the same edge on normalised floats, times `gain` = what lifts them to the PCM units the sub-engines read (a power of
+// two: it commutes with every rounding of the interpolation, so the reference's scale-then-interpolate and interpolate-only forms are both this)
+__global__ __launch_bounds__(256) void k_resample_in_f32(const float* __restrict__ in, float* __restrict__ out, int Lin, int Lout, float scale, float gain, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long r = idx / Lout;
+    const int i = (int)(idx - r * Lout);
+    int i0, i1;
+    float l1;
+    lerp_coords(i, Lin, scale, i0, i1, l1);
+    const float* row = in + r * Lin;
+    out[idx] = ((1.0f - l1) * row[i0] + l1 * row[i1]) * gain;
+}
 __global__ __launch_bounds__(256) void k_resample_in(const int16_t* __restrict__ in, float* __restrict__ out, int Lin, int Lout, float scale, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -941,8 +957,10 @@ __global__ __launch_bounds__(256) void k_resample_in(const int16_t* __restrict__
 }
 // output edge: interpolate the model-rate float waveform, scale to PCM, clamp, cast (truncate_i32: the int32 cast of MossFormer2, which
 // truncates before clamping; otherwise the float clamp then truncating cast of the STFT models)
+// f32_scale: what turns the interpolated waveform into the export's F32 / F16 output (1, or 2^-15 for the families whose waveform is in PCM units); nan_to_num: the
+// reference's torch.nan_to_num(nan=0, posinf=32767, neginf=-32768) / where(isnan, 0) before the tail (ZipEnhancer always, UL-UNAS for float input)
 __global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ in, int16_t* __restrict__ pcm, float* __restrict__ f32, int Lin, int Lout,
-                                                      float scale, float pcm_scale, int truncate_i32, long long total) {
+                                                      float scale, float pcm_scale, int truncate_i32, float f32_scale, int nan_to_num, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const long long r = idx / Lout;
@@ -951,8 +969,9 @@ __global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ 
     float l1;
     lerp_coords(i, Lin, scale, i0, i1, l1);
     const float* row = in + r * Lin;
-    const float y = (1.0f - l1) * row[i0] + l1 * row[i1];
-    if (f32) f32[idx] = y;
+    float y = (1.0f - l1) * row[i0] + l1 * row[i1];
+    if (nan_to_num) y = nan_to_num_pcm(y);
+    if (f32) f32[idx] = y * f32_scale;
     if (pcm) {
         const float v = y * pcm_scale;
         pcm[idx] = (int16_t)(int)fminf(fmaxf(truncate_i32 ? truncf(v) : v, -32768.0f), 32767.0f);
@@ -1027,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_ola_keep(const float* __restrict__ fram
 // output: [interpolate first when the caller rate is BELOW the model rate]; * 32767 for int16 output; [interpolate afterwards when it is ABOVE]; clamp + truncating
 // cast for int16 (Export_GTCRN.py:673-693).  f32 receives the waveform at the output rate without the PCM scale (the F32 / F16 output of the export).
 __global__ __launch_bounds__(256) void k_gt_out(const float* __restrict__ wave, int16_t* __restrict__ pcm, float* __restrict__ f32, int Lw, int Lout, float lerp,
-                                                int scale_first, long long total) {
+                                                int scale_first, int nan_to_num, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const long long r = idx / Lout;
@@ -1043,6 +1062,10 @@ __global__ __launch_bounds__(256) void k_gt_out(const float* __restrict__ wave, 
     } else {
         y = row[i];
         q = y * 32767.0f;
+    }
+    if (nan_to_num) {      // torch.nan_to_num(nan=0, posinf=32767, neginf=-32768) before the cast (Export_UL_UNAS.py:906-907, float input only)
+        y = nan_to_num_pcm(y);
+        q = q != q ? 0.0f : q;       // (the clamp below maps the infinities)
     }
     if (f32) f32[idx] = y;
     if (pcm) pcm[idx] = (int16_t)(int)fminf(fmaxf(q, -32768.0f), 32767.0f);
@@ -1079,13 +1102,13 @@ void launch_gt_sandwich_in(hipStream_t s, const int16_t* pcm, const float* fin, 
     hipLaunchKernelGGL(k_row_mean_f32, dim3((unsigned)rows), dim3(256), 0, s, (const float*)tmp, L1, mean);
     hipLaunchKernelGGL(k_gt_in_stage3, grid1((long long)rows * Lm, 256), dim3(256), 0, s, (const float*)tmp, (const float*)mean, out, L1, Lm, lerp2, (long long)rows * Lm);
 }
-void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first) {
-    hipLaunchKernelGGL(k_gt_out, grid1(rows * Lout, 256), dim3(256), 0, s, wave, pcm, f32, Lw, Lout, lerp, scale_first ? 1 : 0, rows * Lout);
+void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first, bool nan_to_num) {
+    hipLaunchKernelGGL(k_gt_out, grid1(rows * Lout, 256), dim3(256), 0, s, wave, pcm, f32, Lw, Lout, lerp, scale_first ? 1 : 0, nan_to_num ? 1 : 0, rows * Lout);
 }
 void launch_gt_sandwich_out(hipStream_t s, const float* frames, FftTabs tabs, int rows, int T, int keep, float* wave, int16_t* pcm, float* f32, int Lout, float lerp,
                             bool scale_first) {
     hipLaunchKernelGGL(k_ola_keep, grid1((long long)rows * keep, 256), dim3(256), 0, s, frames, tabs.win_sum, tabs.win, T, keep, wave, (long long)rows * keep);
-    hipLaunchKernelGGL(k_gt_out, grid1((long long)rows * Lout, 256), dim3(256), 0, s, (const float*)wave, pcm, f32, keep, Lout, lerp, scale_first ? 1 : 0, (long long)rows * Lout);
+    hipLaunchKernelGGL(k_gt_out, grid1((long long)rows * Lout, 256), dim3(256), 0, s, (const float*)wave, pcm, f32, keep, Lout, lerp, scale_first ? 1 : 0, 0, (long long)rows * Lout);
 }
 void launch_pcm_mean(hipStream_t s, const int16_t* pcm, int B, int L, float* mean, int rows_per_call) {
     hipLaunchKernelGGL(k_pcm_mean, dim3(B / rows_per_call), dim3(256), 0, s, pcm, L, rows_per_call, mean);
@@ -1129,11 +1152,15 @@ void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int
 void launch_stream_concat_flush(hipStream_t s, const int16_t* hist, const int16_t* prev, int16_t* concat, int B) {
     hipLaunchKernelGGL(k_stream_concat_flush, grid1((long long)B * 2 * kHop, 256), dim3(256), 0, s, hist, prev, concat, (long long)B * 2 * kHop);
 }
+void launch_resample_in_f32(hipStream_t s, const float* in, float* out, long long rows, int Lin, int Lout, float scale, float gain) {
+    hipLaunchKernelGGL(k_resample_in_f32, grid1(rows * Lout, 256), dim3(256), 0, s, in, out, Lin, Lout, scale, gain, rows * Lout);
+}
 void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale) {
     hipLaunchKernelGGL(k_resample_in, grid1(rows * Lout, 256), dim3(256), 0, s, in, out, Lin, Lout, scale, rows * Lout);
 }
-void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32) {
-    hipLaunchKernelGGL(k_resample_out, grid1(rows * Lout, 256), dim3(256), 0, s, in, pcm, f32, Lin, Lout, scale, pcm_scale, truncate_i32 ? 1 : 0, rows * Lout);
+void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32,
+                         float f32_scale, bool nan_to_num) {
+    hipLaunchKernelGGL(k_resample_out, grid1(rows * Lout, 256), dim3(256), 0, s, in, pcm, f32, Lin, Lout, scale, pcm_scale, truncate_i32 ? 1 : 0, f32_scale, nan_to_num ? 1 : 0, rows * Lout);
 }
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32) {
     const long long n = (long long)B * T * (kHop / 4);

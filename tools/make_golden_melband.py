@@ -254,6 +254,27 @@ def dynamic_fixture():
     np.savez_compressed(os.path.join(mg.GOLD, "melband_dynamic_seed0.npz"), cases=np.array(json.dumps([c[0] for c in cases])), **out)
 
 
+def float_io_fixture():
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:55-56, :327-328, :667-680): normalised float tensors in and / or out of the static 44.1 kHz export (the 2^-15 of an int16
+    input lives in the STFT kernel, :327-328; a float output leaves the * 32767 and the clamp out).  tests/golden/melband_float_io_seed0.npz; melband_seed0_io.npz's weights."""
+    pcm = read_clip(44100, L)
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32")):
+        ns = import_namespace(L, extra={"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        model, spec, _ = build_model(ns, L)
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            y = model(torch.from_numpy(src.reshape(1, 2, L).copy())).numpy().reshape(2, -1)
+        out[tag] = y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, "melband_float_io_seed0.npz"), **out)
+
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
+
 if __name__ == "__main__" and "--dynamic" in sys.argv:
     dynamic_fixture()
     sys.exit(0)

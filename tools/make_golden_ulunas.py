@@ -162,6 +162,36 @@ def dynamic_fixture(seed=0):
     np.savez_compressed(os.path.join(mg.GOLD, f"ulunas_dynamic_seed{seed}.npz"), cases=np.array(json.dumps([c[0] for c in cases])), **out)
 
 
+def float_io_fixture(seed=0):
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:45-46, :858-859, :897-898, :906-912): normalised float tensors in and / or out of the STATIC 16 kHz export, built as the
+    export's main does (:936-975: the int16 scales are folded into the STFT / ISTFT kernels only for int16 tensors).  tests/golden/ulunas_float_io_seed{seed}.npz."""
+    n = 4096
+    z = np.load(os.path.join(mg.GOLD, f"ulunas_seed{seed}.npz"))
+    pcm = np.ascontiguousarray(z["pcm_in"][0][2000:2000 + n])
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32")):
+        ns = import_namespace(n, extra={"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        STFT_Process = import_stft_process("UL-UNAS").STFT_Process
+        stft = STFT_Process(model_type="stft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"], max_frames=0,
+                            window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"], input_scale=ns["INV_INT16"] if din == "INT16" else 1.0).eval()
+        istft = STFT_Process(model_type="istft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"],
+                             max_frames=ns["MAX_SIGNAL_LENGTH"], window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["STFT_PAD_MODE"],
+                             output_scale=32767.0 if dout == "INT16" else 1.0, static_norm=True).eval()
+        torch.manual_seed(seed)
+        net = ns["ULUNAS"]().eval()
+        seed_network(net, seed)
+        net.prepare_for_export_()
+        model = ns["ULUNAS_CUSTOM"](net.float(), stft, istft, 16000, 16000, remove_dc_offset=False, use_batch_fold=False, fold_window=0,
+                                    input_scale_folded=din == "INT16", output_scale_folded=dout == "INT16").eval()
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            y = model(torch.from_numpy(src.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+        out[tag] = y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, f"ulunas_float_io_seed{seed}.npz"), **out)
+
+
 def fold_fixture(seed=0):
     """USE_BATCH_FOLD = True (:41-44, :866-871, :886-887): BATCH_WINDOW_SECONDS = 0.256 -> W = 4096 (17 frames); INPUT_AUDIO_LENGTH = 10000 ->
     the graph input is 3 whole windows = 12288 samples, folded into the batch; same seeded network as the plain fixture."""
@@ -187,6 +217,10 @@ def fold_fixture(seed=0):
                         fold_window_length=np.int64(4096), batch_window_seconds=np.float64(0.256))
     print("fold out", out.shape, int(np.abs(out).max()))
 
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--dynamic" in sys.argv:
     dynamic_fixture()
