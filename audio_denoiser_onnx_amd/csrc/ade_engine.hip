@@ -1146,11 +1146,11 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
     return ADE_OK;
 }
 
-// fp32 audio in (input_audio_dtype F32 / F16): implemented for GTCRN handles (the sandwich path); out_pcm / out_f32 as in ade_process_device
+// fp32 audio in (input_audio_dtype F32 / F16): GTCRN handles take the sandwich path, sub-engine handles their edge kernels; out_pcm / out_f32 as in ade_process_device
 ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, int16_t* d_out, float* d_f32, void* hip_stream) {
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device_f32: bad arguments");
-    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16 (or its family has no float-input path): call ade_process_device");
+    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process_device");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     ade_status st = reserve(h, batch);
@@ -1167,7 +1167,7 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
 ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* out_pcm, float* out_f32) {
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_f32: bad arguments");
-    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16 (or its family has no float-input path): call ade_process");
+    if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     ade_status st = reserve(h, batch);

@@ -83,7 +83,8 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
                               void* hip_stream);
 
 /* fp32 audio IN (manifest input_audio_dtype "F32" or "F16": normalised samples, no 2^-15 scale -- GTCRN/Export_GTCRN.py:645-646; an F16 tensor crosses this ABI as
- * fp32, the graph computes in fp32 either way).  Implemented for "gtcrn" handles.  The outputs are the same pair as above: out_f32 is the export's F32 / F16 output
+ * fp32, the graph computes in fp32 either way).  Every family: the sub-engine families run such handles through their resampling-edge kernels with the family's input gain
+ * (each export script's own IN_AUDIO_DTYPE branch).  The outputs are the same pair as above: out_f32 is the export's F32 / F16 output
  * (no * 32767, no clamp, :680-693), out_pcm its INT16 output; either may be NULL. */
 ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* out_pcm, float* out_f32);
 ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream);

@@ -234,17 +234,21 @@ class HgtcrnOracle:
         return np.concatenate((m[..., :65], _mm(m[..., 65:], w["erb.ierb_weight_t"])), axis=-1).astype(F32)
 
     # ---- the call ------------------------------------------------------------------------------------------------------------
-    def process(self, pcm: np.ndarray, inject_wpe=None) -> np.ndarray:
+    def process(self, pcm: np.ndarray, inject_wpe=None, float_out: bool = False) -> np.ndarray:
         """pcm int16 (calls, 2, n_win * W) -> int16 (calls, n_win * out_len).  inject_wpe = (re, im), each (B, 2, F, T): continue from a given WPE
-        output instead of this module's own (how the tests pin everything downstream of the ill-conditioned solve on identical inputs)."""
-        assert pcm.ndim == 3 and pcm.shape[1] == 2 and pcm.shape[2] == self.W * self.n_win and pcm.dtype == np.int16
+        output instead of this module's own (how the tests pin everything downstream of the ill-conditioned solve on identical inputs).
+        A float32 `pcm` is an IN_AUDIO_DTYPE F32 / F16 tensor: normalised samples, the * inv_int16 left out (:965-966); float_out: OUT_AUDIO_DTYPE F32 / F16, the waveform
+        without the * 32767 and the clamp (:1042-1043, :1057-1063)."""
+        assert pcm.ndim == 3 and pcm.shape[1] == 2 and pcm.shape[2] == self.W * self.n_win and pcm.dtype in (np.int16, np.float32)
         calls = pcm.shape[0]
-        x = (pcm.astype(F32) * F32(1.0 / 32768.0)).astype(F32)
+        x = (pcm.astype(F32) * F32(1.0 / 32768.0)).astype(F32) if pcm.dtype == np.int16 else pcm
         x = (x - x.reshape(calls, -1).mean(axis=1, dtype=F32)[:, None, None]).astype(F32)                 # (:963-964) the mean of the whole call
         with np.errstate(all="ignore"):
-            y = (self._core(x, inject_wpe) * F32(32767.0)).astype(F32)
+            y = self._core(x, inject_wpe)
+            if not float_out:
+                y = (y * F32(32767.0)).astype(F32)
             y = np.where(np.isnan(y), F32(0.0), y)                                                         # (:1054)
-        return np.clip(y, -32768.0, 32767.0).astype(np.int16)
+        return y.astype(F32) if float_out else np.clip(y, -32768.0, 32767.0).astype(np.int16)
 
     @staticmethod
     def _interp(x, factor):

@@ -175,7 +175,7 @@ class MossFormerOracle:
     def process(self, pcm: np.ndarray, out_len: int = 0) -> np.ndarray:
         """pcm int16 (B, L): B independent windows -> int16 (B, 2, L_out).  L != W or out_len: the resampling edges (in / out rate != 16 kHz):
         the int16 samples are interpolated to W model-rate samples as floats, the restored waveform to out_len before the int cast."""
-        assert pcm.ndim == 2 and pcm.dtype == np.int16
+        assert pcm.ndim == 2 and pcm.dtype in (np.int16, np.float32)      # a float input tensor is read as it is (audio.float(), :563); taps["wav"] * 2^-15 is the float output (:655)
         w, s, n = self.w, self.s, self.n
         B = pcm.shape[0]
         xin = pcm.astype(F32)

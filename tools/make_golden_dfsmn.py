@@ -166,5 +166,27 @@ def main():
     print("fold", y.shape, int(np.abs(y).max()), "resample", y2.shape, int(np.abs(y2).max()))
 
 
+def float_io_fixture():
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:43-44): a float input skips the * INV_INT16 (:178-182), a float output the * 32768 and the clamp (:241-247).
+    tests/golden/dfsmn_float_io_seed0.npz; the network is dfsmn_seed0.adew's."""
+    L = 24000
+    wav = mg.load_wav_i16(os.path.join(REF_ROOT, "Test_Examples", "denoise", "speech_with_noise_48k.wav"))
+    pcm = wav[48000:48000 + L].copy()
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32")):
+        ns, model = build(0, L, {"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            y = model(torch.from_numpy(src.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+        out[tag] = y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, "dfsmn_float_io_seed0.npz"), **out)
+
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()

@@ -28,13 +28,14 @@ from ref_import import REF_ROOT, _stub_absent_modules, import_stft_process  # no
 L = 16384                                                            # a whole number of hops (Export_H_GTCRN.py:33) -> 65 frames
 
 
-def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5, in_rate: int = 16000, out_rate: int = 16000) -> dict:
+def import_namespace(length: int, fold: bool = False, window_seconds: float = 1.5, in_rate: int = 16000, out_rate: int = 16000, extra: dict | None = None) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "H-GTCRN", "Export_H_GTCRN.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds, "IN_SAMPLE_RATE": in_rate,
             "OUT_SAMPLE_RATE": out_rate}
+    over.update(extra or {})
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -213,6 +214,28 @@ def resample_fixture(seed=0):
         print(tag, "in", pcm.shape, "out", y.shape, int(np.abs(y).max()))
     np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}_resample.npz"), **out)
 
+
+def float_io_fixture(seed=0):
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:52-53): a float input skips the * inv_int16 (:965-966), a float output the * 32767 and the clamp (:1042-1063).
+    tests/golden/hgtcrn_float_io_seed{seed}.npz; the network and the input row are hgtcrn_seed{seed}.npz's (row 1)."""
+    z = np.load(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}.npz"))
+    pcm = np.ascontiguousarray(z["pcm_in"][1])
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32")):
+        ns = import_namespace(pcm.shape[1], extra={"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        model, *_ = build(ns, seed)
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            y = model(torch.from_numpy(src.reshape(1, 2, -1).copy())).numpy().reshape(-1)
+        out[tag] = y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_float_io_seed{seed}.npz"), **out)
+
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()

@@ -37,13 +37,14 @@ LAYERS = 2
 WINDOW = 2408          # (2408 - 16) // 8 + 1 = 300 frames: two FLASH groups of 256, the second padded with 212 zero rows
 
 
-def import_namespace(length: int, fold: bool, window_seconds: float, in_rate: int = 16000, out_rate: int = 16000) -> dict:
+def import_namespace(length: int, fold: bool, window_seconds: float, in_rate: int = 16000, out_rate: int = 16000, extra: dict | None = None) -> dict:
     _stub_absent_modules()
     path = os.path.join(REF_ROOT, "MossFormer2_SS_16K", "Export_MossFormer2_SS_16K.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds, "IN_SAMPLE_RATE": in_rate,
             "OUT_SAMPLE_RATE": out_rate}
+    over.update(extra or {})
     keep = []
     for node in tree.body:
         if isinstance(node, ast.ClassDef):
@@ -276,6 +277,25 @@ def main():
     print("resample out", out.shape, np.abs(out).max(axis=1))
 
 
+def float_io_fixture():
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:31-32): the graph reads a float input as it is (norm_audio still multiplies by 2^-15, :403-411, so a normalised input
+    is NOT the int16 path scaled) and a float output is the restored waveform * 2^-15 instead of the int32 cast (:649-657).
+    tests/golden/mossformer_float_io_seed0.npz; the weights are mossformer_seed0_io.npz's."""
+    pcm = read_mix(24000, WINDOW)
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32")):
+        ns = import_namespace(WINDOW, False, 1.5, extra={"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        model, _, _ = build(ns, WINDOW, False, 0)
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            outs = model(torch.from_numpy(src.reshape(1, 1, -1).copy()))
+        y = np.stack([o.numpy().reshape(-1) for o in outs])
+        out[tag] = y
+        print(tag, y.shape, y.dtype, np.abs(y).max(axis=1))
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_float_io_seed0.npz"), **out)
+
+
 def production_size():
     """Fixtures at production-relevant sizes: 4 layers x one 1.5 s window (24000 samples, 2999 frames = 12 FLASH groups,
     the last padded) and 2 layers x one 4 s window (64000 samples, 7999 frames = 32 groups: BASELINE configs[4]'s window).  Both speakers' PCM,
@@ -340,6 +360,10 @@ def fusion_fixture():
                         names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
     print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
 
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--production-size" in sys.argv:
     production_size()

@@ -243,13 +243,14 @@ def install_fake_modelscope():
     mods["modelscope.models.base"].Model = object
 
 
-def import_namespace(length: int, fold: bool, window_seconds: float = 1.5) -> dict:
+def import_namespace(length: int, fold: bool, window_seconds: float = 1.5, extra: dict | None = None) -> dict:
     _stub_absent_modules()
     install_fake_modelscope()
     path = os.path.join(REF_ROOT, "ZipEnhancer", "Export_ZipEnhancer.py")
     with open(path) as f:
         tree = ast.parse(f.read(), filename=path)
     over = {"INPUT_AUDIO_LENGTH": length, "USE_BATCH_FOLD": fold, "BATCH_WINDOW_SECONDS": window_seconds}
+    over.update(extra or {})
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
@@ -269,8 +270,8 @@ def import_namespace(length: int, fold: bool, window_seconds: float = 1.5) -> di
     return ns
 
 
-def build_reference(cfg: zp.ZipConfig, seed: int, length: int, fold: bool):
-    ns = import_namespace(length, fold)
+def build_reference(cfg: zp.ZipConfig, seed: int, length: int, fold: bool, extra: dict | None = None):
+    ns = import_namespace(length, fold, extra=extra)
     net = StandInZipEnhancer(cfg).eval()
     sd = zp.synthetic_state_dict(cfg, seed)
     own = net.state_dict()
@@ -386,6 +387,28 @@ def main():
                         export_length=np.int64(n), fold_window=np.int64(ns["FOLD_WINDOW_LENGTH"]), pcm_in=pcm, pcm_out=o, wave=wv)
     print("fold: windows", n // ns["FOLD_WINDOW_LENGTH"], "out rms", float(np.sqrt(np.mean(o.astype(np.float64) ** 2))))
 
+
+def float_io_fixture():
+    """IN / OUT_AUDIO_DTYPE other than INT16 (:35-36): a float input is lifted by * 32768 (:820-821), a float output is nan_to_num(waveform) * 2^-15 (:920-926).
+    tests/golden/zipenhancer_float_io_seed0.npz; the network is zipenhancer_seed0_io.npz's (seed 0), the clip its wav0 row cut to 0.5 s."""
+    cfg, seed, L = zp.ZipConfig(), 0, 8000
+    z = np.load(os.path.join(GOLD, "zipenhancer_seed0_io.npz"))
+    pcm = np.ascontiguousarray(z["in_wav0"][4000:4000 + L])
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    out = {"pcm_in": pcm, "x_in": x}
+    for tag, din, dout in (("f32_f32", "F32", "F32"), ("f32_i16", "F32", "INT16"), ("i16_f32", "INT16", "F32"), ("i16_i16", "INT16", "INT16")):
+        ns, model, _ = build_reference(cfg, seed, L, fold=False, extra={"IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        src = pcm if din == "INT16" else x
+        with torch.inference_mode():
+            y = model(torch.from_numpy(src.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+        out[tag] = y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(GOLD, "zipenhancer_float_io_seed0.npz"), **out)
+
+
+if __name__ == "__main__" and "--float-io" in sys.argv:
+    float_io_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
