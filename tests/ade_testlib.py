@@ -16,6 +16,20 @@ GOLD = os.path.join(HERE, "golden")
 HIPSIM_LIB = os.path.join(HERE, "hipsim", "_build", "libade_hipsim.so")
 
 
+_MELBAND_CACHE = {}
+
+
+def melband_fixture_weights():
+    """(npz, spec, fused buffers) of tests/golden/melband_seed0_io.npz: 208 M generator-made floats, materialised once per test process (three modules use them)."""
+    import json
+    from audio_denoiser_onnx_amd import weightgen
+    if "w" not in _MELBAND_CACHE:
+        z = np.load(os.path.join(GOLD, "melband_seed0_io.npz"))
+        spec = [(n, s, sc) for n, s, sc in json.loads(str(z["spec"]))]
+        _MELBAND_CACHE["w"] = (z, spec, weightgen.materialise(spec))
+    return _MELBAND_CACHE["w"]
+
+
 def golden_blob(seed: int = 0) -> bytes:
     with open(os.path.join(GOLD, f"gtcrn_seed{seed}.adew"), "rb") as f:
         return f.read()

@@ -91,10 +91,9 @@ def test_ulunas_gpu_float_tensors(ulu):
 # ---- Mel-Band-Roformer -------------------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def melb():
-    from audio_denoiser_onnx_amd import weightgen
-    z = np.load(os.path.join(GOLD, "melband_seed0_io.npz"))
-    spec = [(n, s, sc) for n, s, sc in json.loads(str(z["spec"]))]
-    return z, weightgen.materialise(spec), np.load(os.path.join(GOLD, "melband_float_io_seed0.npz"))
+    from ade_testlib import melband_fixture_weights
+    z, _, w = melband_fixture_weights()
+    return z, w, np.load(os.path.join(GOLD, "melband_float_io_seed0.npz"))
 
 
 def test_melband_oracle_float_tensors(melb):

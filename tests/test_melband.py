@@ -23,9 +23,8 @@ GOLD_FOLD = os.path.join(HERE, "golden", "melband_seed0_fold_io.npz")
 
 @pytest.fixture(scope="module")
 def fixture():
-    z = np.load(GOLD)
-    spec = [(n, s, sc) for n, s, sc in json.loads(str(z["spec"]))]
-    return z, spec, weightgen.materialise(spec)
+    from ade_testlib import melband_fixture_weights
+    return melband_fixture_weights()
 
 
 def test_weightgen_is_a_pure_function_of_name_and_index():

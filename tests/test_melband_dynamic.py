@@ -26,11 +26,11 @@ SR = 44100
 
 @pytest.fixture(scope="module")
 def fixture():
-    z = np.load(GOLD)
-    spec = [(n, s, sc) for n, s, sc in json.loads(str(z["spec"]))]
+    from ade_testlib import melband_fixture_weights
+    z, _, w = melband_fixture_weights()
     d = np.load(GOLD_DYN)
     cases = [(tag, d[tag + "_in"], d[tag + "_out"], int(d[tag + "_rates"][0]), int(d[tag + "_rates"][1])) for tag in json.loads(str(d["cases"]))]
-    return z, weightgen.materialise(spec), cases
+    return z, w, cases
 
 
 def model_length(n: int, in_rate: int) -> int:
