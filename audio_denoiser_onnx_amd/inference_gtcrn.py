@@ -151,9 +151,14 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
     float_io = in_dt != np.int16 or out_dt != np.int16
     dfsmn = family == "dfsmn"
     audio_len = output_length(len(audio), in_rate, out_rate, rounded=dfsmn)
+    # A dynamic-length export returns MORE than its input's duration (the ISTFT keeps the last frame's tail).  The reference driver binds an output of
+    # round(INPUT_AUDIO_LENGTH * scale) samples for such a model (Inference_GTCRN_ONNX.py:300-304), i.e. it only ever keeps that many: slices are stepped by the
+    # input length and each slice's output is cut there before the stitch.
+    dynamic = bool(getattr(session, "metadata", None) and session.metadata.optional_bool("dynamic_axes", False))
+    keep = min(session.out_len, int(round(session.in_len * out_rate / in_rate))) if dynamic else session.out_len
     slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng,
-                           out_stride=(not dfsmn) and in_rate == out_rate)
-    if world > 1 and not sequential and hasattr(session, "run_device") and not float_io:
+                           out_stride=(not dfsmn) and in_rate == out_rate and not dynamic)
+    if world > 1 and not sequential and hasattr(session, "run_device") and not float_io and not dynamic:
         from .distributed import sharded_run
         return sharded_run(session, slices, world, rank, group).reshape(-1)[:audio_len]      # device block -> all-gather -> one D2H
     lo, hi = shard_bounds(len(slices), world, rank)
@@ -169,7 +174,7 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
     else:
         local, _ = session.process(mine)
     full = stitch_rows(local, len(slices), world, rank, group) if world > 1 else local
-    return full.reshape(-1)[:audio_len]            # np.concatenate(saved).reshape(-1)[:audio_len]  (:332)
+    return np.ascontiguousarray(full[:, :keep]).reshape(-1)[:audio_len]            # np.concatenate(saved).reshape(-1)[:audio_len]  (:332)
 
 
 def denoise_streaming(session: InferenceSession, audio: np.ndarray, frames_per_push: int = 62) -> np.ndarray:

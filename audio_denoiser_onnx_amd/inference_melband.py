@@ -54,10 +54,15 @@ def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool, rng=None) -> n
 
 
 def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool, rng=None) -> np.ndarray:
-    """(C, n) int16 -> (C, n) int16: every slice of the file in one batched call."""
+    """(C, n) int16 -> (C, round(n * out_rate / in_rate)) int16: every slice of the file in one batched call.  A dynamic-length export returns more than its input's
+    duration (the ISTFT keeps the last frame's tail); the reference driver binds an output of round(INPUT_AUDIO_LENGTH * scale) samples for it (:322-323), so each
+    slice's output is cut there before the stitch."""
     slices = cut_slices(audio, session.in_len, fold_active, rng)
     out = session.run(None, {session.get_inputs()[0].name: slices})[0]                     # (n_slices, C, out_len)
-    return np.ascontiguousarray(out.transpose(1, 0, 2).reshape(out.shape[1], -1)[:, :audio.shape[1]])
+    scale = session.out_sample_rate / session.in_sample_rate
+    keep = min(session.out_len, int(round(session.in_len * scale)))
+    out = out[:, :, :keep]
+    return np.ascontiguousarray(out.transpose(1, 0, 2).reshape(out.shape[1], -1)[:, :int(round(audio.shape[1] * scale))])
 
 
 def main(argv=None) -> int:

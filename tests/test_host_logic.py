@@ -200,3 +200,41 @@ def test_drivers_with_unequal_sample_rates():
     assert st.shape == (300000,)
     # equal rates, hop-truncated output: stride = output length as before
     assert g.cut_slices(audio, 16000, 15872, out_stride=True)[1] == 15872
+
+
+def test_drivers_stitch_dynamic_length_exports_by_input_length():
+    """A dynamic-length export returns more than its input's duration (the ISTFT keeps the last frame's tail): the drivers step by the input length and cut every slice's
+    output at round(input_audio_length * out_rate / in_rate), what the reference driver's bound output buffer holds (Inference_GTCRN_ONNX.py:300-304)."""
+    from audio_denoiser_onnx_amd import inference_gtcrn, inference_melband
+    from audio_denoiser_onnx_amd.metadata import MetadataReader
+
+    class Fake:
+        in_dtype = out_dtype = np.int16
+
+        def __init__(self, in_len, out_len, in_rate, out_rate, channels=1):
+            self.in_len, self.out_len, self.channels = in_len, out_len, channels
+            self.in_sample_rate, self.out_sample_rate, self.sample_rate = in_rate, out_rate, 16000
+            self.metadata = MetadataReader({"dynamic_axes": "1", "in_sample_rate": str(in_rate), "out_sample_rate": str(out_rate)})
+
+        def process(self, rows, want_f32=False):                      # slice k -> its index + 1 everywhere, the tail marked -1
+            out = np.repeat(np.arange(1, len(rows) + 1, dtype=np.int16)[:, None], self.out_len, axis=1)
+            out[:, -4:] = -1
+            return out, None
+
+        def run(self, _, feed):
+            x = next(iter(feed.values()))
+            out = np.repeat(np.arange(1, len(x) + 1, dtype=np.int16)[:, None, None], self.out_len, axis=2).repeat(self.channels, axis=1)
+            out[:, :, -4:] = -1
+            return [out]
+
+        def get_inputs(self):
+            return [type("A", (), {"name": "noisy_audio"})()]
+
+    audio = np.zeros(2500, np.int16)
+    out = inference_gtcrn.denoise(Fake(1000, 1024, 16000, 16000), audio)             # 256 T = 1024 samples back for 1000 in
+    assert out.shape == (2500,) and np.array_equal(np.unique(out[:1000]), [1]) and np.array_equal(np.unique(out[1000:2000]), [2]) and (out != -1).all()
+    out = inference_gtcrn.denoise(Fake(1000, 520, 16000, 8000), audio)               # down-sampling output edge: 500 kept of 520 per slice
+    assert out.shape == (1250,) and np.array_equal(np.unique(out[500:1000]), [2]) and (out != -1).all()
+    stereo = np.zeros((2, 2500), np.int16)
+    out = inference_melband.denoise(Fake(1000, 1583, 44100, 44100, channels=2), stereo, False, np.random.default_rng(0))
+    assert out.shape == (2, 2500) and np.array_equal(np.unique(out[:, 1000:2000]), [2]) and (out != -1).all()
