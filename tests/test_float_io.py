@@ -307,3 +307,32 @@ def test_zipenhancer_gpu_float_tensors(zipf):
             assert got.dtype == np.float32 and np.array_equal(got, wave_i[0] * np.float32(1.0 / 32768.0)), tag
             d = np.abs(got - z[tag]) * 32768.0
         assert np.median(d) <= 0.05 and d[400:-400].max() <= 1.0, (tag, float(np.median(d)), float(d[400:-400].max()))      # vs the reference, away from the edge frames
+
+
+# ---- NaN samples on the float entry --------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gpu_nan_samples_follow_the_reference_nan_to_num(zipf, ulu):
+    """A float input tensor can carry NaN.  ZipEnhancer's per-window RMS turns the whole window into NaN and the reference returns zeros for it (where(isnan, 0) /
+    nan_to_num, Export_ZipEnhancer.py:913-920); UL-UNAS is causal, so the frames before the bad sample are untouched, and a NaN waveform sample is
+    nan_to_num'ed to 0 (Export_UL_UNAS.py:906-907).  Neither may turn NaN into -32768."""
+    from audio_denoiser_onnx_amd import ulunas, zipenhancer as zp
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    t, z = zipf
+    x = z["x_in"].copy()
+    x[4000] = np.nan
+    n = x.shape[0]
+    for dout in ("INT16", "F32"):
+        with InferenceSession(weights=pack_blob(t), metadata=with_dtypes(zp.metadata(n), "F32", dout)) as sess:
+            both = sess.run(None, {"noisy_audio": np.stack((x, z["x_in"]))[:, None]})[0][:, 0]
+        assert not both[0].any() and both[1].any() and np.isfinite(both[1].astype(np.float64)).all(), dout      # the bad window is zeros; its neighbour in the batch is untouched
+    fused, zu = ulu
+    xu = zu["x_in"].copy()
+    xu[2048] = np.nan                                                     # first touched by frame 7 (256 * 7 = 1792 .. 2304 holds sample 2048; reflect padding: centre at 256 t)
+    with InferenceSession(weights=pack_blob(fused), metadata=with_dtypes(ulunas.metadata(xu.shape[0]), "F32", "INT16")) as sess:
+        got = sess.run(None, {"noisy_audio": xu[None, None]})[0][0, 0]
+        clean = sess.run(None, {"noisy_audio": zu["x_in"][None, None]})[0][0, 0]
+    assert np.array_equal(got[:1024], clean[:1024]) and np.abs(clean[:1024]).max() > 0      # frames well before the bad sample are the clean run's
+    # What the NaN reaches: a NaN waveform sample becomes 0, never the clamp limit.  (The reference's graph keeps NaN through torch.clamp and so zeroes every later
+    # sample; the engine's fmaxf-style clamps (log-power floor) drop it, so later frames come back finite -- garbage in, unspecified finite samples out; DESIGN.md section 3.)
+    assert (got != -32768).all()
