@@ -174,19 +174,27 @@ class InferenceSession:
 
     def run_device(self, d_in, d_out, d_f32=None, stream: Optional[int] = None) -> None:
         """``d_in`` int16 (B, L) / ``d_out`` int16 (B, L_out) CUDA(HIP) tensors; enqueues on ``stream`` (a raw
-        hipStream_t handle, e.g. ``torch.cuda.current_stream().cuda_stream``) or runs synchronously when None."""
+        hipStream_t handle, e.g. ``torch.cuda.current_stream().cuda_stream``) or runs synchronously when None.
+        A model whose input tensor is float (input_audio_dtype F32 / F16) takes a float32 ``d_in`` (``ade_process_device_f32``); ``d_out`` may be None when only the
+        float waveform ``d_f32`` is wanted (a float OUTPUT model)."""
         B = int(d_in.shape[0])
-        if tuple(d_in.shape) != (B, self.row_in) or tuple(d_out.shape) != (B, self.row_out):
-            raise ValueError("device tensors must be (B, channels * in_len) int16 -> (B, channels * out_len) int16")
-        if not d_in.is_contiguous() or not d_out.is_contiguous():
+        if tuple(d_in.shape) != (B, self.row_in) or (d_out is not None and tuple(d_out.shape) != (B, self.row_out)):
+            raise ValueError("device tensors must be (B, channels * in_len) -> (B, channels * out_len)")
+        if not d_in.is_contiguous() or (d_out is not None and not d_out.is_contiguous()):
             raise ValueError("device tensors must be contiguous")
+        float_in = self.in_dtype != np.int16
+        if str(d_in.dtype) != ("torch.float32" if float_in else "torch.int16") or (d_out is not None and str(d_out.dtype) != "torch.int16"):
+            raise ValueError(f"d_in must be {'float32' if float_in else 'int16'} for this model, d_out int16")
+        if d_out is None and d_f32 is None:
+            raise ValueError("ask for at least one output")
         f32_ptr = None
         if d_f32 is not None:
-            if tuple(d_f32.shape) != (B, self.row_out) or not d_f32.is_contiguous():
+            if tuple(d_f32.shape) != (B, self.row_out) or not d_f32.is_contiguous() or str(d_f32.dtype) != "torch.float32":
                 raise ValueError("d_f32 must be a contiguous (B, channels * out_len) float32 tensor")
             f32_ptr = C.c_void_p(d_f32.data_ptr())
-        st = self._lib.c.ade_process_device(self._h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr()), f32_ptr,
-                                            C.c_void_p(stream) if stream else None)
+        fn = self._lib.c.ade_process_device_f32 if float_in else self._lib.c.ade_process_device
+        st = fn(self._h, C.c_void_p(d_in.data_ptr()), B, C.c_void_p(d_out.data_ptr()) if d_out is not None else None, f32_ptr,
+                C.c_void_p(stream) if stream else None)
         self._lib.check(st, self._h)
 
     def reserve(self, batch: int) -> None:

@@ -336,3 +336,35 @@ def test_gpu_nan_samples_follow_the_reference_nan_to_num(zipf, ulu):
     # What the NaN reaches: a NaN waveform sample becomes 0, never the clamp limit.  (The reference's graph keeps NaN through torch.clamp and so zeroes every later
     # sample; the engine's fmaxf-style clamps (log-power floor) drop it, so later frames come back finite -- garbage in, unspecified finite samples out)
     assert (got != -32768).all()
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_float_entry_matches_the_host_entry(ulu):
+    """ade_process_device_f32 on device tensors (the reference's io-binding pattern) = ade_process_f32 on host buffers, bit for bit: a sub-engine family (UL-UNAS, F32 in
+    and out) and GTCRN's sandwich (F32 in, INT16 out), on the caller's stream."""
+    import torch
+    from ade_testlib import default_meta, golden_blob, golden_inputs
+    from audio_denoiser_onnx_amd import ulunas
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    fused, z = ulu
+    x = np.stack((z["x_in"], z["x_in"][::-1] * np.float32(0.5)))
+    with InferenceSession(weights=pack_blob(fused), metadata=with_dtypes(ulunas.metadata(x.shape[1]), "F32", "F32")) as sess:
+        want = sess.run(None, {"noisy_audio": x[:, None]})[0][:, 0]
+        d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        d_f32 = torch.zeros((2, sess.row_out), dtype=torch.float32, device="cuda")
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            sess.run_device(d_in, None, d_f32, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(d_f32.cpu().numpy(), want)
+        with pytest.raises(ValueError):
+            sess.run_device(d_in.to(torch.int16), None, d_f32)                       # a float-input model takes float32 tensors
+    pcm = golden_inputs()["wav0"][:16000]
+    xg = (pcm.astype(np.float32) / np.float32(32768.0))[None]
+    with InferenceSession(weights=golden_blob(0), metadata=default_meta(16000, input_audio_dtype="F32")) as sess:
+        want = sess.run(None, {"noisy_audio": xg[:, None]})[0][:, 0]
+        d_in = torch.from_numpy(xg).cuda()
+        d_out = torch.zeros((1, sess.row_out), dtype=torch.int16, device="cuda")
+        sess.run_device(d_in, d_out)
+        assert np.array_equal(d_out.cpu().numpy(), want) and np.abs(want).max() > 100
