@@ -368,3 +368,38 @@ def test_gpu_device_resident_float_entry_matches_the_host_entry(ulu):
         d_out = torch.zeros((1, sess.row_out), dtype=torch.int16, device="cuda")
         sess.run_device(d_in, d_out)
         assert np.array_equal(d_out.cpu().numpy(), want) and np.abs(want).max() > 100
+
+
+@pytest.mark.gpu
+def test_gpu_float_tensors_with_batch_fold(ulu, melb, zipf, dfs):
+    """USE_BATCH_FOLD exports with float tensors: the fold is a reshape inside the graph (e.g. Export_UL_UNAS.py:866-871) and the dtype switches are the exact steps pinned
+    above, so a folded F32 -> INT16 handle must return the folded INT16 handle's PCM bit for bit (x / 32768 * 32768 is the int16 sample again), and its F32 output the
+    same waveform.  The int16 fold paths are pinned to reference runs in each family's own test file."""
+    from audio_denoiser_onnx_amd import melband, ulunas, zipenhancer as zp
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    rng = np.random.default_rng(5)
+
+    def check(blob, meta, channels, fam):
+        with InferenceSession(weights=blob, metadata=meta) as si:
+            n = si.in_len
+            pcm = (rng.standard_normal((1, channels, n)) * 3000).astype(np.int16)
+            want = si.run(None, {si.get_inputs()[0].name: pcm})[0]
+        x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+        with InferenceSession(weights=blob, metadata=with_dtypes(meta, "F32", "INT16")) as sf:
+            got = sf.run(None, {sf.get_inputs()[0].name: x})[0]
+        assert np.array_equal(got, want) and np.abs(want).max() > 0, fam
+        with InferenceSession(weights=blob, metadata=with_dtypes(meta, "F32", "F32")) as sf:
+            wave = sf.run(None, {sf.get_inputs()[0].name: x})[0]
+        scale = 32768.0 if fam == "dfsmn" else 32767.0
+        d = np.abs(np.clip(wave.astype(np.float64) * scale, -32768, 32767).astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= 1, (fam, d.max())                       # the float output is the waveform the PCM was cast from (ZipEnhancer: * 2^-15 of int16 units, hence <= 1)
+
+    check(pack_blob(ulu[0]), ulunas.metadata(10000, use_batch_fold=True, batch_window_seconds=0.256), 1, "ul_unas")
+    check(pack_blob(melband.model_tensors(melb[1])), melband.metadata(30000, use_batch_fold=True, batch_window_seconds=0.3), 2, "mel_band_roformer")
+    check(pack_blob(zipf[0]), zp.metadata(12000, use_batch_fold=True, batch_window_seconds=0.5), 1, "zipenhancer")
+    with open(os.path.join(GOLD, "dfsmn_seed0.adew"), "rb") as f:
+        blob = f.read()
+    meta = dfsmn_meta(20000)
+    meta.update({"use_batch_fold": "1", "batch_window_seconds": "0.2", "fold_window_length": "9600", "export_audio_length": "28800"})
+    check(blob, meta, 1, "dfsmn")
