@@ -583,8 +583,9 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     // ---- multi-kernel path (any T): channels-last tensors, deferred TRA gates (View)
     if (e->gt_sand) {   // GTCRN_CUSTOM's input sandwich -> the final fp32 waveform at the model rate, which the STFT reads as it is   (Export_GTCRN.py:636-655)
         q.begin("sandwich_in");
-        launch_gt_sandwich_in(s, e->cur_fin ? nullptr : d_in, e->cur_fin, B, e->in_len, e->gt_l1, e->gt_lm, e->gt_lerp1, e->gt_lerp2, e->gt_gain, e->gt_tmp, e->gt_mean,
-                              e->gt_in);
+        // (batch-fold: one mean per CALL of n_win windows, :645-660; a call's windows are contiguous, so the stage runs on B / n_win rows of n_win * W samples)
+        launch_gt_sandwich_in(s, e->cur_fin ? nullptr : d_in, e->cur_fin, B / e->n_win, e->in_len * e->n_win, e->gt_l1 * e->n_win, e->gt_lm * e->n_win, e->gt_lerp1,
+                              e->gt_lerp2, e->gt_gain, e->gt_tmp, e->gt_mean, e->gt_in);
         q.end();
         q.begin("stft_feat"); launch_stft_pcm(s, nullptr, nullptr, B, e->gt_lm, T, e->tabs, e->erb_bm, e->spec, e->feat, true, e->gt_in); q.end();
     } else {
@@ -1026,7 +1027,9 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
     e->in_len = (int)L;
     e->sample_rate = (int)sr_model;
     if (sandwich) {
-        if (fold) return bail(fail(e, ADE_ERR_UNSUPPORTED, "gtcrn: use_batch_fold with float audio, other sample rates or dynamic_axes is not implemented"));
+        // batch-fold needs a static shape and equal rates in the reference (Export_GTCRN.py:41); with a float input tensor the fold is the same reshape after the
+        // centring of the whole call (:645-660): the input stage below runs on whole calls, everything after it on their windows
+        if (fold && (dyn || rates_differ_g)) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires a static shape and equal input/model/output sample rates."));
         // F.interpolate(scale_factor = f): floor(length * f) samples, source step 1 / f (the same evaluation order as the module's attributes, :623-626)
         long Lm = L;
         e->gt_l1 = (int)L;
@@ -1154,11 +1157,12 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process_device");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    ade_status st = reserve(h, batch);
+    const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
+    ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     h->cur_fin = d_in;
-    st = run(h, s, reinterpret_cast<const int16_t*>(d_in), batch, d_out, d_f32);      // (the pointer only keys the graph cache: enqueue reads cur_fin)
+    st = run(h, s, reinterpret_cast<const int16_t*>(d_in), rows, d_out, d_f32);      // (the pointer only keys the graph cache: enqueue reads cur_fin)
     h->cur_fin = nullptr;
     if (st != ADE_OK) return st;
     if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
@@ -1171,12 +1175,13 @@ ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* ou
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    ade_status st = reserve(h, batch);
+    const int rows = batch * h->n_win;
+    ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
-    const size_t nin = (size_t)batch * h->in_len, nout = (size_t)batch * h->out_len;
+    const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
     HIP_TRY(h, hipMemcpyAsync(h->d_f32_in, in, nin * sizeof(float), hipMemcpyHostToDevice, h->stream));
     h->cur_fin = h->d_f32_in;
-    st = run(h, h->stream, reinterpret_cast<const int16_t*>(h->d_f32_in), batch, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
+    st = run(h, h->stream, reinterpret_cast<const int16_t*>(h->d_f32_in), rows, h->d_pcm_out, out_f32 ? h->d_f32_out : nullptr);
     h->cur_fin = nullptr;
     if (st != ADE_OK) return st;
     if (out_pcm) HIP_TRY(h, hipMemcpyAsync(out_pcm, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));

@@ -154,3 +154,47 @@ def test_export_manifest_carries_the_io_switches():
     meta = export.build_audio_metadata(producer="t", model_name="GTCRN", task="denoise", model_family="gtcrn", input_audio_length=48000, in_sample_rate=48000,
                                        out_sample_rate=8000, model_sample_rate=16000, dynamic_axes=True, input_audio_dtype="F32", output_audio_dtype="INT16")
     assert meta["dynamic_axes"] == "1" and meta["input_audio_dtype"] == "F32" and meta["in_sample_rate"] == "48000" and meta["out_sample_rate"] == "8000"
+
+
+# ---- float input tensors on a batch-fold export (Export_GTCRN.py:41, :645-660): the whole call is centred, then folded ------------------------------------------------
+def _fold_f32():
+    g = np.load(os.path.join(GOLD, "gtcrn_seed0_fold_f32.npz"))
+    pcm = np.round(g["x_in"].astype(np.float64) * 32768.0).astype(np.int16)        # the fixture's input is int16 / 32768: the same samples, exactly
+    assert np.array_equal(pcm.astype(np.float32) / np.float32(32768.0), g["x_in"])
+    return g, pcm
+
+
+def test_oracle_batch_fold_with_float_input_matches_reference():
+    from oracle_lib import GtcrnOracle
+    g, pcm = _fold_f32()
+    o = GtcrnOracle(golden_blob(0), int(g["fold_window_length"]))
+    opcm, of32 = o.process_fold(pcm[None], 3, threads=2)
+    assert np.abs(opcm[0].astype(np.int32) - g["f32_i16"].astype(np.int32)).max() <= 1
+    assert np.abs(of32[0] - g["f32_f32"]).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_gpu_batch_fold_with_float_tensors():
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    g, pcm = _fold_f32()
+    for dout, key in (("INT16", "f32_i16"), ("F32", "f32_f32")):
+        meta = build_audio_metadata(producer="tests", model_name="GTCRN", task="denoise", model_family="gtcrn", input_audio_length=int(g["input_audio_length"]),
+                                    use_batch_fold=True, batch_window_seconds=float(g["batch_window_seconds"]), input_audio_dtype="F32", output_audio_dtype=dout)
+        with InferenceSession(weights=golden_blob(0), metadata=meta) as sess:
+            assert (sess.in_len, sess.out_len, sess.frames) == (12288, 12288, 17)
+            x2 = np.stack((g["x_in"], g["x_in"][::-1] * np.float32(0.5)))
+            got = sess.run(None, {"noisy_audio": x2[:, None]})[0][:, 0]
+            alone = sess.run(None, {"noisy_audio": x2[:1, None]})[0][0, 0]
+        assert np.array_equal(alone, got[0])                                         # calls are independent
+        if dout == "INT16":
+            assert np.abs(got[0].astype(np.int32) - g[key].astype(np.int32)).max() <= 1
+        else:
+            assert np.abs(got[0] - g[key]).max() <= 2e-5
+    # the int16 fold handle on the same samples: the same PCM, bit for bit (x * 32768 is the int16 sample again... but the float path centres in fp32 on normalised
+    # samples exactly as the int16 path does after its 2^-15 scale)
+    meta = build_audio_metadata(producer="tests", model_name="GTCRN", task="denoise", model_family="gtcrn", input_audio_length=int(g["input_audio_length"]),
+                                use_batch_fold=True, batch_window_seconds=float(g["batch_window_seconds"]))
+    with InferenceSession(weights=golden_blob(0), metadata=meta) as sess:
+        ref = sess.run(None, {"noisy_audio": pcm[None, None]})[0][0, 0]
+    assert np.abs(ref.astype(np.int32) - g["f32_i16"].astype(np.int32)).max() <= 1

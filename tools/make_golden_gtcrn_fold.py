@@ -22,8 +22,8 @@ import make_golden_gtcrn as mg  # noqa: E402
 from ref_import import REF_ROOT, import_gtcrn_namespace, import_stft_process  # noqa: E402
 
 
-def build_fold_reference(seed: int, input_len: int):
-    ns = import_gtcrn_namespace(input_len, {"USE_BATCH_FOLD": True})
+def build_fold_reference(seed: int, input_len: int, extra: dict | None = None):
+    ns = import_gtcrn_namespace(input_len, dict({"USE_BATCH_FOLD": True}, **(extra or {})))
     assert ns["USE_BATCH_FOLD"] and ns["STATIC_MODEL_BATCH"] == ns["EXPORT_AUDIO_LENGTH"] // ns["FOLD_WINDOW_LENGTH"]
     # the same seeded weights as gtcrn_seed<seed>.adew: weights do not depend on the length constants
     _, custom_plain, _ = mg.build_reference(seed, 16000)
@@ -56,6 +56,29 @@ def main():
                         input_audio_length=np.int64(48000))
     print("fold golden:", W, n_win, L, out.shape, int(np.abs(out.astype(np.int32)).max()))
 
+
+def fold_float():
+    """USE_BATCH_FOLD with float audio tensors (IN / OUT_AUDIO_DTYPE F32): the whole call is centred (:645-647), then folded (:656-660).  BATCH_WINDOW_SECONDS = 0.256
+    -> W = 4096 (17 frames); INPUT_AUDIO_LENGTH = 10000 -> 3 windows = 12288 samples.  tests/golden/gtcrn_seed0_fold_f32.npz; weights = gtcrn_seed0.adew."""
+    z = np.load(os.path.join(mg.GOLD, "gtcrn_seed0_fold.npz"))
+    out = {}
+    for tag, din, dout in (("f32_i16", "F32", "INT16"), ("f32_f32", "F32", "F32")):
+        ns, custom = build_fold_reference(0, 10000, {"BATCH_WINDOW_SECONDS": 0.256, "IN_AUDIO_DTYPE": din, "OUT_AUDIO_DTYPE": dout})
+        W, n_win, L = ns["FOLD_WINDOW_LENGTH"], ns["STATIC_MODEL_BATCH"], ns["EXPORT_AUDIO_LENGTH"]
+        assert (W, n_win, L) == (4096, 3, 12288), (W, n_win, L)
+        pcm = z["pcm_in"][:L].copy()
+        x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+        with torch.inference_mode():
+            y = custom(torch.from_numpy(x.reshape(1, 1, -1))).numpy().reshape(-1)
+        out["x_in"], out[tag] = x, y
+        print(tag, y.shape, y.dtype, float(np.abs(y).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, "gtcrn_seed0_fold_f32.npz"), fold_window_length=np.int64(4096), input_audio_length=np.int64(10000),
+                        batch_window_seconds=np.float64(0.256), **out)
+
+
+if __name__ == "__main__" and "--float" in sys.argv:
+    fold_float()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()
