@@ -851,8 +851,6 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         if (!dtype_ok_d(e->meta["input_audio_dtype"]) || !dtype_ok_d(e->meta["output_audio_dtype"]))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: input_audio_dtype / output_audio_dtype must be INT16, F32 or F16"));
         const bool float_in_d = e->meta["input_audio_dtype"] != "INT16", float_io = float_in_d || e->meta["output_audio_dtype"] != "INT16";
-        if (float_io && fold_d && fam_hg)      // its float entry centres one call's tensor and does not window it (the other families' float entries read folded rows like int16 ones)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "h_gtcrn: float audio tensors together with use_batch_fold=1 are not implemented (pass the windows as batch rows)"));
         if (Ld < 16 || Ld > (1 << 24)) return bail(fail(e, ADE_ERR_SHAPE_MISMATCH, "input_audio_length out of range"));
         long sub_win = 1;
         const long caller_len = Ld;

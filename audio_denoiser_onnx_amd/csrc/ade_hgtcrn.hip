@@ -64,10 +64,16 @@ __global__ __launch_bounds__(256) void k_hg_mean_f32(const float* __restrict__ x
         mean[blockIdx.x] = (float)(tot / ((double)n * 32768.0));
     }
 }
-__global__ __launch_bounds__(256) void k_hg_f2f(const float* __restrict__ in, const float* __restrict__ mean, float* __restrict__ x, int W, long long total) {
+__global__ __launch_bounds__(256) void k_hg_f2f(const float* __restrict__ in, const float* __restrict__ mean, float* __restrict__ x, int W, int n_win, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    x[i] = in[i] * (1.0f / 32768.0f) - mean[i / (2 * (long long)W)];          // rows are already (call, channel): no fold with resampling
+    const int n = (int)(i % W);                                                // the same gather as k_hg_pcm2f (a float input tensor on a batch-fold export)
+    const long long row = i / W;
+    const int ch = (int)(row & 1);
+    const long long wn = row >> 1;
+    const long long call = wn / n_win;
+    const int win = (int)(wn - call * n_win);
+    x[i] = in[(call * 2 + ch) * (long long)n_win * W + (long long)win * W + n] * (1.0f / 32768.0f) - mean[call];
 }
 
 // eps[b] = 1e-3 * mean_f( max_{m,t} |X|^2 )  (:690-691)
@@ -686,10 +692,9 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     const int nfr = B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     if (float_in) {
-        if (n_win != 1) return hfail(err, ADE_ERR_BAD_VALUE, "h_gtcrn: resampled input cannot be folded");
         if (float_src_len > 0 && float_src_len < W) launch_pcm_mean(s, d_in, batch, 2 * float_src_len, mean, 1);      // upsampled: centred before the interpolation
-        else hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_in, (long long)2 * W, mean);
-        hipLaunchKernelGGL(k_hg_f2f, flat((long long)B * 2 * W), dim3(256), 0, s, float_in, (const float*)mean, xf, W, (long long)B * 2 * W);
+        else hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_in, (long long)2 * n_win * W, mean);      // one mean per call (:963-964)
+        hipLaunchKernelGGL(k_hg_f2f, flat((long long)B * 2 * W), dim3(256), 0, s, float_in, (const float*)mean, xf, W, n_win, (long long)B * 2 * W);
     } else {
         launch_pcm_mean(s, d_in, batch, 2 * n_win * W, mean, 1);
         hipLaunchKernelGGL(k_hg_pcm2f, flat((long long)B * 2 * W), dim3(256), 0, s, d_in, (const float*)mean, xf, W, n_win, (long long)B * 2 * W);

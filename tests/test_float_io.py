@@ -403,3 +403,23 @@ def test_gpu_float_tensors_with_batch_fold(ulu, melb, zipf, dfs):
     meta = dfsmn_meta(20000)
     meta.update({"use_batch_fold": "1", "batch_window_seconds": "0.2", "fold_window_length": "9600", "export_audio_length": "28800"})
     check(blob, meta, 1, "dfsmn")
+
+
+@pytest.mark.gpu
+def test_gpu_hgtcrn_float_tensors_with_batch_fold(hg):
+    """H-GTCRN's batch-fold export with a float input: one mean per call, then the same window gather as the int16 entry (Export_H_GTCRN.py:963-981).  The samples that
+    reach the network are the int16 entry's, so the two handles must agree bit for bit (the int16 fold path is pinned in tests/test_hgtcrn.py::test_gpu_fold)."""
+    from audio_denoiser_onnx_amd import hgtcrn
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    fused, _ = hg
+    zf = np.load(os.path.join(GOLD, "hgtcrn_seed0_fold.npz"))
+    pcm = zf["pcm_in"][None]
+    meta = hgtcrn.metadata(20000, use_batch_fold=True, batch_window_seconds=0.512)
+    with InferenceSession(weights=pack_blob(fused), metadata=meta) as si:
+        want = si.run(None, {"noisy_audio": pcm})[0]
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    with InferenceSession(weights=pack_blob(fused), metadata=with_dtypes(meta, "F32", "INT16")) as sf:
+        got = sf.run(None, {"noisy_audio": x})[0]
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 3 and (d != 0).mean() < 0.05, (d.max(), (d != 0).mean())
