@@ -204,6 +204,50 @@ __device__ __forceinline__ float4 pick4(bool first, const float4& a, const float
     return make_float4(first ? a.x : b.x, first ? a.y : b.y, first ? a.z : b.z, first ? a.w : b.w);
 }
 
+// ---- exchange between workgroups of ONE launch (segments of a chunk hand their recurrent states / convolution histories on) -------------
+// Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores, so every shared word moves
+// with agent-scope accesses: payload as write-through (sc1) stores, then EVERY storing wave drains its stores (xdrain), a workgroup barrier,
+// ONE lane raises the flag; the consumer polls that one word (relaxed, sc1), a workgroup barrier, then sc1 loads (they bypass the L1, so no
+// acquire fence is needed).  Placement-independent: nothing here assumes a dispatch order or a workgroup -> XCD map.
+#if defined(__AMDGCN__)
+typedef unsigned ade_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 xld4(const float* base, int float_off) {      // 16-B sc1 load of base[float_off .. +3]
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    const ade_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, float_off * 4, 0, 16);
+    return make_float4(__int_as_float((int)v.x), __int_as_float((int)v.y), __int_as_float((int)v.z), __int_as_float((int)v.w));
+}
+__device__ __forceinline__ void xst4(float* base, int float_off, const float4& v) {   // 16-B sc1 (write-through) store
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    ade_v4u u;
+    u.x = (unsigned)__float_as_int(v.x); u.y = (unsigned)__float_as_int(v.y); u.z = (unsigned)__float_as_int(v.z); u.w = (unsigned)__float_as_int(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, float_off * 4, 0, 16);
+}
+__device__ __forceinline__ float xld1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xst1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned xflag_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xflag_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xdrain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ float4 xld4(const float* base, int float_off) { return *reinterpret_cast<const float4*>(base + float_off); }
+__device__ __forceinline__ void xst4(float* base, int float_off, const float4& v) { *reinterpret_cast<float4*>(base + float_off) = v; }
+__device__ __forceinline__ float xld1(const float* p) { return *p; }
+__device__ __forceinline__ void xst1(float* p, float v) { *p = v; }
+__device__ __forceinline__ unsigned xflag_load(const unsigned* p) { return *(const volatile unsigned*)p; }
+__device__ __forceinline__ void xflag_store(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
+__device__ __forceinline__ void xdrain() {}
+#endif
+// ONE lane polls ONE flag until it is raised, then lowers it again for the next launch (each flag has exactly one consumer; the kernel
+// boundary orders that store before the next launch's producer).  Bounded: after ~0.2 s of wall clock the wait gives up, records the
+// failure in *err and lets the workgroup run on (garbage out, reported by the engine) instead of hanging the device.
+__device__ __forceinline__ void xwait(unsigned* flag, int* err) {
+    const long long t0 = wall_clock64();
+    while (xflag_load(flag) == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 20000000LL) { *reinterpret_cast<volatile int*>(err) = 1; return; }
+    }
+    xflag_store(flag, 0u);
+}
+
 inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace dev

@@ -99,12 +99,19 @@ struct ade_engine {
     int16_t* h_pcm_out = nullptr;
     float* h_f32_out = nullptr;
 
-    int stagger_ticks = 2750;             // 27.5 us, applied when a launch has enough chunks to load the memory system (see enqueue)
+    int stagger_ticks = 2750;             // 27.5 us, applied when a launch has enough chunks to load the memory system (see enqueue; geometry 0 only)
+    int geometry = -1;                    // fused-path workgroup geometry (ade_internal.h): -1 = choose per call, 0 = 1024 threads x 64 frames, 1 = 512 x 32
+    ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
+    float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
+    unsigned* d_xflags = nullptr;         // its flags (zero between launches)
+    int* d_xerr = nullptr;                // page-locked host word the kernels can write: a bounded inter-workgroup wait gave up
+    int xchg_segments = 0;                // slots per chunk the exchange area was sized for
     bool use_graph = true;
     bool graph_supported = true;
     bool use_fused = true;      // per-chunk LDS-resident stage kernels when T <= 64 (ade_fused.hip)
     bool use_single = true;     // ... as ONE launch (k_gtcrn_chunk); profile mode always uses the per-stage kernels
     bool last_fused = false;
+    int last_geometry = -1;
     long long* d_clk = nullptr;   // phase-clock slots (profile modes 1 and 3 only)
     std::vector<GraphEntry> graphs;
 
@@ -288,7 +295,7 @@ struct Loader {
     }
 };
 
-constexpr int kClkSlots = 64 * 10;
+constexpr int kClkSlots = ade::kClkSlotsPerSeg * 2;   // phase clocks of the first two segments
 
 ade_status build_device_constants(ade_engine* e) {
     Loader L{e};
@@ -427,6 +434,11 @@ void free_workspace(ade_engine* e) {
     if (e->h_f32_out) hipHostFree(e->h_f32_out);
     if (e->rs_in) hipFree(e->rs_in);
     if (e->rs_out) hipFree(e->rs_out);
+    if (e->d_fixed) hipFree(e->d_fixed);
+    if (e->d_xchg) hipFree(e->d_xchg);
+    if (e->d_xflags) hipFree(e->d_xflags);
+    if (e->d_xerr) hipHostFree(e->d_xerr);
+    e->d_fixed = nullptr; e->d_xchg = nullptr; e->d_xflags = nullptr; e->d_xerr = nullptr;
     for (float** p : {&e->gt_tmp, &e->gt_in, &e->gt_wave, &e->gt_mean, &e->d_f32_in}) { if (*p) hipFree(*p); *p = nullptr; }
     e->rs_in = e->rs_out = nullptr;
     e->ws = nullptr;
@@ -491,6 +503,25 @@ ade_status reserve(ade_engine* e, int batch) {
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
+    {   // the fused path's device-resident argument block and the segment exchange area (sized for the finest split any geometry would use)
+        ChunkFixed F{};
+        F.tabs = e->tabs; F.erb_bm = e->erb_bm; F.erb_bs = e->erb_bs;
+        F.en0 = e->en0; F.en1 = e->en1; F.de3 = e->de3; F.de4 = e->de4;
+        for (int i = 0; i < 3; ++i) { F.en_gt[i] = e->en_gt[i]; F.de_gt[i] = e->de_gt[i]; F.xe[i] = e->xe[i]; F.xd[i] = e->xd[i]; }
+        for (int i = 0; i < 2; ++i) { F.dp[i] = e->dp[i]; F.dpo[i] = e->dpo[i]; }
+        F.spec = e->spec; F.e0 = e->e0; F.e1 = e->e1;
+        HIP_TRY(e, hipMalloc((void**)&e->d_fixed, sizeof(ChunkFixed)));
+        HIP_TRY(e, hipMemcpy(e->d_fixed, &F, sizeof(ChunkFixed), hipMemcpyHostToDevice));
+        int nseg = 1;
+        for (int g = 0; g < fused_geometries(); ++g)
+            if (fused_supported(e->T, g)) nseg = std::max(nseg, fused_segments(e->T, g));
+        e->xchg_segments = nseg;
+        HIP_TRY(e, hipMalloc((void**)&e->d_xchg, B * nseg * (size_t)kXFloats * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_xflags, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
+        HIP_TRY(e, hipMemset(e->d_xflags, 0, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
+        HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
+        *e->d_xerr = 0;
+    }
     if (e->gt_sand) {
         HIP_TRY(e, hipMalloc((void**)&e->gt_tmp, B * (size_t)e->gt_l1 * sizeof(float)));
         HIP_TRY(e, hipMalloc((void**)&e->gt_in, B * (size_t)e->gt_lm * sizeof(float)));
@@ -532,16 +563,27 @@ struct Seq {
     }
 };
 
+// Fused-path geometry of a call (-1: the frame count fits neither).  Two 512-thread workgroups per CU (geometry 1) overlap one
+// workgroup's serial phases with the other's parallel ones; the option "geometry" pins either.
+int pick_geometry(const ade_engine* e, int /*B*/) {
+    if (e->geometry >= 0) return fused_supported(e->T, e->geometry) ? e->geometry : -1;
+    if (fused_supported(e->T, 1)) return 1;
+    return fused_supported(e->T, 0) ? 0 : -1;
+}
+
 void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32, bool prof) {
     const int T = e->T, nfr = B * T;
     Seq q{e, s, prof};
     const View none{nullptr, nullptr};
-    const bool fused = e->use_fused && fused_supported(T) && !e->gt_sand;      // the sandwich (float audio / other rates / dynamic length) takes the multi-kernel sequence
+    const int geo = pick_geometry(e, B);
+    const bool fused = e->use_fused && geo >= 0 && !e->gt_sand;      // the sandwich (float audio / other rates / dynamic length) takes the multi-kernel sequence
     e->last_fused = fused;
     View x{e->e1, nullptr};
     if (fused) {
-        // ---- fused path: one 1024-thread workgroup per chunk per stage, activations LDS-resident, inter-stage tensors
-        //      channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  10 launches.
+        // ---- fused path: one workgroup per chunk SEGMENT per stage (ade_internal.h: geometries), activations LDS-resident, inter-stage
+        //      tensors channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  1 launch, or 10.
+        const SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr};
+        e->last_geometry = geo;
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
         const float* dc = nullptr;
@@ -550,34 +592,31 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             dc = e->mean;
         }
         if (e->use_single && (!prof || e->profile_mode >= 2)) {
-            ChunkArgs A{};
-            A.dc = dc;
-            A.stagger = B >= 192 ? e->stagger_ticks : 0;       // measured: pays from ~three quarters of a chunk per CU (B = 128: +4.6 %, 256: -4.3 %, 512 / 1024: -2.8 %)
-            A.pcm_in = d_in; A.pcm_out = d_out; A.f32_out = d_f32; A.L = e->in_len; A.T = T;
-            A.tabs = e->tabs; A.erb_bm = e->erb_bm; A.erb_bs = e->erb_bs;
-            A.en0 = e->en0; A.en1 = e->en1; A.de3 = e->de3; A.de4 = e->de4;
-            for (int i = 0; i < 3; ++i) { A.en_gt[i] = e->en_gt[i]; A.de_gt[i] = e->de_gt[i]; A.xe[i] = e->xe[i]; A.xd[i] = e->xd[i]; }
-            for (int i = 0; i < 2; ++i) { A.dp[i] = e->dp[i]; A.dpo[i] = e->dpo[i]; }
-            A.spec = e->spec; A.e0 = e->e0; A.e1 = e->e1; A.d3 = e->d3; A.mask = e->mask;
-            A.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
-            q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, A, B); q.end();
+            ChunkCall C{};
+            C.fixed = e->d_fixed;
+            C.dc = dc;
+            // geometry 0, measured: the stagger pays from ~three quarters of a chunk per CU (B = 128: +4.6 %, 256: -4.3 %, 512 / 1024: -2.8 %)
+            C.stagger = (geo == 0 && B >= 192) ? e->stagger_ticks : 0;
+            C.pcm_in = d_in; C.pcm_out = d_out; C.f32_out = d_f32; C.L = e->in_len; C.T = T; C.B = B;
+            C.plan = plan;
+            C.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
+            q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, geo, C); q.end();
             return;
         }
-        q.begin("front"); launch_front(s, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk, dc); q.end();
+        q.begin("front"); launch_front(s, geo, plan, d_in, B, e->in_len, T, e->tabs, e->erb_bm, e->en0, e->en1, e->spec, e->e0, e->e1, clk, dc); q.end();
         for (int i = 0; i < 3; ++i) {
-            q.begin("gtblock"); launch_gtblock(s, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
+            q.begin("gtblock"); launch_gtblock(s, geo, plan, i, x.x, nullptr, e->en_gt[i], e->xe[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->xe[i], nullptr};
         }
         for (int i = 0; i < 2; ++i) {
-            q.begin("dpgrnn"); launch_dpgrnn(s, x.x, e->dp[i], e->dpo[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
+            q.begin("dpgrnn"); launch_dpgrnn(s, geo, plan, i, x.x, e->dp[i], e->dpo[i], B, T, (prof && i == 0) ? e->d_clk : nullptr); q.end();
             x = View{e->dpo[i], nullptr};
         }
         for (int i = 0; i < 3; ++i) {
-            q.begin("gtblock"); launch_gtblock(s, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T, nullptr); q.end();
+            q.begin("gtblock"); launch_gtblock(s, geo, plan, 3 + i, x.x, e->xe[2 - i], e->de_gt[i], e->xd[i], B, T, nullptr); q.end();
             x = View{e->xd[i], nullptr};
         }
-        q.begin("back"); launch_back(s, x.x, e->e1, e->e0, e->spec, e->de3, e->de4, e->erb_bs, e->tabs, e->d3, e->mask, d_out, d_f32, B, T,
-                                     clk); q.end();
+        q.begin("back"); launch_back(s, geo, plan, x.x, e->e1, e->e0, e->spec, e->de3, e->de4, e->erb_bs, e->tabs, d_out, d_f32, B, T, clk); q.end();
         return;
     }
     // ---- multi-kernel path (any T): channels-last tensors, deferred TRA gates (View)
@@ -674,7 +713,7 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     // depend on the caller's CPU (their workspace is reserved before capture; reserve() drops the graphs when it reallocates).  On the
     // bench host the replay measured the same as plain launches (MossFormer2, 1 window: 26.9 ms both ways): small batches are bound by
     // GPU-side kernel latency and by the few single-workgroup reductions, not by the host.
-    const bool one_kernel = !e->sub && e->use_fused && e->use_single && fused_supported(e->T) && !e->gt_sand;
+    const bool one_kernel = !e->sub && e->use_fused && e->use_single && pick_geometry(e, B) >= 0 && !e->gt_sand;
     if (e->use_graph && e->graph_supported && !one_kernel) {
         GraphEntry* hit = nullptr;
         for (auto& g : e->graphs)
@@ -1121,6 +1160,16 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         h->stagger_ticks = (int)(us * 100.0 + 0.5);
         return ADE_OK;
     }
+    if (strcmp(key, "geometry") == 0) {        // fused-path workgroup geometry: "auto", "0" (1024 threads x 64 frames), "1" (512 x 32, two per CU)
+        int g = -2;
+        if (strcmp(value, "auto") == 0) g = -1;
+        else if (strcmp(value, "0") == 0) g = 0;
+        else if (strcmp(value, "1") == 0) g = 1;
+        if (g == -2) return fail(h, ADE_ERR_BAD_VALUE, "option geometry: auto, 0 or 1");
+        h->geometry = g;
+        free_graphs(h);
+        return ADE_OK;
+    }
     if (strcmp(key, "graph") == 0 || strcmp(key, "fused") == 0 || strcmp(key, "single_launch") == 0) {
         bool b;
         if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, std::string("option ") + key + " must be 0/1");
@@ -1214,6 +1263,11 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     if (out_pcm) HIP_TRY(h, hipMemcpyAsync(pcm_direct ? out_pcm : h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(f32_direct ? out_f32 : h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_xerr && *(volatile int*)h->d_xerr) {   // a segment's bounded wait for its predecessor gave up: the outputs are not to be trusted
+        *h->d_xerr = 0;
+        (void)hipMemset(h->d_xflags, 0, (size_t)h->capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
+        return fail(h, ADE_ERR_DEVICE, "fused path: a chunk segment timed out waiting for its predecessor workgroup (option geometry=0 runs whole chunks per workgroup)");
+    }
     if (out_pcm && !pcm_direct) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
     if (out_f32 && !f32_direct) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
     return ADE_OK;
@@ -1245,12 +1299,33 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         // The single-launch clock build (mode 3) uses one such 64-slot page per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back].
         // Stamps are returned relative to their group of 16; slots 8-15 of the front / back groups are per-phase
         // accumulators over the tile loops (raw tick sums).
-        const size_t n = count >= (size_t)kClkSlots ? (size_t)kClkSlots : 64;
+        // One 640-slot set per segment (the first two segments of chunk 0 are clocked).
+        const size_t n = std::min(count, (size_t)kClkSlots) / 64 * 64;
         long long raw[kClkSlots];
         HIP_TRY(h, hipMemcpy(raw, h->d_clk, n * sizeof(long long), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i)
             out[i] = (i & 15) >= 8 && (i & 63) >= 32 ? (float)raw[i] : (float)(raw[i] - raw[(i / 16) * 16]);
         *written = n;
+        return ADE_OK;
+    }
+    if (strcmp(name, "phase_clock_abs") == 0) {   // the same stamps in ticks since segment 0 entered the front stage (slot 32); -1 = never stamped
+        const size_t n = std::min(count, (size_t)kClkSlots) / 64 * 64;
+        if (n < 64) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+        long long raw[kClkSlots];
+        HIP_TRY(h, hipMemcpy(raw, h->d_clk, n * sizeof(long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) out[i] = raw[i] ? (float)(raw[i] - raw[32]) : -1.0f;
+        *written = n;
+        return ADE_OK;
+    }
+    if (strcmp(name, "xchg_error") == 0) {        // 1 after a bounded inter-workgroup wait of the segmented fused path gave up (sticky)
+        if (count < 1) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+        int v = 0;
+        if (h->d_xerr) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            v = *(volatile int*)h->d_xerr;
+        }
+        out[0] = (float)v;
+        *written = 1;
         return ADE_OK;
     }
     for (const Tap& t : taps)

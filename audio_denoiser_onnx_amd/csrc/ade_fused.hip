@@ -1,12 +1,15 @@
 // ade_fused.hip — kernels of the fused (per-chunk, LDS-resident) path.
 //
-// The stage bodies live in ade_stage_net.h (GTConvBlock, DPGRNN) and ade_stage_frontback.h (front, back).  They are
-// exposed two ways:
-//   * k_gtcrn_chunk: ONE launch for the whole network — a 1024-thread workgroup walks its chunk through
-//     front -> 3 x GTConvBlock -> 2 x DPGRNN -> 3 x GTConvBlock -> back.  Chunks are independent, so there is no
-//     inter-workgroup traffic and no grid barrier; inter-stage tensors (skip connections) go through HBM/L2 in the
-//     quad-planar layout and are re-read by the same workgroup after a workgroup barrier.  At batch = 256 this is one
-//     workgroup per CU of the MI355X for the whole forward.
+// The stage bodies live in ade_stage_net.h (GTConvBlock, DPGRNN) and ade_stage_frontback.h (front, back), templated on the workgroup
+// GEOMETRY (ade_internal.h): geometry 0 = 1024 threads owning up to 64 frames (one workgroup per CU), geometry 1 = 512 threads owning up
+// to 32 frames (two workgroups per CU).  A chunk with more frames than one workgroup owns is split into SEGMENTS of consecutive frames,
+// one workgroup each; segment k + 1 continues the recurrences of segment k through the exchange area (ade_internal.h, dev::xwait).
+// Segments are numbered so that all first segments come first in the grid: a segment only ever waits for a workgroup with a LOWER block
+// index, and its waits are bounded (dev::xwait) -- nothing depends on the dispatch order for correctness of the protocol's termination.
+// The bodies are exposed two ways:
+//   * k_gtcrn_chunk: ONE launch for the whole network — each workgroup walks its segment through
+//     front -> 3 x GTConvBlock -> 2 x DPGRNN -> 3 x GTConvBlock -> back.  Inter-stage tensors (skip connections) go through HBM/L2 in the
+//     quad-planar layout and are re-read by the same workgroup after a workgroup barrier.
 //   * one kernel per stage (k_front / k_gtblock / k_dpgrnn / k_back): used for per-stage HIP-event timing and phase
 //     clocks (ade_profile_last), and as the implementation the single launch is tested against.
 #include "ade_stage_frontback.h"
@@ -18,86 +21,149 @@ using namespace stage;
 namespace {
 
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
-constexpr size_t kChunkSmemBytes = cmax(cmax(kGtSmemBytes, kDpSmemBytes), cmax(kFrontSmemBytes, kBackSmemBytes));
+template <class G> constexpr size_t chunk_smem_bytes() {
+    return cmax(cmax(gt_smem_bytes<G>(), dp_smem_bytes<G>()), cmax(front_smem_bytes<G>(), back_smem_bytes<G>()));
+}
+static_assert(chunk_smem_bytes<Geo1>() * 2 <= 160 * 1024, "two geometry-1 workgroups must fit one CU's LDS");
+static_assert(chunk_smem_bytes<Geo0>() <= 160 * 1024, "geometry 0 must fit one CU's LDS");
 
-__global__ __launch_bounds__(kFusedThreads) void k_front(const int16_t* __restrict__ pcm, int L, int T, FftTabs tabs, BandTab erb,
-                                                         ConvW c0, ConvW c1, float* __restrict__ spec, float* __restrict__ e0,
-                                                         float* __restrict__ e1, long long* __restrict__ clk,
-                                                         const float* __restrict__ dc) {
-    HIP_DYNAMIC_SHARED(float4, smem)
-    front_stage(reinterpret_cast<float*>(smem), blockIdx.x, pcm, L, T, tabs, erb, c0, c1, spec, e0, e1, clk, dc);
+// Block b of a (B x nseg)-block grid -> (chunk, segment): all first segments first.  Frames are dealt as evenly as possible, the earlier
+// segments taking the extra frame (the last segment finishes last; it should not also be the longest).
+__device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int block, int& chunk) {
+    const int seg = block / B;
+    chunk = block - seg * B;
+    const int base = T / plan.nseg, rem = T - base * plan.nseg;
+    Seg sg;
+    sg.T = T;
+    sg.nT = base + (seg < rem ? 1 : 0);
+    sg.t0 = seg * base + (seg < rem ? seg : rem);
+    sg.prev = seg > 0;
+    sg.next = seg + 1 < plan.nseg;
+    const size_t slot = (size_t)chunk * plan.nseg + seg;
+    sg.xo = plan.xchg + slot * kXFloats;
+    sg.xi = plan.xchg + (slot - (seg > 0 ? 1 : 0)) * kXFloats;
+    sg.fo = plan.flags + slot * kXFlags;
+    sg.fi = plan.flags + (slot - (seg > 0 ? 1 : 0)) * kXFlags;
+    sg.err = plan.err;
+    return sg;
 }
-__global__ __launch_bounds__(kFusedThreads) void k_gtblock(const float* __restrict__ a, const float* __restrict__ skip, GtConvW w,
-                                                           float* __restrict__ out, int T, long long* __restrict__ clk) {
-    HIP_DYNAMIC_SHARED(float4, smem)
-    gtblock_stage(smem, blockIdx.x, a, skip, w, out, T, clk);
-}
-__global__ __launch_bounds__(kFusedThreads) void k_dpgrnn(const float* __restrict__ x, DpW w, float* __restrict__ out, int T,
-                                                          long long* __restrict__ clk) {
-    HIP_DYNAMIC_SHARED(float4, smem)
-    dpgrnn_stage(smem, blockIdx.x, x, w, out, T, clk);
-}
-__global__ __launch_bounds__(kFusedThreads) void k_back(const float* __restrict__ x, const float* __restrict__ e1,
-                                                        const float* __restrict__ e0, const float* __restrict__ spec, ConvW c3, ConvW c4,
-                                                        BandTab bs, FftTabs tabs, float* __restrict__ d3, float* __restrict__ mask,
-                                                        int16_t* __restrict__ pcm, float* __restrict__ f32, int T,
-                                                        long long* __restrict__ clk) {
-    HIP_DYNAMIC_SHARED(float4, smem)
-    back_stage(reinterpret_cast<float*>(smem), blockIdx.x, x, e1, e0, spec, c3, c4, bs, tabs, d3, mask, pcm, f32, T, clk);
+__device__ __forceinline__ long long* seg_clk(long long* clk, const Seg& sg, int B, int block) {
+    return clk ? clk + (size_t)(block / B) * kClkSlotsPerSeg : nullptr;
 }
 
-// kClk = false is the shipped kernel (no phase-clock code at all); kClk = true is the same kernel with thread 0 of
-// workgroup 0 stamping phase clocks into A.clk, 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back].
-template <bool kClk>
-__global__ __launch_bounds__(kFusedThreads) void k_gtcrn_chunk(ChunkArgs A) {
+template <class G>
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_front(SegPlan plan, const int16_t* __restrict__ pcm, int B, int L, int T, FftTabs tabs,
+                                                                          BandTab erb, ConvW c0, ConvW c1, float* __restrict__ spec, float* __restrict__ e0,
+                                                                          float* __restrict__ e1, long long* __restrict__ clk, const float* __restrict__ dc) {
     HIP_DYNAMIC_SHARED(float4, smem)
-    long long* const clk0 = kClk ? A.clk : nullptr;
-    const int chunk = blockIdx.x;
+    int chunk;
+    const Seg sg = make_seg(plan, B, T, blockIdx.x, chunk);
+    front_stage<G>(reinterpret_cast<float*>(smem), chunk, sg, pcm, L, tabs, erb, c0, c1, spec, e0, e1, seg_clk(clk, sg, B, blockIdx.x), dc);
+}
+template <class G>
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtblock(SegPlan plan, int blk, const float* __restrict__ a, const float* __restrict__ skip,
+                                                                            GtConvW w, float* __restrict__ out, int B, int T, long long* __restrict__ clk) {
+    HIP_DYNAMIC_SHARED(float4, smem)
+    int chunk;
+    const Seg sg = make_seg(plan, B, T, blockIdx.x, chunk);
+    gtblock_stage<G>(smem, chunk, sg, blk, a, skip, w, out, seg_clk(clk, sg, B, blockIdx.x));
+}
+template <class G>
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_dpgrnn(SegPlan plan, int blk, const float* __restrict__ x, DpW w, float* __restrict__ out,
+                                                                           int B, int T, long long* __restrict__ clk) {
+    HIP_DYNAMIC_SHARED(float4, smem)
+    int chunk;
+    const Seg sg = make_seg(plan, B, T, blockIdx.x, chunk);
+    dpgrnn_stage<G>(smem, chunk, sg, blk, x, w, out, seg_clk(clk, sg, B, blockIdx.x));
+}
+template <class G>
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_back(SegPlan plan, const float* __restrict__ x, const float* __restrict__ e1,
+                                                                         const float* __restrict__ e0, const float* __restrict__ spec, ConvW c3, ConvW c4,
+                                                                         BandTab bs, FftTabs tabs, int16_t* __restrict__ pcm, float* __restrict__ f32, int B,
+                                                                         int T, long long* __restrict__ clk) {
+    HIP_DYNAMIC_SHARED(float4, smem)
+    int chunk;
+    const Seg sg = make_seg(plan, B, T, blockIdx.x, chunk);
+    back_stage<G>(reinterpret_cast<float*>(smem), chunk, sg, x, e1, e0, spec, c3, c4, bs, tabs, pcm, f32, seg_clk(clk, sg, B, blockIdx.x));
+}
+
+// kClk = false is the shipped kernel (no phase-clock code at all); kClk = true is the same kernel with thread 0 of each segment's first
+// workgroup stamping phase clocks into C.clk, 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back], one such set per segment.
+// The per-engine arguments (weights, workspace) are read from device memory stage by stage: ChunkFixed in ade_internal.h.
+template <class G, bool kClk>
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(ChunkCall C) {
+    HIP_DYNAMIC_SHARED(float4, smem)
+    int chunk;
+    const Seg sg = make_seg(C.plan, C.B, C.T, blockIdx.x, chunk);
+    long long* const clk0 = kClk ? seg_clk(C.clk, sg, C.B, blockIdx.x) : nullptr;
     float* fsm = reinterpret_cast<float*>(smem);
-    // De-phase the workgroups.  Every stage begins and ends with an HBM burst (its inputs / skip tensors in, its output out) and at 256
-    // chunks all 256 workgroups -- one per CU -- would issue the same burst at the same instant: measured, the stages run 28 % slower at
-    // 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one GTConvBlock (27 us) makes
-    // one half's bursts land in the other half's compute phases: -3.5 % per step, the delay included (tools/stagger_probe.py).
-    if (A.stagger > 0 && ((chunk >> 3) & 1)) {
+    typedef const ChunkFixed ADE_CONSTANT_AS* fixed_ptr;
+    fixed_ptr F = (fixed_ptr)C.fixed;
+    // De-phase the workgroups (geometry 0: one workgroup per CU).  Every stage begins and ends with an HBM burst (its inputs / skip tensors
+    // in, its output out) and at 256 chunks all 256 workgroups would issue the same burst at the same instant: measured, the stages run 28 %
+    // slower at 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one GTConvBlock makes
+    // one half's bursts land in the other half's compute phases (tools/stagger_probe.py).  With two workgroups per CU (geometry 1) the
+    // segments of a chunk are out of phase by construction.
+    if (C.stagger > 0 && ((chunk >> 3) & 1)) {
         const long long t0 = wall_clock64();                 // 100 MHz, independent of the shader clock
-        while (wall_clock64() - t0 < A.stagger) __builtin_amdgcn_s_sleep(8);
+        while (wall_clock64() - t0 < C.stagger) __builtin_amdgcn_s_sleep(8);
     }
-    front_stage(fsm, chunk, A.pcm_in, A.L, A.T, A.tabs, A.erb_bm, A.en0, A.en1, A.spec, A.e0, A.e1, clk0, A.dc);
+    {
+        ADE_KEEP_IN_LOOP(F);
+        const FftTabs tabs = F->tabs;
+        const BandTab erb = F->erb_bm;
+        const ConvW c0 = F->en0, c1 = F->en1;
+        front_stage<G>(fsm, chunk, sg, C.pcm_in, C.L, tabs, erb, c0, c1, F->spec, F->e0, F->e1, clk0, C.dc);
+    }
     __syncthreads();
-    const float* x = A.e1;
+    const float* x;
+    {
+        ADE_KEEP_IN_LOOP(F);
+        x = F->e1;
+    }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // encoder GTConvBlocks
-        gtblock_stage(smem, chunk, x, nullptr, A.en_gt[i], A.xe[i], A.T, kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0,
-                      /*next_x1=*/i < 2, nullptr);
+        ADE_KEEP_IN_LOOP(F);
+        const GtConvW w = F->en_gt[i];
+        float* const o = F->xe[i];
+        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, o, kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
         __syncthreads();
-        x = A.xe[i];
+        x = o;
     }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
-        dpgrnn_stage(smem, chunk, x, A.dp[i], A.dpo[i], A.T, kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/A.xe[2]);
+        ADE_KEEP_IN_LOOP(F);
+        const DpW w = F->dp[i];
+        float* const o = F->dpo[i];
+        dpgrnn_stage<G>(smem, chunk, sg, i, x, w, o, kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2]);
         __syncthreads();
-        x = A.dpo[i];
+        x = o;
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // decoder GTConvBlocks on x + en_outs[4 - i]
-        gtblock_stage(smem, chunk, x, A.xe[2 - i], A.de_gt[i], A.xd[i], A.T, kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
-                      /*next_skip=*/i < 2 ? A.xe[1 - i] : nullptr);
+        ADE_KEEP_IN_LOOP(F);
+        const GtConvW w = F->de_gt[i];
+        float* const o = F->xd[i];
+        gtblock_stage<G>(smem, chunk, sg, 3 + i, x, F->xe[2 - i], w, o, kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
+                         /*next_skip=*/i < 2 ? F->xe[1 - i] : nullptr);
         __syncthreads();
-        x = A.xd[i];
+        x = o;
     }
-    back_stage(fsm, chunk, x, A.e1, A.e0, A.spec, A.de3, A.de4, A.erb_bs, A.tabs, A.d3, A.mask, A.pcm_out, A.f32_out, A.T,
-               kClk ? clk0 + 64 * 9 : nullptr);
+    {
+        ADE_KEEP_IN_LOOP(F);
+        const FftTabs tabs = F->tabs;
+        const BandTab erb = F->erb_bs;
+        const ConvW c3 = F->de3, c4 = F->de4;
+        back_stage<G>(fsm, chunk, sg, x, F->e1, F->e0, F->spec, c3, c4, erb, tabs, C.pcm_out, C.f32_out, kClk ? clk0 + 64 * 9 : nullptr);
+    }
 }
 
-}  // namespace
-
-bool fused_supported(int T) { return T >= 2 && T <= kTmaxFused; }
-
-hipError_t fused_init() {
-    const void* fns[6] = {reinterpret_cast<const void*>(&k_front), reinterpret_cast<const void*>(&k_gtblock),
-                          reinterpret_cast<const void*>(&k_dpgrnn), reinterpret_cast<const void*>(&k_back),
-                          reinterpret_cast<const void*>(&k_gtcrn_chunk<false>), reinterpret_cast<const void*>(&k_gtcrn_chunk<true>)};
-    const size_t bytes[6] = {kFrontSmemBytes, kGtSmemBytes, kDpSmemBytes, kBackSmemBytes, kChunkSmemBytes, kChunkSmemBytes};
+template <class G>
+hipError_t init_geometry() {
+    const void* fns[6] = {reinterpret_cast<const void*>(&k_front<G>),         reinterpret_cast<const void*>(&k_gtblock<G>),
+                          reinterpret_cast<const void*>(&k_dpgrnn<G>),        reinterpret_cast<const void*>(&k_back<G>),
+                          reinterpret_cast<const void*>(&k_gtcrn_chunk<G, false>), reinterpret_cast<const void*>(&k_gtcrn_chunk<G, true>)};
+    const size_t bytes[6] = {front_smem_bytes<G>(), gt_smem_bytes<G>(), dp_smem_bytes<G>(), back_smem_bytes<G>(), chunk_smem_bytes<G>(), chunk_smem_bytes<G>()};
     for (int i = 0; i < 6; ++i) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes[i]);
         if (e != hipSuccess) return e;
@@ -105,24 +171,51 @@ hipError_t fused_init() {
     return hipSuccess;
 }
 
-void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk) {
-    hipLaunchKernelGGL(k_gtblock, dim3(B), dim3(kFusedThreads), kGtSmemBytes, s, a, skip, w, out, T, clk);
+}  // namespace
+
+int fused_geometries() { return 2; }
+int fused_max_frames(int geometry) { return geometry == 1 ? Geo1::kTmax : Geo0::kTmax; }
+int fused_segments(int T, int geometry) { const int m = fused_max_frames(geometry); return (T + m - 1) / m; }
+bool fused_supported(int T, int geometry) {
+    if (T < 2 || geometry < 0 || geometry > 1) return false;
+    const int n = fused_segments(T, geometry);
+    return n <= kMaxSegments && (n == 1 || T / n >= kXHistFrames);   // a segment must hold the history its successor needs
 }
-void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T, long long* clk) {
-    hipLaunchKernelGGL(k_dpgrnn, dim3(B), dim3(kFusedThreads), kDpSmemBytes, s, x, w, out, T, clk);
+
+hipError_t fused_init() {
+    hipError_t e = init_geometry<Geo0>();
+    return e != hipSuccess ? e : init_geometry<Geo1>();
 }
-void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
+
+#define ADE_GEO_LAUNCH(kernel_tpl, smem_fn, grid, ...)                                                                              \
+    do {                                                                                                                            \
+        if (geometry == 1) hipLaunchKernelGGL(kernel_tpl<Geo1>, dim3(grid), dim3(Geo1::kThreads), smem_fn<Geo1>(), s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel_tpl<Geo0>, dim3(grid), dim3(Geo0::kThreads), smem_fn<Geo0>(), s, __VA_ARGS__);               \
+    } while (0)
+
+void launch_gtblock(hipStream_t s, int geometry, SegPlan plan, int blk, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk) {
+    ADE_GEO_LAUNCH(k_gtblock, gt_smem_bytes, B * plan.nseg, plan, blk, a, skip, w, out, B, T, clk);
+}
+void launch_dpgrnn(hipStream_t s, int geometry, SegPlan plan, int blk, const float* x, DpW w, float* out, int B, int T, long long* clk) {
+    ADE_GEO_LAUNCH(k_dpgrnn, dp_smem_bytes, B * plan.nseg, plan, blk, x, w, out, B, T, clk);
+}
+void launch_front(hipStream_t s, int geometry, SegPlan plan, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
                   float* e0, float* e1, long long* clk, const float* dc) {
-    hipLaunchKernelGGL(k_front, dim3(B), dim3(kFusedThreads), kFrontSmemBytes, s, pcm, L, T, tabs, erb_bm, c0, c1, spec, e0, e1, clk, dc);
+    ADE_GEO_LAUNCH(k_front, front_smem_bytes, B * plan.nseg, plan, pcm, B, L, T, tabs, erb_bm, c0, c1, spec, e0, e1, clk, dc);
 }
-void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
-                 FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk) {
-    hipLaunchKernelGGL(k_back, dim3(B), dim3(kFusedThreads), kBackSmemBytes, s, x, e1, e0, spec, c3, c4, erb_bs, tabs, d3, mask, pcm, f32, T,
-                       clk);
+void launch_back(hipStream_t s, int geometry, SegPlan plan, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
+                 FftTabs tabs, int16_t* pcm, float* f32, int B, int T, long long* clk) {
+    ADE_GEO_LAUNCH(k_back, back_smem_bytes, B * plan.nseg, plan, x, e1, e0, spec, c3, c4, erb_bs, tabs, pcm, f32, B, T, clk);
 }
-void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B) {
-    if (args.clk) hipLaunchKernelGGL(k_gtcrn_chunk<true>, dim3(B), dim3(kFusedThreads), kChunkSmemBytes, s, args);
-    else hipLaunchKernelGGL(k_gtcrn_chunk<false>, dim3(B), dim3(kFusedThreads), kChunkSmemBytes, s, args);
+void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call) {
+    const int grid = call.B * call.plan.nseg;
+    if (geometry == 1) {
+        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, true>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
+        else hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, false>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
+    } else {
+        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo0, true>), dim3(grid), dim3(Geo0::kThreads), chunk_smem_bytes<Geo0>(), s, call);
+        else hipLaunchKernelGGL((k_gtcrn_chunk<Geo0, false>), dim3(grid), dim3(Geo0::kThreads), chunk_smem_bytes<Geo0>(), s, call);
+    }
 }
 
 }  // namespace ade

@@ -127,36 +127,78 @@ void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f3
                          float f32_scale, bool nan_to_num);
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32);
 
-// ---- per-chunk LDS-resident stage kernels (ade_fused.hip); valid for T <= 64 frames -------------------------
-bool fused_supported(int T);
+// ---- per-chunk LDS-resident stage kernels (ade_fused.hip) ------------------------------------------------------
+// A chunk is walked by one workgroup per SEGMENT of consecutive frames.  Two geometries are compiled from the same stage bodies:
+//   geometry 0: 1024-thread workgroups that own up to 64 frames (152 KB of LDS: one workgroup per CU);
+//   geometry 1:  512-thread workgroups that own up to 32 frames ( 79 KB of LDS: TWO workgroups per CU, so the serial phases of one --
+//                TRA recurrence on one wavefront, inter-frame GRU -- run under the position-parallel phases of the other).
+// Everything in GTCRN is causal along time, so segment k + 1 needs from segment k exactly what the streaming path carries between pushes:
+// the depthwise-convolution history of each GTConvBlock (handed over as PARTIAL SUMS of the first 2 x dilation frames, see gtblock_stage),
+// the six TRA GRU states, the two inter-frame GRU states and the 256-sample overlap-add carry.  They cross in the exchange area below
+// (device memory, one slot per (chunk, segment)), each guarded by one flag word; see dev::xwait for the protocol.
+constexpr int kXHistFrames = 10;                               // 2 x the largest dilation
+constexpr int kXHistFloats = 4 * kXHistFrames * kFw * 4;       // per GTConvBlock: [4 channel quads][10 frames x 33] float4
+constexpr int kXTraOff = 6 * kXHistFloats;                     // [6 blocks][16]
+constexpr int kXInterOff = kXTraOff + 6 * 16;                  // [2 blocks][33 x 16]
+constexpr int kXOlaOff = kXInterOff + 2 * kFw * 16;            // [256]
+constexpr int kXFloats = ((kXOlaOff + kHop + 63) / 64) * 64;
+constexpr int kXFlags = 16;                                    // hist 0-5 | tra 6-11 | inter 12-13 | ola 14
+constexpr int kXFlagHist = 0, kXFlagTra = 6, kXFlagInter = 12, kXFlagOla = 14;
+constexpr int kMaxSegments = 8;
+constexpr int kClkSlotsPerSeg = 64 * 10;
+struct SegPlan {           // how a launch splits its chunks (host-computed, passed by value)
+    int nseg;              // segments per chunk (1: the whole chunk in one workgroup)
+    float* xchg;           // [B][nseg][kXFloats]
+    unsigned* flags;       // [B][nseg][kXFlags], zero between launches
+    int* err;              // sticky: a bounded wait gave up
+};
+struct Seg {               // one workgroup's share (device-side)
+    int t0, nT, T;         // first frame, frames owned, frames of the chunk
+    int prev, next;        // there is a segment before / after this one
+    float* xo;             // exchange slot this segment fills (for the next one)
+    float* xi;             // exchange slot of the previous segment
+    unsigned* fo;          // flags this segment raises
+    unsigned* fi;          // flags of the previous segment (polled, then lowered)
+    int* err;
+};
+int fused_geometries();                       // 2
+int fused_max_frames(int geometry);           // frames one workgroup can own
+bool fused_supported(int T, int geometry);    // T >= 2 and ceil(T / max_frames) <= kMaxSegments
+int fused_segments(int T, int geometry);
 hipError_t fused_init();   // raises the dynamic-LDS limit of the stage kernels (once per process/device)
-void launch_gtblock(hipStream_t s, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk);
-void launch_dpgrnn(hipStream_t s, const float* x, DpW w, float* out, int B, int T, long long* clk);
+void launch_gtblock(hipStream_t s, int geometry, SegPlan plan, int blk, const float* a, const float* skip, GtConvW w, float* out, int B, int T, long long* clk);
+void launch_dpgrnn(hipStream_t s, int geometry, SegPlan plan, int blk, const float* x, DpW w, float* out, int B, int T, long long* clk);
 // front / back stages (ade_stage_frontback.h).  All (B,.,.,16) tensors of the fused path are channel-quad planar:
 // X[b][q][p] = float4(channels 4q..4q+3 of position p).
-void launch_front(hipStream_t s, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
+void launch_front(hipStream_t s, int geometry, SegPlan plan, const int16_t* pcm, int B, int L, int T, FftTabs tabs, BandTab erb_bm, ConvW c0, ConvW c1, float* spec,
                   float* e0, float* e1, long long* clk, const float* dc = nullptr);
-void launch_back(hipStream_t s, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
-                 FftTabs tabs, float* d3, float* mask, int16_t* pcm, float* f32, int B, int T, long long* clk);
+void launch_back(hipStream_t s, int geometry, SegPlan plan, const float* x, const float* e1, const float* e0, const float* spec, ConvW c3, ConvW c4, BandTab erb_bs,
+                 FftTabs tabs, int16_t* pcm, float* f32, int B, int T, long long* clk);
 
-// Everything the single-launch chunk kernel needs (passed by value as the kernel argument block, ~1 KB).
-struct ChunkArgs {
-    const int16_t* pcm_in;
-    int16_t* pcm_out;
-    float* f32_out;          // optional pre-PCM waveform
-    int L, T;
+// What the single-launch chunk kernel needs.  The per-engine part lives in DEVICE memory (uploaded when the workspace is reserved) and is
+// fetched stage by stage through the scalar cache: as a by-value kernel argument its ~250 dwords were all loaded at kernel entry and parked
+// in VGPR lanes for the whole launch (232 SGPR spills at the 128-VGPR ceiling).
+struct ChunkFixed {
     FftTabs tabs;
     BandTab erb_bm, erb_bs;
     ConvW en0, en1, de3, de4;
     GtConvW en_gt[3], de_gt[3];
     DpW dp[2];
-    float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3], *d3, *mask;
-    long long* clk;          // optional phase clocks
-    const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
-    int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late, so that the workgroups do not all hit
-                             // HBM with the same stage's burst at the same instant (ade_set_option "stagger_us")
+    float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3];
 };
-void launch_gtcrn_chunk(hipStream_t s, const ChunkArgs& args, int B);
+struct ChunkCall {           // per call, by value
+    const ChunkFixed* fixed;
+    const int16_t* pcm_in;
+    int16_t* pcm_out;
+    float* f32_out;          // optional pre-PCM waveform
+    const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
+    long long* clk;          // optional phase clocks, kClkSlotsPerSeg per segment
+    int L, T, B;
+    int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all
+                             // hit HBM with the same stage's burst at the same instant; ade_set_option "stagger_us")
+    SegPlan plan;
+};
+void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call);
 
 // ---- a tensor of the parsed ADEWGT01 weight blob (host memory, owned by the engine while it is being built)
 struct Tensor {

@@ -27,9 +27,7 @@ namespace ade {
 namespace stage {
 
 constexpr int kWbuf = 264;            // float2 slots of one wave's FFT / spectrum buffer (257 used)
-constexpr int kTileF = 16;            // frames per tile = wavefronts per workgroup
-constexpr int kTileP1 = kTileF * kF1; // 1040 positions of width 65
-constexpr int kTileP = kTileF * kFw;  // 528 positions of width 33
+// frames per tile = wavefronts per workgroup (G::kTileF: 16 / 8); a tile has kTileF * 65 positions of width 65, kTileF * 33 of width 33
 constexpr size_t kTabFloats = 512 + 2 * 256 + 2 * 264;   // window | tw256 | tw512 staged in LDS
 constexpr int kBmCap = 16;            // ERB-merge band rows kept in LDS (wider band tables are read from L2)
 constexpr int kBsCap = 4;             // ERB-split band rows kept in LDS
@@ -45,7 +43,9 @@ __device__ __forceinline__ float2 rfft_bin(float2 zk, float2 zp, float2 w) {
 
 // copy the FFT tables into LDS (L2 is ~1 us away per dependent load); returns LDS-resident views
 struct LdsTabs { const float* win; const float2* tw256; const float2* tw512; };
+template <class G>
 __device__ __forceinline__ LdsTabs stage_tables(float* dst, const FftTabs& t, int tid) {
+    constexpr int kFusedThreads = G::kThreads;
     float* win = dst;
     float* tw256 = dst + 512;
     float* tw512 = tw256 + 512;
@@ -92,18 +92,27 @@ __device__ __forceinline__ void erb_merge(const float* wtab, int count, int s0, 
 // ---------------------------------------------------------------------------------------------------------------
 // FRONT.  LDS (floats): wbuf[16][264]x2 | feat[16][3][129] | E0[4][1040]x4 | tabs | ERB band rows | red[16]
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t kFrontFeatFloats = (size_t)kTileF * 3 * kErb;
 constexpr int kC0TailW = 27 * 16;       // conv0 taps k = 0..2 (all 16 output channels): the weights the fo = 64 tail uses
 constexpr int kC1TailW = 3 * 2 * 64;    // conv1 taps k = 0..2
-constexpr size_t kFrontSmemBytes = ((size_t)16 * kWbuf * 2 + kFrontFeatFloats + (size_t)4 * kTileP1 * 4 + kTabFloats +
-                                    (size_t)kBmCap * kErbBands + kC0TailW + kC1TailW + 16) * 4;
+template <class G> constexpr size_t front_smem_bytes() {
+    return ((size_t)G::kTileF * kWbuf * 2 + (size_t)G::kTileF * 3 * kErb + (size_t)4 * G::kTileF * kF1 * 4 + kTabFloats +
+            (size_t)kBmCap * kErbBands + kC0TailW + kC1TailW + 16) * 4;
+}
 
-__device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_t* __restrict__ pcm, int L, int T, const FftTabs& tabs,
+// sg: the workgroup's segment of the chunk -- frames sg.t0 .. sg.t0 + sg.nT - 1; every frame of this stage is independent of the others
+// (the DC mean is over the whole chunk: each segment's workgroup forms the same exact integer sum).
+template <class G>
+__device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& sg, const int16_t* __restrict__ pcm, int L, const FftTabs& tabs,
                                             const BandTab& erb, const ConvW& c0, const ConvW& c1, float* __restrict__ spec,
                                             float* __restrict__ e0, float* __restrict__ e1, long long* __restrict__ clk,
                                             const float* __restrict__ dc_rows = nullptr) {
+    constexpr int kFusedThreads = G::kThreads, kTileF = G::kTileF, kTileP1 = kTileF * kF1;
+    constexpr size_t kFrontFeatFloats = (size_t)kTileF * 3 * kErb;
+    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : 8);      // lanes of output-channel group g: [g * NT / 2, (g + 1) * NT / 2)
+    static_assert(kFusedThreads == 1024 || kFusedThreads == 512, "front / back conv rounds: 64 lanes per frame");
+    const int T = sg.T, tbeg = sg.t0, tend = sg.t0 + sg.nT;
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
-    float* feat = smem + 16 * kWbuf * 2;
+    float* feat = smem + kTileF * kWbuf * 2;
     float4* E0 = reinterpret_cast<float4*>(feat + kFrontFeatFloats);
     float* E0f = reinterpret_cast<float*>(E0);
     float* tabmem = reinterpret_cast<float*>(E0 + 4 * kTileP1);
@@ -122,8 +131,8 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
     ADE_CLK(32);
     const bool pair_ok = ((L & 1) == 0) && ((reinterpret_cast<size_t>(row) & 3) == 0);
     int raw[4];                                            // tile 0's samples: in flight while the mean is computed
-    load_frame_pairs(row, L, wave, lane, wave < T, pair_ok, raw);
-    const LdsTabs lt = stage_tables(tabmem, tabs, tid);
+    load_frame_pairs(row, L, tbeg + wave, lane, tbeg + wave < tend, pair_ok, raw);
+    const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
     const bool erb_lds = erb.count <= kBmCap;
     if (erb_lds)
         for (int i = tid; i < erb.count * kErbBands; i += kFusedThreads) erbw[i] = erb.w[i];
@@ -158,15 +167,15 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
     } else {
         long long tot = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tot += red[i];
+        for (int i = 0; i < kTileF; ++i) tot += red[i];
         dc = (float)((double)tot / ((double)L * 32768.0));
     }
     ADE_CLK(33);
     long long clk_prev = ADE_CLK_START();
     const cfptr c0b = cptr(c0.b), c1b = cptr(c1.b);
 
-    for (int t0 = 0; t0 < T; t0 += kTileF) {
-        const int nf = T - t0 < kTileF ? T - t0 : kTileF;
+    for (int t0 = tbeg; t0 < tend; t0 += kTileF) {
+        const int nf = tend - t0 < kTileF ? tend - t0 : kTileF;
         // ---- F2-F5: one wavefront per frame of the tile
         {
             int tq = tid;
@@ -185,7 +194,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
             }
             {   // the next tile's samples: issued now, consumed after this tile's two conv phases
                 const int tn = t + kTileF;
-                load_frame_pairs(row, L, tn, lane, tn < T, pair_ok, raw);
+                load_frame_pairs(row, L, tn, lane, tn < tend, pair_ok, raw);
             }
             fft256_inplace(v, buf, lane, lt.tw256);
             wave_sync();                                       // last pass's reads are done (buffer is wave-private)
@@ -308,8 +317,8 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);
-            const int g = __builtin_amdgcn_readfirstlane(tq >> 9);     // wavefronts 0-7: group 0, 8-15: group 1
-            const int tl = (tq >> 5) & 15, fo = tq & 31;
+            const int g = __builtin_amdgcn_readfirstlane(tq >> kGroupShift);     // first half of the wavefronts: group 0, second half: group 1
+            const int tl = (tq >> 5) & (kTileF - 1), fo = tq & 31;
             if (tl < nf) {
                 cfptr cw = cptr(c1.w);
                 ADE_KEEP_IN_LOOP(cw);
@@ -367,23 +376,29 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const int16_
 // BACK.  LDS (floats): S[4][528]x4 (reused as the FFT buffers wbuf[16][264]x2) | D[4][1040]x4 | M[16][2][132] |
 //                      acc[512 + 256*15] | tabs | win_sum[256] | ERB-split rows [4][192] | ERB-split starts [192]
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t kBackAccFloats = (size_t)kNfft + (size_t)kHop * (kTileF - 1);
 constexpr int kC3TailW = 2 * 2 * 64;    // deconv3 taps 2 and 4, both groups
 constexpr int kC4TailW = 2 * 16 * 2;    // deconv4 taps 2 and 4
-constexpr size_t kBackSmemBytes = ((size_t)4 * kTileP * 4 + (size_t)4 * kTileP1 * 4 + (size_t)kTileF * 2 * kErbPad + kBackAccFloats +
-                                   kTabFloats + kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW) * 4;
-static_assert((size_t)4 * kTileP * 4 >= (size_t)16 * kWbuf * 2, "the S tile must be able to hold the 16 FFT buffers");
-constexpr int kSUnits = 4 * kTileP;        // float4 slots of one S tile
-constexpr int kSThreads = kSUnits / 3;     // 704 lanes x 3 slots stage a tile
-static_assert(kSThreads * 3 == kSUnits && kSThreads % 64 == 0, "S staging split");
+template <class G> constexpr size_t back_smem_bytes() {
+    return ((size_t)4 * G::kTileF * kFw * 4 + (size_t)4 * G::kTileF * kF1 * 4 + (size_t)G::kTileF * 2 * kErbPad + (size_t)kNfft + (size_t)kHop * (G::kTileF - 1) +
+            kTabFloats + kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW + kHop) * 4;
+}
 
-__device__ __forceinline__ void back_stage(float* smem, int chunk, const float* __restrict__ x, const float* __restrict__ e1,
+// sg: the workgroup's segment.  The overlap-add is the only step that crosses frames: a segment with a successor hands on its last
+// 256 half-finished samples; a segment with a predecessor parks the first hop of its first frame (pend) and finishes those samples at the
+// very end, when the predecessor's carry has arrived -- each sample still gets exactly its two addends (a + b == b + a: bit-exact).
+template <class G>
+__device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg, const float* __restrict__ x, const float* __restrict__ e1,
                                            const float* __restrict__ e0, const float* __restrict__ spec, const ConvW& c3, const ConvW& c4,
-                                           const BandTab& bs, const FftTabs& tabs, float* __restrict__ d3 /*unused: d3 stays in LDS*/,
-                                           float* __restrict__ mask /*unused: the mask stays in LDS*/, int16_t* __restrict__ pcm,
-                                           float* __restrict__ f32, int T, long long* __restrict__ clk) {
-    (void)d3;
-    (void)mask;
+                                           const BandTab& bs, const FftTabs& tabs, int16_t* __restrict__ pcm,
+                                           float* __restrict__ f32, long long* __restrict__ clk) {
+    constexpr int kFusedThreads = G::kThreads, kTileF = G::kTileF, kTileP1 = kTileF * kF1, kTileP = kTileF * kFw;
+    constexpr size_t kBackAccFloats = (size_t)kNfft + (size_t)kHop * (kTileF - 1);
+    static_assert((size_t)4 * kTileP * 4 >= (size_t)kTileF * kWbuf * 2, "the S tile must be able to hold the FFT buffers");
+    constexpr int kSUnits = 4 * kTileP;        // float4 slots of one S tile
+    constexpr int kSThreads = kSUnits / 3;     // 704 (352) lanes x 3 slots stage a tile
+    static_assert(kSThreads * 3 == kSUnits && kSThreads <= kFusedThreads, "S staging split");
+    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : 8);
+    const int T = sg.T, tbeg = sg.t0, tend = sg.t0 + sg.nT;
     float4* S = reinterpret_cast<float4*>(smem);
     float* Sf = smem;
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
@@ -397,6 +412,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     int* bss = reinterpret_cast<int*>(bsw + kBsCap * kErbHigh);
     float* w3t = reinterpret_cast<float*>(bss + kErbHigh);     // tail weights (see front_stage): [tap 2 | tap 4] x [g][ci][co]
     float* w4t = w3t + kC3TailW;                               // [tap 2 | tap 4] x [ci][co]
+    float* pend = w4t + kC4TailW;                              // [256] first hop of a segment that has a predecessor
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
@@ -414,7 +430,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     // issue_s() only starts the loads; commit_s() adds and writes the tile (called one or more compute phases later).
     // Every lane's sa/sb are (re)defined by each issue_s(), so nothing is live across the tile loop's back edge.
     auto issue_s = [&](int t0n, bool go, float4* sa, float4* sb) {
-        const int nfn = T - t0n < kTileF ? T - t0n : kTileF;
+        const int nfn = tend - t0n < kTileF ? tend - t0n : kTileF;
         int tq = tid;
         ADE_OPAQUE_V(tq);
         const bool on = go && tq < kSThreads;
@@ -438,10 +454,10 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     };
     // e0 addends of a tile's deconv3 main round (lane = (group, frame, column m): outputs 2m, 2m+1 of the group's 2 planes)
     auto issue_e0 = [&](int t0n, bool go, float4* ea, float4* eb) {
-        const int nfn = T - t0n < kTileF ? T - t0n : kTileF;
+        const int nfn = tend - t0n < kTileF ? tend - t0n : kTileF;
         int tq = tid;
         ADE_OPAQUE_V(tq);
-        const int g = tq >> 9, tl = (tq >> 5) & 15, m = tq & 31;
+        const int g = tq >> kGroupShift, tl = (tq >> 5) & (kTileF - 1), m = tq & 31;
         const bool on = go && tl < nfn;
         const int pe = on ? tl * kF1 + 2 * m : 0;
 #pragma unroll
@@ -452,10 +468,10 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         }
     };
     float4 sa0[3], sb0[3];
-    issue_s(0, true, sa0, sb0);
+    issue_s(tbeg, true, sa0, sb0);
     float4 ea[2], eb[2];                    // loop-carried: tile k issues tile k+1's (every lane redefines them each time)
-    issue_e0(0, true, ea, eb);
-    const LdsTabs lt = stage_tables(tabmem, tabs, tid);
+    issue_e0(tbeg, true, ea, eb);
+    const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
     for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
     const bool bs_lds = bs.count <= kBsCap;
     if (bs_lds) {
@@ -470,8 +486,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
     commit_s(sa0, sb0);
     long long clk_prev = ADE_CLK_START();
 
-    for (int t0 = 0; t0 < T; t0 += kTileF) {
-        const int nf = T - t0 < kTileF ? T - t0 : kTileF;
+    for (int t0 = tbeg; t0 < tend; t0 += kTileF) {
+        const int nf = tend - t0 < kTileF ? tend - t0 : kTileF;
         // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase three barriers later
         float sre[5], sim[5];
         {
@@ -495,8 +511,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);
-            const int g = __builtin_amdgcn_readfirstlane(tq >> 9);
-            const int tl = (tq >> 5) & 15, m = tq & 31;
+            const int g = __builtin_amdgcn_readfirstlane(tq >> kGroupShift);
+            const int tl = (tq >> 5) & (kTileF - 1), m = tq & 31;
             if (tl < nf) {
                 const int idx = tl * kFw + m, pe = tl * kF1 + 2 * m;
                 cfptr cw = cptr(c3.w);
@@ -558,7 +574,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         // lock-step -- and the request queue back-pressures the issuing wavefronts for about as long as HBM needs to
         // deliver them, wherever in the tile the requests are placed: measured, not assumed.)
         float4 sa[3], sb[3];
-        const bool has_next = t0 + kTileF < T;
+        const bool has_next = t0 + kTileF < tend;
         issue_s(has_next ? t0 + kTileF : t0, has_next, sa, sb);
         issue_e0(has_next ? t0 + kTileF : t0, has_next, ea, eb);
         // ---- ConvTranspose2d(16->2) + BN + Tanh -> mask tile M (LDS)                                   (:516)
@@ -701,6 +717,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
             if (n < 0 || n >= out_len) continue;
             float v[4], ws[4];
             ld4(acc + i, v);
+            if (sg.prev && t0 == tbeg && i < kHop) { st4(pend + i, v); continue; }   // waits for the predecessor's carry (below)
             ld4(wsum + (i & (kHop - 1)), ws);
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = v[u] / ws[u];
@@ -718,11 +735,39 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const float* 
         {
             float carry = 0.0f;
             if (tf < kHop) carry = acc[kHop * nf + tf];
+            if (sg.next && !has_next && tf < kHop) xst1(sg.xo + kXOlaOff + tf, carry);     // the last tile's carry belongs to the next segment
             __syncthreads();
             for (int i = tf; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = i < kHop ? carry : 0.0f;
         }
         // (the barrier at the top of the next tile orders these writes, and commit_s(), before their readers)
         ADE_CLK_ACC(61);
+    }
+    if (sg.next) {
+        xdrain();
+        __syncthreads();
+        if (tid == 0) xflag_store(sg.fo + kXFlagOla, 1u);
+    }
+    if (sg.prev) {   // the first hop of this segment: pend + the predecessor's carry, then the same tail as above
+        if (tid == 0) xwait(sg.fi + kXFlagOla, sg.err);
+        __syncthreads();
+        int tf = tid;
+        ADE_OPAQUE_V(tf);
+        for (int i4 = tf; i4 < kHop / 4; i4 += kFusedThreads) {
+            const int i = i4 * 4;
+            const int n = kHop * tbeg + i - kHop;
+            float v[4], ws[4];
+            ld4(pend + i, v);
+            ld4(wsum + i, ws);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (xld1(sg.xi + kXOlaOff + i + u) + v[u]) / ws[u];
+            if (fo32) st4(fo32 + n, v);
+            if (po) {
+                short q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = (short)(int)fminf(fmaxf(v[u] * 32767.0f, -32768.0f), 32767.0f);
+                *reinterpret_cast<short4*>(po + n) = make_short4(q[0], q[1], q[2], q[3]);
+            }
+        }
     }
     ADE_CLK(53);
 }

@@ -21,10 +21,22 @@ namespace stage {
 using namespace dev;
 
 
-constexpr int kTmaxFused = 64;
-constexpr int kPmax = kTmaxFused * kFw;   // 2112 positions
-constexpr int kFusedThreads = 1024;
-constexpr int kPosPerThread = 3;          // ceil(2112 / 1024)
+// Geometry of a workgroup: NT threads own up to TMAX consecutive frames of a chunk (see ade_internal.h: two geometries are compiled).
+template <int NT, int TMAX, int WAVES_PER_SIMD>
+struct Geo {
+    static constexpr int kThreads = NT;
+    static constexpr int kWavesPerSimd = WAVES_PER_SIMD;          // __launch_bounds__ second argument: workgroups per CU x NT / 256
+    static constexpr int kTmax = TMAX;
+    static constexpr int kPmax = TMAX * kFw;                      // positions of the LDS-resident activation
+    static constexpr int kPosPerThread = (kPmax + NT - 1) / NT;   // 3 for both geometries
+    static constexpr int kTileF = NT / 64;                        // frames per front / back tile = wavefronts per workgroup
+    static constexpr int kProdBase = ((TMAX * (kFw / 3) + 63) / 64) * 64;   // first lane of the wavefronts that are idle in the conv phases
+    static constexpr int kInterCols = NT >= kFw * 16 ? 64 : 17;   // F columns per pass of the inter-frame GRU (16 lanes per column)
+    static_assert(kPosPerThread == 3, "the conv phases are written for three positions per lane");
+    static_assert(kProdBase + 2 * 5 * (kFw / 3) <= NT, "the history producers need 110 lanes outside the conv lanes");
+};
+typedef Geo<1024, 64, 4> Geo0;     // one workgroup per CU
+typedef Geo<512, 32, 4> Geo1;      // two workgroups per CU (4 waves per SIMD = 2 x 512 / 256)
 
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
@@ -50,7 +62,7 @@ __device__ __forceinline__ void pl_st16(float* Xc, int P, int p, const float* v)
 //   in : a (+ skip), quad-planar (B,4,P,4) ;  out: same layout = interleave(h1 * at, bypass)
 // LDS: H[4][kPmax] float4 | zt[64][8] | at[64][8] ; GI[64][48] and HS[64][16] alias H planes 2-3 after phase 2.
 // ---------------------------------------------------------------------------------------------------------
-constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
+template <class G> constexpr size_t gt_smem_bytes() { return (size_t)4 * G::kPmax * 16 + 2 * G::kTmax * 8 * 4; }
 
 #define ADE_REP16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
@@ -63,21 +75,32 @@ constexpr size_t kGtSmemBytes = (size_t)4 * kPmax * 16 + 2 * kTmaxFused * 8 * 4;
 
 // x1_in_lds : the previous stage of the same launch already left this block's pointwise input (a+skip)[:, :8] in LDS planes 2-3.
 // next_x1   : leave the NEXT GTConvBlock's pointwise input there (out[:, :8] + next_skip[:, :8]); next_skip may be null.
-__device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const float* __restrict__ a, const float* __restrict__ skip,
-                                              const GtConvW& w, float* __restrict__ out, int T, long long* __restrict__ clk,
+// sg / blk  : this workgroup's segment of the chunk and the block's index (0-2 encoder, 3-5 decoder) in the exchange area.  The segment's
+//             frames are LDS-local 0 .. sg.nT-1; the HBM tensors are addressed through bases shifted to the segment's first frame and the
+//             chunk's plane stride Ps.  A segment with a successor hands on (a) the depthwise convolution's history as PARTIAL SUMS: the
+//             successor's first 2 x dilation frames start their accumulators from bias + the taps that reach back into this segment,
+//             added here in the very order a whole-chunk workgroup adds them (so the split is bit-exact), computed by wavefronts that
+//             idle during the conv phases; (b) the TRA GRU state after its last frame.
+template <class G>
+__device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ a, const float* __restrict__ skip,
+                                              const GtConvW& w, float* __restrict__ out, long long* __restrict__ clk,
                                               bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr) {
+    constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* H = smem;
     float* zt = reinterpret_cast<float*>(smem + 4 * kPmax);
     float* at = zt + kTmaxFused * 8;
     float* GI = reinterpret_cast<float*>(smem + 2 * kPmax);
     float* HS = GI + kTmaxFused * 48;
-    const int P = T * kFw;
+    const int T = sg.nT;
+    const int P = T * kFw;                 // positions this workgroup owns
+    const int Ps = sg.T * kFw;             // plane stride of the chunk's HBM tensors
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
-    const float* ac = a + (size_t)chunk * kCh * P;
-    const float* sc = skip ? skip + (size_t)chunk * kCh * P : nullptr;
-    float* oc = out + (size_t)chunk * kCh * P;
+    const size_t cbase = (size_t)chunk * kCh * Ps + (size_t)sg.t0 * kFw * 4;
+    const float* ac = a + cbase;
+    const float* sc = skip ? skip + cbase : nullptr;
+    float* oc = out + cbase;
     const cfptr c_pw1_b = cptr(w.pw1_b), c_dw_b = cptr(w.dw_b), c_pw2_b = cptr(w.pw2_b);
     // Private copies of the weight base pointers: `w` arrives as one 16-dword SGPR tuple, and every use of a member
     // would otherwise restore the whole tuple from its spill lanes (16 v_readlane per weight row).
@@ -94,10 +117,10 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     if (!x1_in_lds) {
         for (int p = tid; p < P; p += kFusedThreads) {
             float x[8];
-            pl_ld8(ac, P, p, 0, x);
+            pl_ld8(ac, Ps, p, 0, x);
             if (sc) {
                 float y[8];
-                pl_ld8(sc, P, p, 0, y);
+                pl_ld8(sc, Ps, p, 0, y);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) x[k] += y[k];
             }
@@ -193,59 +216,104 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             H[3 * kPmax + p0 + i] = make_float4(hi[i][4], hi[i][5], hi[i][6], hi[i][7]);
         }
     }
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagHist + blk, sg.err);     // the previous segment's partial sums (normally long there)
     __syncthreads();
     ADE_CLK(1);
 
     // ---- phase 2: causal dilated depthwise 3x3 + BN + PReLU -> 1x1 (16->8) + BN -> h1 (registers)   (:311-320)
+    // one time tap kt of the depthwise convolution for a lane's three positions: source frame row at LDS position pr
+    auto dw_tap = [&](v2f (&acc)[kPosPerThread][8], const int kt, const int pr, const bool lok, const bool rok) {
+        // weights of (kt, channel quad q): 3 taps x 4 channels; the next quad's are requested after this quad's first FMA
+        v2f wc[3][2], wn[3][2];
+        {
+            cfptr g0 = c_dw + kt * 48;
+            ADE_KEEP_IN_LOOP(g0);
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = mk2(g0[kf * 16], g0[kf * 16 + 1]); wc[kf][1] = mk2(g0[kf * 16 + 2], g0[kf * 16 + 3]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v2f col[5][2];                             // channels 4q..4q+3 of columns f0-1 .. f0+3 at the source frame
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const bool ok = (k != 0 || lok) && (k != 4 || rok);
+                const float4 x = H[q * kPmax + pr - 1 + (ok ? k : 1)];
+                col[k][0] = mk2(ok ? x.x : 0.0f, ok ? x.y : 0.0f);
+                col[k][1] = mk2(ok ? x.z : 0.0f, ok ? x.w : 0.0f);
+            }
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+                for (int i = 0; i < kPosPerThread; ++i) {
+                    acc[i][2 * q] += wc[kf][0] * col[i + kf][0];
+                    if (kf == 0 && i == 0 && q < 3) {
+                        float tok = acc[0][2 * q][0];
+                        cfptr gn = c_dw + kt * 48 + 4 * (q + 1);
+                        ADE_KEEP_AFTER(gn, tok);
+                        acc[0][2 * q][0] = tok;
+#pragma unroll
+                        for (int kk = 0; kk < 3; ++kk) { wn[kk][0] = mk2(gn[kk * 16], gn[kk * 16 + 1]); wn[kk][1] = mk2(gn[kk * 16 + 2], gn[kk * 16 + 3]); }
+                    }
+                    acc[i][2 * q + 1] += wc[kf][1] * col[i + kf][1];
+                }
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = wn[kf][0]; wc[kf][1] = wn[kf][1]; }
+        }
+    };
+    float* const xhist_o = sg.xo + blk * kXHistFloats;
+    if (sg.next && tid >= G::kProdBase) {
+        // History for the NEXT segment, on wavefronts that own no conv lane: lane (t', c) of its first 2 x dilation frames adds, to the
+        // bias, the time taps that land in THIS segment's frames T + t' - (2 - kt) dilation -- kt ascending, exactly the head of the sum
+        // a whole-chunk workgroup forms for that frame.
+        const int u = tid - G::kProdBase;
+        const int tn = u / (kFw / 3), cn = u - tn * (kFw / 3);
+        if (tn < 2 * dilation) {
+            const bool lok = cn != 0, rok = cn != kFw / 3 - 1;
+            v2f acc[kPosPerThread][8];
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int tt = tn - (2 - kt) * dilation;
+                if (tt >= 0) continue;                     // that tap lies in the successor's own frames
+                dw_tap(acc, kt, (T + tt) * kFw + 3 * cn, lok, rok);
+            }
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xst4(xhist_o, (q * kXHistFrames * kFw + tn * kFw + 3 * cn + i) * 4,
+                         make_float4(acc[i][2 * q][0], acc[i][2 * q][1], acc[i][2 * q + 1][0], acc[i][2 * q + 1][1]));
+        }
+        xdrain();                                          // every storing wavefront, ahead of the barrier that precedes the flag
+    }
     float h1r[kPosPerThread][8];
     if (own) {
         const int t = tid / (kFw / 3);
         v2f acc[kPosPerThread][8];
+        if (sg.prev && t < 2 * dilation) {                 // head of the sum: from the previous segment (bias included)
+            const float* xhist_i = sg.xi + blk * kXHistFloats;
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i)
+            for (int i = 0; i < kPosPerThread; ++i)
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = xld4(xhist_i, (q * kXHistFrames * kFw + p0 + i) * 4);
+                    acc[i][2 * q] = mk2(v.x, v.y);
+                    acc[i][2 * q + 1] = mk2(v.z, v.w);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
+        }
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             const int tt = t - (2 - kt) * dilation;
-            if (tt < 0) continue;                          // (per-lane: early frames only; the weights below are indexed by constants)
-            const int pr = p0 - (2 - kt) * dilation * kFw;
-            // weights of (kt, channel quad q): 3 taps x 4 channels; the next quad's are requested after this quad's first FMA
-            v2f wc[3][2], wn[3][2];
-            {
-                cfptr g0 = c_dw + kt * 48;
-                ADE_KEEP_IN_LOOP(g0);
-#pragma unroll
-                for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = mk2(g0[kf * 16], g0[kf * 16 + 1]); wc[kf][1] = mk2(g0[kf * 16 + 2], g0[kf * 16 + 3]); }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v2f col[5][2];                             // channels 4q..4q+3 of columns f0-1 .. f0+3 at frame tt
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const bool ok = (k != 0 || left_ok) && (k != 4 || right_ok);
-                    const float4 x = H[q * kPmax + pr - 1 + (ok ? k : 1)];
-                    col[k][0] = mk2(ok ? x.x : 0.0f, ok ? x.y : 0.0f);
-                    col[k][1] = mk2(ok ? x.z : 0.0f, ok ? x.w : 0.0f);
-                }
-#pragma unroll
-                for (int kf = 0; kf < 3; ++kf)
-#pragma unroll
-                    for (int i = 0; i < kPosPerThread; ++i) {
-                        acc[i][2 * q] += wc[kf][0] * col[i + kf][0];
-                        if (kf == 0 && i == 0 && q < 3) {
-                            float tok = acc[0][2 * q][0];
-                            cfptr gn = c_dw + kt * 48 + 4 * (q + 1);
-                            ADE_KEEP_AFTER(gn, tok);
-                            acc[0][2 * q][0] = tok;
-#pragma unroll
-                            for (int kk = 0; kk < 3; ++kk) { wn[kk][0] = mk2(gn[kk * 16], gn[kk * 16 + 1]); wn[kk][1] = mk2(gn[kk * 16 + 2], gn[kk * 16 + 3]); }
-                        }
-                        acc[i][2 * q + 1] += wc[kf][1] * col[i + kf][1];
-                    }
-#pragma unroll
-                for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = wn[kf][0]; wc[kf][1] = wn[kf][1]; }
-            }
+            if (tt < 0) continue;                          // (per-lane: early frames only; the weights are indexed by constants)
+            dw_tap(acc, kt, p0 - (2 - kt) * dilation * kFw, left_ok, right_ok);
         }
         v2f h2[kPosPerThread][4];
 #pragma unroll
@@ -299,6 +367,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             for (int m = 0; m < 4; ++m) { h1r[i][2 * m] = h2[i][m][0]; h1r[i][2 * m + 1] = h2[i][m][1]; }
     }
     __syncthreads();   // every tap read of H is done: planes may be reused
+    if (sg.next && tid == G::kProdBase) xflag_store(sg.fo + kXFlagHist + blk, 1u);
     ADE_CLK(2);
     if (own) {
 #pragma unroll
@@ -326,14 +395,14 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
     // The next block's skip addend (8 channels per position) is requested HERE, two phases before its use: the compiler
     // drains the vector-memory counter before wave 0 enters the serial recurrence (first use of the weights above), and
     // by then -- after the energy phase -- these HBM loads have landed, so the recurrence does not wait for them.
-    const float* nsc = (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr;
+    const float* nsc = (next_x1 && next_skip) ? next_skip + cbase : nullptr;
     float nsk[kPosPerThread][8];
     auto request_next_skip = [&]() {
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
             const int p = tid + i * kFusedThreads;          // global memory is always walked position-linear (coalesced)
             if (nsc && p < P) {
-                pl_ld8(nsc, P, p, 0, nsk[i]);
+                pl_ld8(nsc, Ps, p, 0, nsk[i]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) nsk[i][k] = 0.0f;
@@ -376,6 +445,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             }
         }
     }
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagTra + blk, sg.err);      // the previous segment's last hidden state
     __syncthreads();
     ADE_CLK(4);
     ADE_CLK(5);
@@ -391,10 +461,10 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
         for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
             float by[8];
-            pl_ld8(ac, P, p, 2, by);
+            pl_ld8(ac, Ps, p, 2, by);
             if (sc) {
                 float y[8];
-                pl_ld8(sc, P, p, 2, y);
+                pl_ld8(sc, Ps, p, 2, y);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) by[k] += y[k];
             }
@@ -410,9 +480,11 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         for (int m = 0; m < 8; ++m) wr[m] = wr_raw[m] * sc;
         const float bh = bh_raw * sc;
         int shb[16];                                                 // h_{t-1} (fp32 bit patterns), wave-uniform
-#pragma unroll
-        for (int k = 0; k < 16; ++k) shb[k] = 0;
         float hv = 0.0f;                                             // h_{t-1}[j] (meaningful in row 3, which computes h_t)
+        if (sg.prev) hv = xld1(sg.xi + kXTraOff + blk * 16 + j);     // the recurrence continues from the previous segment's last frame
+#define ADE_RL(K) shb[K] = __builtin_amdgcn_readlane(__float_as_int(hv), K);
+        ADE_REP16(ADE_RL)
+#undef ADE_RL
         float gi = GI[gsel * 16 + j];                                // this row's input projection, fetched one step ahead
         // row 3 stores h_t; the other rows' (meaningless) values go to GI row 0, which is dead once `gi` is loaded --
         // an address select instead of an exec-mask branch in the serial loop
@@ -448,6 +520,11 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
             *hsp = hc;
             hsp += hs_step;
             gi = gnx;
+        }
+        if (sg.next) {                                               // hand the state on: row 3 holds h_T
+            if (row == 3) xst1(sg.xo + kXTraOff + blk * 16 + j, hv);
+            xdrain();
+            if (tid == 48) xflag_store(sg.fo + kXFlagTra + blk, 1u);
         }
     }
     __syncthreads();
@@ -486,7 +563,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
         if (p < P) {
             const float4 b0 = H[p], b1 = H[kPmax + p], g0 = H[2 * kPmax + p], g1 = H[3 * kPmax + p];
             const float o[16] = {g0.x, b0.x, g0.y, b0.y, g0.z, b0.z, g0.w, b0.w, g1.x, b1.x, g1.y, b1.y, g1.z, b1.z, g1.w, b1.w};
-            pl_st16(oc, P, p, o);
+            pl_st16(oc, Ps, p, o);
 #pragma unroll
             for (int k = 0; k < 8; ++k) n8[i][k] = o[k] + nsk[i][k];
         }
@@ -512,14 +589,16 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const flo
 // LDS: R[4][kPmax] float4 (rnn outputs, then mid, then rnn outputs again) | red[kPmax] | stat[2][64].
 // `mid` is parked in the output buffer between the two halves (same thread writes and re-reads it).
 // ---------------------------------------------------------------------------------------------------------
-constexpr size_t kDpSmemBytes = (size_t)4 * kPmax * 16 + (size_t)kPmax * 4 + 2 * kTmaxFused * 4 + (size_t)4 * kFw * kCh * 4;   // + 4 LayerNorm tables
+template <class G> constexpr size_t dp_smem_bytes() { return (size_t)4 * G::kPmax * 16 + (size_t)G::kPmax * 4 + 2 * G::kTmax * 4 + (size_t)4 * kFw * kCh * 4; }   // + 4 LayerNorm tables
 
 // Linear(16,16) on the rnn output of each of this thread's positions, two-pass LayerNorm statistics per frame
 // through LDS, then  y = res + (v - mean) * rstd * gamma + beta.   v/res/y: [kPosPerThread][16] registers.
+template <class G>
 __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* stat, const float* __restrict__ fc,
                                             const float* __restrict__ fc_b, const float* __restrict__ ln_w,
-                                            const float* __restrict__ ln_b, int T, int P, int tid, float (*v)[16],
+                                            const float* __restrict__ ln_b, int T, int P, int Ps, int tid, float (*v)[16],
                                             const float* __restrict__ pre_src = nullptr, float (*pre)[8] = nullptr) {
+    constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     const cfptr c_fc_b = cptr(fc_b);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
@@ -550,7 +629,7 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
         for (int i = 0; i < kPosPerThread; ++i) {
             const int p = tid + i * kFusedThreads;
             if (pre_src && p < P) {
-                pl_ld8(pre_src, P, p, 0, pre[i]);
+                pl_ld8(pre_src, Ps, p, 0, pre[i]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pre[i][k] = 0.0f;
@@ -599,15 +678,20 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
     }
 }
 
-__device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const float* __restrict__ x, const DpW& w, float* __restrict__ out,
-                                             int T, long long* __restrict__ clk, bool next_x1 = false,
+// sg / blk: see gtblock_stage.  The intra-frame GRU and both LayerNorms are per frame; only the inter-frame GRU's hidden state (33 x 16)
+// crosses from a segment to its successor.
+template <class G>
+__device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ x, const DpW& w, float* __restrict__ out,
+                                             long long* __restrict__ clk, bool next_x1 = false,
                                              const float* __restrict__ next_skip = nullptr) {
+    constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
     float* red = reinterpret_cast<float*>(smem + 4 * kPmax);
     float* stat = red + kPmax;
     float* lnt = stat + 2 * kTmaxFused;   // LDS copies of the 4 LayerNorm tables [intra gamma | intra beta | inter gamma | inter beta]
-    const int P = T * kFw;
+    const int T = sg.nT;
+    const int P = T * kFw, Ps = sg.T * kFw;
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
@@ -617,8 +701,9 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
         lnt[2 * kFw * kCh + i] = w.inter_ln_w[i];
         lnt[3 * kFw * kCh + i] = w.inter_ln_b[i];
     }
-    const float* xc = x + (size_t)chunk * kCh * P;
-    float* oc = out + (size_t)chunk * kCh * P;
+    const size_t cbase = (size_t)chunk * kCh * Ps + (size_t)sg.t0 * kFw * 4;
+    const float* xc = x + cbase;
+    float* oc = out + cbase;
 
     ADE_CLK(16);
     // ---- phase A: intra GRNN.  16 lanes per frame: lane = group*8 + dir*4 + unit (== output channel); GRU(8->4)
@@ -653,11 +738,11 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
         // fully unrolled loop lets the scheduler start the (h-independent) input projections early.
         float xq[4][8];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) pl_ld8(xc, P, prow + (dir ? kFw - 1 - d : d), grp * 2, xq[d]);
+        for (int d = 0; d < 3; ++d) pl_ld8(xc, Ps, prow + (dir ? kFw - 1 - d : d), grp * 2, xq[d]);
 #pragma unroll
         for (int s = 0; s < kFw; ++s) {
             const int f = dir ? kFw - 1 - s : s;
-            if (s + 3 < kFw) pl_ld8(xc, P, prow + (dir ? f - 3 : f + 3), grp * 2, xq[(s + 3) & 3]);
+            if (s + 3 < kFw) pl_ld8(xc, Ps, prow + (dir ? f - 3 : f + 3), grp * 2, xq[(s + 3) & 3]);
             const float* xv = xq[s & 3];
             v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
 #pragma unroll
@@ -683,22 +768,23 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     //      (mid is parked in `out` -- L2-resident, re-read by the same thread in phase D -- instead of 48 live VGPRs)
     {
         float mid[kPosPerThread][16];
-        fc_ln_phase(R, red, stat, w.intra_fc, w.intra_fc_b, lnt, lnt + kFw * kCh, T, P, tid, mid);
+        fc_ln_phase<G>(R, red, stat, w.intra_fc, w.intra_fc_b, lnt, lnt + kFw * kCh, T, P, Ps, tid, mid);
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
             const int p = tid + i * kFusedThreads;
             if (p < P) {
                 float xr[16];
-                pl_ld16(xc, P, p, xr);
+                pl_ld16(xc, Ps, p, xr);
 #pragma unroll
                 for (int co = 0; co < 16; ++co) mid[i][co] += xr[co];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     R[q * kPmax + p] = make_float4(mid[i][4 * q], mid[i][4 * q + 1], mid[i][4 * q + 2], mid[i][4 * q + 3]);
-                pl_st16(oc, P, p, mid[i]);
+                pl_st16(oc, Ps, p, mid[i]);
             }
         }
     }
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagInter + blk, sg.err);    // the previous segment's inter-frame GRU state
     __syncthreads();
     ADE_CLK(18);
     // ---- phase C: inter GRNN.  16 lanes per F column: lane = 2*unit + group; GRU(8->8) along T, in place in R
@@ -707,11 +793,14 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
     //      one packed accumulator, the n gate packed over input pairs, and the 8 hidden values of a lane's own group
     //      fetched with 7 row rotations by 2s (group in the lane's low bit => a rotation by 2s stays inside the group);
     //      each lane keeps its recurrent weights pre-rotated to match.
-    if (tid < ((kFw * 16 + 63) / 64) * 64) {
-        const int f = tid >> 4, q = tid & 15;
+    //      A workgroup with fewer than 33 x 16 lanes walks the columns in passes of G::kInterCols.
+#pragma unroll 1
+    for (int fb = 0; fb < kFw; fb += G::kInterCols)
+    if (tid < (((kFw - fb < G::kInterCols ? kFw - fb : G::kInterCols) * 16 + 63) / 64) * 64) {
+        const int f = fb + (tid >> 4), q = tid & 15;
         const int grp = q & 1, unit = q >> 1;
-        const bool live = f < kFw;
-        const int fc_ = live ? f : kFw - 1;
+        const bool live = f < kFw && (tid >> 4) < G::kInterCols;     // (lanes that only fill up the last wavefront of a pass recompute a column and drop it)
+        const int fc_ = f < kFw ? f : kFw - 1;
         const float* pk = w.inter_gru + (grp * 8 + unit) * 54;      // [W_ih 3x8 | W_hh 3x8 | b_ih 3 | b_hh 3] of this output row
         int ks[8];                                                   // ks[s] = hidden index delivered by rotation s (measured, so the
         ks[0] = unit;                                                // rotation direction convention cannot matter)
@@ -733,6 +822,8 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
         const v2f b_rz = mk2((pk[48] + pk[51]) * kS, (pk[49] + pk[52]) * kS);
         const float bi_n = pk[50] * kN, bh_n = pk[53] * kN;
         float h = 0.0f;
+        float* const xin = sg.xi + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q;
+        if (sg.prev) h = xld1(xin);                                  // the recurrence continues from the previous segment's last frame
         float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
         for (int t = 0; t < T; ++t) {
             const int p = t * kFw + fc_;
@@ -762,23 +853,28 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const floa
             h = n + z * (h - n);
             if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
         }
+        if (sg.next) {
+            if (live) xst1(sg.xo + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q, h);
+            xdrain();
+        }
     }
     __syncthreads();
+    if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagInter + blk, 1u);
     ADE_CLK(19);
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
     float y[kPosPerThread][16];
     float nsk[kPosPerThread][8];       // the following GTConvBlock's skip addend (zero when there is none)
-    fc_ln_phase(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, tid, y,
-                (next_x1 && next_skip) ? next_skip + (size_t)chunk * kCh * P : nullptr, nsk);
+    fc_ln_phase<G>(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, Ps, tid, y,
+                   (next_x1 && next_skip) ? next_skip + cbase : nullptr, nsk);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {
         const int p = tid + i * kFusedThreads;
         if (p < P) {
             float m[16];
-            pl_ld16(oc, P, p, m);     // mid, written by this same thread in phase B
+            pl_ld16(oc, Ps, p, m);     // mid, written by this same thread in phase B
 #pragma unroll
             for (int co = 0; co < 16; ++co) y[i][co] += m[co];
-            pl_st16(oc, P, p, y[i]);
+            pl_st16(oc, Ps, p, y[i]);
             if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (R is dead)
                 float n8[8];
 #pragma unroll
