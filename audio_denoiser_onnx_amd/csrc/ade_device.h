@@ -151,6 +151,16 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r[0] = a; r[1] = b
 #else
 #define ADE_OPAQUE_V(x) ((void)0)
 #endif
+// A plain-data struct fetched through the constant address space (scalar loads), dword by dword: C++ has no copy constructor across address spaces.
+template <class T>
+__device__ __forceinline__ T cload(const void ADE_CONSTANT_AS* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized structs only");
+    union U { T v; unsigned w[sizeof(T) / 4]; __device__ U() {} } u;
+    const unsigned ADE_CONSTANT_AS* s = (const unsigned ADE_CONSTANT_AS*)p;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) u.w[i] = s[i];
+    return u.v;
+}
 typedef const float ADE_CONSTANT_AS* cfptr;
 __device__ __forceinline__ cfptr cptr(const float* p) { return (cfptr)p; }
 

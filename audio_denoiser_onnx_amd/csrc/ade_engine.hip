@@ -100,6 +100,8 @@ struct ade_engine {
     float* h_f32_out = nullptr;
 
     int stagger_ticks = 2750;             // 27.5 us, applied when a launch has enough chunks to load the memory system (see enqueue; geometry 0 only)
+    int wave_swap = 0;                    // option "wave_swap": odd segments run their conv lanes on wavefronts 0-3, 6, 7 (measured neutral to -1 %: off)
+    int seg_prio = 0;                     // wave priority of later segments' workgroups (option "seg_prio", 0-3)
     int geometry = -1;                    // fused-path workgroup geometry (ade_internal.h): -1 = choose per call, 0 = 1024 threads x 64 frames, 1 = 512 x 32
     ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
     float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
@@ -582,7 +584,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     if (fused) {
         // ---- fused path: one workgroup per chunk SEGMENT per stage (ade_internal.h: geometries), activations LDS-resident, inter-stage
         //      tensors channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  1 launch, or 10.
-        const SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr};
+        const SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr, e->wave_swap};
         e->last_geometry = geo;
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
@@ -599,6 +601,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             C.stagger = (geo == 0 && B >= 192) ? e->stagger_ticks : 0;
             C.pcm_in = d_in; C.pcm_out = d_out; C.f32_out = d_f32; C.L = e->in_len; C.T = T; C.B = B;
             C.plan = plan;
+            C.seg_prio = e->seg_prio;
             C.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
             q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, geo, C); q.end();
             return;
@@ -1160,6 +1163,17 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         h->stagger_ticks = (int)(us * 100.0 + 0.5);
         return ADE_OK;
     }
+    if (strcmp(key, "wave_swap") == 0) {
+        bool b;
+        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, "option wave_swap must be 0/1");
+        h->wave_swap = b;
+        return ADE_OK;
+    }
+    if (strcmp(key, "seg_prio") == 0) {        // s_setprio level of the workgroups that own a later segment of a chunk (0-3)
+        if (value[0] < '0' || value[0] > '3' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option seg_prio: 0..3");
+        h->seg_prio = value[0] - '0';
+        return ADE_OK;
+    }
     if (strcmp(key, "geometry") == 0) {        // fused-path workgroup geometry: "auto", "0" (1024 threads x 64 frames), "1" (512 x 32, two per CU)
         int g = -2;
         if (strcmp(value, "auto") == 0) g = -1;
@@ -1315,6 +1329,13 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         HIP_TRY(h, hipMemcpy(raw, h->d_clk, n * sizeof(long long), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) out[i] = raw[i] ? (float)(raw[i] - raw[32]) : -1.0f;
         *written = n;
+        return ADE_OK;
+    }
+    if (strcmp(name, "fused_geometry") == 0) {    // [geometry of the last fused call (-1: none), workgroups per chunk]
+        if (count < 1) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+        out[0] = h->last_fused ? (float)h->last_geometry : -1.0f;
+        if (count > 1) out[1] = h->last_fused ? (float)fused_segments(h->T, h->last_geometry) : 0.0f;
+        *written = count > 1 ? 2 : 1;
         return ADE_OK;
     }
     if (strcmp(name, "xchg_error") == 0) {        // 1 after a bounded inter-workgroup wait of the segmented fused path gave up (sticky)

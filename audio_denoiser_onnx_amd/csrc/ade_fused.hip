@@ -39,6 +39,7 @@ __device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int b
     sg.t0 = seg * base + (seg < rem ? seg : rem);
     sg.prev = seg > 0;
     sg.next = seg + 1 < plan.nseg;
+    sg.swap = plan.wave_swap && (seg & 1);
     const size_t slot = (size_t)chunk * plan.nseg + seg;
     sg.xo = plan.xchg + slot * kXFloats;
     sg.xi = plan.xchg + (slot - (seg > 0 ? 1 : 0)) * kXFloats;
@@ -91,71 +92,87 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_back(SegPlan 
 // workgroup stamping phase clocks into C.clk, 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back], one such set per segment.
 // The per-engine arguments (weights, workspace) are read from device memory stage by stage: ChunkFixed in ade_internal.h.
 template <class G, bool kClk>
-__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(ChunkCall C) {
+__global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(ChunkCall C_) {
     HIP_DYNAMIC_SHARED(float4, smem)
-    int chunk;
-    const Seg sg = make_seg(C.plan, C.B, C.T, blockIdx.x, chunk);
-    long long* const clk0 = kClk ? seg_clk(C.clk, sg, C.B, blockIdx.x) : nullptr;
     float* fsm = reinterpret_cast<float*>(smem);
     typedef const ChunkFixed ADE_CONSTANT_AS* fixed_ptr;
-    fixed_ptr F = (fixed_ptr)C.fixed;
-    // De-phase the workgroups (geometry 0: one workgroup per CU).  Every stage begins and ends with an HBM burst (its inputs / skip tensors
-    // in, its output out) and at 256 chunks all 256 workgroups would issue the same burst at the same instant: measured, the stages run 28 %
-    // slower at 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one GTConvBlock makes
-    // one half's bursts land in the other half's compute phases (tools/stagger_probe.py).  With two workgroups per CU (geometry 1) the
-    // segments of a chunk are out of phase by construction.
-    if (C.stagger > 0 && ((chunk >> 3) & 1)) {
-        const long long t0 = wall_clock64();                 // 100 MHz, independent of the shader clock
-        while (wall_clock64() - t0 < C.stagger) __builtin_amdgcn_s_sleep(8);
-    }
+    typedef const ChunkCall ADE_CONSTANT_AS* call_ptr;
+    // Nothing but the block index stays live from one stage to the next: every stage re-reads what it needs of the call (kernel-argument
+    // segment) and of the per-engine block (device memory) through the scalar cache and re-derives its segment.  Held in registers across
+    // the whole launch, those ~60 scalars were parked in VGPR lanes at every stage boundary.
+#if defined(__AMDGCN__)
+    call_ptr C = (call_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    call_ptr C = (call_ptr)&C_;
+#endif
+    int block = blockIdx.x;
+#define ADE_STAGE_ENTRY()                                                                                  \
+    ADE_KEEP_IN_LOOP(C);                                                                                   \
+    ADE_KEEP_IN_LOOP(block);                                                                               \
+    int chunk;                                                                                             \
+    const Seg sg = make_seg(cload<SegPlan>(&C->plan), C->B, C->T, block, chunk);                           \
+    fixed_ptr F = (fixed_ptr)C->fixed;                                                                     \
+    long long* const clk0 = kClk ? seg_clk(C->clk, sg, C->B, block) : nullptr;                             \
+    (void)clk0
     {
-        ADE_KEEP_IN_LOOP(F);
-        const FftTabs tabs = F->tabs;
-        const BandTab erb = F->erb_bm;
-        const ConvW c0 = F->en0, c1 = F->en1;
-        front_stage<G>(fsm, chunk, sg, C.pcm_in, C.L, tabs, erb, c0, c1, F->spec, F->e0, F->e1, clk0, C.dc);
+        ADE_STAGE_ENTRY();
+        // A later segment is the younger workgroup on its CU and is served last by the oldest-first instruction arbitration; option
+        // "seg_prio" raises its wave priority (measured: it only swaps which of the two workgroups of a CU is held back).
+        if (sg.prev) {
+            const int pr = C->seg_prio;
+            if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+        }
+        // De-phase the workgroups (geometry 0: one workgroup per CU).  Every stage begins and ends with an HBM burst (its inputs / skip
+        // tensors in, its output out) and at 256 chunks all 256 workgroups would issue the same burst at the same instant: measured, the
+        // stages run 28 % slower at 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one
+        // GTConvBlock makes one half's bursts land in the other half's compute phases (tools/stagger_probe.py).  With two workgroups per
+        // CU (geometry 1) the segments of a chunk are out of phase by construction.
+        const int stagger = C->stagger;
+        if (stagger > 0 && ((chunk >> 3) & 1)) {
+            const long long t0 = wall_clock64();                 // 100 MHz, independent of the shader clock
+            while (wall_clock64() - t0 < stagger) __builtin_amdgcn_s_sleep(8);
+        }
+        const FftTabs tabs = cload<FftTabs>(&F->tabs);
+        const BandTab erb = cload<BandTab>(&F->erb_bm);
+        const ConvW c0 = cload<ConvW>(&F->en0), c1 = cload<ConvW>(&F->en1);
+        front_stage<G>(fsm, chunk, sg, C->pcm_in, C->L, tabs, erb, c0, c1, F->spec, F->e0, F->e1, clk0, C->dc);
     }
     __syncthreads();
-    const float* x;
-    {
-        ADE_KEEP_IN_LOOP(F);
-        x = F->e1;
-    }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // encoder GTConvBlocks
-        ADE_KEEP_IN_LOOP(F);
-        const GtConvW w = F->en_gt[i];
-        float* const o = F->xe[i];
-        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, o, kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
+        ADE_STAGE_ENTRY();
+        const GtConvW w = cload<GtConvW>(&F->en_gt[i]);
+        const float* const x = i == 0 ? F->e1 : F->xe[i > 0 ? i - 1 : 0];
+        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, F->xe[i], kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
         __syncthreads();
-        x = o;
     }
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
-        ADE_KEEP_IN_LOOP(F);
-        const DpW w = F->dp[i];
-        float* const o = F->dpo[i];
-        dpgrnn_stage<G>(smem, chunk, sg, i, x, w, o, kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2]);
+        ADE_STAGE_ENTRY();
+        const DpW w = cload<DpW>(&F->dp[i]);
+        const float* const x = i == 0 ? F->xe[2] : F->dpo[0];
+        dpgrnn_stage<G>(smem, chunk, sg, i, x, w, F->dpo[i], kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2]);
         __syncthreads();
-        x = o;
     }
 #pragma unroll 1
     for (int i = 0; i < 3; ++i) {       // decoder GTConvBlocks on x + en_outs[4 - i]
-        ADE_KEEP_IN_LOOP(F);
-        const GtConvW w = F->de_gt[i];
-        float* const o = F->xd[i];
-        gtblock_stage<G>(smem, chunk, sg, 3 + i, x, F->xe[2 - i], w, o, kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
+        ADE_STAGE_ENTRY();
+        const GtConvW w = cload<GtConvW>(&F->de_gt[i]);
+        const float* const x = i == 0 ? F->dpo[1] : F->xd[i > 0 ? i - 1 : 0];
+        gtblock_stage<G>(smem, chunk, sg, 3 + i, x, F->xe[2 - i], w, F->xd[i], kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
                          /*next_skip=*/i < 2 ? F->xe[1 - i] : nullptr);
         __syncthreads();
-        x = o;
     }
     {
-        ADE_KEEP_IN_LOOP(F);
-        const FftTabs tabs = F->tabs;
-        const BandTab erb = F->erb_bs;
-        const ConvW c3 = F->de3, c4 = F->de4;
-        back_stage<G>(fsm, chunk, sg, x, F->e1, F->e0, F->spec, c3, c4, erb, tabs, C.pcm_out, C.f32_out, kClk ? clk0 + 64 * 9 : nullptr);
+        ADE_STAGE_ENTRY();
+        const FftTabs tabs = cload<FftTabs>(&F->tabs);
+        const BandTab erb = cload<BandTab>(&F->erb_bs);
+        const ConvW c3 = cload<ConvW>(&F->de3), c4 = cload<ConvW>(&F->de4);
+        back_stage<G>(fsm, chunk, sg, F->xd[2], F->e1, F->e0, F->spec, c3, c4, erb, tabs, C->pcm_out, C->f32_out, kClk ? clk0 + 64 * 9 : nullptr);
     }
+#undef ADE_STAGE_ENTRY
 }
 
 template <class G>

@@ -151,10 +151,12 @@ struct SegPlan {           // how a launch splits its chunks (host-computed, pas
     float* xchg;           // [B][nseg][kXFloats]
     unsigned* flags;       // [B][nseg][kXFlags], zero between launches
     int* err;              // sticky: a bounded wait gave up
+    int wave_swap;         // 1: odd segments run their conv lanes on wavefronts 0-3, 6, 7 instead of 0-5 (see gtblock_stage)
 };
 struct Seg {               // one workgroup's share (device-side)
     int t0, nT, T;         // first frame, frames owned, frames of the chunk
     int prev, next;        // there is a segment before / after this one
+    int swap;              // this workgroup permutes its upper wavefronts (SegPlan::wave_swap, odd segments)
     float* xo;             // exchange slot this segment fills (for the next one)
     float* xi;             // exchange slot of the previous segment
     unsigned* fo;          // flags this segment raises
@@ -196,6 +198,7 @@ struct ChunkCall {           // per call, by value
     int L, T, B;
     int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all
                              // hit HBM with the same stage's burst at the same instant; ade_set_option "stagger_us")
+    int seg_prio;            // s_setprio level of the workgroups that own a later segment (0 = leave it)
     SegPlan plan;
 };
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call);

@@ -668,7 +668,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                         }
                     }
                 }
-                float2 y = make_float2(xr * m0 - xi * m1, xi * m0 + xr * m1);                        // (:585-590)
+                // (:585-590; which product of a difference is contracted into the FMA is spelled out, so that every instantiation of this stage rounds alike)
+                float2 y = make_float2(__fmaf_rn(xr, m0, -(xi * m1)), __fmaf_rn(xi, m0, xr * m1));
                 if (k == 0 || k == 256) y.y = 0.0f;     // the reference's inverse kernel has sin(0) = sin(pi n) = 0 rows
                 buf[k] = y;
             }
@@ -687,17 +688,29 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             fft256_inplace(v, buf, lane, lt.tw256);
             // overlap-add: frames of equal parity never overlap, so even wavefronts add first, odd ones after a barrier
             // (plain, deterministic adds; every sample gets exactly two addends in total)
+            //   (the windowed sample is ROUNDED, then added: a sample's two addends then commute, so the result depends neither on the tile
+            //    size -- which frame of an overlapping pair adds first -- nor on a segment adding its predecessor's carry last: `park` below.
+            //    Left to the compiler's contraction this was a fused multiply-add onto whichever addend happened to be there first.)
+            const bool park = sg.prev && t0 == tbeg && wave == 0;      // first frame of a segment with a predecessor
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
                 if (live && (wave & 1) == par) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int n = lane + 64 * r;
-                        float2* a = reinterpret_cast<float2*>(acc + kHop * wave + 2 * n);
-                        float2 c = *a;
-                        c.x += v[r].x * (1.0f / 256.0f) * lt.win[2 * n];
-                        c.y += -v[r].y * (1.0f / 256.0f) * lt.win[2 * n + 1];
-                        *a = c;
+                        const float pa = v[r].x * (1.0f / 256.0f), pb = -v[r].y * (1.0f / 256.0f);
+                        float wa = pa * lt.win[2 * n], wb = pb * lt.win[2 * n + 1];
+                        ADE_OPAQUE_V(wa);                                    // (the products are final: nothing downstream may re-fuse them)
+                        ADE_OPAQUE_V(wb);
+                        if (park && r < 2) {                                 // first hop: waits in `pend` for the predecessor's carry
+                            *reinterpret_cast<float2*>(pend + 2 * n) = make_float2(wa, wb);
+                        } else {
+                            float2* a = reinterpret_cast<float2*>(acc + kHop * wave + 2 * n);
+                            float2 c = *a;
+                            c.x += wa;
+                            c.y += wb;
+                            *a = c;
+                        }
                     }
                 }
                 __syncthreads();
@@ -717,7 +730,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             if (n < 0 || n >= out_len) continue;
             float v[4], ws[4];
             ld4(acc + i, v);
-            if (sg.prev && t0 == tbeg && i < kHop) { st4(pend + i, v); continue; }   // waits for the predecessor's carry (below)
+            if (sg.prev && t0 == tbeg && i < kHop) continue;      // this hop waits for the predecessor's carry (after the tile loop)
             ld4(wsum + (i & (kHop - 1)), ws);
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = v[u] / ws[u];
@@ -747,7 +760,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         __syncthreads();
         if (tid == 0) xflag_store(sg.fo + kXFlagOla, 1u);
     }
-    if (sg.prev) {   // the first hop of this segment: pend + the predecessor's carry, then the same tail as above
+    if (sg.prev) {   // the first hop of this segment: the parked samples + the predecessor's carry; then the same tail as above
         if (tid == 0) xwait(sg.fi + kXFlagOla, sg.err);
         __syncthreads();
         int tf = tid;

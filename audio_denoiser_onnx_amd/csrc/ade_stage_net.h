@@ -15,6 +15,8 @@
 #pragma once
 #include "ade_device.h"
 
+#include <type_traits>
+
 namespace ade {
 namespace stage {
 
@@ -95,6 +97,10 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     const int P = T * kFw;                 // positions this workgroup owns
     const int Ps = sg.T * kFw;             // plane stride of the chunk's HBM tensors
     int tid_ = threadIdx.x;
+    // The conv phases occupy the first 5.5 of a 512-thread workgroup's 8 wavefronts, i.e. (wavefront w sits on SIMD w % 4) two on SIMDs 0 / 1
+    // and one on SIMDs 2 / 3.  The two workgroups of a CU would both lean on SIMDs 0 / 1: odd segments swap wavefronts 4, 5 with 6, 7 so
+    // that theirs land on SIMDs 2 / 3.  A pure renaming of lanes (whole wavefronts move; every role below is keyed by `tid`).
+    if (kFusedThreads == 512 && sg.swap) tid_ ^= (tid_ & 256) >> 1;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
     const size_t cbase = (size_t)chunk * kCh * Ps + (size_t)sg.t0 * kFw * 4;
@@ -600,28 +606,70 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
                                             const float* __restrict__ pre_src = nullptr, float (*pre)[8] = nullptr) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     const cfptr c_fc_b = cptr(fc_b);
+    {
+        // Linear(16 -> 16) for the lane's three positions TOGETHER: one weight row (16 scalars) serves the three, and the rows are fetched one
+        // ahead of their use, paced by the FMAs (see gtblock_stage phase 1) -- 256 weights requested per position up front do not
+        // fit the scalar file and came back through v_readlane.  Rounds in which this whole wavefront has no position are skipped (wave-uniform).
+        const int nr = __builtin_amdgcn_readfirstlane(((tid & ~63) + 2 * kFusedThreads < P) ? 3 : (((tid & ~63) + kFusedThreads < P) ? 2 : 1));
+        v2f acc[kPosPerThread][8];
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            float r[16];
+        for (int i = 0; i < kPosPerThread; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 x = R[q * kPmax + p];
-                r[4 * q] = x.x; r[4 * q + 1] = x.y; r[4 * q + 2] = x.z; r[4 * q + 3] = x.w;
+            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_fc_b[2 * m], c_fc_b[2 * m + 1]);
+        const cfptr c_fc = cptr(fc);
+        auto rows = [&](auto nrc) {
+            constexpr int NR = decltype(nrc)::value;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {              // input channels 8 half .. 8 half + 7: two LDS planes at a time (24 live inputs, not 48)
+                float r[NR][8];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int p = tid + i * kFusedThreads;
+                    const int pc = p < P ? p : 0;                // (clamped: the value is computed and dropped)
+                    const float4 x0 = R[(2 * half) * kPmax + pc], x1 = R[(2 * half + 1) * kPmax + pc];
+                    r[i][0] = x0.x; r[i][1] = x0.y; r[i][2] = x0.z; r[i][3] = x0.w;
+                    r[i][4] = x1.x; r[i][5] = x1.y; r[i][6] = x1.z; r[i][7] = x1.w;
+                }
+                v2f wc[8], wn[8];                                // one row (16 scalars) in use, the next one in flight
+                {
+                    cfptr g0 = c_fc + half * 128;
+                    ADE_KEEP_IN_LOOP(g0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) wc[m] = mk2(g0[2 * m], g0[2 * m + 1]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                    // row 8 half + k
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int i = 0; i < NR; ++i) {
+                            acc[i][m] += wc[m] * r[i][k];
+                            if (m == 0 && i == 0 && k < 7) {
+                                float tok = acc[0][0][0];
+                                cfptr gn = c_fc + half * 128 + (k + 1) * 16;
+                                ADE_KEEP_AFTER(gn, tok);
+                                acc[0][0][0] = tok;
+#pragma unroll
+                                for (int mm = 0; mm < 8; ++mm) wn[mm] = mk2(gn[2 * mm], gn[2 * mm + 1]);
+                            }
+                        }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) wc[m] = wn[m];
+                }
             }
-            cfptr c_fc = cptr(fc);
-            ADE_KEEP_IN_LOOP(c_fc);
+        };
+        if (nr == 3) rows(std::integral_constant<int, 3>());
+        else if (nr == 2) rows(std::integral_constant<int, 2>());
+        else rows(std::integral_constant<int, 1>());
 #pragma unroll
-            for (int co = 0; co < 16; ++co) v[i][co] = c_fc_b[co];
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-#pragma unroll
-                for (int co = 0; co < 16; ++co) v[i][co] += c_fc[k * 16 + co] * r[k];
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const int p = tid + i * kFusedThreads;
             float s = 0.0f;
 #pragma unroll
+            for (int m = 0; m < 8; ++m) { v[i][2 * m] = acc[i][m][0]; v[i][2 * m + 1] = acc[i][m][1]; }
+#pragma unroll
             for (int co = 0; co < 16; ++co) s += v[i][co];
-            red[p] = s;
+            if (p < P) red[p] = s;
         }
     }
     if (pre) {   // optional prefetch (8 channels per own position, planes 0-1 of pre_src): in flight across the statistics passes

@@ -84,8 +84,49 @@ def parse_args():
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1"],
+                    help="GTCRN fused-path workgroup geometry: 1 = two 512-thread workgroups per CU, each a 32-frame segment of a chunk (default where it fits); "
+                         "0 = one 1024-thread workgroup per chunk (the round-1/2 kernel)")
+    ap.add_argument("--other-steps", type=int, default=3, help="timed steps of the `other_workloads` leg of the default line (ZipEnhancer 128 x 1 s, f32; 0 = skip)")
     ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed power-state ramp before the W warm-up steps (0 = none)")
     return ap.parse_args()
+
+
+def source_sha1() -> str:
+    """Identity of the kernel sources a measurement belongs to (csrc/*.hip, *.h)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", "*.h*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def other_workload_line(name: str, steps: int, local_rank: int, stream):
+    """A short timed run of another BASELINE config inside the default invocation, so that the driver's own clock covers it too (VERDICT r02 #2)."""
+    import torch
+    wl = build_workload(name, 0, 0, local_rank, "f32")
+    sess, B, x = wl["sess"], wl["B"], wl["x"]
+    sess.reserve(B)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty((B, sess.row_out), dtype=torch.int16, device="cuda")
+    sess.run_device(d_in, d_out, stream=stream)            # warm-up (graph capture, clocks)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sess.run_device(d_in, d_out, stream=stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    audio = B * sess.out_len / wl["sr"]
+    tf = wl["flop"] * B / dt / 1e12
+    line = {"workload": wl["workload"], "steps": steps, "warmup": 1, "ms_per_step": round(dt * 1e3, 3), "value": round(audio / dt, 1), "unit": "audio-s/s",
+            "rtf": float(f"{dt / audio:.3e}"), "dtype": "f32", "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                                             "frac": round(tf / FP32_PEAK_TFLOPS, 4)}}
+    if wl.get("target_rtf"):
+        line["target_rtf"] = wl["target_rtf"]
+    del sess
+    return line
 
 
 def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
@@ -237,6 +278,8 @@ def main():
         args.ramp_ms = 0.0
     if args.no_graph:
         sess.set_option("graph", "0")
+    if gtcrn and args.geometry != "auto":
+        sess.set_option("geometry", args.geometry)
     sess.reserve(B)
     d_in = torch.from_numpy(x_host).cuda()
     d_out = torch.empty((B, sess.row_out), dtype=torch.int16, device="cuda")
@@ -304,7 +347,7 @@ def main():
                           "rtf": float(f"{h_ms * 1e-3 / (B * out_seconds_per_row):.3e}"), "steps": hs,
                           "note": "synchronous ade_process on page-locked host buffers: H2D + kernels + D2H per step, one GPU"}
 
-    roofline = cpu = kernels = None
+    roofline = cpu = kernels = others = None
     if rank == 0 and gtcrn:
         # per-kernel device time, HIP events on the launch stream (ade_profile_last), averaged over a few forwards
         def timed(mode, reps=10):
@@ -324,7 +367,11 @@ def main():
         kernels.update({"stage:" + k: {"ms_per_forward": round(v["ms"], 4), "launches": v["launches"]} for k, v in stages.items()})
         dom = max(acc, key=lambda k: acc[k]["ms"])
         macs, nbytes = KERNEL_MODEL[dom]
-        t_launch = acc[dom]["ms"] * 1e-3 / acc[dom]["launches"]
+        t_events = acc[dom]["ms"] * 1e-3 / acc[dom]["launches"]           # HIP events around the launch (profile mode, a synchronise per step)
+        # When the step IS this one kernel, its average launch duration is the timed loop's own step time (K back-to-back launches between the
+        # two synchronise pairs); the event figure is reported beside it.
+        one_kernel_step = len(acc) == 1 and acc[dom]["launches"] == 1
+        t_launch = (elapsed / max(1, args.steps)) if one_kernel_step else t_events
         flops_launch = 2.0 * macs * B / acc[dom]["launches"]
         bytes_launch = float(nbytes) * B / acc[dom]["launches"]
         tf = flops_launch / t_launch / 1e12
@@ -333,7 +380,9 @@ def main():
             roofline = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                         "peak_note": "packed-fp32 VALU peak, 157.3 TFLOP/s (numerically the same as the dense f32-MFMA rate on gfx950); the kernel has no matrix-core work",
-                        "avg_launch_us": round(t_launch * 1e6, 2), "alt_hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+                        "avg_launch_us": round(t_launch * 1e6, 2), "avg_launch_us_events": round(t_events * 1e6, 2),
+                        "avg_launch_from": "the timed loop (K launches back to back)" if one_kernel_step else "HIP events",
+                        "alt_hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(t_launch * 1e6, 2),
@@ -344,7 +393,10 @@ def main():
             with open(os.path.join(REPO, "profiles", "traffic_pmc.json")) as f:
                 tp = json.load(f)
             ent = tp["kernels"].get(dom)
-            if ent:
+            if ent and tp.get("source_sha1") != source_sha1():
+                roofline["traffic_note"] = ("profiles/traffic_pmc.json was measured on another build of csrc/ (" + str(tp.get("build")) + "): not reported; "
+                                            "re-run tools/pmc_traffic.sh")
+            elif ent:
                 roofline["traffic"] = int((2.0 * ent["fetch_kib"] + ent["write_kib"]) * 1024 * B / tp["batch"])
                 roofline["traffic_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
                                             f"({tp['build']}); fabric-side incl. Infinity-Cache hits; algorithmic bytes per launch = "
@@ -359,6 +411,11 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(blob, x_host, args.cpu_seconds)
+        if world == 1 and args.other_steps > 0:
+            try:
+                others = {"zipenhancer": other_workload_line("zipenhancer", args.other_steps, local_rank, stream)}
+            except Exception as ex:   # the headline must not depend on it
+                others = {"zipenhancer": {"error": repr(ex)}}
     elif rank == 0:
         # A GEMM-shaped family is hundreds of launches per step (fp32 matrix-core GEMMs + row kernels), so the roofline object prices the WHOLE
         # step against the dense fp32 matrix rate: achieved = algorithmic flops of the step / the step's device time.  Per-kernel device times and the
@@ -387,6 +444,7 @@ def main():
             cpu = wl["cpu"]()
 
     if rank == 0:
+        geo = sess.tap("fused_geometry", 2) if gtcrn else None
         line = {
             "metric": "audio_seconds_per_second (GTCRN 16 kHz, batch=256 x 1 s chunks; RTF = 1/value)" if gtcrn else wl["metric"],
             "value": round(value, 1),
@@ -405,7 +463,8 @@ def main():
                                     "(BASELINE.json configs[1])") if gtcrn else wl["workload"],
                        "chunks_per_gpu": B, "chunk_samples": sess.in_len, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
                        "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)" if gtcrn else wl["weights"],
-                       "launch": ("one kernel per step (k_gtcrn_chunk), plain launch" if not args.no_graph else "one kernel per step, hipGraph disabled") if gtcrn
+                       "launch": (f"one kernel per step (k_gtcrn_chunk, geometry {int(geo[0])}: {int(geo[1])} workgroup(s) of {1024 if int(geo[0]) == 0 else 512} threads "
+                                  "per chunk), plain launch") if gtcrn
                                  else "the sub-engine's launch sequence (replayed from a captured hipGraph unless --no-graph)",
                        "stitch_all_gather": bool(gathered is not None)},
             "roofline": roofline,
@@ -413,6 +472,8 @@ def main():
             "host_inclusive": host_inclusive,
             "kernels": kernels,
         }
+        if others:
+            line["other_workloads"] = others
         if not gtcrn and wl.get("target_rtf"):
             line["target_rtf"] = wl["target_rtf"]
         if not gtcrn and wl.get("deviation"):

@@ -139,6 +139,7 @@ static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); ret
 static inline int __builtin_amdgcn_readlane(int x, int lane) { return (int)::hipsim::wave_exchange((uint32_t)x, lane); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 // v_mfma_f32_16x16x4_f32: D = A(16x4) B(4x16) + C, operand layout as documented in csrc/ade_device.h; k-ordered fmaf chain.
 typedef float hipsim_v4f __attribute__((vector_size(16)));
 static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim_v4f c, int, int, int) {

@@ -1,0 +1,93 @@
+"""The fused path's chunk SEGMENTS (csrc/ade_internal.h: geometries): a chunk walked by several workgroups, each owning a run of
+consecutive frames and continuing its predecessor's recurrences, must give the very bits a single workgroup gives.
+
+CPU part (host simulator, test-only build of the same csrc/*.hip): data flow of the hand-offs -- depthwise-convolution partial sums, TRA and
+inter-frame GRU states, overlap-add carry -- for 2, 3 and 4 segments.  GPU part: the same on the MI355X at the benchmark batch (every CU holds two
+workgroups that exchange through device memory), with more workgroups than the chip holds at once, and the sticky time-out word."""
+import numpy as np
+import pytest
+
+from ade_testlib import golden_blob, golden_inputs, hipsim_library, make_session
+from audio_denoiser_onnx_amd.synth import synth_batch
+from oracle_lib import GtcrnOracle
+
+TAPS = ("spec", "e0", "e1", "x_e2", "x_e3", "x_e4", "dp1", "dp2", "x_d0", "x_d1", "x_d2")
+
+
+def run(sess, x, geometry, single="1"):
+    sess.set_option("geometry", geometry)
+    sess.set_option("single_launch", single)
+    pcm, f32 = sess.process(x, want_f32=True)
+    taps = {n: sess.tap(n, x.shape[0] * sess.frames * 65 * 16).copy() for n in TAPS}
+    assert sess.tap("xchg_error", 1)[0] == 0.0
+    return pcm, f32, taps
+
+
+def assert_same(a, b, what):
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f"{what}: output differs, max |d f32| = {np.abs(a[1] - b[1]).max():.3g}"
+    for n in TAPS:
+        assert np.array_equal(a[2][n], b[2][n]), f"{what}: tap {n} differs"
+
+
+@pytest.mark.hipsim
+def test_hipsim_two_segments_equal_one_workgroup():
+    """T = 63: geometry 1 = 32 + 31 frames on two 512-thread workgroups; geometry 0 = one 1024-thread workgroup."""
+    lib = hipsim_library()
+    ins = golden_inputs()
+    x = np.stack([ins["wav0"], ins["randn"]])
+    sess = make_session(lib, seed=0)
+    whole = run(sess, x, "0")
+    assert_same(whole, run(sess, x, "1"), "two segments, one launch")
+    assert_same(whole, run(sess, x, "1", single="0"), "two segments, one launch per stage")
+    opcm, of32 = GtcrnOracle(golden_blob(0), 16000).process(x)
+    assert np.abs(whole[1] - of32).max() <= 1e-4 and np.abs(whole[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.hipsim
+@pytest.mark.parametrize("length", [16384, 32000])
+def test_hipsim_three_and_four_segments_vs_oracle(length):
+    """T = 65 -> 22 + 22 + 21 frames (geometry 1) / 33 + 32 (geometry 0); T = 126 -> 4 x 32 / 2 x 63: bit-equal to each other, and the oracle's."""
+    lib = hipsim_library()
+    x = synth_batch(1, length)
+    sess = make_session(lib, seed=2, length=length)
+    a, b = run(sess, x, "0"), run(sess, x, "1")
+    assert_same(a, b, f"length {length}")
+    opcm, of32 = GtcrnOracle(golden_blob(2), length).process(x)
+    assert np.abs(a[1] - of32).max() <= 1e-4 and np.abs(a[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_gpu_segments_bit_equal_at_benchmark_batch():
+    """256 x 1 s: geometry 1 (512 workgroups, two per CU, hand-offs through device memory) == geometry 0 (one workgroup per chunk), every tap."""
+    x = synth_batch(256)
+    sess = make_session(None, seed=0)
+    whole = run(sess, x, "0")
+    for rep in range(3):                                   # the hand-offs race differently every launch
+        assert_same(whole, run(sess, x, "1"), f"256 chunks, launch {rep}")
+    assert_same(whole, run(sess, x, "1", single="0"), "256 chunks, one launch per stage")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3, 300, 700])
+def test_gpu_segments_more_workgroups_than_the_chip_holds(batch):
+    """600 / 1400 workgroups on 512 slots: later segments start while earlier chunks are still running, or long after their predecessor ended."""
+    x = synth_batch(batch)
+    sess = make_session(None, seed=1)
+    assert_same(run(sess, x, "0"), run(sess, x, "1"), f"batch {batch}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("length", [16384, 20000, 32000, 60000])
+def test_gpu_three_to_eight_segments(length):
+    """T = 65, 79, 126, 235 frames: 3, 3, 4, 8 segments of geometry 1 against 2 - 4 segments of geometry 0 and the multi-kernel path."""
+    x = synth_batch(40, length)
+    sess = make_session(None, seed=2, length=length)
+    a, b = run(sess, x, "0"), run(sess, x, "1")
+    assert_same(a, b, f"length {length}")
+    sess.set_option("fused", "0")
+    m_pcm, m_f32 = sess.process(x, want_f32=True)
+    sess.set_option("fused", "1")
+    assert np.abs(a[1] - m_f32).max() <= 2e-5 and np.abs(a[0].astype(np.int32) - m_pcm.astype(np.int32)).max() <= 1
+    o = GtcrnOracle(golden_blob(2), length)
+    opcm, of32 = o.process(x[:4], threads=4)
+    assert np.abs(a[1][:4] - of32).max() <= 1e-4
