@@ -9,6 +9,10 @@
 
 #include "../../include/ade.h"
 
+#if !defined(HIPSIM)
+#include <dlfcn.h>      // ade_stitch_device opens librccl on first use
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -61,7 +65,7 @@ struct ade_engine {
     bool rs_truncate_i32 = false;
     bool rs_sandwich_out = false;        // Mel-Band: the GTCRN-style output sandwich (interpolate before the PCM scale when down-sampling, after it when up-sampling)
     bool rs_scale_first = false;
-    bool rs_nan_to_num = false;          // torch.nan_to_num / where(isnan, 0) ahead of the PCM tail (ZipEnhancer always; UL-UNAS for float input)
+    int rs_nan_to_num = 0;               // ahead of the PCM tail: 1 = torch.nan_to_num (ZipEnhancer always; UL-UNAS for float input), 2 = where(isnan, 0) only (H-GTCRN keeps its infinities)
     float rs_in_gain = 32768.0f;         // float audio input: normalised samples -> the PCM units the sub-engines read (MossFormer2 is fed as it is: 1)
     float rs_f32_scale = 1.0f;           // the export's F32 / F16 output from the model-rate waveform (2^-15 where that is in PCM units: MossFormer2, ZipEnhancer)
     float *rs_in = nullptr, *rs_out = nullptr;
@@ -73,6 +77,9 @@ struct ade_engine {
     float gt_lerp1 = 0.0f, gt_lerp2 = 0.0f, gt_gain = 1.0f, gt_lerp_out = 0.0f;
     float *gt_tmp = nullptr, *gt_in = nullptr, *gt_wave = nullptr, *gt_mean = nullptr;
     float* d_f32_in = nullptr;                        // staging of ade_process_f32
+    uint16_t *d_f16_in = nullptr, *d_f16_out = nullptr;   // staging of ade_process_f16 (allocated by its first call)
+    uint16_t *h_f16_in = nullptr, *h_f16_out = nullptr;
+    int f16_capacity = 0;
     const float* cur_fin = nullptr;                   // the float input of the call being enqueued (float-input engines)
 
     hipStream_t stream = nullptr;
@@ -442,6 +449,9 @@ void free_workspace(ade_engine* e) {
     if (e->d_xerr) hipHostFree(e->d_xerr);
     e->d_fixed = nullptr; e->d_xchg = nullptr; e->d_xflags = nullptr; e->d_xerr = nullptr;
     for (float** p : {&e->gt_tmp, &e->gt_in, &e->gt_wave, &e->gt_mean, &e->d_f32_in}) { if (*p) hipFree(*p); *p = nullptr; }
+    for (uint16_t** p : {&e->d_f16_in, &e->d_f16_out}) { if (*p) hipFree(*p); *p = nullptr; }
+    for (uint16_t** p : {&e->h_f16_in, &e->h_f16_out}) { if (*p) hipHostFree(*p); *p = nullptr; }
+    e->f16_capacity = 0;
     e->rs_in = e->rs_out = nullptr;
     e->ws = nullptr;
     e->d_pcm_in = e->d_pcm_out = nullptr;
@@ -682,8 +692,11 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
             if (e->cur_fin) launch_resample_in_f32(s, e->cur_fin, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in, e->rs_in_gain);
             else launch_resample_in(s, d_in, e->rs_in, rows_in, e->in_len / e->channels, e->rs_model_in, e->rs_scale_in);
             e->sub->float_in = e->rs_in;
+            e->sub->float_src = e->cur_fin;
+            e->sub->float_src_gain = e->rs_in_gain;
             sub_rc = e->sub->run(s, d_in, B, nullptr, e->rs_out, sub_err);
             e->sub->float_in = nullptr;
+            e->sub->float_src = nullptr;
             if (e->rs_sandwich_out)
                 launch_gt_out(s, e->rs_out, d_out, d_f32, rows_out, e->rs_model_out, e->out_len / (e->out_channels * e->n_outputs), e->rs_scale_out, e->rs_scale_first,
                               e->rs_nan_to_num);
@@ -967,7 +980,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             e->rs_in_gain = fam_moss ? 1.0f : 32768.0f;                 // MossFormer2 normalises its input itself and returns its units (Export_MossFormer2_SS_16K.py:563, 585)
             e->rs_f32_scale = (fam_moss || fam_zip) ? (float)(1.0 / 32768.0) : 1.0f;     // (:655; Export_ZipEnhancer.py:920-922)
         }
-        e->rs_nan_to_num = fam_zip || fam_hg || (fam_ulu && float_in_d);          // (Export_ZipEnhancer.py:913-920; Export_H_GTCRN.py:1056; Export_UL_UNAS.py:906-907)
+        e->rs_nan_to_num = fam_hg ? 2 : ((fam_zip || (fam_ulu && float_in_d)) ? 1 : 0);          // (Export_ZipEnhancer.py:913-920; Export_H_GTCRN.py:1056; Export_UL_UNAS.py:906-907)
         if (rates_differ) {   // F.interpolate(size = ...) on both edges (:562-571, :625-640): source scale = source length / target length
             e->resample = true;
             e->rs_model_in = e->sub->in_len();
@@ -1227,6 +1240,104 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
     h->cur_fin = nullptr;
     if (st != ADE_OK) return st;
     if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+// ---- multi-GPU stitch: one RCCL all-gather of the rank's output rows on the caller's communicator and stream (librccl opened on first use)
+ade_status ade_stitch_device(ade_handle h, const int16_t* d_local, int rows, int16_t* d_all, void* nccl_comm, void* hip_stream) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (rows < 0 || (rows > 0 && (!d_local || !d_all)) || !nccl_comm) return fail(h, ADE_ERR_BAD_VALUE, "ade_stitch_device: bad arguments");
+    if (rows == 0) return ADE_OK;
+#if defined(HIPSIM)
+    (void)hip_stream;
+    return fail(h, ADE_ERR_UNSUPPORTED, "ade_stitch_device: no RCCL under the host simulator");
+#else
+    typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);      // ncclResult_t ncclAllGather(send, recv, count, ncclDataType_t, ncclComm_t, stream)
+    static all_gather_fn all_gather = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) all_gather = reinterpret_cast<all_gather_fn>(dlsym(lib, "ncclAllGather"));
+    }
+    if (!all_gather) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stitch_device: librccl.so / ncclAllGather not found");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)rows * h->out_len * sizeof(int16_t);
+    const int rc = all_gather(d_local, d_all, bytes, /*ncclUint8*/ 1, nccl_comm, hip_stream ? (hipStream_t)hip_stream : h->stream);
+    if (rc != 0) return fail(h, ADE_ERR_DEVICE, "ade_stitch_device: ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ADE_OK;
+#endif
+}
+
+// ---- IEEE-half tensors at the boundary: widen into the fp32 entry's staging, run, narrow the float output
+static ade_status reserve_f16(ade_handle h, int rows) {
+    if (rows <= h->f16_capacity && h->d_f16_out) return ADE_OK;
+    for (uint16_t** p : {&h->d_f16_in, &h->d_f16_out}) { if (*p) hipFree(*p); *p = nullptr; }
+    for (uint16_t** p : {&h->h_f16_in, &h->h_f16_out}) { if (*p) hipHostFree(*p); *p = nullptr; }
+    const size_t cap = (size_t)std::max(rows, h->capacity);
+    HIP_TRY(h, hipMalloc((void**)&h->d_f16_in, cap * h->in_len * sizeof(uint16_t)));
+    HIP_TRY(h, hipMalloc((void**)&h->d_f16_out, cap * h->out_len * sizeof(uint16_t)));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_f16_in, cap * h->in_len * sizeof(uint16_t), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_f16_out, cap * h->out_len * sizeof(uint16_t), hipHostMallocDefault));
+    h->f16_capacity = (int)cap;
+    return ADE_OK;
+}
+
+ade_status ade_process_device_f16(ade_handle h, const void* d_in, int batch, int16_t* d_out, uint16_t* d_f16, void* hip_stream) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device_f16: bad arguments");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rows = batch * h->n_win;
+    ade_status st = reserve(h, rows);
+    if (st != ADE_OK) return st;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    float* f32 = d_f16 ? h->d_f32_out : nullptr;
+    if (h->gt_float_in) {
+        launch_half_to_float(s, static_cast<const uint16_t*>(d_in), h->d_f32_in, (long long)rows * h->in_len);
+        h->cur_fin = h->d_f32_in;
+        st = run(h, s, reinterpret_cast<const int16_t*>(h->d_f32_in), rows, d_out, f32);
+        h->cur_fin = nullptr;
+    } else {
+        st = run(h, s, static_cast<const int16_t*>(d_in), rows, d_out, f32);
+    }
+    if (st != ADE_OK) return st;
+    if (d_f16) launch_float_to_half(s, h->d_f32_out, d_f16, (long long)rows * h->out_len);
+    HIP_TRY(h, hipGetLastError());
+    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    return ADE_OK;
+}
+
+ade_status ade_process_f16(ade_handle h, const void* in, int batch, int16_t* out_pcm, uint16_t* out_f16) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_f16: bad arguments");
+    if (batch == 0) return ADE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rows = batch * h->n_win;
+    ade_status st = reserve(h, rows);
+    if (st != ADE_OK) return st;
+    st = reserve_f16(h, rows);
+    if (st != ADE_OK) return st;
+    const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
+    const void* d_in;
+    if (h->gt_float_in) {
+        memcpy(h->h_f16_in, in, nin * sizeof(uint16_t));
+        HIP_TRY(h, hipMemcpyAsync(h->d_f16_in, h->h_f16_in, nin * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_f16_in;
+    } else {
+        memcpy(h->h_pcm_in, in, nin * sizeof(int16_t));
+        HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in, h->h_pcm_in, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_pcm_in;
+    }
+    st = ade_process_device_f16(h, d_in, batch, out_pcm ? h->d_pcm_out : nullptr, out_f16 ? h->d_f16_out : nullptr, (void*)h->stream);
+    if (st != ADE_OK) return st;
+    if (out_pcm) HIP_TRY(h, hipMemcpyAsync(h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_f16) HIP_TRY(h, hipMemcpyAsync(h->h_f16_out, h->d_f16_out, nout * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_pcm) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
+    if (out_f16) memcpy(out_f16, h->h_f16_out, nout * sizeof(uint16_t));
     return ADE_OK;
 }
 

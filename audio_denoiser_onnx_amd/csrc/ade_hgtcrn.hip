@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_hg_pcm2f(const int16_t* __restrict__ pc
 
 // the resampled entry (:953-970): x = float_in / 32768 - mean.  The mean is that of the tensor the reference centres: the interpolated one when
 // the input rate is above the model rate (mean_src = that float tensor), the caller-rate PCM otherwise (interpolation commutes with the shift).
-__global__ __launch_bounds__(256) void k_hg_mean_f32(const float* __restrict__ x, long long n, float* __restrict__ mean) {
+__global__ __launch_bounds__(256) void k_hg_mean_f32(const float* __restrict__ x, long long n, float* __restrict__ mean, float gain = 1.0f) {
     __shared__ double part[256];
     const float* base = x + (size_t)blockIdx.x * n;
     double s = 0.0;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_hg_mean_f32(const float* __restrict__ x
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int i = 0; i < 256; ++i) tot += part[i];
-        mean[blockIdx.x] = (float)(tot / ((double)n * 32768.0));
+        mean[blockIdx.x] = (float)(tot * (double)gain / ((double)n * 32768.0));
     }
 }
 __global__ __launch_bounds__(256) void k_hg_f2f(const float* __restrict__ in, const float* __restrict__ mean, float* __restrict__ x, int W, int n_win, long long total) {
@@ -692,8 +692,11 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     const int nfr = B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     if (float_in) {
-        if (float_src_len > 0 && float_src_len < W) launch_pcm_mean(s, d_in, batch, 2 * float_src_len, mean, 1);      // upsampled: centred before the interpolation
-        else hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_in, (long long)2 * n_win * W, mean);      // one mean per call (:963-964)
+        if (float_src_len > 0 && float_src_len < W) {      // upsampled: centred before the interpolation, i.e. with the mean of the CALLER-rate samples
+            if (float_src) hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_src, (long long)2 * float_src_len, mean, float_src_gain);   // a float tensor came in: d_in is not PCM
+            else launch_pcm_mean(s, d_in, batch, 2 * float_src_len, mean, 1);
+        }
+        else hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_in, (long long)2 * n_win * W, mean, 1.0f);      // one mean per call (:963-964)
         hipLaunchKernelGGL(k_hg_f2f, flat((long long)B * 2 * W), dim3(256), 0, s, float_in, (const float*)mean, xf, W, n_win, (long long)B * 2 * W);
     } else {
         launch_pcm_mean(s, d_in, batch, 2 * n_win * W, mean, 1);

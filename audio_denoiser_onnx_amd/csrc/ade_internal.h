@@ -121,10 +121,13 @@ void launch_stream_keep(hipStream_t s, const int16_t* concat, int16_t* hist, int
 void launch_stream_concat_flush(hipStream_t s, const int16_t* hist, const int16_t* prev, int16_t* concat, int B);
 // linear resampling of the driver edges (F.interpolate(mode='linear', align_corners=False)); src = scale * (dst + 0.5) - 0.5
 void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long rows, int Lin, int Lout, float scale);
-void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first, bool nan_to_num);
+void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first, int nan_to_num /* 0 off, 1 torch.nan_to_num, 2 NaN -> 0 only */);
 void launch_resample_in_f32(hipStream_t s, const float* in, float* out, long long rows, int Lin, int Lout, float scale, float gain);
 void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32,
-                         float f32_scale, bool nan_to_num);
+                         float f32_scale, int nan_to_num /* 0 off, 1 torch.nan_to_num, 2 NaN -> 0 only */);
+// IEEE half <-> float tensors of the F16 entry points (exact widening; round-to-nearest-even narrowing, as torch's .to(float16))
+void launch_half_to_float(hipStream_t s, const uint16_t* in, float* out, long long n);
+void launch_float_to_half(hipStream_t s, const float* in, uint16_t* out, long long n);
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32);
 
 // ---- per-chunk LDS-resident stage kernels (ade_fused.hip) ------------------------------------------------------
@@ -224,6 +227,8 @@ struct SubEngine {
     // [batch][channels()][in_len()] layout -- instead of d_in (the reference interpolates `audio.float()` before anything else).
     const float* float_in = nullptr;
     int float_src_len = 0;               // samples per channel row of the caller-rate PCM behind float_in (set once by the engine; H-GTCRN's DC mean)
+    const float* float_src = nullptr;    // the caller-rate FLOAT tensor behind float_in when the call came in through a float entry (d_in is then not PCM)
+    float float_src_gain = 1.0f;         // ... times this = int16 units (32768 for normalised samples)
     virtual bool accepts_float_input() const { return false; }
     virtual int n_outputs() const { return 1; }   // output tensors per call; PCM out rows are [batch][n_outputs()][out_channels()][out_len()]
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status

@@ -928,8 +928,12 @@ __device__ __forceinline__ void lerp_coords(int i, int Lin, float scale, int& i0
     i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
     l1 = src - (float)i0;
 }
-__device__ __forceinline__ float nan_to_num_pcm(float v) {      // torch.nan_to_num(nan=0, posinf=32767, neginf=-32768); finite values pass
-    return v != v ? 0.0f : (v > 3.4e38f ? 32767.0f : (v < -3.4e38f ? -32768.0f : v));
+// mode 1: torch.nan_to_num(nan=0, posinf=32767, neginf=-32768); mode 2: torch.where(isnan, 0, x) -- infinities pass (H-GTCRN, Export_H_GTCRN.py:1056).
+// Every finite value passes in both.
+__device__ __forceinline__ float nan_to_num_pcm(float v, int mode) {
+    if (v != v) return 0.0f;
+    if (mode == 1 && __builtin_isinf(v)) return v > 0.0f ? 32767.0f : -32768.0f;
+    return v;
 }
 // float audio tensors (input_audio_dtype F32 / F16): the same edge on normalised floats, times `gain` = what lifts them to the PCM units the sub-engines read (a power of
 // two: it commutes with every rounding of the interpolation, so the reference's scale-then-interpolate and interpolate-only forms are both this)
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void k_resample_out(const float* __restrict__ 
     lerp_coords(i, Lin, scale, i0, i1, l1);
     const float* row = in + r * Lin;
     float y = (1.0f - l1) * row[i0] + l1 * row[i1];
-    if (nan_to_num) y = nan_to_num_pcm(y);
+    if (nan_to_num) y = nan_to_num_pcm(y, nan_to_num);
     if (f32) f32[idx] = y * f32_scale;
     if (pcm) {
         const float v = y * pcm_scale;
@@ -1064,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_gt_out(const float* __restrict__ wave, 
         q = y * 32767.0f;
     }
     if (nan_to_num) {      // torch.nan_to_num(nan=0, posinf=32767, neginf=-32768) before the cast (Export_UL_UNAS.py:906-907, float input only)
-        y = nan_to_num_pcm(y);
+        y = nan_to_num_pcm(y, nan_to_num);
         q = q != q ? 0.0f : q;       // (the clamp below maps the infinities)
     }
     if (f32) f32[idx] = y;
@@ -1102,8 +1106,51 @@ void launch_gt_sandwich_in(hipStream_t s, const int16_t* pcm, const float* fin, 
     hipLaunchKernelGGL(k_row_mean_f32, dim3((unsigned)rows), dim3(256), 0, s, (const float*)tmp, L1, mean);
     hipLaunchKernelGGL(k_gt_in_stage3, grid1((long long)rows * Lm, 256), dim3(256), 0, s, (const float*)tmp, (const float*)mean, out, L1, Lm, lerp2, (long long)rows * Lm);
 }
-void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first, bool nan_to_num) {
-    hipLaunchKernelGGL(k_gt_out, grid1(rows * Lout, 256), dim3(256), 0, s, wave, pcm, f32, Lw, Lout, lerp, scale_first ? 1 : 0, nan_to_num ? 1 : 0, rows * Lout);
+// ---- IEEE half tensors at the ABI (ade_process_f16): bit-level conversions, so that the same source also runs under the host simulator
+__device__ __forceinline__ float half_bits_to_float(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, ex = (h >> 10) & 31u, man = h & 1023u;
+    unsigned u;
+    if (ex == 0) {
+        if (man == 0) u = sign;
+        else {                                           // subnormal: value = man * 2^-24, exact in fp32
+            const float v = (float)man * 5.9604644775390625e-08f;
+            u = sign | (unsigned)__float_as_int(v);
+        }
+    } else if (ex == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((ex + 112u) << 23) | (man << 13);
+    return __int_as_float((int)u);
+}
+__device__ __forceinline__ unsigned float_to_half_bits(float f) {      // round to nearest, ties to even; overflow -> inf; NaN stays NaN
+    const unsigned u = (unsigned)__float_as_int(f);
+    const unsigned sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u);
+    if (a >= 0x477ff000u) return sign | 0x7c00u;                        // >= 65520 rounds to infinity
+    if (a < 0x33000001u) return sign;                                   // <= 2^-25 rounds to zero
+    if (a < 0x38800000u) {                                              // subnormal half: man = round(|f| * 2^24)
+        const float v = __int_as_float((int)a) * 16777216.0f;
+        const float r = v + 12582912.0f;                                // 1.5 * 2^23: rounds v to an integer, ties to even
+        return sign | ((unsigned)__float_as_int(r) & 0x7ffu);
+    }
+    unsigned r = a + 0xfffu + ((a >> 13) & 1u);                         // round the 13 dropped mantissa bits, ties to even
+    return sign | (((r >> 13) - (112u << 10)) & 0x7fffu);
+}
+__global__ __launch_bounds__(256) void k_half_to_float(const uint16_t* __restrict__ in, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = half_bits_to_float(in[i]);
+}
+__global__ __launch_bounds__(256) void k_float_to_half(const float* __restrict__ in, uint16_t* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (uint16_t)float_to_half_bits(in[i]);
+}
+void launch_half_to_float(hipStream_t s, const uint16_t* in, float* out, long long n) {
+    if (n > 0) hipLaunchKernelGGL(k_half_to_float, grid1(n, 256), dim3(256), 0, s, in, out, n);
+}
+void launch_float_to_half(hipStream_t s, const float* in, uint16_t* out, long long n) {
+    if (n > 0) hipLaunchKernelGGL(k_float_to_half, grid1(n, 256), dim3(256), 0, s, in, out, n);
+}
+
+void launch_gt_out(hipStream_t s, const float* wave, int16_t* pcm, float* f32, long long rows, int Lw, int Lout, float lerp, bool scale_first, int nan_to_num) {
+    hipLaunchKernelGGL(k_gt_out, grid1(rows * Lout, 256), dim3(256), 0, s, wave, pcm, f32, Lw, Lout, lerp, scale_first ? 1 : 0, nan_to_num, rows * Lout);
 }
 void launch_gt_sandwich_out(hipStream_t s, const float* frames, FftTabs tabs, int rows, int T, int keep, float* wave, int16_t* pcm, float* f32, int Lout, float lerp,
                             bool scale_first) {
@@ -1159,8 +1206,8 @@ void launch_resample_in(hipStream_t s, const int16_t* in, float* out, long long 
     hipLaunchKernelGGL(k_resample_in, grid1(rows * Lout, 256), dim3(256), 0, s, in, out, Lin, Lout, scale, rows * Lout);
 }
 void launch_resample_out(hipStream_t s, const float* in, int16_t* pcm, float* f32, long long rows, int Lin, int Lout, float scale, float pcm_scale, bool truncate_i32,
-                         float f32_scale, bool nan_to_num) {
-    hipLaunchKernelGGL(k_resample_out, grid1(rows * Lout, 256), dim3(256), 0, s, in, pcm, f32, Lin, Lout, scale, pcm_scale, truncate_i32 ? 1 : 0, f32_scale, nan_to_num ? 1 : 0, rows * Lout);
+                         float f32_scale, int nan_to_num) {
+    hipLaunchKernelGGL(k_resample_out, grid1(rows * Lout, 256), dim3(256), 0, s, in, pcm, f32, Lin, Lout, scale, pcm_scale, truncate_i32 ? 1 : 0, f32_scale, nan_to_num, rows * Lout);
 }
 void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, FftTabs tabs, int B, int T, bool first, int16_t* pcm, float* f32) {
     const long long n = (long long)B * T * (kHop / 4);

@@ -1005,7 +1005,8 @@ template <int MODE, int DT>
 void launch_attn(hipStream_t s, int heads, const float* proj, int ldp, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
     (void)(launch_attn_nt<MODE, 4, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 6, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
            launch_attn_nt<MODE, 7, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 11, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
-           launch_attn_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 20, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv));
+           launch_attn_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 20, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 31, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv));      // 496 keys: the reference's longest un-folded window (3 s = 481 frames) at 124 score registers, 157 KB of LDS
 }
 template <int MODE, int NT, int DT>
 hipError_t raise_one() {
@@ -1017,6 +1018,7 @@ hipError_t raise_attn_lds() {         // the long-window instantiations need mor
     hipError_t e = raise_one<MODE, 11, DT>();
     if (e == hipSuccess) e = raise_one<MODE, 16, DT>();
     if (e == hipSuccess) e = raise_one<MODE, 20, DT>();
+    if (e == hipSuccess) e = raise_one<MODE, 31, DT>();
     return e;
 }
 
@@ -1120,8 +1122,8 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     e->F = (kZF + 2 - 3) / 2 + 1;
     e->dT = (e->T + e->dst - 1) / e->dst;
     e->dF = (e->F + e->dsf - 1) / e->dsf;
-    if (std::max(e->T, e->F) > 320)
-        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: at most 320 frames per window; fold longer audio into windows (use_batch_fold)"));
+    if (std::max(e->T, e->F) > 496)     // the un-folded export reaches INPUT_AUDIO_LENGTH = 48000 -> 481 frames (ZipEnhancer/Export_ZipEnhancer.py:44, :57)
+        return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: at most 496 frames per window; fold longer audio into windows (use_batch_fold)"));
 
     // ---- arena: blob tensors (some repacked), DFT tables, position tables
     std::vector<float> arena;
@@ -1446,7 +1448,9 @@ int ZipEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_
     else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's dense outputs, normalised + PReLU (windows, T, F, 8 C)
     else if (strcmp(name, "nrm") == 0) { src = nrm; n = B * 8 * C * 2; }
     else return zfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
-    if (!src || batch <= 0) return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet (encoder taps are kept for calls of at most 8 windows)");
+    if (!src || batch <= 0)
+        return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet (the encoder snapshots are only carved while the RESERVED capacity is at most 8 windows: "
+                                             "a handle that was ever reserved for more keeps none, whatever the size of the call)");
     if (count < n) return zfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
     ZP_HIP(hipStreamSynchronize(s));
     ZP_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -35,7 +35,9 @@ def main(argv=None) -> int:
     here = Path(__file__).resolve().parent
     noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "speech_with_noise_48k.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_dfsmn.wav"
-    session = InferenceSession(argv[0])
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()
+    session = InferenceSession(argv[0], device_id=local)
     if session.metadata.metadata.get("model_family") != "dfsmn":
         raise ValueError("this driver expects a model_family=dfsmn manifest")
     cfg = runtime_config_from_metadata(session.metadata)
@@ -45,8 +47,11 @@ def main(argv=None) -> int:
     session.reserve(plan_slices(len(audio), session.in_len, session.out_len, out_stride=False)[1])
     fold_active = bool(session.metadata.optional_bool("use_batch_fold", False))      # zeros under batch-fold (:292-295, :300-302)
     t0 = time.time()
-    denoised = denoise(session, audio, tail_pad="zeros" if fold_active else "noise", rng=np.random.default_rng(seed), family="dfsmn")
+    denoised = denoise(session, audio, tail_pad="zeros" if fold_active else "noise", rng=np.random.default_rng(seed), family="dfsmn", rank=rank, world=world)
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])
     duration = len(denoised) / cfg["OUT_SAMPLE_RATE"]
     print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {elapsed / duration:.6f}")

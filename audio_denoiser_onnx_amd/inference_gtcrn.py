@@ -155,7 +155,9 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
     # round(INPUT_AUDIO_LENGTH * scale) samples for such a model (Inference_GTCRN_ONNX.py:300-304), i.e. it only ever keeps that many: slices are stepped by the
     # input length and each slice's output is cut there before the stitch.
     dynamic = bool(getattr(session, "metadata", None) and session.metadata.optional_bool("dynamic_axes", False))
-    keep = min(session.out_len, int(round(session.in_len * out_rate / in_rate))) if dynamic else session.out_len
+    # (a session-like object without rate attributes counts as equal-rate: session_rates() returns 0 for it)
+    ratio = out_rate / in_rate if in_rate > 0 and out_rate > 0 else 1.0
+    keep = min(session.out_len, int(round(session.in_len * ratio))) if dynamic else session.out_len
     slices, _ = cut_slices(audio, session.in_len, session.out_len, tail_pad, rng,
                            out_stride=(not dfsmn) and in_rate == out_rate and not dynamic)
     if world > 1 and not sequential and hasattr(session, "run_device") and not float_io and not dynamic:
@@ -210,7 +212,9 @@ def main(argv=None) -> int:
     noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "gtcrn_mix.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised.wav"
 
-    session = InferenceSession(model)
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()                 # torchrun: one process per GPU; the file's slices are dealt in contiguous blocks, one all-gather stitches them
+    session = InferenceSession(model, device_id=local)
     cfg = runtime_config_from_metadata(session.metadata)
     print(f"\nUsable Providers: {session.get_providers()}")
     print(f"\nTest Input Audio: {noisy}")
@@ -219,8 +223,11 @@ def main(argv=None) -> int:
     print("\nRunning the GTCRN on the MI355X engine.")
     session.reserve(plan_slices(len(audio), session.in_len, session.out_len, cfg["IN_SAMPLE_RATE"] == cfg["OUT_SAMPLE_RATE"])[1])
     t0 = time.time()
-    denoised = denoise_streaming(session, audio, stream_frames) if stream_frames else denoise(session, audio, sequential=sequential)
+    denoised = denoise_streaming(session, audio, stream_frames) if stream_frames else denoise(session, audio, sequential=sequential, rank=rank, world=world)
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     print("Complete: 100.00%")
     (write_wav_int16 if denoised.dtype == np.int16 else write_wav_float32)(out_path, denoised, cfg["OUT_SAMPLE_RATE"])      # PCM_16 / FLOAT (:340)
     duration = len(denoised) / cfg["OUT_SAMPLE_RATE"] if cfg["OUT_SAMPLE_RATE"] > 0 else 0.0

@@ -51,12 +51,13 @@ def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool, out_len: int =
     return np.ascontiguousarray(audio[:, idx].transpose(1, 0, 2))
 
 
-def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool) -> np.ndarray:
+def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool, rank: int = 0, world: int = 1, group=None) -> np.ndarray:
     """(2, n) int16 -> int16 mono of the input's duration at the OUTPUT rate (``int(n * OUT / IN)`` samples, :352):
     every slice of the file in one batched call."""
     in_rate, out_rate = session_rates(session)
     slices = cut_slices(audio, session.in_len, fold_active, session.out_len, in_rate == out_rate)
-    out = session.run(None, {session.get_inputs()[0].name: slices})[0]                     # (n_slices, 1, out_len)
+    from .distributed import run_rows
+    out = run_rows(session, slices, rank, world, group)[0]                                  # (n_slices, 1, out_len)
     n_out = output_length(audio.shape[1], in_rate, out_rate)
     return np.ascontiguousarray(out.reshape(-1)[:n_out])
 
@@ -69,7 +70,9 @@ def main(argv=None) -> int:
     here = Path(__file__).resolve().parent
     noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "h_gtcrn_noisy.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_hgtcrn.wav"
-    session = InferenceSession(argv[0])
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()
+    session = InferenceSession(argv[0], device_id=local)
     if session.metadata.metadata.get("model_family") != "h_gtcrn":
         raise ValueError("this driver expects a model_family=h_gtcrn manifest")
     cfg = runtime_config_from_metadata(session.metadata)
@@ -80,8 +83,11 @@ def main(argv=None) -> int:
     print("\nRunning the H-GTCRN on the MI355X engine.")
     session.reserve(max(1, -(-audio.shape[1] // session.in_len)))
     t0 = time.time()
-    denoised = denoise(session, audio, fold_active)
+    denoised = denoise(session, audio, fold_active, rank, world)
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     write_pcm16(out_path, denoised[None], cfg["OUT_SAMPLE_RATE"])
     duration = denoised.shape[0] / cfg["OUT_SAMPLE_RATE"]
     print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {elapsed / duration:.6f}")

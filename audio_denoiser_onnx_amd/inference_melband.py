@@ -53,13 +53,15 @@ def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool, rng=None) -> n
     return np.ascontiguousarray(audio.reshape(C, n_slices, in_len).transpose(1, 0, 2))
 
 
-def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool, rng=None) -> np.ndarray:
+def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool, rng=None, rank: int = 0, world: int = 1, group=None) -> np.ndarray:
     """(C, n) int16 -> (C, round(n * out_rate / in_rate)) int16: every slice of the file in one batched call.  A dynamic-length export returns more than its input's
     duration (the ISTFT keeps the last frame's tail); the reference driver binds an output of round(INPUT_AUDIO_LENGTH * scale) samples for it (:322-323), so each
     slice's output is cut there before the stitch."""
     slices = cut_slices(audio, session.in_len, fold_active, rng)
-    out = session.run(None, {session.get_inputs()[0].name: slices})[0]                     # (n_slices, C, out_len)
-    scale = session.out_sample_rate / session.in_sample_rate
+    from .distributed import run_rows
+    out = run_rows(session, slices, rank, world, group)[0]                                  # (n_slices, C, out_len); world > 1: each rank runs a block, one all-gather
+    in_rate, out_rate = getattr(session, "in_sample_rate", 0), getattr(session, "out_sample_rate", 0)
+    scale = out_rate / in_rate if in_rate > 0 and out_rate > 0 else 1.0           # (a session-like object without rates counts as equal-rate)
     keep = min(session.out_len, int(round(session.in_len * scale)))
     out = out[:, :, :keep]
     return np.ascontiguousarray(out.transpose(1, 0, 2).reshape(out.shape[1], -1)[:, :int(round(audio.shape[1] * scale))])
@@ -79,7 +81,9 @@ def main(argv=None) -> int:
     here = Path(__file__).resolve().parent
     noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "mel_band_roformer.wav")
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_melband.wav"
-    session = InferenceSession(argv[0])
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()                                                    # torchrun: one process per GPU, slices dealt in blocks (BASELINE configs[3])
+    session = InferenceSession(argv[0], device_id=local)
     if session.metadata.metadata.get("model_family") != "mel_band_roformer":
         raise ValueError("this driver expects a model_family=mel_band_roformer manifest")
     cfg = runtime_config_from_metadata(session.metadata)
@@ -90,8 +94,11 @@ def main(argv=None) -> int:
     print("\nRunning the MelBandRoformer on the MI355X engine.")
     session.reserve(max(1, -(-audio.shape[1] // session.in_len)))
     t0 = time.time()
-    denoised = denoise(session, audio, fold_active, np.random.default_rng(seed))
+    denoised = denoise(session, audio, fold_active, np.random.default_rng(seed), rank, world)
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     write_pcm16(out_path, denoised, cfg["OUT_SAMPLE_RATE"], extensible=True)
     duration = denoised.shape[1] / cfg["OUT_SAMPLE_RATE"]
     print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {elapsed / duration:.6f}")

@@ -40,11 +40,12 @@ def cut_slices(audio: np.ndarray, in_len: int, fold_active: bool, rng=None) -> n
     return np.ascontiguousarray(audio.reshape(n_slices, in_len))
 
 
-def separate(session: InferenceSession, audio: np.ndarray, pad_head: int, fold_active: bool, rng=None):
+def separate(session: InferenceSession, audio: np.ndarray, pad_head: int, fold_active: bool, rng=None, rank: int = 0, world: int = 1, group=None):
     """mono int16 (n,) -> [speaker_0 (n,), speaker_1 (n,)] int16: head padding, one batched call, head drop + trim (:275, :337-338)."""
     padded = np.concatenate((np.zeros(pad_head, audio.dtype), audio))
     slices = cut_slices(padded, session.in_len, fold_active, rng)
-    outs = session.run(None, {session.get_inputs()[0].name: slices[:, None, :]})
+    from .distributed import run_rows
+    outs = run_rows(session, slices[:, None, :], rank, world, group)                     # world > 1: each rank runs a block of slices, one all-gather (both outputs)
     in_rate, out_rate = session_rates(session)
     head_out = output_length(pad_head, in_rate, out_rate, rounded=True)          # pad_head_out, out_audio_len (:308-309)
     end_out = output_length(len(padded), in_rate, out_rate, rounded=True)
@@ -65,7 +66,9 @@ def main(argv=None) -> int:
     here = Path(__file__).resolve().parent
     mix = Path(argv[1]) if len(argv) > 1 else example_audio("separation", "mixed_speech.wav")
     prefix = Path(argv[2]) if len(argv) > 2 else here / "separated"
-    session = InferenceSession(argv[0])
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()                                                  # torchrun: one process per GPU (BASELINE configs[4])
+    session = InferenceSession(argv[0], device_id=local)
     if session.metadata.metadata.get("model_family") != "mossformer2_ss":
         raise ValueError("this driver expects a model_family=mossformer2_ss manifest")
     cfg = runtime_config_from_metadata(session.metadata)
@@ -76,8 +79,11 @@ def main(argv=None) -> int:
     print("\nRunning the MossFormer_SS on the MI355X engine.")
     session.reserve(max(1, -(-(len(audio) + pad_head) // session.in_len)))
     t0 = time.time()
-    spk = separate(session, audio, pad_head, fold_active, np.random.default_rng(seed))
+    spk = separate(session, audio, pad_head, fold_active, np.random.default_rng(seed), rank, world)
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     paths = [Path(f"{prefix}_{i}.wav") for i in range(len(spk))]
     for p, x in zip(paths, spk):
         write_pcm16(p, x, cfg["OUT_SAMPLE_RATE"])

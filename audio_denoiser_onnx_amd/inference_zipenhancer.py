@@ -28,7 +28,9 @@ def main(argv=None) -> int:
     here = Path(__file__).resolve().parent
     noisy = Path(argv[1]) if len(argv) > 1 else example_audio("denoise", "speech_with_noise1.wav")      # Example_Audio.py registry entry "zipenhancer"
     out_path = Path(argv[2]) if len(argv) > 2 else here / "denoised_zipenhancer.wav"
-    session = InferenceSession(argv[0])
+    from .distributed import init_from_env, shutdown
+    rank, world, local = init_from_env()
+    session = InferenceSession(argv[0], device_id=local)
     if session.metadata.metadata.get("model_family") != "zipenhancer":
         raise ValueError("this driver expects a model_family=zipenhancer manifest")
     cfg = runtime_config_from_metadata(session.metadata)
@@ -37,8 +39,11 @@ def main(argv=None) -> int:
     print("\nRunning the ZipEnhancer on the MI355X engine.")
     session.reserve(plan_slices(len(audio), session.in_len, session.out_len, out_stride=False)[1])
     t0 = time.time()
-    denoised = denoise(session, audio, tail_pad="zeros", family="dfsmn")       # input-length stride, rounded output length: the same rules as the DFSMN driver
+    denoised = denoise(session, audio, tail_pad="zeros", family="dfsmn", rank=rank, world=world)       # input-length stride, rounded output length: the same rules as the DFSMN driver
     elapsed = time.time() - t0
+    shutdown()
+    if rank != 0:
+        return 0
     write_wav_int16(out_path, denoised, cfg["OUT_SAMPLE_RATE"])
     duration = len(denoised) / cfg["OUT_SAMPLE_RATE"]
     print(f"\nDenoise Process Complete.\n\nSaving to: {out_path}.\n\nReal-Time Factor (RTF): {elapsed / duration:.6f}")

@@ -85,7 +85,7 @@ class InferenceSession:
         self.in_sample_rate, self.out_sample_rate = io.in_sample_rate, io.out_sample_rate
         self.device_id = io.device
         in_name = "mix_audio" if reader.string("model_family", "") == "mossformer2_ss" else INPUT_NAME        # :688
-        # audio tensor dtypes of the export (Export_GTCRN.py:47-48, 757-760): INT16 PCM, or normalised F32 / F16 (an F16 tensor crosses libade's ABI as fp32)
+        # audio tensor dtypes of the export (Export_GTCRN.py:47-48, 757-760): INT16 PCM, or normalised F32 / F16 (an F16 tensor crosses libade's ABI as IEEE half: ade_process_f16)
         self.in_dtype = {"INT16": np.int16, "F32": np.float32, "F16": np.float16}[reader.string("input_audio_dtype", "INT16")]
         self.out_dtype = {"INT16": np.int16, "F32": np.float32, "F16": np.float16}[reader.string("output_audio_dtype", "INT16")]
         tname = {np.int16: "tensor(int16)", np.float32: "tensor(float)", np.float16: "tensor(float16)"}
@@ -118,6 +118,14 @@ class InferenceSession:
         if x.ndim != 3 or x.shape[1] != self.channels or x.shape[2] != self.in_len:
             raise ValueError(f"{INPUT_NAME} must have shape (B, {self.channels}, {self.in_len}), got {x.shape}")
         float_out = self.out_dtype != np.int16
+        if (self.in_dtype == np.float16 or self.out_dtype == np.float16) and self.in_dtype != np.float32 and not return_f32:
+            # a float16 graph tensor on either side: the half entry (the engine widens / narrows on the device)
+            pcm, f16 = self.process_f16(x.reshape(x.shape[0], self.row_in), want_pcm=not float_out, want_f16=float_out)
+            if float_out:
+                f16 = f16.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
+                return [np.ascontiguousarray(f16[:, i]) for i in range(self.n_outputs)]
+            pcm = pcm.reshape(-1, self.n_outputs, self.out_channels, self.out_len)
+            return [np.ascontiguousarray(pcm[:, i]) for i in range(self.n_outputs)]
         if self.in_dtype == np.int16:
             pcm, f32 = self.process(x.reshape(x.shape[0], self.row_in), want_f32=return_f32 or float_out)
         else:
@@ -143,6 +151,22 @@ class InferenceSession:
         st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if want_f32 else None)
         self._lib.check(st, self._h)
         return out, f32
+
+    def process_f16(self, x: np.ndarray, want_pcm: bool = True, want_f16: bool = True):
+        """IEEE-half audio tensors (``ade_process_f16``): x (B, row_in) in the handle's input dtype -- float16 for a float-input manifest, int16 PCM otherwise --
+        -> (int16 PCM or None, float16 waveform or None)."""
+        want = np.int16 if self.in_dtype == np.int16 else np.float16
+        x = np.ascontiguousarray(x, dtype=want)
+        if x.ndim != 2 or x.shape[1] != self.row_in:
+            raise ValueError(f"input must have shape (B, {self.row_in}), got {x.shape}")
+        if not (want_pcm or want_f16):
+            raise ValueError("nothing to compute")
+        B = x.shape[0]
+        out = np.empty((B, self.row_out), np.int16) if want_pcm else None
+        f16 = np.empty((B, self.row_out), np.float16) if want_f16 else None
+        st = self._lib.c.ade_process_f16(self._h, x.ctypes.data, B, out.ctypes.data if want_pcm else None, f16.ctypes.data if want_f16 else None)
+        self._lib.check(st, self._h)
+        return out, f16
 
     def process_f32(self, x: np.ndarray, want_pcm: bool = True, want_f32: bool = True):
         """fp32 audio in (input_audio_dtype F32 / F16; ``ade_process_f32``): normalised samples (B, row_in) -> (int16 PCM or None, fp32 waveform or None)."""

@@ -61,9 +61,9 @@ typedef struct ade_io_desc {
  * reference's state_dict names.  `device` must be a gfx950 HIP device ordinal (there is no CPU mode).
  * The manifest key `model_family` selects the engine: "gtcrn" (GTCRN/Export_GTCRN.py), "dfsmn" (DFSMN/Export_DFSMN.py),
  * "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py), "mossformer2_ss"
- * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py), "ul_unas" (UL-UNAS/Export_UL_UNAS.py) or "h_gtcrn"
- * (H-GTCRN/Export_H_GTCRN.py: two microphones in, one channel out); the blob then carries that export's fused buffers
- * (INTEGRATION.md). */
+ * (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py), "zipenhancer" (ZipEnhancer/Export_ZipEnhancer.py), "ul_unas"
+ * (UL-UNAS/Export_UL_UNAS.py) or "h_gtcrn" (H-GTCRN/Export_H_GTCRN.py: two microphones in, one channel out); the blob then
+ * carries that export's fused buffers. */
 ade_status ade_create(const char* manifest_json, const void* weights, size_t weights_nbytes, int device,
                       ade_handle* out);
 
@@ -89,10 +89,26 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
 ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* out_pcm, float* out_f32);
 ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, int16_t* d_out_pcm, float* d_out_f32, void* hip_stream);
 
+/* IEEE-half audio tensors at the boundary (manifest input_audio_dtype and / or output_audio_dtype "F16": `noisy_audio` / `denoised_audio` are float16 graph tensors,
+ * GTCRN/Export_GTCRN.py:47-48, 645-646, 691-693; the graph itself computes in fp32 either way).  `in`: the input tensor in the handle's INPUT dtype -- half for an F16 / F32
+ * input manifest (normalised samples, widened exactly), int16 PCM otherwise; out_f16: the export's float output rounded to half (`audio_out.to(torch.float16)`,
+ * round to nearest even), out_pcm its INT16 output; either may be NULL.  Layouts as above. */
+ade_status ade_process_f16(ade_handle h, const void* in, int batch, int16_t* out_pcm, uint16_t* out_f16);
+ade_status ade_process_device_f16(ade_handle h, const void* d_in, int batch, int16_t* d_out_pcm, uint16_t* d_out_f16, void* hip_stream);
+
+/* The stitch step of a multi-GPU job (chunks are dealt to the ranks in contiguous blocks, the only exchange is the final concatenation,
+ * Inference_GTCRN_ONNX.py:326-332): all-gather this rank's `rows` output rows, d_local [rows][n_outputs * out_channels * out_len] int16, into
+ * d_all [world * rows][...] on every rank over the CALLER's RCCL communicator (`nccl_comm` = its ncclComm_t), enqueued on `hip_stream` behind the
+ * ade_process_device call that filled d_local -- one ncclAllGather of bytes (RCCL has no int16 type).  librccl is opened on first use; ADE_ERR_UNSUPPORTED when
+ * it is not installed.  Ranks with fewer rows pad their block (the gathered array is then trimmed by the caller). */
+ade_status ade_stitch_device(ade_handle h, const int16_t* d_local, int rows, int16_t* d_all, void* nccl_comm, void* hip_stream);
+
 /* Grow the workspace so `batch` rows run without allocation inside the timed path. */
 ade_status ade_reserve(ade_handle h, int batch);
 
-/* Options: "graph" = "0"/"1" replay the launch sequence from a captured hipGraph (default 1). */
+/* Options: "graph" = "0"/"1" replay the launch sequence from a captured hipGraph (default 1); "fused" / "single_launch" = "0"/"1" GTCRN's per-chunk LDS-resident path,
+ * as one launch; "geometry" = "auto"/"0"/"1" its workgroup geometry (0: one 1024-thread workgroup per chunk; 1: 512-thread workgroups that each own a run of at most 32
+ * frames, two per CU -- the default where the frame count allows); "stagger_us" (geometry 0), "seg_prio", "wave_swap": measurement knobs, see DESIGN.md. */
 ade_status ade_set_option(ade_handle h, const char* key, const char* value);
 
 /* Parity taps: copy a named intermediate of the LAST processed batch to host (engine-native layout, see
@@ -152,7 +168,8 @@ void ade_stream_destroy(ade_stream_handle s);           /* before ade_destroy of
  * periodic hamming synthesis, no centre pad, DFSMN/Export_DFSMN.py:273-274); class at GTCRN/STFT_Process.py:129-341.
  * Window names: "hann", "hann_sqrt", "hamming" (torch periodic=True), with a "_sym" suffix for periodic=False;
  * "hamming_periodic" is accepted as an alias of "hamming".  Layouts are the reference's: x [B][L] float ->
- * spec [B][2*(n_fft/2+1)][T] (re rows, then im rows) -> y [B][out_len].  Dense windowed DFT as fp32 MFMA GEMMs. */
+ * spec [B][2*(n_fft/2+1)][T] (re rows, then im rows) -> y [B][out_len].  5-smooth transform sizes (every folder's: 512, 400, 2048, 1920) run as mixed-radix
+ * Stockham FFTs in LDS; other sizes as the reference's own dense windowed DFT on the fp32 matrix cores. */
 typedef struct ade_stft_plan* ade_stft_handle;
 typedef struct ade_stft_config {
     int n_fft, win_length, hop;

@@ -423,3 +423,26 @@ def test_gpu_hgtcrn_float_tensors_with_batch_fold(hg):
         got = sf.run(None, {"noisy_audio": x})[0]
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 3 and (d != 0).mean() < 0.05, (d.max(), (d != 0).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_rate", [8000, 16000, 32000])
+def test_gpu_hgtcrn_float_input_equals_int16_input_at_every_input_rate(hg, in_rate):
+    """A float input tensor carries the int16 entry's samples (x 2^-15), so both entries must produce the same PCM -- also BELOW the model rate, where the DC mean is
+    taken from the caller-rate samples before the interpolation (Export_H_GTCRN.py:953-964): the float entry must take it from the float tensor, not from the
+    pointer it was handed in place of PCM."""
+    from audio_denoiser_onnx_amd import hgtcrn
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    fused, _ = hg
+    L = 20480 * in_rate // 16000
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal((1, 2, L)) * 3000 + 700).clip(-32768, 32767).astype(np.int16)       # a DC offset, so that a wrong mean shows
+    meta = hgtcrn.metadata(L, in_sample_rate=in_rate)
+    with InferenceSession(weights=pack_blob(fused), metadata=meta) as si:
+        want = si.run(None, {"noisy_audio": pcm})[0]
+    x = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    with InferenceSession(weights=pack_blob(fused), metadata=with_dtypes(meta, "F32", "INT16")) as sf:
+        got = sf.run(None, {"noisy_audio": x})[0]
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 3 and (d != 0).mean() < 0.05, (in_rate, d.max(), (d != 0).mean())

@@ -54,3 +54,38 @@ def test_file_driver_ragged_tail_matches_per_slice_oracle():
     o = GtcrnOracle(golden_blob(0), 16000)
     ref = np.concatenate([o.process(padded[i * stride:i * stride + 16000])[0][0] for i in range(n)])[:len(audio)]
     assert np.abs(out.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def test_stitch_device_over_rccl_single_rank_communicator():
+    """ade_stitch_device = one ncclAllGather of the rank's int16 rows on the caller's communicator and stream.  A 1-GPU box can only build a world-size-1 communicator
+    (the all-gather is then a device copy through RCCL), which still exercises the library lookup, the call signature, the byte count and the stream order."""
+    import ctypes as C
+    import torch
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 not installed")
+    class UniqueId(C.Structure):                                  # ncclUniqueId is passed BY VALUE
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        sess = make_session(None, seed=1)
+        x = synth_batch(5)
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros((5, sess.row_out), dtype=torch.int16, device="cuda")
+        d_all = torch.zeros((5, sess.row_out), dtype=torch.int16, device="cuda")
+        stream = torch.cuda.Stream()
+        sess.run_device(d_in, d_out, stream=stream.cuda_stream)
+        st = sess._lib.c.ade_stitch_device(sess._h, C.c_void_p(d_out.data_ptr()), 5, C.c_void_p(d_all.data_ptr()), comm, C.c_void_p(stream.cuda_stream))
+        sess._lib.check(st, sess._h)
+        stream.synchronize()
+        want, _ = sess.process(x)
+        assert np.array_equal(d_all.cpu().numpy(), want)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
