@@ -1192,7 +1192,8 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         if (strcmp(value, "auto") == 0) g = -1;
         else if (strcmp(value, "0") == 0) g = 0;
         else if (strcmp(value, "1") == 0) g = 1;
-        if (g == -2) return fail(h, ADE_ERR_BAD_VALUE, "option geometry: auto, 0 or 1");
+        else if (strcmp(value, "2") == 0) g = 2;
+        if (g == -2) return fail(h, ADE_ERR_BAD_VALUE, "option geometry: auto, 0, 1 or 2");
         h->geometry = g;
         free_graphs(h);
         return ADE_OK;

@@ -25,6 +25,7 @@ template <class G> constexpr size_t chunk_smem_bytes() {
     return cmax(cmax(gt_smem_bytes<G>(), dp_smem_bytes<G>()), cmax(front_smem_bytes<G>(), back_smem_bytes<G>()));
 }
 static_assert(chunk_smem_bytes<Geo1>() * 2 <= 160 * 1024, "two geometry-1 workgroups must fit one CU's LDS");
+static_assert(chunk_smem_bytes<Geo2>() * 4 <= 160 * 1024, "four geometry-2 workgroups must fit one CU's LDS");
 static_assert(chunk_smem_bytes<Geo0>() <= 160 * 1024, "geometry 0 must fit one CU's LDS");
 
 // Block b of a (B x nseg)-block grid -> (chunk, segment): all first segments first.  Frames are dealt as evenly as possible, the earlier
@@ -190,23 +191,25 @@ hipError_t init_geometry() {
 
 }  // namespace
 
-int fused_geometries() { return 2; }
-int fused_max_frames(int geometry) { return geometry == 1 ? Geo1::kTmax : Geo0::kTmax; }
+int fused_geometries() { return 3; }
+int fused_max_frames(int geometry) { return geometry == 2 ? Geo2::kTmax : (geometry == 1 ? Geo1::kTmax : Geo0::kTmax); }
 int fused_segments(int T, int geometry) { const int m = fused_max_frames(geometry); return (T + m - 1) / m; }
 bool fused_supported(int T, int geometry) {
-    if (T < 2 || geometry < 0 || geometry > 1) return false;
+    if (T < 2 || geometry < 0 || geometry > 2) return false;
     const int n = fused_segments(T, geometry);
     return n <= kMaxSegments && (n == 1 || T / n >= kXHistFrames);   // a segment must hold the history its successor needs
 }
 
 hipError_t fused_init() {
     hipError_t e = init_geometry<Geo0>();
-    return e != hipSuccess ? e : init_geometry<Geo1>();
+    if (e == hipSuccess) e = init_geometry<Geo1>();
+    return e != hipSuccess ? e : init_geometry<Geo2>();
 }
 
 #define ADE_GEO_LAUNCH(kernel_tpl, smem_fn, grid, ...)                                                                              \
     do {                                                                                                                            \
-        if (geometry == 1) hipLaunchKernelGGL(kernel_tpl<Geo1>, dim3(grid), dim3(Geo1::kThreads), smem_fn<Geo1>(), s, __VA_ARGS__); \
+        if (geometry == 2) hipLaunchKernelGGL(kernel_tpl<Geo2>, dim3(grid), dim3(Geo2::kThreads), smem_fn<Geo2>(), s, __VA_ARGS__); \
+        else if (geometry == 1) hipLaunchKernelGGL(kernel_tpl<Geo1>, dim3(grid), dim3(Geo1::kThreads), smem_fn<Geo1>(), s, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel_tpl<Geo0>, dim3(grid), dim3(Geo0::kThreads), smem_fn<Geo0>(), s, __VA_ARGS__);               \
     } while (0)
 
@@ -226,7 +229,10 @@ void launch_back(hipStream_t s, int geometry, SegPlan plan, const float* x, cons
 }
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call) {
     const int grid = call.B * call.plan.nseg;
-    if (geometry == 1) {
+    if (geometry == 2) {
+        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo2, true>), dim3(grid), dim3(Geo2::kThreads), chunk_smem_bytes<Geo2>(), s, call);
+        else hipLaunchKernelGGL((k_gtcrn_chunk<Geo2, false>), dim3(grid), dim3(Geo2::kThreads), chunk_smem_bytes<Geo2>(), s, call);
+    } else if (geometry == 1) {
         if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, true>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
         else hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, false>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
     } else {

@@ -134,7 +134,8 @@ void launch_ola_pcm_stream(hipStream_t s, const float* frames, float* carry, Fft
 // A chunk is walked by one workgroup per SEGMENT of consecutive frames.  Two geometries are compiled from the same stage bodies:
 //   geometry 0: 1024-thread workgroups that own up to 64 frames (152 KB of LDS: one workgroup per CU);
 //   geometry 1:  512-thread workgroups that own up to 32 frames ( 79 KB of LDS: TWO workgroups per CU, so the serial phases of one --
-//                TRA recurrence on one wavefront, inter-frame GRU -- run under the position-parallel phases of the other).
+//                TRA recurrence on one wavefront, inter-frame GRU -- run under the position-parallel phases of the other);
+//   geometry 2:  256-thread workgroups that own up to 16 frames ( 40 KB of LDS: FOUR workgroups per CU).
 // Everything in GTCRN is causal along time, so segment k + 1 needs from segment k exactly what the streaming path carries between pushes:
 // the depthwise-convolution history of each GTConvBlock (handed over as PARTIAL SUMS of the first 2 x dilation frames, see gtblock_stage),
 // the six TRA GRU states, the two inter-frame GRU states and the 256-sample overlap-add carry.  They cross in the exchange area below
@@ -144,7 +145,8 @@ constexpr int kXHistFloats = 4 * kXHistFrames * kFw * 4;       // per GTConvBloc
 constexpr int kXTraOff = 6 * kXHistFloats;                     // [6 blocks][16]
 constexpr int kXInterOff = kXTraOff + 6 * 16;                  // [2 blocks][33 x 16]
 constexpr int kXOlaOff = kXInterOff + 2 * kFw * 16;            // [256]
-constexpr int kXFloats = ((kXOlaOff + kHop + 63) / 64) * 64;
+constexpr int kXPendOff = kXOlaOff + kHop;                     // [256] scratch of the slot's OWN workgroup (geometry 2 parks its first hop here: 40 KB of LDS per workgroup)
+constexpr int kXFloats = ((kXPendOff + kHop + 63) / 64) * 64;
 constexpr int kXFlags = 16;                                    // hist 0-5 | tra 6-11 | inter 12-13 | ola 14
 constexpr int kXFlagHist = 0, kXFlagTra = 6, kXFlagInter = 12, kXFlagOla = 14;
 constexpr int kMaxSegments = 8;
@@ -166,7 +168,7 @@ struct Seg {               // one workgroup's share (device-side)
     unsigned* fi;          // flags of the previous segment (polled, then lowered)
     int* err;
 };
-int fused_geometries();                       // 2
+int fused_geometries();                       // 3
 int fused_max_frames(int geometry);           // frames one workgroup can own
 bool fused_supported(int T, int geometry);    // T >= 2 and ceil(T / max_frames) <= kMaxSegments
 int fused_segments(int T, int geometry);

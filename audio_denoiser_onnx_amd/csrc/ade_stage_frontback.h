@@ -96,7 +96,7 @@ constexpr int kC0TailW = 27 * 16;       // conv0 taps k = 0..2 (all 16 output ch
 constexpr int kC1TailW = 3 * 2 * 64;    // conv1 taps k = 0..2
 template <class G> constexpr size_t front_smem_bytes() {
     return ((size_t)G::kTileF * kWbuf * 2 + (size_t)G::kTileF * 3 * kErb + (size_t)4 * G::kTileF * kF1 * 4 + kTabFloats +
-            (size_t)kBmCap * kErbBands + kC0TailW + kC1TailW + 16) * 4;
+            (size_t)(G::kLean ? 0 : kBmCap) * kErbBands + kC0TailW + kC1TailW + 16) * 4;
 }
 
 // sg: the workgroup's segment of the chunk -- frames sg.t0 .. sg.t0 + sg.nT - 1; every frame of this stage is independent of the others
@@ -108,8 +108,9 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
                                             const float* __restrict__ dc_rows = nullptr) {
     constexpr int kFusedThreads = G::kThreads, kTileF = G::kTileF, kTileP1 = kTileF * kF1;
     constexpr size_t kFrontFeatFloats = (size_t)kTileF * 3 * kErb;
-    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : 8);      // lanes of output-channel group g: [g * NT / 2, (g + 1) * NT / 2)
-    static_assert(kFusedThreads == 1024 || kFusedThreads == 512, "front / back conv rounds: 64 lanes per frame");
+    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : (kFusedThreads == 512 ? 8 : 7));      // lanes of output-channel group g: [g * NT / 2, (g + 1) * NT / 2)
+    static_assert(kFusedThreads == 1024 || kFusedThreads == 512 || kFusedThreads == 256, "front / back conv rounds: 64 lanes per frame");
+    constexpr int kBmRows = G::kLean ? 0 : kBmCap;                   // ERB-merge rows kept in LDS
     const int T = sg.T, tbeg = sg.t0, tend = sg.t0 + sg.nT;
     float2* wbuf_all = reinterpret_cast<float2*>(smem);
     float* feat = smem + kTileF * kWbuf * 2;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
     float* E0f = reinterpret_cast<float*>(E0);
     float* tabmem = reinterpret_cast<float*>(E0 + 4 * kTileP1);
     float* erbw = tabmem + kTabFloats;
-    float* w0t = erbw + kBmCap * kErbBands;      // tail weights live in LDS: a tail lane owns ONE output channel, so they
+    float* w0t = erbw + kBmRows * kErbBands;     // tail weights live in LDS: a tail lane owns ONE output channel, so they
     float* w1t = w0t + kC0TailW;                 // cannot be scalar operands, and a VMEM load here would have to wait for
     int* red = reinterpret_cast<int*>(w1t + kC1TailW);   // the (in-order) prefetches in flight
     int tid_ = threadIdx.x;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
     int raw[4];                                            // tile 0's samples: in flight while the mean is computed
     load_frame_pairs(row, L, tbeg + wave, lane, tbeg + wave < tend, pair_ok, raw);
     const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
-    const bool erb_lds = erb.count <= kBmCap;
+    const bool erb_lds = erb.count <= kBmRows;
     if (erb_lds)
         for (int i = tid; i < erb.count * kErbBands; i += kFusedThreads) erbw[i] = erb.w[i];
     const int erb_s0 = erb.start[lane];
@@ -378,9 +379,9 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kC3TailW = 2 * 2 * 64;    // deconv3 taps 2 and 4, both groups
 constexpr int kC4TailW = 2 * 16 * 2;    // deconv4 taps 2 and 4
-template <class G> constexpr size_t back_smem_bytes() {
+template <class G> constexpr size_t back_smem_bytes() {      // (the lean geometry keeps win_sum, the ERB-split rows, the tail weights and `pend` out of LDS)
     return ((size_t)4 * G::kTileF * kFw * 4 + (size_t)4 * G::kTileF * kF1 * 4 + (size_t)G::kTileF * 2 * kErbPad + (size_t)kNfft + (size_t)kHop * (G::kTileF - 1) +
-            kTabFloats + kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW + kHop) * 4;
+            kTabFloats + (G::kLean ? 0 : kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW + kHop)) * 4;
 }
 
 // sg: the workgroup's segment.  The overlap-add is the only step that crosses frames: a segment with a successor hands on its last
@@ -397,7 +398,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     constexpr int kSUnits = 4 * kTileP;        // float4 slots of one S tile
     constexpr int kSThreads = kSUnits / 3;     // 704 (352) lanes x 3 slots stage a tile
     static_assert(kSThreads * 3 == kSUnits && kSThreads <= kFusedThreads, "S staging split");
-    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : 8);
+    constexpr int kGroupShift = (kFusedThreads == 1024 ? 9 : (kFusedThreads == 512 ? 8 : 7));
+    constexpr bool kLean = G::kLean;
     const int T = sg.T, tbeg = sg.t0, tend = sg.t0 + sg.nT;
     float4* S = reinterpret_cast<float4*>(smem);
     float* Sf = smem;
@@ -407,12 +409,14 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     float* M = reinterpret_cast<float*>(D + 4 * kTileP1);
     float* acc = M + kTileF * 2 * kErbPad;
     float* tabmem = acc + kBackAccFloats;
-    float* wsum = tabmem + kTabFloats;
+    // (lean geometry: none of the following is carved; win_sum and the ERB-split rows are read from global memory, the tail weights likewise, and the
+    //  parked first hop waits in the spare floats behind this segment's own exchange slot)
+    float* wsum = kLean ? const_cast<float*>(tabs.win_sum) : tabmem + kTabFloats;
     float* bsw = wsum + kHop;
     int* bss = reinterpret_cast<int*>(bsw + kBsCap * kErbHigh);
     float* w3t = reinterpret_cast<float*>(bss + kErbHigh);     // tail weights (see front_stage): [tap 2 | tap 4] x [g][ci][co]
     float* w4t = w3t + kC3TailW;                               // [tap 2 | tap 4] x [ci][co]
-    float* pend = w4t + kC4TailW;                              // [256] first hop of a segment that has a predecessor
+    float* pend = kLean ? sg.xo + kXPendOff : w4t + kC4TailW;  // [256] first hop of a segment that has a predecessor
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
@@ -472,14 +476,20 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     float4 ea[2], eb[2];                    // loop-carried: tile k issues tile k+1's (every lane redefines them each time)
     issue_e0(tbeg, true, ea, eb);
     const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
-    for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
-    const bool bs_lds = bs.count <= kBsCap;
+    if (!kLean)
+        for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
+    const bool bs_lds = !kLean && bs.count <= kBsCap;
     if (bs_lds) {
         for (int i = tid; i < bs.count * kErbHigh; i += kFusedThreads) bsw[i] = bs.w[i];
         for (int i = tid; i < kErbHigh; i += kFusedThreads) bss[i] = bs.start[i];
     }
-    for (int i = tid; i < kC3TailW; i += kFusedThreads) w3t[i] = c3.w[(i < 128 ? 2 : 4) * 128 + (i & 127)];
-    for (int i = tid; i < kC4TailW; i += kFusedThreads) w4t[i] = c4.w[(i < 32 ? 2 : 4) * 32 + (i & 31)];
+    if (!kLean) {
+        for (int i = tid; i < kC3TailW; i += kFusedThreads) w3t[i] = c3.w[(i < 128 ? 2 : 4) * 128 + (i & 127)];
+        for (int i = tid; i < kC4TailW; i += kFusedThreads) w4t[i] = c4.w[(i < 32 ? 2 : 4) * 32 + (i & 31)];
+    }
+    // tail weight (tap block b = 0: tap 2, 1: tap 4) as the LDS copy lays it out, or straight from the weight arena
+    auto w3tail = [&](int b, int j) { return kLean ? c3.w[(b ? 4 : 2) * 128 + j] : w3t[b * 128 + j]; };
+    auto w4tail = [&](int b, int j) { return kLean ? c4.w[(b ? 4 : 2) * 32 + j] : w4t[b * 32 + j]; };
     const float b3t = c3.b[tid & 15], b4t = c4.b[tid & 1];
     for (int i = tid; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = 0.0f;
     const cfptr c3b = cptr(c3.b), c4b = cptr(c4.b), c4w = cptr(c4.w);
@@ -561,7 +571,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                     const int ps = tl * kFw + (kFw - 1) + dlt;
 #pragma unroll
                     for (int ci = 0; ci < 8; ++ci)      // tap ke = 2 - 2 dlt -> w3t block (dlt + 1 ? 0 : 1)
-                        ev += w3t[(dlt < 0 ? 128 : 0) + (g * 8 + ci) * 8 + co] * Sf[((size_t)(2 * g + (ci >> 2)) * kTileP + ps) * 4 + (ci & 3)];
+                        ev += w3tail(dlt < 0 ? 1 : 0, (g * 8 + ci) * 8 + co) * Sf[((size_t)(2 * g + (ci >> 2)) * kTileP + ps) * 4 + (ci & 3)];
                 }
                 Df[((size_t)(2 * g + (co >> 2)) * kTileP1 + pe) * 4 + (co & 3)] = prelu_f(ev, c3.slope) + eadd;
             }
@@ -621,7 +631,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                     const int ps = tl * kF1 + (kF1 - 1) + dlt;
 #pragma unroll
                     for (int ci = 0; ci < 16; ++ci)
-                        ev += w4t[(dlt < 0 ? 32 : 0) + ci * 2 + co] * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
+                        ev += w4tail(dlt < 0 ? 1 : 0, ci * 2 + co) * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
                 }
                 M[(size_t)tl * 2 * kErbPad + co * kErbPad + (kErb - 1)] = tanh_f(ev);
             }

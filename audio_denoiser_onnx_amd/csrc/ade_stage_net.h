@@ -33,12 +33,14 @@ struct Geo {
     static constexpr int kPosPerThread = (kPmax + NT - 1) / NT;   // 3 for both geometries
     static constexpr int kTileF = NT / 64;                        // frames per front / back tile = wavefronts per workgroup
     static constexpr int kProdBase = ((TMAX * (kFw / 3) + 63) / 64) * 64;   // first lane of the wavefronts that are idle in the conv phases
-    static constexpr int kInterCols = NT >= kFw * 16 ? 64 : 17;   // F columns per pass of the inter-frame GRU (16 lanes per column)
+    static constexpr int kInterCols = NT >= kFw * 16 ? 64 : (NT >= 512 ? 17 : 11);   // F columns per pass of the inter-frame GRU (16 lanes per column): 1, 2 or 3 passes
+    static constexpr bool kLean = NT < 512;                       // 40 KB of LDS per workgroup: the front / back stages read their small tables from L1 / L2 instead of LDS copies
     static_assert(kPosPerThread == 3, "the conv phases are written for three positions per lane");
-    static_assert(kProdBase + 2 * 5 * (kFw / 3) <= NT, "the history producers need 110 lanes outside the conv lanes");
+    static_assert(kProdBase < NT, "the history producers need a wavefront outside the conv lanes");
 };
 typedef Geo<1024, 64, 4> Geo0;     // one workgroup per CU
 typedef Geo<512, 32, 4> Geo1;      // two workgroups per CU (4 waves per SIMD = 2 x 512 / 256)
+typedef Geo<256, 16, 4> Geo2;      // four workgroups per CU
 
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
@@ -271,9 +273,9 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         // History for the NEXT segment, on wavefronts that own no conv lane: lane (t', c) of its first 2 x dilation frames adds, to the
         // bias, the time taps that land in THIS segment's frames T + t' - (2 - kt) dilation -- kt ascending, exactly the head of the sum
         // a whole-chunk workgroup forms for that frame.
-        const int u = tid - G::kProdBase;
-        const int tn = u / (kFw / 3), cn = u - tn * (kFw / 3);
-        if (tn < 2 * dilation) {
+#pragma unroll 1
+        for (int u = tid - G::kProdBase; u < 2 * dilation * (kFw / 3); u += kFusedThreads - G::kProdBase) {      // (one round, except for the 256-thread geometry at dilation 5)
+            const int tn = u / (kFw / 3), cn = u - tn * (kFw / 3);
             const bool lok = cn != 0, rok = cn != kFw / 3 - 1;
             v2f acc[kPosPerThread][8];
 #pragma unroll
@@ -595,7 +597,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
 // LDS: R[4][kPmax] float4 (rnn outputs, then mid, then rnn outputs again) | red[kPmax] | stat[2][64].
 // `mid` is parked in the output buffer between the two halves (same thread writes and re-reads it).
 // ---------------------------------------------------------------------------------------------------------
-template <class G> constexpr size_t dp_smem_bytes() { return (size_t)4 * G::kPmax * 16 + (size_t)G::kPmax * 4 + 2 * G::kTmax * 4 + (size_t)4 * kFw * kCh * 4; }   // + 4 LayerNorm tables
+template <class G> constexpr size_t dp_smem_bytes() { return (size_t)4 * G::kPmax * 16 + (size_t)G::kPmax * 4 + 2 * G::kTmax * 4 + (size_t)2 * kFw * kCh * 4; }   // + 2 LayerNorm tables
 
 // Linear(16,16) on the rnn output of each of this thread's positions, two-pass LayerNorm statistics per frame
 // through LDS, then  y = res + (v - mean) * rstd * gamma + beta.   v/res/y: [kPosPerThread][16] registers.
@@ -737,7 +739,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     float* Rf = reinterpret_cast<float*>(smem);
     float* red = reinterpret_cast<float*>(smem + 4 * kPmax);
     float* stat = red + kPmax;
-    float* lnt = stat + 2 * kTmaxFused;   // LDS copies of the 4 LayerNorm tables [intra gamma | intra beta | inter gamma | inter beta]
+    float* lnt = stat + 2 * kTmaxFused;   // LDS copies of two LayerNorm tables [gamma | beta]: the intra pair for phase B, then the inter pair for phase D
     const int T = sg.nT;
     const int P = T * kFw, Ps = sg.T * kFw;
     int tid_ = threadIdx.x;
@@ -746,8 +748,6 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     for (int i = tid; i < kFw * kCh; i += kFusedThreads) {   // (made visible by the barrier after phase A)
         lnt[i] = w.intra_ln_w[i];
         lnt[kFw * kCh + i] = w.intra_ln_b[i];
-        lnt[2 * kFw * kCh + i] = w.inter_ln_w[i];
-        lnt[3 * kFw * kCh + i] = w.inter_ln_b[i];
     }
     const size_t cbase = (size_t)chunk * kCh * Ps + (size_t)sg.t0 * kFw * 4;
     const float* xc = x + cbase;
@@ -834,6 +834,10 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     }
     if (sg.prev && tid == 0) xwait(sg.fi + kXFlagInter + blk, sg.err);    // the previous segment's inter-frame GRU state
     __syncthreads();
+    for (int i = tid; i < kFw * kCh; i += kFusedThreads) {   // phase B is done with the intra pair: the inter pair takes its place (visible after phase C's barrier)
+        lnt[i] = w.inter_ln_w[i];
+        lnt[kFw * kCh + i] = w.inter_ln_b[i];
+    }
     ADE_CLK(18);
     // ---- phase C: inter GRNN.  16 lanes per F column: lane = 2*unit + group; GRU(8->8) along T, in place in R
     //      (a column position is read, then overwritten, by its own 16 lanes only).              (:450-455,478-479)
@@ -912,7 +916,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
     float y[kPosPerThread][16];
     float nsk[kPosPerThread][8];       // the following GTConvBlock's skip addend (zero when there is none)
-    fc_ln_phase<G>(R, red, stat, w.inter_fc, w.inter_fc_b, lnt + 2 * kFw * kCh, lnt + 3 * kFw * kCh, T, P, Ps, tid, y,
+    fc_ln_phase<G>(R, red, stat, w.inter_fc, w.inter_fc_b, lnt, lnt + kFw * kCh, T, P, Ps, tid, y,
                    (next_x1 && next_skip) ? next_skip + cbase : nullptr, nsk);
 #pragma unroll
     for (int i = 0; i < kPosPerThread; ++i) {

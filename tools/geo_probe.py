@@ -18,7 +18,7 @@ outs = {}
 stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 TAPS = ("spec", "e0", "e1", "x_e2", "x_e3", "x_e4", "dp1", "dp2", "x_d0", "x_d1", "x_d2")
-configs = [("0", "0"), ("1", "0"), ("1", "1")]      # (geometry, wave_swap)
+configs = [("0", "0"), ("1", "0"), ("2", "0")]      # (geometry, wave_swap)
 for rep in range(2):
     for geo, prio in configs:
         s = make_session()
@@ -59,6 +59,8 @@ for rep in range(2):
                 for i in range(1, 9):
                     ph = c[seg, i, first[i]:last[i] + 1] / 100
                     print(f"    {names[i]} phase durations:", np.round(np.diff(ph), 1).tolist())
+print("geometry 2 == geometry 0:  pcm", np.array_equal(outs["0"][0], outs["2"][0]), " f32", np.array_equal(outs["0"][1], outs["2"][1]), " device-path pcm", np.array_equal(outs["0"][2], outs["2"][2]),
+      " taps", all(np.array_equal(outs["0"][3][n], outs["2"][3][n]) for n in outs["0"][3]))
 print("geometry 1 == geometry 0:  pcm", np.array_equal(outs["0"][0], outs["1"][0]), " f32", np.array_equal(outs["0"][1], outs["1"][1]),
       " device-path pcm", np.array_equal(outs["0"][2], outs["1"][2]), " max|df32|", float(np.abs(outs["0"][1] - outs["1"][1]).max()))
 for n in outs["0"][3]:
