@@ -575,12 +575,15 @@ struct Seq {
     }
 };
 
-// Fused-path geometry of a call (-1: the frame count fits neither).  Two 512-thread workgroups per CU (geometry 1) overlap one
-// workgroup's serial phases with the other's parallel ones; the option "geometry" pins either.
+// Fused-path geometry of a call (-1: the frame count fits none).  Several small workgroups per CU overlap one workgroup's serial phases (TRA recurrence on one
+// wavefront, the GRUs) with the others' parallel ones: measured on one box at 256 x 1 s, 0.451 ms (geometry 0: one 1024-thread workgroup per CU), 0.418 ms
+// (geometry 1: two of 512 threads) and 0.408 ms (geometry 2: four of 256), identical bits.  The finest split the frame count allows wins; the option
+// "geometry" pins one.
 int pick_geometry(const ade_engine* e, int /*B*/) {
     if (e->geometry >= 0) return fused_supported(e->T, e->geometry) ? e->geometry : -1;
-    if (fused_supported(e->T, 1)) return 1;
-    return fused_supported(e->T, 0) ? 0 : -1;
+    for (int g = fused_geometries() - 1; g >= 0; --g)
+        if (fused_supported(e->T, g)) return g;
+    return -1;
 }
 
 void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* d_out, float* d_f32, bool prof) {

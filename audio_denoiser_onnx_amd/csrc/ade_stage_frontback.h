@@ -375,13 +375,14 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
 
 // ---------------------------------------------------------------------------------------------------------------
 // BACK.  LDS (floats): S[4][528]x4 (reused as the FFT buffers wbuf[16][264]x2) | D[4][1040]x4 | M[16][2][132] |
-//                      acc[512 + 256*15] | tabs | win_sum[256] | ERB-split rows [4][192] | ERB-split starts [192]
+//                      carry[256] | tabs | win_sum[256] | ERB-split rows [4][192] | ERB-split starts [192] ; the overlap-add accumulator acc[512 + 256 (kTileF - 1)]
+//                      aliases D, which is dead from the end of deconv4 to the next tile's deconv3
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kC3TailW = 2 * 2 * 64;    // deconv3 taps 2 and 4, both groups
 constexpr int kC4TailW = 2 * 16 * 2;    // deconv4 taps 2 and 4
-template <class G> constexpr size_t back_smem_bytes() {      // (the lean geometry keeps win_sum, the ERB-split rows, the tail weights and `pend` out of LDS)
-    return ((size_t)4 * G::kTileF * kFw * 4 + (size_t)4 * G::kTileF * kF1 * 4 + (size_t)G::kTileF * 2 * kErbPad + (size_t)kNfft + (size_t)kHop * (G::kTileF - 1) +
-            kTabFloats + (G::kLean ? 0 : kHop + (size_t)kBsCap * kErbHigh + kErbHigh + kC3TailW + kC4TailW + kHop)) * 4;
+template <class G> constexpr size_t back_smem_bytes() {      // (the lean geometry keeps win_sum, the ERB-split start indices and `pend` out of LDS)
+    return ((size_t)4 * G::kTileF * kFw * 4 + (size_t)4 * G::kTileF * kF1 * 4 + (size_t)G::kTileF * 2 * kErbPad + (size_t)kHop + kTabFloats + (size_t)kBsCap * kErbHigh +
+            kC3TailW + kC4TailW + (G::kLean ? 0 : kHop + kErbHigh + kHop)) * 4;
 }
 
 // sg: the workgroup's segment.  The overlap-add is the only step that crosses frames: a segment with a successor hands on its last
@@ -395,6 +396,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     constexpr int kFusedThreads = G::kThreads, kTileF = G::kTileF, kTileP1 = kTileF * kF1, kTileP = kTileF * kFw;
     constexpr size_t kBackAccFloats = (size_t)kNfft + (size_t)kHop * (kTileF - 1);
     static_assert((size_t)4 * kTileP * 4 >= (size_t)kTileF * kWbuf * 2, "the S tile must be able to hold the FFT buffers");
+    static_assert((size_t)4 * kTileP1 * 4 >= kBackAccFloats, "the D tile must be able to hold the overlap-add accumulator");
     constexpr int kSUnits = 4 * kTileP;        // float4 slots of one S tile
     constexpr int kSThreads = kSUnits / 3;     // 704 (352) lanes x 3 slots stage a tile
     static_assert(kSThreads * 3 == kSUnits && kSThreads <= kFusedThreads, "S staging split");
@@ -407,16 +409,17 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     float4* D = S + 4 * kTileP;
     float* Df = reinterpret_cast<float*>(D);
     float* M = reinterpret_cast<float*>(D + 4 * kTileP1);
-    float* acc = M + kTileF * 2 * kErbPad;
-    float* tabmem = acc + kBackAccFloats;
-    // (lean geometry: none of the following is carved; win_sum and the ERB-split rows are read from global memory, the tail weights likewise, and the
-    //  parked first hop waits in the spare floats behind this segment's own exchange slot)
-    float* wsum = kLean ? const_cast<float*>(tabs.win_sum) : tabmem + kTabFloats;
-    float* bsw = wsum + kHop;
-    int* bss = reinterpret_cast<int*>(bsw + kBsCap * kErbHigh);
-    float* w3t = reinterpret_cast<float*>(bss + kErbHigh);     // tail weights (see front_stage): [tap 2 | tap 4] x [g][ci][co]
+    float* acc = Df;                                           // overlap-add accumulator of a tile: lives in D between deconv4 and the next tile's deconv3
+    float* cbuf = M + kTileF * 2 * kErbPad;                    // [256] the half-finished hop carried from one tile to the next
+    float* tabmem = cbuf + kHop;
+    float* bsw = tabmem + kTabFloats;                          // ERB-split rows
+    float* w3t = bsw + kBsCap * kErbHigh;                      // tail weights (see front_stage): [tap 2 | tap 4] x [g][ci][co]
     float* w4t = w3t + kC3TailW;                               // [tap 2 | tap 4] x [ci][co]
-    float* pend = kLean ? sg.xo + kXPendOff : w4t + kC4TailW;  // [256] first hop of a segment that has a predecessor
+    // (lean geometry, 40 KB per workgroup: win_sum and the ERB-split start indices are fetched from global memory into registers at the top of each tile / once per
+    //  stage, and the parked first hop waits in the spare floats behind this segment's own exchange slot)
+    float* wsum = kLean ? const_cast<float*>(tabs.win_sum) : w4t + kC4TailW;
+    int* bss = reinterpret_cast<int*>(wsum + kHop);
+    float* pend = kLean ? sg.xo + kXPendOff : reinterpret_cast<float*>(bss + kErbHigh);  // [256] first hop of a segment that has a predecessor
     int tid_ = threadIdx.x;
     ADE_OPAQUE_V(tid_);
     const int tid = tid_;
@@ -478,20 +481,27 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
     if (!kLean)
         for (int i = tid; i < kHop; i += kFusedThreads) wsum[i] = tabs.win_sum[i];
-    const bool bs_lds = !kLean && bs.count <= kBsCap;
+    const bool bs_lds = bs.count <= kBsCap;
+    int bs_s[4] = {0, 0, 0, 0};                                // lean: start band of the (at most four) high bins this lane masks: k = lane + 64 r (r = 1 .. 3), k = 256 on lane 0
     if (bs_lds) {
         for (int i = tid; i < bs.count * kErbHigh; i += kFusedThreads) bsw[i] = bs.w[i];
-        for (int i = tid; i < kErbHigh; i += kFusedThreads) bss[i] = bs.start[i];
+        if (!kLean) {
+            for (int i = tid; i < kErbHigh; i += kFusedThreads) bss[i] = bs.start[i];
+        } else {
+            int tq = tid;
+            ADE_OPAQUE_V(tq);
+            const int lane = tq & 63;
+#pragma unroll
+            for (int r = 1; r < 5; ++r) {
+                const int k = r < 4 ? lane + 64 * r : 256;
+                bs_s[r - 1] = (k >= kErbLow && (r < 4 || lane == 0)) ? bs.start[k - kErbLow] : 0;
+            }
+        }
     }
-    if (!kLean) {
-        for (int i = tid; i < kC3TailW; i += kFusedThreads) w3t[i] = c3.w[(i < 128 ? 2 : 4) * 128 + (i & 127)];
-        for (int i = tid; i < kC4TailW; i += kFusedThreads) w4t[i] = c4.w[(i < 32 ? 2 : 4) * 32 + (i & 31)];
-    }
-    // tail weight (tap block b = 0: tap 2, 1: tap 4) as the LDS copy lays it out, or straight from the weight arena
-    auto w3tail = [&](int b, int j) { return kLean ? c3.w[(b ? 4 : 2) * 128 + j] : w3t[b * 128 + j]; };
-    auto w4tail = [&](int b, int j) { return kLean ? c4.w[(b ? 4 : 2) * 32 + j] : w4t[b * 32 + j]; };
+    for (int i = tid; i < kC3TailW; i += kFusedThreads) w3t[i] = c3.w[(i < 128 ? 2 : 4) * 128 + (i & 127)];
+    for (int i = tid; i < kC4TailW; i += kFusedThreads) w4t[i] = c4.w[(i < 32 ? 2 : 4) * 32 + (i & 31)];
     const float b3t = c3.b[tid & 15], b4t = c4.b[tid & 1];
-    for (int i = tid; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = 0.0f;
+    for (int i = tid; i < kHop; i += kFusedThreads) cbuf[i] = 0.0f;
     const cfptr c3b = cptr(c3.b), c4b = cptr(c4.b), c4w = cptr(c4.w);
     commit_s(sa0, sb0);
     long long clk_prev = ADE_CLK_START();
@@ -500,6 +510,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         const int nf = tend - t0 < kTileF ? tend - t0 : kTileF;
         // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase three barriers later
         float sre[5], sim[5];
+        float wsr[4] = {1.0f, 1.0f, 1.0f, 1.0f};     // lean: this lane's four win_sum values of the finalize step (nf * 64 float4 slots <= one per lane), requested with the spectrum
+        if (kLean) ld4(wsum + ((tid * 4) & (kHop - 1)), wsr);
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);
@@ -571,7 +583,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                     const int ps = tl * kFw + (kFw - 1) + dlt;
 #pragma unroll
                     for (int ci = 0; ci < 8; ++ci)      // tap ke = 2 - 2 dlt -> w3t block (dlt + 1 ? 0 : 1)
-                        ev += w3tail(dlt < 0 ? 1 : 0, (g * 8 + ci) * 8 + co) * Sf[((size_t)(2 * g + (ci >> 2)) * kTileP + ps) * 4 + (ci & 3)];
+                        ev += w3t[(dlt < 0 ? 128 : 0) + (g * 8 + ci) * 8 + co] * Sf[((size_t)(2 * g + (ci >> 2)) * kTileP + ps) * 4 + (ci & 3)];
                 }
                 Df[((size_t)(2 * g + (co >> 2)) * kTileP1 + pe) * 4 + (co & 3)] = prelu_f(ev, c3.slope) + eadd;
             }
@@ -631,7 +643,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                     const int ps = tl * kF1 + (kF1 - 1) + dlt;
 #pragma unroll
                     for (int ci = 0; ci < 16; ++ci)
-                        ev += w4tail(dlt < 0 ? 1 : 0, ci * 2 + co) * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
+                        ev += w4t[(dlt < 0 ? 32 : 0) + ci * 2 + co] * Df[((size_t)(ci >> 2) * kTileP1 + ps) * 4 + (ci & 3)];
                 }
                 M[(size_t)tl * 2 * kErbPad + co * kErbPad + (kErb - 1)] = tanh_f(ev);
             }
@@ -661,7 +673,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                     const int o = k - kErbLow;
                     m0 = 0.0f; m1 = 0.0f;
                     if (bs_lds) {
-                        const int s0 = bss[o];
+                        const int s0 = kLean ? bs_s[r > 0 ? r - 1 : 0] : bss[o];
                         for (int n = 0; n < bs.count; ++n) {
                             const float wv = bsw[n * kErbHigh + o];
                             const int jj = min(s0 + n, kErbBands - 1);
@@ -701,6 +713,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             //   (the windowed sample is ROUNDED, then added: a sample's two addends then commute, so the result depends neither on the tile
             //    size -- which frame of an overlapping pair adds first -- nor on a segment adding its predecessor's carry last: `park` below.
             //    Left to the compiler's contraction this was a fused multiply-add onto whichever addend happened to be there first.)
+            //   The accumulator is never cleared: the even pass WRITES (its frames tile the span without overlap; the first hop adds the carry of the previous
+            //   tile), the odd pass adds -- except the last frame's second half when no even frame follows, which it writes.
             const bool park = sg.prev && t0 == tbeg && wave == 0;      // first frame of a segment with a predecessor
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -712,14 +726,20 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                         float wa = pa * lt.win[2 * n], wb = pb * lt.win[2 * n + 1];
                         ADE_OPAQUE_V(wa);                                    // (the products are final: nothing downstream may re-fuse them)
                         ADE_OPAQUE_V(wb);
+                        float2* a = reinterpret_cast<float2*>(acc + kHop * wave + 2 * n);
                         if (park && r < 2) {                                 // first hop: waits in `pend` for the predecessor's carry
                             *reinterpret_cast<float2*>(pend + 2 * n) = make_float2(wa, wb);
-                        } else {
-                            float2* a = reinterpret_cast<float2*>(acc + kHop * wave + 2 * n);
+                        } else if (par == 0) {
+                            float2 c = make_float2(0.0f, 0.0f);
+                            if (wave == 0 && r < 2) c = *reinterpret_cast<const float2*>(cbuf + 2 * n);     // what the previous tile's last frame left
+                            *a = make_float2(c.x + wa, c.y + wb);
+                        } else if (r < 2 || wave + 1 < nf) {
                             float2 c = *a;
                             c.x += wa;
                             c.y += wb;
                             *a = c;
+                        } else {
+                            *a = make_float2(0.0f + wa, 0.0f + wb);
                         }
                     }
                 }
@@ -741,7 +761,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             float v[4], ws[4];
             ld4(acc + i, v);
             if (sg.prev && t0 == tbeg && i < kHop) continue;      // this hop waits for the predecessor's carry (after the tile loop)
-            ld4(wsum + (i & (kHop - 1)), ws);
+            if (kLean) { ws[0] = wsr[0]; ws[1] = wsr[1]; ws[2] = wsr[2]; ws[3] = wsr[3]; }       // (i = 4 tid there: one round)
+            else ld4(wsum + (i & (kHop - 1)), ws);
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = v[u] / ws[u];
             if (fo32) st4(fo32 + n, v);
@@ -753,14 +774,12 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             }
         }
         ADE_CLK_ACC(60);
-        __syncthreads();
-        // carry the half-finished last 256 samples to the front of acc, clear the rest
+        // the half-finished last 256 samples wait in cbuf for the next tile (acc itself dies with the next deconv3)
         {
             float carry = 0.0f;
             if (tf < kHop) carry = acc[kHop * nf + tf];
             if (sg.next && !has_next && tf < kHop) xst1(sg.xo + kXOlaOff + tf, carry);     // the last tile's carry belongs to the next segment
-            __syncthreads();
-            for (int i = tf; i < (int)kBackAccFloats; i += kFusedThreads) acc[i] = i < kHop ? carry : 0.0f;
+            if (tf < kHop) cbuf[tf] = carry;
         }
         // (the barrier at the top of the next tile orders these writes, and commit_s(), before their readers)
         ADE_CLK_ACC(61);

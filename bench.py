@@ -84,9 +84,9 @@ def parse_args():
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1"],
-                    help="GTCRN fused-path workgroup geometry: 1 = two 512-thread workgroups per CU, each a 32-frame segment of a chunk (default where it fits); "
-                         "0 = one 1024-thread workgroup per chunk (the round-1/2 kernel)")
+    ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1", "2"],
+                    help="GTCRN fused-path workgroup geometry: 2 = four 256-thread workgroups per CU, each a 16-frame segment of a chunk (default where it fits); "
+                         "1 = two 512-thread workgroups per CU (32-frame segments); 0 = one 1024-thread workgroup per chunk (the round-1/2 kernel)")
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of the `other_workloads` leg of the default line (ZipEnhancer 128 x 1 s, f32; 0 = skip)")
     ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed power-state ramp before the W warm-up steps (0 = none)")
     return ap.parse_args()
@@ -463,7 +463,7 @@ def main():
                                     "(BASELINE.json configs[1])") if gtcrn else wl["workload"],
                        "chunks_per_gpu": B, "chunk_samples": sess.in_len, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
                        "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)" if gtcrn else wl["weights"],
-                       "launch": (f"one kernel per step (k_gtcrn_chunk, geometry {int(geo[0])}: {int(geo[1])} workgroup(s) of {1024 if int(geo[0]) == 0 else 512} threads "
+                       "launch": (f"one kernel per step (k_gtcrn_chunk, geometry {int(geo[0])}: {int(geo[1])} workgroup(s) of {(1024, 512, 256)[int(geo[0])]} threads "
                                   "per chunk), plain launch") if gtcrn
                                  else "the sub-engine's launch sequence (replayed from a captured hipGraph unless --no-graph)",
                        "stitch_all_gather": bool(gathered is not None)},

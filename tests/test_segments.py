@@ -39,6 +39,7 @@ def test_hipsim_two_segments_equal_one_workgroup():
     whole = run(sess, x, "0")
     assert_same(whole, run(sess, x, "1"), "two segments, one launch")
     assert_same(whole, run(sess, x, "1", single="0"), "two segments, one launch per stage")
+    assert_same(whole, run(sess, x, "2"), "four segments of 16 frames (256-thread workgroups), one launch")
     opcm, of32 = GtcrnOracle(golden_blob(0), 16000).process(x)
     assert np.abs(whole[1] - of32).max() <= 1e-4 and np.abs(whole[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
 
@@ -52,6 +53,8 @@ def test_hipsim_three_and_four_segments_vs_oracle(length):
     sess = make_session(lib, seed=2, length=length)
     a, b = run(sess, x, "0"), run(sess, x, "1")
     assert_same(a, b, f"length {length}")
+    if length == 16384:
+        assert_same(a, run(sess, x, "2"), f"length {length}: five segments of 13 frames")
     opcm, of32 = GtcrnOracle(golden_blob(2), length).process(x)
     assert np.abs(a[1] - of32).max() <= 1e-4 and np.abs(a[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
 
@@ -63,8 +66,10 @@ def test_gpu_segments_bit_equal_at_benchmark_batch():
     sess = make_session(None, seed=0)
     whole = run(sess, x, "0")
     for rep in range(3):                                   # the hand-offs race differently every launch
-        assert_same(whole, run(sess, x, "1"), f"256 chunks, launch {rep}")
+        assert_same(whole, run(sess, x, "1"), f"256 chunks, two segments, launch {rep}")
+        assert_same(whole, run(sess, x, "2"), f"256 chunks, four segments, launch {rep}")
     assert_same(whole, run(sess, x, "1", single="0"), "256 chunks, one launch per stage")
+    assert_same(whole, run(sess, x, "2", single="0"), "256 chunks, four segments, one launch per stage")
 
 
 @pytest.mark.gpu
@@ -73,17 +78,21 @@ def test_gpu_segments_more_workgroups_than_the_chip_holds(batch):
     """600 / 1400 workgroups on 512 slots: later segments start while earlier chunks are still running, or long after their predecessor ended."""
     x = synth_batch(batch)
     sess = make_session(None, seed=1)
-    assert_same(run(sess, x, "0"), run(sess, x, "1"), f"batch {batch}")
+    whole = run(sess, x, "0")
+    assert_same(whole, run(sess, x, "1"), f"batch {batch}, two segments")
+    assert_same(whole, run(sess, x, "2"), f"batch {batch}, four segments")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("length", [16384, 20000, 32000, 60000])
 def test_gpu_three_to_eight_segments(length):
-    """T = 65, 79, 126, 235 frames: 3, 3, 4, 8 segments of geometry 1 against 2 - 4 segments of geometry 0 and the multi-kernel path."""
+    """T = 65, 79, 126, 235 frames: 3, 3, 4, 8 segments of geometry 1 (5, 5, 8, - of geometry 2) against 2 - 4 segments of geometry 0 and the multi-kernel path."""
     x = synth_batch(40, length)
     sess = make_session(None, seed=2, length=length)
     a, b = run(sess, x, "0"), run(sess, x, "1")
     assert_same(a, b, f"length {length}")
+    if length <= 32000:
+        assert_same(a, run(sess, x, "2"), f"length {length}, 16-frame segments")
     sess.set_option("fused", "0")
     m_pcm, m_f32 = sess.process(x, want_f32=True)
     sess.set_option("fused", "1")

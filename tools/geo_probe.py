@@ -46,6 +46,10 @@ for rep in range(2):
         print(f"rep {rep} geometry {geo} wave_swap {prio}: {ms:.4f} ms/step  ({B * 0.992 / ms * 1e3:.0f} audio-s/s)  xchg_error {err}", flush=True)
         if rep == 1:
             s.profile(3); s.process(x); s.process(x)
+            rel = s.tap('phase_clock', 1280).reshape(2, 10, 64)
+            for seg in range(2):
+                print(f"  seg {seg} front acc over tiles [stft+feat, conv0, conv1] us:", np.round(rel[seg, 0, 40:43] / 100, 1).tolist(), " mean", round(float(rel[seg, 0, 33] - rel[seg, 0, 32]) / 100, 1),
+                      "| back acc [top, deconv3, s-issue+deconv4, mask+irfft+ola, commit+finalize, carry] us:", np.round(rel[seg, 9, 56:62] / 100, 1).tolist())
             c = s.tap('phase_clock_abs', 1280).reshape(2, 10, 64)
             s.profile(0)
             for seg in range(2):
@@ -59,11 +63,7 @@ for rep in range(2):
                 for i in range(1, 9):
                     ph = c[seg, i, first[i]:last[i] + 1] / 100
                     print(f"    {names[i]} phase durations:", np.round(np.diff(ph), 1).tolist())
-print("geometry 2 == geometry 0:  pcm", np.array_equal(outs["0"][0], outs["2"][0]), " f32", np.array_equal(outs["0"][1], outs["2"][1]), " device-path pcm", np.array_equal(outs["0"][2], outs["2"][2]),
-      " taps", all(np.array_equal(outs["0"][3][n], outs["2"][3][n]) for n in outs["0"][3]))
-print("geometry 1 == geometry 0:  pcm", np.array_equal(outs["0"][0], outs["1"][0]), " f32", np.array_equal(outs["0"][1], outs["1"][1]),
-      " device-path pcm", np.array_equal(outs["0"][2], outs["1"][2]), " max|df32|", float(np.abs(outs["0"][1] - outs["1"][1]).max()))
-for n in outs["0"][3]:
-    a, b = outs["0"][3][n], outs["1"][3].get(n)
-    if b is not None:
-        print(f"  tap {n}: equal {np.array_equal(a, b)}  max|d| {float(np.abs(a - b).max()):.3g}")
+ks = sorted(outs)
+for k in ks[1:]:
+    print(f"geometry {k} == geometry {ks[0]}:  pcm", np.array_equal(outs[ks[0]][0], outs[k][0]), " f32", np.array_equal(outs[ks[0]][1], outs[k][1]), " device-path pcm",
+          np.array_equal(outs[ks[0]][2], outs[k][2]), " taps", all(np.array_equal(outs[ks[0]][3][n], outs[k][3][n]) for n in outs[ks[0]][3]))

@@ -5,6 +5,7 @@ TAG=$1; R=$PWD; O=$R/gpurun_out; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/${TAG}_gpu_tests.txt 2>&1; echo "gpu tests rc $?"; tail -3 $O/${TAG}_gpu_tests.txt
 timeout 300 python bench.py --geometry 0 --cpu-seconds 0 --other-steps 0 > $O/${TAG}_gtcrn_geometry0_bench.json 2> $O/${TAG}_bench0.err; echo "bench geo0 rc $?"
 timeout 600 python bench.py > $O/${TAG}_gtcrn_bench.json 2> $O/${TAG}_bench.err; echo "bench rc $?"
+timeout 300 python bench.py --geometry 1 --cpu-seconds 0 --other-steps 0 > $O/${TAG}_gtcrn_geometry1_bench.json 2>> $O/${TAG}_bench0.err
 timeout 300 python bench.py --geometry 0 --cpu-seconds 0 --other-steps 0 > $O/${TAG}_gtcrn_geometry0_bench_b.json 2>> $O/${TAG}_bench0.err
 timeout 300 python bench.py --cpu-seconds 0 --other-steps 0 > $O/${TAG}_gtcrn_bench_b.json 2>> $O/${TAG}_bench.err
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/${TAG}_prof -- python $R/bench.py --steps 100 --warmup 10 --cpu-seconds 0 --host-steps 0 --other-steps 0 > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.err); echo "rocprof rc $?"
