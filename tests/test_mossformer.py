@@ -223,7 +223,7 @@ def test_gpu_baseline_batch_64_windows_of_4s_properties():
     assert np.isfinite(f32).all() and not outs[5].any()
     d = outs[0].astype(np.int32) - z["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 2
-    assert np.abs(outs[0].astype(np.int32) - solo.reshape(2, W).astype(np.int32)).max() <= 1
+    assert np.array_equal(outs[0], solo.reshape(2, W))          # a row's bits do not depend on its batch (measured at B = 2, 3, 8, 33, 64: identical fp32 waveforms)
 
 
 @pytest.mark.gpu
