@@ -196,8 +196,7 @@ int fused_max_frames(int geometry) { return geometry == 2 ? Geo2::kTmax : (geome
 int fused_segments(int T, int geometry) { const int m = fused_max_frames(geometry); return (T + m - 1) / m; }
 bool fused_supported(int T, int geometry) {
     if (T < 2 || geometry < 0 || geometry > 2) return false;
-    const int n = fused_segments(T, geometry);
-    return n <= kMaxSegments && (n == 1 || T / n >= kXHistFrames);   // a segment must hold the history its successor needs
+    return fused_segments(T, geometry) <= kMaxSegments;      // (segments of any length: a short one passes its predecessor's history on)
 }
 
 hipError_t fused_init() {

@@ -272,21 +272,36 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     if (sg.next && tid >= G::kProdBase) {
         // History for the NEXT segment, on wavefronts that own no conv lane: lane (t', c) of its first 2 x dilation frames adds, to the
         // bias, the time taps that land in THIS segment's frames T + t' - (2 - kt) dilation -- kt ascending, exactly the head of the sum
-        // a whole-chunk workgroup forms for that frame.
+        // a whole-chunk workgroup forms for that frame.  A segment shorter than the history (a streaming push of two frames) passes on
+        // what it received: the sum for frame j = T + t' < 2 x dilation of ITS OWN numbering arrived from its predecessor with the taps
+        // older than this segment already in it, and only the taps that land in this segment's frames are added.
 #pragma unroll 1
         for (int u = tid - G::kProdBase; u < 2 * dilation * (kFw / 3); u += kFusedThreads - G::kProdBase) {      // (one round, except for the 256-thread geometry at dilation 5)
             const int tn = u / (kFw / 3), cn = u - tn * (kFw / 3);
             const bool lok = cn != 0, rok = cn != kFw / 3 - 1;
+            const int j = tn + T;                          // the successor's frame t' in this segment's numbering
             v2f acc[kPosPerThread][8];
+            if (sg.prev && j < 2 * dilation) {             // it starts before this segment's history ends: continue the predecessor's sum
+                const float* xhist_i = sg.xi + blk * kXHistFloats;
 #pragma unroll
-            for (int i = 0; i < kPosPerThread; ++i)
+                for (int i = 0; i < kPosPerThread; ++i)
 #pragma unroll
-                for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = xld4(xhist_i, (q * kXHistFrames * kFw + j * kFw + 3 * cn + i) * 4);
+                        acc[i][2 * q] = mk2(v.x, v.y);
+                        acc[i][2 * q + 1] = mk2(v.z, v.w);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kPosPerThread; ++i)
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const int tt = tn - (2 - kt) * dilation;
-                if (tt >= 0) continue;                     // that tap lies in the successor's own frames
-                dw_tap(acc, kt, (T + tt) * kFw + 3 * cn, lok, rok);
+                const int src = j - (2 - kt) * dilation;   // frame the tap reads: >= T lies in the successor's own frames, < 0 is already in the sum
+                if (src >= T || src < 0) continue;
+                dw_tap(acc, kt, src * kFw + 3 * cn, lok, rok);
             }
 #pragma unroll
             for (int i = 0; i < kPosPerThread; ++i)

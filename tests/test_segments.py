@@ -59,6 +59,19 @@ def test_hipsim_three_and_four_segments_vs_oracle(length):
     assert np.abs(a[1] - of32).max() <= 1e-4 and np.abs(a[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
 
 
+@pytest.mark.hipsim
+def test_hipsim_segments_shorter_than_the_convolution_history():
+    """T = 17 -> 9 + 8 frames under geometry 2: the dilation-5 blocks reach 10 frames back, over a whole segment -- the partial sums are passed on."""
+    lib = hipsim_library()
+    x = synth_batch(2, 4096)
+    sess = make_session(lib, seed=1, length=4096)
+    assert sess.frames == 17
+    a = run(sess, x, "0")
+    assert_same(a, run(sess, x, "2"), "T = 17, segments of 9 and 8 frames")
+    opcm, of32 = GtcrnOracle(golden_blob(1), 4096).process(x)
+    assert np.abs(a[1] - of32).max() <= 1e-4 and np.abs(a[0].astype(np.int32) - opcm.astype(np.int32)).max() <= 1
+
+
 @pytest.mark.gpu
 def test_gpu_segments_bit_equal_at_benchmark_batch():
     """256 x 1 s: geometry 1 (512 workgroups, two per CU, hand-offs through device memory) == geometry 0 (one workgroup per chunk), every tap."""
