@@ -789,6 +789,16 @@ struct ade_stream {
     float* tra_h[6] = {};
     float* inter_h[2] = {};
     float* carry = nullptr;
+    // fused pushes (the single-launch chunk kernel with a carried state, ade_internal.h SegPlan::carry_in / carry_out): decided when the stream is created
+    bool fused = false;
+    int geo = -1, geo_flush = -1;
+    ade::ChunkFixed* d_fixed = nullptr;   // the chunk kernel's per-engine block with THIS stream's push workspace
+    float* xq = nullptr;                  // exchange slots between the segments of one push [S][segments][kXFloats]
+    unsigned* xq_flags = nullptr;
+    float* xstate[2] = {};                // the state a push leaves for the next one, ping-ponged [S][kXFloats]
+    unsigned* xstate_flags[2] = {};
+    int xcur = 0;
+    int* xerr = nullptr;                  // page-locked: a bounded inter-workgroup wait gave up
     float* ws = nullptr;         // activations of one push, same tensor set as the engine's multi-kernel workspace
     float *spec = nullptr, *feat = nullptr, *e0 = nullptr, *e1 = nullptr, *h = nullptr, *zt = nullptr, *rnn = nullptr, *d3 = nullptr, *mask = nullptr,
           *frames = nullptr, *xe[3] = {}, *ate[3] = {}, *xd[3] = {}, *atd[3] = {}, *dpm[2] = {}, *dpo[2] = {};
@@ -804,6 +814,28 @@ void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t*
     else {
         launch_stream_concat(s, st->pcm_hist, d_in, st->concat, B, P, st->first);
         launch_stream_keep(s, st->concat, st->pcm_hist, st->pcm_prev, B, P);
+    }
+    if (st->fused) {
+        // ONE launch for the whole push: the chunk kernel on rows [256 carried samples | the push], its first segment continuing from the exchange slot the previous
+        // push's last segment filled (conv partial sums, TRA / inter-GRU states, overlap-add carry), its last segment filling the other slot for the next push.
+        const int geo = flush ? st->geo_flush : st->geo;
+        ChunkCall C{};
+        C.fixed = st->d_fixed;
+        C.pcm_in = st->concat; C.pcm_out = d_out; C.f32_out = d_f32; C.dc = st->dc;
+        C.L = P + kHop; C.T = T; C.B = B;
+        SegPlan plan{};
+        plan.nseg = fused_segments(T, geo);
+        plan.xchg = st->xq; plan.flags = st->xq_flags; plan.err = st->xerr;
+        plan.carry_in = st->first ? nullptr : st->xstate[st->xcur];
+        plan.carry_in_flags = st->first ? nullptr : st->xstate_flags[st->xcur];
+        plan.carry_out = st->xstate[st->xcur ^ 1];
+        plan.carry_out_flags = st->xstate_flags[st->xcur ^ 1];
+        plan.stream = 1;
+        C.plan = plan;
+        launch_gtcrn_chunk(s, geo, C);
+        st->xcur ^= 1;
+        st->first = false;
+        return;
     }
     launch_stft_pcm(s, st->concat, st->dc, B, P + kHop, T, e->tabs, e->erb_bm, st->spec, st->feat, /*center=*/false);
     launch_conv0(s, st->feat, e->en0, st->e0, nfr);
@@ -1622,6 +1654,33 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
         hipHostMalloc((void**)&st->h_out, S * P * sizeof(int16_t), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&st->h_f32, S * P * sizeof(float), hipHostMallocDefault) != hipSuccess)
         return bail("ade_stream_create: allocation of the PCM staging buffers failed");
+    // Fused pushes: possible whenever the frame count of a push fits a fused geometry (every push of up to 512 frames) and the engine's fused path is on.
+    {
+        int geo = -1, geo1 = -1;
+        for (int g = fused_geometries() - 1; g >= 0 && geo < 0; --g)
+            if ((h->geometry < 0 || h->geometry == g) && fused_supported(frames_per_push, g)) geo = g;
+        for (int g = fused_geometries() - 1; g >= 0 && geo1 < 0; --g)
+            if (fused_supported(2, g)) geo1 = g;                       // the flush is a one-frame push
+        if (h->use_fused && h->use_single && geo >= 0 && geo1 >= 0) {
+            const int nseg = fused_segments(frames_per_push, geo);
+            ChunkFixed F{};
+            F.tabs = h->tabs; F.erb_bm = h->erb_bm; F.erb_bs = h->erb_bs;
+            F.en0 = h->en0; F.en1 = h->en1; F.de3 = h->de3; F.de4 = h->de4;
+            for (int i = 0; i < 3; ++i) { F.en_gt[i] = h->en_gt[i]; F.de_gt[i] = h->de_gt[i]; F.xe[i] = st->xe[i]; F.xd[i] = st->xd[i]; }
+            for (int i = 0; i < 2; ++i) { F.dp[i] = h->dp[i]; F.dpo[i] = st->dpo[i]; }
+            F.spec = st->spec; F.e0 = st->e0; F.e1 = st->e1;
+            if (hipMalloc((void**)&st->d_fixed, sizeof(ChunkFixed)) != hipSuccess || hipMemcpy(st->d_fixed, &F, sizeof(ChunkFixed), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMalloc((void**)&st->xq, S * nseg * (size_t)kXFloats * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&st->xq_flags, S * nseg * (size_t)kXFlags * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc((void**)&st->xstate[0], S * (size_t)kXFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&st->xstate[1], S * (size_t)kXFloats * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&st->xstate_flags[0], S * (size_t)kXFlags * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc((void**)&st->xstate_flags[1], S * (size_t)kXFlags * sizeof(unsigned)) != hipSuccess ||
+                hipHostMalloc((void**)&st->xerr, sizeof(int), hipHostMallocDefault) != hipSuccess)
+                return bail("ade_stream_create: allocation of the fused-push state failed");
+            *st->xerr = 0;
+            st->fused = true; st->geo = geo; st->geo_flush = geo1;
+        }
+    }
     h->live_streams.push_back(st);
     const ade_status rc = ade_stream_reset(st);
     if (rc != ADE_OK) {
@@ -1641,6 +1700,13 @@ ade_status ade_stream_reset(ade_stream_handle st) {
     HIP_TRY(h, hipMemset(st->pcm_hist, 0, (size_t)st->S * kHop * sizeof(int16_t)));
     HIP_TRY(h, hipMemset(st->pcm_prev, 0, (size_t)st->S * sizeof(int16_t)));
     for (int i = 0; i < 6; ++i) st->hist_cur[i] = 0;
+    if (st->fused) {           // no flag of an abandoned signal may survive into the next one
+        const int nseg = fused_segments(st->N, st->geo);
+        HIP_TRY(h, hipMemset(st->xq_flags, 0, (size_t)st->S * nseg * kXFlags * sizeof(unsigned)));
+        for (int i = 0; i < 2; ++i) HIP_TRY(h, hipMemset(st->xstate_flags[i], 0, (size_t)st->S * kXFlags * sizeof(unsigned)));
+        st->xcur = 0;
+        *st->xerr = 0;
+    }
     st->first = true;
     st->flushed = false;
     return ADE_OK;
@@ -1671,6 +1737,7 @@ ade_status ade_stream_push(ade_stream_handle st, const int16_t* in, int16_t* out
     HIP_TRY(h, hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(st->h_f32, st->d_f32, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (st->xerr && *(volatile int*)st->xerr) return fail(h, ADE_ERR_DEVICE, "ade_stream_push: a segment of the fused push timed out waiting for its predecessor");
     if (out_pcm) memcpy(out_pcm, st->h_out, n * sizeof(int16_t));
     if (out_f32) memcpy(out_f32, st->h_f32, n * sizeof(float));
     return ADE_OK;
@@ -1688,6 +1755,7 @@ ade_status ade_stream_flush(ade_stream_handle st, int16_t* out_pcm, float* out_f
     HIP_TRY(h, hipMemcpyAsync(st->h_out, st->d_out, n * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(st->h_f32, st->d_f32, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (st->xerr && *(volatile int*)st->xerr) return fail(h, ADE_ERR_DEVICE, "ade_stream_flush: a segment of the fused push timed out waiting for its predecessor");
     if (out_pcm) memcpy(out_pcm, st->h_out, n * sizeof(int16_t));
     if (out_f32) memcpy(out_f32, st->h_f32, n * sizeof(float));
     return ADE_OK;
@@ -1708,6 +1776,12 @@ void release_stream_buffers(ade_stream* st) {
     if (st->h_in) (void)hipHostFree(st->h_in);
     if (st->h_out) (void)hipHostFree(st->h_out);
     if (st->h_f32) (void)hipHostFree(st->h_f32);
+    if (st->d_fixed) (void)hipFree(st->d_fixed);
+    if (st->xq) (void)hipFree(st->xq);
+    if (st->xq_flags) (void)hipFree(st->xq_flags);
+    for (int i = 0; i < 2; ++i) { if (st->xstate[i]) (void)hipFree(st->xstate[i]); if (st->xstate_flags[i]) (void)hipFree(st->xstate_flags[i]); st->xstate[i] = nullptr; st->xstate_flags[i] = nullptr; }
+    if (st->xerr) (void)hipHostFree(st->xerr);
+    st->d_fixed = nullptr; st->xq = nullptr; st->xq_flags = nullptr; st->xerr = nullptr;
     st->state = st->ws = nullptr;
     st->pcm_hist = st->pcm_prev = st->concat = st->d_in = st->d_out = st->h_in = st->h_out = nullptr;
     st->d_f32 = st->h_f32 = nullptr;

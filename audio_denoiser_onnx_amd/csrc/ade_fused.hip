@@ -41,12 +41,24 @@ __device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int b
     sg.prev = seg > 0;
     sg.next = seg + 1 < plan.nseg;
     sg.swap = plan.wave_swap && (seg & 1);
+    sg.stream = plan.stream;
     const size_t slot = (size_t)chunk * plan.nseg + seg;
     sg.xo = plan.xchg + slot * kXFloats;
     sg.xi = plan.xchg + (slot - (seg > 0 ? 1 : 0)) * kXFloats;
     sg.fo = plan.flags + slot * kXFlags;
     sg.fi = plan.flags + (slot - (seg > 0 ? 1 : 0)) * kXFlags;
     sg.err = plan.err;
+    if (seg == 0 && plan.carry_in) {                 // a stream's push: continue from what the previous push's last segment left
+        sg.prev = 1;
+        sg.xi = plan.carry_in + (size_t)chunk * kXFloats;
+        sg.fi = plan.carry_in_flags + (size_t)chunk * kXFlags;
+    }
+    if (seg + 1 == plan.nseg && plan.carry_out) {
+        sg.next = 1;
+        sg.xo = plan.carry_out + (size_t)chunk * kXFloats;
+        sg.fo = plan.carry_out_flags + (size_t)chunk * kXFlags;
+    }
+    sg.first = !sg.prev;
     return sg;
 }
 __device__ __forceinline__ long long* seg_clk(long long* clk, const Seg& sg, int B, int block) {

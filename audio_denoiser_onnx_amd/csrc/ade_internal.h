@@ -157,11 +157,20 @@ struct SegPlan {           // how a launch splits its chunks (host-computed, pas
     unsigned* flags;       // [B][nseg][kXFlags], zero between launches
     int* err;              // sticky: a bounded wait gave up
     int wave_swap;         // 1: odd segments run their conv lanes on wavefronts 0-3, 6, 7 instead of 0-5 (see gtblock_stage)
+    // STREAMS (ade_stream_*): a push is a chunk whose first segment continues the state its last segment left one launch earlier -- the same exchange slots, one per
+    // stream, ping-ponged between pushes -- framed without centre padding and emitted one hop behind (include/ade.h).
+    float* carry_in;       // [B][kXFloats] state the FIRST segment of every chunk continues from (null: a fresh signal)
+    unsigned* carry_in_flags;
+    float* carry_out;      // [B][kXFloats] state the LAST segment leaves (null: nothing follows)
+    unsigned* carry_out_flags;
+    int stream;            // 1: streaming framing -- frame t reads samples 256 t .. 256 t + 511 of the row (256 carried + the push), output sample n = overlap-add sample n
 };
 struct Seg {               // one workgroup's share (device-side)
     int t0, nT, T;         // first frame, frames owned, frames of the chunk
     int prev, next;        // there is a segment before / after this one
     int swap;              // this workgroup permutes its upper wavefronts (SegPlan::wave_swap, odd segments)
+    int stream;            // SegPlan::stream
+    int first;             // nothing precedes this segment at all: a chunk's / stream's very first frames
     float* xo;             // exchange slot this segment fills (for the next one)
     float* xi;             // exchange slot of the previous segment
     unsigned* fo;          // flags this segment raises

@@ -56,11 +56,12 @@ __device__ __forceinline__ LdsTabs stage_tables(float* dst, const FftTabs& t, in
 
 // The 4 sample pairs (2n, 2n+1), n = lane + 64 r, of frame t that this lane windows: packed int16 pairs, reflect-padded
 // at the chunk edges (STFT_Process.py:306-309).  Plain loads, no dependence on the DC mean: issued a whole tile ahead.
-__device__ __forceinline__ void load_frame_pairs(const int16_t* __restrict__ row, int L, int t, int lane, bool live, bool pair_ok, int* raw) {
+// centre = 0 (streams): the row is [256 carried samples | the push], frame t reads its samples 256 t .. 256 t + 511 as they are.
+__device__ __forceinline__ void load_frame_pairs(const int16_t* __restrict__ row, int L, int t, int lane, bool live, bool pair_ok, int* raw, int centre = kNfft / 2) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = lane + 64 * r;
-        const int j0 = kHop * t + 2 * n - kNfft / 2;             // even index of the pair
+        const int j0 = kHop * t + 2 * n - centre;                // even index of the pair
         if (!live) {
             raw[r] = 0;
         } else if (pair_ok && j0 >= 0 && j0 + 1 < L) {            // interior: one aligned 32-bit load
@@ -132,7 +133,8 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
     ADE_CLK(32);
     const bool pair_ok = ((L & 1) == 0) && ((reinterpret_cast<size_t>(row) & 3) == 0);
     int raw[4];                                            // tile 0's samples: in flight while the mean is computed
-    load_frame_pairs(row, L, tbeg + wave, lane, tbeg + wave < tend, pair_ok, raw);
+    const int centre = sg.stream ? 0 : kNfft / 2;
+    load_frame_pairs(row, L, tbeg + wave, lane, tbeg + wave < tend, pair_ok, raw, centre);
     const LdsTabs lt = stage_tables<G>(tabmem, tabs, tid);
     const bool erb_lds = erb.count <= kBmRows;
     if (erb_lds)
@@ -195,7 +197,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
             }
             {   // the next tile's samples: issued now, consumed after this tile's two conv phases
                 const int tn = t + kTileF;
-                load_frame_pairs(row, L, tn, lane, tn < tend, pair_ok, raw);
+                load_frame_pairs(row, L, tn, lane, tn < tend, pair_ok, raw, centre);
             }
             fft256_inplace(v, buf, lane, lt.tw256);
             wave_sync();                                       // last pass's reads are done (buffer is wave-private)
@@ -428,7 +430,8 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
     const float* e1c = e1 + (size_t)chunk * kCh * P;
     const float* e0c = e0 + (size_t)chunk * kCh * P0;
     const float* specc = spec + (size_t)chunk * T * 2 * kBinsPad;
-    const int out_len = kHop * (T - 1);
+    const int trim = sg.stream ? 0 : kHop;                     // one-shot calls drop the first half window of the overlap-add (centre padding); streams emit it, one hop behind
+    const int out_len = sg.stream ? kHop * T : kHop * (T - 1);
     int16_t* po = pcm ? pcm + (size_t)chunk * out_len : nullptr;
     float* fo32 = f32 ? f32 + (size_t)chunk * out_len : nullptr;
     ADE_CLK(48);
@@ -756,10 +759,11 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         ADE_OPAQUE_V(tf);
         for (int i4 = tf; i4 < nf * (kHop / 4); i4 += kFusedThreads) {
             const int i = i4 * 4;
-            const int n = kHop * t0 + i - kHop;
+            const int n = kHop * t0 + i - trim;
             if (n < 0 || n >= out_len) continue;
             float v[4], ws[4];
             ld4(acc + i, v);
+            if (sg.stream && sg.first && t0 == 0 && i < kHop) { v[0] = 0.0f; v[1] = 0.0f; v[2] = 0.0f; v[3] = 0.0f; }   // a stream's very first hop has no predecessor: blank
             if (sg.prev && t0 == tbeg && i < kHop) continue;      // this hop waits for the predecessor's carry (after the tile loop)
             if (kLean) { ws[0] = wsr[0]; ws[1] = wsr[1]; ws[2] = wsr[2]; ws[3] = wsr[3]; }       // (i = 4 tid there: one round)
             else ld4(wsum + (i & (kHop - 1)), ws);
@@ -796,7 +800,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         ADE_OPAQUE_V(tf);
         for (int i4 = tf; i4 < kHop / 4; i4 += kFusedThreads) {
             const int i = i4 * 4;
-            const int n = kHop * tbeg + i - kHop;
+            const int n = kHop * tbeg + i - trim;
             float v[4], ws[4];
             ld4(pend + i, v);
             ld4(wsum + i, ws);

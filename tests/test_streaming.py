@@ -76,6 +76,44 @@ def test_gpu_streaming_equals_one_shot():
     assert np.array_equal(pcm4, pcm)
 
 
+def fused_vs_multikernel(library, frames_per_push, n_push=4):
+    """A push as ONE launch of the chunk kernel (carried exchange slot) vs the 48-launch multi-kernel push (option fused = 0 when the stream is created): the same stream."""
+    rng = np.random.default_rng(7)
+    P = frames_per_push * HOP
+    sig = np.stack([zero_sum_signal(rng, n_push * P) for _ in range(3)])
+    outs = []
+    for fused in ("1", "0"):
+        sess = make_session(library, seed=2, length=16000)
+        sess.set_option("fused", fused)
+        with StreamingSession(sess, 3, frames_per_push) as st:
+            parts = [st.push(sig[:, i * P:(i + 1) * P], want_f32=True) for i in range(n_push)] + [st.flush(want_f32=True)]
+        outs.append((np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)))
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= 2e-5
+    assert np.abs(outs[0][0].astype(np.int32) - outs[1][0].astype(np.int32)).max() <= 1
+    assert not np.array_equal(outs[0][1], outs[1][1])          # (two implementations of the same arithmetic: if they were identical the option did nothing)
+
+
+@pytest.mark.hipsim
+def test_hipsim_fused_push_equals_multikernel_push():
+    fused_vs_multikernel(hipsim_library(), 3, n_push=3)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_push_equals_multikernel_push_and_segments():
+    fused_vs_multikernel(None, 2)
+    fused_vs_multikernel(None, 40)             # 40 frames per push: three 16-frame segments per stream and launch, the last one carrying into the next push
+    # many streams, more workgroups than the chip holds: 3000 streams x 2 frames
+    rng = np.random.default_rng(3)
+    sig = np.stack([zero_sum_signal(rng, 4 * 2 * HOP)] * 2 + [zero_sum_signal(rng, 4 * 2 * HOP)])
+    big = np.concatenate([sig] * 1000)
+    sess = make_session(None, seed=0)
+    with StreamingSession(sess, 3000, 2) as st:
+        a = np.concatenate([st.push(big[:, i * 512:(i + 1) * 512]) for i in range(4)], axis=1)
+    with StreamingSession(sess, 3, 2) as st:
+        b = np.concatenate([st.push(sig[:, i * 512:(i + 1) * 512]) for i in range(4)], axis=1)
+    assert np.array_equal(a[:3], b) and np.array_equal(a[2997:], b)
+
+
 @pytest.mark.gpu
 def test_gpu_streaming_rejects_other_families_and_bad_sizes():
     sess = make_session(None, seed=0)

@@ -29,8 +29,10 @@ def main():
     ap.add_argument("--streams", default="256,1024")
     ap.add_argument("--frames", default="2,4,16,62")
     ap.add_argument("--pushes", type=int, default=50)
+    ap.add_argument("--fused", default="1", help="1: a push is ONE launch of the chunk kernel with a carried state (default); 0: the 48-launch multi-kernel push")
     a = ap.parse_args()
     sess = make_session(None, seed=0)
+    sess.set_option("fused", a.fused)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     for S in [int(x) for x in a.streams.split(",")]:
