@@ -146,7 +146,9 @@ ade_status ade_istft_forward(ade_handle h, const float* d_spec, int batch, int f
  * on the whole signal in one call (every op of the network is causal in time), with two stated differences: the output is one
  * hop (256 samples, 16 ms) behind the input -- a frame is complete one hop after its centre -- with the stream's first hop zero;
  * and the per-call DC removal of GTCRN_CUSTOM.forward (Export_GTCRN.py:647, a mean over the WHOLE call, not computable causally)
- * is not applied.  GTCRN handles only (not batch-fold, not the other model families).  All streams of a handle advance together. */
+ * is not applied.  GTCRN handles only (not batch-fold, not the other model families).  All streams of a handle advance together.
+ * A push of up to 512 frames is ONE kernel launch (the fused chunk kernel continuing from the state its previous launch left); longer pushes, or a
+ * stream created while the option "fused" is 0, take the multi-kernel sequence. */
 typedef struct ade_stream* ade_stream_handle;
 ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, ade_stream_handle* out);
 /* in / out: [n_streams][frames_per_push * 256] int16 (out_f32 optional float, pre-PCM-tail), caller-owned HOST buffers; synchronous. */
