@@ -911,7 +911,15 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // (Stereo/STFT_Process.py:296-306), UL-UNAS's slices that to the caller-rate input length (Export_UL_UNAS.py:851, 888-889); the engine still serves ONE input
         // length per handle.  The other families' dynamic exports are not built (their static exports resample consistently).
         const bool fam_sand = fam_melband || fam_ulu;       // families whose resampling follows GTCRN_CUSTOM's scale-factor sandwich and needs dynamic axes
-        if (dyn_d && !fam_sand) return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer and ul_unas (static shapes only for " + fam + ")"));
+        // DFSMN's dynamic export (Export_DFSMN.py:28, :186-187, :236-237, :274) differs from its static one in two places only: the edges interpolate by SCALE FACTOR
+        // (floor(n * factor) samples, source step 1 / factor), and the ISTFT builds its overlap-add denominator from the actual frame count -- which IS the static
+        // denominator of that count (no centre padding: nothing is trimmed).  Any input length of at least one frame.
+        // ZipEnhancer's (Export_ZipEnhancer.py:31, :61, :828-829, :898-899, :907-908; STFT_Process.py:294-299): the same two places -- its ISTFT trims half a window on
+        // both sides in either mode, so the output is still 100 (T - 1) samples, cut to the model-rate input length (a no-op), but DIVIDED by the denominator instead of
+        // multiplied by its precomputed reciprocal; the position tables are slices of the same 1024-frame table either way.
+        const bool dyn_sf = dyn_d && (fam_dfsmn || fam_zip);
+        if (dyn_d && !fam_sand && !dyn_sf)
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer, ul_unas, dfsmn and zipenhancer (static shapes only for " + fam + ")"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
         if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
@@ -946,7 +954,8 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         const long caller_len = Ld;
         if (rates_differ) {   // MODEL_AUDIO_LENGTH = round(L * model / in) (:36); batch-fold needs equal rates (:92-93)
             if (fold_d) return bail(fail(e, ADE_ERR_BAD_VALUE, "Batch folding requires equal input/model/output sample rates."));
-            Ld = fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
+            Ld = dyn_sf ? (long)floor((double)caller_len * ((double)srm / (double)sri))               // F.interpolate(scale_factor = float(MODEL / IN))
+                 : fam_hg ? (long)((double)caller_len * (double)srm / (double)sri)                      // int(EXPORT_AUDIO_LENGTH * MODEL / IN) (:45)
                  : fam_melband ? (long)floor((double)caller_len * ((double)srm / (double)sri))       // F.interpolate(scale_factor = float(MODEL / IN)) (Export_MelBandRoformer.py:52, 631-644)
                  : fam_ulu ? (long)floor((double)caller_len * (1.0 / ((double)sri / 16000.0)))       // scale_factor = 1 / (in_sample_rate / 16000.0) (Export_UL_UNAS.py:835-837, 852-868)
                         : (long)nearbyint((double)caller_len * (double)srm / (double)sri)   /* Python round(): half to even */;
@@ -991,7 +1000,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, dyn_d ? (int)caller_len : 0, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
-                       : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, device, &e->sub, derr)
+                       : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
@@ -1021,7 +1030,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             e->rs_model_in = e->sub->in_len();
             e->rs_model_out = e->sub->out_len();
             long out_caller;
-            if (fam_hg) {   // F.interpolate(scale_factor = ...) (Export_H_GTCRN.py:953-970, 1036-1052): floor(length * factor) samples, source step 1 / factor
+            if (fam_hg || dyn_sf) {   // F.interpolate(scale_factor = ...) (Export_H_GTCRN.py:953-970, 1036-1052; DFSMN's dynamic export): floor(length * factor) samples, source step 1 / factor
                 out_caller = (long)floor((double)e->rs_model_out * ((double)sro / (double)srm));
                 e->rs_scale_in = (float)((double)sri / (double)srm);
                 e->rs_scale_out = (float)((double)srm / (double)sro);

@@ -973,9 +973,10 @@ struct PlanarA {               // synthesis A operand: A(j, c) = packed[c][j]
     int J;
     __device__ float operator()(int j, int c) const { return p[(size_t)c * J + j]; }
 };
-// overlap-add gather, x 1 / sum w^2, x the window's norm factor, then the PCM tail (:893-918)
+// overlap-add gather, x 1 / sum w^2 (the static export's precomputed reciprocal, STFT_Process.py:245-249, :294-295) or / sum w^2 (divide = 1: the dynamic export builds
+// the denominator from the frame count and divides, :297-299), x the window's norm factor, then the PCM tail (:893-918)
 __global__ __launch_bounds__(256) void k_zip_ola_pcm(const float* __restrict__ frames, const float* __restrict__ inv_wsum, const float* __restrict__ norm,
-                                                     int16_t* __restrict__ pcm, float* __restrict__ f32, int T, int L, long long total) {
+                                                     int16_t* __restrict__ pcm, float* __restrict__ f32, int T, int L, int divide, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int r = (int)(i / L), m = (int)(i - (long long)r * L) + kZN / 2;
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(256) void k_zip_ola_pcm(const float* __restrict__ f
     const int t_lo = m - kZN + 1 <= 0 ? 0 : (m - kZN + kZHop) / kZHop;
     float s = 0.0f;
     for (int t = t_lo; t <= t_hi; ++t) s += frames[((size_t)r * T + t) * kZN + (m - t * kZHop)];
-    float y = (s * inv_wsum[m - kZN / 2]) * norm[r];
+    float y = (divide ? s / inv_wsum[m - kZN / 2] : s * inv_wsum[m - kZN / 2]) * norm[r];
     if (f32) f32[i] = y;
     if (pcm) {
         if (y != y) y = 0.0f;                                                   // NaN -> 0 (:917)
@@ -1053,6 +1054,7 @@ struct ZipEngine : SubEngine {
     bool exact = false, bf16 = false;     // bf16: ade_gemm_dtype = "bf16" -- every 256 x 64 GEMM takes bf16 inputs (fp32 accumulation); front / attention / norms / PCM tail stay fp32
     float* d_w = nullptr;
     const float *k_fwd = nullptr, *k_inv = nullptr, *inv_wsum = nullptr;
+    bool dynamic_norm = false;         // a DYNAMIC_AXES export: inv_wsum holds sum w^2 itself and the overlap-add divides
     const float *c1_w = nullptr, *c1_b = nullptr, *c1_g = nullptr, *c1_beta = nullptr, *c1_slope = nullptr;
     const float *c2_w = nullptr, *c2_b = nullptr, *c2_g = nullptr, *c2_beta = nullptr, *c2_slope = nullptr;
     ZDense enc_dense{}, dec_dense{};
@@ -1088,7 +1090,7 @@ struct ZipEngine : SubEngine {
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
 
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, int device, SubEngine** out, std::string& err) {
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return zfail(err, ADE_ERR_BAD_VALUE, "zipenhancer: n_win must be >= 1");
     if (window_len < kZN || (n_win > 1 && window_len % kZHop))
@@ -1118,6 +1120,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     if (e->qd != 16 || e->pd != 4)
         return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: the attention kernel is built for query_head_dim 16 and pos_head_dim 4"));
     e->T = window_len / kZHop + 1;
+    e->dynamic_norm = dynamic;
     e->Lo = kZHop * (e->T - 1);                       // STFT (centre pad) -> ISTFT reconstructs whole hops (STFT_Process.py:168-172)
     e->F = (kZF + 2 - 3) / 2 + 1;
     e->dT = (e->T + e->dst - 1) / e->dst;
@@ -1239,7 +1242,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
         std::vector<float> raw((size_t)N + (size_t)kZHop * (e->T - 1), 0.0f);
         for (int t = 0; t < e->T; ++t)
             for (int n = 0; n < N; ++n) raw[(size_t)t * kZHop + n] += win[n] * win[n];
-        for (int m = 0; m < e->Lo; ++m) iws[m] = 1.0f / raw[(size_t)m + N / 2];          // inv_win_sum (static_norm, :245-249)
+        for (int m = 0; m < e->Lo; ++m) iws[m] = dynamic ? raw[(size_t)m + N / 2] : 1.0f / raw[(size_t)m + N / 2];          // inv_win_sum (static_norm, :245-249); the sum itself for a dynamic export
         bind(&e->k_fwd, place(fwd.data(), fwd.size())); bind(&e->k_inv, place(inv.data(), inv.size())); bind(&e->inv_wsum, place(iws.data(), iws.size()));
     }
     // ---- projected position tables (:597-604): rows x = -(n - 1) .. n - 1 of CompactRelPositionalEncoding (the published Zipformer2 table, fp32 like
@@ -1428,7 +1431,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
                        phase_w, phase_b, packed, mask_tap, T, F2, C, J);
     gemm::launch(s, PlanarA{packed, J}, gemm::RowMajorB{k_inv, kZN}, gemm::BiasActStore<gemm::kActNone>{frames_buf, kZN, nullptr, 0.0f}, J, kZN, kZC2);
     const long long total = (long long)B * Lo;
-    hipLaunchKernelGGL(k_zip_ola_pcm, flat(total), dim3(256), 0, s, (const float*)frames_buf, inv_wsum, (const float*)norm, d_out, d_f32, T, Lo, total);
+    hipLaunchKernelGGL(k_zip_ola_pcm, flat(total), dim3(256), 0, s, (const float*)frames_buf, inv_wsum, (const float*)norm, d_out, d_f32, T, Lo, dynamic_norm ? 1 : 0, total);
     ZP_HIP(hipGetLastError());
     return ADE_OK;
 }

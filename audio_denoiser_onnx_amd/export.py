@@ -158,7 +158,8 @@ def export_hgtcrn(checkpoint, out_dir, input_audio_length: int = 32000, use_batc
     return model_path
 
 
-def export_zipenhancer(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = True, name: str = "ZipEnhancer") -> Path:
+def export_zipenhancer(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = True, name: str = "ZipEnhancer", dynamic_axes: bool = False,
+                       in_sample_rate: int = 16000, out_sample_rate: int = 16000) -> Path:
     """ModelScope ``speech_zipenhancer_ans_multiloss_16k_base`` state dict -> ``<name>.adew`` + manifest (the constructor folds of
     ZipEnhancer/Export_ZipEnhancer.py:437-664 minus ONNX; the reference's default export folds 1.5 s windows, :57-60).  The geometry is read from the
     tensor shapes; wrapper prefixes (``module.``, ``model.``, ``generator.``) are dropped; training-only tensors (balancers, whiteners) are ignored."""
@@ -173,7 +174,8 @@ def export_zipenhancer(checkpoint, out_dir, input_audio_length: int = 32000, use
                 k = k[len(pre):]
         sd[k] = v
     save_blob(model_path, zp.fuse_state_dict(sd, zp.config_from_state_dict(sd)))
-    write_metadata(model_path, zp.metadata(input_audio_length, use_batch_fold=use_batch_fold))
+    write_metadata(model_path, zp.metadata(input_audio_length, use_batch_fold=use_batch_fold and not dynamic_axes, dynamic_axes=dynamic_axes,    # (DYNAMIC_AXES, :31)
+                                           in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate))
     return model_path
 
 
@@ -217,7 +219,8 @@ def main(argv=None) -> int:
     elif family == "h_gtcrn":
         path = export_hgtcrn(argv[0], argv[1], length or 32000, fold)
     elif family == "zipenhancer":
-        path = export_zipenhancer(argv[0], argv[1], length or 32000, fold)
+        path = export_zipenhancer(argv[0], argv[1], length or 32000, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"],
+                                  out_sample_rate=gt["out_sample_rate"])
     else:
         path = export_gtcrn(argv[0], argv[1], length or 16000, **gt)
     print(f"Export done: {path} (+ {path.with_name(path.stem + '_Metadata.json').name})")

@@ -323,19 +323,23 @@ def synthetic_tensors(cfg: ZipConfig, seed: int = 0) -> Dict[str, np.ndarray]:
 
 
 def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window_seconds: float = 1.5, in_sample_rate: int = SAMPLE_RATE,
-             out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32", dft_tables: str = "reference") -> Dict[str, str]:
+             out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32", dft_tables: str = "reference", dynamic_axes: bool = False) -> Dict[str, str]:
     """Manifest of a static export (Export_ZipEnhancer.py:977-981).  Without batch-fold ``input_audio_length`` must be whole hops (the
     reference's STFT -> ISTFT pair reconstructs (T - 1) * 100 samples; its default export always folds, :58-60).
     ``gemm_dtype``: "f32" = exact fp32 matrix-core products (the parity path, default); "bf16" = bf16 inputs with fp32 accumulation in every
     projection / convolution GEMM (BASELINE.json's dtype for this model; front end, attention core, norms and PCM tail stay fp32, the sub-paths the
     reference's own fp16 plan keeps in fp32, ZipEnhancer/Optimize_ONNX.py:25-64).  ``dft_tables``: "reference" (its fp32-angle tables) | "exact"."""
-    if not use_batch_fold and input_audio_length % HOP and in_sample_rate == SAMPLE_RATE:
+    # ``dynamic_axes``: the DYNAMIC_AXES export (:31, :61, :828-829, :898-899, :907-908): any input length, scale-factor interpolation on the edges, the ISTFT divides by
+    # the overlap-add denominator of the actual frame count; the handle still serves ONE input length.
+    if dynamic_axes and use_batch_fold:
+        raise ValueError("Batch folding requires static axes.")
+    if not dynamic_axes and not use_batch_fold and input_audio_length % HOP and in_sample_rate == SAMPLE_RATE:
         raise ValueError(f"input_audio_length must be a multiple of the hop ({HOP}) without batch-fold")
     return build_audio_metadata(producer="audio_denoiser_onnx_amd", model_name="ZipEnhancer", task="denoise", model_family="zipenhancer",
                                 input_audio_length=input_audio_length, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate,
                                 model_sample_rate=SAMPLE_RATE, nfft=NFFT, window_length=NFFT, hop_length=HOP,
                                 window_type="hann", center_pad=True, pad_mode="reflect", use_batch_fold=use_batch_fold,
-                                batch_window_seconds=batch_window_seconds, max_dynamic_audio_seconds=2, feature_kind="stft_zipformer",
+                                batch_window_seconds=batch_window_seconds, max_dynamic_audio_seconds=2, feature_kind="stft_zipformer", dynamic_axes=dynamic_axes,
                                 extra={"n_mels": 100, "ade_gemm_dtype": gemm_dtype, "ade_dft_tables": dft_tables})
 
 

@@ -72,6 +72,31 @@ def interpolate_linear(x, out_len):
     return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
 
 
+def interpolate_scale(x, scale_factor: float):
+    """F.interpolate(x, scale_factor=s, mode='linear', align_corners=False): floor(n * s) samples, src = (1 / s) (dst + 0.5) - 0.5 with the step held in fp32
+    (the DYNAMIC_AXES edges, Export_DFSMN.py:186-187, 236-237)."""
+    n = x.shape[-1]
+    out_len = int(np.floor(float(n) * float(scale_factor)))
+    src = np.maximum(F32(1.0 / float(scale_factor)) * (np.arange(out_len, dtype=F32) + F32(0.5)) - F32(0.5), F32(0.0)).astype(F32)
+    i0 = np.minimum(src.astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    l1 = (src - i0.astype(F32)).astype(F32)
+    return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
+def process_dynamic(tensors: dict, pcm: np.ndarray, in_rate: int = 48000, out_rate: int = 48000, exact_dft: bool = False) -> np.ndarray:
+    """The DYNAMIC_AXES export on one int16 row of any length (Export_DFSMN.py:28, :186-187, :236-237, :274): scale-factor interpolation to 48 kHz, frames from the
+    model-rate length (snip edges), the ISTFT's overlap-add denominator built from that frame count -- the static one of the same count --, scale-factor interpolation out."""
+    x = np.asarray(pcm, np.int16).astype(F32)
+    if in_rate != 48000:
+        x = interpolate_scale(x, float(48000 / in_rate))
+    o = DfsmnOracle(tensors, x.shape[-1], exact_dft)
+    y = o._one(x, False)
+    if out_rate != 48000:
+        y = interpolate_scale(y, float(out_rate / 48000))
+    return np.clip(y * F32(32768.0), F32(-32768.0), F32(32767.0)).astype(np.int16)
+
+
 class DfsmnOracle:
     def __init__(self, tensors: dict, in_len: int, exact_dft: bool = False):
         self.w = {k: np.ascontiguousarray(v, F32) for k, v in tensors.items()}

@@ -133,20 +133,24 @@ def causal_conv_2x3(x, w, b, dilation):
 class ZipEnhancerOracle:
     """tensors: blob tensors by name; window_len: samples per window (whole hops); n_win: windows per call (batch-fold)."""
 
-    def __init__(self, tensors: dict, window_len: int, n_win: int = 1, exact_dft: bool = False):
+    def __init__(self, tensors: dict, window_len: int, n_win: int = 1, exact_dft: bool = False, dynamic: bool = False):
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         c = [int(round(float(v))) for v in self.w["zip_config"].reshape(-1)]
         (self.C, self.H, self.q, self.p, self.v, self.pos_dim, self.ff, self.K, self.dt1, self.df1, self.dt2, self.df2, self.r, self.depth) = c[:14]
         self.hid = self.C * 3 // 4
         self.ff1 = self.ff * 3 // 4
-        if window_len % HOP:
+        # dynamic = the DYNAMIC_AXES export (Export_ZipEnhancer.py:31, :61, :898-899; STFT_Process.py:297-299): any length, T = L // hop + 1 frames, 100 (T - 1) samples
+        # out, the overlap-add DIVIDED by its denominator instead of multiplied by the precomputed reciprocal
+        if window_len % HOP and not dynamic:
             raise ValueError("window_len must be whole hops")
+        self.dynamic = bool(dynamic)
         self.L, self.n_win, self.T = window_len, n_win, window_len // HOP + 1
         self.fwd, self.inv, win = stft_kernels(exact_dft)
         raw = np.zeros(NFFT + HOP * (self.T - 1), F32)
         for t in range(self.T):
             raw[t * HOP:t * HOP + NFFT] += win * win
         self.inv_win_sum = (F32(1.0) / raw[NFFT // 2:raw.size - NFFT // 2]).astype(F32)     # static_norm (STFT_Process.py:245-249)
+        self.win_sum = raw[NFFT // 2:raw.size - NFFT // 2].astype(F32)
         self._pos_cache = {}
 
     # ---- STFT / ISTFT (STFT_Process.py:268-281, 291-296) -------------------------------------------------------------------
@@ -162,6 +166,8 @@ class ZipEnhancerOracle:
         raw = np.zeros((B, NFFT + HOP * (self.T - 1)), F32)
         for t in range(self.T):
             raw[:, t * HOP:t * HOP + NFFT] += fr[:, t]
+        if self.dynamic:
+            return (raw[:, NFFT // 2:raw.shape[1] - NFFT // 2] / self.win_sum).astype(F32)
         return (raw[:, NFFT // 2:raw.shape[1] - NFFT // 2] * self.inv_win_sum).astype(F32)
 
     # ---- attention weights with the relative-position term (:232-289) -------------------------------------------------------
@@ -345,7 +351,7 @@ class ZipEnhancerOracle:
         ri = (ph * (magnitude / pn)).astype(F32)                                       # (:891)
         packed = np.concatenate((ri[..., 0].transpose(0, 2, 1), ri[..., 1].transpose(0, 2, 1)), axis=1)   # (B, 402, T) (:892)
         wave = (self.istft(np.ascontiguousarray(packed)) * norm).astype(F32)          # (:893, :900)
-        wave = wave.reshape(Bc, self.n_win * self.L)                                  # (:902)
+        wave = wave.reshape(Bc, -1)                                                   # (:902); 100 (T - 1) samples per window (== L for whole-hop windows)
         y = np.where(np.isnan(wave), F32(0.0), wave)                                  # (:917)
         out = np.clip(y, -32768.0, 32767.0).astype(np.int16)                          # truncation toward zero (:918)
         if taps:

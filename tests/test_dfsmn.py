@@ -156,6 +156,31 @@ def test_dfsmn_oracle_fold_and_resampling_match_reference(tensors):
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02
 
 
+def test_dfsmn_oracle_dynamic_axes_match_reference(tensors):
+    """DYNAMIC_AXES = True (tests/golden/dfsmn_dynamic_seed0.npz = two runs of the reference's forward, tools/make_golden_dfsmn.py --dynamic): a free input length at
+    48 kHz, and 22.05 kHz -> 48 kHz -> 16 kHz through the scale-factor edges."""
+    from dfsmn_oracle import process_dynamic
+    z = np.load(os.path.join(GOLD, "dfsmn_dynamic_seed0.npz"))
+    for tag, ri, ro in (("eq", 48000, 48000), ("rs", int(z["rs_in_rate"]), int(z["rs_out_rate"]))):
+        out = process_dynamic(tensors, z[tag + "_in"], ri, ro)
+        assert out.shape == z[tag + "_out"].shape, tag
+        d = out.astype(np.int32) - z[tag + "_out"].astype(np.int32)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02, tag
+
+
+@pytest.mark.gpu
+def test_gpu_dfsmn_dynamic_axes_match_reference():
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    z = np.load(os.path.join(GOLD, "dfsmn_dynamic_seed0.npz"))
+    for tag, ri, ro, frames in (("eq", 48000, 48000, 9), ("rs", int(z["rs_in_rate"]), int(z["rs_out_rate"]), 12)):
+        x, want = z[tag + "_in"], z[tag + "_out"]
+        with InferenceSession(weights=_blob_bytes(), metadata=_dfsmn_meta(x.shape[0], ri, ro, dynamic_axes=True)) as sess:
+            assert (sess.in_len, sess.out_len, sess.frames) == (x.shape[0], want.shape[0], frames), tag
+            out = sess.run(None, {"noisy_audio": np.stack((x, x))[:, None]})[0][:, 0]
+        d = out[0].astype(np.int32) - want.astype(np.int32)
+        assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05 and np.array_equal(out[0], out[1]), tag
+
+
 @pytest.mark.gpu
 def test_gpu_dfsmn_fold_and_resampling_match_reference():
     from audio_denoiser_onnx_amd.session import InferenceSession

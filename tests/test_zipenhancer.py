@@ -210,6 +210,81 @@ def test_gpu_zipenhancer_full_batch_properties(model):
     assert np.array_equal(outp, out[perm])
 
 
+GOLD_DYN = os.path.join(os.path.dirname(GOLD), "zipenhancer_dynamic_seed0.npz")
+
+
+def _interp_scale(x, sf):              # F.interpolate(scale_factor = sf, mode = 'linear', align_corners = False): floor(n sf) samples, source step 1 / sf in fp32
+    n = x.shape[-1]
+    n_out = int(np.floor(float(n) * float(sf)))
+    src = np.maximum(np.float32(1.0 / float(sf)) * (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) - np.float32(0.5), 0).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    w = (src - i0).astype(np.float32)
+    return ((np.float32(1.0) - w) * x[..., i0] + w * x[..., i1]).astype(np.float32)
+
+
+def test_oracle_dynamic_axes_match_reference(model):
+    """DYNAMIC_AXES = True (tools/make_golden_zipenhancer.py --dynamic: two runs of the reference's forward): a length that is not whole hops at 16 kHz, and
+    12 kHz -> 16 kHz -> 24 kHz through the scale-factor edges; the ISTFT divides by the overlap-add denominator of the actual frame count.  The two-part contract of
+    the static export: the oracle's own spectrum within 2e-5 of the reference's, and everything after it on the reference's spectrum."""
+    from zipenhancer_oracle import ZipEnhancerOracle
+    _, _, _, t = model
+    z = np.load(GOLD_DYN)
+    for tag in ("eq", "rs"):
+        x = z[tag + "_in"].astype(np.float32)
+        if tag == "rs":
+            x = _interp_scale(x, float(16000 / int(z["rs_in_rate"])))
+        o = ZipEnhancerOracle(t, x.shape[0], dynamic=True)
+        norm = np.sqrt(np.mean(x * x, dtype=np.float32) + np.float32(1e-6))
+        re, im = o.stft((x / norm).astype(np.float32)[None])
+        sre, sim = z[tag + "_spec_re"][None], z[tag + "_spec_im"][None]
+        scale = max(1.0, float(np.abs(sre).max()))
+        assert np.abs(re - sre).max() <= 2e-5 * scale and np.abs(im - sim).max() <= 2e-5 * scale, tag
+        _, wave, _ = o.process(x[None], spectrum=(sre, sim))
+        y = np.where(np.isnan(wave[0]), np.float32(0), wave[0])
+        if tag == "rs":
+            y = _interp_scale(y, float(int(z["rs_out_rate"]) / 16000))
+        out = np.clip(y, -32768.0, 32767.0).astype(np.int16)
+        assert out.shape == z[tag + "_out"].shape, tag
+        d = np.abs(out.astype(np.int32) - z[tag + "_out"].astype(np.int32))
+        assert d.max() <= 1 and (d != 0).mean() < 0.02, (tag, d.max(), (d != 0).mean())
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_dynamic_axes_match_reference(model):
+    """The engine on the same two calls: its spectrum against the reference's, the network on its own spectrum against the oracle (the static export's contract), and the
+    reference's PCM end to end when no edge-frame phase took the other branch."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from zipenhancer_oracle import ZipEnhancerOracle
+    _, _, _, t = model
+    z = np.load(GOLD_DYN)
+    for tag, ri, ro in (("eq", 16000, 16000), ("rs", int(z["rs_in_rate"]), int(z["rs_out_rate"]))):
+        x, want = z[tag + "_in"], z[tag + "_out"]
+        meta = zp.metadata(x.shape[0], in_sample_rate=ri, out_sample_rate=ro, dynamic_axes=True)
+        with InferenceSession(weights=pack_blob(t), metadata=meta) as sess:
+            assert (sess.in_len, sess.out_len, sess.frames) == (x.shape[0], want.shape[0], 81), (tag, sess.in_len, sess.out_len, sess.frames)
+            out, f32 = sess.process(np.stack((x, x)), want_f32=True)
+            spec = sess.tap("spec", 402 * 2 * 81).reshape(402, 2, 81).transpose(1, 0, 2)
+        assert np.array_equal(out[0], out[1])
+        sre, sim = z[tag + "_spec_re"], z[tag + "_spec_im"]
+        scale = max(1.0, float(np.abs(sre).max()))
+        assert np.abs(spec[0, :201] - sre).max() <= 2e-5 * scale and np.abs(spec[0, 201:] - sim).max() <= 2e-5 * scale, tag
+        Lm = 8050 if tag == "eq" else 8000
+        _, wave, _ = ZipEnhancerOracle(t, Lm, dynamic=True).process(np.zeros((1, Lm), np.float32), spectrum=(spec[:1, :201], spec[:1, 201:]))
+        xm = x.astype(np.float32) if tag == "eq" else _interp_scale(x.astype(np.float32), float(16000 / ri))
+        norm = np.sqrt(np.mean(xm * xm, dtype=np.float32) + np.float32(1e-6))
+        y = wave[0] / np.sqrt(np.float32(1e-6)) * norm                 # the oracle normalised a zero waveform: undo its norm factor, apply the call's
+        if tag == "rs":
+            y = _interp_scale(y, float(ro / 16000))
+        assert np.abs(f32[0] - y).max() <= 0.5, (tag, float(np.abs(f32[0] - y).max()))
+        flips = int((np.abs(np.arctan2(spec[0, 201:], spec[0, :201] + np.float32(1e-5)) - np.arctan2(sim, sre + np.float32(1e-5))) > 1.0).sum())
+        d = np.abs(out[0].astype(np.int32) - want.astype(np.int32))
+        if flips == 0:
+            assert d.max() <= 1, (tag, d.max())
+        else:
+            print(f"zipenhancer dynamic {tag}: {flips} phase-branch flip(s) vs the reference's STFT; PCM max {d.max()} LSB")
+
+
 @pytest.mark.gpu
 def test_gpu_zipenhancer_resampling_edges(model):
     """8 kHz in -> 16 kHz model -> 48 kHz out through the export's linear-interpolation edges (Export_ZipEnhancer.py:825-832, 904-911)."""

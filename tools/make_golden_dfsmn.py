@@ -91,7 +91,7 @@ def build(seed: int, length: int, overrides: dict = None):
     STFT_Process = import_stft_process("DFSMN").STFT_Process
     stft = STFT_Process("stft_B", ns["NFFT_STFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], 0, ns["WINDOW_TYPE"], False, "constant").eval()
     istft = STFT_Process("istft_B", ns["NFFT_STFT"], ns["WINDOW_LENGTH"], ns["HOP_LENGTH"], ns["MAX_SIGNAL_LENGTH"],
-                         ns["ISTFT_WINDOW_TYPE"], False, "constant", static_norm=True).eval()
+                         ns["ISTFT_WINDOW_TYPE"], False, "constant", static_norm=not ns["DYNAMIC_AXES"]).eval()      # (Export_DFSMN.py:274)
     net = fake_dfsmn(seed)
     model = ns["DFSMN"](net, stft, istft, ns["NFFT_STFT"], ns["N_MELS"], ns["IN_SAMPLE_RATE"], ns["OUT_SAMPLE_RATE"], ns["USE_BATCH_FOLD"],
                         ns["FOLD_WINDOW_LENGTH"] if ns["USE_BATCH_FOLD"] else 0, ns["STATIC_MODEL_BATCH"]).eval()
@@ -166,6 +166,26 @@ def main():
     print("fold", y.shape, int(np.abs(y).max()), "resample", y2.shape, int(np.abs(y2).max()))
 
 
+def dynamic_fixture():
+    """DYNAMIC_AXES = True (:28, :48-49, :68, :186-187, :236-237, :274): the input length is free, the edges interpolate by SCALE FACTOR (floor(n * factor) samples,
+    source step 1 / factor) and the ISTFT builds its overlap-add denominator from the actual frame count (2048-frame bound).  Two runs of the reference's forward:
+    48 kHz throughout on a length that is not a whole number of hops, and 22.05 kHz -> 48 kHz -> 16 kHz."""
+    wav = mg.load_wav_i16(os.path.join(REF_ROOT, "Test_Examples", "denoise", "speech_with_noise_48k.wav"))
+    out = {}
+    ns, model = build(0, 10000, {"DYNAMIC_AXES": True})
+    assert ns["MAX_SIGNAL_LENGTH"] == 2048 and not hasattr(model.istft_model, "static_win_sum")
+    x = wav[60000:60000 + 10000].copy()
+    with torch.inference_mode():
+        out["eq_in"], out["eq_out"] = x, model(torch.from_numpy(x.reshape(1, 1, -1))).numpy().reshape(-1)
+    ns, model = build(0, 6000, {"DYNAMIC_AXES": True, "IN_SAMPLE_RATE": 22050, "OUT_SAMPLE_RATE": 16000})
+    x = np.ascontiguousarray(wav[48000:48000 + 12000:2])
+    with torch.inference_mode():
+        out["rs_in"], out["rs_out"] = x, model(torch.from_numpy(x.reshape(1, 1, -1))).numpy().reshape(-1)
+    out["rs_in_rate"], out["rs_out_rate"] = np.int64(22050), np.int64(16000)
+    np.savez_compressed(os.path.join(mg.GOLD, "dfsmn_dynamic_seed0.npz"), **out)
+    print("dynamic: equal rates", out["eq_in"].shape, "->", out["eq_out"].shape, "; 22.05k -> 16k", out["rs_in"].shape, "->", out["rs_out"].shape)
+
+
 def float_io_fixture():
     """IN / OUT_AUDIO_DTYPE other than INT16 (:43-44): a float input skips the * INV_INT16 (:178-182), a float output the * 32768 and the clamp (:241-247).
     tests/golden/dfsmn_float_io_seed0.npz; the network is dfsmn_seed0.adew's."""
@@ -183,6 +203,10 @@ def float_io_fixture():
         print(tag, y.shape, y.dtype, float(np.abs(y).max()))
     np.savez_compressed(os.path.join(mg.GOLD, "dfsmn_float_io_seed0.npz"), **out)
 
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--float-io" in sys.argv:
     float_io_fixture()

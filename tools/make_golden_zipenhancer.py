@@ -406,6 +406,38 @@ def float_io_fixture():
     np.savez_compressed(os.path.join(GOLD, "zipenhancer_float_io_seed0.npz"), **out)
 
 
+def dynamic_fixture():
+    """DYNAMIC_AXES = True (:31, :61 MAX_SIGNAL_LENGTH = 1024, :828-829, :898-899, :907-908): a free input length, scale-factor edges, position tables sliced from
+    the 1024-frame table, ISTFT denominator built from the frame count and divided.  tests/golden/zipenhancer_dynamic_seed0.npz: 8 050 samples at 16 kHz throughout
+    (80 hops + 50 samples: 81 frames -> 8 000 out) and 6 000 samples at 12 kHz -> 16 kHz -> 24 kHz; the network is seed 0's."""
+    cfg, seed = zp.ZipConfig(), 0
+    z = np.load(os.path.join(GOLD, "zipenhancer_seed0_io.npz"))
+    out = {}
+    ns, model, _ = build_reference(cfg, seed, 8050, fold=False, extra={"DYNAMIC_AXES": True})
+    assert ns["MAX_SIGNAL_LENGTH"] == 1024 and not ns["STATIC_SHAPE"]
+    def run(model, x, tag):       # the reference's output and its analysis spectrum (the network is pinned on identical spectra: the edge frames' phase is ill-conditioned)
+        spec = {}
+        hook = model.stft_model.register_forward_hook(lambda m, i, o: spec.update(re=o[0].numpy().copy(), im=o[1].numpy().copy()))
+        try:
+            with torch.inference_mode():
+                y = model(torch.from_numpy(x.reshape(1, 1, -1).copy())).numpy().reshape(-1)
+        finally:
+            hook.remove()
+        out[tag + "_in"], out[tag + "_out"], out[tag + "_spec_re"], out[tag + "_spec_im"] = x, y, spec["re"][0], spec["im"][0]
+    x = np.ascontiguousarray(z["in_wav0"][3000:3000 + 8050])
+    run(model, x, "eq")
+    ns, model, _ = build_reference(cfg, seed, 6000, fold=False, extra={"DYNAMIC_AXES": True, "IN_SAMPLE_RATE": 12000, "OUT_SAMPLE_RATE": 24000})
+    x = np.ascontiguousarray(z["in_wav0"][2000:2000 + 6000])
+    run(model, x, "rs")
+    out["rs_in_rate"], out["rs_out_rate"] = np.int64(12000), np.int64(24000)
+    np.savez_compressed(os.path.join(GOLD, "zipenhancer_dynamic_seed0.npz"), **out)
+    print("dynamic: equal rates", out["eq_in"].shape, "->", out["eq_out"].shape, "; 12k -> 24k", out["rs_in"].shape, "->", out["rs_out"].shape)
+
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    sys.exit(0)
+
 if __name__ == "__main__" and "--float-io" in sys.argv:
     float_io_fixture()
     sys.exit(0)
