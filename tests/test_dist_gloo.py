@@ -167,7 +167,7 @@ def test_world_size_2_gloo_hgtcrn_driver_two_channel_rows(tmp_path):
         W = 2048
         model = os.path.join(tmp, f"hg_{{rank}}.adew")
         save_blob(model, hgtcrn.fold_state_dict(state)); write_metadata(model, hgtcrn.metadata(W))
-        audio = np.stack([synth_chunk(3, 5000), synth_chunk(4, 5000)])          # 3 slices of 2048 (stride = output length 2048)
+        audio = np.stack([synth_chunk(3, 3000), synth_chunk(4, 3000)])          # 2 slices of 2048 (stride = output length 2048): one per rank
         write_pcm16(os.path.join(tmp, f"in_{{rank}}.wav"), audio, 16000)
         out = os.path.join(tmp, f"out_{{rank}}.wav")
         assert inference_hgtcrn.main([model, os.path.join(tmp, f"in_{{rank}}.wav"), out]) == 0
