@@ -15,6 +15,11 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f);
 }
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
+// The same function as ONE v_med3_f32 per element (the product packs into v_pk_mul_f32): for a slope <= 1 PReLU is max(x, a x), for a slope > 1 it is
+// min(x, a x); median(x, a x, +inf) is the first and median(x, a x, -inf) the second, so the slope picks a wave-uniform third operand once and the
+// body has no branch and no compare + select pair.  Equal to prelu_f for every finite x (a negative slope turns -0 into +0, which compares equal).
+__device__ __forceinline__ float prelu_sel(float a) { return a <= 1.0f ? __builtin_inff() : -__builtin_inff(); }
+__device__ __forceinline__ float prelu_m(float x, float ax, float sel) { return __builtin_amdgcn_fmed3f(x, ax, sel); }
 
 __device__ __forceinline__ void ld4(const float* p, float* v) {
     const float4 q = *reinterpret_cast<const float4*>(p);

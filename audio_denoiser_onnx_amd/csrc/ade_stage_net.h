@@ -117,6 +117,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     ADE_SCALAR_COPY(c_dw, cptr(w.dw));
     ADE_SCALAR_COPY(c_pw2, cptr(w.pw2));
     const float pw1_slope = w.pw1_slope, dw_slope = w.dw_slope;
+    const float pw1_sel = prelu_sel(pw1_slope), dw_sel = prelu_sel(dw_slope);
     const int dilation = w.dilation;
     ADE_CLK(0);
 
@@ -209,7 +210,11 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         for (int i = 0; i < kPosPerThread; ++i) {
             float r[16];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { r[2 * m] = prelu_f(acc[i][m][0], pw1_slope); r[2 * m + 1] = prelu_f(acc[i][m][1], pw1_slope); }
+            for (int m = 0; m < 8; ++m) {
+                const v2f ax = acc[i][m] * mk2(pw1_slope, pw1_slope);
+                r[2 * m] = prelu_m(acc[i][m][0], ax[0], pw1_sel);
+                r[2 * m + 1] = prelu_m(acc[i][m][1], ax[1], pw1_sel);
+            }
             H[p0 + i] = make_float4(r[0], r[1], r[2], r[3]);
             H[kPmax + p0 + i] = make_float4(r[4], r[5], r[6], r[7]);
 #pragma unroll
@@ -342,7 +347,10 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(prelu_f(acc[i][m][0], dw_slope), prelu_f(acc[i][m][1], dw_slope));
+            for (int m = 0; m < 8; ++m) {
+                const v2f ax = acc[i][m] * mk2(dw_slope, dw_slope);
+                acc[i][m] = mk2(prelu_m(acc[i][m][0], ax[0], dw_sel), prelu_m(acc[i][m][1], ax[1], dw_sel));
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) h2[i][m] = mk2(c_pw2_b[2 * m], c_pw2_b[2 * m + 1]);
         }
