@@ -138,274 +138,186 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         }
         __syncthreads();
     }
-    // ---- conv phases: each lane owns THREE ADJACENT columns (t, 3c..3c+2) of the (T,33) grid -- 33 = 3 x 11, so the lane's
-    //      positions are simply 3u, 3u+1, 3u+2 (u = tid < 11 T <= 704).  One weight row fetched into scalar registers
-    //      serves three positions (a third of the scalar-load / SGPR-recycling overhead per position), the 3-tap
-    //      neighbourhoods of the three positions share 5 columns (10 / 60 tap reads instead of 18 / 108), and a lane
-    //      stride of 3 float4 = 48 B is conflict-free for ds_read/write_b128.
-    const int U = T * (kFw / 3);
-    const bool own = tid < U;
-    const int p0 = own ? 3 * tid : 0;
-    const int cfirst = own ? tid % (kFw / 3) : 0;          // column triple index c: f0 = 3c
-    const bool left_ok = cfirst != 0, right_ok = cfirst != kFw / 3 - 1;     // columns f0-1 / f0+3 exist
-    // ---- phase 1: SFE(3) -> 1x1 (24->16) + BN + PReLU.  Output channels 0-7 go straight to planes 0-1; channels 8-15 wait
-    //      in registers until every lane has read its x1 neighbours out of planes 2-3.                     (:305-310)
-    float hi[kPosPerThread][8];
-    if (own) {
-        float xc[5][8];                                    // x1 columns f0-1 .. f0+3 (zero outside the grid: select, not branch)
+    // ---- conv phases on the matrix cores.  The two pointwise convolutions are GEMMs with the 16 output channels as rows: a wavefront owns
+    //      16-POSITION TILES (tile = it * kWaves + wave) and one v_mfma_f32_16x16x4_f32 adds four input channels to the whole 16 x 16 tile.
+    //      Lane (g = lane / 16, j = lane % 16) supplies, as B, channel (4 kk + g) of position j -- one ds_read_b32 out of the quad-planar
+    //      LDS tile, conflict-free (16 B lane stride within a row of lanes, 4 B between the rows) -- and, as A, the weight of that channel
+    //      for output channel j (registers, loaded once per stage); the result registers are output channels 4g .. 4g+3 of position j,
+    //      i.e. exactly one float4 of plane g.  The depthwise 3x3 between the two stays on the VALU in the same ownership (a lane = one
+    //      position x four channels: 9 taps = 18 packed FMAs), its PReLU output feeds the second GEMM from the registers it is in (K index
+    //      = (g, register), the weights are permuted to match), and the 33 tiles spread over ALL wavefronts of the workgroup.
+    constexpr int kWaves = kFusedThreads / 64;
+    constexpr int kTiles = (kPmax / 16 + kWaves - 1) / kWaves;             // tiles per wavefront: 9 in every geometry
+    static_assert(kPmax % 16 == 0, "whole tiles");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = (tid >> 4) & 3, jn = tid & 15;
+    const float* Hf = reinterpret_cast<const float*>(H);
+    // ---- phase 1: SFE(3) -> 1x1 (24->16) + BN + PReLU.  Output channels 0-7 (lane rows 0, 1) go straight to planes 0-1; channels 8-15
+    //      wait in registers until every wavefront has read its x1 columns out of planes 2-3.  The tile bodies are straight-line code (a
+    //      tile past the segment's end works on the clamped last position and stores nothing), so the compiler interleaves the dependent
+    //      MFMA chains of neighbouring tiles.                                                                       (:305-310)
+    const char* const Hb = reinterpret_cast<const char*>(H);
+    constexpr int kZ0 = 4 * kPmax * 16;                    // byte offset of 48 B of zeros (the head of zt, dead during the conv phases): where a tap outside the grid reads
+    // Half of a tile's result waits, so the tiles go in PAIRS that share the registers: the odd tile of a pair runs with the rows of A (and the
+    // bias) rotated by 8, its channels 8-15 come out in lane rows 0, 1 and wait in the half of hi[] that the even tile leaves unused.
+    constexpr int kPairs = (kTiles + 1) / 2;
+    float4 hi[kPairs];
+    {
+        float wa[2][6];                                    // A operands: K block kk = (SFE tap o = kk / 2, input channel 4 (kk % 2) + g), weight row c * 3 + o
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const bool ok = (k != 0 || left_ok) && (k != 4 || right_ok);
-            const int pp = p0 - 1 + (ok ? k : 1);
-            const float4 xa = H[2 * kPmax + pp], xb = H[3 * kPmax + pp];
-            xc[k][0] = ok ? xa.x : 0.0f; xc[k][1] = ok ? xa.y : 0.0f; xc[k][2] = ok ? xa.z : 0.0f; xc[k][3] = ok ? xa.w : 0.0f;
-            xc[k][4] = ok ? xb.x : 0.0f; xc[k][5] = ok ? xb.y : 0.0f; xc[k][6] = ok ? xb.z : 0.0f; xc[k][7] = ok ? xb.w : 0.0f;
+        for (int kk = 0; kk < 6; ++kk) {
+            wa[0][kk] = c_pw1[((4 * (kk & 1) + g) * 3 + (kk >> 1)) * 16 + jn];
+            wa[1][kk] = c_pw1[((4 * (kk & 1) + g) * 3 + (kk >> 1)) * 16 + (jn ^ 8)];
         }
-        v2f acc[kPosPerThread][8];
+        v4f cb[2];
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i)
+        for (int r = 0; r < 4; ++r) { cb[0][r] = c_pw1_b[4 * g + r]; cb[1][r] = c_pw1_b[(4 * g + r) ^ 8]; }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_pw1_b[2 * m], c_pw1_b[2 * m + 1]);
-        // 24 weight rows (input channel c, SFE tap o), each 16 scalars serving 3 positions = 24 packed FMAs.  Scalar loads
-        // return out of order, so a wavefront can only wait for ALL of them: the rows are fetched in double-buffered groups
-        // of two, the next group requested right after the first FMA of the current one (its wait has just drained the
-        // queue) and landing under the remaining 47 FMAs.
-        v2f wc[2][8], wn[2][8];
-        {
-            cfptr g0 = c_pw1;
-            ADE_KEEP_IN_LOOP(g0);
+        for (int it = 0; it < kTiles; ++it) {
+            const int od = it & 1;                         // odd tile of its pair: lane rows 0, 1 hold channels 8-15
+            const int pu = (it * kWaves + wave) * 16 + jn, pos = pu < P ? pu : P - 1;
+            const int f = pos - (pos / kFw) * kFw;
+            const bool lok = f != 0, rok = f != kFw - 1;
+            const char* xb = Hb + (pos * 4 + g) * 4;       // channel g of the position's float4; planes and neighbours are constant offsets
+            v4f d = cb[od];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) wc[j][m] = mk2(g0[j * 16 + 2 * m], g0[j * 16 + 2 * m + 1]);
-        }
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = 2 * g + j, c = r / 3, o = r % 3;        // row index = c * 3 + o (the weight layout)
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-#pragma unroll
-                    for (int i = 0; i < kPosPerThread; ++i) {
-                        acc[i][m] += wc[j][m] * xc[i + o][c];
-                        if (j == 0 && m == 0 && i == 0 && g < 11) {
-                            float tok = acc[0][0][0];
-                            cfptr gn = c_pw1 + (2 * g + 2) * 16;
-                            ADE_KEEP_AFTER(gn, tok);
-                            acc[0][0][0] = tok;
-#pragma unroll
-                            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                                for (int mm = 0; mm < 8; ++mm) wn[jj][mm] = mk2(gn[jj * 16 + 2 * mm], gn[jj * 16 + 2 * mm + 1]);
-                        }
-                    }
+            for (int kk = 0; kk < 6; ++kk) {
+                const int o = kk >> 1;
+                float x = *reinterpret_cast<const float*>(xb + ((2 + (kk & 1)) * kPmax + (o - 1)) * 16);
+                if (o == 0) x = lok ? x : 0.0f;
+                if (o == 2) x = rok ? x : 0.0f;
+                d = mfma16x16x4(wa[od][kk], x, d);
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) wc[j][m] = wn[j][m];
-        }
-#pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            float r[16];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const v2f ax = acc[i][m] * mk2(pw1_slope, pw1_slope);
-                r[2 * m] = prelu_m(acc[i][m][0], ax[0], pw1_sel);
-                r[2 * m + 1] = prelu_m(acc[i][m][1], ax[1], pw1_sel);
+            const v2f d0 = mk2(d[0], d[1]), d1 = mk2(d[2], d[3]);
+            const v2f a0 = d0 * mk2(pw1_slope, pw1_slope), a1 = d1 * mk2(pw1_slope, pw1_slope);
+            const float4 r4 = make_float4(prelu_m(d0[0], a0[0], pw1_sel), prelu_m(d0[1], a0[1], pw1_sel),
+                                          prelu_m(d1[0], a1[0], pw1_sel), prelu_m(d1[1], a1[1], pw1_sel));
+            const bool now = (g < 2) != (od != 0);         // this lane's four channels are 0-7: plane g (even tile) or g - 2 (odd tile)
+            if (now && pu < P) H[(g & 1) * kPmax + pu] = r4;
+            if (!od) {
+                hi[it >> 1] = r4;
+            } else {
+                hi[it >> 1] = make_float4(now ? hi[it >> 1].x : r4.x, now ? hi[it >> 1].y : r4.y, now ? hi[it >> 1].z : r4.z, now ? hi[it >> 1].w : r4.w);
             }
-            H[p0 + i] = make_float4(r[0], r[1], r[2], r[3]);
-            H[kPmax + p0 + i] = make_float4(r[4], r[5], r[6], r[7]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) hi[i][k] = r[8 + k];
         }
     }
     __syncthreads();
-    if (own) {
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            H[2 * kPmax + p0 + i] = make_float4(hi[i][0], hi[i][1], hi[i][2], hi[i][3]);
-            H[3 * kPmax + p0 + i] = make_float4(hi[i][4], hi[i][5], hi[i][6], hi[i][7]);
-        }
+    for (int pr = 0; pr < kPairs; ++pr) {                  // lane rows 2, 3 hold the even tile's channels 8-15, rows 0, 1 the odd tile's
+        const int it = 2 * pr + (g < 2 ? 1 : 0);
+        const int pu = (it * kWaves + wave) * 16 + jn;
+        if (it < kTiles && pu < P) H[(2 + (g & 1)) * kPmax + pu] = hi[pr];
     }
+    if (tid < 12) zt[tid] = 0.0f;
     if (sg.prev && tid == 0) xwait(sg.fi + kXFlagHist + blk, sg.err);     // the previous segment's partial sums (normally long there)
     __syncthreads();
     ADE_CLK(1);
 
-    // ---- phase 2: causal dilated depthwise 3x3 + BN + PReLU -> 1x1 (16->8) + BN -> h1 (registers)   (:311-320)
-    // one time tap kt of the depthwise convolution for a lane's three positions: source frame row at LDS position pr
-    auto dw_tap = [&](v2f (&acc)[kPosPerThread][8], const int kt, const int pr, const bool lok, const bool rok) {
-        // weights of (kt, channel quad q): 3 taps x 4 channels; the next quad's are requested after this quad's first FMA
-        v2f wc[3][2], wn[3][2];
-        {
-            cfptr g0 = c_dw + kt * 48;
-            ADE_KEEP_IN_LOOP(g0);
+    // ---- phase 2: causal dilated depthwise 3x3 + BN + PReLU -> 1x1 (16->8) + BN -> h1 (registers of lane rows 0, 1)   (:311-320)
+    //      The second GEMM has 8 output rows: two tiles share one accumulator, the odd tile of a pair through the weights in rows 8-15 (K =
+    //      its 16 channels, A block-diagonal), so that lane rows 0, 1 hold h1 of the even tile and rows 2, 3 h1 of the odd tile.
+    float4 h1r[kPairs];
+    {
+        v2f wd[3][3][2];                                   // dw[kt][kf][4g .. 4g+3]
 #pragma unroll
-            for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = mk2(g0[kf * 16], g0[kf * 16 + 1]); wc[kf][1] = mk2(g0[kf * 16 + 2], g0[kf * 16 + 3]); }
-        }
+        for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v2f col[5][2];                             // channels 4q..4q+3 of columns f0-1 .. f0+3 at the source frame
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const bool ok = (k != 0 || lok) && (k != 4 || rok);
-                const float4 x = H[q * kPmax + pr - 1 + (ok ? k : 1)];
-                col[k][0] = mk2(ok ? x.x : 0.0f, ok ? x.y : 0.0f);
-                col[k][1] = mk2(ok ? x.z : 0.0f, ok ? x.w : 0.0f);
+            for (int kf = 0; kf < 3; ++kf) {
+                const int o = kt * 48 + kf * 16 + 4 * g;
+                wd[kt][kf][0] = mk2(c_dw[o], c_dw[o + 1]);
+                wd[kt][kf][1] = mk2(c_dw[o + 2], c_dw[o + 3]);
             }
+        const v2f db0 = mk2(c_dw_b[4 * g], c_dw_b[4 * g + 1]), db1 = mk2(c_dw_b[4 * g + 2], c_dw_b[4 * g + 3]);
+        const int dstep = dilation * kFw * 16;             // bytes between the rows two time taps read
+        // The time taps kt < nkt of the depthwise convolution for frame tj (>= T: a frame of the successor), column f, channels 4g .. 4g+3; prow =
+        // tj * 33 + f.  kt ascending, kf ascending -- the order of the sum is the same wherever a frame's taps are split between two segments.
+        // No branch and no select on the data: a tap whose source frame is not in this segment (zero padding, already in the sum, or the
+        // successor's own) or whose column is off the grid reads the zeros at kZ0 instead (one address select each).
+        auto dw_taps = [&](v2f& acc0, v2f& acc1, const int tj, const int f, const int prow, const int nkt) {
+            const bool lok = f != 0, rok = f != kFw - 1;
+            const int rb = (g * kPmax + prow) * 16 - 16;   // the left neighbour of the position in its own frame
 #pragma unroll
-            for (int kf = 0; kf < 3; ++kf)
-#pragma unroll
-                for (int i = 0; i < kPosPerThread; ++i) {
-                    acc[i][2 * q] += wc[kf][0] * col[i + kf][0];
-                    if (kf == 0 && i == 0 && q < 3) {
-                        float tok = acc[0][2 * q][0];
-                        cfptr gn = c_dw + kt * 48 + 4 * (q + 1);
-                        ADE_KEEP_AFTER(gn, tok);
-                        acc[0][2 * q][0] = tok;
-#pragma unroll
-                        for (int kk = 0; kk < 3; ++kk) { wn[kk][0] = mk2(gn[kk * 16], gn[kk * 16 + 1]); wn[kk][1] = mk2(gn[kk * 16 + 2], gn[kk * 16 + 3]); }
-                    }
-                    acc[i][2 * q + 1] += wc[kf][1] * col[i + kf][1];
-                }
-#pragma unroll
-            for (int kf = 0; kf < 3; ++kf) { wc[kf][0] = wn[kf][0]; wc[kf][1] = wn[kf][1]; }
-        }
-    };
-    float* const xhist_o = sg.xo + blk * kXHistFloats;
-    if (sg.next && tid >= G::kProdBase) {
-        // History for the NEXT segment, on wavefronts that own no conv lane: lane (t', c) of its first 2 x dilation frames adds, to the
-        // bias, the time taps that land in THIS segment's frames T + t' - (2 - kt) dilation -- kt ascending, exactly the head of the sum
-        // a whole-chunk workgroup forms for that frame.  A segment shorter than the history (a streaming push of two frames) passes on
-        // what it received: the sum for frame j = T + t' < 2 x dilation of ITS OWN numbering arrived from its predecessor with the taps
-        // older than this segment already in it, and only the taps that land in this segment's frames are added.
+            for (int kt = 0; kt < 3; ++kt) {
+                if (kt >= nkt) continue;
+                const int src = tj - (2 - kt) * dilation;
+                const bool tv = nkt == 3 && kt == 2 ? true : (src >= 0 && src < T);
+                const int row = tv ? rb - (2 - kt) * dstep : kZ0;
+                const int la = lok ? row : kZ0, ra = rok ? row : kZ0;
+                const float4 x0 = *reinterpret_cast<const float4*>(Hb + la);
+                const float4 x1 = *reinterpret_cast<const float4*>(Hb + row + 16);
+                const float4 x2 = *reinterpret_cast<const float4*>(Hb + ra + 32);
+                acc0 += wd[kt][0][0] * mk2(x0.x, x0.y);
+                acc1 += wd[kt][0][1] * mk2(x0.z, x0.w);
+                acc0 += wd[kt][1][0] * mk2(x1.x, x1.y);
+                acc1 += wd[kt][1][1] * mk2(x1.z, x1.w);
+                acc0 += wd[kt][2][0] * mk2(x2.x, x2.y);
+                acc1 += wd[kt][2][1] * mk2(x2.z, x2.w);
+            }
+        };
+        float* const xhist_o = sg.xo + blk * kXHistFloats;
+        const float* const xhist_i = sg.xi + blk * kXHistFloats;
+        const int NP = 2 * dilation * kFw;                 // positions of the frames whose sums start in the previous segment
+        if (sg.next) {
+            // History for the NEXT segment: for its first 2 x dilation frames, bias + the time taps that land in THIS segment's frames
+            // T + t' - (2 - kt) dilation -- kt ascending, exactly the head of the sum a whole-chunk workgroup forms for that frame.  A segment
+            // shorter than the history (a streaming push of two frames) passes on what it received: the sum for frame j = T + t' < 2 x dilation
+            // of ITS OWN numbering arrived from its predecessor with the taps older than this segment already in it.
 #pragma unroll 1
-        for (int u = tid - G::kProdBase; u < 2 * dilation * (kFw / 3); u += kFusedThreads - G::kProdBase) {      // (one round, except for the 256-thread geometry at dilation 5)
-            const int tn = u / (kFw / 3), cn = u - tn * (kFw / 3);
-            const bool lok = cn != 0, rok = cn != kFw / 3 - 1;
-            const int j = tn + T;                          // the successor's frame t' in this segment's numbering
-            v2f acc[kPosPerThread][8];
-            if (sg.prev && j < 2 * dilation) {             // it starts before this segment's history ends: continue the predecessor's sum
-                const float* xhist_i = sg.xi + blk * kXHistFloats;
-#pragma unroll
-                for (int i = 0; i < kPosPerThread; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = xld4(xhist_i, (q * kXHistFrames * kFw + j * kFw + 3 * cn + i) * 4);
-                        acc[i][2 * q] = mk2(v.x, v.y);
-                        acc[i][2 * q + 1] = mk2(v.z, v.w);
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < kPosPerThread; ++i)
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
-            }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const int src = j - (2 - kt) * dilation;   // frame the tap reads: >= T lies in the successor's own frames, < 0 is already in the sum
-                if (src >= T || src < 0) continue;
-                dw_tap(acc, kt, src * kFw + 3 * cn, lok, rok);
-            }
-#pragma unroll
-            for (int i = 0; i < kPosPerThread; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    xst4(xhist_o, (q * kXHistFrames * kFw + tn * kFw + 3 * cn + i) * 4,
-                         make_float4(acc[i][2 * q][0], acc[i][2 * q][1], acc[i][2 * q + 1][0], acc[i][2 * q + 1][1]));
-        }
-        xdrain();                                          // every storing wavefront, ahead of the barrier that precedes the flag
-    }
-    float h1r[kPosPerThread][8];
-    if (own) {
-        const int t = tid / (kFw / 3);
-        v2f acc[kPosPerThread][8];
-        if (sg.prev && t < 2 * dilation) {                 // head of the sum: from the previous segment (bias included)
-            const float* xhist_i = sg.xi + blk * kXHistFloats;
-#pragma unroll
-            for (int i = 0; i < kPosPerThread; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = xld4(xhist_i, (q * kXHistFrames * kFw + p0 + i) * 4);
-                    acc[i][2 * q] = mk2(v.x, v.y);
-                    acc[i][2 * q + 1] = mk2(v.z, v.w);
+            for (int pt = wave; pt * 16 < NP; pt += kWaves) {
+                const int pu = pt * 16 + jn, pn = pu < NP ? pu : NP - 1;
+                const int tn = pn / kFw, f = pn - tn * kFw;
+                const int j = tn + T;                      // the successor's frame t' in this segment's numbering
+                v2f acc0 = db0, acc1 = db1;
+                if (sg.prev && j < 2 * dilation) {         // it starts before this segment's history ends: continue the predecessor's sum
+                    const float4 v = xld4(xhist_i, (g * kXHistFrames * kFw + j * kFw + f) * 4);
+                    acc0 = mk2(v.x, v.y);
+                    acc1 = mk2(v.z, v.w);
                 }
-        } else {
-#pragma unroll
-            for (int i = 0; i < kPosPerThread; ++i)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_dw_b[2 * m], c_dw_b[2 * m + 1]);
-        }
-#pragma unroll
-        for (int kt = 0; kt < 3; ++kt) {
-            const int tt = t - (2 - kt) * dilation;
-            if (tt < 0) continue;                          // (per-lane: early frames only; the weights are indexed by constants)
-            dw_tap(acc, kt, p0 - (2 - kt) * dilation * kFw, left_ok, right_ok);
-        }
-        v2f h2[kPosPerThread][4];
-#pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const v2f ax = acc[i][m] * mk2(dw_slope, dw_slope);
-                acc[i][m] = mk2(prelu_m(acc[i][m][0], ax[0], dw_sel), prelu_m(acc[i][m][1], ax[1], dw_sel));
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) h2[i][m] = mk2(c_pw2_b[2 * m], c_pw2_b[2 * m + 1]);
-        }
-        {   // 1x1 (16->8): 16 rows of 8 scalars, fetched in double-buffered groups of four rows (see phase 1)
-            v2f wc[4][4], wn[4][4];
-            {
-                cfptr g0 = c_pw2;
-                ADE_KEEP_IN_LOOP(g0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) wc[j][m] = mk2(g0[j * 8 + 2 * m], g0[j * 8 + 2 * m + 1]);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ci = 4 * g + j;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int i = 0; i < kPosPerThread; ++i) {
-                            h2[i][m] += wc[j][m] * acc[i][ci >> 1][ci & 1];
-                            if (j == 0 && m == 0 && i == 0 && g < 3) {
-                                float tok = h2[0][0][0];
-                                cfptr gn = c_pw2 + (4 * g + 4) * 8;
-                                ADE_KEEP_AFTER(gn, tok);
-                                h2[0][0][0] = tok;
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                                    for (int mm = 0; mm < 4; ++mm) wn[jj][mm] = mk2(gn[jj * 8 + 2 * mm], gn[jj * 8 + 2 * mm + 1]);
-                            }
-                        }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) wc[j][m] = wn[j][m];
+                dw_taps(acc0, acc1, j, f, pn + P, 2);
+                if (pu < NP) xst4(xhist_o, (g * kXHistFrames * kFw + pn) * 4, make_float4(acc0[0], acc0[1], acc1[0], acc1[1]));
             }
         }
+        float wp[2][4];                                    // A operands of the second GEMM: K block r = (input channel 4g + r); even tile: rows 0-7, odd tile: rows 8-15
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i)
+        for (int r = 0; r < 4; ++r) {
+            const float wv = c_pw2[(4 * g + r) * 8 + (jn & 7)];
+            wp[0][r] = jn < 8 ? wv : 0.0f;
+            wp[1][r] = jn < 8 ? 0.0f : wv;
+        }
+        v4f cb2;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { h1r[i][2 * m] = h2[i][m][0]; h1r[i][2 * m + 1] = h2[i][m][1]; }
+        for (int r = 0; r < 4; ++r) cb2[r] = c_pw2_b[(4 * g + r) & 7];
+        v4f d2 = cb2;
+#pragma unroll
+        for (int it = 0; it < kTiles; ++it) {
+            const int pu = (it * kWaves + wave) * 16 + jn, pos = pu < P ? pu : P - 1;
+            const int t = pos / kFw, f = pos - t * kFw;
+            v2f acc0 = db0, acc1 = db1;
+            if (sg.prev && (it * kWaves + wave) * 16 < NP) {     // (wave-uniform) head of the sum: from the previous segment (bias included)
+                const float4 v = xld4(xhist_i, (g * kXHistFrames * kFw + (pos < NP ? pos : NP - 1)) * 4);
+                const bool head = pos < NP;
+                acc0 = mk2(head ? v.x : db0[0], head ? v.y : db0[1]);
+                acc1 = mk2(head ? v.z : db1[0], head ? v.w : db1[1]);
+            }
+            dw_taps(acc0, acc1, t, f, pos, 3);
+            const v2f a0 = acc0 * mk2(dw_slope, dw_slope), a1 = acc1 * mk2(dw_slope, dw_slope);
+            const float y[4] = {prelu_m(acc0[0], a0[0], dw_sel), prelu_m(acc0[1], a0[1], dw_sel),
+                                prelu_m(acc1[0], a1[0], dw_sel), prelu_m(acc1[1], a1[1], dw_sel)};
+            if (!(it & 1)) d2 = cb2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d2 = mfma16x16x4(wp[it & 1][r], y[r], d2);
+            if ((it & 1) || it == kTiles - 1) h1r[it >> 1] = make_float4(d2[0], d2[1], d2[2], d2[3]);
+        }
+        if (sg.next) xdrain();                             // every storing wavefront, ahead of the barrier that precedes the flag
     }
     __syncthreads();   // every tap read of H is done: planes may be reused
-    if (sg.next && tid == G::kProdBase) xflag_store(sg.fo + kXFlagHist + blk, 1u);
+    if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagHist + blk, 1u);
     ADE_CLK(2);
-    if (own) {
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            H[p0 + i] = make_float4(h1r[i][0], h1r[i][1], h1r[i][2], h1r[i][3]);
-            H[kPmax + p0 + i] = make_float4(h1r[i][4], h1r[i][5], h1r[i][6], h1r[i][7]);
-        }
+    for (int pr = 0; pr < kPairs; ++pr) {
+        const int it = 2 * pr + (g >> 1);
+        const int pu = (it * kWaves + wave) * 16 + jn;
+        if (it < kTiles && pu < P) H[(g & 1) * kPmax + pu] = h1r[pr];
     }
     __syncthreads();
     ADE_CLK(3);
@@ -575,15 +487,13 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     //      (out[:, :8] + next_skip[:, :8]) in planes 2-3.  The column-triple owners hold h1 in registers, but HBM wants
     //      position-linear lanes (16 B per lane, 1 KB contiguous per instruction): the gated half goes through LDS planes
     //      2-3 (GI / HS are dead), and every lane then assembles the positions tid, tid+1024, tid+2048.     (:156,324)
-    if (own) {
-        const int t = tid / (kFw / 3);
-        float g8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) g8[k] = at[t * 8 + k];
-#pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            H[2 * kPmax + p0 + i] = make_float4(h1r[i][0] * g8[0], h1r[i][1] * g8[1], h1r[i][2] * g8[2], h1r[i][3] * g8[3]);
-            H[3 * kPmax + p0 + i] = make_float4(h1r[i][4] * g8[4], h1r[i][5] * g8[5], h1r[i][6] * g8[6], h1r[i][7] * g8[7]);
+    for (int pr = 0; pr < kPairs; ++pr) {
+        const int it = 2 * pr + (g >> 1);
+        const int pu = (it * kWaves + wave) * 16 + jn;
+        if (it < kTiles && pu < P) {
+            const float4 gt = *reinterpret_cast<const float4*>(at + (pu / kFw) * 8 + 4 * (g & 1));
+            H[(2 + (g & 1)) * kPmax + pu] = make_float4(h1r[pr].x * gt.x, h1r[pr].y * gt.y, h1r[pr].z * gt.z, h1r[pr].w * gt.w);
         }
     }
     __syncthreads();
