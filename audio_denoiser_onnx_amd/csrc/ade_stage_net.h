@@ -233,19 +233,22 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         // tj * 33 + f.  kt ascending, kf ascending -- the order of the sum is the same wherever a frame's taps are split between two segments.
         // No branch and no select on the data: a tap whose source frame is not in this segment (zero padding, already in the sum, or the
         // successor's own) or whose column is off the grid reads the zeros at kZ0 instead (one address select each).
+        const char* const zp = Hb + kZ0;
         auto dw_taps = [&](v2f& acc0, v2f& acc1, const int tj, const int f, const int prow, const int nkt) {
             const bool lok = f != 0, rok = f != kFw - 1;
-            const int rb = (g * kPmax + prow) * 16 - 16;   // the left neighbour of the position in its own frame
+            const char* const rb = Hb + ((g * kPmax + prow) * 16 - 16);   // the left neighbour of the position in its own frame
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
                 if (kt >= nkt) continue;
                 const int src = tj - (2 - kt) * dilation;
-                const bool tv = nkt == 3 && kt == 2 ? true : (src >= 0 && src < T);
-                const int row = tv ? rb - (2 - kt) * dstep : kZ0;
-                const int la = lok ? row : kZ0, ra = rok ? row : kZ0;
-                const float4 x0 = *reinterpret_cast<const float4*>(Hb + la);
-                const float4 x1 = *reinterpret_cast<const float4*>(Hb + row + 16);
-                const float4 x2 = *reinterpret_cast<const float4*>(Hb + ra + 32);
+                // (a frame of this segment reads back into it iff it is late enough; a frame of the successor reads into it iff the tap is old enough)
+                const bool tv = nkt == 3 ? (kt == 2 ? true : prow >= (2 - kt) * dilation * kFw) : (src >= 0 && src < T);
+                const char* const row = tv ? rb - (2 - kt) * dstep : zp;
+                const char* const la = lok ? row : zp;
+                const char* const ra = rok ? row : zp;
+                const float4 x0 = *reinterpret_cast<const float4*>(la);
+                const float4 x1 = *reinterpret_cast<const float4*>(row + 16);
+                const float4 x2 = *reinterpret_cast<const float4*>(ra + 32);
                 acc0 += wd[kt][0][0] * mk2(x0.x, x0.y);
                 acc1 += wd[kt][0][1] * mk2(x0.z, x0.w);
                 acc0 += wd[kt][1][0] * mk2(x1.x, x1.y);
