@@ -359,11 +359,25 @@ ade_status build_device_constants(ade_engine* e) {
     const float* w4 = L.get("decoder.de_convs.4.conv.weight", {16, 2, 1, 5});
     const float* b4 = L.get("decoder.de_convs.4.conv.bias", {2});
     if (L.st != ADE_OK) return L.st;
-    const size_t o_w0 = A.alloc(5 * 9 * 16), o_b0 = A.alloc(16), o_w1 = A.alloc(5 * 2 * 8 * 8), o_b1 = A.alloc(16);
+    const size_t o_w0 = A.alloc(5 * 9 * 16 + 3 * 8 * 16), o_b0 = A.alloc(16), o_w1 = A.alloc(5 * 2 * 8 * 8), o_b1 = A.alloc(16);
     const size_t o_w3 = A.alloc(5 * 2 * 8 * 8), o_b3 = A.alloc(16), o_w4 = A.alloc(5 * 16 * 2), o_b4 = A.alloc(2);
     for (int co = 0; co < 16; ++co)
         for (int ci = 0; ci < 9; ++ci)
             for (int k = 0; k < 5; ++k) A.f[o_w0 + (k * 9 + ci) * 16 + co] = w0[(co * 9 + ci) * 5 + k];
+    // conv0 on the matrix cores (front stage, main round): the SFE tap o and the conv tap k with the same k + o read the same input column, so
+    // their weights are one term; the eighth slot of each input channel takes the k = 1, o = 2 term back at fo = 0 (its SFE position is padding).
+    for (int co = 0; co < 16; ++co)
+        for (int c = 0; c < 3; ++c) {
+            for (int jj = 0; jj < 7; ++jj) {
+                float sum = 0.0f;
+                for (int k = 0; k < 5; ++k) {
+                    const int o = jj - k;
+                    if (o >= 0 && o < 3) sum += w0[(co * 9 + c * 3 + o) * 5 + k];
+                }
+                A.f[o_w0 + 720 + (c * 8 + jj) * 16 + co] = sum;
+            }
+            A.f[o_w0 + 720 + (c * 8 + 7) * 16 + co] = -w0[(co * 9 + c * 3 + 2) * 5 + 1];
+        }
     for (int g = 0; g < 2; ++g)
         for (int co = 0; co < 8; ++co)
             for (int ci = 0; ci < 8; ++ci)

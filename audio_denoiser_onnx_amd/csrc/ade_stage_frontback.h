@@ -176,6 +176,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
     ADE_CLK(33);
     long long clk_prev = ADE_CLK_START();
     const cfptr c0b = cptr(c0.b), c1b = cptr(c1.b);
+    const cfptr c0e = cptr(c0.w) + 5 * 9 * 16;           // the merged SFE x conv0 terms [3][8][16] (see the main round of conv0)
 
     for (int t0 = tbeg; t0 < tend; t0 += kTileF) {
         const int nf = tend - t0 < kTileF ? tend - t0 : kTileF;
@@ -248,44 +249,44 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
         ADE_CLK(34);
         ADE_CLK_ACC(40);
         // ---- F6-F7a: SFE(3) + Conv2d(9->16,(1,5),s(1,2),p(0,2)) + BN + PReLU -> E0 (LDS) + e0 (HBM).
-        //      Main round: one lane per (frame, fo < 64), 16 output channels each.
+        //      Main round on the matrix cores: a wavefront per frame, four tiles of 16 output columns fo < 64; lane (g, j) of a tile owns output
+        //      channels 4g .. 4g+3 of column j.  The SFE taps o and the conv taps k that read the same input column 2 fo - 3 + (k + o) are ONE
+        //      term with the weights summed on the host (45 -> 21 terms per input channel set, K = 3 x 8 with the padding below), which is exact
+        //      for fo >= 1: at fo = 0 the conv zero-pads the SFE OUTPUT at p = -1, whose only non-zero contribution (k = 1, o = 2: feat[c][0]) is
+        //      taken back by the K slot that pads each channel's 7 terms to 8 (weight -w[1][c*3+2], input feat[c][0] at fo = 0 and zero elsewhere).
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);                               // keep this phase's index arithmetic out of the other phases' live ranges
-            const int tl = tq >> 6, fo = tq & 63;
+            const int tl = tq >> 6, g = (tq >> 4) & 3, j = tq & 15;
             if (tl < nf) {
                 const float* fr = feat + (size_t)tl * 3 * kErb;
-                cfptr cw = cptr(c0.w);
-                ADE_KEEP_IN_LOOP(cw);
-                float v[3][7];
+                float wa[6];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int kk = 0; kk < 6; ++kk) wa[kk] = c0e[((kk >> 1) * 8 + 4 * (kk & 1) + g) * 16 + j];
+                v4f cb;
 #pragma unroll
-                    for (int j = 0; j < 7; ++j) {
-                        const int q = 2 * fo - 3 + j;
-                        v[c][j] = (q >= 0 && q < kErb) ? fr[c * kErb + q] : 0.0f;
+                for (int r = 0; r < 4; ++r) cb[r] = c0b[4 * g + r];
+                const float sel0 = prelu_sel(c0.slope);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int fo = 16 * mt + j;
+                    const int q0 = 2 * fo - 3 + g;                          // terms 0-3 of a channel
+                    const bool v0 = q0 >= 0;
+                    const int q1 = g == 3 ? 0 : 2 * fo + 1 + g;             // terms 4-6, and the correction slot
+                    const bool v1 = g == 3 ? fo == 0 : q1 < kErb;
+                    v4f d = cb;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float x0 = fr[c * kErb + q0], x1 = fr[c * kErb + q1];
+                        d = mfma16x16x4(wa[2 * c], v0 ? x0 : 0.0f, d);
+                        d = mfma16x16x4(wa[2 * c + 1], v1 ? x1 : 0.0f, d);
                     }
-                float acc[16];
-#pragma unroll
-                for (int co = 0; co < 16; ++co) acc[co] = c0b[co];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const bool pv = 2 * fo - 2 + k >= 0;               // position in the SFE output; the conv zero-pads outside [0,129)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-#pragma unroll
-                        for (int o = 0; o < 3; ++o) {
-                            const float x = pv ? v[c][k + o] : 0.0f;   // SFE channel c*3+o at p = feat[c][p-1+o]
-#pragma unroll
-                            for (int co = 0; co < 16; ++co) acc[co] += cw[(k * 9 + c * 3 + o) * 16 + co] * x;
-                        }
+                    const float4 r4 = make_float4(prelu_m(d[0], d[0] * c0.slope, sel0), prelu_m(d[1], d[1] * c0.slope, sel0),
+                                                  prelu_m(d[2], d[2] * c0.slope, sel0), prelu_m(d[3], d[3] * c0.slope, sel0));
+                    const int idx = tl * kF1 + fo;
+                    E0[g * kTileP1 + idx] = r4;
+                    *reinterpret_cast<float4*>(e0c + ((size_t)g * P0 + (size_t)t0 * kF1 + idx) * 4) = r4;
                 }
-#pragma unroll
-                for (int co = 0; co < 16; ++co) acc[co] = prelu_f(acc[co], c0.slope);
-                const int idx = tl * kF1 + fo;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) E0[q * kTileP1 + idx] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-                pl_st16(e0c, P0, t0 * kF1 + idx, acc);
             }
         }
         //      Tail: column fo = 64 of every frame, one lane per (frame, output channel); taps k = 0..2 reach p = 126..128.
