@@ -379,7 +379,7 @@ def main():
         if tf / FP32_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
             roofline = {"kernel": dom, "bound": "fp32_valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                        "peak_note": "packed-fp32 VALU peak, 157.3 TFLOP/s (numerically the same as the dense f32-MFMA rate on gfx950); the kernel has no matrix-core work",
+                        "peak_note": "fp32 peak, 157.3 TFLOP/s: the packed-fp32 VALU rate and the dense f32-MFMA rate (v_mfma_f32_16x16x4_f32) are the same 64 FLOP/clk/SIMD on gfx950; the kernel uses both (pointwise convolutions of the GTConvBlocks and conv0 on the matrix cores, the rest packed VALU)",
                         "avg_launch_us": round(t_launch * 1e6, 2), "avg_launch_us_events": round(t_events * 1e6, 2),
                         "avg_launch_from": "the timed loop (K launches back to back)" if one_kernel_step else "HIP events",
                         "alt_hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
