@@ -611,7 +611,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             const int tl = tq >> 6, m = tq & 63;
             if (tl < nf) {
                 const int idx = tl * kF1 + m;
-                float ev[2] = {c4b[0], c4b[1]}, od[2] = {c4b[0], c4b[1]};
+                v2f ev = mk2(c4b[0], c4b[1]), od = ev;                 // the two mask channels of a bin: one packed accumulator (weights are channel pairs)
 #pragma unroll
                 for (int dlt = -1; dlt <= 1; ++dlt) {
                     const bool ok = m + dlt >= 0;                       // m + dlt <= 64 is always a valid column; padding by select
@@ -621,12 +621,10 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
                         const float4 xq = D[q * kTileP1 + idx + (ok ? dlt : 0)];
                         const float xv[4] = {ok ? xq.x : 0.0f, ok ? xq.y : 0.0f, ok ? xq.z : 0.0f, ok ? xq.w : 0.0f};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int co = 0; co < 2; ++co) {
-                                ev[co] += c4w[(ke * 16 + 4 * q + c) * 2 + co] * xv[c];
-                                if (dlt >= 0) od[co] += c4w[(ko * 16 + 4 * q + c) * 2 + co] * xv[c];
-                            }
+                        for (int c = 0; c < 4; ++c) {
+                            ev += mk2(c4w[(ke * 16 + 4 * q + c) * 2], c4w[(ke * 16 + 4 * q + c) * 2 + 1]) * xv[c];
+                            if (dlt >= 0) od += mk2(c4w[(ko * 16 + 4 * q + c) * 2], c4w[(ko * 16 + 4 * q + c) * 2 + 1]) * xv[c];
+                        }
                     }
                 }
                 float* mr = M + (size_t)tl * 2 * kErbPad;
