@@ -1293,19 +1293,18 @@ int ZipEngine::reserve(int batch, std::string& err) {
     ws = nullptr; partial = nullptr; capacity = 0;
     const size_t B = (size_t)batch * n_win, J = B * T, tok0 = J * kZF, R = J * F, Rd = B * dT * dF, F2 = (size_t)F * up;
     const size_t wide = (size_t)std::max({3 * hid, H * vd, 2 * C, ffd, ff3});
+    const size_t Rt = std::min<size_t>(B, 8) * T * F;     // encoder snapshots: always carved, for calls of at most 8 windows whatever capacity was reserved
     const size_t dh = std::max(tok0 * 4 * C, R * 8 * C);
     const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
-                            J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, R * C, R * C, R * C, R * C, R * C};
+                            J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, Rt * C, Rt * C, Rt * C, Rt * C, Rt * C};
     float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
                       &enc_tap[3], &enc_tap[4]};
-    keep_taps = B <= 8;                            // encoder snapshots (5 device copies per call) only for test-sized calls
-    const int nbuf = keep_taps ? 22 : 17;
+    const int nbuf = 22;
     size_t total = 0;
     for (int i = 0; i < nbuf; ++i) total += (sizes[i] + 63) & ~(size_t)63;
     ZP_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
     size_t at = 0;
     for (int i = 0; i < nbuf; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
-    if (!keep_taps) for (int i = 0; i < 5; ++i) enc_tap[i] = nullptr;
     nrm2 = nrm + B * 8 * C * 2;                    // statistics of the tensors normalised outside the dense blocks (dense_conv_2, the up-sampler)
     const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
     ZP_HIP(hipMalloc((void**)&partial, B * std::max(nchunk0, nchunk2) * 64 * 2 * sizeof(double)));
@@ -1396,7 +1395,8 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     const int B = batch * n_win, J = B * T, TF0 = T * kZF, F2 = F * up;
     const long long tok0 = (long long)J * kZF, R = (long long)J * F;
     auto flat = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
-    auto snap = [&](int i) { if (enc_tap[i]) (void)hipMemcpyAsync(enc_tap[i], X, (size_t)R * C * sizeof(float), hipMemcpyDeviceToDevice, s); };
+    keep_taps = B <= 8;                            // encoder snapshots (5 device copies per call) only for test-sized CALLS
+    auto snap = [&](int i) { if (keep_taps) (void)hipMemcpyAsync(enc_tap[i], X, (size_t)R * C * sizeof(float), hipMemcpyDeviceToDevice, s); };
     // ---- front (:819-844)
     hipLaunchKernelGGL(k_zip_window_norm, dim3((unsigned)B), dim3(256), 0, s, d_in, float_in, norm, L);
     gemm::launch(s, gemm::RowMajorA{k_fwd, kZN}, ZFrameB{d_in, float_in, norm, L, T}, ZSpecStore{spec, J}, kZC2, J, kZN);
@@ -1451,9 +1451,9 @@ int ZipEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_
     else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's dense outputs, normalised + PReLU (windows, T, F, 8 C)
     else if (strcmp(name, "nrm") == 0) { src = nrm; n = B * 8 * C * 2; }
     else return zfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    if (strncmp(name, "enc", 3) == 0 && B > 8) src = nullptr;
     if (!src || batch <= 0)
-        return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data yet (the encoder snapshots are only carved while the RESERVED capacity is at most 8 windows: "
-                                             "a handle that was ever reserved for more keeps none, whatever the size of the call)");
+        return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data (the encoder snapshots are taken by calls of at most 8 windows, whatever capacity was reserved)");
     if (count < n) return zfail(err, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
     ZP_HIP(hipStreamSynchronize(s));
     ZP_HIP(hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -208,6 +208,14 @@ def test_gpu_zipenhancer_full_batch_properties(model):
     perm = np.random.default_rng(3).permutation(128)
     outp, _ = sess.process(x[perm])
     assert np.array_equal(outp, out[perm])
+    # the encoder snapshots belong to the CALL (at most 8 windows), not to the capacity the handle was once reserved for: a 4-row call on this 128-row handle has them
+    small, _ = sess.process(x[pick])
+    C = zp.ZipConfig().channels
+    enc = sess.tap("enc0", 4 * T * 101 * C)
+    assert enc.size == 4 * T * 101 * C and np.isfinite(enc).all() and np.abs(enc).max() > 0
+    with pytest.raises(Exception):
+        sess.process(x[:16])
+        sess.tap("enc0", 16 * T * 101 * C)
 
 
 GOLD_DYN = os.path.join(os.path.dirname(GOLD), "zipenhancer_dynamic_seed0.npz")
