@@ -436,6 +436,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         // an address select instead of an exec-mask branch in the serial loop
         float* hsp = row == 3 ? HS + j : GI + (tid & 63);
         const int hs_step = row == 3 ? 16 : 0;
+        __builtin_amdgcn_s_setprio(3);
         for (int t = 0; t < T; ++t) {
             const int tn = t + 1 < T ? t + 1 : t;
             const float gnx = GI[tn * 48 + gsel * 16 + j];
@@ -467,6 +468,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
             hsp += hs_step;
             gi = gnx;
         }
+        __builtin_amdgcn_s_setprio(0);
         if (sg.next) {                                               // hand the state on: row 3 holds h_T
             if (row == 3) xst1(sg.xo + kXTraOff + blk * 16 + j, hv);
             xdrain();
@@ -723,6 +725,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         float xq[4][8];
 #pragma unroll
         for (int d = 0; d < 3; ++d) pl_ld8(xc, Ps, prow + (dir ? kFw - 1 - d : d), grp * 2, xq[d]);
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s = 0; s < kFw; ++s) {
             const int f = dir ? kFw - 1 - s : s;
@@ -745,6 +748,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             h = n + z * (h - n);
             if (live) Rf[((size_t)(q >> 2) * kPmax + tc * kFw + f) * 4 + (q & 3)] = h;
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     ADE_CLK(17);
@@ -813,6 +817,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         float* const xin = sg.xi + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q;
         if (sg.prev) h = xld1(xin);                                  // the recurrence continues from the previous segment's last frame
         float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
+        __builtin_amdgcn_s_setprio(3);
         for (int t = 0; t < T; ++t) {
             const int p = t * kFw + fc_;
             const int pn = (t + 1 < T ? t + 1 : t) * kFw + fc_;
@@ -841,6 +846,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             h = n + z * (h - n);
             if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
         }
+        __builtin_amdgcn_s_setprio(0);
         if (sg.next) {
             if (live) xst1(sg.xo + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q, h);
             xdrain();
