@@ -304,7 +304,7 @@ struct Loader {
     }
 };
 
-constexpr int kClkSlots = ade::kClkSlotsPerSeg * 2;   // phase clocks of the first two segments
+constexpr int kClkSlots = ade::kClkSlotsPerSeg * ade::kMaxSegments;   // phase clocks of every segment of chunk 0 (the stage bodies stamp seg * kClkSlotsPerSeg + slot)
 
 ade_status build_device_constants(ade_engine* e) {
     Loader L{e};

@@ -46,14 +46,14 @@ for rep in range(2):
         print(f"rep {rep} geometry {geo} wave_swap {prio}: {ms:.4f} ms/step  ({B * 0.992 / ms * 1e3:.0f} audio-s/s)  xchg_error {err}", flush=True)
         if rep == 1:
             s.profile(3); s.process(x); s.process(x)
-            rel = s.tap('phase_clock', 1280).reshape(2, 10, 64)
+            rel = s.tap('phase_clock', 5120).reshape(-1, 10, 64)
             for seg in range(2):
                 print(f"  seg {seg} front acc over tiles [stft+feat, conv0, conv1] us:", np.round(rel[seg, 0, 40:43] / 100, 1).tolist(), " mean", round(float(rel[seg, 0, 33] - rel[seg, 0, 32]) / 100, 1),
                       "| back acc [top, deconv3, s-issue+deconv4, mask+irfft+ola, commit+finalize, carry] us:", np.round(rel[seg, 9, 56:62] / 100, 1).tolist())
-            c = s.tap('phase_clock_abs', 1280).reshape(2, 10, 64)
+            c = s.tap('phase_clock_abs', 5120).reshape(-1, 10, 64)
             s.profile(0)
-            for seg in range(2):
-                if c[seg, 0, 32] < 0 and seg > 0:
+            for seg in range(min(c.shape[0], 4)):
+                if (c[seg, 0, 32] < 0 or not c[seg].any()) and seg > 0:
                     continue
                 names = ['front', 'enc0', 'enc1', 'enc2', 'dp0', 'dp1', 'dec0', 'dec1', 'dec2', 'back']
                 first = [32, 0, 0, 0, 16, 16, 0, 0, 0, 48]
