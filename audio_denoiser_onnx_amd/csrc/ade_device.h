@@ -263,6 +263,14 @@ __device__ __forceinline__ void xwait(unsigned* flag, int* err) {
     xflag_store(flag, 0u);
 }
 
+// s_setprio takes an immediate: a wave-uniform level goes through a scalar branch chain
+__device__ __forceinline__ void set_prio(int p) {
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 inline dim3 grid1(long long n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 }  // namespace dev

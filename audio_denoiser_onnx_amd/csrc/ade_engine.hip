@@ -611,7 +611,8 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     if (fused) {
         // ---- fused path: one workgroup per chunk SEGMENT per stage (ade_internal.h: geometries), activations LDS-resident, inter-stage
         //      tensors channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  1 launch, or 10.
-        const SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr, e->wave_swap};
+        SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr, e->wave_swap};
+        plan.prio = e->seg_prio;
         e->last_geometry = geo;
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
@@ -1241,7 +1242,7 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         return ADE_OK;
     }
     if (strcmp(key, "seg_prio") == 0) {        // s_setprio level of the workgroups that own a later segment of a chunk (0-3)
-        if (value[0] < '0' || value[0] > '3' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option seg_prio: 0..3");
+        if (value[0] < '0' || value[0] > '4' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option seg_prio: 0..4");
         h->seg_prio = value[0] - '0';
         return ADE_OK;
     }

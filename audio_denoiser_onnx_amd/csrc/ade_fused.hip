@@ -59,6 +59,7 @@ __device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int b
         sg.fo = plan.carry_out_flags + (size_t)chunk * kXFlags;
     }
     sg.first = !sg.prev;
+    sg.base_prio = plan.prio == 4 ? (seg < 2 ? 2 - seg : 0) : (seg > 0 ? plan.prio : 0);
     return sg;
 }
 __device__ __forceinline__ long long* seg_clk(long long* clk, const Seg& sg, int B, int block) {
@@ -131,12 +132,7 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         ADE_STAGE_ENTRY();
         // A later segment is the younger workgroup on its CU and is served last by the oldest-first instruction arbitration; option
         // "seg_prio" raises its wave priority (measured: it only swaps which of the two workgroups of a CU is held back).
-        if (sg.prev) {
-            const int pr = C->seg_prio;
-            if (pr == 1) __builtin_amdgcn_s_setprio(1);
-            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-            else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-        }
+        set_prio(sg.base_prio);
         // De-phase the workgroups (geometry 0: one workgroup per CU).  Every stage begins and ends with an HBM burst (its inputs / skip
         // tensors in, its output out) and at 256 chunks all 256 workgroups would issue the same burst at the same instant: measured, the
         // stages run 28 % slower at 256 chunks than at 3 (tools/phase_clock.py).  Holding every other group of 8 workgroups back by about one

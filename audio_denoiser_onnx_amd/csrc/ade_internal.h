@@ -164,6 +164,7 @@ struct SegPlan {           // how a launch splits its chunks (host-computed, pas
     float* carry_out;      // [B][kXFloats] state the LAST segment leaves (null: nothing follows)
     unsigned* carry_out_flags;
     int stream;            // 1: streaming framing -- frame t reads samples 256 t .. 256 t + 511 of the row (256 carried + the push), output sample n = overlap-add sample n
+    int prio;              // base wave priority of the workgroups by segment (option "seg_prio"): 0 none; 1-3 = that level for every later segment; 4 = earlier segments first (2, 1, 0, 0)
 };
 struct Seg {               // one workgroup's share (device-side)
     int t0, nT, T;         // first frame, frames owned, frames of the chunk
@@ -171,6 +172,7 @@ struct Seg {               // one workgroup's share (device-side)
     int swap;              // this workgroup permutes its upper wavefronts (SegPlan::wave_swap, odd segments)
     int stream;            // SegPlan::stream
     int first;             // nothing precedes this segment at all: a chunk's / stream's very first frames
+    int base_prio;         // wave priority outside the recurrences (which run at 3)
     float* xo;             // exchange slot this segment fills (for the next one)
     float* xi;             // exchange slot of the previous segment
     unsigned* fo;          // flags this segment raises

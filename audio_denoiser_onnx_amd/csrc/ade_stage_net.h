@@ -468,7 +468,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
             hsp += hs_step;
             gi = gnx;
         }
-        __builtin_amdgcn_s_setprio(0);
+        set_prio(sg.base_prio);
         if (sg.next) {                                               // hand the state on: row 3 holds h_T
             if (row == 3) xst1(sg.xo + kXTraOff + blk * 16 + j, hv);
             xdrain();
@@ -748,7 +748,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             h = n + z * (h - n);
             if (live) Rf[((size_t)(q >> 2) * kPmax + tc * kFw + f) * 4 + (q & 3)] = h;
         }
-        __builtin_amdgcn_s_setprio(0);
+        set_prio(sg.base_prio);
     }
     __syncthreads();
     ADE_CLK(17);
@@ -846,7 +846,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             h = n + z * (h - n);
             if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
         }
-        __builtin_amdgcn_s_setprio(0);
+        set_prio(sg.base_prio);
         if (sg.next) {
             if (live) xst1(sg.xo + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q, h);
             xdrain();
