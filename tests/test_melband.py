@@ -284,3 +284,25 @@ def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
     snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
     print(f"mel_band_roformer bf16 vs f32: SNR {snr:.1f} dB")
     assert snr > 20.0
+
+
+@pytest.mark.gpu
+def test_gpu_full_depth_full_length_properties():
+    """BASELINE configs[3]'s network and window -- depth 6, 8 s stereo segments (801 frames) -- on the random-init weights `bench.py --workload melband` times: the
+    whole stack runs at full depth, outputs are finite and non-trivial, and a row's bits do not depend on the rows beside it."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_stereo
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    L = 352800
+    w = weightgen.materialise(melband.synthetic_spec(6))
+    blob = pack_blob(melband.model_tensors(w))
+    del w
+    x = np.stack([synth_stereo(40 + i, L, 44100).reshape(-1) for i in range(3)])
+    with InferenceSession(weights=blob, metadata=melband.metadata(L)) as sess:
+        assert sess.frames == 801
+        out, f32 = sess.process(x, want_f32=True)
+        solo, _ = sess.process(x[1:2])
+        rev, _ = sess.process(x[::-1].copy())
+    assert np.isfinite(f32).all() and np.abs(out).max() > 50
+    assert np.array_equal(out[1:2], solo) and np.array_equal(rev, out[::-1])

@@ -264,3 +264,27 @@ def test_gpu_file_driver_head_padding_two_outputs(fixture, tmp_path):
         want = sess.run(None, {"mix_audio": slices[:, None, :]})
     for spk in range(2):
         assert np.array_equal(outs[spk], want[spk].reshape(-1)[8000:len(padded)])
+
+
+@pytest.mark.gpu
+def test_gpu_full_depth_full_length_properties():
+    """BASELINE configs[4]'s network and window -- 24 layers, 4 s windows (7999 frames) -- on the random-init weights `bench.py --workload mossformer` times: finite
+    outputs, a silent row stays silent, a row's bits do not depend on the rows beside it."""
+    from audio_denoiser_onnx_amd import mossformer
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_chunk
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    L, layers = 64000, 24
+    frames = mossformer.frames_of(L)
+    fused = {n: mossformer.synthetic_tensor(n, sh, sc, frames) for n, sh, sc in mossformer.synthetic_spec(layers)}
+    scalars = dict(mossformer.DEFAULT_SCALARS, fs_front_alpha=[0.25] * layers)
+    blob = pack_blob(mossformer.model_tensors(fused, scalars, L))
+    del fused
+    x = np.stack([synth_chunk(500, L), np.zeros(L, np.int16), synth_chunk(501, L)])
+    with InferenceSession(weights=blob, metadata=mossformer.metadata(L)) as sess:
+        assert sess.frames == 7999
+        out, f32 = sess.process(x, want_f32=True)
+        solo, _ = sess.process(x[2:3])
+    out = out.reshape(3, 2, -1)
+    assert np.isfinite(f32).all() and np.abs(out[0]).max() > 50 and not out[1].any()
+    assert np.array_equal(out[2], solo.reshape(2, -1))
