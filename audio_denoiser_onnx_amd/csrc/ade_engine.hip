@@ -932,9 +932,12 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // ZipEnhancer's (Export_ZipEnhancer.py:31, :61, :828-829, :898-899, :907-908; STFT_Process.py:294-299): the same two places -- its ISTFT trims half a window on
         // both sides in either mode, so the output is still 100 (T - 1) samples, cut to the model-rate input length (a no-op), but DIVIDED by the denominator instead of
         // multiplied by its precomputed reciprocal; the position tables are slices of the same 1024-frame table either way.
-        const bool dyn_sf = dyn_d && (fam_dfsmn || fam_zip);
+        // MossFormer2-SS's (Export_MossFormer2_SS_16K.py:24, :183, :430, :500-501, :565-577, :634-646): scale-factor edges again, and 1 / frames is applied to the reduced
+        // linear-attention product at run time instead of being folded into the OffsetScale row of the linear keys; tables are slices of the 6 s ones, the rotary
+        // half-rotation is the same arithmetic in either form, any window of 16 + 8 k samples.
+        const bool dyn_sf = dyn_d && (fam_dfsmn || fam_zip || fam_moss);
         if (dyn_d && !fam_sand && !dyn_sf)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer, ul_unas, dfsmn and zipenhancer (static shapes only for " + fam + ")"));
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer, ul_unas, dfsmn, zipenhancer and mossformer2_ss (static shapes only for " + fam + ")"));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
         if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
@@ -1016,7 +1019,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, dyn_d ? (int)caller_len : 0, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
-                                     : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, device, &e->sub, derr);
+                                     : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, dyn_d, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();
         e->out_channels = e->sub->out_channels();

@@ -252,7 +252,7 @@ struct SubEngine {
 int dfsmn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
 // model_family "mossformer2_ss" (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662), csrc/ade_mossformer.hip
-int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, int device, SubEngine** out, std::string& err);
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err);
 // model_family "ul_unas" (UL-UNAS/Export_UL_UNAS.py:51-913), csrc/ade_ulunas.hip
 int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int dynamic_keep /* 0: static export; > 0: dynamic, the caller-rate input length */, int device, SubEngine** out, std::string& err);
 // model_family "h_gtcrn" (H-GTCRN/Export_H_GTCRN.py:428-1063), csrc/ade_hgtcrn.hip

@@ -327,6 +327,12 @@ __global__ __launch_bounds__(256) void k_lkv_reduce(const float* __restrict__ pa
     lkv[i] = s;
 }
 
+// DYNAMIC_AXES export (:183, :430, :500-501): 1 / frames is not folded into the linear-key OffsetScale row; the reduced 128 x 2048 product is scaled once at run time
+__global__ __launch_bounds__(256) void k_lkv_scale(float* __restrict__ lkv, float scale, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) lkv[i] = lkv[i] * scale;
+}
+
 // ---- row-wise and time-wise kernels ------------------------------------------------------------------------------------------
 // inv[m] = 1 / max(|token-shifted row m|, eps)   (:457)
 __global__ __launch_bounds__(256) void k_shift_invnorm(const float* __restrict__ h, float* __restrict__ inv, int rows, int n, float eps) {
@@ -655,6 +661,7 @@ struct MossformerEngine : SubEngine {
     float4* partial = nullptr;     // per (window, time tile, channel) partial statistics of the memory convolutions
     float4* wpart = nullptr;       // per (window, slice) partial statistics of the two window norms
     float* lkv_part = nullptr;     // split-K partial sums of the linear-attention key / value product
+    float lin_scale = 0.0f;        // dynamic-axes export: 1 / frames applied to the reduced product at run time (0: folded into the weights)
     int lkv_splits = 1;
     float *rms_in = nullptr, *XE = nullptr, *MI = nullptr, *H = nullptr, *inv = nullptr, *P = nullptr, *P2 = nullptr, *heads = nullptr, *ATT = nullptr, *AO = nullptr,
           *LKV = nullptr, *G = nullptr, *Y = nullptr, *C1 = nullptr, *GF = nullptr, *XN = nullptr, *UV = nullptr, *UV2 = nullptr, *F1 = nullptr, *XP = nullptr,
@@ -675,7 +682,7 @@ struct MossformerEngine : SubEngine {
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
 };
 
-int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, int device, SubEngine** out, std::string& err) {
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return xfail(err, ADE_ERR_BAD_VALUE, "mossformer: n_win must be >= 1");
     if (window_len < kEncK || (window_len - kEncK) % kEncS != 0)
@@ -706,6 +713,7 @@ int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_l
     if (group < 16 || group > 4096 || rot < 2 || rot > kQk || (rot & 1) || (int)e->hyper[hDwPad] != (kDw - 1) / 2 || depth < 1 || depth > 2 || 2 * lorder - 1 != kMemK)
         return bail(xfail(err, ADE_ERR_UNSUPPORTED, "mossformer: unsupported geometry (group 16..4096, even rotary <= 128, depthwise k 17, memory order 20, depth 1..2)"));
     e->bf16 = bf16;
+    e->lin_scale = dynamic ? (float)(1.0 / (double)n) : 0.0f;       // torch: tensor * (1.0 / n) -- the Python float becomes one fp32 scalar
     e->device = device; e->W = window_len; e->n_win = n_win; e->n = n; e->layers = layers;
     e->padded = (n + group - 1) / group * group;
     e->groups = e->padded / group;
@@ -846,6 +854,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
             hipLaunchKernelGGL(k_lkv_reduce, flat((long long)B * kQk * kVu2), dim3(256), 0, s, (const float*)lkv_part, LKV, lkv_splits, (long long)kQk * kVu2,
                                (long long)B * kQk * kVu2);
         }
+        if (lin_scale != 0.0f) hipLaunchKernelGGL(k_lkv_scale, flat((long long)B * kQk * kVu2), dim3(256), 0, s, LKV, lin_scale, (long long)B * kQk * kVu2);
         launch_batched(s, AttOutProb{ATT, P2, lin_q, LKV, AO, g, groups, n, padded}, B * groups, g, kVu2, bf16);
         hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
         launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu, bf16);

@@ -8,7 +8,7 @@ matrices (``ERB.prepare_for_export_`` :109-114), and write the tensors under the
     python -m audio_denoiser_onnx_amd.export <checkpoint.tar|state_dict.npz> <out_dir> [--length 16000] [--dynamic] [--in-rate 48000] [--out-rate 8000]
                                                                                        [--in-dtype F32] [--out-dtype F32]
     python -m audio_denoiser_onnx_amd.export --family mel_band_roformer <MelBandRoformer.ckpt> <out_dir> [--length 66150] [--fold] [--dynamic [--in-rate 48000] [--out-rate 48000]]
-    python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold]
+    python -m audio_denoiser_onnx_amd.export --family mossformer2_ss <checkpoint> <out_dir> [--length 24000] [--fold] [--dynamic [--in-rate 8000] [--out-rate 48000]]
     python -m audio_denoiser_onnx_amd.export --family ul_unas <model_trained_on_dns3.tar> <out_dir> [--length 16000]
     python -m audio_denoiser_onnx_amd.export --family zipenhancer <pytorch_model.bin> <out_dir> [--length 32000] [--fold]
 
@@ -119,16 +119,19 @@ def export_melband(checkpoint, out_dir, input_audio_length: int = 66150, use_bat
     return model_path
 
 
-def export_mossformer(checkpoint, out_dir, input_audio_length: int = 24000, use_batch_fold: bool = False, name: str = "MossFormer2_SS_16K") -> Path:
-    """clearvoice ``MossFormer2_SS_16K`` checkpoint -> ``<name>.adew`` + manifest (Export_MossFormer2_SS_16K.py:672-720 minus ONNX)."""
+def export_mossformer(checkpoint, out_dir, input_audio_length: int = 24000, use_batch_fold: bool = False, name: str = "MossFormer2_SS_16K", dynamic_axes: bool = False,
+                      in_sample_rate: int = 16000, out_sample_rate: int = 16000) -> Path:
+    """clearvoice ``MossFormer2_SS_16K`` checkpoint -> ``<name>.adew`` + manifest (Export_MossFormer2_SS_16K.py:672-720 minus ONNX).
+    ``dynamic_axes``: the DYNAMIC_AXES export (:24): scale-factor edges, 1 / frames left out of the fused OffsetScale row and applied at run time (:183)."""
     from . import mossformer
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     model_path = out_dir / f"{name}.adew"
-    meta = mossformer.metadata(input_audio_length, use_batch_fold=use_batch_fold)
-    window = int(meta["fold_window_length"]) if use_batch_fold else input_audio_length
+    meta = mossformer.metadata(input_audio_length, use_batch_fold=use_batch_fold, dynamic_axes=dynamic_axes, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate)
+    model_len = int(input_audio_length * (16000 / in_sample_rate)) if dynamic_axes else int(round(input_audio_length * 16000 / in_sample_rate))      # (:36; floor for scale_factor)
+    window = int(meta["fold_window_length"]) if use_batch_fold else model_len
     sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in load_state_dict(checkpoint).items()}
-    fused, scalars = mossformer.fuse_checkpoint(sd, mossformer.frames_of(window))
+    fused, scalars = mossformer.fuse_checkpoint(sd, mossformer.frames_of(window), fold_inv_n=not dynamic_axes)
     save_blob(model_path, mossformer.model_tensors(fused, scalars, window))
     write_metadata(model_path, meta)
     return model_path
@@ -213,7 +216,8 @@ def main(argv=None) -> int:
         path = export_melband(argv[0], argv[1], length or 66150, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"],
                               out_sample_rate=gt["out_sample_rate"])
     elif family == "mossformer2_ss":
-        path = export_mossformer(argv[0], argv[1], length or 24000, fold)
+        path = export_mossformer(argv[0], argv[1], length or 24000, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"] or 16000,
+                                 out_sample_rate=gt["out_sample_rate"] or 16000)
     elif family == "ul_unas":
         path = export_ulunas(argv[0], argv[1], length or 16000, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"], out_sample_rate=gt["out_sample_rate"])
     elif family == "h_gtcrn":

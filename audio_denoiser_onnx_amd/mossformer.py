@@ -57,21 +57,26 @@ def model_tensors(fused: Mapping[str, np.ndarray], scalars: Mapping, window: int
 
 
 def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window_seconds: float = 1.5, in_sample_rate: int = SAMPLE_RATE,
-             out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32") -> Dict[str, str]:
+             out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32", dynamic_axes: bool = False) -> Dict[str, str]:
     """Manifest keys the reference stamps for this model (:712-718): two output sources, conv encoder/decoder features.
     ``input_audio_length`` counts INPUT-rate samples; with in / out rates other than 16 kHz the engine interpolates linearly on both
-    edges like the export (:562-571, :625-640) and the model sees round(length * 16000 / in_rate) samples."""
+    edges like the export (:562-571, :625-640) and the model sees round(length * 16000 / in_rate) samples.
+    ``dynamic_axes``: the DYNAMIC_AXES export (:24): the edges interpolate by scale factor (floor(length * 16000 / in_rate) model-rate samples), and the weights carry the
+    linear keys' OffsetScale row WITHOUT the 1 / frames factor, which the graph applies at run time (:183, :430, :500-501) -- ``synthetic_tensor(..., fold_inv_n=False)``."""
+    if dynamic_axes and use_batch_fold:
+        raise ValueError("Batch folding requires a static shape (DYNAMIC_AXES = False)")                   # (:97)
     meta = build_audio_metadata(producer="audio_denoiser_onnx_amd", model_name="MossFormer2_SS_16K", task="source_separation",
                                 model_family="mossformer2_ss", input_audio_length=input_audio_length, in_sample_rate=in_sample_rate,
                                 out_sample_rate=out_sample_rate, model_sample_rate=SAMPLE_RATE,
                                 nfft=ENC_KERNEL, window_length=ENC_KERNEL, hop_length=ENC_STRIDE, window_type="none", center_pad=False,
-                                pad_mode="none", use_batch_fold=use_batch_fold, batch_window_seconds=batch_window_seconds,
+                                pad_mode="none", use_batch_fold=use_batch_fold, batch_window_seconds=batch_window_seconds, dynamic_axes=dynamic_axes,
+                                max_dynamic_audio_seconds=6,
                                 feature_kind="conv_encoder_decoder", extra={"pad_head": 8000, "enc_stride": ENC_STRIDE, "output_sources": 2,
                                                                              "ade_gemm_dtype": gemm_dtype})
     return meta
 
 
-def synthetic_tensor(name: str, shape, scale: float, frames: int, group_size: int = 256) -> np.ndarray:
+def synthetic_tensor(name: str, shape, scale: float, frames: int, group_size: int = 256, fold_inv_n: bool = True) -> np.ndarray:
     """Random-init value of one fused buffer (``weightgen.tensor`` + the constraints that keep the stack well conditioned):
     norm gains positive and away from zero, PReLU slopes positive, and the two factors the reference folds into OffsetScale
     -- 1 / group_size into the quadratic-query row, 1 / frames into the linear-key row (:236-241) -- applied to those rows."""
@@ -83,7 +88,8 @@ def synthetic_tensor(name: str, shape, scale: float, frames: int, group_size: in
     if name.startswith(("qkos_gamma_", "qkos_beta_")):
         v = v.copy()
         v[0] *= np.float32(1.0 / group_size)
-        v[3] *= np.float32(1.0 / frames)
+        if fold_inv_n:                                  # (the DYNAMIC_AXES export leaves this row alone and scales the reduced product instead, :183)
+            v[3] *= np.float32(1.0 / frames)
     return v
 
 
@@ -126,7 +132,7 @@ def flops_per_window(frames: int, layers: int, group: int = 256) -> float:
     return float(layers * per_layer + tail)
 
 
-def fuse_checkpoint(state: Mapping[str, np.ndarray], frames: int, scalars: Mapping = None):
+def fuse_checkpoint(state: Mapping[str, np.ndarray], frames: int, scalars: Mapping = None, fold_inv_n: bool = True):
     """clearvoice ``MossFormer2_SS_16K`` ``state_dict`` -> (fused buffers, scalar attributes) for ``frames`` encoder frames per window.
     Restates the fold algebra of the reference's export wrapper (Export_MossFormer2_SS_16K.py:130-395) in float64 with one rounding
     to fp32, as the reference does:
@@ -165,7 +171,7 @@ def fuse_checkpoint(state: Mapping[str, np.ndarray], frames: int, scalars: Mappi
         out[f"fl_out_w_{i}"] = g[fl + "to_out.mdl.1.weight"] * g[fl + "to_out.mdl.0.g"] * out_fold
         out[f"fl_out_b_{i}"] = g[fl + "to_out.mdl.1.bias"]
         out[f"fl_out_c_{i}"] = g[fl + "to_out.mdl.3.sequential.1.conv.weight"]
-        row = np.array([1.0 / group, 1.0, 1.0, 1.0 / frames])[:, None]
+        row = np.array([1.0 / group, 1.0, 1.0, 1.0 / frames if fold_inv_n else 1.0])[:, None]          # (fold_lin_inv_n = not DYNAMIC_AXES, :183, :252-253)
         out[f"qkos_gamma_{i}"] = g[fl + "qk_offset_scale.gamma"] * row
         out[f"qkos_beta_{i}"] = g[fl + "qk_offset_scale.beta"] * row
         fb = f"{lp}fsmn.{i}."

@@ -58,11 +58,26 @@ def interpolate_linear(x, out_len):
     return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
 
 
+def interpolate_scale(x, factor):
+    """F.interpolate(x, scale_factor=factor, mode='linear', align_corners=False): floor(n * factor) samples, source step 1 / factor in fp32 (the DYNAMIC_AXES export's
+    edges, :565-577, :634-646; recompute_scale_factor is left at None, so the given factor -- not out / in -- is the scale)."""
+    n = x.shape[-1]
+    out_len = int(np.floor(float(n) * float(factor)))
+    src = np.maximum(F32(1.0 / float(factor)) * (np.arange(out_len, dtype=F32) + F32(0.5)) - F32(0.5), F32(0.0)).astype(F32)
+    i0 = np.minimum(src.astype(np.int64), n - 1)
+    i1 = np.minimum(i0 + 1, n - 1)
+    l1 = (src - i0.astype(F32)).astype(F32)
+    return ((F32(1.0) - l1) * x[..., i0] + l1 * x[..., i1]).astype(F32)
+
+
 class MossFormerOracle:
     """tensors: the fused buffers by registered name (encoder_w, front_w, fl_in_w_i, ..., tail_gate_w, decoder_w) plus emb_pos
     (1, 512, n) and rot_cos / rot_signed_sin (1, n, 1, rot_dim); scalars: the dict the golden tool stores."""
 
-    def __init__(self, tensors: dict, scalars: dict, layers: int, window: int):
+    def __init__(self, tensors: dict, scalars: dict, layers: int, window: int, dynamic: bool = False):
+        # dynamic: the DYNAMIC_AXES export (:24): 1 / frames multiplies the reduced linear-attention product at run time (:430, :500-501) instead of being folded into
+        # the linear keys' OffsetScale row (:183, :236-241) -- `tensors` then hold the UNfolded row --, and the resampling edges interpolate by scale factor.
+        self.dynamic = bool(dynamic)
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         self.s = scalars
         self.layers, self.W = int(layers), int(window)
@@ -125,6 +140,8 @@ class MossFormerOracle:
         quad = ((attn * attn) @ vug).astype(F32)                                                            # (:488)
         lkf = lk.reshape(B, G * g, -1).transpose(0, 2, 1)                                                   # (B, 128, padded)
         lin_kvu = (lkf @ vug.reshape(B, G * g, 2048)).astype(F32)                                           # (:491-492), 1/n folded into head 3
+        if self.dynamic:
+            lin_kvu = (lin_kvu * F32(1.0 / n)).astype(F32)                                                  # (:500-501)
         lin = (lq @ lin_kvu[:, None]).astype(F32)                                                           # (:495)
         att = (quad + lin).reshape(B, G * g, 2048)[:, :n]
         av, au = att[..., :1024], att[..., 1024:]
@@ -171,6 +188,21 @@ class MossFormerOracle:
         y = (xv * xu + gf).astype(F32)                                                                      # (:538)
         n2 = _layer_norm(y, w[f"fs_n2_w_{i}"], w[f"fs_n2_b_{i}"], s["fs_n2_eps"])
         return (n2 @ w[f"fs_back_w_{i}"].T + w[f"fs_back_b_{i}"] + h).astype(F32)                          # (:541)
+
+    def process_dynamic(self, pcm: np.ndarray, in_rate: int = 16000, out_rate: int = 16000) -> np.ndarray:
+        """The DYNAMIC_AXES graph on (B, L) input-rate samples: scale-factor interpolation to the model rate (floor(L * 16000 / in) samples must be this oracle's
+        window), the network, scale-factor interpolation to the output rate."""
+        assert self.dynamic
+        xin = pcm.astype(F32)
+        if in_rate != 16000:
+            xin = interpolate_scale(xin, float(16000 / in_rate))
+        assert xin.shape[-1] == self.W, (xin.shape, self.W)
+        self.process(xin)
+        out = self.taps["wav"]
+        if out_rate != 16000:
+            out = interpolate_scale(out, float(out_rate / 16000))
+            self.taps["wav"] = out.copy()
+        return np.clip(np.trunc(out.astype(np.float64)), -32768, 32767).astype(np.int16)
 
     def process(self, pcm: np.ndarray, out_len: int = 0) -> np.ndarray:
         """pcm int16 (B, L): B independent windows -> int16 (B, 2, L_out).  L != W or out_len: the resampling edges (in / out rate != 16 kHz):

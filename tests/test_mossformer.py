@@ -165,6 +165,16 @@ def test_checkpoint_fusion_matches_reference():
               "norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fs_mem_depth"):
         assert abs(float(sc[k]) - float(want_sc[k])) <= 1e-6 * abs(float(want_sc[k])), k
     assert np.allclose(sc["fs_front_alpha"], want_sc["fs_front_alpha"])
+    # the DYNAMIC_AXES constructor (:24, :183): the same buffers except the OffsetScale rows, whose linear-key row carries no 1 / frames
+    dyn, _ = mossformer.fuse_checkpoint(state, int(want_sc["static_frames"]), fold_inv_n=False)
+    for name in fused:
+        if name.startswith("qkos_"):
+            v = dyn[name].reshape(-1).astype(np.float64)
+            got = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+            assert np.allclose(got, z[f"dyn_{name}"], rtol=2e-6, atol=2e-6), name
+            assert not np.array_equal(dyn[name][3], fused[name][3]) and np.array_equal(dyn[name][:3], fused[name][:3]), name
+        elif name != "emb_pos":
+            assert np.array_equal(dyn[name], fused[name]), name
 
 
 @pytest.mark.gpu
@@ -288,3 +298,52 @@ def test_gpu_full_depth_full_length_properties():
     out = out.reshape(3, 2, -1)
     assert np.isfinite(f32).all() and np.abs(out[0]).max() > 50 and not out[1].any()
     assert np.array_equal(out[2], solo.reshape(2, -1))
+
+
+# ---- DYNAMIC_AXES export (Export_MossFormer2_SS_16K.py:24): run-time 1 / frames, scale-factor edges; one reference module instance run on two lengths ------------------
+GOLD_DYN = os.path.join(HERE, "golden", "mossformer_dynamic_seed0.npz")
+
+
+def _dynamic_case(tag):
+    z = np.load(GOLD_DYN)
+    spec, scalars = json.loads(str(z["spec"])), json.loads(str(z["scalars"]))
+    pcm, ref = z["pcm_in_" + tag], z["pcm_out_" + tag]
+    in_rate, out_rate = (8000, 48000) if tag == "c" else (16000, 16000)
+    W = int(np.floor(pcm.shape[0] * (16000 / in_rate)))
+    frames = mossformer.frames_of(W)
+    fused = {n: mossformer.synthetic_tensor(n, s, sc, frames, int(scalars["flash_group_size"]), fold_inv_n=False) for n, s, sc in spec}
+    return pcm, ref, fused, scalars, W, int(z["layers"]), in_rate, out_rate
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_dynamic_axes_match_reference(tag):
+    from mossformer_oracle import MossFormerOracle
+    pcm, ref, fused, scalars, W, layers, in_rate, out_rate = _dynamic_case(tag)
+    tensors = dict(fused)
+    tensors.update(mossformer.position_tables(mossformer.frames_of(W), int(scalars["rot_dim"])))
+    out = MossFormerOracle(tensors, scalars, layers, W, dynamic=True).process_dynamic(pcm[None], in_rate, out_rate)[0]
+    assert out.shape == ref.shape
+    d = out.astype(np.int32) - ref.astype(np.int32)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02, (np.abs(d).max(), (d != 0).mean())
+    # the static arithmetic on the same (unfolded) weights is a different function: the run-time factor matters
+    if tag == "a":
+        stat = MossFormerOracle(tensors, scalars, layers, W, dynamic=False).process(pcm[None])[0]
+        assert np.abs(stat.astype(np.int32) - ref.astype(np.int32)).max() > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gpu_dynamic_axes_match_reference(tag):
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    pcm, ref, fused, scalars, W, layers, in_rate, out_rate = _dynamic_case(tag)
+    meta = mossformer.metadata(pcm.shape[0], in_sample_rate=in_rate, out_sample_rate=out_rate, dynamic_axes=True)
+    with InferenceSession(weights=pack_blob(mossformer.model_tensors(fused, scalars, W)), metadata=meta) as sess:
+        assert sess.frames == mossformer.frames_of(W)
+        out, _ = sess.process(pcm[None], want_f32=True)
+    out = out.reshape(2, -1)
+    assert out.shape == ref.shape
+    d = out.astype(np.int32) - ref.astype(np.int32)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
+    with pytest.raises(Exception):                         # a folded manifest is static by definition (:97)
+        mossformer.metadata(3 * 2408, use_batch_fold=True, dynamic_axes=True)

@@ -196,7 +196,7 @@ SCALAR_ATTRS = ("norm_factor", "flash_group_size", "rot_dim", "dw_pad", "fl_norm
                 "static_window_batch", "static_window_output", "fl_inv_g", "static_inv_n")
 
 
-def build(ns, length, fold, window, in_rate=16000, out_rate=16000, layers=None):
+def build(ns, length, fold, window, in_rate=16000, out_rate=16000, layers=None, fold_inv_n=True):
     torch.manual_seed(0)
     net = stand_in_network(LAYERS if layers is None else layers)
     model = ns["MOSSFORMER_SS"](net, length, in_rate, out_rate, fold, window if fold else 0).eval()
@@ -207,7 +207,7 @@ def build(ns, length, fold, window, in_rate=16000, out_rate=16000, layers=None):
             if name in skip:
                 continue
             scale = weight_scale(name, list(buf.shape))
-            v = mossformer.synthetic_tensor(name, list(buf.shape), scale, model.static_frames, model.flash_group_size)
+            v = mossformer.synthetic_tensor(name, list(buf.shape), scale, model.static_frames, model.flash_group_size, fold_inv_n)
             buf.copy_(torch.from_numpy(v))
             spec.append((name, list(buf.shape), scale))
     scalars = {k: float(getattr(model, k)) for k in SCALAR_ATTRS}
@@ -275,6 +275,35 @@ def main():
     out = np.stack([o.numpy().reshape(-1) for o in outs])
     np.savez_compressed(os.path.join(mg.GOLD, "mossformer_seed0_resample_io.npz"), pcm_in=pcm, pcm_out=out, in_rate=np.int64(8000), out_rate=np.int64(48000))
     print("resample out", out.shape, np.abs(out).max(axis=1))
+
+
+def dynamic_fixture():
+    """DYNAMIC_AXES = True (:24): ONE module instance run on two input lengths at 16 kHz (2408 and 3296 samples: 300 and 411 frames), and a second instance with the
+    scale-factor edges 8 kHz -> 16 kHz -> 48 kHz (:565-577, :634-646).  The buffers are the static fixtures' generator values EXCEPT that the linear keys' OffsetScale
+    row carries no 1 / frames factor -- the dynamic graph multiplies the reduced product by 1 / n at run time (:183, :430, :500-501).
+    tests/golden/mossformer_dynamic_seed0.npz"""
+    ns = import_namespace(WINDOW, False, 1.5, extra={"DYNAMIC_AXES": True})
+    assert ns["DYNAMIC_AXES"] is True and ns["MODEL_AUDIO_LENGTH"] == WINDOW
+    model, spec, scalars = build(ns, WINDOW, False, 0, fold_inv_n=False)
+    assert model.fold_lin_inv_n is False
+    out = {"layers": np.int64(LAYERS), "spec": np.array(json.dumps(spec)), "scalars": np.array(json.dumps(scalars))}
+    for tag, start, length in (("a", 24000, WINDOW), ("b", 30000, 16 + 8 * 410)):
+        pcm = read_mix(start, length)
+        with torch.inference_mode():
+            outs = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy()))
+        y = np.stack([o.numpy().reshape(-1) for o in outs])
+        out["pcm_in_" + tag], out["pcm_out_" + tag] = pcm, y
+        print("dynamic", tag, pcm.shape, "->", y.shape, np.abs(y).max(axis=1))
+    ns = import_namespace(WINDOW // 2, False, 1.5, in_rate=8000, out_rate=48000, extra={"DYNAMIC_AXES": True})
+    model, spec2, _ = build(ns, WINDOW // 2, False, 0, 8000, 48000, fold_inv_n=False)
+    assert [s_[:2] for s_ in spec2] == [s_[:2] for s_ in spec]
+    pcm = np.ascontiguousarray(read_mix(24000, WINDOW)[::2])
+    with torch.inference_mode():
+        outs = model(torch.from_numpy(pcm.reshape(1, 1, -1).copy()))
+    y = np.stack([o.numpy().reshape(-1) for o in outs])
+    out["pcm_in_c"], out["pcm_out_c"] = pcm, y
+    print("dynamic c (8 k -> 16 k -> 48 k)", pcm.shape, "->", y.shape, np.abs(y).max(axis=1))
+    np.savez_compressed(os.path.join(mg.GOLD, "mossformer_dynamic_seed0.npz"), **out)
 
 
 def float_io_fixture():
@@ -356,10 +385,27 @@ def fusion_fixture():
         samples[name] = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
     scalars = {k: float(getattr(model, k)) for k in SCALAR_ATTRS}
     scalars["fs_front_alpha"] = [float(a) for a in model.fs_front_alpha]
+    # the DYNAMIC_AXES constructor on the same tree: only the OffsetScale buffers differ (no 1 / frames in the linear-key row, :183, :252-253)
+    dyn = import_namespace(WINDOW, False, 1.5, extra={"DYNAMIC_AXES": True})["MOSSFORMER_SS"](net, WINDOW, 16000, 16000, False, 0).eval()
+    dyn_samples = {}
+    for name, buf in dyn.named_buffers():
+        if name in skip or name == "emb_pos":              # (emb_pos is the 6 s table there)
+            continue
+        v = buf.detach().numpy().reshape(-1).astype(np.float64)
+        d = np.concatenate((v[::max(1, len(v) // 64)][:64], [v.sum()]))
+        if name.startswith("qkos_"):
+            dyn_samples[name] = d
+        else:
+            assert np.array_equal(d, samples[name]), name
     np.savez_compressed(os.path.join(mg.GOLD, "mossformer_fusion.npz"), spec=np.array(json.dumps(spec)), scalars=np.array(json.dumps(scalars)),
-                        names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()})
+                        names=np.array(json.dumps(list(samples))), **{f"s_{k}": v for k, v in samples.items()}, **{f"dyn_{k}": v for k, v in dyn_samples.items()})
     print("fusion fixture:", len(spec), "checkpoint tensors,", sum(int(np.prod(s)) for _, s, _ in spec) / 1e6, "M floats ->", len(samples), "fused buffers")
 
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    fusion_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--float-io" in sys.argv:
     float_io_fixture()
