@@ -545,72 +545,48 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
                                             const float* __restrict__ ln_b, int T, int P, int Ps, int tid, float (*v)[16],
                                             const float* __restrict__ pre_src = nullptr, float (*pre)[8] = nullptr) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
-    const cfptr c_fc_b = cptr(fc_b);
     {
-        // Linear(16 -> 16) for the lane's three positions TOGETHER: one weight row (16 scalars) serves the three, and the rows are fetched one
-        // ahead of their use, paced by the FMAs (see gtblock_stage phase 1) -- 256 weights requested per position up front do not
-        // fit the scalar file and came back through v_readlane.  Rounds in which this whole wavefront has no position are skipped (wave-uniform).
-        const int nr = __builtin_amdgcn_readfirstlane(((tid & ~63) + 2 * kFusedThreads < P) ? 3 : (((tid & ~63) + kFusedThreads < P) ? 2 : 1));
-        v2f acc[kPosPerThread][8];
+        // Linear(16 -> 16) on the matrix cores, IN PLACE in R: a wavefront owns 16-position tiles (tile = it * kWaves + wave), lane (g, j) reads the float4 of plane g at
+        // position j -- its four components are the K blocks of four v_mfma_f32_16x16x4_f32 (K index = (lane row, component), the weights permuted to match: a dense
+        // 16 x 16 product, nothing padded) -- and gets output channels 4g .. 4g+3 of that position back: the float4 of the same plane and position, which it overwrites.
+        // The position-linear lanes below then pick their 16 channels up from LDS (the element-wise part of the phase costs per POSITION, so it stays one lane per position).
+        constexpr int kWaves = kFusedThreads / 64, kTiles = (kPmax / 16 + kWaves - 1) / kWaves;
+        int tq = tid;
+        ADE_OPAQUE_V(tq);                                    // (this pass's nine tile addresses are its own: not hoisted above the recurrence before the phase)
+        const int wave = __builtin_amdgcn_readfirstlane(tq >> 6), g = (tq >> 4) & 3, jn = tq & 15;
+        float wa[4];
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i)
+        for (int kk = 0; kk < 4; ++kk) wa[kk] = fc[(4 * g + kk) * 16 + jn];       // A: weight of input channel 4g + kk for output channel jn
+        v4f cb;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) acc[i][m] = mk2(c_fc_b[2 * m], c_fc_b[2 * m + 1]);
-        const cfptr c_fc = cptr(fc);
-        auto rows = [&](auto nrc) {
-            constexpr int NR = decltype(nrc)::value;
+        for (int r = 0; r < 4; ++r) cb[r] = fc_b[4 * g + r];
+        float4* Rw = const_cast<float4*>(R);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {              // input channels 8 half .. 8 half + 7: two LDS planes at a time (24 live inputs, not 48)
-                float r[NR][8];
-#pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    const int p = tid + i * kFusedThreads;
-                    const int pc = p < P ? p : 0;                // (clamped: the value is computed and dropped)
-                    const float4 x0 = R[(2 * half) * kPmax + pc], x1 = R[(2 * half + 1) * kPmax + pc];
-                    r[i][0] = x0.x; r[i][1] = x0.y; r[i][2] = x0.z; r[i][3] = x0.w;
-                    r[i][4] = x1.x; r[i][5] = x1.y; r[i][6] = x1.z; r[i][7] = x1.w;
-                }
-                v2f wc[8], wn[8];                                // one row (16 scalars) in use, the next one in flight
-                {
-                    cfptr g0 = c_fc + half * 128;
-                    ADE_KEEP_IN_LOOP(g0);
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) wc[m] = mk2(g0[2 * m], g0[2 * m + 1]);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {                    // row 8 half + k
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-#pragma unroll
-                        for (int i = 0; i < NR; ++i) {
-                            acc[i][m] += wc[m] * r[i][k];
-                            if (m == 0 && i == 0 && k < 7) {
-                                float tok = acc[0][0][0];
-                                cfptr gn = c_fc + half * 128 + (k + 1) * 16;
-                                ADE_KEEP_AFTER(gn, tok);
-                                acc[0][0][0] = tok;
-#pragma unroll
-                                for (int mm = 0; mm < 8; ++mm) wn[mm] = mk2(gn[2 * mm], gn[2 * mm + 1]);
-                            }
-                        }
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) wc[m] = wn[m];
-                }
-            }
-        };
-        if (nr == 3) rows(std::integral_constant<int, 3>());
-        else if (nr == 2) rows(std::integral_constant<int, 2>());
-        else rows(std::integral_constant<int, 1>());
-#pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            const int p = tid + i * kFusedThreads;
-            float s = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) { v[i][2 * m] = acc[i][m][0]; v[i][2 * m + 1] = acc[i][m][1]; }
-#pragma unroll
-            for (int co = 0; co < 16; ++co) s += v[i][co];
-            if (p < P) red[p] = s;
+        for (int it = 0; it < kTiles; ++it) {
+            const int pu = (it * kWaves + wave) * 16 + jn, pos = pu < P ? pu : P - 1;
+            const float4 x = R[g * kPmax + pos];
+            v4f d = cb;
+            d = mfma16x16x4(wa[0], x.x, d);
+            d = mfma16x16x4(wa[1], x.y, d);
+            d = mfma16x16x4(wa[2], x.z, d);
+            d = mfma16x16x4(wa[3], x.w, d);
+            if (pu < P) Rw[g * kPmax + pu] = make_float4(d[0], d[1], d[2], d[3]);
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPosPerThread; ++i) {
+        const int p = tid + i * kFusedThreads;
+        const int pc = p < P ? p : 0;
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = R[q * kPmax + pc];
+            v[i][4 * q] = x.x; v[i][4 * q + 1] = x.y; v[i][4 * q + 2] = x.z; v[i][4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int co = 0; co < 16; ++co) s += v[i][co];
+        if (p < P) red[p] = s;
     }
     if (pre) {   // optional prefetch (8 channels per own position, planes 0-1 of pre_src): in flight across the statistics passes
 #pragma unroll
