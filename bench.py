@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — RTF / audio-seconds-per-second of the chunk path; default = GTCRN at batch = 256 x 1 s chunks (BASELINE.json configs[1]).
 
-`--workload zipenhancer | melband | mossformer` selects the other BASELINE configs (configs[2] / [3] / [4]) at their own batch shapes;
-the default invocation is unchanged.
+`--workload zipenhancer | melband | mossformer` selects the other BASELINE configs (configs[2] / [3] / [4]) at their own batch shapes as the headline;
+the default invocation's line also carries them, briefly timed, in `other_workloads` (so that the driver's clock covers every BASELINE config; `--other`, `--other-steps`).
 
 A "step" is one pass of the hot path (int16 PCM in HBM -> STFT -> GTCRN -> mask -> ISTFT/OLA -> int16 PCM in HBM)
 over one batch of 256 synthetic 1 s chunks per GPU (`configs[1]`), through libade's C ABI on device buffers.
