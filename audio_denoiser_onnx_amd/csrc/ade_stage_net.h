@@ -532,24 +532,24 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
 // DPGRNN, whole block for one chunk (Export_GTCRN.py:466-481; GRNN :409-428).
 //   x (B,T,33,16) -> intra biGRU along F -> Linear -> LayerNorm((33,16)) -> +x = mid
 //                 -> inter GRU along T   -> Linear -> LayerNorm           -> +mid = out
-// LDS: R[4][kPmax] float4 (rnn outputs, then mid, then rnn outputs again) | red[kPmax] | stat[2][64].
+// LDS: R[4][kPmax] float4 (rnn outputs, then mid, then rnn outputs again) | two LayerNorm tables.
 // `mid` is parked in the output buffer between the two halves (same thread writes and re-reads it).
 // ---------------------------------------------------------------------------------------------------------
-template <class G> constexpr size_t dp_smem_bytes() { return (size_t)4 * G::kPmax * 16 + (size_t)G::kPmax * 4 + 2 * G::kTmax * 4 + (size_t)2 * kFw * kCh * 4; }   // + 2 LayerNorm tables
+template <class G> constexpr size_t dp_smem_bytes() { return (size_t)4 * G::kPmax * 16 + (size_t)2 * kFw * kCh * 4; }   // + 2 LayerNorm tables
 
-// Linear(16,16) on the rnn output of each of this thread's positions, two-pass LayerNorm statistics per frame
-// through LDS, then  y = res + (v - mean) * rstd * gamma + beta.   v/res/y: [kPosPerThread][16] registers.
-template <class G>
-__device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* stat, const float* __restrict__ fc,
-                                            const float* __restrict__ fc_b, const float* __restrict__ ln_w,
-                                            const float* __restrict__ ln_b, int T, int P, int Ps, int tid, float (*v)[16],
-                                            const float* __restrict__ pre_src = nullptr, float (*pre)[8] = nullptr) {
-    constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
+// Linear(16,16) on the rnn output + LayerNorm((33,16)) per frame + residual.  The Linear runs on the matrix cores IN PLACE in R: a wavefront owns 16-position tiles
+// (tile = it * kWaves + wave), lane (g, j) reads the float4 of plane g at position j -- its four components are the K blocks of four v_mfma_f32_16x16x4_f32 (K index =
+// (lane row, component), the weights permuted to match: a dense 16 x 16 product, nothing padded) -- and gets output channels 4g .. 4g+3 of that position back: the float4
+// of the same plane and position, which it overwrites.  The LayerNorm of a frame then lives inside ONE 16-lane row: lane j of row t owns columns j
+// and 16 + j of frame t (16 channels each) plus channel j of column 32, so that both statistics are a row-rotation all-reduce in registers -- no LDS round trip and
+// no barrier after the one that follows the Linear (the element-wise part costs per POSITION: it stays one lane per position, not the Linear's tile ownership).  emit_pos(p, y[16]) / emit_one(p, channel, y): the normalised + residual values of an owned position / of the
+// lane's one channel of column 32.  `res`: the residual tensor (quad-planar HBM, plane stride Ps), added here.
+template <class G, class EmitPos, class EmitOne>
+__device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ fc, const float* __restrict__ fc_b, const float* __restrict__ ln_w,
+                                           const float* __restrict__ ln_b, int T, int P, int tid, const float* __restrict__ res, int Ps, EmitPos emit_pos, EmitOne emit_one) {
+    constexpr int kFusedThreads = G::kThreads, kPmax = G::kPmax;
+    static_assert(kFusedThreads / 16 >= G::kTmax, "one 16-lane row per frame");
     {
-        // Linear(16 -> 16) on the matrix cores, IN PLACE in R: a wavefront owns 16-position tiles (tile = it * kWaves + wave), lane (g, j) reads the float4 of plane g at
-        // position j -- its four components are the K blocks of four v_mfma_f32_16x16x4_f32 (K index = (lane row, component), the weights permuted to match: a dense
-        // 16 x 16 product, nothing padded) -- and gets output channels 4g .. 4g+3 of that position back: the float4 of the same plane and position, which it overwrites.
-        // The position-linear lanes below then pick their 16 channels up from LDS (the element-wise part of the phase costs per POSITION, so it stays one lane per position).
         constexpr int kWaves = kFusedThreads / 64, kTiles = (kPmax / 16 + kWaves - 1) / kWaves;
         int tq = tid;
         ADE_OPAQUE_V(tq);                                    // (this pass's nine tile addresses are its own: not hoisted above the recurrence before the phase)
@@ -560,7 +560,6 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
         v4f cb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) cb[r] = fc_b[4 * g + r];
-        float4* Rw = const_cast<float4*>(R);
 #pragma unroll
         for (int it = 0; it < kTiles; ++it) {
             const int pu = (it * kWaves + wave) * 16 + jn, pos = pu < P ? pu : P - 1;
@@ -570,75 +569,57 @@ __device__ __forceinline__ void fc_ln_phase(const float4* R, float* red, float* 
             d = mfma16x16x4(wa[1], x.y, d);
             d = mfma16x16x4(wa[2], x.z, d);
             d = mfma16x16x4(wa[3], x.w, d);
-            if (pu < P) Rw[g * kPmax + pu] = make_float4(d[0], d[1], d[2], d[3]);
+            if (pu < P) R[g * kPmax + pu] = make_float4(d[0], d[1], d[2], d[3]);
         }
     }
     __syncthreads();
+    int tq = tid;
+    ADE_OPAQUE_V(tq);
+    const int tr = tq >> 4, j = tq & 15;
+    const bool live = tr < T;
+    const int t = live ? tr : T - 1;                         // (rows beyond the segment recompute its last frame and emit nothing)
+    const int p0 = t * kFw + j, p1 = p0 + 16, p2 = t * kFw + 32;
+    float* Rf = reinterpret_cast<float*>(R);
+    auto allreduce = [](float s) { s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s); return s; };
+    float v0[16], v1[16];
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        const int pc = p < P ? p : 0;
-        float s = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 x = R[q * kPmax + pc];
-            v[i][4 * q] = x.x; v[i][4 * q + 1] = x.y; v[i][4 * q + 2] = x.z; v[i][4 * q + 3] = x.w;
-        }
-#pragma unroll
-        for (int co = 0; co < 16; ++co) s += v[i][co];
-        if (p < P) red[p] = s;
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = R[q * kPmax + p0], b = R[q * kPmax + p1];
+        v0[4 * q] = a.x; v0[4 * q + 1] = a.y; v0[4 * q + 2] = a.z; v0[4 * q + 3] = a.w;
+        v1[4 * q] = b.x; v1[4 * q + 1] = b.y; v1[4 * q + 2] = b.z; v1[4 * q + 3] = b.w;
     }
-    if (pre) {   // optional prefetch (8 channels per own position, planes 0-1 of pre_src): in flight across the statistics passes
+    const float e = Rf[((size_t)(j >> 2) * kPmax + p2) * 4 + (j & 3)];
+    float s = e;
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            const int p = tid + i * kFusedThreads;
-            if (pre_src && p < P) {
-                pl_ld8(pre_src, Ps, p, 0, pre[i]);
-            } else {
+    for (int c = 0; c < 16; ++c) s += v0[c] + v1[c];
+    const float mean = allreduce(s) / (float)(kFw * kCh);
+    const float de = e - mean;
+    float q2 = de * de;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pre[i][k] = 0.0f;
-            }
-        }
-    }
-    __syncthreads();
-    {   // per-frame total: one 16-lane row per frame, 3 partials per lane, row rotation all-reduce (fixed order)
-        const int tr = tid >> 4, j = tid & 15, t = tr < T ? tr : T - 1;
-        float s = red[t * kFw + j] + red[t * kFw + j + 16] + (j == 0 ? red[t * kFw + 32] : 0.0f);
-        s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s);
-        if (j == 0 && tr < T) stat[t] = s / (float)(kFw * kCh);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            const float mean = stat[p / kFw];
-            float s = 0.0f;
-#pragma unroll
-            for (int co = 0; co < 16; ++co) { const float d = v[i][co] - mean; s += d * d; }
-            red[p] = s;
-        }
-    }
-    __syncthreads();
+    for (int c = 0; c < 16; ++c) { const float a = v0[c] - mean, b = v1[c] - mean; q2 += a * a + b * b; }
+    const float rstd = 1.0f / sqrtf(allreduce(q2) / (float)(kFw * kCh) + 1e-8f);
     {
-        const int tr = tid >> 4, j = tid & 15, t = tr < T ? tr : T - 1;
-        float s = red[t * kFw + j] + red[t * kFw + j + 16] + (j == 0 ? red[t * kFw + 32] : 0.0f);
-        s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s);
-        if (j == 0 && tr < T) stat[kTmaxFused + t] = 1.0f / sqrtf(s / (float)(kFw * kCh) + 1e-8f);
+        float gw[16], gb[16], rs[16];
+        ld16(ln_w + j * kCh, gw);
+        ld16(ln_b + j * kCh, gb);
+        pl_ld16(res, Ps, p0, rs);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v0[c] = ((v0[c] - mean) * rstd * gw[c] + gb[c]) + rs[c];
+        if (live) emit_pos(p0, v0);
     }
-    __syncthreads();
+    {
+        float gw[16], gb[16], rs[16];
+        ld16(ln_w + (16 + j) * kCh, gw);
+        ld16(ln_b + (16 + j) * kCh, gb);
+        pl_ld16(res, Ps, p1, rs);
 #pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            const int t = p / kFw, f = p - t * kFw;
-            const float mean = stat[t], rstd = stat[kTmaxFused + t];
-            float gw[16], gb[16];
-            ld16(ln_w + f * kCh, gw);
-            ld16(ln_b + f * kCh, gb);
-#pragma unroll
-            for (int co = 0; co < 16; ++co) v[i][co] = (v[i][co] - mean) * rstd * gw[co] + gb[co];
-        }
+        for (int c = 0; c < 16; ++c) v1[c] = ((v1[c] - mean) * rstd * gw[c] + gb[c]) + rs[c];
+        if (live) emit_pos(p1, v1);
+    }
+    {
+        const float re = res[((size_t)(j >> 2) * Ps + p2) * 4 + (j & 3)];
+        const float ye = (de * rstd * ln_w[32 * kCh + j] + ln_b[32 * kCh + j]) + re;
+        if (live) emit_one(p2, j, ye);
     }
 }
 
@@ -651,9 +632,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
-    float* red = reinterpret_cast<float*>(smem + 4 * kPmax);
-    float* stat = red + kPmax;
-    float* lnt = stat + 2 * kTmaxFused;   // LDS copies of two LayerNorm tables [gamma | beta]: the intra pair for phase B, then the inter pair for phase D
+    float* lnt = reinterpret_cast<float*>(smem + 4 * kPmax);   // LDS copies of two LayerNorm tables [gamma | beta]: the intra pair for phase B, then the inter pair for phase D
     const int T = sg.nT;
     const int P = T * kFw, Ps = sg.T * kFw;
     int tid_ = threadIdx.x;
@@ -730,24 +709,16 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     ADE_CLK(17);
     // ---- phase B: intra Linear + LayerNorm + residual -> mid (registers, and back into R for the inter GRU)
     //      (mid is parked in `out` -- L2-resident, re-read by the same thread in phase D -- instead of 48 live VGPRs)
-    {
-        float mid[kPosPerThread][16];
-        fc_ln_phase<G>(R, red, stat, w.intra_fc, w.intra_fc_b, lnt, lnt + kFw * kCh, T, P, Ps, tid, mid);
+    fc_ln_rows<G>(R, w.intra_fc, w.intra_fc_b, lnt, lnt + kFw * kCh, T, P, tid, xc, Ps,
+        [&](int p, const float (&m)[16]) {                  // mid: input of the inter-frame GRU (R) and, parked in the output tensor, the residual of phase D
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
-            const int p = tid + i * kFusedThreads;
-            if (p < P) {
-                float xr[16];
-                pl_ld16(xc, Ps, p, xr);
-#pragma unroll
-                for (int co = 0; co < 16; ++co) mid[i][co] += xr[co];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    R[q * kPmax + p] = make_float4(mid[i][4 * q], mid[i][4 * q + 1], mid[i][4 * q + 2], mid[i][4 * q + 3]);
-                pl_st16(oc, Ps, p, mid[i]);
-            }
-        }
-    }
+            for (int q = 0; q < 4; ++q) R[q * kPmax + p] = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+            pl_st16(oc, Ps, p, m);
+        },
+        [&](int p, int c, float m) {
+            Rf[((size_t)(c >> 2) * kPmax + p) * 4 + (c & 3)] = m;
+            oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = m;
+        });
     if (sg.prev && tid == 0) xwait(sg.fi + kXFlagInter + blk, sg.err);    // the previous segment's inter-frame GRU state
     __syncthreads();
     for (int i = tid; i < kFw * kCh; i += kFusedThreads) {   // phase B is done with the intra pair: the inter pair takes its place (visible after phase C's barrier)
@@ -832,27 +803,26 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagInter + blk, 1u);
     ADE_CLK(19);
     // ---- phase D: inter Linear + LayerNorm + residual(mid) -> out
-    float y[kPosPerThread][16];
-    float nsk[kPosPerThread][8];       // the following GTConvBlock's skip addend (zero when there is none)
-    fc_ln_phase<G>(R, red, stat, w.inter_fc, w.inter_fc_b, lnt, lnt + kFw * kCh, T, P, Ps, tid, y,
-                   (next_x1 && next_skip) ? next_skip + cbase : nullptr, nsk);
-#pragma unroll
-    for (int i = 0; i < kPosPerThread; ++i) {
-        const int p = tid + i * kFusedThreads;
-        if (p < P) {
-            float m[16];
-            pl_ld16(oc, Ps, p, m);     // mid, written by this same thread in phase B
-#pragma unroll
-            for (int co = 0; co < 16; ++co) y[i][co] += m[co];
-            pl_st16(oc, Ps, p, y[i]);
-            if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (R is dead)
-                float n8[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) n8[k] = y[i][k] + nsk[i][k];
-                R[2 * kPmax + p] = make_float4(n8[0], n8[1], n8[2], n8[3]);
-                R[3 * kPmax + p] = make_float4(n8[4], n8[5], n8[6], n8[7]);
-            }
-        }
+    {
+        const float* nsc = (next_x1 && next_skip) ? next_skip + cbase : nullptr;
+        // (the residual is mid, written by this same lane in phase B: L2-resident)
+        fc_ln_rows<G>(R, w.inter_fc, w.inter_fc_b, lnt, lnt + kFw * kCh, T, P, tid, oc, Ps,
+            [&](int p, const float (&o)[16]) {
+                pl_st16(oc, Ps, p, o);
+                if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (the frame's row is done with them)
+                    float k8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    if (nsc) pl_ld8(nsc, Ps, p, 0, k8);
+                    R[2 * kPmax + p] = make_float4(o[0] + k8[0], o[1] + k8[1], o[2] + k8[2], o[3] + k8[3]);
+                    R[3 * kPmax + p] = make_float4(o[4] + k8[4], o[5] + k8[5], o[6] + k8[6], o[7] + k8[7]);
+                }
+            },
+            [&](int p, int c, float o) {
+                oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = o;
+                if (next_x1 && c < 8) {
+                    const float k = nsc ? nsc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] : 0.0f;
+                    Rf[((size_t)(2 + (c >> 2)) * kPmax + p) * 4 + (c & 3)] = o + k;
+                }
+            });
     }
     ADE_CLK(20);
 }
