@@ -107,8 +107,9 @@ ade_status ade_stitch_device(ade_handle h, const int16_t* d_local, int rows, int
 ade_status ade_reserve(ade_handle h, int batch);
 
 /* Options: "graph" = "0"/"1" replay the launch sequence from a captured hipGraph (default 1); "fused" / "single_launch" = "0"/"1" GTCRN's per-chunk LDS-resident path,
- * as one launch; "geometry" = "auto"/"0"/"1" its workgroup geometry (0: one 1024-thread workgroup per chunk; 1: 512-thread workgroups that each own a run of at most 32
- * frames, two per CU -- the default where the frame count allows); "stagger_us" (geometry 0), "seg_prio", "wave_swap": measurement knobs, see DESIGN.md. */
+ * as one launch; "geometry" = "auto"/"0"/"1"/"2" its workgroup geometry (0: one 1024-thread workgroup per chunk; 1: 512-thread workgroups that each own a run of at most 32
+ * frames, two per CU; 2: 256-thread workgroups of at most 16 frames, four per CU -- the default where the frame count allows; identical bits in all three);
+ * "stagger_us" (geometry 0), "seg_prio" = "0".."4" (base wave priority by segment; the recurrences always run at priority 3), "wave_swap": measurement knobs, see DESIGN.md. */
 ade_status ade_set_option(ade_handle h, const char* key, const char* value);
 
 /* Parity taps: copy a named intermediate of the LAST processed batch to host (engine-native layout, see
