@@ -936,8 +936,10 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         // linear-attention product at run time instead of being folded into the OffsetScale row of the linear keys; tables are slices of the 6 s ones, the rotary
         // half-rotation is the same arithmetic in either form, any window of 16 + 8 k samples.
         const bool dyn_sf = dyn_d && (fam_dfsmn || fam_zip || fam_moss);
-        if (dyn_d && !fam_sand && !dyn_sf)
-            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is implemented for gtcrn, mel_band_roformer, ul_unas, dfsmn, zipenhancer and mossformer2_ss (static shapes only for " + fam + ")"));
+        // H-GTCRN's (Export_H_GTCRN.py:27, :1075, :1097, :1110): frame counts from the waveform and the ISTFT's dynamic trim -- half a window of tail is kept, L + 256 samples out;
+        // its edges interpolate by scale factor in either mode.
+        if (dyn_d && !fam_sand && !dyn_sf && !fam_hg)
+            return bail(fail(e, ADE_ERR_UNSUPPORTED, "dynamic_axes=1 is not implemented for " + fam));
         if (e->meta.count("use_batch_fold") && !e->meta["use_batch_fold"].empty() && !parse_bool(e->meta["use_batch_fold"], &fold_d))
             return bail(fail(e, ADE_ERR_BAD_VALUE, "Metadata key use_batch_fold must be a boolean encoded as 1/0."));
         if (fold_d && fam_dfsmn) {   // a folded window must reconstruct itself: raw overlap-add length 1920 + 960 (T - 1) == W  (Export_DFSMN.py:54)
@@ -1017,7 +1019,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, dyn_d ? (int)caller_len : 0, device, &e->sub, derr)
-                       : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
+                       : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, dyn_d, device, &e->sub, derr)
                        : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, gemm_bf16, dyn_d, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));

@@ -560,10 +560,10 @@ struct HgtcrnEngine : SubEngine {
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
 };
 
-int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err) {
+int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (window_len < kHNfft || window_len % kHHop) return hfail(err, ADE_ERR_SHAPE_MISMATCH, "h_gtcrn: the window must be whole 256-sample hops and at least one 512-sample frame");
-    if (n_win < 1) return hfail(err, ADE_ERR_BAD_VALUE, "h_gtcrn: bad fold");
+    if (n_win < 1 || (dynamic && n_win != 1)) return hfail(err, ADE_ERR_BAD_VALUE, "h_gtcrn: bad fold (batch folding requires a static shape)");
     const int T = window_len / kHHop + 1;
     if (T > kMaxFrames) return hfail(err, ADE_ERR_SHAPE_MISMATCH, "h_gtcrn: more than 1024 frames per window");
     MapLoader L{tensors, err};
@@ -621,7 +621,10 @@ int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, 
 
     HgtcrnEngine* e = new HgtcrnEngine();
     auto bail = [&](int st) { delete e; return st; };
-    e->device = device; e->W = window_len; e->n_win = n_win; e->T = T; e->out_len_ = kHHop * (T - 1);
+    e->device = device; e->W = window_len; e->n_win = n_win; e->T = T;
+    // DYNAMIC_AXES export (Export_H_GTCRN.py:27, :1097): the ISTFT keeps everything after the leading half window -- half a window more than the static trim --
+    // normalised by the window-square sum of the actual frames (STFT_Process.py:318-327); everything else is the static arithmetic at the call's frame count.
+    e->out_len_ = kHHop * (T - 1) + (dynamic ? kHNfft / 2 : 0);
     if (hipSetDevice(device) != hipSuccess) return bail(hfail(err, ADE_ERR_DEVICE, "hipSetDevice failed"));
     if (hipMalloc((void**)&e->d_w, A.f.size() * sizeof(float)) != hipSuccess || hipMemcpy(e->d_w, A.f.data(), A.f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(hfail(err, ADE_ERR_DEVICE, "upload of the H-GTCRN weights failed"));
@@ -652,6 +655,7 @@ int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hg_wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wpe_lds);
     ade_stft_config cfg{kHNfft, kHNfft, kHHop, "hann", nullptr, 1, "reflect"};          // H-GTCRN/Export_H_GTCRN.py:36-40, 1076-1097
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: STFT plan: ") + ade_stft_last_error(nullptr)));
+    if (dynamic) (void)ade_stft_keep_tail(e->plan, 1);
     *out = e;
     return ADE_OK;
 }

@@ -150,14 +150,16 @@ def export_ulunas(checkpoint, out_dir, input_audio_length: int = 16000, name: st
     return model_path
 
 
-def export_hgtcrn(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = False, name: str = "H_GTCRN") -> Path:
-    """H-GTCRN checkpoint (``ckpt['model']`` of GTCRN_IVA) -> ``<name>.adew`` + manifest (Export_H_GTCRN.py:1119-1186 minus ONNX)."""
+def export_hgtcrn(checkpoint, out_dir, input_audio_length: int = 32000, use_batch_fold: bool = False, name: str = "H_GTCRN", dynamic_axes: bool = False,
+                  in_sample_rate: int = 16000, out_sample_rate: int = 16000) -> Path:
+    """H-GTCRN checkpoint (``ckpt['model']`` of GTCRN_IVA) -> ``<name>.adew`` + manifest (Export_H_GTCRN.py:1119-1186 minus ONNX).  ``dynamic_axes``: the DYNAMIC_AXES
+    export (:27): the ISTFT's dynamic trim, 256 model-rate samples more out than in."""
     from . import hgtcrn
     out_dir = Path(out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
     model_path = out_dir / f"{name}.adew"
     save_blob(model_path, hgtcrn.fold_state_dict(load_state_dict(checkpoint)))
-    write_metadata(model_path, hgtcrn.metadata(input_audio_length, use_batch_fold))
+    write_metadata(model_path, hgtcrn.metadata(input_audio_length, use_batch_fold, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate, dynamic_axes=dynamic_axes))
     return model_path
 
 
@@ -221,7 +223,7 @@ def main(argv=None) -> int:
     elif family == "ul_unas":
         path = export_ulunas(argv[0], argv[1], length or 16000, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"], out_sample_rate=gt["out_sample_rate"])
     elif family == "h_gtcrn":
-        path = export_hgtcrn(argv[0], argv[1], length or 32000, fold)
+        path = export_hgtcrn(argv[0], argv[1], length or 32000, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"], out_sample_rate=gt["out_sample_rate"])
     elif family == "zipenhancer":
         path = export_zipenhancer(argv[0], argv[1], length or 32000, fold, dynamic_axes=gt["dynamic_axes"], in_sample_rate=gt["in_sample_rate"],
                                   out_sample_rate=gt["out_sample_rate"])

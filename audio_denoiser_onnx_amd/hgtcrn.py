@@ -79,13 +79,17 @@ def fold_state_dict(sd: Mapping[str, np.ndarray]) -> "OrderedDict[str, np.ndarra
 
 
 def metadata(input_audio_length: int = 32000, use_batch_fold: bool = False, batch_window_seconds: float = 1.5, in_sample_rate: int = 16000,
-             out_sample_rate: int = 16000) -> Dict[str, str]:
+             out_sample_rate: int = 16000, dynamic_axes: bool = False) -> Dict[str, str]:
     """Manifest keys the reference stamps for this model (:1180-1186): 16 kHz, two microphones in, one channel out, 512 / 256 'hann' STFT;
     the MODEL-rate length int(L * 16000 / in_rate) must be whole hops (:33, :45); optionally batch-fold (WPE / AuxIVA then run per window,
-    :43-47; equal rates only); other input / output rates go through the export's linear-interpolation edges (:953-970, :1036-1052)."""
+    :43-47; equal rates only); other input / output rates go through the export's linear-interpolation edges (:953-970, :1036-1052).
+    ``dynamic_axes``: the DYNAMIC_AXES export (:27, :1075, :1097, :1110): the same arithmetic at the call's frame count with the ISTFT's dynamic trim -- the output is
+    half a window (256 model-rate samples) longer than the input; not with batch folding (:41)."""
+    if dynamic_axes and use_batch_fold:
+        raise ValueError("Batch folding requires a static shape (DYNAMIC_AXES = False)")
     return build_audio_metadata(producer="audio_denoiser_onnx_amd", model_name="H_GTCRN", task="denoise", model_family="h_gtcrn",
                                 input_audio_length=input_audio_length, in_sample_rate=in_sample_rate, out_sample_rate=out_sample_rate, model_sample_rate=16000, nfft=NFFT, window_length=NFFT, hop_length=HOP,
-                                window_type="hann", center_pad=True, pad_mode="reflect", use_batch_fold=use_batch_fold,
+                                window_type="hann", center_pad=True, pad_mode="reflect", use_batch_fold=use_batch_fold, dynamic_axes=dynamic_axes,
                                 batch_window_seconds=batch_window_seconds, input_channels=2, output_channels=1, feature_kind="stft_wpe_auxiva",
                                 extra={"wpe_rt60": WPE_RT60, "wpe_delay": WPE_DELAY, "wpe_iter": WPE_ITER,
                                        "iva_iter": IVA_ITER, "cg_solve_iter": CG_SOLVE_ITER})

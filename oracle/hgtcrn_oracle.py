@@ -136,7 +136,7 @@ def auxiva(Xr, Xi):
 
 
 class HgtcrnOracle:
-    def __init__(self, tensors: dict, window_len: int, n_win: int = 1, exact_dft: bool = False):
+    def __init__(self, tensors: dict, window_len: int, n_win: int = 1, exact_dft: bool = False, dynamic: bool = False):
         self.w = {k: np.asarray(v, F32) for k, v in tensors.items()}
         self.W, self.n_win = int(window_len), int(n_win)
         self.T = self.W // HOP + 1
@@ -144,8 +144,13 @@ class HgtcrnOracle:
         raw = np.zeros(NFFT + HOP * (self.T - 1), F32)
         for t in range(self.T):
             raw[t * HOP:t * HOP + NFFT] += (win * win).astype(F32)
-        self.out_len = HOP * (self.T - 1)
-        self.win_sum = raw[NFFT // 2:NFFT // 2 + self.out_len].copy()                     # static COLA table (STFT_Process.py:262-274)
+        # dynamic: the DYNAMIC_AXES export (Export_H_GTCRN.py:27, :1097): the ISTFT's slice end is sized for 4096 frames, so everything after the leading half window
+        # stays -- half a window more than the static trim -- and the window-square sum is that of the actual frames (STFT_Process.py:318-327): in the kept tail only the last
+        # frame contributes, so the samples are x / w with w running down to hann(511) ~ 4e-5 (the periodic window's zero is at sample 0 of a frame): they saturate the int16 clamp.
+        self.dynamic = bool(dynamic)
+        assert not (self.dynamic and self.n_win != 1), "Batch folding requires a static shape"
+        self.out_len = HOP * (self.T - 1) + (NFFT // 2 if self.dynamic else 0)
+        self.win_sum = raw[NFFT // 2:NFFT // 2 + self.out_len].copy()                     # COLA table (STFT_Process.py:262-274; the same values when computed per call)
         self.taps = {}
 
     # ---- network blocks (B, C, T, F) -----------------------------------------------------------------------------------------

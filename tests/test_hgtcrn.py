@@ -269,3 +269,57 @@ def test_gpu_resampling_edges(fixture, tag):
     assert np.abs(d).max() <= 3 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
     ref = z[tag + "_pcm_out"].astype(np.float64)
     assert np.sqrt(((got[0] - ref) ** 2).mean()) < 0.15 * np.sqrt((ref ** 2).mean())        # end to end: bounded by the ill-conditioned bins
+
+
+# ---- DYNAMIC_AXES export (Export_H_GTCRN.py:27): frame counts from the waveform, the ISTFT keeps half a window of tail -----------------------------------------------
+GOLD_DYN = os.path.join(HERE, "golden", "hgtcrn_seed0_dynamic.npz")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_dynamic_axes_oracle(fixture, tag):
+    """One reference module instance (DYNAMIC_AXES = True) run on 8192 and 12288 samples: the output is L + 256 samples, the last 256 being x / w with the synthesis
+    window running out (x / w with w -> hann(511) ~ 4e-5: most of them saturate the int16 clamp).  Downstream of the reference's WPE tap, as above."""
+    from hgtcrn_oracle import HgtcrnOracle
+    _, fused = fixture
+    z = np.load(GOLD_DYN)
+    pcm, ref = z[tag + "_pcm_in"], z[tag + "_pcm_out"]
+    o = HgtcrnOracle(fused, pcm.shape[1], dynamic=True)
+    out = o.process(pcm[None], inject_wpe=(z[tag + "_wpe_r"], z[tag + "_wpe_i"]))[0]
+    assert out.shape == ref.shape == (pcm.shape[1] + 256,)
+    d = out.astype(np.int32) - ref.astype(np.int32)
+    body, tail = d[:pcm.shape[1]], d[pcm.shape[1]:]
+    assert np.abs(body).max() <= 1 and (body != 0).mean() < 0.02, (np.abs(body).max(), (body != 0).mean())
+    # the tail divides by a vanishing window: values are relative-accurate, so a few LSB where they are large but not yet clamped
+    assert np.abs(tail).max() <= 4 and (np.abs(tail) > 1).mean() < 0.05, (np.abs(tail).max(), (np.abs(tail) > 1).mean())
+    assert (np.abs(ref[-64:].astype(np.int32)) >= 32767).mean() > 0.5                              # the end of the tail saturates
+    # the static export of the same length stops 256 samples earlier and agrees on what both keep
+    stat = HgtcrnOracle(fused, pcm.shape[1]).process(pcm[None], inject_wpe=(z[tag + "_wpe_r"], z[tag + "_wpe_i"]))[0]
+    assert stat.shape[0] == pcm.shape[1] and np.array_equal(stat, out[:pcm.shape[1]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_gpu_dynamic_axes(fixture, tag):
+    """The HIP engine on a dynamic_axes manifest: L + 256 samples out, the two-part contract (downstream of its own WPE output against the oracle; end to end against
+    the reference's PCM bounded by the ill-conditioned bins), and the first L samples equal to the static manifest's output bit for bit."""
+    _, fused = fixture
+    z = np.load(GOLD_DYN)
+    pcm, ref = z[tag + "_pcm_in"][None], z[tag + "_pcm_out"]
+    Lc = pcm.shape[2]
+    T = Lc // 256 + 1
+    with _session(fused, Lc, dynamic_axes=True) as sess:
+        assert sess.in_len == 2 * Lc // 2 and sess.out_len == Lc + 256 and sess.frames == T
+        got = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
+        wpe = sess.tap("wpe", 2 * 514 * T).reshape(1, 2, 2, 257, T)
+    with _session(fused, Lc) as sess:
+        stat = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
+    assert got.shape == (1, Lc + 256) and np.array_equal(got[:, :Lc], stat)
+    from hgtcrn_oracle import HgtcrnOracle
+    want = HgtcrnOracle(fused, Lc, 1, True, dynamic=True).process(pcm, inject_wpe=(wpe[:, :, 0], wpe[:, :, 1]))
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d[:, :Lc]).max() <= 3 and (d[:, :Lc] != 0).mean() < 0.05, (np.abs(d[:, :Lc]).max(), (d[:, :Lc] != 0).mean())
+    assert np.abs(d[:, Lc:]).max() <= 8 and (np.abs(d[:, Lc:]) > 2).mean() < 0.05, np.abs(d[:, Lc:]).max()       # x / w with w -> 4e-5: relative accuracy, large values
+    r = ref.astype(np.float64)
+    assert np.sqrt(((got[0, :Lc] - r[:Lc]) ** 2).mean()) < 0.15 * np.sqrt((r[:Lc] ** 2).mean())                   # end to end: bounded by the ill-conditioned bins
+    with pytest.raises(Exception):
+        hgtcrn.metadata(3 * 8192, use_batch_fold=True, dynamic_axes=True)

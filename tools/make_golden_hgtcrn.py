@@ -77,27 +77,28 @@ def seed_network(net, seed):
                 b.copy_(0.6 + 0.8 * torch.rand(b.shape, generator=g))
 
 
-def build(ns, seed, fold_window=0):
+def build(ns, seed, fold_window=0, dynamic=False):
     STFT_Process = import_stft_process("H-GTCRN").STFT_Process
     stft = STFT_Process(model_type="stft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"], max_frames=0,
                         window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["PAD_MODE"], input_scale=1.0).eval()
     istft = STFT_Process(model_type="istft_B", n_fft=ns["NFFT"], hop_len=ns["HOP_LENGTH"], win_length=ns["WINDOW_LENGTH"],
                          max_frames=ns["MAX_SIGNAL_LENGTH"], window_type=ns["WINDOW_TYPE"], center_pad=True, pad_mode=ns["PAD_MODE"],
-                         output_scale=1.0, static_cola=True).eval()
+                         output_scale=1.0, static_cola=not dynamic).eval()                                                  # (:1097)
     frames, fb = ns["MAX_SIGNAL_LENGTH"], ns["FRONTEND_BATCH"]
+    static_frames = None if dynamic else frames                                                                                # (:1075)
     wpe = ns["OnnxFriendlyWPE"](n_channels=2, rt60=ns["WPE_RT60"], hop_length=ns["HOP_LENGTH"], delay=ns["WPE_DELAY"], sample_rate=16000,
                                 num_iter=ns["WPE_ITER"], ns_iter=ns["CG_SOLVE_ITER"], n_freq_bins=257, max_frames=frames, batch_size=fb,
-                                dynamic_frames=False).eval()
-    iva = ns["OnnxFriendlyAuxIVA"](n_iter=ns["IVA_ITER"], n_channels=2, batch_size=fb, n_frames=frames).eval()
+                                dynamic_frames=dynamic).eval()                                                                 # (:1110)
+    iva = ns["OnnxFriendlyAuxIVA"](n_iter=ns["IVA_ITER"], n_channels=2, batch_size=fb, n_frames=static_frames).eval()
     torch.manual_seed(seed)
-    net = ns["GTCRN_IVA"](batch_size=fb, n_frames=frames).eval()
+    net = ns["GTCRN_IVA"](batch_size=fb, n_frames=static_frames).eval()
     seed_network(net, seed)
     state = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()
              if v.dtype.is_floating_point and not k.endswith("_weight_t") and not k.endswith("_h0") and "zero" not in k}
     net.fuse_bn_()
     model = ns["H_GTCRN_CUSTOM"](net, stft, istft, wpe, iva, n_fft=512, in_sample_rate=ns["IN_SAMPLE_RATE"], out_sample_rate=ns["OUT_SAMPLE_RATE"],
                                  use_batch_fold=bool(fold_window), fold_window=fold_window, model_audio_length=ns["MODEL_AUDIO_LENGTH"],
-                                 n_frames=frames, frontend_batch=fb, fold_input_pcm_scale=False, fold_output_pcm_scale=False).eval()
+                                 n_frames=static_frames, frontend_batch=fb, fold_input_pcm_scale=False, fold_output_pcm_scale=False).eval()
     return model, net, wpe, iva, state
 
 
@@ -215,6 +216,33 @@ def resample_fixture(seed=0):
     np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}_resample.npz"), **out)
 
 
+def dynamic_fixture(seed=0):
+    """DYNAMIC_AXES = True (:27, :43-44, :1075, :1097, :1110): frame counts come from the waveform (MAX_SIGNAL_LENGTH = 4096 only sizes tables), and the ISTFT keeps
+    everything after the leading half window -- half a window more than the static trim -- dividing by the window-square sum of the ACTUAL frames
+    (H-GTCRN/STFT_Process.py:318-327; in that tail only the last frame contributes: x / w with w running out, most of it saturates the int16 clamp).  One module instance on two lengths (8192 and 12288 samples), the same seeded
+    network as hgtcrn_seed{seed}.npz; the WPE outputs are kept for the two-part contract.  tests/golden/hgtcrn_seed{seed}_dynamic.npz"""
+    z = np.load(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}.npz"))
+    ns = import_namespace(8192, extra={"DYNAMIC_AXES": True})
+    assert ns["MAX_SIGNAL_LENGTH"] == 4096 and ns["MODEL_AUDIO_LENGTH"] == 0
+    model, _, wpe, *_ = build(ns, seed, dynamic=True)
+    out = {}
+    for tag, row, length in (("a", 1, 8192), ("b", 2, 12288)):
+        taps = {}
+        orig = type(wpe).forward
+        def tapped(*a, taps=taps):
+            y = orig(wpe, *a)
+            taps["wpe"] = [t.clone().numpy() for t in y]
+            return y
+        wpe.forward = tapped
+        pcm = np.ascontiguousarray(z["pcm_in"][row][:, 500:500 + length])
+        with torch.inference_mode():
+            y = model(torch.from_numpy(pcm.reshape(1, 2, -1).copy())).numpy().reshape(-1)
+        assert y.shape[0] == length + 256, y.shape
+        out.update({f"{tag}_pcm_in": pcm, f"{tag}_pcm_out": y, f"{tag}_wpe_r": taps["wpe"][0], f"{tag}_wpe_i": taps["wpe"][1]})
+        print("dynamic", tag, "in", pcm.shape, "out", y.shape, int(np.abs(y).max()), "tail max", int(np.abs(y[-256:]).max()))
+    np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_seed{seed}_dynamic.npz"), **out)
+
+
 def float_io_fixture(seed=0):
     """IN / OUT_AUDIO_DTYPE other than INT16 (:52-53): a float input skips the * inv_int16 (:965-966), a float output the * 32767 and the clamp (:1042-1063).
     tests/golden/hgtcrn_float_io_seed{seed}.npz; the network and the input row are hgtcrn_seed{seed}.npz's (row 1)."""
@@ -232,6 +260,10 @@ def float_io_fixture(seed=0):
         print(tag, y.shape, y.dtype, float(np.abs(y).max()))
     np.savez_compressed(os.path.join(mg.GOLD, f"hgtcrn_float_io_seed{seed}.npz"), **out)
 
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    dynamic_fixture()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--float-io" in sys.argv:
     float_io_fixture()
