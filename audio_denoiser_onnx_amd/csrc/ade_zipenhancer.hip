@@ -174,11 +174,19 @@ __global__ __launch_bounds__(256) void k_zip_stats_partial(const float* __restri
     const int lo = chunk * kChunkTok, hi = min(tok_per_win, lo + kChunkTok);
     double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
     const float* base = x + (size_t)r * tok_per_win * ld + ch0 + 4 * q;
-    for (int i = lo + tl; i < hi; i += 16) {
-        float v[4];
-        ld4(base + (size_t)i * ld, v);
+    // (the pass is latency-bound: four rows in flight per lane; the fp64 sums are order-insensitive at the precision the statistics are used at)
+    for (int i0 = lo + tl; i0 < hi; i0 += 64) {
+        float v[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s[u] += v[u]; ss[u] += (double)v[u] * v[u]; }
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * r;
+            if (i < hi) ld4(base + (size_t)i * ld, v[r]);
+            else v[r][0] = v[r][1] = v[r][2] = v[r][3] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s[u] += v[r][u]; ss[u] += (double)v[r][u] * v[r][u]; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { red[tl][q][u] = s[u]; red[tl][q][4 + u] = ss[u]; }
