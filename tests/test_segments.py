@@ -113,3 +113,29 @@ def test_gpu_three_to_eight_segments(length):
     o = GtcrnOracle(golden_blob(2), length)
     opcm, of32 = o.process(x[:4], threads=4)
     assert np.abs(a[1][:4] - of32).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_priority_options_and_every_segments_clocks():
+    """The scheduling knobs do not touch a bit ("seg_prio" 0 .. 4: base wave priority by segment; the recurrences always run at priority 3), values outside the range are
+    refused, and the clock build stamps EVERY segment of chunk 0 (four of them in geometry 2: one 640-slot set each)."""
+    x = synth_batch(64)
+    sess = make_session(None, seed=0)
+    ref = run(sess, x, "2")
+    for level in "1234":
+        sess.set_option("seg_prio", level)
+        assert_same(ref, run(sess, x, "2"), f"seg_prio {level}")
+    with pytest.raises(Exception):
+        sess.set_option("seg_prio", "7")
+    sess.set_option("seg_prio", "0")
+    sess.profile(3)
+    sess.process(x)
+    sess.process(x)
+    clocks = sess.tap("phase_clock_abs", 8 * 640).reshape(-1, 10, 64)
+    sess.profile(0)
+    assert clocks.shape[0] == 8
+    for seg in range(4):
+        assert clocks[seg, 9, 53] > clocks[seg, 0, 32] >= 0, (seg, clocks[seg, 0, 32:37].tolist(), clocks[seg, 9, 48:54].tolist())   # the back stage of every segment ended after its front stage began
+    assert (clocks[4:] == -1).all()                                        # no fifth segment at 63 frames
+    ends = [clocks[seg, 9, 53] for seg in range(4)]
+    assert ends == sorted(ends)                                            # a segment cannot finish before its predecessor (its overlap-add carry comes from it)
