@@ -323,3 +323,23 @@ def test_gpu_dynamic_axes(fixture, tag):
     assert np.sqrt(((got[0, :Lc] - r[:Lc]) ** 2).mean()) < 0.15 * np.sqrt((r[:Lc] ** 2).mean())                   # end to end: bounded by the ill-conditioned bins
     with pytest.raises(Exception):
         hgtcrn.metadata(3 * 8192, use_batch_fold=True, dynamic_axes=True)
+
+
+@pytest.mark.hipsim
+def test_hipsim_dynamic_axes_short_clip(fixture):
+    """The dynamic_axes path of csrc/ade_hgtcrn.hip under the host simulator: 13 frames in, L + 256 samples out, the kept tail against the oracle on the engine's own WPE
+    output."""
+    from ade_testlib import hipsim_library
+    from hgtcrn_oracle import HgtcrnOracle
+    z, fused = fixture
+    W = 3072
+    pcm = np.ascontiguousarray(z["pcm_in"][2:3, :, 3000:3000 + W])
+    lib = hipsim_library()
+    with _session(fused, W, lib, dynamic_axes=True) as sess:
+        assert sess.frames == 13 and sess.out_len == W + 256
+        got = sess.run(None, {"noisy_audio": pcm})[0][:, 0]
+        wpe = sess.tap("wpe", 2 * 514 * 13).reshape(1, 2, 2, 257, 13)
+    want = HgtcrnOracle(fused, W, 1, True, dynamic=True).process(pcm, inject_wpe=(wpe[:, :, 0], wpe[:, :, 1]))          # (static == dynamic[:L] is asserted on the GPU)
+    d = got.astype(np.int32) - want.astype(np.int32)
+    # (13 frames: fewer frames than the 25-frame clip above under every statistic, so one-LSB flips are a little more frequent)
+    assert np.abs(d[:, :W]).max() <= 3 and (d[:, :W] != 0).mean() < 0.10 and np.abs(d[:, W:]).max() <= 8, (np.abs(d[:, :W]).max(), (d[:, :W] != 0).mean(), np.abs(d[:, W:]).max())
