@@ -252,13 +252,24 @@ __device__ __forceinline__ void xflag_store(unsigned* p, unsigned v) { *(volatil
 __device__ __forceinline__ void xdrain() {}
 #endif
 // ONE lane polls ONE flag until it is raised, then lowers it again for the next launch (each flag has exactly one consumer; the kernel
-// boundary orders that store before the next launch's producer).  Bounded: after ~0.2 s of wall clock the wait gives up, records the
-// failure in *err and lets the workgroup run on (garbage out, reported by the engine) instead of hanging the device.
-__device__ __forceinline__ void xwait(unsigned* flag, int* err) {
-    const long long t0 = wall_clock64();
-    while (xflag_load(flag) == 0u) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > 20000000LL) { *reinterpret_cast<volatile int*>(err) = 1; return; }
+// boundary orders that store before the next launch's producer).  Bounded: err[1] holds the limit in 10 ns ticks (option "xwait_ms", default 0.2 s; read only
+// once the first poll has found the flag down).  The FIRST wait of a launch that gives up leaves `code` (xcode(): block index and flag index of the waiting segment) in err[0] and
+// lets the workgroup run on instead of hanging the device; it does NOT lower the flag.  The engine then fails the call with ADE_ERR_DEVICE -- no PCM is handed
+// out -- and clears every flag before the next launch (exchange_status() in ade_engine.hip).
+__device__ __forceinline__ int xcode(int flag_index) { return (int)((blockIdx.x + 1u) << 4) | flag_index; }
+__device__ __forceinline__ void xwait(unsigned* flag, int* err, int code) {
+    if (xflag_load(flag) == 0u) {
+        volatile int* const e = reinterpret_cast<volatile int*>(err);
+        const long long t0 = wall_clock64();
+        const long long limit = (long long)e[1];
+        if (e[0] != 0) return;                             // the launch has already failed (the first code stays): nobody waits out another bound
+        do {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > limit) {
+                if (e[0] == 0) e[0] = code;
+                return;
+            }
+        } while (xflag_load(flag) == 0u);
     }
     xflag_store(flag, 0u);
 }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -108,12 +109,15 @@ struct ade_engine {
 
     int stagger_ticks = 2750;             // 27.5 us, applied when a launch has enough chunks to load the memory system (see enqueue; geometry 0 only)
     int wave_swap = 0;                    // option "wave_swap": odd segments run their conv lanes on wavefronts 0-3, 6, 7 (measured neutral to -1 %: off)
-    int seg_prio = 0;                     // wave priority of later segments' workgroups (option "seg_prio", 0-3)
+    int seg_prio = 0;                     // base wave priority of the workgroups by segment (option "seg_prio", 0-4: SegPlan::prio)
+    int xwait_ticks = 20000000;           // bound of one inter-workgroup wait in 10 ns ticks (option "xwait_ms"; 0.2 s)
+    int xchg_withhold = 0;                // test hook (option "xchg_withhold"): SegPlan::withhold
     int geometry = -1;                    // fused-path workgroup geometry (ade_internal.h): -1 = choose per call, 0 = 1024 threads x 64 frames, 1 = 512 x 32
     ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
     float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
     unsigned* d_xflags = nullptr;         // its flags (zero between launches)
-    int* d_xerr = nullptr;                // page-locked host word the kernels can write: a bounded inter-workgroup wait gave up
+    int* d_xerr = nullptr;                // page-locked host words the kernels see: [0] the dev::xcode() of a bounded inter-workgroup wait that gave up, [1] the bound in ticks
+    int xchg_capacity = 0;                // chunks the exchange area holds
     int xchg_segments = 0;                // slots per chunk the exchange area was sized for
     bool use_graph = true;
     bool graph_supported = true;
@@ -446,6 +450,13 @@ void free_graphs(ade_engine* e) {
     e->graphs.clear();
 }
 
+void free_exchange(ade_engine* e) {
+    if (e->d_xchg) hipFree(e->d_xchg);
+    if (e->d_xflags) hipFree(e->d_xflags);
+    e->d_xchg = nullptr; e->d_xflags = nullptr;
+    e->xchg_capacity = 0; e->xchg_segments = 0;
+}
+
 void free_workspace(ade_engine* e) {
     free_graphs(e);
     if (e->ws) hipFree(e->ws);
@@ -458,10 +469,8 @@ void free_workspace(ade_engine* e) {
     if (e->rs_in) hipFree(e->rs_in);
     if (e->rs_out) hipFree(e->rs_out);
     if (e->d_fixed) hipFree(e->d_fixed);
-    if (e->d_xchg) hipFree(e->d_xchg);
-    if (e->d_xflags) hipFree(e->d_xflags);
-    if (e->d_xerr) hipHostFree(e->d_xerr);
-    e->d_fixed = nullptr; e->d_xchg = nullptr; e->d_xflags = nullptr; e->d_xerr = nullptr;
+    e->d_fixed = nullptr;
+    free_exchange(e);
     for (float** p : {&e->gt_tmp, &e->gt_in, &e->gt_wave, &e->gt_mean, &e->d_f32_in}) { if (*p) hipFree(*p); *p = nullptr; }
     for (uint16_t** p : {&e->d_f16_in, &e->d_f16_out}) { if (*p) hipFree(*p); *p = nullptr; }
     for (uint16_t** p : {&e->h_f16_in, &e->h_f16_out}) { if (*p) hipHostFree(*p); *p = nullptr; }
@@ -475,8 +484,40 @@ void free_workspace(ade_engine* e) {
     e->capacity = 0;
 }
 
+int pick_geometry(const ade_engine* e, int B);
+
+// The segment exchange area of the fused path (ade_internal.h: kX*), sized for the geometry the next call will actually take: nothing for the sandwich exports and for
+// chunks one workgroup walks alone (no slot is ever touched there), [capacity][segments] slots otherwise (132 KB each: 135 MB at 256 x 1 s in four segments).
+ade_status ensure_exchange(ade_engine* e) {
+    if (e->sub) return ADE_OK;
+    if (!e->d_xerr) {
+        HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, 4 * sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
+        e->d_xerr[0] = 0;
+    }
+    e->d_xerr[1] = e->xwait_ticks;
+    int nseg = 0;
+    if (e->use_fused && !e->gt_sand) {
+        const int g = pick_geometry(e, e->capacity);
+        if (g >= 0) nseg = fused_segments(e->T, g);
+    }
+    if (nseg <= 1) nseg = 0;
+    if (nseg == e->xchg_segments && (nseg == 0 || e->xchg_capacity >= e->capacity)) return ADE_OK;
+    if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
+    free_graphs(e);
+    free_exchange(e);
+    if (nseg) {
+        const size_t B = (size_t)e->capacity;
+        HIP_TRY(e, hipMalloc((void**)&e->d_xchg, B * nseg * (size_t)kXFloats * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_xflags, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
+        HIP_TRY(e, hipMemset(e->d_xflags, 0, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
+        e->xchg_capacity = e->capacity;
+    }
+    e->xchg_segments = nseg;
+    return ADE_OK;
+}
+
 ade_status reserve(ade_engine* e, int batch) {
-    if (batch <= e->capacity) return ADE_OK;
+    if (batch <= e->capacity) return ensure_exchange(e);
     HIP_TRY(e, hipSetDevice(e->device));
     if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     free_workspace(e);
@@ -529,7 +570,7 @@ ade_status reserve(ade_engine* e, int batch) {
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_in, B * e->in_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_pcm_out, B * e->out_len * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc((void**)&e->h_f32_out, B * e->out_len * sizeof(float), hipHostMallocDefault));
-    {   // the fused path's device-resident argument block and the segment exchange area (sized for the finest split any geometry would use)
+    {   // the fused path's device-resident argument block (the segment exchange area: ensure_exchange)
         ChunkFixed F{};
         F.tabs = e->tabs; F.erb_bm = e->erb_bm; F.erb_bs = e->erb_bs;
         F.en0 = e->en0; F.en1 = e->en1; F.de3 = e->de3; F.de4 = e->de4;
@@ -538,15 +579,6 @@ ade_status reserve(ade_engine* e, int batch) {
         F.spec = e->spec; F.e0 = e->e0; F.e1 = e->e1;
         HIP_TRY(e, hipMalloc((void**)&e->d_fixed, sizeof(ChunkFixed)));
         HIP_TRY(e, hipMemcpy(e->d_fixed, &F, sizeof(ChunkFixed), hipMemcpyHostToDevice));
-        int nseg = 1;
-        for (int g = 0; g < fused_geometries(); ++g)
-            if (fused_supported(e->T, g)) nseg = std::max(nseg, fused_segments(e->T, g));
-        e->xchg_segments = nseg;
-        HIP_TRY(e, hipMalloc((void**)&e->d_xchg, B * nseg * (size_t)kXFloats * sizeof(float)));
-        HIP_TRY(e, hipMalloc((void**)&e->d_xflags, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
-        HIP_TRY(e, hipMemset(e->d_xflags, 0, B * nseg * (size_t)kXFlags * sizeof(unsigned)));
-        HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
-        *e->d_xerr = 0;
     }
     if (e->gt_sand) {
         HIP_TRY(e, hipMalloc((void**)&e->gt_tmp, B * (size_t)e->gt_l1 * sizeof(float)));
@@ -556,7 +588,7 @@ ade_status reserve(ade_engine* e, int batch) {
         if (e->gt_float_in) HIP_TRY(e, hipMalloc((void**)&e->d_f32_in, B * (size_t)e->in_len * sizeof(float)));
     }
     e->capacity = batch;
-    return ADE_OK;
+    return ensure_exchange(e);
 }
 
 // ---- the launch sequence -------------------------------------------------------------------------------
@@ -613,6 +645,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
         //      tensors channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  1 launch, or 10.
         SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr, e->wave_swap};
         plan.prio = e->seg_prio;
+        plan.withhold = e->xchg_withhold;
         e->last_geometry = geo;
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
@@ -629,7 +662,6 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             C.stagger = (geo == 0 && B >= 192) ? e->stagger_ticks : 0;
             C.pcm_in = d_in; C.pcm_out = d_out; C.f32_out = d_f32; C.L = e->in_len; C.T = T; C.B = B;
             C.plan = plan;
-            C.seg_prio = e->seg_prio;
             C.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
             q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, geo, C); q.end();
             return;
@@ -784,6 +816,30 @@ ade_status run(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t
     if (sub_rc != ADE_OK) return fail(e, (ade_status)sub_rc, sub_err);
     HIP_TRY(e, hipGetLastError());
     return ADE_OK;
+}
+
+// The segmented fused path's bounded waits (dev::xwait): a wait that gave up left its dev::xcode() in the page-locked error word and the launch's output is not
+// to be trusted.  Every entry point calls this (a) on entry -- launches on a CALLER's stream are not synchronised by the engine, so a failure of an earlier call is
+// reported by the next one -- and (b) after it has synchronised its own launch, BEFORE any PCM is handed out.  On a failure the device is drained (the waiting
+// workgroups of the failed launch run on for up to their own bounds), every flag is lowered -- a late producer may have raised one that nobody consumed -- and the
+// call fails with ADE_ERR_DEVICE naming the chunk, the segment and the hand-off that did not arrive.
+const char* xflag_name(int idx) {
+    return idx < kXFlagTra ? "depthwise-convolution history" : (idx < kXFlagInter ? "TRA state" : (idx < kXFlagOla ? "inter-frame GRU state" : "overlap-add carry"));
+}
+ade_status exchange_status(ade_engine* h, const char* who, bool earlier) {
+    if (!h->d_xerr) return ADE_OK;
+    const int code = *(volatile int*)h->d_xerr;
+    if (!code) return ADE_OK;
+    (void)hipDeviceSynchronize();
+    h->d_xerr[0] = 0;
+    if (h->d_xflags) (void)hipMemset(h->d_xflags, 0, (size_t)h->xchg_capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
+    const int block = (code >> 4) - 1, idx = code & 15, B = h->last_batch > 0 ? h->last_batch : 1;
+    char msg[384];
+    snprintf(msg, sizeof msg,
+             "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for the %s of its predecessor workgroup; no output was produced "
+             "(option geometry=0 runs whole chunks per workgroup, option xwait_ms raises the bound)",
+             who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5, xflag_name(idx));
+    return fail(h, ADE_ERR_DEVICE, msg);
 }
 
 // ---- streaming: the multi-kernel launch sequence over pushes of N frames with carried state -------
@@ -1246,9 +1302,27 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         h->wave_swap = b;
         return ADE_OK;
     }
-    if (strcmp(key, "seg_prio") == 0) {        // s_setprio level of the workgroups that own a later segment of a chunk (0-3)
+    if (strcmp(key, "seg_prio") == 0) {        // base wave priority by segment: 0 none, 1-3 that level for every later segment, 4 earlier segments first (SegPlan::prio)
         if (value[0] < '0' || value[0] > '4' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option seg_prio: 0..4");
         h->seg_prio = value[0] - '0';
+        return ADE_OK;
+    }
+    if (strcmp(key, "xwait_ms") == 0) {        // bound of one inter-workgroup wait of the segmented fused path, milliseconds (default 200)
+        char* end = nullptr;
+        const double ms = strtod(value, &end);
+        if (!value[0] || *end || !(ms >= 0.001) || ms > 20000.0) return fail(h, ADE_ERR_BAD_VALUE, "option xwait_ms: 0.001..20000");
+        h->xwait_ticks = (int)(ms * 1e5 + 0.5);
+        if (h->d_xerr) {
+            if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+            h->d_xerr[1] = h->xwait_ticks;
+        }
+        return ADE_OK;
+    }
+    if (strcmp(key, "xchg_withhold") == 0) {   // TEST HOOK: the first workgroup of the next fused launches raises its hand-off flags where nobody looks (SegPlan::withhold)
+        bool b;
+        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, "option xchg_withhold must be 0/1");
+        h->xchg_withhold = b;
+        free_graphs(h);
         return ADE_OK;
     }
     if (strcmp(key, "geometry") == 0) {        // fused-path workgroup geometry: "auto", "0" (1024 threads x 64 frames), "1" (512 x 32, two per CU)
@@ -1279,13 +1353,17 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device: bad arguments");
     if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_device_f32");
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process_device", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : h->stream;
     st = run(h, s, d_in, rows, d_out, d_f32);
     if (st != ADE_OK) return st;
-    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    if (!hip_stream) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        return exchange_status(h, "ade_process_device", false);
+    }
     return ADE_OK;
 }
 
@@ -1296,6 +1374,7 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process_device");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process_device_f32", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
@@ -1304,7 +1383,10 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
     st = run(h, s, reinterpret_cast<const int16_t*>(d_in), rows, d_out, d_f32);      // (the pointer only keys the graph cache: enqueue reads cur_fin)
     h->cur_fin = nullptr;
     if (st != ADE_OK) return st;
-    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    if (!hip_stream) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        return exchange_status(h, "ade_process_device_f32", false);
+    }
     return ADE_OK;
 }
 
@@ -1319,13 +1401,12 @@ ade_status ade_stitch_device(ade_handle h, const int16_t* d_local, int rows, int
 #else
     typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);      // ncclResult_t ncclAllGather(send, recv, count, ncclDataType_t, ncclComm_t, stream)
     static all_gather_fn all_gather = nullptr;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;                       // (two handles may stitch from two threads)
+    std::call_once(once, [] {
         void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (lib) all_gather = reinterpret_cast<all_gather_fn>(dlsym(lib, "ncclAllGather"));
-    }
+    });
     if (!all_gather) return fail(h, ADE_ERR_UNSUPPORTED, "ade_stitch_device: librccl.so / ncclAllGather not found");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)rows * h->out_len * sizeof(int16_t);
@@ -1355,6 +1436,7 @@ ade_status ade_process_device_f16(ade_handle h, const void* d_in, int batch, int
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device_f16: bad arguments");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process_device_f16", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
@@ -1371,7 +1453,10 @@ ade_status ade_process_device_f16(ade_handle h, const void* d_in, int batch, int
     if (st != ADE_OK) return st;
     if (d_f16) launch_float_to_half(s, h->d_f32_out, d_f16, (long long)rows * h->out_len);
     HIP_TRY(h, hipGetLastError());
-    if (!hip_stream) HIP_TRY(h, hipStreamSynchronize(s));
+    if (!hip_stream) {
+        HIP_TRY(h, hipStreamSynchronize(s));
+        return exchange_status(h, "ade_process_device_f16", false);
+    }
     return ADE_OK;
 }
 
@@ -1380,6 +1465,7 @@ ade_status ade_process_f16(ade_handle h, const void* in, int batch, int16_t* out
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_f16: bad arguments");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process_f16", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
@@ -1401,6 +1487,7 @@ ade_status ade_process_f16(ade_handle h, const void* in, int batch, int16_t* out
     if (out_pcm) HIP_TRY(h, hipMemcpyAsync(h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f16) HIP_TRY(h, hipMemcpyAsync(h->h_f16_out, h->d_f16_out, nout * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    { const ade_status xs = exchange_status(h, "ade_process_f16", false); if (xs != ADE_OK) return xs; }
     if (out_pcm) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
     if (out_f16) memcpy(out_f16, h->h_f16_out, nout * sizeof(uint16_t));
     return ADE_OK;
@@ -1412,6 +1499,7 @@ ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* ou
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process_f32", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
@@ -1424,6 +1512,14 @@ ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* ou
     if (out_pcm) HIP_TRY(h, hipMemcpyAsync(out_pcm, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(out_f32, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    {
+        const ade_status xs = exchange_status(h, "ade_process_f32", false);
+        if (xs != ADE_OK) {
+            if (out_pcm) memset(out_pcm, 0, nout * sizeof(int16_t));
+            if (out_f32) memset(out_f32, 0, nout * sizeof(float));
+            return xs;
+        }
+    }
     return ADE_OK;
 }
 
@@ -1433,6 +1529,7 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_f32");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { const ade_status xs = exchange_status(h, "ade_process", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
     if (st != ADE_OK) return st;
@@ -1453,10 +1550,11 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     if (out_pcm) HIP_TRY(h, hipMemcpyAsync(pcm_direct ? out_pcm : h->h_pcm_out, h->d_pcm_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     if (out_f32) HIP_TRY(h, hipMemcpyAsync(f32_direct ? out_f32 : h->h_f32_out, h->d_f32_out, nout * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->d_xerr && *(volatile int*)h->d_xerr) {   // a segment's bounded wait for its predecessor gave up: the outputs are not to be trusted
-        *h->d_xerr = 0;
-        (void)hipMemset(h->d_xflags, 0, (size_t)h->capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
-        return fail(h, ADE_ERR_DEVICE, "fused path: a chunk segment timed out waiting for its predecessor workgroup (option geometry=0 runs whole chunks per workgroup)");
+    st = exchange_status(h, "ade_process", false);
+    if (st != ADE_OK) {   // a page-locked destination has already received the failed launch's bytes: blank it
+        if (out_pcm && pcm_direct) memset(out_pcm, 0, nout * sizeof(int16_t));
+        if (out_f32 && f32_direct) memset(out_f32, 0, nout * sizeof(float));
+        return st;
     }
     if (out_pcm && !pcm_direct) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
     if (out_f32 && !f32_direct) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
@@ -1514,7 +1612,7 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         *written = count > 1 ? 2 : 1;
         return ADE_OK;
     }
-    if (strcmp(name, "xchg_error") == 0) {        // 1 after a bounded inter-workgroup wait of the segmented fused path gave up (sticky)
+    if (strcmp(name, "xchg_error") == 0) {        // non-zero (the dev::xcode of the wait) after a bounded inter-workgroup wait of the segmented fused path gave up; sticky until an entry point reports it
         if (count < 1) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
         int v = 0;
         if (h->d_xerr) {
@@ -1595,6 +1693,7 @@ void ade_destroy(ade_handle h) {
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_ints) hipFree(h->d_ints);
     if (h->d_clk) hipFree(h->d_clk);
+    if (h->d_xerr) hipHostFree(h->d_xerr);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1704,9 +1803,10 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
                 hipMalloc((void**)&st->xstate[0], S * (size_t)kXFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&st->xstate[1], S * (size_t)kXFloats * sizeof(float)) != hipSuccess ||
                 hipMalloc((void**)&st->xstate_flags[0], S * (size_t)kXFlags * sizeof(unsigned)) != hipSuccess ||
                 hipMalloc((void**)&st->xstate_flags[1], S * (size_t)kXFlags * sizeof(unsigned)) != hipSuccess ||
-                hipHostMalloc((void**)&st->xerr, sizeof(int), hipHostMallocDefault) != hipSuccess)
+                hipHostMalloc((void**)&st->xerr, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
                 return bail("ade_stream_create: allocation of the fused-push state failed");
-            *st->xerr = 0;
+            st->xerr[0] = 0;
+            st->xerr[1] = h->xwait_ticks;
             st->fused = true; st->geo = geo; st->geo_flush = geo1;
         }
     }

@@ -58,6 +58,7 @@ __device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int b
         sg.xo = plan.carry_out + (size_t)chunk * kXFloats;
         sg.fo = plan.carry_out_flags + (size_t)chunk * kXFlags;
     }
+    if (plan.withhold && block == 0) sg.fo = plan.flags + ((size_t)B * plan.nseg - 1) * kXFlags;   // test hook: see SegPlan::withhold
     sg.first = !sg.prev;
     sg.base_prio = plan.prio == 4 ? (seg < 2 ? 2 - seg : 0) : (seg > 0 ? plan.prio : 0);
     return sg;

@@ -155,7 +155,7 @@ struct SegPlan {           // how a launch splits its chunks (host-computed, pas
     int nseg;              // segments per chunk (1: the whole chunk in one workgroup)
     float* xchg;           // [B][nseg][kXFloats]
     unsigned* flags;       // [B][nseg][kXFlags], zero between launches
-    int* err;              // sticky: a bounded wait gave up
+    int* err;              // page-locked host words: [0] sticky, the dev::xcode() of a bounded wait that gave up; [1] the bound in 10 ns ticks
     int wave_swap;         // 1: odd segments run their conv lanes on wavefronts 0-3, 6, 7 instead of 0-5 (see gtblock_stage)
     // STREAMS (ade_stream_*): a push is a chunk whose first segment continues the state its last segment left one launch earlier -- the same exchange slots, one per
     // stream, ping-ponged between pushes -- framed without centre padding and emitted one hop behind (include/ade.h).
@@ -165,6 +165,7 @@ struct SegPlan {           // how a launch splits its chunks (host-computed, pas
     unsigned* carry_out_flags;
     int stream;            // 1: streaming framing -- frame t reads samples 256 t .. 256 t + 511 of the row (256 carried + the push), output sample n = overlap-add sample n
     int prio;              // base wave priority of the workgroups by segment (option "seg_prio"): 0 none; 1-3 = that level for every later segment; 4 = earlier segments first (2, 1, 0, 0)
+    int withhold;          // TEST HOOK (option "xchg_withhold"): block 0 raises its flags in the launch's LAST slot, which nobody polls, so its successor's bounded waits give up
 };
 struct Seg {               // one workgroup's share (device-side)
     int t0, nT, T;         // first frame, frames owned, frames of the chunk
@@ -214,7 +215,6 @@ struct ChunkCall {           // per call, by value
     int L, T, B;
     int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all
                              // hit HBM with the same stage's burst at the same instant; ade_set_option "stagger_us")
-    int seg_prio;            // s_setprio level of the workgroups that own a later segment (0 = leave it)
     SegPlan plan;
 };
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call);

@@ -793,7 +793,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         if (tid == 0) xflag_store(sg.fo + kXFlagOla, 1u);
     }
     if (sg.prev) {   // the first hop of this segment: the parked samples + the predecessor's carry; then the same tail as above
-        if (tid == 0) xwait(sg.fi + kXFlagOla, sg.err);
+        if (tid == 0) xwait(sg.fi + kXFlagOla, sg.err, xcode(kXFlagOla));
         __syncthreads();
         int tf = tid;
         ADE_OPAQUE_V(tf);

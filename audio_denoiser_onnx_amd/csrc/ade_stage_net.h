@@ -209,7 +209,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         if (it < kTiles && pu < P) H[(2 + (g & 1)) * kPmax + pu] = hi[pr];
     }
     if (tid < 12) zt[tid] = 0.0f;
-    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagHist + blk, sg.err);     // the previous segment's partial sums (normally long there)
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagHist + blk, sg.err, xcode(kXFlagHist + blk));     // the previous segment's partial sums (normally long there)
     __syncthreads();
     ADE_CLK(1);
 
@@ -391,7 +391,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
             }
         }
     }
-    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagTra + blk, sg.err);      // the previous segment's last hidden state
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagTra + blk, sg.err, xcode(kXFlagTra + blk));      // the previous segment's last hidden state
     __syncthreads();
     ADE_CLK(4);
     ADE_CLK(5);
@@ -719,7 +719,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             Rf[((size_t)(c >> 2) * kPmax + p) * 4 + (c & 3)] = m;
             oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = m;
         });
-    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagInter + blk, sg.err);    // the previous segment's inter-frame GRU state
+    if (sg.prev && tid == 0) xwait(sg.fi + kXFlagInter + blk, sg.err, xcode(kXFlagInter + blk));    // the previous segment's inter-frame GRU state
     __syncthreads();
     for (int i = tid; i < kFw * kCh; i += kFusedThreads) {   // phase B is done with the intra pair: the inter pair takes its place (visible after phase C's barrier)
         lnt[i] = w.inter_ln_w[i];

@@ -55,11 +55,18 @@ def denoise(session: InferenceSession, audio: np.ndarray, fold_active: bool, ran
     """(2, n) int16 -> int16 mono of the input's duration at the OUTPUT rate (``int(n * OUT / IN)`` samples, :352):
     every slice of the file in one batched call."""
     in_rate, out_rate = session_rates(session)
-    slices = cut_slices(audio, session.in_len, fold_active, session.out_len, in_rate == out_rate)
+    # A dynamic-length export returns MORE than its input's duration (the ISTFT keeps the last frame's tail: in_len + 256 samples at equal rates).  The reference
+    # driver sees no static output length for such a graph, so it steps by the INPUT length (:341-343 only take the output stride when both shapes are integers) and
+    # binds an output of round(in_len * OUT / IN) samples per slice (:350): the tail never reaches the stitched file.
+    meta = getattr(session, "metadata", None)
+    dynamic = bool(meta and meta.optional_bool("dynamic_axes", False))
+    ratio = out_rate / in_rate if in_rate > 0 and out_rate > 0 else 1.0
+    keep = min(session.out_len, int(round(session.in_len * ratio))) if dynamic else session.out_len
+    slices = cut_slices(audio, session.in_len, fold_active, session.out_len, in_rate == out_rate and not dynamic)
     from .distributed import run_rows
     out = run_rows(session, slices, rank, world, group)[0]                                  # (n_slices, 1, out_len)
     n_out = output_length(audio.shape[1], in_rate, out_rate)
-    return np.ascontiguousarray(out.reshape(-1)[:n_out])
+    return np.ascontiguousarray(out.reshape(out.shape[0], -1)[:, :keep].reshape(-1)[:n_out])
 
 
 def main(argv=None) -> int:

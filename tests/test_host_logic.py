@@ -205,7 +205,7 @@ def test_drivers_with_unequal_sample_rates():
 def test_drivers_stitch_dynamic_length_exports_by_input_length():
     """A dynamic-length export returns more than its input's duration (the ISTFT keeps the last frame's tail): the drivers step by the input length and cut every slice's
     output at round(input_audio_length * out_rate / in_rate), what the reference driver's bound output buffer holds (Inference_GTCRN_ONNX.py:300-304)."""
-    from audio_denoiser_onnx_amd import inference_gtcrn, inference_melband
+    from audio_denoiser_onnx_amd import inference_gtcrn, inference_hgtcrn, inference_melband
     from audio_denoiser_onnx_amd.metadata import MetadataReader
 
     class Fake:
@@ -223,7 +223,7 @@ def test_drivers_stitch_dynamic_length_exports_by_input_length():
 
         def run(self, _, feed):
             x = next(iter(feed.values()))
-            out = np.repeat(np.arange(1, len(x) + 1, dtype=np.int16)[:, None, None], self.out_len, axis=2).repeat(self.channels, axis=1)
+            out = np.repeat(np.arange(1, len(x) + 1, dtype=np.int16)[:, None, None], self.out_len, axis=2).repeat(getattr(self, "out_channels", self.channels), axis=1)
             out[:, :, -4:] = -1
             return [out]
 
@@ -238,3 +238,15 @@ def test_drivers_stitch_dynamic_length_exports_by_input_length():
     stereo = np.zeros((2, 2500), np.int16)
     out = inference_melband.denoise(Fake(1000, 1583, 44100, 44100, channels=2), stereo, False, np.random.default_rng(0))
     assert out.shape == (2, 2500) and np.array_equal(np.unique(out[:, 1000:2000]), [2]) and (out != -1).all()
+    # H-GTCRN (two microphones in, one channel out): in_len + 256 samples per slice at equal rates, every slice's tail dropped before the stitch (Inference_H_GTCRN_ONNX.py:341-350)
+    hg = Fake(1000, 1256, 16000, 16000, channels=2)
+    hg.out_channels = 1
+    ramp = np.arange(2500, dtype=np.int16)
+    seen = inference_hgtcrn.cut_slices(np.stack([ramp, ramp]), 1000, False, 1256, rates_equal=False)
+    assert seen.shape == (3, 2, 1000) and seen[1, 0, 0] == 1000 and seen[2, 1, 0] == 2000              # stepped by the INPUT length: no input sample is skipped
+    out = inference_hgtcrn.denoise(hg, np.stack([ramp, ramp]), False)
+    assert out.shape == (2500,) and np.array_equal(np.unique(out[:1000]), [1]) and np.array_equal(np.unique(out[1000:2000]), [2]) and (out != -1).all()
+    hg = Fake(1000, 648, 16000, 8000, channels=2)                                                      # 500 kept of (1000 + 296) / 2 per slice
+    hg.out_channels = 1
+    out = inference_hgtcrn.denoise(hg, np.stack([ramp, ramp]), False)
+    assert out.shape == (1250,) and np.array_equal(np.unique(out[500:1000]), [2]) and (out != -1).all()

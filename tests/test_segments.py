@@ -139,3 +139,49 @@ def test_gpu_priority_options_and_every_segments_clocks():
     assert (clocks[4:] == -1).all()                                        # no fifth segment at 63 frames
     ends = [clocks[seg, 9, 53] for seg in range(4)]
     assert ends == sorted(ends)                                            # a segment cannot finish before its predecessor (its overlap-add carry comes from it)
+
+
+def _forced_timeout_contract(sess, x, device_path=None):
+    """Option "xchg_withhold" makes block 0 raise its hand-off flags where nobody polls; its successor's bounded waits ("xwait_ms") must give up and the CALL must fail
+    with ADE_ERR_DEVICE naming the segment -- no PCM -- and the next call, hook off, must be clean and bit-equal to the whole-chunk geometry."""
+    from audio_denoiser_onnx_amd._lib import AdeDeviceError
+    ref = run(sess, x, "0")
+    sess.set_option("geometry", "2")
+    sess.set_option("xwait_ms", "2")
+    sess.set_option("xchg_withhold", "1")
+    out = np.full((x.shape[0], sess.row_out), 12345, np.int16)
+    with pytest.raises(AdeDeviceError, match=r"segment 1 of chunk 0 timed out .* depthwise-convolution history"):
+        sess.process_into(x, out)
+    assert (out == 12345).all(), "a failed call must not hand out PCM"
+    if device_path is not None:                      # the caller-stream entry cannot synchronise: the NEXT call on the handle reports it
+        d_in, d_out, stream = device_path(x)
+        sess.run_device(d_in, d_out, stream=stream)  # enqueued, returns ADE_OK
+        with pytest.raises(AdeDeviceError, match=r"earlier call on a caller-provided stream"):
+            sess.run_device(d_in, d_out)
+        with pytest.raises(AdeDeviceError, match=r"segment 1 of chunk 0"):      # engine-stream device entry: synchronises, reports at once
+            sess.run_device(d_in, d_out)
+    sess.set_option("xchg_withhold", "0")
+    sess.set_option("xwait_ms", "200")
+    assert sess.tap("xchg_error", 1)[0] == 0.0       # reported once, then cleared together with every flag
+    for rep in range(2):
+        assert_same(ref, run(sess, x, "2"), f"call {rep} after the forced time-out")
+
+
+@pytest.mark.hipsim
+def test_hipsim_withheld_flag_fails_the_call():
+    lib = hipsim_library()
+    ins = golden_inputs()
+    _forced_timeout_contract(make_session(lib, seed=0), np.stack([ins["wav0"]]))
+
+
+@pytest.mark.gpu
+def test_gpu_withheld_flag_fails_the_call_on_every_entry_point():
+    import torch
+    x = synth_batch(5)
+    sess = make_session(None, seed=0)
+
+    def device_path(x):
+        d_in = torch.from_numpy(x).cuda()
+        d_out = torch.zeros((x.shape[0], sess.row_out), dtype=torch.int16, device="cuda")
+        return d_in, d_out, torch.cuda.current_stream().cuda_stream
+    _forced_timeout_contract(sess, x, device_path)
