@@ -9,6 +9,10 @@ namespace dev {
 // sigmoid / tanh on the hardware exp and reciprocal units (v_exp_f32, v_rcp_f32: ~1 ulp each); the network's
 // gates only need ~1e-6 absolute accuracy (parity tolerance 1e-4 on the waveform, observed ~1e-6).
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_sqrt_f32 / v_rsq_f32 as they are (~1 ulp): sqrtf() and 1.0f / sqrtf() expand to the IEEE-correct sequences (scaling, two refinement FMAs, class checks: ~20 instructions
+// each), and so does a float division (~10).  None of their callers (magnitudes >= 1e-6, LayerNorm variances >= 1e-8, window sums ~1) needs the last bit or the range handling.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) {
     // 1 - 2/(e^{2x}+1): saturates cleanly to +-1 for large |x|
@@ -252,21 +256,38 @@ __device__ __forceinline__ void xflag_store(unsigned* p, unsigned v) { *(volatil
 __device__ __forceinline__ void xdrain() {}
 #endif
 // ONE lane polls ONE flag until it is raised, then lowers it again for the next launch (each flag has exactly one consumer; the kernel
-// boundary orders that store before the next launch's producer).  Bounded: err[1] holds the limit in 10 ns ticks (option "xwait_ms", default 0.2 s; read only
-// once the first poll has found the flag down).  The FIRST wait of a launch that gives up leaves `code` (xcode(): block index and flag index of the waiting segment) in err[0] and
-// lets the workgroup run on instead of hanging the device; it does NOT lower the flag.  The engine then fails the call with ADE_ERR_DEVICE -- no PCM is handed
-// out -- and clears every flag before the next launch (exchange_status() in ade_engine.hip).
+// boundary orders that store before the next launch's producer).  Bounded: `limit` 10 ns ticks (option "xwait_ms", default 0.2 s; a kernel argument -- the wait path
+// reads nothing but the flag and, once the flag is found down, that argument).  The FIRST wait of a launch that gives up leaves `code` (xcode(): block index and flag index of the waiting segment) in the
+// page-locked host word *err and lets the workgroup run on instead of hanging the device; it does NOT lower the flag.  The engine then fails the call with
+// ADE_ERR_DEVICE -- no PCM is handed out -- and clears every flag before the next launch (exchange_status() in ade_engine.hip).  A wait that has lasted a sixteenth
+// of the bound looks at *err once (a PCIe round trip; never in a healthy launch, whose waits last microseconds): when the launch has already failed it gives up at
+// once, so the failure of one hand-off costs its successors a fraction of the bound per wait, not the whole of it.
+// The bound of a wait (SegPlan::wait_ticks): the first word of the kernel-argument segment, fetched where it is needed (a scalar load) instead of living in a register.
+#if defined(__AMDGCN__)
+__device__ __forceinline__ int xlimit() {
+    const int ADE_CONSTANT_AS* p = (const int ADE_CONSTANT_AS*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));          // (opaque: the load stays at the wait, it is not hoisted to the top of the stage)
+    return *p;
+}
+#else
+__device__ __forceinline__ int xlimit() { return 20000000; }      // (host simulator: its clock advances 1000 ticks per read, so any bound ends within milliseconds)
+#endif
 __device__ __forceinline__ int xcode(int flag_index) { return (int)((blockIdx.x + 1u) << 4) | flag_index; }
 __device__ __forceinline__ void xwait(unsigned* flag, int* err, int code) {
     if (xflag_load(flag) == 0u) {
-        volatile int* const e = reinterpret_cast<volatile int*>(err);
         const long long t0 = wall_clock64();
-        const long long limit = (long long)e[1];
-        if (e[0] != 0) return;                             // the launch has already failed (the first code stays): nobody waits out another bound
+        const int limit = xlimit();
+        bool looked = false;
         do {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > limit) {
-                if (e[0] == 0) e[0] = code;
+            const long long dt = wall_clock64() - t0;
+            if (dt > (limit >> 4) && !looked) {
+                looked = true;
+                if (*reinterpret_cast<volatile int*>(err) != 0) return;
+            }
+            if (dt > limit) {
+                volatile int* const e = reinterpret_cast<volatile int*>(err);
+                if (*e == 0) *e = code;
                 return;
             }
         } while (xflag_load(flag) == 0u);

@@ -111,12 +111,13 @@ struct ade_engine {
     int wave_swap = 0;                    // option "wave_swap": odd segments run their conv lanes on wavefronts 0-3, 6, 7 (measured neutral to -1 %: off)
     int seg_prio = 0;                     // base wave priority of the workgroups by segment (option "seg_prio", 0-4: SegPlan::prio)
     int xwait_ticks = 20000000;           // bound of one inter-workgroup wait in 10 ns ticks (option "xwait_ms"; 0.2 s)
+    int full_taps = 0;                    // option "full_taps": the single-launch kernel stores every inter-stage tensor whole (ChunkCall::full_taps)
     int xchg_withhold = 0;                // test hook (option "xchg_withhold"): SegPlan::withhold
     int geometry = -1;                    // fused-path workgroup geometry (ade_internal.h): -1 = choose per call, 0 = 1024 threads x 64 frames, 1 = 512 x 32
     ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
     float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
     unsigned* d_xflags = nullptr;         // its flags (zero between launches)
-    int* d_xerr = nullptr;                // page-locked host words the kernels see: [0] the dev::xcode() of a bounded inter-workgroup wait that gave up, [1] the bound in ticks
+    int* d_xerr = nullptr;                // page-locked host word the kernels see: the dev::xcode() of the first bounded inter-workgroup wait that gave up
     int xchg_capacity = 0;                // chunks the exchange area holds
     int xchg_segments = 0;                // slots per chunk the exchange area was sized for
     bool use_graph = true;
@@ -494,7 +495,6 @@ ade_status ensure_exchange(ade_engine* e) {
         HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, 4 * sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
         e->d_xerr[0] = 0;
     }
-    e->d_xerr[1] = e->xwait_ticks;
     int nseg = 0;
     if (e->use_fused && !e->gt_sand) {
         const int g = pick_geometry(e, e->capacity);
@@ -643,9 +643,11 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
     if (fused) {
         // ---- fused path: one workgroup per chunk SEGMENT per stage (ade_internal.h: geometries), activations LDS-resident, inter-stage
         //      tensors channel-quad planar in HBM, TRA gates applied inside the stage (every tensor is plain).  1 launch, or 10.
-        SegPlan plan{fused_segments(T, geo), e->d_xchg, e->d_xflags, e->d_xerr, e->wave_swap};
+        SegPlan plan{};
+        plan.nseg = fused_segments(T, geo); plan.xchg = e->d_xchg; plan.flags = e->d_xflags; plan.err = e->d_xerr; plan.wave_swap = e->wave_swap;
         plan.prio = e->seg_prio;
         plan.withhold = e->xchg_withhold;
+        plan.wait_ticks = e->xwait_ticks;
         e->last_geometry = geo;
         long long* clk = prof ? e->d_clk : nullptr;
         if (clk) (void)hipMemsetAsync(e->d_clk, 0, kClkSlots * sizeof(long long), s);   // phase accumulators start from zero
@@ -662,6 +664,7 @@ void enqueue(ade_engine* e, hipStream_t s, const int16_t* d_in, int B, int16_t* 
             C.stagger = (geo == 0 && B >= 192) ? e->stagger_ticks : 0;
             C.pcm_in = d_in; C.pcm_out = d_out; C.f32_out = d_f32; C.L = e->in_len; C.T = T; C.B = B;
             C.plan = plan;
+            C.full_taps = e->full_taps;
             C.clk = (prof && e->profile_mode == 3) ? e->d_clk : nullptr;   // mode 3: the phase-clock build of the same kernel
             q.begin("gtcrn_chunk"); launch_gtcrn_chunk(s, geo, C); q.end();
             return;
@@ -897,6 +900,7 @@ void enqueue_stream(ade_stream* st, hipStream_t s, const int16_t* d_in, int16_t*
         SegPlan plan{};
         plan.nseg = fused_segments(T, geo);
         plan.xchg = st->xq; plan.flags = st->xq_flags; plan.err = st->xerr;
+        plan.wait_ticks = e->xwait_ticks;
         plan.carry_in = st->first ? nullptr : st->xstate[st->xcur];
         plan.carry_in_flags = st->first ? nullptr : st->xstate_flags[st->xcur];
         plan.carry_out = st->xstate[st->xcur ^ 1];
@@ -1312,10 +1316,13 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         const double ms = strtod(value, &end);
         if (!value[0] || *end || !(ms >= 0.001) || ms > 20000.0) return fail(h, ADE_ERR_BAD_VALUE, "option xwait_ms: 0.001..20000");
         h->xwait_ticks = (int)(ms * 1e5 + 0.5);
-        if (h->d_xerr) {
-            if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
-            h->d_xerr[1] = h->xwait_ticks;
-        }
+        free_graphs(h);
+        return ADE_OK;
+    }
+    if (strcmp(key, "full_taps") == 0) {       // debugging: x_d0 / x_d1 / dp2 complete in device memory after a single-launch call (their channels 0-7 otherwise never leave LDS)
+        bool b;
+        if (!parse_bool(value, &b)) return fail(h, ADE_ERR_BAD_VALUE, "option full_taps must be 0/1");
+        h->full_taps = b;
         return ADE_OK;
     }
     if (strcmp(key, "xchg_withhold") == 0) {   // TEST HOOK: the first workgroup of the next fused launches raises its hand-off flags where nobody looks (SegPlan::withhold)
@@ -1806,7 +1813,6 @@ ade_status ade_stream_create(ade_handle h, int n_streams, int frames_per_push, a
                 hipHostMalloc((void**)&st->xerr, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
                 return bail("ade_stream_create: allocation of the fused-push state failed");
             st->xerr[0] = 0;
-            st->xerr[1] = h->xwait_ticks;
             st->fused = true; st->geo = geo; st->geo_flush = geo1;
         }
     }

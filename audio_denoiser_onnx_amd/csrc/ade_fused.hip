@@ -103,8 +103,9 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_back(SegPlan 
     back_stage<G>(reinterpret_cast<float*>(smem), chunk, sg, x, e1, e0, spec, c3, c4, bs, tabs, pcm, f32, seg_clk(clk, sg, B, blockIdx.x));
 }
 
-// kClk = false is the shipped kernel (no phase-clock code at all); kClk = true is the same kernel with thread 0 of each segment's first
-// workgroup stamping phase clocks into C.clk, 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back], one such set per segment.
+// kClk = false is the shipped kernel (no phase-clock code at all); kClk = true is the DEBUG build of the same kernel: thread 0 of each segment's first
+// workgroup stamps phase clocks into C.clk (when given), 64 slots per stage: [front | enc 0-2 | dp 0-1 | dec 0-2 | back], one such set per segment, and every
+// inter-stage tensor is stored whole (option "full_taps": the shipped kernel keeps channels 0-7 of x_d0 / x_d1 / dp2 in LDS -- store_lo in ade_stage_net.h).
 // The per-engine arguments (weights, workspace) are read from device memory stage by stage: ChunkFixed in ade_internal.h.
 template <class G, bool kClk>
 __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(ChunkCall C_) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         ADE_STAGE_ENTRY();
         const GtConvW w = cload<GtConvW>(&F->en_gt[i]);
         const float* const x = i == 0 ? F->e1 : F->xe[i > 0 ? i - 1 : 0];
-        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, F->xe[i], kClk ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
+        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, F->xe[i], (kClk && clk0) ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
         __syncthreads();
     }
 #pragma unroll 1
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         ADE_STAGE_ENTRY();
         const DpW w = cload<DpW>(&F->dp[i]);
         const float* const x = i == 0 ? F->xe[2] : F->dpo[0];
-        dpgrnn_stage<G>(smem, chunk, sg, i, x, w, F->dpo[i], kClk ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2]);
+        dpgrnn_stage<G>(smem, chunk, sg, i, x, w, F->dpo[i], (kClk && clk0) ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2],
+                        /*store_lo=*/i == 0 || kClk);
         __syncthreads();
     }
 #pragma unroll 1
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         ADE_STAGE_ENTRY();
         const GtConvW w = cload<GtConvW>(&F->de_gt[i]);
         const float* const x = i == 0 ? F->dpo[1] : F->xd[i > 0 ? i - 1 : 0];
-        gtblock_stage<G>(smem, chunk, sg, 3 + i, x, F->xe[2 - i], w, F->xd[i], kClk ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
-                         /*next_skip=*/i < 2 ? F->xe[1 - i] : nullptr);
+        gtblock_stage<G>(smem, chunk, sg, 3 + i, x, F->xe[2 - i], w, F->xd[i], (kClk && clk0) ? clk0 + 64 * (6 + i) : nullptr, /*x1_in_lds=*/true, /*next_x1=*/i < 2,
+                         /*next_skip=*/i < 2 ? F->xe[1 - i] : nullptr, /*store_lo=*/i == 2 || kClk);
         __syncthreads();
     }
     {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         const FftTabs tabs = cload<FftTabs>(&F->tabs);
         const BandTab erb = cload<BandTab>(&F->erb_bs);
         const ConvW c3 = cload<ConvW>(&F->de3), c4 = cload<ConvW>(&F->de4);
-        back_stage<G>(fsm, chunk, sg, F->xd[2], F->e1, F->e0, F->spec, c3, c4, erb, tabs, C->pcm_out, C->f32_out, kClk ? clk0 + 64 * 9 : nullptr);
+        back_stage<G>(fsm, chunk, sg, F->xd[2], F->e1, F->e0, F->spec, c3, c4, erb, tabs, C->pcm_out, C->f32_out, (kClk && clk0) ? clk0 + 64 * 9 : nullptr);
     }
 #undef ADE_STAGE_ENTRY
 }
@@ -238,13 +240,13 @@ void launch_back(hipStream_t s, int geometry, SegPlan plan, const float* x, cons
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call) {
     const int grid = call.B * call.plan.nseg;
     if (geometry == 2) {
-        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo2, true>), dim3(grid), dim3(Geo2::kThreads), chunk_smem_bytes<Geo2>(), s, call);
+        if (call.clk || call.full_taps) hipLaunchKernelGGL((k_gtcrn_chunk<Geo2, true>), dim3(grid), dim3(Geo2::kThreads), chunk_smem_bytes<Geo2>(), s, call);
         else hipLaunchKernelGGL((k_gtcrn_chunk<Geo2, false>), dim3(grid), dim3(Geo2::kThreads), chunk_smem_bytes<Geo2>(), s, call);
     } else if (geometry == 1) {
-        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, true>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
+        if (call.clk || call.full_taps) hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, true>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
         else hipLaunchKernelGGL((k_gtcrn_chunk<Geo1, false>), dim3(grid), dim3(Geo1::kThreads), chunk_smem_bytes<Geo1>(), s, call);
     } else {
-        if (call.clk) hipLaunchKernelGGL((k_gtcrn_chunk<Geo0, true>), dim3(grid), dim3(Geo0::kThreads), chunk_smem_bytes<Geo0>(), s, call);
+        if (call.clk || call.full_taps) hipLaunchKernelGGL((k_gtcrn_chunk<Geo0, true>), dim3(grid), dim3(Geo0::kThreads), chunk_smem_bytes<Geo0>(), s, call);
         else hipLaunchKernelGGL((k_gtcrn_chunk<Geo0, false>), dim3(grid), dim3(Geo0::kThreads), chunk_smem_bytes<Geo0>(), s, call);
     }
 }

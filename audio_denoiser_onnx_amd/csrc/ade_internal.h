@@ -152,10 +152,13 @@ constexpr int kXFlagHist = 0, kXFlagTra = 6, kXFlagInter = 12, kXFlagOla = 14;
 constexpr int kMaxSegments = 8;
 constexpr int kClkSlotsPerSeg = 64 * 10;
 struct SegPlan {           // how a launch splits its chunks (host-computed, passed by value)
+    int wait_ticks;        // bound of one inter-workgroup wait in 10 ns ticks (option "xwait_ms").  MUST stay the first word of the first kernel argument of every kernel that
+                           // can wait (k_front .. k_back take a SegPlan first, k_gtcrn_chunk a ChunkCall that begins with its SegPlan): dev::xlimit() reads it from offset 0 of
+                           // the kernel-argument segment at the moment of a wait, so that no register holds it across a stage.
     int nseg;              // segments per chunk (1: the whole chunk in one workgroup)
     float* xchg;           // [B][nseg][kXFloats]
     unsigned* flags;       // [B][nseg][kXFlags], zero between launches
-    int* err;              // page-locked host words: [0] sticky, the dev::xcode() of a bounded wait that gave up; [1] the bound in 10 ns ticks
+    int* err;              // page-locked host word, sticky: the dev::xcode() of the first bounded wait that gave up
     int wave_swap;         // 1: odd segments run their conv lanes on wavefronts 0-3, 6, 7 instead of 0-5 (see gtblock_stage)
     // STREAMS (ade_stream_*): a push is a chunk whose first segment continues the state its last segment left one launch earlier -- the same exchange slots, one per
     // stream, ping-ponged between pushes -- framed without centre padding and emitted one hop behind (include/ade.h).
@@ -206,6 +209,7 @@ struct ChunkFixed {
     float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3];
 };
 struct ChunkCall {           // per call, by value
+    SegPlan plan;            // (first: see SegPlan::wait_ticks)
     const ChunkFixed* fixed;
     const int16_t* pcm_in;
     int16_t* pcm_out;
@@ -213,9 +217,10 @@ struct ChunkCall {           // per call, by value
     const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
     long long* clk;          // optional phase clocks, kClkSlotsPerSeg per segment
     int L, T, B;
+    int full_taps;           // 1: launch the debug build, which stores every inter-stage tensor whole (option "full_taps", for ade_debug_tap); 0: the three tensors whose
+                             // channels 0-7 only the following block reads -- through LDS -- keep those planes out of HBM (x_d0, x_d1, dp2).  Read by the launcher only.
     int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all
                              // hit HBM with the same stage's burst at the same instant; ade_set_option "stagger_us")
-    SegPlan plan;
 };
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call);
 

@@ -81,7 +81,7 @@ __device__ __forceinline__ void erb_merge(const float* wtab, int count, int s0, 
     for (int n = 0; n < count; ++n) {
         const float wv = wtab[n * kErbBands + lane];
         const float2 x = buf[kErbLow + min(s0 + n, kErbHigh - 1)];
-        a0 += sqrtf((x.x * x.x + x.y * x.y) + 1e-12f) * wv;
+        a0 += fast_sqrt((x.x * x.x + x.y * x.y) + 1e-12f) * wv;
         a1 += x.x * wv;
         a2 += x.y * wv;
     }
@@ -236,7 +236,7 @@ __device__ __forceinline__ void front_stage(float* smem, int chunk, const Seg& s
                     specc[((size_t)t * 2 + 0) * kBinsPad + k] = x.x;
                     specc[((size_t)t * 2 + 1) * kBinsPad + k] = x.y;
                     if (k < kErbLow) {
-                        fr[k] = sqrtf((x.x * x.x + x.y * x.y) + 1e-12f);          // Export_GTCRN.py:594-595
+                        fr[k] = fast_sqrt((x.x * x.x + x.y * x.y) + 1e-12f);      // Export_GTCRN.py:594-595
                         fr[kErb + k] = x.x;
                         fr[2 * kErb + k] = x.y;
                     }
@@ -515,7 +515,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
         // spectrum of this wavefront's frame: issued now, consumed in the irFFT phase three barriers later
         float sre[5], sim[5];
         float wsr[4] = {1.0f, 1.0f, 1.0f, 1.0f};     // lean: this lane's four win_sum values of the finalize step (nf * 64 float4 slots <= one per lane), requested with the spectrum
-        if (kLean) ld4(wsum + ((tid * 4) & (kHop - 1)), wsr);
+        if (kLean) ld4(wsum + ((tid * 4) & (kHop - 1)), wsr);      // (turned into reciprocals where they are used: the division below is a multiplication)
         {
             int tq = tid;
             ADE_OPAQUE_V(tq);
@@ -767,7 +767,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             if (kLean) { ws[0] = wsr[0]; ws[1] = wsr[1]; ws[2] = wsr[2]; ws[3] = wsr[3]; }       // (i = 4 tid there: one round)
             else ld4(wsum + (i & (kHop - 1)), ws);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = v[u] / ws[u];
+            for (int u = 0; u < 4; ++u) v[u] = v[u] * fast_rcp(ws[u]);                            // (STFT_Process.py:330: / sum(w^2); the sum is within [0.99, 1.01])
             if (fo32) st4(fo32 + n, v);
             if (po) {
                 short q[4];
@@ -804,7 +804,7 @@ __device__ __forceinline__ void back_stage(float* smem, int chunk, const Seg& sg
             ld4(pend + i, v);
             ld4(wsum + i, ws);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (xld1(sg.xi + kXOlaOff + i + u) + v[u]) / ws[u];
+            for (int u = 0; u < 4; ++u) v[u] = (xld1(sg.xi + kXOlaOff + i + u) + v[u]) * fast_rcp(ws[u]);
             if (fo32) st4(fo32 + n, v);
             if (po) {
                 short q[4];

@@ -79,6 +79,8 @@ template <class G> constexpr size_t gt_smem_bytes() { return (size_t)4 * G::kPma
 
 // x1_in_lds : the previous stage of the same launch already left this block's pointwise input (a+skip)[:, :8] in LDS planes 2-3.
 // next_x1   : leave the NEXT GTConvBlock's pointwise input there (out[:, :8] + next_skip[:, :8]); next_skip may be null.
+// store_lo  : false = planes 0-1 (channels 0-7) of `out` are not written to HBM: their only reader is the next block, which gets them through LDS (next_x1),
+//             and no later stage takes this tensor as a skip (decoder blocks 0 and 1, DPGRNN 1).  Option "full_taps" stores them anyway for ade_debug_tap.
 // sg / blk  : this workgroup's segment of the chunk and the block's index (0-2 encoder, 3-5 decoder) in the exchange area.  The segment's
 //             frames are LDS-local 0 .. sg.nT-1; the HBM tensors are addressed through bases shifted to the segment's first frame and the
 //             chunk's plane stride Ps.  A segment with a successor hands on (a) the depthwise convolution's history as PARTIAL SUMS: the
@@ -88,7 +90,7 @@ template <class G> constexpr size_t gt_smem_bytes() { return (size_t)4 * G::kPma
 template <class G>
 __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ a, const float* __restrict__ skip,
                                               const GtConvW& w, float* __restrict__ out, long long* __restrict__ clk,
-                                              bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr) {
+                                              bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr, bool store_lo = true) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* H = smem;
     float* zt = reinterpret_cast<float*>(smem + 4 * kPmax);
@@ -379,7 +381,7 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
                 e[c] += row_ror<4>(e[c]);
                 e[c] += row_ror<2>(e[c]);
                 e[c] += row_ror<1>(e[c]);
-                e[c] = e[c] / (float)kFw;
+                e[c] = e[c] * (1.0f / (float)kFw);
             }
             const float* pk = w.gru + j * 78;
 #pragma unroll
@@ -509,7 +511,12 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
         if (p < P) {
             const float4 b0 = H[p], b1 = H[kPmax + p], g0 = H[2 * kPmax + p], g1 = H[3 * kPmax + p];
             const float o[16] = {g0.x, b0.x, g0.y, b0.y, g0.z, b0.z, g0.w, b0.w, g1.x, b1.x, g1.y, b1.y, g1.z, b1.z, g1.w, b1.w};
-            pl_st16(oc, Ps, p, o);
+            if (store_lo) {
+                pl_st16(oc, Ps, p, o);
+            } else {
+                st4(oc + ((size_t)2 * Ps + p) * 4, o + 8);
+                st4(oc + ((size_t)3 * Ps + p) * 4, o + 12);
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) n8[i][k] = o[k] + nsk[i][k];
         }
@@ -592,12 +599,12 @@ __device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ 
     float s = e;
 #pragma unroll
     for (int c = 0; c < 16; ++c) s += v0[c] + v1[c];
-    const float mean = allreduce(s) / (float)(kFw * kCh);
+    const float mean = allreduce(s) * (1.0f / (float)(kFw * kCh));
     const float de = e - mean;
     float q2 = de * de;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { const float a = v0[c] - mean, b = v1[c] - mean; q2 += a * a + b * b; }
-    const float rstd = 1.0f / sqrtf(allreduce(q2) / (float)(kFw * kCh) + 1e-8f);
+    const float rstd = fast_rsq(allreduce(q2) * (1.0f / (float)(kFw * kCh)) + 1e-8f);
     {
         float gw[16], gb[16], rs[16];
         ld16(ln_w + j * kCh, gw);
@@ -628,7 +635,7 @@ __device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ 
 template <class G>
 __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ x, const DpW& w, float* __restrict__ out,
                                              long long* __restrict__ clk, bool next_x1 = false,
-                                             const float* __restrict__ next_skip = nullptr) {
+                                             const float* __restrict__ next_skip = nullptr, bool store_lo = true) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
@@ -808,7 +815,12 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         // (the residual is mid, written by this same lane in phase B: L2-resident)
         fc_ln_rows<G>(R, w.inter_fc, w.inter_fc_b, lnt, lnt + kFw * kCh, T, P, tid, oc, Ps,
             [&](int p, const float (&o)[16]) {
-                pl_st16(oc, Ps, p, o);
+                if (store_lo) {
+                    pl_st16(oc, Ps, p, o);
+                } else {          // (see gtblock_stage: the following block gets channels 0-7 through LDS)
+                    st4(oc + ((size_t)2 * Ps + p) * 4, o + 8);
+                    st4(oc + ((size_t)3 * Ps + p) * 4, o + 12);
+                }
                 if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (the frame's row is done with them)
                     float k8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     if (nsc) pl_ld8(nsc, Ps, p, 0, k8);
@@ -817,7 +829,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
                 }
             },
             [&](int p, int c, float o) {
-                oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = o;
+                if (store_lo || c >= 8) oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = o;
                 if (next_x1 && c < 8) {
                     const float k = nsc ? nsc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] : 0.0f;
                     Rf[((size_t)(2 + (c >> 2)) * kPmax + p) * 4 + (c & 3)] = o + k;

@@ -82,6 +82,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = the workload's BASELINE batch: 256 / 128 / 32 / 64)")
     ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-inclusive leg (pinned host buffers through ade_process; 0 = skip)")
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank runs its own --batch chunks; strong: ONE batch of --batch chunks (default: the workload's BASELINE batch) is dealt over the "
+                         "ranks in contiguous blocks of ceil(B / N), the way the file drivers shard a file's slices (distributed.shard_bounds; trailing ranks may be idle)")
+    ap.add_argument("--other-cpu-seconds", type=float, default=60.0, help="budget of the CPU-oracle legs of the `other_workloads` block (0 = skip them)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1", "2"],
@@ -104,8 +108,24 @@ def source_sha1() -> str:
     return h.hexdigest()
 
 
-def other_workload_line(name: str, steps: int, local_rank: int, stream):
-    """A short timed run of another BASELINE config inside the default invocation, so that the driver's own clock covers it too (VERDICT r02 #2)."""
+def workload_traffic(name: str, dtype: str, B: int, default_B: int):
+    """Fabric-side bytes of one step of a GEMM-family workload from the committed FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload <name>` (tools/pmc_traffic_workload.sh);
+    the newest round's file wins.  -> (bytes per step scaled to B rows, note) or (None, None)."""
+    for rnd in ("r04", "r03", "r02"):
+        try:
+            with open(os.path.join(REPO, "profiles", f"{rnd}_{name}_{dtype}_traffic.json")) as f:
+                tp = json.load(f)
+            return int(tp["bytes_per_step"] * B / default_B), (f"profiles/{rnd}_{name}_{dtype}_traffic.json: bytes per step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over every kernel "
+                                                                "of a step, separate rocprofv3 --pmc passes; fabric-side incl. Infinity-Cache hits")
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def other_workload_line(name: str, steps: int, local_rank: int, stream, cpu_budget_s: float = 0.0):
+    """A short timed run of another BASELINE config inside the default invocation, so that the driver's own clock covers it too: `steps` (>= 3) individually timed steps after
+    one warm-up step (mean in ms_per_step, spread in ms_min / ms_max), the whole-step roofline with the committed traffic figure, and the workload's CPU-oracle baseline on a
+    bounded sample."""
     import torch
     wl = build_workload(name, 0, 0, local_rank, "f32")
     sess, B, x = wl["sess"], wl["B"], wl["x"]
@@ -114,19 +134,30 @@ def other_workload_line(name: str, steps: int, local_rank: int, stream):
     d_out = torch.empty((B, sess.row_out), dtype=torch.int16, device="cuda")
     sess.run_device(d_in, d_out, stream=stream)            # warm-up (graph capture, clocks)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         sess.run_device(d_in, d_out, stream=stream)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / steps
     audio = B * sess.out_len / wl["sr"]
     tf = wl["flop"] * B / dt / 1e12
-    line = {"workload": wl["workload"], "steps": steps, "warmup": 1, "ms_per_step": round(dt * 1e3, 3), "value": round(audio / dt, 1), "unit": "audio-s/s",
+    traffic, note = workload_traffic(name, "f32", B, B)
+    line = {"workload": wl["workload"], "steps": steps, "warmup": 1, "ms_per_step": round(dt * 1e3, 3), "ms_min": round(min(times) * 1e3, 3), "ms_max": round(max(times) * 1e3, 3),
+            "value": round(audio / dt, 1), "unit": "audio-s/s",
             "rtf": float(f"{dt / audio:.3e}"), "dtype": "f32", "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                                             "frac": round(tf / FP32_PEAK_TFLOPS, 4)}}
+                                                                             "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": note,
+                                                                             "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}}
     if wl.get("target_rtf"):
         line["target_rtf"] = wl["target_rtf"]
-    del sess
+    del sess, d_in, d_out
+    torch.cuda.empty_cache()
+    if cpu_budget_s > 0 and wl.get("cpu") is not None:
+        try:
+            line["cpu_baseline"] = wl["cpu"]()
+        except Exception as ex:   # a baseline leg must not take the line down
+            line["cpu_baseline"] = {"error": repr(ex)}
     return line
 
 
@@ -212,7 +243,17 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         deviation = deviation_from_f32(lambda dt: InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=dt), device_id=local_rank), x, 1) if dtype != "f32" else None
         sess = InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=dtype), device_id=local_rank)
         del blob
-        return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=None, deviation=deviation,
+
+        def cpu():          # bounded sample: the same depth-6 network on ONE 1 s stereo clip (101 frames instead of 801; the oracle's cost is linear in frames except for the time attention)
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            from melband_oracle import MelBandOracle
+            from audio_denoiser_onnx_amd import mel_bands
+            Ls = 44100
+            wts = weightgen.materialise(melband.synthetic_spec(depth))
+            freq_indices, dim_inputs = mel_bands.band_tables()[:2]
+            return cpu_baseline_numpy(lambda: MelBandOracle(wts, freq_indices, dim_inputs, Ls // 441 + 1, depth), synth_stereo(0, Ls, 44100), 1.0,
+                                      "one 1 s stereo clip, 101 frames x 60 bands, depth 6 -- a shorter clip than the 8 s workload rows")
+        return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=cpu, deviation=deviation,
                     metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
                     workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), fp32 matrix cores, int16 PCM resident in HBM "
                              "(BASELINE.json configs[3]; bf16 there, fp32 here)",
@@ -229,7 +270,17 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         deviation = deviation_from_f32(lambda dt: InferenceSession(weights=blob, metadata=mossformer.metadata(L, gemm_dtype=dt), device_id=local_rank), x, 1) if dtype != "f32" else None
         sess = InferenceSession(weights=blob, metadata=mossformer.metadata(L, gemm_dtype=dtype), device_id=local_rank)
         del blob
-        return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=None, deviation=deviation,
+
+        def cpu():          # bounded sample: the same 24-layer network on ONE 1 s window (1999 frames instead of 7999)
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            from mossformer_oracle import MossFormerOracle
+            Ls = 16000
+            fr = mossformer.frames_of(Ls)
+            tensors = {n: mossformer.synthetic_tensor(n, sh, sc, fr) for n, sh, sc in mossformer.synthetic_spec(layers)}
+            tensors.update(mossformer.position_tables(fr, int(scalars["rot_dim"])))
+            xs = (synth_chunk(0, Ls).astype(np.int32) + synth_chunk(10000, Ls)).clip(-32768, 32767).astype(np.int16)[None]
+            return cpu_baseline_numpy(lambda: MossFormerOracle(tensors, scalars, layers, Ls), xs, 1.0, "one 1 s window, 1999 frames, 24 layers -- a shorter window than the 4 s workload rows")
+        return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=cpu, deviation=deviation,
                     metric="audio_seconds_per_second (MossFormer2-SS-16K, batch=64 x 4 s; RTF = 1/value)",
                     workload="MossFormer2-SS-16K two-speaker separation, 24 layers, batch=64 x 4 s (7999 frames), fp32 matrix cores, int16 PCM resident in HBM "
                              "(BASELINE.json configs[4])",
@@ -256,24 +307,31 @@ def main():
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
-    from audio_denoiser_onnx_amd.distributed import stitch_device
+    from audio_denoiser_onnx_amd.distributed import shard_bounds, stitch_device
     from audio_denoiser_onnx_amd.metadata import build_audio_metadata
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_batch
 
     gtcrn = args.workload == "gtcrn"
+    strong = args.scaling == "strong"
     if gtcrn:
         with open(os.path.join(REPO, "tests", "golden", "gtcrn_seed0.adew"), "rb") as f:
             blob = f.read()
         meta = build_audio_metadata(producer="bench.py", model_name="GTCRN", task="denoise", model_family="gtcrn",
                                     input_audio_length=CHUNK)
         sess = InferenceSession(weights=blob, metadata=meta, device_id=local_rank)
-        B = args.batch or 256
-        x_host = synth_batch(B, CHUNK, first_index=rank * B)
+        B_total = args.batch or 256
+        lo, hi = shard_bounds(B_total, world, rank) if strong else (rank * B_total, (rank + 1) * B_total)
+        B = hi - lo
+        x_host = synth_batch(B, CHUNK, first_index=lo)
         sr, wl = SR, None
     else:
-        wl = build_workload(args.workload, args.batch, rank, local_rank, args.dtype)
-        sess, B, x_host, sr = wl["sess"], wl["B"], wl["x"], wl["sr"]
+        default_B = {"zipenhancer": 128, "melband": 32, "mossformer": 64}[args.workload]
+        B_total = args.batch or default_B
+        lo, hi = shard_bounds(B_total, world, rank) if strong else (rank * B_total, (rank + 1) * B_total)
+        B = hi - lo
+        wl = build_workload(args.workload, max(B, 1), rank, local_rank, args.dtype)      # (an idle rank of a strong-scaling run still opens its session)
+        sess, x_host, sr = wl["sess"], wl["x"][:B], wl["sr"]
         if args.steps == 100 and args.warmup == 10:      # the defaults are sized for GTCRN's 0.4 ms steps; these steps take 0.2 - 1.2 s
             args.steps, args.warmup = 5, 1
         args.ramp_ms = 0.0
@@ -281,10 +339,12 @@ def main():
         sess.set_option("graph", "0")
     if gtcrn and args.geometry != "auto":
         sess.set_option("geometry", args.geometry)
-    sess.reserve(B)
+    sess.reserve(max(B, 1))
     d_in = torch.from_numpy(x_host).cuda()
-    d_out = torch.empty((B, sess.row_out), dtype=torch.int16, device="cuda")
-    gathered = torch.empty((world * B, sess.row_out), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
+    per = (B_total + world - 1) // world if strong else B             # rows of a rank's (zero-padded) gather block
+    d_block = torch.zeros((per, sess.row_out), dtype=torch.int16, device="cuda")
+    d_out = d_block[:B]
+    gathered = torch.empty((world * per, sess.row_out), dtype=torch.int16, device="cuda") if (args.stitch and distributed) else None
     # A real (non-null) stream: ade_process_device treats a NULL stream handle as "run synchronously", which would put a
     # host round trip between consecutive steps.  Steps are enqueued back to back; the timed region is still bracketed
     # by barrier + torch.cuda.synchronize() on both sides.
@@ -293,9 +353,10 @@ def main():
     stream = launch_stream.cuda_stream
 
     def step():
-        sess.run_device(d_in, d_out, stream=stream)
+        if B > 0:
+            sess.run_device(d_in, d_out, stream=stream)
         if gathered is not None:
-            stitch_device(d_out, gathered)
+            stitch_device(d_block, gathered)
 
     # Power-state ramp (untimed, disclosed in config.clock_ramp_ms): after process start the GPU needs tens of milliseconds of work before its
     # clocks settle, far more than W = 10 steps of 0.4 ms; without it the first timed steps run at a lower clock and the result depends on
@@ -328,7 +389,7 @@ def main():
     if gtcrn and sess.tap("xchg_error", 1)[0] != 0.0:      # a segment hand-off of the fused path timed out inside the timed loop: the steps after it are not a measurement
         raise SystemExit("bench.py: the fused path reported an inter-workgroup time-out (xchg_error) during the timed loop; no number is reported")
     out_seconds_per_row = sess.out_len / sr
-    audio_s_per_step = world * B * out_seconds_per_row
+    audio_s_per_step = (B_total if strong else world * B) * out_seconds_per_row
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     value = audio_s_per_step * args.steps / elapsed
 
@@ -418,11 +479,11 @@ def main():
             # ZipEnhancer (the second north-star target) with the full step count; the two one-second-per-step transformer configs with ONE timed step
             # each after their warm-up step, so that the driver's clock covers every BASELINE config and the default invocation still ends within minutes.
             others = {}
-            for name, steps in (("zipenhancer", args.other_steps), ("melband", 1), ("mossformer", 1)):
+            for name, steps in (("zipenhancer", max(3, args.other_steps)), ("melband", 3), ("mossformer", 3)):
                 if name not in args.other.split(","):
                     continue
                 try:
-                    others[name] = other_workload_line(name, steps, local_rank, stream)
+                    others[name] = other_workload_line(name, steps, local_rank, stream, args.other_cpu_seconds)
                 except Exception as ex:   # the headline must not depend on it
                     others[name] = {"error": repr(ex)}
     elif rank == 0:
@@ -435,20 +496,16 @@ def main():
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "peak_note": "dense f32-MFMA rate (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s; flops = 2 x MACs of the model's matrix products per row x rows",
                     "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}
-        for cand in (f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json",):
+        for cand in (f"r04_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json"):
+            if "mfma_busy" in roofline:
+                break
             try:
                 with open(os.path.join(REPO, "profiles", cand)) as f:
                     roofline["mfma_busy"] = json.load(f)
                     roofline["evidence"] = "profiles/" + cand
             except (OSError, ValueError):
                 pass
-        try:                # fabric-side bytes of one step from the committed FETCH_SIZE / WRITE_SIZE passes of this command (tools/pmc_traffic_workload.sh)
-            with open(os.path.join(REPO, "profiles", f"r02_{args.workload}_{args.dtype}_traffic.json")) as f:
-                tp = json.load(f)
-            roofline["traffic"] = int(tp["bytes_per_step"] * B / (wl["B"] if args.batch == 0 else B))
-            roofline["traffic_note"] = "bytes per step = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over every kernel of a step, separate rocprofv3 --pmc passes; fabric-side incl. Infinity-Cache hits"
-        except (OSError, KeyError, ValueError):
-            pass
+        roofline["traffic"], roofline["traffic_note"] = workload_traffic(args.workload, args.dtype, B, default_B)
         if world == 1 and args.cpu_seconds > 0 and wl["cpu"] is not None:
             cpu = wl["cpu"]()
 
@@ -464,18 +521,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype if not gtcrn else "f32",
             "data": "synthetic",
             "config": {"workload": ("GTCRN 16 kHz, batch=256 x 1 s chunks, fp32, int16 PCM in/out resident in HBM "
                                     "(BASELINE.json configs[1])") if gtcrn else wl["workload"],
-                       "chunks_per_gpu": B, "chunk_samples": sess.in_len, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
+                       "chunks_per_gpu": B, "chunks_total": B_total if strong else world * B, "ranks": world, "chunk_samples": sess.in_len, "out_samples": sess.out_len, "clock_ramp_ms": args.ramp_ms,
                        "weights": "seeded reference-architecture GTCRN (tests/golden/gtcrn_seed0.adew)" if gtcrn else wl["weights"],
                        "launch": (f"one kernel per step (k_gtcrn_chunk, geometry {int(geo[0])}: {int(geo[1])} workgroup(s) of {(1024, 512, 256)[int(geo[0])]} threads "
                                   "per chunk), plain launch") if gtcrn
                                  else "the sub-engine's launch sequence (replayed from a captured hipGraph unless --no-graph)",
-                       "stitch_all_gather": bool(gathered is not None)},
+                       "stitch_all_gather": bool(gathered is not None),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if distributed else None)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "host_inclusive": host_inclusive,

@@ -109,7 +109,14 @@ ade_status ade_reserve(ade_handle h, int batch);
 /* Options: "graph" = "0"/"1" replay the launch sequence from a captured hipGraph (default 1); "fused" / "single_launch" = "0"/"1" GTCRN's per-chunk LDS-resident path,
  * as one launch; "geometry" = "auto"/"0"/"1"/"2" its workgroup geometry (0: one 1024-thread workgroup per chunk; 1: 512-thread workgroups that each own a run of at most 32
  * frames, two per CU; 2: 256-thread workgroups of at most 16 frames, four per CU -- the default where the frame count allows; identical bits in all three);
- * "stagger_us" (geometry 0), "seg_prio" = "0".."4" (base wave priority by segment; the recurrences always run at priority 3), "wave_swap": measurement knobs, see DESIGN.md. */
+ * "stagger_us" (geometry 0), "seg_prio" = "0".."4" (base wave priority by segment; the recurrences always run at priority 3), "wave_swap": measurement knobs, see DESIGN.md.
+ * "xwait_ms" = bound of one inter-workgroup wait of the segmented fused path in milliseconds (default 200).  When a wait gives up, the CALL fails with ADE_ERR_DEVICE
+ * (message: chunk, segment and the hand-off that did not arrive), no PCM is handed out, every hand-off flag is cleared and the next call starts clean; a launch on a
+ * caller-provided stream is not synchronised by the engine, so its failure is reported by the NEXT call on the handle (or by the debug tap "xchg_error").
+ * "full_taps" = "0"/"1": 1 launches the debug build of the single-launch kernel, which stores every inter-stage tensor whole (the shipped kernel keeps channels 0-7 of
+ * x_d0 / x_d1 / dp2 in LDS -- their only reader is the next block); set it before a call whose ade_debug_tap results are compared channel by channel.
+ * "host_split" = "0".."8": sub-batches ade_process cuts a batch into so that the copies of one overlap the kernel of another (0 = decide per call; see ade_process).
+ * "xchg_withhold" = "0"/"1": TEST HOOK, makes the first workgroup of the next launches raise its hand-off flags where nobody polls (forces the time-out path). */
 ade_status ade_set_option(ade_handle h, const char* key, const char* value);
 
 /* Parity taps: copy a named intermediate of the LAST processed batch to host (engine-native layout, see

@@ -183,6 +183,8 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline unsigned __float_as_uint(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values here
 static inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
+static inline float __builtin_amdgcn_sqrtf(float a) { return sqrtf(a); }
+static inline float __builtin_amdgcn_rsqf(float a) { return 1.0f / sqrtf(a); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
     const float lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);

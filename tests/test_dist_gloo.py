@@ -65,6 +65,51 @@ def test_world_size_2_gloo_shard_and_stitch(tmp_path):
     assert all("ok" in o for o in outs)
 
 
+def test_world_size_4_gloo_idle_ranks_and_uneven_last_block(tmp_path):
+    """World 4 on the real engine (host simulator): a file of 2 slices (fewer rows than ranks: ranks 2 and 3 are idle replicas that still take part in the all-gather) and a
+    file of 5 slices (blocks of ceil(5 / 4) = 2: 2 + 2 + 1 + 0 -- an uneven last block AND an idle rank), both through sharded_run's padded gather blocks, bit-equal to one
+    process.  Short slices (4096 samples, 17 frames) keep the simulator's cost down."""
+    script = tmp_path / "worker4.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {REPO!r}); sys.path.insert(0, {HERE!r})
+        import numpy as np, torch.distributed as dist
+        from ade_testlib import hipsim_library, make_session
+        from audio_denoiser_onnx_amd.distributed import shard_bounds
+        from audio_denoiser_onnx_amd.inference_gtcrn import denoise, plan_slices
+        from audio_denoiser_onnx_amd.synth import synth_chunk
+
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        assert world == 4
+        sess = make_session(hipsim_library(), seed=1, length=4096)                       # 4096 in -> 4096 out (16 hops)
+        for n_slices in (2, 5):
+            n = (n_slices - 1) * sess.out_len + sess.in_len - 100                        # the last slice is partly padding
+            assert plan_slices(n, sess.in_len, sess.out_len)[1] == n_slices
+            audio = np.concatenate([synth_chunk(7 + i, 4096) for i in range(n_slices + 1)])[:n]
+            lo, hi = shard_bounds(n_slices, world, rank)
+            assert (hi - lo) == ([1, 1, 0, 0] if n_slices == 2 else [2, 2, 1, 0])[rank]
+            out = denoise(sess, audio, rank=rank, world=world)
+            assert out.shape == (n,), out.shape
+            if rank == 0:
+                assert np.array_equal(out, denoise(sess, audio)), n_slices              # the single-process answer of the same engine
+            dist.barrier()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """))
+    from ade_testlib import hipsim_library
+    hipsim_library()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="4")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(4)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("ok" in o for o in outs)
+
+
 def test_world_size_2_gloo_stitch_keeps_float_rows(tmp_path):
     """stitch_rows moves the rows in THEIR dtype: a float-output export's rows (normalised samples) must not be squeezed through int16 (they would all become 0)."""
     script = tmp_path / "worker_f32.py"

@@ -32,7 +32,10 @@ def test_library_is_the_hip_build(sess0):
 def test_taps_vs_oracle_exact_dft(sess0):
     ins = golden_inputs()
     pcm_in = np.stack([ins["randn"], ins["wav0"], ins["square_fs"]])
+    lean_pcm, lean_f32 = sess0.process(pcm_in, want_f32=True)     # the shipped launch: channels 0-7 of x_d0 / x_d1 / dp2 never leave LDS
+    sess0.set_option("full_taps", "1")                            # ... and the same launch with every inter-stage tensor stored whole, for the taps below
     pcm, f32 = sess0.process(pcm_in, want_f32=True)
+    assert np.array_equal(pcm, lean_pcm) and np.array_equal(f32, lean_f32)
     o = GtcrnOracle(golden_blob(0), 16000)
     o.set_exact_dft(True)
     for row in (1, 2):
@@ -42,6 +45,7 @@ def test_taps_vs_oracle_exact_dft(sess0):
             # gates use the hardware v_exp_f32 / v_rcp_f32 units (~1 ulp each); 8e-6 observed on the full-scale square
             assert err <= 1e-5 * max(1.0, scale) + 1e-5, f"row {row} tap {name}: {err:.3e} (scale {scale:.3g})"
         assert np.abs(f32[row] - of32[0]).max() <= 1e-5
+    sess0.set_option("full_taps", "0")
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

@@ -22,7 +22,10 @@ def test_hipsim_taps_and_waveform(simlib):
     ins = golden_inputs()
     sess = make_session(simlib, seed=0)
     pcm_in = np.stack([ins["randn"], ins["wav0"]])
+    lean_pcm, lean_f32 = sess.process(pcm_in, want_f32=True)      # the shipped launch: channels 0-7 of x_d0 / x_d1 / dp2 never leave LDS
+    sess.set_option("full_taps", "1")                             # the same launch with every inter-stage tensor stored whole (the taps below read them)
     pcm, f32 = sess.process(pcm_in, want_f32=True)
+    assert np.array_equal(pcm, lean_pcm) and np.array_equal(f32, lean_f32)
     o = GtcrnOracle(golden_blob(0), 16000)
     # (1) against the oracle with the reference's own (fp32-angle) DFT table: the documented 1e-4 contract
     opcm, of32 = o.process(pcm_in)

@@ -306,3 +306,31 @@ def test_gpu_full_depth_full_length_properties():
         rev, _ = sess.process(x[::-1].copy())
     assert np.isfinite(f32).all() and np.abs(out).max() > 50
     assert np.array_equal(out[1:2], solo) and np.array_equal(rev, out[::-1])
+
+
+@pytest.mark.gpu
+def test_gpu_baseline_batch_32_x_8s_properties():
+    """BASELINE configs[3] at its stated batch: 32 stereo segments of 8 s (801 frames), depth 6, ONE call -- the shape `bench.py --workload melband` times.  Size-independent
+    properties: every output finite, a silent row exactly silent, a row's bits the same as in a call of its own and as in the reversed batch (row independence at batch 32)."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_stereo
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    L, B = 352800, 32
+    w = weightgen.materialise(melband.synthetic_spec(6))
+    blob = pack_blob(melband.model_tensors(w))
+    del w
+    x = np.stack([synth_stereo(100 + i, L, 44100).reshape(-1) for i in range(B)])
+    x[5] = 0                                                          # a silent segment among the 32
+    with InferenceSession(weights=blob, metadata=melband.metadata(L)) as sess:
+        assert sess.frames == 801
+        out, f32 = sess.process(x, want_f32=True)
+        assert out.shape == (B, sess.row_out)
+        solo, _ = sess.process(x[17:18])
+        rev, _ = sess.process(x[::-1].copy())
+    assert np.isfinite(f32).all()
+    assert not out[5].any() and not f32[5].any(), "a silent segment must come back exactly silent"
+    loud = np.abs(out).max(axis=1)
+    assert (np.delete(loud, 5) > 50).all(), loud
+    assert np.array_equal(out[17:18], solo), "row 17 depends on its neighbours at batch 32"
+    assert np.array_equal(rev, out[::-1])

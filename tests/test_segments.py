@@ -17,6 +17,7 @@ TAPS = ("spec", "e0", "e1", "x_e2", "x_e3", "x_e4", "dp1", "dp2", "x_d0", "x_d1"
 def run(sess, x, geometry, single="1"):
     sess.set_option("geometry", geometry)
     sess.set_option("single_launch", single)
+    sess.set_option("full_taps", "1")                      # (the single launch otherwise keeps channels 0-7 of x_d0 / x_d1 / dp2 in LDS: test_gpu_lean_stores)
     pcm, f32 = sess.process(x, want_f32=True)
     taps = {n: sess.tap(n, x.shape[0] * sess.frames * 65 * 16).copy() for n in TAPS}
     assert sess.tap("xchg_error", 1)[0] == 0.0
@@ -150,15 +151,17 @@ def _forced_timeout_contract(sess, x, device_path=None):
     sess.set_option("xwait_ms", "2")
     sess.set_option("xchg_withhold", "1")
     out = np.full((x.shape[0], sess.row_out), 12345, np.int16)
-    with pytest.raises(AdeDeviceError, match=r"segment 1 of chunk 0 timed out .* depthwise-convolution history"):
+    with pytest.raises(AdeDeviceError, match=r"segment [123] of chunk 0 timed out .* depthwise-convolution history"):
         sess.process_into(x, out)
     assert (out == 12345).all(), "a failed call must not hand out PCM"
     if device_path is not None:                      # the caller-stream entry cannot synchronise: the NEXT call on the handle reports it
         d_in, d_out, stream = device_path(x)
         sess.run_device(d_in, d_out, stream=stream)  # enqueued, returns ADE_OK
+        import torch
+        torch.cuda.synchronize()                     # (the caller's own synchronisation: the launch has failed by now)
         with pytest.raises(AdeDeviceError, match=r"earlier call on a caller-provided stream"):
             sess.run_device(d_in, d_out)
-        with pytest.raises(AdeDeviceError, match=r"segment 1 of chunk 0"):      # engine-stream device entry: synchronises, reports at once
+        with pytest.raises(AdeDeviceError, match=r"segment [123] of chunk 0"):      # engine-stream device entry: synchronises, reports at once
             sess.run_device(d_in, d_out)
     sess.set_option("xchg_withhold", "0")
     sess.set_option("xwait_ms", "200")
@@ -179,9 +182,33 @@ def test_gpu_withheld_flag_fails_the_call_on_every_entry_point():
     import torch
     x = synth_batch(5)
     sess = make_session(None, seed=0)
+    keep = []
 
     def device_path(x):
         d_in = torch.from_numpy(x).cuda()
         d_out = torch.zeros((x.shape[0], sess.row_out), dtype=torch.int16, device="cuda")
-        return d_in, d_out, torch.cuda.current_stream().cuda_stream
+        side = torch.cuda.Stream()                     # (the default stream's handle is 0 = "run synchronously on the engine's stream")
+        side.wait_stream(torch.cuda.current_stream())
+        keep.append(side)
+        return d_in, d_out, side.cuda_stream
     _forced_timeout_contract(sess, x, device_path)
+
+
+@pytest.mark.gpu
+def test_gpu_lean_stores():
+    """The shipped single launch does not write channels 0-7 of x_d0 / x_d1 / dp2 (their only reader is the next block, through LDS): same PCM / waveform bit for bit as
+    with option full_taps, the stored half (channels 8-15) equal, every other inter-stage tensor equal."""
+    x = synth_batch(37)
+    sess = make_session(None, seed=2)
+    for geometry in "210":
+        full = run(sess, x, geometry)
+        sess.set_option("full_taps", "0")
+        pcm, f32 = sess.process(x, want_f32=True)
+        assert np.array_equal(pcm, full[0]) and np.array_equal(f32, full[1]), f"geometry {geometry}"
+        for name in TAPS:
+            got = sess.tap(name, x.shape[0] * sess.frames * 65 * 16)
+            if name in ("x_d0", "x_d1", "dp2"):
+                got, want = got.reshape(-1, 16)[:, 8:], full[2][name].reshape(-1, 16)[:, 8:]
+            else:
+                want = full[2][name]
+            assert np.array_equal(got, want), f"geometry {geometry}: tap {name}"

@@ -23,6 +23,7 @@ for rep in range(2):
     for geo, prio in configs:
         s = make_session()
         s.set_option("geometry", geo)
+        s.set_option("full_taps", "1")
         s.set_option("wave_swap", prio)
         s.reserve(B)
         d_out = torch.empty((B, s.row_out), dtype=torch.int16, device="cuda")
