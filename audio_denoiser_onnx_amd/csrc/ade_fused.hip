@@ -30,9 +30,10 @@ static_assert(chunk_smem_bytes<Geo0>() <= 160 * 1024, "geometry 0 must fit one C
 
 // Block b of a (B x nseg)-block grid -> (chunk, segment): all first segments first.  Frames are dealt as evenly as possible, the earlier
 // segments taking the extra frame (the last segment finishes last; it should not also be the longest).
-__device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int block, int& chunk) {
+// chunk0: the launch covers chunks chunk0 .. chunk0 + B - 1 of the engine's batch arrays (ade_process cuts a host batch into sub-batches on separate streams).
+__device__ __forceinline__ Seg make_seg(const SegPlan& plan, int B, int T, int block, int& chunk, int chunk0 = 0) {
     const int seg = block / B;
-    chunk = block - seg * B;
+    chunk = chunk0 + block - seg * B;
     const int base = T / plan.nseg, rem = T - base * plan.nseg;
     Seg sg;
     sg.T = T;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
     ADE_KEEP_IN_LOOP(C);                                                                                   \
     ADE_KEEP_IN_LOOP(block);                                                                               \
     int chunk;                                                                                             \
-    const Seg sg = make_seg(cload<SegPlan>(&C->plan), C->B, C->T, block, chunk);                           \
+    const Seg sg = make_seg(cload<SegPlan>(&C->plan), C->B, C->T, block, chunk, C->chunk0);                \
     fixed_ptr F = (fixed_ptr)C->fixed;                                                                     \
     long long* const clk0 = kClk ? seg_clk(C->clk, sg, C->B, block) : nullptr;                             \
     (void)clk0

@@ -217,6 +217,8 @@ struct ChunkCall {           // per call, by value
     const float* dc;         // optional per-row DC means computed upstream (batch-fold: one mean per call, shared by its windows)
     long long* clk;          // optional phase clocks, kClkSlotsPerSeg per segment
     int L, T, B;
+    int chunk0;              // first chunk of this launch in the batch arrays (pcm_in / pcm_out / f32_out, the workspace tensors and the exchange slots are indexed by chunk0 + the
+                             // launch's own chunk number): 0 except for the sub-batch launches of ade_process
     int full_taps;           // 1: launch the debug build, which stores every inter-stage tensor whole (option "full_taps", for ade_debug_tap); 0: the three tensors whose
                              // channels 0-7 only the following block reads -- through LDS -- keep those planes out of HBM (x_d0, x_d1, dp2).  Read by the launcher only.
     int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all

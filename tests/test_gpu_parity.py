@@ -245,3 +245,31 @@ def test_process_into_pageable_and_page_locked_buffers_agree():
     assert np.array_equal(pin_out.numpy(), want) and np.array_equal(pin_f32.numpy(), f32)
     with pytest.raises(ValueError):
         sess.process_into(pcm[:, :-1], out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [37, 256])
+def test_process_sub_batches_on_separate_streams_are_bit_identical(batch):
+    """ade_process can cut a host batch into sub-batches (option "host_split"; off by default: measured slower), each with its own stream: copy in -> its own launch of the
+    chunk kernel (ChunkCall::chunk0) -> copy out, so that the copies of one run under the kernel of another.  Same PCM and waveform, bit for bit, as ONE launch, from page-locked
+    and from pageable buffers, for an uneven last sub-batch and in every geometry."""
+    import torch
+    sess = make_session(None, seed=1)
+    pcm = np.ascontiguousarray(synth_batch(batch, 16000))
+    sess.set_option("host_split", "1")
+    want, want_f32 = sess.process(pcm, want_f32=True)
+    pin_in = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
+    pin_out = torch.empty(want.shape, dtype=torch.int16).pin_memory()
+    pin_f32 = torch.empty(want.shape, dtype=torch.float32).pin_memory()
+    pin_in.numpy()[...] = pcm
+    for split in "0", "2", "3", "4", "8":
+        sess.set_option("host_split", split)
+        for geometry in ("2", "0") if split in "03" else ("2",):
+            sess.set_option("geometry", geometry)
+            got, got_f32 = sess.process(pcm, want_f32=True)                          # pageable buffers: staged through the engine's page-locked ones, sub-batch by sub-batch
+            assert np.array_equal(got, want) and np.array_equal(got_f32, want_f32), (split, geometry)
+            pin_out.zero_()
+            pin_f32.zero_()
+            sess.process_into(pin_in.numpy(), pin_out.numpy(), pin_f32.numpy())      # page-locked buffers: DMA'd directly
+            assert np.array_equal(pin_out.numpy(), want) and np.array_equal(pin_f32.numpy(), want_f32), (split, geometry)
+    assert sess.tap("xchg_error", 1)[0] == 0.0
