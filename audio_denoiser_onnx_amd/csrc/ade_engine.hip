@@ -85,7 +85,7 @@ struct ade_engine {
 
     hipStream_t stream = nullptr;
     hipStream_t sub_streams[8] = {};      // ade_process: one stream per sub-batch (created on first use)
-    int host_split = 0;                   // option "host_split": sub-batches of a host batch (0 / 1 = none: measured slower, see ade_process)
+    int host_split = 0;                   // option "host_split": sub-batches of a host batch (0 = per call: two from 128 rows; 1 = never; see ade_process)
     float* d_weights = nullptr;
     int* d_ints = nullptr;
     FftTabs tabs{};
@@ -1321,7 +1321,7 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         free_graphs(h);
         return ADE_OK;
     }
-    if (strcmp(key, "host_split") == 0) {      // sub-batches ade_process cuts a host batch into (the copies of one overlap the kernel of another); 0 / 1 = no split (the default)
+    if (strcmp(key, "host_split") == 0) {      // sub-batches ade_process cuts a host batch into (the copies of one overlap the kernel of another); 0 = per call (two from 128 rows), 1 = never
         if (value[0] < '0' || value[0] > '8' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option host_split: 0..8");
         h->host_split = value[0] - '0';
         return ADE_OK;
@@ -1557,31 +1557,35 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     };
     const bool in_direct = page_locked(in), pcm_direct = page_locked(out_pcm), f32_direct = page_locked(out_f32);
     // The reference's own timing convention is this call (wall clock around copies + compute, Inference_GTCRN_ONNX.py:323-343).  Run as ONE copy in, ONE launch, ONE copy out
-    // it is the sum of the three (0.16 + 0.36 + 0.16 ms at 256 x 1 s).  Option "host_split" = n cuts the batch into n sub-batches, each on its own stream (H2D -> its own
-    // launch of the chunk kernel -> D2H): chunks are independent calls of the graph, the kernel indexes everything by ChunkCall::chunk0 + its own chunk number, so the
-    // sub-batches share the batch arrays and the workspace without touching each other's rows -- same bits as the single launch (tests/test_gpu_parity.py).  MEASURED
-    // (profiles/r04_b_host_split_probe.txt, 256 x 1 s, page-locked buffers): 0.68 ms unsplit, 0.87 / 1.00 / 1.26 ms in 2 / 4 / 8 sub-batches -- the sub-batch kernels do not
-    // run side by side (a launch of 64 chunks is latency-bound at ~0.22 ms whatever else is in flight), so the copies hidden are worth less than the kernels added.  The
-    // split is therefore OFF unless asked for.
+    // it is the sum of the three (0.16 + 0.36 + 0.16 ms at 256 x 1 s).  A batch of 128 rows or more is cut into TWO sub-batches (option "host_split" = n: n of them), each on
+    // its own stream: chunks are independent calls of the graph, the kernel indexes everything by ChunkCall::chunk0 + its own chunk number, so the sub-batches share the
+    // batch arrays and the workspace without touching each other's rows -- same bits as the single launch (tests/test_gpu_parity.py).  The second sub-batch's copy-in runs
+    // under the first one's kernel, the two kernels run side by side, the first copy-out under the second kernel's tail.  MEASURED (profiles/r04_b_host_split_probe*.txt,
+    // 256 x 1 s, page-locked buffers): 0.678 ms unsplit, 0.598 ms in two; 0.79 / 1.14 ms in 4 / 8 -- this process's streams land on two hardware queues, so a third and
+    // fourth sub-batch queue up behind the first two (rocprofv3 timeline in DESIGN.md section 6), and a launch of 64 chunks is latency-bound at ~0.23 ms however little it carries.
     {
         const int geo = pick_geometry(h, rows);
-        int n_sub = h->host_split ? h->host_split : 1;
+        int n_sub = h->host_split ? h->host_split : (rows >= 128 ? 2 : 1);
         const bool plain = !h->sub && !h->gt_sand && h->use_fused && h->use_single && geo >= 0 && !h->profile && h->n_win == 1;
         if (plain && n_sub > 1 && rows >= 2 * n_sub) {
             const int per = (rows + n_sub - 1) / n_sub;
             h->last_batch = rows;
             h->last_fused = true;
             h->last_geometry = geo;
-            int used = 0;
-            for (int k = 0; k < n_sub; ++k) {
+            // Enqueue order matters: the runtime's copy queue is served in order of submission across streams (traced: with copy-in / launch / copy-out enqueued sub-batch by
+            // sub-batch, the next sub-batch's copy-in waited behind the previous one's copy-out, i.e. behind its kernel -- a fully serial chain).  So: every copy-in first,
+            // then every launch, then every copy-out.
+            const int used = (rows + per - 1) / per;
+            for (int k = 0; k < used; ++k) {
                 const int r0 = k * per, nr = std::min(per, rows - r0);
-                if (nr <= 0) break;
                 if (!h->sub_streams[k]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_streams[k], hipStreamNonBlocking));
-                hipStream_t s = h->sub_streams[k];
-                const size_t i0 = (size_t)r0 * h->in_len, o0 = (size_t)r0 * h->out_len;
+                const size_t i0 = (size_t)r0 * h->in_len;
                 const int16_t* src = in + i0;
                 if (!in_direct) { memcpy(h->h_pcm_in + i0, in + i0, (size_t)nr * h->in_len * sizeof(int16_t)); src = h->h_pcm_in + i0; }
-                HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, s));
+                HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, h->sub_streams[k]));
+            }
+            for (int k = 0; k < used; ++k) {
+                const int r0 = k * per, nr = std::min(per, rows - r0);
                 ChunkCall C{};
                 C.plan.nseg = fused_segments(h->T, geo); C.plan.xchg = h->d_xchg; C.plan.flags = h->d_xflags; C.plan.err = h->d_xerr; C.plan.wave_swap = h->wave_swap;
                 C.plan.prio = h->seg_prio; C.plan.withhold = r0 == 0 ? h->xchg_withhold : 0; C.plan.wait_ticks = h->xwait_ticks;
@@ -1589,11 +1593,15 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
                 C.pcm_in = h->d_pcm_in; C.pcm_out = h->d_pcm_out; C.f32_out = out_f32 ? h->d_f32_out : nullptr;
                 C.L = h->in_len; C.T = h->T; C.B = nr; C.chunk0 = r0;
                 C.full_taps = h->full_taps;
-                launch_gtcrn_chunk(s, geo, C);
+                launch_gtcrn_chunk(h->sub_streams[k], geo, C);
                 HIP_TRY(h, hipGetLastError());
+            }
+            for (int k = 0; k < used; ++k) {
+                const int r0 = k * per, nr = std::min(per, rows - r0);
+                const size_t o0 = (size_t)r0 * h->out_len;
+                hipStream_t s = h->sub_streams[k];
                 if (out_pcm) HIP_TRY(h, hipMemcpyAsync((pcm_direct ? out_pcm : h->h_pcm_out) + o0, h->d_pcm_out + o0, (size_t)nr * h->out_len * sizeof(int16_t), hipMemcpyDeviceToHost, s));
                 if (out_f32) HIP_TRY(h, hipMemcpyAsync((f32_direct ? out_f32 : h->h_f32_out) + o0, h->d_f32_out + o0, (size_t)nr * h->out_len * sizeof(float), hipMemcpyDeviceToHost, s));
-                used = k + 1;
             }
             for (int k = 0; k < used; ++k) HIP_TRY(h, hipStreamSynchronize(h->sub_streams[k]));
             st = exchange_status(h, "ade_process", false);

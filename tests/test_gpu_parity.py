@@ -250,7 +250,7 @@ def test_process_into_pageable_and_page_locked_buffers_agree():
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch", [37, 256])
 def test_process_sub_batches_on_separate_streams_are_bit_identical(batch):
-    """ade_process can cut a host batch into sub-batches (option "host_split"; off by default: measured slower), each with its own stream: copy in -> its own launch of the
+    """ade_process cuts a host batch into sub-batches (option "host_split"; by default two from 128 rows), each with its own stream: copy in -> its own launch of the
     chunk kernel (ChunkCall::chunk0) -> copy out, so that the copies of one run under the kernel of another.  Same PCM and waveform, bit for bit, as ONE launch, from page-locked
     and from pageable buffers, for an uneven last sub-batch and in every geometry."""
     import torch
