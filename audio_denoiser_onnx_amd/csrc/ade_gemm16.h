@@ -1,0 +1,221 @@
+// ade_gemm16.h — bf16 GEMM on the gfx950 matrix cores with bf16 operands STORED in HBM (the real bf16 path of BASELINE.json configs[2] / [3]).
+//
+//   C(m, n) = sum_k A[m][k] * B[n][k]        A, B: bf16, row-major with k contiguous (activations (rows, features); torch Linear weights (out, in));
+//                                            products exact, accumulation fp32 (v_mfma_f32_32x32x16_bf16)
+//
+// Unlike the bf16 MODE of ade_gemm.h (fp32 operands in HBM, rounded on their way into LDS, the half-rate 16x16x16 instruction) the operands here are half the bytes
+// everywhere -- HBM, L2, LDS -- and the instruction is gfx950's full-rate 32x32x16 form (16 x the f32 matrix rate).  At these shapes (M ~ 1.5 M rows, N and K
+// 384 .. 1544) the products are bound by operand / result traffic, not by the matrix cores, so the kernel is built around full-line transfers:
+//   * one 256-thread workgroup = one 128 x 128 tile of C, four wavefronts in 2 x 2, each a 64 x 64 quadrant as 2 x 2 MFMA tiles (64 accumulator registers);
+//   * k runs in slabs of 64: a slab of an operand is 128 rows x 128 bytes, fetched as whole 128-byte lines (8 lanes x 16 bytes per row) into registers one slab
+//     ahead of the MFMAs and written to LDS with a 144-byte row pitch (36 words: the 16 lanes of every ds_read_b128 service group land on 16 distinct 4-bank sets);
+//   * a lane's operand of one MFMA (8 consecutive k of its row) is ONE ds_read_b128;
+//   * the tile is computed TRANSPOSED (MFMA A operand = rows of B, MFMA B operand = rows of A), so a lane's accumulator registers are runs of four consecutive n of
+//     one row m; the epilogue passes the tile through LDS (fp32, 64 rows at a time) and hands the store functor whole float4s (m, n .. n + 3) with consecutive lanes on
+//     consecutive n: every read the store makes (bias, rotary table, the old value of a residual) and every write it makes is a full-line access, whatever the output type.
+// Store functor:  __device__ void operator()(int m, int n, float4 v, int cnt) const;     n % 4 == 0, cnt = min(4, N - n) valid columns
+// K % 8 == 0, lda % 8 == 0, ldb % 8 == 0 and 16-byte aligned bases are required (checked by the launchers' callers); M, N are free.
+#pragma once
+#include "ade_device.h"
+
+#include <cstdint>
+
+namespace ade {
+namespace gemm16 {
+
+using namespace dev;
+
+typedef unsigned short bf16_t;                       // storage type (bit pattern)
+#if defined(__clang__)
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f32 __attribute__((ext_vector_type(2)));
+#else                                                // g++ spelling for the host-side simulator build under tests/hipsim
+typedef short v8bf __attribute__((vector_size(16)));
+typedef float v16f __attribute__((vector_size(64)));
+#endif
+
+constexpr int kTM = 128, kTN = 128, kTK = 64;
+constexpr int kPitch = 144;                          // bytes per staged row (128 + 16)
+constexpr int kSlabBytes = kTM * kPitch;             // one operand's slab
+constexpr int kEpiPitch = 132;                       // floats per row of the epilogue tile (128 + 4: a wave's float4 writes of 8 consecutive rows cover all banks once)
+constexpr int kEpiBytes = 64 * kEpiPitch * 4;
+constexpr int kLdsBytes = 2 * kSlabBytes > kEpiBytes ? 2 * kSlabBytes : kEpiBytes;      // 36 864
+
+// fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+#if defined(__clang__)
+    v2f32 v = {a, b};
+    v2bf r = __builtin_convertvector(v, v2bf);
+    unsigned w;
+    __builtin_memcpy(&w, &r, 4);
+    return w;
+#else
+    auto one = [](float x) { unsigned u = __float_as_uint(x); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };
+    return one(a) | (one(b) << 16);
+#endif
+}
+__device__ __forceinline__ uint2 pack_bf16x4(const float4& v) { return make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ v8bf as_v8bf(const uint4& u) { v8bf r; __builtin_memcpy(&r, &u, 16); return r; }      // (a register rename on the GPU)
+__device__ __forceinline__ v16f mfma32x32x16(const uint4& a, const uint4& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_v8bf(a), as_v8bf(b), c, 0, 0, 0); }
+
+__device__ __forceinline__ uint4 zero_unless(bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
+
+// one 128 x 128 tile of C at (m_blk, n_blk); lds: kLdsBytes, 16-byte aligned
+template <class ST>
+__device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, const ST& store, int M, int N, int K, int m_blk, int n_blk,
+                                          unsigned char* lds) {
+    unsigned char* As = lds;
+    unsigned char* Bs = lds + kSlabBytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l31 = lane & 31, h = lane >> 5;
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging map: lane = (row, 16-byte piece): 8 lanes read one row's 128-byte line; rows r, r + 32, r + 64, r + 96
+    const int sr = tid >> 3, sc = tid & 7;
+    const bf16_t* ap[4];
+    const bf16_t* bp[4];
+    bool aok[4], bok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = m_blk + sr + 32 * u, n = n_blk + sr + 32 * u;
+        aok[u] = m < M;
+        bok[u] = n < N;
+        ap[u] = A + (size_t)(aok[u] ? m : M - 1) * lda;                // out-of-range rows: an in-range address, zeroed after the load (no branch around a load)
+        bp[u] = B + (size_t)(bok[u] ? n : N - 1) * ldb;
+    }
+    uint4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const bool kok = k0 + 8 * sc < K;                                // K % 8 == 0: a piece is all in or all out
+        const int ko = kok ? k0 + 8 * sc : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ra[u] = zero_unless(aok[u] && kok, *reinterpret_cast<const uint4*>(ap[u] + ko));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rb[u] = zero_unless(bok[u] && kok, *reinterpret_cast<const uint4*>(bp[u] + ko));
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<uint4*>(As + (sr + 32 * u) * kPitch + 16 * sc) = ra[u];
+            *reinterpret_cast<uint4*>(Bs + (sr + 32 * u) * kPitch + 16 * sc) = rb[u];
+        }
+    };
+    // MFMA operand layout (32x32x16): lane l supplies row (l & 31), k = 8 (l >> 5) .. + 7 of the 16-deep step.  MFMA-A = rows of B (n), MFMA-B = rows of A (m):
+    // D[i = n][j = m], lane (j = l & 31, h): register r holds n = (r & 3) + 8 (r >> 2) + 4 h of row m = j.
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < kTK / 16; ++ks) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + (wm + 32 * i + l31) * kPitch + 32 * ks + 16 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + (wn + 32 * j + l31) * kPitch + 32 * ks + 16 * h);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(fb[j], fa[i], acc[i][j]);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kTK) {
+        stash();
+        __syncthreads();
+        if (k0 + kTK < K) fetch(k0 + kTK);
+        compute();
+        __syncthreads();
+    }
+    // epilogue: 64 rows at a time through LDS
+    float* E = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if ((wave >> 1) == half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(E + (32 * i + l31) * kEpiPitch + wn + 32 * j + 8 * q + 4 * h) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 256 * u, row = idx >> 5, c4 = idx & 31;
+            const int m = m_blk + 64 * half + row, n = n_blk + 4 * c4;
+            if (m < M && n < N) store(m, n, *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4), N - n < 4 ? N - n : 4);
+        }
+        __syncthreads();
+    }
+}
+
+// Consecutive logical tile ids share an XCD (ade_gemm.h): all n-tiles of an m-strip re-read that strip of A from one L2.
+__device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
+    const int per = total >> 3, rem = total & 7, xcd = w & 7, idx = w >> 3;
+    return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+}
+
+template <class ST>
+__global__ __launch_bounds__(256, 3) void k_gemm16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, ST store, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
+    gemm_tile(A, lda, B, ldb, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, lds);
+}
+
+template <class ST>
+inline void launch(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, const ST& st, int M, int N, int K) {
+    const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm16<ST>), grid, dim3(256), 0, s, A, lda, B, ldb, st, M, N, K);
+}
+
+// Batched form: blockIdx.z selects a problem; prob(z) returns {A, lda, B, ldb, st, M, N, K} (evaluated once per workgroup); tiles outside a problem's own M x N exit at once.
+template <class ST>
+struct Prob { const bf16_t* A; int lda; const bf16_t* B; int ldb; ST st; int M, N, K; };
+template <class P>
+__global__ __launch_bounds__(256, 3) void k_gemm16_batched(P prob) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const int id = xcd_contiguous_id((int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z), gx * gy * (int)gridDim.z);
+    const int z = id / (gx * gy), in_z = id - z * gx * gy;
+    const auto q = prob(z);
+    const int m_blk = (in_z / gx) * kTM, n_blk = (in_z % gx) * kTN;
+    if (m_blk >= q.M || n_blk >= q.N) return;
+    gemm_tile(q.A, q.lda, q.B, q.ldb, q.st, q.M, q.N, q.K, m_blk, n_blk, lds);
+}
+template <class P>
+inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N) {
+    const dim3 grid((unsigned)((max_N + kTN - 1) / kTN), (unsigned)((max_M + kTM - 1) / kTM), (unsigned)batch);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm16_batched<P>), grid, dim3(256), 0, s, prob);
+}
+
+// ---- common stores ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_bf16x4(bf16_t* p, const float4& v, int cnt) {       // p 8-byte aligned when cnt == 4
+    if (cnt == 4) { *reinterpret_cast<uint2*>(p) = pack_bf16x4(v); return; }
+    const float t[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < cnt; ++i) p[i] = (bf16_t)(pack_bf16x2(t[i], 0.0f) & 0xffffu);
+}
+__device__ __forceinline__ float4 load_f32x4(const float* p, int cnt) {
+    if (cnt == 4) return *reinterpret_cast<const float4*>(p);
+    float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < cnt; ++i) t[i] = p[i];
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void store_f32x4(float* p, const float4& v, int cnt) {
+    if (cnt == 4) { *reinterpret_cast<float4*>(p) = v; return; }
+    const float t[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < cnt; ++i) p[i] = t[i];
+}
+
+}  // namespace gemm16
+}  // namespace ade

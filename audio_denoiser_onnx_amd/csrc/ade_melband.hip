@@ -26,6 +26,7 @@
 // tables; manifest key ade_dft_tables = "exact" selects exactly reduced angles instead (closer to torch.stft, which the
 // checkpoints were trained with).
 #include "ade_gemm.h"
+#include "ade_gemm16.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
 
@@ -280,14 +281,10 @@ constexpr int kKvStride = 68;      // floats per staged row: 16 rows x one float
 // chunk (after all four score tiles), not once per 16 keys.  A wave owns QT tiles of 16 queries: every K / V operand read from LDS feeds QT MFMA chains, so with
 // QT = 2 (sequences longer than 64) a chunk is 128 + 128 MFMAs per wave against 32 ds_read_b128 -- at QT = 1 the sixteen waves of a CU ask LDS for its full
 // 128 bytes per cycle and the matrix cores wait for it.
-// BF16 = true (ade_gemm_dtype = bf16): Q, K, V and the probabilities enter the matrix cores as bf16 (v_mfma_f32_16x16x16_bf16: a lane supplies four CONSECUTIVE k, which
-// for the P . V product are exactly its four score registers); scores, softmax statistics and the output accumulate in fp32.  K / V chunks are staged as bf16 (34-word
-// pitch): an eighth of the MFMA time and half the LDS traffic of the fp32 form.
-constexpr int kKvStrideB = 34;     // 32-bit words per staged bf16 row (64 values + 2 words: conflict-free ds_read_b64)
-template <int QT, bool BF16>
+template <int QT>
 __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ qkvg, float* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq,
                                                       int di) {
-    constexpr int kPitch = BF16 ? kKvStrideB : kKvStride;
+    constexpr int kPitch = kKvStride;
     __shared__ __attribute__((aligned(16))) float Ks[kKc * kPitch];            // [key][dim]
     __shared__ __attribute__((aligned(16))) float Vt[kDh * kPitch];            // [dim][key]
     constexpr int kQw = 16 * QT, kQb = 4 * kQw;                                 // queries per wave / per workgroup
@@ -298,7 +295,6 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
     bool q_ok[QT];
     size_t qrow[QT];
     float4 qreg[QT][4];                                                         // Q[query j16 of tile t][d = 16 ks + 4 g + s] (rotary applied by the in-projection's store)
-    gemm::v4s qb[QT][4];                                                        // the same as four bf16 (BF16 only)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         qi[t] = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;              // this lane's query of tile t
@@ -308,7 +304,6 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qreg[t][ks] = keep4(q_ok[t], *reinterpret_cast<const float4*>(src + 16 * ks));
-            if constexpr (BF16) { const uint2 q = gemm::bf16x4(qreg[t][ks]); qb[t][ks] = *reinterpret_cast<const gemm::v4s*>(&q); }
         }
     }
     float m[QT], l[QT];
@@ -341,17 +336,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4;
-            if constexpr (BF16) {
-                *reinterpret_cast<uint2*>(Ks + p * kPitch + d / 2) = gemm::bf16x4(pk[u]);
-                unsigned short* vt = reinterpret_cast<unsigned short*>(Vt);
-                vt[d * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].x);
-                vt[(d + 1) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].y);
-                vt[(d + 2) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].z);
-                vt[(d + 3) * (2 * kPitch) + p] = (unsigned short)gemm::bf16_bits(pv[u].w);
-            } else {
-                *reinterpret_cast<float4*>(Ks + p * kPitch + d) = pk[u];
-                Vt[d * kPitch + p] = pv[u].x; Vt[(d + 1) * kPitch + p] = pv[u].y; Vt[(d + 2) * kPitch + p] = pv[u].z; Vt[(d + 3) * kPitch + p] = pv[u].w;
-            }
+            *reinterpret_cast<float4*>(Ks + p * kPitch + d) = pk[u];
+            Vt[d * kPitch + p] = pv[u].x; Vt[(d + 1) * kPitch + p] = pv[u].y; Vt[(d + 2) * kPitch + p] = pv[u].z; Vt[(d + 3) * kPitch + p] = pv[u].w;
         }
         __syncthreads();
         if (c0 + kKc < n) request(c0 + kKc);
@@ -363,19 +349,13 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
             for (int t = 0; t < QT; ++t) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if constexpr (BF16) {
-                    const gemm::v4s kb = *reinterpret_cast<const gemm::v4s*>(Ks + (16 * kt + j16) * kPitch + 8 * ks + 2 * g);
+                const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kPitch + 16 * ks + 4 * g);
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) st[t][kt] = gemm::mfma16x16x16_bf16(kb, qb[t][ks], st[t][kt]);
-                } else {
-                    const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kPitch + 16 * ks + 4 * g);
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
-                        st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
-                        st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
-                        st[t][kt] = mfma16x16x4(kv.w, qreg[t][ks].w, st[t][kt]);
-                    }
+                for (int t = 0; t < QT; ++t) {
+                    st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
+                    st[t][kt] = mfma16x16x4(kv.w, qreg[t][ks].w, st[t][kt]);
                 }
             }
         }
@@ -407,26 +387,15 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
         }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            gemm::v4s pb[QT];
-            if constexpr (BF16) {
-#pragma unroll
-                for (int t = 0; t < QT; ++t) { const uint2 q = gemm::bf16x4(make_float4(st[t][kt][0], st[t][kt][1], st[t][kt][2], st[t][kt][3])); pb[t] = *reinterpret_cast<const gemm::v4s*>(&q); }
-            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                if constexpr (BF16) {
-                    const gemm::v4s vb = *reinterpret_cast<const gemm::v4s*>(Vt + (16 * dt + j16) * kPitch + 8 * kt + 2 * g);   // V^T[dim 16 dt + j16][keys 16 kt + 4 g ..]
+                const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kPitch + 16 * kt + 4 * g);
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) acc[t][dt] = gemm::mfma16x16x16_bf16(vb, pb[t], acc[t][dt]);
-                } else {
-                    const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kPitch + 16 * kt + 4 * g);
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
-                        acc[t][dt] = mfma16x16x4(vv.y, st[t][kt][1], acc[t][dt]);
-                        acc[t][dt] = mfma16x16x4(vv.z, st[t][kt][2], acc[t][dt]);
-                        acc[t][dt] = mfma16x16x4(vv.w, st[t][kt][3], acc[t][dt]);
-                    }
+                for (int t = 0; t < QT; ++t) {
+                    acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.y, st[t][kt][1], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.z, st[t][kt][2], acc[t][dt]);
+                    acc[t][dt] = mfma16x16x4(vv.w, st[t][kt][3], acc[t][dt]);
                 }
             }
         }
@@ -443,6 +412,263 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
             *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(acc[t][dt][0] * sc, acc[t][dt][1] * sc, acc[t][dt][2] * sc, acc[t][dt][3] * sc);
+    }
+}
+
+// ---- bf16 path (ade_gemm_dtype = "bf16"): bf16 activations and weights STORED in HBM, v_mfma_f32_32x32x16_bf16 / 16x16x32 products, fp32 islands ------------
+// What stays fp32: the STFT / ISTFT GEMMs and the band-split GEMM (the front and the PCM tail), the residual stream X and every norm over it, the softmax
+// statistics and all accumulators, biases, rotary tables, the raw mask-estimator output YT and the GLU / scatter / complex mask.  What is bf16: the normalised
+// copy Xb of the residual stream that feeds the in-projection and the first FFN Linear, q | k | v | gates, the attention output, the FFN and mask-estimator
+// hidden activations, and every Linear weight.  Stores of csrc/ade_gemm16.h: (m, n .. n + 3) float4s, consecutive lanes on consecutive n.
+using gemm16::bf16_t;
+
+struct RotaryQkStore16 {       // q | k | v | gates = Xb W_in^T + b_in, rotary on the q and k blocks (:547-548, :552), -> bf16
+    bf16_t* out;
+    const float* bias;
+    const float *rcos, *rsin;  // [position][kDh], rotate_half's sign folded into rsin
+    int ld, rot_cols, pos_stride, n_pos;
+    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+        const float4 b = gemm16::load_f32x4(bias + n, cnt);
+        float4 u = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+        if (n < rot_cols) {                                          // rot_cols % 4 == 0: a float4 is rotated whole or not at all
+            const int at = ((m / pos_stride) % n_pos) * kDh + (n & (kDh - 1));
+            const float4 c = *reinterpret_cast<const float4*>(rcos + at), sn = *reinterpret_cast<const float4*>(rsin + at);
+            u = make_float4(__fmaf_rn(u.x, c.x, __fmul_rn(u.y, sn.x)), __fmaf_rn(u.y, c.y, __fmul_rn(u.x, sn.y)),
+                            __fmaf_rn(u.z, c.z, __fmul_rn(u.w, sn.z)), __fmaf_rn(u.w, c.w, __fmul_rn(u.z, sn.w)));
+        }
+        gemm16::store_bf16x4(out + (size_t)m * ld + n, u, cnt);
+    }
+};
+template <int ACT>             // 0: gelu (erf form, :564); 1: tanh (:581-582)
+struct BiasActStore16 {        // act(v + bias[n]) -> bf16
+    bf16_t* out;
+    const float* bias;
+    int ld;
+    __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)) : tanhf(x); }
+    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+        const float4 b = gemm16::load_f32x4(bias + n, cnt);
+        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(v.x + b.x), act(v.y + b.y), act(v.z + b.z), act(v.w + b.w)), cnt);
+    }
+};
+struct ResidualStore16 {       // x[m][n] += v (+ bias[n]), fp32 residual stream (:569-570)
+    float* x;
+    const float* bias;         // may be null
+    int ld;
+    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+        float* p = x + (size_t)m * ld + n;
+        const float4 old = gemm16::load_f32x4(p, cnt);
+        if (bias) { const float4 b = gemm16::load_f32x4(bias + n, cnt); v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w); }
+        gemm16::store_f32x4(p, make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w), cnt);
+    }
+};
+struct RowBiasStoreF32 {       // yt[m][n] = v + bias[m], fp32 row-major with any ld (the mask estimator's last Linear computed transposed: rows = output columns, n = bt)
+    float* yt;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+        const float b = bias[m];
+        float* p = yt + (size_t)m * ld + n;
+        const float4 r = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
+        if (cnt == 4 && (ld & 3) == 0) { *reinterpret_cast<float4*>(p) = r; return; }
+        const float t[4] = {r.x, r.y, r.z, r.w};
+        for (int i = 0; i < cnt; ++i) p[i] = t[i];
+    }
+};
+struct MeHiddenProb16 {        // z = band: out_z = tanh(in_z W_z^T + b_z), W_z (N, K) bf16
+    const bf16_t* in;
+    const bf16_t* w;
+    const float* bias;
+    bf16_t* out;
+    int BT, K, N;
+    __device__ gemm16::Prob<BiasActStore16<1>> operator()(int z) const {
+        return {in + (size_t)z * BT * K, K, w + (size_t)z * N * K, K, BiasActStore16<1>{out + (size_t)z * BT * N, bias + (size_t)z * N, N}, BT, N, K};
+    }
+};
+struct MeOutProb16 {           // z = band: YT[2 off_z + c][bt] = sum_k w3_z[c][k] h_z[bt][k] + b3_z[c]   (:583), the product taken transposed so that YT is its row-major result
+    const bf16_t* in;
+    const bf16_t* arena16;     // bf16 copies of the arena's me_w3_z at the same offsets
+    const float* arena;
+    BandTable bt;
+    float* yt;
+    int BT, K;
+    __device__ gemm16::Prob<RowBiasStoreF32> operator()(int z) const {
+        const int off = bt.off[z], d = bt.off[z + 1] - off;
+        return {arena16 + bt.w3[z], K, in + (size_t)z * BT * K, K, RowBiasStoreF32{yt + (size_t)2 * off * BT, arena + bt.b3[z], BT}, 2 * d, BT, K};
+    }
+};
+
+// xb_row = bf16(x_row / max(|x_row|_2, 1e-12)): the normalised operand of the next Linear (:533-538); one wavefront per row
+__global__ __launch_bounds__(256) void k_row_norm16(const float* __restrict__ x, bf16_t* __restrict__ xb, int rows, int dim) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    float s = 0.0f;
+    for (int k = 4 * lane; k < dim; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    const float r = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int k = 4 * lane; k < dim; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + k);
+        *reinterpret_cast<uint2*>(xb + (size_t)row * dim + k) = gemm16::pack_bf16x4(make_float4(v.x * r, v.y * r, v.z * r, v.w * r));
+    }
+}
+// x_row = x_row / max(|x_row|, eps) * g (:571) in fp32, xb_row = bf16(new x_row / max(|new x_row|, eps)) for the next transformer, xc_row = bf16(new x_row) for the mask estimator
+__global__ __launch_bounds__(256) void k_row_normalize_gain16(float* __restrict__ x, const float* __restrict__ g, bf16_t* __restrict__ xb, bf16_t* __restrict__ xc, int rows, int dim) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * dim;
+    float s = 0.0f;
+    for (int k = 4 * lane; k < dim; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    const float r = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    float s2 = 0.0f;
+    for (int k = 4 * lane; k < dim; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + k), gg = *reinterpret_cast<const float4*>(g + k);
+        const float4 y = make_float4(v.x * r * gg.x, v.y * r * gg.y, v.z * r * gg.z, v.w * r * gg.w);
+        *reinterpret_cast<float4*>(xr + k) = y;
+        s2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+    }
+    const float r2 = 1.0f / fmaxf(sqrtf(wave_sum(s2)), 1e-12f);
+    for (int k = 4 * lane; k < dim; k += 256) {
+        const float4 y = *reinterpret_cast<const float4*>(xr + k);          // this lane's own store, read back
+        *reinterpret_cast<uint2*>(xb + (size_t)row * dim + k) = gemm16::pack_bf16x4(make_float4(y.x * r2, y.y * r2, y.z * r2, y.w * r2));
+        if (xc) *reinterpret_cast<uint2*>(xc + (size_t)row * dim + k) = gemm16::pack_bf16x4(y);
+    }
+}
+
+// Attention core on bf16 q | k | v (rotary applied by the in-projection's store), v_mfma_f32_16x16x32_bf16, flash style; same decomposition as k_attention above:
+// grid = (sequence, head, block of 64 QT queries), wave w owns QT tiles of 16 queries, the workgroup streams K and V through LDS 64 keys at a time.
+//   S^T tile (16 keys x 16 queries) = K_tile . Q^T over the 64 dims in two 32-deep steps: lane (g, j) supplies K[key j][dims 32 ks + 8 g .. + 7] (ONE ds_read_b128)
+//     and Q[query j][the same dims] (registers, loaded once), and holds S[key 4 g + r][query j];
+//   O^T tile (16 dims x 16 queries) += V^T . P^T over 32 keys per step: the B operand of lane (g, j) is its own eight probabilities of score tiles 2 kp and 2 kp + 1
+//     (keys 16 (2 kp) + 4 g + r and 16 (2 kp + 1) + 4 g + r: contraction slot 8 g + e <-> key 16 (2 kp + (e >> 2)) + 4 g + (e & 3)), the A operand V^T[dim j][the same
+//     keys]: two ds_read_b64 of the TRANSPOSED V chunk.  Scores, softmax statistics and the output accumulate in fp32; the output is written as bf16.
+constexpr int kKPitch16 = 160;     // bytes per staged K row (64 dims): the 16 lanes of a ds_read_b128 service group (rows j, pieces g) cover all 64 banks once
+constexpr int kVPitch16 = 136;     // bytes per staged V^T row (64 keys + 4)
+__device__ __forceinline__ v4f mfma16x16x32(const uint4& a, const uint4& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemm16::as_v8bf(a), gemm16::as_v8bf(b), c, 0, 0, 0);
+}
+template <int QT>
+__global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict__ qkvg, bf16_t* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[kKc * kKPitch16];           // [key][dim]
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[kDh * kVPitch16];           // [dim][key]
+    constexpr int kQw = 16 * QT, kQb = 4 * kQw;
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j16 = lane & 15, g = lane >> 4;
+    const long long row0 = (long long)seq * seq_stride;
+    bool q_ok[QT];
+    size_t qrow[QT];
+    uint4 qb[QT][2];                                                                     // Q[query j16 of tile t][dims 32 ks + 8 g .. + 7]
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;
+        q_ok[t] = qi < n;
+        qrow[t] = (size_t)(row0 + (long long)(q_ok[t] ? qi : 0) * pos_stride);
+        const bf16_t* src = qkvg + qrow[t] * ldq + head * kDh + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qb[t][ks] = gemm16::zero_unless(q_ok[t], *reinterpret_cast<const uint4*>(src + 32 * ks));
+    }
+    float m[QT], l[QT];
+    v4f acc[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[t][dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const bool wave_live = (int)blockIdx.z * kQb + wave * kQw < n;
+    // staging: lane = (key p = i >> 3, 16-byte piece i & 7) for i = tid, tid + 256: 8 lanes read one key's 128-byte K (and V) line; padded keys are zero rows
+    uint4 pk[2], pv[2];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, p = i >> 3, key = c0 + p;
+            const bool ok = key < n;
+            const bf16_t* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + 8 * (i & 7);
+            pk[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + di));
+            pv[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + 2 * di));
+        }
+    };
+    request(0);
+    for (int c0 = 0; c0 < n; c0 += kKc) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, p = i >> 3, d0 = 8 * (i & 7);
+            *reinterpret_cast<uint4*>(Ks + p * kKPitch16 + 2 * d0) = pk[u];
+            const unsigned w[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<unsigned short*>(Vt + (d0 + e) * kVPitch16 + 2 * p) = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        }
+        __syncthreads();
+        if (c0 + kKc < n) request(c0 + kKc);
+        if (!wave_live) continue;
+        v4f st[QT][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 kb = *reinterpret_cast<const uint4*>(Ks + (16 * kt + j16) * kKPitch16 + 64 * ks + 16 * g);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][kt] = mfma16x16x32(kb, qb[t][ks], st[t][kt]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int key0 = c0 + 16 * kt + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (key0 + r >= n) st[t][kt][r] = -INFINITY;
+                    mx = fmaxf(mx, st[t][kt][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[t], mx);                                // finite: every chunk starts with a real key
+            const float alpha = __expf(m[t] - m_new);
+            m[t] = m_new;
+            float psum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[t][kt][r] = __expf(st[t][kt][r] - m_new); psum += st[t][kt][r]; }
+            l[t] = l[t] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[t][dt] = acc[t][dt] * alpha;
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            uint4 pb[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                pb[t] = make_uint4(gemm16::pack_bf16x2(st[t][2 * kp][0], st[t][2 * kp][1]), gemm16::pack_bf16x2(st[t][2 * kp][2], st[t][2 * kp][3]),
+                                   gemm16::pack_bf16x2(st[t][2 * kp + 1][0], st[t][2 * kp + 1][1]), gemm16::pack_bf16x2(st[t][2 * kp + 1][2], st[t][2 * kp + 1][3]));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned char* vr = Vt + (16 * dt + j16) * kVPitch16 + 2 * (32 * kp + 4 * g);
+                const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 32);
+                const uint4 vb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16x16x32(vb, pb[t], acc[t][dt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (!q_ok[t]) continue;
+        float lt = l[t];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float gv = gemm16::bf16_lo((unsigned)qkvg[qrow[t] * ldq + 3 * di + head]);
+        const float sc = (1.0f / (1.0f + expf(-gv))) / lt;                                  // sigmoid(gates) (:559) / softmax denominator
+        bf16_t* dst = ao + qrow[t] * di + head * kDh + 4 * g;                                // lane (g, j): dims 16 dt + 4 g + r of query j
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<uint2*>(dst + 16 * dt) = gemm16::pack_bf16x4(make_float4(acc[t][dt][0] * sc, acc[t][dt][1] * sc, acc[t][dt][2] * sc, acc[t][dt][3] * sc));
     }
 }
 
@@ -493,7 +719,10 @@ int mfail(std::string& err, int st, const std::string& msg) { err = msg; return 
         if (_e != hipSuccess) return mfail(err, ADE_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-struct TfW { const float *in_w, *in_b, *out_w, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *out_g; };
+struct TfW {
+    const float *in_w, *in_b, *out_w, *ff1_w, *ff1_b, *ff2_w, *ff2_b, *out_g;
+    const gemm16::bf16_t *in_w16, *out_w16, *ff1_w16, *ff2_w16;      // bf16 copies of the four Linear weights (bf16 path only)
+};
 
 }  // namespace
 
@@ -507,7 +736,11 @@ struct MelbandEngine : SubEngine {
     std::vector<TfW> time_tf, freq_tf;
     const int *gcol = nullptr, *off = nullptr, *csr_start = nullptr, *csr_col = nullptr, *csr_d = nullptr;
     BandTable bt{};
-    bool bf16 = false;             // ade_gemm_dtype = "bf16": every projection / FFN / mask-estimator GEMM on bf16 inputs (fp32 accumulation); STFT, attention core, norms, ISTFT fp32
+    bool bf16 = false;             // ade_gemm_dtype = "bf16": the transformer stack and the mask estimator on bf16 activations / weights stored in HBM (csrc/ade_gemm16.h, fp32 accumulation);
+                                   // STFT, band split, residual stream, norms, softmax statistics, GLU / mask, ISTFT stay fp32
+    gemm16::bf16_t* d_w16 = nullptr;   // bf16 path: arena of bf16 weights (the fp32 arena's Linear weights at the same offsets; me_w1t / me_w2t transposed to (out, in))
+    const gemm16::bf16_t *me_w1_16 = nullptr, *me_w2_16 = nullptr;
+    gemm16::bf16_t *Xb = nullptr, *Xc = nullptr, *A16 = nullptr, *B16 = nullptr, *AO16 = nullptr;
     int capacity = 0;
     float* ws = nullptr;
     float *Sp = nullptr, *X = nullptr, *invn = nullptr, *bufA = nullptr, *bufB = nullptr, *AO = nullptr, *YT = nullptr, *MS = nullptr,
@@ -518,6 +751,7 @@ struct MelbandEngine : SubEngine {
         if (d_w) (void)hipFree(d_w);
         if (d_i) (void)hipFree(d_i);
         if (d_ll) (void)hipFree(d_ll);
+        if (d_w16) (void)hipFree(d_w16);
         if (ws) (void)hipFree(ws);
     }
     int frames() const override { return T; }
@@ -529,7 +763,7 @@ struct MelbandEngine : SubEngine {
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
-    void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
+    void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs, bool last);
 };
 
 int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
@@ -712,12 +946,35 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
         hipMemcpy(e->d_i, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(e->d_ll, ll.data(), ll.size() * sizeof(long long), hipMemcpyHostToDevice) != hipSuccess)
         return bail(mfail(err, ADE_ERR_DEVICE, "upload of the band tables failed"));
+    if (bf16) {
+        // bf16 copies (round to nearest even) of every Linear weight at the SAME arena offsets; the mask estimator's first two Linears are stored (in, out) by the
+        // reference's fused buffers (me_w1t / me_w2t) and are transposed here to (out, in): csrc/ade_gemm16.h takes both operands with k contiguous.
+        if ((dim | di | ffd | med | ldq) & 7) return bail(mfail(err, ADE_ERR_UNSUPPORTED, "melband: ade_gemm_dtype = bf16 needs dim, dim_inner, the FFN and mask-estimator widths to be multiples of 8"));
+        auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+        std::vector<uint16_t> h16(arena, 0);
+        auto conv = [&](const Item& it) { for (size_t i = 0; i < it.n; ++i) h16[it.at + i] = to_bf16(it.src[i]); };
+        auto conv_t = [&](size_t at, const float* src, int batch, int K, int N) {      // [batch][K][N] -> [batch][N][K]
+            for (int z = 0; z < batch; ++z)
+                for (int k = 0; k < K; ++k)
+                    for (int n = 0; n < N; ++n) h16[at + ((size_t)z * N + n) * K + k] = to_bf16(src[((size_t)z * K + k) * N + n]);
+        };
+        for (const Item& it : items)
+            if (it.src != m1->data && it.src != m2->data && it.src != fwd.data() && it.src != inv.data()) conv(it);
+        conv_t(a_m1, m1->data, nb, dim, med);
+        conv_t(a_m2, m2->data, nb, med, med);
+        if (hipMalloc((void**)&e->d_w16, arena * sizeof(uint16_t)) != hipSuccess ||
+            hipMemcpy(e->d_w16, h16.data(), arena * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(mfail(err, ADE_ERR_DEVICE, "upload of the bf16 Mel-Band-Roformer weights failed"));
+        e->me_w1_16 = e->d_w16 + a_m1; e->me_w2_16 = e->d_w16 + a_m2;
+    }
     e->k_fwd = e->d_w + a_fwd; e->k_inv = e->d_w + a_inv; e->wsum = e->d_w + a_ws;
     e->tcos = e->d_w + a_tc; e->tsin = e->d_w + a_ts; e->fcos = e->d_w + a_fc; e->fsin = e->d_w + a_fs;
     e->me_w1t = e->d_w + a_m1; e->me_b1 = e->d_w + a_mb1; e->me_w2t = e->d_w + a_m2; e->me_b2 = e->d_w + a_mb2;
     for (size_t k = 0; k < tf_at.size(); ++k) {
         const TfAt& a = tf_at[k];
-        TfW w{e->d_w + a.v[0], e->d_w + a.v[1], e->d_w + a.v[2], e->d_w + a.v[3], e->d_w + a.v[4], e->d_w + a.v[5], e->d_w + a.v[6], e->d_w + a.v[7]};
+        const gemm16::bf16_t* w16 = e->d_w16;     // null on the fp32 path
+        TfW w{e->d_w + a.v[0], e->d_w + a.v[1], e->d_w + a.v[2], e->d_w + a.v[3], e->d_w + a.v[4], e->d_w + a.v[5], e->d_w + a.v[6], e->d_w + a.v[7],
+              w16 ? w16 + a.v[0] : nullptr, w16 ? w16 + a.v[2] : nullptr, w16 ? w16 + a.v[3] : nullptr, w16 ? w16 + a.v[5] : nullptr};
         (k & 1 ? e->freq_tf : e->time_tf).push_back(w);
     }
     e->gcol = e->d_i + i_gcol; e->off = e->d_i + i_off; e->csr_start = e->d_i + i_cs; e->csr_col = e->d_i + i_cc; e->csr_d = e->d_i + i_cd;
@@ -736,36 +993,55 @@ int MelbandEngine::reserve(int batch, std::string& err) {
     const size_t BT = (size_t)batch * n_win * T, R = (size_t)nb * BT;
     const size_t wide = (size_t)(3 * di + heads) > (size_t)med ? (size_t)(3 * di + heads) : (size_t)med;
     const size_t hid = (size_t)ffd > (size_t)med ? (size_t)ffd : (size_t)med;
-    const size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
-                              (size_t)kChan * BT * kNfftM, (size_t)kFc * 2 * BT};
+    size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
+                        (size_t)kChan * BT * kNfftM, (size_t)kFc * 2 * BT};
+    if (bf16) {      // room for the bf16 stream copies behind the bf16 views of bufA and AO (see below; already there whenever dim <= the buffer's own width)
+        sizes[3] = std::max(sizes[3], (((R * wide + 63) & ~(size_t)63) + R * dim) / 2 + 64);
+        sizes[5] = std::max(sizes[5], (((R * di + 63) & ~(size_t)63) + R * dim) / 2 + 64);
+    }
     size_t total = 0;
     for (size_t s : sizes) total += (s + 63) & ~(size_t)63;
     MB_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
     float** ptrs[10] = {&Sp, &X, &invn, &bufA, &bufB, &AO, &YT, &MS, &frames_buf, &mask_tap};
     size_t at = 0;
     for (int i = 0; i < 10; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
+    if (bf16) {      // the bf16 activations live in the fp32 path's buffers (each at most half their size): q | k | v | gates in bufA with the normalised stream copy Xb behind it,
+                     // the hidden activations in bufB, the attention output in AO with the mask estimator's input copy Xc behind it
+        A16 = reinterpret_cast<gemm16::bf16_t*>(bufA); Xb = A16 + ((R * wide + 63) & ~(size_t)63);
+        B16 = reinterpret_cast<gemm16::bf16_t*>(bufB);
+        AO16 = reinterpret_cast<gemm16::bf16_t*>(AO); Xc = AO16 + ((R * di + 63) & ~(size_t)63);
+    }
     capacity = batch;
     return ADE_OK;
 }
 
 void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc,
-                                const float* rs) {
+                                const float* rs, bool last /* the mask estimator follows: it takes a bf16 copy of the result on the bf16 path */) {
     using namespace gemm;
     const int ldq = 3 * di + heads;
-    // invn holds 1 / |x_row| on entry (written by whoever produced X)
-    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, RotaryQkStore{bufA, invn, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim, bf16);   // (:547-548, :552)
-    const dim3 g2((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), g1((unsigned)nseq, (unsigned)heads, 1);            // (:549-560)
-    if (n > 64) {
-        if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<2, true>), g2, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<2, false>), g2, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
-    } else {
-        if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<1, true>), g1, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<1, false>), g1, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    if (bf16) {      // Xb = bf16(x / |x|) on entry (written by whoever produced X)
+        const dim3 rows4((unsigned)((R + 3) / 4));
+        gemm16::launch(s, Xb, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim);                 // (:547-548, :552)
+        if (n > 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<2>), dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s,
+                                       (const gemm16::bf16_t*)A16, AO16, n, seq_stride, pos_stride, ldq, di);                                            // (:549-560)
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<1>), dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const gemm16::bf16_t*)A16, AO16, n,
+                                seq_stride, pos_stride, ldq, di);
+        gemm16::launch(s, AO16, di, w.out_w16, di, ResidualStore16{X, nullptr, dim}, R, dim, di);                                                        // (:561, :569)
+        hipLaunchKernelGGL(k_row_norm16, rows4, dim3(256), 0, s, (const float*)X, Xb, R, dim);
+        gemm16::launch(s, Xb, dim, w.ff1_w16, dim, BiasActStore16<0>{B16, w.ff1_b, ffd}, R, ffd, dim);                                                   // (:564)
+        gemm16::launch(s, B16, ffd, w.ff2_w16, ffd, ResidualStore16{X, w.ff2_b, dim}, R, dim, ffd);                                                      // (:565, :570)
+        hipLaunchKernelGGL(k_row_normalize_gain16, rows4, dim3(256), 0, s, X, w.out_g, Xb, last ? Xc : nullptr, R, dim);                                 // (:571)
+        return;
     }
-    launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di, bf16);                               // (:561, :569)
+    // invn holds 1 / |x_row| on entry (written by whoever produced X)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.in_w, dim}, RotaryQkStore{bufA, invn, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim);   // (:547-548, :552)
+    const dim3 g2((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), g1((unsigned)nseq, (unsigned)heads, 1);            // (:549-560)
+    if (n > 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<2>), g2, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<1>), g1, dim3(256), 0, s, (const float*)bufA, AO, n, seq_stride, pos_stride, ldq, di);
+    launch(s, RowMajorA{AO, di}, WeightNK{w.out_w, di}, ResidualStore{X, nullptr, dim}, R, dim, di);                               // (:561, :569)
     hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
-    launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim, bf16);               // (:564)
-    launch(s, RowMajorA{bufB, ffd}, WeightNK{w.ff2_w, ffd}, ResidualStore{X, w.ff2_b, dim}, R, dim, ffd, bf16);                          // (:565, :570)
+    launch(s, RowMajorA{X, dim}, WeightNK{w.ff1_w, dim}, ScaleBiasGeluStore{bufB, invn, w.ff1_b, ffd}, R, ffd, dim);               // (:564)
+    launch(s, RowMajorA{bufB, ffd}, WeightNK{w.ff2_w, ffd}, ResidualStore{X, w.ff2_b, dim}, R, dim, ffd);                          // (:565, :570)
     hipLaunchKernelGGL(k_row_normalize_gain, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, X, w.out_g, invn, R, dim);            // (:571)
 }
 
@@ -780,17 +1056,24 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     else launch(s, RowMajorA{k_fwd, kNfftM}, StereoFrameB<int16_t>{d_in, L, T, n_win}, BinStore{Sp, T, BT}, 2 * kBinsM, J, kNfftM);
     // band split                                                                                                                   (:597-599)
     hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
-    launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim, bf16);
-    hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
+    launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim);     // fp32 on both paths (the front)
+    if (bf16) hipLaunchKernelGGL(k_row_norm16, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, Xb, R, dim);
+    else hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     // axial transformers: time = T consecutive rows per (band, clip); frequency = nb rows B*T apart per (clip, frame)              (:609-614)
     for (int i = 0; i < depth; ++i) {
-        transformer(s, time_tf[i], R, T, nb * B, (long long)T, 1LL, tcos, tsin);
-        transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin);
+        transformer(s, time_tf[i], R, T, nb * B, (long long)T, 1LL, tcos, tsin, false);
+        transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin, i + 1 == depth);
     }
     // mask estimator: per band 384 -> 1536 -> 1536 (tanh) -> 2 d_i, kept raw and column-major for the GLU / scatter kernel         (:579-585)
-    launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med, bf16);
-    launch_batched(s, MeHiddenProb{bufB, me_w2t, me_b2, bufA, BT, med, med}, nb, BT, med, bf16);
-    launch_batched(s, MeOutProb{bufA, d_w, bt, YT, BT, med}, nb, BT, 2 * max_d, bf16);
+    if (bf16) {
+        gemm16::launch_batched(s, MeHiddenProb16{Xc, me_w1_16, me_b1, B16, BT, dim, med}, nb, BT, med);
+        gemm16::launch_batched(s, MeHiddenProb16{B16, me_w2_16, me_b2, A16, BT, med, med}, nb, BT, med);
+        gemm16::launch_batched(s, MeOutProb16{A16, d_w16, d_w, bt, YT, BT, med}, nb, 2 * max_d, BT);
+    } else {
+        launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med);
+        launch_batched(s, MeHiddenProb{bufB, me_w2t, me_b2, bufA, BT, med, med}, nb, BT, med);
+        launch_batched(s, MeOutProb{bufA, d_w, bt, YT, BT, med}, nb, BT, 2 * max_d);
+    }
     hipLaunchKernelGGL(k_mask_apply, dim3((unsigned)((BT + 255) / 256), (unsigned)kFc), dim3(256), 0, s, (const float*)Sp, (const float*)YT, csr_start, csr_col,
                        csr_d, MS, mask_tap, B, T);                                                                                  // (:616-624)
     // synthesis GEMM + overlap-add + PCM tail                                                                                      (:661, :667-676)

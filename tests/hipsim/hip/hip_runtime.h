@@ -178,6 +178,45 @@ static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hipsim_v4s a,
                 d[r] = fmaf(bf(all_a[q >> 1][(4 * g + r) + 16 * kg], q & 1), bf(all_b[q >> 1][j + 16 * kg], q & 1), d[r]);
     return d;
 }
+// gfx950 v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k of its row as eight bf16 (csrc/ade_gemm16.h documents the maps);
+// D = A B + C in fp32, accumulated k-ordered here (products of bf16 values are exact in fp32).
+typedef short hipsim_v8s __attribute__((vector_size(16)));
+typedef float hipsim_v16f __attribute__((vector_size(64)));
+static inline float hipsim_bf16_of(const uint32_t (*all)[64], int lane, int e) {
+    const uint32_t w = all[e >> 1][lane], u = ((e & 1) ? (w >> 16) : (w & 0xffffu)) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static inline void hipsim_gather8(hipsim_v8s a, hipsim_v8s b, uint32_t (*all_a)[64], uint32_t (*all_b)[64]) {
+    uint32_t aw[4], bw[4];
+    std::memcpy(aw, &a, 16);
+    std::memcpy(bw, &b, 16);
+    for (int q = 0; q < 4; ++q) ::hipsim::wave_allgather2(aw[q], bw[q], all_a[q], all_b[q]);
+}
+static inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipsim_v8s a, hipsim_v8s b, hipsim_v16f c, int, int, int) {
+    const int lane = ::hipsim::lane_id(), j = lane & 31, h = lane >> 5;
+    uint32_t all_a[4][64], all_b[4][64];
+    hipsim_gather8(a, b, all_a, all_b);
+    hipsim_v16f d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int k = 0; k < 16; ++k) d[r] = fmaf(hipsim_bf16_of(all_a, i + 32 * (k >> 3), k & 7), hipsim_bf16_of(all_b, j + 32 * (k >> 3), k & 7), d[r]);
+    }
+    return d;
+}
+static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipsim_v8s a, hipsim_v8s b, hipsim_v4f c, int, int, int) {
+    const int lane = ::hipsim::lane_id(), j = lane & 15, g = lane >> 4;
+    uint32_t all_a[4][64], all_b[4][64];
+    hipsim_gather8(a, b, all_a, all_b);
+    hipsim_v4f d = c;
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 32; ++k) d[r] = fmaf(hipsim_bf16_of(all_a, (4 * g + r) + 16 * (k >> 3), k & 7), hipsim_bf16_of(all_b, j + 16 * (k >> 3), k & 7), d[r]);
+    return d;
+}
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline unsigned __float_as_uint(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }

@@ -269,8 +269,10 @@ def test_gpu_production_size_clips_match_reference(tag):
 
 
 @pytest.mark.gpu
-def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
-    """ade_gemm_dtype = "bf16" (bf16 inputs, fp32 accumulation in every projection / FFN / mask-estimator GEMM): a throughput mode, NOT the parity path."""
+def test_gpu_bf16_path_stays_close_to_f32(fixture):
+    """ade_gemm_dtype = "bf16": the transformer stack and the mask estimator on bf16 activations and weights STORED in HBM (csrc/ade_gemm16.h, the bf16 attention core), fp32
+    residual stream / norms / softmax statistics / front and back ends.  A throughput path (BASELINE.json configs[3] names bf16), NOT the parity path: gated on its distance from
+    the fp32 path on the reference-run fixture -- transformer output tokens and the waveform."""
     from audio_denoiser_onnx_amd import melband
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.weights import pack_blob
@@ -280,10 +282,14 @@ def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
     with InferenceSession(weights=blob, metadata=melband.metadata(L)) as a, InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype="bf16")) as b:
         _, fa = a.process(z["pcm_in"].reshape(1, -1), want_f32=True)
         _, fb = b.process(z["pcm_in"].reshape(1, -1), want_f32=True)
-    err, sig = fb.astype(np.float64) - fa, fa.astype(np.float64)
-    snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
-    print(f"mel_band_roformer bf16 vs f32: SNR {snr:.1f} dB")
-    assert snr > 20.0
+        T = int(z["frames"])
+        ta, tb = a.tap("tokens", 60 * T * 384), b.tap("tokens", 60 * T * 384)
+    def snr_db(x, ref):
+        err, sig = x.astype(np.float64) - ref, ref.astype(np.float64)
+        return 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
+    snr, snr_tok = snr_db(fb, fa), snr_db(tb, ta)
+    print(f"mel_band_roformer bf16 vs f32: waveform SNR {snr:.1f} dB, transformer tokens SNR {snr_tok:.1f} dB")
+    assert np.isfinite(fb).all() and snr > 30.0 and snr_tok > 25.0
 
 
 @pytest.mark.gpu

@@ -1,0 +1,79 @@
+// Unit check of csrc/ade_gemm16.h (TEST INFRASTRUCTURE): C = A B^T on bf16 operands against a double-precision host product.
+// Built two ways by tests/test_gemm16.py: g++ + tests/hipsim (CPU, small shapes) and hipcc --offload-arch=gfx950 (GPU).
+//   usage: gemm16_unit M N K [M N K ...]      exit status 0 = every case within tolerance
+#include <hip/hip_runtime.h>
+
+#include "../../audio_denoiser_onnx_amd/csrc/ade_gemm16.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace ade::gemm16;
+
+struct PlainStore {            // C[m][n] = v (fp32, row-major) and Cb[m][n] = bf16(v + bias[n])
+    float* c;
+    bf16_t* cb;
+    const float* bias;
+    int ld;
+    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+        store_f32x4(c + (size_t)m * ld + n, v, cnt);
+        const float4 b = load_f32x4(bias + n, cnt);
+        store_bf16x4(cb + (size_t)m * ld + n, make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w), cnt);
+    }
+};
+
+static unsigned short to_bf16(float x) { unsigned u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+static float from_bf16(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static int run_case(int M, int N, int K) {
+    const int lda = K + 8, ldb = K, ldc = ((N + 3) / 4) * 4 + 4;
+    std::vector<unsigned short> A((size_t)M * lda), B((size_t)N * ldb);
+    std::vector<float> bias(ldc);
+    unsigned s = 12345u + M * 7 + N * 3 + K;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : A) v = to_bf16(rnd());
+    for (auto& v : B) v = to_bf16(rnd() * 0.5f);
+    for (auto& v : bias) v = rnd();
+    unsigned short *dA, *dB, *dCb;
+    float *dC, *dbias;
+    hipMalloc((void**)&dA, A.size() * 2); hipMalloc((void**)&dB, B.size() * 2);
+    hipMalloc((void**)&dC, (size_t)M * ldc * 4); hipMalloc((void**)&dCb, (size_t)M * ldc * 2); hipMalloc((void**)&dbias, ldc * 4);
+    hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dbias, bias.data(), ldc * 4, hipMemcpyHostToDevice);
+    hipMemset(dC, 0xff, (size_t)M * ldc * 4); hipMemset(dCb, 0xff, (size_t)M * ldc * 2);
+    launch((hipStream_t)0, dA, lda, dB, ldb, PlainStore{dC, dCb, dbias, ldc}, M, N, K);
+    hipDeviceSynchronize();
+    std::vector<float> C((size_t)M * ldc);
+    std::vector<unsigned short> Cb((size_t)M * ldc);
+    hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(Cb.data(), dCb, Cb.size() * 2, hipMemcpyDeviceToHost);
+    double worst = 0.0, worst_b = 0.0;
+    int bad_pad = 0;
+    for (int m = 0; m < M; ++m) {
+        for (int n = 0; n < ldc; ++n) {
+            if (n >= N) {       // padding columns must be untouched
+                unsigned u; memcpy(&u, &C[(size_t)m * ldc + n], 4);
+                if (u != 0xffffffffu || Cb[(size_t)m * ldc + n] != 0xffff) ++bad_pad;
+                continue;
+            }
+            double ref = 0.0;
+            for (int k = 0; k < K; ++k) ref += (double)from_bf16(A[(size_t)m * lda + k]) * (double)from_bf16(B[(size_t)n * ldb + k]);
+            worst = fmax(worst, fabs(ref - (double)C[(size_t)m * ldc + n]));
+            worst_b = fmax(worst_b, fabs(ref + bias[n] - (double)from_bf16(Cb[(size_t)m * ldc + n])) / (1.0 + fabs(ref + bias[n])));
+        }
+    }
+    const double tol = 2e-6 * K + 1e-5;
+    const bool ok = worst <= tol && worst_b <= 0.0045 && bad_pad == 0;
+    printf("gemm16 M=%d N=%d K=%d: max|d| fp32 %.3e (tol %.1e), bf16 rel %.3e, touched padding %d -> %s\n", M, N, K, worst, tol, worst_b, bad_pad, ok ? "OK" : "FAIL");
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
+    return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+    int rc = 0;
+    if (argc < 4) { rc |= run_case(130, 70, 72); return rc; }
+    for (int i = 1; i + 2 < argc; i += 3) rc |= run_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
+    return rc;
+}
