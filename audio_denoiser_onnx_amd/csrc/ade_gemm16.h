@@ -13,7 +13,8 @@
 //   * the tile is computed TRANSPOSED (MFMA A operand = rows of B, MFMA B operand = rows of A), so a lane's accumulator registers are runs of four consecutive n of
 //     one row m; the epilogue passes the tile through LDS (fp32, 64 rows at a time) and hands the store functor whole float4s (m, n .. n + 3) with consecutive lanes on
 //     consecutive n: every read the store makes (bias, rotary table, the old value of a residual) and every write it makes is a full-line access, whatever the output type.
-// Store functor:  __device__ void operator()(int m, int n, float4 v, int cnt) const;     n % 4 == 0, cnt = min(4, N - n) valid columns
+// Store functor:  ColT col(int n, int cnt) const;                                      what it reads per column group (bias ...), fetched once per thread
+//                 __device__ void operator()(int m, int n, float4 v, int cnt, const ColT&) const;     n % 4 == 0, cnt = min(4, N - n) valid columns
 // K % 8 == 0, lda % 8 == 0, ldb % 8 == 0 and 16-byte aligned bases are required (checked by the launchers' callers); M, N are free.
 #pragma once
 #include "ade_device.h"
@@ -84,31 +85,35 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
 
     // staging map: lane = (row, 16-byte piece): 8 lanes read one row's 128-byte line; rows r, r + 32, r + 64, r + 96
     const int sr = tid >> 3, sc = tid & 7;
-    const bf16_t* ap[4];
-    const bf16_t* bp[4];
+    // (addresses = a wave-uniform tile base + a 32-bit lane offset: eight 64-bit lane pointers would cost 16 registers at the 128-register ceiling)
+    const bf16_t* At = A + (size_t)m_blk * lda;
+    const bf16_t* Bt = B + (size_t)n_blk * ldb;
+    int ao[4], bo[4];
     bool aok[4], bok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int m = m_blk + sr + 32 * u, n = n_blk + sr + 32 * u;
-        aok[u] = m < M;
-        bok[u] = n < N;
-        ap[u] = A + (size_t)(aok[u] ? m : M - 1) * lda;                // out-of-range rows: an in-range address, zeroed after the load (no branch around a load)
-        bp[u] = B + (size_t)(bok[u] ? n : N - 1) * ldb;
+        const int r = sr + 32 * u;
+        aok[u] = m_blk + r < M;
+        bok[u] = n_blk + r < N;
+        ao[u] = (aok[u] ? r : M - 1 - m_blk) * lda;                    // out-of-range rows: an in-range address, zeroed after the load (no branch around a load)
+        bo[u] = (bok[u] ? r : N - 1 - n_blk) * ldb;
     }
-    uint4 ra[4], rb[4];
-    auto fetch = [&](int k0) {
+    // (Two register sets -- slab k + 2 requested while slab k is multiplied -- were measured SLOWER: 150+ registers cost the fourth resident workgroup, 268.9 -> 279.0 ms
+    //  per Mel-Band step; what bounds this loop is the CU's 64 B / clk vector-memory path, which a 128 x 128 x 64 slab step loads exactly as fast as it multiplies.)
+    uint4 ra[1][4], rb[1][4];
+    auto fetch = [&](int k0, int set) {
         const bool kok = k0 + 8 * sc < K;                                // K % 8 == 0: a piece is all in or all out
         const int ko = kok ? k0 + 8 * sc : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ra[u] = zero_unless(aok[u] && kok, *reinterpret_cast<const uint4*>(ap[u] + ko));
+        for (int u = 0; u < 4; ++u) ra[set][u] = zero_unless(aok[u] && kok, *reinterpret_cast<const uint4*>(At + (ao[u] + ko)));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rb[u] = zero_unless(bok[u] && kok, *reinterpret_cast<const uint4*>(bp[u] + ko));
+        for (int u = 0; u < 4; ++u) rb[set][u] = zero_unless(bok[u] && kok, *reinterpret_cast<const uint4*>(Bt + (bo[u] + ko)));
     };
-    auto stash = [&]() {
+    auto stash = [&](int set) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            *reinterpret_cast<uint4*>(As + (sr + 32 * u) * kPitch + 16 * sc) = ra[u];
-            *reinterpret_cast<uint4*>(Bs + (sr + 32 * u) * kPitch + 16 * sc) = rb[u];
+            *reinterpret_cast<uint4*>(As + (sr + 32 * u) * kPitch + 16 * sc) = ra[set][u];
+            *reinterpret_cast<uint4*>(Bs + (sr + 32 * u) * kPitch + 16 * sc) = rb[set][u];
         }
     };
     // MFMA operand layout (32x32x16): lane l supplies row (l & 31), k = 8 (l >> 5) .. + 7 of the 16-deep step.  MFMA-A = rows of B (n), MFMA-B = rows of A (m):
@@ -127,11 +132,11 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(fb[j], fa[i], acc[i][j]);
         }
     };
-    fetch(0);
+    fetch(0, 0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
-        stash();
+        stash(0);
         __syncthreads();
-        if (k0 + kTK < K) fetch(k0 + kTK);
+        if (k0 + kTK < K) fetch(k0 + kTK, 0);
         compute();
         __syncthreads();
     }
@@ -150,11 +155,16 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                             make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
         __syncthreads();
+        {   // lane = (row tid >> 5 (+ 8 u), float4 column tid & 31): the column, and whatever the store reads per column (bias), is the same for a thread's 8 rows
+            const int c4 = tid & 31, n = n_blk + 4 * c4, cnt = N - n < 4 ? N - n : 4;
+            if (n < N) {
+                const auto cc = store.col(n, cnt);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = tid + 256 * u, row = idx >> 5, c4 = idx & 31;
-            const int m = m_blk + 64 * half + row, n = n_blk + 4 * c4;
-            if (m < M && n < N) store(m, n, *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4), N - n < 4 ? N - n : 4);
+                for (int u = 0; u < 8; ++u) {
+                    const int row = (tid >> 5) + 8 * u, m = m_blk + 64 * half + row;
+                    if (m < M) store(m, n, *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4), cnt, cc);
+                }
+            }
         }
         __syncthreads();
     }
@@ -167,7 +177,7 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
 }
 
 template <class ST>
-__global__ __launch_bounds__(256, 3) void k_gemm16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, ST store, int M, int N, int K) {
+__global__ __launch_bounds__(256, 4) void k_gemm16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
     const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
     gemm_tile(A, lda, B, ldb, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, lds);
@@ -183,7 +193,7 @@ inline void launch(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int
 template <class ST>
 struct Prob { const bf16_t* A; int lda; const bf16_t* B; int ldb; ST st; int M, N, K; };
 template <class P>
-__global__ __launch_bounds__(256, 3) void k_gemm16_batched(P prob) {
+__global__ __launch_bounds__(256, 4) void k_gemm16_batched(P prob) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
     const int gx = (int)gridDim.x, gy = (int)gridDim.y;
     const int id = xcd_contiguous_id((int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z), gx * gy * (int)gridDim.z);
@@ -200,6 +210,28 @@ inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, i
 }
 
 // ---- common stores ------------------------------------------------------------------------------------------------------
+struct NoCol {};
+// n / d for 0 <= n < 2^31 and a divisor fixed per launch: one v_mul_hi_u32 and a correction instead of the ~40-instruction division sequence.
+// mul = floor(2^32 / d) + 1 over-estimates 2^32 / d by less than 1 / d relative, so the estimate is floor(n / d) or one more (n < 2^32).
+struct FastDiv {
+    unsigned d, mul;
+    __device__ int div(int n) const {
+        if (d == 1u) return n;
+        unsigned q = __umulhi((unsigned)n, mul);
+        if (q * d > (unsigned)n) --q;
+        return (int)q;
+    }
+};
+inline FastDiv make_fastdiv(int d) { return FastDiv{(unsigned)d, d > 1 ? (unsigned)(0x100000000ull / (unsigned)d) + 1u : 0u}; }
+// erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26) on the hardware exp and reciprocal: the bf16 path rounds what follows to 8 mantissa bits, erff()'s ~40 instructions
+// per element are what bound a K = 384 product's epilogue
+__device__ __forceinline__ float erf_fast(float x) {
+    const float a = fabsf(x), t = fast_rcp(fmaf(0.3275911f, a, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float r = 1.0f - poly * __expf(-a * a);
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ void store_bf16x4(bf16_t* p, const float4& v, int cnt) {       // p 8-byte aligned when cnt == 4
     if (cnt == 4) { *reinterpret_cast<uint2*>(p) = pack_bf16x4(v); return; }
     const float t[4] = {v.x, v.y, v.z, v.w};

@@ -426,12 +426,13 @@ struct RotaryQkStore16 {       // q | k | v | gates = Xb W_in^T + b_in, rotary o
     bf16_t* out;
     const float* bias;
     const float *rcos, *rsin;  // [position][kDh], rotate_half's sign folded into rsin
-    int ld, rot_cols, pos_stride, n_pos;
-    __device__ void operator()(int m, int n, float4 v, int cnt) const {
-        const float4 b = gemm16::load_f32x4(bias + n, cnt);
+    int ld, rot_cols;
+    gemm16::FastDiv pos_stride, n_pos;      // position of row m = (m / pos_stride) % n_pos
+    __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
         float4 u = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
         if (n < rot_cols) {                                          // rot_cols % 4 == 0: a float4 is rotated whole or not at all
-            const int at = ((m / pos_stride) % n_pos) * kDh + (n & (kDh - 1));
+            const int q = pos_stride.div(m), at = (q - n_pos.div(q) * (int)n_pos.d) * kDh + (n & (kDh - 1));
             const float4 c = *reinterpret_cast<const float4*>(rcos + at), sn = *reinterpret_cast<const float4*>(rsin + at);
             u = make_float4(__fmaf_rn(u.x, c.x, __fmul_rn(u.y, sn.x)), __fmaf_rn(u.y, c.y, __fmul_rn(u.x, sn.y)),
                             __fmaf_rn(u.z, c.z, __fmul_rn(u.w, sn.z)), __fmaf_rn(u.w, c.w, __fmul_rn(u.z, sn.w)));
@@ -444,9 +445,9 @@ struct BiasActStore16 {        // act(v + bias[n]) -> bf16
     bf16_t* out;
     const float* bias;
     int ld;
-    __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)) : tanhf(x); }
-    __device__ void operator()(int m, int n, float4 v, int cnt) const {
-        const float4 b = gemm16::load_f32x4(bias + n, cnt);
+    __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f)) : tanh_f(x); }
+    __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
         gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(v.x + b.x), act(v.y + b.y), act(v.z + b.z), act(v.w + b.w)), cnt);
     }
 };
@@ -454,18 +455,19 @@ struct ResidualStore16 {       // x[m][n] += v (+ bias[n]), fp32 residual stream
     float* x;
     const float* bias;         // may be null
     int ld;
-    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+    __device__ float4 col(int n, int cnt) const { return bias ? gemm16::load_f32x4(bias + n, cnt) : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
         float* p = x + (size_t)m * ld + n;
         const float4 old = gemm16::load_f32x4(p, cnt);
-        if (bias) { const float4 b = gemm16::load_f32x4(bias + n, cnt); v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w); }
-        gemm16::store_f32x4(p, make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w), cnt);
+        gemm16::store_f32x4(p, make_float4(old.x + (v.x + b.x), old.y + (v.y + b.y), old.z + (v.z + b.z), old.w + (v.w + b.w)), cnt);
     }
 };
 struct RowBiasStoreF32 {       // yt[m][n] = v + bias[m], fp32 row-major with any ld (the mask estimator's last Linear computed transposed: rows = output columns, n = bt)
     float* yt;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+    __device__ gemm16::NoCol col(int, int) const { return gemm16::NoCol{}; }
+    __device__ void operator()(int m, int n, float4 v, int cnt, gemm16::NoCol) const {
         const float b = bias[m];
         float* p = yt + (size_t)m * ld + n;
         const float4 r = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
@@ -1021,7 +1023,7 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     const int ldq = 3 * di + heads;
     if (bf16) {      // Xb = bf16(x / |x|) on entry (written by whoever produced X)
         const dim3 rows4((unsigned)((R + 3) / 4));
-        gemm16::launch(s, Xb, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, ldq, 2 * di, (int)pos_stride, n}, R, ldq, dim);                 // (:547-548, :552)
+        gemm16::launch(s, Xb, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, ldq, 2 * di, gemm16::make_fastdiv((int)pos_stride), gemm16::make_fastdiv(n)}, R, ldq, dim);                 // (:547-548, :552)
         if (n > 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<2>), dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s,
                                        (const gemm16::bf16_t*)A16, AO16, n, seq_stride, pos_stride, ldq, di);                                            // (:549-560)
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<1>), dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const gemm16::bf16_t*)A16, AO16, n,

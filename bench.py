@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--other-cpu-seconds", type=float, default=60.0, help="budget of the CPU-oracle legs of the `other_workloads` block (0 = skip them)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-deviation", action="store_true", help="skip the bf16-vs-f32 deviation run of a --dtype bf16 line (profiling runs)")
     ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1", "2"],
                     help="GTCRN fused-path workgroup geometry: 2 = four 256-thread workgroups per CU, each a 16-frame segment of a chunk (default where it fits); "
                          "1 = two 512-thread workgroups per CU (32-frame segments); 0 = one 1024-thread workgroup per chunk (the round-1/2 kernel)")
@@ -194,8 +195,13 @@ def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, w
             "rtf": round(dt / seconds_per_row, 4)}
 
 
+SKIP_DEVIATION = False
+
+
 def deviation_from_f32(make_session, x, rows: int = 2):
     """What the reduced-precision GEMM inputs cost: the same rows through the exact (f32) path and the selected one."""
+    if SKIP_DEVIATION:
+        return None
     with make_session("f32") as ref:
         want, wf = ref.process(x[:rows], want_f32=True)
     with make_session("bf16") as low:
@@ -255,8 +261,10 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
                                       "one 1 s stereo clip, 101 frames x 60 bands, depth 6 -- a shorter clip than the 8 s workload rows")
         return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=cpu, deviation=deviation,
                     metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
-                    workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), fp32 matrix cores, int16 PCM resident in HBM "
-                             "(BASELINE.json configs[3]; bf16 there, fp32 here)",
+                    workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), " +
+                             ("bf16 activations and weights stored in HBM, v_mfma_f32_32x32x16_bf16 / 16x16x32 (csrc/ade_gemm16.h), fp32 residual stream / norms / softmax "
+                              "statistics / STFT / band split / mask / ISTFT" if dtype == "bf16" else "fp32 matrix cores (the parity dtype; --dtype bf16 is the configs[3] dtype)") +
+                             ", int16 PCM resident in HBM (BASELINE.json configs[3])",
                     weights="random-init weights of the architecture (melband.synthetic_spec, depth 6)", target_rtf=None)
     if name == "mossformer":                                       # BASELINE configs[4]: 64 x 4 s
         from audio_denoiser_onnx_amd import mossformer
@@ -289,7 +297,9 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
 
 
 def main():
+    global SKIP_DEVIATION
     args = parse_args()
+    SKIP_DEVIATION = args.no_deviation
     import torch
     import torch.distributed as dist
 
@@ -543,14 +553,19 @@ def main():
             line["other_workloads"] = others
         if not gtcrn and wl.get("target_rtf"):
             line["target_rtf"] = wl["target_rtf"]
-        if not gtcrn and wl.get("deviation"):
-            line["deviation_from_f32"] = wl["deviation"]
+        if not gtcrn and args.dtype == "bf16":
+            line["deviation_from_f32"] = wl.get("deviation")
             roofline["frac_of_f32_peak"] = roofline["frac"]                    # comparability with the f32 line (can exceed 1: bf16 inputs run on a faster pipe)
             roofline["peak"] = BF16_PEAK_TFLOPS
             roofline["frac"] = round(roofline["achieved"] / BF16_PEAK_TFLOPS, 4)
-            roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); operands stay fp32 in HBM and are rounded on "
-                                     "their way into LDS, so the GEMMs are bound by operand traffic / staging, not by the matrix cores; attention cores, norms, "
-                                     "front / back ends stay fp32")
+            if args.workload == "melband":
+                roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); bf16 operands stored in HBM, 32x32x16 / 16x16x32 "
+                                         "bf16 matrix instructions; at K = 384 .. 1536 and 1.5 M rows the products are bound by the CU's vector-memory path and their epilogues, "
+                                         "not by the matrix cores (DESIGN.md section 6c)")
+            else:
+                roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); operands stay fp32 in HBM and are rounded on "
+                                         "their way into LDS, so the GEMMs are bound by operand traffic / staging, not by the matrix cores; attention cores, norms, "
+                                         "front / back ends stay fp32")
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -217,6 +217,7 @@ static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipsim_v8s a, h
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline unsigned __float_as_uint(float x) { unsigned u; std::memcpy(&u, &x, 4); return u; }

@@ -18,9 +18,9 @@ struct PlainStore {            // C[m][n] = v (fp32, row-major) and Cb[m][n] = b
     bf16_t* cb;
     const float* bias;
     int ld;
-    __device__ void operator()(int m, int n, float4 v, int cnt) const {
+    __device__ float4 col(int n, int cnt) const { return load_f32x4(bias + n, cnt); }
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
         store_f32x4(c + (size_t)m * ld + n, v, cnt);
-        const float4 b = load_f32x4(bias + n, cnt);
         store_bf16x4(cb + (size_t)m * ld + n, make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w), cnt);
     }
 };
