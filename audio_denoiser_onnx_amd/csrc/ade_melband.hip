@@ -416,21 +416,56 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 }
 
 // ---- bf16 path (ade_gemm_dtype = "bf16"): bf16 activations and weights STORED in HBM, v_mfma_f32_32x32x16_bf16 / 16x16x32 products, fp32 islands ------------
-// What stays fp32: the STFT / ISTFT GEMMs and the band-split GEMM (the front and the PCM tail), the residual stream X and every norm over it, the softmax
-// statistics and all accumulators, biases, rotary tables, the raw mask-estimator output YT and the GLU / scatter / complex mask.  What is bf16: the normalised
-// copy Xb of the residual stream that feeds the in-projection and the first FFN Linear, q | k | v | gates, the attention output, the FFN and mask-estimator
-// hidden activations, and every Linear weight.  Stores of csrc/ade_gemm16.h: (m, n .. n + 3) float4s, consecutive lanes on consecutive n.
+// What stays fp32: the STFT / ISTFT GEMMs and the band-split GEMM (the front and the PCM tail), the residual stream X and the norms over it, the softmax
+// statistics and all accumulators, biases, rotary tables, the raw mask-estimator output YT and the GLU / scatter / complex mask.  What is bf16: the operand copies
+// of the residual stream that feed the in-projection, the first FFN Linear and the mask estimator, q | k | v | gates, the attention output, the FFN and
+// mask-estimator hidden activations, and every Linear weight.  Stores of csrc/ade_gemm16.h: (m, n .. n + 3) float4s, consecutive lanes on consecutive n.
 using gemm16::bf16_t;
 
-struct RotaryQkStore16 {       // q | k | v | gates = Xb W_in^T + b_in, rotary on the q and k blocks (:547-548, :552), -> bf16
+// The norms of the reference's transformer (:533-538, :571) never run as passes of their own on this path.  A transformer maps the stream x to
+//     x1 = x + W_o attn(n(x)),   x2 = x1 + FF(n(x1)),   y = n(x2) * g          with n(v) = v / max(|v|_2, 1e-12) per row,
+// and every n() is a ROW SCALAR: the product with a normalised operand is the product with the raw operand times that scalar, applied to the accumulator by the store.
+// So the residual stream X holds the UN-normalised x2 of the last transformer, and what a Linear reads is a bf16 copy of its raw operand plus per-row partial sums of
+// squares, one per 128-column tile of the GEMM that produced the operand (kept apart and added in tile order by the consumer: no atomics, the same bits every run):
+//     FFN-out store     x2 = X + v + b         -> X ; Xg = bf16(x2 * g) ; sq2[m][tile] = sum x2^2 ; sqg[m][tile] = sum (x2 g)^2
+//     in-projection     (q | k | v | gates) = (Xg W_in^T) / |x2 g| + b_in                       (n(y) = x2 g / |x2 g|: the 1 / |x2| inside y cancels)
+//     out-proj store    x1 = X * g / |x2| + v  -> X ; X1 = bf16(x1) ; sq1[m][tile] = sum x1^2   (y itself is formed here, g and 1 / |x2| from the PREVIOUS transformer)
+//     FFN-in store      gelu((X1 W_1^T) / |x1| + b_1)
+//     mask estimator    tanh((Xg W^T) / |x2| + b)   (its input is y = n(x2) g)
+// The first transformer reads the band split's output through k_row_prep16 (g = 1, sq = |x|^2); the tap "tokens" applies g / |x2| to X when asked.
+constexpr int kSqTiles = 4;        // partial sums per row: dim <= 512 in 128-column tiles
+// inv[m] = 1 / max(sqrt(sum of the row's partial sums), 1e-12): run once per produced operand, so that a consuming store reads ONE float per row (a consumer that
+// added the partials and took the root itself, per float4, cost a K = 384 product 30 % of its time)
+__global__ __launch_bounds__(256) void k_rows_inv_norm(const float* __restrict__ sq, int tiles, float* __restrict__ inv, const float* __restrict__ sq_b, float* __restrict__ inv_b, int rows) {
+    const int m = (int)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    const float4 a = *reinterpret_cast<const float4*>(sq + (size_t)m * kSqTiles);
+    inv[m] = 1.0f / fmaxf(sqrtf(tiles > 3 ? ((a.x + a.y) + a.z) + a.w : (tiles > 2 ? (a.x + a.y) + a.z : (tiles > 1 ? a.x + a.y : a.x))), 1e-12f);
+    if (sq_b) {
+        const float4 b = *reinterpret_cast<const float4*>(sq_b + (size_t)m * kSqTiles);
+        inv_b[m] = 1.0f / fmaxf(sqrtf(tiles > 3 ? ((b.x + b.y) + b.z) + b.w : (tiles > 2 ? (b.x + b.y) + b.z : (tiles > 1 ? b.x + b.y : b.x))), 1e-12f);
+    }
+}
+// sum over the 32 lanes that hold one row's 128 columns of a tile (lanes (tid & 31) of the epilogue of csrc/ade_gemm16.h): all 32 must be active
+__device__ __forceinline__ float row32_sum(float v) {
+    v += quad_rot<1>(v);
+    v += quad_rot<2>(v);
+    v += row_ror<4>(v);
+    v += row_ror<8>(v);
+    const Swapped t = swap16(v, v);          // a = [r0, r0, r2, r2], b = [r1, r1, r3, r3] of the four 16-lane rows: one v_permlane16_swap instead of a trip through the LDS crossbar
+    return t.a + t.b;
+}
+struct RotaryQkStore16 {       // q | k | v | gates = (Xg W_in^T) / |x2 g| + b_in, rotary on the q and k blocks (:547-548, :552), -> bf16
     bf16_t* out;
     const float* bias;
     const float *rcos, *rsin;  // [position][kDh], rotate_half's sign folded into rsin
+    const float* inv;          // 1 / |operand row|
     int ld, rot_cols;
     gemm16::FastDiv pos_stride, n_pos;      // position of row m = (m / pos_stride) % n_pos
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
     __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
-        float4 u = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+        const float rs = inv[m];
+        float4 u = make_float4(fmaf(v.x, rs, b.x), fmaf(v.y, rs, b.y), fmaf(v.z, rs, b.z), fmaf(v.w, rs, b.w));
         if (n < rot_cols) {                                          // rot_cols % 4 == 0: a float4 is rotated whole or not at all
             const int q = pos_stride.div(m), at = (q - n_pos.div(q) * (int)n_pos.d) * kDh + (n & (kDh - 1));
             const float4 c = *reinterpret_cast<const float4*>(rcos + at), sn = *reinterpret_cast<const float4*>(rsin + at);
@@ -441,25 +476,55 @@ struct RotaryQkStore16 {       // q | k | v | gates = Xb W_in^T + b_in, rotary o
     }
 };
 template <int ACT>             // 0: gelu (erf form, :564); 1: tanh (:581-582)
-struct BiasActStore16 {        // act(v + bias[n]) -> bf16
+struct BiasActStore16 {        // act(v [/ |operand row|] + bias[n]) -> bf16
     bf16_t* out;
     const float* bias;
+    const float* inv;          // 1 / |operand row|, or null (the operand is used as it is)
     int ld;
     __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f)) : tanh_f(x); }
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
     __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
-        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(v.x + b.x), act(v.y + b.y), act(v.z + b.z), act(v.w + b.w)), cnt);
+        const float rs = inv ? inv[m] : 1.0f;
+        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(fmaf(v.x, rs, b.x)), act(fmaf(v.y, rs, b.y)), act(fmaf(v.z, rs, b.z)), act(fmaf(v.w, rs, b.w))), cnt);
     }
 };
-struct ResidualStore16 {       // x[m][n] += v (+ bias[n]), fp32 residual stream (:569-570)
+struct OutProjStore16 {        // x1 = X * g / |x2| + v -> X (fp32) ; X1 = bf16(x1) ; sq1[m][tile] = sum over the tile's columns of x1^2      (N % 128 == 0)
     float* x;
-    const float* bias;         // may be null
+    bf16_t* x1b;
+    const float* g_prev;       // the previous transformer's gain, or null: X already holds the stream value (first transformer)
+    const float* inv2;         // 1 / |x2 row| of the previous transformer (with g_prev)
+    float* sq1;
     int ld;
-    __device__ float4 col(int n, int cnt) const { return bias ? gemm16::load_f32x4(bias + n, cnt) : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
+    __device__ float4 col(int n, int) const { return g_prev ? *reinterpret_cast<const float4*>(g_prev + n) : make_float4(1.0f, 1.0f, 1.0f, 1.0f); }
+    __device__ void operator()(int m, int n, float4 v, int, const float4& g) const {
         float* p = x + (size_t)m * ld + n;
-        const float4 old = gemm16::load_f32x4(p, cnt);
-        gemm16::store_f32x4(p, make_float4(old.x + (v.x + b.x), old.y + (v.y + b.y), old.z + (v.z + b.z), old.w + (v.w + b.w)), cnt);
+        const float4 old = *reinterpret_cast<const float4*>(p);
+        const float r = g_prev ? inv2[m] : 1.0f;
+        const float4 y = make_float4(fmaf(old.x * r, g.x, v.x), fmaf(old.y * r, g.y, v.y), fmaf(old.z * r, g.z, v.z), fmaf(old.w * r, g.w, v.w));
+        *reinterpret_cast<float4*>(p) = y;
+        *reinterpret_cast<uint2*>(x1b + (size_t)m * ld + n) = gemm16::pack_bf16x4(y);
+        const float s = row32_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
+        if ((threadIdx.x & 31) == 0) sq1[(size_t)m * kSqTiles + (n >> 7)] = s;
+    }
+};
+struct FfOutStore16 {          // x2 = X + v + b -> X (fp32) ; Xg = bf16(x2 * g) ; sq2 / sqg[m][tile] = sums of x2^2 / (x2 g)^2 over the tile's columns   (N % 128 == 0)
+    float* x;
+    bf16_t* xg;
+    const float *bias, *g;
+    float *sq2, *sqg;
+    int ld;
+    struct ColC { float4 b, g; };
+    __device__ ColC col(int n, int) const { return ColC{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(g + n)}; }
+    __device__ void operator()(int m, int n, float4 v, int, const ColC& c) const {
+        float* p = x + (size_t)m * ld + n;
+        const float4 old = *reinterpret_cast<const float4*>(p);
+        const float4 y = make_float4(old.x + (v.x + c.b.x), old.y + (v.y + c.b.y), old.z + (v.z + c.b.z), old.w + (v.w + c.b.w));
+        const float4 yg = make_float4(y.x * c.g.x, y.y * c.g.y, y.z * c.g.z, y.w * c.g.w);
+        *reinterpret_cast<float4*>(p) = y;
+        *reinterpret_cast<uint2*>(xg + (size_t)m * ld + n) = gemm16::pack_bf16x4(yg);
+        const float s2 = row32_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w);
+        const float sg = row32_sum(yg.x * yg.x + yg.y * yg.y + yg.z * yg.z + yg.w * yg.w);
+        if ((threadIdx.x & 31) == 0) { sq2[(size_t)m * kSqTiles + (n >> 7)] = s2; sqg[(size_t)m * kSqTiles + (n >> 7)] = sg; }
     }
 };
 struct RowBiasStoreF32 {       // yt[m][n] = v + bias[m], fp32 row-major with any ld (the mask estimator's last Linear computed transposed: rows = output columns, n = bt)
@@ -476,14 +541,16 @@ struct RowBiasStoreF32 {       // yt[m][n] = v + bias[m], fp32 row-major with an
         for (int i = 0; i < cnt; ++i) p[i] = t[i];
     }
 };
-struct MeHiddenProb16 {        // z = band: out_z = tanh(in_z W_z^T + b_z), W_z (N, K) bf16
+struct MeHiddenProb16 {        // z = band: out_z = tanh((in_z W_z^T) [/ |x2 row|] + b_z), W_z (N, K) bf16
     const bf16_t* in;
     const bf16_t* w;
     const float* bias;
+    const float* inv;          // first layer: 1 / |x2 row| (null for the second)
     bf16_t* out;
     int BT, K, N;
     __device__ gemm16::Prob<BiasActStore16<1>> operator()(int z) const {
-        return {in + (size_t)z * BT * K, K, w + (size_t)z * N * K, K, BiasActStore16<1>{out + (size_t)z * BT * N, bias + (size_t)z * N, N}, BT, N, K};
+        return {in + (size_t)z * BT * K, K, w + (size_t)z * N * K, K,
+                BiasActStore16<1>{out + (size_t)z * BT * N, bias + (size_t)z * N, inv ? inv + (size_t)z * BT : nullptr, N}, BT, N, K};
     }
 };
 struct MeOutProb16 {           // z = band: YT[2 off_z + c][bt] = sum_k w3_z[c][k] h_z[bt][k] + b3_z[c]   (:583), the product taken transposed so that YT is its row-major result
@@ -499,40 +566,26 @@ struct MeOutProb16 {           // z = band: YT[2 off_z + c][bt] = sum_k w3_z[c][
     }
 };
 
-// xb_row = bf16(x_row / max(|x_row|_2, 1e-12)): the normalised operand of the next Linear (:533-538); one wavefront per row
-__global__ __launch_bounds__(256) void k_row_norm16(const float* __restrict__ x, bf16_t* __restrict__ xb, int rows, int dim) {
+// the band split's output as the first transformer's operand: Xg = bf16(x), invg[m] = 1 / |x|; one wavefront per row
+__global__ __launch_bounds__(256) void k_row_prep16(const float* __restrict__ x, bf16_t* __restrict__ xg, float* __restrict__ invg, int rows, int dim) {
     const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * dim;
     float s = 0.0f;
-    for (int k = 4 * lane; k < dim; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-    const float r = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
     for (int k = 4 * lane; k < dim; k += 256) {
         const float4 v = *reinterpret_cast<const float4*>(xr + k);
-        *reinterpret_cast<uint2*>(xb + (size_t)row * dim + k) = gemm16::pack_bf16x4(make_float4(v.x * r, v.y * r, v.z * r, v.w * r));
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        *reinterpret_cast<uint2*>(xg + (size_t)row * dim + k) = gemm16::pack_bf16x4(v);
     }
+    s = wave_sum(s);
+    if (lane == 0) invg[row] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
 }
-// x_row = x_row / max(|x_row|, eps) * g (:571) in fp32, xb_row = bf16(new x_row / max(|new x_row|, eps)) for the next transformer, xc_row = bf16(new x_row) for the mask estimator
-__global__ __launch_bounds__(256) void k_row_normalize_gain16(float* __restrict__ x, const float* __restrict__ g, bf16_t* __restrict__ xb, bf16_t* __restrict__ xc, int rows, int dim) {
+// y = x2 * g / |x2| written out (the tap "tokens"): out of place, X keeps x2
+__global__ __launch_bounds__(256) void k_row_apply_gain(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ inv2, float* __restrict__ y, int rows, int dim) {
     const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    float* xr = x + (size_t)row * dim;
-    float s = 0.0f;
-    for (int k = 4 * lane; k < dim; k += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + k); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-    const float r = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
-    float s2 = 0.0f;
-    for (int k = 4 * lane; k < dim; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + k), gg = *reinterpret_cast<const float4*>(g + k);
-        const float4 y = make_float4(v.x * r * gg.x, v.y * r * gg.y, v.z * r * gg.z, v.w * r * gg.w);
-        *reinterpret_cast<float4*>(xr + k) = y;
-        s2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
-    }
-    const float r2 = 1.0f / fmaxf(sqrtf(wave_sum(s2)), 1e-12f);
-    for (int k = 4 * lane; k < dim; k += 256) {
-        const float4 y = *reinterpret_cast<const float4*>(xr + k);          // this lane's own store, read back
-        *reinterpret_cast<uint2*>(xb + (size_t)row * dim + k) = gemm16::pack_bf16x4(make_float4(y.x * r2, y.y * r2, y.z * r2, y.w * r2));
-        if (xc) *reinterpret_cast<uint2*>(xc + (size_t)row * dim + k) = gemm16::pack_bf16x4(y);
-    }
+    const float r = inv2[row];
+    for (int k = lane; k < dim; k += 64) y[(size_t)row * dim + k] = x[(size_t)row * dim + k] * r * g[k];
 }
 
 // Attention core on bf16 q | k | v (rotary applied by the in-projection's store), v_mfma_f32_16x16x32_bf16, flash style; same decomposition as k_attention above:
@@ -742,7 +795,10 @@ struct MelbandEngine : SubEngine {
                                    // STFT, band split, residual stream, norms, softmax statistics, GLU / mask, ISTFT stay fp32
     gemm16::bf16_t* d_w16 = nullptr;   // bf16 path: arena of bf16 weights (the fp32 arena's Linear weights at the same offsets; me_w1t / me_w2t transposed to (out, in))
     const gemm16::bf16_t *me_w1_16 = nullptr, *me_w2_16 = nullptr;
-    gemm16::bf16_t *Xb = nullptr, *Xc = nullptr, *A16 = nullptr, *B16 = nullptr, *AO16 = nullptr;
+    gemm16::bf16_t *Xg = nullptr, *X1 = nullptr, *A16 = nullptr, *B16 = nullptr, *AO16 = nullptr;      // bf16 operand copies of the stream (see the stores), q | k | v | gates, hidden activations, attention output
+    float *sq1 = nullptr, *sq2 = nullptr, *sqg = nullptr;      // per-row partial sums of squares [R][kSqTiles]
+    float *inv1 = nullptr, *inv2 = nullptr, *invg = nullptr;   // 1 / max(|row|, 1e-12) of x1, x2, x2 * g
+    const float* g_last = nullptr;                            // gain of the last transformer that ran (the stream is x2 * g / |x2|)
     int capacity = 0;
     float* ws = nullptr;
     float *Sp = nullptr, *X = nullptr, *invn = nullptr, *bufA = nullptr, *bufB = nullptr, *AO = nullptr, *YT = nullptr, *MS = nullptr,
@@ -765,7 +821,7 @@ struct MelbandEngine : SubEngine {
     int reserve(int batch, std::string& err) override;
     int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) override;
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
-    void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs, bool last);
+    void transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc, const float* rs);
 };
 
 int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
@@ -951,7 +1007,8 @@ int melband_create(const std::map<std::string, Tensor>& tensors, int in_len, int
     if (bf16) {
         // bf16 copies (round to nearest even) of every Linear weight at the SAME arena offsets; the mask estimator's first two Linears are stored (in, out) by the
         // reference's fused buffers (me_w1t / me_w2t) and are transposed here to (out, in): csrc/ade_gemm16.h takes both operands with k contiguous.
-        if ((dim | di | ffd | med | ldq) & 7) return bail(mfail(err, ADE_ERR_UNSUPPORTED, "melband: ade_gemm_dtype = bf16 needs dim, dim_inner, the FFN and mask-estimator widths to be multiples of 8"));
+        if (((dim | di | ffd | med | ldq) & 7) || (dim & 127) || dim > 128 * kSqTiles)
+            return bail(mfail(err, ADE_ERR_UNSUPPORTED, "melband: ade_gemm_dtype = bf16 needs dim a multiple of 128 (at most 512) and dim_inner, heads, the FFN and mask-estimator widths multiples of 8"));
         auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
         std::vector<uint16_t> h16(arena, 0);
         auto conv = [&](const Item& it) { for (size_t i = 0; i < it.n; ++i) h16[it.at + i] = to_bf16(it.src[i]); };
@@ -997,7 +1054,8 @@ int MelbandEngine::reserve(int batch, std::string& err) {
     const size_t hid = (size_t)ffd > (size_t)med ? (size_t)ffd : (size_t)med;
     size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
                         (size_t)kChan * BT * kNfftM, (size_t)kFc * 2 * BT};
-    if (bf16) {      // room for the bf16 stream copies behind the bf16 views of bufA and AO (see below; already there whenever dim <= the buffer's own width)
+    if (bf16) {      // room for the bf16 stream copies behind the bf16 views of bufA and AO (see below; already there whenever dim <= the buffer's own width), and for the row sums
+        sizes[2] = (size_t)(3 * kSqTiles + 3) * R;
         sizes[3] = std::max(sizes[3], (((R * wide + 63) & ~(size_t)63) + R * dim) / 2 + 64);
         sizes[5] = std::max(sizes[5], (((R * di + 63) & ~(size_t)63) + R * dim) / 2 + 64);
     }
@@ -1007,32 +1065,35 @@ int MelbandEngine::reserve(int batch, std::string& err) {
     float** ptrs[10] = {&Sp, &X, &invn, &bufA, &bufB, &AO, &YT, &MS, &frames_buf, &mask_tap};
     size_t at = 0;
     for (int i = 0; i < 10; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
-    if (bf16) {      // the bf16 activations live in the fp32 path's buffers (each at most half their size): q | k | v | gates in bufA with the normalised stream copy Xb behind it,
-                     // the hidden activations in bufB, the attention output in AO with the mask estimator's input copy Xc behind it
-        A16 = reinterpret_cast<gemm16::bf16_t*>(bufA); Xb = A16 + ((R * wide + 63) & ~(size_t)63);
+    if (bf16) {      // the bf16 activations live in the fp32 path's buffers (each at most half their size): q | k | v | gates in bufA with the stream copy Xg behind it,
+                     // the hidden activations in bufB, the attention output in AO with the stream copy X1 behind it; the partial sums of squares in invn's place
+        A16 = reinterpret_cast<gemm16::bf16_t*>(bufA); Xg = A16 + ((R * wide + 63) & ~(size_t)63);
         B16 = reinterpret_cast<gemm16::bf16_t*>(bufB);
-        AO16 = reinterpret_cast<gemm16::bf16_t*>(AO); Xc = AO16 + ((R * di + 63) & ~(size_t)63);
+        AO16 = reinterpret_cast<gemm16::bf16_t*>(AO); X1 = AO16 + ((R * di + 63) & ~(size_t)63);
+        sq1 = invn; sq2 = sq1 + R * kSqTiles; sqg = sq2 + R * kSqTiles; inv1 = sqg + R * kSqTiles; inv2 = inv1 + R; invg = inv2 + R;
     }
     capacity = batch;
     return ADE_OK;
 }
 
 void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int nseq, long long seq_stride, long long pos_stride, const float* rc,
-                                const float* rs, bool last /* the mask estimator follows: it takes a bf16 copy of the result on the bf16 path */) {
+                                const float* rs) {
     using namespace gemm;
     const int ldq = 3 * di + heads;
-    if (bf16) {      // Xb = bf16(x / |x|) on entry (written by whoever produced X)
-        const dim3 rows4((unsigned)((R + 3) / 4));
-        gemm16::launch(s, Xb, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, ldq, 2 * di, gemm16::make_fastdiv((int)pos_stride), gemm16::make_fastdiv(n)}, R, ldq, dim);                 // (:547-548, :552)
+    if (bf16) {      // on entry: Xg = bf16 operand copy of the stream, sqg its rows' partial sums of squares; X = x2 of the previous transformer (g_last, sq2) or the stream itself
+        const int tiles = (dim + 127) / 128;
+        const dim3 rows256((unsigned)((R + 255) / 256));
+        gemm16::launch(s, Xg, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, invg, ldq, 2 * di, gemm16::make_fastdiv((int)pos_stride), gemm16::make_fastdiv(n)}, R, ldq, dim);   // (:547-548, :552)
         if (n > 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<2>), dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s,
                                        (const gemm16::bf16_t*)A16, AO16, n, seq_stride, pos_stride, ldq, di);                                            // (:549-560)
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<1>), dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const gemm16::bf16_t*)A16, AO16, n,
                                 seq_stride, pos_stride, ldq, di);
-        gemm16::launch(s, AO16, di, w.out_w16, di, ResidualStore16{X, nullptr, dim}, R, dim, di);                                                        // (:561, :569)
-        hipLaunchKernelGGL(k_row_norm16, rows4, dim3(256), 0, s, (const float*)X, Xb, R, dim);
-        gemm16::launch(s, Xb, dim, w.ff1_w16, dim, BiasActStore16<0>{B16, w.ff1_b, ffd}, R, ffd, dim);                                                   // (:564)
-        gemm16::launch(s, B16, ffd, w.ff2_w16, ffd, ResidualStore16{X, w.ff2_b, dim}, R, dim, ffd);                                                      // (:565, :570)
-        hipLaunchKernelGGL(k_row_normalize_gain16, rows4, dim3(256), 0, s, X, w.out_g, Xb, last ? Xc : nullptr, R, dim);                                 // (:571)
+        gemm16::launch(s, AO16, di, w.out_w16, di, OutProjStore16{X, X1, g_last, inv2, sq1, dim}, R, dim, di);                                           // (:561, :569; the previous :571)
+        hipLaunchKernelGGL(k_rows_inv_norm, rows256, dim3(256), 0, s, (const float*)sq1, tiles, inv1, (const float*)nullptr, (float*)nullptr, R);
+        gemm16::launch(s, X1, dim, w.ff1_w16, dim, BiasActStore16<0>{B16, w.ff1_b, inv1, ffd}, R, ffd, dim);                                             // (:564)
+        gemm16::launch(s, B16, ffd, w.ff2_w16, ffd, FfOutStore16{X, Xg, w.ff2_b, w.out_g, sq2, sqg, dim}, R, dim, ffd);                                  // (:565, :570; :571 is applied by the consumers)
+        hipLaunchKernelGGL(k_rows_inv_norm, rows256, dim3(256), 0, s, (const float*)sq2, tiles, inv2, (const float*)sqg, invg, R);
+        g_last = w.out_g;
         return;
     }
     // invn holds 1 / |x_row| on entry (written by whoever produced X)
@@ -1059,17 +1120,17 @@ int MelbandEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d
     // band split                                                                                                                   (:597-599)
     hipLaunchKernelGGL(k_band_invnorm, dim3((unsigned)((BT + 255) / 256), (unsigned)nb), dim3(256), 0, s, (const float*)Sp, gcol, off, invn, BT);
     launch_batched(s, BandSplitProb{Sp, gcol, d_w, bt, invn, X, BT, dim}, nb, BT, dim);     // fp32 on both paths (the front)
-    if (bf16) hipLaunchKernelGGL(k_row_norm16, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, Xb, R, dim);
+    if (bf16) { hipLaunchKernelGGL(k_row_prep16, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, Xg, invg, R, dim); g_last = nullptr; }
     else hipLaunchKernelGGL(k_row_invnorm, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, s, (const float*)X, invn, R, dim);
     // axial transformers: time = T consecutive rows per (band, clip); frequency = nb rows B*T apart per (clip, frame)              (:609-614)
     for (int i = 0; i < depth; ++i) {
-        transformer(s, time_tf[i], R, T, nb * B, (long long)T, 1LL, tcos, tsin, false);
-        transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin, i + 1 == depth);
+        transformer(s, time_tf[i], R, T, nb * B, (long long)T, 1LL, tcos, tsin);
+        transformer(s, freq_tf[i], R, nb, BT, 1LL, (long long)BT, fcos, fsin);
     }
     // mask estimator: per band 384 -> 1536 -> 1536 (tanh) -> 2 d_i, kept raw and column-major for the GLU / scatter kernel         (:579-585)
     if (bf16) {
-        gemm16::launch_batched(s, MeHiddenProb16{Xc, me_w1_16, me_b1, B16, BT, dim, med}, nb, BT, med);
-        gemm16::launch_batched(s, MeHiddenProb16{B16, me_w2_16, me_b2, A16, BT, med, med}, nb, BT, med);
+        gemm16::launch_batched(s, MeHiddenProb16{Xg, me_w1_16, me_b1, inv2, B16, BT, dim, med}, nb, BT, med);      // its input is the stream n(x2) g = Xg / |x2|
+        gemm16::launch_batched(s, MeHiddenProb16{B16, me_w2_16, me_b2, nullptr, A16, BT, med, med}, nb, BT, med);
         gemm16::launch_batched(s, MeOutProb16{A16, d_w16, d_w, bt, YT, BT, med}, nb, 2 * max_d, BT);
     } else {
         launch_batched(s, MeHiddenProb{X, me_w1t, me_b1, bufB, BT, dim, med}, nb, BT, med);
@@ -1090,7 +1151,14 @@ int MelbandEngine::tap(hipStream_t s, const char* name, int batch, float* out, s
     const size_t BT = (size_t)batch * n_win * T;
     const float* src = nullptr;
     size_t n = 0;
-    if (strcmp(name, "tokens") == 0) { src = X; n = (size_t)nb * BT * dim; }              // transformer output (band, clip, frame, dim)
+    if (strcmp(name, "tokens") == 0) {                                                     // transformer output (band, clip, frame, dim)
+        src = X; n = (size_t)nb * BT * dim;
+        if (bf16 && g_last && batch > 0 && X) {      // the bf16 path keeps x2; the stream value x2 * g / |x2| (see the stores) is formed in the hidden-activation buffer, free after a run
+            float* y = bufB;
+            hipLaunchKernelGGL(k_row_apply_gain, dim3((unsigned)((n / dim + 3) / 4)), dim3(256), 0, s, (const float*)X, g_last, (const float*)inv2, y, (int)(n / dim), dim);
+            src = y;
+        }
+    }
     else if (strcmp(name, "mask") == 0) { src = mask_tap; n = (size_t)kFc * 2 * BT; }     // averaged complex mask [fc][re|im][clip*T + t]
     else if (strcmp(name, "spec") == 0) { src = Sp; n = (size_t)kFc * 2 * BT; }
     else return mfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
