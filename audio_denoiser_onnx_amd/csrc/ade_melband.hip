@@ -288,7 +288,13 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float Ks[kKc * kPitch];            // [key][dim]
     __shared__ __attribute__((aligned(16))) float Vt[kDh * kPitch];            // [dim][key]
     constexpr int kQw = 16 * QT, kQb = 4 * kQw;                                 // queries per wave / per workgroup
-    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Block order: the query blocks of one (sequence, head) are CONSECUTIVE logical ids on ONE XCD (gemm::xcd_contiguous_id), so its K / V rows come from HBM once and the
+    // other query blocks find them in that XCD's L2.  With (sequence, head, block) as the grid's x / y / z the blocks of a sequence were nseq * heads ids apart and every one
+    // of them fetched K / V from HBM again (counters: 11.4 GB per launch against 1.2 GB of q | k | v at 8 clips -- the kernel ran at the HBM rate, not the matrix rate).
+    const int nqb = (int)gridDim.z, nhead = (int)gridDim.y;
+    const int id = gemm::xcd_contiguous_id((int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + nhead * (int)blockIdx.z), (int)gridDim.x * nhead * nqb);
+    const int qblk = id % nqb, head = (id / nqb) % nhead, seq = id / (nqb * nhead);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, g = lane >> 4;
     const long long row0 = (long long)seq * seq_stride;
     int qi[QT];
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
     float4 qreg[QT][4];                                                         // Q[query j16 of tile t][d = 16 ks + 4 g + s] (rotary applied by the in-projection's store)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        qi[t] = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;              // this lane's query of tile t
+        qi[t] = qblk * kQb + wave * kQw + 16 * t + j16;                         // this lane's query of tile t
         q_ok[t] = qi[t] < n;
         qrow[t] = (size_t)(row0 + (long long)(q_ok[t] ? qi[t] : 0) * pos_stride);
         const float* src = qkvg + qrow[t] * ldq + head * kDh + 4 * g;
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) acc[t][dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    const bool wave_live = (int)blockIdx.z * kQb + wave * kQw < n;             // a wave whose queries are all padding only helps loading
+    const bool wave_live = qblk * kQb + wave * kQw < n;                        // a wave whose queries are all padding only helps loading
 
     // K / V staging, software-pipelined: the 64 keys of chunk c + 1 are requested into registers (four 16-byte K and V pieces per lane: key p = i >> 4, dims 4 (i & 15) ..)
     // right after chunk c has been written to LDS, and land under chunk c's MFMAs.  Padded keys are zero rows: their p is 0 and 0 * 0 stays 0.
@@ -605,7 +611,10 @@ __global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict
     __shared__ __attribute__((aligned(16))) unsigned char Ks[kKc * kKPitch16];           // [key][dim]
     __shared__ __attribute__((aligned(16))) unsigned char Vt[kDh * kVPitch16];           // [dim][key]
     constexpr int kQw = 16 * QT, kQb = 4 * kQw;
-    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = (int)gridDim.z, nhead = (int)gridDim.y;                              // block order: see k_attention (the query blocks of a (sequence, head) share an XCD's L2)
+    const int id = gemm::xcd_contiguous_id((int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + nhead * (int)blockIdx.z), (int)gridDim.x * nhead * nqb);
+    const int qblk = id % nqb, head = (id / nqb) % nhead, seq = id / (nqb * nhead);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j16 = lane & 15, g = lane >> 4;
     const long long row0 = (long long)seq * seq_stride;
     bool q_ok[QT];
@@ -613,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict
     uint4 qb[QT][2];                                                                     // Q[query j16 of tile t][dims 32 ks + 8 g .. + 7]
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const int qi = (int)blockIdx.z * kQb + wave * kQw + 16 * t + j16;
+        const int qi = qblk * kQb + wave * kQw + 16 * t + j16;
         q_ok[t] = qi < n;
         qrow[t] = (size_t)(row0 + (long long)(q_ok[t] ? qi : 0) * pos_stride);
         const bf16_t* src = qkvg + qrow[t] * ldq + head * kDh + 8 * g;
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) acc[t][dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     }
-    const bool wave_live = (int)blockIdx.z * kQb + wave * kQw < n;
+    const bool wave_live = qblk * kQb + wave * kQw < n;
     // staging: lane = (key p = i >> 3, 16-byte piece i & 7) for i = tid, tid + 256: 8 lanes read one key's 128-byte K (and V) line; padded keys are zero rows
     uint4 pk[2], pv[2];
     auto request = [&](int c0) {
