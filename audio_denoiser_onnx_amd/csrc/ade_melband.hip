@@ -607,7 +607,7 @@ __device__ __forceinline__ v4f mfma16x16x32(const uint4& a, const uint4& b, v4f 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemm16::as_v8bf(a), gemm16::as_v8bf(b), c, 0, 0, 0);
 }
 template <int QT>
-__global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict__ qkvg, bf16_t* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
+__global__ __launch_bounds__(256, 3) void k_attention16(const bf16_t* __restrict__ qkvg, bf16_t* __restrict__ ao, int n, long long seq_stride, long long pos_stride, int ldq, int di) {
     __shared__ __attribute__((aligned(16))) unsigned char Ks[kKc * kKPitch16];           // [key][dim]
     __shared__ __attribute__((aligned(16))) unsigned char Vt[kDh * kVPitch16];           // [dim][key]
     constexpr int kQw = 16 * QT, kQb = 4 * kQw;
@@ -639,32 +639,43 @@ __global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict
         for (int dt = 0; dt < 4; ++dt) acc[t][dt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     }
     const bool wave_live = qblk * kQb + wave * kQw < n;
-    // staging: lane = (key p = i >> 3, 16-byte piece i & 7) for i = tid, tid + 256: 8 lanes read one key's 128-byte K (and V) line; padded keys are zero rows
+    // staging: lane i = tid, tid + 256 = (key pair i >> 4, 16-byte piece (i >> 1) & 7, key of the pair i & 1): 16 lanes read the 128-byte K (and V) lines of two
+    // consecutive keys; padded keys are zero rows.  V goes to LDS TRANSPOSED ([dim][key]): the two lanes of a key pair trade halves of their eight dims
+    // (quad_perm DPP), so that each holds four dims of BOTH keys and writes four 32-bit words (dim, keys 2 kp | 2 kp + 1) -- 16-bit stores of single elements
+    // were 4-way bank conflicts on a third of the LDS cycles.
     uint4 pk[2], pv[2];
     auto request = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + 256 * u, p = i >> 3, key = c0 + p;
+            const int i = tid + 256 * u, p = 2 * (i >> 4) + (i & 1), key = c0 + p;
             const bool ok = key < n;
-            const bf16_t* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + 8 * (i & 7);
+            const bf16_t* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + 8 * ((i >> 1) & 7);
             pk[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + di));
             pv[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + 2 * di));
         }
     };
+    // m / l are kept in the exponent's units: scores are multiplied by log2(e) inside the fused multiply-add that subtracts the running maximum, exp is v_exp_f32 alone
     request(0);
     for (int c0 = 0; c0 < n; c0 += kKc) {
+        const bool last = c0 + kKc >= n;                                                 // (uniform) only the last chunk has padded keys to mask
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + 256 * u, p = i >> 3, d0 = 8 * (i & 7);
-            *reinterpret_cast<uint4*>(Ks + p * kKPitch16 + 2 * d0) = pk[u];
-            const unsigned w[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<unsigned short*>(Vt + (d0 + e) * kVPitch16 + 2 * p) = (unsigned short)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+            const int i = tid + 256 * u, kp2 = i >> 4, odd = i & 1, d0 = 8 * ((i >> 1) & 7);
+            *reinterpret_cast<uint4*>(Ks + (2 * kp2 + odd) * kKPitch16 + 2 * d0) = pk[u];
+            const unsigned w0 = pv[u].x, w1 = pv[u].y, w2 = pv[u].z, w3 = pv[u].w;         // dims d0 + (0,1), (2,3), (4,5), (6,7) of this lane's key
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? w0 : w2), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the partner's word
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? w1 : w3), 0xB1, 0xF, 0xF, true);
+            // even lane (key 2 kp): dims d0 .. d0 + 3, own = low halves; odd lane (key 2 kp + 1): dims d0 + 4 .. d0 + 7, own = high halves
+            const unsigned lo0 = odd ? r0 : w0, hi0 = odd ? w2 : r0, lo1 = odd ? r1 : w1, hi1 = odd ? w3 : r1;
+            unsigned char* vrow = Vt + (d0 + 4 * odd) * kVPitch16 + 4 * kp2;
+            *reinterpret_cast<unsigned*>(vrow) = (lo0 & 0xffffu) | (hi0 << 16);
+            *reinterpret_cast<unsigned*>(vrow + kVPitch16) = (lo0 >> 16) | (hi0 & 0xffff0000u);
+            *reinterpret_cast<unsigned*>(vrow + 2 * kVPitch16) = (lo1 & 0xffffu) | (hi1 << 16);
+            *reinterpret_cast<unsigned*>(vrow + 3 * kVPitch16) = (lo1 >> 16) | (hi1 & 0xffff0000u);
         }
         __syncthreads();
-        if (c0 + kKc < n) request(c0 + kKc);
+        if (!last) request(c0 + kKc);
         if (!wave_live) continue;
         v4f st[QT][4];
 #pragma unroll
@@ -686,20 +697,20 @@ __global__ __launch_bounds__(256, 2) void k_attention16(const bf16_t* __restrict
                 const int key0 = c0 + 16 * kt + 4 * g;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (key0 + r >= n) st[t][kt][r] = -INFINITY;
+                    if (last && key0 + r >= n) st[t][kt][r] = -INFINITY;
                     mx = fmaxf(mx, st[t][kt][r]);
                 }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m[t], mx);                                // finite: every chunk starts with a real key
-            const float alpha = __expf(m[t] - m_new);
+            const float m_new = fmaxf(m[t], mx * kLog2e);                       // finite: every chunk starts with a real key
+            const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
             m[t] = m_new;
             float psum = 0.0f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[t][kt][r] = __expf(st[t][kt][r] - m_new); psum += st[t][kt][r]; }
+                for (int r = 0; r < 4; ++r) { st[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(st[t][kt][r], kLog2e, -m_new)); psum += st[t][kt][r]; }
             l[t] = l[t] * alpha + psum;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) acc[t][dt] = acc[t][dt] * alpha;
