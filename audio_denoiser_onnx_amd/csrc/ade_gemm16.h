@@ -170,6 +170,9 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
     }
 }
 
+// (Measured and not kept: the same tile with both operands DMA'd straight into LDS -- global_load_lds_dwordx4, two unpadded 32 KB stages with an XOR swizzle (piece p of
+//  row r in slot p ^ ((r >> 1) & 7), conflict-free for ds_read_b128), one barrier per slab.  Bit-identical results, but 64 KB of LDS leave two workgroups per CU instead of
+//  four: 230 -> 250 ms per Mel-Band step, same box, alternating runs.  Two register sets (slab k + 2 in flight) lost the fourth workgroup to registers: 269 -> 279 ms.)
 // Consecutive logical tile ids share an XCD (ade_gemm.h): all n-tiles of an m-strip re-read that strip of A from one L2.
 __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
     const int per = total >> 3, rem = total & 7, xcd = w & 7, idx = w >> 3;
@@ -188,6 +191,7 @@ inline void launch(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm16<ST>), grid, dim3(256), 0, s, A, lda, B, ldb, st, M, N, K);
 }
+
 
 // Batched form: blockIdx.z selects a problem; prob(z) returns {A, lda, B, ldb, st, M, N, K} (evaluated once per workgroup); tiles outside a problem's own M x N exit at once.
 template <class ST>
