@@ -295,6 +295,50 @@ __device__ __forceinline__ void xwait(unsigned* flag, int* err, int code) {
     xflag_store(flag, 0u);
 }
 
+// ---- a launch that a host batch streams through (ChunkCall::in_ready / out_done): system-scope words in fine-grained memory, written / polled by the command processor
+#if defined(__AMDGCN__)
+__device__ __forceinline__ unsigned sys_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
+__device__ __forceinline__ void sys_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ unsigned sys_load(const unsigned* p) { return *(const volatile unsigned*)p; }
+__device__ __forceinline__ void sys_store(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
+__device__ __forceinline__ void sys_acquire() {}
+__device__ __forceinline__ void sys_release() {}
+#endif
+// ONE lane waits until the copy engine has delivered this workgroup's rows (bounded like xwait: a copy that never arrives fails the call, it does not hang the device),
+// then drops whatever this CU and its L2 still hold of the previous call's bytes at those addresses; the caller follows with a workgroup barrier.
+__device__ __forceinline__ void wait_rows_in(const unsigned* ready, unsigned epoch, int* err, int code) {
+    if (sys_load(ready) != epoch) {
+        const long long t0 = wall_clock64();
+        const int limit = xlimit();
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > limit) {
+                volatile int* const e = reinterpret_cast<volatile int*>(err);
+                if (*e == 0) *e = code;
+                break;
+            }
+        } while (sys_load(ready) != epoch);
+    }
+    sys_acquire();
+}
+// Every wave has drained its stores and the workgroup has met at a barrier: ONE lane writes this XCD's dirty lines back (the copy engine reads memory, not an L2),
+// counts the workgroup in, and the group's last workgroup tells the copy-out stream.
+__device__ __forceinline__ void signal_rows_out(unsigned* count, unsigned* done, unsigned epoch, unsigned wgs) {
+    sys_release();
+#if defined(__AMDGCN__)
+    const unsigned old = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const unsigned old = (*count)++;
+#endif
+    if (old + 1u == wgs) {
+        xflag_store(count, 0u);
+        sys_store(done, epoch);
+    }
+}
+
 // s_setprio takes an immediate: a wave-uniform level goes through a scalar branch chain
 __device__ __forceinline__ void set_prio(int p) {
     if (p == 0) __builtin_amdgcn_s_setprio(0);

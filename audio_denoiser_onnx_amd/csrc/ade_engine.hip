@@ -86,6 +86,16 @@ struct ade_engine {
     hipStream_t stream = nullptr;
     hipStream_t sub_streams[8] = {};      // ade_process: one stream per sub-batch (created on first use)
     int host_split = 0;                   // option "host_split": sub-batches of a host batch (0 = per call: two from 128 rows; 1 = never; see ade_process)
+    // a host batch streamed through ONE launch (ade_process; ChunkCall::in_ready)
+    static constexpr int kMaxGroups = 8;
+    int host_stream = 0;                  // option "host_stream": row groups of the streamed launch (0 = per call: four from 128 rows; 1 = off: the sub-batch path)
+    int sio_state = 0;                    // 0: not set up yet, 1: ready, -1: unavailable (an allocation was refused)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    unsigned* d_sio_ready = nullptr;      // fine-grained device memory [kMaxGroups][kReadyStride]: block g is overwritten (from h_sio_epoch) behind group g's copy-in
+    unsigned* h_sio_epoch = nullptr;      // page-locked [kReadyStride]: word 0 = the call's epoch, the source of those copies
+    unsigned* h_sio_done = nullptr;       // page-locked [kMaxGroups]: written by a group's last workgroup, polled by the host thread
+    unsigned* d_sio_count = nullptr;      // device memory [kMaxGroups]
+    unsigned sio_epoch = 0;
     float* d_weights = nullptr;
     int* d_ints = nullptr;
     FftTabs tabs{};
@@ -840,10 +850,15 @@ ade_status exchange_status(ade_engine* h, const char* who, bool earlier) {
     if (h->d_xflags) (void)hipMemset(h->d_xflags, 0, (size_t)h->xchg_capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
     const int block = (code >> 4) - 1, idx = code & 15, B = h->last_batch > 0 ? h->last_batch : 1;
     char msg[384];
-    snprintf(msg, sizeof msg,
-             "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for the %s of its predecessor workgroup; no output was produced "
-             "(option geometry=0 runs whole chunks per workgroup, option xwait_ms raises the bound)",
-             who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5, xflag_name(idx));
+    if (idx == 15)      // dev::wait_rows_in: a streamed host batch (ade_process) whose rows were not delivered in time
+        snprintf(msg, sizeof msg, "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for its rows of the host batch to be copied in; no output was produced "
+                 "(option host_stream=1 copies the batch before the launch, option xwait_ms raises the bound)",
+                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5);
+    else
+        snprintf(msg, sizeof msg,
+                 "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for the %s of its predecessor workgroup; no output was produced "
+                 "(option geometry=0 runs whole chunks per workgroup, option xwait_ms raises the bound)",
+                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5, xflag_name(idx));
     return fail(h, ADE_ERR_DEVICE, msg);
 }
 
@@ -1071,12 +1086,22 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             if (e->meta["ade_dft_tables"] == "exact") exact_dft = true;
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
-        bool gemm_bf16 = false;     // ade_gemm_dtype: "f32" (default: exact fp32 matrix-core products, the parity path) | "bf16" (bf16 inputs, fp32 accumulation)
+        // ade_gemm_dtype: "f32" (default: exact fp32 matrix-core products, the parity path)
+        //               | "bf16" (mel_band_roformer: bf16 activations and weights STORED in HBM, gfx950's full-rate bf16 matrix instructions -- csrc/ade_gemm16.h)
+        //               | "bf16_inputs" (zipenhancer, mossformer2_ss: operands stay fp32 in HBM and are rounded to bf16 on their way into LDS -- a rounding mode of the fp32 kernels,
+        //                  about 1.5 x their speed; NOT a bf16 data path, and named for what it is)
+        bool gemm_bf16 = false;
         if (e->meta.count("ade_gemm_dtype") && !e->meta["ade_gemm_dtype"].empty()) {
-            if (e->meta["ade_gemm_dtype"] == "bf16") gemm_bf16 = true;
-            else if (e->meta["ade_gemm_dtype"] != "f32") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_gemm_dtype must be 'f32' or 'bf16'"));
-            if (gemm_bf16 && !fam_zip && !fam_melband && !fam_moss)
-                return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 is implemented for the transformer families (zipenhancer, mel_band_roformer, mossformer2_ss)"));
+            const std::string& dt = e->meta["ade_gemm_dtype"];
+            if (dt == "bf16") {
+                if (!fam_melband) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 (bf16 stored in HBM) is implemented for mel_band_roformer; zipenhancer and mossformer2_ss offer bf16_inputs"));
+                gemm_bf16 = true;
+            } else if (dt == "bf16_inputs") {
+                if (!fam_zip && !fam_moss) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16_inputs is implemented for zipenhancer and mossformer2_ss"));
+                gemm_bf16 = true;
+            } else if (dt != "f32") {
+                return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_gemm_dtype must be 'f32', 'bf16' or 'bf16_inputs'"));
+            }
         }
         const int rc = fam_dfsmn     ? ade::dfsmn_create(e->tensors, (int)Ld, (int)sub_win, device, &e->sub, derr)
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
@@ -1321,6 +1346,11 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         free_graphs(h);
         return ADE_OK;
     }
+    if (strcmp(key, "host_stream") == 0) {     // row groups a host batch is streamed through ONE launch in (ade_process); 0 = per call (four from 128 rows), 1 = off
+        if (value[0] < '0' || value[0] > '8' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option host_stream: 0..8");
+        h->host_stream = value[0] - '0';
+        return ADE_OK;
+    }
     if (strcmp(key, "host_split") == 0) {      // sub-batches ade_process cuts a host batch into (the copies of one overlap the kernel of another); 0 = per call (two from 128 rows), 1 = never
         if (value[0] < '0' || value[0] > '8' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option host_split: 0..8");
         h->host_split = value[0] - '0';
@@ -1563,6 +1593,88 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     // under the first one's kernel, the two kernels run side by side, the first copy-out under the second kernel's tail.  MEASURED (profiles/r04_b_host_split_probe*.txt,
     // 256 x 1 s, page-locked buffers): 0.678 ms unsplit, 0.598 ms in two; 0.79 / 1.14 ms in 4 / 8 -- this process's streams land on two hardware queues, so a third and
     // fourth sub-batch queue up behind the first two (rocprofv3 timeline in DESIGN.md section 6), and a launch of 64 chunks is latency-bound at ~0.23 ms however little it carries.
+    // ---- one launch, the batch streamed through it (ChunkCall::in_ready): the rows are dealt into groups; every group's copy-in is followed on the copy stream by a 64 KB
+    // copy whose first word is this call's epoch, the group's workgroups wait for that word before their first PCM read, the group's last workgroup writes the epoch into
+    // page-locked host memory, and this thread, polling that word, starts the group's copy-out.  The kernel is launched ONCE, at once: group 0 starts when its 1 / n of the
+    // input has arrived, the other copy-ins run under its arithmetic, every copy-out but the last under the later groups' arithmetic.  Unlike the sub-batch path below this
+    // needs no kernel concurrency between streams, i.e. it does not depend on which hardware queues the process's streams were dealt (the sub-batch path measured 0.60 ms
+    // in a process with three streams and 0.80 ms in bench.py's, which has five).
+    {
+        const int geo = pick_geometry(h, rows);
+        const int n_grp = h->host_stream ? h->host_stream : (rows >= 128 ? 4 : 1);
+        const bool plain = !h->sub && !h->gt_sand && h->use_fused && h->use_single && geo >= 0 && !h->profile && h->n_win == 1;
+        const int per = n_grp > 0 ? (rows + n_grp - 1) / n_grp : rows;
+        const bool big = (size_t)per * h->in_len * sizeof(int16_t) >= 65536 && (size_t)per * h->out_len * sizeof(int16_t) >= 65536;      // copies a copy engine takes
+        if (plain && n_grp > 1 && rows >= 2 * n_grp && big && h->sio_state == 0) {
+            h->sio_state = -1;
+            const size_t blk = (size_t)kReadyStride * sizeof(unsigned);
+            bool ok = hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking) == hipSuccess &&
+                      hipExtMallocWithFlags((void**)&h->d_sio_ready, ade_engine::kMaxGroups * blk, hipDeviceMallocFinegrained) == hipSuccess &&
+                      hipMalloc((void**)&h->d_sio_count, ade_engine::kMaxGroups * sizeof(unsigned)) == hipSuccess &&
+                      hipHostMalloc((void**)&h->h_sio_epoch, blk, hipHostMallocDefault) == hipSuccess &&
+                      hipHostMalloc((void**)&h->h_sio_done, ade_engine::kMaxGroups * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+            if (ok) {
+                memset(h->h_sio_epoch, 0, blk);
+                memset(h->h_sio_done, 0, ade_engine::kMaxGroups * sizeof(unsigned));
+                ok = hipMemset(h->d_sio_ready, 0, ade_engine::kMaxGroups * blk) == hipSuccess && hipMemset(h->d_sio_count, 0, ade_engine::kMaxGroups * sizeof(unsigned)) == hipSuccess &&
+                     hipDeviceSynchronize() == hipSuccess;
+            }
+            (void)hipGetLastError();
+            if (ok) h->sio_state = 1;
+        }
+        if (plain && n_grp > 1 && rows >= 2 * n_grp && big && h->sio_state == 1) {
+            const int used = (rows + per - 1) / per;
+            const unsigned epoch = ++h->sio_epoch ? h->sio_epoch : ++h->sio_epoch;            // (never 0: the words start at 0)
+            h->last_batch = rows;
+            h->last_fused = true;
+            h->last_geometry = geo;
+            h->h_sio_epoch[0] = epoch;                                                           // (the previous call's copies of this block are complete: every call ends synchronised)
+            for (int g = 0; g < used; ++g) {
+                const int r0 = g * per, nr = std::min(per, rows - r0);
+                const size_t i0 = (size_t)r0 * h->in_len;
+                const int16_t* src = in + i0;
+                if (!in_direct) { memcpy(h->h_pcm_in + i0, in + i0, (size_t)nr * h->in_len * sizeof(int16_t)); src = h->h_pcm_in + i0; }
+                HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
+                HIP_TRY(h, hipMemcpyAsync(h->d_sio_ready + (size_t)g * kReadyStride, h->h_sio_epoch, (size_t)kReadyStride * sizeof(unsigned), hipMemcpyHostToDevice, h->s_in));
+                if (g == 0) {       // the launch goes out behind the FIRST group's copies (enqueued, not complete): the rest of the enqueueing runs under the copy
+                    ChunkCall C{};
+                    C.plan.nseg = fused_segments(h->T, geo); C.plan.xchg = h->d_xchg; C.plan.flags = h->d_xflags; C.plan.err = h->d_xerr; C.plan.wave_swap = h->wave_swap;
+                    C.plan.prio = h->seg_prio; C.plan.withhold = h->xchg_withhold; C.plan.wait_ticks = h->xwait_ticks;
+                    C.fixed = h->d_fixed;
+                    C.pcm_in = h->d_pcm_in; C.pcm_out = h->d_pcm_out; C.f32_out = out_f32 ? h->d_f32_out : nullptr;
+                    C.L = h->in_len; C.T = h->T; C.B = rows; C.chunk0 = 0;
+                    C.full_taps = h->full_taps;
+                    C.in_ready = h->d_sio_ready; C.out_done = h->h_sio_done; C.out_count = h->d_sio_count; C.epoch = epoch; C.group_rows = per;
+                    launch_gtcrn_chunk(h->stream, geo, C);
+                    HIP_TRY(h, hipGetLastError());
+                }
+            }
+            // copy-outs: started by this thread as the groups finish (a word per group in page-locked memory, written by the group's last workgroup)
+            volatile unsigned* const done = h->h_sio_done;
+            bool finished = false;      // the launch has completed (normally after every group was seen; a failed launch never raises its words)
+            for (int g = 0; g < used; ++g) {
+                const int r0 = g * per, nr = std::min(per, rows - r0);
+                const size_t o0 = (size_t)r0 * h->out_len;
+                for (unsigned spins = 0; done[g] != epoch && !finished; ++spins)
+                    if ((spins & 0x3ffu) == 0x3ffu && hipStreamQuery(h->stream) == hipSuccess) finished = true;
+                if (out_pcm) HIP_TRY(h, hipMemcpyAsync((pcm_direct ? out_pcm : h->h_pcm_out) + o0, h->d_pcm_out + o0, (size_t)nr * h->out_len * sizeof(int16_t), hipMemcpyDeviceToHost, h->s_out));
+                if (out_f32) HIP_TRY(h, hipMemcpyAsync((f32_direct ? out_f32 : h->h_f32_out) + o0, h->d_f32_out + o0, (size_t)nr * h->out_len * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+            }
+            (void)hipGetLastError();
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->s_out));
+            HIP_TRY(h, hipStreamSynchronize(h->s_in));
+            st = exchange_status(h, "ade_process", false);
+            if (st != ADE_OK) {
+                if (out_pcm && pcm_direct) memset(out_pcm, 0, nout * sizeof(int16_t));
+                if (out_f32 && f32_direct) memset(out_f32, 0, nout * sizeof(float));
+                return st;
+            }
+            if (out_pcm && !pcm_direct) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
+            if (out_f32 && !f32_direct) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
+            return ADE_OK;
+        }
+    }
     {
         const int geo = pick_geometry(h, rows);
         int n_sub = h->host_split ? h->host_split : (rows >= 128 ? 2 : 1);
@@ -1768,6 +1880,12 @@ void ade_destroy(ade_handle h) {
     if (h->d_clk) hipFree(h->d_clk);
     if (h->d_xerr) hipHostFree(h->d_xerr);
     for (hipStream_t s : h->sub_streams) if (s) hipStreamDestroy(s);
+    if (h->s_in) hipStreamDestroy(h->s_in);
+    if (h->s_out) hipStreamDestroy(h->s_out);
+    if (h->d_sio_ready) hipFree(h->d_sio_ready);
+    if (h->d_sio_count) hipFree(h->d_sio_count);
+    if (h->h_sio_epoch) hipHostFree(h->h_sio_epoch);
+    if (h->h_sio_done) hipHostFree(h->h_sio_done);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }

@@ -146,6 +146,10 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
             const long long t0 = wall_clock64();                 // 100 MHz, independent of the shader clock
             while (wall_clock64() - t0 < stagger) __builtin_amdgcn_s_sleep(8);
         }
+        if (C->in_ready) {       // a host batch streams through this launch: this chunk's PCM may still be on its way (ChunkCall::in_ready)
+            if (threadIdx.x == 0) wait_rows_in(C->in_ready + (size_t)((chunk - C->chunk0) / C->group_rows) * kReadyStride, C->epoch, sg.err, xcode(15));
+            __syncthreads();
+        }
         const FftTabs tabs = cload<FftTabs>(&F->tabs);
         const BandTab erb = cload<BandTab>(&F->erb_bm);
         const ConvW c0 = cload<ConvW>(&F->en0), c1 = cload<ConvW>(&F->en1);
@@ -184,6 +188,14 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         const BandTab erb = cload<BandTab>(&F->erb_bs);
         const ConvW c3 = cload<ConvW>(&F->de3), c4 = cload<ConvW>(&F->de4);
         back_stage<G>(fsm, chunk, sg, F->xd[2], F->e1, F->e0, F->spec, c3, c4, erb, tabs, C->pcm_out, C->f32_out, (kClk && clk0) ? clk0 + 64 * 9 : nullptr);
+        if (C->in_ready) {       // this segment's share of the chunk's output is stored: count the workgroup in (ChunkCall::out_done)
+            xdrain();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int g = (chunk - C->chunk0) / C->group_rows, rows = C->B - g * C->group_rows < C->group_rows ? C->B - g * C->group_rows : C->group_rows;
+                signal_rows_out(C->out_count + g, C->out_done + g, C->epoch, (unsigned)(rows * (int)(gridDim.x / (unsigned)C->B)));
+            }
+        }
     }
 #undef ADE_STAGE_ENTRY
 }

@@ -208,6 +208,7 @@ struct ChunkFixed {
     DpW dp[2];
     float *spec, *e0, *e1, *xe[3], *dpo[2], *xd[3];
 };
+constexpr int kReadyStride = 16384;      // words: 64 KB, the smallest copy this runtime gives to a copy engine
 struct ChunkCall {           // per call, by value
     SegPlan plan;            // (first: see SegPlan::wait_ticks)
     const ChunkFixed* fixed;
@@ -223,6 +224,17 @@ struct ChunkCall {           // per call, by value
                              // channels 0-7 only the following block reads -- through LDS -- keep those planes out of HBM (x_d0, x_d1, dp2).  Read by the launcher only.
     int stagger;             // > 0: every other group of 8 workgroups starts this many 10 ns ticks late (geometry 0: the workgroups would all
                              // hit HBM with the same stage's burst at the same instant; ade_set_option "stagger_us")
+    // Host batches streamed THROUGH one launch (ade_process): the rows are dealt into groups of `group_rows`; a group's workgroups wait until a copy engine has delivered
+    // the group's PCM (in_ready[g * kReadyStride] == epoch: the first word of a 64 KB block copied behind the group's PCM on the same copy stream) and, once all of them
+    // have stored their output, the last one writes out_done[g] = epoch into page-locked host memory, which the host thread is polling to start the group's copy-out --
+    // the copies of the other groups run under this launch's arithmetic.  in_ready null: PCM is resident, nothing waits and nothing is signalled.
+    // (Why not hipStreamWriteValue32 / hipStreamWaitValue32 or a 4-byte copy: measured on this runtime, those and every copy below 64 KB are executed by a shader and cannot
+    //  start while this launch fills every wavefront slot -- tools/ubench/copy_under_full_gpu_probe.hip; copies from 64 KB up run on the SDMA engines.)
+    const unsigned* in_ready;      // fine-grained device memory, one block of kReadyStride words per group
+    unsigned* out_done;            // [groups] page-locked host memory
+    unsigned* out_count;           // [groups] device memory: workgroups of the group that are done (reset by the last)
+    unsigned epoch;
+    int group_rows;
 };
 void launch_gtcrn_chunk(hipStream_t s, int geometry, const ChunkCall& call);
 

@@ -37,6 +37,9 @@ def metadata(input_audio_length: int, dft_tables: str = "reference", use_batch_f
     windows can still be passed as batch rows.
     ``dft_tables``: "reference" = the reference's fp32-angle DFT matrices (bit-compatible behaviour, default);
     "exact" = exactly reduced angles (see csrc/ade_melband.hip).
+    ``gemm_dtype``: "f32" (default, the parity path) | "bf16" = the transformer stack and the mask estimator on bf16 activations and weights stored in HBM
+    (csrc/ade_gemm16.h; fp32 residual stream, norms, softmax statistics, STFT, band split, mask, ISTFT): BASELINE.json's dtype for this model, ~4.4 x the f32 path,
+    ~41 dB from it.
     ``dynamic_axes`` = a DYNAMIC_AXES export (Export_MelBandRoformer.py:33, :50): any ``input_audio_length`` whose model-rate length reaches one window,
     other input / output sample rates (:52-53, :630-644, :660-680), and an output that keeps the tail of the last frame (Stereo/STFT_Process.py:296-306).
     The engine serves one input length per handle."""

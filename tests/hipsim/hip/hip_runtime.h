@@ -310,6 +310,10 @@ hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s);
 hipError_t hipGraphDestroy(hipGraph_t g);
 hipError_t hipGraphExecDestroy(hipGraphExec_t e);
 }
+// fine-grained device memory: not simulated -- the engine falls back to its sub-batch path when the allocation is refused
+enum { hipDeviceMallocFinegrained = 1 };
+static inline hipError_t hipExtMallocWithFlags(void**, size_t, unsigned) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 

@@ -256,6 +256,7 @@ def test_process_sub_batches_on_separate_streams_are_bit_identical(batch):
     import torch
     sess = make_session(None, seed=1)
     pcm = np.ascontiguousarray(synth_batch(batch, 16000))
+    sess.set_option("host_stream", "1")                                               # (the streamed single launch, the default from 128 rows, has its own test below)
     sess.set_option("host_split", "1")
     want, want_f32 = sess.process(pcm, want_f32=True)
     pin_in = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
@@ -272,4 +273,36 @@ def test_process_sub_batches_on_separate_streams_are_bit_identical(batch):
             pin_f32.zero_()
             sess.process_into(pin_in.numpy(), pin_out.numpy(), pin_f32.numpy())      # page-locked buffers: DMA'd directly
             assert np.array_equal(pin_out.numpy(), want) and np.array_equal(pin_f32.numpy(), want_f32), (split, geometry)
+    assert sess.tap("xchg_error", 1)[0] == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [130, 256])
+def test_process_streamed_through_one_launch_is_bit_identical(batch):
+    """ade_process streams a host batch THROUGH one launch (option "host_stream" = row groups; by default four from 128 rows): each group's copy-in is followed by a 64 KB copy
+    carrying the call's epoch, the group's workgroups wait for that word, the group's last workgroup tells the host thread (a word in page-locked memory), which starts the
+    group's copy-out.  Same PCM and waveform, bit for bit, as the device-resident launch -- on inputs that CHANGE every call (the kernel reads addresses a copy engine has
+    just overwritten: a stale cache line of the previous call would show), from page-locked and pageable buffers, for uneven groups."""
+    import torch
+    sess = make_session(None, seed=2)
+    pin_in = torch.empty((batch, sess.row_in), dtype=torch.int16).pin_memory()
+    pin_out = torch.empty((batch, sess.row_out), dtype=torch.int16).pin_memory()
+    pin_f32 = torch.empty((batch, sess.row_out), dtype=torch.float32).pin_memory()
+    d_out = torch.empty((batch, sess.row_out), dtype=torch.int16, device="cuda")
+    d_f32 = torch.empty((batch, sess.row_out), dtype=torch.float32, device="cuda")
+    call = 0
+    for groups in "0", "2", "3", "8", "4":
+        sess.set_option("host_stream", groups)
+        for rep in range(3):
+            call += 1
+            pcm = np.ascontiguousarray(synth_batch(batch, 16000, first_index=977 * call))
+            sess.run_device(torch.from_numpy(pcm).cuda(), d_out, d_f32)
+            want, want_f32 = d_out.cpu().numpy(), d_f32.cpu().numpy()
+            pin_in.numpy()[...] = pcm
+            pin_out.zero_()
+            pin_f32.zero_()
+            sess.process_into(pin_in.numpy(), pin_out.numpy(), pin_f32.numpy())
+            assert np.array_equal(pin_out.numpy(), want) and np.array_equal(pin_f32.numpy(), want_f32), (groups, rep, "page-locked")
+            got, got_f32 = sess.process(pcm, want_f32=True)
+            assert np.array_equal(got, want) and np.array_equal(got_f32, want_f32), (groups, rep, "pageable")
     assert sess.tap("xchg_error", 1)[0] == 0.0

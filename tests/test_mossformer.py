@@ -238,9 +238,9 @@ def test_gpu_baseline_batch_64_windows_of_4s_properties():
 
 @pytest.mark.gpu
 def test_gpu_bf16_gemm_mode_stays_close_to_f32(fixture):
-    """ade_gemm_dtype = "bf16" (the masking network's GEMMs on bf16 inputs, fp32 accumulation): a throughput mode, NOT the parity path."""
+    """ade_gemm_dtype = "bf16_inputs" (the masking network's GEMMs on bf16 inputs, fp32 accumulation): a throughput mode, NOT the parity path."""
     z, _, _, W = fixture
-    with _session(fixture, W) as a, _session(fixture, W, gemm_dtype="bf16") as b:
+    with _session(fixture, W) as a, _session(fixture, W, gemm_dtype="bf16_inputs") as b:
         _, fa = a.process(z["pcm_in"][None], want_f32=True)
         _, fb = b.process(z["pcm_in"][None], want_f32=True)
     err, sig = fb.astype(np.float64) - fa, fa.astype(np.float64)

@@ -356,13 +356,13 @@ def test_export_and_driver_host_logic(model, tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_zipenhancer_bf16_gemm_mode_stays_close_to_f32(model):
-    """ade_gemm_dtype = "bf16" (bf16 inputs, fp32 accumulation in every projection / convolution GEMM): a throughput mode, NOT the parity path --
+    """ade_gemm_dtype = "bf16_inputs" (bf16 inputs, fp32 accumulation in every projection / convolution GEMM): a throughput mode, NOT the parity path --
     its measured distance from the exact path on the reference's test clip is asserted loosely and printed (bench.py reports it as deviation_from_f32)."""
     from audio_denoiser_onnx_amd.session import InferenceSession
     z, _, _, t = model
     pcm = np.stack([z["in_wav0"], z["in_randn"], z["in_zeros"]])
     with InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000)) as s32, \
-            InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype="bf16")) as s16:
+            InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype="bf16_inputs")) as s16:
         a, af = s32.process(pcm, want_f32=True)
         b, bf = s16.process(pcm, want_f32=True)
     assert not b[2].any()
