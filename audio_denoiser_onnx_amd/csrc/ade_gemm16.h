@@ -172,7 +172,10 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
 
 // (Measured and not kept: the same tile with both operands DMA'd straight into LDS -- global_load_lds_dwordx4, two unpadded 32 KB stages with an XOR swizzle (piece p of
 //  row r in slot p ^ ((r >> 1) & 7), conflict-free for ds_read_b128), one barrier per slab.  Bit-identical results, but 64 KB of LDS leave two workgroups per CU instead of
-//  four: 230 -> 250 ms per Mel-Band step, same box, alternating runs.  Two register sets (slab k + 2 in flight) lost the fourth workgroup to registers: 269 -> 279 ms.)
+//  four: 230 -> 250 ms per Mel-Band step, same box, alternating runs.  Two register sets (slab k + 2 in flight) lost the fourth workgroup to registers: 269 -> 279 ms.
+//  Eight wavefronts per workgroup (2 x 4 quadrants of 64 x 32, 70 registers, 24 - 32 wavefronts per CU instead of 16): within 3 % of this form on every Mel-Band shape
+//  (tests/unit/gemm16_unit -t: 357 / 419 / 694 / 502 against 371 / 417 / 681 / 461 TFLOP/s at N x K = 1544 x 384, 1536 x 384, 384 x 1536, 384 x 512) -- the loop is not
+//  short of wavefronts to cover its loads with; at 0.016 byte per flop it asks the L2s for ~11 TB/s at 700 TFLOP/s, and a larger tile is what would lower that.)
 // Consecutive logical tile ids share an XCD (ade_gemm.h): all n-tiles of an m-strip re-read that strip of A from one L2.
 __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
     const int per = total >> 3, rem = total & 7, xcd = w & 7, idx = w >> 3;

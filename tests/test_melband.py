@@ -315,9 +315,11 @@ def test_gpu_full_depth_full_length_properties():
 
 
 @pytest.mark.gpu
-def test_gpu_baseline_batch_32_x_8s_properties():
-    """BASELINE configs[3] at its stated batch: 32 stereo segments of 8 s (801 frames), depth 6, ONE call -- the shape `bench.py --workload melband` times.  Size-independent
-    properties: every output finite, a silent row exactly silent, a row's bits the same as in a call of its own and as in the reversed batch (row independence at batch 32)."""
+@pytest.mark.parametrize("gemm_dtype", ["f32", "bf16"])
+def test_gpu_baseline_batch_32_x_8s_properties(gemm_dtype):
+    """BASELINE configs[3] at its stated batch: 32 stereo segments of 8 s (801 frames), depth 6, ONE call -- the shape `bench.py --workload melband` times, on the parity
+    dtype and on the bf16 path (bf16 activations and weights stored in HBM).  Size-independent properties: every output finite, a silent row exactly silent, a row's bits the
+    same as in a call of its own and as in the reversed batch (row independence at batch 32: the tile / XCD mapping of a row's products depends on the batch)."""
     from audio_denoiser_onnx_amd import melband
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_stereo
@@ -328,7 +330,7 @@ def test_gpu_baseline_batch_32_x_8s_properties():
     del w
     x = np.stack([synth_stereo(100 + i, L, 44100).reshape(-1) for i in range(B)])
     x[5] = 0                                                          # a silent segment among the 32
-    with InferenceSession(weights=blob, metadata=melband.metadata(L)) as sess:
+    with InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=gemm_dtype)) as sess:
         assert sess.frames == 801
         out, f32 = sess.process(x, want_f32=True)
         assert out.shape == (B, sess.row_out)

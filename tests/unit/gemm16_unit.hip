@@ -71,8 +71,27 @@ static int run_case(int M, int N, int K) {
     return ok ? 0 : 1;
 }
 
+static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the plain-store product (GPU builds)
+    unsigned short *dA, *dB, *dCb; float *dC, *dbias;
+    hipMalloc((void**)&dA, (size_t)M * K * 2); hipMalloc((void**)&dB, (size_t)N * K * 2); hipMalloc((void**)&dC, (size_t)M * N * 4); hipMalloc((void**)&dCb, (size_t)M * N * 2); hipMalloc((void**)&dbias, (size_t)N * 4);
+    hipMemset(dA, 0x3c, (size_t)M * K * 2); hipMemset(dB, 0x3c, (size_t)N * K * 2); hipMemset(dbias, 0, (size_t)N * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) launch((hipStream_t)0, dA, K, dB, K, PlainStore{dC, dCb, dbias, N}, M, N, K);
+    hipEventRecord(e0, 0);
+    const int reps = 10;
+    for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, PlainStore{dC, dCb, dbias, N}, M, N, K);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("gemm16 M=%d N=%d K=%d: %.3f ms, %.1f TFLOP/s\n", M, N, K, ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
+}
+
 int main(int argc, char** argv) {
     int rc = 0;
+    if (argc >= 5 && argv[1][0] == '-' && argv[1][1] == 't') {
+        for (int i = 2; i + 2 < argc; i += 3) time_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
+        return 0;
+    }
     if (argc < 4) { rc |= run_case(130, 70, 72); return rc; }
     for (int i = 1; i + 2 < argc; i += 3) rc |= run_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
     return rc;
