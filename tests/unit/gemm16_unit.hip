@@ -71,6 +71,12 @@ static int run_case(int M, int N, int K) {
     return ok ? 0 : 1;
 }
 
+struct BfStore {               // the cheapest useful store: bf16(v)
+    bf16_t* cb;
+    int ld;
+    __device__ NoCol col(int, int) const { return NoCol{}; }
+    __device__ void operator()(int m, int n, float4 v, int cnt, NoCol) const { store_bf16x4(cb + (size_t)m * ld + n, v, cnt); }
+};
 static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the plain-store product (GPU builds)
     unsigned short *dA, *dB, *dCb; float *dC, *dbias;
     hipMalloc((void**)&dA, (size_t)M * K * 2); hipMalloc((void**)&dB, (size_t)N * K * 2); hipMalloc((void**)&dC, (size_t)M * N * 4); hipMalloc((void**)&dCb, (size_t)M * N * 2); hipMalloc((void**)&dbias, (size_t)N * 4);
@@ -82,7 +88,12 @@ static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the 
     for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, PlainStore{dC, dCb, dbias, N}, M, N, K);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("gemm16 M=%d N=%d K=%d: %.3f ms, %.1f TFLOP/s\n", M, N, K, ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    printf("gemm16 M=%d N=%d K=%d: fp32 + bf16 store %.3f ms, %.1f TFLOP/s", M, N, K, ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, BfStore{dCb, N}, M, N, K);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    printf(" | bf16 store only %.3f ms, %.1f TFLOP/s\n", ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
 }
 
