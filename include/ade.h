@@ -115,8 +115,11 @@ ade_status ade_reserve(ade_handle h, int batch);
  * caller-provided stream is not synchronised by the engine, so its failure is reported by the NEXT call on the handle (or by the debug tap "xchg_error").
  * "full_taps" = "0"/"1": 1 launches the debug build of the single-launch kernel, which stores every inter-stage tensor whole (the shipped kernel keeps channels 0-7 of
  * x_d0 / x_d1 / dp2 in LDS -- their only reader is the next block); set it before a call whose ade_debug_tap results are compared channel by channel.
- * "host_split" = "0".."8": sub-batches ade_process cuts a host batch into, each on its own stream, so that the copies of one overlap the kernel of another (0 = per call:
- * two for 128 rows or more; 1 = never; DESIGN.md section 6 has the measurements).
+ * "host_stream" = "0".."8": row groups ade_process streams a host batch THROUGH ONE LAUNCH in (GTCRN's fused path): every group's copy-in is followed by a 64 KB copy carrying
+ * the call's epoch, the group's workgroups wait for it before their first PCM read, the group's last workgroup tells the host thread, which starts the group's copy-out -- the
+ * copies of the other groups run under the launch's arithmetic (0 = per call: four groups from 128 rows; 1 = off; same bits as the device-resident launch).
+ * "host_split" = "0".."8": with "host_stream" = "1": sub-batches ade_process cuts a host batch into instead, each with its own launch on its own stream (0 = per call: two
+ * for 128 rows or more; 1 = never).  DESIGN.md section 6 has the measurements of both.
  * "xchg_withhold" = "0"/"1": TEST HOOK, makes the first workgroup of the next launches raise its hand-off flags where nobody polls (forces the time-out path). */
 ade_status ade_set_option(ade_handle h, const char* key, const char* value);
 
