@@ -125,6 +125,9 @@ struct ade_engine {
     int xwait_ticks = 20000000;           // bound of one inter-workgroup wait in 10 ns ticks (option "xwait_ms"; 0.2 s)
     int full_taps = 0;                    // option "full_taps": the single-launch kernel stores every inter-stage tensor whole (ChunkCall::full_taps)
     int xchg_withhold = 0;                // test hook (option "xchg_withhold"): SegPlan::withhold
+    int xwait_retry = 1;                  // option "xwait_retry": ade_process re-runs a call whose segmented launch timed out ONCE on the path without hand-offs (see ade_process)
+    bool timed_out = false;               // exchange_status() found a time-out (as opposed to any other ADE_ERR_DEVICE)
+    int retries = 0;                      // calls re-run that way (debug tap "xwait_retries")
     int geometry = -1;                    // fused-path workgroup geometry (ade_internal.h): -1 = choose per call, 0 = 1024 threads x 64 frames, 1 = 512 x 32
     ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
     float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
@@ -849,6 +852,7 @@ ade_status exchange_status(ade_engine* h, const char* who, bool earlier) {
     h->d_xerr[0] = 0;
     if (h->d_xflags) (void)hipMemset(h->d_xflags, 0, (size_t)h->xchg_capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
     const int block = (code >> 4) - 1, idx = code & 15, B = h->last_batch > 0 ? h->last_batch : 1;
+    h->timed_out = true;
     char msg[384];
     if (idx == 15)      // dev::wait_rows_in: a streamed host batch (ade_process) whose rows were not delivered in time
         snprintf(msg, sizeof msg, "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for its rows of the host batch to be copied in; no output was produced "
@@ -1346,6 +1350,11 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         free_graphs(h);
         return ADE_OK;
     }
+    if (strcmp(key, "xwait_retry") == 0) {     // "1" (default): ade_process re-runs a timed-out call once without hand-offs; "0": it fails
+        if ((value[0] != '0' && value[0] != '1') || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option xwait_retry: 0 or 1");
+        h->xwait_retry = value[0] - '0';
+        return ADE_OK;
+    }
     if (strcmp(key, "host_stream") == 0) {     // row groups a host batch is streamed through ONE launch in (ade_process); 0 = per call (four from 128 rows), 1 = off
         if (value[0] < '0' || value[0] > '8' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option host_stream: 0..8");
         h->host_stream = value[0] - '0';
@@ -1567,8 +1576,31 @@ ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* ou
     return ADE_OK;
 }
 
+static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32);
+
+// The host-buffer entry.  A bounded inter-workgroup wait that gives up fails the launch (exchange_status); on a shared or pre-empted GPU, under a debugger or a
+// serialising profiler that can happen to a perfectly valid call.  This entry is synchronous and owns its buffers for the duration of the call, so it re-runs such a
+// call ONCE on the path that has no hand-offs -- whole chunks per workgroup (geometry 0, the same bits), or the multi-kernel sequence where a chunk has more than 64
+// frames -- and reports success; ade_last_error then says that a retry happened.  Option "xwait_retry" = "0" turns this off; the test hook that withholds a flag does too.
 ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32) {
     if (!h) return ADE_ERR_BAD_VALUE;
+    h->timed_out = false;
+    ade_status st = process_once(h, in, batch, out_pcm, out_f32);
+    if (st == ADE_ERR_DEVICE && h->timed_out && h->xwait_retry && !h->xchg_withhold && !h->sub) {
+        const std::string first = h->last_error;
+        const int keep_geo = h->geometry, keep_fused = h->use_fused;
+        if (fused_supported(h->T, 0)) h->geometry = 0; else h->use_fused = 0;
+        free_graphs(h);
+        h->timed_out = false;
+        st = process_once(h, in, batch, out_pcm, out_f32);
+        h->geometry = keep_geo; h->use_fused = keep_fused;
+        free_graphs(h);
+        if (st == ADE_OK) { ++h->retries; h->last_error = "ade_process: re-run without inter-workgroup hand-offs after: " + first; }
+    }
+    return st;
+}
+
+static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32) {
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process: bad arguments");
     if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_f32");
     if (batch == 0) return ADE_OK;
@@ -1636,7 +1668,10 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
                 if (!in_direct) { memcpy(h->h_pcm_in + i0, in + i0, (size_t)nr * h->in_len * sizeof(int16_t)); src = h->h_pcm_in + i0; }
                 HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
                 HIP_TRY(h, hipMemcpyAsync(h->d_sio_ready + (size_t)g * kReadyStride, h->h_sio_epoch, (size_t)kReadyStride * sizeof(unsigned), hipMemcpyHostToDevice, h->s_in));
-                if (g == 0) {       // the launch goes out behind the FIRST group's copies (enqueued, not complete): the rest of the enqueueing runs under the copy
+                if (g == 0) {       // the launch goes out behind the FIRST group's copies (enqueued, not complete): enqueueing the other groups' copies -- ~25 us of API time
+                                    // each -- runs under the first copy; launching only after all of them measured 0.735 ms per call against 0.635.  A later group's
+                                    // workgroups therefore also wait out this thread's progress through the loop: their bound (option "xwait_ms", 200 ms) is four orders
+                                    // of magnitude above it, and a call that does time out is re-run (ade_process above)
                     ChunkCall C{};
                     C.plan.nseg = fused_segments(h->T, geo); C.plan.xchg = h->d_xchg; C.plan.flags = h->d_xflags; C.plan.err = h->d_xerr; C.plan.wave_swap = h->wave_swap;
                     C.plan.prio = h->seg_prio; C.plan.withhold = h->xchg_withhold; C.plan.wait_ticks = h->xwait_ticks;
@@ -1795,6 +1830,12 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         out[0] = h->last_fused ? (float)h->last_geometry : -1.0f;
         if (count > 1) out[1] = h->last_fused ? (float)fused_segments(h->T, h->last_geometry) : 0.0f;
         *written = count > 1 ? 2 : 1;
+        return ADE_OK;
+    }
+    if (strcmp(name, "xwait_retries") == 0) {     // calls ade_process re-ran without hand-offs after a time-out (option "xwait_retry")
+        if (count < 1) return fail(h, ADE_ERR_SHAPE_MISMATCH, "tap buffer too small");
+        out[0] = (float)h->retries;
+        *written = 1;
         return ADE_OK;
     }
     if (strcmp(name, "xchg_error") == 0) {        // non-zero (the dev::xcode of the wait) after a bounded inter-workgroup wait of the segmented fused path gave up; sticky until an entry point reports it

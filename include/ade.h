@@ -113,6 +113,9 @@ ade_status ade_reserve(ade_handle h, int batch);
  * "xwait_ms" = bound of one inter-workgroup wait of the segmented fused path in milliseconds (default 200).  When a wait gives up, the CALL fails with ADE_ERR_DEVICE
  * (message: chunk, segment and the hand-off that did not arrive), no PCM is handed out, every hand-off flag is cleared and the next call starts clean; a launch on a
  * caller-provided stream is not synchronised by the engine, so its failure is reported by the NEXT call on the handle (or by the debug tap "xchg_error").
+ * "xwait_retry" = "1" (default) / "0": ade_process (synchronous, host buffers) re-runs a call whose launch timed out ONCE on the path without hand-offs (whole chunks per
+ * workgroup: the same bits) and returns ADE_OK -- a pre-empted or profiled GPU must not fail a valid call; ade_last_error then names the retry, the tap "xwait_retries" counts
+ * them.  The device-pointer entries and "0" keep the failure.
  * "full_taps" = "0"/"1": 1 launches the debug build of the single-launch kernel, which stores every inter-stage tensor whole (the shipped kernel keeps channels 0-7 of
  * x_d0 / x_d1 / dp2 in LDS -- their only reader is the next block); set it before a call whose ade_debug_tap results are compared channel by channel.
  * "host_stream" = "0".."8": row groups ade_process streams a host batch THROUGH ONE LAUNCH in (GTCRN's fused path): every group's copy-in is followed by a 64 KB copy carrying

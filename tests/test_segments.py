@@ -212,3 +212,32 @@ def test_gpu_lean_stores():
             else:
                 want = full[2][name]
             assert np.array_equal(got, want), f"geometry {geometry}: tap {name}"
+
+
+@pytest.mark.gpu
+def test_gpu_timed_out_call_is_rerun_without_handoffs_by_the_host_entry():
+    """A bounded inter-workgroup wait that gives up on a VALID call (a pre-empted or profiled GPU; forced here by a 1 us bound, which no successor segment can meet) must not
+    fail ade_process: the synchronous host entry re-runs the call once on the path without hand-offs -- the same bits -- and says so; with "xwait_retry" = "0", and on the
+    device-pointer entries, the failure stands."""
+    import torch
+    from audio_denoiser_onnx_amd._lib import AdeDeviceError
+    x = synth_batch(9)
+    sess = make_session(None, seed=0)
+    ref = run(sess, x, "0")
+    sess.set_option("geometry", "2")
+    sess.set_option("xwait_ms", "0.001")
+    out = np.zeros((x.shape[0], sess.row_out), np.int16)
+    before = sess.tap("xwait_retries", 1)[0]
+    sess.process_into(x, out)
+    assert np.array_equal(out, ref[0]), "the re-run must produce the whole-chunk geometry's bits"
+    assert sess.tap("xwait_retries", 1)[0] == before + 1
+    sess.set_option("xwait_retry", "0")
+    with pytest.raises(AdeDeviceError, match=r"timed out"):
+        sess.process_into(x, out)
+    sess.set_option("xwait_retry", "1")
+    d_in, d_out = torch.from_numpy(x).cuda(), torch.zeros((x.shape[0], sess.row_out), dtype=torch.int16, device="cuda")
+    with pytest.raises(AdeDeviceError, match=r"timed out"):
+        sess.run_device(d_in, d_out)                 # device-pointer entry: reports, does not retry
+    sess.set_option("xwait_ms", "200")
+    for rep in range(2):
+        assert_same(ref, run(sess, x, "2"), f"call {rep} after the forced time-outs")

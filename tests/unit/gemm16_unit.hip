@@ -97,8 +97,27 @@ static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the 
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
 }
 
+#if defined(HIPSIM)
+// host-simulator build only (device helpers are plain functions there): the launch-constant division against the real one, and the erf used by the bf16 GELU
+static int helper_checks() {
+    int bad = 0;
+    for (int d : {1, 2, 3, 7, 60, 64, 151, 801, 1000, 25632, 100000, 1537920}) {
+        const FastDiv f = make_fastdiv(d);
+        for (long long n = 0; n < (1ll << 31); n += (n < 70000 ? 1 : 9973)) bad += f.div((int)n) != (int)(n / d);
+        for (long long n : {(1ll << 31) - 1, (long long)d * 1000 - 1, (long long)d * 1000, (long long)d * 1000 + 1}) if (n >= 0 && n < (1ll << 31)) bad += f.div((int)n) != (int)(n / d);
+    }
+    double worst = 0.0;
+    for (int i = -80000; i <= 80000; ++i) { const float x = i * 1e-4f; worst = fmax(worst, fabs((double)erf_fast(x) - erf((double)x))); }
+    printf("FastDiv mismatches %d; erf_fast max |error| %.2e over [-8, 8] -> %s\n", bad, worst, bad == 0 && worst < 5e-7 ? "OK" : "FAIL");
+    return bad == 0 && worst < 5e-7 ? 0 : 1;
+}
+#endif
+
 int main(int argc, char** argv) {
     int rc = 0;
+#if defined(HIPSIM)
+    rc |= helper_checks();
+#endif
     if (argc >= 5 && argv[1][0] == '-' && argv[1][1] == 't') {
         for (int i = 2; i + 2 < argc; i += 3) time_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
         return 0;
