@@ -155,6 +155,29 @@ def test_gpu_batch_fold_matches_reference_fixture(fixture):
 
 
 @pytest.mark.gpu
+def test_gpu_bf16_path_on_a_batch_fold_manifest(fixture):
+    """The bf16 path behind a use_batch_fold = 1 manifest (windows folded inside the engine, two calls in the batch): within 30 dB of the f32 path on the reference-run fold
+    fixture, and the two identical calls of the batch come back identical."""
+    from audio_denoiser_onnx_amd import melband
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    w = fixture[2]
+    zf = np.load(GOLD_FOLD)
+    blob = pack_blob(melband.model_tensors(w))
+    x = np.stack((zf["pcm_in"], zf["pcm_in"]))
+    outs = {}
+    for dt in ("f32", "bf16"):
+        meta = melband.metadata(int(zf["input_audio_length"]), use_batch_fold=True, batch_window_seconds=float(zf["batch_window_seconds"]), gemm_dtype=dt)
+        with InferenceSession(weights=blob, metadata=meta) as sess:
+            outs[dt] = sess.process(x.reshape(2, -1), want_f32=True)[1]
+    err, sig = outs["bf16"].astype(np.float64) - outs["f32"], outs["f32"].astype(np.float64)
+    snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
+    print(f"mel_band_roformer bf16 vs f32 on the fold manifest: SNR {snr:.1f} dB")
+    assert np.isfinite(outs["bf16"]).all() and snr > 30.0
+    assert np.array_equal(outs["bf16"][0], outs["bf16"][1])
+
+
+@pytest.mark.gpu
 def test_gpu_file_driver_slices_batches_and_trims(fixture, session, tmp_path):
     """The reference driver's life-cycle on a stereo WAVEX file that is not a whole number of slices (seeded noise tail)."""
     from audio_denoiser_onnx_amd import inference_melband as drv
