@@ -37,23 +37,8 @@ constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kRow = 20;               // LDS floats per staged row
 constexpr int kSub = 1;                // 16-k slabs staged per barrier pair; 2 measured SLOWER (MossFormer in-projection 1384 -> 1616 us: the 40 KB of LDS cost a resident workgroup)
 constexpr bool kDouble = false;        // two LDS slabs used alternately, ONE barrier per 16-k slab (needs kSub == 1): measured SLOWER on the final round-2 tree (MossFormer 960 -> 1007 ms,
-                                       // Mel-Band 981 -> 1042 ms; the bf16 mode unchanged) -- 40 KB of LDS per workgroup costs a resident workgroup, which hides more than the second barrier costs
+                                       // Mel-Band 981 -> 1042 ms) -- 40 KB of LDS per workgroup costs a resident workgroup, which hides more than the second barrier costs
 constexpr int kSlab = (kDouble ? 2 : kSub) * kTM * kRow;   // floats per operand staging area
-
-// bf16-input mode (BF16 = true on the tile functions below): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS; the products
-// run as v_mfma_f32_16x16x16_bf16 with fp32 accumulation -- one instruction per 16-deep slab and tile instead of four.  A throughput mode, not the parity path.
-#if defined(__clang__)
-typedef short v4s __attribute__((ext_vector_type(4)));
-#else
-typedef short v4s __attribute__((vector_size(8)));
-#endif
-__device__ __forceinline__ unsigned bf16_bits(float x) {            // fp32 -> bf16, round to nearest even (inputs are finite activations / weights)
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ uint2 bf16x4(const float4& v) { return make_uint2(bf16_bits(v.x) | (bf16_bits(v.y) << 16), bf16_bits(v.z) | (bf16_bits(v.w) << 16)); }
-__device__ __forceinline__ v4f mfma16x16x16_bf16(v4s a, v4s b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 // A Store may declare `static constexpr bool kCtx = true` and then provides, instead of operator()(m, n, v),
 //     RowT row(int m) const;  ColT col(int n) const;  PreT pre(int m, int n, const RowT&) const;      (what it needs to READ: per row, per column, per element; `None` if nothing)
@@ -71,17 +56,12 @@ template <class T>
 struct HasVec4<T, std::void_t<decltype(&T::vec4)>> : std::true_type {};
 
 // one 128 x 128 tile of C at (m_blk, n_blk); As / Bs: the workgroup's two kSlab LDS slabs
-template <bool BF16 = false, class AL, class BL, class ST>
+template <class AL, class BL, class ST>
 __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const ST& store, int M, int N, int K, int m_blk, int n_blk,
                                           float* As_all, float* Bs_all) {
-    constexpr int kRowW = BF16 ? kRow / 2 : kRow;      // row pitch in 32-bit words (bf16: 16 values + 4 padding = 10 words)
-    constexpr int kSlabW = kTM * kRowW;                // words per staged 16-k slab
-    constexpr int kS = kSub;                           // (two bf16 slabs per barrier pair -- same LDS -- measured: Mel-Band bf16 447 -> 441 ms but MossFormer bf16 538 -> 585 ms: the extra
-                                                       // prefetch registers spill under the 128-VGPR cap)
-    auto put4 = [&](float* base, int row, int kk, const float4& v) {           // four consecutive k of one row
-        if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kk / 2) = bf16x4(v);
-        else *reinterpret_cast<float4*>(base + row * kRow + kk) = v;
-    };
+    constexpr int kSlabW = kTM * kRow;                 // words per staged 16-k slab
+    constexpr int kS = kSub;
+    auto put4 = [&](float* base, int row, int kk, const float4& v) { *reinterpret_cast<float4*>(base + row * kRow + kk) = v; };      // four consecutive k of one row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int j16 = lane & 15, g = lane >> 4;
@@ -189,44 +169,29 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             const int kk = tid & 15, cg = tid >> 4;
             const float t[8] = {rb[sub][0].x, rb[sub][0].y, rb[sub][0].z, rb[sub][0].w, rb[sub][1].x, rb[sub][1].y, rb[sub][1].z, rb[sub][1].w};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if constexpr (BF16) reinterpret_cast<unsigned short*>(Bs)[(cg + 16 * u) * (2 * kRowW) + kk] = (unsigned short)bf16_bits(t[u]);
-                else Bs[(cg + 16 * u) * kRow + kk] = t[u];
-            }
+            for (int u = 0; u < 8; ++u) Bs[(cg + 16 * u) * kRow + kk] = t[u];
         }
     };
     auto compute = [&](int buf) {
             const float* As = As_all + buf * kSlabW;
             const float* Bs = Bs_all + buf * kSlabW;
-            if constexpr (BF16) {           // lane (g, j16): four consecutive k (= 4 g ..) of its row as four bf16: one ds_read_b64 per operand tile
-                v4s a8[4], b8[4];
+            float4 a4[4];                   // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (wn + 16 * j + j16) * kRowW + 2 * g);
+            for (int j = 0; j < 4; ++j) {                                     // one B operand at a time: 16 MFMAs hide the next ds_read, and 12 fewer live VGPRs
+                const float4 b4 = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
-            } else {
-                float4 a4[4];               // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {                                 // one B operand at a time: 16 MFMAs hide the next ds_read, and 12 fewer live VGPRs
-                    const float4 b4 = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);
-                        acc[i][j] = mfma16x16x4(a4[i].y, b4.y, acc[i][j]);
-                        acc[i][j] = mfma16x16x4(a4[i].z, b4.z, acc[i][j]);
-                        acc[i][j] = mfma16x16x4(a4[i].w, b4.w, acc[i][j]);
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].y, b4.y, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].z, b4.z, acc[i][j]);
+                    acc[i][j] = mfma16x16x4(a4[i].w, b4.w, acc[i][j]);
                 }
             }
     };
     if constexpr (kDouble) {
-        static_assert(!kDouble || (kSub == 1 && !BF16), "the double-buffered loop stages one f32 slab at a time");
+        static_assert(!kDouble || kSub == 1, "the double-buffered loop stages one f32 slab at a time");
         fetch(0, 0);
         stash(0, 0);
         __syncthreads();
@@ -332,25 +297,24 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
     return (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
 }
 
-template <class AL, class BL, class ST, bool BF16 = false>
+template <class AL, class BL, class ST>
 __global__ __launch_bounds__(256, 4) void k_gemm128(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
     const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
-    gemm_tile<BF16>(a_of, b_of, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, As, Bs);
+    gemm_tile(a_of, b_of, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, As, Bs);
 }
 
 template <class AL, class BL, class ST>
-inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K, bool bf16 = false) {
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST, true>), grid, dim3(256), 0, s, a, b, st, M, N, K);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST, false>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }
 
 // Batched form: blockIdx.z selects a problem.  `prob(z)` (evaluated once per workgroup, so its table reads are scalar loads)
 // returns a struct with members a, b, st (functors as above) and M, N, K; problems may differ in every one of them -- tiles
 // outside a problem's own M x N exit at once, the grid is sized for the largest.
-template <class P, bool BF16 = false>
+template <class P>
 __global__ __launch_bounds__(256, 4) void k_gemm128_batched(P prob) {
     __shared__ __attribute__((aligned(16))) float As[kSlab];
     __shared__ __attribute__((aligned(16))) float Bs[kSlab];
@@ -360,14 +324,13 @@ __global__ __launch_bounds__(256, 4) void k_gemm128_batched(P prob) {
     const auto q = prob(z);
     const int m_blk = (in_z / gx) * kTM, n_blk = (in_z % gx) * kTN;
     if (m_blk >= q.M || n_blk >= q.N) return;
-    gemm_tile<BF16>(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
+    gemm_tile(q.a, q.b, q.st, q.M, q.N, q.K, m_blk, n_blk, As, Bs);
 }
 
 template <class P>
-inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N, bool bf16 = false) {
+inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N) {
     const dim3 grid((unsigned)((max_N + kTN - 1) / kTN), (unsigned)((max_M + kTM - 1) / kTM), (unsigned)batch);
-    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P, true>), grid, dim3(256), 0, s, prob);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P, false>), grid, dim3(256), 0, s, prob);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128_batched<P>), grid, dim3(256), 0, s, prob);
 }
 
 // ---- common functors ------------------------------------------------------------------------------------------

@@ -15,9 +15,6 @@
 //   struct Store { __device__ void operator()(int m, int n, float v) const; };
 // The Row hook is what lets an implicit-convolution loader do its (batch, frame, bin) index split once instead of per fetch.
 // K must be a multiple of 4.
-// BF16 = true: the same tile with bf16 INPUTS and fp32 accumulation (v_mfma_f32_16x16x16_bf16: one instruction per 16-deep slab and tile instead of
-// four): operands stay fp32 in HBM and are rounded to bf16 (nearest even) on their way into LDS, so a model can be switched between the exact
-// fp32 path (parity) and the bf16 path (throughput; BASELINE.json's dtype for the transformer families) without touching its data layout.
 #pragma once
 #include "ade_device.h"
 #include "ade_gemm.h"
@@ -29,11 +26,6 @@ using namespace dev;
 
 constexpr int kTM = 256, kTN = 64, kTK = 16, kRow = gemm::kRow;
 
-using gemm::v4s;
-using gemm::bf16_bits;
-using gemm::bf16x4;
-using gemm::mfma16x16x16_bf16;
-
 // waves per SIMD the register allocator aims for: 4 (128 VGPRs) unless the A loader says otherwise -- the implicit-convolution loaders keep per-row state in
 // registers and spill at 128 (measured: the ZipEnhancer step 170 -> 188 ms with spills), so they declare kWavesPerSimd = 3
 template <class T, class = void>
@@ -41,11 +33,10 @@ struct WavesPerSimd { static constexpr int value = 4; };
 template <class T>
 struct WavesPerSimd<T, std::void_t<decltype(T::kWavesPerSimd)>> { static constexpr int value = T::kWavesPerSimd; };
 
-template <class AL, class BL, class ST, bool BF16>
+template <class AL, class BL, class ST>
 __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[kTM * kRow];          // bf16: the same rows at half the pitch (10 words: 16 bf16 + 4 padding)
+    __shared__ __attribute__((aligned(16))) float As[kTM * kRow];
     __shared__ __attribute__((aligned(16))) float Bs[kTN * kRow];
-    constexpr int kRowW = BF16 ? kRow / 2 : kRow;                          // row pitch in 32-bit words
     const int gx = (int)gridDim.x, id = gemm::xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
     const int m_blk = (id / gx) * kTM, n_blk = (id % gx) * kTN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,43 +73,25 @@ __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL 
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
-        if constexpr (BF16) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<uint2*>(As + (r + 64 * h) * kRowW + kq / 2) = bf16x4(ra[h]);
-            *reinterpret_cast<uint2*>(Bs + r * kRowW + kq / 2) = bf16x4(rb);
-        } else {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
-            *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;
-        }
+        for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
+        *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;
         __syncthreads();
         if (k0 + kTK < K) fetch(k0 + kTK);
-        if constexpr (BF16) {               // lane (g, j16): A[row 16 i + j16][k = 4 g .. 4 g + 3] as four bf16 = one ds_read_b64
-            v4s a8[4], b8[4];
+        float4 a4[4], b4[4];                // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a8[i] = *reinterpret_cast<const v4s*>(As + (wm + 16 * i + j16) * kRowW + 2 * g);
+        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const v4s*>(Bs + (16 * j + j16) * kRowW + 2 * g);
+        for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (16 * j + j16) * kRow + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
-        } else {
-            float4 a4[4], b4[4];            // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16]
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(Bs + (16 * j + j16) * kRow + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
-                }
-        }
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma16x16x4(a4[i].x, b4[j].x, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].y, b4[j].y, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].z, b4[j].z, acc[i][j]);
+                acc[i][j] = mfma16x16x4(a4[i].w, b4[j].w, acc[i][j]);
+            }
         __syncthreads();
     }
     // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
@@ -173,11 +146,10 @@ __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL 
 }
 
 template <class AL, class BL, class ST>
-inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K, bool bf16 = false) {
+inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
     if (M <= 0 || N <= 0) return;
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST, true>), grid, dim3(256), 0, s, a, b, st, M, N, K);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST, false>), grid, dim3(256), 0, s, a, b, st, M, N, K);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm256x64<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }
 
 // ---- K = 64 projections: out(m, off + n) = sum_{k < 64} x(m, k) w(n, k) + bias(n) ------------------------------------------------------------------------
@@ -187,25 +159,21 @@ inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M,
 //   * the weights stream through LDS 64 columns at a time, double-buffered (one barrier per 64 columns);
 //   * the product is formed TRANSPOSED (weights as the A operand, activations as B), so a lane's four accumulator registers are four CONSECUTIVE output columns of one
 //     row: one 16-byte store per tile instead of four 4-byte ones.
-// ldx, ldo, off: multiples of 4; w: (N, 64) row-major; N a multiple of 16.  BF16 as above.
-template <bool BF16, int RT>
+// ldx, ldo, off: multiples of 4; w: (N, 64) row-major; N a multiple of 16.
+template <int RT>
 __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
                                                 int ldo, int off, int M, int N) {
     __shared__ __attribute__((aligned(16))) float Ws[2][4 * 64 * kRow];     // [buffer][ks][column][16 k + pad]
-    constexpr int kRowW = BF16 ? kRow / 2 : kRow;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j16 = lane & 15, g = lane >> 4;
     const int m0 = (int)blockIdx.x * (64 * RT) + wave * (16 * RT);
     float4 xa[RT][4];                        // [row tile i][ks]
-    v4s xb[RT][4];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int m = m0 + 16 * i + j16;
         const float* row = x + (size_t)(m < M ? m : 0) * ldx + 4 * g;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const float4 v = keep4(m < M, *reinterpret_cast<const float4*>(row + 16 * ks));      // clamped row, no branch around the load
-            if constexpr (BF16) { const uint2 q = bf16x4(v); xb[i][ks] = *reinterpret_cast<const v4s*>(&q); }
-            else xa[i][ks] = v;
+            xa[i][ks] = keep4(m < M, *reinterpret_cast<const float4*>(row + 16 * ks));           // clamped row, no branch around the load
         }
     }
     auto stage = [&](int n0, int buf) {       // 64 columns x 64 k: 1024 float4, four per lane
@@ -213,9 +181,7 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
         for (int u = 0; u < 4; ++u) {
             const int idx = tid + 256 * u, c = idx >> 4, k4 = (idx & 15) * 4, n = n0 + c;
             const float4 v = keep4(n < N, *reinterpret_cast<const float4*>(w + (size_t)(n < N ? n : 0) * 64 + k4));
-            float* dst = Ws[buf] + ((k4 >> 4) * 64 + c) * kRowW;
-            if constexpr (BF16) *reinterpret_cast<uint2*>(dst + (k4 & 15) / 2) = bf16x4(v);
-            else *reinterpret_cast<float4*>(dst + (k4 & 15)) = v;
+            *reinterpret_cast<float4*>(Ws[buf] + ((k4 >> 4) * 64 + c) * kRow + (k4 & 15)) = v;
         }
     };
     stage(0, 0);
@@ -233,15 +199,7 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
             for (int i = 0; i < RT; ++i) acc[jn][i] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (BF16) {
-                v4s wb[4];
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn) wb[jn] = *reinterpret_cast<const v4s*>(Ws[buf] + (ks * 64 + 16 * jn + j16) * kRowW + 2 * g);
-#pragma unroll
-                for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[jn][i] = mfma16x16x16_bf16(wb[jn], xb[i][ks], acc[jn][i]);
-            } else {
+            {
                 float4 wv[4];
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn) wv[jn] = *reinterpret_cast<const float4*>(Ws[buf] + (ks * 64 + 16 * jn + j16) * kRow + 4 * g);
@@ -279,12 +237,11 @@ __global__ __launch_bounds__(256) void k_proj64(const float* __restrict__ x, int
         }
     }
 }
-inline void launch_proj64(hipStream_t s, const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int off, int M, int N, bool bf16 = false) {
+inline void launch_proj64(hipStream_t s, const float* x, int ldx, const float* w, const float* bias, float* out, int ldo, int off, int M, int N) {
     if (M <= 0 || N <= 0) return;
     constexpr int RT = 2;                        // 16-row tiles per wavefront: 2 -> 128 rows per workgroup, ~120 VGPRs, four wavefronts per SIMD (4 -> 232 VGPRs, two)
     const dim3 grid((unsigned)((M + 64 * RT - 1) / (64 * RT)));
-    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_proj64<true, RT>), grid, dim3(256), 0, s, x, ldx, w, bias, out, ldo, off, M, N);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_proj64<false, RT>), grid, dim3(256), 0, s, x, ldx, w, bias, out, ldo, off, M, N);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_proj64<RT>), grid, dim3(256), 0, s, x, ldx, w, bias, out, ldo, off, M, N);
 }
 
 // ---- common operands ---------------------------------------------------------------------------------------------------

@@ -271,13 +271,13 @@ struct SubEngine {
 int dfsmn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);
 // model_family "mel_band_roformer" (Mel_Band_Roformer/Stereo/Export_MelBandRoformer.py:262-680), csrc/ade_melband.hip
 // model_family "mossformer2_ss" (MossFormer2_SS_16K/Export_MossFormer2_SS_16K.py:84-662), csrc/ade_mossformer.hip
-int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err);
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool dynamic, int device, SubEngine** out, std::string& err);
 // model_family "ul_unas" (UL-UNAS/Export_UL_UNAS.py:51-913), csrc/ade_ulunas.hip
 int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int dynamic_keep /* 0: static export; > 0: dynamic, the caller-rate input length */, int device, SubEngine** out, std::string& err);
 // model_family "h_gtcrn" (H-GTCRN/Export_H_GTCRN.py:428-1063), csrc/ade_hgtcrn.hip
 int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool dynamic, int device, SubEngine** out, std::string& err);
 // model_family "zipenhancer" (ZipEnhancer/Export_ZipEnhancer.py:357-927), csrc/ade_zipenhancer.hip
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic /* DYNAMIC_AXES export: divide by the overlap-add denominator */, int device, SubEngine** out, std::string& err);
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool dynamic /* DYNAMIC_AXES export: divide by the overlap-add denominator */, int device, SubEngine** out, std::string& err);
 int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

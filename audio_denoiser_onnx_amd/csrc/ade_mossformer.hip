@@ -654,7 +654,6 @@ struct MossformerEngine : SubEngine {
                 *mm_w = nullptr, *mm_b = nullptr, *intra_w = nullptr, *intra_b = nullptr, *tail_w = nullptr, *tail_b = nullptr, *maskdec_w = nullptr,
                 *decoder_w = nullptr;
     std::vector<LayerW> L;
-    bool bf16 = false;            // ade_gemm_dtype = "bf16": the masking network's GEMMs on bf16 inputs (fp32 accumulation); encoder framing, mask decode, decoder fp32
     int capacity = 0;
     float* ws = nullptr;
     float2 *gains = nullptr, *wstats = nullptr, *cstats = nullptr;
@@ -682,7 +681,7 @@ struct MossformerEngine : SubEngine {
     int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) override;
 };
 
-int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
+int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return xfail(err, ADE_ERR_BAD_VALUE, "mossformer: n_win must be >= 1");
     if (window_len < kEncK || (window_len - kEncK) % kEncS != 0)
@@ -712,7 +711,6 @@ int mossformer_create(const std::map<std::string, Tensor>& tensors, int window_l
     const int group = (int)e->hyper[hGroup], rot = (int)e->hyper[hRotDim], depth = (int)e->hyper[hMemDepth], lorder = (int)e->hyper[hLorder];
     if (group < 16 || group > 4096 || rot < 2 || rot > kQk || (rot & 1) || (int)e->hyper[hDwPad] != (kDw - 1) / 2 || depth < 1 || depth > 2 || 2 * lorder - 1 != kMemK)
         return bail(xfail(err, ADE_ERR_UNSUPPORTED, "mossformer: unsupported geometry (group 16..4096, even rotary <= 128, depthwise k 17, memory order 20, depth 1..2)"));
-    e->bf16 = bf16;
     e->lin_scale = dynamic ? (float)(1.0 / (double)n) : 0.0f;       // torch: tensor * (1.0 / n) -- the Python float becomes one fp32 scalar
     e->device = device; e->W = window_len; e->n_win = n_win; e->n = n; e->layers = layers;
     e->padded = (n + group - 1) / group * group;
@@ -836,36 +834,36 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     hipLaunchKernelGGL(k_norm_audio, dim3((unsigned)B), dim3(1024), 0, s, d_in, float_in, W, hyper[hNormFactor], gains, rms_in);
     launch(s, EncFrameA{d_in, float_in, gains, W, n}, WeightNK{encoder_w, kEncK}, BiasActRowStore<1>{XE, nullptr, kDim, 0.0f}, R, kDim, kEncK);
     window_stats(s, XE, hyper[hFrontEps]);
-    launch(s, RowMajorA{XE, kDim}, WeightNK{front_w, kDim}, FrontStore{H, MI, wstats, front_wsum, front_b, emb_pos, n}, R, kDim, kDim, bf16);
+    launch(s, RowMajorA{XE, kDim}, WeightNK{front_w, kDim}, FrontStore{H, MI, wstats, front_wsum, front_b, emb_pos, n}, R, kDim, kDim);
 
     for (int i = 0; i < layers; ++i) {
         const LayerW& l = L[i];
         // ---- FLASH block (:451-505)
         hipLaunchKernelGGL(k_shift_invnorm, rows4(R), dim3(256), 0, s, (const float*)H, inv, R, n, hyper[hFlNormEps]);
-        launch(s, ShiftA{H, n}, WeightNK{l.in_w, kDim}, ScaleSiluStore{P, inv, l.in_b, kIn}, R, kIn, kDim, bf16);
+        launch(s, ShiftA{H, n}, WeightNK{l.in_w, kDim}, ScaleSiluStore{P, inv, l.in_b, kIn}, R, kIn, kDim);
         dwconv(s, P, l.in_c, nullptr, P2, kIn, B);
         hipLaunchKernelGGL(k_offset_rotary, dim3((unsigned)padded, (unsigned)B), dim3(kQk), 0, s, (const float*)P2, l.gamma, l.beta, rot_cos, rot_sin, heads, n,
                            padded, rot, head_stride);
         const float *quad_q = heads, *lin_q = heads + head_stride, *quad_k = heads + 2 * head_stride, *lin_k = heads + 3 * head_stride;
-        launch_batched(s, QuadScoreProb{quad_q, quad_k, ATT, g}, B * groups, g, g, bf16);
-        if (lkv_splits == 1) launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded, 1}, B, kQk, kVu2, bf16);
+        launch_batched(s, QuadScoreProb{quad_q, quad_k, ATT, g}, B * groups, g, g);
+        if (lkv_splits == 1) launch_batched(s, LinKvProb{lin_k, P2, LKV, n, padded, 1}, B, kQk, kVu2);
         else {
-            launch_batched(s, LinKvProb{lin_k, P2, lkv_part, n, padded, lkv_splits}, B * lkv_splits, kQk, kVu2, bf16);
+            launch_batched(s, LinKvProb{lin_k, P2, lkv_part, n, padded, lkv_splits}, B * lkv_splits, kQk, kVu2);
             hipLaunchKernelGGL(k_lkv_reduce, flat((long long)B * kQk * kVu2), dim3(256), 0, s, (const float*)lkv_part, LKV, lkv_splits, (long long)kQk * kVu2,
                                (long long)B * kQk * kVu2);
         }
         if (lin_scale != 0.0f) hipLaunchKernelGGL(k_lkv_scale, flat((long long)B * kQk * kVu2), dim3(256), 0, s, LKV, lin_scale, (long long)B * kQk * kVu2);
-        launch_batched(s, AttOutProb{ATT, P2, lin_q, LKV, AO, g, groups, n, padded}, B * groups, g, kVu2, bf16);
+        launch_batched(s, AttOutProb{ATT, P2, lin_q, LKV, AO, g, groups, n, padded}, B * groups, g, kVu2);
         hipLaunchKernelGGL(k_gate_invnorm, rows4(R), dim3(256), 0, s, (const float*)AO, (const float*)P2, G, inv, R, hyper[hFlOutNormEps]);
-        launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu, bf16);
+        launch(s, RowMajorA{G, kVu}, WeightNK{l.out_w, kVu}, ScaleSiluStore{Y, inv, l.out_b, kDim}, R, kDim, kVu);
         dwconv(s, Y, l.out_c, H, H, kDim, B);
         // ---- gated FSMN block (:507-541)
-        launch(s, RowMajorA{H, kDim}, WeightNK{l.front_w, kDim}, BiasActRowStore<3>{C1, l.front_b, kInner, l.front_alpha}, R, kInner, kDim, bf16);
+        launch(s, RowMajorA{H, kDim}, WeightNK{l.front_w, kDim}, BiasActRowStore<3>{C1, l.front_b, kInner, l.front_alpha}, R, kInner, kDim);
         hipLaunchKernelGGL(k_ln_pair, rows4(R), dim3(256), 0, s, (const float*)C1, l.n1_w, l.n1_b, GF, XN, R, hyper[hFsN1Eps], hyper[hFsLnEps]);
-        launch(s, RowMajorA{XN, kInner}, WeightNK{l.uv_w, kInner}, BiasActRowStore<2>{UV, l.uv_b, kDim, 0.0f}, R, kDim, kInner, bf16);
+        launch(s, RowMajorA{XN, kInner}, WeightNK{l.uv_w, kInner}, BiasActRowStore<2>{UV, l.uv_b, kDim, 0.0f}, R, kDim, kInner);
         dwconv(s, UV, l.uv_c, nullptr, UV2, kDim, B);
-        launch(s, RowMajorA{UV2, kDim}, WeightNK{l.ml_w, kInner}, BiasActRowStore<1>{F1, l.ml_b, kInner, 0.0f}, R, kInner, kInner, bf16);
-        launch(s, RowMajorA{F1, kInner}, WeightNK{l.mp_w, kInner}, BiasActRowStore<0>{XP, nullptr, kInner, 0.0f}, R, kInner, kInner, bf16);
+        launch(s, RowMajorA{UV2, kDim}, WeightNK{l.ml_w, kInner}, BiasActRowStore<1>{F1, l.ml_b, kInner, 0.0f}, R, kInner, kInner);
+        launch(s, RowMajorA{F1, kInner}, WeightNK{l.mp_w, kInner}, BiasActRowStore<0>{XP, nullptr, kInner, 0.0f}, R, kInner, kInner);
         float* mem_prev = nullptr;
         for (int j = 0; j < depth; ++j) {
             float* dst = (j & 1) ? M1 : M0;
@@ -887,7 +885,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
         }
         hipLaunchKernelGGL(k_fsmn_combine, rows4(R), dim3(256), 0, s, (const float*)UV2, (const float*)mem_prev, (const float*)GF, l.n2_w, l.n2_b, N2, R,
                            hyper[hFsN2Eps]);
-        launch(s, RowMajorA{N2, kInner}, WeightNK{l.back_w, kInner}, ResidualBiasStore{H, l.back_b, kDim}, R, kDim, kInner, bf16);
+        launch(s, RowMajorA{N2, kInner}, WeightNK{l.back_w, kInner}, ResidualBiasStore{H, l.back_b, kDim}, R, kDim, kInner);
     }
     // final norms + skip (:544-551)
     hipLaunchKernelGGL(k_ln512, rows4(R), dim3(256), 0, s, (const float*)H, mm_w, mm_b, HL, R, hyper[hMmEps]);
@@ -895,7 +893,7 @@ int MossformerEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t
     hipLaunchKernelGGL(k_window_affine_skip, flat((long long)R * kDim), dim3(256), 0, s, (const float*)HL, (const float2*)wstats, intra_w, intra_b,
                        (const float*)MI, MO, n, (long long)R * kDim);
     // speaker tail, decoder, RMS restore (:599-645)
-    launch(s, LeakyA{MO, kDim, hyper[hTailAlpha]}, WeightNK{tail_w, kDim}, BiasActRowStore<0>{GP, tail_b, kSpk * 2 * kDim, 0.0f}, R, kSpk * 2 * kDim, kDim, bf16);
+    launch(s, LeakyA{MO, kDim, hyper[hTailAlpha]}, WeightNK{tail_w, kDim}, BiasActRowStore<0>{GP, tail_b, kSpk * 2 * kDim, 0.0f}, R, kSpk * 2 * kDim, kDim);
     launch(s, SpeakerGateA{GP, R}, WeightNK{maskdec_w, kDim}, MaskEncStore{SEP, XE, R}, kSpk * R, kDim, kDim);
     launch(s, RowMajorA{SEP, kDim}, RowMajorB{decoder_w, kEncK}, BiasActRowStore<0>{FR, nullptr, kEncK, 0.0f}, kSpk * R, kEncK, kDim);
     hipLaunchKernelGGL(k_decode_restore, dim3((unsigned)(B * kSpk)), dim3(1024), 0, s, (const float*)FR, (const float*)rms_in, d_out, d_f32, WAV, W, n, R, n_win);

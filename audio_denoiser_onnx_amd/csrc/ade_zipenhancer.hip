@@ -267,10 +267,9 @@ __global__ __launch_bounds__(256) void k_zip_hist_norm(float* __restrict__ hist,
 // in the operand register): a third of the global / L2 operand traffic, a third of the staging stores and barriers per MFMA.  256 tokens x 64 output
 // channels per workgroup, wavefront tile 64 x 64, pipeline and LDS layout as in ade_gemm64.h.  k runs (kt, channel block, kf, channel) instead of
 // (tap, channel): the same sum in another order.
-template <bool BF16>
 __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const float* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T, int F,
                                                       int dil, const float* __restrict__ w, const float* __restrict__ bias, float* out, int out_ld, int out_off, int M) {
-    constexpr int kRowW = BF16 ? gemm::kRow / 2 : gemm::kRow, kARows = 264;
+    constexpr int kRowW = gemm::kRow, kARows = 264;
     __shared__ __attribute__((aligned(16))) float As[kARows * kRowW];
     __shared__ __attribute__((aligned(16))) float Bs[3 * 64 * kRowW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, j16 = lane & 15, g = lane >> 4;
@@ -320,10 +319,7 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
         rb1 = *reinterpret_cast<const float4*>(wp + cin);
         rb2 = *reinterpret_cast<const float4*>(wp + 2 * cin);
     };
-    auto put4 = [&](float* base, int row, const float4& v) {
-        if constexpr (BF16) *reinterpret_cast<uint2*>(base + row * kRowW + kq / 2) = gemm::bf16x4(v);
-        else *reinterpret_cast<float4*>(base + row * kRowW + kq) = v;
-    };
+    auto put4 = [&](float* base, int row, const float4& v) { *reinterpret_cast<float4*>(base + row * kRowW + kq) = v; };
     fetch(0);
     for (int st = 0; st < nstage; ++st) {
 #pragma unroll
@@ -337,22 +333,7 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
 #pragma unroll
         for (int kf = 0; kf < 3; ++kf) {
             const unsigned mask = kf == 0 ? left : (kf == 2 ? right : 0xfu);
-            if constexpr (BF16) {
-                gemm::v4s a8[4], b8[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint2 raw = *reinterpret_cast<const uint2*>(As + (wm + 16 * i + j16 + kf) * kRowW + 2 * g);
-                    const bool ok = (mask >> i) & 1u;
-                    const uint2 sel = make_uint2(ok ? raw.x : 0u, ok ? raw.y : 0u);
-                    a8[i] = *reinterpret_cast<const gemm::v4s*>(&sel);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b8[j] = *reinterpret_cast<const gemm::v4s*>(Bs + (kf * 64 + 16 * j + j16) * kRowW + 2 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = gemm::mfma16x16x16_bf16(a8[i], b8[j], acc[i][j]);
-            } else {
+            {
                 float4 a4[4], b4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a4[i] = keep4((mask >> i) & 1u, *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16 + kf) * kRowW + 4 * g));
@@ -449,12 +430,9 @@ struct ActRowsA {
 // whole kernel); the weights stream through LDS 64 hidden units at a time (W1 rows and W2 columns of the chunk, 68-float pitch: conflict-free ds_read_b128),
 // double-buffered with one barrier per chunk: 256 MFMAs per wavefront and chunk against 32 ds_read_b128.
 // MODE 0: out = res + ff (feed_forward1: res = the layer input)   1: out = in + ff (in place)   2: out = res + ((in + ff) - res) * cmid (feed_forward2 + bypass_mid)
-// BF16 = true (ade_gemm_dtype = bf16): the same kernel with bf16 INPUTS to both products (v_mfma_f32_16x16x16_bf16, fp32 accumulation): weights are rounded on their
-// way into LDS (34-word pitch), X once into registers, the activated hidden tile when it leaves the accumulators -- whose four registers are exactly the four
-// consecutive k a lane supplies to that instruction; bias, SwooshL, residual and the output stay fp32.
-constexpr int kFfChunk = 64, kFfPitch = 68, kFfPitchB = 34, kFfRows = 256;
-constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float), kFfLdsB = (size_t)2 * 2 * kFfChunk * kFfPitchB * sizeof(float);
-template <int MODE, bool BF16>
+constexpr int kFfChunk = 64, kFfPitch = 68, kFfRows = 256;
+constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float);
+template <int MODE>
 __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                 const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -471,14 +449,7 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xr[t][ks] = *reinterpret_cast<const float4*>(src + 16 * ks);
     }
-    gemm::v4s xb[2][4];                                                     // the same operand as four bf16 (BF16 only)
-    if constexpr (BF16) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { const uint2 q = gemm::bf16x4(xr[t][ks]); xb[t][ks] = *reinterpret_cast<const gemm::v4s*>(&q); }
-    }
-    constexpr int kPitch = BF16 ? kFfPitchB : kFfPitch;                     // 32-bit words per staged row
+    constexpr int kPitch = kFfPitch;                                        // 32-bit words per staged row
     v4f acc2[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -497,13 +468,8 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
     auto deposit = [&](float* buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if constexpr (BF16) {
-                *reinterpret_cast<uint2*>(buf + (sr + 32 * h) * kPitch + sk / 2) = gemm::bf16x4(p1[h]);
-                *reinterpret_cast<uint2*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk / 2) = gemm::bf16x4(p2[h]);
-            } else {
-                *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kPitch + sk) = p1[h];
-                *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk) = p2[h];
-            }
+            *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kPitch + sk) = p1[h];
+            *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk) = p2[h];
         }
     };
     const int ncg = fd / kFfChunk;
@@ -519,11 +485,7 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
             v4f h[2] = {v4f{0.0f, 0.0f, 0.0f, 0.0f}, v4f{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if constexpr (BF16) {
-                    const gemm::v4s a = *reinterpret_cast<const gemm::v4s*>(W1s + (16 * c + j16) * kPitch + 8 * ks + 2 * g);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) h[t] = gemm::mfma16x16x16_bf16(a, xb[t][ks], h[t]);
-                } else {
+                {
                     const float4 a = *reinterpret_cast<const float4*>(W1s + (16 * c + j16) * kPitch + 16 * ks + 4 * g);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -540,17 +502,7 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
                 h[t][0] = swoosh_l(h[t][0] + bb.x); h[t][1] = swoosh_l(h[t][1] + bb.y);
                 h[t][2] = swoosh_l(h[t][2] + bb.z); h[t][3] = swoosh_l(h[t][3] + bb.w);
             }
-            if constexpr (BF16) {
-                gemm::v4s hb[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) { const uint2 q = gemm::bf16x4(make_float4(h[t][0], h[t][1], h[t][2], h[t][3])); hb[t] = *reinterpret_cast<const gemm::v4s*>(&q); }
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    const gemm::v4s a = *reinterpret_cast<const gemm::v4s*>(W2s + (16 * jt + j16) * kPitch + 8 * c + 2 * g);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) acc2[t][jt] = gemm::mfma16x16x16_bf16(a, hb[t], acc2[t][jt]);
-                }
-            } else {
+            {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     const float4 a = *reinterpret_cast<const float4*>(W2s + (16 * jt + j16) * kPitch + 16 * c + 4 * g);
@@ -597,11 +549,10 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
 }
 
 template <int MODE>
-inline void launch_zip_ff(hipStream_t s, bool bf16, int M, const float* xin, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, const float* cmid,
+inline void launch_zip_ff(hipStream_t s, int M, const float* xin, const float* w1, const float* b1, const float* w2, const float* b2, const float* res, const float* cmid,
                           float* out, int fd) {
     const dim3 grid((unsigned)((M + kFfRows - 1) / kFfRows));
-    if (bf16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff<MODE, true>), grid, dim3(512), kFfLdsB, s, xin, w1, b1, w2, b2, res, cmid, out, M, fd);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff<MODE, false>), grid, dim3(512), kFfLds, s, xin, w1, b1, w2, b2, res, cmid, out, M, fd);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff<MODE>), grid, dim3(512), kFfLds, s, xin, w1, b1, w2, b2, res, cmid, out, M, fd);
 }
 
 struct AddFromStore {          // y[m][n] = x[m][n] + v + bias[n]     (the layer's first residual: x stays the layer input, :146, :160)
@@ -1059,7 +1010,7 @@ struct ZipEngine : SubEngine {
     int device = 0, L = 0 /* samples per window in */, Lo = 0 /* out: whole hops, hop * (T - 1) */, n_win = 1, T = 0, F = 0;
     int C = 64, H = 4, qd = 16, pd = 4, vd = 12, pos_dim = 48, ffd = 256, K = 15, dst = 2, dsf = 2, up = 2, depth = 4;
     int hid = 48, ff1 = 192, ff3 = 320, attn_dim = 144, dT = 0, dF = 0;
-    bool exact = false, bf16 = false;     // bf16: ade_gemm_dtype = "bf16" -- every 256 x 64 GEMM takes bf16 inputs (fp32 accumulation); front / attention / norms / PCM tail stay fp32
+    bool exact = false;
     float* d_w = nullptr;
     const float *k_fwd = nullptr, *k_inv = nullptr, *inv_wsum = nullptr;
     bool dynamic_norm = false;         // a DYNAMIC_AXES export: inv_wsum holds sum w^2 itself and the overlap-add divides
@@ -1098,7 +1049,7 @@ struct ZipEngine : SubEngine {
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
 
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return zfail(err, ADE_ERR_BAD_VALUE, "zipenhancer: n_win must be >= 1");
     if (window_len < kZN || (n_win > 1 && window_len % kZHop))
@@ -1114,7 +1065,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     ZipEngine* e = new ZipEngine();
     auto bail = [&](int st) { delete e; return st; };
     auto ci = [&](int i) { return (int)lrintf(cfg->data[i]); };
-    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft; e->bf16 = bf16;
+    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft;
     e->C = ci(0); e->H = ci(1); e->qd = ci(2); e->pd = ci(3); e->vd = ci(4); e->pos_dim = ci(5); e->ffd = ci(6); e->K = ci(7);
     e->dst = ci(10); e->dsf = ci(11); e->up = ci(12); e->depth = ci(13);
     const int C = e->C;
@@ -1284,9 +1235,9 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     for (auto& f : fix) *f.first = e->d_w + f.second;
     if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the feed-forward kernel"));
     *out = e;
     return ADE_OK;
@@ -1333,9 +1284,7 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
             const dim3 grid((unsigned)((M + 255) / 256));             // (C == 64: checked at create)
-            if (bf16) hipLaunchKernelGGL(k_zip_dense<true>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
-                                         d.b[g][i], Dh, ld, off_out, M);
-            else hipLaunchKernelGGL(k_zip_dense<false>, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
+            hipLaunchKernelGGL(k_zip_dense, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
                                     d.b[g][i], Dh, ld, off_out, M);
             stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = (long long)M * 16;
@@ -1358,34 +1307,34 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, Seq
     // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
     auto fused_ff = [&](int fd) { return C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
     if (fused_ff(ff1)) {
-        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim, bf16);                               // (:148-153) attention part of the joint projection
-        launch_zip_ff<0>(s, bf16, M, x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b, x, nullptr, Y, ff1);        // (:160)
+        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);                               // (:148-153) attention part of the joint projection
+        launch_zip_ff<0>(s, M, x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b, x, nullptr, Y, ff1);        // (:160)
     } else {
-        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp, bf16);                                    // (:148-153)
-        launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1, bf16);                  // (:160)
+        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp);                                    // (:148-153)
+        launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1);                  // (:160)
     }
-    launch_proj64(s, Y, C, w.nonlin_in_w, w.nonlin_in_b, S1, 3 * hid, 0, M, 3 * hid, bf16);                           // (:305)
+    launch_proj64(s, Y, C, w.nonlin_in_w, w.nonlin_in_b, S1, 3 * hid, 0, M, 3 * hid);                           // (:305)
     attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
-    launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid, bf16);                              // (:317, :167)
+    launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid);                              // (:317, :167)
     for (int i = 0; i < 2; ++i) {
-        launch_proj64(s, Y, C, w.sa_in_w[i], w.sa_in_b[i], S1, vdim, 0, M, vdim, bf16);                               // (:296)
+        launch_proj64(s, Y, C, w.sa_in_w[i], w.sa_in_b[i], S1, vdim, 0, M, vdim);                               // (:296)
         attention(s, 1, w.pos, S1, vdim, O, vdim, geo, vd);                                                                                   // (:297-300) all heads
-        launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim, bf16);                         // (:301, :168 / :172)
-        launch_proj64(s, Y, C, w.cv_in_w[i], w.cv_in_b[i], S1, 2 * C, 0, M, 2 * C, bf16);                             // (:321)
+        launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim);                         // (:301, :168 / :172)
+        launch_proj64(s, Y, C, w.cv_in_w[i], w.cv_in_b[i], S1, 2 * C, 0, M, 2 * C);                             // (:321)
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
-        launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C, bf16);                            // (:339, :169 / :173)
+        launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
         if (fused_ff(fd)) {
-            if (i == 0) launch_zip_ff<2>(s, bf16, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
-            else launch_zip_ff<1>(s, bf16, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
+            if (i == 0) launch_zip_ff<2>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
+            else launch_zip_ff<1>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
             continue;
         }
-        launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd, bf16);
-        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd, bf16);   // (:170-171)
-        else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd, bf16);                   // (:174)
+        launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd);
+        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd);   // (:170-171)
+        else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
     }
     hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
 }
@@ -1414,7 +1363,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
-    gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C, bf16);
+    gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
     snap(0);
@@ -1432,7 +1381,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
         gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
-                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C, bf16);
+                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
     }
     hipLaunchKernelGGL(k_zip_heads, dim3((unsigned)((J + 15) / 16), (unsigned)kZF), dim3(256), 0, s, (const float*)U, (const float*)nrm2, up_slope, mask_w, mask_b,

@@ -61,8 +61,7 @@ def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window
     """Manifest keys the reference stamps for this model (:712-718): two output sources, conv encoder/decoder features.
     ``input_audio_length`` counts INPUT-rate samples; with in / out rates other than 16 kHz the engine interpolates linearly on both
     edges like the export (:562-571, :625-640) and the model sees round(length * 16000 / in_rate) samples.
-    ``gemm_dtype``: "f32" (default, the parity path and BASELINE.json's dtype for this model) | "bf16_inputs" (the masking network's GEMM operands rounded to bf16 on the
-    way into LDS, fp32 in HBM, fp32 accumulation).
+    ``gemm_dtype``: "f32" only (the parity path and BASELINE.json's dtype for this model); the engine refuses other values.
     ``dynamic_axes``: the DYNAMIC_AXES export (:24): the edges interpolate by scale factor (floor(length * 16000 / in_rate) model-rate samples), and the weights carry the
     linear keys' OffsetScale row WITHOUT the 1 / frames factor, which the graph applies at run time (:183, :430, :500-501) -- ``synthetic_tensor(..., fold_inv_n=False)``."""
     if dynamic_axes and use_batch_fold:

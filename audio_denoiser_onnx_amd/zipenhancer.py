@@ -326,9 +326,8 @@ def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window
              out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32", dft_tables: str = "reference", dynamic_axes: bool = False) -> Dict[str, str]:
     """Manifest of a static export (Export_ZipEnhancer.py:977-981).  Without batch-fold ``input_audio_length`` must be whole hops (the
     reference's STFT -> ISTFT pair reconstructs (T - 1) * 100 samples; its default export always folds, :58-60).
-    ``gemm_dtype``: "f32" = exact fp32 matrix-core products (the parity path, default); "bf16_inputs" = the same kernels with their operands rounded to bf16 on the way
-    into LDS (operands stay fp32 in HBM; fp32 accumulation; front end, attention core, norms and PCM tail fp32): a rounding mode worth ~1.5 x, NOT a bf16 data path
-    (BASELINE.json names bf16 for this model; a bf16-in-HBM path like Mel-Band-Roformer's is not built for it -- DESIGN.md section 8).  ``dft_tables``: "reference" (its fp32-angle tables) | "exact"."""
+    ``gemm_dtype``: "f32" only (exact fp32 matrix-core products).  BASELINE.json names bf16 for this model; a bf16-in-HBM path like Mel-Band-Roformer's is not built for it
+     and the engine refuses the key's other values.  ``dft_tables``: "reference" (its fp32-angle tables) | "exact"."""
     # ``dynamic_axes``: the DYNAMIC_AXES export (:31, :61, :828-829, :898-899, :907-908): any input length, scale-factor interpolation on the edges, the ISTFT divides by
     # the overlap-add denominator of the actual frame count; the handle still serves ONE input length.
     if dynamic_axes and use_batch_fold:

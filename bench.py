@@ -76,10 +76,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="gtcrn", choices=["gtcrn", "zipenhancer", "melband", "mossformer"],
                     help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16_inputs"],
-                    help="f32 = exact fp32 matrix-core products (parity path, default); bf16 = bf16 activations and weights stored in HBM (melband: csrc/ade_gemm16.h); "
-                         "bf16_inputs = fp32 operands rounded to bf16 on their way into LDS (zipenhancer, mossformer: a rounding mode of the fp32 kernels).  The deviation "
-                         "from the f32 path is measured and reported")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = exact fp32 matrix-core products (parity path, default); bf16 = bf16 activations and weights stored in HBM (--workload melband only: "
+                         "csrc/ade_gemm16.h).  The deviation from the f32 path is measured and reported")
     ap.add_argument("--batch", type=int, default=0, help="chunks per GPU per step (0 = the workload's BASELINE batch: 256 / 128 / 32 / 64)")
     ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-inclusive leg (pinned host buffers through ade_process; 0 = skip)")
     ap.add_argument("--stitch", action="store_true", help="all-gather the int16 outputs (RCCL) inside the timed region")
@@ -243,7 +242,7 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         return dict(sess=sess, B=B, x=x, sr=16000, flop=2.0 * zp.macs_per_window(sess.frames, cfg)["total"], cpu=cpu,
                     metric="audio_seconds_per_second (ZipEnhancer 16 kHz, batch=128 x 1 s chunks; RTF = 1/value)",
                     workload="ZipEnhancer 16 kHz, batch=128 x 1 s chunks (161 frames x 101 sub-bands), fp32 matrix cores, int16 PCM in/out resident in HBM "
-                             "(BASELINE.json configs[2] names bf16: a bf16-in-HBM path is built for configs[3] only; --dtype bf16_inputs rounds the fp32 operands on their way into LDS)",
+                             "(BASELINE.json configs[2] names bf16: a bf16-in-HBM path is built for configs[3] only, this model runs f32)",
                     weights="random-init weights of the architecture (zipenhancer.synthetic_tensors, 2.1 M parameters; no checkpoint is available offline)",
                     target_rtf=0.01, deviation=deviation)
     if name == "melband":                                          # BASELINE configs[3]: 32 x 8 s stereo segments @ 44.1 kHz
@@ -309,8 +308,8 @@ def main():
     args = parse_args()
     SKIP_DEVIATION = args.no_deviation
     DEVIATION_DTYPE = args.dtype
-    if args.dtype != "f32" and (args.workload == "gtcrn" or (args.dtype == "bf16") != (args.workload == "melband")):
-        raise SystemExit("--dtype bf16 is the Mel-Band-Roformer path (bf16 stored in HBM); zipenhancer / mossformer offer --dtype bf16_inputs; gtcrn is fp32 only")
+    if args.dtype != "f32" and args.workload != "melband":
+        raise SystemExit("--dtype bf16 is the Mel-Band-Roformer path (bf16 stored in HBM); the other workloads run f32")
     import torch
     import torch.distributed as dist
 
@@ -571,14 +570,9 @@ def main():
             roofline["frac_of_f32_peak"] = roofline["frac"]                    # comparability with the f32 line (can exceed 1: bf16 inputs run on a faster pipe)
             roofline["peak"] = BF16_PEAK_TFLOPS
             roofline["frac"] = round(roofline["achieved"] / BF16_PEAK_TFLOPS, 4)
-            if args.workload == "melband":
-                roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); bf16 operands stored in HBM, 32x32x16 / 16x16x32 "
-                                         "bf16 matrix instructions; at K = 384 .. 1536 and 1.5 M rows the products are bound by the CU's vector-memory path and their epilogues, "
-                                         "not by the matrix cores (DESIGN.md section 6c)")
-            else:
-                roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); operands stay fp32 in HBM and are rounded on "
-                                         "their way into LDS, so the GEMMs are bound by operand traffic / staging, not by the matrix cores; attention cores, norms, "
-                                         "front / back ends stay fp32")
+            roofline["peak_note"] = ("dense bf16-MFMA rate, ~2.5 PFLOP/s (MI355X_MICROARCH.md; not the 2:1-sparsity figure); bf16 operands stored in HBM, 32x32x16 / 16x16x32 "
+                                     "bf16 matrix instructions; at K = 384 .. 1536 and 1.5 M rows the products are bound by their stores and the residual stream's traffic, "
+                                     "not by the matrix cores (DESIGN.md section 6d)")
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -159,25 +159,6 @@ static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
         }
     return d;
 }
-// v_mfma_f32_16x16x16_bf16 (the _1k form): lane l supplies A[i = l & 15][k = 4 (l >> 4) .. + 3] and B[k = 4 (l >> 4) .. + 3][j = l & 15] as four bf16;
-// D = A B + C in fp32 (products of bf16 values are exact in fp32; accumulated k-ordered here).
-typedef short hipsim_v4s __attribute__((vector_size(8)));
-static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hipsim_v4s a, hipsim_v4s b, hipsim_v4f c, int, int, int) {
-    const int lane = ::hipsim::lane_id();
-    const int j = lane & 15, g = lane >> 4;
-    uint32_t aw[2], bw[2], all_a[2][64], all_b[2][64];
-    std::memcpy(aw, &a, 8);
-    std::memcpy(bw, &b, 8);
-    ::hipsim::wave_allgather2(aw[0], bw[0], all_a[0], all_b[0]);
-    ::hipsim::wave_allgather2(aw[1], bw[1], all_a[1], all_b[1]);
-    auto bf = [](uint32_t word, int hi) { const uint32_t u = (hi ? (word >> 16) : (word & 0xffffu)) << 16; float f; std::memcpy(&f, &u, 4); return f; };
-    hipsim_v4f d = c;
-    for (int r = 0; r < 4; ++r)
-        for (int kg = 0; kg < 4; ++kg)
-            for (int q = 0; q < 4; ++q)
-                d[r] = fmaf(bf(all_a[q >> 1][(4 * g + r) + 16 * kg], q & 1), bf(all_b[q >> 1][j + 16 * kg], q & 1), d[r]);
-    return d;
-}
 // gfx950 v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16: a lane supplies 8 consecutive k of its row as eight bf16 (csrc/ade_gemm16.h documents the maps);
 // D = A B + C in fp32, accumulated k-ordered here (products of bf16 values are exact in fp32).
 typedef short hipsim_v8s __attribute__((vector_size(16)));

@@ -355,24 +355,14 @@ def test_export_and_driver_host_logic(model, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_zipenhancer_bf16_gemm_mode_stays_close_to_f32(model):
-    """ade_gemm_dtype = "bf16_inputs" (bf16 inputs, fp32 accumulation in every projection / convolution GEMM): a throughput mode, NOT the parity path --
-    its measured distance from the exact path on the reference's test clip is asserted loosely and printed (bench.py reports it as deviation_from_f32)."""
+def test_gpu_zipenhancer_reduced_precision_manifests_are_refused(model):
+    """ZipEnhancer runs f32: the bf16-in-HBM path exists for Mel-Band-Roformer only and the round-2 rounding mode of the fp32 kernels is gone; a manifest asking for
+    bf16 (BASELINE.json's dtype for this model), for the old mode or for anything else is refused at create."""
     from audio_denoiser_onnx_amd.session import InferenceSession
-    z, _, _, t = model
-    pcm = np.stack([z["in_wav0"], z["in_randn"], z["in_zeros"]])
-    with InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000)) as s32, \
-            InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype="bf16_inputs")) as s16:
-        a, af = s32.process(pcm, want_f32=True)
-        b, bf = s16.process(pcm, want_f32=True)
-    assert not b[2].any()
-    for i in range(2):
-        err, sig = bf[i].astype(np.float64) - af[i], af[i].astype(np.float64)
-        snr = 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
-        print(f"zipenhancer bf16 vs f32, row {i}: SNR {snr:.1f} dB, max |d| {np.abs(err).max():.1f} (int16 units), signal rms {np.sqrt((sig ** 2).mean()):.1f}")
-        assert snr > 20.0
-    with pytest.raises(Exception):
-        InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype="fp8"))
+    t = model[3]
+    for dt in ("bf16", "bf16_inputs", "fp8"):
+        with pytest.raises(Exception):
+            InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype=dt))
 
 
 @pytest.mark.gpu
