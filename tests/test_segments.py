@@ -136,7 +136,9 @@ def test_gpu_priority_options_and_every_segments_clocks():
     sess.profile(0)
     assert clocks.shape[0] == 8
     for seg in range(4):
-        assert clocks[seg, 9, 53] > clocks[seg, 0, 32] >= 0, (seg, clocks[seg, 0, 32:37].tolist(), clocks[seg, 9, 48:54].tolist())   # the back stage of every segment ended after its front stage began
+        # the back stage of every segment ended after its front stage began; the zero of the clocks is segment 0's entry, and a workgroup of another segment -- on another
+        # XCD -- may enter a few ticks (10 ns each) BEFORE block 0 does: HIP promises no dispatch order (seen once: -4 ticks)
+        assert clocks[seg, 9, 53] > clocks[seg, 0, 32] >= -100, (seg, clocks[seg, 0, 32:37].tolist(), clocks[seg, 9, 48:54].tolist())
     assert (clocks[4:] == -1).all()                                        # no fifth segment at 63 frames
     ends = [clocks[seg, 9, 53] for seg in range(4)]
     assert ends == sorted(ends)                                            # a segment cannot finish before its predecessor (its overlap-add carry comes from it)
