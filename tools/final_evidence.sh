@@ -2,7 +2,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 bash tools/run_all_benches.sh gpurun_out/final/r02_s_all_benches.txt
-for W in "gtcrn f32" "zipenhancer f32" "zipenhancer bf16" "melband f32" "melband bf16" "mossformer f32" "mossformer bf16"; do
+for W in "gtcrn f32" "zipenhancer f32" "melband f32" "melband bf16" "mossformer f32"; do      # (round 2 also ran "zipenhancer bf16" and "mossformer bf16": that mode was removed in round 4)
   set -- $W
   python bench.py --workload $1 --dtype $2 2>/dev/null | tail -1 > gpurun_out/final/r02_s_$1_$2_bench.json
 done

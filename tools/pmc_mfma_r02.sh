@@ -5,7 +5,7 @@ R=$PWD
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 CNT="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"
-for W in "zipenhancer f32" "zipenhancer bf16" "mossformer f32" "melband f32"; do
+for W in "zipenhancer f32" "mossformer f32" "melband f32" "melband bf16"; do      # (round 2 also ran "zipenhancer bf16": that mode was removed in round 4)
   set -- $W
   tag=$1; [ "$2" != "f32" ] && tag=$1_$2
   rocprofv3 --kernel-trace --pmc $CNT -f csv -d $R/$OUT/$tag -- python $R/bench.py --workload $1 --dtype $2 --steps 2 --warmup 1 --cpu-seconds 0 --host-steps 0 > $R/$OUT/$tag.log 2>&1 || tail -3 $R/$OUT/$tag.log
