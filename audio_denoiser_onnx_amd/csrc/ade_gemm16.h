@@ -42,7 +42,8 @@ constexpr int kPitch = 144;                          // bytes per staged row (12
 constexpr int kSlabBytes = kTM * kPitch;             // one operand's slab
 constexpr int kEpiPitch = 132;                       // floats per row of the epilogue tile (128 + 4: a wave's float4 writes of 8 consecutive rows cover all banks once)
 constexpr int kEpiBytes = 64 * kEpiPitch * 4;
-constexpr int kLdsBytes = 2 * kSlabBytes > kEpiBytes ? 2 * kSlabBytes : kEpiBytes;      // 36 864
+constexpr int kMainLds = 2 * kSlabBytes > kEpiBytes ? 2 * kSlabBytes : kEpiBytes;       // 36 864: the two operand slabs, later the epilogue tile
+constexpr int kLdsBytes = kMainLds + kTM * 4;        // + the tile's row scales (four workgroups per CU: 149.5 KB)
 
 // fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -67,9 +68,13 @@ __device__ __forceinline__ v16f mfma32x32x16(const uint4& a, const uint4& b, v16
 __device__ __forceinline__ uint4 zero_unless(bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
 
 // one 128 x 128 tile of C at (m_blk, n_blk); lds: kLdsBytes, 16-byte aligned
+// row_scale (may be null): C(m, n) is multiplied by row_scale[m] before the store sees it (the norm of a normalised operand: ade_melband.hip).  The tile's 128 scales are
+// fetched into LDS when the tile starts, so the epilogue -- which runs with nothing in flight to hide a global load behind -- reads them from LDS.
 template <class ST>
 __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, const ST& store, int M, int N, int K, int m_blk, int n_blk,
-                                          unsigned char* lds) {
+                                          unsigned char* lds, const float* __restrict__ row_scale = nullptr) {
+    float* rsc = reinterpret_cast<float*>(lds + kMainLds);
+    if (row_scale && threadIdx.x < kTM) rsc[threadIdx.x] = row_scale[m_blk + (int)threadIdx.x < M ? m_blk + (int)threadIdx.x : M - 1];
     unsigned char* As = lds;
     unsigned char* Bs = lds + kSlabBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,7 +167,11 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int row = (tid >> 5) + 8 * u, m = m_blk + 64 * half + row;
-                    if (m < M) store(m, n, *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4), cnt, cc);
+                    if (m < M) {
+                        float4 v = *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4);
+                        if (row_scale) { const float rs = rsc[64 * half + row]; v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs); }
+                        store(m, n, v, cnt, cc);
+                    }
                 }
             }
         }
@@ -183,22 +192,23 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
 }
 
 template <class ST>
-__global__ __launch_bounds__(256, 4) void k_gemm16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, ST store, int M, int N, int K) {
+__global__ __launch_bounds__(256, 4) void k_gemm16(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, ST store, int M, int N, int K,
+                                                   const float* __restrict__ row_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
     const int gx = (int)gridDim.x, id = xcd_contiguous_id((int)blockIdx.x + gx * (int)blockIdx.y, gx * (int)gridDim.y);
-    gemm_tile(A, lda, B, ldb, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, lds);
+    gemm_tile(A, lda, B, ldb, store, M, N, K, (id / gx) * kTM, (id % gx) * kTN, lds, row_scale);
 }
 
 template <class ST>
-inline void launch(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, const ST& st, int M, int N, int K) {
+inline void launch(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, const ST& st, int M, int N, int K, const float* row_scale = nullptr) {
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm16<ST>), grid, dim3(256), 0, s, A, lda, B, ldb, st, M, N, K);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm16<ST>), grid, dim3(256), 0, s, A, lda, B, ldb, st, M, N, K, row_scale);
 }
 
 
 // Batched form: blockIdx.z selects a problem; prob(z) returns {A, lda, B, ldb, st, M, N, K} (evaluated once per workgroup); tiles outside a problem's own M x N exit at once.
 template <class ST>
-struct Prob { const bf16_t* A; int lda; const bf16_t* B; int ldb; ST st; int M, N, K; };
+struct Prob { const bf16_t* A; int lda; const bf16_t* B; int ldb; ST st; int M, N, K; const float* row_scale; };
 template <class P>
 __global__ __launch_bounds__(256, 4) void k_gemm16_batched(P prob) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm16_batched(P prob) {
     const auto q = prob(z);
     const int m_blk = (in_z / gx) * kTM, n_blk = (in_z % gx) * kTN;
     if (m_blk >= q.M || n_blk >= q.N) return;
-    gemm_tile(q.A, q.lda, q.B, q.ldb, q.st, q.M, q.N, q.K, m_blk, n_blk, lds);
+    gemm_tile(q.A, q.lda, q.B, q.ldb, q.st, q.M, q.N, q.K, m_blk, n_blk, lds, q.row_scale);
 }
 template <class P>
 inline void launch_batched(hipStream_t s, const P& prob, int batch, int max_M, int max_N) {

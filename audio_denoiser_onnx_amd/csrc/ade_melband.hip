@@ -465,13 +465,11 @@ struct RotaryQkStore16 {       // q | k | v | gates = (Xg W_in^T) / |x2 g| + b_i
     bf16_t* out;
     const float* bias;
     const float *rcos, *rsin;  // [position][kDh], rotate_half's sign folded into rsin
-    const float* inv;          // 1 / |operand row|
     int ld, rot_cols;
     gemm16::FastDiv pos_stride, n_pos;      // position of row m = (m / pos_stride) % n_pos
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
     __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
-        const float rs = inv[m];
-        float4 u = make_float4(fmaf(v.x, rs, b.x), fmaf(v.y, rs, b.y), fmaf(v.z, rs, b.z), fmaf(v.w, rs, b.w));
+        float4 u = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);      // (v arrives scaled by 1 / |operand row|: gemm16's row_scale)
         if (n < rot_cols) {                                          // rot_cols % 4 == 0: a float4 is rotated whole or not at all
             const int q = pos_stride.div(m), at = (q - n_pos.div(q) * (int)n_pos.d) * kDh + (n & (kDh - 1));
             const float4 c = *reinterpret_cast<const float4*>(rcos + at), sn = *reinterpret_cast<const float4*>(rsin + at);
@@ -482,16 +480,14 @@ struct RotaryQkStore16 {       // q | k | v | gates = (Xg W_in^T) / |x2 g| + b_i
     }
 };
 template <int ACT>             // 0: gelu (erf form, :564); 1: tanh (:581-582)
-struct BiasActStore16 {        // act(v [/ |operand row|] + bias[n]) -> bf16
+struct BiasActStore16 {        // act(v + bias[n]) -> bf16   (v arrives scaled by 1 / |operand row| where the operand is a normalised one: gemm16's row_scale)
     bf16_t* out;
     const float* bias;
-    const float* inv;          // 1 / |operand row|, or null (the operand is used as it is)
     int ld;
     __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f)) : tanh_f(x); }
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
     __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
-        const float rs = inv ? inv[m] : 1.0f;
-        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(fmaf(v.x, rs, b.x)), act(fmaf(v.y, rs, b.y)), act(fmaf(v.z, rs, b.z)), act(fmaf(v.w, rs, b.w))), cnt);
+        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(v.x + b.x), act(v.y + b.y), act(v.z + b.z), act(v.w + b.w)), cnt);
     }
 };
 struct OutProjStore16 {        // x1 = X * g / |x2| + v -> X (fp32) ; X1 = bf16(x1) ; sq1[m][tile] = sum over the tile's columns of x1^2      (N % 128 == 0)
@@ -556,7 +552,7 @@ struct MeHiddenProb16 {        // z = band: out_z = tanh((in_z W_z^T) [/ |x2 row
     int BT, K, N;
     __device__ gemm16::Prob<BiasActStore16<1>> operator()(int z) const {
         return {in + (size_t)z * BT * K, K, w + (size_t)z * N * K, K,
-                BiasActStore16<1>{out + (size_t)z * BT * N, bias + (size_t)z * N, inv ? inv + (size_t)z * BT : nullptr, N}, BT, N, K};
+                BiasActStore16<1>{out + (size_t)z * BT * N, bias + (size_t)z * N, N}, BT, N, K, inv ? inv + (size_t)z * BT : nullptr};
     }
 };
 struct MeOutProb16 {           // z = band: YT[2 off_z + c][bt] = sum_k w3_z[c][k] h_z[bt][k] + b3_z[c]   (:583), the product taken transposed so that YT is its row-major result
@@ -568,7 +564,7 @@ struct MeOutProb16 {           // z = band: YT[2 off_z + c][bt] = sum_k w3_z[c][
     int BT, K;
     __device__ gemm16::Prob<RowBiasStoreF32> operator()(int z) const {
         const int off = bt.off[z], d = bt.off[z + 1] - off;
-        return {arena16 + bt.w3[z], K, in + (size_t)z * BT * K, K, RowBiasStoreF32{yt + (size_t)2 * off * BT, arena + bt.b3[z], BT}, 2 * d, BT, K};
+        return {arena16 + bt.w3[z], K, in + (size_t)z * BT * K, K, RowBiasStoreF32{yt + (size_t)2 * off * BT, arena + bt.b3[z], BT}, 2 * d, BT, K, nullptr};
     }
 };
 
@@ -1103,14 +1099,14 @@ void MelbandEngine::transformer(hipStream_t s, const TfW& w, int R, int n, int n
     if (bf16) {      // on entry: Xg = bf16 operand copy of the stream, sqg its rows' partial sums of squares; X = x2 of the previous transformer (g_last, sq2) or the stream itself
         const int tiles = (dim + 127) / 128;
         const dim3 rows256((unsigned)((R + 255) / 256));
-        gemm16::launch(s, Xg, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, invg, ldq, 2 * di, gemm16::make_fastdiv((int)pos_stride), gemm16::make_fastdiv(n)}, R, ldq, dim);   // (:547-548, :552)
+        gemm16::launch(s, Xg, dim, w.in_w16, dim, RotaryQkStore16{A16, w.in_b, rc, rs, ldq, 2 * di, gemm16::make_fastdiv((int)pos_stride), gemm16::make_fastdiv(n)}, R, ldq, dim, invg);   // (:547-548, :552)
         if (n > 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<2>), dim3((unsigned)nseq, (unsigned)heads, (unsigned)((n + 127) / 128)), dim3(256), 0, s,
                                        (const gemm16::bf16_t*)A16, AO16, n, seq_stride, pos_stride, ldq, di);                                            // (:549-560)
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention16<1>), dim3((unsigned)nseq, (unsigned)heads, 1), dim3(256), 0, s, (const gemm16::bf16_t*)A16, AO16, n,
                                 seq_stride, pos_stride, ldq, di);
         gemm16::launch(s, AO16, di, w.out_w16, di, OutProjStore16{X, X1, g_last, inv2, sq1, dim}, R, dim, di);                                           // (:561, :569; the previous :571)
         hipLaunchKernelGGL(k_rows_inv_norm, rows256, dim3(256), 0, s, (const float*)sq1, tiles, inv1, (const float*)nullptr, (float*)nullptr, R);
-        gemm16::launch(s, X1, dim, w.ff1_w16, dim, BiasActStore16<0>{B16, w.ff1_b, inv1, ffd}, R, ffd, dim);                                             // (:564)
+        gemm16::launch(s, X1, dim, w.ff1_w16, dim, BiasActStore16<0>{B16, w.ff1_b, ffd}, R, ffd, dim, inv1);                                             // (:564)
         gemm16::launch(s, B16, ffd, w.ff2_w16, ffd, FfOutStore16{X, Xg, w.ff2_b, w.out_g, sq2, sqg, dim}, R, dim, ffd);                                  // (:565, :570; :571 is applied by the consumers)
         hipLaunchKernelGGL(k_rows_inv_norm, rows256, dim3(256), 0, s, (const float*)sq2, tiles, inv2, (const float*)sqg, invg, R);
         g_last = w.out_g;

@@ -64,9 +64,24 @@ static int run_case(int M, int N, int K) {
             worst_b = fmax(worst_b, fabs(ref + bias[n] - (double)from_bf16(Cb[(size_t)m * ldc + n])) / (1.0 + fabs(ref + bias[n])));
         }
     }
+    // the same product with a scale per row (launch's row_scale: the tile keeps its 128 scales in LDS); C2(m, n) must be C(m, n) * scale[m] to an ulp
+    std::vector<float> scale(M);
+    for (auto& v : scale) v = 0.25f + fabsf(rnd());
+    float* dscale;
+    hipMalloc((void**)&dscale, (size_t)M * 4);
+    hipMemcpy(dscale, scale.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+    launch((hipStream_t)0, dA, lda, dB, ldb, PlainStore{dC, dCb, dbias, ldc}, M, N, K, dscale);
+    hipDeviceSynchronize();
+    std::vector<float> C2((size_t)M * ldc);
+    hipMemcpy(C2.data(), dC, C2.size() * 4, hipMemcpyDeviceToHost);
+    int bad_scale = 0;
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) bad_scale += C2[(size_t)m * ldc + n] != C[(size_t)m * ldc + n] * scale[m];
+    hipFree(dscale);
     const double tol = 2e-6 * K + 1e-5;
-    const bool ok = worst <= tol && worst_b <= 0.0045 && bad_pad == 0;
-    printf("gemm16 M=%d N=%d K=%d: max|d| fp32 %.3e (tol %.1e), bf16 rel %.3e, touched padding %d -> %s\n", M, N, K, worst, tol, worst_b, bad_pad, ok ? "OK" : "FAIL");
+    const bool ok = worst <= tol && worst_b <= 0.0045 && bad_pad == 0 && bad_scale == 0;
+    printf("gemm16 M=%d N=%d K=%d: max|d| fp32 %.3e (tol %.1e), bf16 rel %.3e, touched padding %d, row-scale mismatches %d -> %s\n", M, N, K, worst, tol, worst_b, bad_pad, bad_scale,
+           ok ? "OK" : "FAIL");
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
     return ok ? 0 : 1;
 }
