@@ -147,6 +147,11 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
     }
     // epilogue: 64 rows at a time through LDS
     float* E = reinterpret_cast<float*>(lds);
+    // whatever the store reads per column (bias, gains): a thread's column is the same in both halves, and the load is issued here so that it is in flight across the
+    // accumulators' trip to LDS and the barrier instead of stalling each half's stores
+    const int c4 = tid & 31, n = n_blk + 4 * c4, cnt = N - n < 4 ? N - n : 4;
+    const bool full = m_blk + kTM <= M && n_blk + kTN <= N;      // (wave-uniform) an interior tile: no row or column of it needs a bounds check, every store is a whole float4
+    const auto cc = full ? store.col(n, 4) : store.col(n < N ? n : 0, n < N ? cnt : 1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if ((wave >> 1) == half) {
@@ -161,15 +166,27 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
         }
         __syncthreads();
         {   // lane = (row tid >> 5 (+ 8 u), float4 column tid & 31): the column, and whatever the store reads per column (bias), is the same for a thread's 8 rows
-            const int c4 = tid & 31, n = n_blk + 4 * c4, cnt = N - n < 4 ? N - n : 4;
-            if (n < N) {
-                const auto cc = store.col(n, cnt);
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = (tid >> 5) + 8 * u;
+                    float4 v = *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4);
+                    if (row_scale) {
+                        const float rs = rsc[64 * half + row];
+                        v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs);
+                    }
+                    store(m_blk + 64 * half + row, n, v, 4, cc);
+                }
+            } else if (n < N) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int row = (tid >> 5) + 8 * u, m = m_blk + 64 * half + row;
                     if (m < M) {
                         float4 v = *reinterpret_cast<const float4*>(E + row * kEpiPitch + 4 * c4);
-                        if (row_scale) { const float rs = rsc[64 * half + row]; v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs); }
+                        if (row_scale) {
+                            const float rs = rsc[64 * half + row];
+                            v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs);
+                        }
                         store(m, n, v, cnt, cc);
                     }
                 }
@@ -247,6 +264,23 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float r = 1.0f - poly * __expf(-a * a);
     return copysignf(r, x);
+}
+
+// GELU of two values on the packed fp32 pipe: x (1/2 + x_c P(x_c^2)), x_c = x clamped to +-4, P a degree-7 fit of (Phi(x) - 1/2) / x on [-4, 4] (|error| 2.1e-5, Phi(4) = 1 - 3e-5:
+// |gelu - exact| < 1e-4 inside, < 5e-5 |x| outside; the result is rounded to bf16's 8 bits).  14 instructions per PAIR (2 v_med3, 10 v_pk_fma / v_pk_mul) against erf_fast's ~22 per
+// element: a K = 384 product's store is bound by its VALU work (64 outputs per thread and tile at 4 cycles per wave64 instruction outweigh the tile's 96 MFMAs)
+__device__ __forceinline__ v2f gelu_pk(v2f x) {
+    const v2f xc = mk2(__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f));
+    const v2f t = xc * xc;
+    v2f p = mk2(-1.580784725e-09f, -1.580784725e-09f);
+    p = p * t + 1.217110110e-07f;
+    p = p * t + -4.100864317e-06f;
+    p = p * t + 8.066737064e-05f;
+    p = p * t + -1.048204256e-03f;
+    p = p * t + 9.664873593e-03f;
+    p = p * t + -6.617537886e-02f;
+    p = p * t + 3.988475204e-01f;
+    return x * (xc * p) + x * 0.5f;
 }
 
 __device__ __forceinline__ void store_bf16x4(bf16_t* p, const float4& v, int cnt) {       // p 8-byte aligned when cnt == 4

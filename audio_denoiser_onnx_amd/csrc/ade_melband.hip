@@ -484,10 +484,14 @@ struct BiasActStore16 {        // act(v + bias[n]) -> bf16   (v arrives scaled b
     bf16_t* out;
     const float* bias;
     int ld;
-    __device__ float act(float x) const { return ACT == 0 ? 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f)) : tanh_f(x); }
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
     __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
-        gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(act(v.x + b.x), act(v.y + b.y), act(v.z + b.z), act(v.w + b.w)), cnt);
+        if (ACT == 0) {            // GELU, two values per instruction (gemm16::gelu_pk)
+            const v2f lo = gemm16::gelu_pk(mk2(v.x, v.y) + mk2(b.x, b.y)), hi = gemm16::gelu_pk(mk2(v.z, v.w) + mk2(b.z, b.w));
+            gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(lo[0], lo[1], hi[0], hi[1]), cnt);
+        } else {
+            gemm16::store_bf16x4(out + (size_t)m * ld + n, make_float4(tanh_f(v.x + b.x), tanh_f(v.y + b.y), tanh_f(v.z + b.z), tanh_f(v.w + b.w)), cnt);
+        }
     }
 };
 struct OutProjStore16 {        // x1 = X * g / |x2| + v -> X (fp32) ; X1 = bf16(x1) ; sq1[m][tile] = sum over the tile's columns of x1^2      (N % 128 == 0)

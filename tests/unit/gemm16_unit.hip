@@ -92,6 +92,18 @@ struct BfStore {               // the cheapest useful store: bf16(v)
     __device__ NoCol col(int, int) const { return NoCol{}; }
     __device__ void operator()(int m, int n, float4 v, int cnt, NoCol) const { store_bf16x4(cb + (size_t)m * ld + n, v, cnt); }
 };
+template <int GELU>
+struct BfBiasStore {
+    bf16_t* cb;
+    const float* bias;
+    int ld;
+    __device__ float4 col(int n, int cnt) const { return load_f32x4(bias + n, cnt); }
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
+        v2f lo = mk2(v.x, v.y) + mk2(b.x, b.y), hi = mk2(v.z, v.w) + mk2(b.z, b.w);
+        if (GELU) { lo = gelu_pk(lo); hi = gelu_pk(hi); }
+        store_bf16x4(cb + (size_t)m * ld + n, make_float4(lo[0], lo[1], hi[0], hi[1]), cnt);
+    }
+};
 static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the plain-store product (GPU builds)
     unsigned short *dA, *dB, *dCb; float *dC, *dbias;
     hipMalloc((void**)&dA, (size_t)M * K * 2); hipMalloc((void**)&dB, (size_t)N * K * 2); hipMalloc((void**)&dC, (size_t)M * N * 4); hipMalloc((void**)&dCb, (size_t)M * N * 2); hipMalloc((void**)&dbias, (size_t)N * 4);
@@ -99,7 +111,7 @@ static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the 
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) launch((hipStream_t)0, dA, K, dB, K, PlainStore{dC, dCb, dbias, N}, M, N, K);
     hipEventRecord(e0, 0);
-    const int reps = 10;
+    const int reps = getenv("GEMM16_REPS") ? atoi(getenv("GEMM16_REPS")) : 10;
     for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, PlainStore{dC, dCb, dbias, N}, M, N, K);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -108,7 +120,23 @@ static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the 
     for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, BfStore{dCb, N}, M, N, K);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
-    printf(" | bf16 store only %.3f ms, %.1f TFLOP/s\n", ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    printf(" | bf16 store only %.3f ms, %.1f TFLOP/s", ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    // what a model store adds, one piece at a time: a scale per row, a bias per column, the packed GELU
+    float* dscale;
+    hipMalloc((void**)&dscale, (size_t)M * 4);
+    hipMemset(dscale, 0, (size_t)M * 4);
+    auto timed = [&](auto st, const float* rs) {
+        launch((hipStream_t)0, dA, K, dB, K, st, M, N, K, rs);
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < reps; ++it) launch((hipStream_t)0, dA, K, dB, K, st, M, N, K, rs);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        return ms / reps;
+    };
+    const float t_rs = timed(BfStore{dCb, N}, dscale), t_b = timed(BfBiasStore<0>{dCb, dbias, N}, nullptr), t_g = timed(BfBiasStore<1>{dCb, dbias, N}, nullptr),
+                t_all = timed(BfBiasStore<1>{dCb, dbias, N}, dscale);
+    printf(" | + row scale %.3f | + bias %.3f | + bias + gelu %.3f | all three %.3f ms\n", t_rs, t_b, t_g, t_all);
+    hipFree(dscale);
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dCb); hipFree(dbias);
 }
 
@@ -123,8 +151,18 @@ static int helper_checks() {
     }
     double worst = 0.0;
     for (int i = -80000; i <= 80000; ++i) { const float x = i * 1e-4f; worst = fmax(worst, fabs((double)erf_fast(x) - erf((double)x))); }
-    printf("FastDiv mismatches %d; erf_fast max |error| %.2e over [-8, 8] -> %s\n", bad, worst, bad == 0 && worst < 5e-7 ? "OK" : "FAIL");
-    return bad == 0 && worst < 5e-7 ? 0 : 1;
+    double worst_g = 0.0, worst_in = 0.0;          // the packed GELU of the bf16 stores against the erf form
+    for (int i = -100000; i <= 100000; ++i) {
+        const float x = i * 1e-4f;
+        const v2f g = gelu_pk(mk2(x, -x));
+        const double e0 = fabs((double)g[0] - 0.5 * x * (1.0 + erf((double)x * 0.70710678118654752440))), e1 = fabs((double)g[1] - 0.5 * -x * (1.0 + erf((double)-x * 0.70710678118654752440)));
+        worst_g = fmax(worst_g, fmax(e0, e1) / fmax(1.0, fabs((double)x)));
+        if (fabsf(x) <= 4.0f) worst_in = fmax(worst_in, fmax(e0, e1));
+    }
+    const bool ok = bad == 0 && worst < 5e-7 && worst_in < 1.2e-4 && worst_g < 1.2e-4;
+    printf("FastDiv mismatches %d; erf_fast max |error| %.2e over [-8, 8]; gelu_pk max |error| %.2e on [-4, 4], %.2e / max(1, |x|) on [-10, 10] -> %s\n", bad, worst, worst_in, worst_g,
+           ok ? "OK" : "FAIL");
+    return ok ? 0 : 1;
 }
 #endif
 
