@@ -219,6 +219,10 @@ __device__ __forceinline__ void fft256_inplace(float2* v, float2* buf, int lane,
 
 // keep(ok, v) = ok ? v : 0 per component.  (A ?: between two float4 OBJECTS makes the compiler select between their addresses and park both on the stack.)
 __device__ __forceinline__ float4 keep4(bool ok, const float4& v) { return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f); }
+// ld4_or_zero(ok, p): *p if ok, else zeros -- WITHOUT touching the loaded value: the select is made on the ADDRESS (a 16-byte block of zeros stands in), so a prefetch
+// written with it can stay in flight across the matrix work that follows.  keep4(ok, *p) selects on the VALUE, which makes the compiler wait for the load right there.
+__device__ __attribute__((aligned(16))) static float g_zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // never written
+__device__ __forceinline__ float4 ld4_or_zero(bool ok, const float* p) { return *reinterpret_cast<const float4*>(ok ? p : g_zero4); }
 __device__ __forceinline__ float4 pick4(bool first, const float4& a, const float4& b) {
     return make_float4(first ? a.x : b.x, first ? a.y : b.y, first ? a.z : b.z, first ? a.w : b.w);
 }

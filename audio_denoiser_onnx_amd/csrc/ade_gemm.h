@@ -91,21 +91,15 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                 const int r = tid >> 2, k = k0 + 4 * (tid & 3);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int m = m_blk + r + 64 * h;                       // unconditional load from an in-range address, zeroed afterwards: a branch
-                    const bool ok = m < M && k < K;                         // around a load costs a full s_waitcnt and serialises the slab's fetches
-                    const float4 v = a_of.vec4(ok ? m : M - 1, ok ? k : 0);
-                    ra[sub][h] = keep4(ok, v);
+                    const int m = m_blk + r + 64 * h;                       // LOADS ONLY, from addresses that are always in range (see stash)
+                    ra[sub][h] = a_of.vec4(m < M ? m : M - 1, k < K ? k : 0);
                 }
             }
         } else {                            // lane = (row, half slab): 8 k of one row; consecutive lanes = consecutive k-halves / rows
             const int r = AL::kAlongK ? tid >> 1 : tid & 127, kh = (AL::kAlongK ? tid & 1 : tid >> 7) * 8, m = m_blk + r;
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool ok = m < M && k0 + kh + u < K;
-                const float v = a_of(ok ? m : M - 1, ok ? k0 + kh + u : 0);
-                t[u] = ok ? v : 0.0f;
-            }
+            for (int u = 0; u < 8; ++u) t[u] = a_of(m < M ? m : M - 1, k0 + kh + u < K ? k0 + kh + u : 0);
             ra[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             ra[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
@@ -115,20 +109,14 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = n_blk + c + 64 * h;
-                    const bool ok = n < N && k < K;
-                    const float4 v = b_of.vec4(ok ? n : N - 1, ok ? k : 0);
-                    rb[sub][h] = keep4(ok, v);
+                    rb[sub][h] = b_of.vec4(n < N ? n : N - 1, k < K ? k : 0);
                 }
             }
         } else if (BL::kAlongN) {           // lane = (column, half slab): consecutive lanes = consecutive columns
             const int c = tid & 127, kh = (tid >> 7) * 8, n = n_blk + c;
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool ok = n < N && k0 + kh + u < K;
-                const float v = b_of(ok ? k0 + kh + u : 0, ok ? n : N - 1);
-                t[u] = ok ? v : 0.0f;
-            }
+            for (int u = 0; u < 8; ++u) t[u] = b_of(k0 + kh + u < K ? k0 + kh + u : 0, n < N ? n : N - 1);
             rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         } else {                            // lane = (k, column group): consecutive lanes = consecutive k of one column; columns cg + 16 u
@@ -137,17 +125,33 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int n = n_blk + cg + 16 * u;
-                const bool ok = n < N && k0 + kk < K;
-                const float v = b_of(ok ? k0 + kk : 0, ok ? n : N - 1);
-                t[u] = ok ? v : 0.0f;
+                t[u] = b_of(k0 + kk < K ? k0 + kk : 0, n < N ? n : N - 1);
             }
             rb[sub][0] = make_float4(t[0], t[1], t[2], t[3]);
             rb[sub][1] = make_float4(t[4], t[5], t[6], t[7]);
         }
     };
-    auto stash = [&](int sub, int buf) {
+    // stash(sub, buf, k0): registers -> row-major LDS slabs (same lane maps as fetch); k0 = the slab's first k.  What a fetch read from a clamped address is dealt with
+    // HERE, behind the wait the LDS write needs anyway: rows beyond M / N are left as they are (the last row again: their products are never stored), the k >= K part of
+    // the last slab is zeroed in both operands.  (Zeroing at the load -- select(ok, load, 0) -- made the compiler wait for the slab right after requesting it, ahead of the
+    // previous slab's MFMAs: the prefetch hid nothing.)
+    auto stash = [&](int sub, int buf, int k0) {
         float* As = As_all + buf * kSlabW;
-        float* Bs = Bs_all + buf * kSlabW;                    // registers -> row-major LDS slabs (same lane maps as fetch)
+        float* Bs = Bs_all + buf * kSlabW;
+        if (k0 + kTK > K) {                                   // wave-uniform: only the last slab of a K that is not a multiple of 16
+            auto cut = [&](float4 (&v)[2], int first, int step) {     // v[h] holds k = first + step h .. + 3
+                float t[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = first + (u >> 2) * step + (u & 3) < K ? t[u] : 0.0f;
+                v[0] = make_float4(t[0], t[1], t[2], t[3]);
+                v[1] = make_float4(t[4], t[5], t[6], t[7]);
+            };
+            if (a_v4) { const bool in = k0 + 4 * (tid & 3) < K; ra[sub][0] = keep4(in, ra[sub][0]); ra[sub][1] = keep4(in, ra[sub][1]); }
+            else cut(ra[sub], k0 + (AL::kAlongK ? tid & 1 : tid >> 7) * 8, 4);
+            if (b_v4) { const bool in = k0 + 4 * (tid & 3) < K; rb[sub][0] = keep4(in, rb[sub][0]); rb[sub][1] = keep4(in, rb[sub][1]); }
+            else if (BL::kAlongN) cut(rb[sub], k0 + (tid >> 7) * 8, 4);
+            else { const bool in = k0 + (tid & 15) < K; rb[sub][0] = keep4(in, rb[sub][0]); rb[sub][1] = keep4(in, rb[sub][1]); }
+        }
         if (a_v4) {
             const int r = tid >> 2, kq = 4 * (tid & 3);
             put4(As, r, kq, ra[sub][0]);
@@ -193,14 +197,14 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
     if constexpr (kDouble) {
         static_assert(!kDouble || kSub == 1, "the double-buffered loop stages one f32 slab at a time");
         fetch(0, 0);
-        stash(0, 0);
+        stash(0, 0, 0);
         __syncthreads();
         int cur = 0;
         for (int k0 = 0; k0 < K; k0 += kTK) {
             const bool more = k0 + kTK < K;
             if (more) fetch(k0 + kTK, 0);
             compute(cur);
-            if (more) stash(0, cur ^ 1);             // the other slab: last read in the previous iteration, behind that iteration's barrier
+            if (more) stash(0, cur ^ 1, k0 + kTK);   // the other slab: last read in the previous iteration, behind that iteration's barrier
             __syncthreads();
             cur ^= 1;
         }
@@ -209,7 +213,7 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
         for (int sub = 0; sub < kS; ++sub) fetch(kTK * sub, sub);
         for (int k0 = 0; k0 < K; k0 += kTK * kS) {
 #pragma unroll
-            for (int sub = 0; sub < kS; ++sub) stash(sub, sub);
+            for (int sub = 0; sub < kS; ++sub) stash(sub, sub, k0 + kTK * sub);
             __syncthreads();
             if (k0 + kTK * kS < K) {
 #pragma unroll

@@ -94,31 +94,37 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
     const bf16_t* At = A + (size_t)m_blk * lda;
     const bf16_t* Bt = B + (size_t)n_blk * ldb;
     int ao[4], bo[4];
-    bool aok[4], bok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int r = sr + 32 * u;
-        aok[u] = m_blk + r < M;
-        bok[u] = n_blk + r < N;
-        ao[u] = (aok[u] ? r : M - 1 - m_blk) * lda;                    // out-of-range rows: an in-range address, zeroed after the load (no branch around a load)
-        bo[u] = (bok[u] ? r : N - 1 - n_blk) * ldb;
+        ao[u] = (m_blk + r < M ? r : M - 1 - m_blk) * lda;
+        bo[u] = (n_blk + r < N ? r : N - 1 - n_blk) * ldb;
     }
     // (Two register sets -- slab k + 2 requested while slab k is multiplied -- were measured SLOWER: 150+ registers cost the fourth resident workgroup, 268.9 -> 279.0 ms
     //  per Mel-Band step; what bounds this loop is the CU's 64 B / clk vector-memory path, which a 128 x 128 x 64 slab step loads exactly as fast as it multiplies.)
-    uint4 ra[1][4], rb[1][4];
-    auto fetch = [&](int k0, int set) {
-        const bool kok = k0 + 8 * sc < K;                                // K % 8 == 0: a piece is all in or all out
+    // A fetch is LOADS ONLY, from addresses that are always in range: rows beyond M / N re-read the last row (their products are never stored) and the pieces of a slab beyond
+    // K re-read k = 0 and are zeroed in stash(), behind the wait the LDS write needs anyway.  (Zeroing at the load -- `select(ok, load, 0)` -- made the compiler wait for the
+    // slab right after requesting it, ahead of the previous slab's MFMAs: the prefetch hid nothing.)
+    uint4 ra[4], rb[4];
+    bool kok = true, ktail = false;
+    auto fetch = [&](int k0) {
+        ktail = k0 + kTK > K;                                            // wave-uniform
+        kok = k0 + 8 * sc < K;                                           // K % 8 == 0: a piece is all in or all out
         const int ko = kok ? k0 + 8 * sc : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ra[set][u] = zero_unless(aok[u] && kok, *reinterpret_cast<const uint4*>(At + (ao[u] + ko)));
+        for (int u = 0; u < 4; ++u) ra[u] = *reinterpret_cast<const uint4*>(At + (ao[u] + ko));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rb[set][u] = zero_unless(bok[u] && kok, *reinterpret_cast<const uint4*>(Bt + (bo[u] + ko)));
+        for (int u = 0; u < 4; ++u) rb[u] = *reinterpret_cast<const uint4*>(Bt + (bo[u] + ko));
     };
-    auto stash = [&](int set) {
+    auto stash = [&]() {
+        if (ktail) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ra[u] = zero_unless(kok, ra[u]); rb[u] = zero_unless(kok, rb[u]); }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            *reinterpret_cast<uint4*>(As + (sr + 32 * u) * kPitch + 16 * sc) = ra[set][u];
-            *reinterpret_cast<uint4*>(Bs + (sr + 32 * u) * kPitch + 16 * sc) = rb[set][u];
+            *reinterpret_cast<uint4*>(As + (sr + 32 * u) * kPitch + 16 * sc) = ra[u];
+            *reinterpret_cast<uint4*>(Bs + (sr + 32 * u) * kPitch + 16 * sc) = rb[u];
         }
     };
     // MFMA operand layout (32x32x16): lane l supplies row (l & 31), k = 8 (l >> 5) .. + 7 of the 16-deep step.  MFMA-A = rows of B (n), MFMA-B = rows of A (m):
@@ -137,11 +143,11 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(fb[j], fa[i], acc[i][j]);
         }
     };
-    fetch(0, 0);
+    fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
-        stash(0);
+        stash();
         __syncthreads();
-        if (k0 + kTK < K) fetch(k0 + kTK, 0);
+        if (k0 + kTK < K) fetch(k0 + kTK);
         compute();
         __syncthreads();
     }

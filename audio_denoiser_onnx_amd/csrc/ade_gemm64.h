@@ -59,20 +59,23 @@ __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL 
     const int nb = n_blk + r;
     const bool nok = nb < N;
     float4 ra[4], rb;
-    auto fetch = [&](int k0) {                           // unconditional loads from in-range addresses, zeroed afterwards: a branch around a load costs a full s_waitcnt
-        const int k = k0 + kq;
-        const bool kok = k < K;
-        const int kc = kok ? k : 0;
+    // A fetch is LOADS ONLY, from addresses that are always in range: rows beyond M / N re-read row 0 (their products are never stored); the k >= K part of the last slab is
+    // zeroed when the slab goes to LDS, behind the wait that write needs anyway.  (select(ok, load, 0) at the load made the compiler wait for the slab right after requesting
+    // it, ahead of the previous slab's MFMAs: the prefetch hid nothing.)
+    auto fetch = [&](int k0) {
+        const int kc = k0 + kq < K ? k0 + kq : 0;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const float4 v = a_of.vec4(rows[h], kc);
-            ra[h] = keep4(rok[h] && kok, v);
-        }
-        const float4 w = b_of.vec4(nok ? nb : 0, kc);
-        rb = keep4(nok && kok, w);
+        for (int h = 0; h < 4; ++h) ra[h] = a_of.vec4(rows[h], kc);
+        rb = b_of.vec4(nok ? nb : 0, kc);
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
+        if (k0 + kTK > K) {                              // wave-uniform: the last slab of a K that is not a multiple of 16
+            const bool in = k0 + kq < K;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ra[h] = keep4(in, ra[h]);
+            rb = keep4(in, rb);
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(As + (r + 64 * h) * kRow + kq) = ra[h];
         *reinterpret_cast<float4*>(Bs + r * kRow + kq) = rb;

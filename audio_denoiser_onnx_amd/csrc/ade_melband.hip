@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
             const int i = tid + 256 * u, p = i >> 4, d = (i & 15) * 4, key = c0 + p;
             const bool ok = key < n;
             const float* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + d;
-            pk[u] = keep4(ok, *reinterpret_cast<const float4*>(src + di));
-            pv[u] = keep4(ok, *reinterpret_cast<const float4*>(src + 2 * di));
+            pk[u] = ld4_or_zero(ok, src + di);            // (zeros by address, not by a select on the loaded value: the requests stay in flight across the chunk's products)
+            pv[u] = ld4_or_zero(ok, src + 2 * di);
         }
     };
     request(0);

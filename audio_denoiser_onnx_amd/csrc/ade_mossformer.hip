@@ -175,8 +175,7 @@ struct ShiftA {                // token shift (:454-456): first half of the chan
     __device__ bool can_vec4(int) const { return true; }
     __device__ float4 vec4(int m, int k) const {          // branch-free: one load from a valid row, zeroed for the first frame's shifted half
         const bool shifted = k < kHalf, first = (m % n) == 0;
-        const float4 v = *reinterpret_cast<const float4*>(h + (size_t)(shifted && !first ? m - 1 : m) * kDim + k);
-        return keep4(!(shifted && first), v);
+        return ld4_or_zero(!(shifted && first), h + (size_t)(shifted && !first ? m - 1 : m) * kDim + k);      // (zeros by address: a prefetch stays in flight)
     }
 };
 struct ScaleSiluStore {        // silu(v * inv[m] + bias[n])   (ScaleNorm folded, :458-459, :502-503)

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
 #pragma unroll
         for (int h = 0; h < 5; ++h) {
             const bool ok = kt ? sok1[h] : sok0[h];
-            ra[h] = keep4(ok, *reinterpret_cast<const float4*>(src + (stok[h] - (ok ? shift : 0)) * ld));
+            ra[h] = ld4_or_zero(ok, src + (stok[h] - (ok ? shift : 0)) * ld);       // (zeros by address: the loads stay in flight across this stage's products)
         }
         const float* wp = w + (size_t)sr * (6 * cin) + (size_t)(kt * 3) * cin + ci0 + kq;
         rb0 = *reinterpret_cast<const float4*>(wp);
@@ -388,11 +388,11 @@ struct RowConvA {
         const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
         return Row{((long long)b * T + t) * Fin, f * stride - 1};
     }
-    __device__ float4 vec4(const Row& r, int k) const {                  // branch-free: clamped address, zeroed afterwards (a branch around the load would fence it)
+    __device__ float4 vec4(const Row& r, int k) const {                  // branch-free: the padding positions read a block of zeros (no select on the loaded value)
         const int kf = k / C, ci = k - kf * C, f2 = r.f0 + kf;
         const bool ok = f2 >= 0 && f2 < Fin;
         const int ch = ch0 + ci;
-        return keep4(ok, *reinterpret_cast<const float4*>(hist + (size_t)(r.base + (ok ? f2 : 0)) * hist_ld + ch));
+        return ld4_or_zero(ok, hist + (size_t)(r.base + (ok ? f2 : 0)) * hist_ld + ch);
     }
 };
 struct SubPixelStore {         // conv channel n = c * r + u of sub-band f -> U[(b, t, f * r + u)][ch0 + c] (+ bias)   (:767-769)
