@@ -66,6 +66,8 @@ __device__ __forceinline__ v8bf as_v8bf(const uint4& u) { v8bf r; __builtin_memc
 __device__ __forceinline__ v16f mfma32x32x16(const uint4& a, const uint4& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_v8bf(a), as_v8bf(b), c, 0, 0, 0); }
 
 __device__ __forceinline__ uint4 zero_unless(bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
+// eight bf16 at p if ok, else zeros, selected by ADDRESS (ade_device.h, ld4_or_zero): a prefetch written with it stays in flight across the matrix work that follows
+__device__ __forceinline__ uint4 ld8_or_zero(bool ok, const bf16_t* p) { return *reinterpret_cast<const uint4*>(ok ? reinterpret_cast<const void*>(p) : reinterpret_cast<const void*>(g_zero4)); }
 
 // one 128 x 128 tile of C at (m_blk, n_blk); lds: kLdsBytes, 16-byte aligned
 // row_scale (may be null): C(m, n) is multiplied by row_scale[m] before the store sees it (the norm of a normalised operand: ade_melband.hip).  The tile's 128 scales are

@@ -33,6 +33,10 @@ struct WavesPerSimd { static constexpr int value = 4; };
 template <class T>
 struct WavesPerSimd<T, std::void_t<decltype(T::kWavesPerSimd)>> { static constexpr int value = T::kWavesPerSimd; };
 
+template <class T, class = void>
+struct HasFinish : std::false_type {};
+template <class T>
+struct HasFinish<T, std::void_t<decltype(&T::finish)>> : std::true_type {};
 template <class AL, class BL, class ST>
 __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL a_of, BL b_of, ST store, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) float As[kTM * kRow];
@@ -70,6 +74,10 @@ __global__ __launch_bounds__(256, WavesPerSimd<AL>::value) void k_gemm256x64(AL 
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += kTK) {
+        if constexpr (HasFinish<AL>::value) {            // an operand that is a function of what was loaded (an activation): applied here, not at the load
+#pragma unroll
+            for (int h = 0; h < 4; ++h) ra[h] = AL::finish(ra[h]);
+        }
         if (k0 + kTK > K) {                              // wave-uniform: the last slab of a K that is not a multiple of 16
             const bool in = k0 + kq < K;
 #pragma unroll

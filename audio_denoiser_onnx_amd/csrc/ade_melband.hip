@@ -650,8 +650,8 @@ __global__ __launch_bounds__(256, 3) void k_attention16(const bf16_t* __restrict
             const int i = tid + 256 * u, p = 2 * (i >> 4) + (i & 1), key = c0 + p;
             const bool ok = key < n;
             const bf16_t* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + 8 * ((i >> 1) & 7);
-            pk[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + di));
-            pv[u] = gemm16::zero_unless(ok, *reinterpret_cast<const uint4*>(src + 2 * di));
+            pk[u] = gemm16::ld8_or_zero(ok, src + di);
+            pv[u] = gemm16::ld8_or_zero(ok, src + 2 * di);
         }
     };
     // m / l are kept in the exponent's units: scores are multiplied by log2(e) inside the fused multiply-add that subtracts the running maximum, exp is v_exp_f32 alone

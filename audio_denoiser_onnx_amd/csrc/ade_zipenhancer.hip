@@ -414,8 +414,8 @@ struct ActRowsA {
     int ld;
     struct Row { const float* q; };
     __device__ Row row(int m) const { return Row{p + (size_t)m * ld}; }
-    __device__ float4 vec4(const Row& r, int k) const {
-        float4 v = *reinterpret_cast<const float4*>(r.q + k);
+    __device__ float4 vec4(const Row& r, int k) const { return *reinterpret_cast<const float4*>(r.q + k); }      // the load alone: it stays in flight across a slab's products
+    __device__ static float4 finish(float4 v) {           // applied when the slab goes to LDS (k_gemm256x64)
         if (KIND == 1) { v.x = swoosh_l(v.x); v.y = swoosh_l(v.y); v.z = swoosh_l(v.z); v.w = swoosh_l(v.w); }
         if (KIND == 2) { v.x = swoosh_r(v.x); v.y = swoosh_r(v.y); v.z = swoosh_r(v.z); v.w = swoosh_r(v.w); }
         return v;
