@@ -45,6 +45,17 @@ def test_hipsim_attention16_both_axes():
     _run(_build_sim("melband16_unit"), 70, 1, 2, 0, 40, 2, 3, 1, 129, 1, 1, 0)
 
 
+@pytest.mark.hipsim
+def test_hipsim_gemm32_fetch_paths_and_k_tails():
+    """csrc/ade_gemm.h's fp32 tile: the four operand fetch paths, a K that ends inside a slab (the fetch is loads only; the tail is zeroed on the way into LDS), partial tiles"""
+    _run(_build_sim("gemm32_unit"), 130, 70, 37, 129, 200, 64, 40, 300, 20)
+
+
+@pytest.mark.gpu
+def test_gpu_gemm32_fetch_paths_and_k_tails():
+    _run(_build_gpu("gemm32_unit"), 130, 70, 37, 129, 200, 64, 1000, 333, 250, 257, 640, 1029)
+
+
 @pytest.mark.gpu
 def test_gpu_gemm16_many_tiles():
     _run(_build_gpu("gemm16_unit"), 1000, 1544, 384, 777, 384, 1536, 130, 70, 72, 64, 25633, 64, 4096, 512, 512)
