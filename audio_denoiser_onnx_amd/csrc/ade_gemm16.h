@@ -43,7 +43,7 @@ constexpr int kSlabBytes = kTM * kPitch;             // one operand's slab
 constexpr int kEpiPitch = 132;                       // floats per row of the epilogue tile (128 + 4: a wave's float4 writes of 8 consecutive rows cover all banks once)
 constexpr int kEpiBytes = 64 * kEpiPitch * 4;
 constexpr int kMainLds = 2 * kSlabBytes > kEpiBytes ? 2 * kSlabBytes : kEpiBytes;       // 36 864: the two operand slabs, later the epilogue tile
-constexpr int kLdsBytes = kMainLds + kTM * 4;        // + the tile's row scales (four workgroups per CU: 149.5 KB)
+constexpr int kLdsBytes = kMainLds + 2 * kTM * 4;    // + the tile's row scales and row contexts (four workgroups per CU: 151.5 KB)
 
 // fp32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
@@ -70,6 +70,12 @@ __device__ __forceinline__ uint4 zero_unless(bool ok, const uint4& v) { return m
 __device__ __forceinline__ uint4 ld8_or_zero(bool ok, const bf16_t* p) { return *reinterpret_cast<const uint4*>(ok ? reinterpret_cast<const void*>(p) : reinterpret_cast<const void*>(g_zero4)); }
 
 // one 128 x 128 tile of C at (m_blk, n_blk); lds: kLdsBytes, 16-byte aligned
+// A store may provide `int row_ctx(int m) const` (something it needs per ROW that costs integer divisions to derive: Mel-Band's rotary position): the tile computes it once
+// per row into LDS when it starts and hands it to `operator()(m, n, v, cnt, colctx, rowctx)`.
+template <class T, class = void>
+struct HasRowCtx : std::false_type {};
+template <class T>
+struct HasRowCtx<T, std::void_t<decltype(&T::row_ctx)>> : std::true_type {};
 // row_scale (may be null): C(m, n) is multiplied by row_scale[m] before the store sees it (the norm of a normalised operand: ade_melband.hip).  The tile's 128 scales are
 // fetched into LDS when the tile starts, so the epilogue -- which runs with nothing in flight to hide a global load behind -- reads them from LDS.
 template <class ST>
@@ -77,6 +83,10 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                                           unsigned char* lds, const float* __restrict__ row_scale = nullptr) {
     float* rsc = reinterpret_cast<float*>(lds + kMainLds);
     if (row_scale && threadIdx.x < kTM) rsc[threadIdx.x] = row_scale[m_blk + (int)threadIdx.x < M ? m_blk + (int)threadIdx.x : M - 1];
+    int* rcx = reinterpret_cast<int*>(lds + kMainLds + kTM * 4);
+    if constexpr (HasRowCtx<ST>::value) {
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + kTM) { const int rr = (int)threadIdx.x - 128; rcx[rr] = store.row_ctx(m_blk + rr < M ? m_blk + rr : M - 1); }
+    }
     unsigned char* As = lds;
     unsigned char* Bs = lds + kSlabBytes;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +193,8 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                         const float rs = rsc[64 * half + row];
                         v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs);
                     }
-                    store(m_blk + 64 * half + row, n, v, 4, cc);
+                    if constexpr (HasRowCtx<ST>::value) store(m_blk + 64 * half + row, n, v, 4, cc, rcx[64 * half + row]);
+                    else store(m_blk + 64 * half + row, n, v, 4, cc);
                 }
             } else if (n < N) {
 #pragma unroll
@@ -195,7 +206,8 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
                             const float rs = rsc[64 * half + row];
                             v = make_float4(v.x * rs, v.y * rs, v.z * rs, v.w * rs);
                         }
-                        store(m, n, v, cnt, cc);
+                        if constexpr (HasRowCtx<ST>::value) store(m, n, v, cnt, cc, rcx[64 * half + row]);
+                        else store(m, n, v, cnt, cc);
                     }
                 }
             }

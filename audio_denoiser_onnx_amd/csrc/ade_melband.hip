@@ -468,10 +468,11 @@ struct RotaryQkStore16 {       // q | k | v | gates = (Xg W_in^T) / |x2 g| + b_i
     int ld, rot_cols;
     gemm16::FastDiv pos_stride, n_pos;      // position of row m = (m / pos_stride) % n_pos
     __device__ float4 col(int n, int cnt) const { return gemm16::load_f32x4(bias + n, cnt); }
-    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b) const {
+    __device__ int row_ctx(int m) const { const int q = pos_stride.div(m); return (q - n_pos.div(q) * (int)n_pos.d) * kDh; }      // the row's offset into the rotary tables (once per tile row: gemm16)
+    __device__ void operator()(int m, int n, float4 v, int cnt, const float4& b, int row_at) const {
         float4 u = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);      // (v arrives scaled by 1 / |operand row|: gemm16's row_scale)
         if (n < rot_cols) {                                          // rot_cols % 4 == 0: a float4 is rotated whole or not at all
-            const int q = pos_stride.div(m), at = (q - n_pos.div(q) * (int)n_pos.d) * kDh + (n & (kDh - 1));
+            const int at = row_at + (n & (kDh - 1));
             const float4 c = *reinterpret_cast<const float4*>(rcos + at), sn = *reinterpret_cast<const float4*>(rsin + at);
             u = make_float4(__fmaf_rn(u.x, c.x, __fmul_rn(u.y, sn.x)), __fmaf_rn(u.y, c.y, __fmul_rn(u.x, sn.y)),
                             __fmaf_rn(u.z, c.z, __fmul_rn(u.w, sn.z)), __fmaf_rn(u.w, c.w, __fmul_rn(u.z, sn.w)));
