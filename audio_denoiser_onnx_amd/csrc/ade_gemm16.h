@@ -3,9 +3,11 @@
 //   C(m, n) = sum_k A[m][k] * B[n][k]        A, B: bf16, row-major with k contiguous (activations (rows, features); torch Linear weights (out, in));
 //                                            products exact, accumulation fp32 (v_mfma_f32_32x32x16_bf16)
 //
-// Unlike the bf16 MODE of ade_gemm.h (fp32 operands in HBM, rounded on their way into LDS, the half-rate 16x16x16 instruction) the operands here are half the bytes
-// everywhere -- HBM, L2, LDS -- and the instruction is gfx950's full-rate 32x32x16 form (16 x the f32 matrix rate).  At these shapes (M ~ 1.5 M rows, N and K
-// 384 .. 1544) the products are bound by operand / result traffic, not by the matrix cores, so the kernel is built around full-line transfers:
+// The operands are half the bytes everywhere -- HBM, L2, LDS -- and the instruction is gfx950's full-rate 32x32x16 form (16 x the f32 matrix rate).  At these shapes
+// (M ~ 1.5 M rows, N and K 384 .. 1544) the loop is NOT matrix-bound: the counters of the bare loop (tools/pmc_gemm16_unit.sh, K = 1536) show the matrix cores 41 % and the LDS
+// pipe 44 % busy with the wavefronts waiting to ISSUE 60 % of their cycles -- a 128 x 128 x 64 slab step costs the CU's one LDS pipe ~768 cycles (32 ds_write_b128 at 16,
+// 64 ds_read_b128 at 4) against 512 matrix cycles per SIMD, and every VALU instruction of a store takes an issue slot the MFMAs want.  So the kernel is built around
+// full-line transfers, a prefetch that really stays in flight, and stores with as few instructions as they can have:
 //   * one 256-thread workgroup = one 128 x 128 tile of C, four wavefronts in 2 x 2, each a 64 x 64 quadrant as 2 x 2 MFMA tiles (64 accumulator registers);
 //   * k runs in slabs of 64: a slab of an operand is 128 rows x 128 bytes, fetched as whole 128-byte lines (8 lanes x 16 bytes per row) into registers one slab
 //     ahead of the MFMAs and written to LDS with a 144-byte row pitch (36 words: the 16 lanes of every ds_read_b128 service group land on 16 distinct 4-bank sets);
@@ -112,8 +114,8 @@ __device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ A, int lda,
         ao[u] = (m_blk + r < M ? r : M - 1 - m_blk) * lda;
         bo[u] = (n_blk + r < N ? r : N - 1 - n_blk) * ldb;
     }
-    // (Two register sets -- slab k + 2 requested while slab k is multiplied -- were measured SLOWER: 150+ registers cost the fourth resident workgroup, 268.9 -> 279.0 ms
-    //  per Mel-Band step; what bounds this loop is the CU's 64 B / clk vector-memory path, which a 128 x 128 x 64 slab step loads exactly as fast as it multiplies.)
+    // (Two register sets -- slab k + 2 requested while slab k is multiplied -- were measured SLOWER on the first form of this loop: 150+ registers cost the fourth resident
+    //  workgroup, 268.9 -> 279.0 ms per Mel-Band step.)
     // A fetch is LOADS ONLY, from addresses that are always in range: rows beyond M / N re-read the last row (their products are never stored) and the pieces of a slab beyond
     // K re-read k = 0 and are zeroed in stash(), behind the wait the LDS write needs anyway.  (Zeroing at the load -- `select(ok, load, 0)` -- made the compiler wait for the
     // slab right after requesting it, ahead of the previous slab's MFMAs: the prefetch hid nothing.)
