@@ -33,7 +33,6 @@ struct Geo {
     static constexpr int kPosPerThread = (kPmax + NT - 1) / NT;   // 3 for both geometries
     static constexpr int kTileF = NT / 64;                        // frames per front / back tile = wavefronts per workgroup
     static constexpr int kProdBase = ((TMAX * (kFw / 3) + 63) / 64) * 64;   // first lane of the wavefronts that are idle in the conv phases
-    static constexpr int kInterCols = NT >= kFw * 16 ? 64 : (NT >= 512 ? 17 : 11);   // F columns per pass of the inter-frame GRU (16 lanes per column): 1, 2 or 3 passes
     static constexpr bool kLean = NT < 512;                       // 40 KB of LDS per workgroup: the front / back stages read their small tables from L1 / L2 instead of LDS copies
     static_assert(kPosPerThread == 3, "the conv phases are written for three positions per lane");
     static_assert(kProdBase < NT, "the history producers need a wavefront outside the conv lanes");
@@ -739,14 +738,13 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     //      one packed accumulator, the n gate packed over input pairs, and the 8 hidden values of a lane's own group
     //      fetched with 7 row rotations by 2s (group in the lane's low bit => a rotation by 2s stays inside the group);
     //      each lane keeps its recurrent weights pre-rotated to match.
-    //      A workgroup with fewer than 33 x 16 lanes walks the columns in passes of G::kInterCols.
-#pragma unroll 1
-    for (int fb = 0; fb < kFw; fb += G::kInterCols)
-    if (tid < (((kFw - fb < G::kInterCols ? kFw - fb : G::kInterCols) * 16 + 63) / 64) * 64) {
-        const int f = fb + (tid >> 4), q = tid & 15;
+    //      One pass: a 16-lane row walks SEVERAL columns (row, row + 16, ..) through the same step loop -- independent recurrences interleaved instruction by instruction, so
+    //      one column's exp / rcp / rotation latencies are another's issue slots.  (Round 3 walked the columns in three passes of eleven: three dependent loops of T steps
+    //      where this is one, and the recurrence is what a chunk's four segments wait for.)  The weights depend on the lane's role q only: shared by its columns.
+    {
+        constexpr int kRows = G::kThreads / 16;                      // 16-lane rows of the workgroup
+        const int row = tid >> 4, q = tid & 15;
         const int grp = q & 1, unit = q >> 1;
-        const bool live = f < kFw && (tid >> 4) < G::kInterCols;     // (lanes that only fill up the last wavefront of a pass recompute a column and drop it)
-        const int fc_ = f < kFw ? f : kFw - 1;
         const float* pk = w.inter_gru + (grp * 8 + unit) * 54;      // [W_ih 3x8 | W_hh 3x8 | b_ih 3 | b_hh 3] of this output row
         int ks[8];                                                   // ks[s] = hidden index delivered by rotation s (measured, so the
         ks[0] = unit;                                                // rotation direction convention cannot matter)
@@ -767,44 +765,68 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         }
         const v2f b_rz = mk2((pk[48] + pk[51]) * kS, (pk[49] + pk[52]) * kS);
         const float bi_n = pk[50] * kN, bh_n = pk[53] * kN;
-        float h = 0.0f;
-        float* const xin = sg.xi + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q;
-        if (sg.prev) h = xld1(xin);                                  // the recurrence continues from the previous segment's last frame
-        float4 xa = R[(grp * 2) * kPmax + fc_], xb = R[(grp * 2 + 1) * kPmax + fc_];
-        __builtin_amdgcn_s_setprio(3);
-        for (int t = 0; t < T; ++t) {
-            const int p = t * kFw + fc_;
-            const int pn = (t + 1 < T ? t + 1 : t) * kFw + fc_;
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            xa = R[(grp * 2) * kPmax + pn];          // next step's input: issued now, needed after this step's write
-            xb = R[(grp * 2 + 1) * kPmax + pn];
-            v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
+        auto run = [&](auto nc_c) {
+            constexpr int NC = decltype(nc_c)::value;
+            float h[NC];
+            float4 xa[NC], xb[NC];
+            int fc_[NC];
+            bool live[NC];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a_rz += wi_rz[k] * xv[k];
+            for (int c = 0; c < NC; ++c) {
+                const int f = row + kRows * c;
+                live[c] = f < kFw;                                   // (a lane whose column does not exist recomputes the last one and drops it)
+                fc_[c] = live[c] ? f : kFw - 1;
+                h[c] = 0.0f;
+                if (sg.prev) h[c] = xld1(sg.xi + kXInterOff + blk * (kFw * 16) + fc_[c] * 16 + q);      // the recurrence continues from the previous segment's last frame
+                xa[c] = R[(grp * 2) * kPmax + fc_[c]];
+                xb[c] = R[(grp * 2 + 1) * kPmax + fc_[c]];
+            }
+            __builtin_amdgcn_s_setprio(3);
+            for (int t = 0; t < T; ++t) {
+                const int tn = t + 1 < T ? t + 1 : t;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a_n += wi_n[m] * mk2(xv[2 * m], xv[2 * m + 1]);
-            float hs[8];
-            hs[0] = h;
-#define ADE_HS(S) hs[S] = row_ror<2 * S>(h);
-            ADE_HS(1) ADE_HS(2) ADE_HS(3) ADE_HS(4) ADE_HS(5) ADE_HS(6) ADE_HS(7)
+                for (int c = 0; c < NC; ++c) {
+                    const int p = t * kFw + fc_[c], pn = tn * kFw + fc_[c];
+                    const float xv[8] = {xa[c].x, xa[c].y, xa[c].z, xa[c].w, xb[c].x, xb[c].y, xb[c].z, xb[c].w};
+                    xa[c] = R[(grp * 2) * kPmax + pn];          // next step's input: issued now, needed after this step's write
+                    xb[c] = R[(grp * 2 + 1) * kPmax + pn];
+                    v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a_rz += wi_rz[k] * xv[k];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a_n += wi_n[m] * mk2(xv[2 * m], xv[2 * m + 1]);
+                    float hs[8];
+                    hs[0] = h[c];
+#define ADE_HS(S) hs[S] = row_ror<2 * S>(h[c]);
+                    ADE_HS(1) ADE_HS(2) ADE_HS(3) ADE_HS(4) ADE_HS(5) ADE_HS(6) ADE_HS(7)
 #undef ADE_HS
-            v2f c0 = a_rz, c1 = mk2(0.0f, 0.0f), c_n = mk2(bh_n, 0.0f);
+                    v2f c0 = a_rz, c1 = mk2(0.0f, 0.0f), c_n = mk2(bh_n, 0.0f);
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) { c0 += wh_rz[k] * hs[k]; c1 += wh_rz[k + 1] * hs[k + 1]; }
+                    for (int k = 0; k < 8; k += 2) { c0 += wh_rz[k] * hs[k]; c1 += wh_rz[k + 1] * hs[k + 1]; }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) c_n += wh_n[m] * mk2(hs[2 * m], hs[2 * m + 1]);
-            const v2f rz = c0 + c1;
-            const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[0]));
-            const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[1]));
-            const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1])) + 1.0f);
-            h = n + z * (h - n);
-            if (live) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h;
-        }
-        set_prio(sg.base_prio);
-        if (sg.next) {
-            if (live) xst1(sg.xo + kXInterOff + blk * (kFw * 16) + fc_ * 16 + q, h);
-            xdrain();
-        }
+                    for (int m = 0; m < 4; ++m) c_n += wh_n[m] * mk2(hs[2 * m], hs[2 * m + 1]);
+                    const v2f rz = c0 + c1;
+                    const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[0]));
+                    const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[1]));
+                    const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1])) + 1.0f);
+                    h[c] = n + z * (h[c] - n);
+                    if (live[c]) Rf[((size_t)(grp * 2 + (unit >> 2)) * kPmax + p) * 4 + (unit & 3)] = h[c];
+                }
+            }
+            set_prio(sg.base_prio);
+            if (sg.next) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (live[c]) xst1(sg.xo + kXInterOff + blk * (kFw * 16) + fc_[c] * 16 + q, h[c]);
+                xdrain();
+            }
+        };
+        // columns of this WAVEFRONT's first row decide how many it walks (wave-uniform): rows row0 .. row0 + 3 have columns row + 16 c < 33
+        const int row0 = (tid >> 6) * 4, nc = row0 < kFw ? (kFw - 1 - row0) / kRows + 1 : 0;
+        static_assert((kFw + kRows - 1) / kRows <= 3, "at most three columns per 16-lane row");
+        if (nc == 3) run(std::integral_constant<int, 3>{});
+        else if (nc == 2) run(std::integral_constant<int, 2>{});
+        else if (nc == 1) run(std::integral_constant<int, 1>{});
     }
     __syncthreads();
     if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagInter + blk, 1u);
