@@ -587,6 +587,10 @@ __device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ 
     const int p0 = t * kFw + j, p1 = p0 + 16, p2 = t * kFw + 32;
     float* Rf = reinterpret_cast<float*>(R);
     auto allreduce = [](float s) { s += row_ror<8>(s); s += row_ror<4>(s); s += row_ror<2>(s); s += row_ror<1>(s); return s; };
+    // the residual comes from L2 / HBM (a microsecond or two away with every CU busy): requested HERE, ahead of the statistics, used after them
+    float rs0[16], rs1[16];
+    pl_ld16(res, Ps, p0, rs0);
+    const float re = res[((size_t)(j >> 2) * Ps + p2) * 4 + (j & 3)];
     float v0[16], v1[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -605,25 +609,23 @@ __device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ 
     for (int c = 0; c < 16; ++c) { const float a = v0[c] - mean, b = v1[c] - mean; q2 += a * a + b * b; }
     const float rstd = fast_rsq(allreduce(q2) * (1.0f / (float)(kFw * kCh)) + 1e-8f);
     {
-        float gw[16], gb[16], rs[16];
+        float gw[16], gb[16];
         ld16(ln_w + j * kCh, gw);
         ld16(ln_b + j * kCh, gb);
-        pl_ld16(res, Ps, p0, rs);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v0[c] = ((v0[c] - mean) * rstd * gw[c] + gb[c]) + rs[c];
+        for (int c = 0; c < 16; ++c) v0[c] = ((v0[c] - mean) * rstd * gw[c] + gb[c]) + rs0[c];
         if (live) emit_pos(p0, v0);
     }
     {
-        float gw[16], gb[16], rs[16];
+        float gw[16], gb[16];
+        pl_ld16(res, Ps, p1, rs1);
         ld16(ln_w + (16 + j) * kCh, gw);
         ld16(ln_b + (16 + j) * kCh, gb);
-        pl_ld16(res, Ps, p1, rs);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v1[c] = ((v1[c] - mean) * rstd * gw[c] + gb[c]) + rs[c];
+        for (int c = 0; c < 16; ++c) v1[c] = ((v1[c] - mean) * rstd * gw[c] + gb[c]) + rs1[c];
         if (live) emit_pos(p1, v1);
     }
     {
-        const float re = res[((size_t)(j >> 2) * Ps + p2) * 4 + (j & 3)];
         const float ye = (de * rstd * ln_w[32 * kCh + j] + ln_b[32 * kCh + j]) + re;
         if (live) emit_one(p2, j, ye);
     }
