@@ -125,17 +125,25 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     // ---- phase 0: stage the pointwise input x1 = (a + skip)[:, :8] in LDS planes 2-3 (own position, fully coalesced);
     //      skipped when the previous stage of this launch left it there.
     if (!x1_in_lds) {
-        for (int p = tid; p < P; p += kFusedThreads) {
-            float x[8];
-            pl_ld8(ac, Ps, p, 0, x);
-            if (sc) {
-                float y[8];
-                pl_ld8(sc, Ps, p, 0, y);
+        // (all of a lane's positions are requested before the first is used: the tensors come from L2 / HBM, a microsecond or two away with every CU busy)
+        constexpr int kIt = (kPmax + kFusedThreads - 1) / kFusedThreads;
+        float x[kIt][8], y[kIt][8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] += y[k];
+        for (int i = 0; i < kIt; ++i) {
+            const int p = tid + i * kFusedThreads, pc = p < P ? p : P - 1;
+            pl_ld8(ac, Ps, pc, 0, x[i]);
+            if (sc) pl_ld8(sc, Ps, pc, 0, y[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int p = tid + i * kFusedThreads;
+            if (p >= P) break;
+            if (sc) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[i][k] += y[i][k];
             }
-            H[2 * kPmax + p] = make_float4(x[0], x[1], x[2], x[3]);
-            H[3 * kPmax + p] = make_float4(x[4], x[5], x[6], x[7]);
+            H[2 * kPmax + p] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+            H[3 * kPmax + p] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
         }
         __syncthreads();
     }
@@ -406,17 +414,24 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
     //        activation is exp2 -> add -> rcp with no multiply in front.                              (:149,155)
     if (tid >= 64) {
         // waves 1-15, while wave 0 is busy with the serial recurrence: bypass half (a + skip)[:, 8:] -> planes 0-1 (h1 is dead)
-        for (int p = tid - 64; p < P; p += kFusedThreads - 64) {
-            float by[8];
-            pl_ld8(ac, Ps, p, 2, by);
-            if (sc) {
-                float y[8];
-                pl_ld8(sc, Ps, p, 2, y);
+        constexpr int kLanes = kFusedThreads - 64, kIt = (kPmax + kLanes - 1) / kLanes;       // (requests first, as in phase 0)
+        float by[kIt][8], y[kIt][8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) by[k] += y[k];
+        for (int i = 0; i < kIt; ++i) {
+            const int p = tid - 64 + i * kLanes, pc = p < P ? p : P - 1;
+            pl_ld8(ac, Ps, pc, 2, by[i]);
+            if (sc) pl_ld8(sc, Ps, pc, 2, y[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int p = tid - 64 + i * kLanes;
+            if (p >= P) break;
+            if (sc) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) by[i][k] += y[i][k];
             }
-            H[p] = make_float4(by[0], by[1], by[2], by[3]);
-            H[kPmax + p] = make_float4(by[4], by[5], by[6], by[7]);
+            H[p] = make_float4(by[i][0], by[i][1], by[i][2], by[i][3]);
+            H[kPmax + p] = make_float4(by[i][4], by[i][5], by[i][6], by[i][7]);
         }
     } else {
         const int j = tid & 15, row = tid >> 4;
