@@ -645,14 +645,21 @@ __global__ __launch_bounds__(256, 3) void k_attention16(const bf16_t* __restrict
     // (quad_perm DPP), so that each holds four dims of BOTH keys and writes four 32-bit words (dim, keys 2 kp | 2 kp + 1) -- 16-bit stores of single elements
     // were 4-way bank conflicts on a third of the LDS cycles.
     uint4 pk[2], pv[2];
+    const bf16_t* kp[2];                                                                 // this lane's K pieces of the next chunk (advanced by a chunk per request: no per-chunk 64-bit address arithmetic)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u, p = 2 * (i >> 4) + (i & 1);
+        kp[u] = qkvg + (size_t)(row0 + (long long)p * pos_stride) * ldq + head * kDh + 8 * ((i >> 1) & 7) + di;
+    }
+    const long long kstep = (long long)kKc * pos_stride * ldq;
     auto request = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int i = tid + 256 * u, p = 2 * (i >> 4) + (i & 1), key = c0 + p;
-            const bool ok = key < n;
-            const bf16_t* src = qkvg + (size_t)(row0 + (long long)(ok ? key : 0) * pos_stride) * ldq + head * kDh + 8 * ((i >> 1) & 7);
-            pk[u] = gemm16::ld8_or_zero(ok, src + di);
-            pv[u] = gemm16::ld8_or_zero(ok, src + 2 * di);
+            const int i = tid + 256 * u, p = 2 * (i >> 4) + (i & 1);
+            const bool ok = c0 + p < n;                                                  // (a padded key reads zeros by address: its pointer is never dereferenced)
+            pk[u] = gemm16::ld8_or_zero(ok, kp[u]);
+            pv[u] = gemm16::ld8_or_zero(ok, kp[u] + di);
+            kp[u] += kstep;
         }
     };
     // m / l are kept in the exponent's units: scores are multiplied by log2(e) inside the fused multiply-add that subtracts the running maximum, exp is v_exp_f32 alone
@@ -690,17 +697,24 @@ __global__ __launch_bounds__(256, 3) void k_attention16(const bf16_t* __restrict
                 for (int t = 0; t < QT; ++t) st[t][kt] = mfma16x16x32(kb, qb[t][ks], st[t][kt]);
             }
         }
+        if (last) {                       // (wave-uniform branch: the other chunks carry no compare / select per score)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int key0 = c0 + 16 * kt + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + r >= n) st[t][kt][r] = -INFINITY;
+                }
+        }
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const int key0 = c0 + 16 * kt + 4 * g;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (last && key0 + r >= n) st[t][kt][r] = -INFINITY;
-                    mx = fmaxf(mx, st[t][kt][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[t][kt][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
