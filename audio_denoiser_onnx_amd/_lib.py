@@ -53,7 +53,7 @@ class StftConfig(C.Structure):
 
 
 EXPORTED_SYMBOLS = (
-    "ade_create", "ade_get_io", "ade_process", "ade_process_device", "ade_process_f32", "ade_process_device_f32", "ade_process_f16", "ade_process_device_f16", "ade_stitch_device", "ade_reserve", "ade_set_option", "ade_debug_tap",
+    "ade_create", "ade_get_io", "ade_process", "ade_submit", "ade_wait", "ade_process_device", "ade_process_f32", "ade_process_device_f32", "ade_process_f16", "ade_process_device_f16", "ade_stitch_device", "ade_reserve", "ade_set_option", "ade_debug_tap",
     "ade_kernel_count", "ade_kernel_name", "ade_profile_last", "ade_kernel_ms", "ade_last_error", "ade_destroy",
     "ade_stft_forward", "ade_istft_forward",
     "ade_stft_create", "ade_stft_frames", "ade_stft_output_length", "ade_stft_keep_tail", "ade_stft_analyze", "ade_stft_synthesize", "ade_stft_synthesize_polar",
@@ -93,6 +93,8 @@ class AdeLibrary:
         L.ade_stream_destroy.restype = None
         L.ade_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ade_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ade_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ade_wait.argtypes = [C.c_void_p, C.c_uint64]
         L.ade_process_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ade_process_device_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ade_stitch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

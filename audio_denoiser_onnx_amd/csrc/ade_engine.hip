@@ -96,6 +96,25 @@ struct ade_engine {
     unsigned* h_sio_done = nullptr;       // page-locked [kMaxGroups]: written by a group's last workgroup, polled by the host thread
     unsigned* d_sio_count = nullptr;      // device memory [kMaxGroups]
     unsigned sio_epoch = 0;
+    // ade_submit / ade_wait: a ring of `pipe_depth` submissions in flight -- H2D of call k + 1 on s_pin, the kernels of call k on `stream`, D2H of call k - 1 on s_pout
+    struct PipeSlot {
+        int16_t *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;     // device buffers of the slot; page-locked staging for pageable callers
+        float *d_f32 = nullptr, *h_f32 = nullptr;
+        hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+        unsigned long long ticket = 0;
+        int state = 0;                    // 0 free, 1 in flight, 2 finished (its status waits for ade_wait)
+        int rows = 0;
+        int16_t* out_pcm = nullptr;       // where a pageable caller's output goes when the slot is finished (null: it was DMA'd directly)
+        float* out_f32 = nullptr;
+        int status = 0;
+        std::string error;
+    };
+    static constexpr int kMaxPipe = 4;
+    PipeSlot pipe[kMaxPipe];
+    int pipe_depth = 2;                   // option "pipe_depth" (2 .. 4)
+    int pipe_capacity = 0;                // rows every slot's buffers hold
+    unsigned long long pipe_next = 1;     // the next ticket
+    hipStream_t s_pin = nullptr, s_pout = nullptr;
     float* d_weights = nullptr;
     int* d_ints = nullptr;
     FftTabs tabs{};
@@ -517,6 +536,9 @@ ade_status ensure_exchange(ade_engine* e) {
     }
     if (nseg <= 1) nseg = 0;
     if (nseg == e->xchg_segments && (nseg == 0 || e->xchg_capacity >= e->capacity)) return ADE_OK;
+    // a call that needs NO slots (or fewer segments) keeps a larger area that is already there: ade_process's retry flips the geometry to 0 and back, and freeing /
+    // re-allocating 135 MB with two device synchronisations per retried call is exactly what a pre-empted GPU does not need.  The flags are zero between launches.
+    if (e->d_xchg && nseg <= e->xchg_segments && e->xchg_capacity >= e->capacity) return ADE_OK;
     if (e->stream) HIP_TRY(e, hipStreamSynchronize(e->stream));
     free_graphs(e);
     free_exchange(e);
@@ -1347,6 +1369,12 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         free_graphs(h);
         return ADE_OK;
     }
+    if (strcmp(key, "pipe_depth") == 0) {      // submissions ade_submit keeps in flight (2 .. 4); takes effect while nothing is in flight
+        if (value[0] < '2' || value[0] > '4' || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option pipe_depth: 2..4");
+        for (const auto& sl : h->pipe) if (sl.state == 1) return fail(h, ADE_ERR_BAD_VALUE, "option pipe_depth: submissions are in flight (ade_wait them first)");
+        h->pipe_depth = value[0] - '0';
+        return ADE_OK;
+    }
     if (strcmp(key, "xwait_retry") == 0) {     // "1" (default): ade_process re-runs a timed-out call once without hand-offs; "0": it fails
         if ((value[0] != '0' && value[0] != '1') || value[1]) return fail(h, ADE_ERR_BAD_VALUE, "option xwait_retry: 0 or 1");
         h->xwait_retry = value[0] - '0';
@@ -1581,6 +1609,10 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
 // frames -- and reports success; ade_last_error then says that a retry happened.  Option "xwait_retry" = "0" turns this off; the test hook that withholds a flag does too.
 ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32) {
     if (!h) return ADE_ERR_BAD_VALUE;
+    // An EARLIER call's failure (an unsynchronised ade_process_device launch on a caller-provided stream that timed out: include/ade.h says the next call on the handle
+    // reports it) is checked HERE and surfaces as ADE_ERR_DEVICE -- that call's output was garbage and nothing this call does can repair it.  Only a time-out of THIS call's
+    // own launch (found by process_once after its synchronise) is re-run below.
+    if (hipSetDevice(h->device) == hipSuccess) { const ade_status xs = exchange_status(h, "ade_process", true); if (xs != ADE_OK) return xs; }
     h->timed_out = false;
     ade_status st = process_once(h, in, batch, out_pcm, out_f32);
     if (st == ADE_ERR_DEVICE && h->timed_out && h->xwait_retry && !h->xchg_withhold && !h->sub) {
@@ -1653,6 +1685,22 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
         }
         if (plain && n_grp > 1 && rows >= 2 * n_grp && big && h->sio_state == 1) {
             const int used = (rows + per - 1) / per;
+            // A HIP call that fails once the launch is out must not return with the kernel still polling for rows that will never arrive and copies in flight: drain the
+            // three streams (the waiting workgroups give up after their own bound), clear the time-out word and the flags, THEN report the original error.
+            bool launched = false;
+#define SIO_TRY(expr)                                                                                                        \
+            do {                                                                                                             \
+                hipError_t _err = (expr);                                                                                    \
+                if (_err != hipSuccess) {                                                                                    \
+                    const std::string _what = std::string(#expr) + ": " + hipGetErrorString(_err);                           \
+                    if (launched) {                                                                                          \
+                        (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_in); (void)hipStreamSynchronize(h->s_out); \
+                        (void)exchange_status(h, "ade_process", false);                                                      \
+                        (void)hipGetLastError();                                                                             \
+                    }                                                                                                        \
+                    return fail(h, ADE_ERR_DEVICE, _what);                                                                   \
+                }                                                                                                            \
+            } while (0)
             const unsigned epoch = ++h->sio_epoch ? h->sio_epoch : ++h->sio_epoch;            // (never 0: the words start at 0)
             h->last_batch = rows;
             h->last_fused = true;
@@ -1663,8 +1711,8 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
                 const size_t i0 = (size_t)r0 * h->in_len;
                 const int16_t* src = in + i0;
                 if (!in_direct) { memcpy(h->h_pcm_in + i0, in + i0, (size_t)nr * h->in_len * sizeof(int16_t)); src = h->h_pcm_in + i0; }
-                HIP_TRY(h, hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
-                HIP_TRY(h, hipMemcpyAsync(h->d_sio_ready + (size_t)g * kReadyStride, h->h_sio_epoch, (size_t)kReadyStride * sizeof(unsigned), hipMemcpyHostToDevice, h->s_in));
+                SIO_TRY(hipMemcpyAsync(h->d_pcm_in + i0, src, (size_t)nr * h->in_len * sizeof(int16_t), hipMemcpyHostToDevice, h->s_in));
+                SIO_TRY(hipMemcpyAsync(h->d_sio_ready + (size_t)g * kReadyStride, h->h_sio_epoch, (size_t)kReadyStride * sizeof(unsigned), hipMemcpyHostToDevice, h->s_in));
                 if (g == 0) {       // the launch goes out behind the FIRST group's copies (enqueued, not complete): enqueueing the other groups' copies -- ~25 us of API time
                                     // each -- runs under the first copy; launching only after all of them measured 0.735 ms per call against 0.635.  A later group's
                                     // workgroups therefore also wait out this thread's progress through the loop: their bound (option "xwait_ms", 200 ms) is four orders
@@ -1678,7 +1726,8 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
                     C.full_taps = h->full_taps;
                     C.in_ready = h->d_sio_ready; C.out_done = h->h_sio_done; C.out_count = h->d_sio_count; C.epoch = epoch; C.group_rows = per;
                     launch_gtcrn_chunk(h->stream, geo, C);
-                    HIP_TRY(h, hipGetLastError());
+                    launched = true;
+                    SIO_TRY(hipGetLastError());
                 }
             }
             // copy-outs: started by this thread as the groups finish (a word per group in page-locked memory, written by the group's last workgroup)
@@ -1689,9 +1738,10 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
                 const size_t o0 = (size_t)r0 * h->out_len;
                 for (unsigned spins = 0; done[g] != epoch && !finished; ++spins)
                     if ((spins & 0x3ffu) == 0x3ffu && hipStreamQuery(h->stream) == hipSuccess) finished = true;
-                if (out_pcm) HIP_TRY(h, hipMemcpyAsync((pcm_direct ? out_pcm : h->h_pcm_out) + o0, h->d_pcm_out + o0, (size_t)nr * h->out_len * sizeof(int16_t), hipMemcpyDeviceToHost, h->s_out));
-                if (out_f32) HIP_TRY(h, hipMemcpyAsync((f32_direct ? out_f32 : h->h_f32_out) + o0, h->d_f32_out + o0, (size_t)nr * h->out_len * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
+                if (out_pcm) SIO_TRY(hipMemcpyAsync((pcm_direct ? out_pcm : h->h_pcm_out) + o0, h->d_pcm_out + o0, (size_t)nr * h->out_len * sizeof(int16_t), hipMemcpyDeviceToHost, h->s_out));
+                if (out_f32) SIO_TRY(hipMemcpyAsync((f32_direct ? out_f32 : h->h_f32_out) + o0, h->d_f32_out + o0, (size_t)nr * h->out_len * sizeof(float), hipMemcpyDeviceToHost, h->s_out));
             }
+#undef SIO_TRY
             (void)hipGetLastError();
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->s_out));
@@ -1776,6 +1826,131 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
     if (out_pcm && !pcm_direct) memcpy(out_pcm, h->h_pcm_out, nout * sizeof(int16_t));
     if (out_f32 && !f32_direct) memcpy(out_f32, h->h_f32_out, nout * sizeof(float));
     return ADE_OK;
+}
+
+// ---- the pipelined host entry (include/ade.h: ade_submit / ade_wait) -----------------------------------------------------------------------------------------------------
+// The reference's driver times a LOOP of session runs over the slices of a file (Inference_GTCRN_ONNX.py:314-333); ade_process is one such run and pays copy-in + kernels +
+// copy-out in sequence.  A submission is the same call cut into its three legs on three streams, tied by events: s_pin [H2D -> ev_in], stream [wait ev_in -> kernels -> ev_k],
+// s_pout [wait ev_k -> D2H -> ev_out].  With two or more submissions in flight the copy engines move call k + 1 in and call k - 1 out under call k's kernels; the kernels of
+// consecutive calls are serialised on `stream`, so the workspace and the exchange area are shared exactly as between two ade_process calls.  Each slot of the ring owns its
+// device PCM buffers (a call's input must survive until its kernels ran, its output until it was copied out).
+namespace {
+void pipe_free(ade_engine* e) {
+    for (auto& sl : e->pipe) {
+        if (sl.d_in) hipFree(sl.d_in);
+        if (sl.d_out) hipFree(sl.d_out);
+        if (sl.d_f32) hipFree(sl.d_f32);
+        if (sl.h_in) hipHostFree(sl.h_in);
+        if (sl.h_out) hipHostFree(sl.h_out);
+        if (sl.h_f32) hipHostFree(sl.h_f32);
+        sl.d_in = sl.d_out = sl.h_in = sl.h_out = nullptr; sl.d_f32 = sl.h_f32 = nullptr;
+    }
+    e->pipe_capacity = 0;
+}
+// Finish a slot in flight: wait for its copy-out, check the launch's time-out word, hand a pageable caller its bytes.  The status is kept for ade_wait.
+void pipe_finish(ade_engine* h, ade_engine::PipeSlot& sl) {
+    if (sl.state != 1) return;
+    ade_status st = ADE_OK;
+    const hipError_t e = hipEventSynchronize(sl.ev_out);
+    if (e != hipSuccess) st = fail(h, ADE_ERR_DEVICE, std::string("ade_wait: hipEventSynchronize: ") + hipGetErrorString(e));
+    if (st == ADE_OK) st = exchange_status(h, "ade_wait", false);
+    const size_t nout = (size_t)sl.rows * h->out_len;
+    if (st == ADE_OK) {
+        if (sl.out_pcm) memcpy(sl.out_pcm, sl.h_out, nout * sizeof(int16_t));
+        if (sl.out_f32) memcpy(sl.out_f32, sl.h_f32, nout * sizeof(float));
+    } else {
+        // a time-out drained the device and lowered every flag (exchange_status): the other submissions in flight ran on a disturbed exchange area -- they fail with it
+        for (auto& o : h->pipe)
+            if (&o != &sl && o.state == 1) { (void)hipEventSynchronize(o.ev_out); o.state = 2; o.status = st; o.error = h->last_error + " (a submission in flight beside the one that failed)"; }
+    }
+    sl.state = 2;
+    sl.status = st;
+    sl.error = st == ADE_OK ? std::string() : h->last_error;
+}
+}  // namespace
+
+ade_status ade_submit(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32, uint64_t* ticket) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    if (!ticket || batch <= 0 || !in || (!out_pcm && !out_f32)) return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: bad arguments");
+    if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: this handle's input_audio_dtype is F32 / F16 (use ade_process_f32)");
+    if (h->profile) return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: not while ade_profile_last is on");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int rows = batch * h->n_win;
+    bool busy = false;
+    for (const auto& sl : h->pipe) busy = busy || sl.state == 1;
+    if (rows > h->capacity || rows > h->pipe_capacity) {      // growing: nothing may be in flight while buffers are re-allocated
+        for (auto& sl : h->pipe) pipe_finish(h, sl);
+        busy = false;
+    }
+    if (!busy) { const ade_status xs = exchange_status(h, "ade_submit", true); if (xs != ADE_OK) return xs; }     // (an earlier device-pointer call's failure)
+    ade_status st = reserve(h, rows);
+    if (st != ADE_OK) return st;
+    if (!h->s_pin) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_pin, hipStreamNonBlocking));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->s_pout, hipStreamNonBlocking));
+        for (auto& sl : h->pipe) {
+            HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_k, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+        }
+    }
+    if (rows > h->pipe_capacity) {
+        pipe_free(h);
+        const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
+        for (auto& sl : h->pipe) {
+            HIP_TRY(h, hipMalloc((void**)&sl.d_in, nin * sizeof(int16_t)));
+            HIP_TRY(h, hipMalloc((void**)&sl.d_out, nout * sizeof(int16_t)));
+            HIP_TRY(h, hipMalloc((void**)&sl.d_f32, nout * sizeof(float)));
+            HIP_TRY(h, hipHostMalloc((void**)&sl.h_in, nin * sizeof(int16_t), hipHostMallocDefault));
+            HIP_TRY(h, hipHostMalloc((void**)&sl.h_out, nout * sizeof(int16_t), hipHostMallocDefault));
+            HIP_TRY(h, hipHostMalloc((void**)&sl.h_f32, nout * sizeof(float), hipHostMallocDefault));
+        }
+        h->pipe_capacity = rows;
+    }
+    const unsigned long long t = h->pipe_next;
+    ade_engine::PipeSlot& sl = h->pipe[t % (unsigned long long)h->pipe_depth];
+    if (sl.state == 1) pipe_finish(h, sl);       // the ring is full: its oldest submission is completed first (its status still waits for ade_wait)
+    if (sl.state == 2) return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: ticket " + std::to_string(sl.ticket) + " has not been waited for (at most pipe_depth submissions between waits)");
+    auto page_locked = [](const void* p) {
+        hipPointerAttribute_t a;
+        if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool in_direct = page_locked(in), pcm_direct = page_locked(out_pcm), f32_direct = page_locked(out_f32);
+    const size_t nin = (size_t)rows * h->in_len, nout = (size_t)rows * h->out_len;
+    const int16_t* src = in;
+    if (!in_direct) { memcpy(sl.h_in, in, nin * sizeof(int16_t)); src = sl.h_in; }
+    HIP_TRY(h, hipMemcpyAsync(sl.d_in, src, nin * sizeof(int16_t), hipMemcpyHostToDevice, h->s_pin));
+    HIP_TRY(h, hipEventRecord(sl.ev_in, h->s_pin));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
+    st = run(h, h->stream, sl.d_in, rows, out_pcm ? sl.d_out : nullptr, out_f32 ? sl.d_f32 : nullptr);
+    if (st != ADE_OK) { (void)hipStreamSynchronize(h->s_pin); (void)hipStreamSynchronize(h->stream); return st; }
+    HIP_TRY(h, hipEventRecord(sl.ev_k, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->s_pout, sl.ev_k, 0));
+    if (out_pcm) HIP_TRY(h, hipMemcpyAsync(pcm_direct ? out_pcm : sl.h_out, sl.d_out, nout * sizeof(int16_t), hipMemcpyDeviceToHost, h->s_pout));
+    if (out_f32) HIP_TRY(h, hipMemcpyAsync(f32_direct ? out_f32 : sl.h_f32, sl.d_f32, nout * sizeof(float), hipMemcpyDeviceToHost, h->s_pout));
+    HIP_TRY(h, hipEventRecord(sl.ev_out, h->s_pout));
+    sl.ticket = t; sl.state = 1; sl.rows = rows;
+    sl.out_pcm = (out_pcm && !pcm_direct) ? out_pcm : nullptr;
+    sl.out_f32 = (out_f32 && !f32_direct) ? out_f32 : nullptr;
+    sl.status = ADE_OK; sl.error.clear();
+    h->pipe_next = t + 1;
+    *ticket = (uint64_t)t;
+    return ADE_OK;
+}
+
+ade_status ade_wait(ade_handle h, uint64_t ticket) {
+    if (!h) return ADE_ERR_BAD_VALUE;
+    for (auto& sl : h->pipe) {
+        if (sl.state == 0 || sl.ticket != (unsigned long long)ticket) continue;
+        HIP_TRY(h, hipSetDevice(h->device));
+        pipe_finish(h, sl);
+        const ade_status st = (ade_status)sl.status;
+        if (st != ADE_OK) h->last_error = sl.error;
+        sl.state = 0;
+        return st;
+    }
+    return fail(h, ADE_ERR_BAD_VALUE, "ade_wait: unknown ticket " + std::to_string((unsigned long long)ticket) + " (never issued, or already waited for)");
 }
 
 ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t count, size_t* written) {
@@ -1907,6 +2082,15 @@ void ade_destroy(ade_handle h) {
         hipStreamSynchronize(h->stream);
     }
     ade_orphan_streams(h);
+    for (auto& sl : h->pipe) {
+        if (sl.state == 1 && sl.ev_out) hipEventSynchronize(sl.ev_out);
+        if (sl.ev_in) hipEventDestroy(sl.ev_in);
+        if (sl.ev_k) hipEventDestroy(sl.ev_k);
+        if (sl.ev_out) hipEventDestroy(sl.ev_out);
+    }
+    pipe_free(h);
+    if (h->s_pin) hipStreamDestroy(h->s_pin);
+    if (h->s_pout) hipStreamDestroy(h->s_pout);
     free_workspace(h);
     delete h->sub;
     for (auto& ev : h->events) {

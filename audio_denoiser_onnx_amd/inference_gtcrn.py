@@ -140,6 +140,28 @@ def cut_slices(audio: np.ndarray, in_len: int, out_len: int, tail_pad: str = "ze
     return padded[idx], stride
 
 
+PIPELINE_BATCH = 256      # rows per submission of a file that is larger than one batch (BASELINE's batch: one 1 s chunk per CU)
+
+
+def process_rows(session, rows: np.ndarray, batch: int = PIPELINE_BATCH) -> np.ndarray:
+    """All slices of a file through the engine.  Up to ``batch`` rows: ONE ``process`` call.  More: the reference's loop over its slices
+    (Inference_GTCRN_ONNX.py:314-333) as a pipeline of ``batch``-row submissions (``ade_submit`` / ``ade_wait``, two in flight): the copy-in of
+    batch k + 1 and the copy-out of batch k - 1 run under the kernels of batch k.  Same bits either way (rows are independent calls)."""
+    n = len(rows)
+    if n <= batch or not hasattr(session, "submit"):
+        return session.process(rows)[0]
+    rows = np.ascontiguousarray(rows, dtype=np.int16)
+    out = np.empty((n, session.row_out), np.int16)
+    tickets = []
+    for i in range(0, n, batch):
+        if len(tickets) >= 2:
+            session.wait(tickets.pop(0))
+        tickets.append(session.submit(rows[i:i + batch], out[i:i + batch]))
+    for t in tickets:
+        session.wait(t)
+    return out
+
+
 def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = False, rank: int = 0, world: int = 1,
             group=None, tail_pad: str = "zeros", rng=None, family: str = "gtcrn") -> np.ndarray:
     """int16 mono waveform in -> int16 denoised waveform out: the input's duration at the OUTPUT sample rate.
@@ -174,7 +196,7 @@ def denoise(session: InferenceSession, audio: np.ndarray, sequential: bool = Fal
         outs = [session.run(None, {"noisy_audio": s.reshape(1, 1, -1)})[0].reshape(1, -1) for s in mine]
         local = np.concatenate(outs, axis=0) if outs else np.zeros((0, session.out_len), np.int16)
     else:
-        local, _ = session.process(mine)
+        local = process_rows(session, mine)
     full = stitch_rows(local, len(slices), world, rank, group) if world > 1 else local
     return np.ascontiguousarray(full[:, :keep]).reshape(-1)[:audio_len]            # np.concatenate(saved).reshape(-1)[:audio_len]  (:332)
 

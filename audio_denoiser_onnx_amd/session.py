@@ -60,6 +60,7 @@ class InferenceSession:
         ``weights`` + ``metadata`` directly.  ``library`` defaults to the in-tree gfx950 build."""
         self._lib = library or _lib.get_library()
         self._h = C.c_void_p()
+        self._in_flight = {}            # ticket -> (pcm, out, f32): the buffers of submissions that have not been waited for
         if model_path is not None:
             model_path = resolve_model_path(model_path)
             reader = load_runtime_metadata(model_path)          # FileNotFoundError / KeyError like the reference
@@ -195,6 +196,28 @@ class InferenceSession:
             raise ValueError("f32 must be float32 with the shape of out")
         st = self._lib.c.ade_process(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if f32 is not None else None)
         self._lib.check(st, self._h)
+
+    # -- the pipelined form (ade_submit / ade_wait): a file of many batches overlaps copy-in (k + 1), kernels (k) and copy-out (k - 1) -------------------------------
+    def submit(self, pcm: np.ndarray, out: np.ndarray, f32: Optional[np.ndarray] = None) -> int:
+        """Enqueue one ``process_into`` call without waiting; returns the ticket ``wait`` takes.  The three buffers must stay alive and untouched until that
+        ``wait`` -- this object keeps references to them meanwhile.  At most ``pipe_depth`` (option, default 2) tickets between waits."""
+        B = pcm.shape[0]
+        if pcm.dtype != np.int16 or out.dtype != np.int16 or pcm.shape != (B, self.row_in) or out.shape != (B, self.row_out):
+            raise ValueError(f"expected int16 (B, {self.row_in}) -> int16 (B, {self.row_out})")
+        if not pcm.flags.c_contiguous or not out.flags.c_contiguous or (f32 is not None and (not f32.flags.c_contiguous or f32.dtype != np.float32 or f32.shape != out.shape)):
+            raise ValueError("buffers must be C-contiguous (f32: float32 with the shape of out)")
+        t = C.c_uint64(0)
+        st = self._lib.c.ade_submit(self._h, pcm.ctypes.data, B, out.ctypes.data, f32.ctypes.data if f32 is not None else None, C.byref(t))
+        self._lib.check(st, self._h)
+        self._in_flight[int(t.value)] = (pcm, out, f32)
+        return int(t.value)
+
+    def wait(self, ticket: int):
+        """Block until the submission is complete; returns its (out, f32) buffers.  Raises what ``process`` would have raised for that call."""
+        st = self._lib.c.ade_wait(self._h, C.c_uint64(int(ticket)))
+        bufs = self._in_flight.pop(int(ticket), None)
+        self._lib.check(st, self._h)
+        return (bufs[1], bufs[2]) if bufs else (None, None)
 
     def run_device(self, d_in, d_out, d_f32=None, stream: Optional[int] = None) -> None:
         """``d_in`` int16 (B, L) / ``d_out`` int16 (B, L_out) CUDA(HIP) tensors; enqueues on ``stream`` (a raw

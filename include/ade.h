@@ -82,6 +82,17 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
 ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int16_t* d_out_pcm, float* d_out_f32,
                               void* hip_stream);
 
+/* The same call PIPELINED: what the reference's driver does around its session is a LOOP of runs over the slices of a file (Inference_GTCRN_ONNX.py:314-333,
+ * timed as a whole, :323-343).  ade_submit enqueues one ade_process call -- copy-in, kernels, copy-out on three streams tied by events -- and returns a ticket
+ * without waiting; ade_wait(ticket) blocks until that call's output is in the caller's buffers and returns ITS status (a time-out of its launch included).
+ * Up to `pipe_depth` (option, 2..4, default 2) submissions are in flight: the copy engines move call k + 1 in and call k - 1 out under call k's kernels, so a
+ * file of many batches runs at max(kernel, copies) per batch instead of their sum.  Rules: `in`, `out_pcm`, `out_f32` stay the caller's and must stay valid and
+ * untouched from ade_submit until ade_wait of the same ticket (page-locked buffers are DMA'd directly, pageable ones go through the slot's page-locked staging);
+ * tickets may be waited for in any order, each exactly once; submitting into a full ring completes its oldest submission first (its status still waits for
+ * ade_wait).  Results are bit-identical to ade_process on the same rows.  int16 handles of every model family (float-input manifests: ade_process_f32). */
+ade_status ade_submit(ade_handle h, const int16_t* in, int batch, int16_t* out_pcm, float* out_f32, uint64_t* ticket);
+ade_status ade_wait(ade_handle h, uint64_t ticket);
+
 /* fp32 audio IN (manifest input_audio_dtype "F32" or "F16": normalised samples, no 2^-15 scale -- GTCRN/Export_GTCRN.py:645-646; an F16 tensor crosses this ABI as
  * fp32, the graph computes in fp32 either way).  Every family: the sub-engine families run such handles through their resampling-edge kernels with the family's input gain
  * (each export script's own IN_AUDIO_DTYPE branch).  The outputs are the same pair as above: out_f32 is the export's F32 / F16 output

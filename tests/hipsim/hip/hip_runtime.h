@@ -243,7 +243,7 @@ typedef struct hipsimGraph* hipGraph_t;
 typedef struct hipsimGraphExec* hipGraphExec_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0, hipEventDisableTiming = 2 };
 
 struct hipDeviceProp_t {
     char name[256];

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/hwid_probe.hip -o /tmp/hwid_probe && /tmp/hwid_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <vector>
 __global__ __launch_bounds__(256, 4) void k(unsigned* out) {
@@ -20,8 +21,8 @@ __global__ __launch_bounds__(256, 4) void k(unsigned* out) {
     }
     if (lds[255 - threadIdx.x] == 0.0f) out[0] = 0;
 }
-int main() {
-    const int B = 1024;
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1024;      // grid size: 4 = the four segment workgroups of ONE chunk (tools/phase_latency.py 1)
     unsigned* d;
     hipMalloc(&d, B * 4 * 2 * sizeof(unsigned));
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
