@@ -1113,14 +1113,14 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
             else if (e->meta["ade_dft_tables"] != "reference") return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_dft_tables must be 'reference' or 'exact'"));
         }
         // ade_gemm_dtype: "f32" (default: exact fp32 matrix-core products, the parity path)
-        //               | "bf16" (mel_band_roformer: bf16 activations and weights STORED in HBM, gfx950's full-rate bf16 matrix instructions -- csrc/ade_gemm16.h).
+        //               | "bf16" (mel_band_roformer, zipenhancer: bf16 activations and weights STORED in HBM, gfx950's full-rate bf16 matrix instructions -- csrc/ade_gemm16.h, ade_zip16.h).
         // (Rounds 2 - 3 had a "bf16" MODE for the other transformer families -- fp32 operands in HBM rounded on their way into LDS, the half-rate 16x16x16 instruction:
         //  1.5 - 1.8 x at 28 - 34 dB.  It was a rounding mode of the fp32 kernels, not a bf16 data path, and was removed in round 4 when the real path went in.)
         bool gemm_bf16 = false;
         if (e->meta.count("ade_gemm_dtype") && !e->meta["ade_gemm_dtype"].empty()) {
             const std::string& dt = e->meta["ade_gemm_dtype"];
             if (dt == "bf16") {
-                if (!fam_melband) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 (bf16 stored in HBM) is implemented for mel_band_roformer; the other families run f32"));
+                if (!fam_melband && !fam_zip) return bail(fail(e, ADE_ERR_UNSUPPORTED, "ade_gemm_dtype = bf16 (bf16 stored in HBM) is implemented for mel_band_roformer and zipenhancer; the other families run f32"));
                 gemm_bf16 = true;
             } else if (dt != "f32") {
                 return bail(fail(e, ADE_ERR_BAD_VALUE, "manifest: ade_gemm_dtype must be 'f32' or 'bf16'"));
@@ -1130,7 +1130,7 @@ ade_status ade_create(const char* manifest_json, const void* weights, size_t wei
                        : fam_melband ? ade::melband_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                        : fam_ulu     ? ade::ulunas_create(e->tensors, (int)Ld, (int)sub_win, dyn_d ? (int)caller_len : 0, device, &e->sub, derr)
                        : fam_hg      ? ade::hgtcrn_create(e->tensors, (int)Ld, (int)sub_win, dyn_d, device, &e->sub, derr)
-                       : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, dyn_d, device, &e->sub, derr)
+                       : fam_zip     ? ade::zipenhancer_create(e->tensors, (int)Ld, (int)sub_win, exact_dft, gemm_bf16, dyn_d, device, &e->sub, derr)
                                      : ade::mossformer_create(e->tensors, (int)Ld, (int)sub_win, dyn_d, device, &e->sub, derr);
         if (rc != ADE_OK) return bail(fail(e, (ade_status)rc, derr));
         e->channels = e->sub->channels();

@@ -277,7 +277,7 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int window_len, 
 // model_family "h_gtcrn" (H-GTCRN/Export_H_GTCRN.py:428-1063), csrc/ade_hgtcrn.hip
 int hgtcrn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool dynamic, int device, SubEngine** out, std::string& err);
 // model_family "zipenhancer" (ZipEnhancer/Export_ZipEnhancer.py:357-927), csrc/ade_zipenhancer.hip
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool dynamic /* DYNAMIC_AXES export: divide by the overlap-add denominator */, int device, SubEngine** out, std::string& err);
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16 /* ade_gemm_dtype = bf16: csrc/ade_zip16.h */, bool dynamic /* DYNAMIC_AXES export: divide by the overlap-add denominator */, int device, SubEngine** out, std::string& err);
 int melband_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err);
 
 }  // namespace ade

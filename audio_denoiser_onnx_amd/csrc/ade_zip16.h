@@ -1,0 +1,318 @@
+// ade_zip16.h — ZipEnhancer's bf16 path (BASELINE.json configs[2]: "bf16 dual-path transformer ... (MFMA attention)"): bf16 activations and weights STORED in HBM for the
+// causal dense blocks, the feed-forward modules, the K = 64 projections and the attention / convolution-module operands; fp32 exactly where the reference's own
+// reduced-precision plan keeps it (ZipEnhancer/Optimize_ONNX.py:25-64: the RMS front, the magnitude compression, the InstanceNorm statistics, the PCM tail) plus every
+// accumulator, the softmax statistics and the residual stream.  All products run on gfx950's full-rate v_mfma_f32_32x32x16_bf16 (csrc/ade_gemm16.h has the operand maps:
+// lane l supplies row (l & 31), k = 8 (l >> 5) .. + 7 of a 16-deep step; D[i][j] sits in lane (j = l & 31, h = l >> 5), register r = row i = (r & 3) + 8 (r >> 2) + 4 h).
+//
+// Kernels (each cites the reference lines of the f32 kernel it mirrors in ade_zipenhancer.hip):
+//   k_zip_dense16     one layer of a causal dense block as a token-tiled implicit GEMM, 256 tokens x 64 channels per workgroup, the three frequency taps of a time tap share
+//                     one staged operand; tiles never straddle a window, so the epilogue also emits the layer's InstanceNorm partial sums (the f32 path's separate
+//                     statistics pass over the output is gone)
+//   k_zip_hist_norm16 raw fp32 layer output -> InstanceNorm + PReLU -> the bf16 dense history
+//   k_zip_ff16        a whole feed-forward module (64 -> fd SwooshL -> 64 + residual form): the hidden tile feeds the second product from the accumulator registers
+//   k_rows16          the K <= 192 products around the attention / convolution modules: rows straight from global memory into the matrix cores' registers (fp32 rows are
+//                     rounded on the way), weights staged once, full-line stores through LDS
+#pragma once
+#include "ade_gemm16.h"
+
+namespace ade {
+namespace zip16 {
+
+using namespace dev;
+using gemm16::bf16_t;
+using gemm16::ld8_or_zero;
+using gemm16::mfma32x32x16;
+using gemm16::pack_bf16x2;
+using gemm16::v16f;
+using gemm16::zero_unless;
+
+__device__ __forceinline__ float softplus16(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
+__device__ __forceinline__ float swoosh_l16(float x) { return softplus16(x - 4.0f) - 0.08f * x; }       // (Export_ZipEnhancer.py:135-136)
+__device__ __forceinline__ float swoosh_r16(float x) { return softplus16(x - 1.0f) - 0.08f * x; }       // (:138)
+
+__device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) { return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)); }
+__device__ __forceinline__ void unpack8(const uint4& u, float* v) {
+    v[0] = gemm16::bf16_lo(u.x); v[1] = gemm16::bf16_hi(u.x); v[2] = gemm16::bf16_lo(u.y); v[3] = gemm16::bf16_hi(u.y);
+    v[4] = gemm16::bf16_lo(u.z); v[5] = gemm16::bf16_hi(u.z); v[6] = gemm16::bf16_lo(u.w); v[7] = gemm16::bf16_hi(u.w);
+}
+
+// ---- one layer of a causal dense block (Export_ZipEnhancer.py:701-757), bf16 operands -------------------------------------------------------------------------------
+// A(token, k): k = (kt, channel block, kf, channel); the value is input channel ci of position (t - (1 - kt) dil, f + kf - 1), zero outside the map.  Input channels are
+// [this group's newer dense outputs (hist, normalised + PReLU'd bf16) ..., block input (inp, bf16 [tokens][64])].  w: [64 co][6 taps][cin] bf16.
+// A stage = (time tap kt, 32 input channels): rows m_blk - 1 .. m_blk + 256 of that channel block are staged ONCE (64 bytes per row at an 80-byte pitch: the 16 lanes of a
+// ds_read_b128 service group land on 16 distinct 4-bank sets) and the three kf products read it shifted by one row; neighbours outside the map are zeroed in the operand
+// register.  Grid: (blocks per window) x windows through the XCD-contiguous map; a tile's rows all belong to ONE window, so the per-channel sum and sum of squares of
+// (product + bias) over the tile's rows are that window's InstanceNorm partial sums: partial[((win * nblk + blk) * 64 + c) * 2 + {sum, sumsq}] (fp64, k_zip_stats_final's
+// layout).  raw: [tokens][64] fp32 (product + bias).
+constexpr int kDPitch = 80, kDARows = 258;
+__global__ __launch_bounds__(256, 3) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
+                                                        int F, int dil, const bf16_t* __restrict__ w, const float* __restrict__ bias, float* __restrict__ raw,
+                                                        double* __restrict__ partial, int nblk) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[kDARows * kDPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * 64 * kDPitch];
+    __shared__ float red[4][64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, l31 = lane & 31, h = lane >> 5;
+    const int id = gemm16::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x), win = id / nblk, blk = id - win * nblk;
+    const int TF = T * F, m_blk = blk * 256;
+    const size_t wbase = (size_t)win * TF;
+    const bf16_t* const hist_w = hist + wbase * hist_ld + hist_off;
+    const bf16_t* const inp_w = inp + wbase * 64;
+    // staged rows of this lane: r = (tid >> 2) + 64 hh, hh < 4, and for tid < 8 the two halo rows 256, 257; token (inside the window) = m_blk - 1 + r
+    const int sr = tid >> 2, pc = tid & 3;
+    int stok[5];
+    bool sok0[5], sok1[5];
+#pragma unroll
+    for (int hh = 0; hh < 5; ++hh) {
+        const int r = hh < 4 ? sr + 64 * hh : 256 + sr;
+        const int m = m_blk - 1 + r;
+        const bool in = m >= 0 && m < TF && (hh < 4 || tid < 8);
+        const int mc = in ? m : 0, t = mc / F;
+        stok[hh] = mc;
+        sok1[hh] = in;                               // kt = 1: the row itself
+        sok0[hh] = in && t >= dil;                   // kt = 0: the row dil frames earlier, inside the window
+    }
+    unsigned left = 0, right = 0;                    // bit i: row wm + 32 i + l31 has a left (kf = 0) / right (kf = 2) neighbour
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m_blk + wm + 32 * i + l31, f = m % F;
+        if (f != 0) left |= 1u << i;
+        if (f != F - 1) right |= 1u << i;
+    }
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int ncb = cin / 32, nstage = 2 * ncb;
+    uint4 ra[5], rb[3];
+    auto fetch = [&](int st) {
+        const int kt = st / ncb, ci0 = (st - kt * ncb) * 32;
+        const bool from_hist = ci0 < hist_n;
+        const bf16_t* src = from_hist ? hist_w + ci0 + 8 * pc : inp_w + (ci0 - hist_n) + 8 * pc;
+        const int ld = from_hist ? hist_ld : 64, shift = kt ? 0 : dil * F;
+#pragma unroll
+        for (int hh = 0; hh < 5; ++hh) {
+            const bool ok = kt ? sok1[hh] : sok0[hh];
+            ra[hh] = ld8_or_zero(ok, src + (size_t)(stok[hh] - (ok ? shift : 0)) * ld);       // (zeros by address: the loads stay in flight across this stage's products)
+        }
+        const bf16_t* wp = w + (size_t)sr * (6 * cin) + (size_t)(kt * 3) * cin + ci0 + 8 * pc;
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) rb[kf] = *reinterpret_cast<const uint4*>(wp + (size_t)kf * cin);
+    };
+    fetch(0);
+    for (int st = 0; st < nstage; ++st) {
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) *reinterpret_cast<uint4*>(As + (sr + 64 * hh) * kDPitch + 16 * pc) = ra[hh];
+        if (tid < 8) *reinterpret_cast<uint4*>(As + (256 + sr) * kDPitch + 16 * pc) = ra[4];
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) *reinterpret_cast<uint4*>(Bs + (kf * 64 + sr) * kDPitch + 16 * pc) = rb[kf];
+        __syncthreads();
+        if (st + 1 < nstage) fetch(st + 1);
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) {
+            const unsigned mask = kf == 0 ? left : (kf == 2 ? right : 3u);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = zero_unless((mask >> i) & 1u, *reinterpret_cast<const uint4*>(As + (wm + 32 * i + l31 + kf) * kDPitch + 32 * ks + 16 * h));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + (kf * 64 + 32 * j + l31) * kDPitch + 32 * ks + 16 * h);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(fa[i], fb[j], acc[i][j]);      // D[token][channel]
+            }
+        }
+        __syncthreads();
+    }
+    // lane (channel 32 j + l31, h): register r of tile (i, j) is token wm + 32 i + (r & 3) + 8 (r >> 2) + 4 h -- a store instruction writes 32 consecutive channels of two tokens
+    float* const raw_w = raw + wbase * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = 32 * j + l31;
+        const float b = bias[co];
+        float s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_blk + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < TF) {
+                    const float v = acc[i][j][r] + b;
+                    raw_w[(size_t)m * 64 + co] = v;
+                    s += v;
+                    ss = fmaf(v, v, ss);
+                }
+            }
+        s += __shfl_xor(s, 32, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (h == 0) { red[wave][co][0] = s; red[wave][co][1] = ss; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid >> 1, q = tid & 1;
+        const double v = ((double)red[0][c][q] + (double)red[1][c][q]) + ((double)red[2][c][q] + (double)red[3][c][q]);
+        partial[(((size_t)win * nblk + blk) * 64 + c) * 2 + q] = v;
+    }
+}
+
+// raw fp32 layer output -> InstanceNorm + PReLU -> bf16 dense history [tokens][ld] at channels ch0 .. ch0 + 63; optionally the fp32 values too (out32, [tokens][64]: the last
+// layer's output while a consumer still reads fp32).  nrm: [(window * nrm_ld + channel) * 2 + {scale, shift}].  thread = (token, channel quad)
+__global__ __launch_bounds__(256) void k_zip_hist_norm16(const float* __restrict__ raw, bf16_t* __restrict__ hist, int ld, int ch0, const float* __restrict__ nrm, int nrm_ld,
+                                                         const float* __restrict__ slope, int tok_per_win, float* __restrict__ out32, long long total16) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total16) return;
+    const long long tok = i >> 4;
+    const int c = (int)(i & 15) * 4, ch = ch0 + c, b = (int)(tok / tok_per_win);
+    float4 v = *reinterpret_cast<const float4*>(raw + tok * 64 + c);
+    const float* k = nrm + ((size_t)b * nrm_ld + ch) * 2;
+    const float4 s0 = *reinterpret_cast<const float4*>(k), s1 = *reinterpret_cast<const float4*>(k + 4), sl = *reinterpret_cast<const float4*>(slope + ch);
+    v.x = prelu_f(v.x * s0.x + s0.y, sl.x);
+    v.y = prelu_f(v.y * s0.z + s0.w, sl.y);
+    v.z = prelu_f(v.z * s1.x + s1.y, sl.z);
+    v.w = prelu_f(v.w * s1.z + s1.w, sl.w);
+    *reinterpret_cast<uint2*>(hist + tok * ld + ch) = gemm16::pack_bf16x4(v);
+    if (out32) *reinterpret_cast<float4*>(out32 + tok * 64 + c) = v;
+}
+
+// fp32 [n] -> bf16 [n] (n % 4 == 0): the decoder pair's dense-block input is the last encoder's fp32 output
+__global__ __launch_bounds__(256) void k_zip_to_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    *reinterpret_cast<uint2*>(y + 4 * i) = gemm16::pack_bf16x4(*reinterpret_cast<const float4*>(x + 4 * i));
+}
+
+// ---- fused feed-forward module (:160, :170-174) on bf16 operands: out = epilogue(W2 swooshL(W1 x + b1) + b2) --------------------------------------------------------
+// A 256-thread workgroup owns 128 rows (32 per wavefront).  x is read ONCE, fp32, straight into the registers the matrix cores read (rounded to bf16 there); the weights stream
+// through LDS 64 hidden units at a time (W1 rows and W2 columns of the chunk, 144-byte pitch), double-buffered with one barrier per chunk.  Both products are formed
+// TRANSPOSED, so the hidden tile never changes lanes:
+//   H^T (32 hidden x 32 rows) = W1 (32 x 64) . X^T : lane (row j, h) ends with hidden units (r & 3) + 8 (r >> 2) + 4 h of ITS row in the sixteen accumulator registers;
+//   Y^T (32 out x 32 rows)   += W2 (32 x 16 hidden) . act(H^T): the B operand of a 16-deep step is the lane's OWN eight registers 8 s .. 8 s + 7 (bias + SwooshL applied, rounded
+//   to bf16) -- i.e. step s contracts over hidden 16 s + 8 (e >> 2) + 4 h + (e & 3), e < 8, and W2's columns are stored in that order (w2p: the host permutes every group of
+//   16 hidden units: position 8 h + e holds unit 8 (e >> 2) + 4 h + (e & 3)), so its A operand is one ds_read_b128.
+// The output tile goes through LDS (the weight buffers, dead by then) so that the residual reads and the stores are whole 256-byte rows.
+// MODE 0: out = res + ff   1: out = xin + ff   2: out = res + ((xin + ff) - res) * cmid      (as k_zip_ff)
+constexpr int kF16Pitch = 144, kF16Buf = 2 * 64 * kF16Pitch, kF16EPitch = 68;
+constexpr int kF16Lds = 2 * kF16Buf > 4 * 32 * kF16EPitch * 4 ? 2 * kF16Buf : 4 * 32 * kF16EPitch * 4;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+                                                  const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kF16Lds];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31;
+    uint4 xb[4];
+    {
+        const float* src = xin + (size_t)(row < M ? row : M - 1) * 64 + 8 * h;
+        float4 t[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { t[2 * ks] = *reinterpret_cast<const float4*>(src + 16 * ks); t[2 * ks + 1] = *reinterpret_cast<const float4*>(src + 16 * ks + 4); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xb[ks] = pack8(t[2 * ks], t[2 * ks + 1]);
+    }
+    v16f acc2[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[jt][r] = 0.0f;
+    // staging: chunk cg of W1 = rows 64 cg .. + 63 (128 bytes each), of W2p = columns 64 cg .. + 63 of its 64 rows: 512 16-byte pieces each, two + two per thread
+    const int sr = tid >> 3, sp = tid & 7;
+    uint4 p1[2], p2[2];
+    auto request = [&](int cg) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            p1[u] = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr + 32 * u) * 64 + 8 * sp);
+            p2[u] = *reinterpret_cast<const uint4*>(w2p + (size_t)(sr + 32 * u) * fd + 64 * cg + 8 * sp);
+        }
+    };
+    auto deposit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<uint4*>(buf + (sr + 32 * u) * kF16Pitch + 16 * sp) = p1[u];
+            *reinterpret_cast<uint4*>(buf + (64 + sr + 32 * u) * kF16Pitch + 16 * sp) = p2[u];
+        }
+    };
+    const int ncg = fd / 64;
+    request(0);
+    deposit(lds);
+    __syncthreads();
+    for (int cg = 0; cg < ncg; ++cg) {
+        const unsigned char* W1s = lds + (cg & 1) * kF16Buf;
+        const unsigned char* W2s = W1s + 64 * kF16Pitch;
+        if (cg + 1 < ncg) request(cg + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                                       // 32 hidden units at a time
+            v16f hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) hh = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), xb[ks], hh);
+            float4 bb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(b1 + 64 * cg + 32 * c + 8 * q + 4 * h);
+            uint4 hb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float a[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e;
+                    const float4 bq = bb[r >> 2];
+                    const float bv = (r & 3) == 0 ? bq.x : ((r & 3) == 1 ? bq.y : ((r & 3) == 2 ? bq.z : bq.w));
+                    a[e] = swoosh_l16(hh[r] + bv);
+                }
+                hb[s] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    acc2[jt] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * jt + l31) * kF16Pitch + 64 * c + 32 * s + 16 * h), hb[s], acc2[jt]);
+        }
+        if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * kF16Buf);          // the other buffer: last read in iteration cg - 1, behind that iteration's barrier
+        __syncthreads();
+    }
+    // lane (row l31, h): register r of tile jt is output channel 32 jt + (r & 3) + 8 (r >> 2) + 4 h -> through the wave's LDS tile -> whole rows
+    float* E = reinterpret_cast<float*>(lds) + wave * 32 * kF16EPitch;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(E + l31 * kF16EPitch + 32 * jt + 8 * q + 4 * h) = make_float4(acc2[jt][4 * q], acc2[jt][4 * q + 1], acc2[jt][4 * q + 2], acc2[jt][4 * q + 3]);
+    wave_sync();
+    const int c4 = (lane & 15) * 4;
+    const float4 bo = *reinterpret_cast<const float4*>(b2 + c4);
+    const float4 cv = MODE == 2 ? *reinterpret_cast<const float4*>(cmid + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xi[8], rv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = row0 + (lane >> 4) + 4 * u, mc = m < M ? m : M - 1;
+        xi[u] = MODE != 0 ? *reinterpret_cast<const float4*>(xin + (size_t)mc * 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rv[u] = MODE != 1 ? *reinterpret_cast<const float4*>(res + (size_t)mc * 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+        if (m >= M) continue;
+        const float4 a = *reinterpret_cast<const float4*>(E + rl * kF16EPitch + c4);
+        auto fin = [](float acc, float b, float x, float r, float c) -> float {
+            const float f = acc + b;
+            if (MODE == 0) return r + f;
+            if (MODE == 1) return x + f;
+            const float sum = x + f;
+            return r + (sum - r) * c;
+        };
+        *reinterpret_cast<float4*>(out + (size_t)m * 64 + c4) = make_float4(fin(a.x, bo.x, xi[u].x, rv[u].x, cv.x), fin(a.y, bo.y, xi[u].y, rv[u].y, cv.y),
+                                                                             fin(a.z, bo.z, xi[u].z, rv[u].z, cv.z), fin(a.w, bo.w, xi[u].w, rv[u].w, cv.w));
+    }
+}
+template <int MODE>
+inline void launch_zip_ff16(hipStream_t s, int M, const float* xin, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, const float* res, const float* cmid,
+                            float* out, int fd) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff16<MODE>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, xin, w1, b1, w2p, b2, res, cmid, out, M, fd);
+}
+
+}  // namespace zip16
+}  // namespace ade

@@ -30,6 +30,7 @@
 //     own error is part of what the network sees (as for Mel-Band-Roformer).
 // Geometry (channels, heads, kernel sizes) comes from the blob's `zip_config` (audio_denoiser_onnx_amd/zipenhancer.py).
 #include "ade_gemm64.h"
+#include "ade_zip16.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
 
@@ -164,6 +165,24 @@ __global__ __launch_bounds__(256) void k_zip_conv1_apply(const float2* __restric
         v[u] = prelu_f(k.x * mp.x + k.y * mp.y + k.z, slope[c + u]);
     }
     st4(e0 + tok * C + c, v);
+}
+
+// the same values rounded to bf16 (the bf16 path's dense-block input)
+__global__ __launch_bounds__(256) void k_zip_conv1_apply16(const float2* __restrict__ feat, const float4* __restrict__ coef, const float* __restrict__ slope,
+                                                           gemm16::bf16_t* __restrict__ e0, int TF, int C, long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int cq = C >> 2;
+    const long long tok = i / cq;
+    const int c = (int)(i - tok * cq) * 4, r = (int)(tok / TF);
+    const float2 mp = feat[tok];
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 k = coef[(size_t)r * C + c + u];
+        v[u] = prelu_f(k.x * mp.x + k.y * mp.y + k.z, slope[c + u]);
+    }
+    *reinterpret_cast<uint2*>(e0 + tok * C + c) = gemm16::pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
 }
 
 // ---- InstanceNorm statistics of a raw tensor: 64 channels at column ch0 of a [tokens][ld] matrix, per window ------------------------
@@ -996,7 +1015,12 @@ struct ZLayer {
     const float *ff_in_w[2], *ff_in_b[2], *ff_out_w[2], *ff_out_b[2];      // feed_forward2, feed_forward3
     const float *bypass_mid, *norm_bias, *fnorm, *fres;
 };
+struct ZLayer16 {              // bf16 copies of a layer's matrix weights (ade_gemm_dtype = bf16; csrc/ade_zip16.h)
+    const gemm16::bf16_t *ff1_w1, *ff1_w2p;                // the ff1 rows of attn_ff1_w, ff1_out_w with its hidden units in k_zip_ff16's order
+    const gemm16::bf16_t *ff_w1[2], *ff_w2p[2];            // feed_forward2, feed_forward3
+};
 struct ZDense {                // one causal dense block: per layer the repacked weights [co][tap][ci] (per group), bias, norm affine; slopes per hist channel
+    const gemm16::bf16_t* w16[2][8];                       // the same repacked weights in bf16 (bf16 path)
     const float* w[2][8];
     const float* b[2][8];
     const float* gamma[2][8];
@@ -1018,6 +1042,13 @@ struct ZipEngine : SubEngine {
     const float *c2_w = nullptr, *c2_b = nullptr, *c2_g = nullptr, *c2_beta = nullptr, *c2_slope = nullptr;
     ZDense enc_dense{}, dec_dense{};
     ZLayer layers[4][2]{};
+    // ade_gemm_dtype = bf16 (BASELINE.json configs[2]'s dtype): bf16 weights / activations stored in HBM for the dense blocks and the feed-forward modules (csrc/ade_zip16.h)
+    bool bf16 = false;
+    gemm16::bf16_t* d_w16 = nullptr;
+    ZLayer16 layers16[4][2]{};
+    gemm16::bf16_t* ws16 = nullptr;
+    gemm16::bf16_t *Dh16 = nullptr, *E016 = nullptr, *X16 = nullptr;     // dense history, dense-encoder input, the decoder pair's dense-block input
+    float *raw = nullptr, *Dlast = nullptr;                               // a dense layer's raw fp32 output (+ bias); the last layer's normalised output in fp32
     const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
     const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
     const float *mask_w = nullptr, *mask_b = nullptr, *phase_w = nullptr, *phase_b = nullptr;
@@ -1031,6 +1062,8 @@ struct ZipEngine : SubEngine {
     ~ZipEngine() override {
         (void)hipSetDevice(device);
         if (d_w) (void)hipFree(d_w);
+        if (d_w16) (void)hipFree(d_w16);
+        if (ws16) (void)hipFree(ws16);
         if (ws) (void)hipFree(ws);
         if (partial) (void)hipFree(partial);
     }
@@ -1044,12 +1077,13 @@ struct ZipEngine : SubEngine {
 
     void stats(hipStream_t s, const float* x, int ld, int ch0, int tok_per_win, int windows, const float* gamma, const float* beta, float* nrm_, int nrm_ld, int nrm_ch0);
     void dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd);
-    void layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo);
+    void dense_block16(hipStream_t s, const ZDense& d, int groups, const gemm16::bf16_t* inp, int windows, int Fd);
+    void layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo);
     void attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv);
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
 
-int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool dynamic, int device, SubEngine** out, std::string& err) {
+int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, bool exact_dft, bool bf16, bool dynamic, int device, SubEngine** out, std::string& err) {
     *out = nullptr;
     if (n_win < 1) return zfail(err, ADE_ERR_BAD_VALUE, "zipenhancer: n_win must be >= 1");
     if (window_len < kZN || (n_win > 1 && window_len % kZHop))
@@ -1065,7 +1099,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     ZipEngine* e = new ZipEngine();
     auto bail = [&](int st) { delete e; return st; };
     auto ci = [&](int i) { return (int)lrintf(cfg->data[i]); };
-    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft;
+    e->device = device; e->L = window_len; e->n_win = n_win; e->exact = exact_dft; e->bf16 = bf16;
     e->C = ci(0); e->H = ci(1); e->qd = ci(2); e->pd = ci(3); e->vd = ci(4); e->pos_dim = ci(5); e->ffd = ci(6); e->K = ci(7);
     e->dst = ci(10); e->dsf = ci(11); e->up = ci(12); e->depth = ci(13);
     const int C = e->C;
@@ -1113,6 +1147,21 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     struct Off { size_t v; };
     std::vector<std::pair<const float**, size_t>> fix;      // pointer slots to patch once the arena is on the device
     auto bind = [&](const float** slot, size_t at) { fix.push_back({slot, at}); };
+    // bf16 copies (round to nearest even, as torch's .to(bfloat16)) of the matrix weights the bf16 path reads: a second arena, patched like the first
+    std::vector<uint16_t> arena16;
+    std::vector<std::pair<const gemm16::bf16_t**, size_t>> fix16;
+    auto to_bf16 = [](float x) -> uint16_t { uint32_t u; memcpy(&u, &x, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto place16 = [&](const float* src, size_t n) { const size_t at = arena16.size(); arena16.resize(at + n); for (size_t i = 0; i < n; ++i) arena16[at + i] = to_bf16(src[i]); arena16.resize((arena16.size() + 63) & ~(size_t)63); return at; };
+    auto bind16 = [&](const gemm16::bf16_t** slot, size_t at) { fix16.push_back({slot, at}); };
+    // W2 (C, fd) with every group of 16 hidden units in k_zip_ff16's contraction order: position 8 h + e holds unit 8 (e >> 2) + 4 h + (e & 3)
+    auto place16_ffout = [&](const float* src, int fd) {
+        std::vector<float> r((size_t)C * fd);
+        for (int co = 0; co < C; ++co)
+            for (int g0 = 0; g0 < fd; g0 += 16)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int e2 = 0; e2 < 8; ++e2) r[(size_t)co * fd + g0 + 8 * hh + e2] = src[(size_t)co * fd + g0 + 8 * (e2 >> 2) + 4 * hh + (e2 & 3)];
+        return place16(r.data(), r.size());
+    };
     auto slice = [&](const float** slot, const std::string& name, std::vector<int> dims, size_t off = 0) { const size_t at = put(name, dims); bind(slot, at + off); };
 
     slice(&e->c1_w, "enc_conv1_w", {C, 2}); slice(&e->c1_b, "enc_conv1_b", {C}); slice(&e->c1_g, "enc_norm1_w", {C}); slice(&e->c1_beta, "enc_norm1_b", {C});
@@ -1127,7 +1176,11 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
             if (!pr) { ok = false; return; }
             const size_t a_b = put(p + "_b", {groups * C}), a_g = put(p + "_nw", {groups * C}), a_be = put(p + "_nb", {groups * C});
             for (int g = 0; g < groups; ++g) {
-                bind(&d.w[g][i], put_conv(p + "_w", g * C, C, C * (i + 1), 2, 3, groups * C));
+                {
+                    const size_t at = put_conv(p + "_w", g * C, C, C * (i + 1), 2, 3, groups * C);
+                    bind(&d.w[g][i], at);
+                    if (bf16 && ok) bind16(&d.w16[g][i], place16(arena.data() + at, (size_t)C * 6 * C * (i + 1)));
+                }
                 bind(&d.b[g][i], a_b + (size_t)g * C); bind(&d.gamma[g][i], a_g + (size_t)g * C); bind(&d.beta[g][i], a_be + (size_t)g * C);
                 for (int c = 0; c < C; ++c) slopes[((size_t)g * 4 + (3 - i)) * C + c] = pr->data[g * C + c];      // layer i's output lives in slot 3 - i
             }
@@ -1156,6 +1209,18 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
                 slice(&w.cv_dw_b[i], cv + "_dw_b", {C}); slice(&w.cv_out_w[i], cv + "_out_w", {C, C}); slice(&w.cv_out_b[i], cv + "_out_b", {C});
                 slice(&w.ff_in_w[i], ff + "_in_w", {fd, C}); slice(&w.ff_in_b[i], ff + "_in_b", {fd}); slice(&w.ff_out_w[i], ff + "_out_w", {C, fd});
                 slice(&w.ff_out_b[i], ff + "_out_b", {C});
+            }
+            if (bf16 && ok) {
+                ZLayer16& w16 = e->layers16[en][p];
+                const Tensor* t = find(pre + "attn_ff1_w");
+                bind16(&w16.ff1_w1, place16(t->data + (size_t)ad * C, (size_t)e->ff1 * C));
+                bind16(&w16.ff1_w2p, place16_ffout(find(pre + "ff1_out_w")->data, e->ff1));
+                for (int i = 0; i < 2; ++i) {
+                    const std::string ff = pre + "ff" + std::to_string(i + 2);
+                    const int fd = i ? e->ff3 : e->ffd;
+                    bind16(&w16.ff_w1[i], place16(find(ff + "_in_w")->data, (size_t)fd * C));
+                    bind16(&w16.ff_w2p[i], place16_ffout(find(ff + "_out_w")->data, fd));
+                }
             }
             slice(&w.bypass_mid, pre + "bypass_mid", {C}); slice(&w.norm_bias, pre + "norm_bias", {C}); slice(&w.fnorm, pre + "final_norm_scale", {C});
             slice(&w.fres, pre + "final_residual_scale", {C});
@@ -1233,6 +1298,14 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     if (hipMemcpy(e->d_w, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer weights failed"));
     for (auto& f : fix) *f.first = e->d_w + f.second;
+    if (bf16) {
+        if ((e->ff1 % 64) || (e->ffd % 64) || (e->ff3 % 64) || e->depth != 4)
+            return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: ade_gemm_dtype = bf16 needs feed-forward widths that are multiples of 64 and dense blocks of depth 4 (the published geometry)"));
+        if (hipMalloc((void**)&e->d_w16, arena16.size() * sizeof(uint16_t)) != hipSuccess ||
+            hipMemcpy(e->d_w16, arena16.data(), arena16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer bf16 weights failed"));
+        for (auto& f : fix16) *f.first = e->d_w16 + f.second;
+    }
     if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
@@ -1265,8 +1338,18 @@ int ZipEngine::reserve(int batch, std::string& err) {
     size_t at = 0;
     for (int i = 0; i < nbuf; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
     nrm2 = nrm + B * 8 * C * 2;                    // statistics of the tensors normalised outside the dense blocks (dense_conv_2, the up-sampler)
+    if (bf16) {
+        if (ws16) (void)hipFree(ws16);
+        ws16 = nullptr;
+        const size_t n_dh = (dh + 63) & ~(size_t)63, n_e0 = (tok0 * C + 63) & ~(size_t)63, n_x = (R * C + 63) & ~(size_t)63;
+        ZP_HIP(hipMalloc((void**)&ws16, (n_dh + n_e0 + n_x) * sizeof(gemm16::bf16_t)));
+        Dh16 = ws16; E016 = Dh16 + n_dh; X16 = E016 + n_e0;
+        raw = E0;                                  // the fp32 E0 buffer is free on this path (E0 itself is bf16): a dense layer's raw output, [tokens][64]
+        Dlast = Dh;                                // the fp32 history buffer is free on this path: the LAST dense layer's normalised output in fp32, [group][tokens][64] (its fp32 consumers)
+    }
     const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
-    ZP_HIP(hipMalloc((void**)&partial, B * std::max(nchunk0, nchunk2) * 64 * 2 * sizeof(double)));
+    const size_t nblk0 = ((size_t)T * kZF + 255) / 256;         // the bf16 dense kernel emits one partial per 256-token tile
+    ZP_HIP(hipMalloc((void**)&partial, B * std::max({nchunk0, nchunk2, bf16 ? nblk0 : (size_t)0}) * 64 * 2 * sizeof(double)));
     capacity = batch;
     return ADE_OK;
 }
@@ -1292,6 +1375,23 @@ void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const fl
         }
 }
 
+// The same block on bf16 operands (csrc/ade_zip16.h): the history is bf16 [tokens][groups 4 C], layer i's raw fp32 output goes to `raw`, its InstanceNorm partial sums come
+// out of the product's own epilogue, and k_zip_hist_norm16 writes the normalised + PReLU'd bf16 values into the history (the last layer's also in fp32 for its consumers).
+void ZipEngine::dense_block16(hipStream_t s, const ZDense& d, int groups, const gemm16::bf16_t* inp, int windows, int Fd) {
+    const int ld = groups * 4 * C, TF = T * Fd, nblk = (TF + 255) / 256;
+    const long long M = (long long)windows * TF;
+    for (int i = 0; i < depth; ++i)
+        for (int g = 0; g < groups; ++g) {
+            const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
+            hipLaunchKernelGGL(zip16::k_zip_dense16, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
+                               1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
+            hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nblk, (double)TF, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
+            const long long total16 = M * 16;
+            hipLaunchKernelGGL(zip16::k_zip_hist_norm16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
+                               TF, i == depth - 1 ? Dlast + (size_t)g * M * C : nullptr, total16);
+        }
+}
+
 void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
     const int ldp = attn_dim + ff1;
     if (mode == 0) {
@@ -1301,12 +1401,15 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 }
 
 // one fused Zipformer2 encoder layer in place on x (R rows), sequences described by geo (:143-187)
-void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, SeqGeo geo) {
+void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo) {
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
     // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
     auto fused_ff = [&](int fd) { return C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
-    if (fused_ff(ff1)) {
+    if (bf16) {
+        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);
+        zip16::launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                        // (:160)
+    } else if (fused_ff(ff1)) {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);                               // (:148-153) attention part of the joint projection
         launch_zip_ff<0>(s, M, x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b, x, nullptr, Y, ff1);        // (:160)
     } else {
@@ -1327,6 +1430,11 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, Seq
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
+        if (bf16) {
+            if (i == 0) zip16::launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);         // (:170-171)
+            else zip16::launch_zip_ff16<1>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);               // (:174)
+            continue;
+        }
         if (fused_ff(fd)) {
             if (i == 0) launch_zip_ff<2>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
             else launch_zip_ff<1>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
@@ -1341,8 +1449,8 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, float* x, long long R, Seq
 
 void ZipEngine::dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff) {        // (:782-792)
     const long long R = (long long)B * Tt * Ff;
-    layer(s, layers[e][0], x, R, SeqGeo{B * Tt, Ff, 1, (long long)Ff, 0, 1});                               // frequency path: (b, t) sequences of Ff consecutive rows
-    layer(s, layers[e][1], x, R, SeqGeo{B * Ff, Tt, Ff, (long long)Tt * Ff, 1, (long long)Ff});             // time path: (b, f) sequences, rows Ff apart
+    layer(s, layers[e][0], layers16[e][0], x, R, SeqGeo{B * Tt, Ff, 1, (long long)Ff, 0, 1});                               // frequency path: (b, t) sequences of Ff consecutive rows
+    layer(s, layers[e][1], layers16[e][1], x, R, SeqGeo{B * Ff, Tt, Ff, (long long)Tt * Ff, 1, (long long)Ff});             // time path: (b, f) sequences, rows Ff apart
 }
 
 int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) {
@@ -1360,10 +1468,16 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     const int nchunk0 = (TF0 + kChunkTok - 1) / kChunkTok;
     hipLaunchKernelGGL(k_zip_features, dim3((unsigned)nchunk0, (unsigned)B), dim3(256), 0, s, (const float*)spec, (float2*)feat, partial, T, J, kChunkTok);
     hipLaunchKernelGGL(k_zip_conv1_coef, dim3((unsigned)B), dim3(64), 0, s, (const double*)partial, nchunk0, (double)TF0, c1_w, c1_b, c1_g, c1_beta, (float4*)coef, C);
+    if (bf16) {
+        hipLaunchKernelGGL(k_zip_conv1_apply16, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
+        dense_block16(s, enc_dense, 1, E016, B, kZF);
+        gemm64::launch(s, RowConvA{Dlast, C, 0, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
+    } else {
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
     gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
+    }
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
     snap(0);
@@ -1378,9 +1492,13 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
         snap(e + 1);
     }
     // ---- mask | phase decoder pair (:864-893)
-    dense_block(s, dec_dense, 2, X, B, F);
+    if (bf16) {
+        hipLaunchKernelGGL(zip16::k_zip_to_bf16, flat(R * (C / 4)), dim3(256), 0, s, (const float*)X, X16, R * (C / 4));
+        dense_block16(s, dec_dense, 2, X16, B, F);
+    } else dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
-        gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
+        const RowConvA up_a = bf16 ? RowConvA{Dlast + (size_t)g * R * C, C, 0, C, T, F, F, 1} : RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1};
+        gemm64::launch(s, up_a, gemm64::WeightB{up_w[g], 3 * C},
                        SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
     }

@@ -326,8 +326,9 @@ def metadata(input_audio_length: int, use_batch_fold: bool = False, batch_window
              out_sample_rate: int = SAMPLE_RATE, gemm_dtype: str = "f32", dft_tables: str = "reference", dynamic_axes: bool = False) -> Dict[str, str]:
     """Manifest of a static export (Export_ZipEnhancer.py:977-981).  Without batch-fold ``input_audio_length`` must be whole hops (the
     reference's STFT -> ISTFT pair reconstructs (T - 1) * 100 samples; its default export always folds, :58-60).
-    ``gemm_dtype``: "f32" only (exact fp32 matrix-core products).  BASELINE.json names bf16 for this model; a bf16-in-HBM path like Mel-Band-Roformer's is not built for it
-     and the engine refuses the key's other values.  ``dft_tables``: "reference" (its fp32-angle tables) | "exact"."""
+    ``gemm_dtype``: "f32" (default: exact fp32 matrix-core products, the parity path) | "bf16" (BASELINE.json configs[2]'s dtype: bf16 weights and activations stored in
+    HBM for the dense blocks, the feed-forward modules, the projections and the attention / convolution-module operands, fp32 residual stream, statistics, softmax and
+    front / back ends -- csrc/ade_zip16.h; gated on its distance from the f32 path and from the reference-run fixture).  ``dft_tables``: "reference" (its fp32-angle tables) | "exact"."""
     # ``dynamic_axes``: the DYNAMIC_AXES export (:31, :61, :828-829, :898-899, :907-908): any input length, scale-factor interpolation on the edges, the ISTFT divides by
     # the overlap-add denominator of the actual frame count; the handle still serves ONE input length.
     if dynamic_axes and use_batch_fold:

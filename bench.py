@@ -241,8 +241,9 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
             return cpu_baseline_numpy(lambda: ZipEnhancerOracle(tensors, CHUNK), x[:1], 1.0, "one 1 s chunk, 161 frames x 101 sub-bands")
         return dict(sess=sess, B=B, x=x, sr=16000, flop=2.0 * zp.macs_per_window(sess.frames, cfg)["total"], cpu=cpu,
                     metric="audio_seconds_per_second (ZipEnhancer 16 kHz, batch=128 x 1 s chunks; RTF = 1/value)",
-                    workload="ZipEnhancer 16 kHz, batch=128 x 1 s chunks (161 frames x 101 sub-bands), fp32 matrix cores, int16 PCM in/out resident in HBM "
-                             "(BASELINE.json configs[2] names bf16: a bf16-in-HBM path is built for configs[3] only, this model runs f32)",
+                    workload="ZipEnhancer 16 kHz, batch=128 x 1 s chunks (161 frames x 101 sub-bands), int16 PCM in/out resident in HBM, " +
+                             ("bf16 weights and activations stored in HBM (BASELINE.json configs[2]'s dtype; csrc/ade_zip16.h: v_mfma_f32_32x32x16_bf16), fp32 residual stream / "
+                              "InstanceNorm statistics / softmax / STFT front / PCM tail" if dtype == "bf16" else "fp32 matrix cores (the parity dtype; --dtype bf16 is configs[2]'s dtype)"),
                     weights="random-init weights of the architecture (zipenhancer.synthetic_tensors, 2.1 M parameters; no checkpoint is available offline)",
                     target_rtf=0.01, deviation=deviation)
     if name == "melband":                                          # BASELINE configs[3]: 32 x 8 s stereo segments @ 44.1 kHz
@@ -308,8 +309,8 @@ def main():
     args = parse_args()
     SKIP_DEVIATION = args.no_deviation
     DEVIATION_DTYPE = args.dtype
-    if args.dtype != "f32" and args.workload != "melband":
-        raise SystemExit("--dtype bf16 is the Mel-Band-Roformer path (bf16 stored in HBM); the other workloads run f32")
+    if args.dtype != "f32" and args.workload not in ("melband", "zipenhancer"):
+        raise SystemExit("--dtype bf16 (bf16 stored in HBM) exists for the melband and zipenhancer workloads; the other workloads run f32")
     import torch
     import torch.distributed as dist
 
@@ -353,7 +354,7 @@ def main():
         wl = build_workload(args.workload, max(B, 1), rank, local_rank, args.dtype)      # (an idle rank of a strong-scaling run still opens its session)
         sess, x_host, sr = wl["sess"], wl["x"][:B], wl["sr"]
         if args.steps == 100 and args.warmup == 10:      # the defaults are sized for GTCRN's 0.4 ms steps; these steps take 0.2 - 1.2 s
-            args.steps, args.warmup = 5, 1
+            args.steps, args.warmup = 10, 2
         args.ramp_ms = 0.0
     if args.no_graph:
         sess.set_option("graph", "0")
@@ -431,6 +432,30 @@ def main():
         host_inclusive = {"ms_per_step": round(h_ms, 4), "value": round(B * out_seconds_per_row / (h_ms * 1e-3), 1), "unit": "audio-s/s",
                           "rtf": float(f"{h_ms * 1e-3 / (B * out_seconds_per_row):.3e}"), "steps": hs,
                           "note": "synchronous ade_process on page-locked host buffers: H2D + kernels + D2H per step, one GPU"}
+        # The same loop PIPELINED (ade_submit / ade_wait, include/ade.h): what a file of many batches costs per batch once the copy-in of call k + 1 and the copy-out of
+        # call k - 1 run under call k's kernels.  A ring of `depth` page-locked buffer sets whose inputs differ per slot; wall clock over >= 20 back-to-back submissions.
+        if hasattr(sess, "submit"):
+            depth = 2
+            ring_in = [torch.from_numpy(np.roll(x_host, k, axis=0).copy()).pin_memory() for k in range(depth)]
+            ring_out = [torch.empty((B, sess.row_out), dtype=torch.int16).pin_memory() for _ in range(depth)]
+
+            def pipelined(n):
+                tickets = []
+                for k in range(n):
+                    if len(tickets) >= depth:
+                        sess.wait(tickets.pop(0))
+                    tickets.append(sess.submit(ring_in[k % depth].numpy(), ring_out[k % depth].numpy()))
+                for t in tickets:
+                    sess.wait(t)
+            ps = max(20, hs) if gtcrn else max(4, hs)
+            pipelined(4 if gtcrn else 2)
+            t_p = time.perf_counter()
+            pipelined(ps)
+            p_ms = (time.perf_counter() - t_p) / ps * 1e3
+            same = bool(np.array_equal(ring_out[0].numpy(), sess.process(ring_in[0].numpy())[0]))
+            host_inclusive.update({"steady_state_ms_per_step": round(p_ms, 4), "steady_state_value": round(B * out_seconds_per_row / (p_ms * 1e-3), 1), "steady_state_steps": ps,
+                                   "steady_state_equals_ade_process": same,
+                                   "steady_state_note": f"ade_submit / ade_wait, {depth} submissions in flight on page-locked buffers: wall clock per batch over {ps} back-to-back batches"})
 
     roofline = cpu = kernels = others = None
     if rank == 0 and gtcrn:
@@ -500,7 +525,7 @@ def main():
             # ZipEnhancer (the second north-star target) with the full step count; the two one-second-per-step transformer configs with ONE timed step
             # each after their warm-up step, so that the driver's clock covers every BASELINE config and the default invocation still ends within minutes.
             others = {}
-            for name, steps, dt_ in (("zipenhancer", max(3, args.other_steps), "f32"), ("melband", 3, "f32"), ("melband", 3, "bf16"), ("mossformer", 3, "f32")):
+            for name, steps, dt_ in (("zipenhancer", max(3, args.other_steps), "f32"), ("zipenhancer", max(3, args.other_steps), "bf16"), ("melband", 3, "f32"), ("melband", 3, "bf16"), ("mossformer", 3, "f32")):
                 if name not in args.other.split(","):
                     continue
                 key = name if dt_ == "f32" else f"{name}_{dt_}"

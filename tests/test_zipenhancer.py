@@ -354,15 +354,89 @@ def test_export_and_driver_host_logic(model, tmp_path):
     assert np.array_equal(denoise(Echo(), a, tail_pad="zeros", family="dfsmn"), a)
 
 
+def _snr_db(x, ref):
+    err, sig = np.asarray(x, np.float64) - np.asarray(ref, np.float64), np.asarray(ref, np.float64)
+    return float(10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30)))
+
+
 @pytest.mark.gpu
-def test_gpu_zipenhancer_reduced_precision_manifests_are_refused(model):
-    """ZipEnhancer runs f32: the bf16-in-HBM path exists for Mel-Band-Roformer only and the round-2 rounding mode of the fp32 kernels is gone; a manifest asking for
-    bf16 (BASELINE.json's dtype for this model), for the old mode or for anything else is refused at create."""
+def test_gpu_zipenhancer_unknown_dtypes_are_refused(model):
+    """ade_gemm_dtype is "f32" (the parity path) or "bf16" (configs[2]'s dtype, csrc/ade_zip16.h); the round-2 rounding mode of the fp32 kernels and anything else is refused at create."""
     from audio_denoiser_onnx_amd.session import InferenceSession
     t = model[3]
-    for dt in ("bf16", "bf16_inputs", "fp8"):
+    for dt in ("bf16_inputs", "fp8"):
         with pytest.raises(Exception):
             InferenceSession(weights=pack_blob(t), metadata=zp.metadata(16000, gemm_dtype=dt))
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_bf16_vs_f32_and_reference_fixture(model):
+    """BASELINE configs[2]'s dtype: bf16 weights and activations stored in HBM (csrc/ade_zip16.h).  A throughput path, NOT the parity path: gated on its distance (a) from the
+    engine's f32 path -- encoder taps and the waveform -- and (b) from the REFERENCE's own forward on the fixture clips (Export_ZipEnhancer.py:818-927 run by
+    tools/make_golden_zipenhancer.py): SNR >= 30 dB against the reference's fp32 waveform and its PCM on every non-silent clip; silence stays exactly silent."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    z, _, _, t = model
+    L = int(z["length"])
+    names = ("wav0", "randn", "zeros")
+    pcm = np.stack([z["in_" + n] for n in names])
+    blob = pack_blob(t)
+    with InferenceSession(weights=blob, metadata=zp.metadata(L)) as a, InferenceSession(weights=blob, metadata=zp.metadata(L, gemm_dtype="bf16")) as b:
+        oa, fa = a.process(pcm, want_f32=True)
+        ob, fb = b.process(pcm, want_f32=True)
+        T = a.frames
+        taps = {k: (a.tap(k, 3 * T * F * C).copy(), b.tap(k, 3 * T * F * C).copy()) for k in ("enc_in", "enc0", "enc3")}
+        again, _ = b.process(pcm)
+    assert np.isfinite(fb).all() and np.array_equal(again, ob)                    # deterministic
+    assert not ob[2].any()                                                        # silence stays exactly silent
+    report = {k: round(_snr_db(vb, va), 1) for k, (va, vb) in taps.items()}
+    for i, n in enumerate(names[:2]):
+        report[n] = dict(vs_f32_wave=round(_snr_db(fb[i], fa[i]), 1), vs_ref_wave=round(_snr_db(fb[i], z["wave_" + n]), 1), vs_ref_pcm=round(_snr_db(ob[i], z["out_" + n]), 1),
+                         max_lsb_vs_ref=int(np.abs(ob[i].astype(np.int32) - z["out_" + n].astype(np.int32)).max()), ref_peak=int(np.abs(z["out_" + n]).max()))
+    print("zipenhancer bf16:", report)
+    assert min(report[k] for k in ("enc_in", "enc0", "enc3")) >= 30.0, report
+    for n in names[:2]:
+        r = report[n]
+        assert r["vs_f32_wave"] >= 30.0 and r["vs_ref_wave"] >= 30.0 and r["vs_ref_pcm"] >= 30.0, report
+        assert r["max_lsb_vs_ref"] <= 0.1 * r["ref_peak"], report
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_bf16_full_batch_properties(model):
+    """BASELINE configs[2] at its stated dtype AND batch: 128 x 1 s chunks in one call on the bf16 path -- finite, a silent row exactly silent, a row's bits the same alone and
+    in the reversed batch (row independence at batch 128), >= 30 dB from the f32 path on a row sample."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch
+    _, _, _, t = model
+    blob = pack_blob(t)
+    x = synth_batch(128, 16000)
+    x[9] = 0
+    with InferenceSession(weights=blob, metadata=zp.metadata(16000, gemm_dtype="bf16")) as sess:
+        out, f32 = sess.process(x, want_f32=True)
+        solo, _ = sess.process(x[77:78])
+        rev, _ = sess.process(x[::-1].copy())
+    assert out.shape == (128, 16000) and np.isfinite(f32).all() and np.abs(np.delete(out, 9, axis=0)).max(axis=1).min() > 50
+    assert not out[9].any() and np.array_equal(solo[0], out[77]) and np.array_equal(rev, out[::-1])
+    with InferenceSession(weights=blob, metadata=zp.metadata(16000)) as ref:
+        _, w32 = ref.process(x[:4], want_f32=True)
+    snr = _snr_db(f32[:4], w32)
+    print(f"zipenhancer bf16 at 128 x 1 s: {snr:.1f} dB from the f32 path on rows 0-3")
+    assert snr >= 30.0
+
+
+@pytest.mark.hipsim
+@pytest.mark.skipif(not os.environ.get("ADE_SLOW_TESTS"), reason="4 minutes under the host simulator; set ADE_SLOW_TESTS=1")
+def test_hipsim_zipenhancer_bf16_close_to_f32(model):
+    """The bf16 kernels' data flow on the CPU (the simulator emulates v_mfma_f32_32x32x16_bf16 lane for lane): one 800-sample window, bf16 vs f32 engine."""
+    from ade_testlib import hipsim_library
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    _, _, _, t = model
+    pcm = (np.random.default_rng(0).standard_normal((1, 800)) * 2000).astype(np.int16)
+    res = []
+    for dt in ("f32", "bf16"):
+        sess = InferenceSession(weights=pack_blob(t), metadata=zp.metadata(800, gemm_dtype=dt), library=hipsim_library())
+        _, f32 = sess.process(pcm, want_f32=True)
+        res.append((f32, sess.tap("enc3", sess.frames * F * C).copy()))
+    assert _snr_db(res[1][1], res[0][1]) >= 35.0 and _snr_db(res[1][0], res[0][0]) >= 30.0
 
 
 @pytest.mark.gpu
