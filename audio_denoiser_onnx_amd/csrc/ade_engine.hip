@@ -111,7 +111,7 @@ struct ade_engine {
     };
     static constexpr int kMaxPipe = 4;
     PipeSlot pipe[kMaxPipe];
-    int pipe_depth = 2;                   // option "pipe_depth" (2 .. 4)
+    int pipe_depth = 3;                   // option "pipe_depth" (2 .. 4): at 2 the copy-in of call k + 1 can only be enqueued once call k - 1 has been waited for, i.e. behind its copy-out
     int pipe_capacity = 0;                // rows every slot's buffers hold
     unsigned long long pipe_next = 1;     // the next ticket
     hipStream_t s_pin = nullptr, s_pout = nullptr;

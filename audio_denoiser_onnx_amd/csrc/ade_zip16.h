@@ -45,7 +45,7 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
 // (product + bias) over the tile's rows are that window's InstanceNorm partial sums: partial[((win * nblk + blk) * 64 + c) * 2 + {sum, sumsq}] (fp64, k_zip_stats_final's
 // layout).  raw: [tokens][64] fp32 (product + bias).
 constexpr int kDPitch = 80, kDARows = 258;
-__global__ __launch_bounds__(256, 3) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
+__global__ __launch_bounds__(256, 4) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
                                                         int F, int dil, const bf16_t* __restrict__ w, const float* __restrict__ bias, float* __restrict__ raw,
                                                         double* __restrict__ partial, int nblk) {
     __shared__ __attribute__((aligned(16))) unsigned char As[kDARows * kDPitch];
@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) void k_zip_to_bf16(const float* __restrict__ x
 //   16 hidden units: position 8 h + e holds unit 8 (e >> 2) + 4 h + (e & 3)), so its A operand is one ds_read_b128.
 // The output tile goes through LDS (the weight buffers, dead by then) so that the residual reads and the stores are whole 256-byte rows.
 // MODE 0: out = res + ff   1: out = xin + ff   2: out = res + ((xin + ff) - res) * cmid      (as k_zip_ff)
+// MODE 3: the layer's LAST module with the layer's final norm (:175-183) in the same store: y = xin + ff;  out = y / |y - nb|_2 * fs + res * rs  (res = the layer input, out = the
+//         layer output; cmid carries nb | fs | rs, 64 floats each) -- the row's sum of squares meets through four shuffles among the 16 lanes that own the row.
 constexpr int kF16Pitch = 144, kF16Buf = 2 * 64 * kF16Pitch, kF16EPitch = 68;
 constexpr int kF16Lds = 2 * kF16Buf > 4 * 32 * kF16EPitch * 4 ? 2 * kF16Buf : 4 * 32 * kF16EPitch * 4;
 template <int MODE>
@@ -284,7 +286,9 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
     wave_sync();
     const int c4 = (lane & 15) * 4;
     const float4 bo = *reinterpret_cast<const float4*>(b2 + c4);
-    const float4 cv = MODE == 2 ? *reinterpret_cast<const float4*>(cmid + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 cv = (MODE == 2 || MODE == 3) ? *reinterpret_cast<const float4*>(cmid + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 fsv = MODE == 3 ? *reinterpret_cast<const float4*>(cmid + 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 rsv = MODE == 3 ? *reinterpret_cast<const float4*>(cmid + 128 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 xi[8], rv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -295,6 +299,17 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+        if (MODE == 3) {                                                    // (every lane takes part in the row sums: rows beyond M compute on the clamped row and store nothing)
+            const float4 a = *reinterpret_cast<const float4*>(E + rl * kF16EPitch + c4);
+            const float4 y = make_float4(xi[u].x + (a.x + bo.x), xi[u].y + (a.y + bo.y), xi[u].z + (a.z + bo.z), xi[u].w + (a.w + bo.w));
+            const float4 d = make_float4(y.x - cv.x, y.y - cv.y, y.z - cv.z, y.w - cv.w);
+            float ssq = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+            ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64); ssq += __shfl_xor(ssq, 8, 64);
+            const float nrm = sqrtf(ssq);
+            if (m < M) *reinterpret_cast<float4*>(out + (size_t)m * 64 + c4) = make_float4((y.x / nrm) * fsv.x + rv[u].x * rsv.x, (y.y / nrm) * fsv.y + rv[u].y * rsv.y,
+                                                                                          (y.z / nrm) * fsv.z + rv[u].z * rsv.z, (y.w / nrm) * fsv.w + rv[u].w * rsv.w);
+            continue;
+        }
         if (m >= M) continue;
         const float4 a = *reinterpret_cast<const float4*>(E + rl * kF16EPitch + c4);
         auto fin = [](float acc, float b, float x, float r, float c) -> float {
@@ -312,6 +327,151 @@ template <int MODE>
 inline void launch_zip_ff16(hipStream_t s, int M, const float* xin, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, const float* res, const float* cmid,
                             float* out, int fd) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ff16<MODE>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, xin, w1, b1, w2p, b2, res, cmid, out, M, fd);
+}
+
+// ---- element access shared by the kernels that exist for both dtypes (attention core, convolution module): four consecutive elements as a float4 -----------------------
+__device__ __forceinline__ float4 ldx4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldx4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(gemm16::bf16_lo(u.x), gemm16::bf16_hi(u.x), gemm16::bf16_lo(u.y), gemm16::bf16_hi(u.y));
+}
+__device__ __forceinline__ float ldx1(const float* p) { return *p; }
+__device__ __forceinline__ float ldx1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void stx4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stx4(bf16_t* p, const float4& v) { *reinterpret_cast<uint2*>(p) = gemm16::pack_bf16x4(v); }
+__device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stx1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.0f) & 0xffffu); }
+
+// ---- the small-K products of a Zipformer2 layer and of the (1, 3) convolutions: out(m, n) = sum_k A(m, k) W[n][k], K = 16 KS <= 192, N <= 32 NT ------------------------
+// A 256-thread workgroup owns 128 rows, a wavefront 32 of them and ALL output columns.  A row's operand goes straight from global memory into the registers the matrix cores
+// read (lane (row l31, h): k = 16 ks + 8 h .. + 7 of its row, one 16-byte load per step for bf16 rows, two for fp32 rows that are rounded here); the weights (N x K bf16) are
+// staged once per workgroup (pitch 2 K + 16 bytes: conflict-free ds_read_b128 for K = 48, 64, 192).  The product is formed TRANSPOSED (weights = MFMA-A), so a lane ends with
+// runs of four consecutive columns of ITS row; the tile passes through LDS 64 columns at a time and the store functor gets float4s (m, n .. n + 3) with 16 consecutive lanes
+// on one row: whole-line reads (bias, residual) and writes.
+//   AL: uint4 operator()(int m /* < M, clamped by the caller */, int ks, int h) const
+//   ST: void operator()(int m, int n, float4 v) const          n % 4 == 0, n < N
+struct F32Rows {               // fp32 [rows][ld]: the residual stream, rounded to bf16 on the way into the matrix cores
+    const float* p; int ld;
+    __device__ uint4 operator()(int m, int ks, int h) const {
+        const float* q = p + (size_t)m * ld + 16 * ks + 8 * h;
+        return pack8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
+    }
+};
+template <int ACT>             // 0: as stored; 2: SwooshR of the stored value (the convolution module's out-projection, :339)
+struct B16Rows {               // bf16 [rows][ld]
+    const bf16_t* p; int ld;
+    __device__ uint4 operator()(int m, int ks, int h) const {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + (size_t)m * ld + 16 * ks + 8 * h);
+        if (ACT == 0) return u;
+        float v[8];
+        unpack8(u, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = swoosh_r16(v[e]);
+        return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+};
+struct RowConv16 {             // (1, 3) convolution along f over 64 channels at ch0 of the bf16 dense history: k = kf * 64 + ci, input column f * stride - 1 + kf (zero outside)
+    const bf16_t* hist; int ld, ch0, T, Fin, Fout, stride;
+    __device__ uint4 operator()(int m, int ks, int h) const {
+        const int tf = T * Fout, b = m / tf, rem = m - b * tf, t = rem / Fout, f = rem - t * Fout;
+        const int kf = ks >> 2, f2 = f * stride - 1 + kf;
+        const bool ok = f2 >= 0 && f2 < Fin;
+        return ld8_or_zero(ok, hist + ((size_t)(b * T + t) * Fin + (ok ? f2 : 0)) * ld + ch0 + 16 * (ks & 3) + 8 * h);
+    }
+};
+struct Bf16BiasStore {         // out[m][off + n] = bf16(v + bias[n])
+    bf16_t* out; const float* bias; int ld, off;
+    __device__ void operator()(int m, int n, float4 v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        *reinterpret_cast<uint2*>(out + (size_t)m * ld + off + n) = gemm16::pack_bf16x4(make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w));
+    }
+};
+struct F32BiasStore {          // out[m][n] = v + bias[n]
+    float* out; const float* bias; int ld;
+    __device__ void operator()(int m, int n, float4 v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+    }
+};
+struct ResidualStore {         // y[m][n] += v + bias[n]      (fp32 residual stream, 64 columns)
+    float* y; const float* bias;
+    __device__ void operator()(int m, int n, float4 v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        float4* q = reinterpret_cast<float4*>(y + (size_t)m * 64 + n);
+        const float4 o = *q;
+        *q = make_float4(o.x + (v.x + b.x), o.y + (v.y + b.y), o.z + (v.z + b.z), o.w + (v.w + b.w));
+    }
+};
+struct SubPixelStore16 {       // conv channel n = c * r + u of sub-band f -> U[(b, t, f * r + u)][ch0 + c] (+ bias)   (:767-769), fp32
+    float* u; const float* bias; int ld, ch0, r;
+    __device__ void operator()(int m, int n, float4 v) const {
+        const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int c = (n + e) / r, s = (n + e) - c * r; u[((size_t)m * r + s) * ld + ch0 + c] = t[e] + bias[n + e]; }
+    }
+};
+template <int KS, int NT>
+constexpr int rows16_lds() { return (32 * NT * (32 * KS + 16)) > 4 * 32 * 68 * 4 ? (32 * NT * (32 * KS + 16)) : 4 * 32 * 68 * 4; }
+template <int KS, int NT, class AL, class ST>
+__global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restrict__ w, ST store, int M, int N) {
+    constexpr int kPitch = 32 * KS + 16;
+    HIP_DYNAMIC_SHARED(unsigned char, lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31;
+    uint4 xa[KS];
+    {
+        const int mc = row < M ? row : M - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xa[ks] = a_of(mc, ks, h);
+    }
+    // weights: N rows of 2 KS 16-byte pieces (rows beyond N re-read row N - 1: their products are never stored)
+    for (int i = tid; i < 32 * NT * 2 * KS; i += 256) {
+        const int n = i / (2 * KS), pc = i - n * (2 * KS);
+        *reinterpret_cast<uint4*>(lds + n * kPitch + 16 * pc) = *reinterpret_cast<const uint4*>(w + (size_t)(n < N ? n : N - 1) * (16 * KS) + 8 * pc);
+    }
+    __syncthreads();
+    v16f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(lds + (32 * t + l31) * kPitch + 32 * ks + 16 * h), xa[ks], acc[t]);
+    __syncthreads();                                                    // the weights are dead: the wave's epilogue tile takes their place
+    float* E = reinterpret_cast<float*>(lds) + wave * 32 * 68;
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int g = 0; g < (NT + 1) / 2; ++g) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            if (2 * g + jt >= NT) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(E + l31 * 68 + 32 * jt + 8 * q + 4 * h) =
+                    make_float4(acc[2 * g + jt][4 * q], acc[2 * g + jt][4 * q + 1], acc[2 * g + jt][4 * q + 2], acc[2 * g + jt][4 * q + 3]);
+        }
+        wave_sync();
+        const int n = 64 * g + c4;
+        if (n < N && (2 * g + 1 < NT || c4 < 32)) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+                if (m < M) store(m, n, *reinterpret_cast<const float4*>(E + rl * 68 + c4));
+            }
+        }
+        wave_sync();
+    }
+}
+template <int KS, int NT, class AL, class ST>
+inline void launch_rows16(hipStream_t s, const AL& a, const bf16_t* w, const ST& st, int M, int N) {
+    if (M <= 0) return;
+    auto kern = k_rows16<KS, NT, AL, ST>;
+    constexpr int bytes = rows16_lds<KS, NT>();
+    static bool raised = false;                                         // (more than 48 KB of dynamic LDS needs the attribute: K = 192 x N = 128 only)
+    if (bytes > 48 * 1024 && !raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); raised = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w, st, M, N);
 }
 
 }  // namespace zip16

@@ -43,6 +43,10 @@ namespace ade {
 namespace {
 
 using namespace dev;
+using zip16::ldx1;
+using zip16::ldx4;
+using zip16::stx1;
+using zip16::stx4;
 
 constexpr int kZN = 400, kZHop = 100, kZF = kZN / 2 + 1, kZC2 = 2 * kZF;   // Export_ZipEnhancer.py:47-49
 constexpr int kChunkTok = 2048;                                             // tokens per partial-statistics block
@@ -629,9 +633,11 @@ struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_f
 // NT = key tiles held in registers (n <= 16 NT).
 constexpr int kQKs = 20;                    // floats per staged Q / K row (16 + 4: conflict-free ds_read_b128, as in ade_gemm.h)
 constexpr int kUs = 18;                     // floats per scratch row
-template <int MODE, int NT, int DT>
-__global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj, int ldp, const float* __restrict__ pos, const float* __restrict__ src, int lds_,
-                                                  float* __restrict__ out, int ldo, SeqGeo geo, int qd_, int pd_, int dv) {
+// TI: element type of proj / src / out -- float (the parity path) or bf16 (ade_gemm_dtype = bf16: the operands are stored in HBM as bf16 and widened on their way into LDS /
+// the registers; scores, softmax and accumulation are fp32 either way)
+template <int MODE, int NT, int DT, class TI>
+__global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, int ldp, const float* __restrict__ pos, const TI* __restrict__ src, int lds_,
+                                                  TI* __restrict__ out, int ldo, SeqGeo geo, int qd_, int pd_, int dv) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
     const int j16 = lane & 15, g = lane >> 4;
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
         for (int u = 0; u < kIt; ++u) {
             const int i = tid + 256 * u, p = i >> 2, q = i & 3;
             const bool ok = p < n;                                                       // (p >= np16 only in the last, partial round: those lanes skip the store)
-            t4[u] = keep4(ok, *reinterpret_cast<const float4*>(proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 4 * q));
+            t4[u] = keep4(ok, ldx4(proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 4 * q));
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
@@ -685,9 +691,9 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
             for (int u = 0; u < kBatch; ++u) {
                 const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
                 const bool ok = key < n && d < dv;
-                const float* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0);
-                va[u] = keep4(ok, *reinterpret_cast<const float4*>(MODE == 0 ? q : q + h * dv));
-                if (MODE == 0) vb[u] = keep4(ok, *reinterpret_cast<const float4*>(q + dv));
+                const TI* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0);
+                va[u] = keep4(ok, ldx4(MODE == 0 ? q : q + h * dv));
+                if (MODE == 0) vb[u] = keep4(ok, ldx4(q + dv));
             }
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
@@ -702,9 +708,9 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
     __syncthreads();
     for (int qt = wave; qt * 16 < n; qt += 4) {
         const int q0 = qt * 16, qi = q0 + j16;
-        const float* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
-        const float4 qv = keep4(qi < n, *reinterpret_cast<const float4*>(qrow + 4 * g));  // B operand of the score product: Q[query j16][dims 4 g ..]
-        const float pq_raw = qrow[32 + g];
+        const TI* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
+        const float4 qv = keep4(qi < n, ldx4(qrow + 4 * g));  // B operand of the score product: Q[query j16][dims 4 g ..]
+        const float pq_raw = ldx1(qrow + 32 + g);
         const float pq = qi < n ? pq_raw : 0.0f;                                         // B operand of the position product: p[query j16][dim g]
         float st[NT][4];
         float mx = -INFINITY;
@@ -766,12 +772,10 @@ __global__ __launch_bounds__(256) void k_zip_attn(const float* __restrict__ proj
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[d][r] / sum;
                 if (MODE == 0) {
-                    float y[4];
-                    ld4(src + row * lds_ + 2 * dv + col, y);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] *= y[r];
+                    const float4 y = ldx4(src + row * lds_ + 2 * dv + col);
+                    o[0] *= y.x; o[1] *= y.y; o[2] *= y.z; o[3] *= y.w;
                 }
-                st4(out + row * ldo + (MODE == 0 ? 0 : h * dv) + col, o);
+                stx4(out + row * ldo + (MODE == 0 ? 0 : h * dv) + col, make_float4(o[0], o[1], o[2], o[3]));
             }
         }
     }
@@ -784,8 +788,8 @@ inline size_t zip_attn_lds(int n) {
 
 // ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
 // the block's gated rows (+ k / 2 halo on both sides) are staged in LDS once.  g: [rows][2 C] = (value | gate); out: [rows][C].
-template <int CC, int KK>       // CC, KK > 0: channel count / kernel size known at compile time (the published geometry: 64, 15); 0: run-time values
-__global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+template <int CC, int KK, class TI>       // CC, KK > 0: channel count / kernel size known at compile time (the published geometry: 64, 15); 0: run-time values; TI: float | bf16 storage of g / out
+__global__ __launch_bounds__(256) void k_zip_dwconv(const TI* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, TI* __restrict__ out,
                                                     SeqGeo geo, int C_, int K_) {
     HIP_DYNAMIC_SHARED(float, lds)
     const int C = CC > 0 ? CC : C_, K = KK > 0 ? KK : K_;
@@ -800,9 +804,9 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g,
         for (int u = 0; u < kIt; ++u) {
             const int i = tid + 256 * u, p = i >> 4, c = (i & 15) * 4, pos = p0 - half + p;
             const bool ok = p < kRows && pos >= 0 && pos < n;
-            const float* q = g + (size_t)(r0 + (long long)(ok ? pos : 0) * geo.ps) * (2 * CC) + c;
-            va[u] = keep4(ok, *reinterpret_cast<const float4*>(q));
-            vg[u] = *reinterpret_cast<const float4*>(q + CC);
+            const TI* q = g + (size_t)(r0 + (long long)(ok ? pos : 0) * geo.ps) * (2 * CC) + c;
+            va[u] = keep4(ok, ldx4(q));
+            vg[u] = ldx4(q + CC);
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g,
             float a = 0.0f;
 #pragma unroll
             for (int k = 0; k < KK; ++k) a = fmaf(wk[k], lds[(p + k) * CC + c], a);
-            if (pos < n) out[(size_t)(r0 + (long long)pos * geo.ps) * CC + c] = a + bc;
+            if (pos < n) stx1(out + (size_t)(r0 + (long long)pos * geo.ps) * CC + c, a + bc);
         }
         return;
     }
@@ -831,8 +835,8 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g,
         const int p = i / C, c = i - p * C, pos = p0 - half + p;
         float v = 0.0f;
         if (pos >= 0 && pos < n) {
-            const float* q = g + (size_t)(r0 + (long long)pos * geo.ps) * (2 * C);
-            v = q[c] * sigmoid_p(q[C + c]);
+            const TI* q = g + (size_t)(r0 + (long long)pos * geo.ps) * (2 * C);
+            v = ldx1(q + c) * sigmoid_p(ldx1(q + C + c));
         }
         lds[p * C + c] = v;
     }
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const float* __restrict__ g,
         if (pos >= n) continue;
         float a = 0.0f;
         for (int k = 0; k < K; ++k) a = fmaf(w[c * K + k], lds[(p + k) * C + c], a);
-        out[(size_t)(r0 + (long long)pos * geo.ps) * C + c] = a + bias[c];
+        stx1(out + (size_t)(r0 + (long long)pos * geo.ps) * C + c, a + bias[c]);
     }
 }
 
@@ -972,32 +976,223 @@ __global__ __launch_bounds__(256) void k_zip_ola_pcm(const float* __restrict__ f
 }
 
 // the fused attention kernel for this sequence length: NT = key tiles kept in registers (16 NT >= n)
-template <int MODE, int NT, int DT>
-bool launch_attn_nt(hipStream_t s, int heads, const float* proj, int ldp, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
+template <int MODE, int NT, int DT, class TI>
+bool launch_attn_nt(hipStream_t s, int heads, const TI* proj, int ldp, const float* pos, const TI* src, int lds_, TI* out, int ldo, SeqGeo geo, int dv) {
     if (geo.n > 16 * NT) return false;
     const size_t bytes = zip_attn_lds<MODE, NT, DT>(geo.n);
-    auto kern = k_zip_attn<MODE, NT, DT>;
+    auto kern = k_zip_attn<MODE, NT, DT, TI>;
     hipLaunchKernelGGL(kern, dim3((unsigned)geo.nseq, (unsigned)heads), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, 16, 4, dv);
     return true;
 }
-template <int MODE, int DT>
-void launch_attn(hipStream_t s, int heads, const float* proj, int ldp, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
-    (void)(launch_attn_nt<MODE, 4, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 6, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
-           launch_attn_nt<MODE, 7, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 11, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
-           launch_attn_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 20, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
-           launch_attn_nt<MODE, 31, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv));      // 496 keys: the reference's longest un-folded window (3 s = 481 frames) at 124 score registers, 157 KB of LDS
+template <int MODE, int DT, class TI>
+void launch_attn(hipStream_t s, int heads, const TI* proj, int ldp, const float* pos, const TI* src, int lds_, TI* out, int ldo, SeqGeo geo, int dv) {
+    (void)(launch_attn_nt<MODE, 4, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 6, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 7, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 11, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 16, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn_nt<MODE, 20, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+           launch_attn_nt<MODE, 31, DT, TI>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv));      // 496 keys: the reference's longest un-folded window (3 s = 481 frames) at 124 score registers, 157 KB of LDS
+}
+
+// ---- the same attention core on the bf16 matrix instruction (ade_gemm_dtype = bf16; v_mfma_f32_16x16x32_bf16: lane l supplies row (l & 15), k = 8 (l >> 4) .. + 7 of a 32-deep
+// step; D as in the f32 form: lane (g, j16) holds D[4 g + r][j16]) -------------------------------------------------------------------------------------------------------
+// Same decomposition, same skew, fp32 scores / softmax / accumulation; what changes is the operand plumbing:
+//   S^T tile   : ONE instruction (K rows from LDS as 16-byte pieces, Q^T from global; the 16 head dims fill k = 0 .. 15, lane groups 2 / 3 feed a block of zeros);
+//   pos term   : two instructions (the table is staged as bf16 [offset][4 dims]: one 8-byte read per lane of group 0; p^T likewise);
+//   O^T tile   : the probabilities of TWO key tiles are one B operand (the lane's own 2 x 4 registers, rounded to bf16), V^T comes from LDS as two 8-byte pieces (keys 4 g ..
+//                of the even tile, 16 + 4 g .. of the odd one): one instruction per 32 keys and 16 value dims.
+// 7 matrix instructions of 16 cycles per PAIR of key tiles against 20 of 32 cycles: what is left is the softmax's VALU work and the skew's LDS round trip.
+__device__ __forceinline__ v4f zmfma16x16x32(const uint4& a, const uint4& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemm16::as_v8bf(a), gemm16::as_v8bf(b), c, 0, 0, 0); }
+constexpr int kK16Pitch = 48;               // bytes per staged key row: 16 dims bf16 + 16 (the 16 lanes of a read land on 16 distinct 4-bank sets)
+template <int MODE, int NT, int DT>
+__global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __restrict__ proj, int ldp, const float* __restrict__ pos, const gemm16::bf16_t* __restrict__ src, int lds_,
+                                                    gemm16::bf16_t* __restrict__ out, int ldo, SeqGeo geo, int dv) {
+    HIP_DYNAMIC_SHARED(unsigned char, lds8)
+    typedef gemm16::bf16_t bf;
+    constexpr int NP = (NT + 1) / 2, np32 = NP * 32, hd = 36;
+    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
+    const int j16 = lane & 15, g = lane >> 4, n2 = 2 * n - 1, n2p = (n2 + 1) & ~1;
+    constexpr int vp = np32 * 2 + 16;                                                    // bytes per V^T row
+    unsigned char* Zs = lds8;                                                             // 16 bytes of zeros
+    unsigned char* Ks = lds8 + 16;                                                        // [np32][kK16Pitch]
+    unsigned char* Pt = Ks + np32 * kK16Pitch;                                           // [n2p][8]: bf16 x 4 dims per offset
+    unsigned char* Vt = Pt + n2p * 8;                                                    // [DT * 16][vp]
+    float* Us = reinterpret_cast<float*>(Vt + DT * 16 * vp) + wave * 32 * kUs;           // per-wave scratch [32][kUs] (see k_zip_attn)
+    const long long r0 = geo.row0(seq);
+    if (tid < 4) reinterpret_cast<unsigned*>(Zs)[tid] = 0u;
+    {   // keys: two 16-byte pieces per key (rows beyond n are zeros)
+        constexpr int kIt = (np32 * 2 + 255) / 256;
+        uint4 t4[kIt];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i >> 1, q = i & 1;
+            const bool ok = p < n;
+            t4[u] = gemm16::ld8_or_zero(ok, proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 8 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + 256 * u, p = i >> 1, q = i & 1;
+            if (p < np32) *reinterpret_cast<uint4*>(Ks + p * kK16Pitch + 16 * q) = t4[u];
+        }
+    }
+    {   // position table (head, 4 dims, n2) fp32 -> [offset][4] bf16
+        constexpr int kIt = (2 * NT * 16 + 255) / 256;
+        float t[kIt][4];
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int c = tid + 256 * u, cc = c < n2 ? c : 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t[u][d] = pos[(size_t)(h * 4 + d) * n2 + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int c = tid + 256 * u;
+            if (c < n2p) *reinterpret_cast<uint2*>(Pt + c * 8) = c < n2 ? make_uint2(gemm16::pack_bf16x2(t[u][0], t[u][1]), gemm16::pack_bf16x2(t[u][2], t[u][3])) : make_uint2(0u, 0u);
+        }
+    }
+    {   // values, transposed into Vt[dim][key] (bf16): four dims per lane and load; keys beyond n are zeros
+        constexpr int kQuads = DT * 4, kIt = (np32 * kQuads + 255) / 256, kBatch = 4;
+#pragma unroll
+        for (int u0 = 0; u0 < kIt; u0 += kBatch) {
+            float4 va[kBatch], vb[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
+                const bool ok = key < n && d < dv;
+                const bf* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0);
+                va[u] = keep4(ok, ldx4(MODE == 0 ? q : q + h * dv));
+                if (MODE == 0) vb[u] = keep4(ok, ldx4(q + dv));
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
+                if (u0 + u >= kIt || key >= np32) continue;
+                float4 v = va[u];
+                if (MODE == 0) v = make_float4(tanh_f(v.x) * vb[u].x, tanh_f(v.y) * vb[u].y, tanh_f(v.z) * vb[u].z, tanh_f(v.w) * vb[u].w);
+                const unsigned lo = gemm16::pack_bf16x2(v.x, v.y), hi = gemm16::pack_bf16x2(v.z, v.w);
+                bf* col = reinterpret_cast<bf*>(Vt + (size_t)d * vp) + key;
+                col[0] = (bf)(lo & 0xffffu);
+                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + vp) = (bf)(lo >> 16);
+                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + 2 * vp) = (bf)(hi & 0xffffu);
+                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + 3 * vp) = (bf)(hi >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    for (int qt = wave; qt * 16 < n; qt += 4) {
+        const int q0 = qt * 16, qi = q0 + j16;
+        const bf* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
+        const uint4 qv = gemm16::ld8_or_zero(qi < n && g < 2, qrow + 8 * (g & 1));                  // B operand of the score product: Q[query j16][dims 8 g ..] (groups 2, 3: zeros)
+        uint4 pqv = make_uint4(0u, 0u, 0u, 0u);                                                     // B operand of the position product: p[query j16][dims 0 .. 3] in group 0
+        {
+            const uint2 t = *reinterpret_cast<const uint2*>(qrow + 32);
+            const bool ok = qi < n && g == 0;
+            pqv.x = ok ? t.x : 0u; pqv.y = ok ? t.y : 0u;
+        }
+        float st[2 * NP][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int k0 = kt * 16;
+            const uint4 kv = *reinterpret_cast<const uint4*>(g < 2 ? Ks + (k0 + j16) * kK16Pitch + 16 * g : Zs);
+            const v4f sc = zmfma16x16x32(kv, qv, v4f{0.0f, 0.0f, 0.0f, 0.0f});
+            const int c0 = n - 16 - q0 + k0;                   // offset index of (query q0 + 15, key k0): u = 0
+            int ca = c0 + j16, cb = c0 + 16 + j16;
+            ca = ca < 0 ? 0 : (ca > n2 - 1 ? n2 - 1 : ca);       // outside the table only for padded queries / keys
+            cb = cb < 0 ? 0 : (cb > n2 - 1 ? n2 - 1 : cb);
+            const uint2 pa = *reinterpret_cast<const uint2*>(g == 0 ? Pt + ca * 8 : Zs), pb = *reinterpret_cast<const uint2*>(g == 0 ? Pt + cb * 8 : Zs);
+            const v4f u0 = zmfma16x16x32(make_uint4(pa.x, pa.y, 0u, 0u), pqv, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 4 g + r][query j16]
+            const v4f u1 = zmfma16x16x32(make_uint4(pb.x, pb.y, 0u, 0u), pqv, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 16 + 4 g + r][query j16]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Us[(4 * g + r) * kUs + j16] = u0[r]; Us[(16 + 4 * g + r) * kUs + j16] = u1[r]; }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sc[r] + Us[(15 - j16 + 4 * g + r) * kUs + j16];
+                st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        }
+        if (NT & 1) { st[NT][0] = st[NT][1] = st[NT][2] = st[NT][3] = -INFINITY; }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.0f;
+        v4f acc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[d] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float pr[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[r] = __expf(st[2 * p][r] - mx); pr[4 + r] = __expf(st[2 * p + 1][r] - mx); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += pr[r];
+            const uint4 pb = make_uint4(gemm16::pack_bf16x2(pr[0], pr[1]), gemm16::pack_bf16x2(pr[2], pr[3]), gemm16::pack_bf16x2(pr[4], pr[5]), gemm16::pack_bf16x2(pr[6], pr[7]));
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const unsigned char* vr = Vt + (size_t)(16 * d + j16) * vp + (32 * p + 4 * g) * 2;             // V^T[dim 16 d + j16][keys 32 p + 4 g .. | 32 p + 16 + 4 g ..]
+                const uint2 va = *reinterpret_cast<const uint2*>(vr), vb = *reinterpret_cast<const uint2*>(vr + 32);
+                acc[d] = zmfma16x16x32(make_uint4(va.x, va.y, vb.x, vb.y), pb, acc[d]);
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (qi < n) {
+            const size_t row = (size_t)(r0 + (long long)qi * geo.ps);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = 16 * d + 4 * g;
+                if (col >= dv) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[d][r] / sum;
+                if (MODE == 0) {
+                    const float4 y = ldx4(src + row * lds_ + 2 * dv + col);
+                    o[0] *= y.x; o[1] *= y.y; o[2] *= y.z; o[3] *= y.w;
+                }
+                stx4(out + row * ldo + (MODE == 0 ? 0 : h * dv) + col, make_float4(o[0], o[1], o[2], o[3]));
+            }
+        }
+    }
 }
 template <int MODE, int NT, int DT>
-hipError_t raise_one() {
-    auto kern = k_zip_attn<MODE, NT, DT>;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+inline size_t zip_attn16_lds(int n) {
+    constexpr int NP = (NT + 1) / 2, np32 = NP * 32;
+    const int n2p = (2 * n - 1 + 1) & ~1;
+    return 16 + (size_t)np32 * kK16Pitch + (size_t)n2p * 8 + (size_t)DT * 16 * (np32 * 2 + 16) + 4 * 32 * kUs * sizeof(float);
+}
+template <int MODE, int NT, int DT>
+bool launch_attn16_nt(hipStream_t s, int heads, const gemm16::bf16_t* proj, int ldp, const float* pos, const gemm16::bf16_t* src, int lds_, gemm16::bf16_t* out, int ldo, SeqGeo geo, int dv) {
+    if (geo.n > 16 * NT) return false;
+    auto kern = k_zip_attn16<MODE, NT, DT>;
+    const size_t bytes = zip_attn16_lds<MODE, NT, DT>(geo.n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)geo.nseq, (unsigned)heads), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, dv);
+    return true;
+}
+// windows of up to 256 frames / sub-bands take the bf16-instruction kernel (at most 64 KB of LDS, 64 score registers); longer ones the fp32-instruction kernel on bf16 storage
+template <int MODE, int DT>
+void launch_attn16(hipStream_t s, int heads, const gemm16::bf16_t* proj, int ldp, const float* pos, const gemm16::bf16_t* src, int lds_, gemm16::bf16_t* out, int ldo, SeqGeo geo, int dv) {
+    if (launch_attn16_nt<MODE, 4, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 6, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+        launch_attn16_nt<MODE, 8, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 12, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+        launch_attn16_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv)) return;
+    launch_attn<MODE, DT, gemm16::bf16_t>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv);
 }
 template <int MODE, int DT>
+hipError_t raise_attn16_lds() {
+    hipError_t e = hipSuccess;
+    auto one = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    one(k_zip_attn16<MODE, 4, DT>); one(k_zip_attn16<MODE, 6, DT>); one(k_zip_attn16<MODE, 8, DT>); one(k_zip_attn16<MODE, 12, DT>); one(k_zip_attn16<MODE, 16, DT>);
+    return e;
+}
+template <int MODE, int NT, int DT, class TI>
+hipError_t raise_one() {
+    auto kern = k_zip_attn<MODE, NT, DT, TI>;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int MODE, int DT, class TI>
 hipError_t raise_attn_lds() {         // the long-window instantiations need more than the default 64 KB of dynamic LDS
-    hipError_t e = raise_one<MODE, 11, DT>();
-    if (e == hipSuccess) e = raise_one<MODE, 16, DT>();
-    if (e == hipSuccess) e = raise_one<MODE, 20, DT>();
-    if (e == hipSuccess) e = raise_one<MODE, 31, DT>();
+    hipError_t e = raise_one<MODE, 11, DT, TI>();
+    if (e == hipSuccess) e = raise_one<MODE, 16, DT, TI>();
+    if (e == hipSuccess) e = raise_one<MODE, 20, DT, TI>();
+    if (e == hipSuccess) e = raise_one<MODE, 31, DT, TI>();
     return e;
 }
 
@@ -1018,6 +1213,7 @@ struct ZLayer {
 struct ZLayer16 {              // bf16 copies of a layer's matrix weights (ade_gemm_dtype = bf16; csrc/ade_zip16.h)
     const gemm16::bf16_t *ff1_w1, *ff1_w2p;                // the ff1 rows of attn_ff1_w, ff1_out_w with its hidden units in k_zip_ff16's order
     const gemm16::bf16_t *ff_w1[2], *ff_w2p[2];            // feed_forward2, feed_forward3
+    const gemm16::bf16_t *attn_w, *nonlin_in_w, *nonlin_out_w, *sa_in_w[2], *sa_out_w[2], *cv_in_w[2], *cv_out_w[2];      // (N, K) row-major as the fp32 tensors
 };
 struct ZDense {                // one causal dense block: per layer the repacked weights [co][tap][ci] (per group), bias, norm affine; slopes per hist channel
     const gemm16::bf16_t* w16[2][8];                       // the same repacked weights in bf16 (bf16 path)
@@ -1048,7 +1244,9 @@ struct ZipEngine : SubEngine {
     ZLayer16 layers16[4][2]{};
     gemm16::bf16_t* ws16 = nullptr;
     gemm16::bf16_t *Dh16 = nullptr, *E016 = nullptr, *X16 = nullptr;     // dense history, dense-encoder input, the decoder pair's dense-block input
-    float *raw = nullptr, *Dlast = nullptr;                               // a dense layer's raw fp32 output (+ bias); the last layer's normalised output in fp32
+    gemm16::bf16_t *P16 = nullptr, *S16 = nullptr, *O16 = nullptr;       // a layer's attention projection (q | k | p per head), module projection, module core output
+    const gemm16::bf16_t *c2_w16 = nullptr, *up_w16[2] = {};
+    float* raw = nullptr;                                                 // a dense layer's raw fp32 output (+ bias)
     const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
     const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
     const float *mask_w = nullptr, *mask_b = nullptr, *phase_w = nullptr, *phase_b = nullptr;
@@ -1079,6 +1277,7 @@ struct ZipEngine : SubEngine {
     void dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd);
     void dense_block16(hipStream_t s, const ZDense& d, int groups, const gemm16::bf16_t* inp, int windows, int Fd);
     void layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo);
+    void layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo);
     void attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv);
     void dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff);
 };
@@ -1166,7 +1365,11 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
 
     slice(&e->c1_w, "enc_conv1_w", {C, 2}); slice(&e->c1_b, "enc_conv1_b", {C}); slice(&e->c1_g, "enc_norm1_w", {C}); slice(&e->c1_beta, "enc_norm1_b", {C});
     slice(&e->c1_slope, "enc_prelu1", {C});
-    bind(&e->c2_w, put_conv("enc_conv2_w", 0, C, C, 1, 3, C)); slice(&e->c2_b, "enc_conv2_b", {C}); slice(&e->c2_g, "enc_norm2_w", {C}); slice(&e->c2_beta, "enc_norm2_b", {C});
+    {
+        const size_t at = put_conv("enc_conv2_w", 0, C, C, 1, 3, C);
+        bind(&e->c2_w, at);
+        if (bf16 && ok) bind16(&e->c2_w16, place16(arena.data() + at, (size_t)C * 3 * C));
+    } slice(&e->c2_b, "enc_conv2_b", {C}); slice(&e->c2_g, "enc_norm2_w", {C}); slice(&e->c2_beta, "enc_norm2_b", {C});
     slice(&e->c2_slope, "enc_prelu2", {C});
     auto dense = [&](ZDense& d, const std::string& pre, int groups) {
         std::vector<float> slopes((size_t)groups * 4 * C, 1.0f);
@@ -1215,6 +1418,16 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
                 const Tensor* t = find(pre + "attn_ff1_w");
                 bind16(&w16.ff1_w1, place16(t->data + (size_t)ad * C, (size_t)e->ff1 * C));
                 bind16(&w16.ff1_w2p, place16_ffout(find(pre + "ff1_out_w")->data, e->ff1));
+                bind16(&w16.attn_w, place16(t->data, (size_t)ad * C));
+                bind16(&w16.nonlin_in_w, place16(find(pre + "nonlin_in_w")->data, (size_t)3 * e->hid * C));
+                bind16(&w16.nonlin_out_w, place16(find(pre + "nonlin_out_w")->data, (size_t)C * e->hid));
+                for (int i = 0; i < 2; ++i) {
+                    const std::string a = pre + "sa" + std::to_string(i + 1), cv = pre + "conv" + std::to_string(i + 1);
+                    bind16(&w16.sa_in_w[i], place16(find(a + "_in_w")->data, (size_t)vdim * C));
+                    bind16(&w16.sa_out_w[i], place16(find(a + "_out_w")->data, (size_t)C * vdim));
+                    bind16(&w16.cv_in_w[i], place16(find(cv + "_in_w")->data, (size_t)2 * C * C));
+                    bind16(&w16.cv_out_w[i], place16(find(cv + "_out_w")->data, (size_t)C * C));
+                }
                 for (int i = 0; i < 2; ++i) {
                     const std::string ff = pre + "ff" + std::to_string(i + 2);
                     const int fd = i ? e->ff3 : e->ffd;
@@ -1231,7 +1444,11 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
             slice(&e->out_scale[en], pre + "_out_scale", {C}); slice(&e->res_scale[en], pre + "_res_scale", {C});
         }
     }
-    for (int g = 0; g < 2; ++g) bind(&e->up_w[g], put_conv("dec_up_w", g * C * e->up, C * e->up, C, 1, 3, 2 * C * e->up));
+    for (int g = 0; g < 2; ++g) {
+        const size_t at = put_conv("dec_up_w", g * C * e->up, C * e->up, C, 1, 3, 2 * C * e->up);
+        bind(&e->up_w[g], at);
+        if (bf16 && ok) bind16(&e->up_w16[g], place16(arena.data() + at, (size_t)C * e->up * 3 * C));
+    }
     {
         const size_t a = put("dec_up_b", {2 * C * e->up});
         bind(&e->up_b[0], a); bind(&e->up_b[1], a + (size_t)C * e->up);
@@ -1299,14 +1516,17 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
         return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer weights failed"));
     for (auto& f : fix) *f.first = e->d_w + f.second;
     if (bf16) {
-        if ((e->ff1 % 64) || (e->ffd % 64) || (e->ff3 % 64) || e->depth != 4)
-            return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: ade_gemm_dtype = bf16 needs feed-forward widths that are multiples of 64 and dense blocks of depth 4 (the published geometry)"));
+        if ((e->ff1 % 64) || (e->ffd % 64) || (e->ff3 % 64) || e->depth != 4 || e->hid != 48 || e->H * e->vd != 48 || e->attn_dim != 144 || e->up != 2 || e->K != 15)
+            return bail(zfail(err, ADE_ERR_UNSUPPORTED, "zipenhancer: ade_gemm_dtype = bf16 is built for the published geometry (feed-forward widths multiples of 64, dense depth 4, 48 hidden / value "
+                                                        "channels, 4 heads of 16 + 16 + 4, kernel 15, up-scale 2); other geometries run f32"));
         if (hipMalloc((void**)&e->d_w16, arena16.size() * sizeof(uint16_t)) != hipSuccess ||
             hipMemcpy(e->d_w16, arena16.data(), arena16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
             return bail(zfail(err, ADE_ERR_DEVICE, "upload of the ZipEnhancer bf16 weights failed"));
         for (auto& f : fix16) *f.first = e->d_w16 + f.second;
     }
-    if (raise_attn_lds<0, 3>() != hipSuccess || raise_attn_lds<0, 4>() != hipSuccess || raise_attn_lds<1, 1>() != hipSuccess)
+    if (raise_attn_lds<0, 3, float>() != hipSuccess || raise_attn_lds<0, 4, float>() != hipSuccess || raise_attn_lds<1, 1, float>() != hipSuccess ||
+        (bf16 && (raise_attn_lds<0, 3, gemm16::bf16_t>() != hipSuccess || raise_attn_lds<1, 1, gemm16::bf16_t>() != hipSuccess || raise_attn16_lds<0, 3>() != hipSuccess ||
+                  raise_attn16_lds<1, 1>() != hipSuccess)))
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
@@ -1327,7 +1547,7 @@ int ZipEngine::reserve(int batch, std::string& err) {
     const size_t wide = (size_t)std::max({3 * hid, H * vd, 2 * C, ffd, ff3});
     const size_t Rt = std::min<size_t>(B, 8) * T * F;     // encoder snapshots: always carved, for calls of at most 8 windows whatever capacity was reserved
     const size_t dh = std::max(tok0 * 4 * C, R * 8 * C);
-    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
+    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, bf16 ? (size_t)64 : dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
                             J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, Rt * C, Rt * C, Rt * C, Rt * C, Rt * C};
     float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
                       &enc_tap[3], &enc_tap[4]};
@@ -1341,11 +1561,10 @@ int ZipEngine::reserve(int batch, std::string& err) {
     if (bf16) {
         if (ws16) (void)hipFree(ws16);
         ws16 = nullptr;
-        const size_t n_dh = (dh + 63) & ~(size_t)63, n_e0 = (tok0 * C + 63) & ~(size_t)63, n_x = (R * C + 63) & ~(size_t)63;
-        ZP_HIP(hipMalloc((void**)&ws16, (n_dh + n_e0 + n_x) * sizeof(gemm16::bf16_t)));
-        Dh16 = ws16; E016 = Dh16 + n_dh; X16 = E016 + n_e0;
+        const size_t n_dh = (dh + 63) & ~(size_t)63, n_e0 = (tok0 * C + 63) & ~(size_t)63, n_x = (R * C + 63) & ~(size_t)63, n_p = (R * (size_t)attn_dim + 63) & ~(size_t)63;
+        ZP_HIP(hipMalloc((void**)&ws16, (n_dh + n_e0 + 2 * n_x + 2 * n_p) * sizeof(gemm16::bf16_t)));
+        Dh16 = ws16; E016 = Dh16 + n_dh; X16 = E016 + n_e0; O16 = X16 + n_x; P16 = O16 + n_x; S16 = P16 + n_p;
         raw = E0;                                  // the fp32 E0 buffer is free on this path (E0 itself is bf16): a dense layer's raw output, [tokens][64]
-        Dlast = Dh;                                // the fp32 history buffer is free on this path: the LAST dense layer's normalised output in fp32, [group][tokens][64] (its fp32 consumers)
     }
     const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
     const size_t nblk0 = ((size_t)T * kZF + 255) / 256;         // the bf16 dense kernel emits one partial per 256-token tile
@@ -1388,20 +1607,21 @@ void ZipEngine::dense_block16(hipStream_t s, const ZDense& d, int groups, const 
             hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nblk, (double)TF, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = M * 16;
             hipLaunchKernelGGL(zip16::k_zip_hist_norm16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
-                               TF, i == depth - 1 ? Dlast + (size_t)g * M * C : nullptr, total16);
+                               TF, (float*)nullptr, total16);
         }
 }
 
 void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float* src, int lds_, float* out, int ldo, SeqGeo geo, int dv) {
     const int ldp = attn_dim + ff1;
     if (mode == 0) {
-        if (dv <= 48) launch_attn<0, 3>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
-        else launch_attn<0, 4>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
-    } else launch_attn<1, 1>(s, H, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+        if (dv <= 48) launch_attn<0, 3, float>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+        else launch_attn<0, 4, float>(s, 1, P, ldp, pos, src, lds_, out, ldo, geo, dv);
+    } else launch_attn<1, 1, float>(s, H, P, ldp, pos, src, lds_, out, ldo, geo, dv);
 }
 
 // one fused Zipformer2 encoder layer in place on x (R rows), sequences described by geo (:143-187)
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo) {
+    if (bf16) return layer16(s, w, w16, x, R, geo);
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
     // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
@@ -1426,8 +1646,8 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
         launch_proj64(s, Y, C, w.cv_in_w[i], w.cv_in_b[i], S1, 2 * C, 0, M, 2 * C);                             // (:321)
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
-        if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
+        if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, float>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0, float>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
         const int fd = i ? ff3 : ffd;
         if (bf16) {
@@ -1445,6 +1665,37 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
         else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
     }
     hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+}
+
+// The same layer on the bf16 path (csrc/ade_zip16.h): the residual stream x / Y stays fp32; every projection reads it through a loader that rounds to bf16 and stores bf16
+// (P16: q | k | p per head; S16: a module's projection; O16: a module's core output); the attention core and the convolution module read / write bf16 and compute in fp32;
+// the out-projections add into the fp32 stream; the feed-forward modules are k_zip_ff16.
+void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo) {
+    using namespace zip16;
+    const int M = (int)R, n = geo.n, vdim = H * vd;
+    launch_rows16<4, 5>(s, F32Rows{x, C}, w16.attn_w, Bf16BiasStore{P16, w.attn_ff1_b, attn_dim, 0}, M, attn_dim);                                 // (:148-153)
+    launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                                  // (:160)
+    launch_rows16<4, 5>(s, F32Rows{Y, C}, w16.nonlin_in_w, Bf16BiasStore{S16, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid);                              // (:305)
+    launch_attn16<0, 3>(s, 1, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, 3 * hid, O16, hid, geo, hid);   // (:154-159, :310-316)
+    launch_rows16<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, ResidualStore{Y, w.nonlin_out_b}, M, C);                                         // (:317, :167)
+    for (int i = 0; i < 2; ++i) {
+        launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);                                  // (:296)
+        launch_attn16<1, 1>(s, H, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, vdim, O16, vdim, geo, vd);  // (:297-300)
+        launch_rows16<3, 2>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], ResidualStore{Y, w.sa_out_b[i]}, M, C);                                      // (:301)
+        launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], Bf16BiasStore{S16, w.cv_in_b[i], 2 * C, 0}, M, 2 * C);                                // (:321)
+        const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
+        const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)
+        launch_rows16<4, 2>(s, B16Rows<2>{O16, C}, w16.cv_out_w[i], ResidualStore{Y, w.cv_out_b[i]}, M, C);                                         // (:339)
+        const int fd = i ? ff3 : ffd;
+        if (i == 0) launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
+        else if (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128)          // (nb | fs | rs sit side by side in the arena: the final norm rides in the module's store)
+            launch_zip_ff16<3>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.norm_bias, x, fd);                            // (:174-183)
+        else {
+            launch_zip_ff16<1>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
+            hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+        }
+    }
 }
 
 void ZipEngine::dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff) {        // (:782-792)
@@ -1471,7 +1722,7 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     if (bf16) {
         hipLaunchKernelGGL(k_zip_conv1_apply16, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
         dense_block16(s, enc_dense, 1, E016, B, kZF);
-        gemm64::launch(s, RowConvA{Dlast, C, 0, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
+        zip16::launch_rows16<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);                    // (:853)
     } else {
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
@@ -1497,9 +1748,9 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
         dense_block16(s, dec_dense, 2, X16, B, F);
     } else dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
-        const RowConvA up_a = bf16 ? RowConvA{Dlast + (size_t)g * R * C, C, 0, C, T, F, F, 1} : RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1};
-        gemm64::launch(s, up_a, gemm64::WeightB{up_w[g], 3 * C},
-                       SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
+        if (bf16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
+        else gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
+                            SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
     }
     hipLaunchKernelGGL(k_zip_heads, dim3((unsigned)((J + 15) / 16), (unsigned)kZF), dim3(256), 0, s, (const float*)U, (const float*)nrm2, up_slope, mask_w, mask_b,

@@ -145,7 +145,7 @@ PIPELINE_BATCH = 256      # rows per submission of a file that is larger than on
 
 def process_rows(session, rows: np.ndarray, batch: int = PIPELINE_BATCH) -> np.ndarray:
     """All slices of a file through the engine.  Up to ``batch`` rows: ONE ``process`` call.  More: the reference's loop over its slices
-    (Inference_GTCRN_ONNX.py:314-333) as a pipeline of ``batch``-row submissions (``ade_submit`` / ``ade_wait``, two in flight): the copy-in of
+    (Inference_GTCRN_ONNX.py:314-333) as a pipeline of ``batch``-row submissions (``ade_submit`` / ``ade_wait``, three in flight): the copy-in of
     batch k + 1 and the copy-out of batch k - 1 run under the kernels of batch k.  Same bits either way (rows are independent calls)."""
     n = len(rows)
     if n <= batch or not hasattr(session, "submit"):
@@ -154,7 +154,7 @@ def process_rows(session, rows: np.ndarray, batch: int = PIPELINE_BATCH) -> np.n
     out = np.empty((n, session.row_out), np.int16)
     tickets = []
     for i in range(0, n, batch):
-        if len(tickets) >= 2:
+        if len(tickets) >= 3:
             session.wait(tickets.pop(0))
         tickets.append(session.submit(rows[i:i + batch], out[i:i + batch]))
     for t in tickets:

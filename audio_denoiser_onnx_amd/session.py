@@ -200,7 +200,7 @@ class InferenceSession:
     # -- the pipelined form (ade_submit / ade_wait): a file of many batches overlaps copy-in (k + 1), kernels (k) and copy-out (k - 1) -------------------------------
     def submit(self, pcm: np.ndarray, out: np.ndarray, f32: Optional[np.ndarray] = None) -> int:
         """Enqueue one ``process_into`` call without waiting; returns the ticket ``wait`` takes.  The three buffers must stay alive and untouched until that
-        ``wait`` -- this object keeps references to them meanwhile.  At most ``pipe_depth`` (option, default 2) tickets between waits."""
+        ``wait`` -- this object keeps references to them meanwhile.  At most ``pipe_depth`` (option, default 3) tickets between waits."""
         B = pcm.shape[0]
         if pcm.dtype != np.int16 or out.dtype != np.int16 or pcm.shape != (B, self.row_in) or out.shape != (B, self.row_out):
             raise ValueError(f"expected int16 (B, {self.row_in}) -> int16 (B, {self.row_out})")

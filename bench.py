@@ -435,7 +435,7 @@ def main():
         # The same loop PIPELINED (ade_submit / ade_wait, include/ade.h): what a file of many batches costs per batch once the copy-in of call k + 1 and the copy-out of
         # call k - 1 run under call k's kernels.  A ring of `depth` page-locked buffer sets whose inputs differ per slot; wall clock over >= 20 back-to-back submissions.
         if hasattr(sess, "submit"):
-            depth = 2
+            depth = 3
             ring_in = [torch.from_numpy(np.roll(x_host, k, axis=0).copy()).pin_memory() for k in range(depth)]
             ring_out = [torch.empty((B, sess.row_out), dtype=torch.int16).pin_memory() for _ in range(depth)]
 

@@ -85,7 +85,7 @@ ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int1
 /* The same call PIPELINED: what the reference's driver does around its session is a LOOP of runs over the slices of a file (Inference_GTCRN_ONNX.py:314-333,
  * timed as a whole, :323-343).  ade_submit enqueues one ade_process call -- copy-in, kernels, copy-out on three streams tied by events -- and returns a ticket
  * without waiting; ade_wait(ticket) blocks until that call's output is in the caller's buffers and returns ITS status (a time-out of its launch included).
- * Up to `pipe_depth` (option, 2..4, default 2) submissions are in flight: the copy engines move call k + 1 in and call k - 1 out under call k's kernels, so a
+ * Up to `pipe_depth` (option, 2..4, default 3) submissions are in flight: the copy engines move call k + 1 in and call k - 1 out under call k's kernels, so a
  * file of many batches runs at max(kernel, copies) per batch instead of their sum.  Rules: `in`, `out_pcm`, `out_f32` stay the caller's and must stay valid and
  * untouched from ade_submit until ade_wait of the same ticket (page-locked buffers are DMA'd directly, pageable ones go through the slot's page-locked staging);
  * tickets may be waited for in any order, each exactly once; submitting into a full ring completes its oldest submission first (its status still waits for

@@ -7,7 +7,7 @@ from ade_testlib import golden_inputs, hipsim_library, make_session
 from audio_denoiser_onnx_amd.synth import synth_batch
 
 
-def _run_pipeline(sess, batches, depth=2, want_f32=False):
+def _run_pipeline(sess, batches, depth=3, want_f32=False):
     outs = [np.empty((len(b), sess.row_out), np.int16) for b in batches]
     f32s = [np.empty((len(b), sess.row_out), np.float32) if want_f32 else None for b in batches]
     tickets = []
@@ -33,7 +33,8 @@ def test_hipsim_submit_wait_equals_process():
     with pytest.raises(ValueError):
         sess.wait(12345)                      # never issued
     o = np.empty((1, sess.row_out), np.int16)
-    # the ring refuses a third un-waited ticket (its slot's status has not been collected); a ticket is waited for exactly once
+    # the ring refuses one more un-waited ticket than its depth (the slot's status has not been collected); a ticket is waited for exactly once
+    sess.set_option("pipe_depth", "2")
     t1 = sess.submit(batches[0], np.empty_like(o)); t2 = sess.submit(batches[1], np.empty_like(o))
     with pytest.raises(ValueError):
         sess.submit(batches[2], np.empty_like(o))
@@ -43,7 +44,7 @@ def test_hipsim_submit_wait_equals_process():
 
 
 def test_process_rows_splits_large_files_into_submissions():
-    """inference_gtcrn.process_rows: one process call up to a batch, a two-deep pipeline of submissions beyond it, rows stitched in order (host logic, no engine)."""
+    """inference_gtcrn.process_rows: one process call up to a batch, a three-deep pipeline of submissions beyond it, rows stitched in order (host logic, no engine)."""
     from audio_denoiser_onnx_amd.inference_gtcrn import process_rows
 
     class Fake:
@@ -73,7 +74,7 @@ def test_process_rows_splits_large_files_into_submissions():
     assert np.array_equal(process_rows(f, rows, batch=16), rows[:, :4] + 1) and f.calls == [("process", 10)]
     f = Fake()
     assert np.array_equal(process_rows(f, rows, batch=4), rows[:, :4] + 1)
-    assert f.calls == [("submit", 4), ("submit", 4), ("submit", 2)] and f.max_pending == 2 and not f.pending
+    assert f.calls == [("submit", 4), ("submit", 4), ("submit", 2)] and f.max_pending == 3 and not f.pending
 
 
 @pytest.mark.gpu
@@ -87,6 +88,7 @@ def test_gpu_submit_wait_equals_process_on_changing_inputs():
     batches = [np.ascontiguousarray(pool[k:k + B]) for k in range(n)]          # a sliding window: every call differs from its neighbours
     refs = [sess.process(b)[0] for b in batches[:6]] + [None] * (n - 12) + [sess.process(b)[0] for b in batches[-6:]]
     # pageable numpy buffers
+    sess.set_option("pipe_depth", "2")
     outs, _ = _run_pipeline(sess, batches, depth=2)
     for o, r in zip(outs, refs):
         assert r is None or np.array_equal(o, r)
