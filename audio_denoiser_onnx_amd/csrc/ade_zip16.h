@@ -44,13 +44,17 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
 // register.  Grid: (blocks per window) x windows through the XCD-contiguous map; a tile's rows all belong to ONE window, so the per-channel sum and sum of squares of
 // (product + bias) over the tile's rows are that window's InstanceNorm partial sums: partial[((win * nblk + blk) * 64 + c) * 2 + {sum, sumsq}] (fp64, k_zip_stats_final's
 // layout).  raw: [tokens][64] fp32 (product + bias).
-constexpr int kDPitch = 80, kDARows = 258;
-__global__ __launch_bounds__(256, 4) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
+constexpr int kDARows = 258;
+// CB = input channels per stage: 32 (80-byte rows, 38 KB of LDS: four workgroups per CU) or 64 (144-byte rows, 65 KB: two per CU, but half as many barriers and load round
+// trips per product -- the stage's loads are a microsecond or two away and one stage of look-ahead does not cover them)
+template <int CB>
+__global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
                                                         int F, int dil, const bf16_t* __restrict__ w, const float* __restrict__ bias, float* __restrict__ raw,
                                                         double* __restrict__ partial, int nblk) {
+    constexpr int kDPitch = 2 * CB + 16, kPieces = CB / 8, kU = CB / 32;          // bytes per staged row; 16-byte pieces per row; pieces per lane and row
     __shared__ __attribute__((aligned(16))) unsigned char As[kDARows * kDPitch];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * 64 * kDPitch];
-    __shared__ float red[4][64][2];
+    float (*red)[64][2] = reinterpret_cast<float (*)[64][2]>(Bs);          // [4][64][2]: the weights' buffer, dead once the stage loop is over
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, l31 = lane & 31, h = lane >> 5;
     const int id = gemm16::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x), win = id / nblk, blk = id - win * nblk;
     const int TF = T * F, m_blk = blk * 256;
@@ -85,36 +89,50 @@ __global__ __launch_bounds__(256, 4) void k_zip_dense16(const bf16_t* __restrict
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int ncb = cin / 32, nstage = 2 * ncb;
-    uint4 ra[5], rb[3];
-    auto fetch = [&](int st) {
-        const int kt = st / ncb, ci0 = (st - kt * ncb) * 32;
+    const int ncb = cin / CB, nstage = 2 * ncb;
+    uint4 ra[5][kU], rb0[kU], rb1[kU], rb2[kU];
+    auto fetch = [&](int st) __attribute__((always_inline)) {
+        const int kt = st / ncb, ci0 = (st - kt * ncb) * CB;
         const bool from_hist = ci0 < hist_n;
-        const bf16_t* src = from_hist ? hist_w + ci0 + 8 * pc : inp_w + (ci0 - hist_n) + 8 * pc;
+        const bf16_t* src = from_hist ? hist_w + ci0 + 8 * kU * pc : inp_w + (ci0 - hist_n) + 8 * kU * pc;
         const int ld = from_hist ? hist_ld : 64, shift = kt ? 0 : dil * F;
 #pragma unroll
         for (int hh = 0; hh < 5; ++hh) {
             const bool ok = kt ? sok1[hh] : sok0[hh];
-            ra[hh] = ld8_or_zero(ok, src + (size_t)(stok[hh] - (ok ? shift : 0)) * ld);       // (zeros by address: the loads stay in flight across this stage's products)
-        }
-        const bf16_t* wp = w + (size_t)sr * (6 * cin) + (size_t)(kt * 3) * cin + ci0 + 8 * pc;
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) rb[kf] = *reinterpret_cast<const uint4*>(wp + (size_t)kf * cin);
+            for (int u = 0; u < kU; ++u) ra[hh][u] = ld8_or_zero(ok, src + (size_t)(stok[hh] - (ok ? shift : 0)) * ld + (ok ? 8 * u : 0));       // (zeros by address: the loads stay in flight across this stage's products)
+        }
+        const bf16_t* wp = w + (size_t)sr * (6 * cin) + (size_t)(kt * 3) * cin + ci0 + 8 * kU * pc;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            rb0[u] = *reinterpret_cast<const uint4*>(wp + 8 * u);
+            rb1[u] = *reinterpret_cast<const uint4*>(wp + cin + 8 * u);
+            rb2[u] = *reinterpret_cast<const uint4*>(wp + 2 * cin + 8 * u);
+        }
     };
     fetch(0);
     for (int st = 0; st < nstage; ++st) {
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) *reinterpret_cast<uint4*>(As + (sr + 64 * hh) * kDPitch + 16 * pc) = ra[hh];
-        if (tid < 8) *reinterpret_cast<uint4*>(As + (256 + sr) * kDPitch + 16 * pc) = ra[4];
+        for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-        for (int kf = 0; kf < 3; ++kf) *reinterpret_cast<uint4*>(Bs + (kf * 64 + sr) * kDPitch + 16 * pc) = rb[kf];
+            for (int u = 0; u < kU; ++u) *reinterpret_cast<uint4*>(As + (sr + 64 * hh) * kDPitch + 16 * (kU * pc + u)) = ra[hh][u];
+        if (tid < 8) {
+#pragma unroll
+            for (int u = 0; u < kU; ++u) *reinterpret_cast<uint4*>(As + (256 + sr) * kDPitch + 16 * (kU * pc + u)) = ra[4][u];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            *reinterpret_cast<uint4*>(Bs + sr * kDPitch + 16 * (kU * pc + u)) = rb0[u];
+            *reinterpret_cast<uint4*>(Bs + (64 + sr) * kDPitch + 16 * (kU * pc + u)) = rb1[u];
+            *reinterpret_cast<uint4*>(Bs + (128 + sr) * kDPitch + 16 * (kU * pc + u)) = rb2[u];
+        }
         __syncthreads();
         if (st + 1 < nstage) fetch(st + 1);
 #pragma unroll
         for (int kf = 0; kf < 3; ++kf) {
             const unsigned mask = kf == 0 ? left : (kf == 2 ? right : 3u);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < CB / 16; ++ks) {
                 uint4 fa[2], fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = zero_unless((mask >> i) & 1u, *reinterpret_cast<const uint4*>(As + (wm + 32 * i + l31 + kf) * kDPitch + 32 * ks + 16 * h));
@@ -244,17 +262,23 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
         const unsigned char* W1s = lds + (cg & 1) * kF16Buf;
         const unsigned char* W2s = W1s + 64 * kF16Pitch;
         if (cg + 1 < ncg) request(cg + 1);
+        // the chunk's two 32-unit halves side by side: two independent chains of first products, then their activations, then two chains of second products -- the matrix
+        // cores work on one half while the vector pipe finishes the other
+        v16f hh[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {                                       // 32 hidden units at a time
-            v16f hh;
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hh[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) hh[c][r] = 0.0f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) hh = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), xb[ks], hh);
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) hh[c] = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), xb[ks], hh[c]);
+        uint4 hb[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
             float4 bb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(b1 + 64 * cg + 32 * c + 8 * q + 4 * h);
-            uint4 hb[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float a[8];
@@ -263,16 +287,18 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
                     const int r = 8 * s + e;
                     const float4 bq = bb[r >> 2];
                     const float bv = (r & 3) == 0 ? bq.x : ((r & 3) == 1 ? bq.y : ((r & 3) == 2 ? bq.z : bq.w));
-                    a[e] = swoosh_l16(hh[r] + bv);
+                    a[e] = swoosh_l16(hh[c][r] + bv);
                 }
-                hb[s] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+                hb[c][s] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
             }
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    acc2[jt] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * jt + l31) * kF16Pitch + 64 * c + 32 * s + 16 * h), hb[s], acc2[jt]);
         }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    acc2[jt] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * jt + l31) * kF16Pitch + 64 * c + 32 * s + 16 * h), hb[c][s], acc2[jt]);
         if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * kF16Buf);          // the other buffer: last read in iteration cg - 1, behind that iteration's barrier
         __syncthreads();
     }

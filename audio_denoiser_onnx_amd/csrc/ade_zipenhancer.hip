@@ -1247,6 +1247,7 @@ struct ZipEngine : SubEngine {
     gemm16::bf16_t *P16 = nullptr, *S16 = nullptr, *O16 = nullptr;       // a layer's attention projection (q | k | p per head), module projection, module core output
     const gemm16::bf16_t *c2_w16 = nullptr, *up_w16[2] = {};
     float* raw = nullptr;                                                 // a dense layer's raw fp32 output (+ bias)
+    int dense_cb = getenv("ADE_ZIP_DENSE_CB") ? atoi(getenv("ADE_ZIP_DENSE_CB")) : 32;      // input channels per stage of k_zip_dense16 (measurement knob)
     const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
     const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
     const float *mask_w = nullptr, *mask_b = nullptr, *phase_w = nullptr, *phase_b = nullptr;
@@ -1602,8 +1603,12 @@ void ZipEngine::dense_block16(hipStream_t s, const ZDense& d, int groups, const 
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            hipLaunchKernelGGL(zip16::k_zip_dense16, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
-                               1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
+            if (dense_cb == 64)
+                hipLaunchKernelGGL(zip16::k_zip_dense16<64>, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
+                                   1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
+            else
+                hipLaunchKernelGGL(zip16::k_zip_dense16<32>, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
+                                   1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
             hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nblk, (double)TF, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = M * 16;
             hipLaunchKernelGGL(zip16::k_zip_hist_norm16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
