@@ -223,14 +223,13 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
     __shared__ __attribute__((aligned(16))) unsigned char lds[kF16Lds];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31;
-    uint4 xb[4];
+    uint4 xb0, xb1, xb2, xb3;          // (named, not an array: as arrays these operands and the prefetched weight pieces below were kept in scratch memory by the compiler)
     {
         const float* src = xin + (size_t)(row < M ? row : M - 1) * 64 + 8 * h;
         float4 t[8];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { t[2 * ks] = *reinterpret_cast<const float4*>(src + 16 * ks); t[2 * ks + 1] = *reinterpret_cast<const float4*>(src + 16 * ks + 4); }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xb[ks] = pack8(t[2 * ks], t[2 * ks + 1]);
+        xb0 = pack8(t[0], t[1]); xb1 = pack8(t[2], t[3]); xb2 = pack8(t[4], t[5]); xb3 = pack8(t[6], t[7]);
     }
     v16f acc2[2];
 #pragma unroll
@@ -239,20 +238,18 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
         for (int r = 0; r < 16; ++r) acc2[jt][r] = 0.0f;
     // staging: chunk cg of W1 = rows 64 cg .. + 63 (128 bytes each), of W2p = columns 64 cg .. + 63 of its 64 rows: 512 16-byte pieces each, two + two per thread
     const int sr = tid >> 3, sp = tid & 7;
-    uint4 p1[2], p2[2];
-    auto request = [&](int cg) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            p1[u] = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr + 32 * u) * 64 + 8 * sp);
-            p2[u] = *reinterpret_cast<const uint4*>(w2p + (size_t)(sr + 32 * u) * fd + 64 * cg + 8 * sp);
-        }
+    uint4 p1a, p1b, p2a, p2b;
+    auto request = [&](int cg) __attribute__((always_inline)) {
+        p1a = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr) * 64 + 8 * sp);
+        p1b = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr + 32) * 64 + 8 * sp);
+        p2a = *reinterpret_cast<const uint4*>(w2p + (size_t)sr * fd + 64 * cg + 8 * sp);
+        p2b = *reinterpret_cast<const uint4*>(w2p + (size_t)(sr + 32) * fd + 64 * cg + 8 * sp);
     };
-    auto deposit = [&](unsigned char* buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            *reinterpret_cast<uint4*>(buf + (sr + 32 * u) * kF16Pitch + 16 * sp) = p1[u];
-            *reinterpret_cast<uint4*>(buf + (64 + sr + 32 * u) * kF16Pitch + 16 * sp) = p2[u];
-        }
+    auto deposit = [&](unsigned char* buf) __attribute__((always_inline)) {
+        *reinterpret_cast<uint4*>(buf + sr * kF16Pitch + 16 * sp) = p1a;
+        *reinterpret_cast<uint4*>(buf + (sr + 32) * kF16Pitch + 16 * sp) = p1b;
+        *reinterpret_cast<uint4*>(buf + (64 + sr) * kF16Pitch + 16 * sp) = p2a;
+        *reinterpret_cast<uint4*>(buf + (64 + sr + 32) * kF16Pitch + 16 * sp) = p2b;
     };
     const int ncg = fd / 64;
     request(0);
@@ -272,7 +269,7 @@ __global__ __launch_bounds__(256) void k_zip_ff16(const float* xin, const bf16_t
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) hh[c] = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), xb[ks], hh[c]);
+            for (int c = 0; c < 2; ++c) hh[c] = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), ks == 0 ? xb0 : (ks == 1 ? xb1 : (ks == 2 ? xb2 : xb3)), hh[c]);
         uint4 hb[2][2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {

@@ -480,20 +480,19 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
         for (int jt = 0; jt < 4; ++jt) acc2[t][jt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
     // staging: chunk cg of W1 = rows 64 cg .. + 63 (64 k each), of W2 = columns 64 cg .. + 63 of its 64 rows: 1024 float4 each, two per thread
     const int sr = tid >> 4, sk = (tid & 15) * 4;                           // staged row (0..31, + 32), first of its four columns
-    float4 p1[2], p2[2];
+    float4 p1a, p1b, p2a, p2b;            // (named, not arrays: as `float4 p1[2], p2[2]` written by one lambda and read by another they lived in scratch memory -- 80 bytes per lane, a
+                                          //  scratch store + load per chunk on the kernel's critical path; found in round 5 with -Rpass-analysis=kernel-resource-usage)
     auto request = [&](int cg) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            p1[h] = *reinterpret_cast<const float4*>(w1 + (size_t)(64 * cg + sr + 32 * h) * 64 + sk);
-            p2[h] = *reinterpret_cast<const float4*>(w2 + (size_t)(sr + 32 * h) * fd + 64 * cg + sk);
-        }
+        p1a = *reinterpret_cast<const float4*>(w1 + (size_t)(64 * cg + sr) * 64 + sk);
+        p1b = *reinterpret_cast<const float4*>(w1 + (size_t)(64 * cg + sr + 32) * 64 + sk);
+        p2a = *reinterpret_cast<const float4*>(w2 + (size_t)sr * fd + 64 * cg + sk);
+        p2b = *reinterpret_cast<const float4*>(w2 + (size_t)(sr + 32) * fd + 64 * cg + sk);
     };
     auto deposit = [&](float* buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<float4*>(buf + (sr + 32 * h) * kPitch + sk) = p1[h];
-            *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32 * h) * kPitch + sk) = p2[h];
-        }
+        *reinterpret_cast<float4*>(buf + sr * kPitch + sk) = p1a;
+        *reinterpret_cast<float4*>(buf + (sr + 32) * kPitch + sk) = p1b;
+        *reinterpret_cast<float4*>(buf + (kFfChunk + sr) * kPitch + sk) = p2a;
+        *reinterpret_cast<float4*>(buf + (kFfChunk + sr + 32) * kPitch + sk) = p2b;
     };
     const int ncg = fd / kFfChunk;
     request(0);
