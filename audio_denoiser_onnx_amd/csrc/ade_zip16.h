@@ -26,7 +26,13 @@ using gemm16::pack_bf16x2;
 using gemm16::v16f;
 using gemm16::zero_unless;
 
-__device__ __forceinline__ float softplus16(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
+// F.softplus (threshold 20) straight on the transcendental units: ln(1 + e^x) = ln 2 * v_log_f32(1 + v_exp_f32(x log2 e)) -- no range fix-ups (1 + e^x lies in [1, 5e8] where it
+// is used; e^x flushing to 0 below -87 gives the exact limit).  __expf / __logf wrap the same two instructions in denormal scaling and compares: 28 VALU instructions per
+// activation in k_zip_ff16 (4554 per wavefront against 80 matrix instructions, profiles/r05_i_zip_bf16_pmc_summary.txt: the module was VALU-bound), ~9 this way.
+__device__ __forceinline__ float softplus16(float x) {
+    const float sp = 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(x * kLog2e));
+    return x > 20.0f ? x : sp;
+}
 __device__ __forceinline__ float swoosh_l16(float x) { return softplus16(x - 4.0f) - 0.08f * x; }       // (Export_ZipEnhancer.py:135-136)
 __device__ __forceinline__ float swoosh_r16(float x) { return softplus16(x - 1.0f) - 0.08f * x; }       // (:138)
 

@@ -55,7 +55,9 @@ constexpr int kChunkTok = 2048;                                             // t
 // F.softplus (threshold 20) on the hardware exp2 / log2 units (v_exp_f32, v_log_f32, ~1 ulp each): log(1 + e^x) loses RELATIVE accuracy where e^x < 1e-7,
 // i.e. where the result is below 1e-7 ABSOLUTE next to the -0.08 x term of the Swoosh it feeds -- far inside the parity tolerance; libm's expf + log1pf cost
 // ~50 VALU instructions per element and made the Swoosh-loading GEMMs VALU-bound (19 % matrix-core busy, profiles/r02_zipenhancer_mfma_busy.txt).
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : __logf(1.0f + __expf(x)); }
+// (round 5: the two instructions themselves -- __builtin_amdgcn_exp2f / __builtin_amdgcn_logf -- instead of __expf / __logf, which wrap them in denormal scaling and compares
+//  that 1 + e^x in [1, 5e8] never needs: ~9 VALU instructions per activation instead of ~28; the Swoosh-loading kernels were VALU-bound on it)
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(x * kLog2e)); }
 __device__ __forceinline__ float swoosh_l(float x) { return softplus_f(x - 4.0f) - 0.08f * x; }        // (:135-136), offset folded into the bias
 __device__ __forceinline__ float swoosh_r(float x) { return softplus_f(x - 1.0f) - 0.08f * x; }        // (:138)
 __device__ __forceinline__ float sigmoid_p(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -631,7 +633,8 @@ struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_f
 // MODE 1 (SelfAttention): value = head h's dv <= 16 columns of the value projection; DT = 1.
 // NT = key tiles held in registers (n <= 16 NT).
 constexpr int kQKs = 20;                    // floats per staged Q / K row (16 + 4: conflict-free ds_read_b128, as in ade_gemm.h)
-constexpr int kUs = 18;                     // floats per scratch row
+constexpr int kUs = 20;                     // floats per scratch row: 4 rows = 80 words = 16 mod 64, so the four lane groups of a skew write / read (rows 4 g + r, 16 lanes each) land on four
+                                            // disjoint sets of 16 banks (18 put group g + 1 eight banks beside group g: 45 % of the attention kernels' LDS cycles were bank conflicts)
 // TI: element type of proj / src / out -- float (the parity path) or bf16 (ade_gemm_dtype = bf16: the operands are stored in HBM as bf16 and widened on their way into LDS /
 // the registers; scores, softmax and accumulation are fp32 either way)
 template <int MODE, int NT, int DT, class TI>

@@ -215,6 +215,7 @@ static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + 
 static inline void __builtin_amdgcn_wave_barrier() { (void)::hipsim::wave_exchange(0u, ::hipsim::lane_id()); }
 static inline long long clock64() { return 0; }
 static inline float __builtin_amdgcn_exp2f(float a) { return exp2f(a); }
+static inline float __builtin_amdgcn_logf(float a) { return log2f(a); }      // v_log_f32 = log2
 namespace hipsim { extern unsigned char dyn_smem[]; }
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::hipsim::dyn_smem);
 static inline float __fdividef(float a, float b) { return a / b; }
