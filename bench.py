@@ -112,7 +112,7 @@ def source_sha1() -> str:
 def workload_traffic(name: str, dtype: str, B: int, default_B: int):
     """Fabric-side bytes of one step of a GEMM-family workload from the committed FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload <name>` (tools/pmc_traffic_workload.sh);
     the newest round's file wins.  -> (bytes per step scaled to B rows, note) or (None, None)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(REPO, "profiles", f"{rnd}_{name}_{dtype}_traffic.json")) as f:
                 tp = json.load(f)
@@ -121,6 +121,46 @@ def workload_traffic(name: str, dtype: str, B: int, default_B: int):
         except (OSError, KeyError, ValueError):
             continue
     return None, None
+
+
+def kernel_family_roofline(name: str, dtype: str, B: int, frames: int):
+    """Per-kernel roofline of a workload's DOMINANT product family (the dominant kernel priced on its own, beside the whole-step figure): the family's
+    algorithmic flops per step (from the model's dimensions) / the summed device time of its launches in the committed rocprofv3 --kernel-trace --stats summary of the same
+    command (profiles/rNN_z_<workload>_<dtype>_kernel_stats.csv, the newest round's file) / the dtype's dense matrix peak.  -> dict or None (no committed summary)."""
+    import csv
+    peak = FP32_PEAK_TFLOPS if dtype == "f32" else BF16_PEAK_TFLOPS
+    if name == "zipenhancer":
+        from audio_denoiser_onnx_amd import zipenhancer as zp
+        cfg = zp.ZipConfig()
+        C, F0, F = cfg.channels, 201, zp.freq_len()
+        dense_macs = sum(6 * C * C * (i + 1) for i in range(cfg.dense_depth)) * frames * (F0 + 2 * F)
+        pat, what, flops, default_B = "k_zip_dense", "the causal dense blocks' layers (12 launches per step: 4 encoder + 2 x 4 decoder layers, cin 64 .. 256, implicit GEMM)", 2.0 * dense_macs * B, 128
+    elif name == "melband":
+        di, rows = 8 * 64, 60 * frames
+        fam = 2.0 * rows * 384 * ((3 * di + 8) + di + 2 * 4 * 384) * 2 * 6                        # q|k|v|gates, out, FFN in + out; two transformers per depth, depth 6
+        pat = "gemm16::k_gemm16<" if dtype == "bf16" else "gemm::k_gemm128<"
+        what, flops, default_B = "the transformers' Linear products (in-projection, out-projection, FFN in / out: 4 launches per transformer, 12 transformers)", fam * B, 32
+    elif name == "mossformer":
+        pat, what, default_B = "gemm::k_gemm128<", "the FLASH layers' Linear products (non-batched 128 x 128 tiles)", 64
+        flops = 24 * 2.0 * frames * (512 * 2176 + 1024 * 512 + 512 * 256 + 256 * 512 + 2 * 256 * 256 + 256 * 512) * B
+    else:
+        return None
+    for rnd in ("r05", "r04"):
+        path = os.path.join(REPO, "profiles", f"{rnd}_z_{name}_{dtype}_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        rows_ = list(csv.DictReader(open(path)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows_)
+        fam_rows = [r for r in rows_ if pat in r["Name"]]
+        if not fam_rows or tot <= 0:
+            continue
+        steps_in_trace = 4 if name == "zipenhancer" else 4                                   # bench.py --steps 3 --warmup 1: four steps in the trace
+        fam_ns = sum(float(r["TotalDurationNs"]) for r in fam_rows) / steps_in_trace
+        tf = flops * (default_B / B) / (fam_ns * 1e-9) / 1e12 if B else 0.0                  # the summary was taken at the workload's BASELINE batch
+        return {"kernel_family": pat, "what": what, "launches_per_step": int(sum(int(r["Calls"]) for r in fam_rows) / steps_in_trace), "ms_per_step": round(fam_ns * 1e-6, 3),
+                "share_of_step_pct": round(100.0 * fam_ns * steps_in_trace / tot, 1), "algorithmic_tflop_per_step": round(flops * (default_B / B) / 1e12, 3),
+                "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "source": f"profiles/{rnd}_z_{name}_{dtype}_kernel_stats.csv"}
+    return None
 
 
 def other_workload_line(name: str, steps: int, local_rank: int, stream, cpu_budget_s: float = 0.0, dtype: str = "f32"):
@@ -156,6 +196,9 @@ def other_workload_line(name: str, steps: int, local_rank: int, stream, cpu_budg
             "rtf": float(f"{dt / audio:.3e}"), "dtype": dtype, "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                                                              "frac": round(tf / peak, 4), "traffic": traffic, "traffic_note": note,
                                                                              "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}}
+    fam = kernel_family_roofline(name, dtype, B, sess.frames)
+    if fam:
+        line["roofline"]["dominant_kernel"] = fam
     if wl.get("target_rtf"):
         line["target_rtf"] = wl["target_rtf"]
     del sess, d_in, d_out
@@ -543,7 +586,8 @@ def main():
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "peak_note": "dense f32-MFMA rate (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s; flops = 2 x MACs of the model's matrix products per row x rows",
                     "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}
-        for cand in (f"r04_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json"):
+        for cand in (f"r05_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r04_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json",
+                     f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json"):
             if "mfma_busy" in roofline:
                 break
             try:
@@ -553,6 +597,9 @@ def main():
             except (OSError, ValueError):
                 pass
         roofline["traffic"], roofline["traffic_note"] = workload_traffic(args.workload, args.dtype, B, default_B)
+        fam = kernel_family_roofline(args.workload, args.dtype, B, sess.frames)
+        if fam:
+            roofline["dominant_kernel"] = fam
         if world == 1 and args.cpu_seconds > 0 and wl["cpu"] is not None:
             cpu = wl["cpu"]()
 
