@@ -503,5 +503,125 @@ inline void launch_rows16(hipStream_t s, const AL& a, const bf16_t* w, const ST&
     hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w, st, M, N);
 }
 
+
+// ---- an out-projection and the NEXT module's in-projection in one launch ----------------------------------------------------------------------------------------------
+//   y[m] += A1(m) W1^T + b1        (the fp32 residual stream, 64 columns: exactly k_rows16<KS1, 2, AL, ResidualStore>)
+//   out2[m] = bf16(y[m] W2^T + b2)  (exactly k_rows16<4, NT2, F32Rows, Bf16BiasStore> on the updated row)
+// The updated row never leaves the wavefront: it goes from the first product's accumulators through the wave's LDS tile (where the stream's old value and the bias are added
+// and the row is stored, whole lines) straight into the second product's operand registers -- one read of the 256-byte stream row per pair instead of two, one launch instead
+// of two; the values are those of the two-kernel form bit for bit (the second product rounds the fp32 row it would have re-read).  LDS: the epilogue tile (the first weights
+// alias it until the first product is done) + the second weights: 44 - 53 KB, three workgroups per CU.
+template <int KS1, int NT2>
+constexpr int chain16_lds() { return 4 * 32 * 68 * 4 + 32 * NT2 * 144; }
+template <int KS1, int NT2, class AL>
+__global__ __launch_bounds__(256) void k_rows16_chain(AL a_of, const bf16_t* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y, const bf16_t* __restrict__ w2,
+                                                      const float* __restrict__ b2, bf16_t* __restrict__ out2, int ld2, int M, int N2) {
+    constexpr int kP1 = 32 * KS1 + 16, kP2 = 144, kE = 4 * 32 * 68 * 4;
+    static_assert(64 * kP1 <= kE, "the first weights alias the epilogue tile");
+    HIP_DYNAMIC_SHARED(unsigned char, lds)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31;
+    uint4 xa[KS1];
+    {
+        const int mc = row < M ? row : M - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) xa[ks] = a_of(mc, ks, h);
+    }
+    unsigned char* W2s = lds + kE;
+    for (int i = tid; i < 64 * 2 * KS1; i += 256) {
+        const int n = i / (2 * KS1), pc = i - n * (2 * KS1);
+        *reinterpret_cast<uint4*>(lds + n * kP1 + 16 * pc) = *reinterpret_cast<const uint4*>(w1 + (size_t)n * (16 * KS1) + 8 * pc);
+    }
+    for (int i = tid; i < 32 * NT2 * 8; i += 256) {
+        const int n = i >> 3, pc = i & 7;
+        *reinterpret_cast<uint4*>(W2s + n * kP2 + 16 * pc) = *reinterpret_cast<const uint4*>(w2 + (size_t)(n < N2 ? n : N2 - 1) * 64 + 8 * pc);
+    }
+    __syncthreads();
+    v16f acc1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[t][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc1[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(lds + (32 * t + l31) * kP1 + 32 * ks + 16 * h), xa[ks], acc1[t]);
+    __syncthreads();                                                    // the first weights are dead: the wave's tile takes their place
+    float* E = reinterpret_cast<float*>(lds) + wave * 32 * 68;
+    const int c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(E + l31 * 68 + 32 * jt + 8 * q + 4 * h) = make_float4(acc1[jt][4 * q], acc1[jt][4 * q + 1], acc1[jt][4 * q + 2], acc1[jt][4 * q + 3]);
+    wave_sync();
+    {   // the stream's update, whole rows; the new row goes back into the tile for the second product
+        const float4 bb = *reinterpret_cast<const float4*>(b1 + c4);
+        float4 old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = row0 + (lane >> 4) + 4 * u; old[u] = *reinterpret_cast<const float4*>(y + (size_t)(m < M ? m : M - 1) * 64 + c4); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+            const float4 v = *reinterpret_cast<const float4*>(E + rl * 68 + c4);
+            const float4 o = make_float4(old[u].x + (v.x + bb.x), old[u].y + (v.y + bb.y), old[u].z + (v.z + bb.z), old[u].w + (v.w + bb.w));
+            if (m < M) *reinterpret_cast<float4*>(y + (size_t)m * 64 + c4) = o;
+            *reinterpret_cast<float4*>(E + rl * 68 + c4) = o;
+        }
+    }
+    wave_sync();
+    uint4 xb0, xb1, xb2, xb3;
+    {
+        const float* er = E + l31 * 68 + 8 * h;
+        xb0 = pack8(*reinterpret_cast<const float4*>(er), *reinterpret_cast<const float4*>(er + 4));
+        xb1 = pack8(*reinterpret_cast<const float4*>(er + 16), *reinterpret_cast<const float4*>(er + 20));
+        xb2 = pack8(*reinterpret_cast<const float4*>(er + 32), *reinterpret_cast<const float4*>(er + 36));
+        xb3 = pack8(*reinterpret_cast<const float4*>(er + 48), *reinterpret_cast<const float4*>(er + 52));
+    }
+    wave_sync();
+    v16f acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+            acc2[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * t + l31) * kP2 + 32 * ks + 16 * h), ks == 0 ? xb0 : (ks == 1 ? xb1 : (ks == 2 ? xb2 : xb3)), acc2[t]);
+#pragma unroll
+    for (int g = 0; g < NT2 / 2; ++g) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(E + l31 * 68 + 32 * jt + 8 * q + 4 * h) =
+                    make_float4(acc2[2 * g + jt][4 * q], acc2[2 * g + jt][4 * q + 1], acc2[2 * g + jt][4 * q + 2], acc2[2 * g + jt][4 * q + 3]);
+        wave_sync();
+        const int n = 64 * g + c4;
+        if (n < N2) {
+            const float4 bb = *reinterpret_cast<const float4*>(b2 + n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+                if (m >= M) continue;
+                const float4 v = *reinterpret_cast<const float4*>(E + rl * 68 + c4);
+                *reinterpret_cast<uint2*>(out2 + (size_t)m * ld2 + n) = gemm16::pack_bf16x4(make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w));
+            }
+        }
+        wave_sync();
+    }
+}
+template <int KS1, int NT2, class AL>
+inline void launch_rows16_chain(hipStream_t s, const AL& a, const bf16_t* w1, const float* b1, float* y, const bf16_t* w2, const float* b2, bf16_t* out2, int ld2, int M, int N2) {
+    static_assert(NT2 % 2 == 0, "whole 64-column groups");
+    if (M <= 0) return;
+    auto kern = k_rows16_chain<KS1, NT2, AL>;
+    constexpr int bytes = chain16_lds<KS1, NT2>();
+    static bool raised = false;
+    if (bytes > 48 * 1024 && !raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); raised = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w1, b1, y, w2, b2, out2, ld2, M, N2);
+}
+
 }  // namespace zip16
 }  // namespace ade

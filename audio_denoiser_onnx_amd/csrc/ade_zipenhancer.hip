@@ -1249,6 +1249,7 @@ struct ZipEngine : SubEngine {
     gemm16::bf16_t *P16 = nullptr, *S16 = nullptr, *O16 = nullptr;       // a layer's attention projection (q | k | p per head), module projection, module core output
     const gemm16::bf16_t *c2_w16 = nullptr, *up_w16[2] = {};
     float* raw = nullptr;                                                 // a dense layer's raw fp32 output (+ bias)
+    bool zip_chain = !(getenv("ADE_ZIP_CHAIN") && atoi(getenv("ADE_ZIP_CHAIN")) == 0);
     int dense_cb = getenv("ADE_ZIP_DENSE_CB") ? atoi(getenv("ADE_ZIP_DENSE_CB")) : 32;      // input channels per stage of k_zip_dense16 (measurement knob)
     const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
     const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
@@ -1680,16 +1681,21 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
 void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo) {
     using namespace zip16;
     const int M = (int)R, n = geo.n, vdim = H * vd;
+    const bool chain = zip_chain;                    // out-projection + next in-projection pairs in one launch (k_rows16_chain; ADE_ZIP_CHAIN=0: the two-kernel form, same bits)
     launch_rows16<4, 5>(s, F32Rows{x, C}, w16.attn_w, Bf16BiasStore{P16, w.attn_ff1_b, attn_dim, 0}, M, attn_dim);                                 // (:148-153)
     launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                                  // (:160)
     launch_rows16<4, 5>(s, F32Rows{Y, C}, w16.nonlin_in_w, Bf16BiasStore{S16, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid);                              // (:305)
     launch_attn16<0, 3>(s, 1, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, 3 * hid, O16, hid, geo, hid);   // (:154-159, :310-316)
-    launch_rows16<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, ResidualStore{Y, w.nonlin_out_b}, M, C);                                         // (:317, :167)
+    if (chain) launch_rows16_chain<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, w.nonlin_out_b, Y, w16.sa_in_w[0], w.sa_in_b[0], S16, vdim, M, vdim);   // (:317, :167) + (:296)
+    else launch_rows16<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, ResidualStore{Y, w.nonlin_out_b}, M, C);                                    // (:317, :167)
     for (int i = 0; i < 2; ++i) {
-        launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);                                  // (:296)
+        if (!(chain && i == 0)) launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);          // (:296)
         launch_attn16<1, 1>(s, H, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, vdim, O16, vdim, geo, vd);  // (:297-300)
-        launch_rows16<3, 2>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], ResidualStore{Y, w.sa_out_b[i]}, M, C);                                      // (:301)
-        launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], Bf16BiasStore{S16, w.cv_in_b[i], 2 * C, 0}, M, 2 * C);                                // (:321)
+        if (chain) launch_rows16_chain<3, 4>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], w.sa_out_b[i], Y, w16.cv_in_w[i], w.cv_in_b[i], S16, 2 * C, M, 2 * C);   // (:301) + (:321)
+        else {
+            launch_rows16<3, 2>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], ResidualStore{Y, w.sa_out_b[i]}, M, C);                                  // (:301)
+            launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], Bf16BiasStore{S16, w.cv_in_b[i], 2 * C, 0}, M, 2 * C);                            // (:321)
+        }
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)

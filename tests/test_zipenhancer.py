@@ -423,6 +423,21 @@ def test_gpu_zipenhancer_bf16_full_batch_properties(model):
     assert snr >= 30.0
 
 
+@pytest.mark.gpu
+def test_gpu_zipenhancer_bf16_chained_products_equal_the_two_kernel_form(model, monkeypatch):
+    """k_rows16_chain (an out-projection and the next module's in-projection in one launch, the updated residual row handed over inside the wavefront) against the two-kernel
+    form (ADE_ZIP_CHAIN=0, read when the engine is created): the same bits."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch
+    _, _, _, t = model
+    blob, x, outs = pack_blob(t), synth_batch(5, 16000), []
+    for ch in ("1", "0"):
+        monkeypatch.setenv("ADE_ZIP_CHAIN", ch)
+        with InferenceSession(weights=blob, metadata=zp.metadata(16000, gemm_dtype="bf16")) as sess:
+            outs.append(sess.process(x, want_f32=True))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.abs(outs[0][0]).max() > 50
+
+
 @pytest.mark.hipsim
 @pytest.mark.skipif(not os.environ.get("ADE_SLOW_TESTS"), reason="4 minutes under the host simulator; set ADE_SLOW_TESTS=1")
 def test_hipsim_zipenhancer_bf16_close_to_f32(model):
