@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
     constexpr int kDPitch = 2 * CB + 16, kPieces = CB / 8, kU = CB / 32;          // bytes per staged row; 16-byte pieces per row; pieces per lane and row
     __shared__ __attribute__((aligned(16))) unsigned char As[kDARows * kDPitch];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * 64 * kDPitch];
-    float (*red)[64][2] = reinterpret_cast<float (*)[64][2]>(Bs);          // [4][64][2]: the weights' buffer, dead once the stage loop is over
+    double (*red)[64][2] = reinterpret_cast<double (*)[64][2]>(Bs);        // [4][64][2]: the weights' buffer, dead once the stage loop is over
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, l31 = lane & 31, h = lane >> 5;
     const int id = gemm16::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x), win = id / nblk, blk = id - win * nblk;
     const int TF = T * F, m_blk = blk * 256;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
     for (int j = 0; j < 2; ++j) {
         const int co = 32 * j + l31;
         const float b = bias[co];
-        float s = 0.0f, ss = 0.0f;
+        double s = 0.0, ss = 0.0;                    // (fp64 from the first addend: E[x^2] - mean^2 of a channel with a large mean does not survive fp32 sums)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
                 if (m < TF) {
                     const float v = acc[i][j][r] + b;
                     raw_w[(size_t)m * 64 + co] = v;
-                    s += v;
-                    ss = fmaf(v, v, ss);
+                    s += (double)v;
+                    ss = fma((double)v, (double)v, ss);
                 }
             }
         s += __shfl_xor(s, 32, 64);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
     __syncthreads();
     if (tid < 128) {
         const int c = tid >> 1, q = tid & 1;
-        const double v = ((double)red[0][c][q] + (double)red[1][c][q]) + ((double)red[2][c][q] + (double)red[3][c][q]);
+        const double v = (red[0][c][q] + red[1][c][q]) + (red[2][c][q] + red[3][c][q]);
         partial[(((size_t)win * nblk + blk) * 64 + c) * 2 + q] = v;
     }
 }

@@ -292,14 +292,19 @@ __global__ __launch_bounds__(256) void k_zip_hist_norm(float* __restrict__ hist,
 // in the operand register): a third of the global / L2 operand traffic, a third of the staging stores and barriers per MFMA.  256 tokens x 64 output
 // channels per workgroup, wavefront tile 64 x 64, pipeline and LDS layout as in ade_gemm64.h.  k runs (kt, channel block, kf, channel) instead of
 // (tap, channel): the same sum in another order.
+// (round 5) Tiles never straddle a window -- grid = (blocks per window) x windows -- so the epilogue's per-channel sums of (product + bias) and of its square over the tile's rows
+// ARE the layer's InstanceNorm partial sums: partial[((win * nblk + blk) * 64 + c) * 2 + {sum, sumsq}] (k_zip_stats_final's layout); the separate statistics pass over the
+// output (k_zip_stats_partial: 12 launches, 2.6 ms per 128 x 1 s) is gone, as on the bf16 path.
 __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const float* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T, int F,
-                                                      int dil, const float* __restrict__ w, const float* __restrict__ bias, float* out, int out_ld, int out_off, int M) {
+                                                      int dil, const float* __restrict__ w, const float* __restrict__ bias, float* out, int out_ld, int out_off,
+                                                      double* __restrict__ partial, int nblk) {
     constexpr int kRowW = gemm::kRow, kARows = 264;
     __shared__ __attribute__((aligned(16))) float As[kARows * kRowW];
     __shared__ __attribute__((aligned(16))) float Bs[3 * 64 * kRowW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave * 64, j16 = lane & 15, g = lane >> 4;
-    const int m_blk = gemm::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x) * 256;
+    const int id = gemm::xcd_contiguous_id((int)blockIdx.x, (int)gridDim.x), win = id / nblk, blk = id - win * nblk;
     const int TF = T * F;
+    const int wlo = win * TF, M = wlo + TF, m_blk = wlo + blk * 256;           // this tile's rows lie in [wlo, M): one window
     // staged rows of this lane: r = (tid >> 2) + 64 h, h < 4, and for tid < 8 the two halo rows 256, 257; token = m_blk - 1 + r
     const int sr = tid >> 2, kq = 4 * (tid & 3);
     long long stok[5];
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
     for (int h = 0; h < 5; ++h) {
         const int r = h < 4 ? sr + 64 * h : 256 + sr;
         const int m = m_blk - 1 + r;
-        const bool in = m >= 0 && m < M && (h < 4 || tid < 8);
-        const int mc = in ? m : 0, b = mc / TF, t = (mc - b * TF) / F;
+        const bool in = m >= wlo && m < M && (h < 4 || tid < 8);
+        const int mc = in ? m : wlo, t = (mc - wlo) / F;
         stok[h] = mc;
         sok1[h] = in;                               // kt = 1: the row itself
         sok0[h] = in && t >= dil;                   // kt = 0: the row dil frames earlier, inside the window
@@ -378,7 +383,9 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
         __syncthreads();
     }
     // lane (g, j16), register q of tile (i, j) is C[wm + 16 i + 4 g + q][16 j + j16]
+    // (the sums are fp64 from the first addend: a channel whose mean is large against its spread loses E[x^2] - mean^2 to fp32 round-off -- 1.5e-3 on the encoder tap, measured)
     float bj[4];
+    double sj[4] = {0.0, 0.0, 0.0, 0.0}, qj[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) bj[j] = bias[16 * j + j16];
 #pragma unroll
@@ -388,8 +395,26 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
             const int m = m_blk + wm + 16 * i + 4 * g + q;
             if (m >= M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[(size_t)m * out_ld + out_off + 16 * j + j16] = acc[i][j][q] + bj[j];
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[i][j][q] + bj[j];
+                out[(size_t)m * out_ld + out_off + 16 * j + j16] = v;
+                sj[j] += (double)v;
+                qj[j] = fma((double)v, (double)v, qj[j]);
+            }
         }
+    double (*red)[64][2] = reinterpret_cast<double (*)[64][2]>(Bs);        // [4][64][2]: the weights' buffer is dead (the stage loop ended on a barrier)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double a = sj[j], b = qj[j];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (g == 0) { red[wave][16 * j + j16][0] = a; red[wave][16 * j + j16][1] = b; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int c = tid >> 1, q = tid & 1;
+        partial[(((size_t)win * nblk + blk) * 64 + c) * 2 + q] = (red[0][c][q] + red[1][c][q]) + (red[2][c][q] + red[3][c][q]);
+    }
 }
 
 struct BiasColStore {          // out[m * ld + off + n] = v + bias[n]
@@ -455,6 +480,8 @@ struct ActRowsA {
 // whole kernel); the weights stream through LDS 64 hidden units at a time (W1 rows and W2 columns of the chunk, 68-float pitch: conflict-free ds_read_b128),
 // double-buffered with one barrier per chunk: 256 MFMAs per wavefront and chunk against 32 ds_read_b128.
 // MODE 0: out = res + ff (feed_forward1: res = the layer input)   1: out = in + ff (in place)   2: out = res + ((in + ff) - res) * cmid (feed_forward2 + bypass_mid)
+// MODE 3 (round 5): the layer's last module with its final norm (:175-183) in the same store: y = in + ff; out = y / |y - nb|_2 * fs + res * rs (res = the layer input, out = the
+//         layer output, cmid = nb | fs | rs, 64 floats each); a row's 64 columns sit in the four lanes (g) that share its j16: the sum of squares meets through two shuffles.
 constexpr int kFfChunk = 64, kFfPitch = 68, kFfRows = 256;
 constexpr size_t kFfLds = (size_t)2 * 2 * kFfChunk * kFfPitch * sizeof(float);
 template <int MODE>
@@ -546,6 +573,31 @@ __global__ __launch_bounds__(512) void k_zip_ff(const float* xin, const float* _
     // lane (g, j16): output columns 16 jt + 4 g .. + 3 of row j16 of tile t
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+        if (MODE == 3) {                                                    // (every lane takes part in the row sums: a row beyond M works on row 0 and stores nothing)
+            const size_t at = (size_t)(rok[t] ? row[t] : 0) * 64 + 4 * g;
+            float4 y[4], r4[4];
+            float ssq = 0.0f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                r4[jt] = *reinterpret_cast<const float4*>(res + at + 16 * jt);
+                const float4 bo = *reinterpret_cast<const float4*>(b2 + 16 * jt + 4 * g), nb = *reinterpret_cast<const float4*>(cmid + 16 * jt + 4 * g);
+                y[jt] = make_float4(xr[t][jt].x + (acc2[t][jt][0] + bo.x), xr[t][jt].y + (acc2[t][jt][1] + bo.y), xr[t][jt].z + (acc2[t][jt][2] + bo.z), xr[t][jt].w + (acc2[t][jt][3] + bo.w));
+                const float dx = y[jt].x - nb.x, dy = y[jt].y - nb.y, dz = y[jt].z - nb.z, dw = y[jt].w - nb.w;
+                ssq = fmaf(dx, dx, fmaf(dy, dy, fmaf(dz, dz, fmaf(dw, dw, ssq))));
+            }
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            const float nrm = sqrtf(ssq);
+            if (rok[t]) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const float4 fs = *reinterpret_cast<const float4*>(cmid + 64 + 16 * jt + 4 * g), rs = *reinterpret_cast<const float4*>(cmid + 128 + 16 * jt + 4 * g);
+                    *reinterpret_cast<float4*>(out + at + 16 * jt) = make_float4((y[jt].x / nrm) * fs.x + r4[jt].x * rs.x, (y[jt].y / nrm) * fs.y + r4[jt].y * rs.y,
+                                                                                (y[jt].z / nrm) * fs.z + r4[jt].z * rs.z, (y[jt].w / nrm) * fs.w + r4[jt].w * rs.w);
+                }
+            }
+            continue;
+        }
         if (!rok[t]) continue;
         const size_t at = (size_t)row[t] * 64 + 4 * g;
         float4 rv[4], cv[4];
@@ -1534,7 +1586,8 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess)
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the feed-forward kernel"));
     *out = e;
     return ADE_OK;
@@ -1571,8 +1624,8 @@ int ZipEngine::reserve(int batch, std::string& err) {
         raw = E0;                                  // the fp32 E0 buffer is free on this path (E0 itself is bf16): a dense layer's raw output, [tokens][64]
     }
     const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
-    const size_t nblk0 = ((size_t)T * kZF + 255) / 256;         // the bf16 dense kernel emits one partial per 256-token tile
-    ZP_HIP(hipMalloc((void**)&partial, B * std::max({nchunk0, nchunk2, bf16 ? nblk0 : (size_t)0}) * 64 * 2 * sizeof(double)));
+    const size_t nblk0 = ((size_t)T * kZF + 255) / 256;         // the dense kernels emit one partial per 256-token tile
+    ZP_HIP(hipMalloc((void**)&partial, B * std::max({nchunk0, nchunk2, nblk0}) * 64 * 2 * sizeof(double)));
     capacity = batch;
     return ADE_OK;
 }
@@ -1585,14 +1638,14 @@ void ZipEngine::stats(hipStream_t s, const float* x, int ld, int ch0, int tok_pe
 
 // DenseBlockV2 (:701-757): layer i of group g writes its raw output (+ bias) to hist channels [g 4 C + (3 - i) C, + C) and its statistics to nrm
 void ZipEngine::dense_block(hipStream_t s, const ZDense& d, int groups, const float* inp, int windows, int Fd) {
-    const int ld = groups * 4 * C, M = windows * T * Fd;
+    const int ld = groups * 4 * C, M = windows * T * Fd, TF = T * Fd, nblk = (TF + 255) / 256;
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            const dim3 grid((unsigned)((M + 255) / 256));             // (C == 64: checked at create)
+            const dim3 grid((unsigned)(nblk * windows));              // (C == 64: checked at create) tiles per window x windows: a tile's rows share their InstanceNorm statistics
             hipLaunchKernelGGL(k_zip_dense, grid, dim3(256), 0, s, (const float*)Dh, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd, 1 << i, d.w[g][i],
-                                    d.b[g][i], Dh, ld, off_out, M);
-            stats(s, Dh, ld, off_out, T * Fd, windows, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
+                                    d.b[g][i], Dh, ld, off_out, partial, nblk);
+            hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nblk, (double)TF, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = (long long)M * 16;
             hipLaunchKernelGGL(k_zip_hist_norm, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, Dh, ld, off_out, (const float*)nrm, d.slope, T * Fd, total16);
         }
@@ -1634,6 +1687,7 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
     // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
     auto fused_ff = [&](int fd) { return C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
+    const bool fnorm_fused = fused_ff(ff3) && w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128;      // nb | fs | rs side by side in the arena: k_zip_ff<3> applies the final norm
     if (bf16) {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);
         zip16::launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                        // (:160)
@@ -1665,6 +1719,7 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
         }
         if (fused_ff(fd)) {
             if (i == 0) launch_zip_ff<2>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
+            else if (fnorm_fused) launch_zip_ff<3>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.norm_bias, x, fd);         // (:174-183) the final norm rides in the store
             else launch_zip_ff<1>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
             continue;
         }
@@ -1672,7 +1727,7 @@ void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float
         if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd);   // (:170-171)
         else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
     }
-    hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+    if (!fnorm_fused) hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
 }
 
 // The same layer on the bf16 path (csrc/ade_zip16.h): the residual stream x / Y stays fp32; every projection reads it through a loader that rounds to bf16 and stores bf16
