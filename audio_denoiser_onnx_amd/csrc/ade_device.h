@@ -19,6 +19,14 @@ __device__ __forceinline__ float tanh_f(float x) {
     return 1.0f - 2.0f * fast_rcp(__expf(2.0f * x) + 1.0f);
 }
 __device__ __forceinline__ float prelu_f(float x, float a) { return x >= 0.0f ? x : a * x; }
+// butterfly exchange of a double as its two 32-bit halves (what __shfl_xor(double) does on the GPU; the host simulator's shuffles are 32-bit)
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __shfl_xor(u.i[0], mask, 64);
+    u.i[1] = __shfl_xor(u.i[1], mask, 64);
+    return u.d;
+}
 // The same function as ONE v_med3_f32 per element (the product packs into v_pk_mul_f32): for a slope <= 1 PReLU is max(x, a x), for a slope > 1 it is
 // min(x, a x); median(x, a x, +inf) is the first and median(x, a x, -inf) the second, so the slope picks a wave-uniform third operand once and the
 // body has no branch and no compare + select pair.  Equal to prelu_f for every finite x (a negative slope turns -0 into +0, which compares equal).

@@ -127,7 +127,7 @@ struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
     __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
     __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const {
         const float x = v * sc + b;
-        out[(size_t)m * ld + n] = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        out[(size_t)m * ld + n] = 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f));      // (round 5) erf to 1.5e-7 on the hardware exp / rcp: erff() is ~40 instructions per element of the FFN's hidden tensor
     }
 };
 struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)

@@ -12,6 +12,7 @@
 // operator is its own bandwidth-bound kernel (one generic convolution kernel covers all 23 convolutions through a descriptor).
 // The DPGRNN blocks ARE GTCRN's (same widths: 33 bins x 16 channels) and reuse its multi-kernel path (ade_kernels.hip); the STFT
 // pair is the generic operator of ade_stft.hip (dense windowed DFT on the matrix cores, exact-angle tables).
+#include "ade_device.h"
 #include "ade_internal.h"
 #include "../../include/ade.h"
 
@@ -25,7 +26,7 @@ namespace {
 
 constexpr int kUNfft = 512, kUHop = 256, kUBins = 257, kULow = 65, kUBands = 64, kUHigh = 192, kUErb = kULow + kUBands;   // 129
 
-__device__ __forceinline__ float usig(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float usig(float x) { return ade::dev::sigmoid_f(x); }      // (round 5: hardware exp2 / rcp; libm expf + the IEEE division were ~27 instructions per gate of the cTFA GRUs)
 
 struct ConvDesc {              // one (de)convolution + bias [+ AffinePReLU] [+ channel shuffle] over (B, T, F, C) tensors
     const float *w, *b, *pos, *neg, *abias;     // w in torch layout: Conv2d (Cout, Cin/g, kt, kf); ConvTranspose2d (Cin, Cout/g, kt, kf)
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void k_ulu_ta(const float* __restrict__ zt, co
                 si[g] = bi[g] + ((part[0][g][j] + part[1][g][j]) + (part[2][g][j] + part[3][g][j]));
                 sh[g] = bh[g] + ((part[0][3 + g][j] + part[1][3 + g][j]) + (part[2][3 + g][j] + part[3][3 + g][j]));
             }
-            const float r = usig(si[0] + sh[0]), zg = usig(si[1] + sh[1]), n = tanhf(si[2] + r * sh[2]);
+            const float r = usig(si[0] + sh[0]), zg = usig(si[1] + sh[1]), n = ade::dev::tanh_f(si[2] + r * sh[2]);
             h = (1.0f - zg) * n + zg * h;
             hs[j] = h;
         }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_ulu_fa_gru(const float* __restrict__ pf
                 gh[g] = bh[g * 4 + u];
                 for (int k = 0; k < 4; ++k) { gi[g] += wih[g * 4 + u][k] * x[k]; gh[g] += whh[g * 4 + u][k] * h[k]; }
             }
-            const float r = usig(gi[0] + gh[0]), z = usig(gi[1] + gh[1]), n = tanhf(gi[2] + r * gh[2]);
+            const float r = usig(gi[0] + gh[0]), z = usig(gi[1] + gh[1]), n = ade::dev::tanh_f(gi[2] + r * gh[2]);
             hn[u] = (1.0f - z) * n + z * h[u];
         }
         for (int u = 0; u < 4; ++u) { h[u] = hn[u]; fah[((size_t)frame * H + step) * 8 + dir * 4 + u] = hn[u]; }

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
                     ss = fma((double)v, (double)v, ss);
                 }
             }
-        s += __shfl_xor(s, 32, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        s += shfl_xor_f64(s, 32);
+        ss += shfl_xor_f64(ss, 32);
         if (h == 0) { red[wave][co][0] = s; red[wave][co][1] = ss; }
     }
     __syncthreads();

@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256, 3) void k_zip_dense(const float* hist, const f
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         double a = sj[j], b = qj[j];
-        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        a += shfl_xor_f64(a, 16); a += shfl_xor_f64(a, 32);
+        b += shfl_xor_f64(b, 16); b += shfl_xor_f64(b, 32);
         if (g == 0) { red[wave][16 * j + j16][0] = a; red[wave][16 * j + j16][1] = b; }
     }
     __syncthreads();
