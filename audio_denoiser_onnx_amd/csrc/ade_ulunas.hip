@@ -62,6 +62,18 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
         const int cc = d.shuffle ? shuffled(co, d.Cout) : co;       // output position co holds convolution channel cc
         const int g = cc / cog;
         float acc = d.b[cc];
+        if (KT == 1 && KF == 1 && !DECONV && STRIDE == 1 && !(cig & 3) && !(d.Cin & 3)) {
+            // pointwise convolution (twelve launches per call, 28 % of the step): the channel run of the position and the weight row are both contiguous -- four channels per
+            // ds_read_b128 pair instead of two scalar LDS reads per multiply-add; four partial sums, added in a fixed order
+            const float4* xr4 = reinterpret_cast<const float4*>(xin + fo * d.Cin + g * cig);
+            const float4* wr4 = reinterpret_cast<const float4*>(wl + cc * cig);
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            for (int q = 0; q < (cig >> 2); ++q) {
+                const float4 xv = xr4[q], wv = wr4[q];
+                a0 = fmaf(xv.x, wv.x, a0); a1 = fmaf(xv.y, wv.y, a1); a2 = fmaf(xv.z, wv.z, a2); a3 = fmaf(xv.w, wv.w, a3);
+            }
+            acc += (a0 + a1) + (a2 + a3);
+        } else
 #pragma unroll
         for (int a = 0; a < KT; ++a)
 #pragma unroll
