@@ -24,6 +24,9 @@ namespace ade {
 
 namespace {
 
+using dev::mk2;
+using dev::v2f;
+
 constexpr int kUNfft = 512, kUHop = 256, kUBins = 257, kULow = 65, kUBands = 64, kUHigh = 192, kUErb = kULow + kUBands;   // 129
 
 __device__ __forceinline__ float usig(float x) { return ade::dev::sigmoid_f(x); }      // (round 5: hardware exp2 / rcp; libm expf + the IEEE division were ~27 instructions per gate of the cTFA GRUs)
@@ -196,6 +199,85 @@ __global__ __launch_bounds__(256) void k_ulu_ta(const float* __restrict__ zt, co
     }
 }
 
+// The same time attention with the recurrence on ONE wavefront and nothing but the recurrence inside it (round 5).  k_ulu_ta spreads every step's contraction over four
+// wavefronts and pays three workgroup barriers per step: 2.5 us per step, 105 - 160 us per launch, a quarter of the model's time.  Here a workgroup (one clip, 64 frames at
+// a time) runs three phases: (1) all four wavefronts form the input projections b_ih + W_ih z_t of the whole chunk (no dependence between frames) into LDS; (2) wavefront 0
+// alone walks the chunk: lane j = hidden unit j, h_{t-1} broadcast lane by lane into scalar registers (v_readlane), the unit's 3 x H recurrent weights held in REGISTERS (a
+// 256-thread workgroup that fills a CU's LDS is one wavefront per SIMD: 512 registers each; reading them from LDS -- 144 to 192 ds_read_b32 per step -- made the step as slow
+// as the four-wavefront form, 1.6 us), r | z gates as one packed accumulator, h_t into LDS -- no barrier, no other wavefront involved; (3) all four wavefronts apply the output Linear + sigmoid to the chunk's hidden
+// states.  Sums run k ascending (k_ulu_ta adds four partial sums: the results differ by fp32 round-off, 1e-7).
+template <int C>
+__global__ __launch_bounds__(256) void k_ulu_ta2(const float* __restrict__ zt, const float* __restrict__ wih_t, const float* __restrict__ whh_t,
+                                                 const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ fc_t,
+                                                 const float* __restrict__ fc_b, float* __restrict__ at, int T) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int H = 2 * C, G = 3 * H;
+    const int b = blockIdx.x, tid = threadIdx.x, j = tid & 63;
+    constexpr bool kNLds = C >= 32;           // 3 x 64 weights + the loop's working set pass the 256 architected registers: the n-gate row stays in LDS there (measured: 185 us with
+                                              // all three rows in registers, 141 us with all three in LDS)
+    float* s_gi = lds;                        // [64 frames][3][H]
+    float* s_h = s_gi + 64 * G;               // [64 frames][H]
+    float* s_z = s_h + 64 * H;                // [64 frames][C]
+    float* s_wn = s_z + 64 * C;               // [H][H]: W_hn^T (kNLds only)
+    const int u = j < H ? j : H - 1;          // (lanes beyond H compute unit H - 1 again and store nothing)
+    v2f wrz[H];                               // this unit's recurrent rows: (W_hr, W_hz)[u][k] and W_hn[u][k]
+    float wn[kNLds ? 1 : H];
+    if (kNLds)
+        for (int i = tid; i < H * H; i += 256) s_wn[i] = whh_t[((i / H) * 3 + 2) * H + (i % H)];
+    float bh[3] = {0.0f, 0.0f, 0.0f};
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) { wrz[k] = mk2(whh_t[(k * 3 + 0) * H + u], whh_t[(k * 3 + 1) * H + u]); if (!kNLds) wn[k] = whh_t[(k * 3 + 2) * H + u]; }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bh[g] = bhh[g * H + u];
+    } else {
+#pragma unroll
+        for (int k = 0; k < H; ++k) { wrz[k] = mk2(0.0f, 0.0f); if (!kNLds) wn[k] = 0.0f; }
+    }
+    float h = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int nt = min(64, T - t0);
+        __syncthreads();                      // (the previous chunk's phase 3 is done with s_h; first pass: the weights are staged)
+        for (int i = tid; i < nt * C; i += 256) s_z[i] = zt[((size_t)b * T + t0) * C + i];
+        __syncthreads();
+        // (1) input projections of the chunk: output (t, g, u) = b_ih[g][u] + sum_k W_ih^T[k][g][u] z_t[k]; consecutive threads = consecutive u (coalesced weight rows)
+        for (int o = tid; o < nt * G; o += 256) {
+            const int t = o / G, gu = o - t * G;
+            float a = bih[gu];
+#pragma unroll 4
+            for (int k = 0; k < C; ++k) a = fmaf(wih_t[k * G + gu], s_z[t * C + k], a);
+            s_gi[o] = a;
+        }
+        __syncthreads();
+        // (2) the recurrence: wavefront 0, lane j = hidden unit
+        if (tid < 64) {
+            for (int t = 0; t < nt; ++t) {
+                v2f grz = mk2(bh[0], bh[1]);
+                float gn = bh[2];
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    const float hk = __shfl(h, k, 64);               // constant lane: v_readlane into a scalar register
+                    grz += wrz[k] * hk;
+                    gn = fmaf(kNLds ? s_wn[k * H + u] : wn[k], hk, gn);
+                }
+                const float* gi = s_gi + t * G;
+                const float r = usig(gi[u] + grz[0]), zg = usig(gi[H + u] + grz[1]), n = ade::dev::tanh_f(gi[2 * H + u] + r * gn);
+                h = (1.0f - zg) * n + zg * h;
+                if (j < H) s_h[t * H + j] = h;
+            }
+        }
+        __syncthreads();
+        // (3) at[t][c] = sigmoid(fc_b[c] + sum_k fc^T[k][c] h_t[k])
+        for (int o = tid; o < nt * C; o += 256) {
+            const int t = o / C, c = o - t * C;
+            float a = fc_b[c];
+#pragma unroll 4
+            for (int k = 0; k < H; ++k) a = fmaf(fc_t[k * C + c], s_h[t * H + k], a);
+            at[((size_t)b * T + t0) * C + o] = usig(a);
+        }
+    }
+}
+
 // frequency attention GRUs (:151-153): per frame, the zero-padded bin powers in groups of 4 are a sequence of H steps through a
 // bidirectional GRU(4 -> 4).  One thread per (frame, direction); weights [12][4] | [12][4] | [12] | [12] per direction.
 __global__ __launch_bounds__(256) void k_ulu_fa_gru(const float* __restrict__ pfreq, const float* __restrict__ wf, const float* __restrict__ wb,
@@ -343,6 +425,7 @@ void pack_gru_lane(float* dst, const float* wih, const float* whh, const float* 
 struct UlunasEngine : SubEngine {
     int device = 0, L = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0;
     int syn_len = 0;                   // samples per row the ISTFT writes: out_len_ for a static export, 256 T (the kept tail) for a dynamic one
+    bool ta2 = !(getenv("ADE_ULU_TA2") && atoi(getenv("ADE_ULU_TA2")) == 0);     // the single-wavefront time-attention kernel (k_ulu_ta2; ADE_ULU_TA2=0: the four-wavefront form)
     ade_stft_handle plan = nullptr;
     float* d_w = nullptr;
     const float* erb = nullptr;
@@ -543,6 +626,10 @@ int ulunas_create(const std::map<std::string, Tensor>& tensors, int in_len, int 
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // 88 KB at 32 channels
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta2<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);  // 49 KB of recurrent weights + 48 KB of projections + 24 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta2<24>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ulu_ta2<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     ade_stft_config cfg{kUNfft, kUNfft, kUHop, "hann", nullptr, 1, "reflect"};          // UL-UNAS/Export_UL_UNAS.py:33-37, 936-957
     if (ade_stft_create(&cfg, device, &e->plan) != ADE_OK) return bail(ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: STFT plan: ") + ade_stft_last_error(nullptr)));
     if (dynamic_keep > 0) (void)ade_stft_keep_tail(e->plan, 1);
@@ -578,10 +665,13 @@ int UlunasEngine::reserve(int calls, std::string& err) {
 void UlunasEngine::ctfa(hipStream_t s, const Block& bk, const float* x, const float* res, float* out, int B, int shuffle) {
     const int F = bk.width, C = bk.cout, H = (F + 3) / 4;
     const long long nfr = (long long)B * T;
-    const size_t ta_lds = (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float);
+    const size_t ta_lds = ta2 ? (size_t)(64 * 3 * 2 * C + 64 * 2 * C + 64 * C + (C >= 32 ? 4 * C * C : 0)) * sizeof(float)
+                              : (size_t)(C * 3 * 2 * C + 2 * C * 3 * 2 * C + 2 * C * C + 64 * C) * sizeof(float);
 #define ADE_ULU_TA(CC)                                                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta<CC>), dim3((unsigned)B), dim3(256), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
-                       bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t, bk.ctfa.ta_fc_b, at, T)
+    if (ta2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta2<CC>), dim3((unsigned)B), dim3(256), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
+                                bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t, bk.ctfa.ta_fc_b, at, T);                                                \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ulu_ta<CC>), dim3((unsigned)B), dim3(256), ta_lds, s, (const float*)zt, bk.ctfa.ta_wih_t, bk.ctfa.ta_whh_t, \
+                            bk.ctfa.ta_bih, bk.ctfa.ta_bhh, bk.ctfa.ta_fc_t, bk.ctfa.ta_fc_b, at, T)
     switch (C) {               // the channel counts of ULUNAS() (:665); create() rejects anything else
         case 1: ADE_ULU_TA(1); break;
         case 12: ADE_ULU_TA(12); break;
