@@ -526,6 +526,17 @@ struct MapLoader {
 
 }  // namespace
 
+// channels-last (B, P, 16) <-> quad-planar (B, 4, P, 4): thread = one float4 (window b, channel quad q, position p); to_planar = 1: cl -> pl, 0: pl -> cl
+__global__ __launch_bounds__(256) void k_hg_relayout(const float* __restrict__ src, float* __restrict__ dst, int P, int to_planar, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / (4LL * P);
+    const int rem = (int)(i - b * 4LL * P), q = rem / P, p = rem - q * P;
+    const size_t pl = ((size_t)(b * 4 + q) * P + p) * 4, cl = ((size_t)b * P + p) * 16 + 4 * q;
+    if (to_planar) *reinterpret_cast<float4*>(dst + pl) = *reinterpret_cast<const float4*>(src + cl);
+    else *reinterpret_cast<float4*>(dst + cl) = *reinterpret_cast<const float4*>(src + pl);
+}
+
 struct HgtcrnEngine : SubEngine {
     int device = 0, W = 0 /* one window */, n_win = 1, T = 0, out_len_ = 0;
     ade_stft_handle plan = nullptr;
@@ -541,9 +552,19 @@ struct HgtcrnEngine : SubEngine {
           *e0 = nullptr, *e1 = nullptr, *h = nullptr, *zt = nullptr, *xe[3] = {}, *ate[3] = {}, *xd[3] = {}, *atd[3] = {}, *rnn = nullptr, *dpm = nullptr, *dpo[2] = {},
           *d3 = nullptr, *mask = nullptr, *sout = nullptr, *yf = nullptr;
     int* pred = nullptr;
+    // (round 5) the network's middle -- three GTConvBlocks, two DPGRNNs, three GTConvBlocks -- on GTCRN's FUSED per-stage kernels (csrc/ade_fused.hip: LDS-resident segments of 16
+    // frames that hand their recurrent states on through the exchange area) instead of the 26-launch multi-kernel sequence; ADE_HG_FUSED=0 keeps that sequence
+    bool fused_net = !(getenv("ADE_HG_FUSED") && atoi(getenv("ADE_HG_FUSED")) == 0);
+    int fgeo = -1, fseg = 0;              // workgroup geometry / segments per window of the fused stages (-1: the frame count does not fit: multi-kernel)
+    float* d_xchg = nullptr;
+    unsigned* d_xflags = nullptr;
+    int* d_xerr = nullptr;               // page-locked: a bounded inter-workgroup wait that gave up leaves its code here (reported by the next call)
 
     ~HgtcrnEngine() override {
         (void)hipSetDevice(device);
+        if (d_xchg) (void)hipFree(d_xchg);
+        if (d_xflags) (void)hipFree(d_xflags);
+        if (d_xerr) (void)hipHostFree(d_xerr);
         if (plan) ade_stft_destroy(plan);
         if (d_w) (void)hipFree(d_w);
         if (d_ints) (void)hipFree(d_ints);
@@ -680,6 +701,21 @@ int HgtcrnEngine::reserve(int calls, std::string& err) {
     HG_HIP(hipMemset(ws, 0, total * sizeof(float)));                       // the pad columns of feat / mask stay zero
     size_t at_ = 0;
     for (auto& c : cs) { *c.p = ws + at_; at_ += (c.n + 63) & ~(size_t)63; }
+    fgeo = -1; fseg = 0;
+    if (d_xchg) { (void)hipFree(d_xchg); d_xchg = nullptr; }
+    if (d_xflags) { (void)hipFree(d_xflags); d_xflags = nullptr; }
+    if (fused_net && fused_init() != hipSuccess) { (void)hipGetLastError(); fused_net = false; }      // (the stage kernels' dynamic-LDS limit; refused: multi-kernel sequence)
+    if (fused_net) {
+        for (int g = 2; g >= 0 && fgeo < 0; --g)
+            if (fused_supported(T, g)) fgeo = g;
+        if (fgeo >= 0) {
+            fseg = fused_segments(T, fgeo);
+            if (!d_xerr) { HG_HIP(hipHostMalloc((void**)&d_xerr, 4 * sizeof(int), hipHostMallocDefault)); d_xerr[0] = 0; }
+            HG_HIP(hipMalloc((void**)&d_xchg, B * fseg * (size_t)kXFloats * sizeof(float)));
+            HG_HIP(hipMalloc((void**)&d_xflags, B * fseg * (size_t)kXFlags * sizeof(unsigned)));
+            HG_HIP(hipMemset(d_xflags, 0, B * fseg * (size_t)kXFlags * sizeof(unsigned)));
+        }
+    }
     // let the STFT plan size its buffers now (it allocates lazily), so that run() never allocates
     if (ade_stft_analyze(plan, xf, batch * 2, W, spec, nullptr) != ADE_OK) return hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: ") + ade_stft_last_error(plan));
     if (ade_stft_synthesize(plan, sout, batch, T, yf, nullptr) != ADE_OK) return hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: ") + ade_stft_last_error(plan));
@@ -695,6 +731,12 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     const int B = batch * n_win;
     const int nfr = B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
+    if (d_xerr && *(volatile int*)d_xerr) {            // an EARLIER call's fused stage gave up a bounded hand-off wait: its output was not to be trusted
+        (void)hipDeviceSynchronize();
+        d_xerr[0] = 0;
+        if (d_xflags) (void)hipMemset(d_xflags, 0, (size_t)capacity * n_win * fseg * kXFlags * sizeof(unsigned));
+        return hfail(err, ADE_ERR_DEVICE, "h_gtcrn: a segment hand-off of the fused network stages timed out in an earlier call (ADE_HG_FUSED=0 runs the multi-kernel sequence)");
+    }
     if (float_in) {
         if (float_src_len > 0 && float_src_len < W) {      // upsampled: centred before the interpolation, i.e. with the mean of the CALLER-rate samples
             if (float_src) hipLaunchKernelGGL(k_hg_mean_f32, dim3((unsigned)batch), dim3(256), 0, s, float_src, (long long)2 * float_src_len, mean, float_src_gain);   // a float tensor came in: d_in is not PCM
@@ -723,6 +765,20 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     // network: GTCRN's kernels from the second convolution on
     hipLaunchKernelGGL(k_hg_conv0, flat((long long)nfr * kF1), dim3(256), 0, s, (const float*)feat, en0.w, en0.b, en0.slope, e0, nfr);
     launch_conv1(s, e0, en1, e1, nfr);
+    if (fgeo >= 0) {
+        // quad-planar tensors (X[b][q][p] = channels 4 q .. 4 q + 3 of position p) in the buffers the multi-kernel sequence uses channels-last: h = e1, xe / dpo / xd as named
+        SegPlan plan{};
+        plan.wait_ticks = 20000000; plan.nseg = fseg; plan.xchg = d_xchg; plan.flags = d_xflags; plan.err = d_xerr;
+        const int P = T * kFw;
+        const long long quads = (long long)B * 4 * P;
+        hipLaunchKernelGGL(k_hg_relayout, flat(quads), dim3(256), 0, s, (const float*)e1, h, P, 1, quads);
+        const float* xp = h;
+        for (int i = 0; i < 3; ++i) { launch_gtblock(s, fgeo, plan, i, xp, nullptr, en_gt[i], xe[i], B, T, nullptr); xp = xe[i]; }
+        for (int i = 0; i < 2; ++i) { launch_dpgrnn(s, fgeo, plan, i, xp, dp[i], dpo[i], B, T, nullptr); xp = dpo[i]; }
+        for (int i = 0; i < 3; ++i) { launch_gtblock(s, fgeo, plan, 3 + i, xp, xe[2 - i], de_gt[i], xd[i], B, T, nullptr); xp = xd[i]; }
+        hipLaunchKernelGGL(k_hg_relayout, flat(quads), dim3(256), 0, s, xp, rnn, P, 0, quads);                       // back to channels-last for the (1, 3) transposed convolutions
+        launch_deconv3(s, View{rnn, nullptr}, View{e1, nullptr}, de3, d3, nfr);
+    } else {
     const View none{nullptr, nullptr};
     View x{e1, nullptr};
     for (int i = 0; i < 3; ++i) {
@@ -746,6 +802,7 @@ int HgtcrnEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
         x = View{xd[i], atd[i]};
     }
     launch_deconv3(s, x, View{e1, nullptr}, de3, d3, nfr);
+    }
     launch_deconv4(s, d3, e0, de4, mask, nfr);
     hipLaunchKernelGGL(k_hg_mask, flat((long long)B * kHBins * T), dim3(256), 0, s, (const float*)mask, (const float*)spec, erb_bs, sout, T, (long long)B * kHBins * T);
     if (ade_stft_synthesize(plan, sout, B, T, yf, (void*)s) != ADE_OK) return hfail(err, ADE_ERR_DEVICE, std::string("h_gtcrn: ") + ade_stft_last_error(plan));
