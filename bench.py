@@ -98,14 +98,18 @@ def parse_args():
     return ap.parse_args()
 
 
+# The translation units and headers k_gtcrn_chunk and the per-stage kernels are compiled from; the other families' sources do not change those kernels.
+GTCRN_PATH_SOURCES = ("ade_device.h", "ade_engine.hip", "ade_fft.h", "ade_fused.hip", "ade_gtcrn_pack.h", "ade_internal.h", "ade_kernels.hip", "ade_stage_frontback.h",
+                      "ade_stage_net.h")
+
+
 def source_sha1() -> str:
-    """Identity of the kernel sources a measurement belongs to (csrc/*.hip, *.h)."""
-    import glob
+    """Identity of the kernel sources the GTCRN traffic measurement belongs to (GTCRN_PATH_SOURCES under csrc/)."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", "*.h*"))):
-        with open(f, "rb") as fh:
-            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    for name in GTCRN_PATH_SOURCES:
+        with open(os.path.join(REPO, "audio_denoiser_onnx_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
     return h.hexdigest()
 
 
