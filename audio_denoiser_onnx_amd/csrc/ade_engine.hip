@@ -46,6 +46,7 @@ struct GraphEntry {
 
 }  // namespace
 
+constexpr int kXErrWords = 8;      // = the sub-batch streams of ade_process
 struct ade_engine {
     int device = 0;
     int in_len = 0, T = 0, out_len = 0;   // per WINDOW (== per call unless batch-fold)
@@ -154,7 +155,9 @@ struct ade_engine {
     ade::ChunkFixed* d_fixed = nullptr;   // device copy of the chunk kernel's per-engine arguments (rebuilt by reserve)
     float* d_xchg = nullptr;              // segment exchange area [capacity][kMaxSegments slots as needed][kXFloats]
     unsigned* d_xflags = nullptr;         // its flags (zero between launches)
-    int* d_xerr = nullptr;                // page-locked host word the kernels see: the dev::xcode() of the first bounded inter-workgroup wait that gave up
+    int* d_xerr = nullptr;                // page-locked host words the kernels see: the dev::xcode() of the first bounded inter-workgroup wait that gave up.  kXErrWords words: a launch
+                                          // reports into word 0, the k-th concurrent sub-batch launch of ade_process into word k (its block indices count from ITS first chunk)
+    int xl_B[kXErrWords] = {}, xl_chunk0[kXErrWords] = {};      // chunks / first chunk of the launch that reports into word k (xl_B 0: one launch over the whole batch, last_batch)
     int xchg_capacity = 0;                // chunks the exchange area holds
     int xchg_segments = 0;                // slots per chunk the exchange area was sized for
     bool use_graph = true;
@@ -529,8 +532,8 @@ int pick_geometry(const ade_engine* e, int B);
 ade_status ensure_exchange(ade_engine* e) {
     if (e->sub) return ADE_OK;
     if (!e->d_xerr) {
-        HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, 4 * sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
-        e->d_xerr[0] = 0;
+        HIP_TRY(e, hipHostMalloc((void**)&e->d_xerr, kXErrWords * sizeof(int), hipHostMallocDefault));   // page-locked, device-visible: the host reads it after a synchronise
+        for (int k = 0; k < kXErrWords; ++k) e->d_xerr[k] = 0;
     }
     int nseg = 0;
     if (e->use_fused && !e->gt_sand) {
@@ -871,23 +874,25 @@ const char* xflag_name(int idx) {
 }
 ade_status exchange_status(ade_engine* h, const char* who, bool earlier) {
     if (!h->d_xerr) return ADE_OK;
-    const int code = *(volatile int*)h->d_xerr;
+    int code = 0, word = 0;
+    for (int k = 0; k < kXErrWords && !code; ++k) { code = ((volatile int*)h->d_xerr)[k]; word = k; }
     if (!code) return ADE_OK;
     (void)hipDeviceSynchronize();
-    h->d_xerr[0] = 0;
+    for (int k = 0; k < kXErrWords; ++k) h->d_xerr[k] = 0;
     if (h->d_xflags) (void)hipMemset(h->d_xflags, 0, (size_t)h->xchg_capacity * h->xchg_segments * kXFlags * sizeof(unsigned));
-    const int block = (code >> 4) - 1, idx = code & 15, B = h->last_batch > 0 ? h->last_batch : 1;
+    // the block index counts within the reporting launch: segment = block / (chunks of that launch), chunk = its first chunk + block % (chunks of that launch)
+    const int block = (code >> 4) - 1, idx = code & 15, B = h->xl_B[word] > 0 ? h->xl_B[word] : (h->last_batch > 0 ? h->last_batch : 1), chunk0 = h->xl_B[word] > 0 ? h->xl_chunk0[word] : 0;
     h->timed_out = true;
     char msg[384];
     if (idx == 15)      // dev::wait_rows_in: a streamed host batch (ade_process) whose rows were not delivered in time
         snprintf(msg, sizeof msg, "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for its rows of the host batch to be copied in; no output was produced "
                  "(option host_stream=1 copies the batch before the launch, option xwait_ms raises the bound)",
-                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5);
+                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, chunk0 + block % B, h->xwait_ticks * 1e-5);
     else
         snprintf(msg, sizeof msg,
                  "%s: fused path%s: segment %d of chunk %d timed out (%.1f ms) waiting for the %s of its predecessor workgroup; no output was produced "
                  "(option geometry=0 runs whole chunks per workgroup, option xwait_ms raises the bound)",
-                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, block % B, h->xwait_ticks * 1e-5, xflag_name(idx));
+                 who, earlier ? " (an earlier call on a caller-provided stream)" : "", block / B, chunk0 + block % B, h->xwait_ticks * 1e-5, xflag_name(idx));
     return fail(h, ADE_ERR_DEVICE, msg);
 }
 
@@ -1784,7 +1789,9 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
             for (int k = 0; k < used; ++k) {
                 const int r0 = k * per, nr = std::min(per, rows - r0);
                 ChunkCall C{};
-                C.plan.nseg = fused_segments(h->T, geo); C.plan.xchg = h->d_xchg; C.plan.flags = h->d_xflags; C.plan.err = h->d_xerr; C.plan.wave_swap = h->wave_swap;
+                C.plan.nseg = fused_segments(h->T, geo); C.plan.xchg = h->d_xchg; C.plan.flags = h->d_xflags; C.plan.wave_swap = h->wave_swap;
+                C.plan.err = h->d_xerr + k;                               // its own word: exchange_status names the chunk with THIS launch's first chunk and size
+                h->xl_B[k] = nr; h->xl_chunk0[k] = r0;
                 C.plan.prio = h->seg_prio; C.plan.withhold = r0 == 0 ? h->xchg_withhold : 0; C.plan.wait_ticks = h->xwait_ticks;
                 C.fixed = h->d_fixed;
                 C.pcm_in = h->d_pcm_in; C.pcm_out = h->d_pcm_out; C.f32_out = out_f32 ? h->d_f32_out : nullptr;
@@ -1802,6 +1809,7 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
             }
             for (int k = 0; k < used; ++k) HIP_TRY(h, hipStreamSynchronize(h->sub_streams[k]));
             st = exchange_status(h, "ade_process", false);
+            for (int k = 0; k < kXErrWords; ++k) h->xl_B[k] = 0;                 // (every other launch reports into word 0 with the whole batch's block numbering)
             if (st != ADE_OK) {
                 if (out_pcm && pcm_direct) memset(out_pcm, 0, nout * sizeof(int16_t));
                 if (out_f32 && f32_direct) memset(out_f32, 0, nout * sizeof(float));
@@ -2039,7 +2047,7 @@ ade_status ade_debug_tap(ade_handle h, const char* name, float* out, size_t coun
         int v = 0;
         if (h->d_xerr) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
-            v = *(volatile int*)h->d_xerr;
+            for (int k = 0; k < kXErrWords && !v; ++k) v = ((volatile int*)h->d_xerr)[k];
         }
         out[0] = (float)v;
         *written = 1;

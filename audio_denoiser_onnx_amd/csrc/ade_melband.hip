@@ -1089,10 +1089,13 @@ int MelbandEngine::reserve(int batch, std::string& err) {
     const size_t hid = (size_t)ffd > (size_t)med ? (size_t)ffd : (size_t)med;
     size_t sizes[10] = {(size_t)kFc * 2 * BT, R * dim, R, R * wide, R * hid, R * di, (size_t)2 * S2 * BT, (size_t)2 * kBinsM * kChan * BT,
                         (size_t)kChan * BT * kNfftM, (size_t)kFc * 2 * BT};
-    if (bf16) {      // room for the bf16 stream copies behind the bf16 views of bufA and AO (see below; already there whenever dim <= the buffer's own width), and for the row sums
+    if (bf16) {      // the three activation buffers hold bf16 views only (sized for fp32 they were twice what the path touches -- 9.5 GB of bufA alone at 32 x 8 s):
+                     // q | k | v | gates (and the mask estimator's second hidden layer) + the stream copy Xg; the hidden activations (and, as fp32, the "tokens" tap: R dim floats);
+                     // the attention output + the stream copy X1.  invn's place takes the row sums.
         sizes[2] = (size_t)(3 * kSqTiles + 3) * R;
-        sizes[3] = std::max(sizes[3], (((R * wide + 63) & ~(size_t)63) + R * dim) / 2 + 64);
-        sizes[5] = std::max(sizes[5], (((R * di + 63) & ~(size_t)63) + R * dim) / 2 + 64);
+        sizes[3] = (((R * wide + 63) & ~(size_t)63) + R * dim) / 2 + 64;
+        sizes[4] = std::max((R * hid + 1) / 2 + 64, R * dim);
+        sizes[5] = (((R * di + 63) & ~(size_t)63) + R * dim) / 2 + 64;
     }
     size_t total = 0;
     for (size_t s : sizes) total += (s + 63) & ~(size_t)63;

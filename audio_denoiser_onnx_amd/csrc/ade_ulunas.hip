@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace ade {
 
@@ -38,10 +39,154 @@ struct ConvDesc {              // one (de)convolution + bias [+ AffinePReLU] [+ 
 
 __device__ __forceinline__ int shuffled(int j, int C) { return (j & 1) ? (j >> 1) + (C >> 1) : (j >> 1); }   // Shuffle.indices (:200-203)
 
+// One output of one (de)convolution of a frame: position o = fo * Cout + co of the output frame, from the kt staged input frames xin[a][Fi * Cin] (tap a = frame
+// t - (KT - 1) + a, or t - a for a transposed convolution) and the weights wl in their torch layout, both in LDS.  Bias, AffinePReLU and the channel shuffle included.
+template <int KT, int KF, int STRIDE, bool DECONV>      // the five kernel shapes of ULUNAS() (:667) as compile-time constants: the tap loops unroll
+__device__ __forceinline__ float conv_out(const float* __restrict__ xin, int row, const float* __restrict__ wl, const ConvDesc& d, int o, int cog, int cig) {
+    constexpr int pf = KF / 2;
+    const int fo = o / d.Cout, co = o - fo * d.Cout;
+    const int cc = d.shuffle ? shuffled(co, d.Cout) : co;       // output position co holds convolution channel cc
+    const int g = cc / cog;
+    float acc = d.b[cc];
+    if (KT == 1 && KF == 1 && !DECONV && STRIDE == 1 && !(cig & 3) && !(d.Cin & 3)) {
+        // pointwise convolution (twelve per call, 28 % of the step as launches of their own): the channel run of the position and the weight row are both contiguous -- four
+        // channels per ds_read_b128 pair instead of two scalar LDS reads per multiply-add; four partial sums, added in a fixed order
+        const float4* xr4 = reinterpret_cast<const float4*>(xin + fo * d.Cin + g * cig);
+        const float4* wr4 = reinterpret_cast<const float4*>(wl + cc * cig);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int q = 0; q < (cig >> 2); ++q) {
+            const float4 xv = xr4[q], wv = wr4[q];
+            a0 = fmaf(xv.x, wv.x, a0); a1 = fmaf(xv.y, wv.y, a1); a2 = fmaf(xv.z, wv.z, a2); a3 = fmaf(xv.w, wv.w, a3);
+        }
+        acc += (a0 + a1) + (a2 + a3);
+    } else
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int bb = 0; bb < KF; ++bb) {
+            int fi;
+            if (DECONV) {
+                const int num = fo + pf - bb;
+                if (num < 0 || num % STRIDE) continue;
+                fi = num / STRIDE;
+            } else {
+                fi = fo * STRIDE - pf + bb;
+            }
+            if (fi < 0 || fi >= d.Fi) continue;
+            const float* xr = xin + a * row + fi * d.Cin + g * cig;
+            for (int ci = 0; ci < cig; ++ci) {
+                const float wv = DECONV ? wl[(((g * cig + ci) * cog + (cc - g * cog)) * KT + a) * KF + bb] : wl[((cc * cig + ci) * KT + a) * KF + bb];
+                acc += xr[ci] * wv;
+            }
+        }
+    if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
+    return acc;
+}
+
+// A whole output frame of one (de)convolution by the workgroup: emit(o, value) for every position o = fo * Cout + co.  (Round 5.)  conv_out() per output spends its
+// time on index arithmetic -- two integer divisions, the shuffle, the group, three table addresses -- not on multiply-adds: a launch ran at ~13 % of the vector rate.
+// Here a thread KEEPS its output channel (co = tid % Cout, one division per thread and frame) and walks the positions fo0, fo0 + 256 / Cout, ...: channel, group, bias,
+// AffinePReLU rows and -- for the pointwise and the one-input-channel shapes, all but the last deconvolution -- its weight row in registers are per-thread constants.
+template <int CIG>
+__device__ __forceinline__ float pw_dot(const float* __restrict__ xr, const float (&w)[CIG]) {
+    if constexpr (CIG % 4 == 0) {      // four partial sums, added in a fixed order (the order of the float4 path of conv_out)
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < CIG / 4; ++q) {
+            const float4 xv = reinterpret_cast<const float4*>(xr)[q];
+            a0 = fmaf(xv.x, w[4 * q], a0); a1 = fmaf(xv.y, w[4 * q + 1], a1); a2 = fmaf(xv.z, w[4 * q + 2], a2); a3 = fmaf(xv.w, w[4 * q + 3], a3);
+        }
+        return (a0 + a1) + (a2 + a3);
+    } else {
+        float a = 0.0f;
+#pragma unroll
+        for (int q = 0; q < CIG / 2; ++q) {
+            const float2 xv = reinterpret_cast<const float2*>(xr)[q];
+            a += xv.x * w[2 * q]; a += xv.y * w[2 * q + 1];
+        }
+        return a;
+    }
+}
+template <int KT, int KF, int STRIDE, bool DECONV, class Emit>
+__device__ __forceinline__ void conv_frame(const float* __restrict__ xin, int row, const float* __restrict__ wl, const ConvDesc& d, Emit&& emit) {
+    const int Cout = d.Cout, cog = Cout / d.groups, cig = d.Cin / d.groups, Fo = d.Fo;
+    constexpr bool kPw = KT == 1 && KF == 1 && !DECONV && STRIDE == 1;
+    const bool fast = kPw ? (cig == 6 && !(d.Cin & 1)) || ((cig == 8 || cig == 12 || cig == 16) && !(d.Cin & 3)) : cig == 1;      // (vector LDS reads of a position's channel run)
+    if (!fast || Cout > 256) {         // (the last deconvolution: 12 -> 1 channels, 3 x 3 taps)
+        for (int o = threadIdx.x; o < Fo * Cout; o += 256) emit(o, conv_out<KT, KF, STRIDE, DECONV>(xin, row, wl, d, o, cog, cig));
+        return;
+    }
+    const int nper = 256 / Cout, fo0 = (int)threadIdx.x / Cout, co = (int)threadIdx.x - fo0 * Cout;
+    if (fo0 >= nper) return;
+    const int cc = d.shuffle ? shuffled(co, Cout) : co, g = cc / cog;
+    const float bias = d.b[cc];
+    const float *pos = d.pos ? d.pos + cc * Fo : nullptr, *neg = d.pos ? d.neg + cc * Fo : nullptr, *ab = d.pos ? d.abias + cc * Fo : nullptr;
+    auto act = [&](float acc, int fo) { return pos ? (acc > 0.0f ? pos[fo] : neg[fo]) * acc + ab[fo] : acc; };      // AffinePReLU (:128-130)
+    if constexpr (kPw) {
+        const float* xg = xin + g * cig;
+        auto run = [&](auto cig_c) {
+            constexpr int CIG = decltype(cig_c)::value;
+            float w[CIG];
+#pragma unroll
+            for (int q = 0; q < CIG; ++q) w[q] = wl[cc * CIG + q];
+            for (int fo = fo0; fo < Fo; fo += nper) emit(fo * Cout + co, act(bias + pw_dot<CIG>(xg + fo * d.Cin, w), fo));
+        };
+        if (cig == 6) run(std::integral_constant<int, 6>{});
+        else if (cig == 8) run(std::integral_constant<int, 8>{});
+        else if (cig == 12) run(std::integral_constant<int, 12>{});
+        else run(std::integral_constant<int, 16>{});
+    } else {                           // one input channel per output channel (depthwise, and the first block's 1 -> 12): KT x KF weights
+        constexpr int pf = KF / 2;
+        float w[KT][KF];
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int bb = 0; bb < KF; ++bb) w[a][bb] = wl[(cc * KT + a) * KF + bb];      // (both layouts: Conv2d (Cout, 1, kt, kf); ConvTranspose2d (Cin, cog, kt, kf) at cig == 1)
+        const float* xg = xin + g;
+        for (int fo = fo0; fo < Fo; fo += nper) {
+            float acc = bias;
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int bb = 0; bb < KF; ++bb) {
+                    int fi;
+                    if (DECONV) {
+                        const int num = fo + pf - bb;
+                        if (num < 0 || num % STRIDE) continue;
+                        fi = num / STRIDE;
+                    } else {
+                        fi = fo * STRIDE - pf + bb;
+                    }
+                    if (fi < 0 || fi >= d.Fi) continue;
+                    acc += xg[a * row + fi * d.Cin] * w[a][bb];
+                }
+            emit(fo * Cout + co, act(acc, fo));
+        }
+    }
+}
+
+// The cTFA statistics of a block's last convolution (:181-182, :150): zt[c] = mean_f y^2, pfreq[f] = mean_c y^2 of the frame this workgroup has just written to orow.
+// sq: Fo * Cout floats of LDS nobody reads any more (the caller has synchronised).
+__device__ __forceinline__ void frame_stats(const float* __restrict__ orow, float* __restrict__ sq, int Fo, int Cout, long long frame, float* __restrict__ zt,
+                                            float* __restrict__ pfreq) {
+    for (int o = threadIdx.x; o < Fo * Cout; o += 256) { const float v = orow[o]; sq[o] = v * v; }   // own writes: visible to this thread
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cout; c += 256) {
+        float a = 0.0f;
+        for (int f = 0; f < Fo; ++f) a += sq[f * Cout + c];
+        zt[frame * Cout + c] = a / (float)Fo;
+    }
+    for (int f = threadIdx.x; f < Fo; f += 256) {
+        float a = 0.0f;
+        for (int c = 0; c < Cout; ++c) a += sq[f * Cout + c];
+        pfreq[frame * Fo + f] = a / (float)Cout;
+    }
+}
+
 // out[b][t][fo][co] = act(bias + sum over taps / group channels), causal in t (:222-238, :264-267); optional second input added first (:648).
 // One workgroup per frame: the kt input frames it needs (already summed with the skip tensor) and the whole weight tensor are staged in LDS
 // once, so HBM / L2 sees every input element kt times instead of once per tap, channel and output.
-template <int KT, int KF, int STRIDE, bool DECONV>      // the five kernel shapes of ULUNAS() (:667) as compile-time constants: the tap loops unroll
+template <int KT, int KF, int STRIDE, bool DECONV>
 __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, const float* __restrict__ x2, ConvDesc d, float* __restrict__ out, int T, int wsize,
                                                   float* __restrict__ zt, float* __restrict__ pfreq) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -57,64 +202,11 @@ __global__ __launch_bounds__(256) void k_ulu_conv(const float* __restrict__ x, c
     }
     for (int i = threadIdx.x; i < wsize; i += 256) wl[i] = d.w[i];
     __syncthreads();
-    const int cog = d.Cout / d.groups, cig = d.Cin / d.groups;
-    constexpr int pf = KF / 2;
     float* orow = out + (size_t)frame * d.Fo * d.Cout;
-    for (int o = threadIdx.x; o < d.Fo * d.Cout; o += 256) {
-        const int fo = o / d.Cout, co = o - fo * d.Cout;
-        const int cc = d.shuffle ? shuffled(co, d.Cout) : co;       // output position co holds convolution channel cc
-        const int g = cc / cog;
-        float acc = d.b[cc];
-        if (KT == 1 && KF == 1 && !DECONV && STRIDE == 1 && !(cig & 3) && !(d.Cin & 3)) {
-            // pointwise convolution (twelve launches per call, 28 % of the step): the channel run of the position and the weight row are both contiguous -- four channels per
-            // ds_read_b128 pair instead of two scalar LDS reads per multiply-add; four partial sums, added in a fixed order
-            const float4* xr4 = reinterpret_cast<const float4*>(xin + fo * d.Cin + g * cig);
-            const float4* wr4 = reinterpret_cast<const float4*>(wl + cc * cig);
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            for (int q = 0; q < (cig >> 2); ++q) {
-                const float4 xv = xr4[q], wv = wr4[q];
-                a0 = fmaf(xv.x, wv.x, a0); a1 = fmaf(xv.y, wv.y, a1); a2 = fmaf(xv.z, wv.z, a2); a3 = fmaf(xv.w, wv.w, a3);
-            }
-            acc += (a0 + a1) + (a2 + a3);
-        } else
-#pragma unroll
-        for (int a = 0; a < KT; ++a)
-#pragma unroll
-            for (int bb = 0; bb < KF; ++bb) {
-                int fi;
-                if (DECONV) {
-                    const int num = fo + pf - bb;
-                    if (num < 0 || num % STRIDE) continue;
-                    fi = num / STRIDE;
-                } else {
-                    fi = fo * STRIDE - pf + bb;
-                }
-                if (fi < 0 || fi >= d.Fi) continue;
-                const float* xr = xin + a * row + fi * d.Cin + g * cig;
-                for (int ci = 0; ci < cig; ++ci) {
-                    const float wv = DECONV ? wl[(((g * cig + ci) * cog + (cc - g * cog)) * KT + a) * KF + bb] : wl[((cc * cig + ci) * KT + a) * KF + bb];
-                    acc += xr[ci] * wv;
-                }
-            }
-        if (d.pos) acc = (acc > 0.0f ? d.pos[cc * d.Fo + fo] : d.neg[cc * d.Fo + fo]) * acc + d.abias[cc * d.Fo + fo];   // AffinePReLU (:128-130)
-        orow[o] = acc;
-    }
+    conv_frame<KT, KF, STRIDE, DECONV>(xin, row, wl, d, [&](int o, float v) { orow[o] = v; });
     if (!zt) return;
-    // the block's last convolution also leaves the cTFA statistics of its frame (:181-182, :150): zt[c] = mean_f y^2, pfreq[f] = mean_c y^2
-    __syncthreads();                       // every thread is done with the staged inputs: the region is reused for the squares
-    float* sq = lds;                       // Fo * Cout <= the staged size is NOT guaranteed -> sized by the launcher
-    for (int o = threadIdx.x; o < d.Fo * d.Cout; o += 256) { const float v = orow[o]; sq[o] = v * v; }   // own writes: visible to this thread
-    __syncthreads();
-    for (int c = threadIdx.x; c < d.Cout; c += 256) {
-        float a = 0.0f;
-        for (int f = 0; f < d.Fo; ++f) a += sq[f * d.Cout + c];
-        zt[frame * d.Cout + c] = a / (float)d.Fo;
-    }
-    for (int f = threadIdx.x; f < d.Fo; f += 256) {
-        float a = 0.0f;
-        for (int c = 0; c < d.Cout; ++c) a += sq[f * d.Cout + c];
-        pfreq[frame * d.Fo + f] = a / (float)d.Cout;
-    }
+    __syncthreads();                       // every thread is done with the staged inputs: the region is reused for the squares (Fo * Cout <= the staged size is NOT guaranteed -> sized by the launcher)
+    frame_stats(orow, lds, d.Fo, d.Cout, frame, zt, pfreq);
 }
 
 // time attention (:183-186): GRU(C -> 2C) over frames, Linear(2C -> C), sigmoid.  The recurrence is a chain of T dependent steps, so
@@ -437,8 +529,19 @@ struct UlunasEngine : SubEngine {
     float *xf = nullptr, *spec = nullptr, *yf = nullptr, *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr, *dpa = nullptr, *dpb = nullptr, *skip[5] = {}, *zt = nullptr, *pfreq = nullptr, *at = nullptr,
           *fah = nullptr, *rnn = nullptr, *dpm = nullptr, *mask_tap = nullptr;
 
+    // Row groups on side streams (round 5): the network between the two STFTs runs per group of rows, group k > 0 on its own stream between a fork and a join event, so that
+    // one group's latency-bound launches (the time-attention recurrences: one workgroup per clip, 63 dependent steps, 20 % of the call with the chip nearly idle) run under
+    // another group's bandwidth-bound ones.  Same kernels on the same rows: the same bits.  ADE_ULU_GROUPS = 1 .. 4 (1: one stream).
+    int groups_ = getenv("ADE_ULU_GROUPS") ? std::min(4, std::max(1, atoi(getenv("ADE_ULU_GROUPS")))) : 2;
+    hipStream_t side[3] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+    void shift_rows(long long rows);
+    void run_net(hipStream_t s, int B);
+
     ~UlunasEngine() override {
         (void)hipSetDevice(device);
+        for (int k = 0; k < 3; ++k) { if (side[k]) (void)hipStreamDestroy(side[k]); if (ev_join[k]) (void)hipEventDestroy(ev_join[k]); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (plan) ade_stft_destroy(plan);
         if (d_w) (void)hipFree(d_w);
         if (d_tab) (void)hipFree(d_tab);
@@ -655,6 +758,11 @@ int UlunasEngine::reserve(int calls, std::string& err) {
     UL_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
     size_t at_ = 0;
     for (auto& c : cs) { *c.p = ws + at_; at_ += (c.n + 63) & ~(size_t)63; }
+    for (int k = 0; k + 1 < groups_; ++k) {
+        if (!side[k]) UL_HIP(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
+        if (!ev_join[k]) UL_HIP(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
+    }
+    if (!ev_fork) UL_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     // let the STFT plan size its frame buffer now (it allocates lazily), so that run() never allocates
     UL_HIP(hipMemset(spec, 0, B * 2 * kUBins * T * sizeof(float)));
     if (ade_stft_synthesize(plan, spec, batch, T, yf, nullptr) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
@@ -732,11 +840,46 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     int st = reserve(batch, err);
     if (st != ADE_OK) return st;
     const int B = batch * n_win;
-    const long long nfr = (long long)B * T;
     auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     if (float_in) hipLaunchKernelGGL(k_ulu_f2f, flat((long long)B * L), dim3(256), 0, s, float_in, xf, (long long)B * L);
     else hipLaunchKernelGGL(k_ulu_pcm2f, flat((long long)B * L), dim3(256), 0, s, d_in, xf, (long long)B * L);
     if (ade_stft_analyze(plan, xf, B, L, spec, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
+    // the network per row group (see groups_): every buffer between the two STFTs is row-major in the clip, so a group is the same launch sequence on shifted pointers
+    const int floor_rows = getenv("ADE_ULU_GROUPS") ? 1 : 16;          // (an explicit request groups any batch: the tests run three rows in three groups)
+    const int G = B >= floor_rows * groups_ ? groups_ : 1, per = (B + G - 1) / G;
+    if (G > 1) {
+        UL_HIP(hipEventRecord(ev_fork, s));
+        for (int k = 1; k < G; ++k) {
+            const int r0 = k * per, nr = std::min(per, B - r0);
+            if (nr <= 0) break;
+            UL_HIP(hipStreamWaitEvent(side[k - 1], ev_fork, 0));
+            shift_rows(r0);
+            run_net(side[k - 1], nr);
+            shift_rows(-r0);
+            UL_HIP(hipEventRecord(ev_join[k - 1], side[k - 1]));
+        }
+        run_net(s, per);
+        for (int k = 1; k < G && k * per < B; ++k) UL_HIP(hipStreamWaitEvent(s, ev_join[k - 1], 0));
+    } else run_net(s, B);
+    if (ade_stft_synthesize(plan, spec, B, T, yf, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
+    hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, syn_len, out_len_, (long long)B * out_len_);
+    UL_HIP(hipGetLastError());
+    return ADE_OK;
+}
+
+void UlunasEngine::shift_rows(long long rows) {
+    const long long fr = rows * T;
+    spec += rows * 2 * kUBins * T; mask_tap += fr * kUBins;
+    bufA += fr * 1600; bufB += fr * 1600; bufC += fr * 1600; bufD += fr * 1600;
+    dpa += fr * kFw * kCh; dpb += fr * kFw * kCh; rnn += fr * kFw * kCh; dpm += fr * kFw * kCh;
+    zt += fr * 32; pfreq += fr * 132; at += fr * 32; fah += fr * 33 * 8;
+    for (int i = 0; i < 5; ++i) skip[i] += fr * blocks[i].width * blocks[i].cout;
+}
+
+// feature extraction .. mask on the spectrum for B consecutive clips starting at the buffers' current row
+void UlunasEngine::run_net(hipStream_t s, int B) {
+    const long long nfr = (long long)B * T;
+    auto flat = [&](long long total) { return dim3((unsigned)((total + 255) / 256)); };
     hipLaunchKernelGGL(k_ulu_feat, flat(nfr * kUErb), dim3(256), 0, s, (const float*)spec, erb, (const int*)d_tab, (const int*)(d_tab + kUBands), bufC, T, nfr * kUErb);
     const float* x = bufC;
     for (int i = 0; i < 5; ++i) x = run_block(s, blocks[i], x, nullptr, bufA, bufB, skip[i], B);
@@ -760,10 +903,6 @@ int UlunasEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_
     // sigmoid, ERB split, real mask on the spectrum (:649, :734-736, :880); ISTFT; PCM tail (:955, :908)
     hipLaunchKernelGGL(k_ulu_mask, flat(nfr * kUBins), dim3(256), 0, s, dx, erb, (const int*)(d_tab + 2 * kUBands), (const int*)(d_tab + 2 * kUBands + kUHigh), spec, mask_tap, T,
                        nfr * kUBins);
-    if (ade_stft_synthesize(plan, spec, B, T, yf, (void*)s) != ADE_OK) return ufail(err, ADE_ERR_DEVICE, std::string("ul_unas: ") + ade_stft_last_error(plan));
-    hipLaunchKernelGGL(k_ulu_f2pcm, flat((long long)B * out_len_), dim3(256), 0, s, (const float*)yf, d_out, d_f32, syn_len, out_len_, (long long)B * out_len_);
-    UL_HIP(hipGetLastError());
-    return ADE_OK;
 }
 
 int UlunasEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) {

@@ -4,6 +4,8 @@ consecutive frames and continuing its predecessor's recurrences, must give the v
 CPU part (host simulator, test-only build of the same csrc/*.hip): data flow of the hand-offs -- depthwise-convolution partial sums, TRA and
 inter-frame GRU states, overlap-add carry -- for 2, 3 and 4 segments.  GPU part: the same on the MI355X at the benchmark batch (every CU holds two
 workgroups that exchange through device memory), with more workgroups than the chip holds at once, and the sticky time-out word."""
+import re
+
 import numpy as np
 import pytest
 
@@ -236,6 +238,15 @@ def test_gpu_timed_out_call_is_rerun_without_handoffs_by_the_host_entry():
     sess.set_option("xwait_retry", "0")
     with pytest.raises(AdeDeviceError, match=r"timed out"):
         sess.process_into(x, out)
+    # two sub-batches on two streams (option host_split): each launch reports into its own word, and the message names the segment and the chunk of the whole batch
+    # (decoded with the batch's size, block 5 of the 5-chunk launch read "segment 0 of chunk 5" -- a segment that waits for nobody)
+    sess.set_option("host_split", "2")
+    for rep in range(3):
+        with pytest.raises(AdeDeviceError, match=r"timed out") as ei:
+            sess.process_into(x, out)
+        m = re.search(r"segment (\d+) of chunk (\d+)", str(ei.value))
+        assert m and 1 <= int(m.group(1)) < 4 and 0 <= int(m.group(2)) < x.shape[0], str(ei.value)
+    sess.set_option("host_split", "0")
     sess.set_option("xwait_retry", "1")
     d_in, d_out = torch.from_numpy(x).cuda(), torch.zeros((x.shape[0], sess.row_out), dtype=torch.int16, device="cuda")
     with pytest.raises(AdeDeviceError, match=r"timed out"):

@@ -152,3 +152,36 @@ def test_gpu_batch_fold_matches_reference_fixture(fixture):
         out = sess.run(None, {"noisy_audio": np.stack((zf["pcm_in"], zf["pcm_in"]))[:, None]})[0][:, 0]
     d = out[0].astype(np.int32) - zf["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 0.02 and np.array_equal(out[0], out[1])
+
+
+def _variants_identical(fused, pcm, library, rows_tap):
+    """Row groups on side streams (round 5, ADE_ULU_GROUPS; read when the engine is created) are the same launches on the same rows: PCM and mask must come back
+    bit-identical to the one-stream form."""
+    outs = []
+    for groups in ("1", "2", "3", "4"):
+        os.environ["ADE_ULU_GROUPS"] = groups
+        try:
+            with _session(fused, pcm.shape[1], library) as sess:
+                pcm_out = sess.run(None, {"noisy_audio": pcm[:, None]})[0][:, 0].copy()
+                outs.append((pcm_out, sess.tap("mask", rows_tap * sess.frames * 257).copy()))
+        finally:
+            del os.environ["ADE_ULU_GROUPS"]
+    for k in range(1, len(outs)):
+        assert np.array_equal(outs[0][0], outs[k][0]) and np.array_equal(outs[0][1], outs[k][1]), f"variant {k}"
+    assert outs[0][0].any()
+
+
+@pytest.mark.hipsim
+def test_hipsim_row_groups_are_bit_identical(fixture):
+    from ade_testlib import hipsim_library
+    z, fused = fixture
+    pcm = np.ascontiguousarray(z["pcm_in"][:3, 3000:3000 + 2048])
+    _variants_identical(fused, pcm, hipsim_library(), 3)
+
+
+@pytest.mark.gpu
+def test_gpu_row_groups_are_bit_identical(fixture):
+    _, fused = fixture
+    rng = np.random.default_rng(11)
+    pcm = (rng.standard_normal((70, 16000)) * rng.uniform(100.0, 9000.0, (70, 1))).astype(np.int16)       # 70 rows: row groups of 35 / 24 + 24 + 22
+    _variants_identical(fused, pcm, None, 70)
