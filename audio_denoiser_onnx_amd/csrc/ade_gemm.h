@@ -35,8 +35,14 @@ using namespace dev;
 
 constexpr int kTM = 128, kTN = 128, kTK = 16;
 constexpr int kRow = 20;               // LDS floats per staged row
-constexpr int kSub = 1;                // 16-k slabs staged per barrier pair; 2 measured SLOWER (MossFormer in-projection 1384 -> 1616 us: the 40 KB of LDS cost a resident workgroup)
-constexpr bool kDouble = false;        // two LDS slabs used alternately, ONE barrier per 16-k slab (needs kSub == 1): measured SLOWER on the final round-2 tree (MossFormer 960 -> 1007 ms,
+#ifndef ADE_GEMM_KSUB
+#define ADE_GEMM_KSUB 1
+#endif
+#ifndef ADE_GEMM_DOUBLE
+#define ADE_GEMM_DOUBLE false
+#endif
+constexpr int kSub = ADE_GEMM_KSUB;                // 16-k slabs staged per barrier pair; 2 measured SLOWER (MossFormer in-projection 1384 -> 1616 us: the 40 KB of LDS cost a resident workgroup)
+constexpr bool kDouble = ADE_GEMM_DOUBLE;        // two LDS slabs used alternately, ONE barrier per 16-k slab (needs kSub == 1): measured SLOWER on the final round-2 tree (MossFormer 960 -> 1007 ms,
                                        // Mel-Band 981 -> 1042 ms) -- 40 KB of LDS per workgroup costs a resident workgroup, which hides more than the second barrier costs
 constexpr int kSlab = (kDouble ? 2 : kSub) * kTM * kRow;   // floats per operand staging area
 
@@ -182,9 +188,15 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             float4 a4[4];                   // lane (g, j16): A[row 16 i + j16][k = 4 g + s], B[k = 4 g + s][col 16 j + j16], s = 0..3
 #pragma unroll
             for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(As + (wm + 16 * i + j16) * kRow + 4 * g);
+            // one B operand ahead: the ds_read of column tile j + 1 is issued BEFORE the 16 MFMAs of tile j (a second float4; the scheduling barrier keeps the compiler from
+            // sinking it behind them again -- with one register set it placed every read after the products that still used the set and waited for it with an idle pipe)
+            float4 bq[2];
+            bq[0] = *reinterpret_cast<const float4*>(Bs + (wn + j16) * kRow + 4 * g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                                     // one B operand at a time: 16 MFMAs hide the next ds_read, and 12 fewer live VGPRs
-                const float4 b4 = *reinterpret_cast<const float4*>(Bs + (wn + 16 * j + j16) * kRow + 4 * g);
+            for (int j = 0; j < 4; ++j) {
+                if (j < 3) bq[(j + 1) & 1] = *reinterpret_cast<const float4*>(Bs + (wn + 16 * (j + 1) + j16) * kRow + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 b4 = bq[j & 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);

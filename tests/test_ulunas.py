@@ -185,3 +185,22 @@ def test_gpu_row_groups_are_bit_identical(fixture):
     rng = np.random.default_rng(11)
     pcm = (rng.standard_normal((70, 16000)) * rng.uniform(100.0, 9000.0, (70, 1))).astype(np.int16)       # 70 rows: row groups of 35 / 24 + 24 + 22
     _variants_identical(fused, pcm, None, 70)
+
+
+@pytest.mark.gpu
+def test_gpu_pipelined_entry_on_a_sub_engine(fixture):
+    """ade_submit / ade_wait sit on every family's run(): three submissions in flight of 40 rows each (two row groups on side streams inside each) equal ade_process."""
+    _, fused = fixture
+    rng = np.random.default_rng(5)
+    batches = [(rng.standard_normal((40, 16000)) * 4000.0).astype(np.int16) for _ in range(7)]
+    with _session(fused) as sess:
+        refs = [sess.process(b)[0] for b in batches]
+        outs = [np.empty((40, sess.row_out), np.int16) for _ in batches]
+        tickets = []
+        for b, o in zip(batches, outs):
+            if len(tickets) >= 3:
+                sess.wait(tickets.pop(0))
+            tickets.append(sess.submit(b, o))
+        for t in tickets:
+            sess.wait(t)
+        assert all(np.array_equal(o, r) for o, r in zip(outs, refs)) and outs[3].any()

@@ -76,8 +76,27 @@ static int run_case(int M, int N, int K) {
     return rc;
 }
 
+static void time_case(int M, int N, int K) {      // "-t M N K": TFLOP/s of the plain-store product, both operands along k with 16-byte loads (GPU builds)
+    float *dA, *dB, *dC;
+    hipMalloc((void**)&dA, (size_t)M * K * 4); hipMalloc((void**)&dB, (size_t)N * K * 4); hipMalloc((void**)&dC, (size_t)M * N * 4);
+    hipMemset(dA, 0x3c, (size_t)M * K * 4); hipMemset(dB, 0x3c, (size_t)N * K * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 2; ++it) launch((hipStream_t)0, RowMajorA{dA, K}, WeightNK{dB, K}, PlainC{dC, N}, M, N, K);
+    const int reps = 5;
+    hipEventRecord(e0, 0);
+    for (int it = 0; it < reps; ++it) launch((hipStream_t)0, RowMajorA{dA, K}, WeightNK{dB, K}, PlainC{dC, N}, M, N, K);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("gemm32 M=%d N=%d K=%d: plain fp32 store %.3f ms, %.1f TFLOP/s\n", M, N, K, ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+}
+
 int main(int argc, char** argv) {
     int rc = 0;
+    if (argc >= 5 && !strcmp(argv[1], "-t")) {
+        for (int i = 2; i + 2 < argc; i += 3) time_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
+        return 0;
+    }
     if (argc < 4) return run_case(130, 70, 37);
     for (int i = 1; i + 2 < argc; i += 3) rc |= run_case(atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2]));
     return rc;

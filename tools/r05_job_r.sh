@@ -1,4 +1,6 @@
-O=gpurun_out; mkdir -p $O
-timeout 300 python tools/bench_hgtcrn.py 2>&1 | tail -4
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/r05_r_prof -- python $GRAFT_REPO_ROOT/tools/bench_hgtcrn.py --batches 256 --steps 5 > /dev/null 2>&1)
-find $O/r05_r_prof -name "*kernel_stats.csv" -exec cp {} $O/r05_r_hgtcrn_kernel_stats.csv \; ; rm -rf $O/r05_r_prof; head -24 $O/r05_r_hgtcrn_kernel_stats.csv | cut -c1-70,140-230
+mkdir -p tests/unit/_build gpurun_out
+for V in "-DADE_GEMM_KSUB=1" "-DADE_GEMM_KSUB=2" "-DADE_GEMM_DOUBLE=true"; do
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Wno-unused-value $V -I include tests/unit/gemm32_unit.hip -o tests/unit/_build/gemm32_unit_gpu || exit 1
+echo "$V: $(tests/unit/_build/gemm32_unit_gpu 130 70 37 129 200 64 1000 333 250 257 640 1029 | grep -c OK) OK"
+tests/unit/_build/gemm32_unit_gpu -t 1537920 1536 384 1537920 384 1536 511936 2176 512 511936 512 1024
+done | tee gpurun_out/r05_r_gemm32_variants.txt

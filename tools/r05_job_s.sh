@@ -1,5 +1,6 @@
-O=gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/test_hgtcrn.py -m gpu -x -q > $O/r05_t_tests.txt 2>&1; echo "tests rc $?"; tail -3 $O/r05_t_tests.txt
-for K in 1 1; do ADE_HG_FUSED=$K timeout 300 python tools/bench_hgtcrn.py --batches 256 --steps 20 2>/dev/null | grep "B=" | sed "s/^/fused=$K /"; done
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/r05_t_prof -- python $GRAFT_REPO_ROOT/tools/bench_hgtcrn.py --batches 256 --steps 5 > /dev/null 2>&1)
-find $O/r05_t_prof -name "*kernel_stats.csv" -exec cp {} $O/r05_t_hgtcrn_kernel_stats.csv \; ; rm -rf $O/r05_t_prof; head -8 $O/r05_t_hgtcrn_kernel_stats.csv | cut -c1-60,140-230
+mkdir -p tests/unit/_build gpurun_out
+for W in 3 4; do
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -Wno-unused-value -DADE_GEMM16_WGS=$W -I include tests/unit/gemm16_unit.hip -o tests/unit/_build/gemm16_unit_gpu || exit 1
+echo "WGS=$W: $(tests/unit/_build/gemm16_unit_gpu 1000 1544 384 777 384 1536 130 70 72 64 25633 64 4096 512 512 | grep -c OK) OK"
+tests/unit/_build/gemm16_unit_gpu -t 1537920 1544 384 1537920 1536 384 1537920 384 1536 1537920 384 512
+done | tee gpurun_out/r05_s_gemm16_variants.txt
