@@ -111,7 +111,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // WPE, one iteration (:686-757).  grid (257, B), 256 threads, dynamic LDS: X (4 T) | 1 / lambda (T) | R (2 x 36 x 36) | P, x, p (2 x 72 each).  Delay-bank row k = l * 2 + m is microphone m delayed kDelay + l frames (:627-684).
-__global__ __launch_bounds__(256) void k_hg_wpe(const float* __restrict__ spec, const float* __restrict__ eps_b, float* __restrict__ out, int T) {
+__global__ __launch_bounds__(256, 8) void k_hg_wpe(const float* __restrict__ spec, const float* __restrict__ eps_b, float* __restrict__ out, int T) {
     HIP_DYNAMIC_SHARED(float, lds)
     float* Xr = lds;                 // [2][T]
     float* Xi = Xr + 2 * T;
