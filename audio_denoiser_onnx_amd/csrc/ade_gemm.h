@@ -56,6 +56,14 @@ struct HasCtx : std::false_type {};
 template <class T>
 struct HasCtx<T, std::void_t<decltype(T::kCtx)>> : std::true_type {};
 
+// A B operand read along n may declare `bool keep(int k) const`: its operator() is then a LOAD ONLY (from an address that is always in range) and the rows k it wants as
+// zeros are zeroed when the slab goes to LDS -- behind the wait that write needs anyway.  (A select on the loaded VALUE inside operator() makes the compiler wait for the
+// slab right after requesting it, ahead of the previous slab's MFMAs: the prefetch hides nothing.)
+template <class T, class = void>
+struct HasKeep : std::false_type {};
+template <class T>
+struct HasKeep<T, std::void_t<decltype(&T::keep)>> : std::true_type {};
+
 template <class T, class = void>
 struct HasVec4 : std::false_type {};
 template <class T>
@@ -173,6 +181,13 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
             put4(Bs, c + 64, kq, rb[sub][1]);
         } else if (BL::kAlongN) {
             const int c = tid & 127, kh = (tid >> 7) * 8;
+            if constexpr (HasKeep<BL>::value) {
+                const int kb = k0 + kh;
+                rb[sub][0] = make_float4(b_of.keep(kb) ? rb[sub][0].x : 0.0f, b_of.keep(kb + 1) ? rb[sub][0].y : 0.0f, b_of.keep(kb + 2) ? rb[sub][0].z : 0.0f,
+                                         b_of.keep(kb + 3) ? rb[sub][0].w : 0.0f);
+                rb[sub][1] = make_float4(b_of.keep(kb + 4) ? rb[sub][1].x : 0.0f, b_of.keep(kb + 5) ? rb[sub][1].y : 0.0f, b_of.keep(kb + 6) ? rb[sub][1].z : 0.0f,
+                                         b_of.keep(kb + 7) ? rb[sub][1].w : 0.0f);
+            }
             put4(Bs, c, kh, rb[sub][0]);
             put4(Bs, c, kh + 4, rb[sub][1]);
         } else {

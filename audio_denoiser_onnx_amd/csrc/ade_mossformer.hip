@@ -289,12 +289,12 @@ struct VuLkvB {                // B(k, n) = k < g ? value row k of the group (ze
     static constexpr bool kAlongN = true;
     const float *rows, *lkv;
     int ld, valid, g;
-    __device__ float operator()(int k, int n) const {     // one load through a selected pointer, zeroed for the padded rows (no branch around the load)
-        const bool lin = k >= g, ok = lin || k < valid;
-        const float* p = lin ? lkv + (size_t)(k - g) * kVu2 + n : rows + (size_t)(ok ? k : 0) * ld + n;
-        const float v = *p;
-        return ok ? v : 0.0f;
+    __device__ float operator()(int k, int n) const {     // one LOAD through a selected pointer (no branch around it, no select on its value: the padded rows are zeroed by keep())
+        const bool lin = k >= g;
+        const float* p = lin ? lkv + (size_t)(k - g) * kVu2 + n : rows + (size_t)(k < valid ? k : 0) * ld + n;
+        return *p;
     }
+    __device__ bool keep(int k) const { return k >= g || k < valid; }      // gemm::HasKeep: applied when the slab goes to LDS
 };
 struct LinKvProb {             // z = (window, split): partial LKV (128 x 2048) = lin_k^T x value rows over the split's frames   (:490-492; padded keys are
     const float *lk, *vu;      // zero rows, so K = frames).  A single window has only 16 output tiles: splitting its long contraction over
