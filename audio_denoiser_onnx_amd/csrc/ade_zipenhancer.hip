@@ -685,8 +685,6 @@ struct BypassMidStore {        // y = x0 + ((y + v + bias) - x0) * c     (feed_f
 // MODE 1 (SelfAttention): value = head h's dv <= 16 columns of the value projection; DT = 1.
 // NT = key tiles held in registers (n <= 16 NT).
 constexpr int kQKs = 20;                    // floats per staged Q / K row (16 + 4: conflict-free ds_read_b128, as in ade_gemm.h)
-constexpr int kUs = 20;                     // floats per scratch row: 4 rows = 80 words = 16 mod 64, so the four lane groups of a skew write / read (rows 4 g + r, 16 lanes each) land on four
-                                            // disjoint sets of 16 banks (18 put group g + 1 eight banks beside group g: 45 % of the attention kernels' LDS cycles were bank conflicts)
 // TI: element type of proj / src / out -- float (the parity path) or bf16 (ade_gemm_dtype = bf16: the operands are stored in HBM as bf16 and widened on their way into LDS /
 // the registers; scores, softmax and accumulation are fp32 either way)
 template <int MODE, int NT, int DT, class TI>
@@ -697,10 +695,13 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
     const int j16 = lane & 15, g = lane >> 4;
     const int np16 = NT * 16, n2 = 2 * n - 1, vst = np16 + 4;
     float* Ks = lds;                               // [np16][kQKs]   (queries and their position projections are read straight from global memory by the wave that owns them:
-    float* Pt = Ks + np16 * kQKs;                  // [4][n2 (+ pad)]  keeping them out of LDS is what lets a third / fourth workgroup share the CU)
-    float* Vt = Pt + 4 * ((n2 + 3) & ~3);          // [DT * 16][vst]   values, transposed
-    float* Us = Vt + DT * 16 * vst + wave * 32 * kUs;        // per-wave scratch [32][kUs]: a wave's LDS operations execute in issue order, so tile kt + 1's writes cannot
-                                                             // overtake tile kt's reads; the wave-level sync only orders the writes of a tile before its own reads
+    constexpr int kPtFront = 16, kPtRows = 2 * 16 * NT + 2 * kPtFront;          // table rows in LDS: offsets -16 .. 32 NT + 15, zeros outside [0, n2) (padded queries / keys index there)
+    float* Pt = Ks + np16 * kQKs;                  // [kPtRows][4]: the four dims of an offset side by side, row kPtFront = offset 0  (keeping Q out of LDS is what lets a third /
+    float* Vt = Pt + 4 * kPtRows;                  // [DT * 16][vst]   values, transposed                                              fourth workgroup share the CU)
+    // (Round 5: the position term U[query][key] = sum_d p[query][d] table[key - query + n - 1][d] is four multiply-adds per score on the vector pipe -- a lane's four scores
+    //  of a tile are four consecutive table rows, 64 contiguous bytes.  Before, U^T = table x p^T was two matrix instructions per tile, un-skewed through a per-wave LDS
+    //  scratch: 8 writes + 4 reads per tile and 10 KB of LDS per workgroup.)
+    (void)n2;
     const long long r0 = geo.row0(seq);
     // Staging.  Every loop below issues its global loads as one batch from in-range addresses (clamped position, zeroed afterwards) before it touches LDS: with a
     // branch around each load the compiler fences every single one (s_waitcnt vmcnt(0)) and the ~40 loads per lane cost ~40 memory latencies -- more than the 30 score
@@ -721,19 +722,19 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
             if (p < np16) *reinterpret_cast<float4*>(Ks + p * kQKs + 4 * q) = t4[u];
         }
     }
-    const int ptst = (n2 + 3) & ~3;
-    {
-        constexpr int kIt = (4 * (2 * NT * 16 - 1) + 255) / 256;                         // n2 <= 2 np16 - 1
-        float t[kIt];
+    {   // position table (head, 4 dims, n2) -> [offset][4], zeros in front of offset 0 and behind offset n2 - 1
+        constexpr int kIt = (kPtRows + 255) / 256;
+        float t[kIt][4];
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u;
-            t[u] = pos[(size_t)h * 4 * n2 + (i < 4 * n2 ? i : 0)];
+            const int c = tid + 256 * u - kPtFront, cc = c >= 0 && c < n2 ? c : 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t[u][d] = pos[(size_t)(h * 4 + d) * n2 + cc];
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u, d = i / n2, c = i - d * n2;
-            if (i < 4 * n2) Pt[d * ptst + c] = t[u];
+            const int row = tid + 256 * u, c = row - kPtFront;
+            if (row < kPtRows) *reinterpret_cast<float4*>(Pt + 4 * row) = c >= 0 && c < n2 ? make_float4(t[u][0], t[u][1], t[u][2], t[u][3]) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     {   // values, transposed into Vt[dim][key]: four dims per lane and load
@@ -764,8 +765,8 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
         const int q0 = qt * 16, qi = q0 + j16;
         const TI* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
         const float4 qv = keep4(qi < n, ldx4(qrow + 4 * g));  // B operand of the score product: Q[query j16][dims 4 g ..]
-        const float pq_raw = ldx1(qrow + 32 + g);
-        const float pq = qi < n ? pq_raw : 0.0f;                                         // B operand of the position product: p[query j16][dim g]
+        const float4 pq = ldx4(qrow + 32);                                               // p[query j16][dims 0 .. 3]
+        const float* prow = Pt + 4 * (kPtFront + n - 1 - q0 - j16 + 4 * g);              // the lane's first table row of tile 0 (offset of (query q0 + j16, key 4 g)); a tile further on is 16 rows further on
         float st[NT][4];
         float mx = -INFINITY;
 #pragma unroll
@@ -777,21 +778,18 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
             sc = mfma16x16x4(kv.y, qv.y, sc);
             sc = mfma16x16x4(kv.z, qv.z, sc);
             sc = mfma16x16x4(kv.w, qv.w, sc);
-            const int c0 = n - 16 - q0 + k0;                   // offset index of (query q0 + 15, key k0): u = 0
-            int ca = c0 + j16, cb = c0 + 16 + j16;
-            ca = ca < 0 ? 0 : (ca > n2 - 1 ? n2 - 1 : ca);       // outside the table only for padded queries / keys
-            cb = cb < 0 ? 0 : (cb > n2 - 1 ? n2 - 1 : cb);
-            const v4f u0 = mfma16x16x4(Pt[g * ptst + ca], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 4 g + r][query j16]
-            const v4f u1 = mfma16x16x4(Pt[g * ptst + cb], pq, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 16 + 4 g + r][query j16]
+            float4 tr[4];                                      // table rows of keys k0 + 4 g + r, r = 0 .. 3
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { Us[(4 * g + r) * kUs + j16] = u0[r]; Us[(16 + 4 * g + r) * kUs + j16] = u1[r]; }
-            wave_sync();
+            for (int r = 0; r < 4; ++r) tr[r] = *reinterpret_cast<const float4*>(prow + 4 * (k0 + r));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = sc[r] + Us[(15 - j16 + 4 * g + r) * kUs + j16];
+                const float u = fmaf(pq.w, tr[r].w, fmaf(pq.z, tr[r].z, fmaf(pq.y, tr[r].y, pq.x * tr[r].x)));     // the matrix instruction's order: dims 0 .. 3, one rounding per step
+                const float v = sc[r] + u;
                 st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
                 mx = fmaxf(mx, st[kt][r]);
             }
+            ADE_OPAQUE_V(st[kt][0]); ADE_OPAQUE_V(st[kt][1]); ADE_OPAQUE_V(st[kt][2]); ADE_OPAQUE_V(st[kt][3]);      // (see k_zip_attn16: keeps a tile's work with the tile)
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -837,7 +835,8 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
 template <int MODE, int NT, int DT>
 inline size_t zip_attn_lds(int n) {
     const int np16 = NT * 16, n2 = 2 * n - 1;
-    return ((size_t)np16 * kQKs + 4 * (size_t)((n2 + 3) & ~3) + (size_t)DT * 16 * (np16 + 4) + 4 * 32 * kUs) * sizeof(float);
+    (void)n2;
+    return ((size_t)np16 * kQKs + 4 * (size_t)(2 * 16 * NT + 32) + (size_t)DT * 16 * (np16 + 4)) * sizeof(float);
 }
 
 // ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
@@ -1050,10 +1049,13 @@ void launch_attn(hipStream_t s, int heads, const TI* proj, int ldp, const float*
 // step; D as in the f32 form: lane (g, j16) holds D[4 g + r][j16]) -------------------------------------------------------------------------------------------------------
 // Same decomposition, same skew, fp32 scores / softmax / accumulation; what changes is the operand plumbing:
 //   S^T tile   : ONE instruction (K rows from LDS as 16-byte pieces, Q^T from global; the 16 head dims fill k = 0 .. 15, lane groups 2 / 3 feed a block of zeros);
-//   pos term   : two instructions (the table is staged as bf16 [offset][4 dims]: one 8-byte read per lane of group 0; p^T likewise);
+//   pos term   : on the vector pipe (round 5, second form): a lane's four scores of a tile are four CONSECUTIVE offsets of the table (offset = key - query + n - 1), so the
+//                lane reads its 32 bytes of the bf16 table [offset][4 dims] and takes four 4-term dot products with its own query's p (registers).  The first form made
+//                U^T = table x p^T with two matrix instructions per tile and un-skewed it through a per-wave LDS scratch (8 writes + 4 reads per tile): the kernel ran with
+//                its LDS pipe 77 % busy, 45 % of that in bank conflicts (`profiles/r05_i_zip_bf16_pmc_summary.txt`);
 //   O^T tile   : the probabilities of TWO key tiles are one B operand (the lane's own 2 x 4 registers, rounded to bf16), V^T comes from LDS as two 8-byte pieces (keys 4 g ..
 //                of the even tile, 16 + 4 g .. of the odd one): one instruction per 32 keys and 16 value dims.
-// 7 matrix instructions of 16 cycles per PAIR of key tiles against 20 of 32 cycles: what is left is the softmax's VALU work and the skew's LDS round trip.
+// 3 matrix instructions of 16 cycles per PAIR of key tiles against 20 of 32 cycles: what is left is the softmax's and the position term's VALU work.
 __device__ __forceinline__ v4f zmfma16x16x32(const uint4& a, const uint4& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemm16::as_v8bf(a), gemm16::as_v8bf(b), c, 0, 0, 0); }
 constexpr int kK16Pitch = 48;               // bytes per staged key row: 16 dims bf16 + 16 (the 16 lanes of a read land on 16 distinct 4-bank sets)
 template <int MODE, int NT, int DT>
@@ -1065,11 +1067,12 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
     const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
     const int j16 = lane & 15, g = lane >> 4, n2 = 2 * n - 1, n2p = (n2 + 1) & ~1;
     constexpr int vp = np32 * 2 + 16;                                                    // bytes per V^T row
+    constexpr int kPtFront = 16, kPtRows = 2 * 16 * NT + 2 * kPtFront;                   // table rows in LDS: offsets -16 .. 32 NT + 15, zeros outside [0, n2) (padded queries / keys index there)
     unsigned char* Zs = lds8;                                                             // 16 bytes of zeros
     unsigned char* Ks = lds8 + 16;                                                        // [np32][kK16Pitch]
-    unsigned char* Pt = Ks + np32 * kK16Pitch;                                           // [n2p][8]: bf16 x 4 dims per offset
-    unsigned char* Vt = Pt + n2p * 8;                                                    // [DT * 16][vp]
-    float* Us = reinterpret_cast<float*>(Vt + DT * 16 * vp) + wave * 32 * kUs;           // per-wave scratch [32][kUs] (see k_zip_attn)
+    unsigned char* Pt = Ks + np32 * kK16Pitch;                                           // [kPtRows][8]: bf16 x 4 dims per offset, row kPtFront = offset 0
+    unsigned char* Vt = Pt + kPtRows * 8;                                                // [DT * 16][vp]
+    (void)n2p;
     const long long r0 = geo.row0(seq);
     if (tid < 4) reinterpret_cast<unsigned*>(Zs)[tid] = 0u;
     {   // keys: two 16-byte pieces per key (rows beyond n are zeros)
@@ -1087,19 +1090,20 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
             if (p < np32) *reinterpret_cast<uint4*>(Ks + p * kK16Pitch + 16 * q) = t4[u];
         }
     }
-    {   // position table (head, 4 dims, n2) fp32 -> [offset][4] bf16
-        constexpr int kIt = (2 * NT * 16 + 255) / 256;
+    {   // position table (head, 4 dims, n2) fp32 -> [offset][4] bf16, zeros in front of offset 0 and behind offset n2 - 1
+        constexpr int kIt = (kPtRows + 255) / 256;
         float t[kIt][4];
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int c = tid + 256 * u, cc = c < n2 ? c : 0;
+            const int c = tid + 256 * u - kPtFront, cc = c >= 0 && c < n2 ? c : 0;
 #pragma unroll
             for (int d = 0; d < 4; ++d) t[u][d] = pos[(size_t)(h * 4 + d) * n2 + cc];
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
-            const int c = tid + 256 * u;
-            if (c < n2p) *reinterpret_cast<uint2*>(Pt + c * 8) = c < n2 ? make_uint2(gemm16::pack_bf16x2(t[u][0], t[u][1]), gemm16::pack_bf16x2(t[u][2], t[u][3])) : make_uint2(0u, 0u);
+            const int row = tid + 256 * u, c = row - kPtFront;
+            if (row < kPtRows)
+                *reinterpret_cast<uint2*>(Pt + row * 8) = c >= 0 && c < n2 ? make_uint2(gemm16::pack_bf16x2(t[u][0], t[u][1]), gemm16::pack_bf16x2(t[u][2], t[u][3])) : make_uint2(0u, 0u);
         }
     }
     {   // values, transposed into Vt[dim][key] (bf16): four dims per lane and load; keys beyond n are zeros
@@ -1135,12 +1139,13 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
         const int q0 = qt * 16, qi = q0 + j16;
         const bf* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
         const uint4 qv = gemm16::ld8_or_zero(qi < n && g < 2, qrow + 8 * (g & 1));                  // B operand of the score product: Q[query j16][dims 8 g ..] (groups 2, 3: zeros)
-        uint4 pqv = make_uint4(0u, 0u, 0u, 0u);                                                     // B operand of the position product: p[query j16][dims 0 .. 3] in group 0
+        float pq[4];                                                                                // p[query j16][dims 0 .. 3] (rounded to bf16 by the projection's store)
         {
             const uint2 t = *reinterpret_cast<const uint2*>(qrow + 32);
-            const bool ok = qi < n && g == 0;
-            pqv.x = ok ? t.x : 0u; pqv.y = ok ? t.y : 0u;
+            pq[0] = gemm16::bf16_lo(t.x); pq[1] = __uint_as_float(t.x & 0xffff0000u); pq[2] = gemm16::bf16_lo(t.y); pq[3] = __uint_as_float(t.y & 0xffff0000u);
         }
+        // the lane's first table row of tile 0: offset of (query q0 + j16, key 4 g) = n - 1 - (q0 + j16) + 4 g; a tile further on is 16 rows further on
+        const unsigned char* prow = Pt + (kPtFront + n - 1 - q0 - j16 + 4 * g) * 8;
         float st[2 * NP][4];
         float mx = -INFINITY;
 #pragma unroll
@@ -1148,22 +1153,23 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
             const int k0 = kt * 16;
             const uint4 kv = *reinterpret_cast<const uint4*>(g < 2 ? Ks + (k0 + j16) * kK16Pitch + 16 * g : Zs);
             const v4f sc = zmfma16x16x32(kv, qv, v4f{0.0f, 0.0f, 0.0f, 0.0f});
-            const int c0 = n - 16 - q0 + k0;                   // offset index of (query q0 + 15, key k0): u = 0
-            int ca = c0 + j16, cb = c0 + 16 + j16;
-            ca = ca < 0 ? 0 : (ca > n2 - 1 ? n2 - 1 : ca);       // outside the table only for padded queries / keys
-            cb = cb < 0 ? 0 : (cb > n2 - 1 ? n2 - 1 : cb);
-            const uint2 pa = *reinterpret_cast<const uint2*>(g == 0 ? Pt + ca * 8 : Zs), pb = *reinterpret_cast<const uint2*>(g == 0 ? Pt + cb * 8 : Zs);
-            const v4f u0 = zmfma16x16x32(make_uint4(pa.x, pa.y, 0u, 0u), pqv, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 4 g + r][query j16]
-            const v4f u1 = zmfma16x16x32(make_uint4(pb.x, pb.y, 0u, 0u), pqv, v4f{0.0f, 0.0f, 0.0f, 0.0f});     // U^T[u = 16 + 4 g + r][query j16]
+            uint2 tr[4];                                       // table rows of keys k0 + 4 g + r, r = 0 .. 3: 32 consecutive bytes
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { Us[(4 * g + r) * kUs + j16] = u0[r]; Us[(16 + 4 * g + r) * kUs + j16] = u1[r]; }
-            wave_sync();
+            for (int r = 0; r < 4; ++r) tr[r] = *reinterpret_cast<const uint2*>(prow + (k0 + r) * 8);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = sc[r] + Us[(15 - j16 + 4 * g + r) * kUs + j16];
+                float u = pq[0] * gemm16::bf16_lo(tr[r].x);
+                u = fmaf(pq[1], __uint_as_float(tr[r].x & 0xffff0000u), u);
+                u = fmaf(pq[2], gemm16::bf16_lo(tr[r].y), u);
+                u = fmaf(pq[3], __uint_as_float(tr[r].y & 0xffff0000u), u);
+                const float v = sc[r] + u;
                 st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
                 mx = fmaxf(mx, st[kt][r]);
             }
+            // (the tiles are independent: left alone, the compiler requests every tile's table rows up front and sinks the dot products to the softmax below -- 256 registers at
+            //  NT = 12, one wavefront per SIMD.  The opaque uses pin a tile's four scores where they are written; the fence keeps the next tiles' loads behind them.)
+            ADE_OPAQUE_V(st[kt][0]); ADE_OPAQUE_V(st[kt][1]); ADE_OPAQUE_V(st[kt][2]); ADE_OPAQUE_V(st[kt][3]);
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (NT & 1) { st[NT][0] = st[NT][1] = st[NT][2] = st[NT][3] = -INFINITY; }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -1211,7 +1217,8 @@ template <int MODE, int NT, int DT>
 inline size_t zip_attn16_lds(int n) {
     constexpr int NP = (NT + 1) / 2, np32 = NP * 32;
     const int n2p = (2 * n - 1 + 1) & ~1;
-    return 16 + (size_t)np32 * kK16Pitch + (size_t)n2p * 8 + (size_t)DT * 16 * (np32 * 2 + 16) + 4 * 32 * kUs * sizeof(float);
+    (void)n2p;
+    return 16 + (size_t)np32 * kK16Pitch + (size_t)(2 * 16 * NT + 32) * 8 + (size_t)DT * 16 * (np32 * 2 + 16);
 }
 template <int MODE, int NT, int DT>
 bool launch_attn16_nt(hipStream_t s, int heads, const gemm16::bf16_t* proj, int ldp, const float* pos, const gemm16::bf16_t* src, int lds_, gemm16::bf16_t* out, int ldo, SeqGeo geo, int dv) {
