@@ -64,6 +64,20 @@ struct HasKeep : std::false_type {};
 template <class T>
 struct HasKeep<T, std::void_t<decltype(&T::keep)>> : std::true_type {};
 
+// A context Store may ALSO declare `static constexpr bool kV4 = true` (round 5): the tile is then computed TRANSPOSED (the MFMA operands swapped: the same products, the same
+// order of accumulation over k, the same bits), so that a lane's four accumulator registers are four CONSECUTIVE columns of one row, and the epilogue hands the store whole
+// float4s -- 16 of them per lane and tile instead of 64 scalars, 4 row contexts instead of 16, nothing exchanged between lanes for a store that pairs neighbouring columns:
+//     __host__ __device__ bool can_v4(int N) const;      (N, the leading dimension and the pointers allow 16-byte accesses; launch() falls back to the scalar form if not)
+//     Col4T col4(int n) const;  Pre4T pre4(int m, int n, const RowT&) const;      (n % 4 == 0: what the store READS for columns n .. n + 3)
+//     void store4(int m, int n, float4 v, const RowT&, const Col4T&, const Pre4T&) const;
+// row(m) is shared with the scalar form, which stays for N % 4 != 0 (NoV4<ST> hides the flag).
+template <class T, class = void>
+struct HasV4 : std::false_type {};
+template <class T>
+struct HasV4<T, std::void_t<decltype(T::kV4)>> : std::integral_constant<bool, T::kV4> {};
+template <class S>
+struct NoV4 : S { static constexpr bool kV4 = false; };
+
 template <class T, class = void>
 struct HasVec4 : std::false_type {};
 template <class T>
@@ -85,6 +99,7 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
+    constexpr bool kT = HasV4<ST>::value;              // transposed tiles: lane (g, j16), register r of tile (i, j) is C[wm + 16 i + j16][wn + 16 j + 4 g + r]
     constexpr bool kAVec = AL::kAlongK && HasVec4<AL>::value, kBVec = !BL::kAlongN && HasVec4<BL>::value;
     bool a_rt = false, b_rt = false;
     if constexpr (kAVec) a_rt = a_of.can_vec4(K);
@@ -214,10 +229,17 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
                 const float4 b4 = bq[j & 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].y, b4.y, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].z, b4.z, acc[i][j]);
-                    acc[i][j] = mfma16x16x4(a4[i].w, b4.w, acc[i][j]);
+                    if constexpr (kT) {
+                        acc[i][j] = mfma16x16x4(b4.x, a4[i].x, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(b4.y, a4[i].y, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(b4.z, a4[i].z, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(b4.w, a4[i].w, acc[i][j]);
+                    } else {
+                        acc[i][j] = mfma16x16x4(a4[i].x, b4.x, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].y, b4.y, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].z, b4.z, acc[i][j]);
+                        acc[i][j] = mfma16x16x4(a4[i].w, b4.w, acc[i][j]);
+                    }
                 }
             }
     };
@@ -269,6 +291,36 @@ __device__ __forceinline__ void gemm_tile(const AL& a_of, const BL& b_of, const 
     } else {
         k_loop(std::false_type{}, std::false_type{});
     }
+    if constexpr (kT) {
+        // transposed tiles, float4 stores: per 16-row band ONE row context, then the four float4s' reads in a batch, then the four stores
+        auto emit4 = [&](auto guard_c) {
+            constexpr bool G = decltype(guard_c)::value;
+            decltype(store.col4(0)) cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n_blk + wn + 16 * j + 4 * g;
+                cc[j] = store.col4(G && n >= N ? 0 : n);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m_blk + wm + 16 * i + j16, mc = G && m >= M ? M - 1 : m;
+                const auto rc = store.row(mc);
+                decltype(store.pre4(0, 0, rc)) pc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_blk + wn + 16 * j + 4 * g;
+                    pc[j] = store.pre4(mc, G && n >= N ? 0 : n, rc);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_blk + wn + 16 * j + 4 * g;
+                    if (!G || (m < M && n < N)) store.store4(m, n, make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]), rc, cc[j], pc[j]);
+                }
+            }
+        };
+        if (m_blk + kTM <= M && n_blk + kTN <= N) emit4(std::false_type{});
+        else emit4(std::true_type{});
+    } else
     // lane (g, j16), register r of tile (i, j) is C[wm + 16 i + 4 g + r][wn + 16 j + j16]
     if constexpr (HasCtx<ST>::value) {
         // context form (see the header): everything the store READS is requested in batches -- 4 column contexts, then per 16-row band 4 row contexts and 16
@@ -338,6 +390,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm128(AL a_of, BL b_of, ST store, 
 
 template <class AL, class BL, class ST>
 inline void launch(hipStream_t s, const AL& a, const BL& b, const ST& st, int M, int N, int K) {
+    if constexpr (HasV4<ST>::value) {
+        if (!st.can_v4(N)) { launch(s, a, b, NoV4<ST>{st}, M, N, K); return; }
+    }
     const dim3 grid((unsigned)((N + kTN - 1) / kTN), (unsigned)((M + kTM - 1) / kTM));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gemm128<AL, BL, ST>), grid, dim3(256), 0, s, a, b, st, M, N, K);
 }

@@ -115,6 +115,27 @@ struct RotaryQkStore {
         // explicit rounding order: the guarded and the interior copy of the epilogue must not contract this sum of two products differently
         out[(size_t)m * ld + n] = n < rot_cols ? __fmaf_rn(u, cs.x, __fmul_rn(partner, cs.y)) : u;
     }
+    // float4 form (gemm::HasV4: transposed tiles, a lane holds columns n .. n + 3 of a row -- both members of a rotary pair, no lane exchange; the same products and sums)
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const {
+        return !((N | ld | rot_cols) & 3) && !(((size_t)out | (size_t)bias | (size_t)rcos | (size_t)rsin) & 15);
+    }
+    struct Pre4 { float4 c, s; };
+    __device__ float4 col4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ Pre4 pre4(int, int n, const RowC& r) const {
+        const int at = r.tab + (n & (kDh - 1));
+        const float* pc = n < rot_cols ? rcos + at : rcos;                   // (loads through a selected pointer; the v / gate columns ignore what they read)
+        const float* ps = n < rot_cols ? rsin + at : rsin;
+        return Pre4{*reinterpret_cast<const float4*>(pc), *reinterpret_cast<const float4*>(ps)};
+    }
+    __device__ void store4(int m, int n, float4 v, const RowC& r, const float4& b, const Pre4& p) const {
+        const float ux = v.x * r.sc + b.x, uy = v.y * r.sc + b.y, uz = v.z * r.sc + b.z, uw = v.w * r.sc + b.w;
+        float4 o = make_float4(ux, uy, uz, uw);
+        if (n < rot_cols)
+            o = make_float4(__fmaf_rn(ux, p.c.x, __fmul_rn(uy, p.s.x)), __fmaf_rn(uy, p.c.y, __fmul_rn(ux, p.s.y)), __fmaf_rn(uz, p.c.z, __fmul_rn(uw, p.s.z)),
+                            __fmaf_rn(uw, p.c.w, __fmul_rn(uz, p.s.w)));
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = o;
+    }
 };
 struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
     static constexpr bool kCtx = true;
@@ -127,7 +148,16 @@ struct ScaleBiasGeluStore {    // gelu(v * scale[m] + bias[n]), erf form (:564)
     __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
     __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const {
         const float x = v * sc + b;
-        out[(size_t)m * ld + n] = 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f));      // (round 5) erf to 1.5e-7 on the hardware exp / rcp: erff() is ~40 instructions per element of the FFN's hidden tensor
+        out[(size_t)m * ld + n] = gelu1(x);
+    }
+    static __device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.0f + gemm16::erf_fast(x * 0.70710678118654752440f)); }
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)out | (size_t)bias) & 15); }
+    __device__ float4 col4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ gemm::None pre4(int, int, float) const { return gemm::None{}; }
+    __device__ void store4(int m, int n, float4 v, float sc, const float4& b, gemm::None) const {
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = make_float4(gelu1(v.x * sc + b.x), gelu1(v.y * sc + b.y), gelu1(v.z * sc + b.z), gelu1(v.w * sc + b.w));
+        // (round 5) erf to 1.5e-7 on the hardware exp / rcp: erff() is ~40 instructions per element of the FFN's hidden tensor
     }
 };
 struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)
@@ -140,6 +170,15 @@ struct ResidualStore {         // x[m][n] += v (+ bias[n])    (:569-570)
     __device__ ColC col(int n) const { return ColC{bias ? bias[n] : 0.0f, bias != nullptr}; }
     __device__ float pre(int m, int n, gemm::None) const { return x[(size_t)m * ld + n]; }
     __device__ void operator()(int m, int n, float v, gemm::None, const ColC& c, float old) const { x[(size_t)m * ld + n] = old + (c.has ? v + c.b : v); }
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)x | (size_t)bias) & 15); }
+    struct ColC4 { float4 b; bool has; };
+    __device__ ColC4 col4(int n) const { return ColC4{bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), bias != nullptr}; }
+    __device__ float4 pre4(int m, int n, gemm::None) const { return *reinterpret_cast<const float4*>(x + (size_t)m * ld + n); }
+    __device__ void store4(int m, int n, float4 v, gemm::None, const ColC4& c, const float4& old) const {
+        *reinterpret_cast<float4*>(x + (size_t)m * ld + n) = make_float4(old.x + (c.has ? v.x + c.b.x : v.x), old.y + (c.has ? v.y + c.b.y : v.y), old.z + (c.has ? v.z + c.b.z : v.z),
+                                                                         old.w + (c.has ? v.w + c.b.w : v.w));
+    }
 };
 struct BiasTanhStore {         // tanh(v + bias[n])   (:581-582)
     static constexpr bool kCtx = true;

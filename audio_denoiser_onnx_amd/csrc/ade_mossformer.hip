@@ -152,6 +152,20 @@ struct BiasActRowStore {       // out[m * ld + n] = act(v + bias[n])
         if (ACT == 3) v = v >= 0.0f ? v : v * alpha;
         out[(size_t)m * ld + n] = v;
     }
+    // float4 form (gemm::HasV4: transposed tiles, 16 float4 stores per lane and tile instead of 64 scalar ones; the same arithmetic per element)
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)out | (size_t)bias) & 15); }
+    __device__ float4 col4(int n) const { return bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+    __device__ gemm::None pre4(int, int, gemm::None) const { return gemm::None{}; }
+    __device__ float act1(float v) const {
+        if (ACT == 1) v = fmaxf(v, 0.0f);
+        if (ACT == 2) v = silu(v);
+        if (ACT == 3) v = v >= 0.0f ? v : v * alpha;
+        return v;
+    }
+    __device__ void store4(int m, int n, float4 v, gemm::None, const float4& b, gemm::None) const {
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = make_float4(act1(v.x + b.x), act1(v.y + b.y), act1(v.z + b.z), act1(v.w + b.w));
+    }
 };
 struct FrontStore {            // window norm folded: H = MI = v * rstd - rstd * mean * rowsum(W)[n] + b[n] + emb_pos[n][t]   (:586-591)
     float *h, *mi;
@@ -190,6 +204,13 @@ struct ScaleSiluStore {        // silu(v * inv[m] + bias[n])   (ScaleNorm folded
     __device__ float col(int n) const { return bias[n]; }
     __device__ gemm::None pre(int, int, float) const { return gemm::None{}; }
     __device__ void operator()(int m, int n, float v, float sc, float b, gemm::None) const { out[(size_t)m * ld + n] = silu(v * sc + b); }
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)out | (size_t)bias) & 15); }
+    __device__ float4 col4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ gemm::None pre4(int, int, float) const { return gemm::None{}; }
+    __device__ void store4(int m, int n, float4 v, float sc, const float4& b, gemm::None) const {
+        *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = make_float4(silu(v.x * sc + b.x), silu(v.y * sc + b.y), silu(v.z * sc + b.z), silu(v.w * sc + b.w));
+    }
 };
 struct Relu2Store {            // attn = relu(q k^T)^2   (:487-488)
     float* out;
@@ -228,6 +249,13 @@ struct ResidualBiasStore {     // x[m][n] += v + bias[n]   (:541)
     __device__ float col(int n) const { return bias[n]; }
     __device__ float pre(int m, int n, gemm::None) const { return x[(size_t)m * ld + n]; }
     __device__ void operator()(int m, int n, float v, gemm::None, float b, float old) const { x[(size_t)m * ld + n] = old + (v + b); }
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)x | (size_t)bias) & 15); }
+    __device__ float4 col4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ float4 pre4(int m, int n, gemm::None) const { return *reinterpret_cast<const float4*>(x + (size_t)m * ld + n); }
+    __device__ void store4(int m, int n, float4 v, gemm::None, const float4& b, const float4& old) const {
+        *reinterpret_cast<float4*>(x + (size_t)m * ld + n) = make_float4(old.x + (v.x + b.x), old.y + (v.y + b.y), old.z + (v.z + b.z), old.w + (v.w + b.w));
+    }
 };
 struct LeakyA {                // A(m, k) = leaky_relu(x[m][k], alpha)   (:599)
     static constexpr bool kAlongK = true;

@@ -23,6 +23,24 @@ struct PlainC {         // C(m, n) -> p[m * ld + n]
     __device__ void operator()(int m, int n, float v) const { p[(size_t)m * ld + n] = v; }
 };
 
+struct ScaleC4 {        // the float4 store form (gemm::HasV4: transposed tiles): C(m, n) = v * scale[m] + bias[n] + old -> p[m * ld + n]; scalar form for N % 4 != 0 / odd pitches
+    static constexpr bool kCtx = true;
+    float* p;
+    const float *scale, *bias;
+    int ld;
+    __device__ float row(int m) const { return scale[m]; }
+    __device__ float col(int n) const { return bias[n]; }
+    __device__ float pre(int m, int n, float) const { return p[(size_t)m * ld + n]; }
+    __device__ void operator()(int m, int n, float v, float sc, float b, float old) const { p[(size_t)m * ld + n] = old + (v * sc + b); }
+    static constexpr bool kV4 = true;
+    __host__ __device__ bool can_v4(int N) const { return !((N | ld) & 3) && !(((size_t)p | (size_t)bias) & 15); }
+    __device__ float4 col4(int n) const { return *reinterpret_cast<const float4*>(bias + n); }
+    __device__ float4 pre4(int m, int n, float) const { return *reinterpret_cast<const float4*>(p + (size_t)m * ld + n); }
+    __device__ void store4(int m, int n, float4 v, float sc, const float4& b, const float4& old) const {
+        *reinterpret_cast<float4*>(p + (size_t)m * ld + n) = make_float4(old.x + (v.x * sc + b.x), old.y + (v.y * sc + b.y), old.z + (v.z * sc + b.z), old.w + (v.w * sc + b.w));
+    }
+};
+
 static int run_case(int M, int N, int K) {
     // row-major copies with a pitch that allows (K % 4 == 0) or forbids the 16-byte path, plus transposed copies for the other two paths
     const int lda = K + (K % 4 == 0 ? 4 : 1), ldb = K + (K % 4 == 0 ? 8 : 3), ldc = N + 5;
@@ -72,6 +90,38 @@ static int run_case(int M, int N, int K) {
     hipMemset(dC, 0xff, C.size() * 4);
     launch((hipStream_t)0, ColMajorA{dAt, M + 2}, WeightNK{dB, ldb}, PlainC{dC, ldc}, M, N, K);
     check("A along m, B along k");
+    {   // the float4 store form against the scalar form of the SAME functor (gemm::NoV4): bit-identical, on a pitch that allows it (N % 4 == 0) and on one that does not
+        const int ld4 = ((N + 3) & ~3) + 4;
+        std::vector<float> sc(M), bi(N + 4), base((size_t)M * ld4);
+        for (auto& v : sc) v = rnd() + 1.5f;
+        for (auto& v : bi) v = rnd();
+        for (auto& v : base) v = rnd();
+        float *dS, *dBi, *dX, *dY;
+        hipMalloc((void**)&dS, M * 4); hipMalloc((void**)&dBi, bi.size() * 4); hipMalloc((void**)&dX, base.size() * 4); hipMalloc((void**)&dY, base.size() * 4);
+        hipMemcpy(dS, sc.data(), M * 4, hipMemcpyHostToDevice); hipMemcpy(dBi, bi.data(), bi.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dX, base.data(), base.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dY, base.data(), base.size() * 4, hipMemcpyHostToDevice);
+        const ScaleC4 st4{dX, dS, dBi, ld4};
+        launch((hipStream_t)0, RowMajorA{dA, lda}, WeightNK{dB, ldb}, st4, M, N, K);                                   // float4 form when N % 4 == 0, else launch()'s own fallback
+        launch((hipStream_t)0, RowMajorA{dA, lda}, WeightNK{dB, ldb}, NoV4<ScaleC4>{ScaleC4{dY, dS, dBi, ld4}}, M, N, K);   // scalar form
+        hipDeviceSynchronize();
+        std::vector<float> X(base.size()), Y(base.size());
+        hipMemcpy(X.data(), dX, X.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost);
+        size_t diff = 0, untouched_bad = 0;
+        double worst = 0.0;
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < ld4; ++n) {
+                const size_t i = (size_t)m * ld4 + n;
+                if (memcmp(&X[i], &Y[i], 4)) ++diff;
+                if (n >= N) { untouched_bad += memcmp(&X[i], &base[i], 4) != 0; continue; }
+                const double want = (double)base[i] + (ref[(size_t)m * N + n] * (double)sc[m] + (double)bi[n]);
+                worst = fmax(worst, fabs(want - (double)X[i]));
+            }
+        const bool ok = diff == 0 && untouched_bad == 0 && worst <= 3.0 * tol;
+        printf("gemm32 M=%d N=%d K=%d %-34s max|d| %.3e, vs scalar form %zu words differ, touched padding %zu -> %s\n", M, N, K,
+               st4.can_v4(N) ? "float4 store form (transposed)" : "float4 store: scalar fallback", worst, diff, untouched_bad, ok ? "OK" : "FAIL");
+        rc |= ok ? 0 : 1;
+        hipFree(dS); hipFree(dBi); hipFree(dX); hipFree(dY);
+    }
     hipFree(dA); hipFree(dB); hipFree(dAt); hipFree(dBkn); hipFree(dC);
     return rc;
 }
