@@ -388,15 +388,21 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
         if (c0 + kKc < n) request(c0 + kKc);
         if (!wave_live) continue;
         v4f st[QT][4];
+        // The K operand of step e + 1 (e = 4 kt + ks) is requested BEFORE the MFMAs of step e (a second float4; the scheduling barrier keeps the compiler from folding the
+        // two back into one register set).  With one set every ds_read_b128 was issued behind the products that still used it and waited for with an empty pipe -- at two
+        // wavefronts per SIMD nothing else covered it: the kernel ran at 67 % matrix-busy (round 5; the same fault as in ade_gemm.h's tile).
+        {
+            float4 kq[2];
+            kq[0] = *reinterpret_cast<const float4*>(Ks + j16 * kPitch + 4 * g);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int t = 0; t < QT; ++t) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float4 kv = *reinterpret_cast<const float4*>(Ks + (16 * kt + j16) * kPitch + 16 * ks + 4 * g);
+            for (int e = 0; e < 16; ++e) {
+                const int kt = e >> 2, ks = e & 3;
+                if (e + 1 < 16) kq[(e + 1) & 1] = *reinterpret_cast<const float4*>(Ks + (16 * ((e + 1) >> 2) + j16) * kPitch + 16 * ((e + 1) & 3) + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 kv = kq[e & 1];
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
+                    if (ks == 0) st[t][kt] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
                     st[t][kt] = mfma16x16x4(kv.x, qreg[t][ks].x, st[t][kt]);
                     st[t][kt] = mfma16x16x4(kv.y, qreg[t][ks].y, st[t][kt]);
                     st[t][kt] = mfma16x16x4(kv.z, qreg[t][ks].z, st[t][kt]);
@@ -430,11 +436,15 @@ __global__ __launch_bounds__(256, 2) void k_attention(const float* __restrict__ 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) acc[t][dt] = acc[t][dt] * alpha;
         }
+        {   // (the V^T operand one step ahead, as above; e = 4 kt + dt)
+            float4 vq[2];
+            vq[0] = *reinterpret_cast<const float4*>(Vt + j16 * kPitch + 4 * g);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * dt + j16) * kPitch + 16 * kt + 4 * g);
+            for (int e = 0; e < 16; ++e) {
+                const int kt = e >> 2, dt = e & 3;
+                if (e + 1 < 16) vq[(e + 1) & 1] = *reinterpret_cast<const float4*>(Vt + (16 * ((e + 1) & 3) + j16) * kPitch + 16 * ((e + 1) >> 2) + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 vv = vq[e & 1];
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     acc[t][dt] = mfma16x16x4(vv.x, st[t][kt][0], acc[t][dt]);
