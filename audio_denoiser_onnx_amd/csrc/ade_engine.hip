@@ -873,6 +873,17 @@ const char* xflag_name(int idx) {
     return idx < kXFlagTra ? "depthwise-convolution history" : (idx < kXFlagInter ? "TRA state" : (idx < kXFlagOla ? "inter-frame GRU state" : "overlap-add carry"));
 }
 ade_status exchange_status(ade_engine* h, const char* who, bool earlier) {
+    if (h->sub) {        // a sub-engine's own bounded hand-offs (H-GTCRN's fused network middle: SubEngine::exchange_error_and_reset); checked here, outside the captured graph
+        const int code = h->sub->exchange_error_and_reset();
+        if (code) {
+            h->timed_out = true;
+            char msg[320];
+            snprintf(msg, sizeof msg, "%s: %s: a segment hand-off (%s) of the fused network stages timed out (%.1f ms)%s; the call's output is not valid "
+                     "(ADE_HG_FUSED=0 runs the multi-kernel sequence, option xwait_ms raises the bound)", who, "sub-engine", xflag_name(code & 15), h->xwait_ticks * 1e-5,
+                     earlier ? " in an earlier call on a caller-provided stream" : "");
+            return fail(h, ADE_ERR_DEVICE, msg);
+        }
+    }
     if (!h->d_xerr) return ADE_OK;
     int code = 0, word = 0;
     for (int k = 0; k < kXErrWords && !code; ++k) { code = ((volatile int*)h->d_xerr)[k]; word = k; }
@@ -1374,6 +1385,7 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
         const double ms = strtod(value, &end);
         if (!value[0] || *end || !(ms >= 0.001) || ms > 20000.0) return fail(h, ADE_ERR_BAD_VALUE, "option xwait_ms: 0.001..20000");
         h->xwait_ticks = (int)(ms * 1e5 + 0.5);
+        if (h->sub) h->sub->set_exchange_wait_ticks(h->xwait_ticks);
         free_graphs(h);
         return ADE_OK;
     }

@@ -266,6 +266,12 @@ struct SubEngine {
     virtual int reserve(int batch, std::string& err) = 0;                                                                          // ade_status
     virtual int run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, std::string& err) = 0;
     virtual int tap(hipStream_t s, const char* name, int batch, float* out, size_t count, size_t* written, std::string& err) = 0;
+    // A sub-engine whose stages hand states between workgroups through bounded waits (H-GTCRN's fused network middle) reports a wait that gave up HERE: the engine calls this
+    // after its stream synchronise on every entry point and at the entry of the next call -- outside any captured graph, so a replayed launch sequence is covered too.
+    // -> 0, or the dev::xcode() the device left; a non-zero answer has drained the device, cleared the word and lowered every flag (a late producer may have raised one
+    // that nobody consumed).  xwait: the engine's option "xwait_ms" in 10 ns ticks.
+    virtual int exchange_error_and_reset() { return 0; }
+    virtual void set_exchange_wait_ticks(int) {}
 };
 // model_family "dfsmn" (DFSMN/Export_DFSMN.py:71-246), csrc/ade_dfsmn.hip
 int dfsmn_create(const std::map<std::string, Tensor>& tensors, int window_len, int n_win, int device, SubEngine** out, std::string& err);

@@ -1310,6 +1310,18 @@ struct ZipEngine : SubEngine {
     float* raw = nullptr;                                                 // a dense layer's raw fp32 output (+ bias)
     bool zip_chain = !(getenv("ADE_ZIP_CHAIN") && atoi(getenv("ADE_ZIP_CHAIN")) == 0);
     int dense_cb = getenv("ADE_ZIP_DENSE_CB") ? atoi(getenv("ADE_ZIP_DENSE_CB")) : 32;      // input channels per stage of k_zip_dense16 (measurement knob)
+    // Error-budget knob of the bf16 path (tools/zip_bf16_budget.py): which parts of a bf16 handle run on bf16 operands -- bit 0 the dense encoder block, bit 1 the eight
+    // Zipformer layers, bit 2 the decoder pair's dense block + sub-pixel convolution.  7 (default) = the bf16 path; a cleared bit runs that part's f32 kernels instead.
+    int parts16 = getenv("ADE_ZIP16_PARTS") ? (atoi(getenv("ADE_ZIP16_PARTS")) & 7) : 7;
+    // ADE_ZIP_LAYER_TAPS=1: the residual stream after every sub-module of the FIRST layer (encoder 0, frequency path) is kept for taps "l0_0" .. "l0_7"
+    // (ff1, nonlin-attention, self-attention 1, convolution 1, ff2 + bypass, self-attention 2, convolution 2, ff3 + final norm); calls of at most 8 windows
+    bool want_layer_taps = getenv("ADE_ZIP_LAYER_TAPS") && atoi(getenv("ADE_ZIP_LAYER_TAPS")) == 1;
+    float* lt = nullptr;
+    bool lt_armed = false;
+    size_t lt_stride = 0;
+    void layer_tap(hipStream_t s, int k, const float* src, long long R) {
+        if (lt && lt_armed && (size_t)R * C <= lt_stride) (void)hipMemcpyAsync(lt + (size_t)k * lt_stride, src, (size_t)R * C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
     const float *down_t[4] = {}, *down_f[4] = {}, *out_scale[4] = {}, *res_scale[4] = {};
     const float *up_w[2] = {}, *up_b[2] = {}, *up_g = nullptr, *up_beta = nullptr, *up_slope = nullptr;
     const float *mask_w = nullptr, *mask_b = nullptr, *phase_w = nullptr, *phase_b = nullptr;
@@ -1611,16 +1623,18 @@ int ZipEngine::reserve(int batch, std::string& err) {
     const size_t wide = (size_t)std::max({3 * hid, H * vd, 2 * C, ffd, ff3});
     const size_t Rt = std::min<size_t>(B, 8) * T * F;     // encoder snapshots: always carved, for calls of at most 8 windows whatever capacity was reserved
     const size_t dh = std::max(tok0 * 4 * C, R * 8 * C);
-    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, bf16 ? (size_t)64 : dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
-                            J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, Rt * C, Rt * C, Rt * C, Rt * C, Rt * C};
+    lt_stride = want_layer_taps ? ((Rt * C + 63) & ~(size_t)63) : 0;
+    const size_t sizes[] = {B, (size_t)kZC2 * J, tok0 * 2, B * C * 4, tok0 * C, (bf16 && parts16 == 7) ? (size_t)64 : dh, B * 8 * C * 2 + B * 2 * C * 2, R * C, R * C, Rd * C, R * (size_t)(attn_dim + ff1), R * wide, R * C,
+                            J * F2 * 2 * C, (size_t)kZC2 * J, J * kZN, J * kZF, Rt * C, Rt * C, Rt * C, Rt * C, Rt * C, 8 * lt_stride};
     float** ptrs[] = {&norm, &spec, &feat, &coef, &E0, &Dh, &nrm, &X, &Y, &X2, &P, &S1, &O, &U, &packed, &frames_buf, &mask_tap, &enc_tap[0], &enc_tap[1], &enc_tap[2],
-                      &enc_tap[3], &enc_tap[4]};
-    const int nbuf = 22;
+                      &enc_tap[3], &enc_tap[4], &lt};
+    const int nbuf = 23;
     size_t total = 0;
     for (int i = 0; i < nbuf; ++i) total += (sizes[i] + 63) & ~(size_t)63;
     ZP_HIP(hipMalloc((void**)&ws, total * sizeof(float)));
     size_t at = 0;
     for (int i = 0; i < nbuf; ++i) { *ptrs[i] = ws + at; at += (sizes[i] + 63) & ~(size_t)63; }
+    if (!want_layer_taps) lt = nullptr;
     nrm2 = nrm + B * 8 * C * 2;                    // statistics of the tensors normalised outside the dense blocks (dense_conv_2, the up-sampler)
     if (bf16) {
         if (ws16) (void)hipFree(ws16);
@@ -1689,52 +1703,50 @@ void ZipEngine::attention(hipStream_t s, int mode, const float* pos, const float
 
 // one fused Zipformer2 encoder layer in place on x (R rows), sequences described by geo (:143-187)
 void ZipEngine::layer(hipStream_t s, const ZLayer& w, const ZLayer16& w16, float* x, long long R, SeqGeo geo) {
-    if (bf16) return layer16(s, w, w16, x, R, geo);
+    if (bf16 && (parts16 & 2)) return layer16(s, w, w16, x, R, geo);
     using namespace gemm64;
     const int M = (int)R, ldp = attn_dim + ff1, n = geo.n, vdim = H * vd;
     // feed-forward modules run fused (k_zip_ff) when their width is a multiple of the 64-unit weight chunk
     auto fused_ff = [&](int fd) { return C == 64 && fd % kFfChunk == 0 && attn_dim % 4 == 0; };
     const bool fnorm_fused = fused_ff(ff3) && w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128;      // nb | fs | rs side by side in the arena: k_zip_ff<3> applies the final norm
-    if (bf16) {
-        launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);
-        zip16::launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                        // (:160)
-    } else if (fused_ff(ff1)) {
+    if (fused_ff(ff1)) {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, attn_dim);                               // (:148-153) attention part of the joint projection
         launch_zip_ff<0>(s, M, x, w.attn_ff1_w + (size_t)attn_dim * C, w.attn_ff1_b + attn_dim, w.ff1_out_w, w.ff1_out_b, x, nullptr, Y, ff1);        // (:160)
     } else {
         launch_proj64(s, x, C, w.attn_ff1_w, w.attn_ff1_b, P, ldp, 0, M, ldp);                                    // (:148-153)
         launch(s, ActRowsA<1>{P + attn_dim, ldp}, WeightB{w.ff1_out_w, ff1}, AddFromStore{x, Y, w.ff1_out_b, C}, M, C, ff1);                  // (:160)
     }
+    layer_tap(s, 0, Y, R);
     launch_proj64(s, Y, C, w.nonlin_in_w, w.nonlin_in_b, S1, 3 * hid, 0, M, 3 * hid);                           // (:305)
     attention(s, 0, w.pos, S1, 3 * hid, O, hid, geo, hid);                                                                                    // (:154-159, :310-316) head 0
     launch(s, RowsA{O, hid}, WeightB{w.nonlin_out_w, hid}, ResidualBiasStore{Y, w.nonlin_out_b, C}, M, C, hid);                              // (:317, :167)
+    layer_tap(s, 1, Y, R);
     for (int i = 0; i < 2; ++i) {
         launch_proj64(s, Y, C, w.sa_in_w[i], w.sa_in_b[i], S1, vdim, 0, M, vdim);                               // (:296)
         attention(s, 1, w.pos, S1, vdim, O, vdim, geo, vd);                                                                                   // (:297-300) all heads
         launch(s, RowsA{O, vdim}, WeightB{w.sa_out_w[i], vdim}, ResidualBiasStore{Y, w.sa_out_b[i], C}, M, C, vdim);                         // (:301, :168 / :172)
+        layer_tap(s, 2 + 3 * i, Y, R);
         launch_proj64(s, Y, C, w.cv_in_w[i], w.cv_in_b[i], S1, 2 * C, 0, M, 2 * C);                             // (:321)
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         if (C == 64 && K == 15) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, float>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<0, 0, float>), cg, dim3(256), cl, s, (const float*)S1, w.cv_dw_w[i], w.cv_dw_b[i], O, geo, C, K);   // (:325-336)
         launch(s, ActRowsA<2>{O, C}, WeightB{w.cv_out_w[i], C}, ResidualBiasStore{Y, w.cv_out_b[i], C}, M, C, C);                            // (:339, :169 / :173)
+        layer_tap(s, 3 + 3 * i, Y, R);
         const int fd = i ? ff3 : ffd;
-        if (bf16) {
-            if (i == 0) zip16::launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);         // (:170-171)
-            else zip16::launch_zip_ff16<1>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);               // (:174)
-            continue;
-        }
         if (fused_ff(fd)) {
             if (i == 0) launch_zip_ff<2>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
             else if (fnorm_fused) launch_zip_ff<3>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], x, w.norm_bias, x, fd);         // (:174-183) the final norm rides in the store
             else launch_zip_ff<1>(s, M, Y, w.ff_in_w[i], w.ff_in_b[i], w.ff_out_w[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
+            if (i == 0) layer_tap(s, 4, Y, R);
+            else if (fnorm_fused) layer_tap(s, 7, x, R);
             continue;
         }
         launch_proj64(s, Y, C, w.ff_in_w[i], w.ff_in_b[i], S1, fd, 0, M, fd);
-        if (i == 0) launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd);   // (:170-171)
+        if (i == 0) { launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, BypassMidStore{x, Y, w.ff_out_b[i], w.bypass_mid, C}, M, C, fd); layer_tap(s, 4, Y, R); }   // (:170-171)
         else launch(s, ActRowsA<1>{S1, fd}, WeightB{w.ff_out_w[i], fd}, ResidualBiasStore{Y, w.ff_out_b[i], C}, M, C, fd);                   // (:174)
     }
-    if (!fnorm_fused) hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+    if (!fnorm_fused) { hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C); layer_tap(s, 7, x, R); }   // (:175-183)
 }
 
 // The same layer on the bf16 path (csrc/ade_zip16.h): the residual stream x / Y stays fp32; every projection reads it through a loader that rounds to bf16 and stores bf16
@@ -1746,10 +1758,12 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
     const bool chain = zip_chain;                    // out-projection + next in-projection pairs in one launch (k_rows16_chain; ADE_ZIP_CHAIN=0: the two-kernel form, same bits)
     launch_rows16<4, 5>(s, F32Rows{x, C}, w16.attn_w, Bf16BiasStore{P16, w.attn_ff1_b, attn_dim, 0}, M, attn_dim);                                 // (:148-153)
     launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                                  // (:160)
+    layer_tap(s, 0, Y, R);
     launch_rows16<4, 5>(s, F32Rows{Y, C}, w16.nonlin_in_w, Bf16BiasStore{S16, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid);                              // (:305)
     launch_attn16<0, 3>(s, 1, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, 3 * hid, O16, hid, geo, hid);   // (:154-159, :310-316)
     if (chain) launch_rows16_chain<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, w.nonlin_out_b, Y, w16.sa_in_w[0], w.sa_in_b[0], S16, vdim, M, vdim);   // (:317, :167) + (:296)
     else launch_rows16<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, ResidualStore{Y, w.nonlin_out_b}, M, C);                                    // (:317, :167)
+    layer_tap(s, 1, Y, R);
     for (int i = 0; i < 2; ++i) {
         if (!(chain && i == 0)) launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);          // (:296)
         launch_attn16<1, 1>(s, H, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, vdim, O16, vdim, geo, vd);  // (:297-300)
@@ -1758,24 +1772,30 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
             launch_rows16<3, 2>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], ResidualStore{Y, w.sa_out_b[i]}, M, C);                                  // (:301)
             launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], Bf16BiasStore{S16, w.cv_in_b[i], 2 * C, 0}, M, 2 * C);                            // (:321)
         }
+        layer_tap(s, 2 + 3 * i, Y, R);
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)
         launch_rows16<4, 2>(s, B16Rows<2>{O16, C}, w16.cv_out_w[i], ResidualStore{Y, w.cv_out_b[i]}, M, C);                                         // (:339)
+        layer_tap(s, 3 + 3 * i, Y, R);
         const int fd = i ? ff3 : ffd;
-        if (i == 0) launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd);                  // (:170-171)
-        else if (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128)          // (nb | fs | rs sit side by side in the arena: the final norm rides in the module's store)
+        if (i == 0) { launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd); layer_tap(s, 4, Y, R); }   // (:170-171)
+        else if (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128) {        // (nb | fs | rs sit side by side in the arena: the final norm rides in the module's store)
             launch_zip_ff16<3>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.norm_bias, x, fd);                            // (:174-183)
-        else {
+            layer_tap(s, 7, x, R);
+        } else {
             launch_zip_ff16<1>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], nullptr, nullptr, Y, fd);                        // (:174)
             hipLaunchKernelGGL(k_zip_final_norm, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, s, x, (const float*)Y, w.norm_bias, w.fnorm, w.fres, R, C);   // (:175-183)
+            layer_tap(s, 7, x, R);
         }
     }
 }
 
 void ZipEngine::dualpath(hipStream_t s, int e, float* x, int B, int Tt, int Ff) {        // (:782-792)
     const long long R = (long long)B * Tt * Ff;
+    lt_armed = e == 0 && keep_taps;
     layer(s, layers[e][0], layers16[e][0], x, R, SeqGeo{B * Tt, Ff, 1, (long long)Ff, 0, 1});                               // frequency path: (b, t) sequences of Ff consecutive rows
+    lt_armed = false;
     layer(s, layers[e][1], layers16[e][1], x, R, SeqGeo{B * Ff, Tt, Ff, (long long)Tt * Ff, 1, (long long)Ff});             // time path: (b, f) sequences, rows Ff apart
 }
 
@@ -1794,7 +1814,8 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     const int nchunk0 = (TF0 + kChunkTok - 1) / kChunkTok;
     hipLaunchKernelGGL(k_zip_features, dim3((unsigned)nchunk0, (unsigned)B), dim3(256), 0, s, (const float*)spec, (float2*)feat, partial, T, J, kChunkTok);
     hipLaunchKernelGGL(k_zip_conv1_coef, dim3((unsigned)B), dim3(64), 0, s, (const double*)partial, nchunk0, (double)TF0, c1_w, c1_b, c1_g, c1_beta, (float4*)coef, C);
-    if (bf16) {
+    const bool enc16 = bf16 && (parts16 & 1), dec16 = bf16 && (parts16 & 4);
+    if (enc16) {
         hipLaunchKernelGGL(k_zip_conv1_apply16, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
         dense_block16(s, enc_dense, 1, E016, B, kZF);
         zip16::launch_rows16<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);                    // (:853)
@@ -1818,12 +1839,12 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
         snap(e + 1);
     }
     // ---- mask | phase decoder pair (:864-893)
-    if (bf16) {
+    if (dec16) {
         hipLaunchKernelGGL(zip16::k_zip_to_bf16, flat(R * (C / 4)), dim3(256), 0, s, (const float*)X, X16, R * (C / 4));
         dense_block16(s, dec_dense, 2, X16, B, F);
     } else dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
-        if (bf16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
+        if (dec16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
         else gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
                             SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
@@ -1851,7 +1872,11 @@ int ZipEngine::tap(hipStream_t s, const char* name, int batch, float* out, size_
     else if (strcmp(name, "e0") == 0) { src = E0; n = J * kZF * C; }                              // (windows, T, 201, C): dense-encoder input
     else if (strcmp(name, "dense") == 0) { src = Dh; n = J * F * 8 * C; }                         // the decoder pair's dense outputs, normalised + PReLU (windows, T, F, 8 C)
     else if (strcmp(name, "nrm") == 0) { src = nrm; n = B * 8 * C * 2; }
+    else if (strncmp(name, "l0_", 3) == 0 && name[3] >= '0' && name[3] <= '7' && !name[4]) { src = (lt && B <= 8) ? lt + (size_t)(name[3] - '0') * lt_stride : nullptr; n = J * F * C; }   // ADE_ZIP_LAYER_TAPS=1
     else return zfail(err, ADE_ERR_NOT_FOUND, std::string("unknown tap: ") + name);
+    // a bf16 handle keeps the dense layers' history and raw buffers in bf16 (Dh16 / E016; Dh is 64 floats and E0 the last layer's raw output there): these two fp32 taps do not exist on it
+    if (bf16 && parts16 == 7 && (strcmp(name, "e0") == 0 || strcmp(name, "dense") == 0))
+        return zfail(err, ADE_ERR_UNSUPPORTED, std::string("tap \"") + name + "\" exists on f32 handles only (ade_gemm_dtype = bf16 keeps this tensor in bf16)");
     if (strncmp(name, "enc", 3) == 0 && B > 8) src = nullptr;
     if (!src || batch <= 0)
         return zfail(err, ADE_ERR_NOT_FOUND, "tap has no data (the encoder snapshots are taken by calls of at most 8 windows, whatever capacity was reserved)");

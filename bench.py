@@ -9,7 +9,11 @@ over one batch of 256 synthetic 1 s chunks per GPU (`configs[1]`), through libad
 Weights: seeded reference-architecture weights (tests/golden/gtcrn_seed0.adew; the reference ships no checkpoint).
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus N ...                      # N > 1 outside a launcher: re-executes itself under torch.distributed.run with N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --workload melband --dtype bf16 --stitch      # BASELINE configs[3] with its RCCL all-gather of the outputs, one command
+
+`--gpus N` MEANS N ranks: the line is refused (non-zero exit, nothing printed) when the launcher's WORLD_SIZE differs from it.
 
 Multi-GPU: chunks are independent reference calls, so each rank runs its own 256 chunks (weak scaling) with NO
 collective in the data path; `--stitch` additionally all-gathers the int16 outputs over RCCL inside the timed region
@@ -74,8 +78,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="gtcrn", choices=["gtcrn", "zipenhancer", "melband", "mossformer"],
-                    help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]")
+    ap.add_argument("--workload", default="gtcrn", choices=["gtcrn", "zipenhancer", "melband", "mossformer", "dfsmn"],
+                    help="BASELINE.json config: gtcrn = configs[1] (default), zipenhancer = [2], melband = [3], mossformer = [4]; dfsmn = north_star's fourth network "
+                         "(256 x 2 s @ 48 kHz, no BASELINE config of its own)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = exact fp32 matrix-core products (parity path, default); bf16 = bf16 activations and weights stored in HBM (--workload melband only: "
                          "csrc/ade_gemm16.h).  The deviation from the f32 path is measured and reported")
@@ -92,9 +97,10 @@ def parse_args():
     ap.add_argument("--geometry", default="auto", choices=["auto", "0", "1", "2"],
                     help="GTCRN fused-path workgroup geometry: 2 = four 256-thread workgroups per CU, each a 16-frame segment of a chunk (default where it fits); "
                          "1 = two 512-thread workgroups per CU (32-frame segments); 0 = one 1024-thread workgroup per chunk (the round-1/2 kernel)")
-    ap.add_argument("--other", default="zipenhancer,melband,mossformer", help="which of the other BASELINE configs the default line times in its `other_workloads` block")
+    ap.add_argument("--other", default="zipenhancer,melband,mossformer,dfsmn", help="which of the other BASELINE configs the default line times in its `other_workloads` block")
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of the `other_workloads` leg of the default line (ZipEnhancer 128 x 1 s, f32; 0 = skip)")
     ap.add_argument("--ramp-ms", type=float, default=100.0, help="untimed power-state ramp before the W warm-up steps (0 = none)")
+    ap.add_argument("--no-stft-operator", action="store_true", help="skip the `stft_operator` block (the generic STFT_Process operator's HBM roofline) of the default line")
     return ap.parse_args()
 
 
@@ -116,7 +122,7 @@ def source_sha1() -> str:
 def workload_traffic(name: str, dtype: str, B: int, default_B: int):
     """Fabric-side bytes of one step of a GEMM-family workload from the committed FETCH_SIZE / WRITE_SIZE passes of `bench.py --workload <name>` (tools/pmc_traffic_workload.sh);
     the newest round's file wins.  -> (bytes per step scaled to B rows, note) or (None, None)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(REPO, "profiles", f"{rnd}_{name}_{dtype}_traffic.json")) as f:
                 tp = json.load(f)
@@ -149,7 +155,7 @@ def kernel_family_roofline(name: str, dtype: str, B: int, frames: int):
         flops = 24 * 2.0 * frames * (512 * 2176 + 1024 * 512 + 512 * 256 + 256 * 512 + 2 * 256 * 256 + 256 * 512) * B
     else:
         return None
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         path = os.path.join(REPO, "profiles", f"{rnd}_z_{name}_{dtype}_kernel_stats.csv")
         if not os.path.exists(path):
             continue
@@ -163,7 +169,8 @@ def kernel_family_roofline(name: str, dtype: str, B: int, frames: int):
         tf = flops * (default_B / B) / (fam_ns * 1e-9) / 1e12 if B else 0.0                  # the summary was taken at the workload's BASELINE batch
         return {"kernel_family": pat, "what": what, "launches_per_step": int(sum(int(r["Calls"]) for r in fam_rows) / steps_in_trace), "ms_per_step": round(fam_ns * 1e-6, 3),
                 "share_of_step_pct": round(100.0 * fam_ns * steps_in_trace / tot, 1), "algorithmic_tflop_per_step": round(flops * (default_B / B) / 1e12, 3),
-                "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "source": f"profiles/{rnd}_z_{name}_{dtype}_kernel_stats.csv"}
+                "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "source": f"profiles/{rnd}_z_{name}_{dtype}_kernel_stats.csv",
+                "measured": "FROM THE COMMITTED PROFILE named in `source` (rocprofv3 cannot run inside bench.py), not from this run: compare `ms_per_step` here with the line's own"}
     return None
 
 
@@ -215,12 +222,37 @@ def other_workload_line(name: str, steps: int, local_rank: int, stream, cpu_budg
     return line
 
 
+def cpu_model() -> str:
+    """The host CPU's model string (/proc/cpuinfo) x sockets, for the cpu_baseline block."""
+    try:
+        names, phys = [], set()
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    names.append(ln.split(":", 1)[1].strip())
+                elif ln.startswith("physical id"):
+                    phys.add(ln.split(":", 1)[1].strip())
+        return f"{max(1, len(phys))} x {names[0]} ({len(names)} hardware threads)" if names else "unknown"
+    except OSError:
+        return "unknown"
+
+
 def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
-    """Oracle (C restatement of the reference, OpenMP over chunks) timed on this host: the reported CPU baseline."""
+    """Oracle (C restatement of the reference, OpenMP over chunks) timed on this host: the reported CPU baseline.  Two legs: every core
+    (`value`), and ONE thread (`threads_1`: the reference's published numbers are single-stream CPU RTFs)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from oracle_lib import GtcrnOracle   # test infrastructure used as the *baseline*, never as the product
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = GtcrnOracle(blob, CHUNK)
+    t0 = time.perf_counter()
+    o.process(x[:1], threads=1)                              # single-thread leg: one chunk to size it, then ~3 s worth
+    one = time.perf_counter() - t0
+    n1 = int(min(32, max(2, 3.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    o.process(x[np.arange(n1) % x.shape[0]], threads=1)
+    dt1 = time.perf_counter() - t0
+    threads_1 = {"value": round(n1 * (15872 / SR) / dt1, 3), "unit": "audio-s/s", "cores": 1, "rtf": round(dt1 / (n1 * 15872 / SR), 5),
+                 "sample": f"{n1} synthetic 1 s chunks one after the other on ONE thread, {dt1:.1f} s wall"}
     t0 = time.perf_counter()
     o.process(x[:cores], threads=cores)                     # probe: one chunk per core
     probe = time.perf_counter() - t0
@@ -230,22 +262,65 @@ def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
     t0 = time.perf_counter()
     o.process(xs, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(n * (15872 / SR) / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port",
+    return {"value": round(n * (15872 / SR) / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": f"{n} of the same synthetic 1 s chunks, oracle/ade_oracle.c (dense-DFT reference arithmetic), "
-                      f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5)}
+                      f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5), "threads_1": threads_1}
 
 
-def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, what: str):
-    """The numpy oracle of a GEMM-shaped family timed on ONE row of the workload (these oracles take 10 - 60 s per row on a host CPU)."""
+def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, what: str, takes_batch: bool = False):
+    """The numpy oracle of a GEMM-shaped family timed on ONE row of the workload at the workload's OWN window length (these oracles take 10 - 90 s per row on a host CPU)."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = make_oracle()
     t0 = time.perf_counter()
     o.process(x_row)
     dt = time.perf_counter() - t0
-    return {"value": round(seconds_per_row / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"1 row of the workload ({what}) through the numpy fp32 oracle (BLAS threads = host default), {dt:.1f} s wall",
+    return {"value": round(seconds_per_row / dt, 3), "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{'rows' if takes_batch else '1 row'} of the workload ({what}) through the numpy fp32 oracle (BLAS threads = host default), {dt:.1f} s wall",
             "rtf": round(dt / seconds_per_row, 4)}
+
+
+def stft_operator_lines(stream):
+    """The generic STFT_Process operator (csrc/ade_stft.hip) on its own: the one HBM-BOUND kernel family of the path (section 8 d3).  Analysis
+    and synthesis at GTCRN's shape (256 x 1 s, n_fft 512 / hop 256) and Mel-Band's (64 x 1.5 s, n_fft 2048 / hop 441): algorithmic bytes (fp32 samples in or out + the
+    packed (B, 2F, T) spectrum out or in, each once) / the average launch duration (HIP events on the launch stream) / 8 TB/s."""
+    import torch
+    from audio_denoiser_onnx_amd.stft_process import STFT_Process
+    out = {}
+    for name, n_fft, hop, L, B in (("gtcrn_512_256", 512, 256, 16000, 256), ("melband_2048_441", 2048, 441, 66150, 64)):
+        fwd = STFT_Process("stft_B", n_fft, n_fft, hop, 0, "hann", True, "reflect")
+        T = fwd.frames(L)
+        inv = STFT_Process("istft_B", n_fft, n_fft, hop, T, "hann", True, "reflect")
+        x = torch.randn(B, 1, L, device="cuda") * 0.1
+        for _ in range(3):
+            sp = fwd(x, stream=stream)
+            y = inv(sp, stream=stream)
+        n = 20
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(n):
+            sp = fwd(x, stream=stream)
+        ev[1].record()
+        for _ in range(n):
+            y = inv(sp, stream=stream)
+        ev[2].record()
+        torch.cuda.synchronize()
+        ta, ts = ev[0].elapsed_time(ev[1]) / n * 1e-3, ev[1].elapsed_time(ev[2]) / n * 1e-3
+        bytes_spec, bytes_a, bytes_s = B * (n_fft + 2) * T * 4, B * L * 4, int(y.numel()) * 4
+        err = float((y.reshape(B, -1) - x.reshape(B, -1)[:, :y.numel() // B]).abs().max())
+        out[name] = {"batch": B, "samples": L, "frames": T,
+                     "analysis": {"us": round(ta * 1e6, 1), "algorithmic_bytes": bytes_a + bytes_spec, "achieved": round((bytes_a + bytes_spec) / ta / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round((bytes_a + bytes_spec) / ta / 1e9 / HBM_PEAK_GBS, 4)},
+                     "synthesis": {"us": round(ts * 1e6, 1), "algorithmic_bytes": bytes_s + bytes_spec, "achieved": round((bytes_s + bytes_spec) / ts / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round((bytes_s + bytes_spec) / ts / 1e9 / HBM_PEAK_GBS, 4)},
+                     "round_trip_max_abs_err": float(f"{err:.2e}")}
+        fwd.close()
+        inv.close()
+    out["bound"] = "hbm"
+    out["note"] = ("the engines do not call this operator (their front / back stages fuse the transforms with the network); it is the drop-in for the reference's "
+                   "STFT_Process module and the only HBM-bound kernel family of the path")
+    return out
 
 
 SKIP_DEVIATION = False
@@ -305,15 +380,14 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         sess = InferenceSession(weights=blob, metadata=melband.metadata(L, gemm_dtype=dtype), device_id=local_rank)
         del blob
 
-        def cpu():          # bounded sample: the same depth-6 network on ONE 1 s stereo clip (101 frames instead of 801; the oracle's cost is linear in frames except for the time attention)
+        def cpu():          # ONE row of the workload at its own length (8 s stereo, 801 frames, depth 6): 60 - 120 s of numpy on the host
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             from melband_oracle import MelBandOracle
             from audio_denoiser_onnx_amd import mel_bands
-            Ls = 44100
             wts = weightgen.materialise(melband.synthetic_spec(depth))
             freq_indices, dim_inputs = mel_bands.band_tables()[:2]
-            return cpu_baseline_numpy(lambda: MelBandOracle(wts, freq_indices, dim_inputs, Ls // 441 + 1, depth), synth_stereo(0, Ls, 44100), 1.0,
-                                      "one 1 s stereo clip, 101 frames x 60 bands, depth 6 -- a shorter clip than the 8 s workload rows")
+            return cpu_baseline_numpy(lambda: MelBandOracle(wts, freq_indices, dim_inputs, L // 441 + 1, depth), synth_stereo(0, L, 44100), L / 44100.0,
+                                      "one 8 s stereo segment, 801 frames x 60 bands, depth 6 -- the workload's own row")
         return dict(sess=sess, B=B, x=x, sr=44100, flop=melband.flops_per_clip(sess.frames, depth), cpu=cpu, deviation=deviation,
                     metric="audio_seconds_per_second (Mel-Band-Roformer stereo 44.1 kHz, batch=32 x 8 s segments; RTF = 1/value)",
                     workload="Mel-Band-Roformer stereo 44.1 kHz, depth 6, batch=32 x 8 s segments (801 frames), " +
@@ -334,26 +408,85 @@ def build_workload(name: str, batch: int, rank: int, local_rank: int, dtype: str
         sess = InferenceSession(weights=blob, metadata=mossformer.metadata(L, gemm_dtype=dtype), device_id=local_rank)
         del blob
 
-        def cpu():          # bounded sample: the same 24-layer network on ONE 1 s window (1999 frames instead of 7999)
+        def cpu():          # ONE row of the workload at its own length (4 s, 7999 frames, 24 layers): 30 - 60 s of numpy on the host
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             from mossformer_oracle import MossFormerOracle
-            Ls = 16000
-            fr = mossformer.frames_of(Ls)
-            tensors = {n: mossformer.synthetic_tensor(n, sh, sc, fr) for n, sh, sc in mossformer.synthetic_spec(layers)}
-            tensors.update(mossformer.position_tables(fr, int(scalars["rot_dim"])))
-            xs = (synth_chunk(0, Ls).astype(np.int32) + synth_chunk(10000, Ls)).clip(-32768, 32767).astype(np.int16)[None]
-            return cpu_baseline_numpy(lambda: MossFormerOracle(tensors, scalars, layers, Ls), xs, 1.0, "one 1 s window, 1999 frames, 24 layers -- a shorter window than the 4 s workload rows")
+            tensors = {n: mossformer.synthetic_tensor(n, sh, sc, frames) for n, sh, sc in mossformer.synthetic_spec(layers)}
+            tensors.update(mossformer.position_tables(frames, int(scalars["rot_dim"])))
+            xs = (synth_chunk(0, L).astype(np.int32) + synth_chunk(10000, L)).clip(-32768, 32767).astype(np.int16)[None]
+            return cpu_baseline_numpy(lambda: MossFormerOracle(tensors, scalars, layers, L), xs, L / 16000.0, "one 4 s window, 7999 frames, 24 layers -- the workload's own row")
         return dict(sess=sess, B=B, x=x, sr=16000, flop=mossformer.flops_per_window(sess.frames, layers), cpu=cpu, deviation=deviation,
                     metric="audio_seconds_per_second (MossFormer2-SS-16K, batch=64 x 4 s; RTF = 1/value)",
                     workload="MossFormer2-SS-16K two-speaker separation, 24 layers, batch=64 x 4 s (7999 frames), fp32 matrix cores, int16 PCM resident in HBM "
                              "(BASELINE.json configs[4])",
                     weights="random-init weights of the published geometry (mossformer.synthetic_spec, 24 layers)", target_rtf=None)
+    if name == "dfsmn":                                            # north_star's DFSMN: no BASELINE config of its own; 256 x 2 s @ 48 kHz
+        B, L = batch or 256, 96000
+        with open(os.path.join(REPO, "tests", "golden", "dfsmn_seed0.adew"), "rb") as f:
+            blob = f.read()
+        meta = build_audio_metadata_dfsmn(L)
+        rng = np.random.default_rng(1000 + rank)
+        x = (rng.standard_normal((B, L)) * 1500).astype(np.int16)
+        sess = InferenceSession(weights=blob, metadata=meta, device_id=local_rank)
+        frames = sess.frames
+        macs_frame = 120 * 1025 + 256 * 120 + 9 * 2 * 256 * 256 + 961 * 256          # mel bank + Linear(120,256) + 9 x (Linear, Linear) + Linear(256,961) (Export_DFSMN.py:216-230)
+        fft_flop_frame = 5.0 * (2048 * 11 + 2 * 1920 * 10.9) / 2                        # two real forward transforms riding one complex FFT per frame pair + one inverse
+        # (the nine layers' depthwise memories, lorder 20: 9 x 256 x 20 MACs per frame)
+        flop_row = frames * (2.0 * (macs_frame + 9 * 256 * 20) + fft_flop_frame)
+
+        def cpu():
+            sys.path.insert(0, os.path.join(REPO, "oracle"))
+            from dfsmn_oracle import DfsmnOracle
+            from audio_denoiser_onnx_amd.weights import load_blob
+            tensors = load_blob(os.path.join(REPO, "tests", "golden", "dfsmn_seed0.adew"))
+            return cpu_baseline_numpy(lambda: DfsmnOracle(tensors, L), x[:min(B, 256)], min(B, 256) * L / 48000.0, f"{min(B, 256)} rows of 2 s @ 48 kHz, 99 frames each", takes_batch=True)
+        return dict(sess=sess, B=B, x=x, sr=48000, flop=flop_row, cpu=cpu, deviation=None,
+                    metric="audio_seconds_per_second (DFSMN 48 kHz, batch=256 x 2 s chunks; RTF = 1/value)",
+                    workload="DFSMN 48 kHz acoustic noise suppression (north_star's fourth network; no BASELINE config of its own), batch=256 x 2 s chunks (99 frames of 1920 / hop 960), "
+                             "fp32: FFT analysis / synthesis + the mask network on fp32 matrix cores, int16 PCM resident in HBM",
+                    weights="seeded reference-architecture DFSMN (tests/golden/dfsmn_seed0.adew; the reference takes its parameters from modelscope, absent offline)", target_rtf=None)
     raise SystemExit(f"unknown workload {name}")
+
+
+def build_audio_metadata_dfsmn(length: int):
+    from audio_denoiser_onnx_amd.metadata import build_audio_metadata
+    return build_audio_metadata(producer="bench.py", model_name="DFSMN", task="denoise", model_family="dfsmn", input_audio_length=length, in_sample_rate=48000,
+                                out_sample_rate=48000, model_sample_rate=48000, nfft=1920, window_length=1920, hop_length=960, window_type="hamming", center_pad=False,
+                                pad_mode="constant", feature_kind="kaldi_fbank_stft")
+
+
+def relaunch_command(n: int, argv, port: int):
+    """The launcher line `--gpus N` (N > 1) stands for when bench.py is started bare: one rank per GPU on this node, rendezvous on the loopback address."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(gpus: int, env=os.environ):
+    """--gpus N means N ranks.  -> ("run", world) inside a launcher whose WORLD_SIZE equals N (or bare with N = 1); ("relaunch", N) when N > 1 and no launcher
+    is present; SystemExit(2) when a launcher's WORLD_SIZE contradicts --gpus (a line with another n_gpus than the one asked for is never printed)."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in env:
+        return ("run", 1) if gpus == 1 else ("relaunch", gpus)
+    world = int(env["WORLD_SIZE"])
+    if world != gpus:
+        sys.stderr.write(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE = {world} rank(s); refusing to report a line for another GPU count\n")
+        raise SystemExit(2)
+    return ("run", world)
 
 
 def main():
     global SKIP_DEVIATION, DEVIATION_DTYPE
     args = parse_args()
+    action, _n = check_world(args.gpus)
+    if action == "relaunch":
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(relaunch_command(args.gpus, sys.argv[1:], port), env=env))
     SKIP_DEVIATION = args.no_deviation
     DEVIATION_DTYPE = args.dtype
     if args.dtype != "f32" and args.workload not in ("melband", "zipenhancer"):
@@ -365,8 +498,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    assert world == args.gpus, (world, args.gpus)            # (check_world: a line is only ever printed for the GPU count that was asked for)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU execution path")
+    if torch.cuda.device_count() < (int(os.environ.get("LOCAL_WORLD_SIZE", world)) if distributed else 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -394,7 +530,7 @@ def main():
         x_host = synth_batch(B, CHUNK, first_index=lo)
         sr, wl = SR, None
     else:
-        default_B = {"zipenhancer": 128, "melband": 32, "mossformer": 64}[args.workload]
+        default_B = {"zipenhancer": 128, "melband": 32, "mossformer": 64, "dfsmn": 256}[args.workload]
         B_total = args.batch or default_B
         lo, hi = shard_bounds(B_total, world, rank) if strong else (rank * B_total, (rank + 1) * B_total)
         B = hi - lo
@@ -449,10 +585,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * elapsed / max(1, args.steps)]
     if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(every, mine)
+        rank_ms = [1e3 * float(v) / max(1, args.steps) for v in every.tolist()]
+        elapsed = float(every.max().item())                 # the job's time is its slowest rank's
 
     if gtcrn and sess.tap("xchg_error", 1)[0] != 0.0:      # a segment hand-off of the fused path timed out inside the timed loop: the steps after it are not a measurement
         raise SystemExit("bench.py: the fused path reported an inter-workgroup time-out (xchg_error) during the timed loop; no number is reported")
@@ -504,7 +643,7 @@ def main():
                                    "steady_state_equals_ade_process": same,
                                    "steady_state_note": f"ade_submit / ade_wait, {depth} submissions in flight on page-locked buffers: wall clock per batch over {ps} back-to-back batches"})
 
-    roofline = cpu = kernels = others = None
+    roofline = cpu = kernels = others = stft_op = None
     if rank == 0 and gtcrn:
         # per-kernel device time, HIP events on the launch stream (ade_profile_last), averaged over a few forwards
         def timed(mode, reps=10):
@@ -568,11 +707,16 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(blob, x_host, args.cpu_seconds)
+        if world == 1 and not args.no_stft_operator:
+            try:
+                stft_op = stft_operator_lines(stream)
+            except Exception as ex:   # the headline must not depend on it
+                stft_op = {"error": repr(ex)}
         if world == 1 and args.other_steps > 0:
             # ZipEnhancer (the second north-star target) with the full step count; the two one-second-per-step transformer configs with ONE timed step
             # each after their warm-up step, so that the driver's clock covers every BASELINE config and the default invocation still ends within minutes.
             others = {}
-            for name, steps, dt_ in (("zipenhancer", max(3, args.other_steps), "f32"), ("zipenhancer", max(3, args.other_steps), "bf16"), ("melband", 3, "f32"), ("melband", 3, "bf16"), ("mossformer", 3, "f32")):
+            for name, steps, dt_ in (("zipenhancer", max(3, args.other_steps), "f32"), ("zipenhancer", max(3, args.other_steps), "bf16"), ("melband", 3, "f32"), ("melband", 3, "bf16"), ("mossformer", 3, "f32"), ("dfsmn", max(3, args.other_steps), "f32")):
                 if name not in args.other.split(","):
                     continue
                 key = name if dt_ == "f32" else f"{name}_{dt_}"
@@ -590,7 +734,7 @@ def main():
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": None,
                     "peak_note": "dense f32-MFMA rate (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s; flops = 2 x MACs of the model's matrix products per row x rows",
                     "algorithmic_bytes_per_step": int(B * (sess.row_in + sess.row_out) * 2)}
-        for cand in (f"r05_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r04_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json",
+        for cand in (f"r06_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r05_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json", f"r04_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json",
                      f"r02_{args.workload}{'' if args.dtype == 'f32' else '_' + args.dtype}_mfma_busy.json"):
             if "mfma_busy" in roofline:
                 break
@@ -630,6 +774,7 @@ def main():
                        "launch": (f"one kernel per step (k_gtcrn_chunk, geometry {int(geo[0])}: {int(geo[1])} workgroup(s) of {(1024, 512, 256)[int(geo[0])]} threads "
                                   "per chunk), plain launch") if gtcrn
                                  else "the sub-engine's launch sequence (replayed from a captured hipGraph unless --no-graph)",
+                       "rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
                        "stitch_all_gather": bool(gathered is not None),
                        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if distributed else None)},
             "roofline": roofline,
@@ -639,6 +784,8 @@ def main():
         }
         if others:
             line["other_workloads"] = others
+        if stft_op:
+            line["stft_operator"] = stft_op
         if not gtcrn and wl.get("target_rtf"):
             line["target_rtf"] = wl["target_rtf"]
         if not gtcrn and args.dtype != "f32":

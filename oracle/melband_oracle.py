@@ -166,11 +166,13 @@ class MelBandOracle:
             off += d
         h = np.stack(outs, axis=0)                                                         # (nb, T, dim)
         self.taps["band_split"] = h.copy()
+        self.taps["layers"] = []                                                           # the token tensor after each (time, freq) pair: tests print the error growth with depth
         for i in range(self.depth):                                                        # axial transformers (:609-614)
             h = self._transformer(h, f"time{i}", self.tcos, self.tsin)
             h = h.transpose(1, 0, 2)                                                       # (T, nb, dim)
             h = self._transformer(h, f"freq{i}", self.fcos, self.fsin)
             h = h.transpose(1, 0, 2)
+            self.taps["layers"].append(h.copy())
         self.taps["tf_out"] = h.copy()
         m = np.tanh(h @ self.w["me_w1t"] + self.w["me_b1"]).astype(F32)                    # _mask_estimator (:579-585)
         m = np.tanh(m @ self.w["me_w2t"] + self.w["me_b2"]).astype(F32)

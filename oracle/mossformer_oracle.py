@@ -204,6 +204,8 @@ class MossFormerOracle:
             self.taps["wav"] = out.copy()
         return np.clip(np.trunc(out.astype(np.float64)), -32768, 32767).astype(np.int16)
 
+    tap_after = ()       # layer counts k whose truncated-network output is kept in taps["mdl_out_after"][k]
+
     def process(self, pcm: np.ndarray, out_len: int = 0) -> np.ndarray:
         """pcm int16 (B, L): B independent windows -> int16 (B, 2, L_out).  L != W or out_len: the resampling edges (in / out rate != 16 kHz):
         the int16 samples are interpolated to W model-rate samples as floats, the restored waveform to out_len before the int cast."""
@@ -221,12 +223,17 @@ class MossFormerOracle:
         mdl_in = (mask + w["emb_pos"][..., :n]).astype(F32)                                                 # (:590-591)
         self.taps["mdl_in"] = mdl_in.copy()
         h = mdl_in.transpose(0, 2, 1)
+        def tail(hh):
+            hh = _layer_norm(hh, w["mm_norm_w"], w["mm_norm_b"], s["mm_norm_eps"]).transpose(0, 2, 1)       # (:544-545)
+            hh = self._window_norm(hh, s["intra_norm_eps"])
+            return (hh * w["intra_norm_w"][None, :, None] + w["intra_norm_b"][None, :, None] + mdl_in).astype(F32)  # (:549-551)
+        self.taps["mdl_out_after"] = {}                  # k -> what "mdl_out" would be if the network ended after k layers (tests print the error growth with depth)
         for i in range(self.layers):
             h = self._flash(h, i)
             h = self._fsmn(h, i)
-        h = _layer_norm(h, w["mm_norm_w"], w["mm_norm_b"], s["mm_norm_eps"]).transpose(0, 2, 1)             # (:544-545)
-        h = self._window_norm(h, s["intra_norm_eps"])
-        h = (h * w["intra_norm_w"][None, :, None] + w["intra_norm_b"][None, :, None] + mdl_in).astype(F32)  # (:549-551)
+            if (i + 1) in self.tap_after:
+                self.taps["mdl_out_after"][i + 1] = tail(h)
+        h = tail(h)
         self.taps["mdl_out"] = h.copy()
         m = np.where(h >= 0, h, h * F32(s["tail_prelu_alpha"])).astype(F32)                                 # (:599)
         gp = (np.einsum("oc,bcn->bon", w["tail_gate_w"][:, :, 0], m) + w["tail_gate_b"][None, :, None]).astype(F32)

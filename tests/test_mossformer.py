@@ -201,11 +201,69 @@ def _big_fixture(tag):
     return z, fused, scalars, W
 
 
+def test_oracle_full_depth_matches_reference_forward():
+    """The numpy restatement against the reference's own forward at the BASELINE depth: 24 layers (Export_MossFormer2_SS_16K.py:460-550) x one 1 s window (1999 frames)."""
+    from mossformer_oracle import MossFormerOracle
+    z, fused, scalars, W = _big_fixture("l24_1999")
+    assert int(z["layers"]) == 24
+    tensors = dict(fused)
+    tensors.update(mossformer.position_tables(mossformer.frames_of(W), int(scalars["rot_dim"])))
+    o = MossFormerOracle(tensors, scalars, 24, W)
+    out = o.process(z["pcm_in"][None])[0]
+    tap = float(np.abs(o.taps["mdl_out"][0][::8, ::7] - z["mdl_out"]).max())
+    wave = float(np.abs(o.taps["wav"][0][:, ::int(z["wave_step"])] - z["wave"]).max())
+    d = out.astype(np.int32) - z["pcm_out"].astype(np.int32)
+    print("oracle 24 layers vs reference: mdl_out max %.2e, wave max %.3f (int16 units), PCM max %d LSB" % (tap, wave, np.abs(d).max()))
+    # (24 layers of fp32 round-off between numpy's and torch's summation orders: 1.85 units = 5.7e-5 of full scale on the waveform, so the truncating cast may differ by 2)
+    assert tap < 5e-3 and wave <= 3.3 and np.abs(d).max() <= 2 and (d != 0).mean() < 0.10
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,frames", [("l4_2999", 2999), ("l2_7999", 7999)])
+def test_gpu_full_depth_error_growth_vs_oracle():
+    """VERDICT r05 missing #1: HIP vs the numpy oracle at the depth `bench.py --workload mossformer` times (24 layers) on one 1 s window, with the growth of the
+    masking network's output error printed for networks cut after k = 1, 2, 4, 8, 16, 24 layers (the engine has one "mdl_out" tap, so it is built once per k from the
+    first k layers of the same weights; the oracle keeps the truncated outputs of one pass).  Gates at 24 layers: fp32 waveform within 1e-4 of full scale (3.3 in
+    these int16 units), PCM <= 2 LSB."""
+    from mossformer_oracle import MossFormerOracle
+    z, fused, scalars, W = _big_fixture("l24_1999")
+    n = mossformer.frames_of(W)
+    tensors = dict(fused)
+    tensors.update(mossformer.position_tables(n, int(scalars["rot_dim"])))
+    o = MossFormerOracle(tensors, scalars, 24, W)
+    o.tap_after = (1, 2, 4, 8, 16, 24)
+    want = o.process(z["pcm_in"][None])[0]
+    want_wave = o.taps["wav"][0]
+
+    def layer_of(name):
+        parts = name.split("_")
+        idx = [p for p in parts if p.isdigit()]
+        return int(idx[0]) if idx and name.startswith(("fl_", "fs_", "qkos_")) else -1
+    rows = []
+    for k in o.tap_after:
+        fk = {nm: v for nm, v in fused.items() if layer_of(nm) < k}
+        sk = dict(scalars, fs_front_alpha=list(scalars["fs_front_alpha"])[:k])
+        with _session((z, fk, sk, W), W) as sess:
+            pcm, f32 = sess.process(z["pcm_in"][None], want_f32=True)
+            got = sess.tap("mdl_out", n * 512).reshape(n, 512).T
+        ref = o.taps["mdl_out_after"][k][0]
+        e = np.abs(got - ref)
+        rows.append((k, float(np.median(e)), float(e.max()), float(np.sqrt((ref.astype(np.float64) ** 2).mean()))))
+    print("mossformer2 HIP vs oracle, |mdl_out error| of the network cut after k layers (median | max | rms of the tensor):")
+    for r in rows:
+        print("   k = %2d: %.2e | %.2e | %.2f" % r)
+    pcm, f32 = pcm.reshape(2, W), f32.reshape(2, W)
+    wave_err = float(np.abs(f32 - want_wave).max())
+    d = np.abs(pcm.astype(np.int32) - want.astype(np.int32))
+    print("   24 layers: wave max|d| %.3f (int16 units; 1e-4 of full scale = 3.3), PCM max %d LSB, %.3f of samples differ" % (wave_err, d.max(), (d != 0).mean()))
+    assert rows[-1][2] < 5e-3, rows
+    assert wave_err <= 3.3 and d.max() <= 2 and (d != 0).mean() < 0.05, (wave_err, d.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,frames", [("l4_2999", 2999), ("l2_7999", 7999), ("l24_1999", 1999)])
 def test_gpu_production_size_windows_match_reference(tag, frames):
     """HIP vs the reference's own forward: both speakers' PCM <= 2 LSB AND the fp32 waveform before the integer cast within 1e-4 of full scale
-    (3.3 in these int16 units), taps of the masking network at every 8th channel / 7th frame."""
+    (3.3 in these int16 units), taps of the masking network at every 8th channel / 7th frame.  l24_1999 (round 6) = ALL 24 layers on a 1 s window."""
     fx = _big_fixture(tag)
     z, _, _, W = fx
     with _session(fx, W) as sess:
@@ -216,7 +274,9 @@ def test_gpu_production_size_windows_match_reference(tag, frames):
     assert np.abs(mdl_out[::8, ::7] - z["mdl_out"]).max() < 5e-3
     assert np.abs(f32[:, ::int(z["wave_step"])] - z["wave"]).max() <= 3.3
     d = pcm.astype(np.int32) - z["pcm_out"].astype(np.int32)
-    assert np.abs(d).max() <= 2 and (d != 0).mean() < 0.05, (np.abs(d).max(), (d != 0).mean())
+    # (at 24 layers the numpy oracle itself sits 1.85 units / 2 LSB from torch's forward -- summation order; the engine is 0.2 units from the oracle,
+    #  test_gpu_full_depth_error_growth_vs_oracle -- so the share of samples whose truncating cast lands on the other integer is larger there)
+    assert np.abs(d).max() <= 2 and (d != 0).mean() < (0.12 if tag == "l24_1999" else 0.05), (np.abs(d).max(), (d != 0).mean())
 
 
 @pytest.mark.gpu
@@ -234,6 +294,32 @@ def test_gpu_baseline_batch_64_windows_of_4s_properties():
     d = outs[0].astype(np.int32) - z["pcm_out"].astype(np.int32)
     assert np.abs(d).max() <= 2
     assert np.array_equal(outs[0], solo.reshape(2, W))          # a row's bits do not depend on its batch (measured at B = 2, 3, 8, 33, 64: identical fp32 waveforms)
+
+
+@pytest.mark.gpu
+def test_gpu_baseline_batch_64_windows_of_4s_on_the_24_layer_model():
+    """BASELINE configs[4] exactly -- 64 x 4 s (7999 frames), 24 layers, ONE call -- on the random-init weights `bench.py --workload mossformer` times (the
+    64-row test above runs 2 layers).  Size-independent properties: finite, a silent row exactly silent, rows equal their solo run and the reversed batch."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_chunk
+    from audio_denoiser_onnx_amd.weights import pack_blob
+    L, layers, B = 64000, 24, 64
+    frames = mossformer.frames_of(L)
+    fused = {n: mossformer.synthetic_tensor(n, sh, sc, frames) for n, sh, sc in mossformer.synthetic_spec(layers)}
+    scalars = dict(mossformer.DEFAULT_SCALARS, fs_front_alpha=[0.25] * layers)
+    blob = pack_blob(mossformer.model_tensors(fused, scalars, L))
+    del fused
+    x = np.stack([np.zeros(L, np.int16) if i == 5 else synth_chunk(700 + i, L) for i in range(B)])
+    with InferenceSession(weights=blob, metadata=mossformer.metadata(L)) as sess:
+        assert sess.frames == 7999
+        out, f32 = sess.process(x, want_f32=True)
+        solo, _ = sess.process(x[17:18])
+        rev, _ = sess.process(x[::-1].copy())
+    out = out.reshape(B, 2, -1)
+    assert np.isfinite(f32).all() and not out[5].any()
+    assert (np.abs(np.delete(out, 5, axis=0)).max(axis=(1, 2)) > 50).all()
+    assert np.array_equal(out[17], solo.reshape(2, -1)), "row 17 depends on its neighbours at batch 64"
+    assert np.array_equal(rev.reshape(B, 2, -1), out[::-1])
 
 
 @pytest.mark.gpu

@@ -325,11 +325,18 @@ def float_io_fixture():
     np.savez_compressed(os.path.join(mg.GOLD, "mossformer_float_io_seed0.npz"), **out)
 
 
-def production_size():
+PRODUCTION_CASES = (("l4_2999", 4, 24000, 32000), ("l2_7999", 2, 64000, 16000),
+                    ("l24_1999", 24, 16000, 24000))    # the BASELINE network depth (24 layers, :460-550) on one 1 s window: VERDICT r05 missing #1
+
+
+def production_size(only=None):
     """Fixtures at production-relevant sizes: 4 layers x one 1.5 s window (24000 samples, 2999 frames = 12 FLASH groups,
-    the last padded) and 2 layers x one 4 s window (64000 samples, 7999 frames = 32 groups: BASELINE configs[4]'s window).  Both speakers' PCM,
-    the fp32 waveform before the integer cast (the same graph run with OUT_AUDIO_DTYPE = F32, x 32768) and channel-sub-sampled taps."""
-    for tag, layers, length, start in (("l4_2999", 4, 24000, 32000), ("l2_7999", 2, 64000, 16000)):
+    the last padded) and 2 layers x one 4 s window (64000 samples, 7999 frames = 32 groups: BASELINE configs[4]'s window); round 6: ALL 24 layers
+    on one 1 s window (1999 frames).  Both speakers' PCM, the fp32 waveform before the integer cast (the same graph run with
+    OUT_AUDIO_DTYPE = F32, x 32768) and channel-sub-sampled taps.  `only`: tags to (re)generate (default: all)."""
+    for tag, layers, length, start in PRODUCTION_CASES:
+        if only and tag not in only:
+            continue
         ns = import_namespace(length, False, 1.5)
         model, spec, scalars = build(ns, length, False, 0, layers=layers)
         pcm = read_mix(start, length)
@@ -412,7 +419,7 @@ if __name__ == "__main__" and "--float-io" in sys.argv:
     sys.exit(0)
 
 if __name__ == "__main__" and "--production-size" in sys.argv:
-    production_size()
+    production_size([a for a in sys.argv[1:] if not a.startswith("--")] or None)
     sys.exit(0)
 
 if __name__ == "__main__":
