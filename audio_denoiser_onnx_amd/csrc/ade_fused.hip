@@ -161,7 +161,8 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         ADE_STAGE_ENTRY();
         const GtConvW w = cload<GtConvW>(&F->en_gt[i]);
         const float* const x = i == 0 ? F->e1 : F->xe[i > 0 ? i - 1 : 0];
-        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, F->xe[i], (kClk && clk0) ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr);
+        gtblock_stage<G>(smem, chunk, sg, i, x, nullptr, w, F->xe[i], (kClk && clk0) ? clk0 + 64 * (1 + i) : nullptr, /*x1_in_lds=*/i > 0, /*next_x1=*/i < 2, nullptr,
+                         /*store_lo=*/true, /*next_full=*/i == 2);
         __syncthreads();
     }
 #pragma unroll 1
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(G::kThreads, G::kWavesPerSimd) void k_gtcrn_chunk(C
         const DpW w = cload<DpW>(&F->dp[i]);
         const float* const x = i == 0 ? F->xe[2] : F->dpo[0];
         dpgrnn_stage<G>(smem, chunk, sg, i, x, w, F->dpo[i], (kClk && clk0) ? clk0 + 64 * (4 + i) : nullptr, /*next_x1=*/i == 1, /*next_skip=*/F->xe[2],
-                        /*store_lo=*/i == 0 || kClk);
+                        /*store_lo=*/i == 0 || kClk, /*x_in_lds=*/true, /*next_full=*/i == 0);
         __syncthreads();
     }
 #pragma unroll 1

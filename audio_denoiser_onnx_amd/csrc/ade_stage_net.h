@@ -17,6 +17,10 @@
 
 #include <type_traits>
 
+#ifndef ADE_DP_INTER_MFMA
+#define ADE_DP_INTER_MFMA 0      // 1: the inter-frame GRU batched over columns on the matrix cores (measured slower: DESIGN section 6, round 6)
+#endif
+
 namespace ade {
 namespace stage {
 
@@ -78,6 +82,7 @@ template <class G> constexpr size_t gt_smem_bytes() { return (size_t)4 * G::kPma
 
 // x1_in_lds : the previous stage of the same launch already left this block's pointwise input (a+skip)[:, :8] in LDS planes 2-3.
 // next_x1   : leave the NEXT GTConvBlock's pointwise input there (out[:, :8] + next_skip[:, :8]); next_skip may be null.
+// next_full : leave the whole output (16 channels) in planes 0-3: the input of the DPGRNN that follows in the same launch (its x_in_lds).
 // store_lo  : false = planes 0-1 (channels 0-7) of `out` are not written to HBM: their only reader is the next block, which gets them through LDS (next_x1),
 //             and no later stage takes this tensor as a skip (decoder blocks 0 and 1, DPGRNN 1).  Option "full_taps" stores them anyway for ade_debug_tap.
 // sg / blk  : this workgroup's segment of the chunk and the block's index (0-2 encoder, 3-5 decoder) in the exchange area.  The segment's
@@ -89,7 +94,8 @@ template <class G> constexpr size_t gt_smem_bytes() { return (size_t)4 * G::kPma
 template <class G>
 __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ a, const float* __restrict__ skip,
                                               const GtConvW& w, float* __restrict__ out, long long* __restrict__ clk,
-                                              bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr, bool store_lo = true) {
+                                              bool x1_in_lds = false, bool next_x1 = false, const float* __restrict__ next_skip = nullptr, bool store_lo = true,
+                                              bool next_full = false) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* H = smem;
     float* zt = reinterpret_cast<float*>(smem + 4 * kPmax);
@@ -533,6 +539,10 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) n8[i][k] = o[k] + nsk[i][k];
+            if (next_full) {    // a DPGRNN follows in this launch: its whole input stays in LDS (a position is read and rewritten by its own lane only)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) H[q * kPmax + p] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            }
         }
     }
     if (next_x1) {
@@ -646,12 +656,21 @@ __device__ __forceinline__ void fc_ln_rows(float4* R, const float* __restrict__ 
     }
 }
 
+// The gates of one GRU unit from the four rows (r, z, W_hn h + b_hn, W_in x + b_in) of a batched step, pre-scaled for exp2 (r, z by -log2 e, the n rows by 2 log2 e):
+// r = sigmoid, z = sigmoid, n = tanh(nx + r nh), h' = (1 - z) n + z h.  Thirteen vector instructions, six of them exp2 / rcp.
+__device__ __forceinline__ float gru_gates(const v4f& d, float h) {
+    const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(d[0]));
+    const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(d[1]));
+    const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f(d[3] + r * d[2]) + 1.0f);
+    return n + z * (h - n);
+}
+
 // sg / blk: see gtblock_stage.  The intra-frame GRU and both LayerNorms are per frame; only the inter-frame GRU's hidden state (33 x 16)
 // crosses from a segment to its successor.
 template <class G>
 __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg& sg, int blk, const float* __restrict__ x, const DpW& w, float* __restrict__ out,
                                              long long* __restrict__ clk, bool next_x1 = false,
-                                             const float* __restrict__ next_skip = nullptr, bool store_lo = true) {
+                                             const float* __restrict__ next_skip = nullptr, bool store_lo = true, bool x_in_lds = false, bool next_full = false) {
     constexpr int kFusedThreads = G::kThreads, kTmaxFused = G::kTmax, kPmax = G::kPmax, kPosPerThread = G::kPosPerThread;
     float4* R = smem;
     float* Rf = reinterpret_cast<float*>(smem);
@@ -670,63 +689,90 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
     float* oc = out + cbase;
 
     ADE_CLK(16);
-    // ---- phase A: intra GRNN.  16 lanes per frame: lane = group*8 + dir*4 + unit (== output channel); GRU(8->4)
-    //      along F, hidden exchanged inside the quad with quad_perm DPP.                          (:441-446,472-473)
+    // ---- phase A: intra GRNN (GRU(8->4) x 2 groups x 2 directions along F, per frame).                      (:441-446,472-473)
+    //      BATCHED over frames on the matrix cores: a wavefront owns one (group, direction) pair for 16 frames, and a step of its 16 recurrences is three
+    //      v_mfma_f32_16x16x4_f32 whose rows are (unit i, gate c) = 4 i + c with c = r | z | W_hn h | W_in x (the n gate's two halves stay apart because r multiplies
+    //      only the first) and whose columns are the 16 frames: two K blocks of input channels (off the dependent chain: issued a step ahead) and one of the four
+    //      hidden units.  Lane (g, j) gets (r, z, nh, nx) of unit g of frame j in its four result registers, finishes the gates for that one unit and holds h[g] --
+    //      which is exactly the B operand (k = g, column j) of the next step: the hidden state never leaves its lane.  The FMAs of the step (36 per unit) are on
+    //      the matrix pipe; the vector pipe keeps the 13 gate instructions.  x is staged in R once (the reverse direction reads columns the forward one has
+    //      already passed, so the outputs wait in 33 registers and go to R after a barrier).
     {
-        const int t = tid >> 4, q = tid & 15;
-        const int grp = q >> 3, dir = (q >> 2) & 1;
+        constexpr float kS = -kLog2e, kN = 2.0f * kLog2e;   // pre-scaling for exp2-based activations: r, z by -log2 e, n by 2 log2 e
+        if (!x_in_lds) {
+            float4 v[kPosPerThread][4];
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i) {
+                const int p = tid + i * kFusedThreads, pc = p < P ? p : P - 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[i][q] = *reinterpret_cast<const float4*>(xc + ((size_t)q * Ps + pc) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i) {
+                const int p = tid + i * kFusedThreads;
+                if (p < P) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) R[q * kPmax + p] = v[i][q];
+                }
+            }
+            __syncthreads();
+        }
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int g = (tid >> 4) & 3, j = tid & 15;
+        const int grp = (wave >> 1) & 1, dir = wave & 1, t = (wave >> 2) * 16 + j;
         const bool live = t < T;
         const int tc = live ? t : T - 1;
-        const float* pk = w.intra_gru + q * 42;                      // [W_ih 3x8 | W_hh 3x4 | b_ih 3 | b_hh 3] of this output row
-        const int unit = q & 3;
-        int ks[4];                                                   // ks[s] = hidden index delivered by quad rotation s
-        ks[0] = unit;
-        ks[1] = (int)quad_rot<1>((float)unit); ks[2] = (int)quad_rot<2>((float)unit); ks[3] = (int)quad_rot<3>((float)unit);
-        // packed-fp32 formulation (see the inter GRU below): r|z share one accumulator, n is packed over input pairs
-        // weights and biases pre-scaled by -log2(e) (r, z) / 2 log2(e) (n): the activations are exp2 -> add -> rcp
-        constexpr float kS = -kLog2e, kN = 2.0f * kLog2e;
-        v2f wi_rz[8], wh_rz[4], wi_n[4], wh_n[2];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wi_rz[k] = mk2(pk[k] * kS, pk[8 + k] * kS);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wh_rz[k] = mk2(pk[24 + ks[k]] * kS, pk[28 + ks[k]] * kS);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) wi_n[m] = mk2(pk[16 + 2 * m] * kN, pk[16 + 2 * m + 1] * kN);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) wh_n[m] = mk2(pk[32 + ks[2 * m]] * kN, pk[32 + ks[2 * m + 1]] * kN);
-        const v2f b_rz = mk2((pk[36] + pk[39]) * kS, (pk[37] + pk[40]) * kS);
-        const float bi_n = pk[38] * kN, bh_n = pk[41] * kN;
-        const int prow = tc * kFw;
-        float h = 0.0f;
-        // inputs come from HBM/L2 (~1 us away): a 4-slot register ring keeps three steps of loads in flight, and the
-        // fully unrolled loop lets the scheduler start the (h-independent) input projections early.
-        float xq[4][8];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) pl_ld8(xc, Ps, prow + (dir ? kFw - 1 - d : d), grp * 2, xq[d]);
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int s = 0; s < kFw; ++s) {
-            const int f = dir ? kFw - 1 - s : s;
-            if (s + 3 < kFw) pl_ld8(xc, Ps, prow + (dir ? f - 3 : f + 3), grp * 2, xq[(s + 3) & 3]);
-            const float* xv = xq[s & 3];
-            v2f a_rz = b_rz, a_n = mk2(bi_n, 0.0f);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a_rz += wi_rz[k] * xv[k];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a_n += wi_n[m] * mk2(xv[2 * m], xv[2 * m + 1]);
-            const float h1 = quad_rot<1>(h), h2 = quad_rot<2>(h), h3 = quad_rot<3>(h);
-            v2f c0 = a_rz, c1 = mk2(0.0f, 0.0f), c_n = mk2(bh_n, 0.0f);
-            c0 += wh_rz[0] * h; c1 += wh_rz[1] * h1; c0 += wh_rz[2] * h2; c1 += wh_rz[3] * h3;
-            c_n += wh_n[0] * mk2(h, h1);
-            c_n += wh_n[1] * mk2(h2, h3);
-            const v2f rz = c0 + c1;
-            const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[0]));
-            const float z = fast_rcp(1.0f + __builtin_amdgcn_exp2f(rz[1]));
-            const float n = 1.0f - 2.0f * fast_rcp(__builtin_amdgcn_exp2f((a_n[0] + a_n[1]) + r * (c_n[0] + c_n[1])) + 1.0f);
-            h = n + z * (h - n);
-            if (live) Rf[((size_t)(q >> 2) * kPmax + tc * kFw + f) * 4 + (q & 3)] = h;
+        float ax0, ax1, ah;
+        {
+            const int c = j & 3;
+            const float* pk = w.intra_gru + (grp * 8 + dir * 4 + (j >> 2)) * 42;       // [W_ih 3x8 | W_hh 3x4 | b_ih 3 | b_hh 3] of output row (unit j / 4)
+            const float sc_ = c < 2 ? kS : kN;
+            const int gi = c == 3 ? 2 : c;                                             // rows r, z, nx read W_i{r, z, n}; row nh reads W_hn
+            ax0 = c == 2 ? 0.0f : pk[gi * 8 + g] * sc_;
+            ax1 = c == 2 ? 0.0f : pk[gi * 8 + 4 + g] * sc_;
+            ah = c == 3 ? 0.0f : pk[24 + c * 4 + g] * sc_;
         }
-        set_prio(sg.base_prio);
+        v4f cb;
+        {
+            const float* pb = w.intra_gru + (grp * 8 + dir * 4 + g) * 42;
+            cb[0] = (pb[36] + pb[39]) * kS;
+            cb[1] = (pb[37] + pb[40]) * kS;
+            cb[2] = pb[41] * kN;
+            cb[3] = pb[38] * kN;
+        }
+        const float* const xr = Rf + ((size_t)(grp * 2) * kPmax + tc * kFw) * 4 + g;      // channel 8 grp + g of the frame's column 0; + 4: the next plane
+        float hout[kFw];
+        auto run = [&](auto dir_c) {
+            constexpr int DIR = decltype(dir_c)::value;
+            float h = 0.0f;
+            __builtin_amdgcn_s_setprio(3);
+            v4f dx;
+            {
+                constexpr int f0 = DIR ? kFw - 1 : 0;
+                dx = mfma16x16x4(ax0, xr[f0 * 4], cb);
+                dx = mfma16x16x4(ax1, xr[(kPmax + f0) * 4], dx);
+            }
+#pragma unroll
+            for (int s = 0; s < kFw; ++s) {
+                v4f d = mfma16x16x4(ah, h, dx);
+                if (s + 1 < kFw) {
+                    const int fn = DIR ? kFw - 2 - s : s + 1;
+                    dx = mfma16x16x4(ax0, xr[fn * 4], cb);
+                    dx = mfma16x16x4(ax1, xr[(kPmax + fn) * 4], dx);
+                }
+                h = gru_gates(d, h);
+                hout[s] = h;
+            }
+            set_prio(sg.base_prio);
+            __syncthreads();                                 // every wavefront has read its last x column: R takes the rnn outputs
+            float* const hw = Rf + ((size_t)(grp * 2 + DIR) * kPmax + tc * kFw) * 4 + g;
+            if (live) {
+#pragma unroll
+                for (int s = 0; s < kFw; ++s) hw[(DIR ? kFw - 1 - s : s) * 4] = hout[s];
+            }
+        };
+        if (dir) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
     }
     __syncthreads();
     ADE_CLK(17);
@@ -749,6 +795,111 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         lnt[kFw * kCh + i] = w.inter_ln_b[i];
     }
     ADE_CLK(18);
+#if ADE_DP_INTER_MFMA
+    // ---- phase C: inter GRNN (GRU(8->8) x 2 groups along T, per column), in place in R.                          (:450-455,478-479)
+    //      BATCHED over columns on the matrix cores, in the form of phase A: a tile = 16 columns of one group (the 33 columns make two full tiles and one with
+    //      column 32 alone, per group: six tiles, dealt to the wavefronts round robin -- a wavefront's tiles share its group, i.e. its weights); the eight units
+    //      are two row blocks of (unit, gate) rows, K = 8 input channels + 8 hidden units = four products per row block and step, the two input ones issued a step
+    //      ahead.  Lane (g, j) owns units g and 4 + g of column j: its two hidden values are its B operands of the next step, and the positions it reads (channels
+    //      g, 4 + g of the group at (t, column j)) are the two it overwrites.
+    {
+        constexpr float kS = -kLog2e, kN = 2.0f * kLog2e;
+        constexpr int kWaves = kFusedThreads / 64, kTilesC = 6;
+        static_assert(kWaves % 2 == 0, "a wavefront's tiles share its group");
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int g = (tid >> 4) & 3, j = tid & 15;
+        const int grp = wave & 1;
+        float ax[2][2], ah[2][2];
+        v4f cb[2];
+#pragma unroll
+        for (int U = 0; U < 2; ++U) {
+            const int c = j & 3;
+            const float* pk = w.inter_gru + (grp * 8 + 4 * U + (j >> 2)) * 54;      // [W_ih 3x8 | W_hh 3x8 | b_ih 3 | b_hh 3] of output row (unit 4 U + j / 4)
+            const float sc_ = c < 2 ? kS : kN;
+            const int gi = c == 3 ? 2 : c;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                ax[U][kk] = c == 2 ? 0.0f : pk[gi * 8 + 4 * kk + g] * sc_;
+                ah[U][kk] = c == 3 ? 0.0f : pk[24 + c * 8 + 4 * kk + g] * sc_;
+            }
+            const float* pb = w.inter_gru + (grp * 8 + 4 * U + g) * 54;
+            cb[U][0] = (pb[48] + pb[51]) * kS;
+            cb[U][1] = (pb[49] + pb[52]) * kS;
+            cb[U][2] = pb[53] * kN;
+            cb[U][3] = pb[50] * kN;
+        }
+        auto run = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;                // tiles of this wavefront
+            float h[NT][2];
+            bool live[NT];
+            float* xp[NT];                                          // channel 8 grp + g of (frame 0, the lane's column); + 4 kPmax floats: channel 8 grp + 4 + g
+            float* xs[NT];
+            v4f dx[NT][2];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int tile = wave + c * kWaves, f = (tile >> 1) * 16 + j;
+                live[c] = f < kFw;                                   // (a lane whose column does not exist recomputes the last one and drops it)
+                const int fc = live[c] ? f : kFw - 1;
+                xp[c] = Rf + ((size_t)(grp * 2) * kPmax + fc) * 4 + g;
+                xs[c] = sg.xi + kXInterOff + blk * (kFw * 16) + fc * 16 + grp;     // hand-off layout: [column][2 unit + group]
+                h[c][0] = h[c][1] = 0.0f;
+                if (sg.prev) {                                       // the recurrence continues from the previous segment's last frame
+                    h[c][0] = xld1(xs[c] + 2 * g);
+                    h[c][1] = xld1(xs[c] + 2 * (4 + g));
+                }
+                const float x0 = xp[c][0], x1 = xp[c][kPmax * 4];
+#pragma unroll
+                for (int U = 0; U < 2; ++U) {
+                    dx[c][U] = mfma16x16x4(ax[U][0], x0, cb[U]);
+                    dx[c][U] = mfma16x16x4(ax[U][1], x1, dx[c][U]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(3);
+            for (int t = 0; t < T; ++t) {
+                const int tn = t + 1 < T ? 1 : 0;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    v4f d[2];
+#pragma unroll
+                    for (int U = 0; U < 2; ++U) {
+                        d[U] = mfma16x16x4(ah[U][0], h[c][0], dx[c][U]);
+                        d[U] = mfma16x16x4(ah[U][1], h[c][1], d[U]);
+                    }
+                    float* const xn = xp[c] + tn * (kFw * 4);       // next step's input (the last step re-reads its own: dropped)
+                    const float x0 = xn[0], x1 = xn[kPmax * 4];
+#pragma unroll
+                    for (int U = 0; U < 2; ++U) {
+                        dx[c][U] = mfma16x16x4(ax[U][0], x0, cb[U]);
+                        dx[c][U] = mfma16x16x4(ax[U][1], x1, dx[c][U]);
+                    }
+                    h[c][0] = gru_gates(d[0], h[c][0]);
+                    h[c][1] = gru_gates(d[1], h[c][1]);
+                    if (live[c]) {
+                        xp[c][0] = h[c][0];
+                        xp[c][kPmax * 4] = h[c][1];
+                    }
+                    xp[c] = xn;
+                }
+            }
+            set_prio(sg.base_prio);
+            if (sg.next) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    float* const xo = sg.xo + (xs[c] - sg.xi);
+                    if (live[c]) {
+                        xst1(xo + 2 * g, h[c][0]);
+                        xst1(xo + 2 * (4 + g), h[c][1]);
+                    }
+                }
+                xdrain();
+            }
+        };
+        const int nt = wave < kTilesC ? (kTilesC - 1 - wave) / kWaves + 1 : 0;      // (wave-uniform)
+        static_assert((kTilesC + kWaves - 1) / kWaves <= 2, "at most two tiles per wavefront");
+        if (nt == 2) run(std::integral_constant<int, 2>{});
+        else if (nt == 1) run(std::integral_constant<int, 1>{});
+    }
+#else
     // ---- phase C: inter GRNN.  16 lanes per F column: lane = 2*unit + group; GRU(8->8) along T, in place in R
     //      (a column position is read, then overwritten, by its own 16 lanes only).              (:450-455,478-479)
     //      The loop is VALU-issue-bound (9 wavefronts on 4 SIMDs), so it is written for instruction count: r|z gates as
@@ -845,6 +996,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
         else if (nc == 2) run(std::integral_constant<int, 2>{});
         else if (nc == 1) run(std::integral_constant<int, 1>{});
     }
+#endif
     __syncthreads();
     if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagInter + blk, 1u);
     ADE_CLK(19);
@@ -860,6 +1012,10 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
                     st4(oc + ((size_t)2 * Ps + p) * 4, o + 8);
                     st4(oc + ((size_t)3 * Ps + p) * 4, o + 12);
                 }
+                if (next_full) {  // the following DPGRNN's input: the whole output, in place (the frame's row is done with these positions)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) R[q * kPmax + p] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                }
                 if (next_x1) {   // the following GTConvBlock's pointwise input (out + skip)[:, :8] -> LDS planes 2-3 (the frame's row is done with them)
                     float k8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     if (nsc) pl_ld8(nsc, Ps, p, 0, k8);
@@ -869,6 +1025,7 @@ __device__ __forceinline__ void dpgrnn_stage(float4* smem, int chunk, const Seg&
             },
             [&](int p, int c, float o) {
                 if (store_lo || c >= 8) oc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] = o;
+                if (next_full) Rf[((size_t)(c >> 2) * kPmax + p) * 4 + (c & 3)] = o;
                 if (next_x1 && c < 8) {
                     const float k = nsc ? nsc[((size_t)(c >> 2) * Ps + p) * 4 + (c & 3)] : 0.0f;
                     Rf[((size_t)(2 + (c >> 2)) * kPmax + p) * 4 + (c & 3)] = o + k;
