@@ -34,8 +34,11 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f32 __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 #else                                                // g++ spelling for the host-side simulator build under tests/hipsim
 typedef short v8bf __attribute__((vector_size(16)));
+typedef short v8h __attribute__((vector_size(16)));
 typedef float v16f __attribute__((vector_size(64)));
 #endif
 
@@ -66,6 +69,52 @@ __device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w 
 
 __device__ __forceinline__ v8bf as_v8bf(const uint4& u) { v8bf r; __builtin_memcpy(&r, &u, 16); return r; }      // (a register rename on the GPU)
 __device__ __forceinline__ v16f mfma32x32x16(const uint4& a, const uint4& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_v8bf(a), as_v8bf(b), c, 0, 0, 0); }
+
+// IEEE half (fp16) operands of the same matrix instruction family (v_mfma_f32_32x32x16_f16: the bf16 rate): three more mantissa bits than bf16 for tensors whose range is
+// known -- ZipEnhancer's dense blocks, InstanceNorm'd activations of order one (csrc/ade_zip16.h).  fp32 -> fp16 rounds to nearest even (v_cvt_f16_f32 / v_cvt_pk_f16_f32),
+// saturating at the largest finite half instead of overflowing to infinity.
+__host__ __device__ inline unsigned short f16_bits(float x) {            // portable form: the host's weight conversion and the host simulator
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);        // NaN
+    if (u >= 0x477ff000u) return (unsigned short)(sign | 0x7bffu);       // >= 65520 rounds beyond the largest finite half: saturate
+    if (u < 0x33000001u) return (unsigned short)sign;                    // <= 2^-25: rounds to zero
+    if (u < 0x38800000u) {                                               // subnormal half: value = m * 2^-24
+        const int e = (int)(u >> 23);                                    // biased fp32 exponent, 102 .. 112
+        const unsigned m = (u & 0x7fffffu) | 0x800000u;
+        const int sh = 126 - e;                                          // 14 .. 24
+        unsigned r = m >> sh;
+        const unsigned rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (unsigned short)(sign | r);
+    }
+    unsigned r = u - 0x38000000u;                                        // re-bias the exponent: 127 -> 15
+    const unsigned rem = r & 0x1fffu;
+    r >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (unsigned short)(sign | r);
+}
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+#if defined(__clang__) && defined(__AMDGCN__)
+    a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+    v2f32 v = {a, b};
+    v2h r = __builtin_convertvector(v, v2h);
+    unsigned w;
+    __builtin_memcpy(&w, &r, 4);
+    return w;
+#else
+    return (unsigned)f16_bits(a) | ((unsigned)f16_bits(b) << 16);
+#endif
+}
+__device__ __forceinline__ uint2 pack_f16x4(const float4& v) { return make_uint2(pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w)); }
+__device__ __forceinline__ v8h as_v8h(const uint4& u) { v8h r; __builtin_memcpy(&r, &u, 16); return r; }
+__device__ __forceinline__ v16f mfma32x32x16_f16(const uint4& a, const uint4& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a), as_v8h(b), c, 0, 0, 0); }
+// one spelling for kernels templated on the 16-bit operand type of a tensor family: HALF = IEEE half, otherwise bf16
+template <bool HALF> __device__ __forceinline__ v16f mfma32x32x16_t(const uint4& a, const uint4& b, v16f c) { return HALF ? mfma32x32x16_f16(a, b, c) : mfma32x32x16(a, b, c); }
+template <bool HALF> __device__ __forceinline__ uint2 pack16x4_t(const float4& v) { return HALF ? pack_f16x4(v) : pack_bf16x4(v); }
 
 __device__ __forceinline__ uint4 zero_unless(bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); }
 // eight bf16 at p if ok, else zeros, selected by ADDRESS (ade_device.h, ld4_or_zero): a prefetch written with it stays in flight across the matrix work that follows

@@ -294,6 +294,12 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
                 dw_taps(acc0, acc1, j, f, pn + P, 2);
                 if (pu < NP) xst4(xhist_o, (g * kXHistFrames * kFw + pn) * 4, make_float4(acc0[0], acc0[1], acc1[0], acc1[1]));
             }
+            // The flag goes up HERE, ahead of this segment's own tiles: the successor's depthwise phase waits for nothing else, and the segments of a chunk reach this
+            // block within microseconds of each other -- raised after the tile loop, each segment's phase started when its predecessor's ENDED (a chain of whole phases
+            // through the chunk's segments: 12 us of waiting in the last segment of a dilation-5 block, profiles/r06_b_phase_latency_256.txt).
+            xdrain();
+            __syncthreads();
+            if (tid == 0) xflag_store(sg.fo + kXFlagHist + blk, 1u);
         }
         float wp[2][4];                                    // A operands of the second GEMM: K block r = (input channel 4g + r); even tile: rows 0-7, odd tile: rows 8-15
 #pragma unroll
@@ -326,10 +332,8 @@ __device__ __forceinline__ void gtblock_stage(float4* smem, int chunk, const Seg
             for (int r = 0; r < 4; ++r) d2 = mfma16x16x4(wp[it & 1][r], y[r], d2);
             if ((it & 1) || it == kTiles - 1) h1r[it >> 1] = make_float4(d2[0], d2[1], d2[2], d2[3]);
         }
-        if (sg.next) xdrain();                             // every storing wavefront, ahead of the barrier that precedes the flag
     }
     __syncthreads();   // every tap read of H is done: planes may be reused
-    if (sg.next && tid == 0) xflag_store(sg.fo + kXFlagHist + blk, 1u);
     ADE_CLK(2);
 #pragma unroll
     for (int pr = 0; pr < kPairs; ++pr) {

@@ -53,7 +53,9 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
 constexpr int kDARows = 258;
 // CB = input channels per stage: 32 (80-byte rows, 38 KB of LDS: four workgroups per CU) or 64 (144-byte rows, 65 KB: two per CU, but half as many barriers and load round
 // trips per product -- the stage's loads are a microsecond or two away and one stage of look-ahead does not cover them)
-template <int CB>
+// HALF: the block's operands (history, input, weights) are IEEE half instead of bf16 -- the engine's default for the dense blocks (ZipEngine::dense_half): their activations are
+// InstanceNorm'd + PReLU'd values of order one, and bf16's eight significant bits in these three blocks cost the waveform 10 dB (profiles/r06_e_zip_bf16_budget.txt).
+template <int CB, bool HALF>
 __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf16_t* __restrict__ hist, const bf16_t* __restrict__ inp, int hist_ld, int hist_off, int hist_n, int cin, int T,
                                                         int F, int dil, const bf16_t* __restrict__ w, const float* __restrict__ bias, float* __restrict__ raw,
                                                         double* __restrict__ partial, int nblk) {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32x32x16(fa[i], fb[j], acc[i][j]);      // D[token][channel]
+                    for (int j = 0; j < 2; ++j) acc[i][j] = gemm16::mfma32x32x16_t<HALF>(fa[i], fb[j], acc[i][j]);      // D[token][channel]
             }
         }
         __syncthreads();
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256, CB == 32 ? 4 : 2) void k_zip_dense16(const bf1
 
 // raw fp32 layer output -> InstanceNorm + PReLU -> bf16 dense history [tokens][ld] at channels ch0 .. ch0 + 63; optionally the fp32 values too (out32, [tokens][64]: the last
 // layer's output while a consumer still reads fp32).  nrm: [(window * nrm_ld + channel) * 2 + {scale, shift}].  thread = (token, channel quad)
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_zip_hist_norm16(const float* __restrict__ raw, bf16_t* __restrict__ hist, int ld, int ch0, const float* __restrict__ nrm, int nrm_ld,
                                                          const float* __restrict__ slope, int tok_per_win, float* __restrict__ out32, long long total16) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -198,15 +201,16 @@ __global__ __launch_bounds__(256) void k_zip_hist_norm16(const float* __restrict
     v.y = prelu_f(v.y * s0.z + s0.w, sl.y);
     v.z = prelu_f(v.z * s1.x + s1.y, sl.z);
     v.w = prelu_f(v.w * s1.z + s1.w, sl.w);
-    *reinterpret_cast<uint2*>(hist + tok * ld + ch) = gemm16::pack_bf16x4(v);
+    *reinterpret_cast<uint2*>(hist + tok * ld + ch) = gemm16::pack16x4_t<HALF>(v);
     if (out32) *reinterpret_cast<float4*>(out32 + tok * 64 + c) = v;
 }
 
 // fp32 [n] -> bf16 [n] (n % 4 == 0): the decoder pair's dense-block input is the last encoder's fp32 output
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_zip_to_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, long long n4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    *reinterpret_cast<uint2*>(y + 4 * i) = gemm16::pack_bf16x4(*reinterpret_cast<const float4*>(x + 4 * i));
+    *reinterpret_cast<uint2*>(y + 4 * i) = gemm16::pack16x4_t<HALF>(*reinterpret_cast<const float4*>(x + 4 * i));
 }
 
 // ---- fused feed-forward module (:160, :170-174) on bf16 operands: out = epilogue(W2 swooshL(W1 x + b1) + b2) --------------------------------------------------------
@@ -441,7 +445,7 @@ struct SubPixelStore16 {       // conv channel n = c * r + u of sub-band f -> U[
 };
 template <int KS, int NT>
 constexpr int rows16_lds() { return (32 * NT * (32 * KS + 16)) > 4 * 32 * 68 * 4 ? (32 * NT * (32 * KS + 16)) : 4 * 32 * 68 * 4; }
-template <int KS, int NT, class AL, class ST>
+template <int KS, int NT, class AL, class ST, bool HALF = false>        // HALF: operand rows and weights are IEEE half (the (1, 3) convolutions over the dense history)
 __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restrict__ w, ST store, int M, int N) {
     constexpr int kPitch = 32 * KS + 16;
     HIP_DYNAMIC_SHARED(unsigned char, lds)
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(lds + (32 * t + l31) * kPitch + 32 * ks + 16 * h), xa[ks], acc[t]);
+        for (int t = 0; t < NT; ++t) acc[t] = gemm16::mfma32x32x16_t<HALF>(*reinterpret_cast<const uint4*>(lds + (32 * t + l31) * kPitch + 32 * ks + 16 * h), xa[ks], acc[t]);
     __syncthreads();                                                    // the weights are dead: the wave's epilogue tile takes their place
     float* E = reinterpret_cast<float*>(lds) + wave * 32 * 68;
     const int c4 = (lane & 15) * 4;
@@ -493,10 +497,10 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
         wave_sync();
     }
 }
-template <int KS, int NT, class AL, class ST>
+template <int KS, int NT, bool HALF = false, class AL, class ST>
 inline void launch_rows16(hipStream_t s, const AL& a, const bf16_t* w, const ST& st, int M, int N) {
     if (M <= 0) return;
-    auto kern = k_rows16<KS, NT, AL, ST>;
+    auto kern = k_rows16<KS, NT, AL, ST, HALF>;
     constexpr int bytes = rows16_lds<KS, NT>();
     static bool raised = false;                                         // (more than 48 KB of dynamic LDS needs the attribute: K = 192 x N = 128 only)
     if (bytes > 48 * 1024 && !raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); raised = true; }

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void k_zip_conv1_apply(const float2* __restric
     st4(e0 + tok * C + c, v);
 }
 
-// the same values rounded to bf16 (the bf16 path's dense-block input)
+// the same values rounded to bf16 / IEEE half (the bf16 path's dense-block input)
+template <bool HALF>
 __global__ __launch_bounds__(256) void k_zip_conv1_apply16(const float2* __restrict__ feat, const float4* __restrict__ coef, const float* __restrict__ slope,
                                                            gemm16::bf16_t* __restrict__ e0, int TF, int C, long long total4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_zip_conv1_apply16(const float2* __restr
         const float4 k = coef[(size_t)r * C + c + u];
         v[u] = prelu_f(k.x * mp.x + k.y * mp.y + k.z, slope[c + u]);
     }
-    *reinterpret_cast<uint2*>(e0 + tok * C + c) = gemm16::pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+    *reinterpret_cast<uint2*>(e0 + tok * C + c) = gemm16::pack16x4_t<HALF>(make_float4(v[0], v[1], v[2], v[3]));
 }
 
 // ---- InstanceNorm statistics of a raw tensor: 64 channels at column ch0 of a [tokens][ld] matrix, per window ------------------------
@@ -1313,6 +1314,10 @@ struct ZipEngine : SubEngine {
     // Error-budget knob of the bf16 path (tools/zip_bf16_budget.py): which parts of a bf16 handle run on bf16 operands -- bit 0 the dense encoder block, bit 1 the eight
     // Zipformer layers, bit 2 the decoder pair's dense block + sub-pixel convolution.  7 (default) = the bf16 path; a cleared bit runs that part's f32 kernels instead.
     int parts16 = getenv("ADE_ZIP16_PARTS") ? (atoi(getenv("ADE_ZIP16_PARTS")) & 7) : 7;
+    // The 16-bit type of the three causal dense blocks (history, block input, weights, the (1, 3) convolutions that read the history): IEEE half by default -- the same
+    // matrix rate and bytes as bf16, three more mantissa bits, and these tensors are InstanceNorm'd activations of order one (the reference's own reduced-precision plan is
+    // fp16: Optimize_ONNX.py:25-64).  BASELINE configs[2]'s "bf16 dual-path transformer" stays bf16.  ADE_ZIP_DENSE_F16=0 keeps bf16 there too (the budget's comparison leg).
+    bool dense_half = !(getenv("ADE_ZIP_DENSE_F16") && atoi(getenv("ADE_ZIP_DENSE_F16")) == 0);
     // ADE_ZIP_LAYER_TAPS=1: the residual stream after every sub-module of the FIRST layer (encoder 0, frequency path) is kept for taps "l0_0" .. "l0_7"
     // (ff1, nonlin-attention, self-attention 1, convolution 1, ff2 + bypass, self-attention 2, convolution 2, ff3 + final norm); calls of at most 8 windows
     bool want_layer_taps = getenv("ADE_ZIP_LAYER_TAPS") && atoi(getenv("ADE_ZIP_LAYER_TAPS")) == 1;
@@ -1427,6 +1432,11 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     auto to_bf16 = [](float x) -> uint16_t { uint32_t u; memcpy(&u, &x, 4); if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
     auto place16 = [&](const float* src, size_t n) { const size_t at = arena16.size(); arena16.resize(at + n); for (size_t i = 0; i < n; ++i) arena16[at + i] = to_bf16(src[i]); arena16.resize((arena16.size() + 63) & ~(size_t)63); return at; };
     auto bind16 = [&](const gemm16::bf16_t** slot, size_t at) { fix16.push_back({slot, at}); };
+    const bool dense_half = e->dense_half;
+    auto place16d = [&](const float* src, size_t n) {          // the dense blocks' weights: IEEE half unless ADE_ZIP_DENSE_F16=0
+        if (!dense_half) return place16(src, n);
+        const size_t at = arena16.size(); arena16.resize(at + n); for (size_t i = 0; i < n; ++i) arena16[at + i] = gemm16::f16_bits(src[i]); arena16.resize((arena16.size() + 63) & ~(size_t)63); return at;
+    };
     // W2 (C, fd) with every group of 16 hidden units in k_zip_ff16's contraction order: position 8 h + e holds unit 8 (e >> 2) + 4 h + (e & 3)
     auto place16_ffout = [&](const float* src, int fd) {
         std::vector<float> r((size_t)C * fd);
@@ -1443,7 +1453,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     {
         const size_t at = put_conv("enc_conv2_w", 0, C, C, 1, 3, C);
         bind(&e->c2_w, at);
-        if (bf16 && ok) bind16(&e->c2_w16, place16(arena.data() + at, (size_t)C * 3 * C));
+        if (bf16 && ok) bind16(&e->c2_w16, place16d(arena.data() + at, (size_t)C * 3 * C));
     } slice(&e->c2_b, "enc_conv2_b", {C}); slice(&e->c2_g, "enc_norm2_w", {C}); slice(&e->c2_beta, "enc_norm2_b", {C});
     slice(&e->c2_slope, "enc_prelu2", {C});
     auto dense = [&](ZDense& d, const std::string& pre, int groups) {
@@ -1457,7 +1467,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
                 {
                     const size_t at = put_conv(p + "_w", g * C, C, C * (i + 1), 2, 3, groups * C);
                     bind(&d.w[g][i], at);
-                    if (bf16 && ok) bind16(&d.w16[g][i], place16(arena.data() + at, (size_t)C * 6 * C * (i + 1)));
+                    if (bf16 && ok) bind16(&d.w16[g][i], place16d(arena.data() + at, (size_t)C * 6 * C * (i + 1)));
                 }
                 bind(&d.b[g][i], a_b + (size_t)g * C); bind(&d.gamma[g][i], a_g + (size_t)g * C); bind(&d.beta[g][i], a_be + (size_t)g * C);
                 for (int c = 0; c < C; ++c) slopes[((size_t)g * 4 + (3 - i)) * C + c] = pr->data[g * C + c];      // layer i's output lives in slot 3 - i
@@ -1522,7 +1532,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     for (int g = 0; g < 2; ++g) {
         const size_t at = put_conv("dec_up_w", g * C * e->up, C * e->up, C, 1, 3, 2 * C * e->up);
         bind(&e->up_w[g], at);
-        if (bf16 && ok) bind16(&e->up_w16[g], place16(arena.data() + at, (size_t)C * e->up * 3 * C));
+        if (bf16 && ok) bind16(&e->up_w16[g], place16d(arena.data() + at, (size_t)C * e->up * 3 * C));
     }
     {
         const size_t a = put("dec_up_b", {2 * C * e->up});
@@ -1680,16 +1690,17 @@ void ZipEngine::dense_block16(hipStream_t s, const ZDense& d, int groups, const 
     for (int i = 0; i < depth; ++i)
         for (int g = 0; g < groups; ++g) {
             const int cin = (i + 1) * C, off_out = g * 4 * C + (3 - i) * C;
-            if (dense_cb == 64)
-                hipLaunchKernelGGL(zip16::k_zip_dense16<64>, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
-                                   1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
-            else
-                hipLaunchKernelGGL(zip16::k_zip_dense16<32>, dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, i * C, cin, T, Fd,
-                                   1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk);
+#define ADE_DENSE16(CB, HALF) hipLaunchKernelGGL((zip16::k_zip_dense16<CB, HALF>), dim3((unsigned)(nblk * windows)), dim3(256), 0, s, (const gemm16::bf16_t*)Dh16, inp, ld, g * 4 * C + (4 - i) * C, \
+                                                 i * C, cin, T, Fd, 1 << i, d.w16[g][i], d.b[g][i], raw, partial, nblk)
+            if (dense_cb == 64) { if (dense_half) ADE_DENSE16(64, true); else ADE_DENSE16(64, false); }
+            else { if (dense_half) ADE_DENSE16(32, true); else ADE_DENSE16(32, false); }
+#undef ADE_DENSE16
             hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)windows), dim3(64), 0, s, (const double*)partial, nblk, (double)TF, d.gamma[g][i], d.beta[g][i], nrm, ld, off_out);
             const long long total16 = M * 16;
-            hipLaunchKernelGGL(zip16::k_zip_hist_norm16, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
-                               TF, (float*)nullptr, total16);
+            if (dense_half) hipLaunchKernelGGL(zip16::k_zip_hist_norm16<true>, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
+                                               TF, (float*)nullptr, total16);
+            else hipLaunchKernelGGL(zip16::k_zip_hist_norm16<false>, dim3((unsigned)((total16 + 255) / 256)), dim3(256), 0, s, (const float*)raw, Dh16, ld, off_out, (const float*)nrm, ld, d.slope,
+                                    TF, (float*)nullptr, total16);
         }
 }
 
@@ -1816,9 +1827,11 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     hipLaunchKernelGGL(k_zip_conv1_coef, dim3((unsigned)B), dim3(64), 0, s, (const double*)partial, nchunk0, (double)TF0, c1_w, c1_b, c1_g, c1_beta, (float4*)coef, C);
     const bool enc16 = bf16 && (parts16 & 1), dec16 = bf16 && (parts16 & 4);
     if (enc16) {
-        hipLaunchKernelGGL(k_zip_conv1_apply16, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
+        if (dense_half) hipLaunchKernelGGL(k_zip_conv1_apply16<true>, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
+        else hipLaunchKernelGGL(k_zip_conv1_apply16<false>, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
         dense_block16(s, enc_dense, 1, E016, B, kZF);
-        zip16::launch_rows16<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);                    // (:853)
+        if (dense_half) zip16::launch_rows16<12, 2, true>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);   // (:853)
+        else zip16::launch_rows16<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);
     } else {
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
@@ -1840,11 +1853,13 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
     }
     // ---- mask | phase decoder pair (:864-893)
     if (dec16) {
-        hipLaunchKernelGGL(zip16::k_zip_to_bf16, flat(R * (C / 4)), dim3(256), 0, s, (const float*)X, X16, R * (C / 4));
+        if (dense_half) hipLaunchKernelGGL(zip16::k_zip_to_bf16<true>, flat(R * (C / 4)), dim3(256), 0, s, (const float*)X, X16, R * (C / 4));
+        else hipLaunchKernelGGL(zip16::k_zip_to_bf16<false>, flat(R * (C / 4)), dim3(256), 0, s, (const float*)X, X16, R * (C / 4));
         dense_block16(s, dec_dense, 2, X16, B, F);
     } else dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
-        if (dec16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
+        if (dec16 && dense_half) zip16::launch_rows16<12, 4, true>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
+        else if (dec16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
         else gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
                             SubPixelStore{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up, 3 * C);
         stats(s, U, 2 * C, g * C, T * F2, B, up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);

@@ -186,6 +186,27 @@ static inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipsim_v8s a, 
     }
     return d;
 }
+// v_mfma_f32_32x32x16_f16: the same operand maps with IEEE half elements
+static inline float hipsim_f16_of(const uint32_t (*all)[64], int lane, int e) {
+    const uint32_t w = all[e >> 1][lane], hb = (e & 1) ? (w >> 16) : (w & 0xffffu);
+    const uint32_t sign = (hb & 0x8000u) << 16, ex = (hb >> 10) & 0x1fu, m = hb & 0x3ffu;
+    float f;
+    if (ex == 0) { f = std::ldexp((float)m, -24); if (sign) f = -f; return f; }
+    const uint32_t u = ex == 31 ? (sign | 0x7f800000u | (m << 13)) : (sign | ((ex + 112u) << 23) | (m << 13));
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static inline hipsim_v16f __builtin_amdgcn_mfma_f32_32x32x16_f16(hipsim_v8s a, hipsim_v8s b, hipsim_v16f c, int, int, int) {
+    const int lane = ::hipsim::lane_id(), j = lane & 31, h = lane >> 5;
+    uint32_t all_a[4][64], all_b[4][64];
+    hipsim_gather8(a, b, all_a, all_b);
+    hipsim_v16f d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int k = 0; k < 16; ++k) d[r] = fmaf(hipsim_f16_of(all_a, i + 32 * (k >> 3), k & 7), hipsim_f16_of(all_b, j + 32 * (k >> 3), k & 7), d[r]);
+    }
+    return d;
+}
 static inline hipsim_v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipsim_v8s a, hipsim_v8s b, hipsim_v4f c, int, int, int) {
     const int lane = ::hipsim::lane_id(), j = lane & 15, g = lane >> 4;
     uint32_t all_a[4][64], all_b[4][64];

@@ -313,7 +313,7 @@ def test_gpu_bf16_path_stays_close_to_f32(fixture):
         return 10 * np.log10((sig ** 2).mean() / max((err ** 2).mean(), 1e-30))
     snr, snr_tok = snr_db(fb, fa), snr_db(tb, ta)
     print(f"mel_band_roformer bf16 vs f32: waveform SNR {snr:.1f} dB, transformer tokens SNR {snr_tok:.1f} dB")
-    assert np.isfinite(fb).all() and snr > 30.0 and snr_tok > 25.0
+    assert np.isfinite(fb).all() and snr > 38.0 and snr_tok > 30.0
 
 
 def _snr_db(x, ref):
@@ -327,7 +327,7 @@ def test_gpu_bf16_path_vs_reference_fixture(tag):
     """The bf16 path (BASELINE configs[3]'s dtype) against the REFERENCE's own forward, not against this engine's f32 path: the production-size fixtures
     (tools/make_golden_melband.py --production-size: MelBandRoformer.forward, Export_MelBandRoformer.py:629-677, at depth 2 x 151 frames and depth 1 x 801 frames = one 8 s
     segment of configs[3]) hold the reference's PCM and its fp32 waveform before the PCM tail.  A reduced-precision path cannot be held to 1e-4; what is gated is its SNR
-    against the reference's waveform and PCM (>= 30 dB, the gate the path has against the f32 engine) and a bound on the largest PCM deviation relative to the clip's peak."""
+    against the reference's waveform and PCM (>= 38 dB; round 5's gate was 30) and a bound on the largest PCM deviation relative to the clip's peak (-36 dB)."""
     from audio_denoiser_onnx_amd import melband
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.weights import pack_blob
@@ -347,8 +347,9 @@ def test_gpu_bf16_path_vs_reference_fixture(tag):
     report = dict(snr_wave_db=round(snr_wave, 1), snr_pcm_db=round(snr_pcm, 1), pcm_max_lsb=int(d.max()), pcm_median_lsb=float(np.median(d)), ref_peak=peak)
     print("bf16 vs reference fixture", tag, report)
     assert np.isfinite(f32).all() and peak > 500, report
-    assert snr_wave >= 30.0 and snr_pcm >= 30.0, report
-    assert d.max() <= 0.08 * peak, report                       # no sample further off than 8 % of the clip's peak (observed: see the printed report)
+    # measured (profiles/r06_a_full_depth_tests.txt): depth 1 x 801 frames 46.8 dB / -46 dB of peak, depth 2 x 151 44.7 / -44, depth 6 x 151 (the BASELINE depth) 41.9 / -40
+    assert snr_wave >= 38.0 and snr_pcm >= 38.0, report
+    assert 20 * np.log10(max(int(d.max()), 1) / peak) <= -36.0, report                       # no sample further off than -36 dB of the clip's peak
 
 
 def test_oracle_full_depth_matches_reference_forward():

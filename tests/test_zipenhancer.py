@@ -371,9 +371,11 @@ def test_gpu_zipenhancer_unknown_dtypes_are_refused(model):
 
 @pytest.mark.gpu
 def test_gpu_zipenhancer_bf16_vs_f32_and_reference_fixture(model):
-    """BASELINE configs[2]'s dtype: bf16 weights and activations stored in HBM (csrc/ade_zip16.h).  A throughput path, NOT the parity path: gated on its distance (a) from the
-    engine's f32 path -- encoder taps and the waveform -- and (b) from the REFERENCE's own forward on the fixture clips (Export_ZipEnhancer.py:818-927 run by
-    tools/make_golden_zipenhancer.py): SNR >= 30 dB against the reference's fp32 waveform and its PCM on every non-silent clip; silence stays exactly silent."""
+    """BASELINE configs[2]'s dtype: the dual-path transformer on bf16 weights and activations stored in HBM, the three causal dense blocks on IEEE half (csrc/ade_zip16.h; the
+    error budget that put them there: tools/zip_bf16_budget.py, profiles/r06_f_zip_bf16_budget.txt).  A throughput path, NOT the parity path: gated on its distance (a) from
+    the engine's f32 path -- encoder taps and the waveform -- and (b) from the REFERENCE's own forward on the fixture clips (Export_ZipEnhancer.py:818-927 run by
+    tools/make_golden_zipenhancer.py): SNR >= 37 dB against the reference's fp32 waveform and its PCM on every non-silent clip (measured 39.0 / 45.7; round 5's path: 33.3 / 35.1
+    under a 30 dB gate), no sample further off than -32 dB of the clip's peak (measured -33.5 / -44.5); silence stays exactly silent."""
     from audio_denoiser_onnx_amd.session import InferenceSession
     z, _, _, t = model
     L = int(z["length"])
@@ -390,20 +392,42 @@ def test_gpu_zipenhancer_bf16_vs_f32_and_reference_fixture(model):
     assert not ob[2].any()                                                        # silence stays exactly silent
     report = {k: round(_snr_db(vb, va), 1) for k, (va, vb) in taps.items()}
     for i, n in enumerate(names[:2]):
+        dl, peak = int(np.abs(ob[i].astype(np.int32) - z["out_" + n].astype(np.int32)).max()), int(np.abs(z["out_" + n]).max())
         report[n] = dict(vs_f32_wave=round(_snr_db(fb[i], fa[i]), 1), vs_ref_wave=round(_snr_db(fb[i], z["wave_" + n]), 1), vs_ref_pcm=round(_snr_db(ob[i], z["out_" + n]), 1),
-                         max_lsb_vs_ref=int(np.abs(ob[i].astype(np.int32) - z["out_" + n].astype(np.int32)).max()), ref_peak=int(np.abs(z["out_" + n]).max()))
+                         max_lsb_vs_ref=dl, ref_peak=peak, max_dev_db_of_peak=round(float(20 * np.log10(max(dl, 1) / peak)), 1))
     print("zipenhancer bf16:", report)
-    assert min(report[k] for k in ("enc_in", "enc0", "enc3")) >= 30.0, report
+    assert report["enc_in"] >= 55.0 and min(report[k] for k in ("enc0", "enc3")) >= 45.0, report          # measured 62.2 / 51.6 / 49.4
     for n in names[:2]:
         r = report[n]
-        assert r["vs_f32_wave"] >= 30.0 and r["vs_ref_wave"] >= 30.0 and r["vs_ref_pcm"] >= 30.0, report
-        assert r["max_lsb_vs_ref"] <= 0.1 * r["ref_peak"], report
+        assert r["vs_f32_wave"] >= 37.0 and r["vs_ref_wave"] >= 37.0 and r["vs_ref_pcm"] >= 37.0, report
+        assert r["max_dev_db_of_peak"] <= -32.0, report
+
+
+@pytest.mark.gpu
+def test_gpu_zipenhancer_bf16_dense_blocks_on_bf16_knob(model, monkeypatch):
+    """ADE_ZIP_DENSE_F16=0 (read when the engine is created) keeps the dense blocks on bf16 too -- the comparison leg of the error budget: it must still run, and it is the
+    path round 5 shipped (>= 30 dB from the f32 engine; the default is >= 5 dB closer on both clips)."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    z, _, _, t = model
+    L = int(z["length"])
+    pcm = np.stack([z["in_wav0"], z["in_randn"]])
+    blob = pack_blob(t)
+    with InferenceSession(weights=blob, metadata=zp.metadata(L)) as a:
+        _, fa = a.process(pcm, want_f32=True)
+    snr = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("ADE_ZIP_DENSE_F16", knob)
+        with InferenceSession(weights=blob, metadata=zp.metadata(L, gemm_dtype="bf16")) as b:
+            _, fb = b.process(pcm, want_f32=True)
+        snr[knob] = [round(_snr_db(fb[i], fa[i]), 1) for i in range(2)]
+    print("zipenhancer bf16, dense blocks on half / bf16: dB from the f32 engine", snr)
+    assert min(snr["0"]) >= 30.0 and all(h >= b + 5.0 for h, b in zip(snr["1"], snr["0"])), snr
 
 
 @pytest.mark.gpu
 def test_gpu_zipenhancer_bf16_full_batch_properties(model):
     """BASELINE configs[2] at its stated dtype AND batch: 128 x 1 s chunks in one call on the bf16 path -- finite, a silent row exactly silent, a row's bits the same alone and
-    in the reversed batch (row independence at batch 128), >= 30 dB from the f32 path on a row sample."""
+    in the reversed batch (row independence at batch 128), >= 40 dB from the f32 path on a row sample (measured 44.6; round 5's path 34.0 under a 30 dB gate)."""
     from audio_denoiser_onnx_amd.session import InferenceSession
     from audio_denoiser_onnx_amd.synth import synth_batch
     _, _, _, t = model
@@ -420,7 +444,7 @@ def test_gpu_zipenhancer_bf16_full_batch_properties(model):
         _, w32 = ref.process(x[:4], want_f32=True)
     snr = _snr_db(f32[:4], w32)
     print(f"zipenhancer bf16 at 128 x 1 s: {snr:.1f} dB from the f32 path on rows 0-3")
-    assert snr >= 30.0
+    assert snr >= 40.0
 
 
 @pytest.mark.gpu
