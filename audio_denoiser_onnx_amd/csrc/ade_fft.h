@@ -110,5 +110,58 @@ __device__ __forceinline__ float2* forward(float2* a, float2* b, const Plan& p, 
     return in;
 }
 
+// ---- the same passes with the transform size and its radices known at compile time (the starred models' sizes, and two small ones the host-simulator tests use): trip counts,
+// `j % ns` and the twiddle strides fold into constants, the pass loop unrolls.  The factorisation is make_plan's (4s, then 2s, 3s, 5s), so a size's results are bit-identical
+// to the run-time plan's.
+template <int N> struct Static { static constexpr bool known = false; };
+#define ADE_FFT_STATIC(NN, P, R0, R1, R2, R3, R4, R5)                                                                            \
+    template <> struct Static<NN> {                                                                                             \
+        static constexpr bool known = true;                                                                                     \
+        static constexpr int passes = P;                                                                                        \
+        static constexpr int radix(int i) { return i == 0 ? R0 : (i == 1 ? R1 : (i == 2 ? R2 : (i == 3 ? R3 : (i == 4 ? R4 : R5)))); }   \
+    }
+ADE_FFT_STATIC(512, 5, 4, 4, 4, 4, 2, 1);
+ADE_FFT_STATIC(400, 4, 4, 4, 5, 5, 1, 1);
+ADE_FFT_STATIC(2048, 6, 4, 4, 4, 4, 4, 2);
+ADE_FFT_STATIC(1920, 6, 4, 4, 4, 2, 3, 5);
+ADE_FFT_STATIC(64, 3, 4, 4, 4, 1, 1, 1);
+ADE_FFT_STATIC(60, 3, 4, 3, 5, 1, 1, 1);
+#undef ADE_FFT_STATIC
+inline bool static_size(int n) { return n == 512 || n == 400 || n == 2048 || n == 1920 || n == 64 || n == 60; }
+
+template <int R, int N, int NS>
+__device__ __forceinline__ void pass_static(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int tid, int nthreads) {
+    constexpr int nb = N / R, tstep = N / (NS * R);
+    for (int j = tid; j < nb; j += nthreads) {
+        const int k = j % NS;
+        float2 v[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            v[u] = in[j + u * nb];
+            if (u > 0 && NS > 1 && k > 0) v[u] = cmul(v[u], tw[u * k * tstep]);
+        }
+        if (R == 2) dft2(v);
+        if (R == 3) dft3(v);
+        if (R == 4) dft4(v);
+        if (R == 5) dft5(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int u = 0; u < R; ++u) out[j0 + u * NS] = v[u];
+    }
+}
+// Forward DFT of the N values in `a`; the result is in `a` when Static<N>::passes is even, in `b` otherwise (result_in_first<N>()).  Every thread of the workgroup calls it
+// (a barrier precedes each pass); tid / nthreads = the caller's index inside the thread group that shares this transform.
+template <int N> constexpr bool result_in_first() { return Static<N>::passes % 2 == 0; }
+template <int N, int I = 0, int NS = 1>
+__device__ __forceinline__ void forward_static(float2* a, float2* b, const float2* __restrict__ tw, int tid, int nthreads) {
+    if constexpr (I < Static<N>::passes) {
+        __syncthreads();
+        constexpr int R = Static<N>::radix(I);
+        if (I % 2 == 0) pass_static<R, N, NS>(a, b, tw, tid, nthreads);
+        else pass_static<R, N, NS>(b, a, tw, tid, nthreads);
+        forward_static<N, I + 1, NS * R>(a, b, tw, tid, nthreads);
+    }
+}
+
 }  // namespace fft
 }  // namespace ade

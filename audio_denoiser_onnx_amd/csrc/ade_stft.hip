@@ -196,6 +196,134 @@ __global__ __launch_bounds__(256) void k_stft_fft_synth(const float* __restrict_
     }
 }
 
+// ---- FFT formulation, RUN form (round 6): the sizes ade_fft.h knows at compile time ---------------------------------------------------------------------------------------
+// The spectrum's layout is the reference's (B, 2F, T) with the FRAME fastest, and a transform produces every bin of one frame: whoever writes (or reads) it frame pair by frame
+// pair moves 8-byte pieces a row pitch apart (the form above: 8 - 32 bytes per bin and workgroup; 6 - 12 % of the HBM rate, profiles/r06_a_bench.json).  Here a 512-thread
+// workgroup owns a RUN of RP frame pairs of one batch row and keeps ALL their transforms resident in LDS (RP slots of N + 1 complex values -- the odd pitch spreads the pairs of
+// one bin over the banks -- plus one ping-pong buffer per thread group): groups of 128 / 512 threads transform one pair each, pass by pass in step, and the spectrum is then
+// written (analysis) or was read (synthesis) bin by bin with the run's 2 RP frames adjacent: 64 - 256 contiguous bytes per bin, the whole (2F, T) block of a row in one piece
+// when the run is the row (GTCRN's 63 frames).  The synthesis also keeps the overlap-add in the workgroup: it transforms `halo` = ceil(N / hop) - 1 frames before its own
+// (recomputed, not exchanged), windows and sums each output sample's frames out of the resident slots in ascending frame order -- the sums, the order and therefore the bits of
+// the two-kernel form above (frames through HBM, then k_stft_ola), without the B x T x N float round trip.
+constexpr int kRunThreads = 512;
+template <int N> constexpr int run_group_threads() { return N / 4 <= 64 ? 64 : (N / 4 <= 128 ? 128 : (N / 4 <= 256 ? 256 : 512)); }
+
+template <int N>
+__global__ __launch_bounds__(kRunThreads) void k_stft_run_analyze(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ tw, StftDims d, int L,
+                                                                   int T, int RP, int lg_nt, float* __restrict__ spec) {
+    HIP_DYNAMIC_SHARED(float2, lds)
+    constexpr int GT = run_group_threads<N>(), G = kRunThreads / GT, SP = N + 1, F = N / 2 + 1;
+    const int tid = threadIdx.x, grp = tid / GT, lt = tid - grp * GT;
+    const int ppr = (T + 1) / 2, wpr = (ppr + RP - 1) / RP;
+    const int b = (int)blockIdx.x / wpr, p0 = ((int)blockIdx.x - b * wpr) * RP;
+    float2* const scratch = lds + (size_t)RP * SP + (size_t)grp * N;
+    float2* const twl = lds + (size_t)RP * SP + (size_t)G * N;                // the twiddle table in LDS (three scattered 8-byte reads per butterfly and pass: through the L1 they cost more than the butterflies)
+    for (int n = tid; n < N; n += kRunThreads) twl[n] = tw[n];              // (visible behind the barrier that precedes the first pass; pass 0 reads no twiddles)
+    const float* const row = x + (size_t)b * L;
+    for (int pl = grp; pl < RP; pl += G) {
+        const int pair = p0 + pl, t0 = 2 * pair;
+        const bool live = pair < ppr, two = t0 + 1 < T;
+        float2* const slot = lds + (size_t)pl * SP;
+        float2* const A = fft::result_in_first<N>() ? slot : scratch;          // the transform's result lands in the slot
+        float2* const Bf = fft::result_in_first<N>() ? scratch : slot;
+        for (int n = lt; n < N; n += GT) {
+            float2 v = make_float2(0.0f, 0.0f);
+            if (live) {
+                const float w = win[n];
+                v.x = padded_sample(row, d, L, t0 * d.hop + n) * w;
+                if (two) v.y = padded_sample(row, d, L, (t0 + 1) * d.hop + n) * w;
+            }
+            A[n] = v;
+        }
+        fft::forward_static<N>(A, Bf, twl, lt, GT);
+        __syncthreads();                               // (the next pair's samples go into a buffer this pair's last pass may still be reading)
+    }
+    const int nt = 2 * RP, tb = 2 * p0;
+    float* const re = spec + (size_t)b * (2 * F) * T;
+    float* const im = re + (size_t)F * T;
+#pragma unroll 4
+    for (int idx = tid; idx < F * nt; idx += kRunThreads) {
+        const int tl = idx & (nt - 1), f = idx >> lg_nt, t = tb + tl;
+        if (t >= T) continue;
+        const float2* rg = lds + (size_t)(tl >> 1) * SP;
+        const float2 z = rg[f], zc = rg[f == 0 ? 0 : N - f];
+        const bool odd = tl & 1;
+        re[(size_t)f * T + t] = odd ? 0.5f * (z.y + zc.y) : 0.5f * (z.x + zc.x);
+        im[(size_t)f * T + t] = odd ? 0.5f * (zc.x - z.x) : 0.5f * (z.y - zc.y);
+    }
+}
+
+// first owned frame of workgroup w = w * RO, RO = 2 RP - halo; the frames ts = w RO - halo .. ts + 2 RP - 1 are transformed (those outside [0, T) as zeros, never read back)
+template <int N, bool POLAR, bool TWL>      // TWL: the twiddle table is copied into LDS (when the slots leave room for it)
+__global__ __launch_bounds__(kRunThreads) void k_stft_run_synth(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ win,
+                                                                 const float* __restrict__ wsq, const float2* __restrict__ tw, StftDims d, int T, int RP, int lg_rp, int halo,
+                                                                 int out_start, int out_len, float* __restrict__ y) {
+    HIP_DYNAMIC_SHARED(float2, lds)
+    constexpr int GT = run_group_threads<N>(), G = kRunThreads / GT, SP = N + 1, F = N / 2 + 1;
+    const int tid = threadIdx.x, grp = tid / GT, lt = tid - grp * GT;
+    const int RT = 2 * RP, RO = RT - halo, wpr = (T + RO - 1) / RO;
+    const int b = (int)blockIdx.x / wpr, wi = (int)blockIdx.x - b * wpr, to = wi * RO, ts = to - halo;
+    float2* const scratch = lds + (size_t)RP * SP + (size_t)grp * N;
+    const float2* twl = tw;
+    if (TWL) {
+        float2* const t2 = lds + (size_t)RP * SP + (size_t)G * N;
+        for (int n = tid; n < N; n += kRunThreads) t2[n] = tw[n];
+        twl = t2;
+    }
+    auto bin = [&](int f, int t) -> float2 {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (t < 0 || t >= T) return v;
+        if (POLAR) {                                  // istft_A: real = mag cos(phase), imag = mag sin(phase)   (STFT_Process.py:343-347)
+            const size_t at = ((size_t)b * F + f) * T + t;
+            const float m = p0[at], ph = p1[at];
+            v = make_float2(m * cosf(ph), m * sinf(ph));
+        } else {
+            v = make_float2(p0[((size_t)b * d.F2 + f) * T + t], p0[((size_t)b * d.F2 + F + f) * T + t]);
+        }
+        if (f == 0 || (N % 2 == 0 && f == F - 1)) v.y = 0.0f;
+        return v;
+    };
+#pragma unroll 2
+    for (int idx = tid; idx < F * RP; idx += kRunThreads) {
+        const int pl = idx & (RP - 1), f = idx >> lg_rp, t = ts + 2 * pl;
+        const float2 z0 = bin(f, t), z1 = bin(f, t + 1);
+        float2* Ag = lds + (size_t)pl * SP;
+        // W[f] = z0 + i z1 = (z0.x - z1.y, z0.y + z1.x); W[N - f] = conj z0 + i conj z1 = (z0.x + z1.y, z1.x - z0.y); both stored conjugated
+        Ag[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
+        if (f > 0 && f < N - f) Ag[N - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
+    }
+    for (int pl = grp; pl < RP; pl += G) {
+        float2* const slot = lds + (size_t)pl * SP;
+        fft::forward_static<N>(slot, scratch, twl, lt, GT);
+        if (!fft::result_in_first<N>()) {              // an odd number of passes leaves the result in the ping-pong buffer: back into the slot
+            __syncthreads();
+            for (int n = lt; n < N; n += GT) slot[n] = scratch[n];
+        }
+        __syncthreads();
+    }
+    // overlap-add out of the slots: the samples whose LAST contributing frame is one of this workgroup's own (raw index m = t hop + n before the trim); the last workgroup
+    // of a row also takes the tail
+    const int raw_len = N + d.hop * (T - 1);
+    const int m0 = to * d.hop, m1 = wi + 1 == wpr ? raw_len : (to + RO) * d.hop;
+    const float inv = 1.0f / (float)N;
+    float* const yr = y + (size_t)b * out_len;
+    for (int m = m0 + tid; m < m1; m += kRunThreads) {
+        if (m < out_start || m >= out_start + out_len) continue;
+        int t_hi = m / d.hop;
+        if (t_hi > T - 1) t_hi = T - 1;
+        const int t_lo = m - N + 1 <= 0 ? 0 : (m - N + d.hop) / d.hop;      // smallest t with m - t*hop <= n_fft - 1
+        float sacc = 0.0f, wacc = 0.0f;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int n = m - t * d.hop, tl = t - ts;
+            const float2 r = lds[(size_t)(tl >> 1) * SP + n];
+            const float v = (tl & 1) ? -r.y : r.x;
+            sacc += __fmul_rn(v * inv, win[n]);               // (the windowed sample is rounded before it is added, as the frame buffer of the two-kernel form held it)
+            wacc += wsq[n];
+        }
+        yr[m - out_start] = sacc / wacc;
+    }
+}
+
 // torch.{hann,hamming}_window in fp32 (STFT_Process.py:88-113 registries), centre pad / crop to n_fft
 bool make_window(const std::string& name_in, int win_length, int n_fft, std::vector<float>& w, std::string& err) {
     std::string name = name_in;
@@ -228,6 +356,58 @@ bool make_window(const std::string& name_in, int win_length, int n_fft, std::vec
 }  // namespace
 }  // namespace ade
 
+namespace ade {
+namespace {
+#define ADE_RUN_SIZES(M) M(512) M(400) M(2048) M(1920) M(64) M(60)
+bool run_raise_lds(int n) {
+    const int bytes = 160 * 1024;
+    bool ok = true;
+#define ADE_RAISE(NN)                                                                                                                                          \
+    if (n == NN) ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_run_analyze<NN>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&   \
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_run_synth<NN, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_run_synth<NN, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_run_synth<NN, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && \
+                      hipFuncSetAttribute(reinterpret_cast<const void*>(k_stft_run_synth<NN, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    ADE_RUN_SIZES(ADE_RAISE)
+#undef ADE_RAISE
+    return ok;
+}
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// pairs per workgroup for a call with `pairs` frame pairs per row: the largest power of two that the LDS holds and the row can use (never below the thread groups' count)
+inline int run_pairs_for(int n, int rp_max, int pairs) {
+    const int gt = n / 4 <= 64 ? 64 : (n / 4 <= 128 ? 128 : (n / 4 <= 256 ? 256 : 512)), groups = kRunThreads / gt;
+    int rp = rp_max;
+    while (rp / 2 >= pairs && rp / 2 >= groups) rp /= 2;
+    return rp;
+}
+inline size_t run_lds_bytes(int n, int rp, bool twl = true) {
+    const int gt = n / 4 <= 64 ? 64 : (n / 4 <= 128 ? 128 : (n / 4 <= 256 ? 256 : 512)), groups = kRunThreads / gt;
+    return ((size_t)rp * (n + 1) + (size_t)groups * n + (twl ? (size_t)n : 0)) * sizeof(float2);        // slots + ping-pong buffers + the twiddle table
+}
+constexpr size_t kRunLdsBudget = 150 * 1024;
+void run_analyze(hipStream_t s, int n, const float* x, const float* win, const float2* tw, StftDims d, int L, int T, int rp, int batch, float* spec) {
+    const int ppr = (T + 1) / 2, wpr = (ppr + rp - 1) / rp;
+#define ADE_LAUNCH(NN) if (n == NN) hipLaunchKernelGGL(k_stft_run_analyze<NN>, dim3((unsigned)(batch * wpr)), dim3(kRunThreads), run_lds_bytes(n, rp), s, x, win, tw, d, L, T, rp, ilog2(2 * rp), spec);
+    ADE_RUN_SIZES(ADE_LAUNCH)
+#undef ADE_LAUNCH
+}
+template <bool POLAR>
+void run_synth(hipStream_t s, int n, const float* p0, const float* p1, const float* win, const float* wsq, const float2* tw, StftDims d, int T, int rp, int batch, int out_start,
+               int out_len, float* y) {
+    const int halo = (n + d.hop - 1) / d.hop - 1, ro = 2 * rp - halo, wpr = (T + ro - 1) / ro;
+    const bool twl = run_lds_bytes(n, rp, true) <= kRunLdsBudget;
+#define ADE_LAUNCH(NN)                                                                                                                                                       \
+    if (n == NN) {                                                                                                                                                           \
+        if (twl) hipLaunchKernelGGL((k_stft_run_synth<NN, POLAR, true>), dim3((unsigned)(batch * wpr)), dim3(kRunThreads), run_lds_bytes(n, rp, true), s, p0, p1, win, wsq, tw, d, T, rp, ilog2(rp), halo, out_start, out_len, y); \
+        else hipLaunchKernelGGL((k_stft_run_synth<NN, POLAR, false>), dim3((unsigned)(batch * wpr)), dim3(kRunThreads), run_lds_bytes(n, rp, false), s, p0, p1, win, wsq, tw, d, T, rp, ilog2(rp), halo, out_start, out_len, y); \
+    }
+    ADE_RUN_SIZES(ADE_LAUNCH)
+#undef ADE_LAUNCH
+}
+#undef ADE_RUN_SIZES
+}  // namespace
+}  // namespace ade
+
 struct ade_stft_plan {
     int device = 0;
     ade::StftDims d{};
@@ -239,6 +419,8 @@ struct ade_stft_plan {
     float2* d_tw = nullptr;                       // exp(-2 pi i m / n_fft), m < n_fft
     float *d_wa = nullptr, *d_ws = nullptr;       // analysis / synthesis windows
     int pairs_per_group = 1;                      // frame pairs per workgroup
+    bool run_form = false;                        // n_fft is one of ade_fft.h's compile-time sizes: the run kernels (k_stft_run_*)
+    int run_pairs_analyze = 1, run_pairs_synth = 1;   // frame pairs per workgroup of the run kernels (powers of two)
     size_t frames_cap = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -301,6 +483,25 @@ ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_hand
         }
         p->pairs_per_group = 1;
         while (p->pairs_per_group < 8 && (size_t)(2 * p->pairs_per_group) * N <= 4096) p->pairs_per_group *= 2;
+        // run form (k_stft_run_*): the compile-time sizes, unless ADE_STFT_RUN=0; RP slots of N + 1 complex values + one ping-pong buffer per thread group in <= 150 KB of LDS
+        p->run_form = ade::fft::static_size(N) && !(getenv("ADE_STFT_RUN") && atoi(getenv("ADE_STFT_RUN")) == 0);
+        if (p->run_form) {
+            // Run lengths (powers of two, at least one pair per thread group).  Measured on one MI355X (profiles/r06_k_stft_run_pairs_kernel_us.txt): the kernels are bound by
+            // how many workgroups a CU holds, not by the length of the contiguous pieces -- 512-point analysis 48 us with the whole row (32 pairs, 148 KB of LDS, one workgroup
+            // per CU) and 32 us with 4 pairs (33 KB, four per CU).  So: the analysis takes the shortest run; the synthesis the shortest one whose halo (frames transformed for
+            // the overlap-add and not owned) stays below a third of it.
+            const int gt = N / 4 <= 64 ? 64 : (N / 4 <= 128 ? 128 : (N / 4 <= 256 ? 256 : 512)), groups = ade::kRunThreads / gt;
+            const size_t budget = ade::kRunLdsBudget, fixed = (size_t)groups * N * 8;        // (the synthesis leaves its twiddles in global memory when slots + table do not fit)
+            const int halo = (N + cfg->hop - 1) / cfg->hop - 1;
+            int rpa = groups > 2 ? groups : 2, rps = groups;
+            while (2 * rps < 4 * halo) rps *= 2;
+            const int cap = getenv("ADE_STFT_RUN_PAIRS") ? atoi(getenv("ADE_STFT_RUN_PAIRS")) : 0;           // measurement knob: this many pairs per workgroup in both directions
+            if (cap > 0) { rpa = cap > groups ? cap : groups; rps = rpa; }
+            if ((size_t)rpa * (N + 1) * 8 + fixed + (size_t)N * 8 > budget || (size_t)rps * (N + 1) * 8 + fixed > budget || 2 * rps <= halo) p->run_form = false;      // (hops too small for a run)
+            p->run_pairs_analyze = rpa;
+            p->run_pairs_synth = rps;
+        }
+        if (p->run_form && !ade::run_raise_lds(N)) return bail(sfail(p, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the run-form FFT kernels"));
         const int lds_max = 16 * 8192;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(ade::k_stft_fft_analyze), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(ade::k_stft_fft_synth<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
@@ -369,7 +570,9 @@ ade_status ade_stft_analyze(ade_stft_handle p, const float* d_x, int batch, int 
     if (st != ADE_OK) return st;
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
-    if (p->use_fft) {
+    if (p->use_fft && p->run_form) {
+        ade::run_analyze(s, p->d.n_fft, d_x, p->d_wa, p->d_tw, p->d, length, T, ade::run_pairs_for(p->d.n_fft, p->run_pairs_analyze, (T + 1) / 2), batch, d_spec);
+    } else if (p->use_fft) {
         const int G = p->pairs_per_group, groups = ((T + 1) / 2 + G - 1) / G;
         hipLaunchKernelGGL(ade::k_stft_fft_analyze, dim3((unsigned)(batch * groups)), dim3(256), (size_t)G * 2 * p->d.n_fft * sizeof(float2), s, d_x, (const float*)p->d_wa,
                            p->fft_plan, (const float2*)p->d_tw, p->d, length, T, G, d_spec);
@@ -389,6 +592,16 @@ template <bool POLAR, class ALoader>
 ade_status synthesize_from(ade_stft_handle p, ALoader a, const float* p0, const float* p1, int batch, int frames, float* d_y, void* hip_stream) {
     STFT_HIP(p, hipSetDevice(p->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : p->stream;
+    if (p->use_fft && p->run_form) {                 // transforms + overlap-add in one launch: no frame buffer
+        int out_len = 0;
+        (void)ade_stft_output_length(p, frames, &out_len);
+        const int halo = (p->d.n_fft + p->d.hop - 1) / p->d.hop - 1;
+        const int rp = ade::run_pairs_for(p->d.n_fft, p->run_pairs_synth, (frames + halo + 1) / 2);
+        ade::run_synth<POLAR>(s, p->d.n_fft, p0, p1, p->d_ws, p->d_wsq, p->d_tw, p->d, frames, rp, batch, p->center ? p->d.n_fft / 2 : 0, out_len, d_y);
+        STFT_HIP(p, hipGetLastError());
+        if (!hip_stream) STFT_HIP(p, hipStreamSynchronize(s));
+        return ADE_OK;
+    }
     const size_t need = (size_t)batch * frames * p->d.n_fft;
     if (need > p->frames_cap) {
         STFT_HIP(p, hipStreamSynchronize(s));

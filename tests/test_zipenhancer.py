@@ -132,6 +132,10 @@ def engine_vs_oracle(sess, t, pcm, L, n_win=1, ref_pcm=None, ref_wave=None):
     # (3) per WINDOW: a window whose phase features took the same atan2 branch as the numpy STFT everywhere must reproduce the reference's PCM; a window with a
     #     flipped edge-frame bin is a different (equally valid) input to the network and is only counted
     flips = (np.abs(np.arctan2(spec[:, 201:], spec[:, :201] + np.float32(1e-5)) - np.arctan2(im, re + np.float32(1e-5))) > 1.0).reshape(W, -1).sum(axis=1)
+    nbins = int(np.prod(spec[:, :201].shape))
+    print(f"zipenhancer two-part contract: {int(flips.sum())} of {nbins} phase-feature bins ({100.0 * float(flips.sum()) / nbins:.4f} %) took the other atan2 branch than the numpy "
+          f"STFT's ({int((flips > 0).sum())} of {W} windows affected); spectrum max |d| {max(float(np.abs(spec[:, :201] - re).max()), float(np.abs(spec[:, 201:] - im).max())):.2e} "
+          f"at scale {scale:.1f}; network on the engine's own spectra: wave max |d| {float(np.abs(f32 - rw).max()):.3f} int16 units, PCM max {int(np.abs(out.astype(np.int32) - ro.astype(np.int32)).max())} LSB")
     if ref_pcm is not None:
         got_w, got_p = f32.reshape(W, -1), out.reshape(W, -1).astype(np.int32)
         ref_w, ref_p = np.asarray(ref_wave).reshape(W, -1), np.asarray(ref_pcm).reshape(W, -1).astype(np.int32)
