@@ -1446,11 +1446,25 @@ ade_status ade_set_option(ade_handle h, const char* key, const char* value) {
     return fail(h, ADE_ERR_MISSING_KEY, std::string("unknown option: ") + key);
 }
 
+// Submissions in flight (ade_submit) own the exchange area's time-out word until their ade_wait has looked at it: a synchronous entry point that ran beside them would
+// read -- and clear -- a time-out that belongs to one of their tickets, which would then report ADE_OK for garbage.  Every ade_process* entry therefore completes the ring
+// first (each submission's status is kept for its ade_wait, exactly as when a full ring completes its oldest one).
+namespace { void pipe_finish(ade_engine* h, ade_engine::PipeSlot& sl); }
+static void pipe_drain(ade_engine* h) {
+    for (;;) {
+        ade_engine::PipeSlot* oldest = nullptr;
+        for (auto& sl : h->pipe) if (sl.state == 1 && (!oldest || sl.ticket < oldest->ticket)) oldest = &sl;
+        if (!oldest) return;
+        pipe_finish(h, *oldest);
+    }
+}
+
 ade_status ade_process_device(ade_handle h, const int16_t* d_in, int batch, int16_t* d_out, float* d_f32, void* hip_stream) {
     if (!h) return ADE_ERR_BAD_VALUE;
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f32)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device: bad arguments");
     if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_device_f32");
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process_device", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
     ade_status st = reserve(h, rows);
@@ -1472,6 +1486,7 @@ ade_status ade_process_device_f32(ade_handle h, const float* d_in, int batch, in
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process_device");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process_device_f32", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;      // batch-fold: every call is n_win internal rows (windows)
     ade_status st = reserve(h, rows);
@@ -1534,6 +1549,7 @@ ade_status ade_process_device_f16(ade_handle h, const void* d_in, int batch, int
     if (batch < 0 || (batch > 0 && (!d_in || (!d_out && !d_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_device_f16: bad arguments");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process_device_f16", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
@@ -1563,6 +1579,7 @@ ade_status ade_process_f16(ade_handle h, const void* in, int batch, int16_t* out
     if (batch < 0 || (batch > 0 && (!in || (!out_pcm && !out_f16)))) return fail(h, ADE_ERR_BAD_VALUE, "ade_process_f16: bad arguments");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process_f16", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
@@ -1597,6 +1614,7 @@ ade_status ade_process_f32(ade_handle h, const float* in, int batch, int16_t* ou
     if (!h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is INT16: call ade_process");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process_f32", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
@@ -1632,6 +1650,7 @@ ade_status ade_process(ade_handle h, const int16_t* in, int batch, int16_t* out_
     // An EARLIER call's failure (an unsynchronised ade_process_device launch on a caller-provided stream that timed out: include/ade.h says the next call on the handle
     // reports it) is checked HERE and surfaces as ADE_ERR_DEVICE -- that call's output was garbage and nothing this call does can repair it.  Only a time-out of THIS call's
     // own launch (found by process_once after its synchronise) is re-run below.
+    if (hipSetDevice(h->device) == hipSuccess) pipe_drain(h);
     if (hipSetDevice(h->device) == hipSuccess) { const ade_status xs = exchange_status(h, "ade_process", true); if (xs != ADE_OK) return xs; }
     h->timed_out = false;
     ade_status st = process_once(h, in, batch, out_pcm, out_f32);
@@ -1654,6 +1673,7 @@ static ade_status process_once(ade_handle h, const int16_t* in, int batch, int16
     if (h->gt_float_in) return fail(h, ADE_ERR_BAD_VALUE, "this handle's input_audio_dtype is F32 / F16: call ade_process_f32");
     if (batch == 0) return ADE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    pipe_drain(h);
     { const ade_status xs = exchange_status(h, "ade_process", true); if (xs != ADE_OK) return xs; }
     const int rows = batch * h->n_win;
     ade_status st = reserve(h, rows);
@@ -1948,9 +1968,17 @@ ade_status ade_submit(ade_handle h, const int16_t* in, int batch, int16_t* out_p
         h->pipe_capacity = rows;
     }
     const unsigned long long t = h->pipe_next;
-    ade_engine::PipeSlot& sl = h->pipe[t % (unsigned long long)h->pipe_depth];
-    if (sl.state == 1) pipe_finish(h, sl);       // the ring is full: its oldest submission is completed first (its status still waits for ade_wait)
-    if (sl.state == 2) return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: ticket " + std::to_string(sl.ticket) + " has not been waited for (at most pipe_depth submissions between waits)");
+    // ANY free slot of the first pipe_depth (tickets may be waited for in any order, so the free one need not be t % depth).  None free: the oldest submission in flight is
+    // completed (its status still waits for ade_wait) and the call is refused -- at most pipe_depth tickets may be outstanding.
+    ade_engine::PipeSlot* slp = nullptr;
+    for (int i = 0; i < h->pipe_depth && !slp; ++i) if (h->pipe[i].state == 0) slp = &h->pipe[i];
+    if (!slp) {
+        ade_engine::PipeSlot* oldest = nullptr;
+        for (int i = 0; i < h->pipe_depth; ++i) if (!oldest || h->pipe[i].ticket < oldest->ticket) oldest = &h->pipe[i];
+        if (oldest->state == 1) pipe_finish(h, *oldest);
+        return fail(h, ADE_ERR_BAD_VALUE, "ade_submit: ticket " + std::to_string(oldest->ticket) + " has not been waited for (at most pipe_depth submissions between waits)");
+    }
+    ade_engine::PipeSlot& sl = *slp;
     auto page_locked = [](const void* p) {
         hipPointerAttribute_t a;
         if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -1965,11 +1993,20 @@ ade_status ade_submit(ade_handle h, const int16_t* in, int batch, int16_t* out_p
     HIP_TRY(h, hipStreamWaitEvent(h->stream, sl.ev_in, 0));
     st = run(h, h->stream, sl.d_in, rows, out_pcm ? sl.d_out : nullptr, out_f32 ? sl.d_f32 : nullptr);
     if (st != ADE_OK) { (void)hipStreamSynchronize(h->s_pin); (void)hipStreamSynchronize(h->stream); return st; }
-    HIP_TRY(h, hipEventRecord(sl.ev_k, h->stream));
+    // From here on this call's kernels are enqueued into the slot's buffers: a HIP failure must not return with them running and the slot unmarked.  Every stream is
+    // drained, every submission in flight fails with this one (their copies may not have been enqueued), and no ticket is issued.
+    hipError_t pe = hipEventRecord(sl.ev_k, h->stream);
     // the copy-outs of the OLDER submissions go out now, behind this one's copy-in; this one's waits for the next submission or for its ade_wait
-    for (unsigned long long o = t > (unsigned long long)ade_engine::kMaxPipe ? t - ade_engine::kMaxPipe : 1; o < t; ++o)
+    for (unsigned long long o = t > (unsigned long long)ade_engine::kMaxPipe ? t - ade_engine::kMaxPipe : 1; o < t && pe == hipSuccess; ++o)
         for (auto& other : h->pipe)
-            if (other.state == 1 && other.ticket == o) HIP_TRY(h, pipe_copy_out(h, other));
+            if (other.state == 1 && other.ticket == o && pe == hipSuccess) pe = pipe_copy_out(h, other);
+    if (pe != hipSuccess) {
+        (void)hipStreamSynchronize(h->s_pin); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->s_pout);
+        const ade_status fs = fail(h, ADE_ERR_DEVICE, std::string("ade_submit: after the launch: ") + hipGetErrorString(pe));
+        for (auto& other : h->pipe)
+            if (other.state == 1) { other.d2h_pending = false; other.state = 2; other.status = fs; other.error = h->last_error + " (a submission in flight beside the one that failed)"; }
+        return fs;
+    }
     sl.dst_pcm = out_pcm ? (pcm_direct ? out_pcm : sl.h_out) : nullptr;
     sl.dst_f32 = out_f32 ? (f32_direct ? out_f32 : sl.h_f32) : nullptr;
     sl.d2h_pending = true;

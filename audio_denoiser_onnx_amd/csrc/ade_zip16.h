@@ -502,9 +502,14 @@ inline void launch_rows16(hipStream_t s, const AL& a, const bf16_t* w, const ST&
     if (M <= 0) return;
     auto kern = k_rows16<KS, NT, AL, ST, HALF>;
     constexpr int bytes = rows16_lds<KS, NT>();
-    static bool raised = false;                                         // (more than 48 KB of dynamic LDS needs the attribute: K = 192 x N = 128 only)
-    if (bytes > 48 * 1024 && !raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); raised = true; }
+    // (more than 48 KB of dynamic LDS -- K = 192 x N = 128 only -- needs the attribute: raised once per device when the engine is created, raise_rows16_lds below)
     hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w, st, M, N);
+}
+template <int KS, int NT, bool HALF, class AL, class ST>
+inline hipError_t raise_rows16_lds() {
+    constexpr int bytes = rows16_lds<KS, NT>();
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16<KS, NT, AL, ST, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 
@@ -622,9 +627,13 @@ inline void launch_rows16_chain(hipStream_t s, const AL& a, const bf16_t* w1, co
     if (M <= 0) return;
     auto kern = k_rows16_chain<KS1, NT2, AL>;
     constexpr int bytes = chain16_lds<KS1, NT2>();
-    static bool raised = false;
-    if (bytes > 48 * 1024 && !raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); raised = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w1, b1, y, w2, b2, out2, ld2, M, N2);
+}
+template <int KS1, int NT2, class AL>
+inline hipError_t raise_rows16_chain_lds() {
+    constexpr int bytes = chain16_lds<KS1, NT2>();
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16_chain<KS1, NT2, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace zip16

@@ -1613,6 +1613,12 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
         (bf16 && (raise_attn_lds<0, 3, gemm16::bf16_t>() != hipSuccess || raise_attn_lds<1, 1, gemm16::bf16_t>() != hipSuccess || raise_attn16_lds<0, 3>() != hipSuccess ||
                   raise_attn16_lds<1, 1>() != hipSuccess)))
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the attention kernel"));
+    // the bf16 path's row kernels that need more than 48 KB of dynamic LDS: raised here, once per created engine on ITS device, and checked (they used to be raised behind a
+    // per-process flag at the first launch, result ignored)
+    if (bf16 && (zip16::raise_rows16_lds<12, 4, true, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
+                 zip16::raise_rows16_lds<12, 4, false, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
+                 zip16::raise_rows16_chain_lds<3, 4, zip16::B16Rows<0>>() != hipSuccess || zip16::raise_rows16_chain_lds<3, 2, zip16::B16Rows<0>>() != hipSuccess))
+        return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 row kernels"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||

@@ -41,6 +41,15 @@ def test_hipsim_submit_wait_equals_process():
     sess.wait(t1); sess.wait(t2)
     with pytest.raises(ValueError):
         sess.wait(t2)
+    # tickets may be waited for in ANY order: waiting for the newest one frees ITS slot for the next submission (the slot is any free one, not ticket % depth)
+    o1, o2, o3 = np.empty_like(o), np.empty_like(o), np.empty_like(o)
+    t1 = sess.submit(batches[0], o1); t2 = sess.submit(batches[1], o2)
+    sess.wait(t2)
+    t3 = sess.submit(batches[2], o3)
+    # a synchronous call beside submissions in flight completes them first and leaves their statuses for their own ade_wait
+    ref, _ = sess.process(batches[0])
+    sess.wait(t3); sess.wait(t1)
+    assert np.array_equal(o1, outs[0]) and np.array_equal(o2, outs[1]) and np.array_equal(o3, outs[2]) and np.array_equal(ref, outs[0])
 
 
 def test_process_rows_splits_large_files_into_submissions():
