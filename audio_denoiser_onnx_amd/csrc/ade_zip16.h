@@ -636,5 +636,245 @@ inline hipError_t raise_rows16_chain_lds() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16_chain<KS1, NT2, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// ---- a feed-forward module WITH the row-local products around it in one launch (round 6) -------------------------------------------------------------------------------------
+// A Zipformer2 layer touches its fp32 stream row ~20 times; between two sequence-mixing cores (attention, depthwise convolution) everything is row-local, and each of these
+// launches read and wrote the 256-byte row again: a projection before a feed-forward module, the module, a projection after it.  k_zip_ffx is k_zip_ff16 with
+//   PRE = 1   the convolution module's out-projection in front: xin_row := xin_row + (Wpre swooshR(o16 row) + bpre)   (k_rows16<4, 2, B16Rows<2>, ResidualStore>, :339); the
+//             updated row feeds the module from the wave's LDS tile and is NOT written back (its only reader is this module);
+//   PRE = 2   a side product of the module's input: pout = bf16(Wpre xin_row + bpre), N = pre.n <= 160 columns   (k_rows16<4, 5, F32Rows, Bf16BiasStore>: the layer's attention
+//             in-projection, :148-153);
+//   POSTNT    a product of the module's OUTPUT row: post.out = bf16(Wpost out_row + bpost), N = post.n <= 32 POSTNT   (k_rows16<4, NT, F32Rows, Bf16BiasStore>: the next
+//             module's in-projection) -- the row goes from the epilogue's whole-row pass back through the wave's tile into the operand registers.
+// The products are the same matrix instructions on the same operands in the same order as the separate kernels', every rounding happens where it did: the fused layer's
+// output equals the unfused one's bit for bit (ADE_ZIP_FUSE=0 keeps that form; tests/test_zipenhancer.py).  The projections' weights take the module's LDS before / after its
+// streamed chunks (36.9 KB per workgroup as before); their bf16 outputs leave straight from the accumulators -- a lane owns runs of four consecutive columns of ITS row:
+// 8-byte stores -- because the wave's LDS tile is under the weights at that point.
+struct FfxPre { const bf16_t* o16; const bf16_t* w; const float* b; bf16_t* pout; int ldp, n; };
+struct FfxPost { const bf16_t* w; const float* b; bf16_t* out; int ld, n; };
+template <int NT>
+__device__ __forceinline__ void ffx_product(const unsigned char* W, const uint4& x0, const uint4& x1, const uint4& x2, const uint4& x3, int l31, int h, v16f* acc) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(W + (32 * t + l31) * kF16Pitch + 32 * ks + 16 * h), ks == 0 ? x0 : (ks == 1 ? x1 : (ks == 2 ? x2 : x3)), acc[t]);
+}
+// N rows of 64 bf16 (8 pieces of 16 bytes) into LDS at the 144-byte pitch; rows beyond n re-read row n - 1 (their products are never stored)
+template <int NT>
+__device__ __forceinline__ void ffx_stage(unsigned char* lds, const bf16_t* __restrict__ w, int n, int tid) {
+    for (int i = tid; i < 32 * NT * 8; i += 256) {
+        const int r = i >> 3, pc = i & 7;
+        *reinterpret_cast<uint4*>(lds + r * kF16Pitch + 16 * pc) = *reinterpret_cast<const uint4*>(w + (size_t)(r < n ? r : n - 1) * 64 + 8 * pc);
+    }
+}
+// lane (row, h): register r of tile t is column 32 t + (r & 3) + 8 (r >> 2) + 4 h -> bf16(v + bias), four columns per store
+template <int NT>
+__device__ __forceinline__ void ffx_store16(const v16f* acc, const float* __restrict__ bias, bf16_t* __restrict__ out, int ld, int n, int row, int M, int h) {
+    if (row >= M) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * h;
+            if (col >= n) continue;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            *reinterpret_cast<uint2*>(out + (size_t)row * ld + col) =
+                gemm16::pack_bf16x4(make_float4(acc[t][4 * q] + b.x, acc[t][4 * q + 1] + b.y, acc[t][4 * q + 2] + b.z, acc[t][4 * q + 3] + b.w));
+        }
+}
+// Three wavefronts per SIMD: the PRE = 1 forms keep the updated rows in 32 registers across the module and spill 7 - 15 dwords at that bound; at two per SIMD (198 registers, no
+// spill) the step is 1.3 ms slower (profiles/r06_n_zip_ffx_occupancy.txt: 41.9 against 43.2 ms).
+template <int MODE, int PRE, int POSTNT>
+__global__ __launch_bounds__(256, 3) void k_zip_ffx(const float* xin, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+                                                 const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd, FfxPre pre, FfxPost post) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kF16Lds];
+    static_assert(5 * 32 * kF16Pitch <= kF16Lds, "a 160-column projection's weights fit the module's LDS");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31, mrow = row < M ? row : M - 1;
+    const int c4 = (lane & 15) * 4;
+    float* const E = reinterpret_cast<float*>(lds) + wave * 32 * kF16EPitch;
+    uint4 xb0, xb1, xb2, xb3;
+    float4 xiv[8];                     // PRE == 1: the updated rows in the epilogue's ownership (rows (lane >> 4) + 4 u, columns c4 ..)
+    if (PRE == 1) {
+        const B16Rows<2> ld{pre.o16, 64};
+        const uint4 a0 = ld(mrow, 0, h), a1 = ld(mrow, 1, h), a2 = ld(mrow, 2, h), a3 = ld(mrow, 3, h);
+        float4 old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int m = row0 + (lane >> 4) + 4 * u; old[u] = *reinterpret_cast<const float4*>(xin + (size_t)(m < M ? m : M - 1) * 64 + c4); }
+        ffx_stage<2>(lds, pre.w, 64, tid);
+        __syncthreads();
+        v16f acc1[2];
+        ffx_product<2>(lds, a0, a1, a2, a3, l31, h, acc1);
+        __syncthreads();                                                    // the weights are dead: the waves' tiles take their place
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(E + l31 * kF16EPitch + 32 * jt + 8 * q + 4 * h) = make_float4(acc1[jt][4 * q], acc1[jt][4 * q + 1], acc1[jt][4 * q + 2], acc1[jt][4 * q + 3]);
+        wave_sync();
+        const float4 bb = *reinterpret_cast<const float4*>(pre.b + c4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rl = (lane >> 4) + 4 * u;
+            const float4 v = *reinterpret_cast<const float4*>(E + rl * kF16EPitch + c4);
+            const float4 o = make_float4(old[u].x + (v.x + bb.x), old[u].y + (v.y + bb.y), old[u].z + (v.z + bb.z), old[u].w + (v.w + bb.w));
+            xiv[u] = o;
+            *reinterpret_cast<float4*>(E + rl * kF16EPitch + c4) = o;
+        }
+        wave_sync();
+        const float* er = E + l31 * kF16EPitch + 8 * h;
+        xb0 = pack8(*reinterpret_cast<const float4*>(er), *reinterpret_cast<const float4*>(er + 4));
+        xb1 = pack8(*reinterpret_cast<const float4*>(er + 16), *reinterpret_cast<const float4*>(er + 20));
+        xb2 = pack8(*reinterpret_cast<const float4*>(er + 32), *reinterpret_cast<const float4*>(er + 36));
+        xb3 = pack8(*reinterpret_cast<const float4*>(er + 48), *reinterpret_cast<const float4*>(er + 52));
+        __syncthreads();                                                    // every wave holds its operands: the module's weights may take the tiles
+    } else {
+        const float* src = xin + (size_t)mrow * 64 + 8 * h;
+        float4 t[8];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { t[2 * ks] = *reinterpret_cast<const float4*>(src + 16 * ks); t[2 * ks + 1] = *reinterpret_cast<const float4*>(src + 16 * ks + 4); }
+        xb0 = pack8(t[0], t[1]); xb1 = pack8(t[2], t[3]); xb2 = pack8(t[4], t[5]); xb3 = pack8(t[6], t[7]);
+    }
+    if (PRE == 2) {
+        ffx_stage<5>(lds, pre.w, pre.n, tid);
+        __syncthreads();
+        v16f accs[5];
+        ffx_product<5>(lds, xb0, xb1, xb2, xb3, l31, h, accs);
+        ffx_store16<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row, M, h);
+        __syncthreads();                                                    // the projection's weights are dead: the module's first chunk takes their place
+    }
+    v16f acc2[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[jt][r] = 0.0f;
+    const int sr = tid >> 3, sp = tid & 7;
+    uint4 p1a, p1b, p2a, p2b;
+    auto request = [&](int cg) __attribute__((always_inline)) {
+        p1a = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr) * 64 + 8 * sp);
+        p1b = *reinterpret_cast<const uint4*>(w1 + (size_t)(64 * cg + sr + 32) * 64 + 8 * sp);
+        p2a = *reinterpret_cast<const uint4*>(w2p + (size_t)sr * fd + 64 * cg + 8 * sp);
+        p2b = *reinterpret_cast<const uint4*>(w2p + (size_t)(sr + 32) * fd + 64 * cg + 8 * sp);
+    };
+    auto deposit = [&](unsigned char* buf) __attribute__((always_inline)) {
+        *reinterpret_cast<uint4*>(buf + sr * kF16Pitch + 16 * sp) = p1a;
+        *reinterpret_cast<uint4*>(buf + (sr + 32) * kF16Pitch + 16 * sp) = p1b;
+        *reinterpret_cast<uint4*>(buf + (64 + sr) * kF16Pitch + 16 * sp) = p2a;
+        *reinterpret_cast<uint4*>(buf + (64 + sr + 32) * kF16Pitch + 16 * sp) = p2b;
+    };
+    const int ncg = fd / 64;
+    request(0);
+    deposit(lds);
+    __syncthreads();
+    for (int cg = 0; cg < ncg; ++cg) {
+        const unsigned char* W1s = lds + (cg & 1) * kF16Buf;
+        const unsigned char* W2s = W1s + 64 * kF16Pitch;
+        if (cg + 1 < ncg) request(cg + 1);
+        v16f hh[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hh[c][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) hh[c] = mfma32x32x16(*reinterpret_cast<const uint4*>(W1s + (32 * c + l31) * kF16Pitch + 32 * ks + 16 * h), ks == 0 ? xb0 : (ks == 1 ? xb1 : (ks == 2 ? xb2 : xb3)), hh[c]);
+        uint4 hb[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float4 bb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bb[q] = *reinterpret_cast<const float4*>(b1 + 64 * cg + 32 * c + 8 * q + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float a[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e;
+                    const float4 bq = bb[r >> 2];
+                    const float bv = (r & 3) == 0 ? bq.x : ((r & 3) == 1 ? bq.y : ((r & 3) == 2 ? bq.z : bq.w));
+                    a[e] = swoosh_l16(hh[c][r] + bv);
+                }
+                hb[c][s] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(a[4], a[5]), pack_bf16x2(a[6], a[7]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    acc2[jt] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * jt + l31) * kF16Pitch + 64 * c + 32 * s + 16 * h), hb[c][s], acc2[jt]);
+        if (cg + 1 < ncg) deposit(lds + ((cg + 1) & 1) * kF16Buf);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(E + l31 * kF16EPitch + 32 * jt + 8 * q + 4 * h) = make_float4(acc2[jt][4 * q], acc2[jt][4 * q + 1], acc2[jt][4 * q + 2], acc2[jt][4 * q + 3]);
+    wave_sync();
+    const float4 bo = *reinterpret_cast<const float4*>(b2 + c4);
+    const float4 cv = (MODE == 2 || MODE == 3) ? *reinterpret_cast<const float4*>(cmid + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 fsv = MODE == 3 ? *reinterpret_cast<const float4*>(cmid + 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 rsv = MODE == 3 ? *reinterpret_cast<const float4*>(cmid + 128 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 xi[8], rv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = row0 + (lane >> 4) + 4 * u, mc = m < M ? m : M - 1;
+        xi[u] = PRE == 1 ? xiv[u] : (MODE != 0 ? *reinterpret_cast<const float4*>(xin + (size_t)mc * 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        rv[u] = MODE != 1 ? *reinterpret_cast<const float4*>(res + (size_t)mc * 64 + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+        const float4 a = *reinterpret_cast<const float4*>(E + rl * kF16EPitch + c4);
+        float4 ov;
+        if (MODE == 3) {                                                    // (every lane takes part in the row sums: rows beyond M compute on the clamped row and store nothing)
+            const float4 y = make_float4(xi[u].x + (a.x + bo.x), xi[u].y + (a.y + bo.y), xi[u].z + (a.z + bo.z), xi[u].w + (a.w + bo.w));
+            const float4 d = make_float4(y.x - cv.x, y.y - cv.y, y.z - cv.z, y.w - cv.w);
+            float ssq = fmaf(d.x, d.x, fmaf(d.y, d.y, fmaf(d.z, d.z, d.w * d.w)));
+            ssq += __shfl_xor(ssq, 1, 64); ssq += __shfl_xor(ssq, 2, 64); ssq += __shfl_xor(ssq, 4, 64); ssq += __shfl_xor(ssq, 8, 64);
+            const float nrm = sqrtf(ssq);
+            ov = make_float4((y.x / nrm) * fsv.x + rv[u].x * rsv.x, (y.y / nrm) * fsv.y + rv[u].y * rsv.y, (y.z / nrm) * fsv.z + rv[u].z * rsv.z, (y.w / nrm) * fsv.w + rv[u].w * rsv.w);
+        } else {
+            auto fin = [](float acc, float b, float x, float r, float c) -> float {
+                const float f = acc + b;
+                if (MODE == 0) return r + f;
+                if (MODE == 1) return x + f;
+                const float sum = x + f;
+                return r + (sum - r) * c;
+            };
+            ov = make_float4(fin(a.x, bo.x, xi[u].x, rv[u].x, cv.x), fin(a.y, bo.y, xi[u].y, rv[u].y, cv.y), fin(a.z, bo.z, xi[u].z, rv[u].z, cv.z), fin(a.w, bo.w, xi[u].w, rv[u].w, cv.w));
+        }
+        if (m < M) *reinterpret_cast<float4*>(out + (size_t)m * 64 + c4) = ov;
+        if (POSTNT > 0) *reinterpret_cast<float4*>(E + rl * kF16EPitch + c4) = ov;          // (this lane's own slot of the tile: read above, nobody else's)
+    }
+    if (POSTNT > 0) {
+        wave_sync();
+        const float* er = E + l31 * kF16EPitch + 8 * h;
+        const uint4 y0 = pack8(*reinterpret_cast<const float4*>(er), *reinterpret_cast<const float4*>(er + 4));
+        const uint4 y1 = pack8(*reinterpret_cast<const float4*>(er + 16), *reinterpret_cast<const float4*>(er + 20));
+        const uint4 y2 = pack8(*reinterpret_cast<const float4*>(er + 32), *reinterpret_cast<const float4*>(er + 36));
+        const uint4 y3 = pack8(*reinterpret_cast<const float4*>(er + 48), *reinterpret_cast<const float4*>(er + 52));
+        __syncthreads();                                                    // every wave holds its operands: the projection's weights take the tiles
+        constexpr int NTP = POSTNT > 0 ? POSTNT : 1;
+        ffx_stage<NTP>(lds, post.w, post.n, tid);
+        __syncthreads();
+        v16f acc3[NTP];
+        ffx_product<NTP>(lds, y0, y1, y2, y3, l31, h, acc3);
+        ffx_store16<NTP>(acc3, post.b, post.out, post.ld, post.n, row, M, h);
+    }
+}
+template <int MODE, int PRE, int POSTNT>
+inline void launch_zip_ffx(hipStream_t s, int M, const float* xin, const bf16_t* w1, const float* b1, const bf16_t* w2p, const float* b2, const float* res, const float* cmid,
+                           float* out, int fd, const FfxPre& pre, const FfxPost& post) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_ffx<MODE, PRE, POSTNT>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, xin, w1, b1, w2p, b2, res, cmid, out, M, fd, pre, post);
+}
+
 }  // namespace zip16
 }  // namespace ade

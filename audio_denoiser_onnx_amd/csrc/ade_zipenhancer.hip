@@ -1310,6 +1310,7 @@ struct ZipEngine : SubEngine {
     const gemm16::bf16_t *c2_w16 = nullptr, *up_w16[2] = {};
     float* raw = nullptr;                                                 // a dense layer's raw fp32 output (+ bias)
     bool zip_chain = !(getenv("ADE_ZIP_CHAIN") && atoi(getenv("ADE_ZIP_CHAIN")) == 0);
+    bool zip_fuse = !(getenv("ADE_ZIP_FUSE") && atoi(getenv("ADE_ZIP_FUSE")) == 0);      // bf16 path: a feed-forward module and the row-local projections around it in one launch (k_zip_ffx); 0: separate launches, same bits
     int dense_cb = getenv("ADE_ZIP_DENSE_CB") ? atoi(getenv("ADE_ZIP_DENSE_CB")) : 32;      // input channels per stage of k_zip_dense16 (measurement knob)
     // Error-budget knob of the bf16 path (tools/zip_bf16_budget.py): which parts of a bf16 handle run on bf16 operands -- bit 0 the dense encoder block, bit 1 the eight
     // Zipformer layers, bit 2 the decoder pair's dense block + sub-pixel convolution.  7 (default) = the bf16 path; a cleared bit runs that part's f32 kernels instead.
@@ -1773,16 +1774,25 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
     using namespace zip16;
     const int M = (int)R, n = geo.n, vdim = H * vd;
     const bool chain = zip_chain;                    // out-projection + next in-projection pairs in one launch (k_rows16_chain; ADE_ZIP_CHAIN=0: the two-kernel form, same bits)
+    // Row-local runs of the layer in one launch each (k_zip_ffx): [attention in-projection | feed-forward 1 | NonlinAttention in-projection], [convolution 1 out-projection |
+    // feed-forward 2 + bypass | self-attention 2 in-projection], [convolution 2 out-projection | feed-forward 3 + final norm].  Not while the per-module taps of the first layer
+    // are armed: the stream after a convolution module is not written back in the fused form.
+    const bool fuse = zip_fuse && !(lt && lt_armed) && attn_dim <= 160 && 3 * hid <= 160 && vdim <= 64;
+    if (fuse) {
+        launch_zip_ffx<0, 2, 5>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1,
+                                FfxPre{nullptr, w16.attn_w, w.attn_ff1_b, P16, attn_dim, attn_dim}, FfxPost{w16.nonlin_in_w, w.nonlin_in_b, S16, 3 * hid, 3 * hid});       // (:148-153, :160, :305)
+    } else {
     launch_rows16<4, 5>(s, F32Rows{x, C}, w16.attn_w, Bf16BiasStore{P16, w.attn_ff1_b, attn_dim, 0}, M, attn_dim);                                 // (:148-153)
     launch_zip_ff16<0>(s, M, x, w16.ff1_w1, w.attn_ff1_b + attn_dim, w16.ff1_w2p, w.ff1_out_b, x, nullptr, Y, ff1);                                  // (:160)
     layer_tap(s, 0, Y, R);
     launch_rows16<4, 5>(s, F32Rows{Y, C}, w16.nonlin_in_w, Bf16BiasStore{S16, w.nonlin_in_b, 3 * hid, 0}, M, 3 * hid);                              // (:305)
+    }
     launch_attn16<0, 3>(s, 1, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, 3 * hid, O16, hid, geo, hid);   // (:154-159, :310-316)
     if (chain) launch_rows16_chain<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, w.nonlin_out_b, Y, w16.sa_in_w[0], w.sa_in_b[0], S16, vdim, M, vdim);   // (:317, :167) + (:296)
     else launch_rows16<3, 2>(s, B16Rows<0>{O16, hid}, w16.nonlin_out_w, ResidualStore{Y, w.nonlin_out_b}, M, C);                                    // (:317, :167)
     layer_tap(s, 1, Y, R);
     for (int i = 0; i < 2; ++i) {
-        if (!(chain && i == 0)) launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);          // (:296)
+        if (!(chain && i == 0) && !(fuse && i == 1)) launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);          // (:296)
         launch_attn16<1, 1>(s, H, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, vdim, O16, vdim, geo, vd);  // (:297-300)
         if (chain) launch_rows16_chain<3, 4>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], w.sa_out_b[i], Y, w16.cv_in_w[i], w.cv_in_b[i], S16, 2 * C, M, 2 * C);   // (:301) + (:321)
         else {
@@ -1793,9 +1803,16 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)
+        const int fd = i ? ff3 : ffd;
+        if (fuse && (i == 0 || (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128))) {
+            const FfxPre pre{O16, w16.cv_out_w[i], w.cv_out_b[i], nullptr, 0, C};                                                                    // (:339)
+            if (i == 0) launch_zip_ffx<2, 1, 2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd, pre,
+                                                FfxPost{w16.sa_in_w[1], w.sa_in_b[1], S16, vdim, vdim});                                             // (:170-171) + (:296)
+            else launch_zip_ffx<3, 1, 0>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.norm_bias, x, fd, pre, FfxPost{nullptr, nullptr, nullptr, 0, 0});   // (:174-183)
+            continue;
+        }
         launch_rows16<4, 2>(s, B16Rows<2>{O16, C}, w16.cv_out_w[i], ResidualStore{Y, w.cv_out_b[i]}, M, C);                                         // (:339)
         layer_tap(s, 3 + 3 * i, Y, R);
-        const int fd = i ? ff3 : ffd;
         if (i == 0) { launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd); layer_tap(s, 4, Y, R); }   // (:170-171)
         else if (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128) {        // (nb | fs | rs sit side by side in the arena: the final norm rides in the module's store)
             launch_zip_ff16<3>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.norm_bias, x, fd);                            // (:174-183)

@@ -466,6 +466,25 @@ def test_gpu_zipenhancer_bf16_chained_products_equal_the_two_kernel_form(model, 
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.abs(outs[0][0]).max() > 50
 
 
+@pytest.mark.gpu
+def test_gpu_zipenhancer_bf16_fused_row_runs_equal_the_separate_launches(model, monkeypatch):
+    """k_zip_ffx (a feed-forward module with the row-local projections around it in one launch: attention in-projection | feed-forward 1 | NonlinAttention in-projection;
+    convolution out-projection | feed-forward 2 + bypass | self-attention in-projection; convolution out-projection | feed-forward 3 + final norm) against the separate launches
+    (ADE_ZIP_FUSE=0, read when the engine is created): the same bits, on a batch whose row count is not a multiple of the 128-row tiles."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch
+    _, _, _, t = model
+    blob, x, outs = pack_blob(t), synth_batch(3, 16000), []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("ADE_ZIP_FUSE", fuse)
+        with InferenceSession(weights=blob, metadata=zp.metadata(16000, gemm_dtype="bf16")) as sess:
+            o, f = sess.process(x, want_f32=True)
+            outs.append((o, f, sess.tap("enc0", 3 * sess.frames * F * C).copy(), sess.tap("enc3", 3 * sess.frames * F * C).copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert np.abs(outs[0][0]).max() > 50
+
+
 @pytest.mark.hipsim
 @pytest.mark.skipif(not os.environ.get("ADE_SLOW_TESTS"), reason="4 minutes under the host simulator; set ADE_SLOW_TESTS=1")
 def test_hipsim_zipenhancer_bf16_close_to_f32(model):
