@@ -688,8 +688,14 @@ __device__ __forceinline__ void ffx_store16(const v16f* acc, const float* __rest
 }
 // Three wavefronts per SIMD: the PRE = 1 forms keep the updated rows in 32 registers across the module and spill 7 - 15 dwords at that bound; at two per SIMD (198 registers, no
 // spill) the step is 1.3 ms slower (profiles/r06_n_zip_ffx_occupancy.txt: 41.9 against 43.2 ms).
+#ifndef ADE_FFX_WAVES_PRE1
+#define ADE_FFX_WAVES_PRE1 3
+#endif
+#ifndef ADE_FFX_WAVES_PRE2
+#define ADE_FFX_WAVES_PRE2 3
+#endif
 template <int MODE, int PRE, int POSTNT>
-__global__ __launch_bounds__(256, 3) void k_zip_ffx(const float* xin, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
+__global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES_PRE2)) void k_zip_ffx(const float* xin, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
                                                  const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd, FfxPre pre, FfxPost post) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kF16Lds];
     static_assert(5 * 32 * kF16Pitch <= kF16Lds, "a 160-column projection's weights fit the module's LDS");

@@ -1048,123 +1048,160 @@ void launch_attn(hipStream_t s, int heads, const TI* proj, int ldp, const float*
 
 // ---- the same attention core on the bf16 matrix instruction (ade_gemm_dtype = bf16; v_mfma_f32_16x16x32_bf16: lane l supplies row (l & 15), k = 8 (l >> 4) .. + 7 of a 32-deep
 // step; D as in the f32 form: lane (g, j16) holds D[4 g + r][j16]) -------------------------------------------------------------------------------------------------------
-// Same decomposition, same skew, fp32 scores / softmax / accumulation; what changes is the operand plumbing:
-//   S^T tile   : ONE instruction (K rows from LDS as 16-byte pieces, Q^T from global; the 16 head dims fill k = 0 .. 15, lane groups 2 / 3 feed a block of zeros);
-//   pos term   : on the vector pipe (round 5, second form): a lane's four scores of a tile are four CONSECUTIVE offsets of the table (offset = key - query + n - 1), so the
-//                lane reads its 32 bytes of the bf16 table [offset][4 dims] and takes four 4-term dot products with its own query's p (registers).  The first form made
-//                U^T = table x p^T with two matrix instructions per tile and un-skewed it through a per-wave LDS scratch (8 writes + 4 reads per tile): the kernel ran with
-//                its LDS pipe 77 % busy, 45 % of that in bank conflicts (`profiles/r05_i_zip_bf16_pmc_summary.txt`);
+// Same decomposition, same skew, fp32 scores / softmax / accumulation.  The kernel is bound by the vector pipe (the first bf16 form spent 17 vector instructions per score
+// against 1.5 matrix instructions per 64 scores, `profiles/r06_o_zip_bf16_kernel_stats.csv`), so everything that can ride in an instruction that is issued anyway does:
+//   S^T tile   : ONE instruction (K rows from LDS as 16-byte pieces, Q^T from global).  The 16 head dims fill k = 0 .. 15; k = 16 carries the KEY MASK: a staged key row holds
+//                0 (a key of the sequence) or -2^97 (padding) there and every query supplies 1, so padded keys leave the instruction at -1.6e29 and need no compare / select;
+//   pos term   : a lane's four scores of a tile are four CONSECUTIVE offsets of the table (offset = key - query + n - 1): it reads its 32 bytes of the bf16 table
+//                [offset][4 dims] and adds the two 2-term dot products with its own query's p (packed bf16 pairs as the projection stored them) onto the score with
+//                v_dot2c_f32_bf16: two instructions per score (were four conversions + four multiply-adds + an add);
+//   softmax    : exp2(s log2e - max log2e): one multiply-add + v_exp_f32; the row SUM comes out of the O^T product (SUMROW: a V^T row of ones in a spare value dim, i.e. the sum
+//                of the bf16-rounded probabilities the product actually uses) instead of one add per score; one v_rcp_f32 per query instead of IEEE divisions;
 //   O^T tile   : the probabilities of TWO key tiles are one B operand (the lane's own 2 x 4 registers, rounded to bf16), V^T comes from LDS as two 8-byte pieces (keys 4 g ..
-//                of the even tile, 16 + 4 g .. of the odd one): one instruction per 32 keys and 16 value dims.
-// 3 matrix instructions of 16 cycles per PAIR of key tiles against 20 of 32 cycles: what is left is the softmax's and the position term's VALU work.
+//                of the even tile, 16 + 4 g .. of the odd one): one instruction per 32 keys and 16 value dims.  V^T is staged two keys at a time (4-byte LDS writes).
+// Key tiles in steps of one (NT = 7 for the 101 sub-bands, 11 for the 161 frames: the last pair's second tile is a dummy of -inf scores).
 __device__ __forceinline__ v4f zmfma16x16x32(const uint4& a, const uint4& b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(gemm16::as_v8bf(a), gemm16::as_v8bf(b), c, 0, 0, 0); }
-constexpr int kK16Pitch = 48;               // bytes per staged key row: 16 dims bf16 + 16 (the 16 lanes of a read land on 16 distinct 4-bank sets)
-template <int MODE, int NT, int DT>
-__global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __restrict__ proj, int ldp, const float* __restrict__ pos, const gemm16::bf16_t* __restrict__ src, int lds_,
-                                                    gemm16::bf16_t* __restrict__ out, int ldo, SeqGeo geo, int dv) {
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+#if defined(__AMDGCN__)
+    typedef __bf16 v2bf_t __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf_t, a), __builtin_bit_cast(v2bf_t, b), c, false);
+#else
+    return fmaf(gemm16::bf16_hi(a), gemm16::bf16_hi(b), fmaf(gemm16::bf16_lo(a), gemm16::bf16_lo(b), c));        // (tests/hipsim)
+#endif
+}
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float rcp_raw(float x) { return __builtin_amdgcn_rcpf(x); }
+constexpr int kK16Pitch = 48;               // bytes per staged key row: 16 dims bf16 + the mask block (8 bf16: mask, 0 ...); the 16 lanes of a read land on 16 distinct 4-bank sets
+constexpr unsigned kKeyMaskBf16 = 0xF000u;  // -2^97
+// (the second launch bound keeps the register budget at <= 256 per lane, where the compiler writes the matrix instructions' results to ordinary registers: with the default
+//  budget of 512 it parks every score tile in the accumulation file and copies it out, one v_accvgpr_read per score)
+template <int MODE, int NT, int DT, bool SUMROW>
+__global__ __launch_bounds__(256, (NT <= 12 ? 4 : 2)) void k_zip_attn16(const gemm16::bf16_t* __restrict__ proj, int ldp, const float* __restrict__ pos, const gemm16::bf16_t* __restrict__ src, int lds_,
+                                                    gemm16::bf16_t* __restrict__ out, int ldo, SeqGeo geo, int dv, int geo_heads) {
     HIP_DYNAMIC_SHARED(unsigned char, lds8)
     typedef gemm16::bf16_t bf;
     constexpr int NP = (NT + 1) / 2, np32 = NP * 32, hd = 36;
-    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
-    const int j16 = lane & 15, g = lane >> 4, n2 = 2 * n - 1, n2p = (n2 + 1) & ~1;
+    // workgroup -> (sequence, head): the hardware deals consecutive workgroups round-robin to the 8 XCDs; the heads of one sequence run back to back on ONE XCD (they read the
+    // same projection rows: one trip to HBM for the four of them), sequences 8 apart follow each other there
+    const int heads = geo_heads, wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3, h = slot % heads, seq = (slot / heads) * 8 + xcd;
+    if (seq >= geo.nseq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
+    const int j16 = lane & 15, g = lane >> 4, n2 = 2 * n - 1;
     constexpr int vp = np32 * 2 + 16;                                                    // bytes per V^T row
     constexpr int kPtFront = 16, kPtRows = 2 * 16 * NT + 2 * kPtFront;                   // table rows in LDS: offsets -16 .. 32 NT + 15, zeros outside [0, n2) (padded queries / keys index there)
     unsigned char* Zs = lds8;                                                             // 16 bytes of zeros
     unsigned char* Ks = lds8 + 16;                                                        // [np32][kK16Pitch]
     unsigned char* Pt = Ks + np32 * kK16Pitch;                                           // [kPtRows][8]: bf16 x 4 dims per offset, row kPtFront = offset 0
     unsigned char* Vt = Pt + kPtRows * 8;                                                // [DT * 16][vp]
-    (void)n2p;
     const long long r0 = geo.row0(seq);
     if (tid < 4) reinterpret_cast<unsigned*>(Zs)[tid] = 0u;
-    {   // keys: two 16-byte pieces per key (rows beyond n are zeros)
-        constexpr int kIt = (np32 * 2 + 255) / 256;
-        uint4 t4[kIt];
+    // staging: EVERY global load of the workgroup's operands is requested first (a workgroup lives for a few microseconds: three load -> LDS phases one after the other were
+    // three round trips to HBM of its life), then the registers go to LDS as they arrive
+    constexpr int kItK = (np32 * 2 + 255) / 256, kItT = (kPtRows + 255) / 256;
+    constexpr int kQuads = DT * 4, kItems = (np32 / 2) * kQuads, kItV = (kItems + 255) / 256;
+    uint4 t4[kItK];
+    float tb[kItT][4];
+    uint2 va[kItV][2], vg[kItV][2];
 #pragma unroll
-        for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u, p = i >> 1, q = i & 1;
-            const bool ok = p < n;
-            t4[u] = gemm16::ld8_or_zero(ok, proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 8 * q);
-        }
+    for (int u = 0; u < kItK; ++u) {        // keys: two 16-byte pieces per key (rows beyond n are zeros)
+        const int i = tid + 256 * u, p = i >> 1, q = i & 1;
+        const bool ok = p < n;
+        t4[u] = gemm16::ld8_or_zero(ok, proj + (size_t)(r0 + (long long)(ok ? p : 0) * geo.ps) * ldp + h * hd + 16 + 8 * q);
+    }
 #pragma unroll
-        for (int u = 0; u < kIt; ++u) {
-            const int i = tid + 256 * u, p = i >> 1, q = i & 1;
-            if (p < np32) *reinterpret_cast<uint4*>(Ks + p * kK16Pitch + 16 * q) = t4[u];
+    for (int u = 0; u < kItV; ++u) {        // values: an item = four dims of TWO consecutive keys
+        const int i = tid + 256 * u, kp = i / kQuads, d = (i - kp * kQuads) * 4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int key = 2 * kp + e;
+            const bool ok = key < n && d < dv;
+            const bf* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0) + (MODE == 0 ? 0 : h * dv);
+            va[u][e] = *reinterpret_cast<const uint2*>(ok ? reinterpret_cast<const void*>(q) : reinterpret_cast<const void*>(g_zero4));
+            if (MODE == 0) vg[u][e] = *reinterpret_cast<const uint2*>(ok ? reinterpret_cast<const void*>(q + dv) : reinterpret_cast<const void*>(g_zero4));
         }
     }
-    {   // position table (head, 4 dims, n2) fp32 -> [offset][4] bf16, zeros in front of offset 0 and behind offset n2 - 1
-        constexpr int kIt = (kPtRows + 255) / 256;
-        float t[kIt][4];
 #pragma unroll
-        for (int u = 0; u < kIt; ++u) {
-            const int c = tid + 256 * u - kPtFront, cc = c >= 0 && c < n2 ? c : 0;
+    for (int u = 0; u < kItT; ++u) {        // position table (head, 4 dims, n2) fp32
+        const int c = tid + 256 * u - kPtFront, cc = c >= 0 && c < n2 ? c : 0;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) t[u][d] = pos[(size_t)(h * 4 + d) * n2 + cc];
+        for (int d = 0; d < 4; ++d) tb[u][d] = pos[(size_t)(h * 4 + d) * n2 + cc];
+    }
+    // a query tile's operands: B of the score product = Q[query j16][dims 8 g ..] (group 2: the mask's multiplier (1, 0 ...); group 3: zeros) and p[query j16][dims 0, 1 | 2, 3]
+    uint4 qv_n;
+    uint2 pq_n;
+    auto load_q = [&](int qt) __attribute__((always_inline)) {
+        const int qi = qt * 16 + j16;
+        const bf* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
+        qv_n = gemm16::ld8_or_zero(qi < n && g < 2, qrow + 8 * (g & 1));
+        if (g == 2) qv_n.x = 0x3F80u;
+        pq_n = *reinterpret_cast<const uint2*>(qrow + 32);
+    };
+    load_q(wave);
+#pragma unroll
+    for (int u = 0; u < kItK; ++u) {
+        const int i = tid + 256 * u, p = i >> 1, q = i & 1;
+        if (p < np32) *reinterpret_cast<uint4*>(Ks + p * kK16Pitch + 16 * q) = t4[u];
+    }
+    for (int p = tid; p < np32; p += 256) *reinterpret_cast<uint4*>(Ks + p * kK16Pitch + 32) = make_uint4(p < n ? 0u : kKeyMaskBf16, 0u, 0u, 0u);          // the mask block
+#pragma unroll
+    for (int u = 0; u < kItV; ++u) {        // -> Vt[dim][key] (bf16), four 4-byte writes (key pair) per item; keys beyond n are zeros; SUMROW: dim dv is all ones
+        const int i = tid + 256 * u, kp = i / kQuads, d = (i - kp * kQuads) * 4;
+        unsigned w[4];
+        if (MODE == 0) {                    // (:310-316) tanh(s) * x
+            float a0[4], a1[4], g0[4], g1[4];
+            a0[0] = gemm16::bf16_lo(va[u][0].x); a0[1] = gemm16::bf16_hi(va[u][0].x); a0[2] = gemm16::bf16_lo(va[u][0].y); a0[3] = gemm16::bf16_hi(va[u][0].y);
+            a1[0] = gemm16::bf16_lo(va[u][1].x); a1[1] = gemm16::bf16_hi(va[u][1].x); a1[2] = gemm16::bf16_lo(va[u][1].y); a1[3] = gemm16::bf16_hi(va[u][1].y);
+            g0[0] = gemm16::bf16_lo(vg[u][0].x); g0[1] = gemm16::bf16_hi(vg[u][0].x); g0[2] = gemm16::bf16_lo(vg[u][0].y); g0[3] = gemm16::bf16_hi(vg[u][0].y);
+            g1[0] = gemm16::bf16_lo(vg[u][1].x); g1[1] = gemm16::bf16_hi(vg[u][1].x); g1[2] = gemm16::bf16_lo(vg[u][1].y); g1[3] = gemm16::bf16_hi(vg[u][1].y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = gemm16::pack_bf16x2(tanh_f(a0[e]) * g0[e], tanh_f(a1[e]) * g1[e]);
+        } else {                            // values as stored: a shuffle of 16-bit halves
+            w[0] = (va[u][0].x & 0xffffu) | (va[u][1].x << 16);
+            w[1] = (va[u][0].x >> 16) | (va[u][1].x & 0xffff0000u);
+            w[2] = (va[u][0].y & 0xffffu) | (va[u][1].y << 16);
+            w[3] = (va[u][0].y >> 16) | (va[u][1].y & 0xffff0000u);
+            if (SUMROW && d == dv) w[0] = 0x3F803F80u;
         }
-#pragma unroll
-        for (int u = 0; u < kIt; ++u) {
-            const int row = tid + 256 * u, c = row - kPtFront;
-            if (row < kPtRows)
-                *reinterpret_cast<uint2*>(Pt + row * 8) = c >= 0 && c < n2 ? make_uint2(gemm16::pack_bf16x2(t[u][0], t[u][1]), gemm16::pack_bf16x2(t[u][2], t[u][3])) : make_uint2(0u, 0u);
+        if (i < kItems) {
+            unsigned char* col = Vt + (size_t)d * vp + kp * 4;
+            *reinterpret_cast<unsigned*>(col) = w[0];
+            *reinterpret_cast<unsigned*>(col + vp) = w[1];
+            *reinterpret_cast<unsigned*>(col + 2 * vp) = w[2];
+            *reinterpret_cast<unsigned*>(col + 3 * vp) = w[3];
         }
     }
-    {   // values, transposed into Vt[dim][key] (bf16): four dims per lane and load; keys beyond n are zeros
-        constexpr int kQuads = DT * 4, kIt = (np32 * kQuads + 255) / 256, kBatch = 4;
 #pragma unroll
-        for (int u0 = 0; u0 < kIt; u0 += kBatch) {
-            float4 va[kBatch], vb[kBatch];
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
-                const bool ok = key < n && d < dv;
-                const bf* q = src + (size_t)(r0 + (long long)(key < n ? key : 0) * geo.ps) * lds_ + (ok ? d : 0);
-                va[u] = keep4(ok, ldx4(MODE == 0 ? q : q + h * dv));
-                if (MODE == 0) vb[u] = keep4(ok, ldx4(q + dv));
-            }
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                const int i = tid + 256 * (u0 + u), key = i / kQuads, d = (i - key * kQuads) * 4;
-                if (u0 + u >= kIt || key >= np32) continue;
-                float4 v = va[u];
-                if (MODE == 0) v = make_float4(tanh_f(v.x) * vb[u].x, tanh_f(v.y) * vb[u].y, tanh_f(v.z) * vb[u].z, tanh_f(v.w) * vb[u].w);
-                const unsigned lo = gemm16::pack_bf16x2(v.x, v.y), hi = gemm16::pack_bf16x2(v.z, v.w);
-                bf* col = reinterpret_cast<bf*>(Vt + (size_t)d * vp) + key;
-                col[0] = (bf)(lo & 0xffffu);
-                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + vp) = (bf)(lo >> 16);
-                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + 2 * vp) = (bf)(hi & 0xffffu);
-                *reinterpret_cast<bf*>(reinterpret_cast<unsigned char*>(col) + 3 * vp) = (bf)(hi >> 16);
-            }
-        }
+    for (int u = 0; u < kItT; ++u) {        // -> [offset][4] bf16, zeros in front of offset 0 and behind offset n2 - 1
+        const int row = tid + 256 * u, c = row - kPtFront;
+        if (row < kPtRows)
+            *reinterpret_cast<uint2*>(Pt + row * 8) = c >= 0 && c < n2 ? make_uint2(gemm16::pack_bf16x2(tb[u][0], tb[u][1]), gemm16::pack_bf16x2(tb[u][2], tb[u][3])) : make_uint2(0u, 0u);
     }
     __syncthreads();
+    const int sum_lane = 16 * ((dv & 15) >> 2) + j16, sum_reg = dv & 3;                         // SUMROW: value dim dv of the last 16-dim tile = D row dv & 15
     for (int qt = wave; qt * 16 < n; qt += 4) {
         const int q0 = qt * 16, qi = q0 + j16;
-        const bf* qrow = proj + (size_t)(r0 + (long long)(qi < n ? qi : 0) * geo.ps) * ldp + h * hd;
-        const uint4 qv = gemm16::ld8_or_zero(qi < n && g < 2, qrow + 8 * (g & 1));                  // B operand of the score product: Q[query j16][dims 8 g ..] (groups 2, 3: zeros)
-        float pq[4];                                                                                // p[query j16][dims 0 .. 3] (rounded to bf16 by the projection's store)
-        {
-            const uint2 t = *reinterpret_cast<const uint2*>(qrow + 32);
-            pq[0] = gemm16::bf16_lo(t.x); pq[1] = __uint_as_float(t.x & 0xffff0000u); pq[2] = gemm16::bf16_lo(t.y); pq[3] = __uint_as_float(t.y & 0xffff0000u);
-        }
+        const uint4 qv = qv_n;
+        const uint2 pq = pq_n;
+        if ((qt + 4) * 16 < n) load_q(qt + 4);                                                     // the next tile's query rows travel during this tile
         // the lane's first table row of tile 0: offset of (query q0 + j16, key 4 g) = n - 1 - (q0 + j16) + 4 g; a tile further on is 16 rows further on
         const unsigned char* prow = Pt + (kPtFront + n - 1 - q0 - j16 + 4 * g) * 8;
+        const unsigned char* krow = g < 3 ? Ks + j16 * kK16Pitch + 16 * g : Zs;
+        const int kstep = g < 3 ? 16 * kK16Pitch : 0;
         float st[2 * NP][4];
         float mx = -INFINITY;
+        v4f sc_n = zmfma16x16x32(*reinterpret_cast<const uint4*>(krow), qv, v4f{0.0f, 0.0f, 0.0f, 0.0f});
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             const int k0 = kt * 16;
-            const uint4 kv = *reinterpret_cast<const uint4*>(g < 2 ? Ks + (k0 + j16) * kK16Pitch + 16 * g : Zs);
-            const v4f sc = zmfma16x16x32(kv, qv, v4f{0.0f, 0.0f, 0.0f, 0.0f});
+            const v4f sc = sc_n;                               // (the next tile's score product is issued before this tile's vector work: its latency passes there)
+            if (kt + 1 < NT) sc_n = zmfma16x16x32(*reinterpret_cast<const uint4*>(krow + (kt + 1) * kstep), qv, v4f{0.0f, 0.0f, 0.0f, 0.0f});
             uint2 tr[4];                                       // table rows of keys k0 + 4 g + r, r = 0 .. 3: 32 consecutive bytes
 #pragma unroll
             for (int r = 0; r < 4; ++r) tr[r] = *reinterpret_cast<const uint2*>(prow + (k0 + r) * 8);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float u = pq[0] * gemm16::bf16_lo(tr[r].x);
-                u = fmaf(pq[1], __uint_as_float(tr[r].x & 0xffff0000u), u);
-                u = fmaf(pq[2], gemm16::bf16_lo(tr[r].y), u);
-                u = fmaf(pq[3], __uint_as_float(tr[r].y & 0xffff0000u), u);
-                const float v = sc[r] + u;
-                st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
+                st[kt][r] = dot2_bf16(tr[r].y, pq.y, dot2_bf16(tr[r].x, pq.x, sc[r]));
                 mx = fmaxf(mx, st[kt][r]);
             }
             // (the tiles are independent: left alone, the compiler requests every tile's table rows up front and sinks the dot products to the softmax below -- 256 registers at
@@ -1175,6 +1212,7 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
         if (NT & 1) { st[NT][0] = st[NT][1] = st[NT][2] = st[NT][3] = -INFINITY; }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = -mx * kLog2e;
         float sum = 0.0f;
         v4f acc[DT];
 #pragma unroll
@@ -1183,9 +1221,11 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
         for (int p = 0; p < NP; ++p) {
             float pr[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pr[r] = __expf(st[2 * p][r] - mx); pr[4 + r] = __expf(st[2 * p + 1][r] - mx); }
+            for (int r = 0; r < 4; ++r) { pr[r] = exp2_raw(fmaf(st[2 * p][r], kLog2e, mb)); pr[4 + r] = exp2_raw(fmaf(st[2 * p + 1][r], kLog2e, mb)); }
+            if (!SUMROW) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) sum += pr[r];
+                for (int r = 0; r < 8; ++r) sum += pr[r];
+            }
             const uint4 pb = make_uint4(gemm16::pack_bf16x2(pr[0], pr[1]), gemm16::pack_bf16x2(pr[2], pr[3]), gemm16::pack_bf16x2(pr[4], pr[5]), gemm16::pack_bf16x2(pr[6], pr[7]));
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
@@ -1194,8 +1234,15 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
                 acc[d] = zmfma16x16x32(make_uint4(va.x, va.y, vb.x, vb.y), pb, acc[d]);
             }
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        if (SUMROW) {
+            const v4f a = acc[DT - 1];
+            const float sv = sum_reg == 0 ? a[0] : (sum_reg == 1 ? a[1] : (sum_reg == 2 ? a[2] : a[3]));
+            sum = __shfl(sv, sum_lane, 64);
+        } else {
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+        }
+        const float inv = rcp_raw(sum);
         if (qi < n) {
             const size_t row = (size_t)(r0 + (long long)qi * geo.ps);
 #pragma unroll
@@ -1204,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
                 if (col >= dv) continue;
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[d][r] / sum;
+                for (int r = 0; r < 4; ++r) o[r] = acc[d][r] * inv;
                 if (MODE == 0) {
                     const float4 y = ldx4(src + row * lds_ + 2 * dv + col);
                     o[0] *= y.x; o[1] *= y.y; o[2] *= y.z; o[3] *= y.w;
@@ -1217,23 +1264,27 @@ __global__ __launch_bounds__(256) void k_zip_attn16(const gemm16::bf16_t* __rest
 template <int MODE, int NT, int DT>
 inline size_t zip_attn16_lds(int n) {
     constexpr int NP = (NT + 1) / 2, np32 = NP * 32;
-    const int n2p = (2 * n - 1 + 1) & ~1;
-    (void)n2p;
+    (void)n;
     return 16 + (size_t)np32 * kK16Pitch + (size_t)(2 * 16 * NT + 32) * 8 + (size_t)DT * 16 * (np32 * 2 + 16);
 }
 template <int MODE, int NT, int DT>
 bool launch_attn16_nt(hipStream_t s, int heads, const gemm16::bf16_t* proj, int ldp, const float* pos, const gemm16::bf16_t* src, int lds_, gemm16::bf16_t* out, int ldo, SeqGeo geo, int dv) {
     if (geo.n > 16 * NT) return false;
-    auto kern = k_zip_attn16<MODE, NT, DT>;
     const size_t bytes = zip_attn16_lds<MODE, NT, DT>(geo.n);
-    hipLaunchKernelGGL(kern, dim3((unsigned)geo.nseq, (unsigned)heads), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, dv);
+    const dim3 grid((unsigned)(((geo.nseq + 7) / 8) * 8 * heads));
+    // a spare value dim in the last 16-dim tile carries the row sums (dv % 4 == 0 keeps the dim's quad apart from the values')
+    if (dv < 16 * DT && dv > 16 * (DT - 1) && (dv & 3) == 0)
+        hipLaunchKernelGGL((k_zip_attn16<MODE, NT, DT, true>), grid, dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, dv, heads);
+    else
+        hipLaunchKernelGGL((k_zip_attn16<MODE, NT, DT, false>), grid, dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, dv, heads);
     return true;
 }
 // windows of up to 256 frames / sub-bands take the bf16-instruction kernel (at most 64 KB of LDS, 64 score registers); longer ones the fp32-instruction kernel on bf16 storage
 template <int MODE, int DT>
 void launch_attn16(hipStream_t s, int heads, const gemm16::bf16_t* proj, int ldp, const float* pos, const gemm16::bf16_t* src, int lds_, gemm16::bf16_t* out, int ldo, SeqGeo geo, int dv) {
     if (launch_attn16_nt<MODE, 4, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 6, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
-        launch_attn16_nt<MODE, 8, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 12, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+        launch_attn16_nt<MODE, 7, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 8, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
+        launch_attn16_nt<MODE, 11, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) || launch_attn16_nt<MODE, 12, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv) ||
         launch_attn16_nt<MODE, 16, DT>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv)) return;
     launch_attn<MODE, DT, gemm16::bf16_t>(s, heads, proj, ldp, pos, src, lds_, out, ldo, geo, dv);
 }
@@ -1241,7 +1292,10 @@ template <int MODE, int DT>
 hipError_t raise_attn16_lds() {
     hipError_t e = hipSuccess;
     auto one = [&](auto kern) { if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
-    one(k_zip_attn16<MODE, 4, DT>); one(k_zip_attn16<MODE, 6, DT>); one(k_zip_attn16<MODE, 8, DT>); one(k_zip_attn16<MODE, 12, DT>); one(k_zip_attn16<MODE, 16, DT>);
+    one(k_zip_attn16<MODE, 4, DT, true>); one(k_zip_attn16<MODE, 6, DT, true>); one(k_zip_attn16<MODE, 7, DT, true>); one(k_zip_attn16<MODE, 8, DT, true>); one(k_zip_attn16<MODE, 11, DT, true>);
+    one(k_zip_attn16<MODE, 12, DT, true>); one(k_zip_attn16<MODE, 16, DT, true>);
+    one(k_zip_attn16<MODE, 4, DT, false>); one(k_zip_attn16<MODE, 6, DT, false>); one(k_zip_attn16<MODE, 7, DT, false>); one(k_zip_attn16<MODE, 8, DT, false>); one(k_zip_attn16<MODE, 11, DT, false>);
+    one(k_zip_attn16<MODE, 12, DT, false>); one(k_zip_attn16<MODE, 16, DT, false>);
     return e;
 }
 template <int MODE, int NT, int DT, class TI>
