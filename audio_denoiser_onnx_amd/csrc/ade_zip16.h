@@ -372,6 +372,8 @@ __device__ __forceinline__ float ldx1(const float* p) { return *p; }
 __device__ __forceinline__ float ldx1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
 __device__ __forceinline__ void stx4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void stx4(bf16_t* p, const float4& v) { *reinterpret_cast<uint2*>(p) = gemm16::pack_bf16x4(v); }
+__device__ __forceinline__ void stx2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+__device__ __forceinline__ void stx2(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack_bf16x2(a, b); }
 __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stx1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.0f) & 0xffffu); }
 

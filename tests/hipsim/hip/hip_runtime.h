@@ -246,6 +246,7 @@ static inline float __frsqrt_rn(float a) { return 1.0f / sqrtf(a); }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float __saturatef(float a) { return a < 0.f ? 0.f : (a > 1.f ? 1.f : a); }
 template <typename T> static inline T __ldg(const T* p) { return *p; }
 
