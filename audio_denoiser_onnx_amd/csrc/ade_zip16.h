@@ -688,6 +688,32 @@ __device__ __forceinline__ void ffx_store16(const v16f* acc, const float* __rest
                 gemm16::pack_bf16x4(make_float4(acc[t][4 * q] + b.x, acc[t][4 * q + 1] + b.y, acc[t][4 * q + 2] + b.z, acc[t][4 * q + 3] + b.w));
         }
 }
+// The same store as WHOLE ROWS: the wave's tile (+ bias, rounded) goes through the wave's own LDS region at a pitch of 2 n + 8 bytes (the 32 rows of a write land on 32 distinct
+// bank pairs) and leaves as 16-byte pieces, consecutive lanes on consecutive pieces of a row: full lines at the memory side (ffx_store16 hands it 16 bytes per row and
+// instruction, 20 instructions per 288-byte row: the in-projections' stores were 40 % of k_zip_ffx<0, 2, 5>'s bytes and all of its partial-line writes).  The caller has met
+// at a workgroup barrier after the product (the weights under the regions are dead) and meets again before the LDS is re-used.  n % 8 == 0, 32 (2 n + 8) <= kFfxRegion.
+constexpr int kFfxRegion = 32 * (2 * 144 + 8);
+constexpr int kFfxLds = kF16Lds > 4 * kFfxRegion ? kF16Lds : 4 * kFfxRegion;
+template <int NT>
+__device__ __forceinline__ void ffx_store_rows(const v16f* acc, const float* __restrict__ bias, bf16_t* __restrict__ out, int ld, int n, int row0, int M, unsigned char* region, int lane) {
+    const int l31 = lane & 31, h = lane >> 5, pitch = 2 * n + 8;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * h;
+            if (col >= n) continue;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            *reinterpret_cast<uint2*>(region + l31 * pitch + 2 * col) =
+                gemm16::pack_bf16x4(make_float4(acc[t][4 * q] + b.x, acc[t][4 * q + 1] + b.y, acc[t][4 * q + 2] + b.z, acc[t][4 * q + 3] + b.w));
+        }
+    wave_sync();
+    const int pieces = n >> 3, items = 32 * pieces;
+    for (int i = lane; i < items; i += 64) {
+        const int r = i / pieces, pc = i - r * pieces;
+        if (row0 + r < M) *reinterpret_cast<uint4*>(out + (size_t)(row0 + r) * ld + 8 * pc) = *reinterpret_cast<const uint4*>(region + r * pitch + 16 * pc);
+    }
+}
 // Three wavefronts per SIMD: the PRE = 1 forms keep the updated rows in 32 registers across the module and spill 7 - 15 dwords at that bound; at two per SIMD (198 registers, no
 // spill) the step is 1.3 ms slower (profiles/r06_n_zip_ffx_occupancy.txt: 41.9 against 43.2 ms).
 #ifndef ADE_FFX_WAVES_PRE1
@@ -699,8 +725,8 @@ __device__ __forceinline__ void ffx_store16(const v16f* acc, const float* __rest
 template <int MODE, int PRE, int POSTNT>
 __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES_PRE2)) void k_zip_ffx(const float* xin, const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2p,
                                                  const float* __restrict__ b2, const float* res, const float* __restrict__ cmid, float* out, int M, int fd, FfxPre pre, FfxPost post) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kF16Lds];
-    static_assert(5 * 32 * kF16Pitch <= kF16Lds, "a 160-column projection's weights fit the module's LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kFfxLds];
+    static_assert(5 * 32 * kF16Pitch <= kFfxLds, "a 160-column projection's weights fit the module's LDS");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31, mrow = row < M ? row : M - 1;
     const int c4 = (lane & 15) * 4;
@@ -752,8 +778,11 @@ __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES
         __syncthreads();
         v16f accs[5];
         ffx_product<5>(lds, xb0, xb1, xb2, xb3, l31, h, accs);
-        ffx_store16<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row, M, h);
-        __syncthreads();                                                    // the projection's weights are dead: the module's first chunk takes their place
+        if (32 * (2 * pre.n + 8) <= kFfxRegion) {
+            __syncthreads();                                                // the projection's weights are dead: the waves' store regions take their place
+            ffx_store_rows<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row0, M, lds + wave * kFfxRegion, lane);
+        } else ffx_store16<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row, M, h);
+        __syncthreads();                                                    // ... and then the module's first chunk
     }
     v16f acc2[2];
 #pragma unroll
@@ -875,7 +904,10 @@ __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES
         __syncthreads();
         v16f acc3[NTP];
         ffx_product<NTP>(lds, y0, y1, y2, y3, l31, h, acc3);
-        ffx_store16<NTP>(acc3, post.b, post.out, post.ld, post.n, row, M, h);
+        if (32 * (2 * post.n + 8) <= kFfxRegion) {
+            __syncthreads();
+            ffx_store_rows<NTP>(acc3, post.b, post.out, post.ld, post.n, row0, M, lds + wave * kFfxRegion, lane);
+        } else ffx_store16<NTP>(acc3, post.b, post.out, post.ld, post.n, row, M, h);
     }
 }
 template <int MODE, int PRE, int POSTNT>

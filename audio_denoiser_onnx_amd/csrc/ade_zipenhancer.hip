@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_zip_upsample_combine(float* __restrict_
     const float4 xv = *xp;
     // Both products rounded, then the sum: the reference's three operations.  Under -ffp-contract=fast the back end fuses one product into the add whatever the source says
     // (__fmul_rn / __fadd_rn and `#pragma clang fp contract(off)` do not stop it); the opaque uses do.  Where the two terms cancel that is not a last-bit matter: with the fused
-    // form the bf16 path's distance from the f32 path on the reference's speech clip drops from 40.2 to 37.9 dB (measured, tools/r06_job_v.sh).
+    // form the bf16 path's distance from the f32 path on the reference's speech clip drops from 40.2 to 37.9 dB (measured: the bisection is in DESIGN.md section 9).
     float4 a = make_float4(xv.x * r.x, xv.y * r.y, xv.z * r.z, xv.w * r.w), bq = make_float4(yv.x * o.x, yv.y * o.y, yv.z * o.z, yv.w * o.w);
     ADE_OPAQUE_V(a.x); ADE_OPAQUE_V(a.y); ADE_OPAQUE_V(a.z); ADE_OPAQUE_V(a.w);
     ADE_OPAQUE_V(bq.x); ADE_OPAQUE_V(bq.y); ADE_OPAQUE_V(bq.z); ADE_OPAQUE_V(bq.w);
