@@ -700,10 +700,13 @@ constexpr int kQKs = 20;                    // floats per staged Q / K row (16 +
 // TI: element type of proj / src / out -- float (the parity path) or bf16 (ade_gemm_dtype = bf16: the operands are stored in HBM as bf16 and widened on their way into LDS /
 // the registers; scores, softmax and accumulation are fp32 either way)
 template <int MODE, int NT, int DT, class TI>
-__global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, int ldp, const float* __restrict__ pos, const TI* __restrict__ src, int lds_,
-                                                  TI* __restrict__ out, int ldo, SeqGeo geo, int qd_, int pd_, int dv) {
+__global__ __launch_bounds__(256, (NT <= 11 ? 4 : (NT <= 20 ? 2 : 1))) void k_zip_attn(const TI* __restrict__ proj, int ldp, const float* __restrict__ pos, const TI* __restrict__ src, int lds_,
+                                                  TI* __restrict__ out, int ldo, SeqGeo geo, int qd_, int pd_, int dv, int heads) {
     HIP_DYNAMIC_SHARED(float, lds)
-    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
+    // workgroup -> (sequence, head): the heads of one sequence back to back on ONE XCD (consecutive workgroups go round-robin to the 8 XCDs; see k_zip_attn16)
+    const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3, h = slot % heads, seq = (slot / heads) * 8 + xcd;
+    if (seq >= geo.nseq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = geo.n;
     const int j16 = lane & 15, g = lane >> 4;
     const int np16 = NT * 16, n2 = 2 * n - 1, vst = np16 + 4;
     float* Ks = lds;                               // [np16][kQKs]   (queries and their position projections are read straight from global memory by the wave that owns them:
@@ -796,16 +799,22 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float u = fmaf(pq.w, tr[r].w, fmaf(pq.z, tr[r].z, fmaf(pq.y, tr[r].y, pq.x * tr[r].x)));     // the matrix instruction's order: dims 0 .. 3, one rounding per step
-                const float v = sc[r] + u;
-                st[kt][r] = (k0 + 4 * g + r < n) ? v : -INFINITY;
-                mx = fmaxf(mx, st[kt][r]);
+                st[kt][r] = sc[r] + u;
             }
+            if (k0 + 16 > n) {              // (wave-uniform: only the tiles that hold padded keys pay the compare / select; the empty asm keeps it a branch)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][r] = (k0 + 4 * g + r < n) ? st[kt][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
             ADE_OPAQUE_V(st[kt][0]); ADE_OPAQUE_V(st[kt][1]); ADE_OPAQUE_V(st[kt][2]); ADE_OPAQUE_V(st[kt][3]);      // (see k_zip_attn16: keeps a tile's work with the tile)
             if (kt & 1) __builtin_amdgcn_sched_barrier(0);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.0f;
+        const float mb = -mx * kLog2e;
         v4f acc[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) acc[d] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
@@ -813,7 +822,7 @@ __global__ __launch_bounds__(256) void k_zip_attn(const TI* __restrict__ proj, i
         for (int kt = 0; kt < NT; ++kt) {
             float pr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pr[r] = __expf(st[kt][r] - mx); sum += pr[r]; }          // hardware exp2 (~1 ulp); exp(-inf) = 0 for the padded keys
+            for (int r = 0; r < 4; ++r) { pr[r] = __builtin_amdgcn_exp2f(fmaf(st[kt][r], kLog2e, mb)); sum += pr[r]; }          // hardware exp2 (~1 ulp), the subtraction inside the multiply-add; exp2(-inf) = 0 for the padded keys
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 const float4 vv = *reinterpret_cast<const float4*>(Vt + (16 * d + j16) * vst + kt * 16 + 4 * g);   // V^T[dim 16 d + j16][keys k0 + 4 g ..]
@@ -1060,7 +1069,7 @@ bool launch_attn_nt(hipStream_t s, int heads, const TI* proj, int ldp, const flo
     if (geo.n > 16 * NT) return false;
     const size_t bytes = zip_attn_lds<MODE, NT, DT>(geo.n);
     auto kern = k_zip_attn<MODE, NT, DT, TI>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)geo.nseq, (unsigned)heads), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, 16, 4, dv);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((geo.nseq + 7) / 8) * 8 * heads)), dim3(256), bytes, s, proj, ldp, pos, src, lds_, out, ldo, geo, 16, 4, dv, heads);
     return true;
 }
 template <int MODE, int DT, class TI>
