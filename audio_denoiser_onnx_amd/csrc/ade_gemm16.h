@@ -110,6 +110,27 @@ __device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
 #endif
 }
 __device__ __forceinline__ uint2 pack_f16x4(const float4& v) { return make_uint2(pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w)); }
+__host__ __device__ inline float f16_value(unsigned short b) {           // portable form (the host simulator)
+    const unsigned sign = (unsigned)(b & 0x8000u) << 16, e = (b >> 10) & 31u, m = b & 0x3ffu;
+    unsigned u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { int k = 0; unsigned mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++k; } u = sign | ((unsigned)(113 - k) << 23) | ((mm & 0x3ffu) << 13); }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__device__ __forceinline__ void unpack_f16x2(unsigned w, float& lo, float& hi) {
+#if defined(__clang__) && defined(__AMDGCN__)
+    v2h h;
+    __builtin_memcpy(&h, &w, 4);
+    lo = (float)h[0]; hi = (float)h[1];
+#else
+    lo = f16_value((unsigned short)(w & 0xffffu)); hi = f16_value((unsigned short)(w >> 16));
+#endif
+}
 __device__ __forceinline__ v8h as_v8h(const uint4& u) { v8h r; __builtin_memcpy(&r, &u, 16); return r; }
 __device__ __forceinline__ v16f mfma32x32x16_f16(const uint4& a, const uint4& b, v16f c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a), as_v8h(b), c, 0, 0, 0); }
 // one spelling for kernels templated on the 16-bit operand type of a tensor family: HALF = IEEE half, otherwise bf16

@@ -13,6 +13,7 @@
 //   k_rows16          the K <= 192 products around the attention / convolution modules: rows straight from global memory into the matrix cores' registers (fp32 rows are
 //                     rounded on the way), weights staged once, full-line stores through LDS
 #pragma once
+#include <type_traits>
 #include "ade_gemm16.h"
 
 namespace ade {
@@ -36,6 +37,7 @@ __device__ __forceinline__ float softplus16(float x) {
 __device__ __forceinline__ float swoosh_l16(float x) { return softplus16(x - 4.0f) - 0.08f * x; }       // (Export_ZipEnhancer.py:135-136)
 __device__ __forceinline__ float swoosh_r16(float x) { return softplus16(x - 1.0f) - 0.08f * x; }       // (:138)
 
+__device__ __forceinline__ float sigmoid16(float x) { return 1.0f / (1.0f + __expf(-x)); }                // (the convolution module's GLU gate, :322-323: the form its staging used)
 __device__ __forceinline__ uint4 pack8(const float4& a, const float4& b) { return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)); }
 __device__ __forceinline__ void unpack8(const uint4& u, float* v) {
     v[0] = gemm16::bf16_lo(u.x); v[1] = gemm16::bf16_hi(u.x); v[2] = gemm16::bf16_lo(u.y); v[3] = gemm16::bf16_hi(u.y);
@@ -368,6 +370,15 @@ __device__ __forceinline__ float4 ldx4(const bf16_t* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     return make_float4(gemm16::bf16_lo(u.x), gemm16::bf16_hi(u.x), gemm16::bf16_lo(u.y), gemm16::bf16_hi(u.y));
 }
+// the same for a bf16_t-typed buffer that holds IEEE half (the convolution module's two private tensors on the bf16 path: neither feeds a matrix instruction directly)
+__device__ __forceinline__ float4 ldh4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    float4 v;
+    gemm16::unpack_f16x2(u.x, v.x, v.y);
+    gemm16::unpack_f16x2(u.y, v.z, v.w);
+    return v;
+}
+__device__ __forceinline__ void sth1(bf16_t* p, float v) { *p = (bf16_t)(gemm16::pack_f16x2(v, 0.0f) & 0xffffu); }
 __device__ __forceinline__ float ldx1(const float* p) { return *p; }
 __device__ __forceinline__ float ldx1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
 __device__ __forceinline__ void stx4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
@@ -392,14 +403,16 @@ struct F32Rows {               // fp32 [rows][ld]: the residual stream, rounded 
         return pack8(*reinterpret_cast<const float4*>(q), *reinterpret_cast<const float4*>(q + 4));
     }
 };
-template <int ACT>             // 0: as stored; 2: SwooshR of the stored value (the convolution module's out-projection, :339)
+template <int ACT, bool HALFIN = false>     // 0: as stored; 2: SwooshR of the stored value (the convolution module's out-projection, :339); HALFIN: the stored values are IEEE half (ACT 2 only)
 struct B16Rows {               // bf16 [rows][ld]
     const bf16_t* p; int ld;
     __device__ uint4 operator()(int m, int ks, int h) const {
         const uint4 u = *reinterpret_cast<const uint4*>(p + (size_t)m * ld + 16 * ks + 8 * h);
+        static_assert(!HALFIN || ACT == 2, "half rows pass through the activation's unpack / repack");
         if (ACT == 0) return u;
         float v[8];
-        unpack8(u, v);
+        if (HALFIN) { gemm16::unpack_f16x2(u.x, v[0], v[1]); gemm16::unpack_f16x2(u.y, v[2], v[3]); gemm16::unpack_f16x2(u.z, v[4], v[5]); gemm16::unpack_f16x2(u.w, v[6], v[7]); }
+        else unpack8(u, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = swoosh_r16(v[e]);
         return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
@@ -447,6 +460,11 @@ struct SubPixelStore16 {       // conv channel n = c * r + u of sub-band f -> U[
 };
 template <int KS, int NT>
 constexpr int rows16_lds() { return (32 * NT * (32 * KS + 16)) > 4 * 32 * 68 * 4 ? (32 * NT * (32 * KS + 16)) : 4 * 32 * 68 * 4; }
+struct GluStore16 {            // the two-kernel form of k_rows16_chain<.., GLU>: columns (a | gate) of a 2 C-wide product -> out[m][c] = half((a + bias) * sigmoid(gate + bias)), C = 64 columns
+    bf16_t* out; const float* bias; int ld;
+};
+template <class ST> struct IsGluStore : std::false_type {};
+template <> struct IsGluStore<GluStore16> : std::true_type {};
 template <int KS, int NT, class AL, class ST, bool HALF = false>        // HALF: operand rows and weights are IEEE half (the (1, 3) convolutions over the dense history)
 __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restrict__ w, ST store, int M, int N) {
     constexpr int kPitch = 32 * KS + 16;
@@ -477,6 +495,8 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
     __syncthreads();                                                    // the weights are dead: the wave's epilogue tile takes their place
     float* E = reinterpret_cast<float*>(lds) + wave * 32 * 68;
     const int c4 = (lane & 15) * 4;
+    float4 glu_a[8];                                                    // (GluStore16 only)
+    (void)glu_a;
 #pragma unroll
     for (int g = 0; g < (NT + 1) / 2; ++g) {
 #pragma unroll
@@ -489,7 +509,19 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
         }
         wave_sync();
         const int n = 64 * g + c4;
-        if (n < N && (2 * g + 1 < NT || c4 < 32)) {
+        if constexpr (IsGluStore<ST>::value) {
+            static_assert(!IsGluStore<ST>::value || NT == 4, "GLU: 64 value columns + 64 gate columns");
+            const float4 bb = *reinterpret_cast<const float4*>(store.bias + n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
+                const float4 v = *reinterpret_cast<const float4*>(E + rl * 68 + c4);
+                const float4 o = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+                if (g == 0) { glu_a[u] = o; continue; }
+                if (m < M) *reinterpret_cast<uint2*>(store.out + (size_t)m * store.ld + c4) =
+                    gemm16::pack_f16x4(make_float4(glu_a[u].x * sigmoid16(o.x), glu_a[u].y * sigmoid16(o.y), glu_a[u].z * sigmoid16(o.z), glu_a[u].w * sigmoid16(o.w)));
+            }
+        } else if (n < N && (2 * g + 1 < NT || c4 < 32)) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
@@ -524,7 +556,10 @@ inline hipError_t raise_rows16_lds() {
 // alias it until the first product is done) + the second weights: 44 - 53 KB, three workgroups per CU.
 template <int KS1, int NT2>
 constexpr int chain16_lds() { return 4 * 32 * 68 * 4 + 32 * NT2 * 144; }
-template <int KS1, int NT2, class AL>
+// GLU (round 6): the second product is the convolution module's in-projection (:321), whose 2 C columns are (a | gate): the store writes bf16(a * sigmoid(gate)), C columns at ld2,
+// instead of both halves -- the gate was applied by the depthwise kernel's staging, which read 256 bytes per row (and the halo rows again) where it now reads 128.  The C columns
+// are stored as IEEE HALF (saturating): the tensor is private to the convolution module (vector-pipe consumer), so the three extra mantissa bits are free.
+template <int KS1, int NT2, class AL, bool GLU = false>
 __global__ __launch_bounds__(256) void k_rows16_chain(AL a_of, const bf16_t* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ y, const bf16_t* __restrict__ w2,
                                                       const float* __restrict__ b2, bf16_t* __restrict__ out2, int ld2, int M, int N2) {
     constexpr int kP1 = 32 * KS1 + 16, kP2 = 144, kE = 4 * 32 * 68 * 4;
@@ -600,6 +635,8 @@ __global__ __launch_bounds__(256) void k_rows16_chain(AL a_of, const bf16_t* __r
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
             acc2[t] = mfma32x32x16(*reinterpret_cast<const uint4*>(W2s + (32 * t + l31) * kP2 + 32 * ks + 16 * h), ks == 0 ? xb0 : (ks == 1 ? xb1 : (ks == 2 ? xb2 : xb3)), acc2[t]);
+    static_assert(!GLU || NT2 == 4, "GLU: 64 value columns + 64 gate columns");
+    float4 glu_a[8];                                                    // GLU: the value half (+ bias) of this lane's eight (row, column quad) slots, kept until the gate half arrives
 #pragma unroll
     for (int g = 0; g < NT2 / 2; ++g) {
 #pragma unroll
@@ -615,27 +652,34 @@ __global__ __launch_bounds__(256) void k_rows16_chain(AL a_of, const bf16_t* __r
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
-                if (m >= M) continue;
                 const float4 v = *reinterpret_cast<const float4*>(E + rl * 68 + c4);
-                *reinterpret_cast<uint2*>(out2 + (size_t)m * ld2 + n) = gemm16::pack_bf16x4(make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w));
+                const float4 o = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+                if (GLU) {
+                    if (g == 0) { glu_a[u] = o; continue; }
+                    if (m < M) *reinterpret_cast<uint2*>(out2 + (size_t)m * ld2 + c4) =
+                        gemm16::pack_f16x4(make_float4(glu_a[u].x * sigmoid16(o.x), glu_a[u].y * sigmoid16(o.y), glu_a[u].z * sigmoid16(o.z), glu_a[u].w * sigmoid16(o.w)));
+                    continue;
+                }
+                if (m >= M) continue;
+                *reinterpret_cast<uint2*>(out2 + (size_t)m * ld2 + n) = gemm16::pack_bf16x4(o);
             }
         }
         wave_sync();
     }
 }
-template <int KS1, int NT2, class AL>
+template <int KS1, int NT2, bool GLU = false, class AL>
 inline void launch_rows16_chain(hipStream_t s, const AL& a, const bf16_t* w1, const float* b1, float* y, const bf16_t* w2, const float* b2, bf16_t* out2, int ld2, int M, int N2) {
     static_assert(NT2 % 2 == 0, "whole 64-column groups");
     if (M <= 0) return;
-    auto kern = k_rows16_chain<KS1, NT2, AL>;
+    auto kern = k_rows16_chain<KS1, NT2, AL, GLU>;
     constexpr int bytes = chain16_lds<KS1, NT2>();
     hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w1, b1, y, w2, b2, out2, ld2, M, N2);
 }
-template <int KS1, int NT2, class AL>
+template <int KS1, int NT2, class AL, bool GLU = false>
 inline hipError_t raise_rows16_chain_lds() {
     constexpr int bytes = chain16_lds<KS1, NT2>();
     if (bytes <= 48 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16_chain<KS1, NT2, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16_chain<KS1, NT2, AL, GLU>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // ---- a feed-forward module WITH the row-local products around it in one launch (round 6) -------------------------------------------------------------------------------------
@@ -734,7 +778,7 @@ __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES
     uint4 xb0, xb1, xb2, xb3;
     float4 xiv[8];                     // PRE == 1: the updated rows in the epilogue's ownership (rows (lane >> 4) + 4 u, columns c4 ..)
     if (PRE == 1) {
-        const B16Rows<2> ld{pre.o16, 64};
+        const B16Rows<2, true> ld{pre.o16, 64};                             // (the depthwise kernel's output: IEEE half on this path)
         const uint4 a0 = ld(mrow, 0, h), a1 = ld(mrow, 1, h), a2 = ld(mrow, 2, h), a3 = ld(mrow, 3, h);
         float4 old[8];
 #pragma unroll

@@ -45,6 +45,7 @@ namespace {
 using namespace dev;
 using zip16::ldx1;
 using zip16::ldx4;
+using zip16::ldh4;
 using zip16::stx1;
 using zip16::stx2;
 using zip16::stx4;
@@ -862,7 +863,9 @@ inline size_t zip_attn_lds(int n) {
 
 // ConvolutionModule core (:325-336): GLU then the depthwise Conv1d(k, padding k / 2) along the sequence.  grid (sequence, 64-position blocks);
 // the block's gated rows (+ k / 2 halo on both sides) are staged in LDS once.  g: [rows][2 C] = (value | gate); out: [rows][C].
-template <int CC, int KK, class TI>       // CC, KK > 0: channel count / kernel size known at compile time (the published geometry: 64, 15); 0: run-time values; TI: float | bf16 storage of g / out
+// PREGLU (the bf16 path, round 6): g holds C columns of IEEE half, the GLU already applied by the in-projection's store (zip16::k_rows16_chain<.., GLU> / GluStore16), and out
+// is written as IEEE half too (its one reader, the out-projection's loader zip16::B16Rows<2, true>, unpacks it for SwooshR anyway)
+template <int CC, int KK, class TI, bool PREGLU = false>       // CC, KK > 0: channel count / kernel size known at compile time (the published geometry: 64, 15); 0: run-time values; TI: float | bf16 storage of g / out
 __global__ __launch_bounds__(256) void k_zip_dwconv(const TI* __restrict__ g, const float* __restrict__ w, const float* __restrict__ bias, TI* __restrict__ out,
                                                     SeqGeo geo, int C_, int K_) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -878,16 +881,17 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const TI* __restrict__ g, co
         for (int u = 0; u < kIt; ++u) {
             const int i = tid + 256 * u, p = i >> 4, c = (i & 15) * 4, pos = p0 - half + p;
             const bool ok = p < kRows && pos >= 0 && pos < n;
-            const TI* q = g + (size_t)(r0 + (long long)(ok ? pos : 0) * geo.ps) * (2 * CC) + c;
-            va[u] = keep4(ok, ldx4(q));
-            vg[u] = ldx4(q + CC);
+            const TI* q = g + (size_t)(r0 + (long long)(ok ? pos : 0) * geo.ps) * (PREGLU ? CC : 2 * CC) + c;
+            if constexpr (PREGLU) va[u] = keep4(ok, ldh4(q));
+            else va[u] = keep4(ok, ldx4(q));
+            if (!PREGLU) vg[u] = ldx4(q + CC);
         }
 #pragma unroll
         for (int u = 0; u < kIt; ++u) {
             const int i = tid + 256 * u, p = i >> 4, c = (i & 15) * 4;
             if (p < kRows)
-                *reinterpret_cast<float4*>(lds + p * CC + c) = make_float4(va[u].x * sigmoid_p(vg[u].x), va[u].y * sigmoid_p(vg[u].y), va[u].z * sigmoid_p(vg[u].z),
-                                                                           va[u].w * sigmoid_p(vg[u].w));
+                *reinterpret_cast<float4*>(lds + p * CC + c) = PREGLU ? va[u] : make_float4(va[u].x * sigmoid_p(vg[u].x), va[u].y * sigmoid_p(vg[u].y), va[u].z * sigmoid_p(vg[u].z),
+                                                                                             va[u].w * sigmoid_p(vg[u].w));
         }
         const int c = tid & 63;
         float wk[KK];
@@ -901,10 +905,14 @@ __global__ __launch_bounds__(256) void k_zip_dwconv(const TI* __restrict__ g, co
             float a = 0.0f;
 #pragma unroll
             for (int k = 0; k < KK; ++k) a = fmaf(wk[k], lds[(p + k) * CC + c], a);
-            if (pos < n) stx1(out + (size_t)(r0 + (long long)pos * geo.ps) * CC + c, a + bc);
+            if (pos < n) {
+                if constexpr (PREGLU) zip16::sth1(out + (size_t)(r0 + (long long)pos * geo.ps) * CC + c, a + bc);        // (PREGLU = the bf16 path: input and output are IEEE half)
+                else stx1(out + (size_t)(r0 + (long long)pos * geo.ps) * CC + c, a + bc);
+            }
         }
         return;
     }
+    static_assert(!PREGLU || (CC == 64 && KK > 0), "PREGLU: the published geometry only");
     for (int i = tid; i < rowsN * C; i += 256) {
         const int p = i / C, c = i - p * C, pos = p0 - half + p;
         float v = 0.0f;
@@ -1706,7 +1714,7 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     // per-process flag at the first launch, result ignored)
     if (bf16 && (zip16::raise_rows16_lds<12, 4, true, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
                  zip16::raise_rows16_lds<12, 4, false, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
-                 zip16::raise_rows16_chain_lds<3, 4, zip16::B16Rows<0>>() != hipSuccess || zip16::raise_rows16_chain_lds<3, 2, zip16::B16Rows<0>>() != hipSuccess))
+                 zip16::raise_rows16_chain_lds<3, 4, zip16::B16Rows<0>, true>() != hipSuccess || zip16::raise_rows16_chain_lds<3, 2, zip16::B16Rows<0>>() != hipSuccess))
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 row kernels"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
@@ -1882,15 +1890,16 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
     for (int i = 0; i < 2; ++i) {
         if (!(chain && i == 0) && !(fuse && i == 1)) launch_rows16<4, 2>(s, F32Rows{Y, C}, w16.sa_in_w[i], Bf16BiasStore{S16, w.sa_in_b[i], vdim, 0}, M, vdim);          // (:296)
         launch_attn16<1, 1>(s, H, (const gemm16::bf16_t*)P16, attn_dim, w.pos, (const gemm16::bf16_t*)S16, vdim, O16, vdim, geo, vd);  // (:297-300)
-        if (chain) launch_rows16_chain<3, 4>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], w.sa_out_b[i], Y, w16.cv_in_w[i], w.cv_in_b[i], S16, 2 * C, M, 2 * C);   // (:301) + (:321)
+        // the in-projection's store applies the GLU (:322-323): S16 holds C columns, a * sigmoid(gate)
+        if (chain) launch_rows16_chain<3, 4, true>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], w.sa_out_b[i], Y, w16.cv_in_w[i], w.cv_in_b[i], S16, C, M, 2 * C);   // (:301) + (:321-323)
         else {
             launch_rows16<3, 2>(s, B16Rows<0>{O16, vdim}, w16.sa_out_w[i], ResidualStore{Y, w.sa_out_b[i]}, M, C);                                  // (:301)
-            launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], Bf16BiasStore{S16, w.cv_in_b[i], 2 * C, 0}, M, 2 * C);                            // (:321)
+            launch_rows16<4, 4>(s, F32Rows{Y, C}, w16.cv_in_w[i], GluStore16{S16, w.cv_in_b[i], C}, M, 2 * C);                                      // (:321-323)
         }
         layer_tap(s, 2 + 3 * i, Y, R);
         const dim3 cg((unsigned)geo.nseq, (unsigned)((n + 63) / 64));
         const size_t cl = (size_t)(64 + K - 1) * C * sizeof(float);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zip_dwconv<64, 15, gemm16::bf16_t, true>), cg, dim3(256), cl, s, (const gemm16::bf16_t*)S16, w.cv_dw_w[i], w.cv_dw_b[i], O16, geo, C, K);   // (:325-336)
         const int fd = i ? ff3 : ffd;
         if (fuse && (i == 0 || (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128))) {
             const FfxPre pre{O16, w16.cv_out_w[i], w.cv_out_b[i], nullptr, 0, C};                                                                    // (:339)
@@ -1899,7 +1908,7 @@ void ZipEngine::layer16(hipStream_t s, const ZLayer& w, const ZLayer16& w16, flo
             else launch_zip_ffx<3, 1, 0>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.norm_bias, x, fd, pre, FfxPost{nullptr, nullptr, nullptr, 0, 0});   // (:174-183)
             continue;
         }
-        launch_rows16<4, 2>(s, B16Rows<2>{O16, C}, w16.cv_out_w[i], ResidualStore{Y, w.cv_out_b[i]}, M, C);                                         // (:339)
+        launch_rows16<4, 2>(s, B16Rows<2, true>{O16, C}, w16.cv_out_w[i], ResidualStore{Y, w.cv_out_b[i]}, M, C);                                         // (:339)
         layer_tap(s, 3 + 3 * i, Y, R);
         if (i == 0) { launch_zip_ff16<2>(s, M, Y, w16.ff_w1[i], w.ff_in_b[i], w16.ff_w2p[i], w.ff_out_b[i], x, w.bypass_mid, Y, fd); layer_tap(s, 4, Y, R); }   // (:170-171)
         else if (w.fnorm == w.norm_bias + 64 && w.fres == w.norm_bias + 128) {        // (nb | fs | rs sit side by side in the arena: the final norm rides in the module's store)
