@@ -163,5 +163,50 @@ __device__ __forceinline__ void forward_static(float2* a, float2* b, const float
     }
 }
 
+// ---- the same passes executed by ONE wavefront on a buffer only it touches, IN PLACE: every butterfly of a pass is read into registers before any is written back (LDS
+// serves a wavefront's accesses in program order; wave_sync() keeps the compiler -- and the host simulator's lanes -- to that order), so neither a ping-pong buffer nor a
+// workgroup barrier is needed.  Same butterflies, twiddles and sums as pass_static: bit-identical results.
+template <int R, int N, int NS>
+__device__ __forceinline__ void pass_wave(float2* __restrict__ buf, const float2* __restrict__ tw, int lane) {
+    constexpr int nb = N / R, tstep = N / (NS * R), KB = (nb + 63) / 64;
+    float2 v[KB][R];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        const int j = lane + 64 * b;
+        if (nb % 64 == 0 || j < nb) {
+            const int k = j % NS;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                v[b][u] = buf[j + u * nb];
+                if (u > 0 && NS > 1 && k > 0) v[b][u] = cmul(v[b][u], tw[u * k * tstep]);
+            }
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        const int j = lane + 64 * b;
+        if (nb % 64 == 0 || j < nb) {
+            const int k = j % NS;
+            if (R == 2) dft2(v[b]);
+            if (R == 3) dft3(v[b]);
+            if (R == 4) dft4(v[b]);
+            if (R == 5) dft5(v[b]);
+            const int j0 = (j - k) * R + k;
+#pragma unroll
+            for (int u = 0; u < R; ++u) buf[j0 + u * NS] = v[b][u];
+        }
+    }
+    wave_sync();
+}
+template <int N, int I = 0, int NS = 1>
+__device__ __forceinline__ void forward_wave(float2* buf, const float2* __restrict__ tw, int lane) {
+    if constexpr (I < Static<N>::passes) {
+        constexpr int R = Static<N>::radix(I);
+        pass_wave<R, N, NS>(buf, tw, lane);
+        forward_wave<N, I + 1, NS * R>(buf, tw, lane);
+    }
+}
+
 }  // namespace fft
 }  // namespace ade

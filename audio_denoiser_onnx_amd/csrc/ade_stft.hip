@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void k_stft_fft_synth(const float* __restrict_
 // (recomputed, not exchanged), windows and sums each output sample's frames out of the resident slots in ascending frame order -- the sums, the order and therefore the bits of
 // the two-kernel form above (frames through HBM, then k_stft_ola), without the B x T x N float round trip.
 constexpr int kRunThreads = 512;
-template <int N> constexpr int run_group_threads() { return N / 4 <= 64 ? 64 : (N / 4 <= 128 ? 128 : (N / 4 <= 256 ? 256 : 512)); }
+// threads that share one transform: ONE wavefront up to 512 points (round 6: the transform then runs in place in its slot with no workgroup barrier and no ping-pong buffer,
+// fft::forward_wave -- eight pairs in flight per workgroup, each at its own pace), otherwise a quarter of the points
+constexpr int run_gt(int n) { return n <= 512 ? 64 : (n / 4 <= 256 ? 256 : 512); }
+template <int N> constexpr int run_group_threads() { return run_gt(N); }
 
 template <int N>
 __global__ __launch_bounds__(kRunThreads) void k_stft_run_analyze(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ tw, StftDims d, int L,
@@ -216,15 +219,17 @@ __global__ __launch_bounds__(kRunThreads) void k_stft_run_analyze(const float* _
     const int tid = threadIdx.x, grp = tid / GT, lt = tid - grp * GT;
     const int ppr = (T + 1) / 2, wpr = (ppr + RP - 1) / RP;
     const int b = (int)blockIdx.x / wpr, p0 = ((int)blockIdx.x - b * wpr) * RP;
+    constexpr bool kWave = GT == 64;                                            // one wavefront per transform: in place, no ping-pong buffers
     float2* const scratch = lds + (size_t)RP * SP + (size_t)grp * N;
-    float2* const twl = lds + (size_t)RP * SP + (size_t)G * N;                // the twiddle table in LDS (three scattered 8-byte reads per butterfly and pass: through the L1 they cost more than the butterflies)
+    float2* const twl = lds + (size_t)RP * SP + (kWave ? 0 : (size_t)G * N);  // the twiddle table in LDS (three scattered 8-byte reads per butterfly and pass: through the L1 they cost more than the butterflies)
     for (int n = tid; n < N; n += kRunThreads) twl[n] = tw[n];              // (visible behind the barrier that precedes the first pass; pass 0 reads no twiddles)
+    if (kWave) __syncthreads();
     const float* const row = x + (size_t)b * L;
     for (int pl = grp; pl < RP; pl += G) {
         const int pair = p0 + pl, t0 = 2 * pair;
         const bool live = pair < ppr, two = t0 + 1 < T;
         float2* const slot = lds + (size_t)pl * SP;
-        float2* const A = fft::result_in_first<N>() ? slot : scratch;          // the transform's result lands in the slot
+        float2* const A = kWave || fft::result_in_first<N>() ? slot : scratch;          // the transform's result lands in the slot
         float2* const Bf = fft::result_in_first<N>() ? scratch : slot;
         for (int n = lt; n < N; n += GT) {
             float2 v = make_float2(0.0f, 0.0f);
@@ -235,9 +240,15 @@ __global__ __launch_bounds__(kRunThreads) void k_stft_run_analyze(const float* _
             }
             A[n] = v;
         }
-        fft::forward_static<N>(A, Bf, twl, lt, GT);
-        __syncthreads();                               // (the next pair's samples go into a buffer this pair's last pass may still be reading)
+        if constexpr (kWave) {
+            wave_sync();
+            fft::forward_wave<N>(slot, twl, lt);
+        } else {
+            fft::forward_static<N>(A, Bf, twl, lt, GT);
+            __syncthreads();                           // (the next pair's samples go into a buffer this pair's last pass may still be reading)
+        }
     }
+    if (kWave) __syncthreads();
     const int nt = 2 * RP, tb = 2 * p0;
     float* const re = spec + (size_t)b * (2 * F) * T;
     float* const im = re + (size_t)F * T;
@@ -263,10 +274,11 @@ __global__ __launch_bounds__(kRunThreads) void k_stft_run_synth(const float* __r
     const int tid = threadIdx.x, grp = tid / GT, lt = tid - grp * GT;
     const int RT = 2 * RP, RO = RT - halo, wpr = (T + RO - 1) / RO;
     const int b = (int)blockIdx.x / wpr, wi = (int)blockIdx.x - b * wpr, to = wi * RO, ts = to - halo;
+    constexpr bool kWave = GT == 64;
     float2* const scratch = lds + (size_t)RP * SP + (size_t)grp * N;
     const float2* twl = tw;
     if (TWL) {
-        float2* const t2 = lds + (size_t)RP * SP + (size_t)G * N;
+        float2* const t2 = lds + (size_t)RP * SP + (kWave ? 0 : (size_t)G * N);
         for (int n = tid; n < N; n += kRunThreads) t2[n] = tw[n];
         twl = t2;
     }
@@ -292,15 +304,21 @@ __global__ __launch_bounds__(kRunThreads) void k_stft_run_synth(const float* __r
         Ag[f] = make_float2(z0.x - z1.y, -(z0.y + z1.x));
         if (f > 0 && f < N - f) Ag[N - f] = make_float2(z0.x + z1.y, z0.y - z1.x);
     }
+    if (kWave) __syncthreads();                        // (the slots are filled by the whole workgroup, the twiddles copied)
     for (int pl = grp; pl < RP; pl += G) {
         float2* const slot = lds + (size_t)pl * SP;
-        fft::forward_static<N>(slot, scratch, twl, lt, GT);
-        if (!fft::result_in_first<N>()) {              // an odd number of passes leaves the result in the ping-pong buffer: back into the slot
+        if constexpr (kWave) {
+            fft::forward_wave<N>(slot, twl, lt);
+        } else {
+            fft::forward_static<N>(slot, scratch, twl, lt, GT);
+            if (!fft::result_in_first<N>()) {          // an odd number of passes leaves the result in the ping-pong buffer: back into the slot
+                __syncthreads();
+                for (int n = lt; n < N; n += GT) slot[n] = scratch[n];
+            }
             __syncthreads();
-            for (int n = lt; n < N; n += GT) slot[n] = scratch[n];
         }
-        __syncthreads();
     }
+    if (kWave) __syncthreads();
     // overlap-add out of the slots: the samples whose LAST contributing frame is one of this workgroup's own (raw index m = t hop + n before the trim); the last workgroup
     // of a row also takes the tail
     const int raw_len = N + d.hop * (T - 1);
@@ -375,14 +393,14 @@ bool run_raise_lds(int n) {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // pairs per workgroup for a call with `pairs` frame pairs per row: the largest power of two that the LDS holds and the row can use (never below the thread groups' count)
 inline int run_pairs_for(int n, int rp_max, int pairs) {
-    const int gt = n / 4 <= 64 ? 64 : (n / 4 <= 128 ? 128 : (n / 4 <= 256 ? 256 : 512)), groups = kRunThreads / gt;
+    const int gt = run_gt(n), groups = kRunThreads / gt;
     int rp = rp_max;
     while (rp / 2 >= pairs && rp / 2 >= groups) rp /= 2;
     return rp;
 }
 inline size_t run_lds_bytes(int n, int rp, bool twl = true) {
-    const int gt = n / 4 <= 64 ? 64 : (n / 4 <= 128 ? 128 : (n / 4 <= 256 ? 256 : 512)), groups = kRunThreads / gt;
-    return ((size_t)rp * (n + 1) + (size_t)groups * n + (twl ? (size_t)n : 0)) * sizeof(float2);        // slots + ping-pong buffers + the twiddle table
+    const int gt = run_gt(n), groups = kRunThreads / gt;
+    return ((size_t)rp * (n + 1) + (gt == 64 ? 0 : (size_t)groups * n) + (twl ? (size_t)n : 0)) * sizeof(float2);        // slots + ping-pong buffers (none for one-wavefront transforms) + the twiddle table
 }
 constexpr size_t kRunLdsBudget = 150 * 1024;
 void run_analyze(hipStream_t s, int n, const float* x, const float* win, const float2* tw, StftDims d, int L, int T, int rp, int batch, float* spec) {
@@ -490,8 +508,8 @@ ade_status ade_stft_create(const ade_stft_config* cfg, int device, ade_stft_hand
             // how many workgroups a CU holds, not by the length of the contiguous pieces -- 512-point analysis 48 us with the whole row (32 pairs, 148 KB of LDS, one workgroup
             // per CU) and 32 us with 4 pairs (33 KB, four per CU).  So: the analysis takes the shortest run; the synthesis the shortest one whose halo (frames transformed for
             // the overlap-add and not owned) stays below a third of it.
-            const int gt = N / 4 <= 64 ? 64 : (N / 4 <= 128 ? 128 : (N / 4 <= 256 ? 256 : 512)), groups = ade::kRunThreads / gt;
-            const size_t budget = ade::kRunLdsBudget, fixed = (size_t)groups * N * 8;        // (the synthesis leaves its twiddles in global memory when slots + table do not fit)
+            const int gt = ade::run_gt(N), groups = ade::kRunThreads / gt;
+            const size_t budget = ade::kRunLdsBudget, fixed = gt == 64 ? 0 : (size_t)groups * N * 8;        // (the synthesis leaves its twiddles in global memory when slots + table do not fit)
             const int halo = (N + cfg->hop - 1) / cfg->hop - 1;
             int rpa = groups > 2 ? groups : 2, rps = groups;
             while (2 * rps < 4 * halo) rps *= 2;
