@@ -732,15 +732,15 @@ __device__ __forceinline__ void ffx_store16(const v16f* acc, const float* __rest
                 gemm16::pack_bf16x4(make_float4(acc[t][4 * q] + b.x, acc[t][4 * q + 1] + b.y, acc[t][4 * q + 2] + b.z, acc[t][4 * q + 3] + b.w));
         }
 }
-// The same store as WHOLE ROWS: the wave's tile (+ bias, rounded) goes through the wave's own LDS region at a pitch of 2 n + 8 bytes (the 32 rows of a write land on 32 distinct
-// bank pairs) and leaves as 16-byte pieces, consecutive lanes on consecutive pieces of a row: full lines at the memory side (ffx_store16 hands it 16 bytes per row and
+// The same store as WHOLE ROWS: the wave's tile (+ bias, rounded) goes through the wave's own LDS region at a pitch of 2 n + 16 bytes (16-byte aligned rows; 8-byte writes of
+// rows r and r + 16 share banks: two-way at worst) and leaves as 16-byte pieces, consecutive lanes on consecutive pieces of a row: full lines at the memory side (ffx_store16 hands it 16 bytes per row and
 // instruction, 20 instructions per 288-byte row: the in-projections' stores were 40 % of k_zip_ffx<0, 2, 5>'s bytes and all of its partial-line writes).  The caller has met
-// at a workgroup barrier after the product (the weights under the regions are dead) and meets again before the LDS is re-used.  n % 8 == 0, 32 (2 n + 8) <= kFfxRegion.
-constexpr int kFfxRegion = 32 * (2 * 144 + 8);
+// at a workgroup barrier after the product (the weights under the regions are dead) and meets again before the LDS is re-used.  n % 8 == 0, 32 (2 n + 16) <= kFfxRegion.
+constexpr int kFfxRegion = 32 * (2 * 144 + 16);
 constexpr int kFfxLds = kF16Lds > 4 * kFfxRegion ? kF16Lds : 4 * kFfxRegion;
 template <int NT>
 __device__ __forceinline__ void ffx_store_rows(const v16f* acc, const float* __restrict__ bias, bf16_t* __restrict__ out, int ld, int n, int row0, int M, unsigned char* region, int lane) {
-    const int l31 = lane & 31, h = lane >> 5, pitch = 2 * n + 8;
+    const int l31 = lane & 31, h = lane >> 5, pitch = 2 * n + 16;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES
         __syncthreads();
         v16f accs[5];
         ffx_product<5>(lds, xb0, xb1, xb2, xb3, l31, h, accs);
-        if (32 * (2 * pre.n + 8) <= kFfxRegion) {
+        if (32 * (2 * pre.n + 16) <= kFfxRegion) {
             __syncthreads();                                                // the projection's weights are dead: the waves' store regions take their place
             ffx_store_rows<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row0, M, lds + wave * kFfxRegion, lane);
         } else ffx_store16<5>(accs, pre.b, pre.pout, pre.ldp, pre.n, row, M, h);
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256, (PRE == 1 ? ADE_FFX_WAVES_PRE1 : ADE_FFX_WAVES
         __syncthreads();
         v16f acc3[NTP];
         ffx_product<NTP>(lds, y0, y1, y2, y3, l31, h, acc3);
-        if (32 * (2 * post.n + 8) <= kFfxRegion) {
+        if (32 * (2 * post.n + 16) <= kFfxRegion) {
             __syncthreads();
             ffx_store_rows<NTP>(acc3, post.b, post.out, post.ld, post.n, row0, M, lds + wave * kFfxRegion, lane);
         } else ffx_store16<NTP>(acc3, post.b, post.out, post.ld, post.n, row, M, h);
