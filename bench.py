@@ -262,9 +262,19 @@ def cpu_baseline(blob: bytes, x: np.ndarray, budget_s: float):
     t0 = time.perf_counter()
     o.process(xs, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(n * (15872 / SR) / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-            "sample": f"{n} of the same synthetic 1 s chunks, oracle/ade_oracle.c (dense-DFT reference arithmetic), "
-                      f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5), "threads_1": threads_1}
+    out = {"value": round(n * (15872 / SR) / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "sample": f"{n} of the same synthetic 1 s chunks, oracle/ade_oracle.c (dense-DFT reference arithmetic), "
+                     f"OpenMP over chunks, {dt:.1f} s wall", "rtf": round(dt / (n * 15872 / SR), 5), "threads_1": threads_1}
+    # the reference's OWN forward in PyTorch eager mode, timed once in the build container (where /root/reference exists) by
+    # tools/ref_eager_cpu_timing.py and committed: a recorded figure from another CPU, shown beside the live legs, never mixed with them.
+    try:
+        with open(os.path.join(REPO, "profiles", "r06_ref_eager_cpu.json")) as f:
+            ref = json.load(f)
+        out["reference_eager_build_container"] = {"from": "profiles/r06_ref_eager_cpu.json (tools/ref_eager_cpu_timing.py; NOT measured on this host)", "cpu": ref.get("cpu"),
+                                                  "hardware_threads": ref.get("hardware_threads"), "torch": ref.get("torch"), "runs": ref.get("runs")}
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 def cpu_baseline_numpy(make_oracle, x_row: np.ndarray, seconds_per_row: float, what: str, takes_batch: bool = False):
