@@ -383,8 +383,6 @@ __device__ __forceinline__ float ldx1(const float* p) { return *p; }
 __device__ __forceinline__ float ldx1(const bf16_t* p) { return __uint_as_float((unsigned)*p << 16); }
 __device__ __forceinline__ void stx4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void stx4(bf16_t* p, const float4& v) { *reinterpret_cast<uint2*>(p) = gemm16::pack_bf16x4(v); }
-__device__ __forceinline__ void stx2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
-__device__ __forceinline__ void stx2(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack_bf16x2(a, b); }
 __device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stx1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.0f) & 0xffffu); }
 
@@ -465,12 +463,19 @@ struct GluStore16 {            // the two-kernel form of k_rows16_chain<.., GLU>
 };
 template <class ST> struct IsGluStore : std::false_type {};
 template <> struct IsGluStore<GluStore16> : std::true_type {};
-template <int KS, int NT, class AL, class ST, bool HALF = false>        // HALF: operand rows and weights are IEEE half (the (1, 3) convolutions over the dense history)
-__global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restrict__ w, ST store, int M, int N) {
+// STATS (round 6): the product feeds an InstanceNorm (the (1, 3) convolutions before the encoders and after the decoders, :853, :767-769).  The grid is then (tiles per window) x
+// windows -- TFw rows per window, a tile never straddles one -- and the epilogue also emits, per tile and output CHANNEL (= column / cdiv: the sub-pixel convolution folds
+// cdiv = 2 columns into a channel), the fp64 sum and sum of squares of (product + bias) over the tile's rows: partial[((window * nblk + tile) * 64 + channel) * 2 + {sum, sumsq}],
+// k_zip_stats_final's layout.  The separate pass over the stored tensor (k_zip_stats_partial: 0.2 ms per call at 128 x 1 s) is gone.  ST must expose `bias` indexed by column.
+template <int KS, int NT, class AL, class ST, bool HALF = false, bool STATS = false>        // HALF: operand rows and weights are IEEE half (the (1, 3) convolutions over the dense history)
+__global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restrict__ w, ST store, int M_all, int N, int TFw = 0, int nblk = 0, double* __restrict__ partial = nullptr,
+                                                int cdiv = 1) {
     constexpr int kPitch = 32 * KS + 16;
     HIP_DYNAMIC_SHARED(unsigned char, lds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int row0 = (int)blockIdx.x * 128 + wave * 32, row = row0 + l31;
+    const int win = STATS ? (int)blockIdx.x / nblk : 0, blk = STATS ? (int)blockIdx.x - win * nblk : (int)blockIdx.x;
+    const int M = STATS ? (win + 1) * TFw : M_all;                       // rows at or beyond M are clamped on the way in and dropped on the way out
+    const int row0 = (STATS ? win * TFw : 0) + blk * 128 + wave * 32, row = row0 + l31;
     uint4 xa[KS];
     {
         const int mc = row < M ? row : M - 1;
@@ -497,8 +502,16 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
     const int c4 = (lane & 15) * 4;
     float4 glu_a[8];                                                    // (GluStore16 only)
     (void)glu_a;
+    constexpr int kGroups = (NT + 1) / 2;
+    double ssum[STATS ? kGroups : 1][4], ssq[STATS ? kGroups : 1][4];   // (STATS) this lane's columns 64 g + c4 .. + 3 over its eight rows
+    if (STATS) {
 #pragma unroll
-    for (int g = 0; g < (NT + 1) / 2; ++g) {
+        for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[g][e] = 0.0; ssq[g][e] = 0.0; }
+    }
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
             if (2 * g + jt >= NT) continue;
@@ -522,13 +535,52 @@ __global__ __launch_bounds__(256) void k_rows16(AL a_of, const bf16_t* __restric
                     gemm16::pack_f16x4(make_float4(glu_a[u].x * sigmoid16(o.x), glu_a[u].y * sigmoid16(o.y), glu_a[u].z * sigmoid16(o.z), glu_a[u].w * sigmoid16(o.w)));
             }
         } else if (n < N && (2 * g + 1 < NT || c4 < 32)) {
+            float4 bq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (STATS) bq = *reinterpret_cast<const float4*>(store.bias + n);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int rl = (lane >> 4) + 4 * u, m = row0 + rl;
-                if (m < M) store(m, n, *reinterpret_cast<const float4*>(E + rl * 68 + c4));
+                if (m < M) {
+                    const float4 v = *reinterpret_cast<const float4*>(E + rl * 68 + c4);
+                    store(m, n, v);
+                    if constexpr (STATS) {
+                        const float t[4] = {v.x + bq.x, v.y + bq.y, v.z + bq.z, v.w + bq.w};        // (the stored values: the store adds the same bias)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ssum[g][e] += (double)t[e]; ssq[g][e] = fma((double)t[e], (double)t[e], ssq[g][e]); }
+                    }
+                }
             }
         }
         wave_sync();
+    }
+    if constexpr (STATS) {
+        // rows: the four 16-lane groups of a wave, then the four waves (through LDS: every wave is past its tile), then the cdiv columns of a channel
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ssum[g][e] += shfl_xor_f64(ssum[g][e], 16); ssum[g][e] += shfl_xor_f64(ssum[g][e], 32);
+                ssq[g][e] += shfl_xor_f64(ssq[g][e], 16); ssq[g][e] += shfl_xor_f64(ssq[g][e], 32);
+            }
+        __syncthreads();
+        double (*red)[32 * NT][2] = reinterpret_cast<double (*)[32 * NT][2]>(lds);          // [4 waves][columns][2]
+        if (lane < 16) {
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = 64 * g + c4 + e;
+                    if (n < 32 * NT) { red[wave][n][0] = n < N ? ssum[g][e] : 0.0; red[wave][n][1] = n < N ? ssq[g][e] : 0.0; }
+                }
+        }
+        __syncthreads();
+        const int nch = N / cdiv;
+        if (tid < 2 * nch) {
+            const int c = tid >> 1, q = tid & 1;
+            double v = 0.0;
+            for (int u = 0; u < cdiv; ++u) { const int n = c * cdiv + u; v += (red[0][n][q] + red[1][n][q]) + (red[2][n][q] + red[3][n][q]); }
+            partial[(((size_t)win * nblk + blk) * 64 + c) * 2 + q] = v;
+        }
     }
 }
 template <int KS, int NT, bool HALF = false, class AL, class ST>
@@ -537,13 +589,21 @@ inline void launch_rows16(hipStream_t s, const AL& a, const bf16_t* w, const ST&
     auto kern = k_rows16<KS, NT, AL, ST, HALF>;
     constexpr int bytes = rows16_lds<KS, NT>();
     // (more than 48 KB of dynamic LDS -- K = 192 x N = 128 only -- needs the attribute: raised once per device when the engine is created, raise_rows16_lds below)
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w, st, M, N);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + 127) / 128)), dim3(256), bytes, s, a, w, st, M, N, 0, 0, (double*)nullptr, 1);
 }
-template <int KS, int NT, bool HALF, class AL, class ST>
+template <int KS, int NT, bool HALF = false, class AL, class ST>
+inline void launch_rows16_stats(hipStream_t s, const AL& a, const bf16_t* w, const ST& st, int N, int TFw, int windows, double* partial, int cdiv) {
+    static_assert(4 * 32 * NT * 2 * 8 <= rows16_lds<KS, NT>(), "the per-wave column sums fit the epilogue's LDS");
+    const int nblk = (TFw + 127) / 128;
+    auto kern = k_rows16<KS, NT, AL, ST, HALF, true>;
+    constexpr int bytes = rows16_lds<KS, NT>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * windows)), dim3(256), bytes, s, a, w, st, windows * TFw, N, TFw, nblk, partial, cdiv);
+}
+template <int KS, int NT, bool HALF, class AL, class ST, bool STATS = false>
 inline hipError_t raise_rows16_lds() {
     constexpr int bytes = rows16_lds<KS, NT>();
     if (bytes <= 48 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16<KS, NT, AL, ST, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rows16<KS, NT, AL, ST, HALF, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 
@@ -760,6 +820,7 @@ __device__ __forceinline__ void ffx_store_rows(const v16f* acc, const float* __r
 }
 // Three wavefronts per SIMD: the PRE = 1 forms keep the updated rows in 32 registers across the module and spill 7 - 15 dwords at that bound; at two per SIMD (198 registers, no
 // spill) the step is 1.3 ms slower (profiles/r06_n_zip_ffx_occupancy.txt: 41.9 against 43.2 ms).
+// (measurement knobs of profiles/r06_t_zip_ffx_occupancy.txt: tools/build_variant.sh <name> ade_zipenhancer -DADE_FFX_WAVES_PRE2=4 ...)
 #ifndef ADE_FFX_WAVES_PRE1
 #define ADE_FFX_WAVES_PRE1 3
 #endif

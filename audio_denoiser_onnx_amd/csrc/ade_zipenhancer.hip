@@ -47,7 +47,6 @@ using zip16::ldx1;
 using zip16::ldx4;
 using zip16::ldh4;
 using zip16::stx1;
-using zip16::stx2;
 using zip16::stx4;
 
 constexpr int kZN = 400, kZHop = 100, kZF = kZN / 2 + 1, kZC2 = 2 * kZF;   // Export_ZipEnhancer.py:47-49
@@ -235,14 +234,10 @@ __global__ __launch_bounds__(256) void k_zip_stats_final(const double* __restric
     __shared__ double red[4][64][2];
     const int r = blockIdx.x, c = threadIdx.x & 63, part = threadIdx.x >> 6;       // 64 threads per window walked up to 64 partials one after the other: 30 us of latency per call, 15 calls per step
     double a = 0.0, b = 0.0;
-#ifdef ADE_STATS_SERIAL
-    if (part == 0) for (int k = 0; k < nchunk; ++k) { const double* src = partial + (((size_t)r * nchunk + k) * 64 + c) * 2; a += src[0]; b += src[1]; }
-#else
     for (int k = part; k < nchunk; k += 4) {
         const double* src = partial + (((size_t)r * nchunk + k) * 64 + c) * 2;
         a += src[0]; b += src[1];
     }
-#endif
     red[part][c][0] = a; red[part][c][1] = b;
     __syncthreads();
     if (part != 0) return;
@@ -1714,6 +1709,8 @@ int zipenhancer_create(const std::map<std::string, Tensor>& tensors, int window_
     // per-process flag at the first launch, result ignored)
     if (bf16 && (zip16::raise_rows16_lds<12, 4, true, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
                  zip16::raise_rows16_lds<12, 4, false, zip16::RowConv16, zip16::SubPixelStore16>() != hipSuccess ||
+                 zip16::raise_rows16_lds<12, 4, true, zip16::RowConv16, zip16::SubPixelStore16, true>() != hipSuccess ||
+                 zip16::raise_rows16_lds<12, 4, false, zip16::RowConv16, zip16::SubPixelStore16, true>() != hipSuccess ||
                  zip16::raise_rows16_chain_lds<3, 4, zip16::B16Rows<0>, true>() != hipSuccess || zip16::raise_rows16_chain_lds<3, 2, zip16::B16Rows<0>>() != hipSuccess))
         return bail(zfail(err, ADE_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the bf16 row kernels"));
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zip_ff<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFfLds) != hipSuccess ||
@@ -1759,7 +1756,8 @@ int ZipEngine::reserve(int batch, std::string& err) {
     }
     const size_t nchunk0 = ((size_t)T * kZF + kChunkTok - 1) / kChunkTok, nchunk2 = ((size_t)T * F2 + kChunkTok - 1) / kChunkTok;
     const size_t nblk0 = ((size_t)T * kZF + 255) / 256;         // the dense kernels emit one partial per 256-token tile
-    ZP_HIP(hipMalloc((void**)&partial, B * std::max({nchunk0, nchunk2, nblk0}) * 64 * 2 * sizeof(double)));
+    const size_t nblk_rows = ((size_t)T * F + 127) / 128;                  // (zip16::k_rows16<.., STATS>: tiles of 128 rows per window)
+    ZP_HIP(hipMalloc((void**)&partial, B * std::max({nchunk0, nchunk2, nblk0, nblk_rows}) * 64 * 2 * sizeof(double)));
     capacity = batch;
     return ADE_OK;
 }
@@ -1950,15 +1948,18 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
         if (dense_half) hipLaunchKernelGGL(k_zip_conv1_apply16<true>, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
         else hipLaunchKernelGGL(k_zip_conv1_apply16<false>, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E016, TF0, C, tok0 * (C / 4));
         dense_block16(s, enc_dense, 1, E016, B, kZF);
-        if (dense_half) zip16::launch_rows16<12, 2, true>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);   // (:853)
-        else zip16::launch_rows16<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, (int)R, C);
+        // (:853) the convolution's epilogue also emits its output's InstanceNorm partial sums (zip16::k_rows16<.., STATS>): no pass over X for them
+        const int nblk_x = (T * F + 127) / 128;
+        if (dense_half) zip16::launch_rows16_stats<12, 2, true>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, C, T * F, B, partial, 1);
+        else zip16::launch_rows16_stats<12, 2>(s, zip16::RowConv16{Dh16, 4 * C, 0, T, kZF, F, 2}, c2_w16, zip16::F32BiasStore{X, c2_b, C}, C, T * F, B, partial, 1);
+        hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)B), dim3(256), 0, s, (const double*)partial, nblk_x, (double)(T * F), c2_g, c2_beta, nrm2, C, 0);
     } else {
     hipLaunchKernelGGL(k_zip_conv1_apply, flat(tok0 * (C / 4)), dim3(256), 0, s, (const float2*)feat, (const float4*)coef, c1_slope, E0, TF0, C, tok0 * (C / 4));   // (:851)
     // ---- DenseEncoder (:852-853)
     dense_block(s, enc_dense, 1, E0, B, kZF);
     gemm64::launch(s, RowConvA{Dh, 4 * C, (4 - depth) * C, C, T, kZF, F, 2}, gemm64::WeightB{c2_w, 3 * C}, BiasColStore{X, c2_b, C, 0}, (int)R, C, 3 * C);
-    }
     stats(s, X, C, 0, T * F, B, c2_g, c2_beta, nrm2, C, 0);
+    }
     hipLaunchKernelGGL(k_zip_norm_apply, flat(R * (C / 4)), dim3(256), 0, s, X, (const float*)nrm2, c2_slope, T * F, C, R * (C / 4));
     snap(0);
     // ---- the four dual-path encoders (:859-863)
@@ -1978,6 +1979,13 @@ int ZipEngine::run(hipStream_t s, const int16_t* d_in, int batch, int16_t* d_out
         dense_block16(s, dec_dense, 2, X16, B, F);
     } else dense_block(s, dec_dense, 2, X, B, F);
     for (int g = 0; g < 2; ++g) {
+        if (dec16 && up == 2 && C * up <= 128) {       // statistics of the up-sampled map out of the sub-pixel convolution's own epilogue (a channel = `up` adjacent columns)
+            const int nblk_u = (T * F + 127) / 128;
+            if (dense_half) zip16::launch_rows16_stats<12, 4, true>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, C * up, T * F, B, partial, up);
+            else zip16::launch_rows16_stats<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, C * up, T * F, B, partial, up);
+            hipLaunchKernelGGL(k_zip_stats_final, dim3((unsigned)B), dim3(256), 0, s, (const double*)partial, nblk_u, (double)(T * F2), up_g + g * C, up_beta + g * C, nrm2, 2 * C, g * C);
+            continue;
+        }
         if (dec16 && dense_half) zip16::launch_rows16<12, 4, true>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
         else if (dec16) zip16::launch_rows16<12, 4>(s, zip16::RowConv16{Dh16, 8 * C, g * 4 * C, T, F, F, 1}, up_w16[g], zip16::SubPixelStore16{U, up_b[g], 2 * C, g * C, up}, (int)R, C * up);
         else gemm64::launch(s, RowConvA{Dh, 8 * C, g * 4 * C + (4 - depth) * C, C, T, F, F, 1}, gemm64::WeightB{up_w[g], 3 * C},
