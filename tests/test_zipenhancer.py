@@ -455,6 +455,30 @@ def test_gpu_zipenhancer_bf16_full_batch_properties(model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L", [4800, 11200, 24000, 40000])
+def test_gpu_zipenhancer_bf16_other_window_lengths(model, L):
+    """The bf16 attention core picks its key-tile count from the sequence length (k_zip_attn16<.., NT>: 4, 6, 7, 8, 11, 12, 16 tiles of 16 keys; beyond 256 frames / sub-bands the
+    fp32-instruction core on bf16 storage, k_zip_attn<.., bf16_t>): windows of 0.3 s (49 frames: NT 4), 0.7 s (113: NT 8), 1.5 s (241: NT 16) and 2.5 s (401 frames: the
+    fall-back core), with 101 / 51 sub-bands on the other axis throughout.  Each against the engine's f32 path on the same rows: finite, deterministic, a silent row silent,
+    >= 38 dB (the 1 s window measures 44 dB; the key mask, the ones row and the padded query tiles are what differs between these sizes)."""
+    from audio_denoiser_onnx_amd.session import InferenceSession
+    from audio_denoiser_onnx_amd.synth import synth_batch
+    _, _, _, t = model
+    blob = pack_blob(t)
+    x = synth_batch(3, L)
+    x[2] = 0
+    with InferenceSession(weights=blob, metadata=zp.metadata(L)) as a, InferenceSession(weights=blob, metadata=zp.metadata(L, gemm_dtype="bf16")) as b:
+        _, fa = a.process(x, want_f32=True)
+        ob, fb = b.process(x, want_f32=True)
+        again, _ = b.process(x)
+        frames = b.frames
+    snr = _snr_db(fb[:2], fa[:2])
+    print(f"zipenhancer bf16, window of {L} samples ({frames} frames): {snr:.1f} dB from the f32 path")
+    assert np.isfinite(fb).all() and np.array_equal(again, ob) and not ob[2].any() and np.abs(ob[:2]).max() > 50
+    assert snr >= 38.0
+
+
+@pytest.mark.gpu
 def test_gpu_zipenhancer_bf16_chained_products_equal_the_two_kernel_form(model, monkeypatch):
     """k_rows16_chain (an out-projection and the next module's in-projection in one launch, the updated residual row handed over inside the wavefront) against the two-kernel
     form (ADE_ZIP_CHAIN=0, read when the engine is created): the same bits."""
