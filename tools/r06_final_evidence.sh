@@ -52,3 +52,5 @@ find $O/${TAG}_dprof -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_dfsmn_kerne
 timeout 300 python tools/bench_ulunas.py > $O/${TAG}_ulunas_bench.txt 2>&1; timeout 300 python tools/bench_hgtcrn.py > $O/${TAG}_hgtcrn_bench.txt 2>&1
 timeout 600 python tools/zip_bf16_budget.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_zip_bf16_budget.txt
 bash tools/r06_job_l.sh > /dev/null 2>&1; cp $O/r06_l_stft_kernel_us.txt $O/${TAG}_stft_kernel_us.txt
+# per-kernel counters of the ZipEnhancer step, both dtypes (tools/pmc_workload.sh: stall split, instruction mix, matrix-core busy, LDS conflicts, FETCH / WRITE per kernel)
+for D in bf16 f32; do timeout 1200 bash tools/pmc_workload.sh gpurun_out/${TAG}_zpmc_$D --workload zipenhancer --dtype $D > $O/${TAG}_zipenhancer_${D}_pmc_summary.txt 2>&1; rm -rf $O/${TAG}_zpmc_$D; done
